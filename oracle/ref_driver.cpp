@@ -157,11 +157,12 @@ static int probeOverlap(int argc, const char **argv) {
     return 0;
 }
 
-// probe evalue <dbResidues> : stdin lines "score qLen" -> "evalue(hex) bitscore(hex) %.3E"
+// probe evalue <dbResidues> <path of nucleotide.out> : stdin lines "score qLen" -> "evalue(hex) bitscore(hex) %.3E"
 static int probeEvalue(int argc, const char **argv) {
     if (argc < 1) return 2;
+    if (argc < 2) return 2;
     size_t dbRes = strtoull(argv[0], NULL, 10);
-    NucleotideMatrix subMat(localPar.scoringMatrixFile.nucleotides, 1.0, 0.0);
+    NucleotideMatrix subMat(argv[1], 1.0, 0.0);
     EvalueComputation evaluer(dbRes, &subMat);
     std::string line;
     while (std::getline(std::cin, line)) {
@@ -173,6 +174,30 @@ static int probeEvalue(int argc, const char **argv) {
         double bs = evaluer.computeBitScore(score);
         printf("%a %a %.3E %a\n", ev, bs, ev, evaluer.computeRawScoreFromBitScore(static_cast<int>(bs + 0.5)));
     }
+    return 0;
+}
+
+// probe alp : the gapless Gumbel parameters ALP derives for nucleotide.out, obtained exactly the way
+// EvalueComputation::init does for an ungapped matrix (M/alignment/EvalueComputation.h:96-128)
+static int probeAlp(int argc, const char **argv) {
+    if (argc < 1) return 2;
+    NucleotideMatrix subMat(argv[0], 1.0, 0.0);  // path of lib/mmseqs/data/nucleotide.out
+    long **tmpMat = new long *[subMat.alphabetSize];
+    long *tmpMatData = new long[subMat.alphabetSize * subMat.alphabetSize];
+    for (int i = 0; i < subMat.alphabetSize; i++) {
+        tmpMat[i] = &tmpMatData[i * subMat.alphabetSize];
+        for (int j = 0; j < subMat.alphabetSize; j++) tmpMat[i][j] = subMat.subMatrix[i][j];
+    }
+    Sls::AlignmentEvaluer ev;
+    ev.initGapless(subMat.alphabetSize - 1, (const long *const *) tmpMat, subMat.pBack, subMat.pBack, 60.0);
+    const Sls::ALP_set_of_parameters &p = ev.parameters();
+    printf("lambda %a\nK %a\na_I %a\na_J %a\nalpha_I %a\nalpha_J %a\nsigma %a\nb_I %a\nb_J %a\nbeta_I %a\nbeta_J %a\ntau %a\n",
+           p.lambda, p.K, p.a_I, p.a_J, p.alpha_I, p.alpha_J, p.sigma, p.b_I, p.b_J, p.beta_I, p.beta_J, p.tau);
+    printf("matrix");
+    for (int i = 0; i < subMat.alphabetSize; i++) for (int j = 0; j < subMat.alphabetSize; j++) printf(" %d", (int) subMat.subMatrix[i][j]);
+    printf("\npBack");
+    for (int i = 0; i < subMat.alphabetSize; i++) printf(" %a", subMat.pBack[i]);
+    printf("\n");
     return 0;
 }
 
@@ -191,6 +216,7 @@ int main(int argc, const char **argv) {
         if (!strcmp(argv[2], "mostlikeli")) return probeMostLikeli(argc - 3, argv + 3);
         if (!strcmp(argv[2], "overlap")) return probeOverlap(argc - 3, argv + 3);
         if (!strcmp(argv[2], "evalue")) return probeEvalue(argc - 3, argv + 3);
+        if (!strcmp(argv[2], "alp")) return probeAlp(argc - 3, argv + 3);
         return 2;
     }
     FileUtil::fixRlimitNoFile();
