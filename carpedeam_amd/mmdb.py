@@ -85,3 +85,42 @@ def dump_keyed(path):
         lines.append("#%d\t%d" % (k, e))
         lines.append(payload.decode("latin1").rstrip("\n"))
     return "\n".join(lines) + "\n"
+
+
+def load_keyed(path):
+    """Inverse of dump_keyed (plain or .gz): dict key -> (payload bytes incl. trailing newline(s), wasExtended)."""
+    import gzip
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rb") as f:
+        text = f.read().decode("latin1")
+    out = {}
+    key = None
+    buf = []
+    for line in text.split("\n"):
+        if line.startswith("#"):
+            if key is not None:
+                out[key[0]] = (_join(buf), key[1])
+            k, e = line[1:].split("\t")
+            key = (int(k), int(e))
+            buf = []
+        elif key is not None:
+            buf.append(line)
+    if key is not None:
+        if buf and buf[-1] == "":
+            buf.pop()
+        out[key[0]] = (_join(buf), key[1])
+    return out
+
+
+def _join(lines):
+    body = "\n".join(lines)
+    return (body + "\n").encode("latin1") if body != "" else b""
+
+
+def write_from_keyed(path, keyed, dbtype):
+    write_db(path, ((k, keyed[k][0]) for k in sorted(keyed)), dbtype, {k: v[1] for k, v in keyed.items()})
+
+
+def canon(db):
+    """Canonical comparable form of read_db()/load_keyed() output."""
+    return {k: (v[0].rstrip(b"\n"), v[1]) for k, v in db.items()}

@@ -104,3 +104,19 @@ def generate(n, L=100, seed=1, coverage=20, mixed=None, p5=P5_DHIGH, p3=P3_DHIGH
 def generate_strings(n, **kw):
     seqs, _ = generate(n, **kw)
     return [s.tobytes().decode() for s in seqs]
+
+
+PROF_HEADER = "A>C\tA>G\tA>T\tC>A\tC>G\tC>T\tG>A\tG>C\tG>T\tT>A\tT>C\tT>G"
+
+
+def write_dhigh_profiles(prefix, p5=P5_DHIGH, p3=P3_DHIGH):
+    """Write <prefix>5p.prof / <prefix>3p.prof byte-identical to the reference's example/dhigh{5p,3p}.prof
+    (12 tab-separated substitution-rate columns, header line, 5 rows; C>T is column 5, G>A column 6)."""
+    with open(prefix + "5p.prof", "w") as f:
+        f.write(PROF_HEADER + "\n")
+        for p in p5:
+            f.write("\t".join(["0"] * 5 + [repr(p)] + ["0"] * 6) + "\n")
+    with open(prefix + "3p.prof", "w") as f:
+        f.write(PROF_HEADER + "\n")
+        for p in p3:
+            f.write("\t".join(["0"] * 6 + [repr(p)] + ["0"] * 5) + "\n")

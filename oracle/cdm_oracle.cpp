@@ -770,7 +770,8 @@ static double alpArea(double y, double m, double n) {  // sls_pvalues.cpp:366-54
 }
 // AlignmentEvaluer::area(score, seqlen1, seqlen2) passes (y, m=seqlen2, n=seqlen1) (sls_alignment_evaluer.cpp:1010-1014)
 static double computeEvalue(double score, double qLen, size_t dbRes) { double epa = G.K * exp(-G.lambda * score); return epa * alpArea(score, (double) dbRes, qLen); }
-static double computeBitScore(double score) { return (G.lambda * score - log(G.K)) / log(2.0); }
+static const double LOGK = log(G.K);
+static double computeBitScore(double score) { return std::fma(G.lambda, score, -LOGK) / log(2.0); }  // the reference build contracts this into an FMA (-O3 -mfma, GCC default -ffp-contract=fast)
 static double rawScoreFromBitScore(double bits) { return (log(G.K) + bits * std::log(2.0)) / G.lambda; }
 
 // ----------------------------------------------------------------------------- R: rescorediagonal

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference's own object code.
+
+Run in the build container only (needs /root/reference and oracle/_ref/carpedeam_ref built by
+`make -C oracle -f Makefile.ref`).  Nothing here reads or copies reference *source*; the outputs
+are data: inputs (synthetic reads from carpedeam_amd/synth.py, the reference's example reads) and
+the reference binary's outputs on them (keyed DB dumps, function-level known answers).
+
+    python tests/golden/make_golden.py
+"""
+import gzip
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from carpedeam_amd import mmdb, synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "carpedeam_ref")
+OUT = os.path.join(ROOT, "tests", "golden")
+REFROOT = "/root/reference"
+
+# stage flags exactly as `carpedeam ancient_assemble` emits them on defaults (SURVEY.md 3.1;
+# createParameterString passes every parameter of the module's list, src/workflow/Nuclassembler.cpp:103-118)
+K_FLAGS = ("--kmer-per-seq 200 --kmer-per-seq-scale 0.2 --hash-shift 67 --ignore-multi-kmer 1 --mask 0 "
+           "--adjust-kmer-len 0 --cov-mode 1 -c 0 --include-only-extendable 0 -k 20").split()
+R_FLAGS = ("--rescore-mode 3 -e 0.001 --min-seq-id 0.9 --seq-id-mode 0 --sort-results 0 -a 0 --filter-hits 0 "
+           "--cov-mode 1 -c 0").split()
+A_FLAGS = ("--rescore-mode 3 --max-seq-len 200000 --min-seq-id 0.9 --ext-random-align 0.85 --excess-penalty 0.0625 "
+           "--min-ryseq-id-corr-reads 0.99 --likelihood-ratio-threshold 0.5 --unsafe 0 --min-cov-safe 5").split()
+
+
+def run(*args, inp=None):
+    r = subprocess.run([REF] + list(args), input=inp, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.exit("reference failed: %s\n%s" % (" ".join(args), r.stderr[-2000:]))
+    return r.stdout
+
+
+def gz_write(path, text):
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(text.encode("latin1"))
+
+
+def chain(tmp, name, seqs, iterations, prefix, threads):
+    """Run `iterations` read-loop iterations of the four stages; dump every DB keyed."""
+    d = os.path.join(OUT, name)
+    os.makedirs(d, exist_ok=True)
+    inp = os.path.join(tmp, name + "_reads")
+    mmdb.write_seqdb(inp, seqs)
+    gz_write(os.path.join(d, "reads.keyed.gz"), mmdb.dump_keyed(inp))
+    sums = {}
+    for it in range(iterations):
+        p = lambda s: os.path.join(tmp, "%s_%s_%d" % (name, s, it))
+        # kmermatcher single-threaded: the reference's parallel sort leaves the order of equal tuples
+        # (and thereby the strand sign of a hit whose best diagonal has mixed strands) run-dependent
+        run("kmermatcher", inp, p("pref"), *K_FLAGS, "--threads", "1")
+        run("rescorediagonal", inp, inp, p("pref"), p("aln"), *R_FLAGS, "--threads", str(threads))
+        run("ancient_correction", inp, p("aln"), p("corr"), *A_FLAGS, "--ancient-damage", prefix, "--threads", str(threads))
+        run("ancient_read_assemble", p("corr"), p("aln"), p("asm"), *A_FLAGS, "--ancient-damage", prefix, "--threads", str(threads))
+        for s in ("pref", "aln", "corr", "asm"):
+            txt = mmdb.dump_keyed(p(s))
+            gz_write(os.path.join(d, "%s_%d.keyed.gz" % (s, it)), txt)
+            sums["%s_%d" % (s, it)] = hashlib.sha256(txt.encode("latin1")).hexdigest()
+        inp = p("asm")
+    with open(os.path.join(d, "sha256.txt"), "w") as f:
+        for k in sorted(sums):
+            f.write("%s  %s\n" % (sums[k], k))
+
+
+def probes(tmp, prefix):
+    d = os.path.join(OUT, "functions")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(12345)
+    # D1: damage tables for dhigh, the all-zero template and the empty prefix
+    open(os.path.join(d, "damage_dhigh.txt"), "w").write(run("probe", "damage", prefix))
+    open(os.path.join(d, "damage_template.txt"), "w").write(run("probe", "damage", os.path.join(tmp, "tmpl")))
+    open(os.path.join(d, "damage_empty.txt"), "w").write(run("probe", "damage", ""))
+    open(os.path.join(d, "seqerr.txt"), "w").write(run("probe", "seqerr", "0.01") + run("probe", "seqerr", "0.001"))
+    open(os.path.join(d, "alp.txt"), "w").write(run("probe", "alp", os.path.join(REFROOT, "lib/mmseqs/data/nucleotide.out")))
+    # C2: mostLikeliBaseRead vectors: realistic pile-ups, heavy pile-ups, reverse-strand mixes, near ties
+    lines = []
+    for i in range(3000):
+        qLen = int(rng.integers(30, 200))
+        qIter = int(rng.integers(0, qLen))
+        if i % 3 == 0:
+            qIter = int(rng.choice([0, 1, 2, 3, 4, qLen - 5, qLen - 4, qLen - 3, qLen - 2, qLen - 1]))
+        qBase = int(rng.integers(0, 4))
+        wasCorr = int(rng.integers(0, 5) == 0)
+        cnt = np.zeros((4, 11), dtype=int)
+        rev = np.zeros((4, 11), dtype=int)
+        cov = int(rng.integers(2, 9)) if i % 10 else int(rng.integers(20, 400))
+        dom = qBase if rng.random() < 0.8 else int(rng.integers(0, 4))
+        for _ in range(cov):
+            t = dom if rng.random() < 0.85 else int(rng.integers(0, 4))
+            cl = 5 if rng.random() < 0.8 else int(rng.integers(0, 11))
+            cnt[t, cl] += 1
+            if rng.random() < 0.4:
+                rev[t, cl] += 1
+        lines.append(" ".join(map(str, [qBase, qIter, qLen, wasCorr] + cnt.ravel().tolist() + rev.ravel().tolist())))
+    inp = "\n".join(lines) + "\n"
+    outp = run("probe", "mostlikeli", prefix, inp=inp)
+    gz_write(os.path.join(d, "mostlikeli.tsv.gz"), "".join(a + "\t" + b + "\n" for a, b in zip(lines, outp.split("\n"))))
+    # E3: overlap likelihoods (calcLikelihoodConsensus via r_s_pair), safe-mode consensus = N^L q N^L
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    lines = []
+    for i in range(1500):
+        L = int(rng.integers(40, 160))
+        dbLen = int(rng.integers(40, L + 1))   # the query is the k-mer group's longest member, so dbLen <= qLen on this path
+        q = acgt[rng.integers(0, 4, L)].tobytes().decode()
+        aln = int(rng.integers(30, min(L, dbLen)))
+        left = bool(rng.integers(0, 2))
+        if left:      # query prefix overlaps the target suffix
+            qs, qe, ds, de = 0, aln - 1, dbLen - aln, dbLen - 1
+        else:         # query suffix overlaps the target prefix
+            qs, qe, ds, de = L - aln, L - 1, 0, aln - 1
+        t = list(acgt[rng.integers(0, 4, dbLen)].tobytes().decode())
+        for k in range(aln):
+            t[ds + k] = q[qs + k]
+        for k in range(int(rng.integers(0, 4))):   # a few mismatches, biased to deamination-like ones
+            pos = int(rng.integers(0, aln))
+            c = q[qs + pos]
+            t[ds + pos] = {"C": "T", "G": "A"}.get(c, "ACGT"[int(rng.integers(0, 4))]) if rng.random() < 0.7 else "ACGT"[int(rng.integers(0, 4))]
+        if rng.random() < 0.1:
+            t[int(rng.integers(0, dbLen))] = "N"
+        t = "".join(t)
+        cons = "N" * L + q + "N" * L
+        isRev = int(rng.integers(0, 2))
+        maxL = aln + int(rng.integers(0, 20))
+        maxR = aln + int(rng.integers(0, 20))
+        lines.append("%s %s %d %d %d %d %d %d %d %d %d %d %d 0.85 0.0625" % (cons, t, L, 7, qs, qe, ds, de, dbLen, aln, isRev, maxL, maxR))
+    inp = "\n".join(lines) + "\n"
+    outp = run("probe", "overlap", prefix, inp=inp)
+    gz_write(os.path.join(d, "overlap.tsv.gz"), "".join(a + "\t" + b + "\n" for a, b in zip(lines, outp.split("\n"))))
+    # R3: E-value / bit score table
+    lines = ["%d %d" % (s, ql) for ql in (20, 35, 50, 75, 100, 150, 300, 1000, 20000) for s in range(0, 301, 3)]
+    inp = "\n".join(lines) + "\n"
+    txt = ""
+    for dbRes in (200000, 5000000000):
+        outp = run("probe", "evalue", str(dbRes), os.path.join(REFROOT, "lib/mmseqs/data/nucleotide.out"), inp=inp)
+        txt += "".join("%d %s\t%s\n" % (dbRes, a, b) for a, b in zip(lines, outp.split("\n")))
+    gz_write(os.path.join(d, "evalue.tsv.gz"), txt)
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("build oracle/_ref first: make -C oracle -f Makefile.ref")
+    with tempfile.TemporaryDirectory() as tmp:
+        prefix = os.path.join(tmp, "dhigh")
+        synth.write_dhigh_profiles(prefix)
+        for s in ("5p", "3p"):   # our writer must reproduce the reference's example profiles byte for byte
+            assert open(prefix + s + ".prof", "rb").read() == open(os.path.join(REFROOT, "example", "dhigh%s.prof" % s), "rb").read()
+        with open(os.path.join(tmp, "tmpl5p.prof"), "w") as f5, open(os.path.join(tmp, "tmpl3p.prof"), "w") as f3:
+            body = synth.PROF_HEADER + "\n" + ("\t".join(["0.0"] * 12) + "\n") * 5
+            f5.write(body)
+            f3.write(body)
+        probes(tmp, prefix)
+        chain(tmp, "synth2k", synth.generate_strings(2000, L=100, seed=1), 2, prefix, 4)
+        chain(tmp, "mixed3k", synth.generate_strings(3000, seed=2, mixed=(60, 150)), 3, prefix, 4)
+        seqs = []
+        with gzip.open(os.path.join(REFROOT, "example", "test_data.fq.gz"), "rt") as f:
+            for i, l in enumerate(f):
+                if i % 4 == 1:
+                    seqs.append(l.strip())
+        chain(tmp, "example", seqs, 1, prefix, 4)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,7 @@
+"""Stage flags exactly as `carpedeam ancient_assemble` emits them on defaults."""
+K_FLAGS = ("--kmer-per-seq 200 --kmer-per-seq-scale 0.2 --hash-shift 67 --ignore-multi-kmer 1 --mask 0 "
+           "--adjust-kmer-len 0 --cov-mode 1 -c 0 --include-only-extendable 0 -k 20").split()
+R_FLAGS = ("--rescore-mode 3 -e 0.001 --min-seq-id 0.9 --seq-id-mode 0 --sort-results 0 -a 0 --filter-hits 0 "
+           "--cov-mode 1 -c 0").split()
+A_FLAGS = ("--rescore-mode 3 --max-seq-len 200000 --min-seq-id 0.9 --ext-random-align 0.85 --excess-penalty 0.0625 "
+           "--min-ryseq-id-corr-reads 0.99 --likelihood-ratio-threshold 0.5 --unsafe 0 --min-cov-safe 5").split()

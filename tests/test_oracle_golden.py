@@ -1,0 +1,109 @@
+"""The CPU oracle (oracle/cdm_oracle.cpp) against the golden vectors produced by the reference's own
+object code (tests/golden/make_golden.py).  This is what pins the oracle; the GPU parity tests then
+compare the HIP path with the oracle."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from carpedeam_amd import mmdb
+from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def run(exe, *args, inp=None):
+    r = subprocess.run([exe] + list(args), input=inp, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def _lines(path):
+    with gzip.open(path, "rt") as f:
+        return [l.rstrip("\n").split("\t") for l in f if l.strip()]
+
+
+@pytest.mark.parametrize("name,prefix_kind", [("damage_dhigh.txt", "dhigh"), ("damage_empty.txt", "empty"), ("damage_template.txt", "tmpl")])
+def test_damage_tables(oracle_bin, dhigh_prefix, tmp_path, name, prefix_kind):
+    if prefix_kind == "dhigh":
+        prefix = dhigh_prefix
+    elif prefix_kind == "empty":
+        prefix = ""
+    else:
+        from carpedeam_amd import synth
+        prefix = str(tmp_path / "tmpl")
+        body = synth.PROF_HEADER + "\n" + ("\t".join(["0.0"] * 12) + "\n") * 5
+        open(prefix + "5p.prof", "w").write(body)
+        open(prefix + "3p.prof", "w").write(body)
+    assert run(oracle_bin, "probe", "damage", prefix) == open(os.path.join(GOLD, "functions", name)).read()
+
+
+def test_seqerr(oracle_bin):
+    got = run(oracle_bin, "probe", "seqerr", "0.01") + run(oracle_bin, "probe", "seqerr", "0.001")
+    assert got == open(os.path.join(GOLD, "functions", "seqerr.txt")).read()
+
+
+def test_most_likeli_base(oracle_bin, dhigh_prefix):
+    rows = _lines(os.path.join(GOLD, "functions", "mostlikeli.tsv.gz"))
+    out = run(oracle_bin, "probe", "mostlikeli", dhigh_prefix, inp="".join(r[0] + "\n" for r in rows)).split("\n")
+    bad = [i for i, r in enumerate(rows) if out[i] != r[1]]
+    assert not bad, "first mismatches: %s" % bad[:5]
+
+
+def test_overlap_likelihood(oracle_bin, dhigh_prefix):
+    rows = _lines(os.path.join(GOLD, "functions", "overlap.tsv.gz"))
+    out = run(oracle_bin, "probe", "overlap", dhigh_prefix, inp="".join(r[0] + "\n" for r in rows)).split("\n")
+    # bit-exact: sLenNorm and sRatio as C99 hex doubles
+    bad = [i for i, r in enumerate(rows) if out[i] != r[1]]
+    assert not bad, "first mismatches: %s" % [(rows[i][1], out[i]) for i in bad[:3]]
+
+
+def test_evalue_table(oracle_bin):
+    rows = _lines(os.path.join(GOLD, "functions", "evalue.tsv.gz"))
+    by_db = {}
+    for r in rows:
+        db, rest = r[0].split(" ", 1)
+        by_db.setdefault(db, []).append((rest, r[1]))
+    for db, items in by_db.items():
+        out = run(oracle_bin, "probe", "evalue", db, inp="".join(a + "\n" for a, _ in items)).split("\n")
+        for (a, exp), got in zip(items, out):
+            e, g = exp.split(" "), got.split(" ")
+            assert g[2] == e[2], (db, a, exp, got)           # the %.3E text that reaches the alignment DB
+            assert g[1] == e[1] and g[3] == e[3], (db, a)     # bit score / raw score: bit-exact
+            assert abs(float.fromhex(g[0]) - float.fromhex(e[0])) <= 1e-12 * abs(float.fromhex(e[0])), (db, a)
+
+
+def _stage_chain(oracle_bin, dhigh_prefix, tmp_path, name, iterations):
+    """Stage-isolated: every oracle stage consumes the *reference's* upstream DBs and must reproduce
+    the reference's output DB key by key."""
+    g = os.path.join(GOLD, name)
+    t = lambda s: str(tmp_path / s)
+    inp_keyed = mmdb.load_keyed(os.path.join(g, "reads.keyed.gz"))
+    for it in range(iterations):
+        mmdb.write_from_keyed(t("in"), inp_keyed, mmdb.DBTYPE_NUCLEOTIDES)
+        gold = {s: mmdb.load_keyed(os.path.join(g, "%s_%d.keyed.gz" % (s, it))) for s in ("pref", "aln", "corr", "asm")}
+        mmdb.write_from_keyed(t("pref_ref"), gold["pref"], mmdb.DBTYPE_PREFILTER_REV_RES)
+        mmdb.write_from_keyed(t("aln_ref"), gold["aln"], mmdb.DBTYPE_ALIGNMENT_RES)
+        mmdb.write_from_keyed(t("corr_ref"), gold["corr"], mmdb.DBTYPE_NUCLEOTIDES)
+        run(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "2")
+        run(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref_ref"), t("aln"), *R_FLAGS, "--threads", "2")
+        run(oracle_bin, "ancient_correction", t("in"), t("aln_ref"), t("corr"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "2")
+        run(oracle_bin, "ancient_read_assemble", t("corr_ref"), t("aln_ref"), t("asm"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "2")
+        for s in ("pref", "aln", "corr", "asm"):
+            got, exp = mmdb.canon(mmdb.read_db(t(s))), mmdb.canon(gold[s])
+            bad = [k for k in sorted(set(got) | set(exp)) if got.get(k) != exp.get(k)]
+            assert not bad, "%s iteration %d stage %s: %d keys differ, e.g. %s" % (name, it, s, len(bad), bad[:5])
+        inp_keyed = gold["asm"]
+
+
+def test_chain_synth2k(oracle_bin, dhigh_prefix, tmp_path):
+    _stage_chain(oracle_bin, dhigh_prefix, tmp_path, "synth2k", 2)
+
+
+def test_chain_mixed3k(oracle_bin, dhigh_prefix, tmp_path):
+    _stage_chain(oracle_bin, dhigh_prefix, tmp_path, "mixed3k", 3)
+
+
+def test_chain_example(oracle_bin, dhigh_prefix, tmp_path):
+    _stage_chain(oracle_bin, dhigh_prefix, tmp_path, "example", 1)
