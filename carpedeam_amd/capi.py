@@ -1,0 +1,352 @@
+"""ctypes binding of the C ABI (include/carpedeam_hip.h) -- used by tests and bench.py.
+
+There is no CPU fallback: importing works anywhere (so that `-m "not gpu"` tests can check that the library loads and
+exports its symbols), but every compute entry point needs a gfx950 device and raises CdmError otherwise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcarpedeam_hip.so")
+
+HIT_DTYPE = np.dtype([("target", "<u4"), ("score", "<i4"), ("diagonal", "<i4")])
+ALN_DTYPE = np.dtype([("target", "<u4"), ("raw_score", "<i4"), ("ident", "<i4"), ("q_start", "<i4"), ("q_end", "<i4"),
+                      ("db_start", "<i4"), ("db_end", "<i4"), ("seq_id", "<f4")])
+
+
+class KmerParams(C.Structure):
+    _fields_ = [("kmer_size", C.c_int32), ("kmers_per_seq", C.c_int32), ("kmers_per_seq_scale", C.c_float), ("hash_shift", C.c_uint64),
+                ("ignore_multi_kmer", C.c_int32), ("include_only_extendable", C.c_int32), ("cov_mode", C.c_int32), ("cov_thr", C.c_float)]
+
+    @classmethod
+    def reads_default(cls):
+        return cls(20, 200, 0.2, 67, 1, 0, 1, 0.0)
+
+
+class RescoreParams(C.Structure):
+    _fields_ = [("seq_id_thr", C.c_float), ("eval_thr", C.c_double), ("cov_mode", C.c_int32), ("cov_thr", C.c_float),
+                ("seq_id_mode", C.c_int32), ("min_aln_len", C.c_int32)]
+
+    @classmethod
+    def default(cls):
+        return cls(0.9, 0.001, 1, 0.0, 0, 0)
+
+
+class AncientParams(C.Structure):
+    _fields_ = [("seq_id_thr", C.c_float), ("corr_reads_ry_seq_id", C.c_float), ("ry_seq_id_thr", C.c_float), ("rand_align_penal", C.c_float),
+                ("excess_penal", C.c_float), ("likelihood_threshold", C.c_float), ("unsafe", C.c_int32), ("min_cov_safe", C.c_int32),
+                ("max_seq_len", C.c_uint64)]
+
+    @classmethod
+    def default(cls):
+        return cls(0.9, 0.99, 0.99, 0.85, 0.0625, 0.5, 0, 5, 200000)
+
+
+EXPORTS = [
+    "cdm_last_error", "cdm_ctx_create", "cdm_ctx_destroy", "cdm_ctx_sync", "cdm_ctx_stream", "cdm_ctx_last_kernel_ms",
+    "cdm_seqdb_upload", "cdm_seqdb_synth", "cdm_seqdb_size", "cdm_seqdb_residues", "cdm_seqdb_max_len", "cdm_seqdb_meta",
+    "cdm_seqdb_download", "cdm_seqdb_free", "cdm_damage_load", "cdm_damage_get", "cdm_kmermatch", "cdm_hits_upload", "cdm_hits_count",
+    "cdm_hits_download", "cdm_hits_free", "cdm_rescore", "cdm_alns_upload", "cdm_alns_count", "cdm_alns_download", "cdm_alns_free",
+    "cdm_evalue", "cdm_bit_score", "cdm_correct", "cdm_extend",
+]
+
+
+class CdmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libcarpedeam_hip.so (built in-tree by carpedeam_amd.build); fail loudly when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CdmError("libcarpedeam_hip.so not built: run `python -m carpedeam_amd.build` (no CPU fallback exists)")
+        l = C.CDLL(LIB_PATH)
+        vp, u64p, u32p, u8p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+        l.cdm_last_error.restype = C.c_char_p
+        l.cdm_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        l.cdm_ctx_destroy.argtypes = [vp]
+        l.cdm_ctx_destroy.restype = None
+        l.cdm_ctx_sync.argtypes = [vp]
+        l.cdm_ctx_stream.argtypes = [vp]
+        l.cdm_ctx_stream.restype = vp
+        l.cdm_ctx_last_kernel_ms.argtypes = [vp, C.c_int]
+        l.cdm_ctx_last_kernel_ms.restype = C.c_float
+        l.cdm_seqdb_upload.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]
+        l.cdm_seqdb_synth.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(vp)]
+        for f in (l.cdm_seqdb_size, l.cdm_seqdb_residues, l.cdm_hits_count, l.cdm_alns_count):
+            f.argtypes = [vp]
+            f.restype = C.c_uint64
+        l.cdm_seqdb_max_len.argtypes = [vp]
+        l.cdm_seqdb_max_len.restype = C.c_uint32
+        l.cdm_seqdb_meta.argtypes = [vp, vp, vp, vp, vp]
+        l.cdm_seqdb_download.argtypes = [vp, vp, vp, vp]
+        for f in (l.cdm_seqdb_free, l.cdm_hits_free, l.cdm_alns_free):
+            f.argtypes = [vp]
+            f.restype = None
+        l.cdm_damage_load.argtypes = [vp, C.c_char_p]
+        l.cdm_damage_get.argtypes = [vp, vp]
+        l.cdm_kmermatch.argtypes = [vp, vp, C.POINTER(KmerParams), C.POINTER(vp)]
+        l.cdm_hits_upload.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
+        l.cdm_hits_download.argtypes = [vp, vp, vp, vp]
+        l.cdm_rescore.argtypes = [vp, vp, vp, C.POINTER(RescoreParams), C.POINTER(vp)]
+        l.cdm_alns_upload.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
+        l.cdm_alns_download.argtypes = [vp, vp, vp, vp]
+        l.cdm_evalue.argtypes = [C.c_double, C.c_double, C.c_uint64]
+        l.cdm_evalue.restype = C.c_double
+        l.cdm_bit_score.argtypes = [C.c_double]
+        l.cdm_correct.argtypes = [vp, vp, vp, C.POINTER(AncientParams), C.POINTER(vp)]
+        l.cdm_extend.argtypes = [vp, vp, vp, C.POINTER(AncientParams), C.POINTER(vp), vp]
+        _lib = l
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise CdmError("cdm error %d: %s" % (rc, lib().cdm_last_error().decode()))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class SeqDb:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().cdm_seqdb_free(self.h)
+            self.h = None
+
+    @property
+    def n(self):
+        return int(lib().cdm_seqdb_size(self.h))
+
+    @property
+    def residues(self):
+        return int(lib().cdm_seqdb_residues(self.h))
+
+    def meta(self):
+        n = self.n
+        lens, keys, ext = np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.uint8)
+        _check(lib().cdm_seqdb_meta(self.ctx.h, self.h, _ptr(lens), _ptr(keys), _ptr(ext)))
+        return lens, keys, ext
+
+    def download(self):
+        """-> (list of bytes sequences, keys, ext)"""
+        lens, keys, ext = self.meta()
+        offs = np.zeros(self.n, np.uint64)
+        offs[1:] = np.cumsum(lens[:-1].astype(np.uint64) + 1)
+        total = int(lens.astype(np.uint64).sum() + self.n)
+        buf = np.empty(total, np.uint8)
+        _check(lib().cdm_seqdb_download(self.ctx.h, self.h, _ptr(buf), _ptr(offs)))
+        raw = buf.tobytes()
+        seqs = [raw[int(o):int(o) + int(l)] for o, l in zip(offs, lens)]
+        return seqs, keys, ext
+
+
+class _Csr:
+    free = None
+    count_fn = None
+    download_fn = None
+    dtype = None
+
+    def __init__(self, ctx, handle, n):
+        self.ctx, self.h, self.n = ctx, handle, n
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(lib(), self.free)(self.h)
+            self.h = None
+
+    @property
+    def count(self):
+        return int(getattr(lib(), self.count_fn)(self.h))
+
+    def download(self):
+        off = np.empty(self.n + 1, np.uint64)
+        rec = np.empty(self.count, self.dtype)
+        _check(getattr(lib(), self.download_fn)(self.ctx.h, self.h, _ptr(off), _ptr(rec)))
+        return off, rec
+
+
+class Hits(_Csr):
+    free, count_fn, download_fn, dtype = "cdm_hits_free", "cdm_hits_count", "cdm_hits_download", HIT_DTYPE
+
+
+class Alns(_Csr):
+    free, count_fn, download_fn, dtype = "cdm_alns_free", "cdm_alns_count", "cdm_alns_download", ALN_DTYPE
+
+
+class Ctx:
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(lib().cdm_ctx_create(device, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().cdm_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        _check(lib().cdm_ctx_sync(self.h))
+
+    def last_kernel_ms(self, which):
+        return float(lib().cdm_ctx_last_kernel_ms(self.h, which))
+
+    def damage_load(self, prefix):
+        _check(lib().cdm_damage_load(self.h, prefix.encode()))
+
+    def damage_get(self):
+        out = np.empty(352, np.longdouble)
+        _check(lib().cdm_damage_get(self.h, _ptr(out)))
+        return out.reshape(2, 11, 4, 4)
+
+    # ---- sequence DB
+    def upload_seqs(self, seqs, keys=None, ext=None):
+        """seqs: list of bytes/str; builds the 'SEQ\\n\\0' data blob the way the DB data file holds it."""
+        bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        n = len(bs)
+        lens = np.array([len(b) for b in bs], np.uint32)
+        offs = np.zeros(n, np.uint64)
+        offs[1:] = np.cumsum(lens[:-1].astype(np.uint64) + 2)
+        data = np.frombuffer(b"".join(b + b"\n\0" for b in bs), np.uint8)
+        keys = np.arange(n, dtype=np.uint32) if keys is None else np.asarray(keys, np.uint32)
+        ext = None if ext is None else np.asarray(ext, np.uint8)
+        h = C.c_void_p()
+        _check(lib().cdm_seqdb_upload(self.h, _ptr(data), _ptr(offs), _ptr(lens), _ptr(keys), _ptr(ext), n, C.byref(h)))
+        return SeqDb(self, h)
+
+    def upload_keyed_seqdb(self, keyed):
+        """keyed: dict key -> (payload incl. newline, ext) as mmdb.read_db / load_keyed give it."""
+        ks = sorted(keyed)
+        return self.upload_seqs([keyed[k][0].rstrip(b"\n") for k in ks], ks, [keyed[k][1] for k in ks])
+
+    def synth(self, n, lo, hi, seed, n_total=None, first=0):
+        h = C.c_void_p()
+        _check(lib().cdm_seqdb_synth(self.h, n if n_total is None else n_total, first, n, lo, hi, seed, C.byref(h)))
+        return SeqDb(self, h)
+
+    # ---- containers
+    def upload_hits(self, db, off, rec):
+        off = np.ascontiguousarray(off, np.uint64)
+        rec = np.ascontiguousarray(rec, HIT_DTYPE)
+        h = C.c_void_p()
+        _check(lib().cdm_hits_upload(self.h, db.h, _ptr(off), _ptr(rec), C.byref(h)))
+        return Hits(self, h, db.n)
+
+    def upload_alns(self, db, off, rec):
+        off = np.ascontiguousarray(off, np.uint64)
+        rec = np.ascontiguousarray(rec, ALN_DTYPE)
+        h = C.c_void_p()
+        _check(lib().cdm_alns_upload(self.h, db.h, _ptr(off), _ptr(rec), C.byref(h)))
+        return Alns(self, h, db.n)
+
+    # ---- stages
+    def kmermatch(self, db, par=None):
+        par = par or KmerParams.reads_default()
+        h = C.c_void_p()
+        _check(lib().cdm_kmermatch(self.h, db.h, C.byref(par), C.byref(h)))
+        return Hits(self, h, db.n)
+
+    def rescore(self, db, hits, par=None):
+        par = par or RescoreParams.default()
+        h = C.c_void_p()
+        _check(lib().cdm_rescore(self.h, db.h, hits.h, C.byref(par), C.byref(h)))
+        return Alns(self, h, db.n)
+
+    def correct(self, db, alns, par=None):
+        par = par or AncientParams.default()
+        h = C.c_void_p()
+        _check(lib().cdm_correct(self.h, db.h, alns.h, C.byref(par), C.byref(h)))
+        return SeqDb(self, h)
+
+    def extend(self, db, alns, par=None, want_scores=False):
+        par = par or AncientParams.default()
+        h = C.c_void_p()
+        scores = np.full(alns.count, np.nan, np.float64) if want_scores else None
+        _check(lib().cdm_extend(self.h, db.h, alns.h, C.byref(par), C.byref(h), _ptr(scores)))
+        out = SeqDb(self, h)
+        return (out, scores) if want_scores else out
+
+
+# ------------------------------------------------------------------------------------------------ text codecs (tests)
+def parse_pref_db(keyed, keys):
+    """Prefilter DB text (QueryMatcher.h:81-126) -> CSR (offsets, HIT_DTYPE) over the key-sorted sequence index."""
+    idx = {int(k): i for i, k in enumerate(keys)}
+    off = np.zeros(len(keys) + 1, np.uint64)
+    recs = []
+    for i, k in enumerate(keys):
+        payload = keyed.get(int(k), (b"", 0))[0]
+        for line in payload.decode().split("\n"):
+            if not line:
+                continue
+            t, s, d = line.split("\t")
+            recs.append((idx[int(t)], int(s), int(d)))
+        off[i + 1] = len(recs)
+    return off, np.array(recs, HIT_DTYPE) if recs else np.empty(0, HIT_DTYPE)
+
+
+def hits_to_text(off, rec, keys):
+    out = {}
+    for i, k in enumerate(keys):
+        lines = ["%d\t%d\t%d" % (keys[r["target"]], r["score"], r["diagonal"]) for r in rec[int(off[i]):int(off[i + 1])]]
+        out[int(k)] = ("\n".join(lines) + "\n").encode() if lines else b""
+    return out
+
+
+def parse_aln_db(keyed, keys):
+    """Alignment DB text (Matcher.cpp:274-404) -> CSR (offsets, ALN_DTYPE).  raw_score is re-derived from the bit score
+    the way the reference's consumers do (correction.cpp:222); ident is not in the text (-1)."""
+    idx = {int(k): i for i, k in enumerate(keys)}
+    off = np.zeros(len(keys) + 1, np.uint64)
+    recs = []
+    ln2 = float(np.log(2.0))
+    lam, logk = float.fromhex("0x1.4478764a1b24ap-1"), float(np.log(float.fromhex("0x1.a1c1e68ea2ab1p-2")))
+    for i, k in enumerate(keys):
+        payload = keyed.get(int(k), (b"", 0))[0]
+        for line in payload.decode().split("\n"):
+            if not line:
+                continue
+            f = line.split("\t")
+            raw = int((logk + int(f[1]) * ln2) / lam + 0.5)
+            recs.append((idx[int(f[0])], raw, -1, int(f[4]), int(f[5]), int(f[7]), int(f[8]), np.float32(float(f[2]))))
+        off[i + 1] = len(recs)
+    return off, np.array(recs, ALN_DTYPE) if recs else np.empty(0, ALN_DTYPE)
+
+
+def fast_seqid_text(seq_id):
+    """Util::fastSeqIdToBuffer + the tab that eats the last written char (Util.cpp:278-307, Matcher.cpp:362-363)."""
+    s = np.float32(seq_id)
+    if s == np.float32(1.0):
+        return "1.00"
+    out = "0."
+    if s < np.float32(0.10):
+        out += "0"
+    if s < np.float32(0.01):
+        out += "0"
+    return out + str(int(np.float32(s * np.float32(1000))))
+
+
+def alns_to_text(off, rec, keys, lens, db_residues):
+    """CSR alignments -> alignment DB text as Matcher::resultToBuffer writes it."""
+    l = lib()
+    out = {}
+    for i, k in enumerate(keys):
+        lines = []
+        for r in rec[int(off[i]):int(off[i + 1])]:
+            qs, qe, ds, de = int(r["q_start"]), int(r["q_end"]), int(r["db_start"]), int(r["db_end"])
+            aln_len = max(abs(qe - qs), abs(de - ds)) + 1
+            sid = np.float32(np.float32(int(r["ident"])) / np.float32(aln_len)) if r["ident"] >= 0 else np.float32(r["seq_id"])
+            ev = l.cdm_evalue(float(r["raw_score"]), float(lens[i]), db_residues)
+            lines.append("%d\t%d\t%s\t%.3E\t%d\t%d\t%d\t%d\t%d\t%d" % (keys[r["target"]], l.cdm_bit_score(float(r["raw_score"])), fast_seqid_text(sid), ev,
+                                                                    qs, qe, lens[i], ds, de, lens[r["target"]]))
+        out[int(k)] = ("\n".join(lines) + "\n").encode() if lines else b""
+    return out

@@ -1,0 +1,339 @@
+// C-ABI entry points: context, sequence DB (upload / 2-bit packing / download), hit and alignment containers.
+// Stage kernels live in correct.hip, rescore.hip, kmermatch.hip, extend.hip, synth.hip.
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "devutil.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+void cdm_set_error(const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char *cdm_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------ context
+extern "C" int cdm_ctx_create(int device, cdm_ctx **out) {
+    if (!out) { cdm_set_error("cdm_ctx_create: out is NULL"); return CDM_ERR_INVALID; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        cdm_set_error("no HIP device available: the carpedeam MI355X path has no CPU fallback");
+        return CDM_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) { cdm_set_error("device ordinal %d out of range (%d devices)", device, count); return CDM_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { cdm_set_error("hipGetDeviceProperties failed"); return CDM_ERR_NO_DEVICE; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        cdm_set_error("device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+        return CDM_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) { cdm_set_error("hipSetDevice(%d) failed", device); return CDM_ERR_NO_DEVICE; }
+    cdm_ctx *c = new cdm_ctx();
+    c->device = device;
+    c->cuCount = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess || hipMalloc(&c->lutDev, sizeof(DamageLut)) != hipSuccess) {
+        cdm_set_error("context resource creation failed"); delete c; return CDM_ERR_HIP;
+    }
+    *out = c;
+    return CDM_OK;
+}
+extern "C" void cdm_ctx_destroy(cdm_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->lutDev) hipFree(c->lutDev);
+    delete c;
+}
+extern "C" int cdm_ctx_sync(cdm_ctx *c) { CDM_HIP(hipSetDevice(c->device)); CDM_HIP(hipStreamSynchronize(c->stream)); return CDM_OK; }
+extern "C" void *cdm_ctx_stream(cdm_ctx *c) { return (void *) c->stream; }
+extern "C" float cdm_ctx_last_kernel_ms(cdm_ctx *c, int which) { return (which >= 0 && which < 8) ? c->lastMs[which] : -1.f; }
+
+extern "C" int cdm_damage_load(cdm_ctx *c, const char *prefix) {
+    std::string err;
+    int rc = cdm_build_damage(prefix, c->mats, &c->lutHost, &err);
+    if (rc != CDM_OK) { cdm_set_error("%s", err.c_str()); return rc; }
+    CDM_HIP(hipSetDevice(c->device));
+    CDM_HIP(hipMemcpyAsync(c->lutDev, &c->lutHost, sizeof(DamageLut), hipMemcpyHostToDevice, c->stream));
+    CDM_HIP(hipStreamSynchronize(c->stream));
+    c->haveDamage = true;
+    return CDM_OK;
+}
+extern "C" int cdm_damage_get(cdm_ctx *c, long double *out) {
+    if (!c->haveDamage) { cdm_set_error("cdm_damage_get: no damage model loaded"); return CDM_ERR_INVALID; }
+    memcpy(out, c->mats, sizeof(c->mats));
+    return CDM_OK;
+}
+extern "C" double cdm_evalue(double raw, double qLen, uint64_t dbRes) { return cdm_evalue_host(raw, qLen, dbRes); }
+extern "C" int cdm_bit_score(double raw) { return cdm_bit_score_host(raw); }
+
+// ------------------------------------------------------------------------------------------------ sequence DB
+int cdm_seqdb_alloc(cdm_ctx *ctx, uint64_t n, cdm_seqdb **out) {
+    cdm_seqdb *db = new cdm_seqdb();
+    db->n = n; db->device = ctx->device;
+    if (hipMalloc(&db->woff, (n + 1) * sizeof(uint32_t)) != hipSuccess || hipMalloc(&db->len, (n + 1) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&db->key, (n + 1) * sizeof(uint32_t)) != hipSuccess || hipMalloc(&db->ext, n + 1) != hipSuccess ||
+        hipMalloc(&db->hasN, n + 1) != hipSuccess) {
+        cdm_set_error("out of device memory allocating a %llu-entry sequence DB", (unsigned long long) n);
+        cdm_seqdb_free(db); return CDM_ERR_HIP;
+    }
+    *out = db;
+    return CDM_OK;
+}
+static int seqdb_alloc_codes(cdm_seqdb *db, uint64_t words) {
+    db->words = words;
+    uint64_t maskWords = (words * 16 + 31) / 32 + 1;
+    if (hipMalloc(&db->codes, (words + 2) * sizeof(uint32_t)) != hipSuccess || hipMalloc(&db->nmask, maskWords * sizeof(uint32_t)) != hipSuccess) {
+        cdm_set_error("out of device memory allocating %llu code words", (unsigned long long) words); return CDM_ERR_HIP;
+    }
+    return CDM_OK;
+}
+int cdm_seqdb_alloc_like(cdm_ctx *ctx, const cdm_seqdb *src, cdm_seqdb **out) {
+    cdm_seqdb *db = nullptr;
+    int rc = cdm_seqdb_alloc(ctx, src->n, &db);
+    if (rc) return rc;
+    db->residues = src->residues; db->maxLen = src->maxLen; db->nCount = src->nCount;
+    rc = seqdb_alloc_codes(db, src->words);
+    if (rc) { cdm_seqdb_free(db); return rc; }
+    hipStream_t s = ctx->stream;
+    CDM_HIP(hipMemcpyAsync(db->woff, src->woff, (src->n + 1) * 4, hipMemcpyDeviceToDevice, s));
+    CDM_HIP(hipMemcpyAsync(db->len, src->len, src->n * 4, hipMemcpyDeviceToDevice, s));
+    CDM_HIP(hipMemcpyAsync(db->key, src->key, src->n * 4, hipMemcpyDeviceToDevice, s));
+    CDM_HIP(hipMemcpyAsync(db->ext, src->ext, src->n, hipMemcpyDeviceToDevice, s));
+    CDM_HIP(hipMemcpyAsync(db->hasN, src->hasN, src->n, hipMemcpyDeviceToDevice, s));
+    *out = db;
+    return CDM_OK;
+}
+extern "C" void cdm_seqdb_free(cdm_seqdb *db) {
+    if (!db) return;
+    hipSetDevice(db->device);
+    hipFree(db->woff); hipFree(db->len); hipFree(db->key); hipFree(db->ext); hipFree(db->hasN); hipFree(db->codes); hipFree(db->nmask);
+    delete db;
+}
+extern "C" uint64_t cdm_seqdb_size(const cdm_seqdb *db) { return db->n; }
+extern "C" uint64_t cdm_seqdb_residues(const cdm_seqdb *db) { return db->residues; }
+extern "C" uint32_t cdm_seqdb_max_len(const cdm_seqdb *db) { return db->maxLen; }
+
+// one thread per (sequence, word): 16 ASCII letters -> one code word + 16 N bits
+__global__ void k_pack(const char *__restrict__ data, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+                       const uint32_t *__restrict__ woff, uint64_t n, uint64_t words, uint32_t *__restrict__ codes,
+                       uint32_t *__restrict__ nmask, uint8_t *__restrict__ hasN, unsigned long long *__restrict__ counters) {
+    uint64_t gw = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (gw >= words) return;
+    // sequence that owns word gw: last i with woff[i] <= gw
+    uint64_t lo = 0, hi = n;
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (woff[mid] <= gw) lo = mid; else hi = mid; }
+    const uint64_t i = lo;
+    const uint32_t w = (uint32_t) (gw - woff[i]);
+    const uint32_t L = len[i];
+    const char *s = data + off[i] + (uint64_t) w * 16;
+    const uint32_t cnt = min(16u, L - min(L, w * 16u));
+    uint32_t code = 0, nb = 0, bad = 0;
+    for (uint32_t j = 0; j < cnt; j++) {
+        char c = s[j];
+        uint32_t v = 0;
+        switch (c) {
+            case 'A': v = 0; break; case 'C': v = 1; break; case 'G': v = 2; break; case 'T': v = 3; break;
+            case 'N': nb |= 1u << j; break;
+            default: bad++; nb |= 1u << j; break;
+        }
+        code |= v << (2 * j);
+    }
+    codes[gw] = code;
+    // two sequence words share one mask word; sequences start on code-word (16 bit) boundaries of the mask
+    uint16_t *m16 = reinterpret_cast<uint16_t *>(nmask);
+    m16[gw] = (uint16_t) nb;
+    if (nb) { hasN[i] = 1; atomicAdd(&counters[0], (unsigned long long) __popc(nb)); }
+    if (bad) atomicAdd(&counters[1], (unsigned long long) bad);
+}
+
+extern "C" int cdm_seqdb_upload(cdm_ctx *ctx, const char *data, const uint64_t *offsets, const uint32_t *lengths, const uint32_t *keys,
+                                const uint8_t *ext, uint64_t n, cdm_seqdb **out) {
+    if (!ctx || !data || !offsets || !lengths || !keys || !out) { cdm_set_error("cdm_seqdb_upload: NULL argument"); return CDM_ERR_INVALID; }
+    if (n == 0) { cdm_set_error("cdm_seqdb_upload: empty sequence DB"); return CDM_ERR_INVALID; }
+    if (n >= 0xFFFFFFFFull) { cdm_set_error("cdm_seqdb_upload: more than 2^32-1 sequences"); return CDM_ERR_UNSUPPORTED; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    std::vector<uint32_t> woff(n + 1);
+    uint64_t words = 0, residues = 0, lo = UINT64_MAX, hi = 0; uint32_t maxLen = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (i && keys[i] <= keys[i - 1]) { cdm_set_error("cdm_seqdb_upload: keys must be strictly increasing (entry %llu)", (unsigned long long) i); return CDM_ERR_INVALID; }
+        woff[i] = (uint32_t) words;
+        words += (lengths[i] + 15) / 16;
+        residues += lengths[i];
+        maxLen = std::max(maxLen, lengths[i]);
+        lo = std::min(lo, offsets[i]); hi = std::max(hi, offsets[i] + lengths[i]);
+        if (words >= 0xFFFFFFF0ull) { cdm_set_error("cdm_seqdb_upload: more than 2^32 code words (68 G bases) in one DB"); return CDM_ERR_UNSUPPORTED; }
+    }
+    woff[n] = (uint32_t) words;
+    cdm_seqdb *db = nullptr;
+    int rc = cdm_seqdb_alloc(ctx, n, &db);
+    if (rc) return rc;
+    db->residues = residues; db->maxLen = maxLen;
+    rc = seqdb_alloc_codes(db, words);
+    if (rc) { cdm_seqdb_free(db); return rc; }
+    hipStream_t s = ctx->stream;
+    char *dData = nullptr; uint64_t *dOff = nullptr; unsigned long long *dCnt = nullptr;
+    std::vector<uint64_t> rel(n);
+    for (uint64_t i = 0; i < n; i++) rel[i] = offsets[i] - lo;
+    int ret = CDM_OK;
+    do {
+        if (hipMalloc(&dData, hi - lo + 16) != hipSuccess || hipMalloc(&dOff, n * 8) != hipSuccess || hipMalloc(&dCnt, 16) != hipSuccess) {
+            cdm_set_error("out of device memory staging %llu bytes of sequence text", (unsigned long long) (hi - lo)); ret = CDM_ERR_HIP; break;
+        }
+        hipMemsetAsync(dCnt, 0, 16, s);
+        hipMemsetAsync(db->hasN, 0, n, s);
+        hipMemcpyAsync(dData, data + lo, hi - lo, hipMemcpyHostToDevice, s);
+        hipMemcpyAsync(dOff, rel.data(), n * 8, hipMemcpyHostToDevice, s);
+        hipMemcpyAsync(db->woff, woff.data(), (n + 1) * 4, hipMemcpyHostToDevice, s);
+        hipMemcpyAsync(db->len, lengths, n * 4, hipMemcpyHostToDevice, s);
+        hipMemcpyAsync(db->key, keys, n * 4, hipMemcpyHostToDevice, s);
+        if (ext) hipMemcpyAsync(db->ext, ext, n, hipMemcpyHostToDevice, s); else hipMemsetAsync(db->ext, 0, n, s);
+        if (words) {
+            hipLaunchKernelGGL(k_pack, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, s, dData, dOff, db->len, db->woff, n, words, db->codes,
+                               db->nmask, db->hasN, dCnt);
+        }
+        unsigned long long cnt[2] = {0, 0};
+        hipMemcpyAsync(cnt, dCnt, 16, hipMemcpyDeviceToHost, s);
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { cdm_set_error("sequence upload/packing failed: %s", hipGetErrorString(e)); ret = CDM_ERR_HIP; break; }
+        db->nCount = cnt[0];
+        if (cnt[1]) {
+            cdm_set_error("sequence DB contains %llu letters other than A,C,G,T,N (lower case / IUPAC codes): not supported by the device path yet", cnt[1]);
+            ret = CDM_ERR_UNSUPPORTED; break;
+        }
+    } while (0);
+    hipFree(dData); hipFree(dOff); hipFree(dCnt);
+    if (ret != CDM_OK) { cdm_seqdb_free(db); return ret; }
+    *out = db;
+    return CDM_OK;
+}
+
+extern "C" int cdm_seqdb_meta(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t *lengths, uint32_t *keys, uint8_t *ext) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    if (lengths) CDM_HIP(hipMemcpyAsync(lengths, db->len, db->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (keys) CDM_HIP(hipMemcpyAsync(keys, db->key, db->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ext) CDM_HIP(hipMemcpyAsync(ext, db->ext, db->n, hipMemcpyDeviceToHost, ctx->stream));
+    CDM_HIP(hipStreamSynchronize(ctx->stream));
+    return CDM_OK;
+}
+
+// one thread per (sequence, word): 16 letters + the trailing '\n' after the last base
+__global__ void k_unpack(const uint32_t *__restrict__ codes, const uint32_t *__restrict__ nmask, const uint32_t *__restrict__ woff,
+                         const uint32_t *__restrict__ len, const uint64_t *__restrict__ outOff, uint64_t n, uint64_t words, char *__restrict__ out) {
+    uint64_t gw = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (gw >= words) return;
+    uint64_t lo = 0, hi = n;
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (woff[mid] <= gw) lo = mid; else hi = mid; }
+    const uint64_t i = lo;
+    const uint32_t w = (uint32_t) (gw - woff[i]);
+    const uint32_t L = len[i];
+    const uint32_t cnt = min(16u, L - min(L, w * 16u));
+    const uint32_t code = codes[gw];
+    const uint32_t nb = reinterpret_cast<const uint16_t *>(nmask)[gw];
+    char *o = out + outOff[i] + (uint64_t) w * 16;
+    for (uint32_t j = 0; j < cnt; j++) o[j] = ((nb >> j) & 1u) ? 'N' : "ACGT"[(code >> (2 * j)) & 3u];
+    if (w * 16u + cnt == L) o[cnt] = '\n';
+}
+extern "C" int cdm_seqdb_download(cdm_ctx *ctx, const cdm_seqdb *db, char *out, const uint64_t *outOffsets) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    std::vector<uint32_t> len(db->n);
+    CDM_HIP(hipMemcpy(len.data(), db->len, db->n * 4, hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < db->n; i++) total = std::max(total, outOffsets[i] + len[i] + 1);
+    char *dOut = nullptr; uint64_t *dOff = nullptr;
+    if (hipMalloc(&dOut, total + 16) != hipSuccess || hipMalloc(&dOff, db->n * 8) != hipSuccess) { hipFree(dOut); cdm_set_error("out of device memory in cdm_seqdb_download"); return CDM_ERR_HIP; }
+    hipMemsetAsync(dOut, 0, total, ctx->stream);
+    hipMemcpyAsync(dOff, outOffsets, db->n * 8, hipMemcpyHostToDevice, ctx->stream);
+    // zero-length sequences own no word: their '\n' is written by the host below
+    if (db->words) hipLaunchKernelGGL(k_unpack, dim3((unsigned) ((db->words + 255) / 256)), dim3(256), 0, ctx->stream, db->codes, db->nmask, db->woff, db->len, dOff, db->n, db->words, dOut);
+    hipMemcpyAsync(out, dOut, total, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipFree(dOut); hipFree(dOff);
+    if (e != hipSuccess) { cdm_set_error("cdm_seqdb_download failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
+    for (uint64_t i = 0; i < db->n; i++) if (len[i] == 0) out[outOffsets[i]] = '\n';
+    return CDM_OK;
+}
+extern "C" int cdm_seqdb_synth(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, uint64_t n, uint32_t lo, uint32_t hi, uint64_t seed, cdm_seqdb **out) {
+    return cdm_synth_impl(ctx, nTotal, first, n, lo, hi, seed, out);
+}
+
+// ------------------------------------------------------------------------------------------------ hits / alignments
+template <typename H, typename R>
+static int csr_upload(cdm_ctx *ctx, uint64_t n, const uint64_t *offsets, const R *recs, H **out) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    for (uint64_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) { cdm_set_error("CSR offsets not monotone at %llu", (unsigned long long) i); return CDM_ERR_INVALID; }
+    H *h = new H(); h->n = n; h->count = offsets[n];
+    if (hipMalloc(&h->off, (n + 1) * 8) != hipSuccess || hipMalloc(&h->rec, (h->count + 1) * sizeof(R)) != hipSuccess) {
+        cdm_set_error("out of device memory for %llu records", (unsigned long long) h->count); hipFree(h->off); hipFree(h->rec); delete h; return CDM_ERR_HIP;
+    }
+    CDM_HIP(hipMemcpyAsync(h->off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (h->count) CDM_HIP(hipMemcpyAsync(h->rec, recs, h->count * sizeof(R), hipMemcpyHostToDevice, ctx->stream));
+    CDM_HIP(hipStreamSynchronize(ctx->stream));
+    *out = h;
+    return CDM_OK;
+}
+extern "C" int cdm_hits_upload(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *offsets, const cdm_hit *hits, cdm_hits **out) {
+    static_assert(sizeof(cdm_hit) == sizeof(HitRec), "layout");
+    return csr_upload<cdm_hits, HitRec>(ctx, db->n, offsets, reinterpret_cast<const HitRec *>(hits), out);
+}
+extern "C" uint64_t cdm_hits_count(const cdm_hits *h) { return h->count; }
+extern "C" int cdm_hits_download(cdm_ctx *ctx, const cdm_hits *h, uint64_t *offsets, cdm_hit *hits) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    if (offsets) CDM_HIP(hipMemcpyAsync(offsets, h->off, (h->n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (hits && h->count) CDM_HIP(hipMemcpyAsync(hits, h->rec, h->count * sizeof(HitRec), hipMemcpyDeviceToHost, ctx->stream));
+    CDM_HIP(hipStreamSynchronize(ctx->stream));
+    return CDM_OK;
+}
+extern "C" void cdm_hits_free(cdm_hits *h) { if (!h) return; hipFree(h->off); hipFree(h->rec); delete h; }
+
+extern "C" int cdm_alns_upload(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *offsets, const cdm_aln *alns, cdm_alns **out) {
+    static_assert(sizeof(cdm_aln) == sizeof(AlnRec), "layout");
+    return csr_upload<cdm_alns, AlnRec>(ctx, db->n, offsets, reinterpret_cast<const AlnRec *>(alns), out);
+}
+extern "C" uint64_t cdm_alns_count(const cdm_alns *a) { return a->count; }
+extern "C" int cdm_alns_download(cdm_ctx *ctx, const cdm_alns *a, uint64_t *offsets, cdm_aln *alns) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    if (offsets) CDM_HIP(hipMemcpyAsync(offsets, a->off, (a->n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (alns && a->count) CDM_HIP(hipMemcpyAsync(alns, a->rec, a->count * sizeof(AlnRec), hipMemcpyDeviceToHost, ctx->stream));
+    CDM_HIP(hipStreamSynchronize(ctx->stream));
+    return CDM_OK;
+}
+extern "C" void cdm_alns_free(cdm_alns *a) { if (!a) return; hipFree(a->off); hipFree(a->rec); delete a; }
+
+// ------------------------------------------------------------------------------------------------ stage wrappers
+extern "C" int cdm_correct(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out) {
+    if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_correct: NULL argument"); return CDM_ERR_INVALID; }
+    if (!ctx->haveDamage) { cdm_set_error("cdm_correct: call cdm_damage_load first"); return CDM_ERR_INVALID; }
+    if (alns->n != db->n) { cdm_set_error("cdm_correct: alignment CSR has %llu queries, DB has %llu", (unsigned long long) alns->n, (unsigned long long) db->n); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    cdm_seqdb *o = nullptr;
+    int rc = cdm_seqdb_alloc_like(ctx, db, &o);
+    if (rc) return rc;
+    rc = cdm_correct_impl(ctx, db, alns, par, o);
+    if (rc) { cdm_seqdb_free(o); return rc; }
+    *out = o;
+    return CDM_OK;
+}
+extern "C" int cdm_rescore(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, const cdm_rescore_params *par, cdm_alns **out) {
+    if (!ctx || !db || !hits || !par || !out) { cdm_set_error("cdm_rescore: NULL argument"); return CDM_ERR_INVALID; }
+    if (hits->n != db->n) { cdm_set_error("cdm_rescore: hit CSR / DB size mismatch"); return CDM_ERR_INVALID; }
+    if (par->seq_id_mode != 0) { cdm_set_error("cdm_rescore: only --seq-id-mode 0 is implemented"); return CDM_ERR_UNSUPPORTED; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    return cdm_rescore_impl(ctx, db, hits, par, out);
+}
+extern "C" int cdm_kmermatch(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+    if (!ctx || !db || !par || !out) { cdm_set_error("cdm_kmermatch: NULL argument"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    return cdm_kmermatch_impl(ctx, db, par, out);
+}
+extern "C" int cdm_extend(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out, double *scores) {
+    if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_extend: NULL argument"); return CDM_ERR_INVALID; }
+    if (!ctx->haveDamage) { cdm_set_error("cdm_extend: call cdm_damage_load first"); return CDM_ERR_INVALID; }
+    if (par->unsafe) { cdm_set_error("cdm_extend: --unsafe 1 (consensus mode) is not implemented on the device path"); return CDM_ERR_UNSUPPORTED; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    return cdm_extend_impl(ctx, db, alns, par, out, scores);
+}

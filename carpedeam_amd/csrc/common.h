@@ -1,0 +1,104 @@
+// Internal declarations shared by the C-ABI implementation files (not installed; the public header is
+// include/carpedeam_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/carpedeam_hip.h"
+
+void cdm_set_error(const char *fmt, ...);
+
+#define CDM_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            cdm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);   \
+            return CDM_ERR_HIP;                                                                         \
+        }                                                                                               \
+    } while (0)
+
+#define CDM_LAUNCH_CHECK()                                                                              \
+    do {                                                                                                \
+        hipError_t _e = hipGetLastError();                                                              \
+        if (_e != hipSuccess) {                                                                         \
+            cdm_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return CDM_ERR_HIP;                                                                         \
+        }                                                                                               \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------- damage LUTs
+// Host-built tables (host/damage.cpp) in the reference's exact mixed precision; layout used by the kernels.
+struct DamageLut {
+    // ancient_correction (src/assembler/correction.cpp:48-77,93-107; seqErr = 0.01)
+    double logT[4][4];        // [qBase][t]      = (double) logl(seqErr.p[t][qBase])
+    double logQ[12][4][4];    // [qcls][qBase][q]: qcls 0..10 = log(max((double)D[qcls].p[q][qBase], 1e-3)); 11 = contig = logT
+    double logD[2][11][4][4]; // [rev][l][q][t]  = log(max((double)D(rev)[l].p[q][t], 1e-3))
+    // ancient_read_assemble (nuclassembleUtil.cpp:259-276; seqErr = 0.001): log of the per-column likelihood
+    double logLik[2][11][4][4];  // [rev][cls][qBase][tBase]
+};
+int cdm_build_damage(const char *prefix, long double mats[2][11][4][4], DamageLut *lut, std::string *err);
+
+// ------------------------------------------------------------------------------------------------- handles
+struct cdm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool haveDamage = false;
+    long double mats[2][11][4][4];
+    DamageLut lutHost;
+    DamageLut *lutDev = nullptr;
+    float lastMs[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    int cuCount = 256;
+};
+
+// Sequence DB in HBM.  Base codes A,C,G,T = 0..3 (CarpeDeam's own order, src/assembler/correction.cpp:170-174),
+// 16 bases per 32-bit word, little end first; every sequence starts on a word boundary.  'N' (any X-class letter)
+// is stored as code 0 plus a bit in nmask (bit index = 16 * woff[i] + pos).
+struct cdm_seqdb {
+    uint64_t n = 0;
+    uint64_t words = 0;     // total code words
+    uint64_t residues = 0;  // sum of lengths
+    uint32_t maxLen = 0;
+    uint64_t nCount = 0;    // number of N letters in the whole DB
+    uint32_t *woff = nullptr;   // [n+1] word offset of each sequence
+    uint32_t *len = nullptr;    // [n]
+    uint32_t *key = nullptr;    // [n]
+    uint8_t *ext = nullptr;     // [n] wasExtended flag
+    uint8_t *hasN = nullptr;    // [n] sequence contains an N
+    uint32_t *codes = nullptr;  // [words]
+    uint32_t *nmask = nullptr;  // [(words*16+31)/32]
+    int device = 0;
+};
+
+struct HitRec { uint32_t target; int32_t score; int32_t diagonal; };  // == cdm_hit
+struct cdm_hits {
+    uint64_t n = 0, count = 0;
+    uint64_t *off = nullptr;  // [n+1]
+    HitRec *rec = nullptr;    // [count]
+};
+
+struct AlnRec { uint32_t target; int32_t rawScore; int32_t ident; int32_t qStart, qEnd, dbStart, dbEnd; float seqId; };  // == cdm_aln
+struct cdm_alns {
+    uint64_t n = 0, count = 0;
+    uint64_t *off = nullptr;  // [n+1]
+    AlnRec *rec = nullptr;    // [count]
+};
+
+int cdm_seqdb_alloc_like(cdm_ctx *ctx, const cdm_seqdb *src, cdm_seqdb **out);  // same n/lengths/layout, codes uninitialised
+int cdm_seqdb_alloc(cdm_ctx *ctx, uint64_t n, cdm_seqdb **out);
+
+// stage implementations (one .hip file each)
+int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb *out);
+int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, const cdm_rescore_params *par, cdm_alns **out);
+int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out);
+int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out, double *scores);
+int cdm_synth_impl(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, uint64_t n, uint32_t lo, uint32_t hi, uint64_t seed, cdm_seqdb **out);
+
+// host E-value helpers (host/evalue.cpp)
+double cdm_evalue_host(double rawScore, double qLen, uint64_t dbResidues);
+int cdm_bit_score_host(double rawScore);
+// smallest raw score whose E-value is <= thr for a query of that length (monotone in the score); INT_MAX if none up to 2*maxLen
+void cdm_min_score_table(double evalThr, uint64_t dbResidues, uint32_t maxLen, std::vector<int32_t> &table);

@@ -1,0 +1,284 @@
+// ancient_correction on the device.
+//
+// Replaces the OpenMP loop of doCorrection (src/assembler/correction.cpp:200-476) and mostLikeliBaseRead (:7-123).
+// One wavefront (64 lanes) owns one query that has more than one alignment record; queries with only their self
+// alignment have coverage <= 1 everywhere and keep their bases (:418-420) -- for them the output DB is a plain copy.
+//
+// Per query the wave runs three passes over the query's alignment records (CSR slice):
+//   pass 0  avCov = sum(alnLength) / qLen                                              (:218-245)
+//   pass 1  per record, all 64 lanes over the aligned columns: RY-space identity (nuclassembleUtil.cpp:78-92), the
+//           rymer threshold (:297-301), the right/left/inside class gate (:311-322) and the pile-up gate (:359).
+//           The accept bit goes to a scratch byte per record.
+//   pass 2  per chunk of 64 query positions (lane = position): pile up the accepted targets into 44 (tBase, damage
+//           class) counters per position (:361-385), held in LDS as counter[slot][lane] = total | reverse << 16,
+//           then call the base: coverage <= 1 keeps the base, otherwise arg-max over four log-likelihoods that are
+//           accumulated in software x87 extended precision in the reference's term order (:80-122), so ties and
+//           near-ties resolve exactly as `long double` does on the host.
+// All logs come from host-built tables (DamageLut) staged in LDS.
+#include "common.h"
+#include "devutil.h"
+
+namespace {
+
+struct CorrectArgs {
+    const uint32_t *woff, *len, *codes, *nmask;
+    const uint8_t *ext, *hasN;
+    const uint64_t *aoff;
+    const AlnRec *rec;
+    const uint32_t *active;
+    const unsigned int *nActive;
+    uint8_t *accept;          // [alignment count] scratch
+    unsigned int *errFlag;    // set when a query has more records than the 16-bit pile-up counters hold
+    uint32_t *outCodes, *outNmask;
+    const DamageLut *lut;
+    float seqIdThr, corrRy;
+};
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int SLOTS = 44;
+
+__device__ __forceinline__ uint32_t alnLength(const AlnRec &r) {   // Matcher::computeAlnLength, M/alignment/Matcher.cpp:204-206
+    int a = abs(r.qEnd - r.qStart), b = abs(r.dbEnd - r.dbStart);
+    return (uint32_t) max(a, b) + 1u;
+}
+// oriented copy of a record (correction.cpp:229-242)
+struct Oriented { int qs, qe, ds, de; bool rev; };
+__device__ __forceinline__ Oriented orient(const AlnRec &r, uint32_t dbLen) {
+    Oriented o;
+    if (r.qStart > r.qEnd) { o.qs = r.qEnd; o.qe = r.qStart; o.ds = (int) dbLen - r.dbEnd - 1; o.de = (int) dbLen - r.dbStart - 1; o.rev = true; }
+    else { o.qs = r.qStart; o.qe = r.qEnd; o.ds = r.dbStart; o.de = r.dbEnd; o.rev = false; }
+    return o;
+}
+// base of the oriented target (reverse complement when rev), with N -> 'A' (0) as nucleotideMap/ryMap do for any
+// letter outside ACGT; getNuclRevFragment maps X to 'N', which those maps also send to 0 (nuclassembleUtil.cpp:67-76)
+__device__ __forceinline__ uint32_t targetBase(const CorrectArgs &a, uint32_t tw, uint32_t tLen, bool tHasN, bool rev, uint32_t tpos) {
+    uint32_t p = rev ? (tLen - 1u - tpos) : tpos;
+    uint32_t c = cdm_base(a.codes, tw, p);
+    if (tHasN && cdm_isN(a.nmask, tw, p)) return 0u;
+    return rev ? (3u - c) : c;
+}
+
+// mostLikeliBaseRead (src/assembler/correction.cpp:7-123) for one query position.  counts(slot) returns
+// total | reverse << 16 for slot = tBase * 11 + damage class.  keep is set when coverage <= 1 (:418-420).
+template <typename F>
+__device__ __forceinline__ uint32_t callBase(const double *sLogT, const double *sLogQ, const double *sLogD, uint32_t qb, uint32_t p, uint32_t qLen,
+                                             bool qWasExt, F counts, bool &keep) {
+    uint32_t cov[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int tb = 0; tb < 4; tb++)
+        for (int l = 0; l < 11; l++) cov[tb] += counts(tb * 11 + l) & 0xFFFFu;
+    const uint32_t total = cov[0] + cov[1] + cov[2] + cov[3];
+    keep = total <= 1;
+    if (keep) return qb;
+    if (!qWasExt) {
+        const double ct = static_cast<double>(cov[3]) / (cov[1] + cov[3] + cov[0] + cov[2]);
+        const double ga = static_cast<double>(cov[0]) / (cov[1] + cov[3] + cov[0] + cov[2]);
+        if (ct >= 0.4 || ga >= 0.4) return qb;
+    }
+    int qcls;
+    if (qWasExt) qcls = 11;
+    else if (p < 5) qcls = (int) p;
+    else if (p >= qLen - 5) qcls = 11 - (int) (qLen - p);
+    else qcls = 5;
+    const double *lq = &sLogQ[(qcls * 4 + qb) * 4];
+    const double *lt = &sLogT[qb * 4];
+    X87 acc[4] = {x87_zero(), x87_zero(), x87_zero(), x87_zero()};
+    for (int tb = 0; tb < 4; tb++) {
+        if (cov[tb] == 0) continue;
+        for (int l = 0; l < 11; l++) {
+            const uint32_t v = counts(tb * 11 + l);
+            const int c = (int) (v & 0xFFFFu), nr = (int) (v >> 16);
+            if (c == 0) continue;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const double base2 = __dadd_rn(lt[tb], lq[qq]);
+                const double f = __dadd_rn(base2, sLogD[((0 * 11 + l) * 4 + qq) * 4 + tb]);
+                const double g = __dadd_rn(base2, sLogD[((1 * 11 + l) * 4 + qq) * 4 + tb]);
+                acc[qq] = x87_add(acc[qq], x87_from_double(__dmul_rn((double) (c - nr), f)));
+                acc[qq] = x87_add(acc[qq], x87_from_double(__dmul_rn((double) nr, g)));
+            }
+        }
+    }
+    int best = 0;
+#pragma unroll
+    for (int qq = 1; qq < 4; qq++) if (x87_lt(acc[best], acc[qq])) best = qq;
+    return (uint32_t) best;
+}
+
+__global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {
+    __shared__ double sLogT[16], sLogQ[12 * 16], sLogD[2 * 11 * 16];
+    __shared__ uint32_t sCnt[WAVES_PER_BLOCK][SLOTS][64];
+    for (int i = threadIdx.x; i < 16; i += blockDim.x) sLogT[i] = (&a.lut->logT[0][0])[i];
+    for (int i = threadIdx.x; i < 12 * 16; i += blockDim.x) sLogQ[i] = (&a.lut->logQ[0][0][0])[i];
+    for (int i = threadIdx.x; i < 2 * 11 * 16; i += blockDim.x) sLogD[i] = (&a.lut->logD[0][0][0][0])[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int nAct = *a.nActive;
+    uint32_t (*cnt)[64] = sCnt[wave];
+
+    for (unsigned int item = blockIdx.x * WAVES_PER_BLOCK + wave; item < nAct; item += gridDim.x * WAVES_PER_BLOCK) {
+        const uint32_t q = a.active[item];
+        const uint32_t qLen = a.len[q], qw = a.woff[q];
+        const bool qHasN = a.hasN[q] != 0;
+        const bool qWasExt = a.ext[q] != 0;
+        const uint64_t r0 = a.aoff[q], r1 = a.aoff[q + 1];
+        if (r1 - r0 > 65535) { if (lane == 0) atomicOr(a.errFlag, 1u); continue; }
+
+        // ---- pass 0: average coverage (float sum of small integers: exact, order independent)
+        int sumLen = 0;
+        for (uint64_t r = r0 + lane; r < r1; r += 64) sumLen += (int) alnLength(a.rec[r]);
+        sumLen = cdm_wave_sum(sumLen);
+        const float avCov = static_cast<float>(static_cast<float>(sumLen)) / qLen;
+
+        // ---- pass 1: gates
+        for (uint64_t r = r0; r < r1; r++) {
+            const AlnRec rec = a.rec[r];
+            const uint32_t t = rec.target;
+            const uint32_t tLen = a.len[t], tw = a.woff[t];
+            const bool tHasN = a.hasN[t] != 0;
+            const uint32_t aLen = alnLength(rec);
+            const Oriented o = orient(rec, tLen);
+            bool ok = a.ext[t] == 0;                              // target must be a read (:280-284)
+            int mism = 0;
+            if (ok) {
+                for (uint32_t c = lane; c < aLen; c += 64) {
+                    uint32_t qb = cdm_base(a.codes, qw, o.qs + c);
+                    if (qHasN && cdm_isN(a.nmask, qw, o.qs + c)) qb = 0;
+                    uint32_t tb = targetBase(a, tw, tLen, tHasN, o.rev, o.ds + c);
+                    mism += ((qb & 1u) != (tb & 1u));             // RY class = low bit of the A,C,G,T = 0..3 code
+                }
+                mism = cdm_wave_sum(mism);
+                const float ryId = static_cast<float>(aLen - (uint32_t) mism) / static_cast<float>(aLen);
+                float thr = a.corrRy;
+                if (aLen <= 100) { thr = (static_cast<float>(aLen) - 1) / static_cast<float>(aLen); thr = floorf(thr * 1000) / 1000; }
+                const bool ry = ryId >= thr;
+                const bool right = o.ds == 0 && (uint32_t) o.qe == (qLen - 1);
+                const bool left = o.qs == 0 && (uint32_t) o.de == (tLen - 1);
+                const bool cls = right || left || (avCov < 50);
+                ok = ry && cls && rec.seqId >= a.seqIdThr && aLen >= 30;
+            }
+            if (lane == 0) __hip_atomic_store(&a.accept[r], (uint8_t) (ok ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // accept[] is read back by this same wave below: drain the stores, and read with agent-scope (L1-bypassing) loads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- pass 2: pile-up + call, 64 positions at a time
+        const uint32_t lastWord = (qLen + 15) / 16;
+        for (uint32_t base = 0; base < qLen; base += 64) {
+            const uint32_t p = base + lane;
+#pragma unroll 4
+            for (int s = 0; s < SLOTS; s++) cnt[s][lane] = 0;
+            for (uint64_t r = r0; r < r1; r++) {
+                if (!__hip_atomic_load(&a.accept[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                const AlnRec rec = a.rec[r];
+                const uint32_t t = rec.target, tLen = a.len[t], tw = a.woff[t];
+                const Oriented o = orient(rec, tLen);
+                if ((uint32_t) o.qe < base || (uint32_t) o.qs >= base + 64) continue;   // wave uniform
+                if (p >= (uint32_t) o.qs && p <= (uint32_t) o.qe && p < qLen) {
+                    const uint32_t tpos = (uint32_t) o.ds + (p - (uint32_t) o.qs);
+                    const uint32_t tb = targetBase(a, tw, tLen, a.hasN[t] != 0, o.rev, tpos);
+                    const uint32_t cls = tpos < 5 ? tpos : (tpos >= tLen - 5 ? 6 + (tpos - (tLen - 5)) : 5);
+                    cnt[tb * 11 + cls][lane] += 1u + (o.rev ? 0x10000u : 0u);
+                }
+            }
+            // ---- call
+            uint32_t newCode = 0; bool keep = true;
+            if (p < qLen) {
+                uint32_t qb = cdm_base(a.codes, qw, p);
+                const bool qIsN = qHasN && cdm_isN(a.nmask, qw, p);
+                if (qIsN) qb = 0;
+                newCode = callBase(sLogT, sLogQ, sLogD, qb, p, qLen, qWasExt, [&](int slot) { return cnt[slot][lane]; }, keep);
+            }
+            // ---- write 64 positions = 4 code words (+ N bits): lanes 0..3 assemble one word each from ballots
+            const uint64_t b0 = cdm_ballot((newCode & 1u) != 0), b1 = cdm_ballot((newCode & 2u) != 0);
+            uint64_t nb = 0;
+            if (qHasN) nb = cdm_ballot(p < qLen && keep && cdm_isN(a.nmask, qw, p));
+            if (lane < 4) {
+                const uint32_t w = (base >> 4) + lane;
+                if (w < lastWord) {
+                    const uint32_t lo = (uint32_t) (b0 >> (16 * lane)), hi = (uint32_t) (b1 >> (16 * lane));
+                    a.outCodes[qw + w] = cdm_spread16(lo) | (cdm_spread16(hi) << 1);
+                    if (qHasN) reinterpret_cast<uint16_t *>(a.outNmask)[qw + w] = (uint16_t) (nb >> (16 * lane));
+                }
+            }
+        }
+    }
+}
+
+// queries with more than one alignment record
+__global__ void k_mark_active(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t *__restrict__ active, unsigned int *__restrict__ nActive) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    if (aoff[q + 1] - aoff[q] > 1) { unsigned int pos = atomicAdd(nActive, 1u); active[pos] = q; }
+}
+
+
+// test hook: one thread per count vector {qBase, qIter, qLen, wasCorr, 44 x (total | reverse << 16)}
+__global__ void k_debug_call(const DamageLut *lut, const uint32_t *vec, uint32_t n, uint8_t *out) {
+    __shared__ double sLogT[16], sLogQ[12 * 16], sLogD[2 * 11 * 16];
+    for (int i = threadIdx.x; i < 16; i += blockDim.x) sLogT[i] = (&lut->logT[0][0])[i];
+    for (int i = threadIdx.x; i < 12 * 16; i += blockDim.x) sLogQ[i] = (&lut->logQ[0][0][0])[i];
+    for (int i = threadIdx.x; i < 2 * 11 * 16; i += blockDim.x) sLogD[i] = (&lut->logD[0][0][0][0])[i];
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *v = vec + (size_t) i * 48;
+    bool keep;
+    out[i] = (uint8_t) callBase(sLogT, sLogQ, sLogD, v[0], v[1], v[2], v[3] != 0, [&](int slot) { return v[4 + slot]; }, keep);
+}
+
+}  // namespace
+
+// not part of the public header: used by tests/test_gpu_correct.py through ctypes to run the reference's
+// mostLikeliBaseRead known answers (tests/golden/functions/mostlikeli.tsv.gz) through the device call path
+extern "C" int cdm_debug_call_bases(cdm_ctx *ctx, const uint32_t *vectors, uint32_t n, uint8_t *out) {
+    if (!ctx->haveDamage) { cdm_set_error("cdm_debug_call_bases: no damage model"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    uint32_t *dv = nullptr; uint8_t *dout = nullptr;
+    CDM_HIP(hipMalloc(&dv, (size_t) n * 48 * 4));
+    CDM_HIP(hipMalloc(&dout, n));
+    hipMemcpyAsync(dv, vectors, (size_t) n * 48 * 4, hipMemcpyHostToDevice, ctx->stream);
+    hipLaunchKernelGGL(k_debug_call, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->lutDev, dv, n, dout);
+    hipMemcpyAsync(out, dout, n, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipFree(dv); hipFree(dout);
+    if (e != hipSuccess) { cdm_set_error("debug kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
+    return CDM_OK;
+}
+
+int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb *out) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t) db->n;
+    uint32_t *active = nullptr; unsigned int *nActive = nullptr; uint8_t *accept = nullptr;
+    if (hipMalloc(&active, (size_t) n * 4) != hipSuccess || hipMalloc(&nActive, 8) != hipSuccess || hipMalloc(&accept, alns->count + 1) != hipSuccess) {
+        hipFree(active); hipFree(nActive); hipFree(accept);
+        cdm_set_error("out of device memory in cdm_correct"); return CDM_ERR_HIP;
+    }
+    int rc = CDM_OK;
+    do {
+        // coverage <= 1 everywhere unless the kernel overwrites: start from a copy of the input bases
+        hipMemcpyAsync(out->codes, db->codes, db->words * 4, hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(out->nmask, db->nmask, ((db->words * 16 + 31) / 32) * 4, hipMemcpyDeviceToDevice, s);
+        hipMemsetAsync(nActive, 0, 8, s);
+        hipLaunchKernelGGL(k_mark_active, dim3((n + 255) / 256), dim3(256), 0, s, alns->off, n, active, nActive);
+        CorrectArgs a;
+        a.woff = db->woff; a.len = db->len; a.codes = db->codes; a.nmask = db->nmask; a.ext = db->ext; a.hasN = db->hasN;
+        a.aoff = alns->off; a.rec = alns->rec; a.active = active; a.nActive = nActive; a.accept = accept; a.errFlag = nActive + 1;
+        a.outCodes = out->codes; a.outNmask = out->nmask; a.lut = ctx->lutDev; a.seqIdThr = par->seq_id_thr; a.corrRy = par->corr_reads_ry_seq_id;
+        const int blocks = ctx->cuCount * 8;
+        hipEventRecord(ctx->ev0, s);
+        hipLaunchKernelGGL(k_correct, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+        hipEventRecord(ctx->ev1, s);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { cdm_set_error("ancient_correction kernel failed: %s", hipGetErrorString(e)); rc = CDM_ERR_HIP; break; }
+        hipEventElapsedTime(&ctx->lastMs[0], ctx->ev0, ctx->ev1);
+        unsigned int flags[2] = {0, 0};
+        hipMemcpy(flags, nActive, 8, hipMemcpyDeviceToHost);
+        if (flags[1]) { cdm_set_error("ancient_correction: a query has more than 65535 alignment records (unsupported)"); rc = CDM_ERR_UNSUPPORTED; break; }
+    } while (0);
+    hipFree(active); hipFree(nActive); hipFree(accept);
+    return rc;
+}

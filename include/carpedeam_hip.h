@@ -1,0 +1,190 @@
+/*
+ * carpedeam_hip.h -- C ABI of the MI355X (gfx950) implementation of CarpeDeam's hot path
+ *
+ *     kmermatcher -> rescorediagonal -> ancient_correction -> ancient_read_assemble
+ *
+ * This is the drop-in boundary.  The reference has no FFI: its "plugin" surface is the
+ * module function  int fn(int argc, const char **argv, const Command&)  (lib/mmseqs/src/commons/Command.h:92-103)
+ * whose body is an OpenMP loop over a DBReader.  Each entry point below replaces one such loop; the reference
+ * lines it replaces are cited per function.  INTEGRATION.md shows the few lines a maintainer adds to the
+ * reference's module bodies to call them.
+ *
+ * Conventions
+ *   - plain C, POD structs, opaque handles; no exceptions cross the boundary.
+ *   - every function returns 0 on success, a negative cdm_status otherwise; cdm_last_error() gives the text
+ *     (thread local).  There is NO CPU fallback: without a usable gfx950 device cdm_ctx_create fails.
+ *   - handles own device memory (HBM); *_download copies into caller-allocated host buffers.
+ *   - sequences are addressed by *index* (position in the key-sorted DB index, i.e. DBReader's local id,
+ *     lib/mmseqs/src/commons/DBReader.cpp:238-) on the device; keys travel alongside for the host codecs.
+ *   - a context is bound to one device and one HIP stream; one context per host thread.
+ */
+#ifndef CARPEDEAM_HIP_H
+#define CARPEDEAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cdm_status {
+    CDM_OK = 0,
+    CDM_ERR_NO_DEVICE = -1,   /* no gfx950 device / HIP runtime failure at create */
+    CDM_ERR_HIP = -2,         /* HIP API or kernel launch failure */
+    CDM_ERR_INVALID = -3,     /* invalid argument / inconsistent input */
+    CDM_ERR_UNSUPPORTED = -4, /* input outside what the device path implements (see cdm_last_error) */
+    CDM_ERR_IO = -5           /* damage profile could not be read / parsed */
+} cdm_status;
+
+typedef struct cdm_ctx cdm_ctx;
+typedef struct cdm_seqdb cdm_seqdb; /* 2-bit packed sequence DB resident in HBM */
+typedef struct cdm_hits cdm_hits;   /* prefilter hits (kmermatcher output), CSR by query */
+typedef struct cdm_alns cdm_alns;   /* ungapped alignments (rescorediagonal output), CSR by query */
+
+const char *cdm_last_error(void);
+int cdm_ctx_create(int device_ordinal, cdm_ctx **out);
+void cdm_ctx_destroy(cdm_ctx *ctx);
+/* blocks until all work queued on the context's stream is done */
+int cdm_ctx_sync(cdm_ctx *ctx);
+/* the hipStream_t the context launches on (as void*), for callers that time with HIP events */
+void *cdm_ctx_stream(cdm_ctx *ctx);
+/* device time in ms of the dominant kernel(s) of the last stage call, measured with HIP events on the context stream;
+ * which = 0: ancient_correction pile-up/call kernel, 1: rescore kernel, 2: kmermatcher sorts, 3: kmer extraction,
+ * 4: extension kernel.  Returns a negative value when that stage has not run. */
+float cdm_ctx_last_kernel_ms(cdm_ctx *ctx, int which);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Sequence DB.  Replaces DBReader<unsigned int>::getData/getSeqLen/getDbKey/getExtData random access
+ * (lib/mmseqs/src/commons/DBReader.h:193-213, DBReader.cpp:1001-1012) inside the four stage loops.
+ *
+ * data      : the DB data file as mapped (entries "SEQUENCE\n\0")
+ * offsets[i]: byte offset of entry i in data;  lengths[i]: sequence length WITHOUT "\n\0"
+ * keys[i]   : DB key of entry i; entries must be ordered by key (the order DBReader's index has after open()).
+ * ext[i]    : the fork's 4th index column "wasExtended" (DBReader.cpp:808-817); may be NULL (= all 0)
+ * Letters other than A,C,G,T are kept as 'N' exceptions (side bit plane); any letter other than ACGTN
+ * (lower case, IUPAC codes) is rejected with CDM_ERR_UNSUPPORTED in this round.
+ */
+int cdm_seqdb_upload(cdm_ctx *ctx, const char *data, const uint64_t *offsets, const uint32_t *lengths,
+                     const uint32_t *keys, const uint8_t *ext, uint64_t n, cdm_seqdb **out);
+/* Synthetic reads generated on the device with the counter-based generator specified in carpedeam_amd/synth.py
+ * (SURVEY.md 8(d)): n reads, fixed length len_lo == len_hi or uniform in [len_lo, len_hi], 20x coverage genome,
+ * dhigh damage.  Keys are 0..n-1, ext = 0.  first_read lets a rank generate its own shard [first_read, first_read+n)
+ * of a larger corpus (the genome is that of the whole corpus of n_total reads). */
+int cdm_seqdb_synth(cdm_ctx *ctx, uint64_t n_total, uint64_t first_read, uint64_t n, uint32_t len_lo, uint32_t len_hi,
+                    uint64_t seed, cdm_seqdb **out);
+uint64_t cdm_seqdb_size(const cdm_seqdb *db);
+uint64_t cdm_seqdb_residues(const cdm_seqdb *db); /* sum of sequence lengths (DBReader::getAminoAcidDBSize) */
+uint32_t cdm_seqdb_max_len(const cdm_seqdb *db);
+/* lengths/keys/ext: caller arrays of size n (any may be NULL) */
+int cdm_seqdb_meta(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t *lengths, uint32_t *keys, uint8_t *ext);
+/* ASCII download: out must hold sum(len[i] + 1) bytes; entry i is written at out_offsets[i] followed by '\n' */
+int cdm_seqdb_download(cdm_ctx *ctx, const cdm_seqdb *db, char *out, const uint64_t *out_offsets);
+void cdm_seqdb_free(cdm_seqdb *db);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Damage model.  Replaces the per-thread initDeamProbabilities + getSeqErrorProf calls
+ * (src/assembler/correction.cpp:184-197, ancientReadsResults.cpp:161-173; nuclassembleUtil.cpp:821-1007,49-65).
+ * prefix is --ancient-damage: files <prefix>5p.prof and <prefix>3p.prof; "" means no damage (zero matrices).
+ * The host side of the library builds the 11+11 substitution matrices in the reference's mixed
+ * long double/double arithmetic and from them the log look-up tables the kernels use.
+ */
+int cdm_damage_load(cdm_ctx *ctx, const char *prefix);
+/* the 2 x 11 x 4 x 4 matrices as long double (fwd then rev), for tests */
+int cdm_damage_get(cdm_ctx *ctx, long double *out352);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * kmermatcher.  Replaces doComputation + writeKmerMatcherResult + the fill-in loop
+ * (lib/mmseqs/src/linclust/kmermatcher.cpp:391-451, 453-562, 815-930, 717-729) in single-split semantics.
+ */
+typedef struct cdm_kmer_params {
+    int32_t kmer_size;               /* -k (20 for reads, 22 for contigs) */
+    int32_t kmers_per_seq;           /* --kmer-per-seq */
+    float kmers_per_seq_scale;       /* --kmer-per-seq-scale */
+    uint64_t hash_shift;             /* --hash-shift (xxhash seed) */
+    int32_t ignore_multi_kmer;       /* --ignore-multi-kmer */
+    int32_t include_only_extendable; /* --include-only-extendable */
+    int32_t cov_mode;                /* --cov-mode */
+    float cov_thr;                   /* -c */
+} cdm_kmer_params;
+
+/* one prefilter line "targetKey \t score \t diagonal" (lib/mmseqs/src/prefiltering/QueryMatcher.h:35-39,114-126);
+ * score < 0 means the query has to be reverse-complemented */
+typedef struct cdm_hit {
+    uint32_t target; /* sequence index (not key) */
+    int32_t score;
+    int32_t diagonal; /* already truncated to short as the reference stores it */
+} cdm_hit;
+
+int cdm_kmermatch(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out);
+/* offsets: n+1 entries (CSR by query index); every query has at least its self hit as first record */
+int cdm_hits_upload(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *offsets, const cdm_hit *hits, cdm_hits **out);
+uint64_t cdm_hits_count(const cdm_hits *h);
+int cdm_hits_download(cdm_ctx *ctx, const cdm_hits *h, uint64_t *offsets, cdm_hit *hits);
+void cdm_hits_free(cdm_hits *h);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * rescorediagonal (--rescore-mode 3, query DB == target DB).  Replaces the loop at
+ * lib/mmseqs/src/alignment/rescorediagonal.cpp:145-356 (DistanceCalculator.h:93-175,204-220).
+ */
+typedef struct cdm_rescore_params {
+    float seq_id_thr; /* --min-seq-id */
+    double eval_thr;  /* -e */
+    int32_t cov_mode; /* --cov-mode */
+    float cov_thr;    /* -c */
+    int32_t seq_id_mode; /* --seq-id-mode (0 only) */
+    int32_t min_aln_len; /* --min-aln-len */
+} cdm_rescore_params;
+
+/* one alignment record = the ten text columns of Matcher::resultToBuffer (lib/mmseqs/src/alignment/Matcher.cpp:356-404)
+ * minus lengths (taken from the seq DB); raw_score/ident let the host derive bit score, E-value and seq.id. text.
+ * q_start > q_end encodes a reverse-strand hit as in the reference (rescorediagonal.cpp:294-297). */
+typedef struct cdm_aln {
+    uint32_t target;  /* sequence index */
+    int32_t raw_score;
+    int32_t ident;    /* identical columns */
+    int32_t q_start, q_end, db_start, db_end;
+    float seq_id;     /* value a reader of the text record gets: (float)strtod(fastSeqIdToBuffer(ident/alnLen)) */
+} cdm_aln;
+
+int cdm_rescore(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, const cdm_rescore_params *par, cdm_alns **out);
+int cdm_alns_upload(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *offsets, const cdm_aln *alns, cdm_alns **out);
+uint64_t cdm_alns_count(const cdm_alns *a);
+int cdm_alns_download(cdm_ctx *ctx, const cdm_alns *a, uint64_t *offsets, cdm_aln *alns);
+void cdm_alns_free(cdm_alns *a);
+/* host helpers for the text codec of the alignment DB: E-value, bit score (EvalueComputation.h:18-40 over ALP) */
+double cdm_evalue(double raw_score, double query_len, uint64_t db_residues);
+int cdm_bit_score(double raw_score);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * ancient_correction.  Replaces the loop at src/assembler/correction.cpp:200-476 (mostLikeliBaseRead :7-123).
+ * Output: a new sequence DB with identical keys/lengths/flags and corrected bases.
+ */
+typedef struct cdm_ancient_params {
+    float seq_id_thr;            /* --min-seq-id */
+    float corr_reads_ry_seq_id;  /* --min-ryseq-id-corr-reads */
+    float ry_seq_id_thr;         /* rySeqIdThr (not settable on the module's command line; 0.99) */
+    float rand_align_penal;      /* --ext-random-align */
+    float excess_penal;          /* --excess-penalty */
+    float likelihood_threshold;  /* --likelihood-ratio-threshold */
+    int32_t unsafe;              /* --unsafe (0 only on the device path) */
+    int32_t min_cov_safe;        /* --min-cov-safe */
+    uint64_t max_seq_len;        /* --max-seq-len */
+} cdm_ancient_params;
+
+int cdm_correct(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * ancient_read_assemble.  Replaces the loops at src/assembler/ancientReadsResults.cpp:178-581.
+ * db must be the corrected DB.  Output: new sequence DB (extended sequences get ext=1, others are copied through).
+ * scores (optional, may be NULL): for tests, the per-candidate likelihood of the first scoring round
+ * (calcLikelihoodConsensus, nuclassembleUtil.cpp:203-374): one double sLenNorm per alignment record, NaN where the
+ * record is not a candidate.
+ */
+int cdm_extend(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out,
+               double *scores);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

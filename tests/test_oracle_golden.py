@@ -74,6 +74,31 @@ def test_evalue_table(oracle_bin):
             assert abs(float.fromhex(g[0]) - float.fromhex(e[0])) <= 1e-12 * abs(float.fromhex(e[0])), (db, a)
 
 
+def pref_sign_ties(got, exp):
+    """Keys whose prefilter lists differ ONLY by the strand sign of one hit (same target, |score|, diagonal).
+
+    Reference nondeterminism N1: assignGroup starts with repIsReverse=false whatever the strand of
+    the very first k-mer group's representative (M/linclust/kmermatcher.cpp:453-467), so that one group can emit
+    tuples whose strand bit contradicts the other tuples of the same (rep, target, diagonal); the comparator of
+    the second sort ignores the strand bit (kmermatcher.h:98-114) and the sort (ips4o) is unstable, so which
+    strand `writeKmerMatcherResult` sees last - and reports - depends on the run (it changes with --threads).
+    At most one k-mer group per run is affected."""
+    ties, bad = [], []
+    for k in sorted(set(got) | set(exp)):
+        if got.get(k) == exp.get(k):
+            continue
+        if k not in got or k not in exp or got[k][1] != exp[k][1]:
+            bad.append(k)
+            continue
+        a, b = got[k][0].decode().split("\n"), exp[k][0].decode().split("\n")
+        diff = [(x.split("\t"), y.split("\t")) for x, y in zip(a, b) if x != y]
+        if len(a) == len(b) and all(x[0] == y[0] and x[2] == y[2] and int(x[1]) == -int(y[1]) for x, y in diff):
+            ties.append((k, len(diff)))
+        else:
+            bad.append(k)
+    return ties, bad
+
+
 def _stage_chain(oracle_bin, dhigh_prefix, tmp_path, name, iterations):
     """Stage-isolated: every oracle stage consumes the *reference's* upstream DBs and must reproduce
     the reference's output DB key by key."""
@@ -93,6 +118,9 @@ def _stage_chain(oracle_bin, dhigh_prefix, tmp_path, name, iterations):
         for s in ("pref", "aln", "corr", "asm"):
             got, exp = mmdb.canon(mmdb.read_db(t(s))), mmdb.canon(gold[s])
             bad = [k for k in sorted(set(got) | set(exp)) if got.get(k) != exp.get(k)]
+            if s == "pref":
+                ties, bad = pref_sign_ties(got, exp)
+                assert sum(n for _, n in ties) <= 1, ties
             assert not bad, "%s iteration %d stage %s: %d keys differ, e.g. %s" % (name, it, s, len(bad), bad[:5])
         inp_keyed = gold["asm"]
 
