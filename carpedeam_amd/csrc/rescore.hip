@@ -1,0 +1,230 @@
+// rescorediagonal (--rescore-mode 3, query DB == target DB) on the device.
+//
+// Replaces the loop at lib/mmseqs/src/alignment/rescorediagonal.cpp:145-356:
+//   per prefilter hit: query strand (:194-202), canBeCovered (:211-213), ungapped end-to-end score on the voted diagonal
+//   incl. the +-65536 probing of the 16-bit diagonal (DistanceCalculator.h:93-113,115-175,204-220; scores +2/-3, any X -3),
+//   E-value gate (:251, decided through a host-built "minimum passing raw score per query length" table so that the
+//   double-precision ALP arithmetic stays on the host), identity count (:278-282), coverage / seq.id. filters (:304-314),
+//   reverse-strand coordinate encoding (:294-297).
+// One thread per hit; sequences are compared 16 bases at a time on the 2-bit words (XOR + popcount).  Hits whose two
+// sequences contain an N take a per-base path.  Survivors are compacted per query with a prefix sum.
+#include <hipcub/hipcub.hpp>
+
+#include <cfloat>
+#include <climits>
+
+#include "common.h"
+#include "devutil.h"
+
+namespace {
+
+struct RescoreArgs {
+    const uint32_t *woff, *len, *codes, *nmask;
+    const uint8_t *hasN;
+    const uint64_t *hoff;
+    const HitRec *hit;
+    const int32_t *minScore;   // [maxLen+1]
+    uint64_t nHits;
+    uint32_t n;
+    float seqIdThr, covThr;
+    int covMode, minAlnLen;
+    AlnRec *tmp;               // [nHits] candidate records
+    uint8_t *valid;            // [nHits]
+};
+
+__device__ __forceinline__ bool canBeCovered(float covThr, int covMode, float ql, float tl) {   // M/commons/Util.cpp:533-550
+    switch (covMode) {
+        case 0: return ((ql / tl >= covThr) && (tl / ql >= covThr));
+        case 2: return ((tl / ql) >= covThr);
+        case 1: return ((ql / tl) >= covThr);
+        case 3: return ((tl / ql) >= covThr) && (tl / ql) <= 1.0;
+        case 4: return ((ql / tl) >= covThr) && (ql / tl) <= 1.0;
+        case 5: return (fminf(tl, ql) / fmaxf(tl, ql)) >= covThr;
+        default: return true;
+    }
+}
+__device__ __forceinline__ bool hasCoverage(float covThr, int covMode, float qc, float tc) {   // Util.cpp:552-567
+    switch (covMode) { case 0: return qc >= covThr && tc >= covThr; case 2: return qc >= covThr; case 1: return tc >= covThr; default: return true; }
+}
+__device__ __forceinline__ float computeCov(unsigned s, unsigned e, unsigned len) {           // StripedSmithWaterman.cpp:1055-1057
+    return (min(len, max(s, e)) - min(s, e) + 1) / (float) len;
+}
+
+// 16 bases of the (optionally reverse-complemented) sequence starting at oriented position i
+__device__ __forceinline__ uint32_t orientedWindow(const uint32_t *codes, uint32_t w0, uint32_t L, uint32_t lastWord, bool rc, uint32_t i) {
+    if (!rc) return cdm_window16(codes, w0, i, lastWord);
+    const int s = (int) L - 16 - (int) i;
+    uint32_t w = (s >= 0) ? cdm_window16(codes, w0, (uint32_t) s, lastWord) : (cdm_window16(codes, w0, 0, lastWord) << (2 * (-s)));
+    return cdm_revcomp16(w);
+}
+// oriented base and N flag (per-base path)
+__device__ __forceinline__ void orientedBase(const RescoreArgs &a, uint32_t w0, uint32_t L, bool hasN, bool rc, uint32_t i, uint32_t &code, bool &isN) {
+    const uint32_t p = rc ? (L - 1 - i) : i;
+    code = cdm_base(a.codes, w0, p);
+    isN = hasN && cdm_isN(a.nmask, w0, p);
+    if (rc) code = 3u - code;
+}
+
+struct Diag { unsigned score; unsigned diagLen; unsigned dist; int diagonal; unsigned ident; bool any; };
+
+// ungappedAlignmentByDiagonal + computeGlobalSubstitutionStartEndDistance for one real diagonal
+__device__ __forceinline__ void scoreDiagonal(const RescoreArgs &a, uint32_t qw, uint32_t qLen, bool qN, bool rc, uint32_t tw, uint32_t tLen, bool tN,
+                                              int diagonal, Diag &best) {
+    const unsigned md = (unsigned) abs(diagonal);
+    uint32_t qOff, tOff, m;
+    if (diagonal >= 0 && md < qLen) { qOff = md; tOff = 0; m = min(tLen, qLen - md); }
+    else if (diagonal < 0 && md < tLen) { qOff = 0; tOff = md; m = min(tLen - md, qLen); }
+    else return;   // res.score stays 0: never beats max (strict >)
+    unsigned mism = 0, identN = 0;
+    if (!qN && !tN) {
+        const uint32_t qLast = (qLen + 15) / 16 - 1, tLast = (tLen + 15) / 16 - 1;
+        for (uint32_t k = 0; k < m; k += 16) {
+            const uint32_t x = orientedWindow(a.codes, qw, qLen, qLast, rc, qOff + k) ^ cdm_window16(a.codes, tw, tOff + k, tLast);
+            uint32_t mm = (x | (x >> 1)) & 0x55555555u;
+            const uint32_t rem = m - k;
+            if (rem < 16) mm &= (1u << (2 * rem)) - 1u;
+            mism += __popc(mm);
+        }
+    } else {
+        for (uint32_t k = 0; k < m; k++) {
+            uint32_t qc, tc; bool qn, tn;
+            orientedBase(a, qw, qLen, qN, rc, qOff + k, qc, qn);
+            orientedBase(a, tw, tLen, tN, false, tOff + k, tc, tn);
+            const bool match = !qn && !tn && qc == tc;
+            mism += !match;
+            // identity count compares letters: forward N == N; the reversed query spells N as 'X' (rescorediagonal.cpp:173-179)
+            identN += (qn && tn && !rc);
+        }
+    }
+    const long long sc = 2ll * (m - mism) - 3ll * mism;
+    const unsigned score = sc > 0 ? (unsigned) sc : 0u;
+    if (score > best.score) { best.score = score; best.diagLen = m; best.dist = md; best.diagonal = diagonal; best.ident = (m - mism) + identN; best.any = true; }
+}
+
+__global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, const uint32_t *__restrict__ hitQuery) {
+    const uint64_t h = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= a.nHits) return;
+    const uint32_t q = hitQuery[h];
+    const HitRec hit = a.hit[h];
+    const uint32_t t = hit.target;
+    const uint32_t qLen = a.len[q], tLen = a.len[t], qw = a.woff[q], tw = a.woff[t];
+    const bool qN = a.hasN[q] != 0, tN = a.hasN[t] != 0;
+    const bool isReverse = hit.score < 0;
+    const bool isIdentity = (q == t);
+    a.valid[h] = 0;
+    if (!canBeCovered(a.covThr, a.covMode, (float) qLen, (float) tLen)) return;
+    // computeUngappedAlignment (DistanceCalculator.h:93-113) on the 16-bit diagonal
+    const unsigned short u = (unsigned short) (short) hit.diagonal;
+    Diag best; best.score = 0; best.diagLen = 0; best.dist = 0; best.diagonal = 0; best.ident = 0; best.any = false;
+    for (unsigned d = 1; d <= 1 + tLen / 32768; d++) scoreDiagonal(a, qw, qLen, qN, isReverse, tw, tLen, tN, (int) (-(int) d * 65536 + (int) u), best);
+    for (unsigned d = 0; d <= qLen / 65536; d++) scoreDiagonal(a, qw, qLen, qN, isReverse, tw, tLen, tN, (int) (d * 65536 + u), best);
+    if (!best.any) return;   // score 0 on every probe: E-value(0) never passes; (identity of an all-N sequence is not representable)
+    const int startPos = 0, endPos = (int) best.diagLen - 1;
+    const int alnLen = (endPos - startPos) + 1;
+    int qs, qe, ds, de;
+    if (best.diagonal >= 0) { qs = startPos + (int) best.dist; qe = endPos + (int) best.dist; ds = startPos; de = endPos; }
+    else { qs = startPos; qe = endPos; ds = startPos + (int) best.dist; de = endPos + (int) best.dist; }
+    const bool hasEvalue = (int) best.score >= a.minScore[qLen];
+    float seqId = 0.f;
+    if (hasEvalue || isIdentity) seqId = static_cast<float>(best.ident) / static_cast<float>(alnLen);
+    const float queryCov = computeCov(qs, qe, qLen), targetCov = computeCov(ds, de, tLen);
+    if (isReverse) { qs = (int) qLen - qs - 1; qe = (int) qLen - qe - 1; }
+    const bool hasCov = hasCoverage(a.covThr, a.covMode, queryCov, targetCov);
+    const bool hasSeqId = (double) seqId >= (double) (a.seqIdThr - FLT_EPSILON);
+    const bool hasAlnLen = alnLen >= a.minAlnLen;
+    if (!(isIdentity || (hasAlnLen && hasCov && hasSeqId && hasEvalue))) return;
+    AlnRec r;
+    r.target = t; r.rawScore = (int) best.score; r.ident = (int) best.ident; r.qStart = qs; r.qEnd = qe; r.dbStart = ds; r.dbEnd = de;
+    // what a reader of the text record gets back: fastSeqIdToBuffer truncates to 3 decimals, "1.00" for 1 (Util.cpp:278-307)
+    r.seqId = (seqId == 1.0f) ? 1.0f : (float) ((double) (int) (seqId * 1000) / 1000.0);
+    a.tmp[h] = r;
+    a.valid[h] = 1;
+}
+
+// hit -> owning query (CSR expansion): one thread per query
+__global__ void k_expand(const uint64_t *__restrict__ off, uint32_t n, uint32_t *__restrict__ owner) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    for (uint64_t h = off[q]; h < off[q + 1]; h++) owner[h] = q;
+}
+__global__ void k_count_valid(const uint64_t *__restrict__ off, const uint8_t *__restrict__ valid, uint32_t n, uint64_t *__restrict__ cnt) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    uint64_t c = 0;
+    for (uint64_t h = off[q]; h < off[q + 1]; h++) c += valid[h];
+    cnt[q] = c;
+}
+__global__ void k_scatter(const uint64_t *__restrict__ off, const uint8_t *__restrict__ valid, const AlnRec *__restrict__ tmp, uint32_t n,
+                          const uint64_t *__restrict__ outOff, AlnRec *__restrict__ out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    uint64_t o = outOff[q];
+    for (uint64_t h = off[q]; h < off[q + 1]; h++) if (valid[h]) out[o++] = tmp[h];
+}
+__global__ void k_len_hist(const uint32_t *__restrict__ len, uint32_t n, uint32_t *__restrict__ present) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) present[len[i]] = 1;
+}
+
+}  // namespace
+
+int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, const cdm_rescore_params *par, cdm_alns **out) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t) db->n;
+    const uint64_t nHits = hits->count;
+    if (db->maxLen >= (1u << 30)) { cdm_set_error("cdm_rescore: sequence too long"); return CDM_ERR_UNSUPPORTED; }
+    // E-value gate table for the lengths that occur (host ALP arithmetic, host/evalue.cpp)
+    std::vector<uint32_t> present(db->maxLen + 1);
+    uint32_t *dPresent = nullptr; int32_t *dMin = nullptr; uint32_t *owner = nullptr; AlnRec *tmp = nullptr; uint8_t *valid = nullptr;
+    uint64_t *cnt = nullptr; void *scanTmp = nullptr;
+    cdm_alns *res = nullptr;
+    int rc = CDM_OK;
+    auto fail = [&](const char *what) { cdm_set_error("cdm_rescore: %s", what); rc = CDM_ERR_HIP; };
+    do {
+        if (hipMalloc(&dPresent, (size_t) (db->maxLen + 1) * 4) != hipSuccess || hipMalloc(&dMin, (size_t) (db->maxLen + 1) * 4) != hipSuccess ||
+            hipMalloc(&owner, (nHits + 1) * 4) != hipSuccess || hipMalloc(&tmp, (nHits + 1) * sizeof(AlnRec)) != hipSuccess ||
+            hipMalloc(&valid, nHits + 1) != hipSuccess || hipMalloc(&cnt, ((size_t) n + 1) * 8) != hipSuccess) { fail("out of device memory"); break; }
+        hipMemsetAsync(dPresent, 0, (size_t) (db->maxLen + 1) * 4, s);
+        hipLaunchKernelGGL(k_len_hist, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, dPresent);
+        hipMemcpyAsync(present.data(), dPresent, (size_t) (db->maxLen + 1) * 4, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { fail("length histogram failed"); break; }
+        std::vector<int32_t> minScore(db->maxLen + 1, INT_MAX);
+        for (uint32_t L = 1; L <= db->maxLen; L++) {
+            if (!present[L]) continue;
+            int lo = 0, hi = 2 * (int) L;   // E-value decreases with the score (checked in tests for the lengths used)
+            if (!(cdm_evalue_host(hi, L, db->residues) <= par->eval_thr)) continue;
+            while (lo < hi) { int mid = (lo + hi) / 2; if (cdm_evalue_host(mid, L, db->residues) <= par->eval_thr) hi = mid; else lo = mid + 1; }
+            minScore[L] = lo;
+        }
+        hipMemcpyAsync(dMin, minScore.data(), (size_t) (db->maxLen + 1) * 4, hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL(k_expand, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, n, owner);
+        RescoreArgs a;
+        a.woff = db->woff; a.len = db->len; a.codes = db->codes; a.nmask = db->nmask; a.hasN = db->hasN; a.hoff = hits->off; a.hit = hits->rec;
+        a.minScore = dMin; a.nHits = nHits; a.n = n; a.seqIdThr = par->seq_id_thr; a.covThr = par->cov_thr; a.covMode = par->cov_mode;
+        a.minAlnLen = par->min_aln_len; a.tmp = tmp; a.valid = valid;
+        hipEventRecord(ctx->ev0, s);
+        if (nHits) hipLaunchKernelGGL(k_rescore, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, s, a, owner);
+        hipEventRecord(ctx->ev1, s);
+        hipLaunchKernelGGL(k_count_valid, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid, n, cnt);
+        res = new cdm_alns(); res->n = n;
+        if (hipMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { fail("out of device memory"); break; }
+        size_t tmpBytes = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cnt, res->off, n + 1, s);
+        if (hipMalloc(&scanTmp, tmpBytes + 16) != hipSuccess) { fail("out of device memory"); break; }
+        hipMemsetAsync(cnt + n, 0, 8, s);
+        hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, cnt, res->off, n + 1, s);
+        uint64_t total = 0;
+        hipMemcpyAsync(&total, res->off + n, 8, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { fail("kernel failed"); break; }
+        res->count = total;
+        if (hipMalloc(&res->rec, (total + 1) * sizeof(AlnRec)) != hipSuccess) { fail("out of device memory"); break; }
+        hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid, tmp, n, res->off, res->rec);
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { fail(hipGetErrorString(e)); break; }
+        hipEventElapsedTime(&ctx->lastMs[1], ctx->ev0, ctx->ev1);
+    } while (0);
+    hipFree(dPresent); hipFree(dMin); hipFree(owner); hipFree(tmp); hipFree(valid); hipFree(cnt); hipFree(scanTmp);
+    if (rc != CDM_OK) { if (res) cdm_alns_free(res); return rc; }
+    *out = res;
+    return CDM_OK;
+}

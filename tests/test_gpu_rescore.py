@@ -1,0 +1,53 @@
+"""GPU parity of rescorediagonal: device integers + host text codec must reproduce the reference's alignment DB text."""
+import numpy as np
+import pytest
+
+from carpedeam_amd import capi, mmdb
+from gpuutil import DATASETS, diff_keys, gold, run_oracle, stage_input
+from stageflags import K_FLAGS, R_FLAGS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return capi.Ctx(0)
+
+
+def rescore_text(ctx, seq_keyed, pref_keyed):
+    db = ctx.upload_keyed_seqdb(seq_keyed)
+    lens, keys, _ = db.meta()
+    off, rec = capi.parse_pref_db(pref_keyed, keys)
+    alns = ctx.rescore(db, ctx.upload_hits(db, off, rec))
+    aoff, arec = alns.download()
+    return {k: (v, 0) for k, v in capi.alns_to_text(aoff, arec, keys, lens, db.residues).items()}
+
+
+@pytest.mark.parametrize("name,its", DATASETS)
+def test_rescore_matches_golden(ctx, name, its):
+    for it in range(its):
+        got = rescore_text(ctx, stage_input(name, it), gold(name, "pref", it))
+        assert not diff_keys(got, gold(name, "aln", it)), (name, it)
+
+
+def test_rescore_with_N_matches_oracle(ctx, oracle_bin, tmp_path):
+    from carpedeam_amd import synth
+    rng = np.random.default_rng(11)
+    seqs = synth.generate_strings(1500, seed=9, mixed=(30, 150))
+    seqs = ["".join("N" if rng.random() < 0.01 else c for c in s) for s in seqs]
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
+    run_oracle(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref"), t("aln"), *R_FLAGS, "--threads", "4")
+    got = rescore_text(ctx, mmdb.read_db(t("in")), mmdb.read_db(t("pref")))
+    assert not diff_keys(got, mmdb.read_db(t("aln")))
+
+
+def test_evalue_gate_is_monotone():
+    """the device decides `evalue <= thr` as `score >= minScore[qLen]`: check on the host that the pass set is an up-set"""
+    l = capi.lib()
+    for db_res in (200000, 5000000000):
+        for L in list(range(20, 400, 7)) + [1000, 5000, 20000]:
+            passed = [l.cdm_evalue(float(s), float(L), db_res) <= 0.001 for s in range(0, 2 * L + 1)]
+            first = passed.index(True) if True in passed else len(passed)
+            assert all(passed[first:]), (db_res, L)
