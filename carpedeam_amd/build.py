@@ -17,7 +17,7 @@ BIN = os.path.join(HERE, "carpedeam")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ROCM_INC = "/opt/rocm/include"
 
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 GXX_FLAGS = ["-O3", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-fsigned-char", "-Wall",
              "-D__HIP_PLATFORM_AMD__", "-I" + ROCM_INC]
 

@@ -1,0 +1,492 @@
+// kmermatcher (linclust-style k-mer matching) on the device, single-split semantics.
+//
+// Replaces lib/mmseqs/src/linclust/kmermatcher.cpp doComputation (:391-451) and the result writer (:815-930, :717-729):
+//   K1 k_extract      fillKmerPositionArray :77-388  per sequence: canonical k-mers, XXH64 16-bit min-hash, per-sequence
+//                     ordering by (hash, k-mer, pos) for the repeated-k-mer skipping and the bottom-m selection, + the
+//                     whole-sequence hash tuple
+//   K2 sort 1         :412   stable LSD radix sort on the 63-bit k-mer (rocPRIM), strand bit 63 carried along
+//   K3 k_groups       assignGroup :453-562  first sequence of every k-mer run by (length desc, id, pos) is the
+//                     representative; members become (rep, id, diagonal, strand); singletons dropped
+//   K2 sort 2         :431   stable radix sort on (rep, id, diagonal) packed into one 64-bit key
+//   K4 k_vote         writeKmerMatcherResult :815-930  per (rep, target): shared k-mer count, most frequent diagonal
+//                     (last maximum wins), strand of that diagonal's last tuple; every sequence gets a record that starts
+//                     with its self hit (fill-in :717-729)
+// Quirks kept on purpose (they are observable in the prefilter DB): the repeated-k-mer skip that processes the element
+// after a run unconditionally (:277-350); repIsReverse starting as false for the very first k-mer group (:453-467); the
+// per-target scan in the writer running on into the next representative's tuples when they have the same target id
+// (:875-887).
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+#include "devutil.h"
+
+namespace {
+
+constexpr uint64_t BIT63 = 1ull << 63;
+
+// xxHash64 of one 8-byte word (lib/mmseqs/lib/xxhash/xxhash.h XXH64, len = 8; kmermatcher.cpp:33-38)
+__host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__host__ __device__ __forceinline__ uint64_t xxh64_u64(uint64_t in, uint64_t seed) {
+    const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL, P4 = 9650029242287828579ULL,
+                   P5 = 2870177450012600261ULL;
+    uint64_t h = seed + P5 + 8;
+    uint64_t k1 = in * P2; k1 = rotl64(k1, 31); k1 *= P1;
+    h ^= k1; h = rotl64(h, 27) * P1 + P4;
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+// Util::revComplement (M/commons/Util.cpp:601-638) in MMseqs2's A,C,T,G = 0..3 coding: complement = xor 2
+__device__ __forceinline__ uint64_t revComplement(uint64_t kmer, int k) {
+    uint64_t x = kmer ^ 0xAAAAAAAAAAAAAAAAULL;
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = __builtin_bswap64(x);
+    return x >> (64 - 2 * k);
+}
+
+struct ExtractArgs {
+    const uint32_t *woff, *len, *codes, *nmask;
+    const uint8_t *hasN;
+    const uint32_t *list;       // sequence indices this launch handles
+    uint32_t nList;
+    int k, kmersPerSeq; float scale; uint64_t seed; int ignoreMultiKmer;
+    uint64_t *keys, *vals;      // tuple array: key = k-mer | strand bit 63, val = id << 32 | seqLen << 16 | pos
+    unsigned long long *count;  // number of tuples written
+    uint64_t capacity;
+    unsigned int *err;
+};
+
+// sort element of the per-sequence ordering compareByScoreReverse (kmermatcher.h:30-46): (score, kmer|bit63, pos)
+struct SeqPos { uint64_t a, b; };   // a = score << 48 | kmer63 >> 15 ; b = (kmer63 & 0x7FFF) << 49 | pos << 1 | forward
+__device__ __forceinline__ bool spLess(const SeqPos &x, const SeqPos &y) { return x.a < y.a || (x.a == y.a && x.b < y.b); }
+__device__ __forceinline__ uint64_t spKmer63(const SeqPos &x) { return ((x.a & 0xFFFFFFFFFFFFull) << 15) | (x.b >> 49); }
+__device__ __forceinline__ uint32_t spScore(const SeqPos &x) { return (uint32_t) (x.a >> 48); }
+__device__ __forceinline__ uint32_t spPos(const SeqPos &x) { return (uint32_t) ((x.b >> 1) & 0xFFFFFFFFFFFFull); }
+
+// One workgroup of NT threads per sequence; CAP = power of two >= number of k-mers of the sequence.
+template <int CAP, int NT>
+__global__ __launch_bounds__(NT) void k_extract(ExtractArgs a) {
+    __shared__ SeqPos sp[CAP];
+    __shared__ uint8_t sel[CAP];
+    __shared__ uint32_t sN, sOk, sCursor;
+    __shared__ unsigned long long sBase64;
+    const int tid = threadIdx.x;
+    for (uint32_t item = blockIdx.x; item < a.nList; item += gridDim.x) {
+        const uint32_t seq = a.list[item];
+        const uint32_t L = a.len[seq], w0 = a.woff[seq];
+        const bool hasN = a.hasN[seq] != 0;
+        const int k = a.k;
+        const uint32_t nPos = (L >= (uint32_t) k) ? (L - k + 1) : 0;
+        if (tid == 0) sN = 0;
+        __syncthreads();
+        // ---- k-mers (Sequence::nextKmer + Indexer::computeKmerIdx, canonical pick kmermatcher.cpp:155-190)
+        const uint32_t lastWord = (L + 15) / 16 - 1;
+        for (uint32_t pos = tid; pos < nPos; pos += NT) {
+            // k bases starting at pos in MMseqs coding (gray code of ours), first base most significant
+            uint64_t idx = 0; bool x = false;
+            for (int j = 0; j < k; j += 16) {
+                uint32_t w = cdm_window16(a.codes, w0, pos + j, lastWord);
+                w ^= (w >> 1) & 0x55555555u;                       // A,C,G,T -> A,C,T,G
+                const int take = min(16, k - j);
+                for (int b = 0; b < take; b++) idx = (idx << 2) | ((w >> (2 * b)) & 3u);
+            }
+            if (hasN) for (int j = 0; j < k; j++) x |= cdm_isN(a.nmask, w0, pos + j) != 0;
+            if (x) continue;
+            const uint64_t rc = revComplement(idx, k);
+            if (rc == idx) continue;
+            const bool pickRev = rc < idx;
+            const uint64_t km = pickRev ? rc : idx;
+            const uint32_t score = (uint32_t) (xxh64_u64(km, a.seed) & 0xFFFFu);
+            const uint32_t p = pickRev ? (L - pos - k) : pos;
+            SeqPos e;
+            e.a = ((uint64_t) score << 48) | (km >> 15);
+            e.b = ((km & 0x7FFFull) << 49) | ((uint64_t) p << 1) | (pickRev ? 0ull : 1ull);
+            const uint32_t slot = atomicAdd(&sN, 1u);
+            sp[slot] = e;
+        }
+        __syncthreads();
+        const uint32_t n = sN;
+        // ---- sort by (score, kmer, pos): bitonic over the next power of two, padding = max
+        uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
+        for (uint32_t i = n + tid; i < np2; i += NT) { sp[i].a = ~0ull; sp[i].b = ~0ull; }
+        __syncthreads();
+        for (uint32_t size = 2; size <= np2; size <<= 1)
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t t = tid; t < np2 / 2; t += NT) {
+                    const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    SeqPos x = sp[lo], y = sp[hi];
+                    if (spLess(y, x) == up) { sp[lo] = y; sp[hi] = x; }
+                }
+                __syncthreads();
+            }
+        // ---- selection (kmermatcher.cpp:224-240, 277-350)
+        const size_t considered = min((size_t) (float) ((float) (a.kmersPerSeq - 1) + (a.scale * (float) L)), (size_t) n);
+        // fast path test: no two equal k-mers next to each other, and every k-mer is taken
+        int dup = 0;
+        for (uint32_t i = tid; i + 1 < n; i += NT) dup |= (spKmer63(sp[i]) == spKmer63(sp[i + 1]));
+        const int anyDup = __syncthreads_or(dup && a.ignoreMultiKmer);
+        if (!anyDup && considered == n) {
+            for (uint32_t i = tid; i < n; i += NT) sel[i] = 1;
+        } else {
+            for (uint32_t i = tid; i < n; i += NT) sel[i] = 0;
+            __syncthreads();
+            if (tid == 0 && n > 0) {
+                // threshold = (score of the considered-th smallest) + 1, inBins = #(score < threshold)  [:224-240]
+                uint32_t threshold = 0; size_t inBins = 0;
+                if (considered > 0) {
+                    threshold = spScore(sp[considered - 1]) + 1;
+                    inBins = considered;
+                    while (inBins < n && spScore(sp[inBins]) < threshold) inBins++;
+                } else {
+                    // the reference's loops leave threshold at the start of the first non-empty 512-bin and subtract that bin
+                    threshold = (spScore(sp[0]) >> 9) * 512; inBins = 0;
+                }
+                int tooMuch = (int) (inBins - considered);
+                size_t selected = 0;
+                for (size_t ki = 0; ki < n && selected < considered; ki++) {
+                    if (a.ignoreMultiKmer) {
+                        const uint64_t km = spKmer63(sp[ki]);
+                        if (ki + 1 < n) {
+                            uint64_t nx = spKmer63(sp[ki + 1]);
+                            if (km == nx) {
+                                while (km == nx && ki < n) { ki++; if (ki >= n) break; nx = spKmer63(sp[ki]); }
+                            }
+                        }
+                        if (ki >= n) break;
+                    }
+                    if (spScore(sp[ki]) < threshold) {
+                        if (spScore(sp[ki]) == (threshold - 1) && tooMuch) { tooMuch--; threshold -= (tooMuch == 0) ? 1 : 0; }
+                        selected++;
+                        sel[ki] = 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- emit: 1 whole-sequence tuple (:244-267) + the selected k-mers
+        uint32_t mine = 0;
+        for (uint32_t i = tid; i < n; i += NT) mine += sel[i];
+        // block total via shared atomic
+        if (tid == 0) sN = 1;
+        __syncthreads();
+        if (mine) atomicAdd(&sN, mine);
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long base = atomicAdd(a.count, (unsigned long long) sN);
+            sOk = (base + sN <= a.capacity) ? 1u : 0u;
+            if (!sOk) atomicOr(a.err, 1u);
+            sBase64 = base;
+            sCursor = 1;
+        }
+        __syncthreads();
+        if (sOk) {
+            const unsigned long long base = sBase64;
+            if (tid == 0) {
+                // Util::hash over the numeric sequence (M/commons/Util.h:338-346) then XXH64 (kmermatcher.cpp:135-138)
+                uint64_t h = 0;
+                for (uint32_t i = 0; i < L; i++) {
+                    uint32_t c = cdm_base(a.codes, w0, i);
+                    c ^= c >> 1;
+                    if (hasN && cdm_isN(a.nmask, w0, i)) c = 4;
+                    h = h * 31 + c;
+                }
+                a.keys[base] = xxh64_u64(h, a.seed);
+                a.vals[base] = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | 0ull;
+            }
+            // slot order within the sequence does not matter (a global sort follows)
+            for (uint32_t i = tid; i < n; i += NT) {
+                if (!sel[i]) continue;
+                const uint32_t o = atomicAdd(&sCursor, 1u);
+                const SeqPos e = sp[i];
+                a.keys[base + o] = spKmer63(e) | ((e.b & 1ull) ? BIT63 : 0ull);
+                a.vals[base + o] = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | (uint64_t) spPos(e);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K3: groups
+struct GroupArgs {
+    const uint64_t *keys, *vals;   // sorted by k-mer (bits 0..62)
+    uint64_t n;
+    int onlyExtendable, covMode; float covThr;
+    uint64_t *outKeys;             // per input tuple: packed (rep, id, diagonal, strand) or ~0 when dropped
+    uint32_t idBits, diagBits; int diagBias;
+};
+__device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float ql, float tl) {
+    switch (covMode) {
+        case 0: return ((ql / tl >= covThr) && (tl / ql >= covThr));
+        case 2: return ((tl / ql) >= covThr);
+        case 1: return ((ql / tl) >= covThr);
+        case 3: return ((tl / ql) >= covThr) && (tl / ql) <= 1.0;
+        case 4: return ((ql / tl) >= covThr) && (ql / tl) <= 1.0;
+        case 5: return (fminf(tl, ql) / fmaxf(tl, ql)) >= covThr;
+        default: return true;
+    }
+}
+// key layout of the second sort: [ rep | id | diagonal + bias | strand ] , strand (1 = query needs no reversal) in bit 0
+__device__ __forceinline__ uint64_t packGroupKey(const GroupArgs &a, uint32_t rep, uint32_t id, int diag, bool noRev) {
+    return ((((uint64_t) rep << a.idBits) | id) << (a.diagBits + 1)) | ((uint64_t) (uint32_t) (diag + a.diagBias) << 1) | (noRev ? 1ull : 0ull);
+}
+__global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const uint64_t km = a.keys[i] & ~BIT63;
+    if (i > 0 && (a.keys[i - 1] & ~BIT63) == km) return;       // not the first tuple of its k-mer run
+    // scan the run: size and representative = min by (seqLen desc, id asc, pos asc)  [sort order kmermatcher.h:76-96]
+    uint64_t e = i; uint64_t best = a.vals[i]; uint64_t bestKey = a.keys[i];
+    auto better = [](uint64_t x, uint64_t y) {   // x before y ?
+        const uint32_t xl = (x >> 16) & 0xFFFF, yl = (y >> 16) & 0xFFFF;
+        if (xl != yl) return xl > yl;
+        const uint32_t xi = (uint32_t) (x >> 32), yi = (uint32_t) (y >> 32);
+        if (xi != yi) return xi < yi;
+        return (x & 0xFFFF) < (y & 0xFFFF);
+    };
+    for (e = i + 1; e < a.n && (a.keys[e] & ~BIT63) == km; e++) {
+        const uint64_t v = a.vals[e];
+        if (better(v, best)) { best = v; bestKey = a.keys[e]; }
+    }
+    if (e - i == 1) { a.outKeys[i] = ~0ull; return; }          // singleton (:479)
+    const uint32_t repId = (uint32_t) (best >> 32);
+    const int queryLen = (int) ((best >> 16) & 0xFFFF), repPos = (int) (best & 0xFFFF);
+    // the reference initialises repIsReverse = false and only updates it when a NEW run starts (:465,:535-538):
+    // the very first run of the array keeps false whatever its strand
+    const bool repIsReverse = (i == 0) ? false : ((bestKey & BIT63) == 0);
+    for (uint64_t j = i; j < e; j++) {
+        const uint64_t v = a.vals[j];
+        const uint32_t id = (uint32_t) (v >> 32);
+        const int tLen = (int) ((v >> 16) & 0xFFFF), tPos0 = (int) (v & 0xFFFF);
+        const bool targetIsReverse = (a.keys[j] & BIT63) == 0;
+        int qPos, tPos; bool qRev;
+        if (repIsReverse && !targetIsReverse) { qPos = repPos; tPos = tPos0; qRev = true; }
+        else if (repIsReverse && targetIsReverse) { qPos = (queryLen - 1) - repPos; tPos = (tLen - 1) - tPos0; qRev = false; }
+        else if (!repIsReverse && targetIsReverse) { qPos = (queryLen - 1) - repPos; tPos = (tLen - 1) - tPos0; qRev = true; }
+        else { qPos = repPos; tPos = tPos0; qRev = false; }
+        const int diagonal = (int) (short) qPos - (int) (short) tPos;
+        const bool canBeExtended = diagonal < 0 || (diagonal > (queryLen - tLen));
+        const bool cbc = canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) tLen);
+        const bool keep = (a.onlyExtendable == 0 && cbc) || (canBeExtended && a.onlyExtendable != 0);
+        a.outKeys[j] = keep ? packGroupKey(a, repId, id, (int) (short) diagonal, !qRev) : ~0ull;
+    }
+}
+
+struct U8toU32 { __host__ __device__ uint32_t operator()(const uint8_t &v) const { return v; } };
+struct NotDropped { __host__ __device__ bool operator()(const uint64_t &k) const { return k != ~0ull; } };
+
+// ------------------------------------------------------------------------------------------------ K4: vote
+struct VoteArgs {
+    const uint64_t *keys;   // sorted (rep, id, diag), strand in bit 0
+    uint64_t n;
+    uint32_t idBits, diagBits; int diagBias;
+    uint8_t *flag;          // 1 where a (rep, target != rep) segment starts
+    HitRec *hit;            // per segment start
+    unsigned long long *perRep;  // [nSeq] number of hits per representative
+};
+__global__ __launch_bounds__(256) void k_vote(VoteArgs a) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const uint64_t idMask = (1ull << a.idBits) - 1, diagMask = (1ull << a.diagBits) - 1;
+    const uint64_t key = a.keys[i];
+    const uint64_t seg = key >> (a.diagBits + 1);              // rep|id
+    a.flag[i] = 0;
+    if (i > 0 && (a.keys[i - 1] >> (a.diagBits + 1)) == seg) return;
+    const uint32_t target = (uint32_t) (seg & idMask), rep = (uint32_t) (seg >> a.idBits);
+    if (target == rep) return;                                  // self tuples (:898-903)
+    // the writer scans while the TARGET id stays the same, also across a change of representative (:875-887)
+    uint64_t kk = i; uint32_t prevDiag = (uint32_t) ((key >> 1) & diagMask), diagonal = prevDiag;
+    unsigned long long maxDiag = 0, diagCnt = 0, top = 0; int bestRev = (key & 1ull) ? 0 : 1;
+    for (; kk < a.n; kk++) {
+        const uint64_t k2 = a.keys[kk];
+        if ((uint32_t) ((k2 >> (a.diagBits + 1)) & idMask) != target) break;
+        const uint32_t d = (uint32_t) ((k2 >> 1) & diagMask);
+        if (prevDiag == d) diagCnt++; else diagCnt = 1;
+        if (diagCnt >= maxDiag) { diagonal = d; maxDiag = diagCnt; bestRev = (k2 & 1ull) ? 0 : 1; }
+        prevDiag = d; top++;
+    }
+    HitRec h;
+    h.target = target;
+    h.score = bestRev ? -(int) top : (int) top;
+    h.diagonal = (int) (short) ((int) diagonal - a.diagBias);
+    a.hit[i] = h;
+    a.flag[i] = 1;
+    atomicAdd(&a.perRep[rep], 1ull);
+}
+__global__ void k_offsets(const unsigned long long *__restrict__ perRepScan, uint32_t n, uint64_t *__restrict__ off) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q <= n) off[q] = (uint64_t) q + perRepScan[q];        // one self hit per sequence in front of its own hits
+}
+__global__ void k_self(const uint64_t *__restrict__ off, uint32_t n, HitRec *__restrict__ out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    HitRec h; h.target = q; h.score = 0; h.diagonal = 0;
+    out[off[q]] = h;
+}
+__global__ __launch_bounds__(256) void k_place(VoteArgs a, const uint32_t *__restrict__ rank, const unsigned long long *__restrict__ perRepScan,
+                                               const uint64_t *__restrict__ off, HitRec *__restrict__ out) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n || !a.flag[i]) return;
+    const uint32_t rep = (uint32_t) (a.keys[i] >> (a.diagBits + 1 + a.idBits));
+    out[off[rep] + 1 + ((uint64_t) rank[i] - perRepScan[rep])] = a.hit[i];
+}
+__global__ void k_classify(const uint32_t *__restrict__ len, uint32_t n, int k, uint32_t shortCap, uint32_t *__restrict__ listShort,
+                           uint32_t *__restrict__ listLong, unsigned int *__restrict__ cnt, uint32_t longCap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t L = len[i];
+    const uint32_t nk = (L >= (uint32_t) k) ? (L - k + 1) : 0;
+    if (nk < shortCap) listShort[atomicAdd(&cnt[0], 1u)] = i;
+    else if (nk < longCap) listLong[atomicAdd(&cnt[1], 1u)] = i;
+    else atomicAdd(&cnt[2], 1u);
+}
+__global__ void k_count_kmers(const uint32_t *__restrict__ len, uint32_t n, int k, int kmersPerSeq, float scale, unsigned long long *__restrict__ total) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (i < n) {   // computeKmerCount kmermatcher.cpp:573-582
+        const int L = (int) len[i];
+        const int adj = max(1, L - k + 2);
+        v = (unsigned long long) min(adj, static_cast<int>(kmersPerSeq + (scale * L)));
+    }
+    // wave reduce then one atomic
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    bool alloc(size_t n) { return hipMalloc(&p, (n + 1) * sizeof(T)) == hipSuccess; }
+};
+inline uint32_t bitsFor(uint64_t v) { uint32_t b = 1; while ((1ull << b) < v) b++; return b; }
+
+}  // namespace
+
+int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t) db->n;
+    const int k = par->kmer_size;
+    if (k < 4 || k > 31) { cdm_set_error("cdm_kmermatch: k must be in 4..31 (got %d)", k); return CDM_ERR_INVALID; }
+    if (db->maxLen + 2 >= 32767u) { cdm_set_error("cdm_kmermatch: sequences of 32765 letters or more (the reference's `int` position path) are not implemented on the device yet"); return CDM_ERR_UNSUPPORTED; }
+    constexpr uint32_t SHORT_CAP = 256, LONG_CAP = 4096;
+    const uint32_t idBits = bitsFor(n), diagBits = bitsFor(2ull * db->maxLen + 2);
+    if (2 * idBits + diagBits + 1 > 64) { cdm_set_error("cdm_kmermatch: %u sequences x max length %u do not fit the 64-bit (rep,id,diagonal) sort key", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
+    const int diagBias = (int) db->maxLen + 1;
+
+    DevBuf<unsigned long long> counters;      // [0] tuple capacity, [1] tuples written, [2..] scratch
+    DevBuf<unsigned int> cls;                 // classify counters + error flag
+    DevBuf<uint32_t> listShort, listLong;
+    if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    hipMemsetAsync(counters.p, 0, 8 * 8, s);
+    hipMemsetAsync(cls.p, 0, 8 * 4, s);
+    hipLaunchKernelGGL(k_count_kmers, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, k, par->kmers_per_seq, par->kmers_per_seq_scale, counters.p);
+    hipLaunchKernelGGL(k_classify, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, k, SHORT_CAP, listShort.p, listLong.p, cls.p, LONG_CAP);
+    unsigned long long hc[2]; unsigned int hcls[4];
+    hipMemcpyAsync(hc, counters.p, 16, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(hcls, cls.p, 16, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: counting kernels failed"); return CDM_ERR_HIP; }
+    if (hcls[2]) { cdm_set_error("cdm_kmermatch: %u sequences have %u k-mers or more; the per-sequence ordering of such sequences is not implemented on the device yet", hcls[2], LONG_CAP); return CDM_ERR_UNSUPPORTED; }
+    // upper bound of tuples: every k-mer position + the whole-sequence tuple (the reference's computeKmerCount bound is smaller
+    // for long sequences; we size for the positions because selection happens after extraction)
+    const uint64_t capacity = std::max<uint64_t>(hc[0], 1) + n + 16;
+
+    rocprim::double_buffer<uint64_t> keys, vals;
+    DevBuf<uint64_t> k0, k1, v0, v1;
+    if (!k0.alloc(capacity) || !k1.alloc(capacity) || !v0.alloc(capacity) || !v1.alloc(capacity)) {
+        cdm_set_error("cdm_kmermatch: out of device memory for %llu k-mer tuples (%.1f GB)", (unsigned long long) capacity, capacity * 32.0 / 1e9); return CDM_ERR_HIP;
+    }
+    ExtractArgs ea;
+    ea.woff = db->woff; ea.len = db->len; ea.codes = db->codes; ea.nmask = db->nmask; ea.hasN = db->hasN;
+    ea.k = k; ea.kmersPerSeq = par->kmers_per_seq; ea.scale = par->kmers_per_seq_scale; ea.seed = par->hash_shift; ea.ignoreMultiKmer = par->ignore_multi_kmer;
+    ea.keys = k0.p; ea.vals = v0.p; ea.count = counters.p + 1; ea.capacity = capacity; ea.err = cls.p + 3;
+    hipEventRecord(ctx->ev0, s);
+    if (hcls[0]) {
+        ea.list = listShort.p; ea.nList = hcls[0];
+        hipLaunchKernelGGL((k_extract<SHORT_CAP, 64>), dim3(std::min<uint32_t>(hcls[0], ctx->cuCount * 32)), dim3(64), 0, s, ea);
+    }
+    if (hcls[1]) {
+        ea.list = listLong.p; ea.nList = hcls[1];
+        hipLaunchKernelGGL((k_extract<LONG_CAP, 256>), dim3(std::min<uint32_t>(hcls[1], ctx->cuCount * 2)), dim3(256), 0, s, ea);
+    }
+    hipEventRecord(ctx->ev1, s);
+    unsigned long long nTuples = 0; unsigned int err = 0;
+    hipMemcpyAsync(&nTuples, counters.p + 1, 8, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(&err, cls.p + 3, 4, hipMemcpyDeviceToHost, s);
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    if (err) { cdm_set_error("cdm_kmermatch: k-mer tuple array overflow"); return CDM_ERR_HIP; }
+    hipEventElapsedTime(&ctx->lastMs[3], ctx->ev0, ctx->ev1);
+
+    // ---- sort 1: by k-mer (63 bits), stable
+    keys = rocprim::double_buffer<uint64_t>(k0.p, k1.p); vals = rocprim::double_buffer<uint64_t>(v0.p, v1.p);
+    size_t tmpBytes = 0;
+    rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) nTuples, 0, 63, s);
+    DevBuf<char> tmp1;
+    if (!tmp1.alloc(tmpBytes + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
+    hipEventRecord(ctx->ev0, s);
+    if (rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) nTuples, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
+    hipEventRecord(ctx->ev1, s);
+    // ---- K3
+    GroupArgs ga;
+    ga.keys = keys.current(); ga.vals = vals.current(); ga.n = nTuples; ga.onlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode;
+    ga.covThr = par->cov_thr; ga.outKeys = keys.alternate(); ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias;
+    if (nTuples) hipLaunchKernelGGL(k_groups, dim3((unsigned) ((nTuples + 255) / 256)), dim3(256), 0, s, ga);
+    // non-first tuples of a run are written by their run's first thread; runs of one write ~0 themselves
+    // compact the kept keys (stable) into vals.alternate() (free now)
+    uint64_t *gkeys = vals.alternate();
+    unsigned long long *dSel = counters.p + 2;
+    size_t selBytes = 0;
+    rocprim::select(nullptr, selBytes, ga.outKeys, gkeys, dSel, (size_t) nTuples, NotDropped(), s);
+    DevBuf<char> tmp2;
+    if (!tmp2.alloc(selBytes + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (select temp)"); return CDM_ERR_HIP; }
+    rocprim::select(tmp2.p, selBytes, ga.outKeys, gkeys, dSel, (size_t) nTuples, NotDropped(), s);
+    unsigned long long nGroup = 0;
+    hipMemcpyAsync(&nGroup, dSel, 8, hipMemcpyDeviceToHost, s);
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    float msSort1 = 0; hipEventElapsedTime(&msSort1, ctx->ev0, ctx->ev1);
+
+    // ---- sort 2: by (rep, id, diagonal) = key bits 1.., stable; strand bit 0 rides along
+    rocprim::double_buffer<uint64_t> g(gkeys, vals.current());
+    size_t tmpBytes2 = 0;
+    rocprim::radix_sort_keys(nullptr, tmpBytes2, g, (size_t) nGroup, 1, 2 * idBits + diagBits + 1, s);
+    DevBuf<char> tmp3;
+    if (!tmp3.alloc(tmpBytes2 + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
+    hipEventRecord(ctx->ev0, s);
+    if (rocprim::radix_sort_keys(tmp3.p, tmpBytes2, g, (size_t) nGroup, 1, 2 * idBits + diagBits + 1, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+    hipEventRecord(ctx->ev1, s);
+
+    // ---- K4
+    DevBuf<uint8_t> flag; DevBuf<HitRec> segHit; DevBuf<uint32_t> rank; DevBuf<unsigned long long> perRep, perRepScan;
+    if (!flag.alloc(nGroup) || !segHit.alloc(nGroup) || !rank.alloc(nGroup) || !perRep.alloc((size_t) n + 1) || !perRepScan.alloc((size_t) n + 1)) {
+        cdm_set_error("cdm_kmermatch: out of device memory (vote)"); return CDM_ERR_HIP;
+    }
+    if (nGroup >= 0x7FFFFFFFull) { cdm_set_error("cdm_kmermatch: more than 2^32 group tuples"); return CDM_ERR_UNSUPPORTED; }
+    hipMemsetAsync(perRep.p, 0, ((size_t) n + 1) * 8, s);
+    VoteArgs va;
+    va.keys = g.current(); va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.flag = flag.p; va.hit = segHit.p; va.perRep = perRep.p;
+    if (nGroup) hipLaunchKernelGGL(k_vote, dim3((unsigned) ((nGroup + 255) / 256)), dim3(256), 0, s, va);
+    size_t sb1 = 0, sb2 = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, sb1, perRep.p, perRepScan.p, (int) (n + 1), s);
+    hipcub::TransformInputIterator<uint32_t, U8toU32, uint8_t *> flagIt(flag.p, U8toU32());
+    hipcub::DeviceScan::ExclusiveSum(nullptr, sb2, flagIt, rank.p, (int) std::max<unsigned long long>(nGroup, 1), s);
+    DevBuf<char> tmp4;
+    if (!tmp4.alloc(std::max(sb1, sb2) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (scan temp)"); return CDM_ERR_HIP; }
+    hipcub::DeviceScan::ExclusiveSum(tmp4.p, sb1, perRep.p, perRepScan.p, (int) (n + 1), s);
+    if (nGroup) hipcub::DeviceScan::ExclusiveSum(tmp4.p, sb2, flagIt, rank.p, (int) nGroup, s);
+    cdm_hits *res = new cdm_hits(); res->n = n;
+    if (hipMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { delete res; cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    hipLaunchKernelGGL(k_offsets, dim3((n + 256) / 256), dim3(256), 0, s, perRepScan.p, n, res->off);
+    uint64_t total = 0;
+    hipMemcpyAsync(&total, res->off + n, 8, hipMemcpyDeviceToHost, s);
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: vote failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    res->count = total;
+    if (hipMalloc(&res->rec, (total + 1) * sizeof(HitRec)) != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    hipLaunchKernelGGL(k_self, dim3((n + 255) / 256), dim3(256), 0, s, res->off, n, res->rec);
+    if (nGroup) hipLaunchKernelGGL(k_place, dim3((unsigned) ((nGroup + 255) / 256)), dim3(256), 0, s, va, rank.p, perRepScan.p, res->off, res->rec);
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: placing hits failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    float msSort2 = 0; hipEventElapsedTime(&msSort2, ctx->ev0, ctx->ev1);
+    ctx->lastMs[2] = msSort1 + msSort2;
+    *out = res;
+    return CDM_OK;
+}

@@ -1,0 +1,59 @@
+"""GPU parity of kmermatcher: prefilter DB text identical to the oracle / the reference's goldens."""
+import numpy as np
+import pytest
+
+from carpedeam_amd import capi, mmdb
+from gpuutil import DATASETS, diff_keys, gold, run_oracle, stage_input
+from stageflags import K_FLAGS
+from test_oracle_golden import pref_sign_ties
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return capi.Ctx(0)
+
+
+def kmermatch_text(ctx, seq_keyed, par=None):
+    db = ctx.upload_keyed_seqdb(seq_keyed)
+    _, keys, _ = db.meta()
+    off, rec = ctx.kmermatch(db, par).download()
+    return {k: (v, 0) for k, v in capi.hits_to_text(off, rec, keys).items()}
+
+
+def strip_ext(db):
+    return {k: (v[0], 0) for k, v in db.items()}
+
+
+@pytest.mark.parametrize("name,its", DATASETS)
+def test_kmermatch_matches_oracle_and_golden(ctx, oracle_bin, tmp_path, name, its):
+    for it in range(its):
+        seq_keyed = stage_input(name, it)
+        got = kmermatch_text(ctx, seq_keyed)
+        t = lambda s: str(tmp_path / s)
+        mmdb.write_from_keyed(t("in"), seq_keyed, mmdb.DBTYPE_NUCLEOTIDES)
+        run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
+        # bit-exact against the oracle (same deterministic tie rule) ...
+        assert not diff_keys(got, strip_ext(mmdb.read_db(t("pref")))), (name, it)
+        # ... and against the reference's own output up to its run-dependent strand tie (N1)
+        ties, bad = pref_sign_ties(mmdb.canon(got), mmdb.canon(strip_ext(gold(name, "pref", it))))
+        assert not bad and sum(n for _, n in ties) <= 1, (name, it, bad[:5], ties)
+
+
+def test_kmermatch_N_repeats_and_contig_params(ctx, oracle_bin, tmp_path):
+    """N letters break k-mers; low-complexity reads exercise the repeated-k-mer skip; k=22 / include-only-extendable
+    are the contig-phase parameters."""
+    from carpedeam_amd import synth
+    rng = np.random.default_rng(3)
+    seqs = synth.generate_strings(1200, seed=4, mixed=(30, 150))
+    seqs = ["".join("N" if rng.random() < 0.01 else c for c in s) for s in seqs]
+    seqs += ["ACGTTGCA" * 12, "AC" * 50, "A" * 80, "ACGTACGTAC" * 9 + "GGGTTTAAACCC", "ACGTTGCA" * 12, "TTGCAACG" * 11, "ACG", ""]
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    for flags, par in ((K_FLAGS, capi.KmerParams.reads_default()),
+                       (" ".join(K_FLAGS).replace("-k 20", "-k 22").replace("--include-only-extendable 0", "--include-only-extendable 1").split(),
+                        capi.KmerParams(22, 200, 0.2, 67, 1, 1, 1, 0.0))):
+        run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *flags, "--threads", "4")
+        got = kmermatch_text(ctx, mmdb.read_db(t("in")), par)
+        assert not diff_keys(got, strip_ext(mmdb.read_db(t("pref"))))
