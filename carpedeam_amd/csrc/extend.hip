@@ -1,0 +1,423 @@
+// ancient_read_assemble on the device (safe mode, --unsafe 0).
+//
+// Replaces doNuclAssembly1 (src/assembler/ancientReadsResults.cpp:178-581).  One thread owns one query that has more than
+// one alignment record and runs the reference's per-query algorithm literally:
+//   A-C  end-overlap filter, identity recomputation on the corrected sequences, candidate gate          (:202-315)
+//   cons safe-mode consensus = N^L query N^L (nuclassembleUtil.cpp:586-592) -> the overlap columns are the alignment itself
+//   upd  updateSeqIdConsensusReads (nuclassembleUtil.cpp:377-500): ids over the non-N columns, longest overlap per side
+//   D    r_s_pair / calcLikelihoodConsensus (:48-70, nuclassembleUtil.cpp:203-374): per-column log-likelihoods from the
+//        host-built table, summed in software x87 extended precision in column order; excess penalty and random-alignment
+//        terms in float exactly as the reference's overload resolution computes them
+//   E    greedy extension with std::priority_queue order (libstdc++ binary heap: the tie order of equal scores matters),
+//        parked hits re-aligned on the grown query by diagonal (DistanceCalculator.h:115-175, mode 3), updateNuclAlignment
+//        (nuclassembleUtil.cpp:9-47), re-scored and re-queued                                              (:374-546)
+// The grown query is never materialised while the algorithm runs: it is a list of pieces (target, start, length) around
+// the original query, and a second kernel writes the packed output DB once all final lengths are known.
+//
+// Reverse-strand records can never pass the reference's end-overlap test, which is evaluated on the raw coordinates
+// where q_start > q_end encodes the strand (:204-213: rightStart needs q_end == qLen-1 < q_start, leftStart needs
+// q_start == 0 > q_end), so useReverse[] stays false and no fragment is ever reverse-complemented on this path.
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+
+#include "common.h"
+#include "devutil.h"
+
+namespace {
+
+struct Cand {
+    int qs, qe, ds, de;
+    uint32_t target, alnLen, dbLen, qLen;
+    float seqId, rySeqId;
+    double sLenNorm;
+    uint32_t pieceStart, pieceLen;   // set when the candidate donated a fragment
+};
+
+struct ExtArgs {
+    const uint32_t *woff, *len, *key, *codes, *nmask;
+    const uint8_t *ext, *hasN;
+    const uint64_t *aoff;
+    const AlnRec *rec;
+    const uint32_t *active; const unsigned int *nActive;
+    const DamageLut *lut;
+    Cand *cand;            // [alignment count]
+    uint32_t *lists;       // [4 * alignment count]: heap, parked, left pieces, right pieces (per-query slices)
+    uint32_t *newLen;      // [n] final length (0 = not extended)
+    uint32_t *nLeft, *nRight, *leftTotal;   // [n]
+    double *scores;        // optional [alignment count]
+    float seqIdThr, rySeqIdThr, likelihoodThr;
+    float excessLog, randLog;   // logf(excessPenal), logf(randAlnPenal) from the host
+    double ratioLogit;          // log(1/thr - 1): sRatio > thr  <=>  randAln - likMod < ratioLogit
+    uint64_t maxSeqLen;
+};
+
+// ---- the query as it grows: pieces to the left (most recent first), the original, pieces to the right
+struct VQuery {
+    const ExtArgs *a;
+    uint32_t q, qLen0, qw;
+    const Cand *cand; const uint32_t *leftL, *rightL;
+    uint32_t nL, nR, leftTotal, total;
+    bool anyN;
+    __device__ void baseAt(uint32_t p, uint32_t &code, bool &isN) const {
+        const ExtArgs &A = *a;
+        uint32_t t, tp;
+        if (p < leftTotal) {
+            uint32_t acc = 0; t = 0; tp = 0;
+            for (int i = (int) nL - 1; i >= 0; i--) { const Cand &c = cand[leftL[i]]; if (p < acc + c.pieceLen) { t = c.target; tp = c.pieceStart + (p - acc); break; } acc += c.pieceLen; }
+        } else if (p < leftTotal + qLen0) { t = q; tp = p - leftTotal; }
+        else {
+            uint32_t acc = leftTotal + qLen0; t = 0; tp = 0;
+            for (uint32_t i = 0; i < nR; i++) { const Cand &c = cand[rightL[i]]; if (p < acc + c.pieceLen) { t = c.target; tp = c.pieceStart + (p - acc); break; } acc += c.pieceLen; }
+        }
+        const uint32_t w = A.woff[t];
+        code = cdm_base(A.codes, w, tp);
+        isN = A.hasN[t] && cdm_isN(A.nmask, w, tp);
+    }
+};
+
+__device__ __forceinline__ void targetBaseAt(const ExtArgs &A, uint32_t t, uint32_t p, uint32_t &code, bool &isN) {
+    const uint32_t w = A.woff[t];
+    code = cdm_base(A.codes, w, p);
+    isN = A.hasN[t] && cdm_isN(A.nmask, w, p);
+}
+
+// updateSeqIdConsensusReads for one candidate on the current query (nuclassembleUtil.cpp:377-500, safe-mode consensus)
+__device__ void updateIds(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t &maxLeft, uint32_t &maxRight) {
+    const uint32_t qLen = Q.total;
+    const bool rightStart = (uint32_t) c.ds == 0 && (uint32_t) c.qe == (qLen - 1);
+    const bool leftStart = (uint32_t) c.qs == 0 && (uint32_t) c.de == (c.dbLen - 1);
+    int idCnt = 0, idRy = 0; uint32_t tot = 0;
+    if (leftStart || rightStart) {
+        // padded target against N^L query N^L: the columns where both are defined are the overlap itself
+        const uint32_t offset = c.dbLen - c.alnLen;
+        uint32_t q0, t0, ncol;
+        if (leftStart) { t0 = offset; q0 = 0; ncol = min(c.dbLen - offset, qLen); }
+        else { t0 = 0; q0 = qLen - c.alnLen; ncol = min(c.alnLen, c.dbLen); }
+        for (uint32_t i = 0; i < ncol; i++) {
+            uint32_t qc, tc; bool qn, tn;
+            Q.baseAt(q0 + i, qc, qn); targetBaseAt(A, c.target, t0 + i, tc, tn);
+            if (qn || tn) continue;
+            idCnt += (qc == tc); idRy += ((qc & 1u) == (tc & 1u)); tot++;
+        }
+    }
+    if (tot != 0) { c.seqId = static_cast<float>(idCnt) / tot; c.rySeqId = static_cast<float>(idRy) / tot; }
+    if (leftStart && tot > maxLeft) maxLeft = tot; else if (rightStart && tot > maxRight) maxRight = tot;
+}
+
+// calcLikelihoodConsensus via r_s_pair; returns sRatio > threshold, sets c.sLenNorm
+__device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t maxLeft, uint32_t maxRight, const double *logLik /* [11][4][4] fwd */) {
+    const uint32_t qLen = Q.total;
+    uint32_t maxAln = maxRight;
+    if ((uint32_t) c.qs == 0 && (uint32_t) c.de == (c.dbLen - 1)) maxAln = maxLeft;
+    const bool rightStart = (uint32_t) c.ds == 0 && (uint32_t) c.qe == (qLen - 1);
+    const bool leftStart = (uint32_t) c.qs == 0 && (uint32_t) c.de == (c.dbLen - 1);
+    X87 lik = x87_zero();
+    uint32_t alnCount = 0;
+    if (leftStart || rightStart) {
+        const uint32_t offset = c.dbLen - c.alnLen;
+        uint32_t q0, t0, ncol;
+        if (leftStart) { t0 = offset; q0 = 0; ncol = min(c.dbLen - offset, qLen); }
+        else { t0 = 0; q0 = qLen - c.alnLen; ncol = min(c.alnLen, c.dbLen); }
+        // tIdx counts the non-N target letters up to and including the column (pad letters are 'N'); before the overlap
+        // the left-start target contributes its own prefix t[0..offset)
+        uint32_t tIdx = 0;
+        if (leftStart) for (uint32_t j = 0; j < t0; j++) { uint32_t tc; bool tn; targetBaseAt(A, c.target, j, tc, tn); tIdx += !tn; }
+        for (uint32_t i = 0; i < ncol; i++) {
+            uint32_t qc, tc; bool qn, tn;
+            Q.baseAt(q0 + i, qc, qn); targetBaseAt(A, c.target, t0 + i, tc, tn);
+            if (!tn) tIdx++;
+            if (qn || tn) continue;
+            alnCount++;
+            const uint32_t ti = tIdx - 1;
+            const uint32_t cls = ti < 5 ? ti : (ti >= c.dbLen - 5 ? 6 + (ti - (c.dbLen - 5)) : 5);
+            lik = x87_add(lik, x87_from_double(logLik[(cls * 4 + qc) * 4 + tc]));
+        }
+    }
+    const uint32_t excess = maxAln - alnCount;
+    const float pen = (float) excess * A.excessLog;            // unsigned * float
+    lik = x87_add(lik, x87_from_double((double) pen));
+    const double randAln = (double) ((float) maxAln * A.randLog);
+    c.sLenNorm = x87_to_double(lik);
+    X87 neg = lik; neg.s ^= 1u;
+    const double x = x87_to_double(x87_add(x87_from_double(randAln), neg));   // randAln - likMod
+    return x < A.ratioLogit;
+}
+
+// ---- std::priority_queue<scorePerRes, vector, CompareNuclResultByScoreReads> on candidate indices (libstdc++ heap order)
+struct Heap {
+    uint32_t *h; uint32_t n; const Cand *cand;
+    __device__ bool less(uint32_t x, uint32_t y) const { return cand[x].sLenNorm < cand[y].sLenNorm; }
+    __device__ void siftUp(uint32_t hole, uint32_t top, uint32_t value) {
+        while (hole > top) { const uint32_t parent = (hole - 1) / 2; if (!less(h[parent], value)) break; h[hole] = h[parent]; hole = parent; }
+        h[hole] = value;
+    }
+    __device__ void push(uint32_t v) { n++; siftUp(n - 1, 0, v); }
+    __device__ uint32_t pop() {
+        const uint32_t topV = h[0];
+        const uint32_t len = n - 1;
+        if (len > 0) {
+            const uint32_t value = h[len];
+            uint32_t hole = 0, child = 0;
+            while (child < (len - 1) / 2) { child = 2 * (child + 1); if (less(h[child], h[child - 1])) child--; h[hole] = h[child]; hole = child; }
+            if ((len & 1u) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); h[hole] = h[child - 1]; hole = child - 1; }
+            siftUp(hole, 0, value);
+        }
+        n = len;
+        return topV;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_extend(ExtArgs A) {
+    __shared__ double sLogLik[11 * 16];
+    for (int i = threadIdx.x; i < 11 * 16; i += blockDim.x) sLogLik[i] = (&A.lut->logLik[0][0][0][0])[i];
+    __syncthreads();
+    const unsigned int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= *A.nActive) return;
+    const uint32_t q = A.active[item];
+    const uint64_t r0 = A.aoff[q], r1 = A.aoff[q + 1];
+    const uint32_t nRec = (uint32_t) (r1 - r0);
+    const uint32_t qLen0 = A.len[q], qKey = A.key[q];
+    Cand *cand = A.cand + r0;
+    uint32_t *heapL = A.lists + 4 * r0, *parkL = heapL + nRec, *leftL = parkL + nRec, *rightL = leftL + nRec;
+    VQuery Q; Q.a = &A; Q.q = q; Q.qLen0 = qLen0; Q.qw = A.woff[q]; Q.cand = cand; Q.leftL = leftL; Q.rightL = rightL;
+    Q.nL = 0; Q.nR = 0; Q.leftTotal = 0; Q.total = qLen0;
+
+    // ---- A-C: candidates ("notContig"), in record order
+    uint32_t nCand = 0;   // candidate k lives at cand[k] (compacted), keeping the record index for the score output
+    for (uint32_t r = 0; r < nRec; r++) {
+        const AlnRec rec = A.rec[r0 + r];
+        if (A.scores) A.scores[r0 + r] = NAN;
+        const uint32_t tLen = A.len[rec.target];
+        const uint32_t ds = (uint32_t) rec.dbStart, de = (uint32_t) rec.dbEnd, qs = (uint32_t) rec.qStart, qe = (uint32_t) rec.qEnd;
+        const bool rightStart = ds == 0 && qe == (qLen0 - 1);
+        const bool leftStart = qs == 0 && de == (tLen - 1);
+        if (!rightStart && !leftStart) continue;
+        if (rec.qStart > rec.qEnd) continue;   // cannot happen given the test above; reverse strand never extends
+        const uint32_t alnLen = (uint32_t) max(abs(rec.qEnd - rec.qStart), abs(rec.dbEnd - rec.dbStart)) + 1u;
+        float seqId = rec.seqId, rySeqId = 0.f;
+        if (rec.target != qKey) {   // the reference compares the target's *id* with the query's *key* (:264)
+            int idCnt = 0, idRy = 0;
+            for (int i = rec.qStart; i <= rec.qEnd; i++) {
+                uint32_t qc, tc; bool qn, tn;
+                Q.baseAt((uint32_t) i, qc, qn); targetBaseAt(A, rec.target, (uint32_t) (rec.dbStart + (i - rec.qStart)), tc, tn);
+                // letters are compared: N == N; N maps to purine (0) in ryMap
+                const uint32_t ql = qn ? 4u : qc, tl = tn ? 4u : tc;
+                idCnt += (ql == tl);
+                idRy += (((qn ? 0u : qc) & 1u) == ((tn ? 0u : tc) & 1u));
+            }
+            seqId = static_cast<float>(idCnt) / alnLen; rySeqId = static_cast<float>(idRy) / alnLen;
+        }
+        const bool noOffset = (tLen - alnLen) == 0;
+        if (A.ext[rec.target] == 0 && alnLen >= 30 && seqId >= A.seqIdThr && !noOffset) {
+            Cand c; c.qs = rec.qStart; c.qe = rec.qEnd; c.ds = rec.dbStart; c.de = rec.dbEnd; c.target = rec.target; c.alnLen = alnLen; c.dbLen = tLen;
+            c.qLen = qLen0; c.seqId = seqId; c.rySeqId = rySeqId; c.sLenNorm = 0; c.pieceStart = r; c.pieceLen = 0;   // pieceStart keeps the record index until used
+            cand[nCand++] = c;
+        }
+    }
+    if (nCand == 0) { A.newLen[q] = 0; return; }
+    uint32_t maxLeft = 0, maxRight = 0;
+    for (uint32_t k = 0; k < nCand; k++) updateIds(A, Q, cand[k], maxLeft, maxRight);
+    // ---- D
+    Heap heap; heap.h = heapL; heap.n = 0; heap.cand = cand;
+    for (uint32_t k = 0; k < nCand; k++) {
+        Cand &c = cand[k];
+        const bool notInside = c.dbLen != c.alnLen;
+        const bool rightStart = c.ds == 0, leftStart = c.qs == 0, notId = A.key[c.target] != qKey;
+        if ((rightStart || leftStart) && notInside && notId && c.rySeqId >= A.rySeqIdThr && c.seqId >= A.seqIdThr) {
+            const bool pass = scoreCand(A, Q, c, maxLeft, maxRight, sLogLik);
+            if (A.scores) A.scores[r0 + c.pieceStart] = c.sLenNorm;
+            if (pass) heap.push(k);
+        }
+    }
+    // ---- E
+    bool couldExtend = false;
+    while (heap.n > 0) {
+        uint32_t leftOff = 0, rightOff = 0, nPark = 0;
+        const uint32_t qLen = Q.total;
+        while (true) {
+            // selectNuclFragmentToExtendReads (:76-92)
+            bool found = false; uint32_t bi = 0;
+            while (heap.n > 0) {
+                const uint32_t k = heap.pop();
+                const Cand &c = cand[k];
+                const bool notBoth = !(c.ds == 0 && c.qs == 0);
+                const bool rightStart = c.ds == 0 && (c.de != static_cast<int>(c.dbLen) - 1);
+                const bool leftStart = c.qs == 0 && (c.qe != static_cast<int>(c.qLen) - 1);
+                if ((rightStart || leftStart) && notBoth && A.key[c.target] != qKey) { found = true; bi = k; break; }
+            }
+            if (!found) break;
+            Cand &b = cand[bi];
+            const uint32_t tLen = A.len[b.target];
+            if (b.ds == 0) { if ((tLen - (uint32_t) (b.de + 1)) <= rightOff) continue; }
+            else if (b.qs == 0) { if (b.ds <= static_cast<int>(leftOff)) continue; }
+            const uint32_t ds = (uint32_t) b.ds, de = (uint32_t) b.de, qs = (uint32_t) b.qs, qe = (uint32_t) b.qe;
+            if (ds == 0 && qe == (qLen - 1)) {
+                if (rightOff > 0) { parkL[nPark++] = bi; continue; }
+                const uint32_t fragLen = tLen - (de + 1);
+                if ((uint64_t) Q.total + fragLen >= A.maxSeqLen) break;
+                b.pieceStart = de + 1; b.pieceLen = fragLen;
+                rightL[Q.nR++] = bi; Q.total += fragLen; rightOff += fragLen;
+            } else if (qs == 0 && de == (tLen - 1)) {
+                if (leftOff > 0) { parkL[nPark++] = bi; continue; }
+                const uint32_t fragLen = ds;
+                if ((uint64_t) Q.total + fragLen >= A.maxSeqLen) break;
+                b.pieceStart = 0; b.pieceLen = fragLen;
+                leftL[Q.nL++] = bi; Q.leftTotal += fragLen; Q.total += fragLen; leftOff += fragLen;
+            }
+        }
+        if (leftOff > 0 || rightOff > 0) couldExtend = true;
+        if (heap.n > 0) break;
+        // ---- re-align the parked hits on the grown query (:484-509)
+        const uint32_t newLen = Q.total;
+        for (uint32_t i = 0; i < nPark; i++) {
+            Cand &c = cand[parkL[i]];
+            const uint32_t tLen = A.len[c.target];
+            const int diag = (c.qs + (int) leftOff) - c.ds;
+            const unsigned md = (unsigned) abs(diag);
+            // ungappedAlignmentByDiagonal, mode 3 (whole overlap, score clamped at 0)
+            uint32_t qOff = 0, tOff = 0, m = 0; int startPos = -1, endPos = -1; unsigned score = 0;
+            bool has = false;
+            if (diag >= 0 && md < newLen) { qOff = md; tOff = 0; m = min(tLen, newLen - md); has = true; }
+            else if (diag < 0 && md < tLen) { qOff = 0; tOff = md; m = min(tLen - md, newLen); has = true; }
+            if (has) {
+                long long sc = 0;
+                for (uint32_t j = 0; j < m; j++) {
+                    uint32_t qc, tc; bool qn, tn;
+                    Q.baseAt(qOff + j, qc, qn); targetBaseAt(A, c.target, tOff + j, tc, tn);
+                    sc += (!qn && !tn && qc == tc) ? 2 : -3;
+                }
+                score = sc > 0 ? (unsigned) sc : 0u; startPos = 0; endPos = (int) m - 1;
+            }
+            // updateNuclAlignment (nuclassembleUtil.cpp:9-47)
+            int qs2, qe2, ds2, de2; const int dist = (int) md;
+            if (diag >= 0) { qs2 = startPos + dist; qe2 = endPos + dist; ds2 = startPos; de2 = endPos; }
+            else { qs2 = startPos; qe2 = endPos; ds2 = startPos + dist; de2 = endPos + dist; }
+            int idCnt = 0;
+            for (int j = qs2; j < qe2; j++) {
+                uint32_t qc, tc; bool qn, tn;
+                Q.baseAt((uint32_t) j, qc, qn); targetBaseAt(A, c.target, (uint32_t) (ds2 + (j - qs2)), tc, tn);
+                idCnt += ((qn ? 4u : qc) == (tn ? 4u : tc));
+            }
+            c.seqId = static_cast<float>(idCnt) / (static_cast<float>(qe2) - static_cast<float>(qs2));
+            c.qLen = newLen; c.dbLen = tLen; c.alnLen = has ? m : 0;
+            (void) score;
+            c.qs = qs2; c.qe = qe2; c.ds = ds2; c.de = de2;
+        }
+        for (uint32_t i = 0; i < nPark; i++) updateIds(A, Q, cand[parkL[i]], maxLeft, maxRight);
+        for (uint32_t i = 0; i < nPark; i++) {
+            Cand &c = cand[parkL[i]];
+            const bool notInside = c.dbLen != c.alnLen;
+            const bool rightStart = c.ds == 0, leftStart = c.qs == 0, notId = A.key[c.target] != qKey;
+            if (c.seqId >= A.seqIdThr && (rightStart || leftStart) && notId && notInside) {
+                if (scoreCand(A, Q, c, maxLeft, maxRight, sLogLik)) heap.push(parkL[i]);
+            }
+        }
+    }
+    A.newLen[q] = couldExtend ? Q.total : 0;
+    A.nLeft[q] = Q.nL; A.nRight[q] = Q.nR; A.leftTotal[q] = Q.leftTotal;
+}
+
+__global__ void k_mark_active2(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t *__restrict__ active, unsigned int *__restrict__ nActive,
+                               uint32_t *__restrict__ newLen) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    newLen[q] = 0;
+    if (aoff[q + 1] - aoff[q] > 1) { unsigned int pos = atomicAdd(nActive, 1u); active[pos] = q; }
+}
+// output geometry: length, words, ext flag
+__global__ void k_out_meta(const uint32_t *__restrict__ len, const uint8_t *__restrict__ ext, const uint32_t *__restrict__ newLen, uint32_t n,
+                           uint32_t *__restrict__ oLen, uint8_t *__restrict__ oExt, uint32_t *__restrict__ oWords, unsigned long long *__restrict__ stats) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const uint32_t L = newLen[q] ? newLen[q] : len[q];
+    oLen[q] = L; oExt[q] = newLen[q] ? 1 : ext[q]; oWords[q] = (L + 15) / 16;
+    atomicAdd(&stats[0], (unsigned long long) L);
+    atomicMax(&stats[1], (unsigned long long) L);
+}
+// one thread per output word
+__global__ __launch_bounds__(256) void k_write(ExtArgs A, const uint32_t *__restrict__ oWoff, const uint32_t *__restrict__ oLen, uint32_t n, uint64_t words,
+                                               uint32_t *__restrict__ oCodes, uint32_t *__restrict__ oNmask, uint8_t *__restrict__ oHasN) {
+    const uint64_t gw = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (gw >= words) return;
+    uint64_t lo = 0, hi = n;
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (oWoff[mid] <= gw) lo = mid; else hi = mid; }
+    const uint32_t q = (uint32_t) lo, w = (uint32_t) (gw - oWoff[q]), L = oLen[q];
+    const uint32_t cnt = min(16u, L - min(L, w * 16u));
+    uint32_t code = 0, nb = 0;
+    if (A.newLen[q] == 0) {   // copy through (:564-581)
+        code = A.codes[A.woff[q] + w];
+        nb = reinterpret_cast<const uint16_t *>(A.nmask)[A.woff[q] + w];
+    } else {
+        const uint64_t r0 = A.aoff[q]; const uint32_t nRec = (uint32_t) (A.aoff[q + 1] - r0);
+        VQuery Q; Q.a = &A; Q.q = q; Q.qLen0 = A.len[q]; Q.qw = A.woff[q]; Q.cand = A.cand + r0;
+        Q.leftL = A.lists + 4 * r0 + 2 * (uint64_t) nRec; Q.rightL = Q.leftL + nRec; Q.nL = A.nLeft[q]; Q.nR = A.nRight[q]; Q.leftTotal = A.leftTotal[q]; Q.total = L;
+        for (uint32_t j = 0; j < cnt; j++) { uint32_t c; bool isN; Q.baseAt(w * 16 + j, c, isN); if (isN) { nb |= 1u << j; c = 0; } code |= c << (2 * j); }
+    }
+    oCodes[gw] = code;
+    reinterpret_cast<uint16_t *>(oNmask)[gw] = (uint16_t) nb;
+    if (nb) oHasN[q] = 1;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    bool alloc(size_t n) { return hipMalloc(&p, (n + 1) * sizeof(T)) == hipSuccess; }
+};
+
+}  // namespace
+
+int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out, double *scores) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t) db->n;
+    if (alns->n != db->n) { cdm_set_error("cdm_extend: alignment CSR / DB size mismatch"); return CDM_ERR_INVALID; }
+    DevBuf<uint32_t> active, lists, newLen, nLeft, nRight, leftTotal, oWords;
+    DevBuf<unsigned int> nActive; DevBuf<Cand> cand; DevBuf<double> dScores; DevBuf<unsigned long long> stats;
+    if (!active.alloc(n) || !lists.alloc(4 * alns->count) || !newLen.alloc(n) || !nLeft.alloc(n) || !nRight.alloc(n) || !leftTotal.alloc(n) ||
+        !oWords.alloc(n) || !nActive.alloc(2) || !cand.alloc(alns->count) || !stats.alloc(2) || (scores && !dScores.alloc(alns->count))) {
+        cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP;
+    }
+    hipMemsetAsync(nActive.p, 0, 8, s);
+    hipMemsetAsync(stats.p, 0, 16, s);
+    hipLaunchKernelGGL(k_mark_active2, dim3((n + 255) / 256), dim3(256), 0, s, alns->off, n, active.p, nActive.p, newLen.p);
+    unsigned int hAct = 0;
+    hipMemcpyAsync(&hAct, nActive.p, 4, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_extend: setup failed"); return CDM_ERR_HIP; }
+    ExtArgs A;
+    A.woff = db->woff; A.len = db->len; A.key = db->key; A.codes = db->codes; A.nmask = db->nmask; A.ext = db->ext; A.hasN = db->hasN;
+    A.aoff = alns->off; A.rec = alns->rec; A.active = active.p; A.nActive = nActive.p; A.lut = ctx->lutDev; A.cand = cand.p; A.lists = lists.p;
+    A.newLen = newLen.p; A.nLeft = nLeft.p; A.nRight = nRight.p; A.leftTotal = leftTotal.p; A.scores = scores ? dScores.p : nullptr;
+    A.seqIdThr = par->seq_id_thr; A.rySeqIdThr = par->ry_seq_id_thr; A.likelihoodThr = par->likelihood_threshold;
+    A.excessLog = std::log(par->excess_penal); A.randLog = std::log(par->rand_align_penal);   // std::log(float): float, as in the reference
+    A.ratioLogit = (double) logl(1.0L / (long double) par->likelihood_threshold - 1.0L);
+    A.maxSeqLen = par->max_seq_len;
+    hipEventRecord(ctx->ev0, s);
+    if (hAct) hipLaunchKernelGGL(k_extend, dim3((hAct + 63) / 64), dim3(64), 0, s, A);
+    hipEventRecord(ctx->ev1, s);
+    // ---- output DB
+    cdm_seqdb *o = nullptr;
+    int rc = cdm_seqdb_alloc(ctx, n, &o);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_out_meta, dim3((n + 255) / 256), dim3(256), 0, s, db->len, db->ext, newLen.p, n, o->len, o->ext, oWords.p, stats.p);
+    size_t sb = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, sb, oWords.p, o->woff, (int) (n + 1), s);
+    DevBuf<char> tmp;
+    if (!tmp.alloc(sb + 256)) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP; }
+    hipMemsetAsync(oWords.p + n, 0, 4, s);
+    hipcub::DeviceScan::ExclusiveSum(tmp.p, sb, oWords.p, o->woff, (int) (n + 1), s);
+    uint32_t words = 0; unsigned long long hstats[2] = {0, 0};
+    hipMemcpyAsync(&words, o->woff + n, 4, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(hstats, stats.p, 16, hipMemcpyDeviceToHost, s);
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: extension kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    hipEventElapsedTime(&ctx->lastMs[4], ctx->ev0, ctx->ev1);
+    o->words = words; o->residues = hstats[0]; o->maxLen = (uint32_t) hstats[1];
+    const uint64_t maskWords = ((uint64_t) words * 16 + 31) / 32 + 1;
+    if (hipMalloc(&o->codes, ((size_t) words + 2) * 4) != hipSuccess || hipMalloc(&o->nmask, maskWords * 4) != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP; }
+    hipMemcpyAsync(o->key, db->key, (size_t) n * 4, hipMemcpyDeviceToDevice, s);
+    hipMemsetAsync(o->hasN, 0, n, s);
+    if (words) hipLaunchKernelGGL(k_write, dim3((unsigned) (((uint64_t) words + 255) / 256)), dim3(256), 0, s, A, o->woff, o->len, n, (uint64_t) words, o->codes, o->nmask, o->hasN);
+    if (scores) hipMemcpyAsync(scores, dScores.p, alns->count * 8, hipMemcpyDeviceToHost, s);
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: output kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    *out = o;
+    return CDM_OK;
+}

@@ -1,4 +1,3 @@
 // Stages not implemented yet fail loudly (no CPU fallback).
 #include "common.h"
-int cdm_extend_impl(cdm_ctx *, const cdm_seqdb *, const cdm_alns *, const cdm_ancient_params *, cdm_seqdb **, double *) { cdm_set_error("cdm_extend: not implemented yet"); return CDM_ERR_UNSUPPORTED; }
 int cdm_synth_impl(cdm_ctx *, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t, uint64_t, cdm_seqdb **) { cdm_set_error("cdm_seqdb_synth: not implemented yet"); return CDM_ERR_UNSUPPORTED; }

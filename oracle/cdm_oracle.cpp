@@ -597,6 +597,7 @@ static int doAssemble(const std::string &seqPath, const std::string &alnPath, co
     std::vector<uint8_t> wasExtended(seq.size(), 0);
     std::vector<DiNuc> D, Drev; initDeam(par.damage + "5p.prof", par.damage + "3p.prof", D, Drev);
     DiNuc seqErr; seqErrProf(seqErr, 0.001L);
+    FILE *scoreLog = getenv("ORACLE_SCORES") ? fopen(getenv("ORACLE_SCORES"), "w") : NULL;
 #pragma omp parallel num_threads(par.threads)
     {
         std::vector<Aln> alns, notContig, tmpAl;
@@ -662,6 +663,10 @@ static int doAssemble(const std::string &seqPath, const std::string &alnPath, co
                 const bool rightStart = a.dbStartPos == 0, leftStart = a.qStartPos == 0, notId = (a.dbKey != qKey);
                 if ((rightStart || leftStart) && notInside && notId && a.rySeqId >= par.rySeqIdThr && a.seqId >= par.seqIdThr) {
                     Scored s = rsPair(a, cons, ts, qLen, D, Drev, maxLeft, maxRight, par.randAlnPenal, seqErr, par.excessPenal);
+                    if (scoreLog) {  // test hook: first-round likelihood scores, which the module itself never prints
+#pragma omp critical
+                        fprintf(scoreLog, "%u\t%u\t%a\t%a\n", qKey, a.dbKey, s.sLenNorm, s.sRatio);
+                    }
                     if (getenv("ORACLE_TRACE") && (uint32_t) atoi(getenv("ORACLE_TRACE")) == qKey) fprintf(stderr, "D cand %u q[%d,%d] t[%d,%d] sid %.4f ry %.4f sLen %.6f ratio %.6f maxL %u maxR %u\n", a.dbKey, a.qStartPos, a.qEndPos, a.dbStartPos, a.dbEndPos, a.seqId, a.rySeqId, s.sLenNorm, s.sRatio, maxLeft, maxRight);
                     if (s.sRatio > par.likelihoodThreshold) queue.push(s);
                 }
@@ -723,6 +728,7 @@ static int doAssemble(const std::string &seqPath, const std::string &alnPath, co
             if (couldExtend) { query.push_back('\n'); wasExtended[id] |= 0x20; out.set(id, qKey, query, 1); }
         }
     }
+    if (scoreLog) fclose(scoreLog);
     for (size_t id = 0; id < seq.size(); id++)  // :564-581
         if (!(wasExtended[id] & 0x20)) out.set(id, seq.key[id], std::string(seq.getData(id), seq.len[id] - 1), seq.ext[id]);
     out.write(outPath, seq.dbtype);

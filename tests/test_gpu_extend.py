@@ -1,0 +1,83 @@
+"""GPU parity of ancient_read_assemble: extended sequences identical to oracle/goldens, likelihood scores bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from carpedeam_amd import capi, mmdb
+from gpuutil import DATASETS, diff_keys, gold, run_oracle, seqdb_to_keyed
+from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(dhigh_prefix):
+    c = capi.Ctx(0)
+    c.damage_load(dhigh_prefix)
+    return c
+
+
+def extend(ctx, corr_keyed, aln_keyed, want_scores=False):
+    db = ctx.upload_keyed_seqdb(corr_keyed)
+    _, keys, _ = db.meta()
+    off, rec = capi.parse_aln_db(aln_keyed, keys)
+    res = ctx.extend(db, ctx.upload_alns(db, off, rec), want_scores=want_scores)
+    if want_scores:
+        out, scores = res
+        return seqdb_to_keyed(*out.download()), (off, rec, keys, scores)
+    return seqdb_to_keyed(*res.download())
+
+
+@pytest.mark.parametrize("name,its", DATASETS)
+def test_extension_matches_golden_and_scores_match_oracle(ctx, oracle_bin, dhigh_prefix, tmp_path, name, its):
+    for it in range(its):
+        corr, aln = gold(name, "corr", it), gold(name, "aln", it)
+        got, (off, rec, keys, scores) = extend(ctx, corr, aln, want_scores=True)
+        assert not diff_keys(got, gold(name, "asm", it)), (name, it)
+        # likelihood scores of the first scoring round: the oracle logs them (the module never prints them)
+        t = lambda s: str(tmp_path / s)
+        mmdb.write_from_keyed(t("corr"), corr, mmdb.DBTYPE_NUCLEOTIDES)
+        mmdb.write_from_keyed(t("aln"), aln, mmdb.DBTYPE_ALIGNMENT_RES)
+        os.environ["ORACLE_SCORES"] = t("scores.tsv")
+        try:
+            run_oracle(oracle_bin, "ancient_read_assemble", t("corr"), t("aln"), t("asm"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "2")
+        finally:
+            del os.environ["ORACLE_SCORES"]
+        exp = {}
+        for line in open(t("scores.tsv")):
+            q, tk, s, _ = line.split("\t")
+            exp[(int(q), int(tk))] = float.fromhex(s)
+        got_scores = {}
+        for i, k in enumerate(keys):
+            for r in range(int(off[i]), int(off[i + 1])):
+                if not np.isnan(scores[r]):
+                    got_scores[(int(k), int(keys[rec[r]["target"]]))] = float(scores[r])
+        assert set(got_scores) == set(exp), (name, it, len(got_scores), len(exp))
+        assert len(exp) > 100
+        bad = [k for k in exp if got_scores[k] != exp[k]]          # bit-exact (tolerance of the north star: 1e-6 relative)
+        assert not bad, (name, it, bad[:3], [(got_scores[k], exp[k]) for k in bad[:3]])
+
+
+def test_extension_with_N_and_max_seq_len(ctx, oracle_bin, dhigh_prefix, tmp_path):
+    from carpedeam_amd import synth
+    rng = np.random.default_rng(21)
+    seqs = synth.generate_strings(1500, seed=13, mixed=(40, 150))
+    seqs = ["".join("N" if rng.random() < 0.004 else c for c in s) for s in seqs]
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
+    run_oracle(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref"), t("aln"), *R_FLAGS, "--threads", "4")
+    run_oracle(oracle_bin, "ancient_correction", t("in"), t("aln"), t("corr"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "4")
+    for max_len in (200000, 230):
+        flags = " ".join(A_FLAGS).replace("--max-seq-len 200000", "--max-seq-len %d" % max_len).split()
+        run_oracle(oracle_bin, "ancient_read_assemble", t("corr"), t("aln"), t("asm"), *flags, "--ancient-damage", dhigh_prefix, "--threads", "4")
+        db = ctx.upload_keyed_seqdb(mmdb.read_db(t("corr")))
+        _, keys, _ = db.meta()
+        off, rec = capi.parse_aln_db(mmdb.read_db(t("aln")), keys)
+        par = capi.AncientParams.default()
+        par.max_seq_len = max_len
+        got = seqdb_to_keyed(*ctx.extend(db, ctx.upload_alns(db, off, rec), par).download())
+        exp = mmdb.read_db(t("asm"))
+        assert not diff_keys(got, exp), max_len
+        assert sum(v[1] for v in exp.values()) > 50
