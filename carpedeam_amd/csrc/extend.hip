@@ -379,6 +379,7 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     }
     hipMemsetAsync(nActive.p, 0, 8, s);
     hipMemsetAsync(stats.p, 0, 16, s);
+    if (scores) hipMemsetAsync(dScores.p, 0xFF, alns->count * 8, s);   // all-ones = NaN: records of inactive queries
     hipLaunchKernelGGL(k_mark_active2, dim3((n + 255) / 256), dim3(256), 0, s, alns->off, n, active.p, nActive.p, newLen.p);
     unsigned int hAct = 0;
     hipMemcpyAsync(&hAct, nActive.p, 4, hipMemcpyDeviceToHost, s);
