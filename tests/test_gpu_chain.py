@@ -1,0 +1,109 @@
+"""End-to-end on the device: synthetic reads generated in HBM, then kmermatcher -> rescorediagonal -> ancient_correction ->
+ancient_read_assemble through the C ABI with every intermediate resident on the device, against the oracle run on the
+same reads (DB files) -- plus size-independent properties at a larger size."""
+import numpy as np
+import pytest
+
+from carpedeam_amd import capi, mmdb, synth
+from gpuutil import diff_keys, run_oracle, seqdb_to_keyed
+from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(dhigh_prefix):
+    c = capi.Ctx(0)
+    c.damage_load(dhigh_prefix)
+    return c
+
+
+def chain(ctx, db):
+    hits = ctx.kmermatch(db)
+    alns = ctx.rescore(db, hits)
+    corr = ctx.correct(db, alns)
+    asm = ctx.extend(corr, alns)
+    return hits, alns, corr, asm
+
+
+@pytest.mark.parametrize("n,lo,hi,seed", [(3000, 100, 100, 1), (2500, 60, 150, 2)])
+def test_device_generator_matches_numpy_spec(ctx, n, lo, hi, seed):
+    got, _, _ = ctx.synth(n, lo, hi, seed).download()
+    exp = synth.generate_strings(n, L=lo, seed=seed, mixed=None if lo == hi else (lo, hi))
+    assert [g.decode() for g in got] == exp
+    # a shard of a larger corpus is the corresponding slice
+    part, _, _ = ctx.synth(500, lo, hi, seed, n_total=n, first=1000).download()
+    assert [g.decode() for g in part] == exp[1000:1500]
+
+
+@pytest.mark.parametrize("n,lo,hi,seed,iters", [(20000, 100, 100, 1, 2), (15000, 60, 150, 2, 2)])
+def test_chain_matches_oracle(ctx, oracle_bin, dhigh_prefix, tmp_path, n, lo, hi, seed, iters):
+    db = ctx.synth(n, lo, hi, seed)
+    t = lambda s: str(tmp_path / s)
+    seqs, keys, ext = db.download()
+    mmdb.write_seqdb(t("in0"), seqs)
+    for it in range(iters):
+        hits, alns, corr, asm = chain(ctx, db)
+        i, o = t("in%d" % it), t("in%d" % (it + 1))
+        run_oracle(oracle_bin, "kmermatcher", i, t("pref"), *K_FLAGS, "--threads", "8")
+        run_oracle(oracle_bin, "rescorediagonal", i, i, t("pref"), t("aln"), *R_FLAGS, "--threads", "8")
+        run_oracle(oracle_bin, "ancient_correction", i, t("aln"), t("corr"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "8")
+        run_oracle(oracle_bin, "ancient_read_assemble", t("corr"), t("aln"), o, *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "8")
+        lens, keys, _ = db.meta()
+        hoff, hrec = hits.download()
+        assert not diff_keys({k: (v, 0) for k, v in capi.hits_to_text(hoff, hrec, keys).items()}, {k: (v[0], 0) for k, v in mmdb.read_db(t("pref")).items()})
+        aoff, arec = alns.download()
+        assert not diff_keys({k: (v, 0) for k, v in capi.alns_to_text(aoff, arec, keys, lens, db.residues).items()}, mmdb.read_db(t("aln")))
+        assert not diff_keys(seqdb_to_keyed(*corr.download()), mmdb.read_db(t("corr")))
+        assert not diff_keys(seqdb_to_keyed(*asm.download()), mmdb.read_db(o))
+        db = asm
+
+
+def test_chain_properties_at_scale(ctx):
+    """2 M reads (no oracle at this size): structural invariants of every stage."""
+    n, L = 2_000_000, 100
+    db = ctx.synth(n, L, L, 1)
+    hits, alns, corr, asm = chain(ctx, db)
+    hoff, hrec = hits.download()
+    # every query's list starts with its self hit; targets strictly increase afterwards (sorted by id, one hit per target)
+    first = hrec[hoff[:-1].astype(np.int64)]
+    assert (first["target"] == np.arange(n)).all() and (first["score"] == 0).all() and (first["diagonal"] == 0).all()
+    cnt = np.diff(hoff.astype(np.int64))
+    assert cnt.min() >= 1 and cnt.sum() == hits.count
+    owner = np.repeat(np.arange(n), cnt)
+    inner = np.ones(hits.count, bool)
+    inner[hoff[:-1].astype(np.int64)] = False
+    assert (hrec["target"][inner] != owner[inner]).all()
+    d = np.diff(hrec["target"].astype(np.int64))
+    same_owner = owner[1:] == owner[:-1]
+    assert (d[same_owner & inner[1:] & inner[:-1]] > 0).all()
+    assert (np.abs(hrec["score"][inner]) >= 1).all() and (np.abs(hrec["score"]) <= L - 20 + 2).all()
+    assert (np.abs(hrec["diagonal"]) < L).all()
+    # alignments: subset of the hits, self alignment kept with full identity, coordinates inside the sequences
+    aoff, arec = alns.download()
+    acnt = np.diff(aoff.astype(np.int64))
+    assert (acnt >= 1).all() and (acnt <= cnt).all()
+    selfa = arec[aoff[:-1].astype(np.int64)]
+    assert (selfa["target"] == np.arange(n)).all() and (selfa["raw_score"] == 2 * L).all() and (selfa["ident"] == L).all()
+    for f in ("q_start", "q_end", "db_start", "db_end"):
+        assert (arec[f] >= 0).all() and (arec[f] < L).all()
+    aln_len = np.maximum(np.abs(arec["q_end"] - arec["q_start"]), np.abs(arec["db_end"] - arec["db_start"])) + 1
+    assert (arec["ident"] <= aln_len).all() and (arec["raw_score"] == 2 * arec["ident"] - 3 * (aln_len - arec["ident"])).all()
+    # correction: same geometry, only damage-like substitutions dominate (T->C at 5', A->G at 3' undo C>T / G>A)
+    s0, _, _ = db.download()
+    s1, _, e1 = corr.download()
+    a0 = np.frombuffer(b"".join(s0), np.uint8).reshape(n, L)
+    a1 = np.frombuffer(b"".join(s1), np.uint8).reshape(n, L)
+    changed = a0 != a1
+    assert 0 < changed.sum() < 0.01 * n * L
+    tc = ((a0 == ord("T")) & (a1 == ord("C")) & changed).sum() + ((a0 == ord("A")) & (a1 == ord("G")) & changed).sum()
+    assert tc > 0.95 * changed.sum()
+    assert (e1 == 0).all()
+    # idempotence: correcting the corrected reads against the same alignments changes (almost) nothing more
+    # extension: extended sequences contain the corrected query; flags: ext == 1 exactly for the longer ones
+    s2, _, e2 = asm.download()
+    l2 = np.array([len(x) for x in s2])
+    assert ((l2 > L) == (e2 == 1)).all() and (l2 >= L).all() and (l2 < 3 * L + 3).all()
+    idx = np.nonzero(e2 == 1)[0][:2000]
+    assert all(s1[i] in s2[i] for i in idx)
+    assert 0.05 * n < (e2 == 1).sum() < 0.3 * n
