@@ -14,6 +14,54 @@ void cdm_set_error(const char *fmt, ...) {
 }
 extern "C" const char *cdm_last_error(void) { return g_err; }
 
+// ------------------------------------------------------------------------------------------------ caching allocator
+#include <map>
+#include <mutex>
+#include <unordered_map>
+namespace {
+struct Pool {
+    std::mutex m;
+    std::multimap<size_t, void *> freeBlocks;
+    std::unordered_map<void *, size_t> sizes;
+};
+Pool &poolOf(int dev) { static Pool pools[64]; return pools[dev & 63]; }
+}  // namespace
+hipError_t cdmMallocRaw(void **p, size_t bytes) {
+    int dev = 0; hipGetDevice(&dev);
+    Pool &pool = poolOf(dev);
+    bytes = (bytes + 255) & ~(size_t) 255;
+    if (bytes == 0) bytes = 256;
+    {
+        std::lock_guard<std::mutex> g(pool.m);
+        auto it = pool.freeBlocks.lower_bound(bytes);
+        if (it != pool.freeBlocks.end() && it->first <= bytes + bytes / 8) { *p = it->second; pool.freeBlocks.erase(it); return hipSuccess; }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {   // out of memory with blocks parked in the cache: release them and retry once
+        (void) hipGetLastError();
+        cdmPoolTrim();
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> g(pool.m); pool.sizes[*p] = bytes; }
+    return e;
+}
+void cdmFree(void *p) {
+    if (!p) return;
+    int dev = 0; hipGetDevice(&dev);
+    Pool &pool = poolOf(dev);
+    std::lock_guard<std::mutex> g(pool.m);
+    auto it = pool.sizes.find(p);
+    if (it == pool.sizes.end()) { hipFree(p); return; }
+    pool.freeBlocks.emplace(it->second, p);
+}
+void cdmPoolTrim() {
+    int dev = 0; hipGetDevice(&dev);
+    Pool &pool = poolOf(dev);
+    std::lock_guard<std::mutex> g(pool.m);
+    for (auto &kv : pool.freeBlocks) { pool.sizes.erase(kv.second); hipFree(kv.second); }
+    pool.freeBlocks.clear();
+}
+
 // ------------------------------------------------------------------------------------------------ context
 extern "C" int cdm_ctx_create(int device, cdm_ctx **out) {
     if (!out) { cdm_set_error("cdm_ctx_create: out is NULL"); return CDM_ERR_INVALID; }
@@ -34,7 +82,7 @@ extern "C" int cdm_ctx_create(int device, cdm_ctx **out) {
     c->device = device;
     c->cuCount = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-        hipEventCreate(&c->ev1) != hipSuccess || hipMalloc(&c->lutDev, sizeof(DamageLut)) != hipSuccess) {
+        hipEventCreate(&c->ev1) != hipSuccess || cdmMalloc(&c->lutDev, sizeof(DamageLut)) != hipSuccess) {
         cdm_set_error("context resource creation failed"); delete c; return CDM_ERR_HIP;
     }
     *out = c;
@@ -46,7 +94,8 @@ extern "C" void cdm_ctx_destroy(cdm_ctx *c) {
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
-    if (c->lutDev) hipFree(c->lutDev);
+    if (c->lutDev) cdmFree(c->lutDev);
+    cdmPoolTrim();
     delete c;
 }
 extern "C" int cdm_ctx_sync(cdm_ctx *c) { CDM_HIP(hipSetDevice(c->device)); CDM_HIP(hipStreamSynchronize(c->stream)); return CDM_OK; }
@@ -75,9 +124,9 @@ extern "C" int cdm_bit_score(double raw) { return cdm_bit_score_host(raw); }
 int cdm_seqdb_alloc(cdm_ctx *ctx, uint64_t n, cdm_seqdb **out) {
     cdm_seqdb *db = new cdm_seqdb();
     db->n = n; db->device = ctx->device;
-    if (hipMalloc(&db->woff, (n + 1) * sizeof(uint32_t)) != hipSuccess || hipMalloc(&db->len, (n + 1) * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&db->key, (n + 1) * sizeof(uint32_t)) != hipSuccess || hipMalloc(&db->ext, n + 1) != hipSuccess ||
-        hipMalloc(&db->hasN, n + 1) != hipSuccess) {
+    if (cdmMalloc(&db->woff, (n + 1) * sizeof(uint32_t)) != hipSuccess || cdmMalloc(&db->len, (n + 1) * sizeof(uint32_t)) != hipSuccess ||
+        cdmMalloc(&db->key, (n + 1) * sizeof(uint32_t)) != hipSuccess || cdmMalloc(&db->ext, n + 1) != hipSuccess ||
+        cdmMalloc(&db->hasN, n + 1) != hipSuccess) {
         cdm_set_error("out of device memory allocating a %llu-entry sequence DB", (unsigned long long) n);
         cdm_seqdb_free(db); return CDM_ERR_HIP;
     }
@@ -87,7 +136,7 @@ int cdm_seqdb_alloc(cdm_ctx *ctx, uint64_t n, cdm_seqdb **out) {
 static int seqdb_alloc_codes(cdm_seqdb *db, uint64_t words) {
     db->words = words;
     uint64_t maskWords = (words * 16 + 31) / 32 + 1;
-    if (hipMalloc(&db->codes, (words + 2) * sizeof(uint32_t)) != hipSuccess || hipMalloc(&db->nmask, maskWords * sizeof(uint32_t)) != hipSuccess) {
+    if (cdmMalloc(&db->codes, (words + 2) * sizeof(uint32_t)) != hipSuccess || cdmMalloc(&db->nmask, maskWords * sizeof(uint32_t)) != hipSuccess) {
         cdm_set_error("out of device memory allocating %llu code words", (unsigned long long) words); return CDM_ERR_HIP;
     }
     return CDM_OK;
@@ -111,7 +160,7 @@ int cdm_seqdb_alloc_like(cdm_ctx *ctx, const cdm_seqdb *src, cdm_seqdb **out) {
 extern "C" void cdm_seqdb_free(cdm_seqdb *db) {
     if (!db) return;
     hipSetDevice(db->device);
-    hipFree(db->woff); hipFree(db->len); hipFree(db->key); hipFree(db->ext); hipFree(db->hasN); hipFree(db->codes); hipFree(db->nmask);
+    cdmFree(db->woff); cdmFree(db->len); cdmFree(db->key); cdmFree(db->ext); cdmFree(db->hasN); cdmFree(db->codes); cdmFree(db->nmask);
     delete db;
 }
 extern "C" uint64_t cdm_seqdb_size(const cdm_seqdb *db) { return db->n; }
@@ -181,7 +230,7 @@ extern "C" int cdm_seqdb_upload(cdm_ctx *ctx, const char *data, const uint64_t *
     for (uint64_t i = 0; i < n; i++) rel[i] = offsets[i] - lo;
     int ret = CDM_OK;
     do {
-        if (hipMalloc(&dData, hi - lo + 16) != hipSuccess || hipMalloc(&dOff, n * 8) != hipSuccess || hipMalloc(&dCnt, 16) != hipSuccess) {
+        if (cdmMalloc(&dData, hi - lo + 16) != hipSuccess || cdmMalloc(&dOff, n * 8) != hipSuccess || cdmMalloc(&dCnt, 16) != hipSuccess) {
             cdm_set_error("out of device memory staging %llu bytes of sequence text", (unsigned long long) (hi - lo)); ret = CDM_ERR_HIP; break;
         }
         hipMemsetAsync(dCnt, 0, 16, s);
@@ -206,7 +255,7 @@ extern "C" int cdm_seqdb_upload(cdm_ctx *ctx, const char *data, const uint64_t *
             ret = CDM_ERR_UNSUPPORTED; break;
         }
     } while (0);
-    hipFree(dData); hipFree(dOff); hipFree(dCnt);
+    cdmFree(dData); cdmFree(dOff); cdmFree(dCnt);
     if (ret != CDM_OK) { cdm_seqdb_free(db); return ret; }
     *out = db;
     return CDM_OK;
@@ -245,14 +294,14 @@ extern "C" int cdm_seqdb_download(cdm_ctx *ctx, const cdm_seqdb *db, char *out, 
     uint64_t total = 0;
     for (uint64_t i = 0; i < db->n; i++) total = std::max(total, outOffsets[i] + len[i] + 1);
     char *dOut = nullptr; uint64_t *dOff = nullptr;
-    if (hipMalloc(&dOut, total + 16) != hipSuccess || hipMalloc(&dOff, db->n * 8) != hipSuccess) { hipFree(dOut); cdm_set_error("out of device memory in cdm_seqdb_download"); return CDM_ERR_HIP; }
+    if (cdmMalloc(&dOut, total + 16) != hipSuccess || cdmMalloc(&dOff, db->n * 8) != hipSuccess) { cdmFree(dOut); cdm_set_error("out of device memory in cdm_seqdb_download"); return CDM_ERR_HIP; }
     hipMemsetAsync(dOut, 0, total, ctx->stream);
     hipMemcpyAsync(dOff, outOffsets, db->n * 8, hipMemcpyHostToDevice, ctx->stream);
     // zero-length sequences own no word: their '\n' is written by the host below
     if (db->words) hipLaunchKernelGGL(k_unpack, dim3((unsigned) ((db->words + 255) / 256)), dim3(256), 0, ctx->stream, db->codes, db->nmask, db->woff, db->len, dOff, db->n, db->words, dOut);
     hipMemcpyAsync(out, dOut, total, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    hipFree(dOut); hipFree(dOff);
+    cdmFree(dOut); cdmFree(dOff);
     if (e != hipSuccess) { cdm_set_error("cdm_seqdb_download failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
     for (uint64_t i = 0; i < db->n; i++) if (len[i] == 0) out[outOffsets[i]] = '\n';
     return CDM_OK;
@@ -267,8 +316,8 @@ static int csr_upload(cdm_ctx *ctx, uint64_t n, const uint64_t *offsets, const R
     CDM_HIP(hipSetDevice(ctx->device));
     for (uint64_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) { cdm_set_error("CSR offsets not monotone at %llu", (unsigned long long) i); return CDM_ERR_INVALID; }
     H *h = new H(); h->n = n; h->count = offsets[n];
-    if (hipMalloc(&h->off, (n + 1) * 8) != hipSuccess || hipMalloc(&h->rec, (h->count + 1) * sizeof(R)) != hipSuccess) {
-        cdm_set_error("out of device memory for %llu records", (unsigned long long) h->count); hipFree(h->off); hipFree(h->rec); delete h; return CDM_ERR_HIP;
+    if (cdmMalloc(&h->off, (n + 1) * 8) != hipSuccess || cdmMalloc(&h->rec, (h->count + 1) * sizeof(R)) != hipSuccess) {
+        cdm_set_error("out of device memory for %llu records", (unsigned long long) h->count); cdmFree(h->off); cdmFree(h->rec); delete h; return CDM_ERR_HIP;
     }
     CDM_HIP(hipMemcpyAsync(h->off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (h->count) CDM_HIP(hipMemcpyAsync(h->rec, recs, h->count * sizeof(R), hipMemcpyHostToDevice, ctx->stream));
@@ -288,7 +337,7 @@ extern "C" int cdm_hits_download(cdm_ctx *ctx, const cdm_hits *h, uint64_t *offs
     CDM_HIP(hipStreamSynchronize(ctx->stream));
     return CDM_OK;
 }
-extern "C" void cdm_hits_free(cdm_hits *h) { if (!h) return; hipFree(h->off); hipFree(h->rec); delete h; }
+extern "C" void cdm_hits_free(cdm_hits *h) { if (!h) return; cdmFree(h->off); cdmFree(h->rec); delete h; }
 
 extern "C" int cdm_alns_upload(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *offsets, const cdm_aln *alns, cdm_alns **out) {
     static_assert(sizeof(cdm_aln) == sizeof(AlnRec), "layout");
@@ -302,7 +351,7 @@ extern "C" int cdm_alns_download(cdm_ctx *ctx, const cdm_alns *a, uint64_t *offs
     CDM_HIP(hipStreamSynchronize(ctx->stream));
     return CDM_OK;
 }
-extern "C" void cdm_alns_free(cdm_alns *a) { if (!a) return; hipFree(a->off); hipFree(a->rec); delete a; }
+extern "C" void cdm_alns_free(cdm_alns *a) { if (!a) return; cdmFree(a->off); cdmFree(a->rec); delete a; }
 
 // ------------------------------------------------------------------------------------------------ stage wrappers
 extern "C" int cdm_correct(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out) {

@@ -11,6 +11,14 @@
 
 void cdm_set_error(const char *fmt, ...);
 
+// Caching device allocator (api.hip): hipMalloc/hipFree of multi-GB buffers cost tens of ms each, and every stage call
+// allocates its working set; freed blocks are kept per device and reused for later requests of (nearly) the same size.
+// All stage entry points synchronise their stream before they return, so a block is idle when it is handed back.
+hipError_t cdmMallocRaw(void **p, size_t bytes);
+void cdmFree(void *p);
+void cdmPoolTrim();   // give every cached block back to the driver
+template <typename T> inline hipError_t cdmMalloc(T **p, size_t bytes) { return cdmMallocRaw(reinterpret_cast<void **>(p), bytes); }
+
 #define CDM_HIP(expr)                                                                                   \
     do {                                                                                                \
         hipError_t _e = (expr);                                                                         \

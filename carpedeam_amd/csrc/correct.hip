@@ -237,13 +237,13 @@ extern "C" int cdm_debug_call_bases(cdm_ctx *ctx, const uint32_t *vectors, uint3
     if (!ctx->haveDamage) { cdm_set_error("cdm_debug_call_bases: no damage model"); return CDM_ERR_INVALID; }
     CDM_HIP(hipSetDevice(ctx->device));
     uint32_t *dv = nullptr; uint8_t *dout = nullptr;
-    CDM_HIP(hipMalloc(&dv, (size_t) n * 48 * 4));
-    CDM_HIP(hipMalloc(&dout, n));
+    CDM_HIP(cdmMalloc(&dv, (size_t) n * 48 * 4));
+    CDM_HIP(cdmMalloc(&dout, n));
     hipMemcpyAsync(dv, vectors, (size_t) n * 48 * 4, hipMemcpyHostToDevice, ctx->stream);
     hipLaunchKernelGGL(k_debug_call, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->lutDev, dv, n, dout);
     hipMemcpyAsync(out, dout, n, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    hipFree(dv); hipFree(dout);
+    cdmFree(dv); cdmFree(dout);
     if (e != hipSuccess) { cdm_set_error("debug kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
     return CDM_OK;
 }
@@ -252,8 +252,8 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t) db->n;
     uint32_t *active = nullptr; unsigned int *nActive = nullptr; uint8_t *accept = nullptr;
-    if (hipMalloc(&active, (size_t) n * 4) != hipSuccess || hipMalloc(&nActive, 8) != hipSuccess || hipMalloc(&accept, alns->count + 1) != hipSuccess) {
-        hipFree(active); hipFree(nActive); hipFree(accept);
+    if (cdmMalloc(&active, (size_t) n * 4) != hipSuccess || cdmMalloc(&nActive, 8) != hipSuccess || cdmMalloc(&accept, alns->count + 1) != hipSuccess) {
+        cdmFree(active); cdmFree(nActive); cdmFree(accept);
         cdm_set_error("out of device memory in cdm_correct"); return CDM_ERR_HIP;
     }
     int rc = CDM_OK;
@@ -279,6 +279,6 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
         hipMemcpy(flags, nActive, 8, hipMemcpyDeviceToHost);
         if (flags[1]) { cdm_set_error("ancient_correction: a query has more than 65535 alignment records (unsupported)"); rc = CDM_ERR_UNSUPPORTED; break; }
     } while (0);
-    hipFree(active); hipFree(nActive); hipFree(accept);
+    cdmFree(active); cdmFree(nActive); cdmFree(accept);
     return rc;
 }

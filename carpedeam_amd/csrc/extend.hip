@@ -361,8 +361,8 @@ __global__ __launch_bounds__(256) void k_write(ExtArgs A, const uint32_t *__rest
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    bool alloc(size_t n) { return hipMalloc(&p, (n + 1) * sizeof(T)) == hipSuccess; }
+    ~DevBuf() { if (p) cdmFree(p); }
+    bool alloc(size_t n) { return cdmMalloc(&p, (n + 1) * sizeof(T)) == hipSuccess; }
 };
 
 }  // namespace
@@ -413,7 +413,7 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     hipEventElapsedTime(&ctx->lastMs[4], ctx->ev0, ctx->ev1);
     o->words = words; o->residues = hstats[0]; o->maxLen = (uint32_t) hstats[1];
     const uint64_t maskWords = ((uint64_t) words * 16 + 31) / 32 + 1;
-    if (hipMalloc(&o->codes, ((size_t) words + 2) * 4) != hipSuccess || hipMalloc(&o->nmask, maskWords * 4) != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP; }
+    if (cdmMalloc(&o->codes, ((size_t) words + 2) * 4) != hipSuccess || cdmMalloc(&o->nmask, maskWords * 4) != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP; }
     hipMemcpyAsync(o->key, db->key, (size_t) n * 4, hipMemcpyDeviceToDevice, s);
     hipMemsetAsync(o->hasN, 0, n, s);
     if (words) hipLaunchKernelGGL(k_write, dim3((unsigned) (((uint64_t) words + 255) / 256)), dim3(256), 0, s, A, o->woff, o->len, n, (uint64_t) words, o->codes, o->nmask, o->hasN);

@@ -53,10 +53,101 @@ struct ExtractArgs {
     uint32_t nList;
     int k, kmersPerSeq; float scale; uint64_t seed; int ignoreMultiKmer;
     uint64_t *keys, *vals;      // tuple array: key = k-mer | strand bit 63, val = id << 32 | seqLen << 16 | pos
-    unsigned long long *count;  // number of tuples written
-    uint64_t capacity;
-    unsigned int *err;
+    const uint64_t *slotOff;    // [n+1] first slot of every sequence: 1 whole-sequence tuple + one slot per k-mer position;
+                                // unused slots hold the key ~0 (sorts last, dropped by k_groups)
+    uint32_t *slowShort, *slowLong; unsigned int *slowCnt;   // sequences the fast kernel hands to the general one
+    uint32_t n;
 };
+
+// 2k-bit window of the sequence starting at base pos, MMseqs2 coding (A,C,T,G), first base in the LOW bits
+__device__ __forceinline__ uint64_t kmerWindow(const uint32_t *__restrict__ codes, uint32_t w0, uint32_t pos, uint32_t lastWord, int k) {
+    const uint32_t w = pos >> 4, sh = (pos & 15u) * 2u;
+    const uint64_t a = codes[w0 + w];
+    const uint64_t b = (w + 1 <= lastWord) ? codes[w0 + w + 1] : 0u;
+    const uint64_t c = (w + 2 <= lastWord) ? codes[w0 + w + 2] : 0u;
+    uint64_t x = (a | (b << 32)) >> sh;
+    if (sh) x |= c << (64 - sh);
+    x ^= (x >> 1) & 0x5555555555555555ull;                     // A,C,G,T -> A,C,T,G
+    return x & ((k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1ull));
+}
+// Indexer::computeKmerIdx order (first base most significant) from the window: reverse the 2-bit groups
+__device__ __forceinline__ uint64_t groupsReversed(uint64_t x, int k) {
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = __builtin_bswap64(x);
+    return x >> (64 - 2 * k);
+}
+__device__ __forceinline__ uint64_t pow31(uint32_t e) { uint64_t r = 1, b = 31; while (e) { if (e & 1u) r *= b; b *= b; e >>= 1; } return r; }
+// Util::hash over the numeric sequence (M/commons/Util.h:338-346): sum c_i * 31^(L-1-i); lanes take contiguous chunks
+__device__ __forceinline__ uint64_t waveSeqHash(const uint32_t *codes, const uint32_t *nmask, uint32_t w0, uint32_t L, bool hasN, int lane) {
+    const uint32_t cs = (L + 63) / 64, b0 = min(L, lane * cs), b1 = min(L, b0 + cs);
+    uint64_t h = 0;
+    for (uint32_t i = b0; i < b1; i++) {
+        uint32_t c = cdm_base(codes, w0, i); c ^= c >> 1;
+        if (hasN && cdm_isN(nmask, w0, i)) c = 4;
+        h = h * 31 + c;
+    }
+    h *= pow31(L - b1);
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor((unsigned long long) h, o, 64);
+    return h;
+}
+
+constexpr int FAST_WAVES = 4, FAST_TABLE = 1024, FAST_CAP = 448;
+// Fast path of K1: one wavefront per sequence, no per-sequence sort.  Valid when every k-mer is taken
+// (positions <= kmersPerSeq - 1 + scale * L) and no canonical k-mer occurs twice in the sequence (checked with an LDS
+// hash set); then the selection is "all k-mers" whatever the (hash, k-mer, pos) order.  Anything else goes to k_extract.
+__global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs a) {
+    __shared__ unsigned long long sTable[FAST_WAVES][FAST_TABLE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long *table = sTable[wave];
+    const int k = a.k;
+    for (uint32_t seq = blockIdx.x * FAST_WAVES + wave; seq < a.n; seq += gridDim.x * FAST_WAVES) {
+        const uint32_t L = a.len[seq], w0 = a.woff[seq];
+        const bool hasN = a.hasN[seq] != 0;
+        const uint32_t nPos = (L >= (uint32_t) k) ? (L - k + 1) : 0;
+        const uint64_t base = a.slotOff[seq];
+        const size_t cap = (size_t) (float) ((float) (a.kmersPerSeq - 1) + (a.scale * (float) L));
+        if (nPos > cap || nPos > FAST_CAP) {   // wave uniform
+            if (lane == 0) { if (nPos < 256) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq; else a.slowLong[atomicAdd(&a.slowCnt[1], 1u)] = seq; }
+            continue;
+        }
+        for (int i = lane; i < FAST_TABLE; i += 64) table[i] = ~0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+        const uint32_t lastWord = (L + 15) / 16 - 1;
+        bool dup = false;
+        for (uint32_t pos = lane; pos < nPos; pos += 64) {
+            const uint64_t w = kmerWindow(a.codes, w0, pos, lastWord, k);
+            bool x = false;
+            if (hasN) for (int j = 0; j < k; j++) x |= cdm_isN(a.nmask, w0, pos + j) != 0;
+            const uint64_t idx = groupsReversed(w, k);
+            const uint64_t rc = (w ^ 0xAAAAAAAAAAAAAAAAull) & ((1ull << (2 * k)) - 1ull);   // Util::revComplement(idx): window order, complemented
+            uint64_t key = ~0ull, val = 0;
+            if (!x && rc != idx) {
+                const bool pickRev = rc < idx;
+                const uint64_t km = pickRev ? rc : idx;
+                const uint32_t p = pickRev ? (L - pos - k) : pos;
+                key = km | (pickRev ? 0ull : BIT63);
+                val = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | (uint64_t) p;
+                if (a.ignoreMultiKmer) {
+                    uint32_t h = (uint32_t) ((km * 0x9E3779B97F4A7C15ull) >> 54) & (FAST_TABLE - 1);
+                    while (true) {
+                        const unsigned long long old = atomicCAS(&table[h], ~0ull, (unsigned long long) km);
+                        if (old == ~0ull) break;
+                        if (old == km) { dup = true; break; }
+                        h = (h + 1) & (FAST_TABLE - 1);
+                    }
+                }
+            }
+            a.keys[base + 1 + pos] = key;
+            a.vals[base + 1 + pos] = val;
+        }
+        const uint64_t h = waveSeqHash(a.codes, a.nmask, w0, L, hasN, lane);
+        if (lane == 0) { a.keys[base] = xxh64_u64(h, a.seed); a.vals[base] = ((uint64_t) seq << 32) | ((uint64_t) L << 16); }
+        if (__ballot(dup) != 0ull && lane == 0) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;   // rewritten by k_extract
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 
 // sort element of the per-sequence ordering compareByScoreReverse (kmermatcher.h:30-46): (score, kmer|bit63, pos)
 struct SeqPos { uint64_t a, b; };   // a = score << 48 | kmer63 >> 15 ; b = (kmer63 & 0x7FFF) << 49 | pos << 1 | forward
@@ -70,8 +161,7 @@ template <int CAP, int NT>
 __global__ __launch_bounds__(NT) void k_extract(ExtractArgs a) {
     __shared__ SeqPos sp[CAP];
     __shared__ uint8_t sel[CAP];
-    __shared__ uint32_t sN, sOk, sCursor;
-    __shared__ unsigned long long sBase64;
+    __shared__ uint32_t sN, sCursor;
     const int tid = threadIdx.x;
     for (uint32_t item = blockIdx.x; item < a.nList; item += gridDim.x) {
         const uint32_t seq = a.list[item];
@@ -167,23 +257,8 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs a) {
         }
         __syncthreads();
         // ---- emit: 1 whole-sequence tuple (:244-267) + the selected k-mers
-        uint32_t mine = 0;
-        for (uint32_t i = tid; i < n; i += NT) mine += sel[i];
-        // block total via shared atomic
-        if (tid == 0) sN = 1;
-        __syncthreads();
-        if (mine) atomicAdd(&sN, mine);
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned long long base = atomicAdd(a.count, (unsigned long long) sN);
-            sOk = (base + sN <= a.capacity) ? 1u : 0u;
-            if (!sOk) atomicOr(a.err, 1u);
-            sBase64 = base;
-            sCursor = 1;
-        }
-        __syncthreads();
-        if (sOk) {
-            const unsigned long long base = sBase64;
+        {
+            const uint64_t base = a.slotOff[seq];
             if (tid == 0) {
                 // Util::hash over the numeric sequence (M/commons/Util.h:338-346) then XXH64 (kmermatcher.cpp:135-138)
                 uint64_t h = 0;
@@ -195,15 +270,19 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs a) {
                 }
                 a.keys[base] = xxh64_u64(h, a.seed);
                 a.vals[base] = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | 0ull;
+                sCursor = 0;
             }
-            // slot order within the sequence does not matter (a global sort follows)
+            __syncthreads();
+            // selected tuples first (their order within the sequence does not matter: a global sort follows), then sentinels
             for (uint32_t i = tid; i < n; i += NT) {
                 if (!sel[i]) continue;
                 const uint32_t o = atomicAdd(&sCursor, 1u);
                 const SeqPos e = sp[i];
-                a.keys[base + o] = spKmer63(e) | ((e.b & 1ull) ? BIT63 : 0ull);
-                a.vals[base + o] = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | (uint64_t) spPos(e);
+                a.keys[base + 1 + o] = spKmer63(e) | ((e.b & 1ull) ? BIT63 : 0ull);
+                a.vals[base + 1 + o] = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | (uint64_t) spPos(e);
             }
+            __syncthreads();
+            for (uint32_t i = sCursor + tid; i < nPos; i += NT) { a.keys[base + 1 + i] = ~0ull; a.vals[base + 1 + i] = 0; }
         }
         __syncthreads();
     }
@@ -235,6 +314,7 @@ __device__ __forceinline__ uint64_t packGroupKey(const GroupArgs &a, uint32_t re
 __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
+    if (a.keys[i] == ~0ull) { a.outKeys[i] = ~0ull; return; }  // unused slot
     const uint64_t km = a.keys[i] & ~BIT63;
     if (i > 0 && (a.keys[i - 1] & ~BIT63) == km) return;       // not the first tuple of its k-mer run
     // scan the run: size and representative = min by (seqLen desc, id asc, pos asc)  [sort order kmermatcher.h:76-96]
@@ -246,7 +326,7 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
         if (xi != yi) return xi < yi;
         return (x & 0xFFFF) < (y & 0xFFFF);
     };
-    for (e = i + 1; e < a.n && (a.keys[e] & ~BIT63) == km; e++) {
+    for (e = i + 1; e < a.n && a.keys[e] != ~0ull && (a.keys[e] & ~BIT63) == km; e++) {
         const uint64_t v = a.vals[e];
         if (better(v, best)) { best = v; bestKey = a.keys[e]; }
     }
@@ -332,6 +412,13 @@ __global__ __launch_bounds__(256) void k_place(VoteArgs a, const uint32_t *__res
     const uint32_t rep = (uint32_t) (a.keys[i] >> (a.diagBits + 1 + a.idBits));
     out[off[rep] + 1 + ((uint64_t) rank[i] - perRepScan[rep])] = a.hit[i];
 }
+__global__ void k_slot_counts(const uint32_t *__restrict__ len, uint32_t n, int k, unsigned long long *__restrict__ slots) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { slots[i] = 0; return; }
+    const uint32_t L = len[i];
+    slots[i] = 1ull + ((L >= (uint32_t) k) ? (L - k + 1) : 0);
+}
 __global__ void k_classify(const uint32_t *__restrict__ len, uint32_t n, int k, uint32_t shortCap, uint32_t *__restrict__ listShort,
                            uint32_t *__restrict__ listLong, unsigned int *__restrict__ cnt, uint32_t longCap) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,8 +444,8 @@ __global__ void k_count_kmers(const uint32_t *__restrict__ len, uint32_t n, int 
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    bool alloc(size_t n) { return hipMalloc(&p, (n + 1) * sizeof(T)) == hipSuccess; }
+    ~DevBuf() { if (p) cdmFree(p); }
+    bool alloc(size_t n) { return cdmMalloc(&p, (n + 1) * sizeof(T)) == hipSuccess; }
 };
 inline uint32_t bitsFor(uint64_t v) { uint32_t b = 1; while ((1ull << b) < v) b++; return b; }
 
@@ -371,26 +458,36 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     if (k < 4 || k > 31) { cdm_set_error("cdm_kmermatch: k must be in 4..31 (got %d)", k); return CDM_ERR_INVALID; }
     if (db->maxLen + 2 >= 32767u) { cdm_set_error("cdm_kmermatch: sequences of 32765 letters or more (the reference's `int` position path) are not implemented on the device yet"); return CDM_ERR_UNSUPPORTED; }
     constexpr uint32_t SHORT_CAP = 256, LONG_CAP = 4096;
+    if (db->maxLen >= (uint32_t) k && db->maxLen - k + 1 >= LONG_CAP) {
+        cdm_set_error("cdm_kmermatch: sequences with %u k-mer positions or more (max length %u) need the global per-sequence ordering, not implemented on the device yet", LONG_CAP, db->maxLen);
+        return CDM_ERR_UNSUPPORTED;
+    }
     const uint32_t idBits = bitsFor(n), diagBits = bitsFor(2ull * db->maxLen + 2);
     if (2 * idBits + diagBits + 1 > 64) { cdm_set_error("cdm_kmermatch: %u sequences x max length %u do not fit the 64-bit (rep,id,diagonal) sort key", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
     const int diagBias = (int) db->maxLen + 1;
 
-    DevBuf<unsigned long long> counters;      // [0] tuple capacity, [1] tuples written, [2..] scratch
-    DevBuf<unsigned int> cls;                 // classify counters + error flag
+    DevBuf<unsigned long long> counters;      // scratch counters ([2] = number of kept group tuples)
+    DevBuf<unsigned int> cls;                 // slow-path list sizes
     DevBuf<uint32_t> listShort, listLong;
-    if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    DevBuf<unsigned long long> slots; DevBuf<uint64_t> slotOff;
+    if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1)) {
+        cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP;
+    }
     hipMemsetAsync(counters.p, 0, 8 * 8, s);
     hipMemsetAsync(cls.p, 0, 8 * 4, s);
-    hipLaunchKernelGGL(k_count_kmers, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, k, par->kmers_per_seq, par->kmers_per_seq_scale, counters.p);
-    hipLaunchKernelGGL(k_classify, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, k, SHORT_CAP, listShort.p, listLong.p, cls.p, LONG_CAP);
-    unsigned long long hc[2]; unsigned int hcls[4];
-    hipMemcpyAsync(hc, counters.p, 16, hipMemcpyDeviceToHost, s);
-    hipMemcpyAsync(hcls, cls.p, 16, hipMemcpyDeviceToHost, s);
-    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: counting kernels failed"); return CDM_ERR_HIP; }
-    if (hcls[2]) { cdm_set_error("cdm_kmermatch: %u sequences have %u k-mers or more; the per-sequence ordering of such sequences is not implemented on the device yet", hcls[2], LONG_CAP); return CDM_ERR_UNSUPPORTED; }
-    // upper bound of tuples: every k-mer position + the whole-sequence tuple (the reference's computeKmerCount bound is smaller
-    // for long sequences; we size for the positions because selection happens after extraction)
-    const uint64_t capacity = std::max<uint64_t>(hc[0], 1) + n + 16;
+    // one slot per k-mer position + one for the whole-sequence tuple, at a fixed offset per sequence (no global counter)
+    hipLaunchKernelGGL(k_slot_counts, dim3((n + 256) / 256), dim3(256), 0, s, db->len, n, k, slots.p);
+    {
+        size_t sb = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, sb, slots.p, (unsigned long long *) slotOff.p, (int) (n + 1), s);
+        DevBuf<char> t0;
+        if (!t0.alloc(sb + 256)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+        hipcub::DeviceScan::ExclusiveSum(t0.p, sb, slots.p, (unsigned long long *) slotOff.p, (int) (n + 1), s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: slot scan failed"); return CDM_ERR_HIP; }
+    }
+    uint64_t capacity = 0;
+    hipMemcpy(&capacity, slotOff.p + n, 8, hipMemcpyDeviceToHost);
+    const unsigned long long nTuples = capacity;
 
     rocprim::double_buffer<uint64_t> keys, vals;
     DevBuf<uint64_t> k0, k1, v0, v1;
@@ -400,8 +497,14 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     ExtractArgs ea;
     ea.woff = db->woff; ea.len = db->len; ea.codes = db->codes; ea.nmask = db->nmask; ea.hasN = db->hasN;
     ea.k = k; ea.kmersPerSeq = par->kmers_per_seq; ea.scale = par->kmers_per_seq_scale; ea.seed = par->hash_shift; ea.ignoreMultiKmer = par->ignore_multi_kmer;
-    ea.keys = k0.p; ea.vals = v0.p; ea.count = counters.p + 1; ea.capacity = capacity; ea.err = cls.p + 3;
+    ea.keys = k0.p; ea.vals = v0.p; ea.slotOff = slotOff.p; ea.slowShort = listShort.p; ea.slowLong = listLong.p; ea.slowCnt = cls.p; ea.n = n;
+    ea.list = nullptr; ea.nList = 0;
     hipEventRecord(ctx->ev0, s);
+    hipLaunchKernelGGL(k_extract_fast, dim3(std::min<uint32_t>((n + FAST_WAVES - 1) / FAST_WAVES, ctx->cuCount * 16)), dim3(64 * FAST_WAVES), 0, s, ea);
+    unsigned int hcls[2] = {0, 0};
+    hipMemcpyAsync(hcls, cls.p, 8, hipMemcpyDeviceToHost, s);
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    // sequences that need the exact per-sequence ordering (repeated k-mers, more positions than the bottom-m budget)
     if (hcls[0]) {
         ea.list = listShort.p; ea.nList = hcls[0];
         hipLaunchKernelGGL((k_extract<SHORT_CAP, 64>), dim3(std::min<uint32_t>(hcls[0], ctx->cuCount * 32)), dim3(64), 0, s, ea);
@@ -411,11 +514,7 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
         hipLaunchKernelGGL((k_extract<LONG_CAP, 256>), dim3(std::min<uint32_t>(hcls[1], ctx->cuCount * 2)), dim3(256), 0, s, ea);
     }
     hipEventRecord(ctx->ev1, s);
-    unsigned long long nTuples = 0; unsigned int err = 0;
-    hipMemcpyAsync(&nTuples, counters.p + 1, 8, hipMemcpyDeviceToHost, s);
-    hipMemcpyAsync(&err, cls.p + 3, 4, hipMemcpyDeviceToHost, s);
-    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
-    if (err) { cdm_set_error("cdm_kmermatch: k-mer tuple array overflow"); return CDM_ERR_HIP; }
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction (general path) failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     hipEventElapsedTime(&ctx->lastMs[3], ctx->ev0, ctx->ev1);
 
     // ---- sort 1: by k-mer (63 bits), stable
@@ -475,13 +574,13 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     hipcub::DeviceScan::ExclusiveSum(tmp4.p, sb1, perRep.p, perRepScan.p, (int) (n + 1), s);
     if (nGroup) hipcub::DeviceScan::ExclusiveSum(tmp4.p, sb2, flagIt, rank.p, (int) nGroup, s);
     cdm_hits *res = new cdm_hits(); res->n = n;
-    if (hipMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { delete res; cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    if (cdmMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { delete res; cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipLaunchKernelGGL(k_offsets, dim3((n + 256) / 256), dim3(256), 0, s, perRepScan.p, n, res->off);
     uint64_t total = 0;
     hipMemcpyAsync(&total, res->off + n, 8, hipMemcpyDeviceToHost, s);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: vote failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     res->count = total;
-    if (hipMalloc(&res->rec, (total + 1) * sizeof(HitRec)) != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    if (cdmMalloc(&res->rec, (total + 1) * sizeof(HitRec)) != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipLaunchKernelGGL(k_self, dim3((n + 255) / 256), dim3(256), 0, s, res->off, n, res->rec);
     if (nGroup) hipLaunchKernelGGL(k_place, dim3((unsigned) ((nGroup + 255) / 256)), dim3(256), 0, s, va, rank.p, perRepScan.p, res->off, res->rec);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: placing hits failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }

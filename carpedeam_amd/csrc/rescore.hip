@@ -181,9 +181,9 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     int rc = CDM_OK;
     auto fail = [&](const char *what) { cdm_set_error("cdm_rescore: %s", what); rc = CDM_ERR_HIP; };
     do {
-        if (hipMalloc(&dPresent, (size_t) (db->maxLen + 1) * 4) != hipSuccess || hipMalloc(&dMin, (size_t) (db->maxLen + 1) * 4) != hipSuccess ||
-            hipMalloc(&owner, (nHits + 1) * 4) != hipSuccess || hipMalloc(&tmp, (nHits + 1) * sizeof(AlnRec)) != hipSuccess ||
-            hipMalloc(&valid, nHits + 1) != hipSuccess || hipMalloc(&cnt, ((size_t) n + 1) * 8) != hipSuccess) { fail("out of device memory"); break; }
+        if (cdmMalloc(&dPresent, (size_t) (db->maxLen + 1) * 4) != hipSuccess || cdmMalloc(&dMin, (size_t) (db->maxLen + 1) * 4) != hipSuccess ||
+            cdmMalloc(&owner, (nHits + 1) * 4) != hipSuccess || cdmMalloc(&tmp, (nHits + 1) * sizeof(AlnRec)) != hipSuccess ||
+            cdmMalloc(&valid, nHits + 1) != hipSuccess || cdmMalloc(&cnt, ((size_t) n + 1) * 8) != hipSuccess) { fail("out of device memory"); break; }
         hipMemsetAsync(dPresent, 0, (size_t) (db->maxLen + 1) * 4, s);
         hipLaunchKernelGGL(k_len_hist, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, dPresent);
         hipMemcpyAsync(present.data(), dPresent, (size_t) (db->maxLen + 1) * 4, hipMemcpyDeviceToHost, s);
@@ -207,23 +207,23 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
         hipEventRecord(ctx->ev1, s);
         hipLaunchKernelGGL(k_count_valid, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid, n, cnt);
         res = new cdm_alns(); res->n = n;
-        if (hipMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { fail("out of device memory"); break; }
+        if (cdmMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { fail("out of device memory"); break; }
         size_t tmpBytes = 0;
         hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cnt, res->off, n + 1, s);
-        if (hipMalloc(&scanTmp, tmpBytes + 16) != hipSuccess) { fail("out of device memory"); break; }
+        if (cdmMalloc(&scanTmp, tmpBytes + 16) != hipSuccess) { fail("out of device memory"); break; }
         hipMemsetAsync(cnt + n, 0, 8, s);
         hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, cnt, res->off, n + 1, s);
         uint64_t total = 0;
         hipMemcpyAsync(&total, res->off + n, 8, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { fail("kernel failed"); break; }
         res->count = total;
-        if (hipMalloc(&res->rec, (total + 1) * sizeof(AlnRec)) != hipSuccess) { fail("out of device memory"); break; }
+        if (cdmMalloc(&res->rec, (total + 1) * sizeof(AlnRec)) != hipSuccess) { fail("out of device memory"); break; }
         hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid, tmp, n, res->off, res->rec);
         hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess) { fail(hipGetErrorString(e)); break; }
         hipEventElapsedTime(&ctx->lastMs[1], ctx->ev0, ctx->ev1);
     } while (0);
-    hipFree(dPresent); hipFree(dMin); hipFree(owner); hipFree(tmp); hipFree(valid); hipFree(cnt); hipFree(scanTmp);
+    cdmFree(dPresent); cdmFree(dMin); cdmFree(owner); cdmFree(tmp); cdmFree(valid); cdmFree(cnt); cdmFree(scanTmp);
     if (rc != CDM_OK) { if (res) cdm_alns_free(res); return rc; }
     *out = res;
     return CDM_OK;

@@ -71,19 +71,19 @@ int cdm_synth_impl(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, uint64_t n, ui
     uint32_t *wordsPer = nullptr; void *tmp = nullptr;
     int ret = CDM_OK;
     do {
-        if (hipMalloc(&wordsPer, (n + 1) * 4) != hipSuccess) { cdm_set_error("cdm_seqdb_synth: out of device memory"); ret = CDM_ERR_HIP; break; }
+        if (cdmMalloc(&wordsPer, (n + 1) * 4) != hipSuccess) { cdm_set_error("cdm_seqdb_synth: out of device memory"); ret = CDM_ERR_HIP; break; }
         hipLaunchKernelGGL(k_synth_len, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, a, db->len, wordsPer, db->key);
         hipMemsetAsync(wordsPer + n, 0, 4, s);
         size_t sb = 0;
         hipcub::DeviceScan::ExclusiveSum(nullptr, sb, wordsPer, db->woff, (int) (n + 1), s);
-        if (hipMalloc(&tmp, sb + 256) != hipSuccess) { cdm_set_error("cdm_seqdb_synth: out of device memory"); ret = CDM_ERR_HIP; break; }
+        if (cdmMalloc(&tmp, sb + 256) != hipSuccess) { cdm_set_error("cdm_seqdb_synth: out of device memory"); ret = CDM_ERR_HIP; break; }
         hipcub::DeviceScan::ExclusiveSum(tmp, sb, wordsPer, db->woff, (int) (n + 1), s);
         uint32_t words = 0;
         hipMemcpyAsync(&words, db->woff + n, 4, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_seqdb_synth: length kernel failed"); ret = CDM_ERR_HIP; break; }
         db->words = words;
         const uint64_t maskWords = ((uint64_t) words * 16 + 31) / 32 + 1;
-        if (hipMalloc(&db->codes, ((size_t) words + 2) * 4) != hipSuccess || hipMalloc(&db->nmask, maskWords * 4) != hipSuccess) { cdm_set_error("cdm_seqdb_synth: out of device memory"); ret = CDM_ERR_HIP; break; }
+        if (cdmMalloc(&db->codes, ((size_t) words + 2) * 4) != hipSuccess || cdmMalloc(&db->nmask, maskWords * 4) != hipSuccess) { cdm_set_error("cdm_seqdb_synth: out of device memory"); ret = CDM_ERR_HIP; break; }
         hipMemsetAsync(db->nmask, 0, maskWords * 4, s);
         hipMemsetAsync(db->ext, 0, n, s);
         hipMemsetAsync(db->hasN, 0, n, s);
@@ -99,7 +99,7 @@ int cdm_synth_impl(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, uint64_t n, ui
             db->residues = t; db->maxLen = mx;
         }
     } while (0);
-    hipFree(wordsPer); hipFree(tmp);
+    cdmFree(wordsPer); cdmFree(tmp);
     if (ret != CDM_OK) { cdm_seqdb_free(db); return ret; }
     *out = db;
     return CDM_OK;
