@@ -207,11 +207,126 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {
     }
 }
 
-// queries with more than one alignment record
-__global__ void k_mark_active(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t *__restrict__ active, unsigned int *__restrict__ nActive) {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast kernel for queries with at most 64 alignment records (all but the heaviest pile-ups): lane = record in the gate
+// phase (RY identity on 16-base words, XOR + popcount), accepted records parked in LDS, lane = position in the pile-up.
+// Same arithmetic as k_correct; 8-bit pile-up counters (a slot cannot exceed the 64 records).
+constexpr int FAST_WAVES = 4;
+struct RecInfo { uint32_t tw, tLen; int qs, qe, ds; uint32_t flags; };   // flags: 1 rev, 2 target has N
+
+__global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a, const uint32_t *__restrict__ list, const unsigned int *__restrict__ nList) {
+    __shared__ double sLogT[16], sLogQ[12 * 16], sLogD[2 * 11 * 16];
+    __shared__ uint16_t sCnt[FAST_WAVES][SLOTS][64];
+    __shared__ RecInfo sRec[FAST_WAVES][64];
+    for (int i = threadIdx.x; i < 16; i += blockDim.x) sLogT[i] = (&a.lut->logT[0][0])[i];
+    for (int i = threadIdx.x; i < 12 * 16; i += blockDim.x) sLogQ[i] = (&a.lut->logQ[0][0][0])[i];
+    for (int i = threadIdx.x; i < 2 * 11 * 16; i += blockDim.x) sLogD[i] = (&a.lut->logD[0][0][0][0])[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int nItems = *nList;
+    uint16_t (*cnt)[64] = sCnt[wave];
+    RecInfo *recs = sRec[wave];
+    for (unsigned int item = blockIdx.x * FAST_WAVES + wave; item < nItems; item += gridDim.x * FAST_WAVES) {
+        const uint32_t q = list[item];
+        const uint32_t qLen = a.len[q], qw = a.woff[q];
+        const bool qHasN = a.hasN[q] != 0, qWasExt = a.ext[q] != 0;
+        const uint64_t r0 = a.aoff[q];
+        const uint32_t nRec = (uint32_t) (a.aoff[q + 1] - r0);
+        const uint32_t qLast = (qLen + 15) / 16 - 1;
+        // ---- gate phase, lane = record
+        AlnRec rec; uint32_t aLen = 0;
+        const bool have = (uint32_t) lane < nRec;
+        if (have) { rec = a.rec[r0 + lane]; aLen = alnLength(rec); }
+        const float avCov = static_cast<float>(static_cast<float>(cdm_wave_sum((int) aLen))) / qLen;
+        bool ok = false; RecInfo info;
+        if (have) {
+            const uint32_t t = rec.target, tLen = a.len[t], tw = a.woff[t];
+            const bool tHasN = a.hasN[t] != 0;
+            const Oriented o = orient(rec, tLen);
+            ok = a.ext[t] == 0;
+            if (ok) {
+                uint32_t mism = 0;
+                if (!qHasN && !tHasN) {
+                    const uint32_t tLast = (tLen + 15) / 16 - 1;
+                    for (uint32_t c = 0; c < aLen; c += 16) {
+                        const uint32_t x = cdm_window16(a.codes, qw, (uint32_t) o.qs + c, qLast) ^ cdm_oriented_window16(a.codes, tw, tLen, tLast, o.rev, (uint32_t) o.ds + c);
+                        uint32_t mm = x & 0x55555555u;                   // RY class = low bit of the code
+                        const uint32_t rem = aLen - c;
+                        if (rem < 16) mm &= (1u << (2 * rem)) - 1u;
+                        mism += __popc(mm);
+                    }
+                } else {
+                    for (uint32_t c = 0; c < aLen; c++) {
+                        uint32_t qb = cdm_base(a.codes, qw, o.qs + c);
+                        if (qHasN && cdm_isN(a.nmask, qw, o.qs + c)) qb = 0;
+                        const uint32_t tb = targetBase(a, tw, tLen, tHasN, o.rev, o.ds + c);
+                        mism += ((qb & 1u) != (tb & 1u));
+                    }
+                }
+                const float ryId = static_cast<float>(aLen - mism) / static_cast<float>(aLen);
+                float thr = a.corrRy;
+                if (aLen <= 100) { thr = (static_cast<float>(aLen) - 1) / static_cast<float>(aLen); thr = floorf(thr * 1000) / 1000; }
+                const bool right = o.ds == 0 && (uint32_t) o.qe == (qLen - 1);
+                const bool left = o.qs == 0 && (uint32_t) o.de == (tLen - 1);
+                ok = (ryId >= thr) && (right || left || (avCov < 50)) && rec.seqId >= a.seqIdThr && aLen >= 30;
+            }
+            info.tw = tw; info.tLen = tLen; info.qs = o.qs; info.qe = o.qe; info.ds = o.ds; info.flags = (o.rev ? 1u : 0u) | (tHasN ? 2u : 0u);
+        }
+        // compact the accepted records into LDS, keeping record order (the pile-up is order independent anyway)
+        const uint64_t okMask = __ballot(ok);
+        const int nAcc = __popcll(okMask);
+        if (ok) recs[__popcll(okMask & ((1ull << lane) - 1ull))] = info;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+
+        // ---- pile-up + call, 64 positions at a time
+        const uint32_t lastWord = (qLen + 15) / 16;
+        for (uint32_t base = 0; base < qLen; base += 64) {
+            const uint32_t p = base + lane;
+#pragma unroll 4
+            for (int s = 0; s < SLOTS; s++) cnt[s][lane] = 0;
+            for (int r = 0; r < nAcc; r++) {
+                const RecInfo ri = recs[r];
+                if ((uint32_t) ri.qe < base || (uint32_t) ri.qs >= base + 64) continue;   // wave uniform
+                if (p >= (uint32_t) ri.qs && p <= (uint32_t) ri.qe && p < qLen) {
+                    const uint32_t tpos = (uint32_t) ri.ds + (p - (uint32_t) ri.qs);
+                    const uint32_t tb = targetBase(a, ri.tw, ri.tLen, (ri.flags & 2u) != 0, (ri.flags & 1u) != 0, tpos);
+                    const uint32_t cls = tpos < 5 ? tpos : (tpos >= ri.tLen - 5 ? 6 + (tpos - (ri.tLen - 5)) : 5);
+                    cnt[tb * 11 + cls][lane] += (uint16_t) (1u + ((ri.flags & 1u) ? 0x100u : 0u));
+                }
+            }
+            uint32_t newCode = 0; bool keep = true;
+            if (p < qLen) {
+                uint32_t qb = cdm_base(a.codes, qw, p);
+                const bool qIsN = qHasN && cdm_isN(a.nmask, qw, p);
+                if (qIsN) qb = 0;
+                newCode = callBase(sLogT, sLogQ, sLogD, qb, p, qLen, qWasExt,
+                                   [&](int slot) { const uint32_t v = cnt[slot][lane]; return (v & 0xFFu) | ((v >> 8) << 16); }, keep);
+            }
+            const uint64_t b0 = cdm_ballot((newCode & 1u) != 0), b1 = cdm_ballot((newCode & 2u) != 0);
+            uint64_t nb = 0;
+            if (qHasN) nb = cdm_ballot(p < qLen && keep && cdm_isN(a.nmask, qw, p));
+            if (lane < 4) {
+                const uint32_t w = (base >> 4) + lane;
+                if (w < lastWord) {
+                    const uint32_t lo = (uint32_t) (b0 >> (16 * lane)), hi = (uint32_t) (b1 >> (16 * lane));
+                    a.outCodes[qw + w] = cdm_spread16(lo) | (cdm_spread16(hi) << 1);
+                    if (qHasN) reinterpret_cast<uint16_t *>(a.outNmask)[qw + w] = (uint16_t) (nb >> (16 * lane));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// queries with more than one alignment record: up to 64 records -> fast list, more -> general list
+__global__ void k_mark_active(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t *__restrict__ active, uint32_t *__restrict__ activeFast,
+                              unsigned int *__restrict__ counters) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
-    if (aoff[q + 1] - aoff[q] > 1) { unsigned int pos = atomicAdd(nActive, 1u); active[pos] = q; }
+    const uint64_t c = aoff[q + 1] - aoff[q];
+    if (c > 64) active[atomicAdd(&counters[0], 1u)] = q;
+    else if (c > 1) activeFast[atomicAdd(&counters[2], 1u)] = q;
 }
 
 
@@ -251,9 +366,9 @@ extern "C" int cdm_debug_call_bases(cdm_ctx *ctx, const uint32_t *vectors, uint3
 int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb *out) {
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t) db->n;
-    uint32_t *active = nullptr; unsigned int *nActive = nullptr; uint8_t *accept = nullptr;
-    if (cdmMalloc(&active, (size_t) n * 4) != hipSuccess || cdmMalloc(&nActive, 8) != hipSuccess || cdmMalloc(&accept, alns->count + 1) != hipSuccess) {
-        cdmFree(active); cdmFree(nActive); cdmFree(accept);
+    uint32_t *active = nullptr, *activeFast = nullptr; unsigned int *nActive = nullptr; uint8_t *accept = nullptr;
+    if (cdmMalloc(&active, (size_t) n * 4) != hipSuccess || cdmMalloc(&activeFast, (size_t) n * 4) != hipSuccess || cdmMalloc(&nActive, 16) != hipSuccess || cdmMalloc(&accept, alns->count + 1) != hipSuccess) {
+        cdmFree(active); cdmFree(activeFast); cdmFree(nActive); cdmFree(accept);
         cdm_set_error("out of device memory in cdm_correct"); return CDM_ERR_HIP;
     }
     int rc = CDM_OK;
@@ -261,15 +376,16 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
         // coverage <= 1 everywhere unless the kernel overwrites: start from a copy of the input bases
         hipMemcpyAsync(out->codes, db->codes, db->words * 4, hipMemcpyDeviceToDevice, s);
         hipMemcpyAsync(out->nmask, db->nmask, ((db->words * 16 + 31) / 32) * 4, hipMemcpyDeviceToDevice, s);
-        hipMemsetAsync(nActive, 0, 8, s);
-        hipLaunchKernelGGL(k_mark_active, dim3((n + 255) / 256), dim3(256), 0, s, alns->off, n, active, nActive);
+        hipMemsetAsync(nActive, 0, 16, s);
+        hipLaunchKernelGGL(k_mark_active, dim3((n + 255) / 256), dim3(256), 0, s, alns->off, n, active, activeFast, nActive);
         CorrectArgs a;
         a.woff = db->woff; a.len = db->len; a.codes = db->codes; a.nmask = db->nmask; a.ext = db->ext; a.hasN = db->hasN;
         a.aoff = alns->off; a.rec = alns->rec; a.active = active; a.nActive = nActive; a.accept = accept; a.errFlag = nActive + 1;
         a.outCodes = out->codes; a.outNmask = out->nmask; a.lut = ctx->lutDev; a.seqIdThr = par->seq_id_thr; a.corrRy = par->corr_reads_ry_seq_id;
         const int blocks = ctx->cuCount * 8;
         hipEventRecord(ctx->ev0, s);
-        hipLaunchKernelGGL(k_correct, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+        hipLaunchKernelGGL(k_correct_fast, dim3(blocks), dim3(64 * FAST_WAVES), 0, s, a, activeFast, nActive + 2);
+        hipLaunchKernelGGL(k_correct, dim3(blocks / 4), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
         hipEventRecord(ctx->ev1, s);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -279,6 +395,6 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
         hipMemcpy(flags, nActive, 8, hipMemcpyDeviceToHost);
         if (flags[1]) { cdm_set_error("ancient_correction: a query has more than 65535 alignment records (unsupported)"); rc = CDM_ERR_UNSUPPORTED; break; }
     } while (0);
-    cdmFree(active); cdmFree(nActive); cdmFree(accept);
+    cdmFree(active); cdmFree(activeFast); cdmFree(nActive); cdmFree(accept);
     return rc;
 }

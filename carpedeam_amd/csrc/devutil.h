@@ -29,6 +29,13 @@ __device__ __forceinline__ uint32_t cdm_revcomp16(uint32_t x) {
     x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
     return __builtin_bswap32(x);
 }
+// 16 bases of the (optionally reverse-complemented) sequence starting at oriented position i (i < L)
+__device__ __forceinline__ uint32_t cdm_oriented_window16(const uint32_t *__restrict__ codes, uint32_t w0, uint32_t L, uint32_t lastWord, bool rc, uint32_t i) {
+    if (!rc) return cdm_window16(codes, w0, i, lastWord);
+    const int s = (int) L - 16 - (int) i;
+    const uint32_t w = (s >= 0) ? cdm_window16(codes, w0, (uint32_t) s, lastWord) : (cdm_window16(codes, w0, 0, lastWord) << (2 * (-s)));
+    return cdm_revcomp16(w);
+}
 // spread the low 16 bits of x to the even bit positions
 __device__ __forceinline__ uint32_t cdm_spread16(uint32_t x) {
     x &= 0xFFFFu;

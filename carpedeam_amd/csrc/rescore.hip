@@ -50,13 +50,6 @@ __device__ __forceinline__ float computeCov(unsigned s, unsigned e, unsigned len
     return (min(len, max(s, e)) - min(s, e) + 1) / (float) len;
 }
 
-// 16 bases of the (optionally reverse-complemented) sequence starting at oriented position i
-__device__ __forceinline__ uint32_t orientedWindow(const uint32_t *codes, uint32_t w0, uint32_t L, uint32_t lastWord, bool rc, uint32_t i) {
-    if (!rc) return cdm_window16(codes, w0, i, lastWord);
-    const int s = (int) L - 16 - (int) i;
-    uint32_t w = (s >= 0) ? cdm_window16(codes, w0, (uint32_t) s, lastWord) : (cdm_window16(codes, w0, 0, lastWord) << (2 * (-s)));
-    return cdm_revcomp16(w);
-}
 // oriented base and N flag (per-base path)
 __device__ __forceinline__ void orientedBase(const RescoreArgs &a, uint32_t w0, uint32_t L, bool hasN, bool rc, uint32_t i, uint32_t &code, bool &isN) {
     const uint32_t p = rc ? (L - 1 - i) : i;
@@ -79,7 +72,7 @@ __device__ __forceinline__ void scoreDiagonal(const RescoreArgs &a, uint32_t qw,
     if (!qN && !tN) {
         const uint32_t qLast = (qLen + 15) / 16 - 1, tLast = (tLen + 15) / 16 - 1;
         for (uint32_t k = 0; k < m; k += 16) {
-            const uint32_t x = orientedWindow(a.codes, qw, qLen, qLast, rc, qOff + k) ^ cdm_window16(a.codes, tw, tOff + k, tLast);
+            const uint32_t x = cdm_oriented_window16(a.codes, qw, qLen, qLast, rc, qOff + k) ^ cdm_window16(a.codes, tw, tOff + k, tLast);
             uint32_t mm = (x | (x >> 1)) & 0x55555555u;
             const uint32_t rem = m - k;
             if (rem < 16) mm &= (1u << (2 * rem)) - 1u;
