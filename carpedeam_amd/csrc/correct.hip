@@ -323,10 +323,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
 __global__ void k_mark_active(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t *__restrict__ active, uint32_t *__restrict__ activeFast,
                               unsigned int *__restrict__ counters) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    const uint64_t c = aoff[q + 1] - aoff[q];
-    if (c > 64) active[atomicAdd(&counters[0], 1u)] = q;
-    else if (c > 1) activeFast[atomicAdd(&counters[2], 1u)] = q;
+    const uint64_t c = (q < n) ? aoff[q + 1] - aoff[q] : 0;
+    const uint32_t s0 = cdm_wave_append(&counters[0], c > 64), s2 = cdm_wave_append(&counters[2], c > 1 && c <= 64);
+    if (c > 64) active[s0] = q; else if (c > 1) activeFast[s2] = q;
 }
 
 

@@ -63,6 +63,18 @@ __device__ __forceinline__ int cdm_wave_sum(int v) {
     return v;
 }
 
+// slot for this lane in a global append list: one atomic per wave instead of one per lane (a single word saturates at
+// ~88 atomics/us, MI355X_MICROARCH.md "dequeue"); every lane of the wave must call it
+__device__ __forceinline__ uint32_t cdm_wave_append(unsigned int *counter, bool pred) {
+    const uint64_t m = __ballot(pred);
+    if (m == 0) return 0;
+    const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long) m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned int) __popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+}
+
 // ---------------------------------------------------------------------------------------------- x87 extended precision
 // Software model of the x87 80-bit format (64-bit significand, round to nearest even), for the `long double`
 // accumulators of the reference (src/assembler/correction.cpp:82,110-111; nuclassembleUtil.cpp:212,279).  Only what

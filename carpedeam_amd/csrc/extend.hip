@@ -321,19 +321,23 @@ __global__ __launch_bounds__(64) void k_extend(ExtArgs A) {
 __global__ void k_mark_active2(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t *__restrict__ active, unsigned int *__restrict__ nActive,
                                uint32_t *__restrict__ newLen) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    newLen[q] = 0;
-    if (aoff[q + 1] - aoff[q] > 1) { unsigned int pos = atomicAdd(nActive, 1u); active[pos] = q; }
+    const bool act = q < n && (aoff[q + 1] - aoff[q] > 1);
+    if (q < n) newLen[q] = 0;
+    const uint32_t slot = cdm_wave_append(nActive, act);
+    if (act) active[slot] = q;
 }
 // output geometry: length, words, ext flag
 __global__ void k_out_meta(const uint32_t *__restrict__ len, const uint8_t *__restrict__ ext, const uint32_t *__restrict__ newLen, uint32_t n,
                            uint32_t *__restrict__ oLen, uint8_t *__restrict__ oExt, uint32_t *__restrict__ oWords, unsigned long long *__restrict__ stats) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    const uint32_t L = newLen[q] ? newLen[q] : len[q];
-    oLen[q] = L; oExt[q] = newLen[q] ? 1 : ext[q]; oWords[q] = (L + 15) / 16;
-    atomicAdd(&stats[0], (unsigned long long) L);
-    atomicMax(&stats[1], (unsigned long long) L);
+    uint32_t L = 0;
+    if (q < n) {
+        L = newLen[q] ? newLen[q] : len[q];
+        oLen[q] = L; oExt[q] = newLen[q] ? 1 : ext[q]; oWords[q] = (L + 15) / 16;
+    }
+    unsigned long long sum = L; uint32_t mx = L;
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); mx = max(mx, (uint32_t) __shfl_xor((int) mx, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], sum); atomicMax(&stats[1], (unsigned long long) mx); }
 }
 // one thread per output word
 __global__ __launch_bounds__(256) void k_write(ExtArgs A, const uint32_t *__restrict__ oWoff, const uint32_t *__restrict__ oLen, uint32_t n, uint64_t words,

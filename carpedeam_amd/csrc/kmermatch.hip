@@ -293,7 +293,6 @@ struct GroupArgs {
     const uint64_t *keys, *vals;   // sorted by k-mer (bits 0..62)
     uint64_t n;
     int onlyExtendable, covMode; float covThr;
-    uint64_t *outKeys;             // per input tuple: packed (rep, id, diagonal, strand) or ~0 when dropped
     uint32_t idBits, diagBits; int diagBias;
 };
 __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float ql, float tl) {
@@ -311,47 +310,81 @@ __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float q
 __device__ __forceinline__ uint64_t packGroupKey(const GroupArgs &a, uint32_t rep, uint32_t id, int diag, bool noRev) {
     return ((((uint64_t) rep << a.idBits) | id) << (a.diagBits + 1)) | ((uint64_t) (uint32_t) (diag + a.diagBias) << 1) | (noRev ? 1ull : 0ull);
 }
-__global__ __launch_bounds__(256) void k_groups(GroupArgs a) {
+// run start index of every tuple = inclusive max-scan of (start ? i : 0); fed to the scan through this functor
+struct StartIndex {
+    const uint64_t *keys;
+    __host__ __device__ unsigned long long operator()(unsigned long long i) const {
+        if (i == 0) return 0ull;
+        const uint64_t a = keys[i], b = keys[i - 1];
+        const bool start = (a == ~0ull) || (b == ~0ull) || ((a & ~BIT63) != (b & ~BIT63));
+        return start ? i : 0ull;
+    }
+};
+struct MaxU64 { __host__ __device__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; } };
+
+// K3, one thread per tuple.  The tuple array was filled in (sequence length descending, id ascending, position) order and
+// the radix sort is stable, so the first tuple of a k-mer run is the reference's representative (sort order
+// kmermatcher.h:76-96); only a k-mer that the representative's own sequence carries twice needs a look at the next tuples.
+__global__ __launch_bounds__(256) void k_groups(GroupArgs a, unsigned long long *__restrict__ startIo /* in: run start, out: packed key */) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    if (a.keys[i] == ~0ull) { a.outKeys[i] = ~0ull; return; }  // unused slot
-    const uint64_t km = a.keys[i] & ~BIT63;
-    if (i > 0 && (a.keys[i - 1] & ~BIT63) == km) return;       // not the first tuple of its k-mer run
-    // scan the run: size and representative = min by (seqLen desc, id asc, pos asc)  [sort order kmermatcher.h:76-96]
-    uint64_t e = i; uint64_t best = a.vals[i]; uint64_t bestKey = a.keys[i];
-    auto better = [](uint64_t x, uint64_t y) {   // x before y ?
-        const uint32_t xl = (x >> 16) & 0xFFFF, yl = (y >> 16) & 0xFFFF;
-        if (xl != yl) return xl > yl;
-        const uint32_t xi = (uint32_t) (x >> 32), yi = (uint32_t) (y >> 32);
-        if (xi != yi) return xi < yi;
-        return (x & 0xFFFF) < (y & 0xFFFF);
-    };
-    for (e = i + 1; e < a.n && a.keys[e] != ~0ull && (a.keys[e] & ~BIT63) == km; e++) {
-        const uint64_t v = a.vals[e];
-        if (better(v, best)) { best = v; bestKey = a.keys[e]; }
+    const uint64_t key = a.keys[i];
+    if (key == ~0ull) { startIo[i] = ~0ull; return; }          // unused slot
+    const uint64_t st = startIo[i];
+    const uint64_t km = key & ~BIT63;
+    const bool hasNext = (i + 1 < a.n) && a.keys[i + 1] != ~0ull && (a.keys[i + 1] & ~BIT63) == km;
+    if (st == i && !hasNext) { startIo[i] = ~0ull; return; }   // singleton (:479)
+    uint64_t best = a.vals[st], bestKey = a.keys[st];
+    {   // same sequence twice in the run: the smaller position wins (rare)
+        const uint32_t repSeq = (uint32_t) (best >> 32);
+        for (uint64_t e = st + 1; e < a.n && a.keys[e] != ~0ull && (a.keys[e] & ~BIT63) == km && (uint32_t) (a.vals[e] >> 32) == repSeq; e++)
+            if ((a.vals[e] & 0xFFFF) < (best & 0xFFFF)) { best = a.vals[e]; bestKey = a.keys[e]; }
     }
-    if (e - i == 1) { a.outKeys[i] = ~0ull; return; }          // singleton (:479)
     const uint32_t repId = (uint32_t) (best >> 32);
     const int queryLen = (int) ((best >> 16) & 0xFFFF), repPos = (int) (best & 0xFFFF);
     // the reference initialises repIsReverse = false and only updates it when a NEW run starts (:465,:535-538):
     // the very first run of the array keeps false whatever its strand
-    const bool repIsReverse = (i == 0) ? false : ((bestKey & BIT63) == 0);
-    for (uint64_t j = i; j < e; j++) {
-        const uint64_t v = a.vals[j];
-        const uint32_t id = (uint32_t) (v >> 32);
-        const int tLen = (int) ((v >> 16) & 0xFFFF), tPos0 = (int) (v & 0xFFFF);
-        const bool targetIsReverse = (a.keys[j] & BIT63) == 0;
-        int qPos, tPos; bool qRev;
-        if (repIsReverse && !targetIsReverse) { qPos = repPos; tPos = tPos0; qRev = true; }
-        else if (repIsReverse && targetIsReverse) { qPos = (queryLen - 1) - repPos; tPos = (tLen - 1) - tPos0; qRev = false; }
-        else if (!repIsReverse && targetIsReverse) { qPos = (queryLen - 1) - repPos; tPos = (tLen - 1) - tPos0; qRev = true; }
-        else { qPos = repPos; tPos = tPos0; qRev = false; }
-        const int diagonal = (int) (short) qPos - (int) (short) tPos;
-        const bool canBeExtended = diagonal < 0 || (diagonal > (queryLen - tLen));
-        const bool cbc = canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) tLen);
-        const bool keep = (a.onlyExtendable == 0 && cbc) || (canBeExtended && a.onlyExtendable != 0);
-        a.outKeys[j] = keep ? packGroupKey(a, repId, id, (int) (short) diagonal, !qRev) : ~0ull;
-    }
+    const bool repIsReverse = (st == 0) ? false : ((bestKey & BIT63) == 0);
+    const uint64_t v = a.vals[i];
+    const uint32_t id = (uint32_t) (v >> 32);
+    const int tLen = (int) ((v >> 16) & 0xFFFF), tPos0 = (int) (v & 0xFFFF);
+    const bool targetIsReverse = (key & BIT63) == 0;
+    int qPos, tPos; bool qRev;
+    if (repIsReverse && !targetIsReverse) { qPos = repPos; tPos = tPos0; qRev = true; }
+    else if (repIsReverse && targetIsReverse) { qPos = (queryLen - 1) - repPos; tPos = (tLen - 1) - tPos0; qRev = false; }
+    else if (!repIsReverse && targetIsReverse) { qPos = (queryLen - 1) - repPos; tPos = (tLen - 1) - tPos0; qRev = true; }
+    else { qPos = repPos; tPos = tPos0; qRev = false; }
+    const int diagonal = (int) (short) qPos - (int) (short) tPos;
+    const bool canBeExtended = diagonal < 0 || (diagonal > (queryLen - tLen));
+    const bool cbc = canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) tLen);
+    const bool keep = (a.onlyExtendable == 0 && cbc) || (canBeExtended && a.onlyExtendable != 0);
+    startIo[i] = keep ? packGroupKey(a, repId, id, (int) (short) diagonal, !qRev) : ~0ull;
+}
+
+// order preserving compaction of the kept keys: tiles of 4096 (256 threads x 16 consecutive items)
+constexpr int CP_ITEMS = 16, CP_TILE = 256 * CP_ITEMS;
+__global__ __launch_bounds__(256) void k_tile_count(const uint64_t *__restrict__ in, uint64_t n, unsigned long long *__restrict__ tileCnt) {
+    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE + (uint64_t) threadIdx.x * CP_ITEMS;
+    unsigned int c = 0;
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; j++) if (base + j < n) c += in[base + j] != ~0ull;
+    typedef hipcub::BlockReduce<unsigned int, 256> BR;
+    __shared__ typename BR::TempStorage tmp;
+    const unsigned int tot = BR(tmp).Sum(c);
+    if (threadIdx.x == 0) tileCnt[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_tile_compact(const uint64_t *__restrict__ in, uint64_t n, const unsigned long long *__restrict__ tileOff, uint64_t *__restrict__ out) {
+    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE + (uint64_t) threadIdx.x * CP_ITEMS;
+    uint64_t v[CP_ITEMS]; unsigned int c = 0;
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; j++) { v[j] = (base + j < n) ? in[base + j] : ~0ull; c += v[j] != ~0ull; }
+    typedef hipcub::BlockScan<unsigned int, 256> BS;
+    __shared__ typename BS::TempStorage tmp;
+    unsigned int off;
+    BS(tmp).ExclusiveSum(c, off);
+    uint64_t o = tileOff[blockIdx.x] + off;
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; j++) if (v[j] != ~0ull) out[o++] = v[j];
 }
 
 struct U8toU32 { __host__ __device__ uint32_t operator()(const uint8_t &v) const { return v; } };
@@ -412,12 +445,22 @@ __global__ __launch_bounds__(256) void k_place(VoteArgs a, const uint32_t *__res
     const uint32_t rep = (uint32_t) (a.keys[i] >> (a.diagBits + 1 + a.idBits));
     out[off[rep] + 1 + ((uint64_t) rank[i] - perRepScan[rep])] = a.hit[i];
 }
-__global__ void k_slot_counts(const uint32_t *__restrict__ len, uint32_t n, int k, unsigned long long *__restrict__ slots) {
+__global__ void k_len_keys(const uint32_t *__restrict__ len, uint32_t n, uint32_t maxLen, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;
-    if (i == n) { slots[i] = 0; return; }
-    const uint32_t L = len[i];
-    slots[i] = 1ull + ((L >= (uint32_t) k) ? (L - k + 1) : 0);
+    if (i < n) { key[i] = maxLen - len[i]; val[i] = i; }   // ascending key = descending length; stable sort keeps ids ascending
+}
+// slots of the r-th sequence in (length desc, id asc) order
+__global__ void k_slot_counts(const uint32_t *__restrict__ len, const uint32_t *__restrict__ order, uint32_t n, int k, unsigned long long *__restrict__ slots) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n) return;
+    if (r == n) { slots[r] = 0; return; }
+    const uint32_t L = len[order[r]];
+    slots[r] = 1ull + ((L >= (uint32_t) k) ? (L - k + 1) : 0);
+}
+__global__ void k_slot_scatter(const uint32_t *__restrict__ order, const unsigned long long *__restrict__ ordOff, uint32_t n, uint64_t *__restrict__ slotOff) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) slotOff[order[r]] = ordOff[r];
+    if (r == n) slotOff[n] = ordOff[n];
 }
 __global__ void k_classify(const uint32_t *__restrict__ len, uint32_t n, int k, uint32_t shortCap, uint32_t *__restrict__ listShort,
                            uint32_t *__restrict__ listLong, unsigned int *__restrict__ cnt, uint32_t longCap) {
@@ -475,18 +518,28 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     }
     hipMemsetAsync(counters.p, 0, 8 * 8, s);
     hipMemsetAsync(cls.p, 0, 8 * 4, s);
-    // one slot per k-mer position + one for the whole-sequence tuple, at a fixed offset per sequence (no global counter)
-    hipLaunchKernelGGL(k_slot_counts, dim3((n + 256) / 256), dim3(256), 0, s, db->len, n, k, slots.p);
-    {
-        size_t sb = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, sb, slots.p, (unsigned long long *) slotOff.p, (int) (n + 1), s);
-        DevBuf<char> t0;
-        if (!t0.alloc(sb + 256)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
-        hipcub::DeviceScan::ExclusiveSum(t0.p, sb, slots.p, (unsigned long long *) slotOff.p, (int) (n + 1), s);
-        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: slot scan failed"); return CDM_ERR_HIP; }
-    }
+    // One slot per k-mer position + one for the whole-sequence tuple, at a fixed offset per sequence (no global counter).
+    // Slots are laid out in (sequence length descending, id ascending) order: after the stable k-mer sort the first tuple
+    // of every run is then the representative.
     uint64_t capacity = 0;
-    hipMemcpy(&capacity, slotOff.p + n, 8, hipMemcpyDeviceToHost);
+    {
+        DevBuf<uint32_t> lk0, lk1, lv0, lv1; DevBuf<unsigned long long> ordOff;
+        if (!lk0.alloc(n) || !lk1.alloc(n) || !lv0.alloc(n) || !lv1.alloc(n) || !ordOff.alloc((size_t) n + 1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+        hipLaunchKernelGGL(k_len_keys, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, db->maxLen, lk0.p, lv0.p);
+        rocprim::double_buffer<uint32_t> lk(lk0.p, lk1.p), lv(lv0.p, lv1.p);
+        size_t sb0 = 0, sb1 = 0;
+        const unsigned lenBits = bitsFor((uint64_t) db->maxLen + 2);
+        rocprim::radix_sort_pairs(nullptr, sb0, lk, lv, (size_t) n, 0, lenBits, s);
+        hipcub::DeviceScan::ExclusiveSum(nullptr, sb1, slots.p, ordOff.p, (int) (n + 1), s);
+        DevBuf<char> t0;
+        if (!t0.alloc(std::max(sb0, sb1) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+        rocprim::radix_sort_pairs(t0.p, sb0, lk, lv, (size_t) n, 0, lenBits, s);
+        hipLaunchKernelGGL(k_slot_counts, dim3((n + 256) / 256), dim3(256), 0, s, db->len, lv.current(), n, k, slots.p);
+        hipcub::DeviceScan::ExclusiveSum(t0.p, sb1, slots.p, ordOff.p, (int) (n + 1), s);
+        hipLaunchKernelGGL(k_slot_scatter, dim3((n + 256) / 256), dim3(256), 0, s, lv.current(), ordOff.p, n, slotOff.p);
+        hipMemcpyAsync(&capacity, ordOff.p + n, 8, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: slot layout failed"); return CDM_ERR_HIP; }
+    }
     const unsigned long long nTuples = capacity;
 
     rocprim::double_buffer<uint64_t> keys, vals;
@@ -526,23 +579,34 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     hipEventRecord(ctx->ev0, s);
     if (rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) nTuples, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev1, s);
-    // ---- K3
+    // ---- K3: run starts (max-scan), parallel emit, order-preserving compaction
     GroupArgs ga;
     ga.keys = keys.current(); ga.vals = vals.current(); ga.n = nTuples; ga.onlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode;
-    ga.covThr = par->cov_thr; ga.outKeys = keys.alternate(); ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias;
-    if (nTuples) hipLaunchKernelGGL(k_groups, dim3((unsigned) ((nTuples + 255) / 256)), dim3(256), 0, s, ga);
-    // non-first tuples of a run are written by their run's first thread; runs of one write ~0 themselves
-    // compact the kept keys (stable) into vals.alternate() (free now)
+    ga.covThr = par->cov_thr; ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias;
+    unsigned long long *startIo = (unsigned long long *) keys.alternate();   // free after the sort
     uint64_t *gkeys = vals.alternate();
-    unsigned long long *dSel = counters.p + 2;
-    size_t selBytes = 0;
-    rocprim::select(nullptr, selBytes, ga.outKeys, gkeys, dSel, (size_t) nTuples, NotDropped(), s);
-    DevBuf<char> tmp2;
-    if (!tmp2.alloc(selBytes + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (select temp)"); return CDM_ERR_HIP; }
-    rocprim::select(tmp2.p, selBytes, ga.outKeys, gkeys, dSel, (size_t) nTuples, NotDropped(), s);
     unsigned long long nGroup = 0;
-    hipMemcpyAsync(&nGroup, dSel, 8, hipMemcpyDeviceToHost, s);
-    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    {
+        auto startIt = rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned long long>(0ull), StartIndex{ga.keys});
+        size_t sb = 0, sb2 = 0;
+        rocprim::inclusive_scan(nullptr, sb, startIt, startIo, (size_t) nTuples, MaxU64(), s);
+        const uint64_t nTiles = (nTuples + CP_TILE - 1) / CP_TILE;
+        DevBuf<unsigned long long> tileCnt, tileOff;
+        if (!tileCnt.alloc(nTiles + 1) || !tileOff.alloc(nTiles + 1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+        hipcub::DeviceScan::ExclusiveSum(nullptr, sb2, tileCnt.p, tileOff.p, (int) (nTiles + 1), s);
+        DevBuf<char> tmp2;
+        if (!tmp2.alloc(std::max(sb, sb2) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (scan temp)"); return CDM_ERR_HIP; }
+        if (nTuples) {
+            rocprim::inclusive_scan(tmp2.p, sb, startIt, startIo, (size_t) nTuples, MaxU64(), s);
+            hipLaunchKernelGGL(k_groups, dim3((unsigned) ((nTuples + 255) / 256)), dim3(256), 0, s, ga, startIo);
+            hipLaunchKernelGGL(k_tile_count, dim3((unsigned) nTiles), dim3(256), 0, s, (const uint64_t *) startIo, (uint64_t) nTuples, tileCnt.p);
+        }
+        hipMemsetAsync(tileCnt.p + nTiles, 0, 8, s);
+        hipcub::DeviceScan::ExclusiveSum(tmp2.p, sb2, tileCnt.p, tileOff.p, (int) (nTiles + 1), s);
+        if (nTuples) hipLaunchKernelGGL(k_tile_compact, dim3((unsigned) nTiles), dim3(256), 0, s, (const uint64_t *) startIo, (uint64_t) nTuples, tileOff.p, gkeys);
+        hipMemcpyAsync(&nGroup, tileOff.p + nTiles, 8, hipMemcpyDeviceToHost, s);
+        { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    }
     float msSort1 = 0; hipEventElapsedTime(&msSort1, ctx->ev0, ctx->ev1);
 
     // ---- sort 2: by (rep, id, diagonal) = key bits 1.., stable; strand bit 0 rides along
