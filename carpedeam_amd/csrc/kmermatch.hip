@@ -395,24 +395,23 @@ struct VoteArgs {
     const uint64_t *keys;   // sorted (rep, id, diag), strand in bit 0
     uint64_t n;
     uint32_t idBits, diagBits; int diagBias;
-    uint8_t *flag;          // 1 where a (rep, target != rep) segment starts
-    HitRec *hit;            // per segment start
     unsigned long long *perRep;  // [nSeq] number of hits per representative
 };
-__global__ __launch_bounds__(256) void k_vote(VoteArgs a) {
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+// a (rep, target != rep) segment starts at i
+__device__ __forceinline__ bool validStart(const VoteArgs &a, uint64_t i, uint32_t &rep, uint32_t &target) {
+    const uint64_t seg = a.keys[i] >> (a.diagBits + 1);
+    if (i > 0 && (a.keys[i - 1] >> (a.diagBits + 1)) == seg) return false;
+    target = (uint32_t) (seg & ((1ull << a.idBits) - 1)); rep = (uint32_t) (seg >> a.idBits);
+    return target != rep;   // self tuples give no hit (:898-903)
+}
+// writeKmerMatcherResult's inner loop for the segment that starts at i (:867-910)
+__device__ __forceinline__ HitRec voteSegment(const VoteArgs &a, uint64_t i, uint32_t target) {
     const uint64_t idMask = (1ull << a.idBits) - 1, diagMask = (1ull << a.diagBits) - 1;
     const uint64_t key = a.keys[i];
-    const uint64_t seg = key >> (a.diagBits + 1);              // rep|id
-    a.flag[i] = 0;
-    if (i > 0 && (a.keys[i - 1] >> (a.diagBits + 1)) == seg) return;
-    const uint32_t target = (uint32_t) (seg & idMask), rep = (uint32_t) (seg >> a.idBits);
-    if (target == rep) return;                                  // self tuples (:898-903)
     // the writer scans while the TARGET id stays the same, also across a change of representative (:875-887)
-    uint64_t kk = i; uint32_t prevDiag = (uint32_t) ((key >> 1) & diagMask), diagonal = prevDiag;
+    uint32_t prevDiag = (uint32_t) ((key >> 1) & diagMask), diagonal = prevDiag;
     unsigned long long maxDiag = 0, diagCnt = 0, top = 0; int bestRev = (key & 1ull) ? 0 : 1;
-    for (; kk < a.n; kk++) {
+    for (uint64_t kk = i; kk < a.n; kk++) {
         const uint64_t k2 = a.keys[kk];
         if ((uint32_t) ((k2 >> (a.diagBits + 1)) & idMask) != target) break;
         const uint32_t d = (uint32_t) ((k2 >> 1) & diagMask);
@@ -424,9 +423,41 @@ __global__ __launch_bounds__(256) void k_vote(VoteArgs a) {
     h.target = target;
     h.score = bestRev ? -(int) top : (int) top;
     h.diagonal = (int) (short) ((int) diagonal - a.diagBias);
-    a.hit[i] = h;
-    a.flag[i] = 1;
-    atomicAdd(&a.perRep[rep], 1ull);
+    return h;
+}
+// tiles of 4096 tuples (256 threads x 16 consecutive): number of hit-producing segment starts per tile and per representative
+__global__ __launch_bounds__(256) void k_seg_count(VoteArgs a, unsigned long long *__restrict__ tileCnt) {
+    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE + (uint64_t) threadIdx.x * CP_ITEMS;
+    unsigned int c = 0;
+    for (int j = 0; j < CP_ITEMS; j++) {
+        uint32_t rep, target;
+        if (base + j < a.n && validStart(a, base + j, rep, target)) { c++; atomicAdd(&a.perRep[rep], 1ull); }
+    }
+    typedef hipcub::BlockReduce<unsigned int, 256> BR;
+    __shared__ typename BR::TempStorage tmp;
+    const unsigned int tot = BR(tmp).Sum(c);
+    if (threadIdx.x == 0) tileCnt[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_seg_place(VoteArgs a, const unsigned long long *__restrict__ tileOff, const unsigned long long *__restrict__ perRepScan,
+                                                   const uint64_t *__restrict__ off, HitRec *__restrict__ out) {
+    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE + (uint64_t) threadIdx.x * CP_ITEMS;
+    unsigned int c = 0, mask = 0;
+    for (int j = 0; j < CP_ITEMS; j++) {
+        uint32_t rep, target;
+        if (base + j < a.n && validStart(a, base + j, rep, target)) { c++; mask |= 1u << j; }
+    }
+    typedef hipcub::BlockScan<unsigned int, 256> BS;
+    __shared__ typename BS::TempStorage tmp;
+    unsigned int pre;
+    BS(tmp).ExclusiveSum(c, pre);
+    unsigned long long rank = tileOff[blockIdx.x] + pre;   // number of hit-producing segments before this one, whole array
+    for (int j = 0; j < CP_ITEMS; j++) {
+        if (!((mask >> j) & 1u)) continue;
+        uint32_t rep, target;
+        validStart(a, base + j, rep, target);
+        out[off[rep] + 1 + (rank - perRepScan[rep])] = voteSegment(a, base + j, target);
+        rank++;
+    }
 }
 __global__ void k_offsets(const unsigned long long *__restrict__ perRepScan, uint32_t n, uint64_t *__restrict__ off) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -437,13 +468,6 @@ __global__ void k_self(const uint64_t *__restrict__ off, uint32_t n, HitRec *__r
     if (q >= n) return;
     HitRec h; h.target = q; h.score = 0; h.diagonal = 0;
     out[off[q]] = h;
-}
-__global__ __launch_bounds__(256) void k_place(VoteArgs a, const uint32_t *__restrict__ rank, const unsigned long long *__restrict__ perRepScan,
-                                               const uint64_t *__restrict__ off, HitRec *__restrict__ out) {
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n || !a.flag[i]) return;
-    const uint32_t rep = (uint32_t) (a.keys[i] >> (a.diagBits + 1 + a.idBits));
-    out[off[rep] + 1 + ((uint64_t) rank[i] - perRepScan[rep])] = a.hit[i];
 }
 __global__ void k_len_keys(const uint32_t *__restrict__ len, uint32_t n, uint32_t maxLen, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -619,24 +643,24 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     if (rocprim::radix_sort_keys(tmp3.p, tmpBytes2, g, (size_t) nGroup, 1, 2 * idBits + diagBits + 1, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev1, s);
 
-    // ---- K4
-    DevBuf<uint8_t> flag; DevBuf<HitRec> segHit; DevBuf<uint32_t> rank; DevBuf<unsigned long long> perRep, perRepScan;
-    if (!flag.alloc(nGroup) || !segHit.alloc(nGroup) || !rank.alloc(nGroup) || !perRep.alloc((size_t) n + 1) || !perRepScan.alloc((size_t) n + 1)) {
+    // ---- K4: count hit-producing segments (per tile and per representative), scan, vote + place
+    DevBuf<unsigned long long> perRep, perRepScan, vTileCnt, vTileOff;
+    const uint64_t vTiles = (nGroup + CP_TILE - 1) / CP_TILE;
+    if (!perRep.alloc((size_t) n + 1) || !perRepScan.alloc((size_t) n + 1) || !vTileCnt.alloc(vTiles + 1) || !vTileOff.alloc(vTiles + 1)) {
         cdm_set_error("cdm_kmermatch: out of device memory (vote)"); return CDM_ERR_HIP;
     }
-    if (nGroup >= 0x7FFFFFFFull) { cdm_set_error("cdm_kmermatch: more than 2^32 group tuples"); return CDM_ERR_UNSUPPORTED; }
     hipMemsetAsync(perRep.p, 0, ((size_t) n + 1) * 8, s);
+    hipMemsetAsync(vTileCnt.p, 0, (vTiles + 1) * 8, s);
     VoteArgs va;
-    va.keys = g.current(); va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.flag = flag.p; va.hit = segHit.p; va.perRep = perRep.p;
-    if (nGroup) hipLaunchKernelGGL(k_vote, dim3((unsigned) ((nGroup + 255) / 256)), dim3(256), 0, s, va);
+    va.keys = g.current(); va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.perRep = perRep.p;
+    if (nGroup) hipLaunchKernelGGL(k_seg_count, dim3((unsigned) vTiles), dim3(256), 0, s, va, vTileCnt.p);
     size_t sb1 = 0, sb2 = 0;
     hipcub::DeviceScan::ExclusiveSum(nullptr, sb1, perRep.p, perRepScan.p, (int) (n + 1), s);
-    hipcub::TransformInputIterator<uint32_t, U8toU32, uint8_t *> flagIt(flag.p, U8toU32());
-    hipcub::DeviceScan::ExclusiveSum(nullptr, sb2, flagIt, rank.p, (int) std::max<unsigned long long>(nGroup, 1), s);
+    hipcub::DeviceScan::ExclusiveSum(nullptr, sb2, vTileCnt.p, vTileOff.p, (int) (vTiles + 1), s);
     DevBuf<char> tmp4;
     if (!tmp4.alloc(std::max(sb1, sb2) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (scan temp)"); return CDM_ERR_HIP; }
     hipcub::DeviceScan::ExclusiveSum(tmp4.p, sb1, perRep.p, perRepScan.p, (int) (n + 1), s);
-    if (nGroup) hipcub::DeviceScan::ExclusiveSum(tmp4.p, sb2, flagIt, rank.p, (int) nGroup, s);
+    hipcub::DeviceScan::ExclusiveSum(tmp4.p, sb2, vTileCnt.p, vTileOff.p, (int) (vTiles + 1), s);
     cdm_hits *res = new cdm_hits(); res->n = n;
     if (cdmMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { delete res; cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipLaunchKernelGGL(k_offsets, dim3((n + 256) / 256), dim3(256), 0, s, perRepScan.p, n, res->off);
@@ -646,7 +670,7 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     res->count = total;
     if (cdmMalloc(&res->rec, (total + 1) * sizeof(HitRec)) != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipLaunchKernelGGL(k_self, dim3((n + 255) / 256), dim3(256), 0, s, res->off, n, res->rec);
-    if (nGroup) hipLaunchKernelGGL(k_place, dim3((unsigned) ((nGroup + 255) / 256)), dim3(256), 0, s, va, rank.p, perRepScan.p, res->off, res->rec);
+    if (nGroup) hipLaunchKernelGGL(k_seg_place, dim3((unsigned) vTiles), dim3(256), 0, s, va, vTileOff.p, perRepScan.p, res->off, res->rec);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: placing hits failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     float msSort2 = 0; hipEventElapsedTime(&msSort2, ctx->ev0, ctx->ev1);
     ctx->lastMs[2] = msSort1 + msSort2;
