@@ -1,0 +1,233 @@
+// carpedeam (MI355X build): the module surface of the reference's hot path.
+//
+//   carpedeam kmermatcher           <seqDB> <prefDB> [flags]                  lib/mmseqs/src/linclust/kmermatcher.cpp:786
+//   carpedeam rescorediagonal       <qDB> <tDB> <prefDB> <alnDB> [flags]      lib/mmseqs/src/alignment/rescorediagonal.cpp:381
+//   carpedeam ancient_correction    <seqDB> <alnDB> <outDB> [flags]           src/assembler/correction.cpp:492
+//   carpedeam ancient_read_assemble <seqDB> <alnDB> <outDB> [flags]           src/assembler/ancientReadsResults.cpp:598
+//
+// Same positional arguments, flag names, on-disk DB formats and exit codes as the reference modules, so the workflow script
+// (data/nuclassemble.sh:105,115,126,136) can call this binary for these four stages.  Each module reads its DBs, hands the
+// work to the gfx950 library through the C ABI (include/carpedeam_hip.h) and writes the result DB with the reference's text
+// codecs.  There is no CPU path: without an MI355X the module exits with an error, like any other fatal error in the
+// reference ("Debug(Debug::ERROR) << ...; EXIT(EXIT_FAILURE)").
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "carpedeam_hip.h"
+#include "mmdb.h"
+
+namespace {
+[[noreturn]] void die(const std::string &msg) { fprintf(stderr, "%s\n", msg.c_str()); exit(EXIT_FAILURE); }
+void check(int rc, const char *what) { if (rc != CDM_OK) die(std::string(what) + ": " + cdm_last_error()); }
+
+struct Args { std::vector<std::string> pos; std::map<std::string, std::string> flag; };
+Args parse(int argc, char **argv) {
+    Args a;
+    for (int i = 0; i < argc; i++) {
+        std::string s = argv[i];
+        if (s.size() > 1 && s[0] == '-' && !isdigit((unsigned char) s[1])) { if (i + 1 < argc) { a.flag[s] = argv[i + 1]; i++; } }
+        else a.pos.push_back(s);
+    }
+    return a;
+}
+float fflag(Args &a, const char *n, float d) { return a.flag.count(n) ? strtof(a.flag[n].c_str(), NULL) : d; }
+long iflag(Args &a, const char *n, long d) { return a.flag.count(n) ? strtol(a.flag[n].c_str(), NULL, 10) : d; }
+
+cdm_ctx *openCtx() {
+    cdm_ctx *ctx = NULL;
+    const char *dev = getenv("CARPEDEAM_DEVICE");
+    check(cdm_ctx_create(dev ? atoi(dev) : 0, &ctx), "Can not initialise the MI355X device");
+    return ctx;
+}
+cdm_seqdb *uploadSeqDb(cdm_ctx *ctx, const MmDb &db) {
+    std::vector<uint32_t> lens(db.size());
+    for (size_t i = 0; i < db.size(); i++) lens[i] = db.len[i] >= 2 ? (uint32_t) (db.len[i] - 2) : 0;   // DBReader::getSeqLen
+    cdm_seqdb *h = NULL;
+    check(cdm_seqdb_upload(ctx, db.data.data(), db.off.data(), lens.data(), db.key.data(), db.ext.data(), db.size(), &h), "Can not load the sequence DB");
+    return h;
+}
+void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) {
+    const uint64_t n = cdm_seqdb_size(h);
+    std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
+    check(cdm_seqdb_meta(ctx, h, lens.data(), keys.data(), ext.data()), "meta");
+    std::vector<uint64_t> offs(n); uint64_t tot = 0;
+    for (uint64_t i = 0; i < n; i++) { offs[i] = tot; tot += lens[i] + 1; }
+    std::string buf(tot, '\0');
+    check(cdm_seqdb_download(ctx, h, &buf[0], offs.data()), "download");
+    MmDbWriter w(path, dbtype);
+    for (uint64_t i = 0; i < n; i++) w.add(keys[i], buf.substr(offs[i], lens[i] + 1), ext[i]);
+    std::string err; if (!w.close(&err)) die(err);
+}
+// ---- text codecs
+char *utoa(unsigned long long v, char *p) { char b[24]; int n = 0; do { b[n++] = '0' + v % 10; v /= 10; } while (v); while (n) *p++ = b[--n]; return p; }
+char *itoa(long long v, char *p) { if (v < 0) { *p++ = '-'; return utoa((unsigned long long) -v, p); } return utoa(v, p); }
+char *seqIdText(float s, char *p) {   // Util::fastSeqIdToBuffer + the tab overwriting its last char (Util.cpp:278-307, Matcher.cpp:362-363)
+    if (s == 1.0) { memcpy(p, "1.00", 4); return p + 4; }
+    *p++ = '0'; *p++ = '.';
+    if (s < 0.10) *p++ = '0';
+    if (s < 0.01) *p++ = '0';
+    return itoa((int) (s * 1000), p);
+}
+void parseAlnDb(const MmDb &aln, const MmDb &seq, std::vector<uint64_t> &off, std::vector<cdm_aln> &rec) {   // Matcher.cpp:274-353
+    off.assign(seq.size() + 1, 0);
+    const double lam = 0x1.4478764a1b24ap-1, logk = log(0x1.a1c1e68ea2ab1p-2);
+    for (size_t i = 0; i < seq.size(); i++) {
+        const int64_t a = aln.idOf(seq.key[i]);
+        if (a >= 0) {
+            const char *d = aln.entry(a);
+            while (*d) {
+                char *e; cdm_aln r;
+                const uint32_t tkey = strtoul(d, &e, 10); d = e + 1;
+                const int bits = strtol(d, &e, 10); d = e + 1;
+                r.seq_id = (float) strtod(d, &e); d = e + 1;
+                strtod(d, &e); d = e + 1;
+                r.q_start = strtol(d, &e, 10); d = e + 1; r.q_end = strtol(d, &e, 10); d = e + 1; strtol(d, &e, 10); d = e + 1;
+                r.db_start = strtol(d, &e, 10); d = e + 1; r.db_end = strtol(d, &e, 10); d = e + 1; strtol(d, &e, 10); d = e;
+                const int64_t t = seq.idOf(tkey);
+                if (t < 0) die("Invalid database read for key " + std::to_string(tkey));
+                r.target = (uint32_t) t; r.ident = -1;
+                r.raw_score = static_cast<int>((logk + bits * std::log(2.0)) / lam + 0.5);   // computeRawScoreFromBitScore as the consumers do
+                rec.push_back(r);
+                while (*d && *d != '\n') d++;
+                if (*d == '\n') d++;
+            }
+        }
+        off[i + 1] = rec.size();
+    }
+}
+cdm_ancient_params ancientParams(Args &a) {
+    cdm_ancient_params p;
+    p.seq_id_thr = fflag(a, "--min-seq-id", 0.9f); p.corr_reads_ry_seq_id = fflag(a, "--min-ryseq-id-corr-reads", 0.99f); p.ry_seq_id_thr = 0.99f;
+    p.rand_align_penal = fflag(a, "--ext-random-align", 0.85f); p.excess_penal = fflag(a, "--excess-penalty", 0.0625f);
+    p.likelihood_threshold = fflag(a, "--likelihood-ratio-threshold", 0.5f); p.unsafe = (int) iflag(a, "--unsafe", 0);
+    p.min_cov_safe = (int) iflag(a, "--min-cov-safe", 5); p.max_seq_len = (uint64_t) iflag(a, "--max-seq-len", 65535);
+    return p;
+}
+
+int kmermatcher(Args &a) {
+    if (a.pos.size() < 2) die("Usage: carpedeam kmermatcher <i:sequenceDB> <o:prefilterDB>");
+    MmDb seq; std::string err; if (!seq.load(a.pos[0], &err)) die(err);
+    cdm_ctx *ctx = openCtx();
+    cdm_seqdb *db = uploadSeqDb(ctx, seq);
+    cdm_kmer_params p;
+    p.kmer_size = (int) iflag(a, "-k", 15); p.kmers_per_seq = (int) iflag(a, "--kmer-per-seq", 21); p.kmers_per_seq_scale = fflag(a, "--kmer-per-seq-scale", 0.2f);
+    p.hash_shift = (uint64_t) iflag(a, "--hash-shift", 67); p.ignore_multi_kmer = (int) iflag(a, "--ignore-multi-kmer", 0);
+    p.include_only_extendable = (int) iflag(a, "--include-only-extendable", 0); p.cov_mode = (int) iflag(a, "--cov-mode", 0); p.cov_thr = fflag(a, "-c", 0.8f);
+    cdm_hits *hits = NULL;
+    check(cdm_kmermatch(ctx, db, &p, &hits), "kmermatcher");
+    std::vector<uint64_t> off(seq.size() + 1); std::vector<cdm_hit> rec(cdm_hits_count(hits));
+    check(cdm_hits_download(ctx, hits, off.data(), rec.data()), "download");
+    MmDbWriter w(a.pos[1], 14);   // DBTYPE_PREFILTER_REV_RES (kmermatcher.cpp:682)
+    char b[64];
+    for (size_t i = 0; i < seq.size(); i++) {
+        std::string out;
+        for (uint64_t h = off[i]; h < off[i + 1]; h++) {   // QueryMatcher::prefilterHitToBuffer
+            char *p2 = utoa(seq.key[rec[h].target], b); *p2++ = '\t'; p2 = itoa(rec[h].score, p2); *p2++ = '\t'; p2 = itoa((short) rec[h].diagonal, p2); *p2++ = '\n';
+            out.append(b, p2 - b);
+        }
+        // representatives' records carry wasExtended 0, fill-in records the sequence's flag (kmermatcher.cpp:727, DBWriter default)
+        w.add(seq.key[i], std::move(out), (off[i + 1] - off[i] > 1) ? 0 : seq.ext[i]);
+    }
+    if (!w.close(&err)) die(err);
+    cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
+    return EXIT_SUCCESS;
+}
+
+int rescorediagonal(Args &a) {
+    if (a.pos.size() < 4) die("Usage: carpedeam rescorediagonal <i:queryDB> <i:targetDB> <i:prefilterDB> <o:resultDB>");
+    if (a.pos[0] != a.pos[1]) die("rescorediagonal: query and target DB must be the same on the MI355X path");
+    if (iflag(a, "--rescore-mode", 3) != 3) die("rescorediagonal: only --rescore-mode 3 is implemented on the MI355X path");
+    MmDb seq, pref; std::string err; if (!seq.load(a.pos[1], &err) || !pref.load(a.pos[2], &err)) die(err);
+    cdm_ctx *ctx = openCtx();
+    cdm_seqdb *db = uploadSeqDb(ctx, seq);
+    std::vector<uint64_t> off(seq.size() + 1, 0); std::vector<cdm_hit> rec;
+    for (size_t i = 0; i < seq.size(); i++) {   // QueryMatcher::parsePrefilterHits
+        const int64_t pi = pref.idOf(seq.key[i]);
+        if (pi >= 0) {
+            const char *d = pref.entry(pi);
+            while (*d) {
+                char *e; cdm_hit h;
+                const uint32_t tkey = strtoul(d, &e, 10); d = e + 1; h.score = strtol(d, &e, 10); d = e + 1; h.diagonal = (short) strtol(d, &e, 10); d = e;
+                const int64_t t = seq.idOf(tkey);
+                if (t < 0) die("Invalid database read for key " + std::to_string(tkey));
+                h.target = (uint32_t) t; rec.push_back(h);
+                while (*d && *d != '\n') d++;
+                if (*d == '\n') d++;
+            }
+        }
+        off[i + 1] = rec.size();
+    }
+    cdm_hits *hits = NULL; cdm_alns *alns = NULL;
+    check(cdm_hits_upload(ctx, db, off.data(), rec.data(), &hits), "upload");
+    cdm_rescore_params p;
+    p.seq_id_thr = fflag(a, "--min-seq-id", 0.0f); p.eval_thr = a.flag.count("-e") ? strtod(a.flag["-e"].c_str(), NULL) : 0.001;
+    p.cov_mode = (int) iflag(a, "--cov-mode", 0); p.cov_thr = fflag(a, "-c", 0.0f); p.seq_id_mode = (int) iflag(a, "--seq-id-mode", 0); p.min_aln_len = (int) iflag(a, "--min-aln-len", 0);
+    check(cdm_rescore(ctx, db, hits, &p, &alns), "rescorediagonal");
+    std::vector<uint64_t> aoff(seq.size() + 1); std::vector<cdm_aln> arec(cdm_alns_count(alns));
+    check(cdm_alns_download(ctx, alns, aoff.data(), arec.data()), "download");
+    const uint64_t dbRes = cdm_seqdb_residues(db);
+    MmDbWriter w(a.pos[3], 5);
+    char b[256];
+    for (size_t i = 0; i < seq.size(); i++) {
+        if (pref.idOf(seq.key[i]) < 0) continue;
+        std::string out;
+        const int qLen = (int) (seq.len[i] - 2);
+        for (uint64_t r = aoff[i]; r < aoff[i + 1]; r++) {   // Matcher::resultToBuffer (Matcher.cpp:356-404)
+            const cdm_aln &x = arec[r];
+            const int alnLen = std::max(abs(x.q_end - x.q_start), abs(x.db_end - x.db_start)) + 1;
+            const float sid = static_cast<float>(x.ident) / static_cast<float>(alnLen);
+            char *p2 = utoa(seq.key[x.target], b); *p2++ = '\t';
+            p2 = itoa(cdm_bit_score(x.raw_score), p2); *p2++ = '\t';
+            p2 = seqIdText(sid, p2); *p2++ = '\t';
+            p2 += sprintf(p2, "%.3E", cdm_evalue(x.raw_score, qLen, dbRes)); *p2++ = '\t';
+            p2 = itoa(x.q_start, p2); *p2++ = '\t'; p2 = itoa(x.q_end, p2); *p2++ = '\t'; p2 = itoa(qLen, p2); *p2++ = '\t';
+            p2 = itoa(x.db_start, p2); *p2++ = '\t'; p2 = itoa(x.db_end, p2); *p2++ = '\t'; p2 = itoa((int) (seq.len[x.target] - 2), p2); *p2++ = '\n';
+            out.append(b, p2 - b);
+        }
+        w.add(seq.key[i], std::move(out), 0);
+    }
+    if (!w.close(&err)) die(err);
+    cdm_alns_free(alns); cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
+    return EXIT_SUCCESS;
+}
+
+int ancientModule(Args &a, bool assemble) {
+    if (a.pos.size() < 3) die(std::string("Usage: carpedeam ") + (assemble ? "ancient_read_assemble" : "ancient_correction") + " <i:sequenceDB> <i:alnResult> <o:reprSeqDB>");
+    MmDb seq, aln; std::string err; if (!seq.load(a.pos[0], &err) || !aln.load(a.pos[1], &err)) die(err);
+    cdm_ctx *ctx = openCtx();
+    check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");
+    cdm_seqdb *db = uploadSeqDb(ctx, seq);
+    std::vector<uint64_t> off; std::vector<cdm_aln> rec;
+    parseAlnDb(aln, seq, off, rec);
+    cdm_alns *alns = NULL; cdm_seqdb *out = NULL;
+    check(cdm_alns_upload(ctx, db, off.data(), rec.data(), &alns), "upload");
+    cdm_ancient_params p = ancientParams(a);
+    if (assemble) check(cdm_extend(ctx, db, alns, &p, &out, NULL), "ancient_read_assemble");
+    else check(cdm_correct(ctx, db, alns, &p, &out), "ancient_correction");
+    writeSeqDb(ctx, out, a.pos[2], seq.dbtype);
+    cdm_seqdb_free(out); cdm_alns_free(alns); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
+    return EXIT_SUCCESS;
+}
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 2) { fprintf(stderr, "usage: carpedeam <kmermatcher|rescorediagonal|ancient_correction|ancient_read_assemble> <args>\n"); return EXIT_FAILURE; }
+    const std::string cmd = argv[1];
+    Args a = parse(argc - 2, argv + 2);
+    auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    if (cmd == "kmermatcher") rc = kmermatcher(a);
+    else if (cmd == "rescorediagonal") rc = rescorediagonal(a);
+    else if (cmd == "ancient_correction") rc = ancientModule(a, false);
+    else if (cmd == "ancient_read_assemble") rc = ancientModule(a, true);
+    else { fprintf(stderr, "Invalid Command: %s\n", cmd.c_str()); return EXIT_FAILURE; }
+    fprintf(stderr, "Time for processing: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return rc;
+}

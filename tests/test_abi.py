@@ -64,3 +64,17 @@ def test_host_evalue_matches_reference_table(libpath):
         ev = l.cdm_evalue(float(score), float(qlen), int(db))
         assert "%.3E" % ev == exp[2], (a, ev, exp)
         assert l.cdm_bit_score(float(score)) == int(float.fromhex(exp[1]) + 0.5), a
+
+
+def test_host_binary_fails_loudly_without_gpu(libpath, tmp_path):
+    """The module binary has no CPU path either: on a box without a GPU it exits non-zero with an error message."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from carpedeam_amd import mmdb
+    exe = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
+    assert os.path.exists(exe)
+    mmdb.write_seqdb(str(tmp_path / "s"), ["ACGT" * 10, "ACGTT" * 8])
+    r = subprocess.run([exe, "kmermatcher", str(tmp_path / "s"), str(tmp_path / "p"), "-k", "20"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr

@@ -1,0 +1,54 @@
+"""The drop-in surface: the `carpedeam` host binary run module by module on DB files with the reference's argv/flags;
+output DBs must equal the reference's goldens key by key (payload and wasExtended flag)."""
+import os
+import subprocess
+
+import pytest
+
+from carpedeam_amd import mmdb
+from gpuutil import diff_keys, gold, stage_input
+from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
+from test_oracle_golden import pref_sign_ties
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "carpedeam_amd", "carpedeam")
+
+
+def run(*args):
+    r = subprocess.run([BIN] + list(args), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name,it", [("synth2k", 0), ("synth2k", 1), ("mixed3k", 2), ("example", 0)])
+def test_modules_reproduce_reference_dbs(tmp_path, dhigh_prefix, name, it):
+    from carpedeam_amd import build
+    build.build()
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_from_keyed(t("in"), stage_input(name, it), mmdb.DBTYPE_NUCLEOTIDES)
+    run("kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
+    ties, bad = pref_sign_ties(mmdb.canon(mmdb.read_db(t("pref"))), mmdb.canon(gold(name, "pref", it)))
+    assert not bad and sum(n for _, n in ties) <= 1
+    assert mmdb.read_dbtype(t("pref")) == mmdb.DBTYPE_PREFILTER_REV_RES
+    # downstream modules consume the reference's own upstream DBs (stage isolation, as for the oracle)
+    mmdb.write_from_keyed(t("pref_ref"), gold(name, "pref", it), mmdb.DBTYPE_PREFILTER_REV_RES)
+    run("rescorediagonal", t("in"), t("in"), t("pref_ref"), t("aln"), *R_FLAGS, "--threads", "4")
+    assert not diff_keys(mmdb.read_db(t("aln")), gold(name, "aln", it))
+    assert mmdb.read_dbtype(t("aln")) == mmdb.DBTYPE_ALIGNMENT_RES
+    mmdb.write_from_keyed(t("aln_ref"), gold(name, "aln", it), mmdb.DBTYPE_ALIGNMENT_RES)
+    run("ancient_correction", t("in"), t("aln_ref"), t("corr"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "4")
+    assert not diff_keys(mmdb.read_db(t("corr")), gold(name, "corr", it))
+    mmdb.write_from_keyed(t("corr_ref"), gold(name, "corr", it), mmdb.DBTYPE_NUCLEOTIDES)
+    run("ancient_read_assemble", t("corr_ref"), t("aln_ref"), t("asm"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "4")
+    assert not diff_keys(mmdb.read_db(t("asm")), gold(name, "asm", it))
+
+
+def test_error_behaviour(tmp_path):
+    r = subprocess.run([BIN, "ancient_correction", str(tmp_path / "nope"), str(tmp_path / "nope2"), str(tmp_path / "out")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Could not open" in r.stderr
+    r = subprocess.run([BIN, "frobnicate"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Invalid Command" in r.stderr
+    mmdb.write_seqdb(str(tmp_path / "s"), ["ACGT" * 10])
+    mmdb.write_db(str(tmp_path / "a"), [(0, b"0\t74\t1.00\t1E-10\t0\t39\t40\t0\t39\t40\n")], mmdb.DBTYPE_ALIGNMENT_RES)
+    r = subprocess.run([BIN, "ancient_correction", str(tmp_path / "s"), str(tmp_path / "a"), str(tmp_path / "o"), "--ancient-damage", str(tmp_path / "missing")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "Profile not 12 fields" in r.stderr
