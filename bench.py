@@ -94,7 +94,9 @@ def main():
         synth.write_dhigh_profiles(os.path.join(d, "dhigh"))
         ctx.damage_load(os.path.join(d, "dhigh"))
     n, L = args.reads, args.len
-    db = ctx.synth(n, L, L, args.seed + rank)          # resident in HBM before the timed region
+    from carpedeam_amd import dist as cd
+    plan = cd.shard_plan(rank, world, n, args.seed)
+    db = ctx.synth(plan["n"], L, L, plan["seed"])      # resident in HBM before the timed region
     residues = db.residues
 
     def step():
@@ -104,7 +106,7 @@ def main():
         del hits
         corr = ctx.correct(db, alns)
         asm = ctx.extend(corr, alns)
-        ms = [ctx.last_kernel_ms(i) for i in range(5)]
+        ms = [ctx.last_kernel_ms(i) for i in range(7)]
         return asm, stats, ms
 
     def sync():
@@ -117,7 +119,7 @@ def main():
         del out
     sync()
     t0 = time.perf_counter()
-    kernel_ms = [0.0] * 5
+    kernel_ms = [0.0] * 7
     stats = (0, 0)
     asm = None
     for _ in range(args.steps):
@@ -126,38 +128,48 @@ def main():
         kernel_ms = [a + b for a, b in zip(kernel_ms, ms)]
     sync()
     dt = time.perf_counter() - t0
+    gathered = None
     if dist is not None:
-        tmax = torch.tensor([dt], device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        # the single data-path collective of the north star: all-gather of the per-shard contigs (lengths here; the packed
-        # bases follow the same call) - outside the timed steps' critical path only in that it runs once per job
-        lens, _, ext = asm.meta()
-        import numpy as np
-        mine = torch.tensor([int((ext == 1).sum()), int(lens[ext == 1].sum())], device="cuda", dtype=torch.int64)
-        allc = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allc, mine)
+        dt = cd.max_over_ranks(dist, dt, device="cuda")
+        # the single data-path collective of the north star: RCCL all-gather of the per-shard contigs (packed bases,
+        # lengths, keys); every rank ends up holding the contigs of all shards as one device DB
+        t1 = time.perf_counter()
+        allc = cd.allgather_contigs(dist, ctx, asm, world, key_stride=n)
+        torch.cuda.synchronize()
+        gathered = {"contigs": allc.n, "bases": allc.residues, "seconds": time.perf_counter() - t1}
     if rank == 0:
         total_bases = residues * args.steps * world
         k_ms = [m / args.steps for m in kernel_ms]
-        # dominant kernel group: kmermatcher's two radix sorts.  Algorithmic bytes per launch group:
-        # the 16-byte tuple array written once and read once = 2 * 16 * (L - k + 2) bytes per read.
+        # Dominant kernel (rocprofv3 --stats, profiles/): rocPRIM's radix_sort_onesweep_iteration on the (k-mer, payload)
+        # tuple array, launched ceil(63/8) = 8 times by sort 1 after one histogram launch.  Algorithmic bytes of ONE launch
+        # (SURVEY.md 8(d)): the 16-byte tuples read once and written once = 2 * 16 * (L - k + 2) bytes per read.  Its average
+        # launch duration is taken from the HIP-event time of the sort-1 call on the library's stream; the histogram launch
+        # of that call reads the 8-byte keys once, i.e. 1/4 of an iteration's traffic, hence the 8.25.
         tuples_per_read = L - 20 + 2
         sort_bytes = 2.0 * 16.0 * tuples_per_read * n
-        achieved = sort_bytes / (k_ms[2] * 1e-3) / 1e9 if k_ms[2] > 0 else 0.0
+        iter_ms = k_ms[5] / 8.25 if k_ms[5] > 0 else 0.0
+        achieved = sort_bytes / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
         line = {
             "metric": "corrected bases/sec on 50M x 100bp synthetic reads (dhigh)", "value": total_bases / dt, "unit": "corrected bases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (2-bit packed bases; int32 scores; software x87 f80 likelihood sums)", "data": "synthetic",
             "config": {"workload": "%d synthetic %d bp reads per GPU, dhigh, full correction + kmermatcher/rescorediagonal/ancient_read_assemble (BASELINE.json configs[2])" % (n, L),
                        "reads_per_gpu": n, "read_len": L, "seed": args.seed, "prefilter_hits": stats[0], "alignments": stats[1],
-                       "stage_kernel_ms": {"kmer_extract": k_ms[3], "kmer_sorts": k_ms[2], "rescore": k_ms[1], "correct": k_ms[0], "extend": k_ms[4]}},
-            "roofline": {"bound": "hbm", "kernel": "kmermatcher radix sorts (rocPRIM onesweep passes, sort 1 on 63-bit k-mer + sort 2 on (rep,id,diag))",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+                       "stage_kernel_ms": {"kmer_extract": k_ms[3], "kmer_sort1_call": k_ms[5], "kmer_sort2_call": k_ms[6], "rescore": k_ms[1],
+                                           "correct": k_ms[0], "extend": k_ms[4]}},
+            "roofline": {"bound": "hbm", "kernel": "rocprim radix_sort_onesweep_iteration<u64 key, u64 value> (kmermatcher sort 1, one of 8 launches per step)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": iter_ms, "launches_per_step": 8, "algorithmic_bytes_per_launch": sort_bytes,
+                         "stage_level": {"what": "whole kmermatcher stage against its algorithmic bytes (26.8 B/base, SURVEY.md 8(d))",
+                                         "achieved": 26.8 * n * L / ((k_ms[3] + k_ms[5] + k_ms[6]) * 1e-3) / 1e9 if (k_ms[3] + k_ms[5] + k_ms[6]) > 0 else 0.0,
+                                         "unit": "GB/s"}},
         }
+        if gathered is not None:
+            line["config"]["allgather_contigs"] = gathered
         if not args.no_cpu_baseline and world == 1:
             try:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_reads, L, args.seed, os.cpu_count() or 1)
+                # the pool gives a one-GPU job 16 host cores; the reference's kmermatcher slows down when oversubscribed
+                line["cpu_baseline"] = cpu_baseline(args.cpu_reads, L, args.seed, min(os.cpu_count() or 1, int(os.environ.get("CDM_CPU_THREADS", 16))))
             except Exception as e:   # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "corrected bases/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": str(e)[:200]}
         print(json.dumps(line))

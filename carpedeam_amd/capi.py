@@ -47,7 +47,7 @@ class AncientParams(C.Structure):
 EXPORTS = [
     "cdm_last_error", "cdm_ctx_create", "cdm_ctx_destroy", "cdm_ctx_sync", "cdm_ctx_stream", "cdm_ctx_last_kernel_ms",
     "cdm_seqdb_upload", "cdm_seqdb_synth", "cdm_seqdb_size", "cdm_seqdb_residues", "cdm_seqdb_max_len", "cdm_seqdb_meta",
-    "cdm_seqdb_download", "cdm_seqdb_free", "cdm_damage_load", "cdm_damage_get", "cdm_kmermatch", "cdm_hits_upload", "cdm_hits_count",
+    "cdm_seqdb_download", "cdm_seqdb_free", "cdm_seqdb_select_ext", "cdm_seqdb_words", "cdm_seqdb_copy_packed", "cdm_seqdb_from_packed", "cdm_damage_load", "cdm_damage_get", "cdm_kmermatch", "cdm_hits_upload", "cdm_hits_count",
     "cdm_hits_download", "cdm_hits_free", "cdm_rescore", "cdm_alns_upload", "cdm_alns_count", "cdm_alns_download", "cdm_alns_free",
     "cdm_evalue", "cdm_bit_score", "cdm_correct", "cdm_extend",
 ]
@@ -89,6 +89,11 @@ def lib():
         for f in (l.cdm_seqdb_free, l.cdm_hits_free, l.cdm_alns_free):
             f.argtypes = [vp]
             f.restype = None
+        l.cdm_seqdb_select_ext.argtypes = [vp, vp, C.POINTER(vp)]
+        l.cdm_seqdb_words.argtypes = [vp]
+        l.cdm_seqdb_words.restype = C.c_uint64
+        l.cdm_seqdb_copy_packed.argtypes = [vp, vp, vp, vp, vp, vp]
+        l.cdm_seqdb_from_packed.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint8, C.POINTER(vp)]
         l.cdm_damage_load.argtypes = [vp, C.c_char_p]
         l.cdm_damage_get.argtypes = [vp, vp]
         l.cdm_kmermatch.argtypes = [vp, vp, C.POINTER(KmerParams), C.POINTER(vp)]
@@ -131,6 +136,20 @@ class SeqDb:
     @property
     def residues(self):
         return int(lib().cdm_seqdb_residues(self.h))
+
+    @property
+    def words(self):
+        return int(lib().cdm_seqdb_words(self.h))
+
+    def select_ext(self):
+        """the contigs (wasExtended == 1) as a new device DB"""
+        h = C.c_void_p()
+        _check(lib().cdm_seqdb_select_ext(self.ctx.h, self.h, C.byref(h)))
+        return SeqDb(self.ctx, h)
+
+    def copy_packed(self, codes_ptr, nmask_ptr, len_ptr, key_ptr):
+        """copy the packed form into DEVICE buffers (raw pointers, e.g. torch tensor .data_ptr())"""
+        _check(lib().cdm_seqdb_copy_packed(self.ctx.h, self.h, codes_ptr, nmask_ptr, len_ptr, key_ptr))
 
     def meta(self):
         n = self.n
@@ -232,6 +251,11 @@ class Ctx:
     def synth(self, n, lo, hi, seed, n_total=None, first=0):
         h = C.c_void_p()
         _check(lib().cdm_seqdb_synth(self.h, n if n_total is None else n_total, first, n, lo, hi, seed, C.byref(h)))
+        return SeqDb(self, h)
+
+    def from_packed(self, codes_ptr, nmask_ptr, len_ptr, key_ptr, n, words, ext_value=1):
+        h = C.c_void_p()
+        _check(lib().cdm_seqdb_from_packed(self.h, codes_ptr, nmask_ptr, len_ptr, key_ptr, n, words, ext_value, C.byref(h)))
         return SeqDb(self, h)
 
     # ---- containers

@@ -310,6 +310,123 @@ extern "C" int cdm_seqdb_synth(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, ui
     return cdm_synth_impl(ctx, nTotal, first, n, lo, hi, seed, out);
 }
 
+// ------------------------------------------------------------------------------------------------ multi-GPU hand-off
+#include <hipcub/hipcub.hpp>
+namespace {
+__global__ void k_sel_words(const uint32_t *__restrict__ len, const uint8_t *__restrict__ ext, uint32_t n, uint32_t *__restrict__ selWords, uint32_t *__restrict__ selOne) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const bool s = i < n && ext[i] == 1;
+    selWords[i] = s ? (len[i] + 15) / 16 : 0; selOne[i] = s ? 1 : 0;
+}
+__global__ void k_sel_meta(const cdm_seqdb src, const uint32_t *__restrict__ rank, const uint32_t *__restrict__ wordOff, uint32_t n, cdm_seqdb dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || src.ext[i] != 1) return;
+    const uint32_t r = rank[i];
+    dst.len[r] = src.len[i]; dst.key[r] = src.key[i]; dst.ext[r] = 1; dst.hasN[r] = src.hasN[i]; dst.woff[r] = wordOff[i];
+}
+__global__ void k_sel_copy(const cdm_seqdb src, const uint32_t *__restrict__ wordOff, uint32_t n, cdm_seqdb dst) {
+    // one wave per selected sequence
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (i >= n || src.ext[i] != 1) return;
+    const uint32_t w = (src.len[i] + 15) / 16, s0 = src.woff[i], d0 = wordOff[i];
+    for (uint32_t j = lane; j < w; j += 64) {
+        dst.codes[d0 + j] = src.codes[s0 + j];
+        reinterpret_cast<uint16_t *>(dst.nmask)[d0 + j] = reinterpret_cast<const uint16_t *>(src.nmask)[s0 + j];
+    }
+}
+__global__ void k_words_of(const uint32_t *__restrict__ len, uint32_t n, uint32_t *__restrict__ w, uint8_t *__restrict__ ext, uint8_t extValue, uint8_t *__restrict__ hasN) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    w[i] = i < n ? (len[i] + 15) / 16 : 0;
+    if (i < n) { ext[i] = extValue; hasN[i] = 0; }
+}
+__global__ void k_mark_hasN(const uint32_t *__restrict__ woff, const uint32_t *__restrict__ nmask, uint32_t n, uint64_t words, uint8_t *__restrict__ hasN) {
+    const uint64_t gw = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (gw >= words || reinterpret_cast<const uint16_t *>(nmask)[gw] == 0) return;
+    uint64_t lo = 0, hi = n;
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (woff[mid] <= gw) lo = mid; else hi = mid; }
+    hasN[lo] = 1;
+}
+}  // namespace
+extern "C" uint64_t cdm_seqdb_words(const cdm_seqdb *db) { return db->words; }
+extern "C" int cdm_seqdb_select_ext(cdm_ctx *ctx, const cdm_seqdb *db, cdm_seqdb **out) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t) db->n;
+    uint32_t *selWords = nullptr, *selOne = nullptr, *wordOff = nullptr, *rank = nullptr; void *tmp = nullptr;
+    if (cdmMalloc(&selWords, ((size_t) n + 1) * 4) != hipSuccess || cdmMalloc(&selOne, ((size_t) n + 1) * 4) != hipSuccess ||
+        cdmMalloc(&wordOff, ((size_t) n + 1) * 4) != hipSuccess || cdmMalloc(&rank, ((size_t) n + 1) * 4) != hipSuccess) { cdm_set_error("cdm_seqdb_select_ext: out of device memory"); return CDM_ERR_HIP; }
+    hipLaunchKernelGGL(k_sel_words, dim3((n + 256) / 256), dim3(256), 0, s, db->len, db->ext, n, selWords, selOne);
+    size_t sb = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, sb, selWords, wordOff, (int) (n + 1), s);
+    if (cdmMalloc(&tmp, sb + 256) != hipSuccess) { cdm_set_error("cdm_seqdb_select_ext: out of device memory"); return CDM_ERR_HIP; }
+    hipcub::DeviceScan::ExclusiveSum(tmp, sb, selWords, wordOff, (int) (n + 1), s);
+    hipcub::DeviceScan::ExclusiveSum(tmp, sb, selOne, rank, (int) (n + 1), s);
+    uint32_t m = 0, words = 0;
+    hipMemcpyAsync(&m, rank + n, 4, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(&words, wordOff + n, 4, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_seqdb_select_ext failed"); return CDM_ERR_HIP; }
+    cdm_seqdb *o = nullptr;
+    int rc = cdm_seqdb_alloc(ctx, m, &o);
+    if (rc == CDM_OK) rc = seqdb_alloc_codes(o, words);
+    if (rc != CDM_OK) { cdmFree(selWords); cdmFree(selOne); cdmFree(wordOff); cdmFree(rank); cdmFree(tmp); if (o) cdm_seqdb_free(o); return rc; }
+    hipLaunchKernelGGL(k_sel_meta, dim3((n + 255) / 256), dim3(256), 0, s, *db, rank, wordOff, n, *o);
+    hipLaunchKernelGGL(k_sel_copy, dim3((unsigned) (((uint64_t) n * 64 + 255) / 256)), dim3(256), 0, s, *db, wordOff, n, *o);
+    hipMemcpyAsync(o->woff + m, &words, 4, hipMemcpyHostToDevice, s);
+    // residues / max length on the host (contig lists are small next to the read DB)
+    std::vector<uint32_t> l(m);
+    hipMemcpyAsync(l.data(), o->len, (size_t) m * 4, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    cdmFree(selWords); cdmFree(selOne); cdmFree(wordOff); cdmFree(rank); cdmFree(tmp);
+    if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_select_ext: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
+    for (uint32_t v : l) { o->residues += v; o->maxLen = std::max(o->maxLen, v); }
+    *out = o;
+    return CDM_OK;
+}
+extern "C" int cdm_seqdb_copy_packed(cdm_ctx *ctx, const cdm_seqdb *db, void *codes, void *nmask16, void *lengths, void *keys) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (codes) CDM_HIP(hipMemcpyAsync(codes, db->codes, db->words * 4, hipMemcpyDeviceToDevice, s));
+    if (nmask16) CDM_HIP(hipMemcpyAsync(nmask16, db->nmask, db->words * 2, hipMemcpyDeviceToDevice, s));
+    if (lengths) CDM_HIP(hipMemcpyAsync(lengths, db->len, db->n * 4, hipMemcpyDeviceToDevice, s));
+    if (keys) CDM_HIP(hipMemcpyAsync(keys, db->key, db->n * 4, hipMemcpyDeviceToDevice, s));
+    CDM_HIP(hipStreamSynchronize(s));
+    return CDM_OK;
+}
+extern "C" int cdm_seqdb_from_packed(cdm_ctx *ctx, const void *codes, const void *nmask16, const void *lengths, const void *keys, uint64_t n, uint64_t words,
+                                     uint8_t extValue, cdm_seqdb **out) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    cdm_seqdb *o = nullptr;
+    int rc = cdm_seqdb_alloc(ctx, n, &o);
+    if (rc == CDM_OK) rc = seqdb_alloc_codes(o, words);
+    if (rc != CDM_OK) { if (o) cdm_seqdb_free(o); return rc; }
+    uint32_t *w = nullptr; void *tmp = nullptr;
+    size_t sb = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, sb, w, o->woff, (int) (n + 1), s);
+    if (cdmMalloc(&w, (n + 1) * 4) != hipSuccess || cdmMalloc(&tmp, sb + 256) != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_from_packed: out of device memory"); return CDM_ERR_HIP; }
+    hipMemcpyAsync(o->len, lengths, n * 4, hipMemcpyDeviceToDevice, s);
+    hipMemcpyAsync(o->key, keys, n * 4, hipMemcpyDeviceToDevice, s);
+    hipMemcpyAsync(o->codes, codes, words * 4, hipMemcpyDeviceToDevice, s);
+    hipMemsetAsync(o->nmask, 0, (((uint64_t) words * 16 + 31) / 32 + 1) * 4, s);
+    hipMemcpyAsync(o->nmask, nmask16, words * 2, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(k_words_of, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, s, o->len, (uint32_t) n, w, o->ext, extValue, o->hasN);
+    hipcub::DeviceScan::ExclusiveSum(tmp, sb, w, o->woff, (int) (n + 1), s);
+    if (words) hipLaunchKernelGGL(k_mark_hasN, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, s, o->woff, o->nmask, (uint32_t) n, words, o->hasN);
+    std::vector<uint32_t> l(n);
+    hipMemcpyAsync(l.data(), o->len, n * 4, hipMemcpyDeviceToHost, s);
+    uint32_t total = 0;
+    hipMemcpyAsync(&total, o->woff + n, 4, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    cdmFree(w); cdmFree(tmp);
+    if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_from_packed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
+    if (total != words) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_from_packed: lengths need %u code words, %llu given", total, (unsigned long long) words); return CDM_ERR_INVALID; }
+    for (uint32_t v : l) { o->residues += v; o->maxLen = std::max(o->maxLen, v); }
+    *out = o;
+    return CDM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ hits / alignments
 template <typename H, typename R>
 static int csr_upload(cdm_ctx *ctx, uint64_t n, const uint64_t *offsets, const R *recs, H **out) {

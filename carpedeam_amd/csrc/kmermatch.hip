@@ -674,6 +674,8 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: placing hits failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     float msSort2 = 0; hipEventElapsedTime(&msSort2, ctx->ev0, ctx->ev1);
     ctx->lastMs[2] = msSort1 + msSort2;
+    ctx->lastMs[5] = msSort1;   // sort 1 call alone (1 histogram + ceil(63/8) onesweep launches)
+    ctx->lastMs[6] = msSort2;
     *out = res;
     return CDM_OK;
 }

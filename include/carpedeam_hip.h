@@ -51,7 +51,8 @@ int cdm_ctx_sync(cdm_ctx *ctx);
 void *cdm_ctx_stream(cdm_ctx *ctx);
 /* device time in ms of the dominant kernel(s) of the last stage call, measured with HIP events on the context stream;
  * which = 0: ancient_correction pile-up/call kernel, 1: rescore kernel, 2: kmermatcher sorts, 3: kmer extraction,
- * 4: extension kernel.  Returns a negative value when that stage has not run. */
+ * 4: extension kernel, 5: kmermatcher sort 1 (rocPRIM radix_sort_pairs call), 6: sort 2 (radix_sort_keys call).
+ * Returns a negative value when that stage has not run. */
 float cdm_ctx_last_kernel_ms(cdm_ctx *ctx, int which);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -81,6 +82,16 @@ int cdm_seqdb_meta(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t *lengths, uint32_
 /* ASCII download: out must hold sum(len[i] + 1) bytes; entry i is written at out_offsets[i] followed by '\n' */
 int cdm_seqdb_download(cdm_ctx *ctx, const cdm_seqdb *db, char *out, const uint64_t *out_offsets);
 void cdm_seqdb_free(cdm_seqdb *db);
+/* Multi-GPU hand-off (one process per GPU, RCCL all-gather of per-shard contigs): the sequences with wasExtended == 1
+ * (the contigs an ancient_read_assemble pass produced) as a new DB; its packed form copied into caller-provided DEVICE
+ * buffers (e.g. torch tensors that RCCL then all-gathers); and a DB rebuilt from such packed device buffers.
+ * Packed form: codes = 16 bases per uint32 (A,C,G,T = 0..3), every sequence starting on a word boundary, nmask = one
+ * uint16 per code word (bit j = base j is 'N'), lengths and keys one uint32 per sequence. */
+int cdm_seqdb_select_ext(cdm_ctx *ctx, const cdm_seqdb *db, cdm_seqdb **out);
+uint64_t cdm_seqdb_words(const cdm_seqdb *db);
+int cdm_seqdb_copy_packed(cdm_ctx *ctx, const cdm_seqdb *db, void *dev_codes, void *dev_nmask16, void *dev_lengths, void *dev_keys);
+int cdm_seqdb_from_packed(cdm_ctx *ctx, const void *dev_codes, const void *dev_nmask16, const void *dev_lengths, const void *dev_keys,
+                          uint64_t n, uint64_t words, uint8_t ext_value, cdm_seqdb **out);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Damage model.  Replaces the per-thread initDeamProbabilities + getSeqErrorProf calls
