@@ -107,3 +107,27 @@ def test_chain_properties_at_scale(ctx):
     idx = np.nonzero(e2 == 1)[0][:2000]
     assert all(s1[i] in s2[i] for i in idx)
     assert 0.05 * n < (e2 == 1).sum() < 0.3 * n
+
+
+def test_contig_handoff_roundtrip(ctx):
+    """select_ext -> packed device tensors -> from_packed: what the RCCL all-gather of bench.py --gpus N moves."""
+    import torch
+    db = ctx.synth(30000, 100, 100, 3)
+    _, _, _, asm = chain(ctx, db)
+    seqs, keys, ext = asm.download()
+    contigs = asm.select_ext()
+    exp = [(int(k), s) for s, k, e in zip(seqs, keys, ext) if e == 1]
+    got_s, got_k, got_e = contigs.download()
+    assert [(int(k), s) for s, k in zip(got_s, got_k)] == exp and (got_e == 1).all() and len(exp) > 1000
+    dev = torch.device("cuda", 0)
+    n, words = contigs.n, contigs.words
+    codes = torch.zeros(words, dtype=torch.int32, device=dev)
+    nmask = torch.zeros(words, dtype=torch.int16, device=dev)
+    lens = torch.zeros(n, dtype=torch.int32, device=dev)
+    kk = torch.zeros(n, dtype=torch.int32, device=dev)
+    contigs.copy_packed(codes.data_ptr(), nmask.data_ptr(), lens.data_ptr(), kk.data_ptr())
+    torch.cuda.synchronize()
+    assert int(lens.sum().item()) == contigs.residues
+    again = ctx.from_packed(codes.data_ptr(), nmask.data_ptr(), lens.data_ptr(), kk.data_ptr(), n, words, 1)
+    s2, k2, e2 = again.download()
+    assert [(int(k), s) for s, k in zip(s2, k2)] == exp and (e2 == 1).all()
