@@ -58,6 +58,29 @@ __device__ __forceinline__ uint32_t targetBase(const CorrectArgs &a, uint32_t tw
     return rev ? (3u - c) : c;
 }
 
+// exact arg-max in software x87, one accumulator at a time (keeps the register footprint of the callers small)
+template <typename F>
+__device__ __noinline__ uint32_t callBaseExact(const double *lt, const double *lq, const double *sLogD, F counts) {
+    X87 bestAcc = x87_zero(); int best = 0;
+    for (int qq = 0; qq < 4; qq++) {
+        X87 acc = x87_zero();
+#pragma unroll 1
+        for (int slot = 0; slot < 44; slot++) {
+            const uint32_t v = counts(slot);
+            const int c = (int) (v & 0xFFFFu), nr = (int) (v >> 16);
+            if (c == 0) continue;
+            const int tb = slot / 11, l = slot - tb * 11;
+            const double base2 = __dadd_rn(lt[tb], lq[qq]);
+            const double f = __dadd_rn(base2, sLogD[((0 * 11 + l) * 4 + qq) * 4 + tb]);
+            const double g = __dadd_rn(base2, sLogD[((1 * 11 + l) * 4 + qq) * 4 + tb]);
+            acc = x87_add(acc, x87_from_double(__dmul_rn((double) (c - nr), f)));
+            acc = x87_add(acc, x87_from_double(__dmul_rn((double) nr, g)));
+        }
+        if (qq == 0 || x87_lt(bestAcc, acc)) { bestAcc = acc; best = qq; }   // first maximum wins (:119-122)
+    }
+    return (uint32_t) best;
+}
+
 // mostLikeliBaseRead (src/assembler/correction.cpp:7-123) for one query position.  counts(slot) returns
 // total | reverse << 16 for slot = tBase * 11 + damage class.  keep is set when coverage <= 1 (:418-420).
 template <typename F>
@@ -82,27 +105,35 @@ __device__ __forceinline__ uint32_t callBase(const double *sLogT, const double *
     else qcls = 5;
     const double *lq = &sLogQ[(qcls * 4 + qb) * 4];
     const double *lt = &sLogT[qb * 4];
-    X87 acc[4] = {x87_zero(), x87_zero(), x87_zero(), x87_zero()};
-    for (int tb = 0; tb < 4; tb++) {
-        if (cov[tb] == 0) continue;
-        for (int l = 0; l < 11; l++) {
-            const uint32_t v = counts(tb * 11 + l);
-            const int c = (int) (v & 0xFFFFu), nr = (int) (v >> 16);
-            if (c == 0) continue;
+    // ---- decision in plain double first.  All addends are <= 0, so each of the four sums (at most 88 addends) differs from
+    // the reference's long double sum by less than 88 * 2^-52 * |sum|; when the largest sum beats every other one by more
+    // than that, the long double arg-max is the same and the extended-precision emulation is skipped.  Near ties and exact
+    // ties (the first maximum wins) go through callBaseExact.
+    double sd[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int slot = 0; slot < 44; slot++) {
+        const uint32_t v = counts(slot);
+        const int c = (int) (v & 0xFFFFu), nr = (int) (v >> 16);
+        if (c == 0) continue;
+        const int tb = slot / 11, l = slot - tb * 11;
 #pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                const double base2 = __dadd_rn(lt[tb], lq[qq]);
-                const double f = __dadd_rn(base2, sLogD[((0 * 11 + l) * 4 + qq) * 4 + tb]);
-                const double g = __dadd_rn(base2, sLogD[((1 * 11 + l) * 4 + qq) * 4 + tb]);
-                acc[qq] = x87_add(acc[qq], x87_from_double(__dmul_rn((double) (c - nr), f)));
-                acc[qq] = x87_add(acc[qq], x87_from_double(__dmul_rn((double) nr, g)));
-            }
+        for (int qq = 0; qq < 4; qq++) {
+            const double base2 = __dadd_rn(lt[tb], lq[qq]);
+            const double f = __dadd_rn(base2, sLogD[((0 * 11 + l) * 4 + qq) * 4 + tb]);
+            const double g = __dadd_rn(base2, sLogD[((1 * 11 + l) * 4 + qq) * 4 + tb]);
+            sd[qq] = __dadd_rn(sd[qq], __dmul_rn((double) (c - nr), f));
+            sd[qq] = __dadd_rn(sd[qq], __dmul_rn((double) nr, g));
         }
     }
-    int best = 0;
+    int bestD = 0;
 #pragma unroll
-    for (int qq = 1; qq < 4; qq++) if (x87_lt(acc[best], acc[qq])) best = qq;
-    return (uint32_t) best;
+    for (int qq = 1; qq < 4; qq++) if (sd[bestD] < sd[qq]) bestD = qq;
+    bool clear = true;
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++)
+        if (qq != bestD) clear = clear && (sd[bestD] - sd[qq] > 1e-12 * (fabs(sd[bestD]) + fabs(sd[qq])) + 1e-300);
+    if (clear) return (uint32_t) bestD;
+    return callBaseExact(lt, lq, sLogD, counts);
 }
 
 __global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {

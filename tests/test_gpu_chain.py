@@ -110,8 +110,19 @@ def test_chain_properties_at_scale(ctx):
 
 
 def test_contig_handoff_roundtrip(ctx):
-    """select_ext -> packed device tensors -> from_packed: what the RCCL all-gather of bench.py --gpus N moves."""
-    import torch
+    """select_ext -> packed DEVICE buffers -> from_packed: what the RCCL all-gather of bench.py --gpus N moves.
+    (device buffers come straight from the HIP runtime here; bench.py passes torch tensors' data_ptr())"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+
+    def dmalloc(nbytes):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), max(nbytes, 4)) == 0
+        return p
+
     db = ctx.synth(30000, 100, 100, 3)
     _, _, _, asm = chain(ctx, db)
     seqs, keys, ext = asm.download()
@@ -119,15 +130,14 @@ def test_contig_handoff_roundtrip(ctx):
     exp = [(int(k), s) for s, k, e in zip(seqs, keys, ext) if e == 1]
     got_s, got_k, got_e = contigs.download()
     assert [(int(k), s) for s, k in zip(got_s, got_k)] == exp and (got_e == 1).all() and len(exp) > 1000
-    dev = torch.device("cuda", 0)
     n, words = contigs.n, contigs.words
-    codes = torch.zeros(words, dtype=torch.int32, device=dev)
-    nmask = torch.zeros(words, dtype=torch.int16, device=dev)
-    lens = torch.zeros(n, dtype=torch.int32, device=dev)
-    kk = torch.zeros(n, dtype=torch.int32, device=dev)
-    contigs.copy_packed(codes.data_ptr(), nmask.data_ptr(), lens.data_ptr(), kk.data_ptr())
-    torch.cuda.synchronize()
-    assert int(lens.sum().item()) == contigs.residues
-    again = ctx.from_packed(codes.data_ptr(), nmask.data_ptr(), lens.data_ptr(), kk.data_ptr(), n, words, 1)
+    codes, nmask, lens, kk = dmalloc(words * 4), dmalloc(words * 2), dmalloc(n * 4), dmalloc(n * 4)
+    contigs.copy_packed(codes, nmask, lens, kk)
+    hl = np.zeros(n, np.uint32)
+    assert hip.hipMemcpy(hl.ctypes.data_as(ctypes.c_void_p), lens, n * 4, 2) == 0   # hipMemcpyDeviceToHost
+    assert int(hl.sum()) == contigs.residues
+    again = ctx.from_packed(codes, nmask, lens, kk, n, words, 1)
     s2, k2, e2 = again.download()
     assert [(int(k), s) for s, k in zip(s2, k2)] == exp and (e2 == 1).all()
+    for p in (codes, nmask, lens, kk):
+        hip.hipFree(p)
