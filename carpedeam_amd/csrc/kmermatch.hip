@@ -363,28 +363,39 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs a, unsigned long long 
 
 // order preserving compaction of the kept keys: tiles of 4096 (256 threads x 16 consecutive items)
 constexpr int CP_ITEMS = 16, CP_TILE = 256 * CP_ITEMS;
+// LDS index with one pad slot per 16 items: thread t walks items 16t..16t+15 without bank conflicts
+__device__ __forceinline__ int padIdx(int i) { return i + (i >> 4); }
+constexpr int CP_LDS = CP_TILE + CP_TILE / 16 + 1;
+
 __global__ __launch_bounds__(256) void k_tile_count(const uint64_t *__restrict__ in, uint64_t n, unsigned long long *__restrict__ tileCnt) {
-    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE + (uint64_t) threadIdx.x * CP_ITEMS;
+    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE;
     unsigned int c = 0;
 #pragma unroll
-    for (int j = 0; j < CP_ITEMS; j++) if (base + j < n) c += in[base + j] != ~0ull;
+    for (int j = 0; j < CP_ITEMS; j++) { const uint64_t i = base + threadIdx.x + 256 * j; if (i < n) c += in[i] != ~0ull; }   // coalesced
     typedef hipcub::BlockReduce<unsigned int, 256> BR;
     __shared__ typename BR::TempStorage tmp;
     const unsigned int tot = BR(tmp).Sum(c);
     if (threadIdx.x == 0) tileCnt[blockIdx.x] = tot;
 }
 __global__ __launch_bounds__(256) void k_tile_compact(const uint64_t *__restrict__ in, uint64_t n, const unsigned long long *__restrict__ tileOff, uint64_t *__restrict__ out) {
-    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE + (uint64_t) threadIdx.x * CP_ITEMS;
-    uint64_t v[CP_ITEMS]; unsigned int c = 0;
+    __shared__ uint64_t sIn[CP_LDS];
+    __shared__ uint64_t sOut[CP_TILE];
+    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE;
 #pragma unroll
-    for (int j = 0; j < CP_ITEMS; j++) { v[j] = (base + j < n) ? in[base + j] : ~0ull; c += v[j] != ~0ull; }
+    for (int j = 0; j < CP_ITEMS; j++) { const int li = threadIdx.x + 256 * j; const uint64_t i = base + li; sIn[padIdx(li)] = (i < n) ? in[i] : ~0ull; }
+    __syncthreads();
+    unsigned int c = 0;
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; j++) c += sIn[padIdx(threadIdx.x * CP_ITEMS + j)] != ~0ull;
     typedef hipcub::BlockScan<unsigned int, 256> BS;
     __shared__ typename BS::TempStorage tmp;
-    unsigned int off;
-    BS(tmp).ExclusiveSum(c, off);
-    uint64_t o = tileOff[blockIdx.x] + off;
+    unsigned int off, total;
+    BS(tmp).ExclusiveSum(c, off, total);
 #pragma unroll
-    for (int j = 0; j < CP_ITEMS; j++) if (v[j] != ~0ull) out[o++] = v[j];
+    for (int j = 0; j < CP_ITEMS; j++) { const uint64_t v = sIn[padIdx(threadIdx.x * CP_ITEMS + j)]; if (v != ~0ull) sOut[off++] = v; }
+    __syncthreads();
+    const uint64_t o = tileOff[blockIdx.x];
+    for (unsigned int i = threadIdx.x; i < total; i += 256) out[o + i] = sOut[i];   // coalesced
 }
 
 struct U8toU32 { __host__ __device__ uint32_t operator()(const uint8_t &v) const { return v; } };
@@ -425,26 +436,61 @@ __device__ __forceinline__ HitRec voteSegment(const VoteArgs &a, uint64_t i, uin
     h.diagonal = (int) (short) ((int) diagonal - a.diagBias);
     return h;
 }
-// tiles of 4096 tuples (256 threads x 16 consecutive): number of hit-producing segment starts per tile and per representative
+// tiles of 4096 tuples: number of hit-producing segment starts per tile and per representative (coalesced, order free)
 __global__ __launch_bounds__(256) void k_seg_count(VoteArgs a, unsigned long long *__restrict__ tileCnt) {
-    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE + (uint64_t) threadIdx.x * CP_ITEMS;
+    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE;
     unsigned int c = 0;
+#pragma unroll
     for (int j = 0; j < CP_ITEMS; j++) {
+        const uint64_t i = base + threadIdx.x + 256 * j;
         uint32_t rep, target;
-        if (base + j < a.n && validStart(a, base + j, rep, target)) { c++; atomicAdd(&a.perRep[rep], 1ull); }
+        if (i < a.n && validStart(a, i, rep, target)) { c++; atomicAdd(&a.perRep[rep], 1ull); }
     }
     typedef hipcub::BlockReduce<unsigned int, 256> BR;
     __shared__ typename BR::TempStorage tmp;
     const unsigned int tot = BR(tmp).Sum(c);
     if (threadIdx.x == 0) tileCnt[blockIdx.x] = tot;
 }
+// vote of the segment starting at tile-local index li, reading the tile from LDS and whatever lies beyond it from memory
+__device__ __forceinline__ HitRec voteSegmentTile(const VoteArgs &a, const uint64_t *sKeys, uint64_t base, int li, uint32_t target) {
+    const uint64_t idMask = (1ull << a.idBits) - 1, diagMask = (1ull << a.diagBits) - 1;
+    const uint64_t key = sKeys[padIdx(li)];
+    uint32_t prevDiag = (uint32_t) ((key >> 1) & diagMask), diagonal = prevDiag;
+    unsigned long long maxDiag = 0, diagCnt = 0, top = 0; int bestRev = (key & 1ull) ? 0 : 1;
+    for (uint64_t kk = base + li; kk < a.n; kk++) {
+        const uint64_t k2 = (kk < base + CP_TILE) ? sKeys[padIdx((int) (kk - base))] : a.keys[kk];
+        if ((uint32_t) ((k2 >> (a.diagBits + 1)) & idMask) != target) break;
+        const uint32_t d = (uint32_t) ((k2 >> 1) & diagMask);
+        if (prevDiag == d) diagCnt++; else diagCnt = 1;
+        if (diagCnt >= maxDiag) { diagonal = d; maxDiag = diagCnt; bestRev = (k2 & 1ull) ? 0 : 1; }
+        prevDiag = d; top++;
+    }
+    HitRec h;
+    h.target = target;
+    h.score = bestRev ? -(int) top : (int) top;
+    h.diagonal = (int) (short) ((int) diagonal - a.diagBias);
+    return h;
+}
 __global__ __launch_bounds__(256) void k_seg_place(VoteArgs a, const unsigned long long *__restrict__ tileOff, const unsigned long long *__restrict__ perRepScan,
                                                    const uint64_t *__restrict__ off, HitRec *__restrict__ out) {
-    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE + (uint64_t) threadIdx.x * CP_ITEMS;
+    __shared__ uint64_t sKeys[CP_LDS];
+    __shared__ uint64_t sPrev;
+    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE;
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; j++) { const int li = threadIdx.x + 256 * j; const uint64_t i = base + li; sKeys[padIdx(li)] = (i < a.n) ? a.keys[i] : ~0ull; }
+    if (threadIdx.x == 0) sPrev = base ? a.keys[base - 1] : ~0ull;
+    __syncthreads();
+    const int shift = a.diagBits + 1;
+    const uint64_t idMask = (1ull << a.idBits) - 1;
     unsigned int c = 0, mask = 0;
+#pragma unroll
     for (int j = 0; j < CP_ITEMS; j++) {
-        uint32_t rep, target;
-        if (base + j < a.n && validStart(a, base + j, rep, target)) { c++; mask |= 1u << j; }
+        const int li = threadIdx.x * CP_ITEMS + j;
+        if (base + li >= a.n) break;
+        const uint64_t seg = sKeys[padIdx(li)] >> shift;
+        const uint64_t prevSeg = ((li == 0) ? sPrev : sKeys[padIdx(li - 1)]) >> shift;
+        const bool first = (base + li == 0) || prevSeg != seg;
+        if (first && (uint32_t) (seg & idMask) != (uint32_t) (seg >> a.idBits)) { c++; mask |= 1u << j; }
     }
     typedef hipcub::BlockScan<unsigned int, 256> BS;
     __shared__ typename BS::TempStorage tmp;
@@ -453,9 +499,10 @@ __global__ __launch_bounds__(256) void k_seg_place(VoteArgs a, const unsigned lo
     unsigned long long rank = tileOff[blockIdx.x] + pre;   // number of hit-producing segments before this one, whole array
     for (int j = 0; j < CP_ITEMS; j++) {
         if (!((mask >> j) & 1u)) continue;
-        uint32_t rep, target;
-        validStart(a, base + j, rep, target);
-        out[off[rep] + 1 + (rank - perRepScan[rep])] = voteSegment(a, base + j, target);
+        const int li = threadIdx.x * CP_ITEMS + j;
+        const uint64_t seg = sKeys[padIdx(li)] >> shift;
+        const uint32_t target = (uint32_t) (seg & idMask), rep = (uint32_t) (seg >> a.idBits);
+        out[off[rep] + 1 + (rank - perRepScan[rep])] = voteSegmentTile(a, sKeys, base, li, target);
         rank++;
     }
 }
