@@ -58,7 +58,7 @@ struct VQuery {
     uint32_t q, qLen0, qw;
     const Cand *cand; const uint32_t *leftL, *rightL;
     uint32_t nL, nR, leftTotal, total;
-    bool anyN;
+    bool plain;   // no pieces yet and no N in the query: positions index the original sequence, word-wise paths apply
     __device__ void baseAt(uint32_t p, uint32_t &code, bool &isN) const {
         const ExtArgs &A = *a;
         uint32_t t, tp;
@@ -82,6 +82,21 @@ __device__ __forceinline__ void targetBaseAt(const ExtArgs &A, uint32_t t, uint3
     isN = A.hasN[t] && cdm_isN(A.nmask, w, p);
 }
 
+// identical / same-RY-class columns of q[q0..q0+n) vs t[t0..t0+n), 16 bases per XOR (neither sequence has an N)
+__device__ __forceinline__ void countMatchesWords(const ExtArgs &A, uint32_t q, uint32_t q0, uint32_t t, uint32_t t0, uint32_t n, int &idCnt, int &idRy) {
+    const uint32_t qw = A.woff[q], tw = A.woff[t];
+    const uint32_t qLast = (A.len[q] + 15) / 16 - 1, tLast = (A.len[t] + 15) / 16 - 1;
+    uint32_t mm = 0, ry = 0;
+    for (uint32_t k = 0; k < n; k += 16) {
+        const uint32_t x = cdm_window16(A.codes, qw, q0 + k, qLast) ^ cdm_window16(A.codes, tw, t0 + k, tLast);
+        uint32_t any = (x | (x >> 1)) & 0x55555555u, lowbit = x & 0x55555555u;
+        const uint32_t rem = n - k;
+        if (rem < 16) { const uint32_t m = (1u << (2 * rem)) - 1u; any &= m; lowbit &= m; }
+        mm += __popc(any); ry += __popc(lowbit);
+    }
+    idCnt = (int) (n - mm); idRy = (int) (n - ry);
+}
+
 // updateSeqIdConsensusReads for one candidate on the current query (nuclassembleUtil.cpp:377-500, safe-mode consensus)
 __device__ void updateIds(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t &maxLeft, uint32_t &maxRight) {
     const uint32_t qLen = Q.total;
@@ -94,6 +109,8 @@ __device__ void updateIds(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t &
         uint32_t q0, t0, ncol;
         if (leftStart) { t0 = offset; q0 = 0; ncol = min(c.dbLen - offset, qLen); }
         else { t0 = 0; q0 = qLen - c.alnLen; ncol = min(c.alnLen, c.dbLen); }
+        if (Q.plain && !A.hasN[c.target]) { countMatchesWords(A, Q.q, q0, c.target, t0, ncol, idCnt, idRy); tot = ncol; }
+        else
         for (uint32_t i = 0; i < ncol; i++) {
             uint32_t qc, tc; bool qn, tn;
             Q.baseAt(q0 + i, qc, qn); targetBaseAt(A, c.target, t0 + i, tc, tn);
@@ -122,6 +139,22 @@ __device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t m
         // tIdx counts the non-N target letters up to and including the column (pad letters are 'N'); before the overlap
         // the left-start target contributes its own prefix t[0..offset)
         uint32_t tIdx = 0;
+        if (Q.plain && !A.hasN[c.target]) {
+            // no N anywhere: tIdx - 1 is the target position itself; walk the two sequences a 16-base word at a time
+            const uint32_t qw = A.woff[Q.q], tw = A.woff[c.target];
+            const uint32_t qLast = (Q.qLen0 + 15) / 16 - 1, tLast = (c.dbLen + 15) / 16 - 1;
+            for (uint32_t k = 0; k < ncol; k += 16) {
+                uint32_t qwin = cdm_window16(A.codes, qw, q0 + k, qLast), twin = cdm_window16(A.codes, tw, t0 + k, tLast);
+                const uint32_t m = min(16u, ncol - k);
+                for (uint32_t j = 0; j < m; j++) {
+                    const uint32_t ti = t0 + k + j;
+                    const uint32_t cls = ti < 5 ? ti : (ti >= c.dbLen - 5 ? 6 + (ti - (c.dbLen - 5)) : 5);
+                    lik = x87_add(lik, x87_from_double(logLik[(cls * 4 + (qwin & 3u)) * 4 + (twin & 3u)]));
+                    qwin >>= 2; twin >>= 2;
+                }
+            }
+            alnCount = ncol;
+        } else {
         if (leftStart) for (uint32_t j = 0; j < t0; j++) { uint32_t tc; bool tn; targetBaseAt(A, c.target, j, tc, tn); tIdx += !tn; }
         for (uint32_t i = 0; i < ncol; i++) {
             uint32_t qc, tc; bool qn, tn;
@@ -132,6 +165,7 @@ __device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t m
             const uint32_t ti = tIdx - 1;
             const uint32_t cls = ti < 5 ? ti : (ti >= c.dbLen - 5 ? 6 + (ti - (c.dbLen - 5)) : 5);
             lik = x87_add(lik, x87_from_double(logLik[(cls * 4 + qc) * 4 + tc]));
+        }
         }
     }
     const uint32_t excess = maxAln - alnCount;
@@ -181,7 +215,7 @@ __global__ __launch_bounds__(64) void k_extend(ExtArgs A) {
     Cand *cand = A.cand + r0;
     uint32_t *heapL = A.lists + 4 * r0, *parkL = heapL + nRec, *leftL = parkL + nRec, *rightL = leftL + nRec;
     VQuery Q; Q.a = &A; Q.q = q; Q.qLen0 = qLen0; Q.qw = A.woff[q]; Q.cand = cand; Q.leftL = leftL; Q.rightL = rightL;
-    Q.nL = 0; Q.nR = 0; Q.leftTotal = 0; Q.total = qLen0;
+    Q.nL = 0; Q.nR = 0; Q.leftTotal = 0; Q.total = qLen0; Q.plain = A.hasN[q] == 0;
 
     // ---- A-C: candidates ("notContig"), in record order
     uint32_t nCand = 0;   // candidate k lives at cand[k] (compacted), keeping the record index for the score output
@@ -198,6 +232,8 @@ __global__ __launch_bounds__(64) void k_extend(ExtArgs A) {
         float seqId = rec.seqId, rySeqId = 0.f;
         if (rec.target != qKey) {   // the reference compares the target's *id* with the query's *key* (:264)
             int idCnt = 0, idRy = 0;
+            if (Q.plain && !A.hasN[rec.target]) countMatchesWords(A, q, (uint32_t) rec.qStart, rec.target, (uint32_t) rec.dbStart, (uint32_t) (rec.qEnd - rec.qStart + 1), idCnt, idRy);
+            else
             for (int i = rec.qStart; i <= rec.qEnd; i++) {
                 uint32_t qc, tc; bool qn, tn;
                 Q.baseAt((uint32_t) i, qc, qn); targetBaseAt(A, rec.target, (uint32_t) (rec.dbStart + (i - rec.qStart)), tc, tn);
@@ -257,13 +293,13 @@ __global__ __launch_bounds__(64) void k_extend(ExtArgs A) {
                 const uint32_t fragLen = tLen - (de + 1);
                 if ((uint64_t) Q.total + fragLen >= A.maxSeqLen) break;
                 b.pieceStart = de + 1; b.pieceLen = fragLen;
-                rightL[Q.nR++] = bi; Q.total += fragLen; rightOff += fragLen;
+                rightL[Q.nR++] = bi; Q.total += fragLen; rightOff += fragLen; Q.plain = false;
             } else if (qs == 0 && de == (tLen - 1)) {
                 if (leftOff > 0) { parkL[nPark++] = bi; continue; }
                 const uint32_t fragLen = ds;
                 if ((uint64_t) Q.total + fragLen >= A.maxSeqLen) break;
                 b.pieceStart = 0; b.pieceLen = fragLen;
-                leftL[Q.nL++] = bi; Q.leftTotal += fragLen; Q.total += fragLen; leftOff += fragLen;
+                leftL[Q.nL++] = bi; Q.leftTotal += fragLen; Q.total += fragLen; leftOff += fragLen; Q.plain = false;
             }
         }
         if (leftOff > 0 || rightOff > 0) couldExtend = true;
@@ -355,7 +391,7 @@ __global__ __launch_bounds__(256) void k_write(ExtArgs A, const uint32_t *__rest
     } else {
         const uint64_t r0 = A.aoff[q]; const uint32_t nRec = (uint32_t) (A.aoff[q + 1] - r0);
         VQuery Q; Q.a = &A; Q.q = q; Q.qLen0 = A.len[q]; Q.qw = A.woff[q]; Q.cand = A.cand + r0;
-        Q.leftL = A.lists + 4 * r0 + 2 * (uint64_t) nRec; Q.rightL = Q.leftL + nRec; Q.nL = A.nLeft[q]; Q.nR = A.nRight[q]; Q.leftTotal = A.leftTotal[q]; Q.total = L;
+        Q.leftL = A.lists + 4 * r0 + 2 * (uint64_t) nRec; Q.rightL = Q.leftL + nRec; Q.nL = A.nLeft[q]; Q.nR = A.nRight[q]; Q.leftTotal = A.leftTotal[q]; Q.total = L; Q.plain = false;
         for (uint32_t j = 0; j < cnt; j++) { uint32_t c; bool isN; Q.baseAt(w * 16 + j, c, isN); if (isN) { nb |= 1u << j; c = 0; } code |= c << (2 * j); }
     }
     oCodes[gw] = code;
