@@ -57,7 +57,19 @@ struct ExtractArgs {
                                 // unused slots hold the key ~0 (sorts last, dropped by k_groups)
     uint32_t *slowShort, *slowLong; unsigned int *slowCnt;   // sequences the fast kernel hands to the general one
     uint32_t n;
+    // The whole-sequence hash tuple (63 random bits) lives in a second region behind the k-mer slots, [hashBase, hashBase+n),
+    // at the sequence's rank in (length desc, id asc) order, unless its key happens to fit the 2k bits of a k-mer (then it
+    // stays in slot 0 of the sequence).  Region 1 is sorted on 2k bits, region 2 on 63: every key of region 1 is smaller
+    // than every key of region 2, so the concatenation is the array the reference sorts on the full key.
+    uint64_t hashBase; const uint32_t *rankOf;
 };
+__device__ __forceinline__ void putSeqHashTuple(const ExtractArgs &a, uint32_t seq, uint32_t L, uint64_t base, uint64_t h) {
+    const uint64_t key = xxh64_u64(h, a.seed), val = ((uint64_t) seq << 32) | ((uint64_t) L << 16);
+    const uint64_t hslot = a.hashBase + a.rankOf[seq];
+    const bool small = (key & ~BIT63) < (1ull << (2 * a.k));
+    a.keys[base] = small ? key : ~0ull; a.vals[base] = small ? val : 0ull;
+    a.keys[hslot] = small ? ~0ull : key; a.vals[hslot] = small ? 0ull : val;
+}
 
 // 2k-bit window of the sequence starting at base pos, MMseqs2 coding (A,C,T,G), first base in the LOW bits
 __device__ __forceinline__ uint64_t kmerWindow(const uint32_t *__restrict__ codes, uint32_t w0, uint32_t pos, uint32_t lastWord, int k) {
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs a)
             a.vals[base + 1 + pos] = val;
         }
         const uint64_t h = waveSeqHash(a.codes, a.nmask, w0, L, hasN, lane);
-        if (lane == 0) { a.keys[base] = xxh64_u64(h, a.seed); a.vals[base] = ((uint64_t) seq << 32) | ((uint64_t) L << 16); }
+        if (lane == 0) putSeqHashTuple(a, seq, L, base, h);
         if (__ballot(dup) != 0ull && lane == 0) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;   // rewritten by k_extract
         __builtin_amdgcn_wave_barrier();
     }
@@ -268,8 +280,7 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs a) {
                     if (hasN && cdm_isN(a.nmask, w0, i)) c = 4;
                     h = h * 31 + c;
                 }
-                a.keys[base] = xxh64_u64(h, a.seed);
-                a.vals[base] = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | 0ull;
+                putSeqHashTuple(a, seq, L, base, h);
                 sCursor = 0;
             }
             __syncthreads();
@@ -528,9 +539,10 @@ __global__ void k_slot_counts(const uint32_t *__restrict__ len, const uint32_t *
     const uint32_t L = len[order[r]];
     slots[r] = 1ull + ((L >= (uint32_t) k) ? (L - k + 1) : 0);
 }
-__global__ void k_slot_scatter(const uint32_t *__restrict__ order, const unsigned long long *__restrict__ ordOff, uint32_t n, uint64_t *__restrict__ slotOff) {
+__global__ void k_slot_scatter(const uint32_t *__restrict__ order, const unsigned long long *__restrict__ ordOff, uint32_t n, uint64_t *__restrict__ slotOff,
+                               uint32_t *__restrict__ rankOf) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) slotOff[order[r]] = ordOff[r];
+    if (r < n) { slotOff[order[r]] = ordOff[r]; rankOf[order[r]] = r; }
     if (r == n) slotOff[n] = ordOff[n];
 }
 __global__ void k_classify(const uint32_t *__restrict__ len, uint32_t n, int k, uint32_t shortCap, uint32_t *__restrict__ listShort,
@@ -583,8 +595,8 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     DevBuf<unsigned long long> counters;      // scratch counters ([2] = number of kept group tuples)
     DevBuf<unsigned int> cls;                 // slow-path list sizes
     DevBuf<uint32_t> listShort, listLong;
-    DevBuf<unsigned long long> slots; DevBuf<uint64_t> slotOff;
-    if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1)) {
+    DevBuf<unsigned long long> slots; DevBuf<uint64_t> slotOff; DevBuf<uint32_t> rankOf;
+    if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1) || !rankOf.alloc(n)) {
         cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP;
     }
     hipMemsetAsync(counters.p, 0, 8 * 8, s);
@@ -607,10 +619,12 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
         rocprim::radix_sort_pairs(t0.p, sb0, lk, lv, (size_t) n, 0, lenBits, s);
         hipLaunchKernelGGL(k_slot_counts, dim3((n + 256) / 256), dim3(256), 0, s, db->len, lv.current(), n, k, slots.p);
         hipcub::DeviceScan::ExclusiveSum(t0.p, sb1, slots.p, ordOff.p, (int) (n + 1), s);
-        hipLaunchKernelGGL(k_slot_scatter, dim3((n + 256) / 256), dim3(256), 0, s, lv.current(), ordOff.p, n, slotOff.p);
+        hipLaunchKernelGGL(k_slot_scatter, dim3((n + 256) / 256), dim3(256), 0, s, lv.current(), ordOff.p, n, slotOff.p, rankOf.p);
         hipMemcpyAsync(&capacity, ordOff.p + n, 8, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: slot layout failed"); return CDM_ERR_HIP; }
     }
+    const uint64_t kmerSlots = capacity;             // region 1: k-mer slots (+ slot 0 per sequence)
+    capacity += n;                                   // region 2: whole-sequence hash tuples
     const unsigned long long nTuples = capacity;
 
     rocprim::double_buffer<uint64_t> keys, vals;
@@ -622,7 +636,7 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     ea.woff = db->woff; ea.len = db->len; ea.codes = db->codes; ea.nmask = db->nmask; ea.hasN = db->hasN;
     ea.k = k; ea.kmersPerSeq = par->kmers_per_seq; ea.scale = par->kmers_per_seq_scale; ea.seed = par->hash_shift; ea.ignoreMultiKmer = par->ignore_multi_kmer;
     ea.keys = k0.p; ea.vals = v0.p; ea.slotOff = slotOff.p; ea.slowShort = listShort.p; ea.slowLong = listLong.p; ea.slowCnt = cls.p; ea.n = n;
-    ea.list = nullptr; ea.nList = 0;
+    ea.list = nullptr; ea.nList = 0; ea.hashBase = kmerSlots; ea.rankOf = rankOf.p;
     hipEventRecord(ctx->ev0, s);
     hipLaunchKernelGGL(k_extract_fast, dim3(std::min<uint32_t>((n + FAST_WAVES - 1) / FAST_WAVES, ctx->cuCount * 16)), dim3(64 * FAST_WAVES), 0, s, ea);
     unsigned int hcls[2] = {0, 0};
@@ -641,15 +655,27 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction (general path) failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     hipEventElapsedTime(&ctx->lastMs[3], ctx->ev0, ctx->ev1);
 
-    // ---- sort 1: by k-mer (63 bits), stable
+    // ---- sort 1: stable LSD radix sort by k-mer.  Region 1 (k-mer slots) on the 2k key bits, region 2 (whole-sequence hashes)
+    // on 63 bits into the same physical buffers; the strand bit 63 rides along outside the sorted bit range.
     keys = rocprim::double_buffer<uint64_t>(k0.p, k1.p); vals = rocprim::double_buffer<uint64_t>(v0.p, v1.p);
-    size_t tmpBytes = 0;
-    rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) nTuples, 0, 63, s);
+    size_t tmpBytes = 0, tmpBytesH = 0;
+    rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, 0, 2 * k, s);
+    rocprim::radix_sort_pairs(nullptr, tmpBytesH, k0.p + kmerSlots, k1.p + kmerSlots, v0.p + kmerSlots, v1.p + kmerSlots, (size_t) n, 0, 63, s);
     DevBuf<char> tmp1;
-    if (!tmp1.alloc(tmpBytes + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
+    if (!tmp1.alloc(std::max(tmpBytes, tmpBytesH) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev0, s);
-    if (rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) nTuples, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
+    if (rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, 0, 2 * k, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev1, s);
+    {
+        // region 2 goes to wherever region 1 ended up (explicit in/out form: input is always the extraction buffers k0/v0)
+        uint64_t *kOut = keys.current() + kmerSlots, *vOut = vals.current() + kmerSlots;
+        uint64_t *kIn = k0.p + kmerSlots, *vIn = v0.p + kmerSlots;
+        if (kOut == kIn) {   // region 1 finished in the extraction buffers: sort region 2 via the alternate buffers and copy back
+            if (rocprim::radix_sort_pairs(tmp1.p, tmpBytesH, kIn, k1.p + kmerSlots, vIn, v1.p + kmerSlots, (size_t) n, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
+            hipMemcpyAsync(kOut, k1.p + kmerSlots, (size_t) n * 8, hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(vOut, v1.p + kmerSlots, (size_t) n * 8, hipMemcpyDeviceToDevice, s);
+        } else if (rocprim::radix_sort_pairs(tmp1.p, tmpBytesH, kIn, kOut, vIn, vOut, (size_t) n, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
+    }
     // ---- K3: run starts (max-scan), parallel emit, order-preserving compaction
     GroupArgs ga;
     ga.keys = keys.current(); ga.vals = vals.current(); ga.n = nTuples; ga.onlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode;
