@@ -355,7 +355,7 @@ __global__ void k_mark_active(const uint64_t *__restrict__ aoff, uint32_t n, uin
                               unsigned int *__restrict__ counters) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t c = (q < n) ? aoff[q + 1] - aoff[q] : 0;
-    const uint32_t s0 = cdm_wave_append(&counters[0], c > 64), s2 = cdm_wave_append(&counters[2], c > 1 && c <= 64);
+    const uint32_t s0 = cdm_wave_append(&counters[0], c > 64), s2 = cdm_block_append(&counters[2], c > 1 && c <= 64);
     if (c > 64) active[s0] = q; else if (c > 1) activeFast[s2] = q;
 }
 
@@ -407,7 +407,7 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
         hipMemcpyAsync(out->codes, db->codes, db->words * 4, hipMemcpyDeviceToDevice, s);
         hipMemcpyAsync(out->nmask, db->nmask, ((db->words * 16 + 31) / 32) * 4, hipMemcpyDeviceToDevice, s);
         hipMemsetAsync(nActive, 0, 16, s);
-        hipLaunchKernelGGL(k_mark_active, dim3((n + 255) / 256), dim3(256), 0, s, alns->off, n, active, activeFast, nActive);
+        hipLaunchKernelGGL(k_mark_active, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, n, active, activeFast, nActive);
         CorrectArgs a;
         a.woff = db->woff; a.len = db->len; a.codes = db->codes; a.nmask = db->nmask; a.ext = db->ext; a.hasN = db->hasN;
         a.aoff = alns->off; a.rec = alns->rec; a.active = active; a.nActive = nActive; a.accept = accept; a.errFlag = nActive + 1;

@@ -75,6 +75,25 @@ __device__ __forceinline__ uint32_t cdm_wave_append(unsigned int *counter, bool 
     return base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
 }
 
+// block-wide version (blockDim.x threads, up to 1024): one atomic per block; every thread of the block must call it
+__device__ __forceinline__ uint32_t cdm_block_append(unsigned int *counter, bool pred) {
+    __shared__ uint32_t sWaveCnt[16];
+    __shared__ uint32_t sBase;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const uint64_t m = __ballot(pred);
+    if (lane == 0) sWaveCnt[wave] = (uint32_t) __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < nw; w++) { const uint32_t c = sWaveCnt[w]; sWaveCnt[w] = tot; tot += c; }
+        sBase = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t r = sBase + sWaveCnt[wave] + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------- x87 extended precision
 // Software model of the x87 80-bit format (64-bit significand, round to nearest even), for the `long double`
 // accumulators of the reference (src/assembler/correction.cpp:82,110-111; nuclassembleUtil.cpp:212,279).  Only what

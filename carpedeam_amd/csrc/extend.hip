@@ -359,7 +359,7 @@ __global__ void k_mark_active2(const uint64_t *__restrict__ aoff, uint32_t n, ui
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const bool act = q < n && (aoff[q + 1] - aoff[q] > 1);
     if (q < n) newLen[q] = 0;
-    const uint32_t slot = cdm_wave_append(nActive, act);
+    const uint32_t slot = cdm_block_append(nActive, act);
     if (act) active[slot] = q;
 }
 // output geometry: length, words, ext flag
@@ -373,7 +373,13 @@ __global__ void k_out_meta(const uint32_t *__restrict__ len, const uint8_t *__re
     }
     unsigned long long sum = L; uint32_t mx = L;
     for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); mx = max(mx, (uint32_t) __shfl_xor((int) mx, o, 64)); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], sum); atomicMax(&stats[1], (unsigned long long) mx); }
+    __shared__ unsigned long long sSum[16]; __shared__ uint32_t sMax[16];
+    if ((threadIdx.x & 63) == 0) { sSum[threadIdx.x >> 6] = sum; sMax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // one pair of atomics per 1024-thread block
+        for (unsigned w = 1; w < (blockDim.x + 63) / 64; w++) { sum += sSum[w]; mx = max(mx, sMax[w]); }
+        atomicAdd(&stats[0], sum); atomicMax(&stats[1], (unsigned long long) mx);
+    }
 }
 // one thread per output word
 __global__ __launch_bounds__(256) void k_write(ExtArgs A, const uint32_t *__restrict__ oWoff, const uint32_t *__restrict__ oLen, uint32_t n, uint64_t words,
@@ -420,7 +426,7 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     hipMemsetAsync(nActive.p, 0, 8, s);
     hipMemsetAsync(stats.p, 0, 16, s);
     if (scores) hipMemsetAsync(dScores.p, 0xFF, alns->count * 8, s);   // all-ones = NaN: records of inactive queries
-    hipLaunchKernelGGL(k_mark_active2, dim3((n + 255) / 256), dim3(256), 0, s, alns->off, n, active.p, nActive.p, newLen.p);
+    hipLaunchKernelGGL(k_mark_active2, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, n, active.p, nActive.p, newLen.p);
     unsigned int hAct = 0;
     hipMemcpyAsync(&hAct, nActive.p, 4, hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_extend: setup failed"); return CDM_ERR_HIP; }
@@ -439,7 +445,7 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     cdm_seqdb *o = nullptr;
     int rc = cdm_seqdb_alloc(ctx, n, &o);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_out_meta, dim3((n + 255) / 256), dim3(256), 0, s, db->len, db->ext, newLen.p, n, o->len, o->ext, oWords.p, stats.p);
+    hipLaunchKernelGGL(k_out_meta, dim3((n + 1023) / 1024), dim3(1024), 0, s, db->len, db->ext, newLen.p, n, o->len, o->ext, oWords.p, stats.p);
     size_t sb = 0;
     hipcub::DeviceScan::ExclusiveSum(nullptr, sb, oWords.p, o->woff, (int) (n + 1), s);
     DevBuf<char> tmp;

@@ -123,7 +123,10 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs a)
             if (lane == 0) { if (nPos < 256) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq; else a.slowLong[atomicAdd(&a.slowCnt[1], 1u)] = seq; }
             continue;
         }
-        for (int i = lane; i < FAST_TABLE; i += 64) table[i] = ~0ull;
+        // hash set sized to the sequence (load factor <= 1/2): clearing it is a large share of this kernel's LDS traffic
+        uint32_t tsize = 64; while (tsize < 2 * nPos) tsize <<= 1;
+        const uint32_t tmask = tsize - 1;
+        for (uint32_t i = lane; i < tsize; i += 64) table[i] = ~0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
         const uint32_t lastWord = (L + 15) / 16 - 1;
         bool dup = false;
@@ -141,12 +144,12 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs a)
                 key = km | (pickRev ? 0ull : BIT63);
                 val = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | (uint64_t) p;
                 if (a.ignoreMultiKmer) {
-                    uint32_t h = (uint32_t) ((km * 0x9E3779B97F4A7C15ull) >> 54) & (FAST_TABLE - 1);
+                    uint32_t h = (uint32_t) ((km * 0x9E3779B97F4A7C15ull) >> 40) & tmask;
                     while (true) {
                         const unsigned long long old = atomicCAS(&table[h], ~0ull, (unsigned long long) km);
                         if (old == ~0ull) break;
                         if (old == km) { dup = true; break; }
-                        h = (h + 1) & (FAST_TABLE - 1);
+                        h = (h + 1) & tmask;
                     }
                 }
             }
@@ -418,6 +421,7 @@ struct VoteArgs {
     uint64_t n;
     uint32_t idBits, diagBits; int diagBias;
     unsigned long long *perRep;  // [nSeq] number of hits per representative
+    int dbg;
 };
 // a (rep, target != rep) segment starts at i
 __device__ __forceinline__ bool validStart(const VoteArgs &a, uint64_t i, uint32_t &rep, uint32_t &target) {
@@ -468,13 +472,26 @@ __device__ __forceinline__ HitRec voteSegmentTile(const VoteArgs &a, const uint6
     const uint64_t key = sKeys[padIdx(li)];
     uint32_t prevDiag = (uint32_t) ((key >> 1) & diagMask), diagonal = prevDiag;
     unsigned long long maxDiag = 0, diagCnt = 0, top = 0; int bestRev = (key & 1ull) ? 0 : 1;
-    for (uint64_t kk = base + li; kk < a.n; kk++) {
-        const uint64_t k2 = (kk < base + CP_TILE) ? sKeys[padIdx((int) (kk - base))] : a.keys[kk];
-        if ((uint32_t) ((k2 >> (a.diagBits + 1)) & idMask) != target) break;
+    // two separate loops so that the common in-tile walk issues LDS reads only
+    const int tileEnd = (int) min((uint64_t) CP_TILE, a.n - base);
+    int i = li; bool done = false;
+    for (; i < tileEnd; i++) {
+        const uint64_t k2 = sKeys[padIdx(i)];
+        if ((uint32_t) ((k2 >> (a.diagBits + 1)) & idMask) != target) { done = true; break; }
         const uint32_t d = (uint32_t) ((k2 >> 1) & diagMask);
         if (prevDiag == d) diagCnt++; else diagCnt = 1;
         if (diagCnt >= maxDiag) { diagonal = d; maxDiag = diagCnt; bestRev = (k2 & 1ull) ? 0 : 1; }
         prevDiag = d; top++;
+    }
+    if (!done) {
+        for (uint64_t kk = base + CP_TILE; kk < a.n; kk++) {
+            const uint64_t k2 = a.keys[kk];
+            if ((uint32_t) ((k2 >> (a.diagBits + 1)) & idMask) != target) break;
+            const uint32_t d = (uint32_t) ((k2 >> 1) & diagMask);
+            if (prevDiag == d) diagCnt++; else diagCnt = 1;
+            if (diagCnt >= maxDiag) { diagonal = d; maxDiag = diagCnt; bestRev = (k2 & 1ull) ? 0 : 1; }
+            prevDiag = d; top++;
+        }
     }
     HitRec h;
     h.target = target;
@@ -508,12 +525,16 @@ __global__ __launch_bounds__(256) void k_seg_place(VoteArgs a, const unsigned lo
     unsigned int pre;
     BS(tmp).ExclusiveSum(c, pre);
     unsigned long long rank = tileOff[blockIdx.x] + pre;   // number of hit-producing segments before this one, whole array
-    for (int j = 0; j < CP_ITEMS; j++) {
-        if (!((mask >> j) & 1u)) continue;
+#pragma unroll 1
+    while (mask) {   // one copy of the walk in the instruction stream (an unrolled x16 body thrashes the instruction cache)
+        const int j = __ffs(mask) - 1;
+        mask &= mask - 1;
         const int li = threadIdx.x * CP_ITEMS + j;
         const uint64_t seg = sKeys[padIdx(li)] >> shift;
         const uint32_t target = (uint32_t) (seg & idMask), rep = (uint32_t) (seg >> a.idBits);
-        out[off[rep] + 1 + (rank - perRepScan[rep])] = voteSegmentTile(a, sKeys, base, li, target);
+        HitRec hh;
+        if (a.dbg & 1) { hh.target = target; hh.score = 1; hh.diagonal = 0; } else hh = voteSegmentTile(a, sKeys, base, li, target);
+        if (a.dbg & 2) { if (hh.score == 123456789) out[rank] = hh; } else out[off[rep] + 1 + (rank - perRepScan[rep])] = hh;
         rank++;
     }
 }
@@ -725,7 +746,7 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     hipMemsetAsync(perRep.p, 0, ((size_t) n + 1) * 8, s);
     hipMemsetAsync(vTileCnt.p, 0, (vTiles + 1) * 8, s);
     VoteArgs va;
-    va.keys = g.current(); va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.perRep = perRep.p;
+    va.keys = g.current(); va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.perRep = perRep.p; va.dbg = getenv("CDM_DBG_VOTE") ? atoi(getenv("CDM_DBG_VOTE")) : 0;
     if (nGroup) hipLaunchKernelGGL(k_seg_count, dim3((unsigned) vTiles), dim3(256), 0, s, va, vTileCnt.p);
     size_t sb1 = 0, sb2 = 0;
     hipcub::DeviceScan::ExclusiveSum(nullptr, sb1, perRep.p, perRepScan.p, (int) (n + 1), s);
