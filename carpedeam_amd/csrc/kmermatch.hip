@@ -421,7 +421,6 @@ struct VoteArgs {
     uint64_t n;
     uint32_t idBits, diagBits; int diagBias;
     unsigned long long *perRep;  // [nSeq] number of hits per representative
-    int dbg;
 };
 // a (rep, target != rep) segment starts at i
 __device__ __forceinline__ bool validStart(const VoteArgs &a, uint64_t i, uint32_t &rep, uint32_t &target) {
@@ -532,9 +531,7 @@ __global__ __launch_bounds__(256) void k_seg_place(VoteArgs a, const unsigned lo
         const int li = threadIdx.x * CP_ITEMS + j;
         const uint64_t seg = sKeys[padIdx(li)] >> shift;
         const uint32_t target = (uint32_t) (seg & idMask), rep = (uint32_t) (seg >> a.idBits);
-        HitRec hh;
-        if (a.dbg & 1) { hh.target = target; hh.score = 1; hh.diagonal = 0; } else hh = voteSegmentTile(a, sKeys, base, li, target);
-        if (a.dbg & 2) { if (hh.score == 123456789) out[rank] = hh; } else out[off[rep] + 1 + (rank - perRepScan[rep])] = hh;
+        out[off[rep] + 1 + (rank - perRepScan[rep])] = voteSegmentTile(a, sKeys, base, li, target);
         rank++;
     }
 }
@@ -746,7 +743,7 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     hipMemsetAsync(perRep.p, 0, ((size_t) n + 1) * 8, s);
     hipMemsetAsync(vTileCnt.p, 0, (vTiles + 1) * 8, s);
     VoteArgs va;
-    va.keys = g.current(); va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.perRep = perRep.p; va.dbg = getenv("CDM_DBG_VOTE") ? atoi(getenv("CDM_DBG_VOTE")) : 0;
+    va.keys = g.current(); va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.perRep = perRep.p;
     if (nGroup) hipLaunchKernelGGL(k_seg_count, dim3((unsigned) vTiles), dim3(256), 0, s, va, vTileCnt.p);
     size_t sb1 = 0, sb2 = 0;
     hipcub::DeviceScan::ExclusiveSum(nullptr, sb1, perRep.p, perRepScan.p, (int) (n + 1), s);
