@@ -106,7 +106,7 @@ def main():
         del hits
         corr = ctx.correct(db, alns)
         asm = ctx.extend(corr, alns)
-        ms = [ctx.last_kernel_ms(i) for i in range(7)]
+        ms = [ctx.last_kernel_ms(i) for i in range(8)]
         return asm, stats, ms
 
     def sync():
@@ -119,7 +119,7 @@ def main():
         del out
     sync()
     t0 = time.perf_counter()
-    kernel_ms = [0.0] * 7
+    kernel_ms = [0.0] * 8
     stats = (0, 0)
     asm = None
     for _ in range(args.steps):
@@ -140,34 +140,36 @@ def main():
     if rank == 0:
         total_bases = residues * args.steps * world
         k_ms = [m / args.steps for m in kernel_ms]
-        # Dominant kernel (rocprofv3 --stats, profiles/): rocPRIM's radix_sort_onesweep_iteration on the (k-mer, payload)
-        # tuple array, launched ceil(63/8) = 8 times by sort 1 after one histogram launch.  Algorithmic bytes of ONE launch
-        # (SURVEY.md 8(d)): the 16-byte tuples read once and written once = 2 * 16 * (L - k + 2) bytes per read.  Its average
-        # launch duration is taken from the HIP-event time of the sort-1 call on the library's stream; the histogram launch
-        # of that call reads the 8-byte keys once, i.e. 1/4 of an iteration's traffic, hence the 8.25.
-        # rocPRIM sorts at most 2^30 items per launch, so one radix pass is `chunks` launches; sort 1 sorts the k-mer slots on
-        # the 2k = 40 key bits (5 passes) and its histogram launch costs about half an iteration launch per chunk.
+        # Dominant kernel (rocprofv3 --stats, profiles/): rocPRIM's radix_sort_onesweep_iteration<u64 key, u64 value>, launched
+        # by kmermatcher's sort 1: the k-mer slots are sorted on the 2k = 40 key bits (5 passes), the n whole-sequence hash
+        # tuples on 63 bits (8 passes); rocPRIM sorts at most 2^30 items per launch, so a pass is ceil(items / 2^30) launches.
+        # Algorithmic bytes of one launch: its 16-byte tuples read once and written once.  The average launch
+        # duration comes from the HIP-event times of the two sort calls on the library's stream; each call also runs one
+        # histogram launch per 2^30 items, which costs about half an iteration launch (it reads the 8-byte keys once).
         tuples_per_read = L - 20 + 2
-        n_tuples = tuples_per_read * n
-        chunks = -(-n_tuples // (1 << 30))
-        passes = 5
-        launches = passes * chunks
-        sort_bytes = 2.0 * 16.0 * n_tuples / chunks
-        iter_ms = k_ms[5] / (launches + 0.5 * chunks) if k_ms[5] > 0 else 0.0
-        achieved = sort_bytes / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
+        n1, n2 = tuples_per_read * n, n
+        c1, c2 = -(-n1 // (1 << 30)), -(-n2 // (1 << 30))
+        l1, l2 = 5 * c1, 8 * c2
+        t1 = k_ms[5] * l1 / (l1 + 0.5 * c1) if k_ms[5] > 0 else 0.0      # ms spent in region-1 iteration launches
+        t2 = k_ms[7] * l2 / (l2 + 0.5 * c2) if k_ms[7] > 0 else 0.0
+        launches = l1 + l2
+        bytes_all = 2.0 * 16.0 * (5 * n1 + 8 * n2)                        # summed over this kernel's launches in one step
+        iter_ms = (t1 + t2) / launches if launches else 0.0               # = rocprof's AverageNs for this kernel
+        sort_bytes = bytes_all / launches
+        achieved = bytes_all / ((t1 + t2) * 1e-3) / 1e9 if (t1 + t2) > 0 else 0.0
         line = {
             "metric": "corrected bases/sec on 50M x 100bp synthetic reads (dhigh)", "value": total_bases / dt, "unit": "corrected bases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (2-bit packed bases; int32 scores; software x87 f80 likelihood sums)", "data": "synthetic",
             "config": {"workload": "%d synthetic %d bp reads per GPU, dhigh, full correction + kmermatcher/rescorediagonal/ancient_read_assemble (BASELINE.json configs[2])" % (n, L),
                        "reads_per_gpu": n, "read_len": L, "seed": args.seed, "prefilter_hits": stats[0], "alignments": stats[1],
-                       "stage_kernel_ms": {"kmer_extract": k_ms[3], "kmer_sort1_call": k_ms[5], "kmer_sort2_call": k_ms[6], "rescore": k_ms[1],
+                       "stage_kernel_ms": {"kmer_extract": k_ms[3], "kmer_sort1_call": k_ms[5], "kmer_sort1_hash_call": k_ms[7], "kmer_sort2_call": k_ms[6], "rescore": k_ms[1],
                                            "correct": k_ms[0], "extend": k_ms[4]}},
-            "roofline": {"bound": "hbm", "kernel": "rocprim radix_sort_onesweep_iteration<u64 key, u64 value> (kmermatcher sort 1: 5 passes x ceil(tuples / 2^30) launches per step)",
+            "roofline": {"bound": "hbm", "kernel": "rocprim radix_sort_onesweep_iteration<u64 key, u64 value> (kmermatcher sort 1: 5 passes over the k-mer slots + 8 over the hash tuples)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": iter_ms, "launches_per_step": launches, "algorithmic_bytes_per_launch": sort_bytes,
                          "stage_level": {"what": "whole kmermatcher stage against its algorithmic bytes (26.8 B/base, SURVEY.md 8(d))",
-                                         "achieved": 26.8 * n * L / ((k_ms[3] + k_ms[5] + k_ms[6]) * 1e-3) / 1e9 if (k_ms[3] + k_ms[5] + k_ms[6]) > 0 else 0.0,
+                                         "achieved": 26.8 * n * L / ((k_ms[3] + k_ms[5] + k_ms[6] + k_ms[7]) * 1e-3) / 1e9 if (k_ms[3] + k_ms[5] + k_ms[6]) > 0 else 0.0,
                                          "unit": "GB/s"}},
         }
         if gathered is not None:

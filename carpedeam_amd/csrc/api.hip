@@ -82,7 +82,8 @@ extern "C" int cdm_ctx_create(int device, cdm_ctx **out) {
     c->device = device;
     c->cuCount = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-        hipEventCreate(&c->ev1) != hipSuccess || cdmMalloc(&c->lutDev, sizeof(DamageLut)) != hipSuccess) {
+        hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess ||
+        cdmMalloc(&c->lutDev, sizeof(DamageLut)) != hipSuccess) {
         cdm_set_error("context resource creation failed"); delete c; return CDM_ERR_HIP;
     }
     *out = c;
@@ -94,6 +95,8 @@ extern "C" void cdm_ctx_destroy(cdm_ctx *c) {
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev2) hipEventDestroy(c->ev2);
+    if (c->ev3) hipEventDestroy(c->ev3);
     if (c->lutDev) cdmFree(c->lutDev);
     cdmPoolTrim();
     delete c;

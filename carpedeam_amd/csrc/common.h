@@ -53,7 +53,7 @@ int cdm_build_damage(const char *prefix, long double mats[2][11][4][4], DamageLu
 struct cdm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool haveDamage = false;
     long double mats[2][11][4][4];
     DamageLut lutHost;

@@ -684,6 +684,7 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     hipEventRecord(ctx->ev0, s);
     if (rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, 0, 2 * k, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev1, s);
+    hipEventRecord(ctx->ev2, s);
     {
         // region 2 goes to wherever region 1 ended up (explicit in/out form: input is always the extraction buffers k0/v0)
         uint64_t *kOut = keys.current() + kmerSlots, *vOut = vals.current() + kmerSlots;
@@ -694,6 +695,7 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
             hipMemcpyAsync(vOut, v1.p + kmerSlots, (size_t) n * 8, hipMemcpyDeviceToDevice, s);
         } else if (rocprim::radix_sort_pairs(tmp1.p, tmpBytesH, kIn, kOut, vIn, vOut, (size_t) n, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
     }
+    hipEventRecord(ctx->ev3, s);
     // ---- K3: run starts (max-scan), parallel emit, order-preserving compaction
     GroupArgs ga;
     ga.keys = keys.current(); ga.vals = vals.current(); ga.n = nTuples; ga.onlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode;
@@ -767,6 +769,7 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     ctx->lastMs[2] = msSort1 + msSort2;
     ctx->lastMs[5] = msSort1;   // sort 1 call alone (1 histogram + ceil(63/8) onesweep launches)
     ctx->lastMs[6] = msSort2;
+    hipEventElapsedTime(&ctx->lastMs[7], ctx->ev2, ctx->ev3);   // sort 1, region 2 (whole-sequence hash tuples)
     *out = res;
     return CDM_OK;
 }

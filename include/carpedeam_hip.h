@@ -51,7 +51,8 @@ int cdm_ctx_sync(cdm_ctx *ctx);
 void *cdm_ctx_stream(cdm_ctx *ctx);
 /* device time in ms of the dominant kernel(s) of the last stage call, measured with HIP events on the context stream;
  * which = 0: ancient_correction pile-up/call kernel, 1: rescore kernel, 2: kmermatcher sorts, 3: kmer extraction,
- * 4: extension kernel, 5: kmermatcher sort 1 (rocPRIM radix_sort_pairs call), 6: sort 2 (radix_sort_keys call).
+ * 4: extension kernel, 5: kmermatcher sort 1 on the k-mer slots (rocPRIM radix_sort_pairs call), 6: sort 2 (radix_sort_keys
+ * call), 7: sort 1 on the whole-sequence hash tuples (second radix_sort_pairs call).
  * Returns a negative value when that stage has not run. */
 float cdm_ctx_last_kernel_ms(cdm_ctx *ctx, int which);
 
