@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("CDM_BENCH_READS", 50_000_000)), help="reads per GPU")
     ap.add_argument("--len", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-reads", type=int, default=500_000)
+    ap.add_argument("--cpu-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -157,6 +157,15 @@ def main():
         iter_ms = (t1 + t2) / launches if launches else 0.0               # = rocprof's AverageNs for this kernel
         sort_bytes = bytes_all / launches
         achieved = bytes_all / ((t1 + t2) * 1e-3) / 1e9 if (t1 + t2) > 0 else 0.0
+        # HBM traffic of that kernel from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc runs of
+        # this very command at the default size; profiles/r01_pmc_50M.json) - only quoted for the workload it was measured on
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_50M.json")
+        if n == 50_000_000 and L == 100 and os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc))["kernels"]["rocprim onesweep_iteration <u64,u64> (sort 1)"]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         line = {
             "metric": "corrected bases/sec on 50M x 100bp synthetic reads (dhigh)", "value": total_bases / dt, "unit": "corrected bases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
@@ -166,7 +175,7 @@ def main():
                        "stage_kernel_ms": {"kmer_extract": k_ms[3], "kmer_sort1_call": k_ms[5], "kmer_sort1_hash_call": k_ms[7], "kmer_sort2_call": k_ms[6], "rescore": k_ms[1],
                                            "correct": k_ms[0], "extend": k_ms[4]}},
             "roofline": {"bound": "hbm", "kernel": "rocprim radix_sort_onesweep_iteration<u64 key, u64 value> (kmermatcher sort 1: 5 passes over the k-mer slots + 8 over the hash tuples)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": iter_ms, "launches_per_step": launches, "algorithmic_bytes_per_launch": sort_bytes,
                          "stage_level": {"what": "whole kmermatcher stage against its algorithmic bytes (26.8 B/base, SURVEY.md 8(d))",
                                          "achieved": 26.8 * n * L / ((k_ms[3] + k_ms[5] + k_ms[6] + k_ms[7]) * 1e-3) / 1e9 if (k_ms[3] + k_ms[5] + k_ms[6]) > 0 else 0.0,
