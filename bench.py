@@ -80,7 +80,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("CDM_FORCE_DIST"):   # CDM_FORCE_DIST: exercise the collective path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
