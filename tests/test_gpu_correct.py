@@ -107,3 +107,23 @@ def test_seqdb_roundtrip(ctx):
     assert [g.decode() for g in got] == seqs and list(keys) == [3, 5, 6, 10, 11, 12, 99] and list(ext) == [0, 1, 0, 0, 1, 0, 0]
     with pytest.raises(capi.CdmError):
         ctx.upload_seqs(["ACGTacgt"])
+
+
+def test_correction_deep_pileups(ctx, oracle_bin, dhigh_prefix, tmp_path):
+    """100x coverage: queries with more than 64 alignment records (general kernel), avCov >= 50 (inside hits are gated
+    out, correction.cpp:319) and pile-ups deep enough that several candidate bases get close likelihoods."""
+    from carpedeam_amd import synth
+    from stageflags import K_FLAGS, R_FLAGS
+    seqs = synth.generate_strings(6000, L=100, seed=11, coverage=100)
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
+    run_oracle(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref"), t("aln"), *R_FLAGS, "--threads", "4")
+    run_oracle(oracle_bin, "ancient_correction", t("in"), t("aln"), t("corr"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "4")
+    aln = mmdb.read_db(t("aln"))
+    assert max(v[0].count(b"\n") for v in aln.values()) > 64
+    db = ctx.upload_seqs(seqs)
+    _, keys, _ = db.meta()
+    off, rec = capi.parse_aln_db(aln, keys)
+    got = seqdb_to_keyed(*ctx.correct(db, ctx.upload_alns(db, off, rec)).download())
+    assert not diff_keys(got, mmdb.read_db(t("corr")))

@@ -81,3 +81,22 @@ def test_extension_with_N_and_max_seq_len(ctx, oracle_bin, dhigh_prefix, tmp_pat
         exp = mmdb.read_db(t("asm"))
         assert not diff_keys(got, exp), max_len
         assert sum(v[1] for v in exp.values()) > 50
+
+
+def test_extension_deep_coverage_many_rounds(ctx, oracle_bin, dhigh_prefix, tmp_path):
+    """100x coverage, two iterations: dozens of candidates per query, many equal scores (heap tie order), several
+    re-alignment rounds per query, and extended sequences as queries in the second iteration."""
+    from carpedeam_amd import synth
+    seqs = synth.generate_strings(5000, L=100, seed=23, coverage=100)
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in0"), seqs)
+    for it in range(2):
+        i = t("in%d" % it)
+        run_oracle(oracle_bin, "kmermatcher", i, t("pref"), *K_FLAGS, "--threads", "4")
+        run_oracle(oracle_bin, "rescorediagonal", i, i, t("pref"), t("aln"), *R_FLAGS, "--threads", "4")
+        run_oracle(oracle_bin, "ancient_correction", i, t("aln"), t("corr"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "4")
+        run_oracle(oracle_bin, "ancient_read_assemble", t("corr"), t("aln"), t("in%d" % (it + 1)), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "4")
+        got = extend(ctx, mmdb.read_db(t("corr")), mmdb.read_db(t("aln")))
+        exp = mmdb.read_db(t("in%d" % (it + 1)))
+        assert not diff_keys(got, exp), it
+        assert sum(v[1] for v in exp.values()) > 500

@@ -57,3 +57,32 @@ def test_kmermatch_N_repeats_and_contig_params(ctx, oracle_bin, tmp_path):
         run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *flags, "--threads", "4")
         got = kmermatch_text(ctx, mmdb.read_db(t("in")), par)
         assert not diff_keys(got, strip_ext(mmdb.read_db(t("pref"))))
+
+
+def test_kmermatch_long_sequences_bottom_m_selection(ctx, oracle_bin, tmp_path):
+    """Sequences of 300..3500 bp: more k-mer positions than the per-sequence budget (199 + 0.2 L), so the hash threshold /
+    bottom-m selection of fillKmerPositionArray (kmermatcher.cpp:224-240,277-350) and the block-per-sequence kernel run."""
+    rng = np.random.default_rng(17)
+    genome = rng.integers(0, 4, 40000)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    seqs = []
+    for _ in range(400):
+        L = int(rng.integers(300, 3500))
+        s = int(rng.integers(0, len(genome) - L))
+        c = genome[s:s + L].copy()
+        if rng.random() < 0.5:
+            c = (3 - c)[::-1]
+        seqs.append(letters[c].tobytes().decode())
+    seqs += ["ACGTTGCAAT" * 150, "AC" * 400]          # repeats longer than the fast path's capacity
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    for k, ext in ((20, 0), (22, 1)):
+        flags = " ".join(K_FLAGS).replace("-k 20", "-k %d" % k).replace("--include-only-extendable 0", "--include-only-extendable %d" % ext).split()
+        run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *flags, "--threads", "4")
+        got = kmermatch_text(ctx, mmdb.read_db(t("in")), capi.KmerParams(k, 200, 0.2, 67, 1, ext, 1, 0.0))
+        assert not diff_keys(got, strip_ext(mmdb.read_db(t("pref")))), k
+
+
+def test_kmermatch_rejects_what_it_does_not_implement(ctx):
+    with pytest.raises(capi.CdmError):
+        kmermatch_text(ctx, {0: (b"ACGT" * 2000 + b"\n", 0), 1: (b"ACGTTGCA" * 1000 + b"\n", 0)})   # >= 4096 k-mer positions
