@@ -215,10 +215,46 @@ int ancientModule(Args &a, bool assemble) {
     cdm_seqdb_free(out); cdm_alns_free(alns); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
+// Fused reads loop: the body of `while [ $STEP -lt $NUM_IT_READS ]` of data/nuclassemble.sh:100-146
+// - kmermatcher, rescorediagonal, ancient_correction, ancient_read_assemble per iteration - in one process with every
+// intermediate resident in HBM; no prefilter/alignment/correction text DB is written, only the final sequence DB.
+// Not a module of the reference; the per-stage modules above remain the drop-in surface.
+int readsLoop(Args &a) {
+    if (a.pos.size() < 2) die("Usage: carpedeam ancient_reads_loop <i:sequenceDB> <o:sequenceDB> --ancient-damage <prefix> [--num-iter-reads-only N]");
+    MmDb seq; std::string err; if (!seq.load(a.pos[0], &err)) die(err);
+    cdm_ctx *ctx = openCtx();
+    check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");
+    cdm_seqdb *db = uploadSeqDb(ctx, seq);
+    cdm_kmer_params kp;
+    kp.kmer_size = (int) iflag(a, "--k-ancient-reads", 20); kp.kmers_per_seq = (int) iflag(a, "--kmer-per-seq-ancient", 200);
+    kp.kmers_per_seq_scale = fflag(a, "--kmer-per-seq-scale-ancient", 0.2f); kp.hash_shift = (uint64_t) iflag(a, "--hash-shift", 67);
+    kp.ignore_multi_kmer = 1; kp.include_only_extendable = (int) iflag(a, "--include-only-extendable-ancient-reads", 0); kp.cov_mode = 1; kp.cov_thr = 0.0f;
+    cdm_rescore_params rp;
+    rp.seq_id_thr = fflag(a, "--min-seq-id", 0.9f); rp.eval_thr = a.flag.count("-e") ? strtod(a.flag["-e"].c_str(), NULL) : 0.001;
+    rp.cov_mode = 1; rp.cov_thr = 0.0f; rp.seq_id_mode = 0; rp.min_aln_len = 0;
+    cdm_ancient_params ap = ancientParams(a);
+    if (!a.flag.count("--max-seq-len")) ap.max_seq_len = 200000;   // setGuidedNuclAssemblerWorkflowDefaults (GuidedNuclassembler.cpp:29)
+    const long iters = iflag(a, "--num-iter-reads-only", 5);       // LocalParameters.h:304
+    for (long it = 0; it < iters; it++) {
+        cdm_hits *hits = NULL; cdm_alns *alns = NULL; cdm_seqdb *corr = NULL, *next = NULL;
+        check(cdm_kmermatch(ctx, db, &kp, &hits), "kmermatcher");
+        check(cdm_rescore(ctx, db, hits, &rp, &alns), "rescorediagonal");
+        cdm_hits_free(hits);
+        check(cdm_correct(ctx, db, alns, &ap, &corr), "ancient_correction");
+        check(cdm_extend(ctx, corr, alns, &ap, &next, NULL), "ancient_read_assemble");
+        fprintf(stderr, "STEP: %ld  sequences %llu  residues %llu -> %llu  alignments %llu\n", it, (unsigned long long) cdm_seqdb_size(db),
+                (unsigned long long) cdm_seqdb_residues(db), (unsigned long long) cdm_seqdb_residues(next), (unsigned long long) cdm_alns_count(alns));
+        cdm_alns_free(alns); cdm_seqdb_free(corr); cdm_seqdb_free(db);
+        db = next;
+    }
+    writeSeqDb(ctx, db, a.pos[1], seq.dbtype);
+    cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
+    return EXIT_SUCCESS;
+}
 }  // namespace
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: carpedeam <kmermatcher|rescorediagonal|ancient_correction|ancient_read_assemble> <args>\n"); return EXIT_FAILURE; }
+    if (argc < 2) { fprintf(stderr, "usage: carpedeam <kmermatcher|rescorediagonal|ancient_correction|ancient_read_assemble|ancient_reads_loop> <args>\n"); return EXIT_FAILURE; }
     const std::string cmd = argv[1];
     Args a = parse(argc - 2, argv + 2);
     auto t0 = std::chrono::steady_clock::now();
@@ -227,6 +263,7 @@ int main(int argc, char **argv) {
     else if (cmd == "rescorediagonal") rc = rescorediagonal(a);
     else if (cmd == "ancient_correction") rc = ancientModule(a, false);
     else if (cmd == "ancient_read_assemble") rc = ancientModule(a, true);
+    else if (cmd == "ancient_reads_loop") rc = readsLoop(a);
     else { fprintf(stderr, "Invalid Command: %s\n", cmd.c_str()); return EXIT_FAILURE; }
     fprintf(stderr, "Time for processing: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return rc;
