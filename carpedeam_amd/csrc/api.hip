@@ -445,8 +445,22 @@ static int csr_upload(cdm_ctx *ctx, uint64_t n, const uint64_t *offsets, const R
     *out = h;
     return CDM_OK;
 }
+// The kernels index sequences with the record fields: everything that comes from a file is range-checked on the host first
+// (a bad index in a hand-written kernel is a GPU fault, not an error code).
+static int fetchLens(cdm_ctx *ctx, const cdm_seqdb *db, std::vector<uint32_t> &lens) {
+    lens.resize(db->n);
+    CDM_HIP(hipMemcpy(lens.data(), db->len, db->n * 4, hipMemcpyDeviceToHost));
+    return CDM_OK;
+}
 extern "C" int cdm_hits_upload(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *offsets, const cdm_hit *hits, cdm_hits **out) {
     static_assert(sizeof(cdm_hit) == sizeof(HitRec), "layout");
+    if (!ctx || !db || !offsets || !out || (offsets[db->n] && !hits)) { cdm_set_error("cdm_hits_upload: NULL argument"); return CDM_ERR_INVALID; }
+    for (uint64_t i = 0; i < offsets[db->n]; i++)
+        if (hits[i].target >= db->n || hits[i].diagonal < -32768 || hits[i].diagonal > 32767) {
+            cdm_set_error("cdm_hits_upload: record %llu is out of range (target %u of %llu sequences, diagonal %d)", (unsigned long long) i, hits[i].target,
+                          (unsigned long long) db->n, hits[i].diagonal);
+            return CDM_ERR_INVALID;
+        }
     return csr_upload<cdm_hits, HitRec>(ctx, db->n, offsets, reinterpret_cast<const HitRec *>(hits), out);
 }
 extern "C" uint64_t cdm_hits_count(const cdm_hits *h) { return h->count; }
@@ -461,6 +475,25 @@ extern "C" void cdm_hits_free(cdm_hits *h) { if (!h) return; cdmFree(h->off); cd
 
 extern "C" int cdm_alns_upload(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *offsets, const cdm_aln *alns, cdm_alns **out) {
     static_assert(sizeof(cdm_aln) == sizeof(AlnRec), "layout");
+    if (!ctx || !db || !offsets || !out || (offsets[db->n] && !alns)) { cdm_set_error("cdm_alns_upload: NULL argument"); return CDM_ERR_INVALID; }
+    {
+        CDM_HIP(hipSetDevice(ctx->device));
+        std::vector<uint32_t> lens;
+        int rc = fetchLens(ctx, db, lens);
+        if (rc) return rc;
+        for (uint64_t q = 0; q < db->n; q++)
+            for (uint64_t i = offsets[q]; i < offsets[q + 1] && offsets[q + 1] >= offsets[q]; i++) {
+                const cdm_aln &r = alns[i];
+                const bool ok = r.target < db->n && r.q_start >= 0 && r.q_end >= 0 && (uint32_t) r.q_start < lens[q] && (uint32_t) r.q_end < lens[q] &&
+                                r.db_start >= 0 && r.db_end >= r.db_start && (uint32_t) r.db_end < lens[r.target < db->n ? r.target : 0] &&
+                                abs(r.q_end - r.q_start) == r.db_end - r.db_start;   // ungapped: both spans have the same length
+                if (!ok) {
+                    cdm_set_error("cdm_alns_upload: alignment record %llu of query %llu does not fit the sequence DB (target %u, q %d-%d of %u, db %d-%d)",
+                                  (unsigned long long) i, (unsigned long long) q, r.target, r.q_start, r.q_end, lens[q], r.db_start, r.db_end);
+                    return CDM_ERR_INVALID;
+                }
+            }
+    }
     return csr_upload<cdm_alns, AlnRec>(ctx, db->n, offsets, reinterpret_cast<const AlnRec *>(alns), out);
 }
 extern "C" uint64_t cdm_alns_count(const cdm_alns *a) { return a->count; }

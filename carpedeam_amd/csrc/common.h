@@ -19,6 +19,17 @@ void cdmFree(void *p);
 void cdmPoolTrim();   // give every cached block back to the driver
 template <typename T> inline hipError_t cdmMalloc(T **p, size_t bytes) { return cdmMallocRaw(reinterpret_cast<void **>(p), bytes); }
 
+// RAII device buffer from the caching allocator (freed on every exit path of a stage function)
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) cdmFree(p); }
+    bool alloc(size_t n) { return cdmMalloc(&p, (n + 1) * sizeof(T)) == hipSuccess; }
+    T *release() { T *r = p; p = nullptr; return r; }
+};
+
 #define CDM_HIP(expr)                                                                                   \
     do {                                                                                                \
         hipError_t _e = (expr);                                                                         \

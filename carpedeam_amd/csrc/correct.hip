@@ -396,35 +396,27 @@ extern "C" int cdm_debug_call_bases(cdm_ctx *ctx, const uint32_t *vectors, uint3
 int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb *out) {
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t) db->n;
-    uint32_t *active = nullptr, *activeFast = nullptr; unsigned int *nActive = nullptr; uint8_t *accept = nullptr;
-    if (cdmMalloc(&active, (size_t) n * 4) != hipSuccess || cdmMalloc(&activeFast, (size_t) n * 4) != hipSuccess || cdmMalloc(&nActive, 16) != hipSuccess || cdmMalloc(&accept, alns->count + 1) != hipSuccess) {
-        cdmFree(active); cdmFree(activeFast); cdmFree(nActive); cdmFree(accept);
-        cdm_set_error("out of device memory in cdm_correct"); return CDM_ERR_HIP;
-    }
-    int rc = CDM_OK;
-    do {
-        // coverage <= 1 everywhere unless the kernel overwrites: start from a copy of the input bases
-        hipMemcpyAsync(out->codes, db->codes, db->words * 4, hipMemcpyDeviceToDevice, s);
-        hipMemcpyAsync(out->nmask, db->nmask, ((db->words * 16 + 31) / 32) * 4, hipMemcpyDeviceToDevice, s);
-        hipMemsetAsync(nActive, 0, 16, s);
-        hipLaunchKernelGGL(k_mark_active, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, n, active, activeFast, nActive);
-        CorrectArgs a;
-        a.woff = db->woff; a.len = db->len; a.codes = db->codes; a.nmask = db->nmask; a.ext = db->ext; a.hasN = db->hasN;
-        a.aoff = alns->off; a.rec = alns->rec; a.active = active; a.nActive = nActive; a.accept = accept; a.errFlag = nActive + 1;
-        a.outCodes = out->codes; a.outNmask = out->nmask; a.lut = ctx->lutDev; a.seqIdThr = par->seq_id_thr; a.corrRy = par->corr_reads_ry_seq_id;
-        const int blocks = ctx->cuCount * 8;
-        hipEventRecord(ctx->ev0, s);
-        hipLaunchKernelGGL(k_correct_fast, dim3(blocks), dim3(64 * FAST_WAVES), 0, s, a, activeFast, nActive + 2);
-        hipLaunchKernelGGL(k_correct, dim3(blocks / 4), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
-        hipEventRecord(ctx->ev1, s);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { cdm_set_error("ancient_correction kernel failed: %s", hipGetErrorString(e)); rc = CDM_ERR_HIP; break; }
-        hipEventElapsedTime(&ctx->lastMs[0], ctx->ev0, ctx->ev1);
-        unsigned int flags[2] = {0, 0};
-        hipMemcpy(flags, nActive, 8, hipMemcpyDeviceToHost);
-        if (flags[1]) { cdm_set_error("ancient_correction: a query has more than 65535 alignment records (unsupported)"); rc = CDM_ERR_UNSUPPORTED; break; }
-    } while (0);
-    cdmFree(active); cdmFree(activeFast); cdmFree(nActive); cdmFree(accept);
-    return rc;
+    DevBuf<uint32_t> active, activeFast; DevBuf<unsigned int> counters; DevBuf<uint8_t> accept;
+    if (!active.alloc(n) || !activeFast.alloc(n) || !counters.alloc(4) || !accept.alloc(alns->count)) { cdm_set_error("out of device memory in cdm_correct"); return CDM_ERR_HIP; }
+    // coverage <= 1 everywhere unless the kernels overwrite: start from a copy of the input bases
+    CDM_HIP(hipMemcpyAsync(out->codes, db->codes, db->words * 4, hipMemcpyDeviceToDevice, s));
+    CDM_HIP(hipMemcpyAsync(out->nmask, db->nmask, ((db->words * 16 + 31) / 32) * 4, hipMemcpyDeviceToDevice, s));
+    CDM_HIP(hipMemsetAsync(counters.p, 0, 16, s));   // [0] queries for the general kernel, [1] error flag, [2] queries for the fast kernel
+    hipLaunchKernelGGL(k_mark_active, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, n, active.p, activeFast.p, counters.p);
+    CorrectArgs a;
+    a.woff = db->woff; a.len = db->len; a.codes = db->codes; a.nmask = db->nmask; a.ext = db->ext; a.hasN = db->hasN;
+    a.aoff = alns->off; a.rec = alns->rec; a.active = active.p; a.nActive = counters.p; a.accept = accept.p; a.errFlag = counters.p + 1;
+    a.outCodes = out->codes; a.outNmask = out->nmask; a.lut = ctx->lutDev; a.seqIdThr = par->seq_id_thr; a.corrRy = par->corr_reads_ry_seq_id;
+    const int blocks = ctx->cuCount * 8;
+    hipEventRecord(ctx->ev0, s);
+    hipLaunchKernelGGL(k_correct_fast, dim3(blocks), dim3(64 * FAST_WAVES), 0, s, a, activeFast.p, counters.p + 2);
+    hipLaunchKernelGGL(k_correct, dim3(blocks / 4), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+    hipEventRecord(ctx->ev1, s);
+    CDM_LAUNCH_CHECK();
+    unsigned int flags[2] = {0, 0};
+    CDM_HIP(hipMemcpyAsync(flags, counters.p, 8, hipMemcpyDeviceToHost, s));
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("ancient_correction kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    hipEventElapsedTime(&ctx->lastMs[0], ctx->ev0, ctx->ev1);
+    if (flags[1]) { cdm_set_error("ancient_correction: a query has more than 65535 alignment records (unsupported)"); return CDM_ERR_UNSUPPORTED; }
+    return CDM_OK;
 }

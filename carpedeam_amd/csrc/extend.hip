@@ -405,11 +405,6 @@ __global__ __launch_bounds__(256) void k_write(ExtArgs A, const uint32_t *__rest
     if (nb) oHasN[q] = 1;
 }
 
-template <typename T> struct DevBuf {
-    T *p = nullptr;
-    ~DevBuf() { if (p) cdmFree(p); }
-    bool alloc(size_t n) { return cdmMalloc(&p, (n + 1) * sizeof(T)) == hipSuccess; }
-};
 
 }  // namespace
 

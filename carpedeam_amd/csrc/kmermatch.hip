@@ -563,34 +563,6 @@ __global__ void k_slot_scatter(const uint32_t *__restrict__ order, const unsigne
     if (r < n) { slotOff[order[r]] = ordOff[r]; rankOf[order[r]] = r; }
     if (r == n) slotOff[n] = ordOff[n];
 }
-__global__ void k_classify(const uint32_t *__restrict__ len, uint32_t n, int k, uint32_t shortCap, uint32_t *__restrict__ listShort,
-                           uint32_t *__restrict__ listLong, unsigned int *__restrict__ cnt, uint32_t longCap) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t L = len[i];
-    const uint32_t nk = (L >= (uint32_t) k) ? (L - k + 1) : 0;
-    if (nk < shortCap) listShort[atomicAdd(&cnt[0], 1u)] = i;
-    else if (nk < longCap) listLong[atomicAdd(&cnt[1], 1u)] = i;
-    else atomicAdd(&cnt[2], 1u);
-}
-__global__ void k_count_kmers(const uint32_t *__restrict__ len, uint32_t n, int k, int kmersPerSeq, float scale, unsigned long long *__restrict__ total) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long v = 0;
-    if (i < n) {   // computeKmerCount kmermatcher.cpp:573-582
-        const int L = (int) len[i];
-        const int adj = max(1, L - k + 2);
-        v = (unsigned long long) min(adj, static_cast<int>(kmersPerSeq + (scale * L)));
-    }
-    // wave reduce then one atomic
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
-}
-
-template <typename T> struct DevBuf {
-    T *p = nullptr;
-    ~DevBuf() { if (p) cdmFree(p); }
-    bool alloc(size_t n) { return cdmMalloc(&p, (n + 1) * sizeof(T)) == hipSuccess; }
-};
 inline uint32_t bitsFor(uint64_t v) { uint32_t b = 1; while ((1ull << b) < v) b++; return b; }
 
 }  // namespace

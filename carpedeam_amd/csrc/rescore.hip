@@ -166,58 +166,52 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     const uint32_t n = (uint32_t) db->n;
     const uint64_t nHits = hits->count;
     if (db->maxLen >= (1u << 30)) { cdm_set_error("cdm_rescore: sequence too long"); return CDM_ERR_UNSUPPORTED; }
+    DevBuf<uint32_t> dPresent, owner; DevBuf<int32_t> dMin; DevBuf<AlnRec> tmp; DevBuf<uint8_t> valid; DevBuf<uint64_t> cnt; DevBuf<char> scanTmp;
+    if (!dPresent.alloc(db->maxLen + 1) || !dMin.alloc(db->maxLen + 1) || !owner.alloc(nHits) || !tmp.alloc(nHits) || !valid.alloc(nHits) || !cnt.alloc((size_t) n + 1)) {
+        cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP;
+    }
     // E-value gate table for the lengths that occur (host ALP arithmetic, host/evalue.cpp)
     std::vector<uint32_t> present(db->maxLen + 1);
-    uint32_t *dPresent = nullptr; int32_t *dMin = nullptr; uint32_t *owner = nullptr; AlnRec *tmp = nullptr; uint8_t *valid = nullptr;
-    uint64_t *cnt = nullptr; void *scanTmp = nullptr;
-    cdm_alns *res = nullptr;
-    int rc = CDM_OK;
-    auto fail = [&](const char *what) { cdm_set_error("cdm_rescore: %s", what); rc = CDM_ERR_HIP; };
-    do {
-        if (cdmMalloc(&dPresent, (size_t) (db->maxLen + 1) * 4) != hipSuccess || cdmMalloc(&dMin, (size_t) (db->maxLen + 1) * 4) != hipSuccess ||
-            cdmMalloc(&owner, (nHits + 1) * 4) != hipSuccess || cdmMalloc(&tmp, (nHits + 1) * sizeof(AlnRec)) != hipSuccess ||
-            cdmMalloc(&valid, nHits + 1) != hipSuccess || cdmMalloc(&cnt, ((size_t) n + 1) * 8) != hipSuccess) { fail("out of device memory"); break; }
-        hipMemsetAsync(dPresent, 0, (size_t) (db->maxLen + 1) * 4, s);
-        hipLaunchKernelGGL(k_len_hist, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, dPresent);
-        hipMemcpyAsync(present.data(), dPresent, (size_t) (db->maxLen + 1) * 4, hipMemcpyDeviceToHost, s);
-        if (hipStreamSynchronize(s) != hipSuccess) { fail("length histogram failed"); break; }
-        std::vector<int32_t> minScore(db->maxLen + 1, INT_MAX);
-        for (uint32_t L = 1; L <= db->maxLen; L++) {
-            if (!present[L]) continue;
-            int lo = 0, hi = 2 * (int) L;   // E-value decreases with the score (checked in tests for the lengths used)
-            if (!(cdm_evalue_host(hi, L, db->residues) <= par->eval_thr)) continue;
-            while (lo < hi) { int mid = (lo + hi) / 2; if (cdm_evalue_host(mid, L, db->residues) <= par->eval_thr) hi = mid; else lo = mid + 1; }
-            minScore[L] = lo;
-        }
-        hipMemcpyAsync(dMin, minScore.data(), (size_t) (db->maxLen + 1) * 4, hipMemcpyHostToDevice, s);
-        hipLaunchKernelGGL(k_expand, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, n, owner);
-        RescoreArgs a;
-        a.woff = db->woff; a.len = db->len; a.codes = db->codes; a.nmask = db->nmask; a.hasN = db->hasN; a.hoff = hits->off; a.hit = hits->rec;
-        a.minScore = dMin; a.nHits = nHits; a.n = n; a.seqIdThr = par->seq_id_thr; a.covThr = par->cov_thr; a.covMode = par->cov_mode;
-        a.minAlnLen = par->min_aln_len; a.tmp = tmp; a.valid = valid;
-        hipEventRecord(ctx->ev0, s);
-        if (nHits) hipLaunchKernelGGL(k_rescore, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, s, a, owner);
-        hipEventRecord(ctx->ev1, s);
-        hipLaunchKernelGGL(k_count_valid, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid, n, cnt);
-        res = new cdm_alns(); res->n = n;
-        if (cdmMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { fail("out of device memory"); break; }
-        size_t tmpBytes = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cnt, res->off, n + 1, s);
-        if (cdmMalloc(&scanTmp, tmpBytes + 16) != hipSuccess) { fail("out of device memory"); break; }
-        hipMemsetAsync(cnt + n, 0, 8, s);
-        hipcub::DeviceScan::ExclusiveSum(scanTmp, tmpBytes, cnt, res->off, n + 1, s);
-        uint64_t total = 0;
-        hipMemcpyAsync(&total, res->off + n, 8, hipMemcpyDeviceToHost, s);
-        if (hipStreamSynchronize(s) != hipSuccess) { fail("kernel failed"); break; }
-        res->count = total;
-        if (cdmMalloc(&res->rec, (total + 1) * sizeof(AlnRec)) != hipSuccess) { fail("out of device memory"); break; }
-        hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid, tmp, n, res->off, res->rec);
-        hipError_t e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { fail(hipGetErrorString(e)); break; }
-        hipEventElapsedTime(&ctx->lastMs[1], ctx->ev0, ctx->ev1);
-    } while (0);
-    cdmFree(dPresent); cdmFree(dMin); cdmFree(owner); cdmFree(tmp); cdmFree(valid); cdmFree(cnt); cdmFree(scanTmp);
-    if (rc != CDM_OK) { if (res) cdm_alns_free(res); return rc; }
+    CDM_HIP(hipMemsetAsync(dPresent.p, 0, (size_t) (db->maxLen + 1) * 4, s));
+    hipLaunchKernelGGL(k_len_hist, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, dPresent.p);
+    CDM_HIP(hipMemcpyAsync(present.data(), dPresent.p, (size_t) (db->maxLen + 1) * 4, hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> minScore(db->maxLen + 1, INT_MAX);
+    for (uint32_t L = 1; L <= db->maxLen; L++) {
+        if (!present[L]) continue;
+        int lo = 0, hi = 2 * (int) L;   // E-value decreases with the score (tests/test_gpu_rescore.py checks it for the lengths used)
+        if (!(cdm_evalue_host(hi, L, db->residues) <= par->eval_thr)) continue;
+        while (lo < hi) { int mid = (lo + hi) / 2; if (cdm_evalue_host(mid, L, db->residues) <= par->eval_thr) hi = mid; else lo = mid + 1; }
+        minScore[L] = lo;
+    }
+    CDM_HIP(hipMemcpyAsync(dMin.p, minScore.data(), (size_t) (db->maxLen + 1) * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_expand, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, n, owner.p);
+    RescoreArgs a;
+    a.woff = db->woff; a.len = db->len; a.codes = db->codes; a.nmask = db->nmask; a.hasN = db->hasN; a.hoff = hits->off; a.hit = hits->rec;
+    a.minScore = dMin.p; a.nHits = nHits; a.n = n; a.seqIdThr = par->seq_id_thr; a.covThr = par->cov_thr; a.covMode = par->cov_mode;
+    a.minAlnLen = par->min_aln_len; a.tmp = tmp.p; a.valid = valid.p;
+    hipEventRecord(ctx->ev0, s);
+    if (nHits) hipLaunchKernelGGL(k_rescore, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, s, a, owner.p);
+    hipEventRecord(ctx->ev1, s);
+    hipLaunchKernelGGL(k_count_valid, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid.p, n, cnt.p);
+    CDM_LAUNCH_CHECK();
+    cdm_alns *res = new cdm_alns(); res->n = n;
+    struct Guard { cdm_alns *&r; bool armed = true; ~Guard() { if (armed && r) { cdm_alns_free(r); r = nullptr; } } } guard{res};
+    if (cdmMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
+    size_t tmpBytes = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cnt.p, res->off, n + 1, s);
+    if (!scanTmp.alloc(tmpBytes + 16)) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
+    CDM_HIP(hipMemsetAsync(cnt.p + n, 0, 8, s));
+    hipcub::DeviceScan::ExclusiveSum(scanTmp.p, tmpBytes, cnt.p, res->off, n + 1, s);
+    uint64_t total = 0;
+    CDM_HIP(hipMemcpyAsync(&total, res->off + n, 8, hipMemcpyDeviceToHost, s));
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_rescore: kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    res->count = total;
+    if (cdmMalloc(&res->rec, (total + 1) * sizeof(AlnRec)) != hipSuccess) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
+    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid.p, tmp.p, n, res->off, res->rec);
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_rescore: compaction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    hipEventElapsedTime(&ctx->lastMs[1], ctx->ev0, ctx->ev1);
+    guard.armed = false;
     *out = res;
     return CDM_OK;
 }

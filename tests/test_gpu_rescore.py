@@ -51,3 +51,16 @@ def test_evalue_gate_is_monotone():
             passed = [l.cdm_evalue(float(s), float(L), db_res) <= 0.001 for s in range(0, 2 * L + 1)]
             first = passed.index(True) if True in passed else len(passed)
             assert all(passed[first:]), (db_res, L)
+
+
+def test_uploads_are_range_checked(ctx):
+    """records that come from files are validated on the host before any kernel indexes with them"""
+    db = ctx.upload_seqs(["ACGT" * 10, "ACGTT" * 8])
+    off = np.array([0, 1, 1], np.uint64)
+    with pytest.raises(capi.CdmError):
+        ctx.upload_hits(db, off, np.array([(7, 0, 0)], capi.HIT_DTYPE))
+    with pytest.raises(capi.CdmError):
+        ctx.upload_alns(db, off, np.array([(1, 10, 5, 0, 60, 0, 60, 1.0)], capi.ALN_DTYPE))      # q_end beyond the query
+    with pytest.raises(capi.CdmError):
+        ctx.upload_alns(db, off, np.array([(1, 10, 5, 0, 20, 0, 30, 1.0)], capi.ALN_DTYPE))      # spans differ: not ungapped
+    ctx.upload_alns(db, off, np.array([(1, 10, 5, 0, 20, 5, 25, 1.0)], capi.ALN_DTYPE))
