@@ -28,6 +28,7 @@ template <typename T> struct DevBuf {
     ~DevBuf() { if (p) cdmFree(p); }
     bool alloc(size_t n) { return cdmMalloc(&p, (n + 1) * sizeof(T)) == hipSuccess; }
     T *release() { T *r = p; p = nullptr; return r; }
+    void free() { if (p) { cdmFree(p); p = nullptr; } }
 };
 
 #define CDM_HIP(expr)                                                                                   \

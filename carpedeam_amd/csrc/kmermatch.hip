@@ -46,13 +46,55 @@ __device__ __forceinline__ uint64_t revComplement(uint64_t kmer, int k) {
     return x >> (64 - 2 * k);
 }
 
-struct ExtractArgs {
+// ------------------------------------------------------------------------------------------------ tuple layouts
+// Two physical layouts of the (k-mer, strand, sequence id, sequence length, position) tuple the reference keeps in
+// KmerPosition<T> (kmermatcher.h:49-54).  Region 1 of the array (one slot per k-mer position + slot 0 per sequence) is sorted
+// on the low 2k key bits, region 2 (one whole-sequence hash tuple per sequence, 63 random bits) on 63 bits.
+struct TupleGeom {
+    int kbits, lb;              // 2k, bits of a length/position field
+    uint64_t kmerSlots;         // size of region 1
+    const uint32_t *lenArr;     // sequence lengths (region-2 tuples of the packed layout look their length up)
+};
+// 16 bytes: u64 key = k-mer | strand << 63, u64 value = id << 32 | len << 16 | pos.  Always applicable.
+struct LayoutWide {
+    typedef uint64_t V;
+    __device__ static void store(uint64_t *keys, V *vals, uint64_t slot, uint64_t kmer63, bool fwd, uint32_t seq, uint32_t L, uint32_t pos, const TupleGeom &) {
+        keys[slot] = kmer63 | (fwd ? BIT63 : 0ull); vals[slot] = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | pos;
+    }
+    __device__ static void storeHash(uint64_t *keys, V *vals, uint64_t slot, uint64_t hash64, uint32_t seq, uint32_t L, const TupleGeom &) {
+        keys[slot] = hash64; vals[slot] = ((uint64_t) seq << 32) | ((uint64_t) L << 16);
+    }
+    __device__ static void storeEmpty(uint64_t *keys, V *vals, uint64_t slot) { keys[slot] = ~0ull; vals[slot] = 0; }
+    __device__ static uint64_t kmerOf(uint64_t key, uint64_t, const TupleGeom &) { return key & ~BIT63; }
+    __device__ static uint32_t seqOf(V v) { return (uint32_t) (v >> 32); }
+    __device__ static uint32_t lenOf(uint64_t, V v, uint64_t, const TupleGeom &) { return (uint32_t) ((v >> 16) & 0xFFFF); }
+    __device__ static uint32_t posOf(uint64_t, V v, uint64_t, const TupleGeom &) { return (uint32_t) (v & 0xFFFF); }
+};
+// 12 bytes: u64 key = k-mer | pos << 2k | len << (2k + lb) | strand << 63, u32 value = id.  Needs 2k + 2 lb <= 63 (k = 20: sequences
+// up to 2047 letters); a quarter less traffic in every radix pass.  Only the low 2k bits of region 1 are sorted.
+struct LayoutPacked {
+    typedef uint32_t V;
+    __device__ static void store(uint64_t *keys, V *vals, uint64_t slot, uint64_t kmer63, bool fwd, uint32_t seq, uint32_t L, uint32_t pos, const TupleGeom &g) {
+        keys[slot] = kmer63 | ((uint64_t) pos << g.kbits) | ((uint64_t) L << (g.kbits + g.lb)) | (fwd ? BIT63 : 0ull); vals[slot] = seq;
+    }
+    __device__ static void storeHash(uint64_t *keys, V *vals, uint64_t slot, uint64_t hash64, uint32_t seq, uint32_t L, const TupleGeom &g) {
+        // region 1 (a hash that fits 2k bits): position 0, length packed above it; region 2: the full hash, length looked up
+        keys[slot] = (slot < g.kmerSlots) ? (hash64 | ((uint64_t) L << (g.kbits + g.lb))) : hash64; vals[slot] = seq;
+    }
+    __device__ static void storeEmpty(uint64_t *keys, V *vals, uint64_t slot) { keys[slot] = ~0ull; vals[slot] = 0; }
+    __device__ static uint64_t kmerOf(uint64_t key, uint64_t slot, const TupleGeom &g) { return slot < g.kmerSlots ? (key & ((1ull << g.kbits) - 1ull)) : (key & ~BIT63); }
+    __device__ static uint32_t seqOf(V v) { return v; }
+    __device__ static uint32_t lenOf(uint64_t key, V v, uint64_t slot, const TupleGeom &g) { return slot < g.kmerSlots ? (uint32_t) ((key >> (g.kbits + g.lb)) & ((1ull << g.lb) - 1ull)) : g.lenArr[v]; }
+    __device__ static uint32_t posOf(uint64_t key, V, uint64_t slot, const TupleGeom &g) { return slot < g.kmerSlots ? (uint32_t) ((key >> g.kbits) & ((1ull << g.lb) - 1ull)) : 0u; }
+};
+
+template <typename LY> struct ExtractArgs {
     const uint32_t *woff, *len, *codes, *nmask;
     const uint8_t *hasN;
     const uint32_t *list;       // sequence indices this launch handles
     uint32_t nList;
     int k, kmersPerSeq; float scale; uint64_t seed; int ignoreMultiKmer;
-    uint64_t *keys, *vals;      // tuple array: key = k-mer | strand bit 63, val = id << 32 | seqLen << 16 | pos
+    uint64_t *keys; typename LY::V *vals;   // tuple array
     const uint64_t *slotOff;    // [n+1] first slot of every sequence: 1 whole-sequence tuple + one slot per k-mer position;
                                 // unused slots hold the key ~0 (sorts last, dropped by k_groups)
     uint32_t *slowShort, *slowLong; unsigned int *slowCnt;   // sequences the fast kernel hands to the general one
@@ -62,13 +104,15 @@ struct ExtractArgs {
     // stays in slot 0 of the sequence).  Region 1 is sorted on 2k bits, region 2 on 63: every key of region 1 is smaller
     // than every key of region 2, so the concatenation is the array the reference sorts on the full key.
     uint64_t hashBase; const uint32_t *rankOf;
+    TupleGeom geom;
 };
-__device__ __forceinline__ void putSeqHashTuple(const ExtractArgs &a, uint32_t seq, uint32_t L, uint64_t base, uint64_t h) {
-    const uint64_t key = xxh64_u64(h, a.seed), val = ((uint64_t) seq << 32) | ((uint64_t) L << 16);
+template <typename LY>
+__device__ __forceinline__ void putSeqHashTuple(const ExtractArgs<LY> &a, uint32_t seq, uint32_t L, uint64_t base, uint64_t h) {
+    const uint64_t key = xxh64_u64(h, a.seed);
     const uint64_t hslot = a.hashBase + a.rankOf[seq];
     const bool small = (key & ~BIT63) < (1ull << (2 * a.k));
-    a.keys[base] = small ? key : ~0ull; a.vals[base] = small ? val : 0ull;
-    a.keys[hslot] = small ? ~0ull : key; a.vals[hslot] = small ? 0ull : val;
+    if (small) { LY::storeHash(a.keys, a.vals, base, key, seq, L, a.geom); LY::storeEmpty(a.keys, a.vals, hslot); }
+    else { LY::storeEmpty(a.keys, a.vals, base); LY::storeHash(a.keys, a.vals, hslot, key, seq, L, a.geom); }
 }
 
 // 2k-bit window of the sequence starting at base pos, MMseqs2 coding (A,C,T,G), first base in the LOW bits
@@ -108,7 +152,8 @@ constexpr int FAST_WAVES = 4, FAST_TABLE = 1024, FAST_CAP = 448;
 // Fast path of K1: one wavefront per sequence, no per-sequence sort.  Valid when every k-mer is taken
 // (positions <= kmersPerSeq - 1 + scale * L) and no canonical k-mer occurs twice in the sequence (checked with an LDS
 // hash set); then the selection is "all k-mers" whatever the (hash, k-mer, pos) order.  Anything else goes to k_extract.
-__global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs a) {
+template <typename LY>
+__global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY> a) {
     __shared__ unsigned long long sTable[FAST_WAVES][FAST_TABLE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long *table = sTable[wave];
@@ -136,13 +181,12 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs a)
             if (hasN) for (int j = 0; j < k; j++) x |= cdm_isN(a.nmask, w0, pos + j) != 0;
             const uint64_t idx = groupsReversed(w, k);
             const uint64_t rc = (w ^ 0xAAAAAAAAAAAAAAAAull) & ((1ull << (2 * k)) - 1ull);   // Util::revComplement(idx): window order, complemented
-            uint64_t key = ~0ull, val = 0;
+            bool real = false; uint64_t km = 0; uint32_t p = 0; bool pickRev = false;
             if (!x && rc != idx) {
-                const bool pickRev = rc < idx;
-                const uint64_t km = pickRev ? rc : idx;
-                const uint32_t p = pickRev ? (L - pos - k) : pos;
-                key = km | (pickRev ? 0ull : BIT63);
-                val = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | (uint64_t) p;
+                real = true;
+                pickRev = rc < idx;
+                km = pickRev ? rc : idx;
+                p = pickRev ? (L - pos - k) : pos;
                 if (a.ignoreMultiKmer) {
                     uint32_t h = (uint32_t) ((km * 0x9E3779B97F4A7C15ull) >> 40) & tmask;
                     while (true) {
@@ -153,8 +197,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs a)
                     }
                 }
             }
-            a.keys[base + 1 + pos] = key;
-            a.vals[base + 1 + pos] = val;
+            if (real) LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom);
+            else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
         }
         const uint64_t h = waveSeqHash(a.codes, a.nmask, w0, L, hasN, lane);
         if (lane == 0) putSeqHashTuple(a, seq, L, base, h);
@@ -172,8 +216,8 @@ __device__ __forceinline__ uint32_t spScore(const SeqPos &x) { return (uint32_t)
 __device__ __forceinline__ uint32_t spPos(const SeqPos &x) { return (uint32_t) ((x.b >> 1) & 0xFFFFFFFFFFFFull); }
 
 // One workgroup of NT threads per sequence; CAP = power of two >= number of k-mers of the sequence.
-template <int CAP, int NT>
-__global__ __launch_bounds__(NT) void k_extract(ExtractArgs a) {
+template <typename LY, int CAP, int NT>
+__global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
     __shared__ SeqPos sp[CAP];
     __shared__ uint8_t sel[CAP];
     __shared__ uint32_t sN, sCursor;
@@ -292,22 +336,24 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs a) {
                 if (!sel[i]) continue;
                 const uint32_t o = atomicAdd(&sCursor, 1u);
                 const SeqPos e = sp[i];
-                a.keys[base + 1 + o] = spKmer63(e) | ((e.b & 1ull) ? BIT63 : 0ull);
-                a.vals[base + 1 + o] = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | (uint64_t) spPos(e);
+                LY::store(a.keys, a.vals, base + 1 + o, spKmer63(e), (e.b & 1ull) != 0, seq, L, spPos(e), a.geom);
             }
             __syncthreads();
-            for (uint32_t i = sCursor + tid; i < nPos; i += NT) { a.keys[base + 1 + i] = ~0ull; a.vals[base + 1 + i] = 0; }
+            for (uint32_t i = sCursor + tid; i < nPos; i += NT) LY::storeEmpty(a.keys, a.vals, base + 1 + i);
         }
         __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------------ K3: groups
-struct GroupArgs {
-    const uint64_t *keys, *vals;   // sorted by k-mer (bits 0..62)
+struct GroupParams {
     uint64_t n;
     int onlyExtendable, covMode; float covThr;
     uint32_t idBits, diagBits; int diagBias;
+};
+template <typename LY> struct GroupArgs : GroupParams {
+    const uint64_t *keys; const typename LY::V *vals;   // sorted by k-mer
+    TupleGeom geom;
 };
 __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float ql, float tl) {
     switch (covMode) {
@@ -321,16 +367,16 @@ __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float q
     }
 }
 // key layout of the second sort: [ rep | id | diagonal + bias | strand ] , strand (1 = query needs no reversal) in bit 0
-__device__ __forceinline__ uint64_t packGroupKey(const GroupArgs &a, uint32_t rep, uint32_t id, int diag, bool noRev) {
+__device__ __forceinline__ uint64_t packGroupKey(const GroupParams &a, uint32_t rep, uint32_t id, int diag, bool noRev) {
     return ((((uint64_t) rep << a.idBits) | id) << (a.diagBits + 1)) | ((uint64_t) (uint32_t) (diag + a.diagBias) << 1) | (noRev ? 1ull : 0ull);
 }
 // run start index of every tuple = inclusive max-scan of (start ? i : 0); fed to the scan through this functor
-struct StartIndex {
-    const uint64_t *keys;
-    __host__ __device__ unsigned long long operator()(unsigned long long i) const {
+template <typename LY> struct StartIndex {
+    const uint64_t *keys; TupleGeom geom;
+    __device__ unsigned long long operator()(unsigned long long i) const {
         if (i == 0) return 0ull;
         const uint64_t a = keys[i], b = keys[i - 1];
-        const bool start = (a == ~0ull) || (b == ~0ull) || ((a & ~BIT63) != (b & ~BIT63));
+        const bool start = (a == ~0ull) || (b == ~0ull) || (LY::kmerOf(a, i, geom) != LY::kmerOf(b, i - 1, geom));
         return start ? i : 0ull;
     }
 };
@@ -339,29 +385,31 @@ struct MaxU64 { __host__ __device__ unsigned long long operator()(unsigned long 
 // K3, one thread per tuple.  The tuple array was filled in (sequence length descending, id ascending, position) order and
 // the radix sort is stable, so the first tuple of a k-mer run is the reference's representative (sort order
 // kmermatcher.h:76-96); only a k-mer that the representative's own sequence carries twice needs a look at the next tuples.
-__global__ __launch_bounds__(256) void k_groups(GroupArgs a, unsigned long long *__restrict__ startIo /* in: run start, out: packed key */) {
+template <typename LY>
+__global__ __launch_bounds__(256) void k_groups(GroupArgs<LY> a, unsigned long long *__restrict__ startIo /* in: run start, out: packed key */) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const uint64_t key = a.keys[i];
     if (key == ~0ull) { startIo[i] = ~0ull; return; }          // unused slot
     const uint64_t st = startIo[i];
-    const uint64_t km = key & ~BIT63;
-    const bool hasNext = (i + 1 < a.n) && a.keys[i + 1] != ~0ull && (a.keys[i + 1] & ~BIT63) == km;
+    const uint64_t km = LY::kmerOf(key, i, a.geom);
+    const bool hasNext = (i + 1 < a.n) && a.keys[i + 1] != ~0ull && LY::kmerOf(a.keys[i + 1], i + 1, a.geom) == km;
     if (st == i && !hasNext) { startIo[i] = ~0ull; return; }   // singleton (:479)
-    uint64_t best = a.vals[st], bestKey = a.keys[st];
-    {   // same sequence twice in the run: the smaller position wins (rare)
-        const uint32_t repSeq = (uint32_t) (best >> 32);
-        for (uint64_t e = st + 1; e < a.n && a.keys[e] != ~0ull && (a.keys[e] & ~BIT63) == km && (uint32_t) (a.vals[e] >> 32) == repSeq; e++)
-            if ((a.vals[e] & 0xFFFF) < (best & 0xFFFF)) { best = a.vals[e]; bestKey = a.keys[e]; }
+    uint64_t bestKey = a.keys[st]; typename LY::V best = a.vals[st];
+    const uint32_t repId = LY::seqOf(best);
+    uint32_t bestPos = LY::posOf(bestKey, best, st, a.geom);
+    // same sequence twice in the run: the smaller position wins (rare)
+    for (uint64_t e = st + 1; e < a.n && a.keys[e] != ~0ull && LY::kmerOf(a.keys[e], e, a.geom) == km && LY::seqOf(a.vals[e]) == repId; e++) {
+        const uint32_t pe = LY::posOf(a.keys[e], a.vals[e], e, a.geom);
+        if (pe < bestPos) { bestPos = pe; bestKey = a.keys[e]; }
     }
-    const uint32_t repId = (uint32_t) (best >> 32);
-    const int queryLen = (int) ((best >> 16) & 0xFFFF), repPos = (int) (best & 0xFFFF);
+    const int queryLen = (int) LY::lenOf(bestKey, best, st, a.geom), repPos = (int) bestPos;
     // the reference initialises repIsReverse = false and only updates it when a NEW run starts (:465,:535-538):
     // the very first run of the array keeps false whatever its strand
     const bool repIsReverse = (st == 0) ? false : ((bestKey & BIT63) == 0);
-    const uint64_t v = a.vals[i];
-    const uint32_t id = (uint32_t) (v >> 32);
-    const int tLen = (int) ((v >> 16) & 0xFFFF), tPos0 = (int) (v & 0xFFFF);
+    const typename LY::V v = a.vals[i];
+    const uint32_t id = LY::seqOf(v);
+    const int tLen = (int) LY::lenOf(key, v, i, a.geom), tPos0 = (int) LY::posOf(key, v, i, a.geom);
     const bool targetIsReverse = (key & BIT63) == 0;
     int qPos, tPos; bool qRev;
     if (repIsReverse && !targetIsReverse) { qPos = repPos; tPos = tPos0; qRev = true; }
@@ -565,9 +613,9 @@ __global__ void k_slot_scatter(const uint32_t *__restrict__ order, const unsigne
 }
 inline uint32_t bitsFor(uint64_t v) { uint32_t b = 1; while ((1ull << b) < v) b++; return b; }
 
-}  // namespace
-
-int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+template <typename LY>
+int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+    typedef typename LY::V V;
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t) db->n;
     const int k = par->kmer_size;
@@ -617,29 +665,30 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     capacity += n;                                   // region 2: whole-sequence hash tuples
     const unsigned long long nTuples = capacity;
 
-    rocprim::double_buffer<uint64_t> keys, vals;
-    DevBuf<uint64_t> k0, k1, v0, v1;
+    rocprim::double_buffer<uint64_t> keys; rocprim::double_buffer<V> vals;
+    DevBuf<uint64_t> k0, k1; DevBuf<V> v0, v1;
     if (!k0.alloc(capacity) || !k1.alloc(capacity) || !v0.alloc(capacity) || !v1.alloc(capacity)) {
-        cdm_set_error("cdm_kmermatch: out of device memory for %llu k-mer tuples (%.1f GB)", (unsigned long long) capacity, capacity * 32.0 / 1e9); return CDM_ERR_HIP;
+        cdm_set_error("cdm_kmermatch: out of device memory for %llu k-mer tuples (%.1f GB)", (unsigned long long) capacity, capacity * (16.0 + 2 * sizeof(V)) / 1e9); return CDM_ERR_HIP;
     }
-    ExtractArgs ea;
+    TupleGeom geom; geom.kbits = 2 * k; geom.lb = (int) bitsFor((uint64_t) db->maxLen + 1); geom.kmerSlots = kmerSlots; geom.lenArr = db->len;
+    ExtractArgs<LY> ea; ea.geom = geom;
     ea.woff = db->woff; ea.len = db->len; ea.codes = db->codes; ea.nmask = db->nmask; ea.hasN = db->hasN;
     ea.k = k; ea.kmersPerSeq = par->kmers_per_seq; ea.scale = par->kmers_per_seq_scale; ea.seed = par->hash_shift; ea.ignoreMultiKmer = par->ignore_multi_kmer;
     ea.keys = k0.p; ea.vals = v0.p; ea.slotOff = slotOff.p; ea.slowShort = listShort.p; ea.slowLong = listLong.p; ea.slowCnt = cls.p; ea.n = n;
     ea.list = nullptr; ea.nList = 0; ea.hashBase = kmerSlots; ea.rankOf = rankOf.p;
     hipEventRecord(ctx->ev0, s);
-    hipLaunchKernelGGL(k_extract_fast, dim3(std::min<uint32_t>((n + FAST_WAVES - 1) / FAST_WAVES, ctx->cuCount * 16)), dim3(64 * FAST_WAVES), 0, s, ea);
+    hipLaunchKernelGGL(k_extract_fast<LY>, dim3(std::min<uint32_t>((n + FAST_WAVES - 1) / FAST_WAVES, ctx->cuCount * 16)), dim3(64 * FAST_WAVES), 0, s, ea);
     unsigned int hcls[2] = {0, 0};
     hipMemcpyAsync(hcls, cls.p, 8, hipMemcpyDeviceToHost, s);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     // sequences that need the exact per-sequence ordering (repeated k-mers, more positions than the bottom-m budget)
     if (hcls[0]) {
         ea.list = listShort.p; ea.nList = hcls[0];
-        hipLaunchKernelGGL((k_extract<SHORT_CAP, 64>), dim3(std::min<uint32_t>(hcls[0], ctx->cuCount * 32)), dim3(64), 0, s, ea);
+        hipLaunchKernelGGL((k_extract<LY, SHORT_CAP, 64>), dim3(std::min<uint32_t>(hcls[0], ctx->cuCount * 32)), dim3(64), 0, s, ea);
     }
     if (hcls[1]) {
         ea.list = listLong.p; ea.nList = hcls[1];
-        hipLaunchKernelGGL((k_extract<LONG_CAP, 256>), dim3(std::min<uint32_t>(hcls[1], ctx->cuCount * 2)), dim3(256), 0, s, ea);
+        hipLaunchKernelGGL((k_extract<LY, LONG_CAP, 256>), dim3(std::min<uint32_t>(hcls[1], ctx->cuCount * 2)), dim3(256), 0, s, ea);
     }
     hipEventRecord(ctx->ev1, s);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction (general path) failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
@@ -647,7 +696,7 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
 
     // ---- sort 1: stable LSD radix sort by k-mer.  Region 1 (k-mer slots) on the 2k key bits, region 2 (whole-sequence hashes)
     // on 63 bits into the same physical buffers; the strand bit 63 rides along outside the sorted bit range.
-    keys = rocprim::double_buffer<uint64_t>(k0.p, k1.p); vals = rocprim::double_buffer<uint64_t>(v0.p, v1.p);
+    keys = rocprim::double_buffer<uint64_t>(k0.p, k1.p); vals = rocprim::double_buffer<V>(v0.p, v1.p);
     size_t tmpBytes = 0, tmpBytesH = 0;
     rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, 0, 2 * k, s);
     rocprim::radix_sort_pairs(nullptr, tmpBytesH, k0.p + kmerSlots, k1.p + kmerSlots, v0.p + kmerSlots, v1.p + kmerSlots, (size_t) n, 0, 63, s);
@@ -659,24 +708,24 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     hipEventRecord(ctx->ev2, s);
     {
         // region 2 goes to wherever region 1 ended up (explicit in/out form: input is always the extraction buffers k0/v0)
-        uint64_t *kOut = keys.current() + kmerSlots, *vOut = vals.current() + kmerSlots;
-        uint64_t *kIn = k0.p + kmerSlots, *vIn = v0.p + kmerSlots;
+        uint64_t *kOut = keys.current() + kmerSlots, *kIn = k0.p + kmerSlots;
+        V *vOut = vals.current() + kmerSlots, *vIn = v0.p + kmerSlots;
         if (kOut == kIn) {   // region 1 finished in the extraction buffers: sort region 2 via the alternate buffers and copy back
             if (rocprim::radix_sort_pairs(tmp1.p, tmpBytesH, kIn, k1.p + kmerSlots, vIn, v1.p + kmerSlots, (size_t) n, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
             hipMemcpyAsync(kOut, k1.p + kmerSlots, (size_t) n * 8, hipMemcpyDeviceToDevice, s);
-            hipMemcpyAsync(vOut, v1.p + kmerSlots, (size_t) n * 8, hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(vOut, v1.p + kmerSlots, (size_t) n * sizeof(V), hipMemcpyDeviceToDevice, s);
         } else if (rocprim::radix_sort_pairs(tmp1.p, tmpBytesH, kIn, kOut, vIn, vOut, (size_t) n, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
     }
     hipEventRecord(ctx->ev3, s);
     // ---- K3: run starts (max-scan), parallel emit, order-preserving compaction
-    GroupArgs ga;
+    GroupArgs<LY> ga; ga.geom = geom;
     ga.keys = keys.current(); ga.vals = vals.current(); ga.n = nTuples; ga.onlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode;
     ga.covThr = par->cov_thr; ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias;
     unsigned long long *startIo = (unsigned long long *) keys.alternate();   // free after the sort
-    uint64_t *gkeys = vals.alternate();
+    uint64_t *gkeys = keys.current();                                        // free once k_groups has run
     unsigned long long nGroup = 0;
     {
-        auto startIt = rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned long long>(0ull), StartIndex{ga.keys});
+        auto startIt = rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned long long>(0ull), StartIndex<LY>{ga.keys, geom});
         size_t sb = 0, sb2 = 0;
         rocprim::inclusive_scan(nullptr, sb, startIt, startIo, (size_t) nTuples, MaxU64(), s);
         const uint64_t nTiles = (nTuples + CP_TILE - 1) / CP_TILE;
@@ -687,7 +736,7 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
         if (!tmp2.alloc(std::max(sb, sb2) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (scan temp)"); return CDM_ERR_HIP; }
         if (nTuples) {
             rocprim::inclusive_scan(tmp2.p, sb, startIt, startIo, (size_t) nTuples, MaxU64(), s);
-            hipLaunchKernelGGL(k_groups, dim3((unsigned) ((nTuples + 255) / 256)), dim3(256), 0, s, ga, startIo);
+            hipLaunchKernelGGL(k_groups<LY>, dim3((unsigned) ((nTuples + 255) / 256)), dim3(256), 0, s, ga, startIo);
             hipLaunchKernelGGL(k_tile_count, dim3((unsigned) nTiles), dim3(256), 0, s, (const uint64_t *) startIo, (uint64_t) nTuples, tileCnt.p);
         }
         hipMemsetAsync(tileCnt.p + nTiles, 0, 8, s);
@@ -699,7 +748,8 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     float msSort1 = 0; hipEventElapsedTime(&msSort1, ctx->ev0, ctx->ev1);
 
     // ---- sort 2: by (rep, id, diagonal) = key bits 1.., stable; strand bit 0 rides along
-    rocprim::double_buffer<uint64_t> g(gkeys, vals.current());
+    v0.free(); v1.free();                                                    // the tuple values are dead after k_groups
+    rocprim::double_buffer<uint64_t> g(gkeys, (uint64_t *) startIo);
     size_t tmpBytes2 = 0;
     rocprim::radix_sort_keys(nullptr, tmpBytes2, g, (size_t) nGroup, 1, 2 * idBits + diagBits + 1, s);
     DevBuf<char> tmp3;
@@ -744,4 +794,20 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     hipEventElapsedTime(&ctx->lastMs[7], ctx->ev2, ctx->ev3);   // sort 1, region 2 (whole-sequence hash tuples)
     *out = res;
     return CDM_OK;
+}
+
+}  // namespace
+
+int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+    // packed 12-byte tuples when k-mer, position and length share 63 key bits; CDM_KMER_LAYOUT=wide|packed pins one (tests)
+    const int k = par->kmer_size;
+    const bool fits = 2 * k + 2 * (int) bitsFor((uint64_t) db->maxLen + 1) <= 63;
+    bool packed = fits;
+    if (const char *e = getenv("CDM_KMER_LAYOUT")) {
+        if (!strcmp(e, "wide")) packed = false;
+        else if (!strcmp(e, "packed")) {
+            if (!fits) { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT=packed needs 2k + 2 x length bits <= 63 (k %d, max length %u)", k, db->maxLen); return CDM_ERR_INVALID; }
+        } else { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT must be wide or packed"); return CDM_ERR_INVALID; }
+    }
+    return packed ? kmermatchT<LayoutPacked>(ctx, db, par, out) : kmermatchT<LayoutWide>(ctx, db, par, out);
 }

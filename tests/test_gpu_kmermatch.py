@@ -83,6 +83,23 @@ def test_kmermatch_long_sequences_bottom_m_selection(ctx, oracle_bin, tmp_path):
         assert not diff_keys(got, strip_ext(mmdb.read_db(t("pref")))), k
 
 
+def test_kmermatch_tuple_layouts_agree(ctx, oracle_bin, tmp_path, monkeypatch):
+    """The packed 12-byte tuples (short sequences) and the wide 16-byte ones are two layouts of the same algorithm."""
+    from carpedeam_amd import synth
+    seqs = synth.generate_strings(3000, seed=9, mixed=(20, 400)) + ["ACGTTGCA" * 12, "AC" * 50, "ACGTTGCA" * 12, ""]
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
+    want = strip_ext(mmdb.read_db(t("pref")))
+    for layout in ("packed", "wide"):
+        monkeypatch.setenv("CDM_KMER_LAYOUT", layout)
+        assert not diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), want), layout
+    monkeypatch.setenv("CDM_KMER_LAYOUT", "packed")
+    with pytest.raises(capi.CdmError):      # 2 * 20 + 2 * 12 bits do not fit
+        kmermatch_text(ctx, {0: (b"ACGT" * 700 + b"\n", 0), 1: (b"ACGTTGCA" * 300 + b"\n", 0)})
+    monkeypatch.delenv("CDM_KMER_LAYOUT")
+
+
 def test_kmermatch_rejects_what_it_does_not_implement(ctx):
     with pytest.raises(capi.CdmError):
         kmermatch_text(ctx, {0: (b"ACGT" * 2000 + b"\n", 0), 1: (b"ACGTTGCA" * 1000 + b"\n", 0)})   # >= 4096 k-mer positions
