@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "devutil.h"
+#include "bucket.h"
 
 namespace {
 
@@ -70,22 +71,24 @@ struct LayoutWide {
     __device__ static uint32_t lenOf(uint64_t, V v, uint64_t, const TupleGeom &) { return (uint32_t) ((v >> 16) & 0xFFFF); }
     __device__ static uint32_t posOf(uint64_t, V v, uint64_t, const TupleGeom &) { return (uint32_t) (v & 0xFFFF); }
 };
-// 12 bytes: u64 key = k-mer | pos << 2k | len << (2k + lb) | strand << 63, u32 value = id.  Needs 2k + 2 lb <= 63 (k = 20: sequences
-// up to 2047 letters); a quarter less traffic in every radix pass.  Only the low 2k bits of region 1 are sorted.
+// 12 bytes: u64 key = k-mer | pos << (2k + 1) | len << (2k + 1 + lb) | strand << 63, u32 value = id.  Needs 2k + 1 + 2 lb <= 63
+// (k = 20: sequences up to 2047 letters); a quarter less traffic in every radix pass.  Bit 2k stays clear in every real tuple
+// of region 1 (in both layouts): it is set only in the unused-slot key ~0, so sorting region 1 on bits up to and including
+// 2k moves the unused slots behind all real tuples.
 struct LayoutPacked {
     typedef uint32_t V;
     __device__ static void store(uint64_t *keys, V *vals, uint64_t slot, uint64_t kmer63, bool fwd, uint32_t seq, uint32_t L, uint32_t pos, const TupleGeom &g) {
-        keys[slot] = kmer63 | ((uint64_t) pos << g.kbits) | ((uint64_t) L << (g.kbits + g.lb)) | (fwd ? BIT63 : 0ull); vals[slot] = seq;
+        keys[slot] = kmer63 | ((uint64_t) pos << (g.kbits + 1)) | ((uint64_t) L << (g.kbits + 1 + g.lb)) | (fwd ? BIT63 : 0ull); vals[slot] = seq;
     }
     __device__ static void storeHash(uint64_t *keys, V *vals, uint64_t slot, uint64_t hash64, uint32_t seq, uint32_t L, const TupleGeom &g) {
         // region 1 (a hash that fits 2k bits): position 0, length packed above it; region 2: the full hash, length looked up
-        keys[slot] = (slot < g.kmerSlots) ? (hash64 | ((uint64_t) L << (g.kbits + g.lb))) : hash64; vals[slot] = seq;
+        keys[slot] = (slot < g.kmerSlots) ? (hash64 | ((uint64_t) L << (g.kbits + 1 + g.lb))) : hash64; vals[slot] = seq;
     }
     __device__ static void storeEmpty(uint64_t *keys, V *vals, uint64_t slot) { keys[slot] = ~0ull; vals[slot] = 0; }
     __device__ static uint64_t kmerOf(uint64_t key, uint64_t slot, const TupleGeom &g) { return slot < g.kmerSlots ? (key & ((1ull << g.kbits) - 1ull)) : (key & ~BIT63); }
     __device__ static uint32_t seqOf(V v) { return v; }
-    __device__ static uint32_t lenOf(uint64_t key, V v, uint64_t slot, const TupleGeom &g) { return slot < g.kmerSlots ? (uint32_t) ((key >> (g.kbits + g.lb)) & ((1ull << g.lb) - 1ull)) : g.lenArr[v]; }
-    __device__ static uint32_t posOf(uint64_t key, V, uint64_t slot, const TupleGeom &g) { return slot < g.kmerSlots ? (uint32_t) ((key >> g.kbits) & ((1ull << g.lb) - 1ull)) : 0u; }
+    __device__ static uint32_t lenOf(uint64_t key, V v, uint64_t slot, const TupleGeom &g) { return slot < g.kmerSlots ? (uint32_t) ((key >> (g.kbits + 1 + g.lb)) & ((1ull << g.lb) - 1ull)) : g.lenArr[v]; }
+    __device__ static uint32_t posOf(uint64_t key, V, uint64_t slot, const TupleGeom &g) { return slot < g.kmerSlots ? (uint32_t) ((key >> (g.kbits + 1)) & ((1ull << g.lb) - 1ull)) : 0u; }
 };
 
 template <typename LY> struct ExtractArgs {
@@ -350,6 +353,8 @@ struct GroupParams {
     uint64_t n;
     int onlyExtendable, covMode; float covThr;
     uint32_t idBits, diagBits; int diagBias;
+    uint64_t first;             // the kernel covers the tuples [first, n)
+    uint64_t firstRunIdx;       // index of the array's very first tuple in this view (0; ~0 if the view does not hold it)
 };
 template <typename LY> struct GroupArgs : GroupParams {
     const uint64_t *keys; const typename LY::V *vals;   // sorted by k-mer
@@ -372,9 +377,9 @@ __device__ __forceinline__ uint64_t packGroupKey(const GroupParams &a, uint32_t 
 }
 // run start index of every tuple = inclusive max-scan of (start ? i : 0); fed to the scan through this functor
 template <typename LY> struct StartIndex {
-    const uint64_t *keys; TupleGeom geom;
+    const uint64_t *keys; TupleGeom geom; unsigned long long first;
     __device__ unsigned long long operator()(unsigned long long i) const {
-        if (i == 0) return 0ull;
+        if (i == first) return i;
         const uint64_t a = keys[i], b = keys[i - 1];
         const bool start = (a == ~0ull) || (b == ~0ull) || (LY::kmerOf(a, i, geom) != LY::kmerOf(b, i - 1, geom));
         return start ? i : 0ull;
@@ -385,31 +390,17 @@ struct MaxU64 { __host__ __device__ unsigned long long operator()(unsigned long 
 // K3, one thread per tuple.  The tuple array was filled in (sequence length descending, id ascending, position) order and
 // the radix sort is stable, so the first tuple of a k-mer run is the reference's representative (sort order
 // kmermatcher.h:76-96); only a k-mer that the representative's own sequence carries twice needs a look at the next tuples.
+// (rep, id, diagonal, strand) key of one member of a k-mer run, ~0 if the member is dropped (assignGroup :453-562)
 template <typename LY>
-__global__ __launch_bounds__(256) void k_groups(GroupArgs<LY> a, unsigned long long *__restrict__ startIo /* in: run start, out: packed key */) {
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const uint64_t key = a.keys[i];
-    if (key == ~0ull) { startIo[i] = ~0ull; return; }          // unused slot
-    const uint64_t st = startIo[i];
-    const uint64_t km = LY::kmerOf(key, i, a.geom);
-    const bool hasNext = (i + 1 < a.n) && a.keys[i + 1] != ~0ull && LY::kmerOf(a.keys[i + 1], i + 1, a.geom) == km;
-    if (st == i && !hasNext) { startIo[i] = ~0ull; return; }   // singleton (:479)
-    uint64_t bestKey = a.keys[st]; typename LY::V best = a.vals[st];
-    const uint32_t repId = LY::seqOf(best);
-    uint32_t bestPos = LY::posOf(bestKey, best, st, a.geom);
-    // same sequence twice in the run: the smaller position wins (rare)
-    for (uint64_t e = st + 1; e < a.n && a.keys[e] != ~0ull && LY::kmerOf(a.keys[e], e, a.geom) == km && LY::seqOf(a.vals[e]) == repId; e++) {
-        const uint32_t pe = LY::posOf(a.keys[e], a.vals[e], e, a.geom);
-        if (pe < bestPos) { bestPos = pe; bestKey = a.keys[e]; }
-    }
-    const int queryLen = (int) LY::lenOf(bestKey, best, st, a.geom), repPos = (int) bestPos;
+__device__ __forceinline__ uint64_t groupKeyOf(const GroupParams &a, const TupleGeom &geom, uint64_t repKey, typename LY::V repVal, uint64_t repSlot, uint32_t repPos0,
+                                               bool firstRun, uint64_t key, typename LY::V v, uint64_t slot) {
+    const uint32_t repId = LY::seqOf(repVal);
+    const int queryLen = (int) LY::lenOf(repKey, repVal, repSlot, geom), repPos = (int) repPos0;
     // the reference initialises repIsReverse = false and only updates it when a NEW run starts (:465,:535-538):
     // the very first run of the array keeps false whatever its strand
-    const bool repIsReverse = (st == 0) ? false : ((bestKey & BIT63) == 0);
-    const typename LY::V v = a.vals[i];
+    const bool repIsReverse = firstRun ? false : ((repKey & BIT63) == 0);
     const uint32_t id = LY::seqOf(v);
-    const int tLen = (int) LY::lenOf(key, v, i, a.geom), tPos0 = (int) LY::posOf(key, v, i, a.geom);
+    const int tLen = (int) LY::lenOf(key, v, slot, geom), tPos0 = (int) LY::posOf(key, v, slot, geom);
     const bool targetIsReverse = (key & BIT63) == 0;
     int qPos, tPos; bool qRev;
     if (repIsReverse && !targetIsReverse) { qPos = repPos; tPos = tPos0; qRev = true; }
@@ -420,7 +411,152 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs<LY> a, unsigned long l
     const bool canBeExtended = diagonal < 0 || (diagonal > (queryLen - tLen));
     const bool cbc = canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) tLen);
     const bool keep = (a.onlyExtendable == 0 && cbc) || (canBeExtended && a.onlyExtendable != 0);
-    startIo[i] = keep ? packGroupKey(a, repId, id, (int) (short) diagonal, !qRev) : ~0ull;
+    return keep ? packGroupKey(a, repId, id, (int) (short) diagonal, !qRev) : ~0ull;
+}
+
+template <typename LY>
+__global__ __launch_bounds__(256) void k_groups(GroupArgs<LY> a, unsigned long long *__restrict__ startIo /* in: run start, out: packed key */) {
+    const uint64_t i = a.first + (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const uint64_t key = a.keys[i];
+    if (key == ~0ull) { startIo[i] = ~0ull; return; }          // unused slot
+    const uint64_t st = startIo[i];
+    const uint64_t km = LY::kmerOf(key, i, a.geom);
+    const bool hasNext = (i + 1 < a.n) && a.keys[i + 1] != ~0ull && LY::kmerOf(a.keys[i + 1], i + 1, a.geom) == km;
+    if (st == i && !hasNext) { startIo[i] = ~0ull; return; }   // singleton (:479)
+    uint64_t bestKey = a.keys[st]; const typename LY::V best = a.vals[st];
+    const uint32_t repId = LY::seqOf(best);
+    uint32_t bestPos = LY::posOf(bestKey, best, st, a.geom);
+    // same sequence twice in the run: the smaller position wins (rare)
+    for (uint64_t e = st + 1; e < a.n && a.keys[e] != ~0ull && LY::kmerOf(a.keys[e], e, a.geom) == km && LY::seqOf(a.vals[e]) == repId; e++) {
+        const uint32_t pe = LY::posOf(a.keys[e], a.vals[e], e, a.geom);
+        if (pe < bestPos) { bestPos = pe; bestKey = a.keys[e]; }
+    }
+    startIo[i] = groupKeyOf<LY>(a, a.geom, bestKey, best, st, bestPos, st == a.firstRunIdx, key, a.vals[i], i);
+}
+
+// K2b + K3 fused for region 1 when only the top bits of the k-mer went through the global radix passes (bucket.h): a wave
+// sorts a group of buckets on the remaining low bits in registers, finds the k-mer runs in the sorted order and writes the
+// group keys of the members straight to their final slots.  W = word of the network: (bucket ordinal, low bits, position).
+template <typename LY, typename W>
+struct BucketGroupArgs : GroupParams {
+    const uint64_t *keys; const typename LY::V *vals; TupleGeom geom;
+    unsigned long long *out;        // group key (or ~0) per slot, in k-mer order
+    int lowBits;                    // k-mer bits the global passes left unsorted
+    uint32_t cap, maxBucket; bucket::BigList big;
+};
+struct HiOfKmer {
+    const uint64_t *keys; uint64_t kmask; int lowBits;
+    __device__ __forceinline__ uint64_t operator()(uint64_t p) const { return (keys[p] & kmask) >> lowBits; }
+};
+template <typename LY, typename W>
+__global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs<LY, W> a) {
+    using namespace bucket;
+    typedef typename LY::V V;
+    __shared__ uint64_t sKey[BK_C];
+    __shared__ V sVal[BK_C];
+    __shared__ W sS[BK_WAVES][BK_MAXB];
+    __shared__ uint16_t sSt[BK_WAVES][BK_MAXB];
+    __shared__ ChunkLds c;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t kmask = (2ull << a.geom.kbits) - 1ull, lowMask = (1ull << a.lowBits) - 1ull;   // k-mer bits + the unused-slot bit
+    const HiOfKmer hiOf{a.keys, kmask, a.lowBits};
+    const uint64_t r0 = (uint64_t) blockIdx.x * BK_T;
+    uint64_t pos = findBoundary(hiOf, a.n, r0, c);
+    const uint64_t end = (r0 + BK_T >= a.n) ? a.n : findBoundary(hiOf, a.n, r0 + BK_T, c);
+    W *ss = sS[wave];
+    while (pos < end) {
+        int len = (int) min((uint64_t) a.cap, end - pos);
+        const bool cut = pos + (uint64_t) len < end;
+        for (int i = tid; i < BK_C; i += BK_NT) {
+            bool first = false;
+            if (i < len) {
+                const uint64_t k = a.keys[pos + i];
+                sKey[i] = k; sVal[i] = a.vals[pos + i];
+                first = (i == 0) || (((k & kmask) >> a.lowBits) != hiOf(pos + i - 1));
+            }
+            const unsigned long long m = __ballot(first);
+            if (lane == 0) c.bits[i >> 6] = m;
+        }
+        __syncthreads();
+        listBucketStarts(c, len);
+        __syncthreads();
+        int nB = (int) c.nB;
+        if (cut) {
+            if (nB == 1) {
+                const uint64_t bEnd = findBoundary(hiOf, a.n, pos + 1, c);
+                if (tid == 0) a.big.add(pos, bEnd);
+                pos = bEnd;
+                __syncthreads();
+                continue;
+            }
+            nB--; len = c.sB[nB];
+        }
+        int j = c.pre[wave * (BK_WIN / 64)];
+        const int jEnd = min(nB, (int) c.pre[(wave + 1) * (BK_WIN / 64)]);
+        Group g;
+        while (nextGroup(c, j, jEnd, g)) {
+            const int gm = g.g1 - g.g0;
+            if (gm > (int) a.maxBucket) { if (lane == 0) a.big.add(pos + g.g0, pos + g.g1); continue; }
+            const int idxBits = gm > 256 ? 9 : 8;
+            const W idxMask = (W) ((1u << idxBits) - 1u);
+            const int g0 = g.g0, j0 = g.j0, lowBits = a.lowBits;
+            sortGroup<W>(gm, lane,
+                [&](int i) {
+                    const W low = (W) (sKey[g0 + i] & lowMask);
+                    return (W) ((((((W) (ordOf(c, g0 + i) - j0)) << lowBits) | low) << idxBits) | (W) i);
+                },
+                [&](auto &v) {
+                    // sorted words and the start of every element's run (= equal bucket and low bits) to LDS; the run starts
+                    // come from an inclusive max-scan of the start positions over the wave
+                    constexpr int R = sizeof(v) / sizeof(v[0]);
+                    const W prevLast = shflUpW<W>(v[R - 1], 1);
+                    int st[R], last = -1;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int p = lane * R + r;
+                        const W prev = r ? v[r - 1] : prevLast;
+                        if (p == 0 || (v[r] >> idxBits) != (prev >> idxBits)) last = p;
+                        st[r] = last;
+                        ss[p] = v[r];
+                    }
+                    int sc = last;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(sc, d, 64); if (lane >= d) sc = max(sc, o); }
+                    const int carry = __shfl_up(sc, 1, 64);
+#pragma unroll
+                    for (int r = 0; r < R; r++) sSt[wave][lane * R + r] = (uint16_t) (st[r] < 0 ? carry : st[r]);
+                });
+            waveLdsSync();
+            // one copy of the member code in the instruction stream, whatever the size of the network before it
+#pragma unroll 1
+            for (int p = lane; p < gm; p += 64) {
+                const int s0 = sSt[wave][p];
+                const W cw = ss[p], kp = cw >> idxBits;
+                const int e = g0 + (int) (cw & idxMask);
+                const uint64_t key = sKey[e];
+                unsigned long long gk = ~0ull;
+                const bool hasNext = (p + 1 < gm) && (ss[p + 1] >> idxBits) == kp;
+                if (key != ~0ull && (s0 != p || hasNext)) {
+                    const int er = g0 + (int) (ss[s0] & idxMask);
+                    uint64_t bestKey = sKey[er]; const V best = sVal[er];
+                    const uint32_t repId = LY::seqOf(best);
+                    uint32_t bestPos = LY::posOf(bestKey, best, pos + er, a.geom);
+                    for (int t = s0 + 1; t < gm && (ss[t] >> idxBits) == kp; t++) {     // same sequence twice in the run (rare)
+                        const int et = g0 + (int) (ss[t] & idxMask);
+                        if (LY::seqOf(sVal[et]) != repId) break;
+                        const uint32_t pe = LY::posOf(sKey[et], sVal[et], pos + et, a.geom);
+                        if (pe < bestPos) { bestPos = pe; bestKey = sKey[et]; }
+                    }
+                    gk = groupKeyOf<LY>(a, a.geom, bestKey, best, pos + er, bestPos, pos + g0 + s0 == a.firstRunIdx, key, sVal[e], pos + e);
+                }
+                a.out[pos + g0 + p] = gk;
+            }
+            waveLdsSync();      // ss / sSt are reused by the next group
+        }
+        pos += (uint64_t) len;
+        __syncthreads();
+    }
 }
 
 // order preserving compaction of the kept keys: tiles of 4096 (256 threads x 16 consecutive items)
@@ -611,6 +747,12 @@ __global__ void k_slot_scatter(const uint32_t *__restrict__ order, const unsigne
     if (r < n) { slotOff[order[r]] = ordOff[r]; rankOf[order[r]] = r; }
     if (r == n) slotOff[n] = ordOff[n];
 }
+// number of real tuples in region 1 once it is sorted on bits up to 2k: the first key with bit 2k set
+__global__ void k_live_count(const uint64_t *__restrict__ keys, uint64_t n, int kbits, unsigned long long *__restrict__ out) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((keys[mid] >> kbits) & 1ull) hi = mid; else lo = mid + 1; }
+    *out = lo;
+}
 inline uint32_t bitsFor(uint64_t v) { uint32_t b = 1; while ((1ull << b) < v) b++; return b; }
 
 template <typename LY>
@@ -629,6 +771,8 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     const uint32_t idBits = bitsFor(n), diagBits = bitsFor(2ull * db->maxLen + 2);
     if (2 * idBits + diagBits + 1 > 64) { cdm_set_error("cdm_kmermatch: %u sequences x max length %u do not fit the 64-bit (rep,id,diagonal) sort key", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
     const int diagBias = (int) db->maxLen + 1;
+    const char *sortEnv = getenv("CDM_KMER_SORT");
+    const bool lsdOnly = sortEnv && !strcmp(sortEnv, "lsd");
 
     DevBuf<unsigned long long> counters;      // scratch counters ([2] = number of kept group tuples)
     DevBuf<unsigned int> cls;                 // slow-path list sizes
@@ -697,13 +841,18 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     // ---- sort 1: stable LSD radix sort by k-mer.  Region 1 (k-mer slots) on the 2k key bits, region 2 (whole-sequence hashes)
     // on 63 bits into the same physical buffers; the strand bit 63 rides along outside the sorted bit range.
     keys = rocprim::double_buffer<uint64_t>(k0.p, k1.p); vals = rocprim::double_buffer<V>(v0.p, v1.p);
+    // Region 1: only the top 32 k-mer bits go through global passes, the low bits are finished per bucket by k_bucket_groups
+    // (bucket.h); CDM_KMER_SORT=lsd sorts all 2k bits globally and keeps the separate scan + k_groups kernels (A/B).
+    // With low bits left over the passes cover bits [lowBits, 2k]: bit 2k is set only in unused slots, which end up last.
+    const int lowBits = lsdOnly ? 0 : std::max(0, 2 * k + 1 - 32);
+    const int sortTop = lowBits ? 2 * k + 1 : 2 * k;
     size_t tmpBytes = 0, tmpBytesH = 0;
-    rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, 0, 2 * k, s);
+    rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s);
     rocprim::radix_sort_pairs(nullptr, tmpBytesH, k0.p + kmerSlots, k1.p + kmerSlots, v0.p + kmerSlots, v1.p + kmerSlots, (size_t) n, 0, 63, s);
     DevBuf<char> tmp1;
     if (!tmp1.alloc(std::max(tmpBytes, tmpBytesH) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev0, s);
-    if (rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, 0, 2 * k, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
+    if (rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev1, s);
     hipEventRecord(ctx->ev2, s);
     {
@@ -717,28 +866,92 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
         } else if (rocprim::radix_sort_pairs(tmp1.p, tmpBytesH, kIn, kOut, vIn, vOut, (size_t) n, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
     }
     hipEventRecord(ctx->ev3, s);
-    // ---- K3: run starts (max-scan), parallel emit, order-preserving compaction
+    // ---- K3: group keys per slot (fused bucket kernel for region 1, run-start max-scan + k_groups elsewhere), then the
+    // order-preserving compaction
     GroupArgs<LY> ga; ga.geom = geom;
     ga.keys = keys.current(); ga.vals = vals.current(); ga.n = nTuples; ga.onlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode;
-    ga.covThr = par->cov_thr; ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias;
+    ga.covThr = par->cov_thr; ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias; ga.first = 0; ga.firstRunIdx = 0;
     unsigned long long *startIo = (unsigned long long *) keys.alternate();   // free after the sort
-    uint64_t *gkeys = keys.current();                                        // free once k_groups has run
+    uint64_t *gkeys = keys.current();                                        // free once the group keys are written
     unsigned long long nGroup = 0;
     {
-        auto startIt = rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned long long>(0ull), StartIndex<LY>{ga.keys, geom});
-        size_t sb = 0, sb2 = 0;
-        rocprim::inclusive_scan(nullptr, sb, startIt, startIo, (size_t) nTuples, MaxU64(), s);
+        // scan + k_groups over the tuples [first, last) of (kk, vv), group keys to io[first..last)
+        auto scanGroups = [&](GroupArgs<LY> g, unsigned long long *io) -> int {
+            const size_t cnt = (size_t) (g.n - g.first);
+            if (cnt == 0) return CDM_OK;
+            auto startIt = rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned long long>((unsigned long long) g.first),
+                                                            StartIndex<LY>{g.keys, g.geom, (unsigned long long) g.first});
+            size_t sb = 0;
+            rocprim::inclusive_scan(nullptr, sb, startIt, io + g.first, cnt, MaxU64(), s);
+            DevBuf<char> t;
+            if (!t.alloc(sb + 256)) return CDM_ERR_HIP;
+            if (rocprim::inclusive_scan(t.p, sb, startIt, io + g.first, cnt, MaxU64(), s) != hipSuccess) return CDM_ERR_HIP;
+            hipLaunchKernelGGL(k_groups<LY>, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, s, g, io);
+            return hipStreamSynchronize(s) == hipSuccess ? CDM_OK : CDM_ERR_HIP;      // t is released on return
+        };
+        int rc = CDM_OK;
+        if (lowBits == 0) rc = scanGroups(ga, startIo);
+        else {
+            uint32_t cap, maxBucket; bucket::capacities(cap, maxBucket);
+            DevBuf<unsigned long long> bigList; DevBuf<unsigned int> bigCnt;
+            if (!bigList.alloc(bucket::bigListSlots(kmerSlots, cap, maxBucket)) || !bigCnt.alloc(1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+            hipMemsetAsync(bigCnt.p, 0, 4, s);
+            unsigned long long live = 0;
+            if (kmerSlots) {
+                hipLaunchKernelGGL(k_live_count, dim3(1), dim3(1), 0, s, ga.keys, (uint64_t) kmerSlots, 2 * k, counters.p + 3);
+                hipMemcpyAsync(&live, counters.p + 3, 8, hipMemcpyDeviceToHost, s);
+                if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed"); return CDM_ERR_HIP; }
+                hipMemsetAsync(startIo + live, 0xFF, (size_t) (kmerSlots - live) * 8, s);     // unused slots: no group key
+            }
+            auto launchFused = [&](auto wordTag) {
+                typedef decltype(wordTag) W;
+                BucketGroupArgs<LY, W> ba;
+                static_cast<GroupParams &>(ba) = ga; ba.n = live;
+                ba.keys = ga.keys; ba.vals = ga.vals; ba.geom = geom; ba.out = startIo; ba.lowBits = lowBits; ba.cap = cap; ba.maxBucket = maxBucket;
+                ba.big.list = bigList.p; ba.big.cnt = bigCnt.p;
+                if (live) hipLaunchKernelGGL((k_bucket_groups<LY, W>), dim3((unsigned) ((live + bucket::BK_T - 1) / bucket::BK_T)), dim3(bucket::BK_NT), 0, s, ba);
+            };
+            if (lowBits <= 16) launchFused(uint32_t()); else launchFused(uint64_t());
+            unsigned int nBig = 0;
+            hipMemcpyAsync(&nBig, bigCnt.p, 4, hipMemcpyDeviceToHost, s);
+            GroupArgs<LY> g2 = ga; g2.first = kmerSlots;                      // region 2 is sorted on all its bits
+            rc = scanGroups(g2, startIo);
+            if (rc == CDM_OK && nBig) {
+                // buckets the kernel left alone: gather them, sort on the whole k-mer, group, scatter the group keys back
+                DevBuf<unsigned long long> ranges; uint64_t total = 0; unsigned long long firstStart = ~0ull;
+                rc = bucket::loadBigList(s, bigList.p, nBig, ranges, total, &firstStart);
+                if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "kmermatch sort 1: %llu slots, low bits %d: %u big buckets, %llu tuples\n", (unsigned long long) kmerSlots, lowBits, nBig, (unsigned long long) total);
+                DevBuf<uint64_t> dk0, dk1; DevBuf<V> dv0, dv1; DevBuf<unsigned long long> ds; DevBuf<char> t; size_t tb = 0;
+                if (rc == CDM_OK && (!dk0.alloc(total) || !dk1.alloc(total) || !dv0.alloc(total) || !dv1.alloc(total) || !ds.alloc(total))) rc = CDM_ERR_HIP;
+                if (rc == CDM_OK) {
+                    const unsigned int grid = std::min<unsigned int>(nBig, 1u << 20);
+                    hipLaunchKernelGGL((bucket::k_big_copy<uint64_t, true>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(ga.keys), dk0.p);
+                    hipLaunchKernelGGL((bucket::k_big_copy<V, true>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<V *>(ga.vals), dv0.p);
+                    rocprim::double_buffer<uint64_t> dk(dk0.p, dk1.p); rocprim::double_buffer<V> dv(dv0.p, dv1.p);
+                    if (rocprim::radix_sort_pairs(nullptr, tb, dk, dv, (size_t) total, 0, 2 * k, s) != hipSuccess || !t.alloc(tb + 256) ||
+                        rocprim::radix_sort_pairs(t.p, tb, dk, dv, (size_t) total, 0, 2 * k, s) != hipSuccess) rc = CDM_ERR_HIP;
+                    if (rc == CDM_OK) {
+                        GroupArgs<LY> gd = ga; gd.keys = dk.current(); gd.vals = dv.current(); gd.n = total; gd.first = 0;
+                        gd.geom.kmerSlots = ~0ull;                                   // every tuple of the dense view is a region-1 tuple
+                        gd.firstRunIdx = (firstStart == 0) ? 0ull : ~0ull;           // dense index 0 is the array's first tuple only then
+                        rc = scanGroups(gd, ds.p);
+                    }
+                    if (rc == CDM_OK) {
+                        hipLaunchKernelGGL((bucket::k_big_copy<unsigned long long, false>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, startIo, ds.p);
+                        if (hipStreamSynchronize(s) != hipSuccess) rc = CDM_ERR_HIP;
+                    }
+                }
+            }
+        }
+        if (rc != CDM_OK) { cdm_set_error("cdm_kmermatch: grouping failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+        size_t sb2 = 0;
         const uint64_t nTiles = (nTuples + CP_TILE - 1) / CP_TILE;
         DevBuf<unsigned long long> tileCnt, tileOff;
         if (!tileCnt.alloc(nTiles + 1) || !tileOff.alloc(nTiles + 1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
         hipcub::DeviceScan::ExclusiveSum(nullptr, sb2, tileCnt.p, tileOff.p, (int) (nTiles + 1), s);
         DevBuf<char> tmp2;
-        if (!tmp2.alloc(std::max(sb, sb2) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (scan temp)"); return CDM_ERR_HIP; }
-        if (nTuples) {
-            rocprim::inclusive_scan(tmp2.p, sb, startIt, startIo, (size_t) nTuples, MaxU64(), s);
-            hipLaunchKernelGGL(k_groups<LY>, dim3((unsigned) ((nTuples + 255) / 256)), dim3(256), 0, s, ga, startIo);
-            hipLaunchKernelGGL(k_tile_count, dim3((unsigned) nTiles), dim3(256), 0, s, (const uint64_t *) startIo, (uint64_t) nTuples, tileCnt.p);
-        }
+        if (!tmp2.alloc(sb2 + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (scan temp)"); return CDM_ERR_HIP; }
+        if (nTuples) hipLaunchKernelGGL(k_tile_count, dim3((unsigned) nTiles), dim3(256), 0, s, (const uint64_t *) startIo, (uint64_t) nTuples, tileCnt.p);
         hipMemsetAsync(tileCnt.p + nTiles, 0, 8, s);
         hipcub::DeviceScan::ExclusiveSum(tmp2.p, sb2, tileCnt.p, tileOff.p, (int) (nTiles + 1), s);
         if (nTuples) hipLaunchKernelGGL(k_tile_compact, dim3((unsigned) nTiles), dim3(256), 0, s, (const uint64_t *) startIo, (uint64_t) nTuples, tileOff.p, gkeys);
@@ -747,15 +960,23 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     }
     float msSort1 = 0; hipEventElapsedTime(&msSort1, ctx->ev0, ctx->ev1);
 
-    // ---- sort 2: by (rep, id, diagonal) = key bits 1.., stable; strand bit 0 rides along
+    // ---- sort 2: by (rep, id, diagonal) = key bits 1.., stable; strand bit 0 rides along.  The top 32 bits go through global
+    // radix passes, the rest is finished bucket by bucket in LDS (bucket.h); CDM_KMER_SORT=lsd keeps the all-global sort (A/B)
     v0.free(); v1.free();                                                    // the tuple values are dead after k_groups
     rocprim::double_buffer<uint64_t> g(gkeys, (uint64_t *) startIo);
+    const int top2 = (int) (2 * idBits + diagBits + 1);
+    const int shiftHi2 = lsdOnly ? 1 : std::max(1, top2 - 32);
     size_t tmpBytes2 = 0;
-    rocprim::radix_sort_keys(nullptr, tmpBytes2, g, (size_t) nGroup, 1, 2 * idBits + diagBits + 1, s);
+    rocprim::radix_sort_keys(nullptr, tmpBytes2, g, (size_t) nGroup, shiftHi2, top2, s);
     DevBuf<char> tmp3;
     if (!tmp3.alloc(tmpBytes2 + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev0, s);
-    if (rocprim::radix_sort_keys(tmp3.p, tmpBytes2, g, (size_t) nGroup, 1, 2 * idBits + diagBits + 1, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+    if (rocprim::radix_sort_keys(tmp3.p, tmpBytes2, g, (size_t) nGroup, shiftHi2, top2, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+    const uint64_t *sorted2 = g.current();
+    if (shiftHi2 > 1) {
+        if (bucket::bucketSortKeys(s, g.current(), g.alternate(), nGroup, shiftHi2, 1, top2) != CDM_OK) { cdm_set_error("cdm_kmermatch: bucket sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+        sorted2 = g.alternate();
+    }
     hipEventRecord(ctx->ev1, s);
 
     // ---- K4: count hit-producing segments (per tile and per representative), scan, vote + place
@@ -767,7 +988,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     hipMemsetAsync(perRep.p, 0, ((size_t) n + 1) * 8, s);
     hipMemsetAsync(vTileCnt.p, 0, (vTiles + 1) * 8, s);
     VoteArgs va;
-    va.keys = g.current(); va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.perRep = perRep.p;
+    va.keys = sorted2; va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.perRep = perRep.p;
     if (nGroup) hipLaunchKernelGGL(k_seg_count, dim3((unsigned) vTiles), dim3(256), 0, s, va, vTileCnt.p);
     size_t sb1 = 0, sb2 = 0;
     hipcub::DeviceScan::ExclusiveSum(nullptr, sb1, perRep.p, perRepScan.p, (int) (n + 1), s);
@@ -801,12 +1022,12 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
 int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
     // packed 12-byte tuples when k-mer, position and length share 63 key bits; CDM_KMER_LAYOUT=wide|packed pins one (tests)
     const int k = par->kmer_size;
-    const bool fits = 2 * k + 2 * (int) bitsFor((uint64_t) db->maxLen + 1) <= 63;
+    const bool fits = 2 * k + 1 + 2 * (int) bitsFor((uint64_t) db->maxLen + 1) <= 63;
     bool packed = fits;
     if (const char *e = getenv("CDM_KMER_LAYOUT")) {
         if (!strcmp(e, "wide")) packed = false;
         else if (!strcmp(e, "packed")) {
-            if (!fits) { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT=packed needs 2k + 2 x length bits <= 63 (k %d, max length %u)", k, db->maxLen); return CDM_ERR_INVALID; }
+            if (!fits) { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT=packed needs 2k + 1 + 2 x length bits <= 63 (k %d, max length %u)", k, db->maxLen); return CDM_ERR_INVALID; }
         } else { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT must be wide or packed"); return CDM_ERR_INVALID; }
     }
     return packed ? kmermatchT<LayoutPacked>(ctx, db, par, out) : kmermatchT<LayoutWide>(ctx, db, par, out);

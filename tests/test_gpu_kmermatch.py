@@ -100,6 +100,24 @@ def test_kmermatch_tuple_layouts_agree(ctx, oracle_bin, tmp_path, monkeypatch):
     monkeypatch.delenv("CDM_KMER_LAYOUT")
 
 
+def test_kmermatch_bucket_sort_paths_agree(ctx, oracle_bin, tmp_path, monkeypatch):
+    """The in-LDS bucket finish of the two sorts, its big-bucket path (forced by a tiny chunk capacity) and the plain
+    all-global radix sort give the same prefilter DB."""
+    from carpedeam_amd import synth
+    seqs = synth.generate_strings(6000, seed=11, mixed=(40, 160)) + ["ACGTTGCA" * 12] * 40 + ["AC" * 50, ""]
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
+    want = strip_ext(mmdb.read_db(t("pref")))
+    for env in ({}, {"CDM_BUCKET_CAP": "64"}, {"CDM_BUCKET_CAP": "5"}, {"CDM_BUCKET_CAP": "300,3"}, {"CDM_BUCKET_CAP": "2048,1"},
+                {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_BUCKET_CAP": "40,6"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert not diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), want), env
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_kmermatch_rejects_what_it_does_not_implement(ctx):
     with pytest.raises(capi.CdmError):
         kmermatch_text(ctx, {0: (b"ACGT" * 2000 + b"\n", 0), 1: (b"ACGTTGCA" * 1000 + b"\n", 0)})   # >= 4096 k-mer positions
