@@ -1,18 +1,18 @@
 // Finishing a most-significant-digit sort inside small buckets.
 //
 // Both sorts of kmermatcher (kmermatcher.cpp:412 by k-mer, :431 by (rep, id, diagonal)) order a few 10^9 tuples.  A
-// least-significant-digit radix sort streams the whole array through HBM once per 8 key bits.  Here only the TOP bits go through
-// those global passes (rocPRIM onesweep); what is left are runs of equal high bits ("buckets") that are contiguous in memory,
-// and they are finished on chip: a wavefront takes a group of consecutive whole buckets (up to 256 elements, or one bucket of
-// up to 512), builds one word per element = (bucket ordinal, low key bits, position) and sorts the words with a bitonic
-// network held in registers (exchanges between lanes are shuffles).  The position is part of the compared word, so the result
-// is the same stable order the reference's std::sort / ips4o comparators produce on the full key.
+// least-significant-digit radix sort streams the whole array through HBM once per 8 key bits.  Here only the TOP 32 bits go
+// through those global passes (rocPRIM onesweep); what is left are runs of equal high bits ("buckets") that are contiguous in
+// memory, and they are finished on chip: a wavefront takes a group of consecutive whole buckets (up to 256 elements, or one
+// bucket of up to 512), builds one word per element = (bucket ordinal, low key bits, position) and sorts the words with a
+// bitonic network held in registers (exchanges between lanes are shuffles).  The position is part of the compared word, so the
+// result is the same stable order the reference's std::sort / ips4o comparators produce on the full key.
 //
-// Work distribution: the array is cut into ranges of BK_T slots; a block owns the buckets that START in its range and walks them
-// in chunks of whole buckets (at most BK_C slots in LDS); wave w of the block owns the buckets that start in the w-th quarter
-// of the chunk.  A bucket larger than BK_MAXB is appended to a list and finished by the caller: the listed ranges are
-// gathered, sorted on the complete key by rocPRIM and scattered back (bucketSortKeys below, the fused k-mer kernel's
-// fallback in kmermatch.hip).
+// Work distribution: no block-level synchronisation at all.  The array is cut into ranges of WV_OWN slots; a WAVE owns the
+// buckets that START in its range, stages a window of WV_WIN slots (its range plus the longest bucket it can finish) in its
+// private part of the LDS, finds the bucket starts with ballots and walks them group by group.  A bucket that does not fit
+// (more than BK_MAXB elements) is appended to a list and finished by the caller: the listed ranges are gathered, sorted on the
+// complete key by rocPRIM and scattered back (bucketSortKeys below, the fused k-mer kernel's fallback in kmermatch.hip).
 #pragma once
 #include <algorithm>
 #include <cstdio>
@@ -25,84 +25,58 @@
 
 namespace bucket {
 
-constexpr int BK_NT = 256;              // threads per block
+constexpr int BK_NT = 256;              // threads per block: 4 independent waves
 constexpr int BK_WAVES = BK_NT / 64;
-constexpr int BK_C = 2048;              // chunk capacity (slots in LDS)
-constexpr int BK_T = 1024;              // ownership granule
-constexpr int BK_WORDS = BK_C / 64;
-constexpr int BK_WIN = BK_C / BK_WAVES; // a wave owns the buckets starting in its window of the chunk
+constexpr int WV_OWN = 256;             // a wave owns the buckets that start in its range of this many slots
+constexpr int WV_WIN = 768;             // slots a wave stages: the owned range + the longest bucket it finishes itself
+constexpr int WV_WORDS = WV_WIN / 64;
+constexpr int WV_FIRST = 512;           // staged up front; the rest only if the last owned bucket runs on
 constexpr int BK_GROUP = 256;           // largest group of several buckets
 constexpr int BK_MAXB = 512;            // largest single bucket finished in registers
 constexpr int BK_ORD = 8;               // bits of a bucket ordinal inside a group
 
-// per-chunk bookkeeping in LDS
-struct ChunkLds {
-    unsigned long long bits[BK_WORDS];  // "starts a bucket" bit per slot, written with wave ballots
-    unsigned long long found64;
-    uint16_t pre[BK_WORDS + 1];         // bucket starts before word w
-    uint16_t sB[BK_C + 2];              // ordered bucket starts, sB[nB] = chunk length
-    unsigned int found, nB;
-};
-// first p >= x that starts a bucket (p == 0 or high bits differ from p - 1), n if there is none.  Block-uniform.  The array is
-// sorted on the high bits: one parallel probe of the next BK_NT slots, then a binary search (a bucket may be very large).
-template <typename HiOf>
-__device__ __forceinline__ uint64_t findBoundary(const HiOf &hiOf, uint64_t n, uint64_t x, ChunkLds &c) {
-    if (x == 0) return 0;
-    if (x >= n) return n;
-    if (threadIdx.x == 0) c.found = BK_NT;
-    __syncthreads();
-    const uint64_t p = x + threadIdx.x;
-    if (p < n && hiOf(p) != hiOf(p - 1)) atomicMin(&c.found, threadIdx.x);
-    __syncthreads();
-    const unsigned int f = c.found;
-    __syncthreads();
-    if (f < (unsigned int) BK_NT) return x + f;
-    if (x + BK_NT >= n) return n;
-    if (threadIdx.x == 0) {
-        const auto h = hiOf(x - 1);
-        uint64_t lo = x + BK_NT, hi = n;                // first index in [lo, hi) whose high bits differ from h, or n
-        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (hiOf(mid) == h) lo = mid + 1; else hi = mid; }
-        c.found64 = lo;
-    }
-    __syncthreads();
-    const uint64_t r = c.found64;
-    __syncthreads();
-    return r;
+// makes the LDS writes of a wave visible to its other lanes (one wave works on its own data, no block barrier)
+__device__ __forceinline__ void waveLdsSync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ordered list of the bucket starts from the bit words; runs on wave 0, the block syncs around it
-__device__ __forceinline__ void listBucketStarts(ChunkLds &c, int len) {
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        unsigned long long w = (lane < BK_WORDS) ? c.bits[lane] : 0ull;
-        const int cnt = __popcll(w);
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-        int o = incl - cnt;
-        if (lane <= BK_WORDS) c.pre[lane] = (uint16_t) o;       // lanes >= BK_WORDS hold the total
-        while (w) { const int b = __ffsll(w) - 1; w &= w - 1; c.sB[o++] = (uint16_t) (lane * 64 + b); }
-        if (lane == 63) { c.nB = (unsigned int) incl; c.sB[incl] = (uint16_t) len; }
+// per-wave bookkeeping in LDS: "starts a bucket" bit per window slot (written with ballots) and their prefix counts
+struct WaveLds {
+    unsigned long long bits[WV_WORDS];
+    uint16_t pre[WV_WORDS + 1];
+};
+// first set bit in [from, limit), -1 if none.  Wave-uniform.
+__device__ __forceinline__ int firstSetFrom(const WaveLds &w, int from, int limit) {
+    for (int word = from >> 6; word * 64 < limit; word++) {
+        unsigned long long m = w.bits[word];
+        if (word == (from >> 6)) m &= ~0ull << (from & 63);
+        if (m) { const int p = word * 64 + __ffsll(m) - 1; return p < limit ? p : -1; }
     }
+    return -1;
 }
-// ordinal of the bucket that slot i belongs to
-__device__ __forceinline__ int ordOf(const ChunkLds &c, int i) {
-    return (int) c.pre[i >> 6] + __popcll(c.bits[i >> 6] & ((2ull << (i & 63)) - 1ull)) - 1;
-}
-// next group of whole buckets [j, j1) for a wave that owns the buckets [.., jEnd): elements [g0, g1).  Wave-uniform.
-struct Group { int g0, g1, j0, j1; };
-__device__ __forceinline__ bool nextGroup(const ChunkLds &c, int &j, int jEnd, Group &g) {
-    if (j >= jEnd) return false;
-    g.j0 = j; g.g0 = c.sB[j];
-    int jj = j + 1, e = c.sB[jj];
-    while (jj < jEnd && jj - j < (1 << BK_ORD)) {
-        const int e2 = c.sB[jj + 1];
-        if (e2 - g.g0 > BK_GROUP) break;
-        e = e2; jj++;
+// last set bit in (lo, hi], -1 if none.  Wave-uniform.
+__device__ __forceinline__ int lastSetIn(const WaveLds &w, int lo, int hi) {
+    const int wl = (lo + 1) >> 6;
+    for (int word = hi >> 6; word >= wl; word--) {
+        unsigned long long m = w.bits[word];
+        if (word == (hi >> 6)) m &= (2ull << (hi & 63)) - 1ull;
+        if (word == wl) m &= ~0ull << ((lo + 1) & 63);
+        if (m) return word * 64 + 63 - __clzll(m);
     }
-    g.j1 = jj; g.g1 = e; j = jj;
-    return true;
+    return -1;
 }
+// ordinal of the bucket that window slot i belongs to
+__device__ __forceinline__ int ordOf(const WaveLds &w, int i) {
+    return (int) w.pre[i >> 6] + __popcll(w.bits[i >> 6] & ((2ull << (i & 63)) - 1ull)) - 1;
+}
+
+struct BigList {
+    unsigned long long *list;       // (start, end) of every range left to the caller
+    unsigned int *cnt;
+    __device__ __forceinline__ void add(uint64_t s, uint64_t e) const { const unsigned int q = atomicAdd(cnt, 1u); list[2 * (size_t) q] = s; list[2 * (size_t) q + 1] = e; }
+};
 
 template <typename W> __device__ __forceinline__ W shflXorW(W a, int m);
 template <> __device__ __forceinline__ uint32_t shflXorW<uint32_t>(uint32_t a, int m) { return (uint32_t) __shfl_xor((int) a, m, 64); }
@@ -163,93 +137,107 @@ __device__ __forceinline__ void sortGroup(int gm, int lane, const MakeComp &mk, 
     else if (gm <= 256) sortGroupRegs<4, W>(gm, lane, mk, done);
     else sortGroupRegs<8, W>(gm, lane, mk, done);
 }
-// makes the LDS writes of a wave visible to its other lanes (one wave works on a group, no block barrier)
-__device__ __forceinline__ void waveLdsSync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// The walk of one wave over the buckets it owns.  stage(g, i) loads the tuple at global index g into window slot i and returns
+// its high bits; hiAt(g) returns the high bits of the tuple at g; groupFn(g0, gm, ord0) finishes the group of whole buckets in
+// the window slots [g0, g0 + gm), ord0 = ordinal of its first bucket.
+template <typename Stage, typename HiAt, typename GroupFn>
+__device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, uint32_t maxBucket, const BigList &big, WaveLds &w, int lane,
+                                            const Stage &stage, const HiAt &hiAt, const GroupFn &groupFn) {
+    const int avail = (int) min((uint64_t) WV_WIN, n - r0);
+    uint64_t carry = r0 ? hiAt(r0 - 1) : 0ull;
+    auto loadRows = [&](int t0, int t1) {
+        for (int t = t0; t < t1; t++) {
+            const int i = t * 64 + lane;
+            const bool valid = i < avail;
+            const uint64_t h = valid ? stage(r0 + (uint64_t) i, i) : 0ull;
+            uint64_t up = shflUpW<uint64_t>(h, 1);
+            if (lane == 0) up = carry;
+            const bool first = valid && ((r0 + (uint64_t) i == 0) || h != up);
+            const unsigned long long m = __ballot(first);
+            if (lane == 0) w.bits[t] = m;
+            carry = ((uint64_t) (uint32_t) __shfl((int) (h >> 32), 63, 64) << 32) | (uint32_t) __shfl((int) (uint32_t) h, 63, 64);
+        }
+    };
+    if (lane >= WV_FIRST / 64 && lane < WV_WORDS) w.bits[lane] = 0ull;
+    loadRows(0, WV_FIRST / 64);
+    waveLdsSync();
+    const int ownEnd = min(own, avail);
+    const int sLast = lastSetIn(w, -1, ownEnd - 1);         // start of the last bucket this wave owns
+    if (sLast < 0) return;
+    const int p0 = firstSetFrom(w, 0, ownEnd);
+    int loaded = min(avail, WV_FIRST);
+    int eLast = firstSetFrom(w, sLast + 1, loaded);
+    if (eLast < 0 && loaded < avail) {
+        loadRows(WV_FIRST / 64, WV_WORDS);
+        waveLdsSync();
+        loaded = avail;
+        eLast = firstSetFrom(w, sLast + 1, loaded);
+    }
+    if (eLast < 0 && r0 + (uint64_t) avail == n) eLast = avail;         // the array ends inside the window
+    int eOwn = eLast;
+    if (eLast < 0) {        // the last owned bucket is longer than the window: find its end, leave it to the caller
+        const uint64_t h = hiAt(r0 + (uint64_t) sLast);
+        uint64_t lo = r0 + (uint64_t) avail, hi = n;
+        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (hiAt(mid) == h) lo = mid + 1; else hi = mid; }
+        if (lane == 0) big.add(r0 + (uint64_t) sLast, lo);
+        eOwn = sLast;
+    }
+    {   // prefix counts of the bucket starts per word
+        const int cnt = (lane < WV_WORDS) ? __popcll(w.bits[lane]) : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        if (lane <= WV_WORDS) w.pre[lane] = (uint16_t) (incl - cnt);
+    }
+    waveLdsSync();
+    int g0 = p0;
+    while (g0 < eOwn) {
+        const int lim = min(g0 + BK_GROUP, eOwn);
+        int e = (lim == eOwn) ? eOwn : lastSetIn(w, g0, lim);
+        if (e < 0) { e = firstSetFrom(w, g0 + 1, eOwn); if (e < 0) e = eOwn; }     // one bucket larger than a group
+        const int gm = e - g0;
+        if (gm > (int) maxBucket) { if (lane == 0) big.add(r0 + (uint64_t) g0, r0 + (uint64_t) e); }
+        else groupFn(g0, gm, ordOf(w, g0));
+        g0 = e;
+    }
 }
-
-struct BigList {
-    unsigned long long *list;       // (start, end) of every bucket left to the caller
-    unsigned int *cnt;
-    __device__ __forceinline__ void add(uint64_t s, uint64_t e) const { const unsigned int q = atomicAdd(cnt, 1u); list[2 * (size_t) q] = s; list[2 * (size_t) q + 1] = e; }
-};
 
 struct SortArgs {
     const uint64_t *in; uint64_t *out; uint64_t n;
     int shiftHi;                    // bucket id = key >> shiftHi (the array is sorted on it)
     int ign;                        // lowest bits that ride along uncompared
-    uint32_t cap, maxBucket;        // chunk / single-bucket capacity in use (tests lower them to reach the big-bucket path)
+    int own; uint32_t maxBucket;    // WV_OWN / BK_MAXB; tests lower them to reach the other paths on small inputs
     BigList big;
-};
-struct HiOfKey {
-    const uint64_t *in; int shift;
-    __device__ __forceinline__ uint64_t operator()(uint64_t p) const { return in[p] >> shift; }
 };
 
 // keys only, out of place: out = in with every bucket stably sorted on bits [ign, shiftHi)
 __global__ __launch_bounds__(BK_NT) void k_bucket_sort(SortArgs a) {
-    __shared__ uint64_t sKey[BK_C];
-    __shared__ ChunkLds c;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const HiOfKey hiOf{a.in, a.shiftHi};
-    const uint64_t r0 = (uint64_t) blockIdx.x * BK_T;
-    uint64_t pos = findBoundary(hiOf, a.n, r0, c);
-    const uint64_t end = (r0 + BK_T >= a.n) ? a.n : findBoundary(hiOf, a.n, r0 + BK_T, c);
+    __shared__ uint64_t sKeyAll[BK_WAVES][WV_WIN];
+    __shared__ WaveLds wAll[BK_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t r0 = ((uint64_t) blockIdx.x * BK_WAVES + wave) * (uint64_t) a.own;
+    if (r0 >= a.n) return;
+    uint64_t *sKey = sKeyAll[wave];
+    WaveLds &w = wAll[wave];
     const uint64_t lowMask = (1ull << a.shiftHi) - 1ull;
-    const int lowW = a.shiftHi - a.ign;
-    while (pos < end) {
-        int len = (int) min((uint64_t) a.cap, end - pos);
-        const bool cut = pos + (uint64_t) len < end;
-        for (int i = tid; i < BK_C; i += BK_NT) {       // BK_C is a multiple of the block size: whole waves, ballots are complete
-            bool first = false;
-            if (i < len) {
-                const uint64_t k = a.in[pos + i];
-                sKey[i] = k;
-                first = (i == 0) || ((k >> a.shiftHi) != (a.in[pos + i - 1] >> a.shiftHi));
-            }
-            const unsigned long long m = __ballot(first);
-            if (lane == 0) c.bits[i >> 6] = m;
-        }
-        __syncthreads();
-        listBucketStarts(c, len);
-        __syncthreads();
-        int nB = (int) c.nB;
-        if (cut) {
-            if (nB == 1) {      // the bucket at pos does not fit a chunk
-                const uint64_t bEnd = findBoundary(hiOf, a.n, pos + 1, c);
-                if (tid == 0) a.big.add(pos, bEnd);
-                pos = bEnd;
-                __syncthreads();
-                continue;
-            }
-            nB--; len = c.sB[nB];     // drop the partial bucket at the end of the chunk (sB[nB] is the new length)
-        }
-        // wave w: buckets starting in [w BK_WIN, (w + 1) BK_WIN)
-        int j = c.pre[wave * (BK_WIN / 64)];
-        const int jEnd = min(nB, (int) c.pre[(wave + 1) * (BK_WIN / 64)]);
-        Group g;
-        while (nextGroup(c, j, jEnd, g)) {
-            const int gm = g.g1 - g.g0;
-            if (gm > (int) a.maxBucket) { if (lane == 0) a.big.add(pos + g.g0, pos + g.g1); continue; }
+    const int lowW = a.shiftHi - a.ign, ign = a.ign, shiftHi = a.shiftHi;
+    waveBuckets(r0, a.n, a.own, a.maxBucket, a.big, w, lane,
+        [&](uint64_t g, int i) { const uint64_t k = a.in[g]; sKey[i] = k; return k >> shiftHi; },
+        [&](uint64_t g) { return a.in[g] >> shiftHi; },
+        [&](int g0, int gm, int ord0) {
             const int idxBits = gm > 256 ? 9 : 8;
             const uint64_t idxMask = (1ull << idxBits) - 1ull;
-            const int g0 = g.g0, j0 = g.j0, ign = a.ign;
             sortGroup<uint64_t>(gm, lane,
                 [&](int i) {
                     const uint64_t low = (sKey[g0 + i] & lowMask) >> ign;
-                    return ((((uint64_t) (ordOf(c, g0 + i) - j0) << lowW) | low) << idxBits) | (uint64_t) i;
+                    return ((((uint64_t) (ordOf(w, g0 + i) - ord0) << lowW) | low) << idxBits) | (uint64_t) i;
                 },
                 [&](auto &v) {
                     constexpr int R = sizeof(v) / sizeof(v[0]);
 #pragma unroll
-                    for (int r = 0; r < R; r++) { const int p = lane * R + r; if (p < gm) a.out[pos + g0 + p] = sKey[g0 + (int) (v[r] & idxMask)]; }
+                    for (int r = 0; r < R; r++) { const int p = lane * R + r; if (p < gm) a.out[r0 + (uint64_t) (g0 + p)] = sKey[g0 + (int) (v[r] & idxMask)]; }
                 });
-        }
-        pos += (uint64_t) len;
-        __syncthreads();
-    }
+        });
 }
 
 // copies the listed ranges between the array and a dense staging buffer (ranges sorted by start, off = prefix sums of sizes)
@@ -280,26 +268,27 @@ inline int loadBigList(hipStream_t s, const unsigned long long *bigList, unsigne
     return CDM_OK;
 }
 
-// CDM_BUCKET_CAP=<chunk slots>[,<largest bucket>] lowers the capacities (tests: reach the big-bucket path on small inputs)
-inline void capacities(uint32_t &cap, uint32_t &maxBucket) {
-    cap = BK_C; maxBucket = BK_MAXB;
+// CDM_BUCKET_CAP=<largest bucket>[,<owned range>] lowers the capacities (tests: reach the big-bucket path on small inputs)
+inline void capacities(int &own, uint32_t &maxBucket) {
+    own = WV_OWN; maxBucket = BK_MAXB;
     if (const char *e = getenv("CDM_BUCKET_CAP")) {
-        const long v = atol(e);
-        if (v >= 2 && v <= BK_C) cap = (uint32_t) v;
-        if (const char *comma = strchr(e, ',')) { const long m = atol(comma + 1); if (m >= 1 && m <= BK_MAXB) maxBucket = (uint32_t) m; }
+        const long m = atol(e);
+        if (m >= 1 && m <= BK_MAXB) maxBucket = (uint32_t) m;
+        if (const char *comma = strchr(e, ',')) { const long v = atol(comma + 1); if (v >= 1 && v <= WV_OWN) own = (int) v; }
     }
 }
-inline size_t bigListSlots(uint64_t n, uint32_t cap, uint32_t maxBucket) { return 2 * (size_t) (n / std::min(cap, maxBucket + 1) + 2); }
+inline size_t bigListSlots(uint64_t n, uint32_t maxBucket) { return 2 * (size_t) (n / ((uint64_t) maxBucket + 1) + 2); }
 
 // `in` is stably sorted on key bits [shiftHi, top); afterwards `out` is stably sorted on [ign, top).  Synchronises the stream.
 inline int bucketSortKeys(hipStream_t s, const uint64_t *in, uint64_t *out, uint64_t n, int shiftHi, int ign, int top) {
     if (n == 0) return CDM_OK;
-    uint32_t cap, maxBucket; capacities(cap, maxBucket);
+    int own; uint32_t maxBucket; capacities(own, maxBucket);
     DevBuf<unsigned long long> bigList; DevBuf<unsigned int> bigCnt;
-    if (!bigList.alloc(bigListSlots(n, cap, maxBucket)) || !bigCnt.alloc(1)) return CDM_ERR_HIP;
+    if (!bigList.alloc(bigListSlots(n, maxBucket)) || !bigCnt.alloc(1)) return CDM_ERR_HIP;
     hipMemsetAsync(bigCnt.p, 0, 4, s);
-    SortArgs a; a.in = in; a.out = out; a.n = n; a.shiftHi = shiftHi; a.ign = ign; a.cap = cap; a.maxBucket = maxBucket; a.big.list = bigList.p; a.big.cnt = bigCnt.p;
-    hipLaunchKernelGGL(k_bucket_sort, dim3((unsigned) ((n + BK_T - 1) / BK_T)), dim3(BK_NT), 0, s, a);
+    SortArgs a; a.in = in; a.out = out; a.n = n; a.shiftHi = shiftHi; a.ign = ign; a.own = own; a.maxBucket = maxBucket; a.big.list = bigList.p; a.big.cnt = bigCnt.p;
+    const uint64_t perBlock = (uint64_t) own * BK_WAVES;
+    hipLaunchKernelGGL(k_bucket_sort, dim3((unsigned) ((n + perBlock - 1) / perBlock)), dim3(BK_NT), 0, s, a);
     unsigned int cnt = 0;
     if (hipMemcpyAsync(&cnt, bigCnt.p, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
     if (cnt == 0) return CDM_OK;

@@ -443,68 +443,34 @@ struct BucketGroupArgs : GroupParams {
     const uint64_t *keys; const typename LY::V *vals; TupleGeom geom;
     unsigned long long *out;        // group key (or ~0) per slot, in k-mer order
     int lowBits;                    // k-mer bits the global passes left unsorted
-    uint32_t cap, maxBucket; bucket::BigList big;
-};
-struct HiOfKmer {
-    const uint64_t *keys; uint64_t kmask; int lowBits;
-    __device__ __forceinline__ uint64_t operator()(uint64_t p) const { return (keys[p] & kmask) >> lowBits; }
+    int own; uint32_t maxBucket; bucket::BigList big;
 };
 template <typename LY, typename W>
 __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs<LY, W> a) {
     using namespace bucket;
     typedef typename LY::V V;
-    __shared__ uint64_t sKey[BK_C];
-    __shared__ V sVal[BK_C];
-    __shared__ W sS[BK_WAVES][BK_MAXB];
-    __shared__ uint16_t sSt[BK_WAVES][BK_MAXB];
-    __shared__ ChunkLds c;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t kmask = (2ull << a.geom.kbits) - 1ull, lowMask = (1ull << a.lowBits) - 1ull;   // k-mer bits + the unused-slot bit
-    const HiOfKmer hiOf{a.keys, kmask, a.lowBits};
-    const uint64_t r0 = (uint64_t) blockIdx.x * BK_T;
-    uint64_t pos = findBoundary(hiOf, a.n, r0, c);
-    const uint64_t end = (r0 + BK_T >= a.n) ? a.n : findBoundary(hiOf, a.n, r0 + BK_T, c);
-    W *ss = sS[wave];
-    while (pos < end) {
-        int len = (int) min((uint64_t) a.cap, end - pos);
-        const bool cut = pos + (uint64_t) len < end;
-        for (int i = tid; i < BK_C; i += BK_NT) {
-            bool first = false;
-            if (i < len) {
-                const uint64_t k = a.keys[pos + i];
-                sKey[i] = k; sVal[i] = a.vals[pos + i];
-                first = (i == 0) || (((k & kmask) >> a.lowBits) != hiOf(pos + i - 1));
-            }
-            const unsigned long long m = __ballot(first);
-            if (lane == 0) c.bits[i >> 6] = m;
-        }
-        __syncthreads();
-        listBucketStarts(c, len);
-        __syncthreads();
-        int nB = (int) c.nB;
-        if (cut) {
-            if (nB == 1) {
-                const uint64_t bEnd = findBoundary(hiOf, a.n, pos + 1, c);
-                if (tid == 0) a.big.add(pos, bEnd);
-                pos = bEnd;
-                __syncthreads();
-                continue;
-            }
-            nB--; len = c.sB[nB];
-        }
-        int j = c.pre[wave * (BK_WIN / 64)];
-        const int jEnd = min(nB, (int) c.pre[(wave + 1) * (BK_WIN / 64)]);
-        Group g;
-        while (nextGroup(c, j, jEnd, g)) {
-            const int gm = g.g1 - g.g0;
-            if (gm > (int) a.maxBucket) { if (lane == 0) a.big.add(pos + g.g0, pos + g.g1); continue; }
+    __shared__ uint64_t sKeyAll[BK_WAVES][WV_WIN];
+    __shared__ V sValAll[BK_WAVES][WV_WIN];
+    __shared__ W sSAll[BK_WAVES][BK_MAXB];
+    __shared__ uint16_t sStAll[BK_WAVES][BK_MAXB];
+    __shared__ WaveLds wAll[BK_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t r0 = ((uint64_t) blockIdx.x * BK_WAVES + wave) * (uint64_t) a.own;
+    if (r0 >= a.n) return;
+    uint64_t *sKey = sKeyAll[wave]; V *sVal = sValAll[wave]; W *ss = sSAll[wave]; uint16_t *sSt = sStAll[wave];
+    WaveLds &w = wAll[wave];
+    const uint64_t hmask = (2ull << a.geom.kbits) - 1ull, lowMask = (1ull << a.lowBits) - 1ull;   // k-mer bits + the unused-slot bit
+    const int lowBits = a.lowBits;
+    waveBuckets(r0, a.n, a.own, a.maxBucket, a.big, w, lane,
+        [&](uint64_t g, int i) { const uint64_t k = a.keys[g]; sKey[i] = k; sVal[i] = a.vals[g]; return (k & hmask) >> lowBits; },
+        [&](uint64_t g) { return (a.keys[g] & hmask) >> lowBits; },
+        [&](int g0, int gm, int ord0) {
             const int idxBits = gm > 256 ? 9 : 8;
             const W idxMask = (W) ((1u << idxBits) - 1u);
-            const int g0 = g.g0, j0 = g.j0, lowBits = a.lowBits;
             sortGroup<W>(gm, lane,
                 [&](int i) {
                     const W low = (W) (sKey[g0 + i] & lowMask);
-                    return (W) ((((((W) (ordOf(c, g0 + i) - j0)) << lowBits) | low) << idxBits) | (W) i);
+                    return (W) ((((((W) (ordOf(w, g0 + i) - ord0)) << lowBits) | low) << idxBits) | (W) i);
                 },
                 [&](auto &v) {
                     // sorted words and the start of every element's run (= equal bucket and low bits) to LDS; the run starts
@@ -525,13 +491,13 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
                     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(sc, d, 64); if (lane >= d) sc = max(sc, o); }
                     const int carry = __shfl_up(sc, 1, 64);
 #pragma unroll
-                    for (int r = 0; r < R; r++) sSt[wave][lane * R + r] = (uint16_t) (st[r] < 0 ? carry : st[r]);
+                    for (int r = 0; r < R; r++) sSt[lane * R + r] = (uint16_t) (st[r] < 0 ? carry : st[r]);
                 });
             waveLdsSync();
             // one copy of the member code in the instruction stream, whatever the size of the network before it
 #pragma unroll 1
             for (int p = lane; p < gm; p += 64) {
-                const int s0 = sSt[wave][p];
+                const int s0 = sSt[p];
                 const W cw = ss[p], kp = cw >> idxBits;
                 const int e = g0 + (int) (cw & idxMask);
                 const uint64_t key = sKey[e];
@@ -541,22 +507,19 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
                     const int er = g0 + (int) (ss[s0] & idxMask);
                     uint64_t bestKey = sKey[er]; const V best = sVal[er];
                     const uint32_t repId = LY::seqOf(best);
-                    uint32_t bestPos = LY::posOf(bestKey, best, pos + er, a.geom);
+                    uint32_t bestPos = LY::posOf(bestKey, best, r0 + er, a.geom);
                     for (int t = s0 + 1; t < gm && (ss[t] >> idxBits) == kp; t++) {     // same sequence twice in the run (rare)
                         const int et = g0 + (int) (ss[t] & idxMask);
                         if (LY::seqOf(sVal[et]) != repId) break;
-                        const uint32_t pe = LY::posOf(sKey[et], sVal[et], pos + et, a.geom);
+                        const uint32_t pe = LY::posOf(sKey[et], sVal[et], r0 + et, a.geom);
                         if (pe < bestPos) { bestPos = pe; bestKey = sKey[et]; }
                     }
-                    gk = groupKeyOf<LY>(a, a.geom, bestKey, best, pos + er, bestPos, pos + g0 + s0 == a.firstRunIdx, key, sVal[e], pos + e);
+                    gk = groupKeyOf<LY>(a, a.geom, bestKey, best, r0 + er, bestPos, r0 + (uint64_t) (g0 + s0) == a.firstRunIdx, key, sVal[e], r0 + e);
                 }
-                a.out[pos + g0 + p] = gk;
+                a.out[r0 + (uint64_t) (g0 + p)] = gk;
             }
             waveLdsSync();      // ss / sSt are reused by the next group
-        }
-        pos += (uint64_t) len;
-        __syncthreads();
-    }
+        });
 }
 
 // order preserving compaction of the kept keys: tiles of 4096 (256 threads x 16 consecutive items)
@@ -892,9 +855,9 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
         int rc = CDM_OK;
         if (lowBits == 0) rc = scanGroups(ga, startIo);
         else {
-            uint32_t cap, maxBucket; bucket::capacities(cap, maxBucket);
+            int own; uint32_t maxBucket; bucket::capacities(own, maxBucket);
             DevBuf<unsigned long long> bigList; DevBuf<unsigned int> bigCnt;
-            if (!bigList.alloc(bucket::bigListSlots(kmerSlots, cap, maxBucket)) || !bigCnt.alloc(1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+            if (!bigList.alloc(bucket::bigListSlots(kmerSlots, maxBucket)) || !bigCnt.alloc(1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
             hipMemsetAsync(bigCnt.p, 0, 4, s);
             unsigned long long live = 0;
             if (kmerSlots) {
@@ -907,9 +870,10 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
                 typedef decltype(wordTag) W;
                 BucketGroupArgs<LY, W> ba;
                 static_cast<GroupParams &>(ba) = ga; ba.n = live;
-                ba.keys = ga.keys; ba.vals = ga.vals; ba.geom = geom; ba.out = startIo; ba.lowBits = lowBits; ba.cap = cap; ba.maxBucket = maxBucket;
+                ba.keys = ga.keys; ba.vals = ga.vals; ba.geom = geom; ba.out = startIo; ba.lowBits = lowBits; ba.own = own; ba.maxBucket = maxBucket;
                 ba.big.list = bigList.p; ba.big.cnt = bigCnt.p;
-                if (live) hipLaunchKernelGGL((k_bucket_groups<LY, W>), dim3((unsigned) ((live + bucket::BK_T - 1) / bucket::BK_T)), dim3(bucket::BK_NT), 0, s, ba);
+                const uint64_t perBlock = (uint64_t) own * bucket::BK_WAVES;
+                if (live) hipLaunchKernelGGL((k_bucket_groups<LY, W>), dim3((unsigned) ((live + perBlock - 1) / perBlock)), dim3(bucket::BK_NT), 0, s, ba);
             };
             if (lowBits <= 16) launchFused(uint32_t()); else launchFused(uint64_t());
             unsigned int nBig = 0;

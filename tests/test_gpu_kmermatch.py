@@ -109,8 +109,8 @@ def test_kmermatch_bucket_sort_paths_agree(ctx, oracle_bin, tmp_path, monkeypatc
     mmdb.write_seqdb(t("in"), seqs)
     run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
     want = strip_ext(mmdb.read_db(t("pref")))
-    for env in ({}, {"CDM_BUCKET_CAP": "64"}, {"CDM_BUCKET_CAP": "5"}, {"CDM_BUCKET_CAP": "300,3"}, {"CDM_BUCKET_CAP": "2048,1"},
-                {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_BUCKET_CAP": "40,6"}):
+    for env in ({}, {"CDM_BUCKET_CAP": "64"}, {"CDM_BUCKET_CAP": "5"}, {"CDM_BUCKET_CAP": "3,17"}, {"CDM_BUCKET_CAP": "1"}, {"CDM_BUCKET_CAP": "512,40"},
+                {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_BUCKET_CAP": "6,100"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         assert not diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), want), env
