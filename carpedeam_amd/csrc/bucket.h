@@ -42,10 +42,10 @@ __device__ __forceinline__ void waveLdsSync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// per-wave bookkeeping in LDS: "starts a bucket" bit per window slot (written with ballots) and their prefix counts
+// per-wave bookkeeping in LDS: "starts a bucket" bit per window slot (written with ballots) and the ordinal of every slot's bucket
 struct WaveLds {
     unsigned long long bits[WV_WORDS];
-    uint16_t pre[WV_WORDS + 1];
+    uint16_t ord[WV_WIN];
 };
 // first set bit in [from, limit), -1 if none.  Wave-uniform.
 __device__ __forceinline__ int firstSetFrom(const WaveLds &w, int from, int limit) {
@@ -66,10 +66,6 @@ __device__ __forceinline__ int lastSetIn(const WaveLds &w, int lo, int hi) {
         if (m) return word * 64 + 63 - __clzll(m);
     }
     return -1;
-}
-// ordinal of the bucket that window slot i belongs to
-__device__ __forceinline__ int ordOf(const WaveLds &w, int i) {
-    return (int) w.pre[i >> 6] + __popcll(w.bits[i >> 6] & ((2ull << (i & 63)) - 1ull)) - 1;
 }
 
 struct BigList {
@@ -137,29 +133,38 @@ __device__ __forceinline__ void sortGroup(int gm, int lane, const MakeComp &mk, 
     else if (gm <= 256) sortGroupRegs<4, W>(gm, lane, mk, done);
     else sortGroupRegs<8, W>(gm, lane, mk, done);
 }
-// The walk of one wave over the buckets it owns.  stage(g, i) loads the tuple at global index g into window slot i and returns
-// its high bits; hiAt(g) returns the high bits of the tuple at g; groupFn(g0, gm, ord0) finishes the group of whole buckets in
-// the window slots [g0, g0 + gm), ord0 = ordinal of its first bucket.
-template <typename Stage, typename HiAt, typename GroupFn>
+// The walk of one wave over the buckets it owns.  T fetch(g) loads the tuple at global index g into registers, put(i, t) stores
+// it in window slot i and returns its high bits, hiAt(g) returns the high bits of the tuple at g; groupFn(g0, gm) finishes the
+// group of whole buckets in the window slots [g0, g0 + gm).  w.ord[i] = ordinal of slot i's bucket in the window.
+template <typename T, typename Fetch, typename Put, typename HiAt, typename GroupFn>
 __device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, uint32_t maxBucket, const BigList &big, WaveLds &w, int lane,
-                                            const Stage &stage, const HiAt &hiAt, const GroupFn &groupFn) {
+                                            const Fetch &fetch, const Put &put, const HiAt &hiAt, const GroupFn &groupFn) {
     const int avail = (int) min((uint64_t) WV_WIN, n - r0);
     uint64_t carry = r0 ? hiAt(r0 - 1) : 0ull;
-    auto loadRows = [&](int t0, int t1) {
-        for (int t = t0; t < t1; t++) {
-            const int i = t * 64 + lane;
+    int ordBase = -1;
+    // all loads of a batch of rows are issued before the first one is consumed
+    auto loadRows = [&](auto rowsTag, int t0) {
+        constexpr int ROWS = decltype(rowsTag)::value;
+        T tup[ROWS];
+#pragma unroll
+        for (int t = 0; t < ROWS; t++) { const int i = (t0 + t) * 64 + lane; if (i < avail) tup[t] = fetch(r0 + (uint64_t) i); }
+#pragma unroll
+        for (int t = 0; t < ROWS; t++) {
+            const int i = (t0 + t) * 64 + lane;
             const bool valid = i < avail;
-            const uint64_t h = valid ? stage(r0 + (uint64_t) i, i) : 0ull;
+            const uint64_t h = valid ? put(i, tup[t]) : 0ull;
             uint64_t up = shflUpW<uint64_t>(h, 1);
             if (lane == 0) up = carry;
             const bool first = valid && ((r0 + (uint64_t) i == 0) || h != up);
             const unsigned long long m = __ballot(first);
-            if (lane == 0) w.bits[t] = m;
+            if (lane == 0) w.bits[t0 + t] = m;
+            if (valid) w.ord[i] = (uint16_t) (ordBase + __popcll(m & ((2ull << lane) - 1ull)));
+            ordBase += __popcll(m);
             carry = ((uint64_t) (uint32_t) __shfl((int) (h >> 32), 63, 64) << 32) | (uint32_t) __shfl((int) (uint32_t) h, 63, 64);
         }
     };
     if (lane >= WV_FIRST / 64 && lane < WV_WORDS) w.bits[lane] = 0ull;
-    loadRows(0, WV_FIRST / 64);
+    loadRows(std::integral_constant<int, WV_FIRST / 64>(), 0);
     waveLdsSync();
     const int ownEnd = min(own, avail);
     const int sLast = lastSetIn(w, -1, ownEnd - 1);         // start of the last bucket this wave owns
@@ -168,7 +173,7 @@ __device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, ui
     int loaded = min(avail, WV_FIRST);
     int eLast = firstSetFrom(w, sLast + 1, loaded);
     if (eLast < 0 && loaded < avail) {
-        loadRows(WV_FIRST / 64, WV_WORDS);
+        loadRows(std::integral_constant<int, WV_WORDS - WV_FIRST / 64>(), WV_FIRST / 64);
         waveLdsSync();
         loaded = avail;
         eLast = firstSetFrom(w, sLast + 1, loaded);
@@ -182,14 +187,6 @@ __device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, ui
         if (lane == 0) big.add(r0 + (uint64_t) sLast, lo);
         eOwn = sLast;
     }
-    {   // prefix counts of the bucket starts per word
-        const int cnt = (lane < WV_WORDS) ? __popcll(w.bits[lane]) : 0;
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-        if (lane <= WV_WORDS) w.pre[lane] = (uint16_t) (incl - cnt);
-    }
-    waveLdsSync();
     int g0 = p0;
     while (g0 < eOwn) {
         const int lim = min(g0 + BK_GROUP, eOwn);
@@ -197,10 +194,12 @@ __device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, ui
         if (e < 0) { e = firstSetFrom(w, g0 + 1, eOwn); if (e < 0) e = eOwn; }     // one bucket larger than a group
         const int gm = e - g0;
         if (gm > (int) maxBucket) { if (lane == 0) big.add(r0 + (uint64_t) g0, r0 + (uint64_t) e); }
-        else groupFn(g0, gm, ordOf(w, g0));
+        else groupFn(g0, gm);
         g0 = e;
     }
 }
+
+constexpr int WV_IDX = 10;      // bits of a window slot / of a bucket ordinal in the sorted word
 
 struct SortArgs {
     const uint64_t *in; uint64_t *out; uint64_t n;
@@ -221,21 +220,20 @@ __global__ __launch_bounds__(BK_NT) void k_bucket_sort(SortArgs a) {
     WaveLds &w = wAll[wave];
     const uint64_t lowMask = (1ull << a.shiftHi) - 1ull;
     const int lowW = a.shiftHi - a.ign, ign = a.ign, shiftHi = a.shiftHi;
-    waveBuckets(r0, a.n, a.own, a.maxBucket, a.big, w, lane,
-        [&](uint64_t g, int i) { const uint64_t k = a.in[g]; sKey[i] = k; return k >> shiftHi; },
+    waveBuckets<uint64_t>(r0, a.n, a.own, a.maxBucket, a.big, w, lane,
+        [&](uint64_t g) { return a.in[g]; },
+        [&](int i, uint64_t k) { sKey[i] = k; return k >> shiftHi; },
         [&](uint64_t g) { return a.in[g] >> shiftHi; },
-        [&](int g0, int gm, int ord0) {
-            const int idxBits = gm > 256 ? 9 : 8;
-            const uint64_t idxMask = (1ull << idxBits) - 1ull;
+        [&](int g0, int gm) {
             sortGroup<uint64_t>(gm, lane,
                 [&](int i) {
                     const uint64_t low = (sKey[g0 + i] & lowMask) >> ign;
-                    return ((((uint64_t) (ordOf(w, g0 + i) - ord0) << lowW) | low) << idxBits) | (uint64_t) i;
+                    return ((((uint64_t) w.ord[g0 + i] << lowW) | low) << WV_IDX) | (uint64_t) (g0 + i);
                 },
                 [&](auto &v) {
                     constexpr int R = sizeof(v) / sizeof(v[0]);
 #pragma unroll
-                    for (int r = 0; r < R; r++) { const int p = lane * R + r; if (p < gm) a.out[r0 + (uint64_t) (g0 + p)] = sKey[g0 + (int) (v[r] & idxMask)]; }
+                    for (int r = 0; r < R; r++) { const int p = lane * R + r; if (p < gm) a.out[r0 + (uint64_t) (g0 + p)] = sKey[(int) (v[r] & ((1u << WV_IDX) - 1u))]; }
                 });
         });
 }

@@ -451,30 +451,27 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
     typedef typename LY::V V;
     __shared__ uint64_t sKeyAll[BK_WAVES][WV_WIN];
     __shared__ V sValAll[BK_WAVES][WV_WIN];
-    __shared__ W sSAll[BK_WAVES][BK_MAXB];
-    __shared__ uint16_t sStAll[BK_WAVES][BK_MAXB];
+    __shared__ uint32_t sSAll[BK_WAVES][BK_MAXB];
     __shared__ WaveLds wAll[BK_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t r0 = ((uint64_t) blockIdx.x * BK_WAVES + wave) * (uint64_t) a.own;
     if (r0 >= a.n) return;
-    uint64_t *sKey = sKeyAll[wave]; V *sVal = sValAll[wave]; W *ss = sSAll[wave]; uint16_t *sSt = sStAll[wave];
+    uint64_t *sKey = sKeyAll[wave]; V *sVal = sValAll[wave]; uint32_t *ss = sSAll[wave];
     WaveLds &w = wAll[wave];
     const uint64_t hmask = (2ull << a.geom.kbits) - 1ull, lowMask = (1ull << a.lowBits) - 1ull;   // k-mer bits + the unused-slot bit
     const int lowBits = a.lowBits;
-    waveBuckets(r0, a.n, a.own, a.maxBucket, a.big, w, lane,
-        [&](uint64_t g, int i) { const uint64_t k = a.keys[g]; sKey[i] = k; sVal[i] = a.vals[g]; return (k & hmask) >> lowBits; },
+    struct Tup { uint64_t k; V v; };
+    constexpr uint32_t IDXM = (1u << WV_IDX) - 1u;
+    waveBuckets<Tup>(r0, a.n, a.own, a.maxBucket, a.big, w, lane,
+        [&](uint64_t g) { Tup t; t.k = a.keys[g]; t.v = a.vals[g]; return t; },
+        [&](int i, const Tup &t) { sKey[i] = t.k; sVal[i] = t.v; return (t.k & hmask) >> lowBits; },
         [&](uint64_t g) { return (a.keys[g] & hmask) >> lowBits; },
-        [&](int g0, int gm, int ord0) {
-            const int idxBits = gm > 256 ? 9 : 8;
-            const W idxMask = (W) ((1u << idxBits) - 1u);
+        [&](int g0, int gm) {
             sortGroup<W>(gm, lane,
-                [&](int i) {
-                    const W low = (W) (sKey[g0 + i] & lowMask);
-                    return (W) ((((((W) (ordOf(w, g0 + i) - ord0)) << lowBits) | low) << idxBits) | (W) i);
-                },
+                [&](int i) { return (W) ((((W) w.ord[g0 + i] << lowBits | (W) (sKey[g0 + i] & lowMask)) << WV_IDX) | (W) (g0 + i)); },
                 [&](auto &v) {
-                    // sorted words and the start of every element's run (= equal bucket and low bits) to LDS; the run starts
-                    // come from an inclusive max-scan of the start positions over the wave
+                    // per sorted position: window slot of the element, start of its run (= equal bucket and low bits; from an
+                    // inclusive max-scan of the start positions over the wave) and whether it starts one
                     constexpr int R = sizeof(v) / sizeof(v[0]);
                     const W prevLast = shflUpW<W>(v[R - 1], 1);
                     int st[R], last = -1;
@@ -482,34 +479,35 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
                     for (int r = 0; r < R; r++) {
                         const int p = lane * R + r;
                         const W prev = r ? v[r - 1] : prevLast;
-                        if (p == 0 || (v[r] >> idxBits) != (prev >> idxBits)) last = p;
+                        if (p == 0 || (v[r] >> WV_IDX) != (prev >> WV_IDX)) last = p;
                         st[r] = last;
-                        ss[p] = v[r];
                     }
                     int sc = last;
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(sc, d, 64); if (lane >= d) sc = max(sc, o); }
                     const int carry = __shfl_up(sc, 1, 64);
 #pragma unroll
-                    for (int r = 0; r < R; r++) sSt[lane * R + r] = (uint16_t) (st[r] < 0 ? carry : st[r]);
+                    for (int r = 0; r < R; r++) {
+                        const int p = lane * R + r, s0 = st[r] < 0 ? carry : st[r];
+                        ss[p] = ((uint32_t) v[r] & IDXM) | ((uint32_t) s0 << WV_IDX) | (s0 == p ? 1u << 31 : 0u);
+                    }
                 });
             waveLdsSync();
             // one copy of the member code in the instruction stream, whatever the size of the network before it
 #pragma unroll 1
             for (int p = lane; p < gm; p += 64) {
-                const int s0 = sSt[p];
-                const W cw = ss[p], kp = cw >> idxBits;
-                const int e = g0 + (int) (cw & idxMask);
+                const uint32_t cw = ss[p];
+                const int s0 = (int) ((cw >> WV_IDX) & 1023u), e = (int) (cw & IDXM);
                 const uint64_t key = sKey[e];
                 unsigned long long gk = ~0ull;
-                const bool hasNext = (p + 1 < gm) && (ss[p + 1] >> idxBits) == kp;
+                const bool hasNext = (p + 1 < gm) && !(ss[p + 1] >> 31);
                 if (key != ~0ull && (s0 != p || hasNext)) {
-                    const int er = g0 + (int) (ss[s0] & idxMask);
+                    const int er = (int) (ss[s0] & IDXM);
                     uint64_t bestKey = sKey[er]; const V best = sVal[er];
                     const uint32_t repId = LY::seqOf(best);
                     uint32_t bestPos = LY::posOf(bestKey, best, r0 + er, a.geom);
-                    for (int t = s0 + 1; t < gm && (ss[t] >> idxBits) == kp; t++) {     // same sequence twice in the run (rare)
-                        const int et = g0 + (int) (ss[t] & idxMask);
+                    for (int t = s0 + 1; t < gm && !(ss[t] >> 31); t++) {     // same sequence twice in the run (rare)
+                        const int et = (int) (ss[t] & IDXM);
                         if (LY::seqOf(sVal[et]) != repId) break;
                         const uint32_t pe = LY::posOf(sKey[et], sVal[et], r0 + et, a.geom);
                         if (pe < bestPos) { bestPos = pe; bestKey = sKey[et]; }
@@ -518,49 +516,15 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
                 }
                 a.out[r0 + (uint64_t) (g0 + p)] = gk;
             }
-            waveLdsSync();      // ss / sSt are reused by the next group
+            waveLdsSync();      // ss is reused by the next group
         });
 }
 
-// order preserving compaction of the kept keys: tiles of 4096 (256 threads x 16 consecutive items)
+// tiles of the vote kernels: 4096 keys (256 threads x 16 consecutive items)
 constexpr int CP_ITEMS = 16, CP_TILE = 256 * CP_ITEMS;
 // LDS index with one pad slot per 16 items: thread t walks items 16t..16t+15 without bank conflicts
 __device__ __forceinline__ int padIdx(int i) { return i + (i >> 4); }
 constexpr int CP_LDS = CP_TILE + CP_TILE / 16 + 1;
-
-__global__ __launch_bounds__(256) void k_tile_count(const uint64_t *__restrict__ in, uint64_t n, unsigned long long *__restrict__ tileCnt) {
-    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE;
-    unsigned int c = 0;
-#pragma unroll
-    for (int j = 0; j < CP_ITEMS; j++) { const uint64_t i = base + threadIdx.x + 256 * j; if (i < n) c += in[i] != ~0ull; }   // coalesced
-    typedef hipcub::BlockReduce<unsigned int, 256> BR;
-    __shared__ typename BR::TempStorage tmp;
-    const unsigned int tot = BR(tmp).Sum(c);
-    if (threadIdx.x == 0) tileCnt[blockIdx.x] = tot;
-}
-__global__ __launch_bounds__(256) void k_tile_compact(const uint64_t *__restrict__ in, uint64_t n, const unsigned long long *__restrict__ tileOff, uint64_t *__restrict__ out) {
-    __shared__ uint64_t sIn[CP_LDS];
-    __shared__ uint64_t sOut[CP_TILE];
-    const uint64_t base = (uint64_t) blockIdx.x * CP_TILE;
-#pragma unroll
-    for (int j = 0; j < CP_ITEMS; j++) { const int li = threadIdx.x + 256 * j; const uint64_t i = base + li; sIn[padIdx(li)] = (i < n) ? in[i] : ~0ull; }
-    __syncthreads();
-    unsigned int c = 0;
-#pragma unroll
-    for (int j = 0; j < CP_ITEMS; j++) c += sIn[padIdx(threadIdx.x * CP_ITEMS + j)] != ~0ull;
-    typedef hipcub::BlockScan<unsigned int, 256> BS;
-    __shared__ typename BS::TempStorage tmp;
-    unsigned int off, total;
-    BS(tmp).ExclusiveSum(c, off, total);
-#pragma unroll
-    for (int j = 0; j < CP_ITEMS; j++) { const uint64_t v = sIn[padIdx(threadIdx.x * CP_ITEMS + j)]; if (v != ~0ull) sOut[off++] = v; }
-    __syncthreads();
-    const uint64_t o = tileOff[blockIdx.x];
-    for (unsigned int i = threadIdx.x; i < total; i += 256) out[o + i] = sOut[i];   // coalesced
-}
-
-struct U8toU32 { __host__ __device__ uint32_t operator()(const uint8_t &v) const { return v; } };
-struct NotDropped { __host__ __device__ bool operator()(const uint64_t &k) const { return k != ~0ull; } };
 
 // ------------------------------------------------------------------------------------------------ K4: vote
 struct VoteArgs {
@@ -710,7 +674,8 @@ __global__ void k_slot_scatter(const uint32_t *__restrict__ order, const unsigne
     if (r < n) { slotOff[order[r]] = ordOff[r]; rankOf[order[r]] = r; }
     if (r == n) slotOff[n] = ordOff[n];
 }
-// number of real tuples in region 1 once it is sorted on bits up to 2k: the first key with bit 2k set
+// number of keys in front of the unused / dropped ones (key ~0) once the array is sorted on bits up to `bit`, which is set
+// only in them: the first key with that bit set
 __global__ void k_live_count(const uint64_t *__restrict__ keys, uint64_t n, int kbits, unsigned long long *__restrict__ out) {
     uint64_t lo = 0, hi = n;
     while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((keys[mid] >> kbits) & 1ull) hi = mid; else lo = mid + 1; }
@@ -732,7 +697,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
         return CDM_ERR_UNSUPPORTED;
     }
     const uint32_t idBits = bitsFor(n), diagBits = bitsFor(2ull * db->maxLen + 2);
-    if (2 * idBits + diagBits + 1 > 64) { cdm_set_error("cdm_kmermatch: %u sequences x max length %u do not fit the 64-bit (rep,id,diagonal) sort key", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
+    if (2 * idBits + diagBits + 1 > 63) { cdm_set_error("cdm_kmermatch: %u sequences x max length %u do not fit the 64-bit (rep,id,diagonal) sort key", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
     const int diagBias = (int) db->maxLen + 1;
     const char *sortEnv = getenv("CDM_KMER_SORT");
     const bool lsdOnly = sortEnv && !strcmp(sortEnv, "lsd");
@@ -835,8 +800,6 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     ga.keys = keys.current(); ga.vals = vals.current(); ga.n = nTuples; ga.onlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode;
     ga.covThr = par->cov_thr; ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias; ga.first = 0; ga.firstRunIdx = 0;
     unsigned long long *startIo = (unsigned long long *) keys.alternate();   // free after the sort
-    uint64_t *gkeys = keys.current();                                        // free once the group keys are written
-    unsigned long long nGroup = 0;
     {
         // scan + k_groups over the tuples [first, last) of (kk, vv), group keys to io[first..last)
         auto scanGroups = [&](GroupArgs<LY> g, unsigned long long *io) -> int {
@@ -875,7 +838,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
                 const uint64_t perBlock = (uint64_t) own * bucket::BK_WAVES;
                 if (live) hipLaunchKernelGGL((k_bucket_groups<LY, W>), dim3((unsigned) ((live + perBlock - 1) / perBlock)), dim3(bucket::BK_NT), 0, s, ba);
             };
-            if (lowBits <= 16) launchFused(uint32_t()); else launchFused(uint64_t());
+            if (lowBits <= 12) launchFused(uint32_t()); else launchFused(uint64_t());   // bucket ordinal + low bits + window slot in one word
             unsigned int nBig = 0;
             hipMemcpyAsync(&nBig, bigCnt.p, 4, hipMemcpyDeviceToHost, s);
             GroupArgs<LY> g2 = ga; g2.first = kmerSlots;                      // region 2 is sorted on all its bits
@@ -908,34 +871,31 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
             }
         }
         if (rc != CDM_OK) { cdm_set_error("cdm_kmermatch: grouping failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
-        size_t sb2 = 0;
-        const uint64_t nTiles = (nTuples + CP_TILE - 1) / CP_TILE;
-        DevBuf<unsigned long long> tileCnt, tileOff;
-        if (!tileCnt.alloc(nTiles + 1) || !tileOff.alloc(nTiles + 1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
-        hipcub::DeviceScan::ExclusiveSum(nullptr, sb2, tileCnt.p, tileOff.p, (int) (nTiles + 1), s);
-        DevBuf<char> tmp2;
-        if (!tmp2.alloc(sb2 + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (scan temp)"); return CDM_ERR_HIP; }
-        if (nTuples) hipLaunchKernelGGL(k_tile_count, dim3((unsigned) nTiles), dim3(256), 0, s, (const uint64_t *) startIo, (uint64_t) nTuples, tileCnt.p);
-        hipMemsetAsync(tileCnt.p + nTiles, 0, 8, s);
-        hipcub::DeviceScan::ExclusiveSum(tmp2.p, sb2, tileCnt.p, tileOff.p, (int) (nTiles + 1), s);
-        if (nTuples) hipLaunchKernelGGL(k_tile_compact, dim3((unsigned) nTiles), dim3(256), 0, s, (const uint64_t *) startIo, (uint64_t) nTuples, tileOff.p, gkeys);
-        hipMemcpyAsync(&nGroup, tileOff.p + nTiles, 8, hipMemcpyDeviceToHost, s);
         { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     }
     float msSort1 = 0; hipEventElapsedTime(&msSort1, ctx->ev0, ctx->ev1);
 
-    // ---- sort 2: by (rep, id, diagonal) = key bits 1.., stable; strand bit 0 rides along.  The top 32 bits go through global
-    // radix passes, the rest is finished bucket by bucket in LDS (bucket.h); CDM_KMER_SORT=lsd keeps the all-global sort (A/B)
+    // ---- sort 2: by (rep, id, diagonal) = key bits 1.., stable; strand bit 0 rides along.  No compaction before it: dropped
+    // members carry the key ~0, and bit top2 (the first bit above the key fields) is set only there, so sorting on bits up to and
+    // including top2 moves them behind all kept members, in the order the reference's (rep, id, diagonal) sort leaves the
+    // kept ones.  The top 32 of those bits go through global radix passes, the rest is finished bucket by bucket on chip
+    // (bucket.h); CDM_KMER_SORT=lsd keeps the all-global sort (A/B).
     v0.free(); v1.free();                                                    // the tuple values are dead after k_groups
-    rocprim::double_buffer<uint64_t> g(gkeys, (uint64_t *) startIo);
+    rocprim::double_buffer<uint64_t> g((uint64_t *) startIo, keys.current());
     const int top2 = (int) (2 * idBits + diagBits + 1);
-    const int shiftHi2 = lsdOnly ? 1 : std::max(1, top2 - 32);
+    const int shiftHi2 = lsdOnly ? 1 : std::max(1, top2 + 1 - 32);
     size_t tmpBytes2 = 0;
-    rocprim::radix_sort_keys(nullptr, tmpBytes2, g, (size_t) nGroup, shiftHi2, top2, s);
+    rocprim::radix_sort_keys(nullptr, tmpBytes2, g, (size_t) nTuples, shiftHi2, top2 + 1, s);
     DevBuf<char> tmp3;
     if (!tmp3.alloc(tmpBytes2 + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev0, s);
-    if (rocprim::radix_sort_keys(tmp3.p, tmpBytes2, g, (size_t) nGroup, shiftHi2, top2, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+    if (rocprim::radix_sort_keys(tmp3.p, tmpBytes2, g, (size_t) nTuples, shiftHi2, top2 + 1, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+    unsigned long long nGroup = 0;
+    if (nTuples) {
+        hipLaunchKernelGGL(k_live_count, dim3(1), dim3(1), 0, s, (const uint64_t *) g.current(), (uint64_t) nTuples, top2, counters.p + 2);
+        hipMemcpyAsync(&nGroup, counters.p + 2, 8, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+    }
     const uint64_t *sorted2 = g.current();
     if (shiftHi2 > 1) {
         if (bucket::bucketSortKeys(s, g.current(), g.alternate(), nGroup, shiftHi2, 1, top2) != CDM_OK) { cdm_set_error("cdm_kmermatch: bucket sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
