@@ -74,10 +74,35 @@ struct BigList {
     __device__ __forceinline__ void add(uint64_t s, uint64_t e) const { const unsigned int q = atomicAdd(cnt, 1u); list[2 * (size_t) q] = s; list[2 * (size_t) q + 1] = e; }
 };
 
-template <typename W> __device__ __forceinline__ W shflXorW(W a, int m);
-template <> __device__ __forceinline__ uint32_t shflXorW<uint32_t>(uint32_t a, int m) { return (uint32_t) __shfl_xor((int) a, m, 64); }
-template <> __device__ __forceinline__ uint64_t shflXorW<uint64_t>(uint64_t a, int m) {
-    return ((uint64_t) (uint32_t) __shfl_xor((int) (a >> 32), m, 64) << 32) | (uint32_t) __shfl_xor((int) (uint32_t) a, m, 64);
+// value of lane (lane ^ M): DPP lane permutations inside a row of 16 (no LDS round trip), ds_swizzle across rows of a half,
+// a general shuffle only between the two halves of the wave
+template <int M> __device__ __forceinline__ uint32_t xorLane32(uint32_t a) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "lane distance");
+    if (M == 1) return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) a, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    if (M == 2) return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) a, 0x4E, 0xF, 0xF, false);        // quad_perm [2,3,0,1]
+    if (M == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int) a, 0x104, 0xF, 0x5, false);                    // row_shl:4 into banks 0, 2
+        return (uint32_t) __builtin_amdgcn_update_dpp(t, (int) a, 0x114, 0xF, 0xA, false);                // row_shr:4 into banks 1, 3
+    }
+    if (M == 8) return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) a, 0x128, 0xF, 0xF, false);       // row_ror:8
+    if (M == 16) return (uint32_t) __builtin_amdgcn_ds_swizzle((int) a, 0x401F);                          // xor 0x10 within 32 lanes
+    return (uint32_t) __shfl_xor((int) a, 32, 64);
+}
+template <typename W, int M> struct XorLane;
+template <int M> struct XorLane<uint32_t, M> { __device__ static __forceinline__ uint32_t get(uint32_t a) { return xorLane32<M>(a); } };
+template <int M> struct XorLane<uint64_t, M> {
+    __device__ static __forceinline__ uint64_t get(uint64_t a) { return ((uint64_t) xorLane32<M>((uint32_t) (a >> 32)) << 32) | xorLane32<M>((uint32_t) a); }
+};
+// d is a constant once the network loops are unrolled: the switch folds away
+template <typename W> __device__ __forceinline__ W xorLane(W a, int d) {
+    switch (d) {
+        case 1: return XorLane<W, 1>::get(a);
+        case 2: return XorLane<W, 2>::get(a);
+        case 4: return XorLane<W, 4>::get(a);
+        case 8: return XorLane<W, 8>::get(a);
+        case 16: return XorLane<W, 16>::get(a);
+        default: return XorLane<W, 32>::get(a);
+    }
 }
 template <typename W> __device__ __forceinline__ W shflUpW(W a, int d);
 template <> __device__ __forceinline__ uint32_t shflUpW<uint32_t>(uint32_t a, int d) { return (uint32_t) __shfl_up((int) a, d, 64); }
@@ -100,8 +125,8 @@ __device__ __forceinline__ void bitonicRegs(W (&v)[R], int lane) {
                     if (p > r) {
                         const bool up = (((lane * R + r) & k) == 0);
                         const W a = v[r], b = v[p];
-                        const W lo = a < b ? a : b, hi = a < b ? b : a;
-                        v[r] = up ? lo : hi; v[p] = up ? hi : lo;
+                        const bool sw = (b < a) == up;           // one compare, the direction is folded into the lane mask
+                        v[r] = sw ? b : a; v[p] = sw ? a : b;
                     }
                 }
             } else {
@@ -109,9 +134,8 @@ __device__ __forceinline__ void bitonicRegs(W (&v)[R], int lane) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const bool up = (((lane * R + r) & k) == 0);
-                    const W a = v[r], b = shflXorW<W>(a, j / R);
-                    const W lo = a < b ? a : b, hi = a < b ? b : a;
-                    v[r] = (up == lower) ? lo : hi;
+                    const W a = v[r], b = xorLane<W>(a, j / R);
+                    v[r] = ((b < a) == (up == lower)) ? b : a;
                 }
             }
         }

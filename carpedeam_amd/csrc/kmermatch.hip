@@ -70,6 +70,8 @@ struct LayoutWide {
     __device__ static uint32_t seqOf(V v) { return (uint32_t) (v >> 32); }
     __device__ static uint32_t lenOf(uint64_t, V v, uint64_t, const TupleGeom &) { return (uint32_t) ((v >> 16) & 0xFFFF); }
     __device__ static uint32_t posOf(uint64_t, V v, uint64_t, const TupleGeom &) { return (uint32_t) (v & 0xFFFF); }
+    // length and position of a region-1 tuple
+    __device__ static void unpackR1(uint64_t, V v, const TupleGeom &, uint32_t &len, uint32_t &pos) { const uint32_t lo = (uint32_t) v; pos = lo & 0xFFFFu; len = lo >> 16; }
 };
 // 12 bytes: u64 key = k-mer | pos << (2k + 1) | len << (2k + 1 + lb) | strand << 63, u32 value = id.  Needs 2k + 1 + 2 lb <= 63
 // (k = 20: sequences up to 2047 letters); a quarter less traffic in every radix pass.  Bit 2k stays clear in every real tuple
@@ -89,6 +91,10 @@ struct LayoutPacked {
     __device__ static uint32_t seqOf(V v) { return v; }
     __device__ static uint32_t lenOf(uint64_t key, V v, uint64_t slot, const TupleGeom &g) { return slot < g.kmerSlots ? (uint32_t) ((key >> (g.kbits + 1 + g.lb)) & ((1ull << g.lb) - 1ull)) : g.lenArr[v]; }
     __device__ static uint32_t posOf(uint64_t key, V, uint64_t slot, const TupleGeom &g) { return slot < g.kmerSlots ? (uint32_t) ((key >> (g.kbits + 1)) & ((1ull << g.lb) - 1ull)) : 0u; }
+    __device__ static void unpackR1(uint64_t key, V, const TupleGeom &g, uint32_t &len, uint32_t &pos) {
+        const uint32_t t = (uint32_t) (key >> (g.kbits + 1)), m = (1u << g.lb) - 1u;      // 2 lb + 1 <= 63 - 2k - 1 bits are left
+        pos = t & m; len = (t >> g.lb) & m;
+    }
 };
 
 template <typename LY> struct ExtractArgs {
@@ -391,17 +397,8 @@ struct MaxU64 { __host__ __device__ unsigned long long operator()(unsigned long 
 // the radix sort is stable, so the first tuple of a k-mer run is the reference's representative (sort order
 // kmermatcher.h:76-96); only a k-mer that the representative's own sequence carries twice needs a look at the next tuples.
 // (rep, id, diagonal, strand) key of one member of a k-mer run, ~0 if the member is dropped (assignGroup :453-562)
-template <typename LY>
-__device__ __forceinline__ uint64_t groupKeyOf(const GroupParams &a, const TupleGeom &geom, uint64_t repKey, typename LY::V repVal, uint64_t repSlot, uint32_t repPos0,
-                                               bool firstRun, uint64_t key, typename LY::V v, uint64_t slot) {
-    const uint32_t repId = LY::seqOf(repVal);
-    const int queryLen = (int) LY::lenOf(repKey, repVal, repSlot, geom), repPos = (int) repPos0;
-    // the reference initialises repIsReverse = false and only updates it when a NEW run starts (:465,:535-538):
-    // the very first run of the array keeps false whatever its strand
-    const bool repIsReverse = firstRun ? false : ((repKey & BIT63) == 0);
-    const uint32_t id = LY::seqOf(v);
-    const int tLen = (int) LY::lenOf(key, v, slot, geom), tPos0 = (int) LY::posOf(key, v, slot, geom);
-    const bool targetIsReverse = (key & BIT63) == 0;
+__device__ __forceinline__ uint64_t groupKeyCore(const GroupParams &a, uint32_t repId, int queryLen, int repPos, bool repIsReverse,
+                                                 uint32_t id, int tLen, int tPos0, bool targetIsReverse) {
     int qPos, tPos; bool qRev;
     if (repIsReverse && !targetIsReverse) { qPos = repPos; tPos = tPos0; qRev = true; }
     else if (repIsReverse && targetIsReverse) { qPos = (queryLen - 1) - repPos; tPos = (tLen - 1) - tPos0; qRev = false; }
@@ -409,9 +406,18 @@ __device__ __forceinline__ uint64_t groupKeyOf(const GroupParams &a, const Tuple
     else { qPos = repPos; tPos = tPos0; qRev = false; }
     const int diagonal = (int) (short) qPos - (int) (short) tPos;
     const bool canBeExtended = diagonal < 0 || (diagonal > (queryLen - tLen));
-    const bool cbc = canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) tLen);
+    // coverage modes 0-2 with a threshold <= 0 hold for any two positive lengths: skip the divisions
+    const bool cbc = (a.covThr <= 0.0f && a.covMode <= 2 && queryLen > 0 && tLen > 0) ? true : canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) tLen);
     const bool keep = (a.onlyExtendable == 0 && cbc) || (canBeExtended && a.onlyExtendable != 0);
     return keep ? packGroupKey(a, repId, id, (int) (short) diagonal, !qRev) : ~0ull;
+}
+template <typename LY>
+__device__ __forceinline__ uint64_t groupKeyOf(const GroupParams &a, const TupleGeom &geom, uint64_t repKey, typename LY::V repVal, uint64_t repSlot, uint32_t repPos0,
+                                               bool firstRun, uint64_t key, typename LY::V v, uint64_t slot) {
+    // the reference initialises repIsReverse = false and only updates it when a NEW run starts (:465,:535-538):
+    // the very first run of the array keeps false whatever its strand
+    return groupKeyCore(a, LY::seqOf(repVal), (int) LY::lenOf(repKey, repVal, repSlot, geom), (int) repPos0, firstRun ? false : ((repKey & BIT63) == 0),
+                        LY::seqOf(v), (int) LY::lenOf(key, v, slot, geom), (int) LY::posOf(key, v, slot, geom), (key & BIT63) == 0);
 }
 
 template <typename LY>
@@ -498,21 +504,26 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
             for (int p = lane; p < gm; p += 64) {
                 const uint32_t cw = ss[p];
                 const int s0 = (int) ((cw >> WV_IDX) & 1023u), e = (int) (cw & IDXM);
-                const uint64_t key = sKey[e];
                 unsigned long long gk = ~0ull;
                 const bool hasNext = (p + 1 < gm) && !(ss[p + 1] >> 31);
-                if (key != ~0ull && (s0 != p || hasNext)) {
+                if (s0 != p || hasNext) {       // the staged range holds real tuples only (the unused slots sorted behind it)
                     const int er = (int) (ss[s0] & IDXM);
                     uint64_t bestKey = sKey[er]; const V best = sVal[er];
                     const uint32_t repId = LY::seqOf(best);
-                    uint32_t bestPos = LY::posOf(bestKey, best, r0 + er, a.geom);
+                    uint32_t repLen, bestPos;
+                    LY::unpackR1(bestKey, best, a.geom, repLen, bestPos);
                     for (int t = s0 + 1; t < gm && !(ss[t] >> 31); t++) {     // same sequence twice in the run (rare)
                         const int et = (int) (ss[t] & IDXM);
                         if (LY::seqOf(sVal[et]) != repId) break;
-                        const uint32_t pe = LY::posOf(sKey[et], sVal[et], r0 + et, a.geom);
+                        uint32_t le, pe;
+                        LY::unpackR1(sKey[et], sVal[et], a.geom, le, pe);
                         if (pe < bestPos) { bestPos = pe; bestKey = sKey[et]; }
                     }
-                    gk = groupKeyOf<LY>(a, a.geom, bestKey, best, r0 + er, bestPos, r0 + (uint64_t) (g0 + s0) == a.firstRunIdx, key, sVal[e], r0 + e);
+                    const uint64_t key = sKey[e]; const V val = sVal[e];
+                    uint32_t tLen, tPos;
+                    LY::unpackR1(key, val, a.geom, tLen, tPos);
+                    const bool firstRun = r0 + (uint64_t) (g0 + s0) == a.firstRunIdx;
+                    gk = groupKeyCore(a, repId, (int) repLen, (int) bestPos, firstRun ? false : ((bestKey & BIT63) == 0), LY::seqOf(val), (int) tLen, (int) tPos, (key & BIT63) == 0);
                 }
                 a.out[r0 + (uint64_t) (g0 + p)] = gk;
             }
