@@ -157,38 +157,51 @@ __device__ __forceinline__ void sortGroup(int gm, int lane, const MakeComp &mk, 
     else if (gm <= 256) sortGroupRegs<4, W>(gm, lane, mk, done);
     else sortGroupRegs<8, W>(gm, lane, mk, done);
 }
+// value of lane - 1 (wave_shr:1), lane 0 keeps its own
+__device__ __forceinline__ uint64_t prevLane64(uint64_t a) {
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp((int) (uint32_t) a, (int) (uint32_t) a, 0x138, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp((int) (uint32_t) (a >> 32), (int) (uint32_t) (a >> 32), 0x138, 0xF, 0xF, false);
+    return ((uint64_t) hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readLane64(uint64_t a, int l) {
+    return ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (a >> 32), l) << 32) | (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) a, l);
+}
+
 // The walk of one wave over the buckets it owns.  T fetch(g) loads the tuple at global index g into registers, put(i, t) stores
-// it in window slot i and returns its high bits, hiAt(g) returns the high bits of the tuple at g; groupFn(g0, gm) finishes the
-// group of whole buckets in the window slots [g0, g0 + gm).  w.ord[i] = ordinal of slot i's bucket in the window.
-template <typename T, typename Fetch, typename Put, typename HiAt, typename GroupFn>
-__device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, uint32_t maxBucket, const BigList &big, WaveLds &w, int lane,
-                                            const Fetch &fetch, const Put &put, const HiAt &hiAt, const GroupFn &groupFn) {
+// it in window slot i and returns its key, keyAt(g) returns the key of the tuple at g; two tuples are in the same bucket when
+// their keys agree in the bits of hiMask.  groupFn(g0, gm) finishes the group of whole buckets in the window slots
+// [g0, g0 + gm).  w.ord[i] = ordinal of slot i's bucket in the window.
+template <typename T, typename Fetch, typename Put, typename KeyAt, typename GroupFn>
+__device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, uint32_t maxBucket, uint64_t hiMask, const BigList &big, WaveLds &w, int lane,
+                                            const Fetch &fetch, const Put &put, const KeyAt &keyAt, const GroupFn &groupFn) {
     const int avail = (int) min((uint64_t) WV_WIN, n - r0);
-    uint64_t carry = r0 ? hiAt(r0 - 1) : 0ull;
+    uint64_t carry = r0 ? keyAt(r0 - 1) : 0ull;     // key in front of the row being flagged (wave-uniform)
     int ordBase = -1;
     // all loads of a batch of rows are issued before the first one is consumed
-    auto loadRows = [&](auto rowsTag, int t0) {
+    auto loadRows = [&](auto rowsTag, int t0, auto fullTag) {
         constexpr int ROWS = decltype(rowsTag)::value;
+        constexpr bool FULL = decltype(fullTag)::value;         // every slot of these rows exists
         T tup[ROWS];
 #pragma unroll
-        for (int t = 0; t < ROWS; t++) { const int i = (t0 + t) * 64 + lane; if (i < avail) tup[t] = fetch(r0 + (uint64_t) i); }
+        for (int t = 0; t < ROWS; t++) { const int i = (t0 + t) * 64 + lane; if (FULL || i < avail) tup[t] = fetch(r0 + (uint64_t) i); }
 #pragma unroll
         for (int t = 0; t < ROWS; t++) {
             const int i = (t0 + t) * 64 + lane;
-            const bool valid = i < avail;
-            const uint64_t h = valid ? put(i, tup[t]) : 0ull;
-            uint64_t up = shflUpW<uint64_t>(h, 1);
-            if (lane == 0) up = carry;
-            const bool first = valid && ((r0 + (uint64_t) i == 0) || h != up);
-            const unsigned long long m = __ballot(first);
+            const bool valid = FULL || i < avail;
+            const uint64_t k = valid ? put(i, tup[t]) : 0ull;
+            const bool differs = ((k ^ prevLane64(k)) & hiMask) != 0ull;
+            unsigned long long m = __ballot(valid && differs) & ~1ull;              // lane 0 compares with the previous row / range
+            if ((FULL || (t0 + t) * 64 < avail) && ((r0 == 0 && t0 + t == 0) || ((readLane64(k, 0) ^ carry) & hiMask) != 0ull)) m |= 1ull;
             if (lane == 0) w.bits[t0 + t] = m;
-            if (valid) w.ord[i] = (uint16_t) (ordBase + __popcll(m & ((2ull << lane) - 1ull)));
+            const int below = (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+            if (valid) w.ord[i] = (uint16_t) (ordBase + below + (int) ((m >> lane) & 1ull));
             ordBase += __popcll(m);
-            carry = ((uint64_t) (uint32_t) __shfl((int) (h >> 32), 63, 64) << 32) | (uint32_t) __shfl((int) (uint32_t) h, 63, 64);
+            carry = readLane64(k, 63);
         }
     };
     if (lane >= WV_FIRST / 64 && lane < WV_WORDS) w.bits[lane] = 0ull;
-    loadRows(std::integral_constant<int, WV_FIRST / 64>(), 0);
+    if (avail >= WV_FIRST) loadRows(std::integral_constant<int, WV_FIRST / 64>(), 0, std::true_type());
+    else loadRows(std::integral_constant<int, WV_FIRST / 64>(), 0, std::false_type());
     waveLdsSync();
     const int ownEnd = min(own, avail);
     const int sLast = lastSetIn(w, -1, ownEnd - 1);         // start of the last bucket this wave owns
@@ -197,7 +210,7 @@ __device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, ui
     int loaded = min(avail, WV_FIRST);
     int eLast = firstSetFrom(w, sLast + 1, loaded);
     if (eLast < 0 && loaded < avail) {
-        loadRows(std::integral_constant<int, WV_WORDS - WV_FIRST / 64>(), WV_FIRST / 64);
+        loadRows(std::integral_constant<int, WV_WORDS - WV_FIRST / 64>(), WV_FIRST / 64, std::false_type());
         waveLdsSync();
         loaded = avail;
         eLast = firstSetFrom(w, sLast + 1, loaded);
@@ -205,9 +218,9 @@ __device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, ui
     if (eLast < 0 && r0 + (uint64_t) avail == n) eLast = avail;         // the array ends inside the window
     int eOwn = eLast;
     if (eLast < 0) {        // the last owned bucket is longer than the window: find its end, leave it to the caller
-        const uint64_t h = hiAt(r0 + (uint64_t) sLast);
+        const uint64_t h = keyAt(r0 + (uint64_t) sLast) & hiMask;
         uint64_t lo = r0 + (uint64_t) avail, hi = n;
-        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (hiAt(mid) == h) lo = mid + 1; else hi = mid; }
+        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((keyAt(mid) & hiMask) == h) lo = mid + 1; else hi = mid; }
         if (lane == 0) big.add(r0 + (uint64_t) sLast, lo);
         eOwn = sLast;
     }
@@ -243,11 +256,11 @@ __global__ __launch_bounds__(BK_NT) void k_bucket_sort(SortArgs a) {
     uint64_t *sKey = sKeyAll[wave];
     WaveLds &w = wAll[wave];
     const uint64_t lowMask = (1ull << a.shiftHi) - 1ull;
-    const int lowW = a.shiftHi - a.ign, ign = a.ign, shiftHi = a.shiftHi;
-    waveBuckets<uint64_t>(r0, a.n, a.own, a.maxBucket, a.big, w, lane,
+    const int lowW = a.shiftHi - a.ign, ign = a.ign;
+    waveBuckets<uint64_t>(r0, a.n, a.own, a.maxBucket, ~lowMask, a.big, w, lane,
         [&](uint64_t g) { return a.in[g]; },
-        [&](int i, uint64_t k) { sKey[i] = k; return k >> shiftHi; },
-        [&](uint64_t g) { return a.in[g] >> shiftHi; },
+        [&](int i, uint64_t k) { sKey[i] = k; return k; },
+        [&](uint64_t g) { return a.in[g]; },
         [&](int g0, int gm) {
             sortGroup<uint64_t>(gm, lane,
                 [&](int i) {

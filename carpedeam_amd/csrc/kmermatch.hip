@@ -468,10 +468,10 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
     const int lowBits = a.lowBits;
     struct Tup { uint64_t k; V v; };
     constexpr uint32_t IDXM = (1u << WV_IDX) - 1u;
-    waveBuckets<Tup>(r0, a.n, a.own, a.maxBucket, a.big, w, lane,
+    waveBuckets<Tup>(r0, a.n, a.own, a.maxBucket, hmask & ~lowMask, a.big, w, lane,
         [&](uint64_t g) { Tup t; t.k = a.keys[g]; t.v = a.vals[g]; return t; },
-        [&](int i, const Tup &t) { sKey[i] = t.k; sVal[i] = t.v; return (t.k & hmask) >> lowBits; },
-        [&](uint64_t g) { return (a.keys[g] & hmask) >> lowBits; },
+        [&](int i, const Tup &t) { sKey[i] = t.k; sVal[i] = t.v; return t.k; },
+        [&](uint64_t g) { return a.keys[g]; },
         [&](int g0, int gm) {
             sortGroup<W>(gm, lane,
                 [&](int i) { return (W) ((((W) w.ord[g0 + i] << lowBits | (W) (sKey[g0 + i] & lowMask)) << WV_IDX) | (W) (g0 + i)); },
