@@ -60,12 +60,13 @@ __device__ __forceinline__ uint32_t targetBase(const CorrectArgs &a, uint32_t tw
 
 // exact arg-max in software x87, one accumulator at a time (keeps the register footprint of the callers small)
 template <typename F>
-__device__ __noinline__ uint32_t callBaseExact(const double *lt, const double *lq, const double *sLogD, F counts) {
+__device__ __noinline__ uint32_t callBaseExact(const double *lt, const double *lq, const double *sLogD, F counts, uint64_t mask) {
     X87 bestAcc = x87_zero(); int best = 0;
     for (int qq = 0; qq < 4; qq++) {
         X87 acc = x87_zero();
 #pragma unroll 1
-        for (int slot = 0; slot < 44; slot++) {
+        for (uint64_t m = mask; m; m &= m - 1) {        // ascending slots, the reference's loop order (:60-110)
+            const int slot = __ffsll((unsigned long long) m) - 1;
             const uint32_t v = counts(slot);
             const int c = (int) (v & 0xFFFFu), nr = (int) (v >> 16);
             if (c == 0) continue;
@@ -82,14 +83,19 @@ __device__ __noinline__ uint32_t callBaseExact(const double *lt, const double *l
 }
 
 // mostLikeliBaseRead (src/assembler/correction.cpp:7-123) for one query position.  counts(slot) returns
-// total | reverse << 16 for slot = tBase * 11 + damage class.  keep is set when coverage <= 1 (:418-420).
+// total | reverse << 16 for slot = tBase * 11 + damage class; mask has a bit for every slot that may be non-zero (a pile-up
+// touches a handful of the 44).  keep is set when coverage <= 1 (:418-420).
+constexpr uint64_t ALL_SLOTS = (1ull << 44) - 1ull;
 template <typename F>
 __device__ __forceinline__ uint32_t callBase(const double *sLogT, const double *sLogQ, const double *sLogD, uint32_t qb, uint32_t p, uint32_t qLen,
-                                             bool qWasExt, F counts, bool &keep) {
-    uint32_t cov[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int tb = 0; tb < 4; tb++)
-        for (int l = 0; l < 11; l++) cov[tb] += counts(tb * 11 + l) & 0xFFFFu;
+                                             bool qWasExt, F counts, uint64_t mask, bool &keep) {
+    uint64_t covPacked = 0;         // four 16-bit coverage counters, target base tb in bits 16 tb .. (at most 65535 records pile up)
+#pragma unroll 1
+    for (uint64_t m = mask; m; m &= m - 1) {
+        const int slot = __ffsll((unsigned long long) m) - 1;
+        covPacked += (uint64_t) (counts(slot) & 0xFFFFu) << (16 * (slot / 11));
+    }
+    const uint32_t cov[4] = {(uint32_t) (covPacked & 0xFFFF), (uint32_t) ((covPacked >> 16) & 0xFFFF), (uint32_t) ((covPacked >> 32) & 0xFFFF), (uint32_t) (covPacked >> 48)};
     const uint32_t total = cov[0] + cov[1] + cov[2] + cov[3];
     keep = total <= 1;
     if (keep) return qb;
@@ -111,7 +117,8 @@ __device__ __forceinline__ uint32_t callBase(const double *sLogT, const double *
     // ties (the first maximum wins) go through callBaseExact.
     double sd[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
-    for (int slot = 0; slot < 44; slot++) {
+    for (uint64_t m = mask; m; m &= m - 1) {
+        const int slot = __ffsll((unsigned long long) m) - 1;
         const uint32_t v = counts(slot);
         const int c = (int) (v & 0xFFFFu), nr = (int) (v >> 16);
         if (c == 0) continue;
@@ -133,7 +140,7 @@ __device__ __forceinline__ uint32_t callBase(const double *sLogT, const double *
     for (int qq = 0; qq < 4; qq++)
         if (qq != bestD) clear = clear && (sd[bestD] - sd[qq] > 1e-12 * (fabs(sd[bestD]) + fabs(sd[qq])) + 1e-300);
     if (clear) return (uint32_t) bestD;
-    return callBaseExact(lt, lq, sLogD, counts);
+    return callBaseExact(lt, lq, sLogD, counts, mask);
 }
 
 __global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {
                 uint32_t qb = cdm_base(a.codes, qw, p);
                 const bool qIsN = qHasN && cdm_isN(a.nmask, qw, p);
                 if (qIsN) qb = 0;
-                newCode = callBase(sLogT, sLogQ, sLogD, qb, p, qLen, qWasExt, [&](int slot) { return cnt[slot][lane]; }, keep);
+                newCode = callBase(sLogT, sLogQ, sLogD, qb, p, qLen, qWasExt, [&](int slot) { return cnt[slot][lane]; }, ALL_SLOTS, keep);
             }
             // ---- write 64 positions = 4 code words (+ N bits): lanes 0..3 assemble one word each from ballots
             const uint64_t b0 = cdm_ballot((newCode & 1u) != 0), b1 = cdm_ballot((newCode & 2u) != 0);
@@ -258,6 +265,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
     const unsigned int nItems = *nList;
     uint16_t (*cnt)[64] = sCnt[wave];
     RecInfo *recs = sRec[wave];
+#pragma unroll 4
+    for (int s = 0; s < SLOTS; s++) cnt[s][lane] = 0;       // a lane clears the slots it touched after every call
     for (unsigned int item = blockIdx.x * FAST_WAVES + wave; item < nItems; item += gridDim.x * FAST_WAVES) {
         const uint32_t q = list[item];
         const uint32_t qLen = a.len[q], qw = a.woff[q];
@@ -314,8 +323,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
         const uint32_t lastWord = (qLen + 15) / 16;
         for (uint32_t base = 0; base < qLen; base += 64) {
             const uint32_t p = base + lane;
-#pragma unroll 4
-            for (int s = 0; s < SLOTS; s++) cnt[s][lane] = 0;
+            uint64_t touched = 0;       // slots of this lane's column that are non-zero
             for (int r = 0; r < nAcc; r++) {
                 const RecInfo ri = recs[r];
                 if ((uint32_t) ri.qe < base || (uint32_t) ri.qs >= base + 64) continue;   // wave uniform
@@ -323,7 +331,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
                     const uint32_t tpos = (uint32_t) ri.ds + (p - (uint32_t) ri.qs);
                     const uint32_t tb = targetBase(a, ri.tw, ri.tLen, (ri.flags & 2u) != 0, (ri.flags & 1u) != 0, tpos);
                     const uint32_t cls = tpos < 5 ? tpos : (tpos >= ri.tLen - 5 ? 6 + (tpos - (ri.tLen - 5)) : 5);
-                    cnt[tb * 11 + cls][lane] += (uint16_t) (1u + ((ri.flags & 1u) ? 0x100u : 0u));
+                    const uint32_t slot = tb * 11 + cls;
+                    cnt[slot][lane] += (uint16_t) (1u + ((ri.flags & 1u) ? 0x100u : 0u));
+                    touched |= 1ull << slot;
                 }
             }
             uint32_t newCode = 0; bool keep = true;
@@ -332,8 +342,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
                 const bool qIsN = qHasN && cdm_isN(a.nmask, qw, p);
                 if (qIsN) qb = 0;
                 newCode = callBase(sLogT, sLogQ, sLogD, qb, p, qLen, qWasExt,
-                                   [&](int slot) { const uint32_t v = cnt[slot][lane]; return (v & 0xFFu) | ((v >> 8) << 16); }, keep);
+                                   [&](int slot) { const uint32_t v = cnt[slot][lane]; return (v & 0xFFu) | ((v >> 8) << 16); }, touched, keep);
             }
+            for (uint64_t m = touched; m; m &= m - 1) cnt[__ffsll((unsigned long long) m) - 1][lane] = 0;
             const uint64_t b0 = cdm_ballot((newCode & 1u) != 0), b1 = cdm_ballot((newCode & 2u) != 0);
             uint64_t nb = 0;
             if (qHasN) nb = cdm_ballot(p < qLen && keep && cdm_isN(a.nmask, qw, p));
@@ -371,7 +382,7 @@ __global__ void k_debug_call(const DamageLut *lut, const uint32_t *vec, uint32_t
     if (i >= n) return;
     const uint32_t *v = vec + (size_t) i * 48;
     bool keep;
-    out[i] = (uint8_t) callBase(sLogT, sLogQ, sLogD, v[0], v[1], v[2], v[3] != 0, [&](int slot) { return v[4 + slot]; }, keep);
+    out[i] = (uint8_t) callBase(sLogT, sLogQ, sLogD, v[0], v[1], v[2], v[3] != 0, [&](int slot) { return v[4 + slot]; }, ALL_SLOTS, keep);
 }
 
 }  // namespace
