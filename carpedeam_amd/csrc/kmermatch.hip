@@ -142,19 +142,29 @@ __device__ __forceinline__ uint64_t groupsReversed(uint64_t x, int k) {
     x = __builtin_bswap64(x);
     return x >> (64 - 2 * k);
 }
-__device__ __forceinline__ uint64_t pow31(uint32_t e) { uint64_t r = 1, b = 31; while (e) { if (e & 1u) r *= b; b *= b; e >>= 1; } return r; }
-// Util::hash over the numeric sequence (M/commons/Util.h:338-346): sum c_i * 31^(L-1-i); lanes take contiguous chunks
-__device__ __forceinline__ uint64_t waveSeqHash(const uint32_t *codes, const uint32_t *nmask, uint32_t w0, uint32_t L, bool hasN, int lane) {
-    const uint32_t cs = (L + 63) / 64, b0 = min(L, lane * cs), b1 = min(L, b0 + cs);
+// The whole-sequence tuple of every sequence (kmermatcher.cpp:244-267): Util::hash over the numeric sequence
+// (M/commons/Util.h:338-346, h = h * 31 + c) then XXH64 (:135-138).  One thread per sequence: a serial Horner walk over packed
+// words costs a wave a few instructions per sequence, where the wave-per-sequence extraction kernels spent hundreds on it.
+template <typename LY>
+__global__ __launch_bounds__(256) void k_seq_hash(ExtractArgs<LY> a) {
+    const uint32_t seq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= a.n) return;
+    const uint32_t L = a.len[seq], w0 = a.woff[seq];
     uint64_t h = 0;
-    for (uint32_t i = b0; i < b1; i++) {
-        uint32_t c = cdm_base(codes, w0, i); c ^= c >> 1;
-        if (hasN && cdm_isN(nmask, w0, i)) c = 4;
-        h = h * 31 + c;
+    if (a.hasN[seq]) {
+        for (uint32_t i = 0; i < L; i++) {
+            uint32_t c = cdm_base(a.codes, w0, i); c ^= c >> 1;
+            if (cdm_isN(a.nmask, w0, i)) c = 4;
+            h = h * 31 + c;
+        }
+    } else {
+        for (uint32_t i = 0; i < L; i += 16) {
+            uint32_t word = a.codes[w0 + (i >> 4)];
+            const uint32_t nb = min(16u, L - i);
+            for (uint32_t j = 0; j < nb; j++) { uint32_t c = word & 3u; c ^= c >> 1; h = h * 31 + c; word >>= 2; }
+        }
     }
-    h *= pow31(L - b1);
-    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor((unsigned long long) h, o, 64);
-    return h;
+    putSeqHashTuple(a, seq, L, a.slotOff[seq], h);
 }
 
 constexpr int FAST_WAVES = 4, FAST_TABLE = 1024, FAST_CAP = 448;
@@ -209,8 +219,6 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
             if (real) LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom);
             else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
         }
-        const uint64_t h = waveSeqHash(a.codes, a.nmask, w0, L, hasN, lane);
-        if (lane == 0) putSeqHashTuple(a, seq, L, base, h);
         if (__ballot(dup) != 0ull && lane == 0) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;   // rewritten by k_extract
         __builtin_amdgcn_wave_barrier();
     }
@@ -327,18 +335,7 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
         // ---- emit: 1 whole-sequence tuple (:244-267) + the selected k-mers
         {
             const uint64_t base = a.slotOff[seq];
-            if (tid == 0) {
-                // Util::hash over the numeric sequence (M/commons/Util.h:338-346) then XXH64 (kmermatcher.cpp:135-138)
-                uint64_t h = 0;
-                for (uint32_t i = 0; i < L; i++) {
-                    uint32_t c = cdm_base(a.codes, w0, i);
-                    c ^= c >> 1;
-                    if (hasN && cdm_isN(a.nmask, w0, i)) c = 4;
-                    h = h * 31 + c;
-                }
-                putSeqHashTuple(a, seq, L, base, h);
-                sCursor = 0;
-            }
+            if (tid == 0) sCursor = 0;       // (the whole-sequence tuple :244-267 is written by k_seq_hash)
             __syncthreads();
             // selected tuples first (their order within the sequence does not matter: a global sort follows), then sentinels
             for (uint32_t i = tid; i < n; i += NT) {
@@ -760,6 +757,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     ea.keys = k0.p; ea.vals = v0.p; ea.slotOff = slotOff.p; ea.slowShort = listShort.p; ea.slowLong = listLong.p; ea.slowCnt = cls.p; ea.n = n;
     ea.list = nullptr; ea.nList = 0; ea.hashBase = kmerSlots; ea.rankOf = rankOf.p;
     hipEventRecord(ctx->ev0, s);
+    hipLaunchKernelGGL(k_seq_hash<LY>, dim3((n + 255) / 256), dim3(256), 0, s, ea);
     hipLaunchKernelGGL(k_extract_fast<LY>, dim3(std::min<uint32_t>((n + FAST_WAVES - 1) / FAST_WAVES, ctx->cuCount * 16)), dim3(64 * FAST_WAVES), 0, s, ea);
     unsigned int hcls[2] = {0, 0};
     hipMemcpyAsync(hcls, cls.p, 8, hipMemcpyDeviceToHost, s);
