@@ -133,7 +133,7 @@ __device__ __forceinline__ uint64_t kmerWindow(const uint32_t *__restrict__ code
     uint64_t x = (a | (b << 32)) >> sh;
     if (sh) x |= c << (64 - sh);
     x ^= (x >> 1) & 0x5555555555555555ull;                     // A,C,G,T -> A,C,T,G
-    return x & ((k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1ull));
+    return x;                                                   // 32 bases from pos on; callers mask what they need
 }
 // Indexer::computeKmerIdx order (first base most significant) from the window: reverse the 2-bit groups
 __device__ __forceinline__ uint64_t groupsReversed(uint64_t x, int k) {
@@ -194,18 +194,14 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
         const uint32_t lastWord = (L + 15) / 16 - 1;
         bool dup = false;
-        for (uint32_t pos = lane; pos < nPos; pos += 64) {
-            const uint64_t w = kmerWindow(a.codes, w0, pos, lastWord, k);
-            bool x = false;
-            if (hasN) for (int j = 0; j < k; j++) x |= cdm_isN(a.nmask, w0, pos + j) != 0;
-            const uint64_t idx = groupsReversed(w, k);
-            const uint64_t rc = (w ^ 0xAAAAAAAAAAAAAAAAull) & ((1ull << (2 * k)) - 1ull);   // Util::revComplement(idx): window order, complemented
-            bool real = false; uint64_t km = 0; uint32_t p = 0; bool pickRev = false;
+        const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+        // canonical k-mer of the window w (idx = the same k-mer in Indexer order) at position pos: insert, store
+        auto emit = [&](uint64_t w, uint64_t idx, uint32_t pos, bool x) {
+            const uint64_t rc = (w ^ 0xAAAAAAAAAAAAAAAAull) & kmask;     // Util::revComplement(idx): window order, complemented
             if (!x && rc != idx) {
-                real = true;
-                pickRev = rc < idx;
-                km = pickRev ? rc : idx;
-                p = pickRev ? (L - pos - k) : pos;
+                const bool pickRev = rc < idx;
+                const uint64_t km = pickRev ? rc : idx;
+                const uint32_t p = pickRev ? (L - pos - k) : pos;
                 if (a.ignoreMultiKmer) {
                     uint32_t h = (uint32_t) ((km * 0x9E3779B97F4A7C15ull) >> 40) & tmask;
                     while (true) {
@@ -215,9 +211,28 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
                         h = (h + 1) & tmask;
                     }
                 }
+                LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom);
+            } else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
+        };
+        if (hasN) {
+            for (uint32_t pos = lane; pos < nPos; pos += 64) {
+                const uint64_t w = kmerWindow(a.codes, w0, pos, lastWord, k) & kmask;
+                bool x = false;
+                for (int j = 0; j < k; j++) x |= cdm_isN(a.nmask, w0, pos + j) != 0;
+                emit(w, groupsReversed(w, k), pos, x);
             }
-            if (real) LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom);
-            else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
+        } else {
+            // two consecutive positions per lane: the second window is the first one shifted by a base, and its Indexer-order
+            // k-mer follows from the first one's without a second bit reversal
+            for (uint32_t pos = 2 * lane; pos < nPos; pos += 128) {
+                const uint64_t xr = kmerWindow(a.codes, w0, pos, lastWord, k);      // k + 1 bases
+                const uint64_t wA = xr & kmask, idxA = groupsReversed(wA, k);
+                emit(wA, idxA, pos, false);
+                if (pos + 1 < nPos) {
+                    const uint64_t wB = (xr >> 2) & kmask, idxB = ((idxA << 2) & kmask) | ((xr >> (2 * k)) & 3ull);
+                    emit(wB, idxB, pos + 1, false);
+                }
+            }
         }
         if (__ballot(dup) != 0ull && lane == 0) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;   // rewritten by k_extract
         __builtin_amdgcn_wave_barrier();
