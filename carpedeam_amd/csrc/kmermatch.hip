@@ -569,7 +569,7 @@ __device__ __forceinline__ HitRec voteSegment(const VoteArgs &a, uint64_t i, uin
     const uint64_t key = a.keys[i];
     // the writer scans while the TARGET id stays the same, also across a change of representative (:875-887)
     uint32_t prevDiag = (uint32_t) ((key >> 1) & diagMask), diagonal = prevDiag;
-    unsigned long long maxDiag = 0, diagCnt = 0, top = 0; int bestRev = (key & 1ull) ? 0 : 1;
+    uint32_t maxDiag = 0, diagCnt = 0, top = 0; int bestRev = (key & 1ull) ? 0 : 1;
     for (uint64_t kk = i; kk < a.n; kk++) {
         const uint64_t k2 = a.keys[kk];
         if ((uint32_t) ((k2 >> (a.diagBits + 1)) & idMask) != target) break;
@@ -604,7 +604,7 @@ __device__ __forceinline__ HitRec voteSegmentTile(const VoteArgs &a, const uint6
     const uint64_t idMask = (1ull << a.idBits) - 1, diagMask = (1ull << a.diagBits) - 1;
     const uint64_t key = sKeys[padIdx(li)];
     uint32_t prevDiag = (uint32_t) ((key >> 1) & diagMask), diagonal = prevDiag;
-    unsigned long long maxDiag = 0, diagCnt = 0, top = 0; int bestRev = (key & 1ull) ? 0 : 1;
+    uint32_t maxDiag = 0, diagCnt = 0, top = 0; int bestRev = (key & 1ull) ? 0 : 1;
     // two separate loops so that the common in-tile walk issues LDS reads only
     const int tileEnd = (int) min((uint64_t) CP_TILE, a.n - base);
     int i = li; bool done = false;
