@@ -21,8 +21,8 @@
 namespace {
 
 struct CorrectArgs {
-    const uint32_t *woff, *len, *codes, *nmask;
-    const uint8_t *ext, *hasN;
+    MetaWoff woff; MetaLen len; MetaHasN hasN; MetaExt ext;      // per-sequence metadata, one record per sequence
+    const uint32_t *codes, *nmask;
     const uint64_t *aoff;
     const AlnRec *rec;
     const uint32_t *active;
@@ -414,8 +414,10 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
     CDM_HIP(hipMemcpyAsync(out->nmask, db->nmask, ((db->words * 16 + 31) / 32) * 4, hipMemcpyDeviceToDevice, s));
     CDM_HIP(hipMemsetAsync(counters.p, 0, 16, s));   // [0] queries for the general kernel, [1] error flag, [2] queries for the fast kernel
     hipLaunchKernelGGL(k_mark_active, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, n, active.p, activeFast.p, counters.p);
+    DevBuf<SeqMeta> meta;
+    if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
     CorrectArgs a;
-    a.woff = db->woff; a.len = db->len; a.codes = db->codes; a.nmask = db->nmask; a.ext = db->ext; a.hasN = db->hasN;
+    a.woff.m = a.len.m = a.hasN.m = a.ext.m = meta.p; a.codes = db->codes; a.nmask = db->nmask;
     a.aoff = alns->off; a.rec = alns->rec; a.active = active.p; a.nActive = counters.p; a.accept = accept.p; a.errFlag = counters.p + 1;
     a.outCodes = out->codes; a.outNmask = out->nmask; a.lut = ctx->lutDev; a.seqIdThr = par->seq_id_thr; a.corrRy = par->corr_reads_ry_seq_id;
     const int blocks = ctx->cuCount * 8;

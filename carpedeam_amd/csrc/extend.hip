@@ -35,8 +35,8 @@ struct Cand {
 };
 
 struct ExtArgs {
-    const uint32_t *woff, *len, *key, *codes, *nmask;
-    const uint8_t *ext, *hasN;
+    MetaWoff woff; MetaLen len; MetaHasN hasN; MetaExt ext;      // per-sequence metadata, one record per sequence
+    const uint32_t *key, *codes, *nmask;
     const uint64_t *aoff;
     const AlnRec *rec;
     const uint32_t *active; const unsigned int *nActive;
@@ -425,8 +425,10 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     unsigned int hAct = 0;
     hipMemcpyAsync(&hAct, nActive.p, 4, hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_extend: setup failed"); return CDM_ERR_HIP; }
+    DevBuf<SeqMeta> meta;
+    if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
     ExtArgs A;
-    A.woff = db->woff; A.len = db->len; A.key = db->key; A.codes = db->codes; A.nmask = db->nmask; A.ext = db->ext; A.hasN = db->hasN;
+    A.woff.m = A.len.m = A.hasN.m = A.ext.m = meta.p; A.key = db->key; A.codes = db->codes; A.nmask = db->nmask;
     A.aoff = alns->off; A.rec = alns->rec; A.active = active.p; A.nActive = nActive.p; A.lut = ctx->lutDev; A.cand = cand.p; A.lists = lists.p;
     A.newLen = newLen.p; A.nLeft = nLeft.p; A.nRight = nRight.p; A.leftTotal = leftTotal.p; A.scores = scores ? dScores.p : nullptr;
     A.seqIdThr = par->seq_id_thr; A.rySeqIdThr = par->ry_seq_id_thr; A.likelihoodThr = par->likelihood_threshold;

@@ -19,8 +19,8 @@
 namespace {
 
 struct RescoreArgs {
-    const uint32_t *woff, *len, *codes, *nmask;
-    const uint8_t *hasN;
+    MetaWoff woff; MetaLen len; MetaHasN hasN;      // per-sequence metadata, one record per sequence
+    const uint32_t *codes, *nmask;
     const uint64_t *hoff;
     const HitRec *hit;
     const int32_t *minScore;   // [maxLen+1]
@@ -186,8 +186,10 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     }
     CDM_HIP(hipMemcpyAsync(dMin.p, minScore.data(), (size_t) (db->maxLen + 1) * 4, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_expand, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, n, owner.p);
+    DevBuf<SeqMeta> meta;
+    if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
     RescoreArgs a;
-    a.woff = db->woff; a.len = db->len; a.codes = db->codes; a.nmask = db->nmask; a.hasN = db->hasN; a.hoff = hits->off; a.hit = hits->rec;
+    a.woff.m = a.len.m = a.hasN.m = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.hoff = hits->off; a.hit = hits->rec;
     a.minScore = dMin.p; a.nHits = nHits; a.n = n; a.seqIdThr = par->seq_id_thr; a.covThr = par->cov_thr; a.covMode = par->cov_mode;
     a.minAlnLen = par->min_aln_len; a.tmp = tmp.p; a.valid = valid.p;
     hipEventRecord(ctx->ev0, s);
