@@ -118,6 +118,42 @@ def test_kmermatch_bucket_sort_paths_agree(ctx, oracle_bin, tmp_path, monkeypatc
             monkeypatch.delenv(k)
 
 
+def test_kmermatch_variants_identical_at_scale(ctx, monkeypatch):
+    """1 M reads at 20x coverage (k-mer buckets of a few dozen tuples, as in the bench): the hybrid sorts, the all-global
+    radix sort and the two tuple layouts return identical hit arrays."""
+    db = ctx.synth(1_000_000, 100, 100, 5)
+    ref = None
+    for env in ({}, {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_KMER_SORT": "lsd"}, {"CDM_BUCKET_CAP": "48"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        off, rec = ctx.kmermatch(db).download()
+        for k in env:
+            monkeypatch.delenv(k)
+        if ref is None:
+            ref = (off, rec)
+            assert len(rec) > 3_000_000
+        else:
+            assert np.array_equal(off, ref[0]) and np.array_equal(rec, ref[1]), env
+
+
+def test_kmermatch_high_multiplicity_buckets(ctx, oracle_bin, tmp_path):
+    """Hundreds of identical / overlapping reads: k-mer buckets of 257..512 tuples (the 8-words-per-lane network), buckets
+    beyond 512 (gathered and sorted globally) and representatives with tens of thousands of group tuples, all at the default
+    capacities."""
+    from carpedeam_amd import synth
+    rng = np.random.default_rng(23)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    region = letters[rng.integers(0, 4, 400)].tobytes().decode()
+    seqs = synth.generate_strings(2500, seed=12, mixed=(60, 140))
+    seqs += [region[0:100]] * 400 + [region[30:130]] * 300 + [region[150:250]] * 700 + [region[160:280]] * 90
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
+    assert not diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), strip_ext(mmdb.read_db(t("pref"))))
+
+
 def test_kmermatch_rejects_what_it_does_not_implement(ctx):
     with pytest.raises(capi.CdmError):
         kmermatch_text(ctx, {0: (b"ACGT" * 2000 + b"\n", 0), 1: (b"ACGTTGCA" * 1000 + b"\n", 0)})   # >= 4096 k-mer positions
