@@ -1,14 +1,16 @@
 // kmermatcher (linclust-style k-mer matching) on the device, single-split semantics.
 //
 // Replaces lib/mmseqs/src/linclust/kmermatcher.cpp doComputation (:391-451) and the result writer (:815-930, :717-729):
-//   K1 k_extract      fillKmerPositionArray :77-388  per sequence: canonical k-mers, XXH64 16-bit min-hash, per-sequence
-//                     ordering by (hash, k-mer, pos) for the repeated-k-mer skipping and the bottom-m selection, + the
-//                     whole-sequence hash tuple
-//   K2 sort 1         :412   stable LSD radix sort on the 63-bit k-mer (rocPRIM), strand bit 63 carried along
-//   K3 k_groups       assignGroup :453-562  first sequence of every k-mer run by (length desc, id, pos) is the
-//                     representative; members become (rep, id, diagonal, strand); singletons dropped
-//   K2 sort 2         :431   stable radix sort on (rep, id, diagonal) packed into one 64-bit key
-//   K4 k_vote         writeKmerMatcherResult :815-930  per (rep, target): shared k-mer count, most frequent diagonal
+//   K1 k_seq_hash, k_extract_fast, k_extract   fillKmerPositionArray :77-388  per sequence: canonical k-mers, XXH64 16-bit
+//                     min-hash, per-sequence ordering by (hash, k-mer, pos) for the repeated-k-mer skipping and the bottom-m
+//                     selection, + the whole-sequence hash tuple
+//   K2 sort 1         :412   stable sort on the k-mer: the top 32 bits by rocPRIM radix passes, the low bits per bucket on chip
+//   K3 k_bucket_groups (k_groups)   assignGroup :453-562  first sequence of every k-mer run by (length desc, id, pos) is the
+//                     representative; members become (rep, id, diagonal, strand); singletons dropped.  Fused with the
+//                     on-chip part of sort 1 (bucket.h)
+//   K2 sort 2         :431   stable sort on (rep, id, diagonal) packed into one 64-bit key: radix passes on the top 32 bits,
+//                     k_bucket_sort on the rest
+//   K4 k_seg_count/place   writeKmerMatcherResult :815-930  per (rep, target): shared k-mer count, most frequent diagonal
 //                     (last maximum wins), strand of that diagonal's last tuple; every sequence gets a record that starts
 //                     with its self hit (fill-in :717-729)
 // Quirks kept on purpose (they are observable in the prefilter DB): the repeated-k-mer skip that processes the element
@@ -562,27 +564,6 @@ __device__ __forceinline__ bool validStart(const VoteArgs &a, uint64_t i, uint32
     if (i > 0 && (a.keys[i - 1] >> (a.diagBits + 1)) == seg) return false;
     target = (uint32_t) (seg & ((1ull << a.idBits) - 1)); rep = (uint32_t) (seg >> a.idBits);
     return target != rep;   // self tuples give no hit (:898-903)
-}
-// writeKmerMatcherResult's inner loop for the segment that starts at i (:867-910)
-__device__ __forceinline__ HitRec voteSegment(const VoteArgs &a, uint64_t i, uint32_t target) {
-    const uint64_t idMask = (1ull << a.idBits) - 1, diagMask = (1ull << a.diagBits) - 1;
-    const uint64_t key = a.keys[i];
-    // the writer scans while the TARGET id stays the same, also across a change of representative (:875-887)
-    uint32_t prevDiag = (uint32_t) ((key >> 1) & diagMask), diagonal = prevDiag;
-    uint32_t maxDiag = 0, diagCnt = 0, top = 0; int bestRev = (key & 1ull) ? 0 : 1;
-    for (uint64_t kk = i; kk < a.n; kk++) {
-        const uint64_t k2 = a.keys[kk];
-        if ((uint32_t) ((k2 >> (a.diagBits + 1)) & idMask) != target) break;
-        const uint32_t d = (uint32_t) ((k2 >> 1) & diagMask);
-        if (prevDiag == d) diagCnt++; else diagCnt = 1;
-        if (diagCnt >= maxDiag) { diagonal = d; maxDiag = diagCnt; bestRev = (k2 & 1ull) ? 0 : 1; }
-        prevDiag = d; top++;
-    }
-    HitRec h;
-    h.target = target;
-    h.score = bestRev ? -(int) top : (int) top;
-    h.diagonal = (int) (short) ((int) diagonal - a.diagBias);
-    return h;
 }
 // tiles of 4096 tuples: number of hit-producing segment starts per tile and per representative (coalesced, order free)
 __global__ __launch_bounds__(256) void k_seg_count(VoteArgs a, unsigned long long *__restrict__ tileCnt) {
