@@ -74,6 +74,18 @@ struct VQuery {
         code = cdm_base(A.codes, w, tp);
         isN = A.hasN[t] && cdm_isN(A.nmask, w, tp);
     }
+    // source (sequence t, position tp) of position p and the number of positions from p on that come from the same piece
+    __device__ void spanAt(uint32_t p, uint32_t &t, uint32_t &tp, uint32_t &run) const {
+        t = q; tp = 0; run = 1;
+        if (p < leftTotal) {
+            uint32_t acc = 0;
+            for (int i = (int) nL - 1; i >= 0; i--) { const Cand &c = cand[leftL[i]]; if (p < acc + c.pieceLen) { t = c.target; tp = c.pieceStart + (p - acc); run = acc + c.pieceLen - p; break; } acc += c.pieceLen; }
+        } else if (p < leftTotal + qLen0) { t = q; tp = p - leftTotal; run = leftTotal + qLen0 - p; }
+        else {
+            uint32_t acc = leftTotal + qLen0;
+            for (uint32_t i = 0; i < nR; i++) { const Cand &c = cand[rightL[i]]; if (p < acc + c.pieceLen) { t = c.target; tp = c.pieceStart + (p - acc); run = acc + c.pieceLen - p; break; } acc += c.pieceLen; }
+        }
+    }
 };
 
 __device__ __forceinline__ void targetBaseAt(const ExtArgs &A, uint32_t t, uint32_t p, uint32_t &code, bool &isN) {
@@ -386,8 +398,12 @@ __global__ __launch_bounds__(256) void k_write(ExtArgs A, const uint32_t *__rest
                                                uint32_t *__restrict__ oCodes, uint32_t *__restrict__ oNmask, uint8_t *__restrict__ oHasN) {
     const uint64_t gw = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (gw >= words) return;
+    // owner of word gw = last sequence whose first word is <= gw: one binary search per wave (for its first word, the same
+    // loads in every lane), then a short walk forward per lane
+    const uint64_t gw0 = gw - (threadIdx.x & 63);
     uint64_t lo = 0, hi = n;
-    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (oWoff[mid] <= gw) lo = mid; else hi = mid; }
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (oWoff[mid] <= gw0) lo = mid; else hi = mid; }
+    while (lo + 1 < n && oWoff[lo + 1] <= gw) lo++;
     const uint32_t q = (uint32_t) lo, w = (uint32_t) (gw - oWoff[q]), L = oLen[q];
     const uint32_t cnt = min(16u, L - min(L, w * 16u));
     uint32_t code = 0, nb = 0;
@@ -398,7 +414,22 @@ __global__ __launch_bounds__(256) void k_write(ExtArgs A, const uint32_t *__rest
         const uint64_t r0 = A.aoff[q]; const uint32_t nRec = (uint32_t) (A.aoff[q + 1] - r0);
         VQuery Q; Q.a = &A; Q.q = q; Q.qLen0 = A.len[q]; Q.qw = A.woff[q]; Q.cand = A.cand + r0;
         Q.leftL = A.lists + 4 * r0 + 2 * (uint64_t) nRec; Q.rightL = Q.leftL + nRec; Q.nL = A.nLeft[q]; Q.nR = A.nRight[q]; Q.leftTotal = A.leftTotal[q]; Q.total = L; Q.plain = false;
-        for (uint32_t j = 0; j < cnt; j++) { uint32_t c; bool isN; Q.baseAt(w * 16 + j, c, isN); if (isN) { nb |= 1u << j; c = 0; } code |= c << (2 * j); }
+        for (uint32_t j = 0; j < cnt;) {       // piece by piece: a word rarely spans more than two
+            uint32_t t, tp, run;
+            Q.spanAt(w * 16 + j, t, tp, run);
+            const uint32_t m = min(run, cnt - j), tw = A.woff[t];
+            if (!A.hasN[t]) {
+                const uint32_t bits = cdm_window16(A.codes, tw, tp, (A.len[t] + 15) / 16 - 1);
+                code |= ((m < 16) ? (bits & ((1u << (2 * m)) - 1u)) : bits) << (2 * j);
+            } else {
+                for (uint32_t i = 0; i < m; i++) {
+                    uint32_t c = cdm_base(A.codes, tw, tp + i);
+                    if (cdm_isN(A.nmask, tw, tp + i)) { nb |= 1u << (j + i); c = 0; }
+                    code |= c << (2 * (j + i));
+                }
+            }
+            j += m;
+        }
     }
     oCodes[gw] = code;
     reinterpret_cast<uint16_t *>(oNmask)[gw] = (uint16_t) nb;
