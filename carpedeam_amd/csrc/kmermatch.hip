@@ -375,7 +375,17 @@ struct GroupParams {
     uint32_t idBits, diagBits; int diagBias;
     uint64_t first;             // the kernel covers the tuples [first, n)
     uint64_t firstRunIdx;       // index of the array's very first tuple in this view (0; ~0 if the view does not hold it)
+    unsigned long long *stat;   // [0] += members kept, [1] = max group key kept (the last tuple of the (rep, id, diagonal) order)
 };
+// one atomic pair per wave for the kept-member statistics (every lane of the wave must call)
+__device__ __forceinline__ void waveGroupStats(unsigned long long *stat, uint32_t cnt, unsigned long long mx) {
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += (uint32_t) __shfl_xor((int) cnt, o, 64);
+        const unsigned long long other = ((unsigned long long) (uint32_t) __shfl_xor((int) (mx >> 32), o, 64) << 32) | (uint32_t) __shfl_xor((int) (uint32_t) mx, o, 64);
+        mx = other > mx ? other : mx;
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) { atomicAdd(stat, (unsigned long long) cnt); atomicMax(stat + 1, mx); }
+}
 template <typename LY> struct GroupArgs : GroupParams {
     const uint64_t *keys; const typename LY::V *vals;   // sorted by k-mer
     TupleGeom geom;
@@ -437,22 +447,28 @@ __device__ __forceinline__ uint64_t groupKeyOf(const GroupParams &a, const Tuple
 template <typename LY>
 __global__ __launch_bounds__(256) void k_groups(GroupArgs<LY> a, unsigned long long *__restrict__ startIo /* in: run start, out: packed key */) {
     const uint64_t i = a.first + (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const uint64_t key = a.keys[i];
-    if (key == ~0ull) { startIo[i] = ~0ull; return; }          // unused slot
-    const uint64_t st = startIo[i];
-    const uint64_t km = LY::kmerOf(key, i, a.geom);
-    const bool hasNext = (i + 1 < a.n) && a.keys[i + 1] != ~0ull && LY::kmerOf(a.keys[i + 1], i + 1, a.geom) == km;
-    if (st == i && !hasNext) { startIo[i] = ~0ull; return; }   // singleton (:479)
-    uint64_t bestKey = a.keys[st]; const typename LY::V best = a.vals[st];
-    const uint32_t repId = LY::seqOf(best);
-    uint32_t bestPos = LY::posOf(bestKey, best, st, a.geom);
-    // same sequence twice in the run: the smaller position wins (rare)
-    for (uint64_t e = st + 1; e < a.n && a.keys[e] != ~0ull && LY::kmerOf(a.keys[e], e, a.geom) == km && LY::seqOf(a.vals[e]) == repId; e++) {
-        const uint32_t pe = LY::posOf(a.keys[e], a.vals[e], e, a.geom);
-        if (pe < bestPos) { bestPos = pe; bestKey = a.keys[e]; }
+    unsigned long long gk = ~0ull;
+    if (i < a.n) {
+        const uint64_t key = a.keys[i];
+        if (key != ~0ull) {                                        // (an unused slot has no group key)
+            const uint64_t st = startIo[i];
+            const uint64_t km = LY::kmerOf(key, i, a.geom);
+            const bool hasNext = (i + 1 < a.n) && a.keys[i + 1] != ~0ull && LY::kmerOf(a.keys[i + 1], i + 1, a.geom) == km;
+            if (st != i || hasNext) {                              // singletons are dropped (:479)
+                uint64_t bestKey = a.keys[st]; const typename LY::V best = a.vals[st];
+                const uint32_t repId = LY::seqOf(best);
+                uint32_t bestPos = LY::posOf(bestKey, best, st, a.geom);
+                // same sequence twice in the run: the smaller position wins (rare)
+                for (uint64_t e = st + 1; e < a.n && a.keys[e] != ~0ull && LY::kmerOf(a.keys[e], e, a.geom) == km && LY::seqOf(a.vals[e]) == repId; e++) {
+                    const uint32_t pe = LY::posOf(a.keys[e], a.vals[e], e, a.geom);
+                    if (pe < bestPos) { bestPos = pe; bestKey = a.keys[e]; }
+                }
+                gk = groupKeyOf<LY>(a, a.geom, bestKey, best, st, bestPos, st == a.firstRunIdx, key, a.vals[i], i);
+            }
+        }
+        startIo[i] = gk;
     }
-    startIo[i] = groupKeyOf<LY>(a, a.geom, bestKey, best, st, bestPos, st == a.firstRunIdx, key, a.vals[i], i);
+    waveGroupStats(a.stat, gk != ~0ull ? 1u : 0u, gk != ~0ull ? gk : 0ull);
 }
 
 // K2b + K3 fused for region 1 when only the top bits of the k-mer went through the global radix passes (bucket.h): a wave
@@ -475,13 +491,14 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
     __shared__ WaveLds wAll[BK_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t r0 = ((uint64_t) blockIdx.x * BK_WAVES + wave) * (uint64_t) a.own;
-    if (r0 >= a.n) return;
+    if (r0 >= a.n) return;      // (whole wave)
     uint64_t *sKey = sKeyAll[wave]; V *sVal = sValAll[wave]; uint32_t *ss = sSAll[wave];
     WaveLds &w = wAll[wave];
     const uint64_t hmask = (2ull << a.geom.kbits) - 1ull, lowMask = (1ull << a.lowBits) - 1ull;   // k-mer bits + the unused-slot bit
     const int lowBits = a.lowBits;
     struct Tup { uint64_t k; V v; };
     constexpr uint32_t IDXM = (1u << WV_IDX) - 1u;
+    uint32_t keptCnt = 0; unsigned long long keptMax = 0;       // per lane, reduced once per wave
     waveBuckets<Tup>(r0, a.n, a.own, a.maxBucket, hmask & ~lowMask, a.big, w, lane,
         [&](uint64_t g) { Tup t; t.k = a.keys[g]; t.v = a.vals[g]; return t; },
         [&](int i, const Tup &t) { sKey[i] = t.k; sVal[i] = t.v; return t.k; },
@@ -540,9 +557,11 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
                     gk = groupKeyCore(a, repId, (int) repLen, (int) bestPos, firstRun ? false : ((bestKey & BIT63) == 0), LY::seqOf(val), (int) tLen, (int) tPos, (key & BIT63) == 0);
                 }
                 a.out[r0 + (uint64_t) (g0 + p)] = gk;
+                if (gk != ~0ull) { keptCnt++; keptMax = gk > keptMax ? gk : keptMax; }
             }
             waveLdsSync();      // ss is reused by the next group
         });
+    waveGroupStats(a.stat, keptCnt, keptMax);
 }
 
 // tiles of the vote kernels: 4096 keys (256 threads x 16 consecutive items)
@@ -557,7 +576,14 @@ struct VoteArgs {
     uint64_t n;
     uint32_t idBits, diagBits; int diagBias;
     unsigned long long *perRep;  // [nSeq] number of hits per representative
+    // The reference's per-target scan does not stop at the end of the sorted group tuples: it runs on into the tuples that
+    // assignGroup's in-place compaction left behind (kmermatcher.cpp:875-887 reads hashSeqPair[kmerPos + kmerOffset].id up to
+    // the end of the array), i.e. the k-mer-ordered tuples from index nGroup on, while their sequence id equals the target.
+    // stale[0] = number of such tuples for the last target, stale[1..] their positions (k_stale_tail); their k-mer field is
+    // UINT64_MAX by then, so they count as forward.
+    const uint32_t *stale; uint32_t staleTarget;
 };
+constexpr int STALE_MAX = 62;
 // a (rep, target != rep) segment starts at i
 __device__ __forceinline__ bool validStart(const VoteArgs &a, uint64_t i, uint32_t &rep, uint32_t &target) {
     const uint64_t seg = a.keys[i] >> (a.diagBits + 1);
@@ -600,10 +626,19 @@ __device__ __forceinline__ HitRec voteSegmentTile(const VoteArgs &a, const uint6
     if (!done) {
         for (uint64_t kk = base + CP_TILE; kk < a.n; kk++) {
             const uint64_t k2 = a.keys[kk];
-            if ((uint32_t) ((k2 >> (a.diagBits + 1)) & idMask) != target) break;
+            if ((uint32_t) ((k2 >> (a.diagBits + 1)) & idMask) != target) { done = true; break; }
             const uint32_t d = (uint32_t) ((k2 >> 1) & diagMask);
             if (prevDiag == d) diagCnt++; else diagCnt = 1;
             if (diagCnt >= maxDiag) { diagonal = d; maxDiag = diagCnt; bestRev = (k2 & 1ull) ? 0 : 1; }
+            prevDiag = d; top++;
+        }
+    }
+    if (!done && target == a.staleTarget) {     // the scan reached the end of the group tuples: on into the stale ones
+        const uint32_t m = a.stale[0];
+        for (uint32_t j = 0; j < m; j++) {
+            const uint32_t d = a.stale[1 + j] + (uint32_t) a.diagBias;
+            if (prevDiag == d) diagCnt++; else diagCnt = 1;
+            if (diagCnt >= maxDiag) { diagonal = d; maxDiag = diagCnt; bestRev = 0; }
             prevDiag = d; top++;
         }
     }
@@ -684,6 +719,69 @@ __global__ void k_live_count(const uint64_t *__restrict__ keys, uint64_t n, int 
     uint64_t lo = 0, hi = n;
     while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((keys[mid] >> kbits) & 1ull) hi = mid; else lo = mid + 1; }
     *out = lo;
+}
+// The tuples the reference's last per-target scan runs into (see VoteArgs): k-mer-ordered real tuples from index J = nGroup on
+// while their sequence id is `target`.  Region 1 is only sorted on its high bits in memory (unless `sorted`): the bucket that
+// holds index J is ranked here (all pairs, one block); buckets larger than STALE_BUCKET were finished through the big-bucket
+// path, which leaves them sorted in memory.  Region 2 is sorted.
+constexpr int STALE_BUCKET = 2048;
+template <typename LY>
+struct StaleArgs {
+    const uint64_t *keys; const typename LY::V *vals; TupleGeom geom;
+    uint64_t live, kmerSlots, nTuples, J; uint32_t target; int lowBits; bool sorted;
+    uint32_t *out;      // [0] count, [1..] positions
+};
+template <typename LY>
+__global__ __launch_bounds__(256) void k_stale_tail(StaleArgs<LY> a) {
+    __shared__ uint64_t sC[STALE_BUCKET];
+    __shared__ uint64_t sB[2];
+    __shared__ int sSel;
+    const uint64_t hmask = (2ull << a.geom.kbits) - 1ull, lowMask = (1ull << a.lowBits) - 1ull;
+    uint32_t cnt = 0;
+    for (uint64_t j = a.J; cnt < (uint32_t) STALE_MAX; j++) {
+        uint64_t idx;
+        if (j < a.live) {
+            idx = j;
+            if (!a.sorted) {
+                if (threadIdx.x == 0) {     // bucket of j: equal high bits
+                    const uint64_t h = (a.keys[j] & hmask) >> a.lowBits;
+                    uint64_t lo = 0, hi = j;
+                    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (((a.keys[mid] & hmask) >> a.lowBits) < h) lo = mid + 1; else hi = mid; }
+                    sB[0] = lo;
+                    lo = j; hi = a.live;
+                    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (((a.keys[mid] & hmask) >> a.lowBits) == h) lo = mid + 1; else hi = mid; }
+                    sB[1] = lo;
+                }
+                __syncthreads();
+                const uint64_t b0 = sB[0], b1 = sB[1];
+                const int m = (int) min((uint64_t) STALE_BUCKET + 1, b1 - b0);
+                if (m <= STALE_BUCKET) {
+                    for (int i = threadIdx.x; i < m; i += blockDim.x) sC[i] = ((a.keys[b0 + i] & lowMask) << 12) | (uint64_t) i;
+                    if (threadIdx.x == 0) sSel = 0;
+                    __syncthreads();
+                    const int want = (int) (j - b0);
+                    for (int e = threadIdx.x; e < m; e += blockDim.x) {
+                        const uint64_t mine = sC[e]; int r = 0;
+                        for (int f = 0; f < m; f++) r += sC[f] < mine;
+                        if (r == want) sSel = e;
+                    }
+                    __syncthreads();
+                    idx = b0 + (uint64_t) sSel;
+                }
+                __syncthreads();
+            }
+        } else {
+            idx = a.kmerSlots + (j - a.live);
+            if (idx >= a.nTuples) break;
+        }
+        const uint64_t key = a.keys[idx];
+        if (key == ~0ull) break;                                   // end of the real tuples
+        const typename LY::V v = a.vals[idx];
+        if (LY::seqOf(v) != a.target) break;
+        if (threadIdx.x == 0) a.out[1 + cnt] = LY::posOf(key, v, idx, a.geom);
+        cnt++;
+    }
+    if (threadIdx.x == 0) a.out[0] = cnt;
 }
 inline uint32_t bitsFor(uint64_t v) { uint32_t b = 1; while ((1ull << b) < v) b++; return b; }
 
@@ -804,7 +902,13 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     GroupArgs<LY> ga; ga.geom = geom;
     ga.keys = keys.current(); ga.vals = vals.current(); ga.n = nTuples; ga.onlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode;
     ga.covThr = par->cov_thr; ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias; ga.first = 0; ga.firstRunIdx = 0;
+    ga.stat = counters.p + 4;
     unsigned long long *startIo = (unsigned long long *) keys.alternate();   // free after the sort
+    unsigned long long live = 0, groupStat[2] = {0, 0};
+    DevBuf<uint32_t> staleBuf;
+    if (!staleBuf.alloc(STALE_MAX + 2)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    hipMemsetAsync(staleBuf.p, 0, (STALE_MAX + 2) * 4, s);
+    uint32_t staleTarget = ~0u;
     {
         // scan + k_groups over the tuples [first, last) of (kk, vv), group keys to io[first..last)
         auto scanGroups = [&](GroupArgs<LY> g, unsigned long long *io) -> int {
@@ -821,19 +925,18 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
             return hipStreamSynchronize(s) == hipSuccess ? CDM_OK : CDM_ERR_HIP;      // t is released on return
         };
         int rc = CDM_OK;
+        if (kmerSlots) {        // real tuples of region 1 (the unused slots sort behind them in both variants)
+            hipLaunchKernelGGL(k_live_count, dim3(1), dim3(1), 0, s, ga.keys, (uint64_t) kmerSlots, 2 * k, counters.p + 3);
+            hipMemcpyAsync(&live, counters.p + 3, 8, hipMemcpyDeviceToHost, s);
+            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed"); return CDM_ERR_HIP; }
+        }
         if (lowBits == 0) rc = scanGroups(ga, startIo);
         else {
             int own; uint32_t maxBucket; bucket::capacities(own, maxBucket);
             DevBuf<unsigned long long> bigList; DevBuf<unsigned int> bigCnt;
             if (!bigList.alloc(bucket::bigListSlots(kmerSlots, maxBucket)) || !bigCnt.alloc(1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
             hipMemsetAsync(bigCnt.p, 0, 4, s);
-            unsigned long long live = 0;
-            if (kmerSlots) {
-                hipLaunchKernelGGL(k_live_count, dim3(1), dim3(1), 0, s, ga.keys, (uint64_t) kmerSlots, 2 * k, counters.p + 3);
-                hipMemcpyAsync(&live, counters.p + 3, 8, hipMemcpyDeviceToHost, s);
-                if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed"); return CDM_ERR_HIP; }
-                hipMemsetAsync(startIo + live, 0xFF, (size_t) (kmerSlots - live) * 8, s);     // unused slots: no group key
-            }
+            if (kmerSlots) hipMemsetAsync(startIo + live, 0xFF, (size_t) (kmerSlots - live) * 8, s);     // unused slots: no group key
             auto launchFused = [&](auto wordTag) {
                 typedef decltype(wordTag) W;
                 BucketGroupArgs<LY, W> ba;
@@ -863,6 +966,9 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
                     if (rocprim::radix_sort_pairs(nullptr, tb, dk, dv, (size_t) total, 0, 2 * k, s) != hipSuccess || !t.alloc(tb + 256) ||
                         rocprim::radix_sort_pairs(t.p, tb, dk, dv, (size_t) total, 0, 2 * k, s) != hipSuccess) rc = CDM_ERR_HIP;
                     if (rc == CDM_OK) {
+                        // the sorted tuples go back in place too: k_stale_tail indexes big buckets directly
+                        hipLaunchKernelGGL((bucket::k_big_copy<uint64_t, false>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(ga.keys), dk.current());
+                        hipLaunchKernelGGL((bucket::k_big_copy<V, false>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<V *>(ga.vals), dv.current());
                         GroupArgs<LY> gd = ga; gd.keys = dk.current(); gd.vals = dv.current(); gd.n = total; gd.first = 0;
                         gd.geom.kmerSlots = ~0ull;                                   // every tuple of the dense view is a region-1 tuple
                         gd.firstRunIdx = (firstStart == 0) ? 0ull : ~0ull;           // dense index 0 is the array's first tuple only then
@@ -876,7 +982,23 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
             }
         }
         if (rc != CDM_OK) { cdm_set_error("cdm_kmermatch: grouping failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+        hipMemcpyAsync(groupStat, counters.p + 4, 16, hipMemcpyDeviceToHost, s);
         { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+        if (groupStat[0]) {
+            // the tuples behind the kept ones that the reference's last per-target scan runs into (VoteArgs, k_stale_tail)
+            staleTarget = (uint32_t) ((groupStat[1] >> (diagBits + 1)) & ((1ull << idBits) - 1ull));
+            StaleArgs<LY> sa;
+            sa.keys = ga.keys; sa.vals = ga.vals; sa.geom = geom; sa.live = live; sa.kmerSlots = kmerSlots; sa.nTuples = nTuples; sa.J = groupStat[0];
+            sa.target = staleTarget; sa.lowBits = lowBits; sa.sorted = (lowBits == 0); sa.out = staleBuf.p;
+            hipLaunchKernelGGL(k_stale_tail<LY>, dim3(1), dim3(256), 0, s, sa);
+            uint32_t nStale = 0;
+            hipMemcpyAsync(&nStale, staleBuf.p, 4, hipMemcpyDeviceToHost, s);
+            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed"); return CDM_ERR_HIP; }
+            if (nStale >= (uint32_t) STALE_MAX) {
+                cdm_set_error("cdm_kmermatch: the reference's last per-target scan would run over %d or more left-over tuples of sequence %u; not reproduced on the device", STALE_MAX, staleTarget);
+                return CDM_ERR_UNSUPPORTED;
+            }
+        }
     }
     float msSort1 = 0; hipEventElapsedTime(&msSort1, ctx->ev0, ctx->ev1);
 
@@ -917,6 +1039,8 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     hipMemsetAsync(perRep.p, 0, ((size_t) n + 1) * 8, s);
     hipMemsetAsync(vTileCnt.p, 0, (vTiles + 1) * 8, s);
     VoteArgs va;
+    if (nGroup != groupStat[0]) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu sorted", groupStat[0], nGroup); return CDM_ERR_HIP; }
+    va.stale = staleBuf.p; va.staleTarget = staleTarget;
     va.keys = sorted2; va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.perRep = perRep.p;
     if (nGroup) hipLaunchKernelGGL(k_seg_count, dim3((unsigned) vTiles), dim3(256), 0, s, va, vTileCnt.p);
     size_t sb1 = 0, sb2 = 0;

@@ -154,6 +154,40 @@ def test_kmermatch_high_multiplicity_buckets(ctx, oracle_bin, tmp_path):
     assert not diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), strip_ext(mmdb.read_db(t("pref"))))
 
 
+@pytest.mark.parametrize("seqs", [["ACGTTGCAAGGCTTAACGGATCCGATTACAGGCATCGA"], ["ACG", "TTGCA", "", "ACGTACGTAC"],
+                                  ["ACGTTGCAAGGCTTAACGGATCCGATTACAGGCATCGA"] * 3, ["ACGTTGCAAGGCTTAACGGA", "ACGTTGCAAGGCTTAACGGA", "TCCGTTAAGCCTTGCAACGT"]])
+def test_kmermatch_tiny_databases(ctx, oracle_bin, tmp_path, seqs):
+    """One sequence; only sequences shorter than k (no k-mer tuple at all); identical sequences; exactly k letters."""
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "2")
+    assert not diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), strip_ext(mmdb.read_db(t("pref"))))
+
+
+def test_kmermatch_fuzz_small_databases(ctx, oracle_bin, tmp_path):
+    """60 random databases of 2..14 short reads cut from a 120 bp genome (both strands, duplicates, reads shorter than k):
+    with so few sequences the reference's quirks decide most records - the first-group strand rule, the per-target scan
+    running on into the next representative's tuples and past the end of the group tuples into the left-over ones."""
+    rng = np.random.default_rng(99)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    t = lambda s: str(tmp_path / s)
+    for case in range(60):
+        genome = rng.integers(0, 4, 120)
+        seqs = []
+        for _ in range(int(rng.integers(2, 15))):
+            L = int(rng.integers(12, 70)); st = int(rng.integers(0, 120 - L))
+            c = genome[st:st + L].copy()
+            if rng.random() < 0.5:
+                c = (3 - c)[::-1]
+            seqs.append(letters[c].tobytes().decode())
+        if rng.random() < 0.3:
+            seqs.append(seqs[0])
+        mmdb.write_seqdb(t("in"), seqs)
+        run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "1")
+        bad = diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), strip_ext(mmdb.read_db(t("pref"))))
+        assert not bad, (case, seqs, bad)
+
+
 def test_kmermatch_rejects_what_it_does_not_implement(ctx):
     with pytest.raises(capi.CdmError):
         kmermatch_text(ctx, {0: (b"ACGT" * 2000 + b"\n", 0), 1: (b"ACGTTGCA" * 1000 + b"\n", 0)})   # >= 4096 k-mer positions

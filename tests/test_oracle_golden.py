@@ -135,3 +135,39 @@ def test_chain_mixed3k(oracle_bin, dhigh_prefix, tmp_path):
 
 def test_chain_example(oracle_bin, dhigh_prefix, tmp_path):
     _stage_chain(oracle_bin, dhigh_prefix, tmp_path, "example", 1)
+
+
+REF_BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "carpedeam_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref (the reference's own object code) not built")
+def test_kmermatcher_small_databases_against_reference_binary(oracle_bin, tmp_path):
+    """The oracle against the reference's own kmermatcher on 60 databases of 2..14 short reads, where the reference's quirks
+    (first-group strand rule, per-target scan running on into the next representative's tuples and past the end of the group
+    tuples into the left-over ones) decide most records.  Same generator as tests/test_gpu_kmermatch.py's fuzz test."""
+    import numpy as np
+    rng = np.random.default_rng(99)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    t = lambda s: str(tmp_path / s)
+    ties_total = 0
+    for case in range(60):
+        genome = rng.integers(0, 4, 120)
+        seqs = []
+        for _ in range(int(rng.integers(2, 15))):
+            L = int(rng.integers(12, 70)); st = int(rng.integers(0, 120 - L))
+            c = genome[st:st + L].copy()
+            if rng.random() < 0.5:
+                c = (3 - c)[::-1]
+            seqs.append(letters[c].tobytes().decode())
+        if rng.random() < 0.3:
+            seqs.append(seqs[0])
+        mmdb.write_seqdb(t("in"), seqs)
+        run(oracle_bin, "kmermatcher", t("in"), t("po"), *K_FLAGS, "--threads", "1")
+        run(REF_BIN, "kmermatcher", t("in"), t("pr"), *K_FLAGS, "--threads", "1")
+        strip = lambda db: mmdb.canon({k: (v[0], 0) for k, v in db.items()})
+        ties, bad = pref_sign_ties(strip(mmdb.read_db(t("po"))), strip(mmdb.read_db(t("pr"))))
+        assert not bad, (case, seqs, bad[:3])
+        ties_total += sum(n for _, n in ties)
+        for f in os.listdir(tmp_path):
+            os.remove(t(f))
+    assert ties_total <= 60      # at most the one run-dependent strand tie (N1) per database
