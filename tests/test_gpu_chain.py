@@ -59,6 +59,52 @@ def test_chain_matches_oracle(ctx, oracle_bin, dhigh_prefix, tmp_path, n, lo, hi
         db = asm
 
 
+def test_chain_fuzz_small_databases(ctx, oracle_bin, dhigh_prefix, tmp_path):
+    """40 random databases of 6..60 reads (30..120 bp, both strands, end damage, a few N) from a 300 bp genome, three
+    iterations each: every stage of the device chain against the oracle.  Small, dense pile-ups reach corner cases the
+    big synthetic sets rarely do (reads contained in others, identical reads, extensions that meet)."""
+    rng = np.random.default_rng(2024)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    t = lambda s: str(tmp_path / s)
+    for case in range(40):
+        genome = rng.integers(0, 4, 300)
+        seqs = []
+        for _ in range(int(rng.integers(6, 61))):
+            L = int(rng.integers(30, 121)); st = int(rng.integers(0, 300 - L))
+            c = genome[st:st + L].copy()
+            if rng.random() < 0.5:
+                c = (3 - c)[::-1]
+            for j in range(3):                      # deamination at the ends: C->T at 5', G->A at 3'
+                if c[j] == 1 and rng.random() < 0.3:
+                    c[j] = 3
+                if c[L - 1 - j] == 2 and rng.random() < 0.3:
+                    c[L - 1 - j] = 0
+            sq = letters[c].tobytes().decode()
+            if rng.random() < 0.05:
+                k = int(rng.integers(0, L)); sq = sq[:k] + "N" + sq[k + 1:]
+            seqs.append(sq)
+        if rng.random() < 0.4:
+            seqs.append(seqs[int(rng.integers(0, len(seqs)))])
+        mmdb.write_seqdb(t("in0"), seqs)
+        db = ctx.upload_seqs(seqs)
+        for it in range(3):
+            hits, alns, corr, asm = chain(ctx, db)
+            i, o = t("in%d" % it), t("in%d" % (it + 1))
+            run_oracle(oracle_bin, "kmermatcher", i, t("pref"), *K_FLAGS, "--threads", "1")
+            run_oracle(oracle_bin, "rescorediagonal", i, i, t("pref"), t("aln"), *R_FLAGS, "--threads", "1")
+            run_oracle(oracle_bin, "ancient_correction", i, t("aln"), t("corr"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "1")
+            run_oracle(oracle_bin, "ancient_read_assemble", t("corr"), t("aln"), o, *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "1")
+            lens, keys, _ = db.meta()
+            hoff, hrec = hits.download()
+            ctxt = (case, it, seqs)
+            assert not diff_keys({k: (v, 0) for k, v in capi.hits_to_text(hoff, hrec, keys).items()}, {k: (v[0], 0) for k, v in mmdb.read_db(t("pref")).items()}), ctxt
+            aoff, arec = alns.download()
+            assert not diff_keys({k: (v, 0) for k, v in capi.alns_to_text(aoff, arec, keys, lens, db.residues).items()}, mmdb.read_db(t("aln"))), ctxt
+            assert not diff_keys(seqdb_to_keyed(*corr.download()), mmdb.read_db(t("corr"))), ctxt
+            assert not diff_keys(seqdb_to_keyed(*asm.download()), mmdb.read_db(o)), ctxt
+            db = asm
+
+
 def test_chain_properties_at_scale(ctx):
     """2 M reads (no oracle at this size): structural invariants of every stage."""
     n, L = 2_000_000, 100

@@ -171,3 +171,53 @@ def test_kmermatcher_small_databases_against_reference_binary(oracle_bin, tmp_pa
         for f in os.listdir(tmp_path):
             os.remove(t(f))
     assert ties_total <= 60      # at most the one run-dependent strand tie (N1) per database
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref (the reference's own object code) not built")
+def test_chain_small_databases_against_reference_binary(oracle_bin, dhigh_prefix, tmp_path):
+    """All four stages of the oracle against the reference's own object code on 40 databases of 6..60 reads (both strands, end
+    damage, N, duplicates) over three iterations; stage-isolated: both programs consume the oracle's upstream DB.  Same
+    generator as tests/test_gpu_chain.py's fuzz test, which pins the device path to the oracle on the same inputs."""
+    import numpy as np
+    rng = np.random.default_rng(2024)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    t = lambda s: str(tmp_path / s)
+    canon = lambda p: mmdb.canon(mmdb.read_db(p))
+    for case in range(40):
+        genome = rng.integers(0, 4, 300)
+        seqs = []
+        for _ in range(int(rng.integers(6, 61))):
+            L = int(rng.integers(30, 121)); st = int(rng.integers(0, 300 - L))
+            c = genome[st:st + L].copy()
+            if rng.random() < 0.5:
+                c = (3 - c)[::-1]
+            for j in range(3):
+                if c[j] == 1 and rng.random() < 0.3:
+                    c[j] = 3
+                if c[L - 1 - j] == 2 and rng.random() < 0.3:
+                    c[L - 1 - j] = 0
+            sq = letters[c].tobytes().decode()
+            if rng.random() < 0.05:
+                k = int(rng.integers(0, L)); sq = sq[:k] + "N" + sq[k + 1:]
+            seqs.append(sq)
+        if rng.random() < 0.4:
+            seqs.append(seqs[int(rng.integers(0, len(seqs)))])
+        mmdb.write_seqdb(t("in0"), seqs)
+        for it in range(3):
+            i, o = t("in%d" % it), t("in%d" % (it + 1))
+            ctxt = (case, it, seqs)
+            for exe, sfx in ((oracle_bin, ""), (REF_BIN, "R")):
+                run(exe, "kmermatcher", i, t("pref" + sfx), *K_FLAGS, "--threads", "1")
+                run(exe, "rescorediagonal", i, i, t("pref"), t("aln" + sfx), *R_FLAGS, "--threads", "1")
+                run(exe, "ancient_correction", i, t("aln"), t("corr" + sfx), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "1")
+                run(exe, "ancient_read_assemble", t("corr"), t("aln"), o if sfx == "" else t("asmR"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "1")
+            strip = lambda p: mmdb.canon({k: (v[0], 0) for k, v in mmdb.read_db(p).items()})
+            ties, bad = pref_sign_ties(strip(t("pref")), strip(t("prefR")))
+            assert not bad, ctxt
+            assert canon(t("aln")) == canon(t("alnR")), ctxt
+            assert canon(t("corr")) == canon(t("corrR")), ctxt
+            assert canon(o) == canon(t("asmR")), ctxt
+            for f in ("pref", "prefR", "aln", "alnR", "corr", "corrR", "asmR"):
+                for ext in ("", ".index", ".dbtype"):
+                    if os.path.exists(t(f) + ext):
+                        os.remove(t(f) + ext)
