@@ -1,0 +1,86 @@
+"""Exploratory fuzzing of the device chain against the oracle (test infrastructure; run on a GPU box):
+    python scripts/fuzz_chain.py <mode> <cases> <seed>
+modes: small, deep (100x+ pile-ups, > 64 records per query), repeats (low-complexity / tandem repeats), contigparams (k = 22,
+include-only-extendable), longreads (up to 600 bp: general extraction kernel)."""
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+from carpedeam_amd import capi, mmdb, synth
+from gpuutil import diff_keys, run_oracle, seqdb_to_keyed
+from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
+
+mode, cases, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+rng = np.random.default_rng(seed)
+letters = np.frombuffer(b"ACGT", np.uint8)
+d = tempfile.mkdtemp()
+t = lambda s: os.path.join(d, s)
+synth.write_dhigh_profiles(t("dhigh"))
+oracle = os.path.join(ROOT, "oracle", "_build", "cdm_oracle")
+ctx = capi.Ctx(0)
+ctx.damage_load(t("dhigh"))
+kflags, kpar = K_FLAGS, None
+if mode == "contigparams":
+    kflags = " ".join(K_FLAGS).replace("-k 20", "-k 22").replace("--include-only-extendable 0", "--include-only-extendable 1").split()
+    kpar = capi.KmerParams(22, 200, 0.2, 67, 1, 1, 1, 0.0)
+fails = 0
+for case in range(cases):
+    G = {"small": 300, "deep": 150, "repeats": 200, "contigparams": 400, "longreads": 1500}[mode]
+    genome = rng.integers(0, 4, G)
+    if mode == "repeats":
+        unit = rng.integers(0, 4, int(rng.integers(1, 9)))
+        a = int(rng.integers(0, G - 80)); genome[a:a + 80] = np.resize(unit, 80)
+    nreads = {"small": (6, 61), "deep": (150, 400), "repeats": (10, 80), "contigparams": (10, 80), "longreads": (10, 60)}[mode]
+    lr = {"small": (30, 121), "deep": (40, 101), "repeats": (30, 121), "contigparams": (40, 200), "longreads": (100, 600)}[mode]
+    seqs = []
+    for _ in range(int(rng.integers(*nreads))):
+        L = int(rng.integers(*lr)); L = min(L, G - 1); st = int(rng.integers(0, G - L))
+        c = genome[st:st + L].copy()
+        if rng.random() < 0.5:
+            c = (3 - c)[::-1]
+        for j in range(3):
+            if c[j] == 1 and rng.random() < 0.3:
+                c[j] = 3
+            if c[L - 1 - j] == 2 and rng.random() < 0.3:
+                c[L - 1 - j] = 0
+        if rng.random() < 0.2:
+            k = int(rng.integers(0, L)); c[k] = (c[k] + 1) % 4          # a sequencing error
+        sq = letters[c].tobytes().decode()
+        if rng.random() < 0.05:
+            k = int(rng.integers(0, L)); sq = sq[:k] + "N" + sq[k + 1:]
+        seqs.append(sq)
+    if rng.random() < 0.4:
+        seqs.append(seqs[int(rng.integers(0, len(seqs)))])
+    mmdb.write_seqdb(t("in0"), seqs)
+    db = ctx.upload_seqs(seqs)
+    try:
+        for it in range(3):
+            hits = ctx.kmermatch(db, kpar); alns = ctx.rescore(db, hits); corr = ctx.correct(db, alns); asm = ctx.extend(corr, alns)
+            i, o = t("in%d" % it), t("in%d" % (it + 1))
+            run_oracle(oracle, "kmermatcher", i, t("pref"), *kflags, "--threads", "4")
+            run_oracle(oracle, "rescorediagonal", i, i, t("pref"), t("aln"), *R_FLAGS, "--threads", "4")
+            run_oracle(oracle, "ancient_correction", i, t("aln"), t("corr"), *A_FLAGS, "--ancient-damage", t("dhigh"), "--threads", "4")
+            run_oracle(oracle, "ancient_read_assemble", t("corr"), t("aln"), o, *A_FLAGS, "--ancient-damage", t("dhigh"), "--threads", "4")
+            lens, keys, _ = db.meta()
+            hoff, hrec = hits.download(); aoff, arec = alns.download()
+            bad = [("pref", diff_keys({k: (v, 0) for k, v in capi.hits_to_text(hoff, hrec, keys).items()}, {k: (v[0], 0) for k, v in mmdb.read_db(t("pref")).items()})),
+                   ("aln", diff_keys({k: (v, 0) for k, v in capi.alns_to_text(aoff, arec, keys, lens, db.residues).items()}, mmdb.read_db(t("aln")))),
+                   ("corr", diff_keys(seqdb_to_keyed(*corr.download()), mmdb.read_db(t("corr")))),
+                   ("asm", diff_keys(seqdb_to_keyed(*asm.download()), mmdb.read_db(o)))]
+            bad = [(n, b) for n, b in bad if b]
+            if bad:
+                fails += 1
+                print("FAIL", mode, "case", case, "iter", it, [(n, str(b)[:300]) for n, b in bad], flush=True)
+                open(t("fail_%s_%d.txt" % (mode, case)), "w").write("\n".join(seqs))
+                print("  reads saved:", t("fail_%s_%d.txt" % (mode, case)), len(seqs), flush=True)
+                break
+            db = asm
+    except capi.CdmError as e:
+        print("ERROR", mode, "case", case, str(e)[:300], flush=True); fails += 1
+print("mode", mode, "cases", cases, "failures", fails, flush=True)
