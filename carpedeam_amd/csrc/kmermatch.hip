@@ -501,8 +501,10 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
         [&](int i, const Tup &t) { sKey[i] = t.k; sVal[i] = t.v; return t.k; },
         [&](uint64_t g) { return a.keys[g]; },
         [&](int g0, int gm) {
+            // word of the network: (bucket ordinal within the group, low k-mer bits, position within the group)
+            const int idxBits = gm > 256 ? 9 : 8, ord0 = w.ord[g0];
             sortGroup<W>(gm, lane,
-                [&](int i) { return (W) ((((W) w.ord[g0 + i] << lowBits | (W) (sKey[g0 + i] & lowMask)) << WV_IDX) | (W) (g0 + i)); },
+                [&](int i) { return (W) ((((W) (w.ord[g0 + i] - ord0) << lowBits | (W) (sKey[g0 + i] & lowMask)) << idxBits) | (W) i); },
                 [&](auto &v) {
                     // per sorted position: window slot of the element, start of its run (= equal bucket and low bits; from an
                     // inclusive max-scan of the start positions over the wave) and whether it starts one
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
                     for (int r = 0; r < R; r++) {
                         const int p = lane * R + r;
                         const W prev = r ? v[r - 1] : prevLast;
-                        if (p == 0 || (v[r] >> WV_IDX) != (prev >> WV_IDX)) last = p;
+                        if (p == 0 || (v[r] >> idxBits) != (prev >> idxBits)) last = p;
                         st[r] = last;
                     }
                     int sc = last;
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         const int p = lane * R + r, s0 = st[r] < 0 ? carry : st[r];
-                        ss[p] = ((uint32_t) v[r] & IDXM) | ((uint32_t) s0 << WV_IDX) | (s0 == p ? 1u << 31 : 0u);
+                        ss[p] = (uint32_t) (g0 + (int) ((uint32_t) v[r] & ((1u << idxBits) - 1u))) | ((uint32_t) s0 << WV_IDX) | (s0 == p ? 1u << 31 : 0u);
                     }
                 });
             waveLdsSync();
@@ -878,18 +880,24 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     // ---- sort 1: stable LSD radix sort by k-mer.  Region 1 (k-mer slots) on the 2k key bits, region 2 (whole-sequence hashes)
     // on 63 bits into the same physical buffers; the strand bit 63 rides along outside the sorted bit range.
     keys = rocprim::double_buffer<uint64_t>(k0.p, k1.p); vals = rocprim::double_buffer<V>(v0.p, v1.p);
-    // Region 1: only the top 32 k-mer bits go through global passes, the low bits are finished per bucket by k_bucket_groups
+    // Region 1: only the top 27 sort bits go through global passes, the low bits are finished per bucket by k_bucket_groups
     // (bucket.h); CDM_KMER_SORT=lsd sorts all 2k bits globally and keeps the separate scan + k_groups kernels (A/B).
     // With low bits left over the passes cover bits [lowBits, 2k]: bit 2k is set only in unused slots, which end up last.
-    const int lowBits = lsdOnly ? 0 : std::max(0, 2 * k + 1 - 32);
+    // 27 high bits = 3 onesweep passes of 9 bits (rocPRIM's tuned default is 8 bits per pass; 9 still fits the LDS and three
+    // 9-bit passes take 29 ms per 2^30 tuples where four 8-bit ones take 35).
+    typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                       rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 16>, rocprim::kernel_config<512, 16>, 9, rocprim::block_radix_rank_algorithm::match>> Sort1Config;
+    const int lowBits = lsdOnly ? 0 : std::max(0, 2 * k + 1 - 27);
     const int sortTop = lowBits ? 2 * k + 1 : 2 * k;
     size_t tmpBytes = 0, tmpBytesH = 0;
-    rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s);
+    if (lsdOnly) rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s);
+    else rocprim::radix_sort_pairs<Sort1Config>(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s);
     rocprim::radix_sort_pairs(nullptr, tmpBytesH, k0.p + kmerSlots, k1.p + kmerSlots, v0.p + kmerSlots, v1.p + kmerSlots, (size_t) n, 0, 63, s);
     DevBuf<char> tmp1;
     if (!tmp1.alloc(std::max(tmpBytes, tmpBytesH) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev0, s);
-    if (rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
+    if ((lsdOnly ? rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)
+                 : rocprim::radix_sort_pairs<Sort1Config>(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev1, s);
     hipEventRecord(ctx->ev2, s);
     {
@@ -954,7 +962,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
                 const uint64_t perBlock = (uint64_t) own * bucket::BK_WAVES;
                 if (live) hipLaunchKernelGGL((k_bucket_groups<LY, W>), dim3((unsigned) ((live + perBlock - 1) / perBlock)), dim3(bucket::BK_NT), 0, s, ba);
             };
-            if (lowBits <= 12) launchFused(uint32_t()); else launchFused(uint64_t());   // bucket ordinal + low bits + window slot in one word
+            if (lowBits <= 15) launchFused(uint32_t()); else launchFused(uint64_t());   // 8 bits of bucket ordinal + low bits + 9 of position in one word
             unsigned int nBig = 0;
             hipMemcpyAsync(&nBig, bigCnt.p, 4, hipMemcpyDeviceToHost, s);
             GroupArgs<LY> g2 = ga; g2.first = kmerSlots;                      // region 2 is sorted on all its bits
