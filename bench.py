@@ -148,32 +148,31 @@ def main():
     if rank == 0:
         total_bases = residues * args.steps * world
         k_ms = [m / args.steps for m in kernel_ms]
-        # Dominant kernel (rocprofv3 --stats, profiles/): rocPRIM's radix_sort_onesweep_iteration<u64 key, u32 value>, launched
-        # by kmermatcher's sort 1 on the packed 12-byte tuples: the k-mer slots go through the top 32 of their 2k + 1 = 41 sort
-        # bits (4 passes; the low 9 bits are finished on chip by k_bucket_groups), the n whole-sequence hash tuples through 63
-        # bits (8 passes); rocPRIM sorts at most 2^30 items per launch, so a pass is ceil(items / 2^30) launches.
+        # Dominant kernel (rocprofv3 --stats, profiles/): rocPRIM's radix_sort_onesweep_iteration<u64 key, u32 value> in the 9-bit
+        # configuration kmermatcher's sort 1 uses on the packed 12-byte tuples of the k-mer slots: the top 27 of their
+        # 2k + 1 = 41 sort bits go through 3 passes (the low 14 bits are finished on chip by k_bucket_groups); rocPRIM sorts at
+        # most 2^30 items per launch, so a pass is ceil(items / 2^30) launches.  (The n whole-sequence hash tuples are sorted by
+        # the default 8-bit configuration, a different kernel: 8 short launches, 3 ms per step.)
         # Algorithmic bytes of one launch: its 12-byte tuples read once and written once.  The average launch
-        # duration comes from the HIP-event times of the two sort calls on the library's stream; each call also runs one
-        # histogram launch per 2^30 items, which costs about half an iteration launch (it reads the 8-byte keys once).
+        # duration comes from the HIP-event time of the sort call on the library's stream; the call also runs one histogram
+        # launch per 2^30 items, which costs about half an iteration launch (it reads the 8-byte keys once).
         tuples_per_read = L - 20 + 2
-        n1, n2 = tuples_per_read * n, n
-        c1, c2 = -(-n1 // (1 << 30)), -(-n2 // (1 << 30))
-        p1 = -(-min(32, 2 * 20 + 1) // 8)
-        l1, l2 = p1 * c1, 8 * c2
-        t1 = k_ms[5] * l1 / (l1 + 0.5 * c1) if k_ms[5] > 0 else 0.0      # ms spent in region-1 iteration launches
-        t2 = k_ms[7] * l2 / (l2 + 0.5 * c2) if k_ms[7] > 0 else 0.0
-        launches = l1 + l2
-        bytes_all = 2.0 * 12.0 * (p1 * n1 + 8 * n2)                       # summed over this kernel's launches in one step
-        iter_ms = (t1 + t2) / launches if launches else 0.0               # = rocprof's AverageNs for this kernel
-        sort_bytes = bytes_all / launches
-        achieved = bytes_all / ((t1 + t2) * 1e-3) / 1e9 if (t1 + t2) > 0 else 0.0
+        n1 = tuples_per_read * n
+        c1 = -(-n1 // (1 << 30))
+        p1 = -(-min(27, 2 * 20 + 1) // 9)
+        launches = p1 * c1
+        t1 = k_ms[5] * launches / (launches + 0.5 * c1) if k_ms[5] > 0 else 0.0      # ms spent in the iteration launches
+        bytes_all = 2.0 * 12.0 * p1 * n1                                   # summed over this kernel's launches in one step
+        iter_ms = t1 / launches if launches else 0.0                       # = rocprof's AverageNs for this kernel
+        sort_bytes = bytes_all / launches if launches else 0.0
+        achieved = bytes_all / (t1 * 1e-3) / 1e9 if t1 > 0 else 0.0
         # HBM traffic of that kernel from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc runs of
         # this very command at the default size; profiles/r01_pmc_50M.json) - only quoted for the workload it was measured on
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_50M_g.json")
         if n == 50_000_000 and L == 100 and os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc))["kernels"]["rocprim radix_sort_onesweep onesweep_iteration <u64, u32>"]["hbm_bytes_per_launch"]
+                traffic = json.load(open(pmc))["kernels"]["rocprim onesweep_iteration 9-bit <u64, u32>"]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
         line = {
@@ -184,7 +183,7 @@ def main():
                        "reads_per_gpu": n, "read_len": L, "seed": args.seed, "prefilter_hits": stats[0], "alignments": stats[1],
                        "stage_kernel_ms": {"kmer_extract": k_ms[3], "kmer_sort1_call": k_ms[5], "kmer_sort1_hash_call": k_ms[7], "kmer_sort2_call": k_ms[6], "rescore": k_ms[1],
                                            "correct": k_ms[0], "extend": k_ms[4]}},
-            "roofline": {"bound": "hbm", "kernel": "rocprim radix_sort_onesweep_iteration<u64 key, u32 value> (kmermatcher sort 1: 4 passes over the k-mer slots + 8 over the hash tuples)",
+            "roofline": {"bound": "hbm", "kernel": "rocprim radix_sort_onesweep_iteration<u64 key, u32 value> (9-bit configuration; kmermatcher sort 1: 3 passes over the k-mer slots)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": iter_ms, "launches_per_step": launches, "algorithmic_bytes_per_launch": sort_bytes,
                          "stage_level": {"what": "whole kmermatcher stage against its algorithmic bytes (26.8 B/base, SURVEY.md 8(d))",

@@ -12,14 +12,31 @@ import re
 import sys
 
 
+def _split_top(t):
+    out, depth, cur = [], 0, ""
+    for ch in t:
+        if ch in "<(":
+            depth += 1
+        elif ch in ">)":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    out.append(cur.strip())
+    return out
+
+
 def short(name):
     n = name.replace("(anonymous namespace)::", "")
-    m = re.search(r"wrapped_(\w+?)_config<[^,]+, ([^>]*?)>", n)
+    m = re.search(r"wrapped_(\w+?)_config<(.*?)>, \(rocprim::\w+::detail::target_arch\)", n)
     if "rocprim" in n and m:
-        kind = m.group(1)
-        types = m.group(2).replace("unsigned long", "u64").replace("unsigned int", "u32").replace("rocprim::ROCPRIM_400200_NS::empty_type", "-")
-        sub = "onesweep_iteration" if "onesweep_iteration" in n else ("onesweep_histograms" if "onesweep_histograms" in n else "")
-        return "rocprim %s %s <%s>" % (kind, sub, types)
+        parts = _split_top(m.group(2))
+        sub = "onesweep_iteration" if "onesweep_iteration" in n else ("onesweep_histograms" if "onesweep_global_offsets" in n else m.group(1))
+        bits = re.search(r">, (\d+)u, \(", parts[0])               # a non-default onesweep configuration
+        types = ", ".join(parts[1:]).replace("unsigned long long", "u64").replace("unsigned long", "u64").replace("unsigned int", "u32")
+        types = re.sub(r"rocprim::\w+::empty_type", "-", types)
+        return "rocprim %s%s <%s>" % (sub, " %s-bit" % bits.group(1) if bits else "", types)
     n = re.sub(r"^void ", "", n)
     return re.split(r"[(<]", n)[0] + ("<" + n.split("<", 1)[1].split(">")[0] + ">" if "<" in n.split("(")[0] else "")
 
