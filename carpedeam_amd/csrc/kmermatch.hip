@@ -887,16 +887,17 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     // 9-bit passes take 29 ms per 2^30 tuples where four 8-bit ones take 35).
     typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                        rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 16>, rocprim::kernel_config<512, 16>, 9, rocprim::block_radix_rank_algorithm::match>> Sort1Config;
-    const int lowBits = lsdOnly ? 0 : std::max(0, 2 * k + 1 - 27);
+    const bool fourPasses = sortEnv && !strcmp(sortEnv, "4x8");      // CDM_KMER_SORT=4x8: rocPRIM's default 8-bit passes over 32 bits (A/B)
+    const int lowBits = lsdOnly ? 0 : std::max(0, 2 * k + 1 - (fourPasses ? 32 : 27));
     const int sortTop = lowBits ? 2 * k + 1 : 2 * k;
     size_t tmpBytes = 0, tmpBytesH = 0;
-    if (lsdOnly) rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s);
+    if (lsdOnly || fourPasses) rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s);
     else rocprim::radix_sort_pairs<Sort1Config>(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s);
     rocprim::radix_sort_pairs(nullptr, tmpBytesH, k0.p + kmerSlots, k1.p + kmerSlots, v0.p + kmerSlots, v1.p + kmerSlots, (size_t) n, 0, 63, s);
     DevBuf<char> tmp1;
     if (!tmp1.alloc(std::max(tmpBytes, tmpBytesH) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev0, s);
-    if ((lsdOnly ? rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)
+    if (((lsdOnly || fourPasses) ? rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)
                  : rocprim::radix_sort_pairs<Sort1Config>(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev1, s);
     hipEventRecord(ctx->ev2, s);
