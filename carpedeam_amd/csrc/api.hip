@@ -1,6 +1,7 @@
 // C-ABI entry points: context, sequence DB (upload / 2-bit packing / download), hit and alignment containers.
 // Stage kernels live in correct.hip, rescore.hip, kmermatch.hip, extend.hip, synth.hip.
 #include <cstdarg>
+#include <atomic>
 #include <cstring>
 #include <vector>
 
@@ -125,7 +126,9 @@ extern "C" int cdm_bit_score(double raw) { return cdm_bit_score_host(raw); }
 
 // ------------------------------------------------------------------------------------------------ sequence DB
 int cdm_seqdb_alloc(cdm_ctx *ctx, uint64_t n, cdm_seqdb **out) {
+    static std::atomic<uint64_t> nextSerial{1};
     cdm_seqdb *db = new cdm_seqdb();
+    db->serial = nextSerial++;
     db->n = n; db->device = ctx->device;
     if (cdmMalloc(&db->woff, (n + 1) * sizeof(uint32_t)) != hipSuccess || cdmMalloc(&db->len, (n + 1) * sizeof(uint32_t)) != hipSuccess ||
         cdmMalloc(&db->key, (n + 1) * sizeof(uint32_t)) != hipSuccess || cdmMalloc(&db->ext, n + 1) != hipSuccess ||
@@ -519,7 +522,7 @@ extern "C" int cdm_alns_download(cdm_ctx *ctx, const cdm_alns *a, uint64_t *offs
     CDM_HIP(hipStreamSynchronize(ctx->stream));
     return CDM_OK;
 }
-extern "C" void cdm_alns_free(cdm_alns *a) { if (!a) return; cdmFree(a->off); cdmFree(a->rec); delete a; }
+extern "C" void cdm_alns_free(cdm_alns *a) { if (!a) return; cdmFree(a->off); cdmFree(a->rec); if (a->ryMism) cdmFree(a->ryMism); delete a; }
 
 // ------------------------------------------------------------------------------------------------ stage wrappers
 extern "C" int cdm_correct(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out) {

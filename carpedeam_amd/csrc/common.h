@@ -91,6 +91,7 @@ struct cdm_seqdb {
     uint32_t *codes = nullptr;  // [words]
     uint32_t *nmask = nullptr;  // [(words*16+31)/32]
     int device = 0;
+    uint64_t serial = 0;    // unique per handle (cdm_seqdb_alloc)
 };
 
 // Per-sequence metadata gathered by target id in rescore / correction / extension: one 16-byte record instead of four arrays
@@ -115,6 +116,9 @@ struct cdm_alns {
     uint64_t n = 0, count = 0;
     uint64_t *off = nullptr;  // [n+1]
     AlnRec *rec = nullptr;    // [count]
+    // by-product of cdm_rescore, which walks the very columns ancient_correction's RY gate looks at: purine/pyrimidine
+    // mismatches per record (0xFFFF = not known, e.g. a sequence with N); only valid for the sequence DB it was computed on
+    uint16_t *ryMism = nullptr; uint64_t rySerial = 0;
 };
 
 int cdm_seqdb_alloc_like(cdm_ctx *ctx, const cdm_seqdb *src, cdm_seqdb **out);  // same n/lengths/layout, codes uninitialised

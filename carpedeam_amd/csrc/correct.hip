@@ -25,6 +25,7 @@ struct CorrectArgs {
     const uint32_t *codes, *nmask;
     const uint64_t *aoff;
     const AlnRec *rec;
+    const uint16_t *ry;       // purine/pyrimidine mismatches per record from cdm_rescore (0xFFFF = count here), or NULL
     const uint32_t *active;
     const unsigned int *nActive;
     uint8_t *accept;          // [alignment count] scratch
@@ -179,7 +180,10 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {
             const Oriented o = orient(rec, tLen);
             bool ok = a.ext[t] == 0;                              // target must be a read (:280-284)
             int mism = 0;
+            const uint32_t preRy = a.ry ? a.ry[r] : 0xFFFFu;
+            if (ok && preRy != 0xFFFFu) mism = (int) preRy;         // counted by cdm_rescore on the same columns
             if (ok) {
+                if (preRy == 0xFFFFu) {
                 for (uint32_t c = lane; c < aLen; c += 64) {
                     uint32_t qb = cdm_base(a.codes, qw, o.qs + c);
                     if (qHasN && cdm_isN(a.nmask, qw, o.qs + c)) qb = 0;
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {
                     mism += ((qb & 1u) != (tb & 1u));             // RY class = low bit of the A,C,G,T = 0..3 code
                 }
                 mism = cdm_wave_sum(mism);
+                }
                 const float ryId = static_cast<float>(aLen - (uint32_t) mism) / static_cast<float>(aLen);
                 float thr = a.corrRy;
                 if (aLen <= 100) { thr = (static_cast<float>(aLen) - 1) / static_cast<float>(aLen); thr = floorf(thr * 1000) / 1000; }
@@ -286,8 +291,11 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
             const Oriented o = orient(rec, tLen);
             ok = a.ext[t] == 0;
             if (ok) {
-                uint32_t mism = 0;
-                if (!qHasN && !tHasN) {
+                uint32_t mism = a.ry ? a.ry[r0 + lane] : 0xFFFFu;
+                if (mism != 0xFFFFu) {
+                    // counted by cdm_rescore on the same columns
+                } else if (!qHasN && !tHasN) {
+                    mism = 0;
                     const uint32_t tLast = (tLen + 15) / 16 - 1;
                     for (uint32_t c = 0; c < aLen; c += 16) {
                         const uint32_t x = cdm_window16(a.codes, qw, (uint32_t) o.qs + c, qLast) ^ cdm_oriented_window16(a.codes, tw, tLen, tLast, o.rev, (uint32_t) o.ds + c);
@@ -297,6 +305,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
                         mism += __popc(mm);
                     }
                 } else {
+                    mism = 0;
                     for (uint32_t c = 0; c < aLen; c++) {
                         uint32_t qb = cdm_base(a.codes, qw, o.qs + c);
                         if (qHasN && cdm_isN(a.nmask, qw, o.qs + c)) qb = 0;
@@ -418,7 +427,7 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
     if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
     CorrectArgs a;
     a.woff.m = a.len.m = a.hasN.m = a.ext.m = meta.p; a.codes = db->codes; a.nmask = db->nmask;
-    a.aoff = alns->off; a.rec = alns->rec; a.active = active.p; a.nActive = counters.p; a.accept = accept.p; a.errFlag = counters.p + 1;
+    a.aoff = alns->off; a.rec = alns->rec; a.ry = (alns->ryMism && alns->rySerial == db->serial) ? alns->ryMism : nullptr; a.active = active.p; a.nActive = counters.p; a.accept = accept.p; a.errFlag = counters.p + 1;
     a.outCodes = out->codes; a.outNmask = out->nmask; a.lut = ctx->lutDev; a.seqIdThr = par->seq_id_thr; a.corrRy = par->corr_reads_ry_seq_id;
     const int blocks = ctx->cuCount * 8;
     hipEventRecord(ctx->ev0, s);

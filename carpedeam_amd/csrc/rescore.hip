@@ -29,6 +29,7 @@ struct RescoreArgs {
     float seqIdThr, covThr;
     int covMode, minAlnLen;
     AlnRec *tmp;               // [nHits] candidate records
+    uint16_t *tmpRy;           // [nHits] purine/pyrimidine mismatches of the candidate (0xFFFF = not counted)
     uint8_t *valid;            // [nHits]
 };
 
@@ -58,7 +59,7 @@ __device__ __forceinline__ void orientedBase(const RescoreArgs &a, uint32_t w0, 
     if (rc) code = 3u - code;
 }
 
-struct Diag { unsigned score; unsigned diagLen; unsigned dist; int diagonal; unsigned ident; bool any; };
+struct Diag { unsigned score; unsigned diagLen; unsigned dist; int diagonal; unsigned ident; unsigned ry; bool any; };
 
 // ungappedAlignmentByDiagonal + computeGlobalSubstitutionStartEndDistance for one real diagonal
 __device__ __forceinline__ void scoreDiagonal(const RescoreArgs &a, uint32_t qw, uint32_t qLen, bool qN, bool rc, uint32_t tw, uint32_t tLen, bool tN,
@@ -68,15 +69,17 @@ __device__ __forceinline__ void scoreDiagonal(const RescoreArgs &a, uint32_t qw,
     if (diagonal >= 0 && md < qLen) { qOff = md; tOff = 0; m = min(tLen, qLen - md); }
     else if (diagonal < 0 && md < tLen) { qOff = 0; tOff = md; m = min(tLen - md, qLen); }
     else return;   // res.score stays 0: never beats max (strict >)
-    unsigned mism = 0, identN = 0;
+    unsigned mism = 0, identN = 0, ry = 0xFFFFu;
     if (!qN && !tN) {
+        ry = 0;
         const uint32_t qLast = (qLen + 15) / 16 - 1, tLast = (tLen + 15) / 16 - 1;
         for (uint32_t k = 0; k < m; k += 16) {
             const uint32_t x = cdm_oriented_window16(a.codes, qw, qLen, qLast, rc, qOff + k) ^ cdm_window16(a.codes, tw, tOff + k, tLast);
             uint32_t mm = (x | (x >> 1)) & 0x55555555u;
             const uint32_t rem = m - k;
-            if (rem < 16) mm &= (1u << (2 * rem)) - 1u;
-            mism += __popc(mm);
+            uint32_t rr = x & 0x55555555u;                      // RY class = low bit of the code; complementing both keeps it
+            if (rem < 16) { mm &= (1u << (2 * rem)) - 1u; rr &= (1u << (2 * rem)) - 1u; }
+            mism += __popc(mm); ry += __popc(rr);
         }
     } else {
         for (uint32_t k = 0; k < m; k++) {
@@ -91,7 +94,7 @@ __device__ __forceinline__ void scoreDiagonal(const RescoreArgs &a, uint32_t qw,
     }
     const long long sc = 2ll * (m - mism) - 3ll * mism;
     const unsigned score = sc > 0 ? (unsigned) sc : 0u;
-    if (score > best.score) { best.score = score; best.diagLen = m; best.dist = md; best.diagonal = diagonal; best.ident = (m - mism) + identN; best.any = true; }
+    if (score > best.score) { best.score = score; best.diagLen = m; best.dist = md; best.diagonal = diagonal; best.ident = (m - mism) + identN; best.ry = ry; best.any = true; }
 }
 
 __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, const uint32_t *__restrict__ hitQuery) {
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, const uint32_t *
     if (!canBeCovered(a.covThr, a.covMode, (float) qLen, (float) tLen)) return;
     // computeUngappedAlignment (DistanceCalculator.h:93-113) on the 16-bit diagonal
     const unsigned short u = (unsigned short) (short) hit.diagonal;
-    Diag best; best.score = 0; best.diagLen = 0; best.dist = 0; best.diagonal = 0; best.ident = 0; best.any = false;
+    Diag best; best.score = 0; best.diagLen = 0; best.dist = 0; best.diagonal = 0; best.ident = 0; best.ry = 0xFFFFu; best.any = false;
     for (unsigned d = 1; d <= 1 + tLen / 32768; d++) scoreDiagonal(a, qw, qLen, qN, isReverse, tw, tLen, tN, (int) (-(int) d * 65536 + (int) u), best);
     for (unsigned d = 0; d <= qLen / 65536; d++) scoreDiagonal(a, qw, qLen, qN, isReverse, tw, tLen, tN, (int) (d * 65536 + u), best);
     if (!best.any) return;   // score 0 on every probe: E-value(0) never passes; (identity of an all-N sequence is not representable)
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, const uint32_t *
     // what a reader of the text record gets back: fastSeqIdToBuffer truncates to 3 decimals, "1.00" for 1 (Util.cpp:278-307)
     r.seqId = (seqId == 1.0f) ? 1.0f : (float) ((double) (int) (seqId * 1000) / 1000.0);
     a.tmp[h] = r;
+    a.tmpRy[h] = (uint16_t) min(best.ry, 0xFFFFu);
     a.valid[h] = 1;
 }
 
@@ -147,12 +151,12 @@ __global__ void k_count_valid(const uint64_t *__restrict__ off, const uint8_t *_
     for (uint64_t h = off[q]; h < off[q + 1]; h++) c += valid[h];
     cnt[q] = c;
 }
-__global__ void k_scatter(const uint64_t *__restrict__ off, const uint8_t *__restrict__ valid, const AlnRec *__restrict__ tmp, uint32_t n,
-                          const uint64_t *__restrict__ outOff, AlnRec *__restrict__ out) {
+__global__ void k_scatter(const uint64_t *__restrict__ off, const uint8_t *__restrict__ valid, const AlnRec *__restrict__ tmp, const uint16_t *__restrict__ tmpRy, uint32_t n,
+                          const uint64_t *__restrict__ outOff, AlnRec *__restrict__ out, uint16_t *__restrict__ outRy) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     uint64_t o = outOff[q];
-    for (uint64_t h = off[q]; h < off[q + 1]; h++) if (valid[h]) out[o++] = tmp[h];
+    for (uint64_t h = off[q]; h < off[q + 1]; h++) if (valid[h]) { out[o] = tmp[h]; outRy[o] = tmpRy[h]; o++; }
 }
 __global__ void k_len_hist(const uint32_t *__restrict__ len, uint32_t n, uint32_t *__restrict__ present) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,8 +170,8 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     const uint32_t n = (uint32_t) db->n;
     const uint64_t nHits = hits->count;
     if (db->maxLen >= (1u << 30)) { cdm_set_error("cdm_rescore: sequence too long"); return CDM_ERR_UNSUPPORTED; }
-    DevBuf<uint32_t> dPresent, owner; DevBuf<int32_t> dMin; DevBuf<AlnRec> tmp; DevBuf<uint8_t> valid; DevBuf<uint64_t> cnt; DevBuf<char> scanTmp;
-    if (!dPresent.alloc(db->maxLen + 1) || !dMin.alloc(db->maxLen + 1) || !owner.alloc(nHits) || !tmp.alloc(nHits) || !valid.alloc(nHits) || !cnt.alloc((size_t) n + 1)) {
+    DevBuf<uint32_t> dPresent, owner; DevBuf<int32_t> dMin; DevBuf<AlnRec> tmp; DevBuf<uint16_t> tmpRy; DevBuf<uint8_t> valid; DevBuf<uint64_t> cnt; DevBuf<char> scanTmp;
+    if (!dPresent.alloc(db->maxLen + 1) || !dMin.alloc(db->maxLen + 1) || !owner.alloc(nHits) || !tmp.alloc(nHits) || !tmpRy.alloc(nHits) || !valid.alloc(nHits) || !cnt.alloc((size_t) n + 1)) {
         cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP;
     }
     // E-value gate table for the lengths that occur (host ALP arithmetic, host/evalue.cpp)
@@ -191,7 +195,7 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     RescoreArgs a;
     a.woff.m = a.len.m = a.hasN.m = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.hoff = hits->off; a.hit = hits->rec;
     a.minScore = dMin.p; a.nHits = nHits; a.n = n; a.seqIdThr = par->seq_id_thr; a.covThr = par->cov_thr; a.covMode = par->cov_mode;
-    a.minAlnLen = par->min_aln_len; a.tmp = tmp.p; a.valid = valid.p;
+    a.minAlnLen = par->min_aln_len; a.tmp = tmp.p; a.tmpRy = tmpRy.p; a.valid = valid.p;
     hipEventRecord(ctx->ev0, s);
     if (nHits) hipLaunchKernelGGL(k_rescore, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, s, a, owner.p);
     hipEventRecord(ctx->ev1, s);
@@ -209,8 +213,9 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     CDM_HIP(hipMemcpyAsync(&total, res->off + n, 8, hipMemcpyDeviceToHost, s));
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_rescore: kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     res->count = total;
-    if (cdmMalloc(&res->rec, (total + 1) * sizeof(AlnRec)) != hipSuccess) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
-    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid.p, tmp.p, n, res->off, res->rec);
+    if (cdmMalloc(&res->rec, (total + 1) * sizeof(AlnRec)) != hipSuccess || cdmMalloc(&res->ryMism, (total + 1) * sizeof(uint16_t)) != hipSuccess) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
+    res->rySerial = db->serial;
+    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid.p, tmp.p, tmpRy.p, n, res->off, res->rec, res->ryMism);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_rescore: compaction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     hipEventElapsedTime(&ctx->lastMs[1], ctx->ev0, ctx->ev1);
     guard.armed = false;
