@@ -278,28 +278,54 @@ __global__ __launch_bounds__(BK_NT) void k_bucket_sort(SortArgs a) {
 // copies the listed ranges between the array and a dense staging buffer (ranges sorted by start, off = prefix sums of sizes)
 template <typename T, bool GATHER>
 __global__ __launch_bounds__(256) void k_big_copy(const unsigned long long *__restrict__ ranges /* start, end, off */, unsigned int cnt, T *arr, T *dense) {
-    for (unsigned int r = blockIdx.x; r < cnt; r += gridDim.x) {
+    // a wave per range (the ranges are a few hundred to a few thousand elements each, there can be a million of them)
+    const unsigned int lane = threadIdx.x & 63, wavesPerGrid = gridDim.x * 4;
+    for (unsigned int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < cnt; r += wavesPerGrid) {
         const unsigned long long s = ranges[3 * (size_t) r], e = ranges[3 * (size_t) r + 1], o = ranges[3 * (size_t) r + 2];
-        for (unsigned long long i = threadIdx.x; i < e - s; i += 256) {
+        for (unsigned long long i = lane; i < e - s; i += 64) {
             if (GATHER) dense[o + i] = arr[s + i]; else arr[s + i] = dense[o + i];
         }
     }
 }
 
-// host: reads the big-bucket list, returns it sorted by start with prefix offsets (device copy in `ranges`)
+inline unsigned int bigCopyGrid(unsigned int cnt) { return std::min<unsigned int>((cnt + 3) / 4, 1u << 16); }
+
+// (start, end) list in append order -> ranges sorted by start with their offsets in a dense array: rocPRIM sort by start, sizes,
+// exclusive scan.  Everything stays on the device except the total (and the first start, which the k-mer path wants).
+__global__ void k_big_sizes(const unsigned long long *__restrict__ st, const unsigned long long *__restrict__ en, unsigned int cnt, unsigned long long *__restrict__ sz) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) sz[i] = en[i] - st[i]; else if (i == cnt) sz[i] = 0;
+}
+__global__ void k_big_pack(const unsigned long long *__restrict__ st, const unsigned long long *__restrict__ en, const unsigned long long *__restrict__ off, unsigned int cnt,
+                           unsigned long long *__restrict__ ranges) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) { ranges[3 * (size_t) i] = st[i]; ranges[3 * (size_t) i + 1] = en[i]; ranges[3 * (size_t) i + 2] = off[i]; }
+}
+__global__ void k_big_split(const unsigned long long *__restrict__ list, unsigned int cnt, unsigned long long *__restrict__ st, unsigned long long *__restrict__ en) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) { st[i] = list[2 * (size_t) i]; en[i] = list[2 * (size_t) i + 1]; }
+}
 inline int loadBigList(hipStream_t s, const unsigned long long *bigList, unsigned int cnt, DevBuf<unsigned long long> &ranges, uint64_t &total,
                        unsigned long long *firstStart = nullptr) {
-    std::vector<unsigned long long> raw(2 * (size_t) cnt);
-    if (hipMemcpyAsync(raw.data(), bigList, raw.size() * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
-    std::vector<std::pair<unsigned long long, unsigned long long>> v(cnt);
-    for (unsigned int i = 0; i < cnt; i++) v[i] = {raw[2 * (size_t) i], raw[2 * (size_t) i + 1]};
-    std::sort(v.begin(), v.end());
-    std::vector<unsigned long long> h(3 * (size_t) cnt);
-    total = 0;
-    for (unsigned int i = 0; i < cnt; i++) { h[3 * (size_t) i] = v[i].first; h[3 * (size_t) i + 1] = v[i].second; h[3 * (size_t) i + 2] = total; total += v[i].second - v[i].first; }
-    if (firstStart) *firstStart = cnt ? v[0].first : ~0ull;
-    if (!ranges.alloc(h.size())) return CDM_ERR_HIP;
-    if (hipMemcpyAsync(ranges.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
+    DevBuf<unsigned long long> s0, s1, e0, e1, sz, off; DevBuf<char> tmp;
+    if (!s0.alloc(cnt) || !s1.alloc(cnt) || !e0.alloc(cnt) || !e1.alloc(cnt) || !sz.alloc((size_t) cnt + 1) || !off.alloc((size_t) cnt + 1) || !ranges.alloc(3 * (size_t) cnt)) return CDM_ERR_HIP;
+    const unsigned int g = (cnt + 256) / 256;
+    hipLaunchKernelGGL(k_big_split, dim3(g), dim3(256), 0, s, bigList, cnt, s0.p, e0.p);
+    rocprim::double_buffer<unsigned long long> ks(s0.p, s1.p), vs(e0.p, e1.p);
+    size_t tb = 0, tb2 = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tb, ks, vs, (size_t) cnt, 0, 64, s) != hipSuccess) return CDM_ERR_HIP;
+    if (rocprim::exclusive_scan(nullptr, tb2, sz.p, off.p, 0ull, (size_t) cnt + 1, rocprim::plus<unsigned long long>(), s) != hipSuccess) return CDM_ERR_HIP;
+    if (!tmp.alloc(std::max(tb, tb2) + 256)) return CDM_ERR_HIP;
+    if (rocprim::radix_sort_pairs(tmp.p, tb, ks, vs, (size_t) cnt, 0, 64, s) != hipSuccess) return CDM_ERR_HIP;
+    hipLaunchKernelGGL(k_big_sizes, dim3(g), dim3(256), 0, s, (const unsigned long long *) ks.current(), (const unsigned long long *) vs.current(), cnt, sz.p);
+    if (rocprim::exclusive_scan(tmp.p, tb2, sz.p, off.p, 0ull, (size_t) cnt + 1, rocprim::plus<unsigned long long>(), s) != hipSuccess) return CDM_ERR_HIP;
+    hipLaunchKernelGGL(k_big_pack, dim3(g), dim3(256), 0, s, (const unsigned long long *) ks.current(), (const unsigned long long *) vs.current(), (const unsigned long long *) off.p, cnt, ranges.p);
+    unsigned long long tot = 0, first = ~0ull;
+    hipMemcpyAsync(&tot, off.p + cnt, 8, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(&first, ks.current(), 8, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
+    total = tot;
+    if (firstStart) *firstStart = cnt ? first : ~0ull;
     return CDM_OK;
 }
 
@@ -332,7 +358,7 @@ inline int bucketSortKeys(hipStream_t s, const uint64_t *in, uint64_t *out, uint
     if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "bucketSortKeys: n %llu shiftHi %d: %u big buckets, %llu elements\n", (unsigned long long) n, shiftHi, cnt, (unsigned long long) total);
     DevBuf<uint64_t> d0, d1; DevBuf<char> tmp; size_t tb = 0;
     if (!d0.alloc(total) || !d1.alloc(total)) return CDM_ERR_HIP;
-    const unsigned int grid = std::min<unsigned int>(cnt, 1u << 20);
+    const unsigned int grid = bigCopyGrid(cnt);
     hipLaunchKernelGGL((k_big_copy<uint64_t, true>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, cnt, const_cast<uint64_t *>(in), d0.p);
     rocprim::double_buffer<uint64_t> db(d0.p, d1.p);
     if (rocprim::radix_sort_keys(nullptr, tb, db, (size_t) total, ign, top, s) != hipSuccess || !tmp.alloc(tb + 256)) return CDM_ERR_HIP;

@@ -976,7 +976,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
                 DevBuf<uint64_t> dk0, dk1; DevBuf<V> dv0, dv1; DevBuf<unsigned long long> ds; DevBuf<char> t; size_t tb = 0;
                 if (rc == CDM_OK && (!dk0.alloc(total) || !dk1.alloc(total) || !dv0.alloc(total) || !dv1.alloc(total) || !ds.alloc(total))) rc = CDM_ERR_HIP;
                 if (rc == CDM_OK) {
-                    const unsigned int grid = std::min<unsigned int>(nBig, 1u << 20);
+                    const unsigned int grid = bucket::bigCopyGrid(nBig);
                     hipLaunchKernelGGL((bucket::k_big_copy<uint64_t, true>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(ga.keys), dk0.p);
                     hipLaunchKernelGGL((bucket::k_big_copy<V, true>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<V *>(ga.vals), dv0.p);
                     rocprim::double_buffer<uint64_t> dk(dk0.p, dk1.p); rocprim::double_buffer<V> dv(dv0.p, dv1.p);
