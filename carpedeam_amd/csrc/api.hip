@@ -170,16 +170,16 @@ extern "C" void cdm_seqdb_free(cdm_seqdb *db) {
     delete db;
 }
 __global__ void k_build_meta(const uint32_t *__restrict__ woff, const uint32_t *__restrict__ len, const uint8_t *__restrict__ hasN, const uint8_t *__restrict__ ext,
-                             uint32_t n, SeqMeta *__restrict__ out) {
+                             const uint32_t *__restrict__ key, uint32_t n, SeqMeta *__restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SeqMeta m; m.woff = woff[i]; m.len = len[i]; m.flags = (hasN[i] ? 1u : 0u) | (ext[i] ? 2u : 0u); m.pad = 0;
+    SeqMeta m; m.woff = woff[i]; m.len = len[i]; m.flags = (hasN[i] ? 1u : 0u) | (ext[i] ? 2u : 0u); m.key = key[i];
     out[i] = m;
 }
 int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out) {
     SeqMeta *m = nullptr;
     if (cdmMalloc(&m, (db->n + 1) * sizeof(SeqMeta)) != hipSuccess) { cdm_set_error("out of device memory (sequence metadata)"); return CDM_ERR_HIP; }
-    if (db->n) hipLaunchKernelGGL(k_build_meta, dim3((unsigned) ((db->n + 255) / 256)), dim3(256), 0, ctx->stream, db->woff, db->len, db->hasN, db->ext, (uint32_t) db->n, m);
+    if (db->n) hipLaunchKernelGGL(k_build_meta, dim3((unsigned) ((db->n + 255) / 256)), dim3(256), 0, ctx->stream, db->woff, db->len, db->hasN, db->ext, db->key, (uint32_t) db->n, m);
     *out = m;
     return CDM_OK;
 }

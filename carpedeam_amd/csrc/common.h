@@ -97,10 +97,11 @@ struct cdm_seqdb {
 // Per-sequence metadata gathered by target id in rescore / correction / extension: one 16-byte record instead of four arrays
 // (a random target then costs one cache line, not four).  Built per call from the cdm_seqdb arrays (cdm_build_meta, api.hip);
 // the proxies keep the kernels' `a.len[t]` spelling.
-struct SeqMeta { uint32_t woff, len, flags, pad; };      // flags: 1 = has N, 2 = wasExtended
+struct SeqMeta { uint32_t woff, len, flags, key; };      // flags: 1 = has N, 2 = wasExtended
 struct MetaWoff { const SeqMeta *m; __host__ __device__ uint32_t operator[](uint32_t i) const { return m[i].woff; } };
 struct MetaLen { const SeqMeta *m; __host__ __device__ uint32_t operator[](uint32_t i) const { return m[i].len; } };
 struct MetaHasN { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) (m[i].flags & 1u); } };
+struct MetaKey { const SeqMeta *m; __host__ __device__ uint32_t operator[](uint32_t i) const { return m[i].key; } };
 struct MetaExt { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) ((m[i].flags >> 1) & 1u); } };
 int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out);      // cdmFree the result
 

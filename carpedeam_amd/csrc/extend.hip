@@ -35,8 +35,8 @@ struct Cand {
 };
 
 struct ExtArgs {
-    MetaWoff woff; MetaLen len; MetaHasN hasN; MetaExt ext;      // per-sequence metadata, one record per sequence
-    const uint32_t *key, *codes, *nmask;
+    MetaWoff woff; MetaLen len; MetaHasN hasN; MetaExt ext; MetaKey key;      // per-sequence metadata, one record per sequence
+    const uint32_t *codes, *nmask;
     const uint64_t *aoff;
     const AlnRec *rec;
     const uint32_t *active; const unsigned int *nActive;
@@ -459,7 +459,7 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     DevBuf<SeqMeta> meta;
     if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
     ExtArgs A;
-    A.woff.m = A.len.m = A.hasN.m = A.ext.m = meta.p; A.key = db->key; A.codes = db->codes; A.nmask = db->nmask;
+    A.woff.m = A.len.m = A.hasN.m = A.ext.m = A.key.m = meta.p; A.codes = db->codes; A.nmask = db->nmask;
     A.aoff = alns->off; A.rec = alns->rec; A.active = active.p; A.nActive = nActive.p; A.lut = ctx->lutDev; A.cand = cand.p; A.lists = lists.p;
     A.newLen = newLen.p; A.nLeft = nLeft.p; A.nRight = nRight.p; A.leftTotal = leftTotal.p; A.scores = scores ? dScores.p : nullptr;
     A.seqIdThr = par->seq_id_thr; A.rySeqIdThr = par->ry_seq_id_thr; A.likelihoodThr = par->likelihood_threshold;
