@@ -32,7 +32,7 @@ def short(name):
     m = re.search(r"wrapped_(\w+?)_config<(.*?)>, \(rocprim::\w+::detail::target_arch\)", n)
     if "rocprim" in n and m:
         parts = _split_top(m.group(2))
-        sub = "onesweep_iteration" if "onesweep_iteration" in n else ("onesweep_histograms" if "onesweep_global_offsets" in n else m.group(1))
+        sub = "onesweep_iteration" if "onesweep_iteration" in n else ("onesweep_digit_histograms" if "onesweep_global_offsets" in n else ("onesweep_scan_histograms" if "onesweep_scan" in n else m.group(1)))
         bits = re.search(r">, (\d+)u, \(", parts[0])               # a non-default onesweep configuration
         types = ", ".join(parts[1:]).replace("unsigned long long", "u64").replace("unsigned long", "u64").replace("unsigned int", "u32")
         types = re.sub(r"rocprim::\w+::empty_type", "-", types)
