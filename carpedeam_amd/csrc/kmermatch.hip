@@ -109,6 +109,8 @@ template <typename LY> struct ExtractArgs {
     const uint64_t *slotOff;    // [n+1] first slot of every sequence: 1 whole-sequence tuple + one slot per k-mer position;
                                 // unused slots hold the key ~0 (sorts last, dropped by k_groups)
     uint32_t *slowShort, *slowLong; unsigned int *slowCnt;   // sequences the fast kernel hands to the general one
+    uint32_t *single;           // sequences k_extract_pair hands to k_extract_fast (count in slowCnt[2])
+    const unsigned int *listCount;   // device-side length of `list` for k_extract_fast (NULL: all sequences)
     uint32_t n;
     // The whole-sequence hash tuple (63 random bits) lives in a second region behind the k-mer slots, [hashBase, hashBase+n),
     // at the sequence's rank in (length desc, id asc) order, unless its key happens to fit the 2k bits of a k-mer (then it
@@ -179,7 +181,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long *table = sTable[wave];
     const int k = a.k;
-    for (uint32_t seq = blockIdx.x * FAST_WAVES + wave; seq < a.n; seq += gridDim.x * FAST_WAVES) {
+    const uint32_t nItems = a.listCount ? *a.listCount : a.n;
+    for (uint32_t item = blockIdx.x * FAST_WAVES + wave; item < nItems; item += gridDim.x * FAST_WAVES) {
+        const uint32_t seq = a.listCount ? a.list[item] : item;
         const uint32_t L = a.len[seq], w0 = a.woff[seq];
         const bool hasN = a.hasN[seq] != 0;
         const uint32_t nPos = (L >= (uint32_t) k) ? (L - k + 1) : 0;
@@ -241,6 +245,66 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
     }
 }
 
+
+// Short reads, two per wavefront: a half-wave per sequence, three consecutive positions per lane (one 64-bit window and one
+// bit reversal serve all three), each half with its own LDS hash set.  A 100 bp read has 81 positions: 27 busy lanes per half
+// instead of 41 of 64 with a wave per read, and the per-sequence bookkeeping is shared by two sequences.  Sequences that do not
+// fit (N letters, more than 96 positions, not every k-mer taken) go to k_extract_fast through the `single` list.
+constexpr int PAIR_POS = 96, PAIR_TABLE = 256;
+template <typename LY>
+__global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_pair(ExtractArgs<LY> a) {
+    __shared__ unsigned long long sTable[FAST_WAVES][2 * PAIR_TABLE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+    unsigned long long *table = sTable[wave] + half * PAIR_TABLE;
+    const int k = a.k;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+    const uint32_t nPairs = (a.n + 1) / 2;
+    for (uint32_t pr = blockIdx.x * FAST_WAVES + wave; pr < nPairs; pr += gridDim.x * FAST_WAVES) {
+        const uint32_t seq = 2 * pr + (uint32_t) half;
+        const bool have = seq < a.n;
+        uint32_t L = 0, w0 = 0; bool hasN = false; uint64_t base = 0;
+        if (have) { L = a.len[seq]; w0 = a.woff[seq]; hasN = a.hasN[seq] != 0; base = a.slotOff[seq]; }
+        const uint32_t nPos = (L >= (uint32_t) k) ? (L - k + 1) : 0;
+        const size_t cap = (size_t) (float) ((float) (a.kmersPerSeq - 1) + (a.scale * (float) L));
+        const bool elig = have && nPos <= cap && nPos <= (uint32_t) PAIR_POS && !hasN;
+        if (have && !elig && hl == 0) a.single[atomicAdd(&a.slowCnt[2], 1u)] = seq;
+        for (int i = hl; i < PAIR_TABLE; i += 32) table[i] = ~0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+        bool dup = false;
+        auto emit = [&](uint64_t w, uint64_t idx, uint32_t pos) {
+            const uint64_t rc = (w ^ 0xAAAAAAAAAAAAAAAAull) & kmask;     // Util::revComplement(idx): window order, complemented
+            if (rc != idx) {
+                const bool pickRev = rc < idx;
+                const uint64_t km = pickRev ? rc : idx;
+                const uint32_t p = pickRev ? (L - pos - k) : pos;
+                if (a.ignoreMultiKmer) {
+                    uint32_t h = (uint32_t) ((km * 0x9E3779B97F4A7C15ull) >> 40) & (PAIR_TABLE - 1);
+                    while (true) {
+                        const unsigned long long old = atomicCAS(&table[h], ~0ull, (unsigned long long) km);
+                        if (old == ~0ull) break;
+                        if (old == km) { dup = true; break; }
+                        h = (h + 1) & (PAIR_TABLE - 1);
+                    }
+                }
+                LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom);
+            } else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
+        };
+        const uint32_t pos = 3u * (uint32_t) hl;
+        if (elig && pos < nPos) {
+            const uint64_t xr = kmerWindow(a.codes, w0, pos, (L + 15) / 16 - 1, k);     // k + 2 bases
+            const uint64_t wA = xr & kmask, idxA = groupsReversed(wA, k);
+            emit(wA, idxA, pos);
+            if (pos + 1 < nPos) {
+                const uint64_t idxB = ((idxA << 2) & kmask) | ((xr >> (2 * k)) & 3ull);
+                emit((xr >> 2) & kmask, idxB, pos + 1);
+                if (pos + 2 < nPos) emit((xr >> 4) & kmask, ((idxB << 2) & kmask) | ((xr >> (2 * k + 2)) & 3ull), pos + 2);
+            }
+        }
+        const unsigned long long dm = __ballot(dup);
+        if ((half ? (dm >> 32) : (dm & 0xFFFFFFFFull)) != 0ull && hl == 0) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;   // rewritten by k_extract
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 // sort element of the per-sequence ordering compareByScoreReverse (kmermatcher.h:30-46): (score, kmer|bit63, pos)
 struct SeqPos { uint64_t a, b; };   // a = score << 48 | kmer63 >> 15 ; b = (kmer63 & 0x7FFF) << 49 | pos << 1 | forward
@@ -814,9 +878,9 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
 
     DevBuf<unsigned long long> counters;      // scratch counters ([2] = number of kept group tuples)
     DevBuf<unsigned int> cls;                 // slow-path list sizes
-    DevBuf<uint32_t> listShort, listLong;
+    DevBuf<uint32_t> listShort, listLong, listSingle;
     DevBuf<unsigned long long> slots; DevBuf<uint64_t> slotOff; DevBuf<uint32_t> rankOf;
-    if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1) || !rankOf.alloc(n)) {
+    if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !listSingle.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1) || !rankOf.alloc(n)) {
         cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP;
     }
     hipMemsetAsync(counters.p, 0, 8 * 8, s);
@@ -860,7 +924,13 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     ea.list = nullptr; ea.nList = 0; ea.hashBase = kmerSlots; ea.rankOf = rankOf.p;
     hipEventRecord(ctx->ev0, s);
     hipLaunchKernelGGL(k_seq_hash<LY>, dim3((n + 255) / 256), dim3(256), 0, s, ea);
+    ea.single = listSingle.p; ea.listCount = nullptr;
+    if (k <= 30) {      // two short reads per wave; what does not fit comes back through the `single` list
+        hipLaunchKernelGGL(k_extract_pair<LY>, dim3(std::min<uint32_t>(((n + 1) / 2 + FAST_WAVES - 1) / FAST_WAVES, ctx->cuCount * 16)), dim3(64 * FAST_WAVES), 0, s, ea);
+        ea.list = listSingle.p; ea.listCount = cls.p + 2;
+    }
     hipLaunchKernelGGL(k_extract_fast<LY>, dim3(std::min<uint32_t>((n + FAST_WAVES - 1) / FAST_WAVES, ctx->cuCount * 16)), dim3(64 * FAST_WAVES), 0, s, ea);
+    ea.listCount = nullptr;
     unsigned int hcls[2] = {0, 0};
     hipMemcpyAsync(hcls, cls.p, 8, hipMemcpyDeviceToHost, s);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
