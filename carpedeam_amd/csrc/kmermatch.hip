@@ -1,7 +1,7 @@
 // kmermatcher (linclust-style k-mer matching) on the device, single-split semantics.
 //
 // Replaces lib/mmseqs/src/linclust/kmermatcher.cpp doComputation (:391-451) and the result writer (:815-930, :717-729):
-//   K1 k_seq_hash, k_extract_fast, k_extract   fillKmerPositionArray :77-388  per sequence: canonical k-mers, XXH64 16-bit
+//   K1 k_seq_hash, k_extract_pair, k_extract_fast, k_extract   fillKmerPositionArray :77-388  per sequence: canonical k-mers, XXH64 16-bit
 //                     min-hash, per-sequence ordering by (hash, k-mer, pos) for the repeated-k-mer skipping and the bottom-m
 //                     selection, + the whole-sequence hash tuple
 //   K2 sort 1         :412   stable sort on the k-mer: the top 32 bits by rocPRIM radix passes, the low bits per bucket on chip
