@@ -715,36 +715,64 @@ __global__ __launch_bounds__(256) void k_seg_place(VoteArgs a, const unsigned lo
                                                    const uint64_t *__restrict__ off, HitRec *__restrict__ out) {
     __shared__ uint64_t sKeys[CP_LDS];
     __shared__ uint64_t sPrev;
+    __shared__ __align__(8) uint16_t sFirst[CP_TILE / 16 + 4];       // "starts a (rep, target) segment" bits, 16 per thread = one bit array
     const uint64_t base = (uint64_t) blockIdx.x * CP_TILE;
 #pragma unroll
     for (int j = 0; j < CP_ITEMS; j++) { const int li = threadIdx.x + 256 * j; const uint64_t i = base + li; sKeys[padIdx(li)] = (i < a.n) ? a.keys[i] : ~0ull; }
     if (threadIdx.x == 0) sPrev = base ? a.keys[base - 1] : ~0ull;
+    if (threadIdx.x < 4) sFirst[CP_TILE / 16 + threadIdx.x] = 0;
     __syncthreads();
     const int shift = a.diagBits + 1;
-    const uint64_t idMask = (1ull << a.idBits) - 1;
-    unsigned int c = 0, mask = 0;
+    const uint64_t idMask = (1ull << a.idBits) - 1, diagMask = (1ull << a.diagBits) - 1;
+    const int tileEnd = (int) min((uint64_t) CP_TILE, a.n - base);
+    unsigned int c = 0, mask = 0, firstBits = 0;
 #pragma unroll
     for (int j = 0; j < CP_ITEMS; j++) {
         const int li = threadIdx.x * CP_ITEMS + j;
-        if (base + li >= a.n) break;
+        if (li >= tileEnd) break;
         const uint64_t seg = sKeys[padIdx(li)] >> shift;
         const uint64_t prevSeg = ((li == 0) ? sPrev : sKeys[padIdx(li - 1)]) >> shift;
         const bool first = (base + li == 0) || prevSeg != seg;
+        if (first) firstBits |= 1u << j;
         if (first && (uint32_t) (seg & idMask) != (uint32_t) (seg >> a.idBits)) { c++; mask |= 1u << j; }
     }
+    sFirst[threadIdx.x] = (uint16_t) firstBits;
     typedef hipcub::BlockScan<unsigned int, 256> BS;
     __shared__ typename BS::TempStorage tmp;
     unsigned int pre;
-    BS(tmp).ExclusiveSum(c, pre);
+    BS(tmp).ExclusiveSum(c, pre);       // (its barriers also publish sFirst)
     unsigned long long rank = tileOff[blockIdx.x] + pre;   // number of hit-producing segments before this one, whole array
+    const unsigned long long *firstWords = reinterpret_cast<const unsigned long long *>(sFirst);
 #pragma unroll 1
     while (mask) {   // one copy of the walk in the instruction stream (an unrolled x16 body thrashes the instruction cache)
         const int j = __ffs(mask) - 1;
         mask &= mask - 1;
         const int li = threadIdx.x * CP_ITEMS + j;
-        const uint64_t seg = sKeys[padIdx(li)] >> shift;
+        const uint64_t k0 = sKeys[padIdx(li)], seg = k0 >> shift;
         const uint32_t target = (uint32_t) (seg & idMask), rep = (uint32_t) (seg >> a.idBits);
-        out[off[rep] + 1 + (rank - perRepScan[rep])] = voteSegmentTile(a, sKeys, base, li, target);
+        // Most segments are one run of one diagonal that ends where the next segment starts: the next start is the next set bit
+        // of the bit array; if the tuple there has another target id (no run-on into the next representative) and the first
+        // and last tuples of the segment agree on the diagonal (they are sorted by it), the vote is known without a walk.
+        HitRec h; bool quick = false;
+        {
+            int e = -1;
+            for (int w = (li + 1) >> 6; w < CP_TILE / 64 && e < 0; w++) {
+                unsigned long long m = firstWords[w];
+                if (w == ((li + 1) >> 6)) m &= ~0ull << ((li + 1) & 63);
+                if (m) e = w * 64 + __ffsll(m) - 1;
+            }
+            if (e > 0 && e < tileEnd) {
+                const uint64_t kn = sKeys[padIdx(e)], kl = sKeys[padIdx(e - 1)];
+                if ((uint32_t) ((kn >> shift) & idMask) != target && ((k0 >> 1) & diagMask) == ((kl >> 1) & diagMask)) {
+                    h.target = target;
+                    h.score = (kl & 1ull) ? (e - li) : -(e - li);
+                    h.diagonal = (int) (short) ((int) ((k0 >> 1) & diagMask) - a.diagBias);
+                    quick = true;
+                }
+            }
+        }
+        if (!quick) h = voteSegmentTile(a, sKeys, base, li, target);
+        out[off[rep] + 1 + (rank - perRepScan[rep])] = h;
         rank++;
     }
 }
