@@ -1,11 +1,11 @@
 // Finishing a most-significant-digit sort inside small buckets.
 //
 // Both sorts of kmermatcher (kmermatcher.cpp:412 by k-mer, :431 by (rep, id, diagonal)) order a few 10^9 tuples.  A
-// least-significant-digit radix sort streams the whole array through HBM once per 8 key bits.  Here only the TOP 32 bits go
-// through those global passes (rocPRIM onesweep); what is left are runs of equal high bits ("buckets") that are contiguous in
+// least-significant-digit radix sort streams the whole array through HBM once per 8 key bits.  Here only the TOP bits (27 for the
+// k-mer sort, 32 for the group-key sort) go through those global passes (rocPRIM onesweep); what is left are runs of equal high bits ("buckets") that are contiguous in
 // memory, and they are finished on chip: a wavefront takes a group of consecutive whole buckets (up to 256 elements, or one
 // bucket of up to 512), builds one word per element = (bucket ordinal, low key bits, position) and sorts the words with a
-// bitonic network held in registers (exchanges between lanes are shuffles).  The position is part of the compared word, so the
+// bitonic network held in registers (exchanges between lanes are DPP row permutations / ds_swizzle).  The position is part of the compared word, so the
 // result is the same stable order the reference's std::sort / ips4o comparators produce on the full key.
 //
 // Work distribution: no block-level synchronisation at all.  The array is cut into ranges of WV_OWN slots; a WAVE owns the

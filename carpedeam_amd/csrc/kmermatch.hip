@@ -4,7 +4,7 @@
 //   K1 k_seq_hash, k_extract_pair, k_extract_fast, k_extract   fillKmerPositionArray :77-388  per sequence: canonical k-mers, XXH64 16-bit
 //                     min-hash, per-sequence ordering by (hash, k-mer, pos) for the repeated-k-mer skipping and the bottom-m
 //                     selection, + the whole-sequence hash tuple
-//   K2 sort 1         :412   stable sort on the k-mer: the top 32 bits by rocPRIM radix passes, the low bits per bucket on chip
+//   K2 sort 1         :412   stable sort on the k-mer: the top 27 sort bits by rocPRIM radix passes, the low bits per bucket on chip
 //   K3 k_bucket_groups (k_groups)   assignGroup :453-562  first sequence of every k-mer run by (length desc, id, pos) is the
 //                     representative; members become (rep, id, diagonal, strand); singletons dropped.  Fused with the
 //                     on-chip part of sort 1 (bucket.h)

@@ -24,17 +24,40 @@ template <typename C> float run(uint64_t *k0, uint64_t *k1, uint32_t *v0, uint32
     printf("%s bits [%d,%d): %.1f ms\n", name, b0, b1, best); fflush(stdout);
     hipFree(tmp); return best;
 }
+template <typename C> float runk(uint64_t *k0, uint64_t *k1, size_t n, int b0, int b1, const char *name) {
+    rocprim::double_buffer<uint64_t> kb(k0, k1);
+    size_t tb = 0; void *tmp = nullptr;
+    if (rocprim::radix_sort_keys<C>(nullptr, tb, kb, n, b0, b1, 0) != hipSuccess) { printf("%s: size query failed\n", name); return -1; }
+    hipMalloc(&tmp, tb);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int it = 0; it < 3; it++) {
+        hipEventRecord(e0, 0);
+        hipError_t e = rocprim::radix_sort_keys<C>(tmp, tb, kb, n, b0, b1, 0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        if (e != hipSuccess || hipGetLastError() != hipSuccess) { printf("%s: sort failed\n", name); return -1; }
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    printf("keys %s bits [%d,%d): %.1f ms\n", name, b0, b1, best); fflush(stdout);
+    hipFree(tmp); return best;
+}
 int main(int argc, char **argv) {
     size_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 1000000000ull;
     uint64_t *k0, *k1; uint32_t *v0, *v1;
     hipMalloc(&k0, n * 8); hipMalloc(&k1, n * 8); hipMalloc(&v0, n * 4); hipMalloc(&v1, n * 4);
     fill<<<(unsigned) ((n + 255) / 256), 256>>>(k0, v0, n); hipDeviceSynchronize();
     run<rocprim::default_config>(k0, k1, v0, v1, n, 9, 41, "default 4x8");
-    run<Cfg<8, 1024, 8>>(k0, k1, v0, v1, n, 9, 41, "cfg 8b 1024x8");
-    run<Cfg<9, 1024, 8>>(k0, k1, v0, v1, n, 14, 41, "cfg 9b 1024x8 (3 passes)");
-    run<Cfg<9, 512, 12>>(k0, k1, v0, v1, n, 14, 41, "cfg 9b 512x12 (3 passes)");
-    run<Cfg<9, 1024, 6>>(k0, k1, v0, v1, n, 14, 41, "cfg 9b 1024x6 (3 passes)");
-    run<Cfg<10, 1024, 6>>(k0, k1, v0, v1, n, 11, 41, "cfg 10b 1024x6 (3 passes)");
-    run<Cfg<10, 512, 8>>(k0, k1, v0, v1, n, 11, 41, "cfg 10b 512x8 (3 passes)");
+    run<Cfg<9, 512, 16>>(k0, k1, v0, v1, n, 14, 41, "cfg 9b 512x16 (3 passes)");
+    run<Cfg<9, 512, 20>>(k0, k1, v0, v1, n, 14, 41, "cfg 9b 512x20 (3 passes)");
+    run<Cfg<9, 256, 32>>(k0, k1, v0, v1, n, 14, 41, "cfg 9b 256x32 (3 passes)");
+    run<Cfg<9, 768, 12>>(k0, k1, v0, v1, n, 14, 41, "cfg 9b 768x12 (3 passes)");
+    run<Cfg<9, 640, 14>>(k0, k1, v0, v1, n, 14, 41, "cfg 9b 640x14 (3 passes)");
+    runk<rocprim::default_config>(k0, k1, n, 9, 41, "default 4x8");
+    runk<Cfg<9, 1024, 8>>(k0, k1, n, 14, 41, "cfg 9b 1024x8 (3 passes)");
+    runk<Cfg<8, 512, 24>>(k0, k1, n, 9, 41, "cfg 8b 512x24");
+    runk<Cfg<8, 1024, 12>>(k0, k1, n, 9, 41, "cfg 8b 1024x12");
+    runk<Cfg<8, 768, 16>>(k0, k1, n, 9, 41, "cfg 8b 768x16");
+    runk<Cfg<8, 512, 16>>(k0, k1, n, 9, 41, "cfg 8b 512x16");
+    runk<Cfg<8, 1024, 16>>(k0, k1, n, 9, 41, "cfg 8b 1024x16");
     return 0;
 }
