@@ -89,12 +89,16 @@ __device__ __noinline__ uint32_t callBaseExact(const double *lt, const double *l
 constexpr uint64_t ALL_SLOTS = (1ull << 44) - 1ull;
 template <typename F>
 __device__ __forceinline__ uint32_t callBase(const double *sLogT, const double *sLogQ, const double *sLogD, uint32_t qb, uint32_t p, uint32_t qLen,
-                                             bool qWasExt, F counts, uint64_t mask, bool &keep) {
-    uint64_t covPacked = 0;         // four 16-bit coverage counters, target base tb in bits 16 tb .. (at most 65535 records pile up)
+                                             bool qWasExt, F counts, uint64_t mask, bool &keep, uint64_t covPacked = ~0ull) {
+    // covPacked: four 16-bit coverage counters, target base tb in bits 16 tb .. (at most 65535 records pile up); callers that
+    // counted them while piling up pass them in, ~0 = sum the slots here
+    if (covPacked == ~0ull) {
+        covPacked = 0;
 #pragma unroll 1
-    for (uint64_t m = mask; m; m &= m - 1) {
-        const int slot = __ffsll((unsigned long long) m) - 1;
-        covPacked += (uint64_t) (counts(slot) & 0xFFFFu) << (16 * (slot / 11));
+        for (uint64_t m = mask; m; m &= m - 1) {
+            const int slot = __ffsll((unsigned long long) m) - 1;
+            covPacked += (uint64_t) (counts(slot) & 0xFFFFu) << (16 * (slot / 11));
+        }
     }
     const uint32_t cov[4] = {(uint32_t) (covPacked & 0xFFFF), (uint32_t) ((covPacked >> 16) & 0xFFFF), (uint32_t) ((covPacked >> 32) & 0xFFFF), (uint32_t) (covPacked >> 48)};
     const uint32_t total = cov[0] + cov[1] + cov[2] + cov[3];
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
         for (uint32_t base = 0; base < qLen; base += 64) {
             const uint32_t p = base + lane;
             uint64_t touched = 0;       // slots of this lane's column that are non-zero
+            uint64_t covPacked = 0;     // records per target base (16 bits each), counted on the way
             for (int r = 0; r < nAcc; r++) {
                 const RecInfo ri = recs[r];
                 if ((uint32_t) ri.qe < base || (uint32_t) ri.qs >= base + 64) continue;   // wave uniform
@@ -343,6 +348,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
                     const uint32_t slot = tb * 11 + cls;
                     cnt[slot][lane] += (uint16_t) (1u + ((ri.flags & 1u) ? 0x100u : 0u));
                     touched |= 1ull << slot;
+                    covPacked += 1ull << (16 * tb);
                 }
             }
             uint32_t newCode = 0; bool keep = true;
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
                 const bool qIsN = qHasN && cdm_isN(a.nmask, qw, p);
                 if (qIsN) qb = 0;
                 newCode = callBase(sLogT, sLogQ, sLogD, qb, p, qLen, qWasExt,
-                                   [&](int slot) { const uint32_t v = cnt[slot][lane]; return (v & 0xFFu) | ((v >> 8) << 16); }, touched, keep);
+                                   [&](int slot) { const uint32_t v = cnt[slot][lane]; return (v & 0xFFu) | ((v >> 8) << 16); }, touched, keep, covPacked);
             }
             for (uint64_t m = touched; m; m &= m - 1) cnt[__ffsll((unsigned long long) m) - 1][lane] = 0;
             const uint64_t b0 = cdm_ballot((newCode & 1u) != 0), b1 = cdm_ballot((newCode & 2u) != 0);
