@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcarpedeam_hip.so")
+LIB_PATH = os.environ.get("CDM_LIB", os.path.join(HERE, "libcarpedeam_hip.so"))      # CDM_LIB: another build of the library (bisecting)
 
 HIT_DTYPE = np.dtype([("target", "<u4"), ("score", "<i4"), ("diagonal", "<i4")])
 ALN_DTYPE = np.dtype([("target", "<u4"), ("raw_score", "<i4"), ("ident", "<i4"), ("q_start", "<i4"), ("q_end", "<i4"),

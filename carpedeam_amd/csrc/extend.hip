@@ -265,7 +265,18 @@ __global__ __launch_bounds__(64) void k_extend(ExtArgs A) {
     }
     if (nCand == 0) { A.newLen[q] = 0; return; }
     uint32_t maxLeft = 0, maxRight = 0;
-    for (uint32_t k = 0; k < nCand; k++) updateIds(A, Q, cand[k], maxLeft, maxRight);
+    for (uint32_t k = 0; k < nCand; k++) {
+        Cand &c = cand[k];
+        if (Q.plain && !A.hasN[c.target] && c.target != qKey) {      // (the candidate pass compares the target id with the query key)
+            // updateSeqIdConsensusReads would count the very columns the candidate pass above just counted (an end overlap of
+            // two sequences without N): seqId / rySeqId stand, only the longest overlap per side is updated
+            const bool rightStart = (uint32_t) c.ds == 0 && (uint32_t) c.qe == (qLen0 - 1);
+            const bool leftStart = (uint32_t) c.qs == 0 && (uint32_t) c.de == (c.dbLen - 1);
+            const uint32_t offset = c.dbLen - c.alnLen;
+            const uint32_t tot = leftStart ? min(c.dbLen - offset, qLen0) : (rightStart ? min(c.alnLen, c.dbLen) : 0u);
+            if (leftStart && tot > maxLeft) maxLeft = tot; else if (rightStart && tot > maxRight) maxRight = tot;
+        } else updateIds(A, Q, c, maxLeft, maxRight);
+    }
     // ---- D
     Heap heap; heap.h = heapL; heap.n = 0; heap.cand = cand;
     for (uint32_t k = 0; k < nCand; k++) {

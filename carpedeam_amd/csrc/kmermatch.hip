@@ -313,6 +313,114 @@ __device__ __forceinline__ uint64_t spKmer63(const SeqPos &x) { return ((x.a & 0
 __device__ __forceinline__ uint32_t spScore(const SeqPos &x) { return (uint32_t) (x.a >> 48); }
 __device__ __forceinline__ uint32_t spPos(const SeqPos &x) { return (uint32_t) ((x.b >> 1) & 0xFFFFFFFFFFFFull); }
 
+// the (score, k-mer, position, strand) record of the k-mer at pos, false if it has an N or is its own reverse complement
+// (Sequence::nextKmer + Indexer::computeKmerIdx, canonical pick kmermatcher.cpp:155-190)
+template <typename LY>
+__device__ __forceinline__ bool makeSeqPos(const ExtractArgs<LY> &a, uint32_t w0, uint32_t L, uint32_t lastWord, bool hasN, int k, uint32_t pos, SeqPos &e) {
+    // k bases starting at pos in MMseqs coding (gray code of ours), first base most significant
+    uint64_t idx = 0; bool x = false;
+    for (int j = 0; j < k; j += 16) {
+        uint32_t w = cdm_window16(a.codes, w0, pos + j, lastWord);
+        w ^= (w >> 1) & 0x55555555u;                       // A,C,G,T -> A,C,T,G
+        const int take = min(16, k - j);
+        for (int b = 0; b < take; b++) idx = (idx << 2) | ((w >> (2 * b)) & 3u);
+    }
+    if (hasN) for (int j = 0; j < k; j++) x |= cdm_isN(a.nmask, w0, pos + j) != 0;
+    if (x) return false;
+    const uint64_t rc = revComplement(idx, k);
+    if (rc == idx) return false;
+    const bool pickRev = rc < idx;
+    const uint64_t km = pickRev ? rc : idx;
+    const uint32_t score = (uint32_t) (xxh64_u64(km, a.seed) & 0xFFFFu);
+    const uint32_t p = pickRev ? (L - pos - k) : pos;
+    e.a = ((uint64_t) score << 48) | (km >> 15);
+    e.b = ((km & 0x7FFFull) << 49) | ((uint64_t) p << 1) | (pickRev ? 0ull : 1ull);
+    return true;
+}
+
+// SequencePosition::compareByScoreReverse (kmermatcher.h:29-46): score, k-mer without the strand bit, position - NOT the strand
+__device__ __forceinline__ bool spCmp(const SeqPos &x, const SeqPos &y) { return x.a < y.a || (x.a == y.a && (x.b >> 1) < (y.b >> 1)); }
+
+// libstdc++'s std::sort (bits/stl_algo.h: introsort with median-of-three, threshold 16, heap sort below the depth limit, final
+// insertion sort), statement for statement.  The reference sorts a sequence's k-mers with it (SORT_SERIAL, kmermatcher.cpp:271)
+// and its comparator ignores the strand: when a sequence carries the same canonical k-mer at the same stored position on both
+// strands, which of the two comes first - and with it the strand of a tuple - is whatever this algorithm leaves.  Serial, one
+// thread; only such sequences come here.
+__device__ void stdAdjustHeap(SeqPos *first, long holeIndex, long len, SeqPos value) {
+    const long topIndex = holeIndex;
+    long secondChild = holeIndex;
+    while (secondChild < (len - 1) / 2) {
+        secondChild = 2 * (secondChild + 1);
+        if (spCmp(first[secondChild], first[secondChild - 1])) secondChild--;
+        first[holeIndex] = first[secondChild];
+        holeIndex = secondChild;
+    }
+    if ((len & 1) == 0 && secondChild == (len - 2) / 2) {
+        secondChild = 2 * (secondChild + 1);
+        first[holeIndex] = first[secondChild - 1];
+        holeIndex = secondChild - 1;
+    }
+    long parent = (holeIndex - 1) / 2;                          // __push_heap
+    while (holeIndex > topIndex && spCmp(first[parent], value)) { first[holeIndex] = first[parent]; holeIndex = parent; parent = (holeIndex - 1) / 2; }
+    first[holeIndex] = value;
+}
+__device__ void stdHeapSort(SeqPos *first, long n) {           // __partial_sort(first, last, last): make_heap + sort_heap
+    if (n >= 2) {
+        long parent = (n - 2) / 2;
+        while (true) { const SeqPos v = first[parent]; stdAdjustHeap(first, parent, n, v); if (parent == 0) break; parent--; }
+    }
+    for (long last = n; last > 1;) { --last; const SeqPos v = first[last]; first[last] = first[0]; stdAdjustHeap(first, 0, last, v); }
+}
+__device__ void stdUnguardedLinearInsert(SeqPos *base, long last) {
+    const SeqPos val = base[last];
+    long next = last - 1;
+    while (spCmp(val, base[next])) { base[last] = base[next]; last = next; --next; }
+    base[last] = val;
+}
+__device__ void stdInsertionSort(SeqPos *base, long first, long last) {
+    if (first == last) return;
+    for (long i = first + 1; i != last; ++i) {
+        if (spCmp(base[i], base[first])) { const SeqPos val = base[i]; for (long j = i; j > first; j--) base[j] = base[j - 1]; base[first] = val; }
+        else stdUnguardedLinearInsert(base, i);
+    }
+}
+__device__ void stdSort(SeqPos *base, long n) {
+    if (n <= 0) return;
+    // __introsort_loop with an explicit stack for its one recursive call
+    long stFirst[64], stLast[64]; int stDepth[64]; int top = 0;
+    int lg = 0; for (long v = n; v > 1; v >>= 1) lg++;
+    stFirst[0] = 0; stLast[0] = n; stDepth[0] = 2 * lg; top = 1;
+    while (top > 0) {
+        top--;
+        long first = stFirst[top], last = stLast[top]; int depth = stDepth[top];
+        while (last - first > 16) {
+            if (depth == 0) { stdHeapSort(base + first, last - first); break; }
+            --depth;
+            // __unguarded_partition_pivot
+            const long mid = first + (last - first) / 2, ia = first + 1, ib = mid, ic = last - 1;
+            long m;                                             // __move_median_to_first(first, a, b, c)
+            if (spCmp(base[ia], base[ib])) { if (spCmp(base[ib], base[ic])) m = ib; else if (spCmp(base[ia], base[ic])) m = ic; else m = ia; }
+            else if (spCmp(base[ia], base[ic])) m = ia; else if (spCmp(base[ib], base[ic])) m = ic; else m = ib;
+            { const SeqPos t = base[first]; base[first] = base[m]; base[m] = t; }
+            long lo = first + 1, hi = last;                     // __unguarded_partition(first + 1, last, first)
+            while (true) {
+                while (spCmp(base[lo], base[first])) ++lo;
+                --hi;
+                while (spCmp(base[first], base[hi])) --hi;
+                if (!(lo < hi)) break;
+                { const SeqPos t = base[lo]; base[lo] = base[hi]; base[hi] = t; }
+                ++lo;
+            }
+            const long cut = lo;
+            stFirst[top] = cut; stLast[top] = last; stDepth[top] = depth; top++;     // __introsort_loop(cut, last, depth)
+            last = cut;
+        }
+    }
+    // __final_insertion_sort
+    if (n > 16) { stdInsertionSort(base, 0, 16); for (long i = 16; i != n; ++i) stdUnguardedLinearInsert(base, i); }
+    else stdInsertionSort(base, 0, n);
+}
+
 // One workgroup of NT threads per sequence; CAP = power of two >= number of k-mers of the sequence.
 template <typename LY, int CAP, int NT>
 __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
@@ -331,25 +439,8 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
         // ---- k-mers (Sequence::nextKmer + Indexer::computeKmerIdx, canonical pick kmermatcher.cpp:155-190)
         const uint32_t lastWord = (L + 15) / 16 - 1;
         for (uint32_t pos = tid; pos < nPos; pos += NT) {
-            // k bases starting at pos in MMseqs coding (gray code of ours), first base most significant
-            uint64_t idx = 0; bool x = false;
-            for (int j = 0; j < k; j += 16) {
-                uint32_t w = cdm_window16(a.codes, w0, pos + j, lastWord);
-                w ^= (w >> 1) & 0x55555555u;                       // A,C,G,T -> A,C,T,G
-                const int take = min(16, k - j);
-                for (int b = 0; b < take; b++) idx = (idx << 2) | ((w >> (2 * b)) & 3u);
-            }
-            if (hasN) for (int j = 0; j < k; j++) x |= cdm_isN(a.nmask, w0, pos + j) != 0;
-            if (x) continue;
-            const uint64_t rc = revComplement(idx, k);
-            if (rc == idx) continue;
-            const bool pickRev = rc < idx;
-            const uint64_t km = pickRev ? rc : idx;
-            const uint32_t score = (uint32_t) (xxh64_u64(km, a.seed) & 0xFFFFu);
-            const uint32_t p = pickRev ? (L - pos - k) : pos;
             SeqPos e;
-            e.a = ((uint64_t) score << 48) | (km >> 15);
-            e.b = ((km & 0x7FFFull) << 49) | ((uint64_t) p << 1) | (pickRev ? 0ull : 1ull);
+            if (!makeSeqPos(a, w0, L, lastWord, hasN, k, pos, e)) continue;
             const uint32_t slot = atomicAdd(&sN, 1u);
             sp[slot] = e;
         }
@@ -369,6 +460,21 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
                 }
                 __syncthreads();
             }
+        // The bitonic order breaks comparator ties by the strand bit.  The reference's comparator has no such rule: if two records
+        // tie (same score, k-mer, stored position, opposite strands) redo the sort the way the reference does, from the order
+        // in which fillKmerPositionArray generated the records (ascending position).
+        {
+            int tie = 0;
+            for (uint32_t i = tid; i + 1 < n; i += NT) tie |= (sp[i].a == sp[i + 1].a && (sp[i].b >> 1) == (sp[i + 1].b >> 1));
+            if (__syncthreads_or(tie && a.ignoreMultiKmer)) {
+                if (tid == 0) {
+                    uint32_t m = 0;
+                    for (uint32_t pos = 0; pos < nPos; pos++) { SeqPos e; if (makeSeqPos(a, w0, L, lastWord, hasN, k, pos, e)) sp[m++] = e; }
+                    stdSort(sp, (long) m);
+                }
+                __syncthreads();
+            }
+        }
         // ---- selection (kmermatcher.cpp:224-240, 277-350)
         const size_t considered = min((size_t) (float) ((float) (a.kmersPerSeq - 1) + (a.scale * (float) L)), (size_t) n);
         // fast path test: no two equal k-mers next to each other, and every k-mer is taken

@@ -1,7 +1,8 @@
 """Exploratory fuzzing of the device chain against the oracle (test infrastructure; run on a GPU box):
     python scripts/fuzz_chain.py <mode> <cases> <seed>
 modes: small, deep (100x+ pile-ups, > 64 records per query), repeats (low-complexity / tandem repeats), contigparams (k = 22,
-include-only-extendable), longreads (up to 600 bp: general extraction kernel)."""
+include-only-extendable), longreads (up to 600 bp: general extraction kernel), palrepeats (tandem repeats of reverse-palindromic
+units: comparator ties in the per-sequence k-mer sort)."""
 import os
 import subprocess
 import sys
@@ -15,6 +16,7 @@ import numpy as np
 from carpedeam_amd import capi, mmdb, synth
 from gpuutil import diff_keys, run_oracle, seqdb_to_keyed
 from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
+from test_oracle_golden import pref_sign_ties
 
 mode, cases, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 rng = np.random.default_rng(seed)
@@ -30,14 +32,20 @@ if mode == "contigparams":
     kflags = " ".join(K_FLAGS).replace("-k 20", "-k 22").replace("--include-only-extendable 0", "--include-only-extendable 1").split()
     kpar = capi.KmerParams(22, 200, 0.2, 67, 1, 1, 1, 0.0)
 fails = 0
+ties = 0
 for case in range(cases):
-    G = {"small": 300, "deep": 150, "repeats": 200, "contigparams": 400, "longreads": 1500}[mode]
+    G = {"small": 300, "deep": 150, "repeats": 200, "contigparams": 400, "longreads": 1500, "palrepeats": 700}[mode]
     genome = rng.integers(0, 4, G)
     if mode == "repeats":
         unit = rng.integers(0, 4, int(rng.integers(1, 9)))
         a = int(rng.integers(0, G - 80)); genome[a:a + 80] = np.resize(unit, 80)
-    nreads = {"small": (6, 61), "deep": (150, 400), "repeats": (10, 80), "contigparams": (10, 80), "longreads": (10, 60)}[mode]
-    lr = {"small": (30, 121), "deep": (40, 101), "repeats": (30, 121), "contigparams": (40, 200), "longreads": (100, 600)}[mode]
+    if mode == "palrepeats":
+        units = ["GTACGC", "GTAC", "ACGT", "GATC", "CATG", "GCGC", "AT", "TGCA", "AGCT", "GTACGCGTAC", "ACGTTGCAACGT"]
+        for _ in range(2):
+            u = np.array(["ACGT".index(ch) for ch in units[int(rng.integers(0, len(units)))]])
+            ln = int(rng.integers(60, 300)); a = int(rng.integers(0, G - ln)); genome[a:a + ln] = np.resize(u, ln)
+    nreads = {"small": (6, 61), "deep": (150, 400), "repeats": (10, 80), "contigparams": (10, 80), "longreads": (10, 60), "palrepeats": (8, 50)}[mode]
+    lr = {"small": (30, 121), "deep": (40, 101), "repeats": (30, 121), "contigparams": (40, 200), "longreads": (100, 600), "palrepeats": (30, 320)}[mode]
     seqs = []
     for _ in range(int(rng.integers(*nreads))):
         L = int(rng.integers(*lr)); L = min(L, G - 1); st = int(rng.integers(0, G - L))
@@ -63,12 +71,20 @@ for case in range(cases):
         for it in range(3):
             hits = ctx.kmermatch(db, kpar); alns = ctx.rescore(db, hits); corr = ctx.correct(db, alns); asm = ctx.extend(corr, alns)
             i, o = t("in%d" % it), t("in%d" % (it + 1))
-            run_oracle(oracle, "kmermatcher", i, t("pref"), *kflags, "--threads", "4")
+            run_oracle(oracle, "kmermatcher", i, t("pref"), *kflags, "--threads", "1")     # (a parallel sort breaks comparator ties differently)
             run_oracle(oracle, "rescorediagonal", i, i, t("pref"), t("aln"), *R_FLAGS, "--threads", "4")
             run_oracle(oracle, "ancient_correction", i, t("aln"), t("corr"), *A_FLAGS, "--ancient-damage", t("dhigh"), "--threads", "4")
             run_oracle(oracle, "ancient_read_assemble", t("corr"), t("aln"), o, *A_FLAGS, "--ancient-damage", t("dhigh"), "--threads", "4")
             lens, keys, _ = db.meta()
             hoff, hrec = hits.download(); aoff, arec = alns.download()
+            # strand ties of the reference's global sort (reference nondeterminism): the reference's own answer depends
+            # on its thread count there; the case cannot be followed further
+            gp = mmdb.canon({k: (v, 0) for k, v in capi.hits_to_text(hoff, hrec, keys).items()}); ep = mmdb.canon({k: (v[0], 0) for k, v in mmdb.read_db(t("pref")).items()})
+            if gp != ep:
+                tie_list, other = pref_sign_ties(gp, ep)
+                if not other:
+                    ties += 1
+                    break
             bad = [("pref", diff_keys({k: (v, 0) for k, v in capi.hits_to_text(hoff, hrec, keys).items()}, {k: (v[0], 0) for k, v in mmdb.read_db(t("pref")).items()})),
                    ("aln", diff_keys({k: (v, 0) for k, v in capi.alns_to_text(aoff, arec, keys, lens, db.residues).items()}, mmdb.read_db(t("aln")))),
                    ("corr", diff_keys(seqdb_to_keyed(*corr.download()), mmdb.read_db(t("corr")))),
@@ -77,10 +93,12 @@ for case in range(cases):
             if bad:
                 fails += 1
                 print("FAIL", mode, "case", case, "iter", it, [(n, str(b)[:300]) for n, b in bad], flush=True)
-                open(t("fail_%s_%d.txt" % (mode, case)), "w").write("\n".join(seqs))
-                print("  reads saved:", t("fail_%s_%d.txt" % (mode, case)), len(seqs), flush=True)
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                fn = os.path.join(ROOT, "gpurun_out", "fuzz_fail_%s_%d_%d.txt" % (mode, seed, case))
+                open(fn, "w").write("\n".join(seqs) + "\n")
+                print("  reads saved:", fn, len(seqs), flush=True)
                 break
             db = asm
     except capi.CdmError as e:
         print("ERROR", mode, "case", case, str(e)[:300], flush=True); fails += 1
-print("mode", mode, "cases", cases, "failures", fails, flush=True)
+print("mode", mode, "cases", cases, "failures", fails, "sign-tie cases skipped", ties, flush=True)
