@@ -221,3 +221,33 @@ def test_chain_small_databases_against_reference_binary(oracle_bin, dhigh_prefix
                 for ext in ("", ".index", ".dbtype"):
                     if os.path.exists(t(f) + ext):
                         os.remove(t(f) + ext)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref (the reference's own object code) not built")
+def test_kmermatcher_palindromic_repeats_against_reference_binary(oracle_bin, tmp_path):
+    """Tandem repeats of reverse-palindromic units: the same canonical k-mer sits at the same stored position on both strands of a
+    sequence, the per-sequence comparator ties, and libstdc++'s std::sort decides (the oracle uses the same std::sort as the
+    reference; the device path emulates it, tests/test_gpu_kmermatch.py).  Ties in the reference's global ips4o sort remain
+    run-dependent: only a strand sign may differ."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    units = ["GTACGC", "GTAC", "ACGT", "GATC", "CATG", "GCGC", "AT", "TGCA", "AGCT", "GTACGCGTAC", "ACGTTGCAACGT"]
+    letters = "ACGT"
+    t = lambda s: str(tmp_path / s)
+    for case in range(60):
+        seqs = []
+        for _ in range(int(rng.integers(2, 12))):
+            u = units[int(rng.integers(0, len(units)))]
+            L = int(rng.integers(30, 300)); o = int(rng.integers(0, len(u)))
+            body = (u * (L // len(u) + 2))[o:o + L]
+            left = "".join(letters[int(x)] for x in rng.integers(0, 4, int(rng.integers(0, 4))))
+            right = "".join(letters[int(x)] for x in rng.integers(0, 4, int(rng.integers(0, 4))))
+            seqs.append(left + body + right)
+        mmdb.write_seqdb(t("in"), seqs)
+        run(oracle_bin, "kmermatcher", t("in"), t("po"), *K_FLAGS, "--threads", "1")
+        run(REF_BIN, "kmermatcher", t("in"), t("pr"), *K_FLAGS, "--threads", "1")
+        strip = lambda db: mmdb.canon({k: (v[0], 0) for k, v in db.items()})
+        ties, bad = pref_sign_ties(strip(mmdb.read_db(t("po"))), strip(mmdb.read_db(t("pr"))))
+        assert not bad, (case, seqs, bad[:3])
+        for f in os.listdir(tmp_path):
+            os.remove(t(f))
