@@ -99,6 +99,7 @@ struct LayoutPacked {
     }
 };
 
+struct SeqPos;
 template <typename LY> struct ExtractArgs {
     const uint32_t *woff, *len, *codes, *nmask;
     const uint8_t *hasN;
@@ -110,6 +111,8 @@ template <typename LY> struct ExtractArgs {
                                 // unused slots hold the key ~0 (sorts last, dropped by k_groups)
     uint32_t *slowShort, *slowLong; unsigned int *slowCnt;   // sequences the fast kernel hands to the general one
     uint32_t *single;           // sequences k_extract_pair hands to k_extract_fast (count in slowCnt[2])
+    uint32_t *slowHuge;         // sequences with 4096 k-mer positions or more (count in slowCnt[3]): k_extract with global scratch
+    SeqPos *hugeSp; uint8_t *hugeSel; uint32_t hugeCap;   // that scratch: hugeCap records per block
     const unsigned int *listCount;   // device-side length of `list` for k_extract_fast (NULL: all sequences)
     uint32_t n;
     // The whole-sequence hash tuple (63 random bits) lives in a second region behind the k-mer slots, [hashBase, hashBase+n),
@@ -190,7 +193,11 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
         const uint64_t base = a.slotOff[seq];
         const size_t cap = (size_t) (float) ((float) (a.kmersPerSeq - 1) + (a.scale * (float) L));
         if (nPos > cap || nPos > FAST_CAP) {   // wave uniform
-            if (lane == 0) { if (nPos < 256) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq; else a.slowLong[atomicAdd(&a.slowCnt[1], 1u)] = seq; }
+            if (lane == 0) {
+                if (nPos < 256) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;
+                else if (nPos < 4096) a.slowLong[atomicAdd(&a.slowCnt[1], 1u)] = seq;
+                else a.slowHuge[atomicAdd(&a.slowCnt[3], 1u)] = seq;
+            }
             continue;
         }
         // hash set sized to the sequence (load factor <= 1/2): clearing it is a large share of this kernel's LDS traffic
@@ -421,11 +428,14 @@ __device__ void stdSort(SeqPos *base, long n) {
     else stdInsertionSort(base, 0, n);
 }
 
-// One workgroup of NT threads per sequence; CAP = power of two >= number of k-mers of the sequence.
+// One workgroup of NT threads per sequence; CAP = power of two >= number of k-mers of the sequence, records in LDS; CAP = 0:
+// records in a per-block slice of global scratch (sequences with 4096 positions or more: rare, speed is not the point).
 template <typename LY, int CAP, int NT>
 __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
-    __shared__ SeqPos sp[CAP];
-    __shared__ uint8_t sel[CAP];
+    __shared__ SeqPos sSp[CAP ? CAP : 1];
+    __shared__ uint8_t sSel[CAP ? CAP : 1];
+    SeqPos *sp = CAP ? sSp : a.hugeSp + (size_t) blockIdx.x * a.hugeCap;
+    uint8_t *sel = CAP ? sSel : a.hugeSel + (size_t) blockIdx.x * a.hugeCap;
     __shared__ uint32_t sN, sCursor;
     const int tid = threadIdx.x;
     for (uint32_t item = blockIdx.x; item < a.nList; item += gridDim.x) {
@@ -1000,10 +1010,6 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     if (k < 4 || k > 31) { cdm_set_error("cdm_kmermatch: k must be in 4..31 (got %d)", k); return CDM_ERR_INVALID; }
     if (db->maxLen + 2 >= 32767u) { cdm_set_error("cdm_kmermatch: sequences of 32765 letters or more (the reference's `int` position path) are not implemented on the device yet"); return CDM_ERR_UNSUPPORTED; }
     constexpr uint32_t SHORT_CAP = 256, LONG_CAP = 4096;
-    if (db->maxLen >= (uint32_t) k && db->maxLen - k + 1 >= LONG_CAP) {
-        cdm_set_error("cdm_kmermatch: sequences with %u k-mer positions or more (max length %u) need the global per-sequence ordering, not implemented on the device yet", LONG_CAP, db->maxLen);
-        return CDM_ERR_UNSUPPORTED;
-    }
     const uint32_t idBits = bitsFor(n), diagBits = bitsFor(2ull * db->maxLen + 2);
     if (2 * idBits + diagBits + 1 > 63) { cdm_set_error("cdm_kmermatch: %u sequences x max length %u do not fit the 64-bit (rep,id,diagonal) sort key", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
     const int diagBias = (int) db->maxLen + 1;
@@ -1012,9 +1018,9 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
 
     DevBuf<unsigned long long> counters;      // scratch counters ([2] = number of kept group tuples)
     DevBuf<unsigned int> cls;                 // slow-path list sizes
-    DevBuf<uint32_t> listShort, listLong, listSingle;
+    DevBuf<uint32_t> listShort, listLong, listSingle, listHuge;
     DevBuf<unsigned long long> slots; DevBuf<uint64_t> slotOff; DevBuf<uint32_t> rankOf;
-    if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !listSingle.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1) || !rankOf.alloc(n)) {
+    if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !listSingle.alloc(n) || !listHuge.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1) || !rankOf.alloc(n)) {
         cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP;
     }
     hipMemsetAsync(counters.p, 0, 8 * 8, s);
@@ -1054,7 +1060,8 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     ExtractArgs<LY> ea; ea.geom = geom;
     ea.woff = db->woff; ea.len = db->len; ea.codes = db->codes; ea.nmask = db->nmask; ea.hasN = db->hasN;
     ea.k = k; ea.kmersPerSeq = par->kmers_per_seq; ea.scale = par->kmers_per_seq_scale; ea.seed = par->hash_shift; ea.ignoreMultiKmer = par->ignore_multi_kmer;
-    ea.keys = k0.p; ea.vals = v0.p; ea.slotOff = slotOff.p; ea.slowShort = listShort.p; ea.slowLong = listLong.p; ea.slowCnt = cls.p; ea.n = n;
+    ea.keys = k0.p; ea.vals = v0.p; ea.slotOff = slotOff.p; ea.slowShort = listShort.p; ea.slowLong = listLong.p; ea.slowHuge = listHuge.p; ea.slowCnt = cls.p; ea.n = n;
+    ea.hugeSp = nullptr; ea.hugeSel = nullptr; ea.hugeCap = 0;
     ea.list = nullptr; ea.nList = 0; ea.hashBase = kmerSlots; ea.rankOf = rankOf.p;
     hipEventRecord(ctx->ev0, s);
     hipLaunchKernelGGL(k_seq_hash<LY>, dim3((n + 255) / 256), dim3(256), 0, s, ea);
@@ -1065,8 +1072,8 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     }
     hipLaunchKernelGGL(k_extract_fast<LY>, dim3(std::min<uint32_t>((n + FAST_WAVES - 1) / FAST_WAVES, ctx->cuCount * 16)), dim3(64 * FAST_WAVES), 0, s, ea);
     ea.listCount = nullptr;
-    unsigned int hcls[2] = {0, 0};
-    hipMemcpyAsync(hcls, cls.p, 8, hipMemcpyDeviceToHost, s);
+    unsigned int hcls[4] = {0, 0, 0, 0};
+    hipMemcpyAsync(hcls, cls.p, 16, hipMemcpyDeviceToHost, s);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     // sequences that need the exact per-sequence ordering (repeated k-mers, more positions than the bottom-m budget)
     if (hcls[0]) {
@@ -1076,6 +1083,14 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     if (hcls[1]) {
         ea.list = listLong.p; ea.nList = hcls[1];
         hipLaunchKernelGGL((k_extract<LY, LONG_CAP, 256>), dim3(std::min<uint32_t>(hcls[1], ctx->cuCount * 2)), dim3(256), 0, s, ea);
+    }
+    DevBuf<SeqPos> hugeSp; DevBuf<uint8_t> hugeSel;
+    if (hcls[3]) {
+        uint32_t cap = LONG_CAP; while (cap < db->maxLen) cap <<= 1;
+        const uint32_t blocks = std::min<uint32_t>(hcls[3], 64);
+        if (!hugeSp.alloc((size_t) blocks * cap) || !hugeSel.alloc((size_t) blocks * cap)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+        ea.list = listHuge.p; ea.nList = hcls[3]; ea.hugeSp = hugeSp.p; ea.hugeSel = hugeSel.p; ea.hugeCap = cap;
+        hipLaunchKernelGGL((k_extract<LY, 0, 256>), dim3(blocks), dim3(256), 0, s, ea);
     }
     hipEventRecord(ctx->ev1, s);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction (general path) failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from carpedeam_amd import capi, mmdb
+from carpedeam_amd import capi, mmdb, synth
 from gpuutil import DATASETS, diff_keys, gold, run_oracle, stage_input
 from stageflags import K_FLAGS
 from test_oracle_golden import pref_sign_ties
@@ -212,6 +212,29 @@ def test_kmermatch_strand_ties_follow_std_sort(ctx, oracle_bin, tmp_path):
         assert not bad, (case, seqs, bad)
 
 
+def test_kmermatch_sequences_beyond_4096_positions(ctx, oracle_bin, tmp_path):
+    """Sequences of 4 100 .. 12 000 letters (contigs late in the reads loop): more k-mer positions than the LDS version of the
+    general extraction kernel holds, so its global-scratch variant runs; bottom-m selection picks 199 + 0.2 L of them."""
+    rng = np.random.default_rng(41)
+    genome = rng.integers(0, 4, 30000)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    seqs = []
+    for _ in range(24):
+        L = int(rng.integers(4100, 12000)); st = int(rng.integers(0, len(genome) - L))
+        c = genome[st:st + L].copy()
+        if rng.random() < 0.5:
+            c = (3 - c)[::-1]
+        seqs.append(letters[c].tobytes().decode())
+    seqs += ["ACGTTGCAAT" * 600, synth.generate_strings(1, seed=3, mixed=(100, 101))[0]]
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    for k, ext in ((20, 0), (22, 1)):
+        flags = " ".join(K_FLAGS).replace("-k 20", "-k %d" % k).replace("--include-only-extendable 0", "--include-only-extendable %d" % ext).split()
+        run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *flags, "--threads", "1")
+        got = kmermatch_text(ctx, mmdb.read_db(t("in")), capi.KmerParams(k, 200, 0.2, 67, 1, ext, 1, 0.0))
+        assert not diff_keys(got, strip_ext(mmdb.read_db(t("pref")))), k
+
+
 def test_kmermatch_rejects_what_it_does_not_implement(ctx):
     with pytest.raises(capi.CdmError):
-        kmermatch_text(ctx, {0: (b"ACGT" * 2000 + b"\n", 0), 1: (b"ACGTTGCA" * 1000 + b"\n", 0)})   # >= 4096 k-mer positions
+        kmermatch_text(ctx, {0: (b"ACGT" * 8200 + b"\n", 0), 1: (b"ACGTTGCA" * 1000 + b"\n", 0)})   # >= 32 765 letters: the reference's `int` position path
