@@ -509,6 +509,12 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
                 }
                 int tooMuch = (int) (inBins - considered);
                 size_t selected = 0;
+                if (!a.ignoreMultiKmer) {
+                    // without --ignore-multi-kmer the reference does not sort (:269-275): the selection walks the k-mers in the
+                    // order they were generated; the threshold above only needed the score distribution
+                    uint32_t m = 0;
+                    for (uint32_t pos = 0; pos < nPos; pos++) { SeqPos e; if (makeSeqPos(a, w0, L, lastWord, hasN, k, pos, e)) sp[m++] = e; }
+                }
                 for (size_t ki = 0; ki < n && selected < considered; ki++) {
                     if (a.ignoreMultiKmer) {
                         const uint64_t km = spKmer63(sp[ki]);

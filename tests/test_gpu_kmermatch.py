@@ -212,6 +212,28 @@ def test_kmermatch_strand_ties_follow_std_sort(ctx, oracle_bin, tmp_path):
         assert not bad, (case, seqs, bad)
 
 
+def test_kmermatch_without_ignore_multi_kmer(ctx, oracle_bin, tmp_path):
+    """--ignore-multi-kmer 0: no per-sequence sort, repeated k-mers stay, the bottom-m selection walks positions in order."""
+    rng = np.random.default_rng(77)
+    genome = rng.integers(0, 4, 5000)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    seqs = []
+    for _ in range(150):
+        L = int(rng.integers(40, 900)); st = int(rng.integers(0, len(genome) - L))
+        c = genome[st:st + L].copy()
+        if rng.random() < 0.5:
+            c = (3 - c)[::-1]
+        seqs.append(letters[c].tobytes().decode())
+    seqs += ["ACGTTGCA" * 12, "GTACGC" * 20, "AC" * 50]
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    flags = " ".join(K_FLAGS).replace("--ignore-multi-kmer 1", "--ignore-multi-kmer 0").split()
+    assert flags != K_FLAGS
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *flags, "--threads", "1")
+    got = kmermatch_text(ctx, mmdb.read_db(t("in")), capi.KmerParams(20, 200, 0.2, 67, 0, 0, 1, 0.0))
+    assert not diff_keys(got, strip_ext(mmdb.read_db(t("pref"))))
+
+
 def test_kmermatch_sequences_beyond_4096_positions(ctx, oracle_bin, tmp_path):
     """Sequences of 4 100 .. 12 000 letters (contigs late in the reads loop): more k-mer positions than the LDS version of the
     general extraction kernel holds, so its global-scratch variant runs; bottom-m selection picks 199 + 0.2 L of them."""
