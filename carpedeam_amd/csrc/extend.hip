@@ -405,46 +405,47 @@ __global__ void k_out_meta(const uint32_t *__restrict__ len, const uint8_t *__re
     }
 }
 // one thread per output word
-__global__ __launch_bounds__(256) void k_write(ExtArgs A, const uint32_t *__restrict__ oWoff, const uint32_t *__restrict__ oLen, uint32_t n, uint64_t words,
+// One thread per output sequence (a read is 7 code words; the words of 64 neighbouring sequences are contiguous, so the strided
+// stores of a wave fill whole lines between them).  A thread per output WORD needed a 26-step owner search per wave, which was
+// most of the kernel's time.
+__global__ __launch_bounds__(256) void k_write(ExtArgs A, const uint32_t *__restrict__ oWoff, const uint32_t *__restrict__ oLen, uint32_t n,
                                                uint32_t *__restrict__ oCodes, uint32_t *__restrict__ oNmask, uint8_t *__restrict__ oHasN) {
-    const uint64_t gw = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (gw >= words) return;
-    // owner of word gw = last sequence whose first word is <= gw: one binary search per wave (for its first word, the same
-    // loads in every lane), then a short walk forward per lane
-    const uint64_t gw0 = gw - (threadIdx.x & 63);
-    uint64_t lo = 0, hi = n;
-    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (oWoff[mid] <= gw0) lo = mid; else hi = mid; }
-    while (lo + 1 < n && oWoff[lo + 1] <= gw) lo++;
-    const uint32_t q = (uint32_t) lo, w = (uint32_t) (gw - oWoff[q]), L = oLen[q];
-    const uint32_t cnt = min(16u, L - min(L, w * 16u));
-    uint32_t code = 0, nb = 0;
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const uint32_t L = oLen[q], nw = (L + 15) / 16, ob = oWoff[q];
+    uint16_t *oN16 = reinterpret_cast<uint16_t *>(oNmask);
+    uint32_t anyN = 0;
     if (A.newLen[q] == 0) {   // copy through (:564-581)
-        code = A.codes[A.woff[q] + w];
-        nb = reinterpret_cast<const uint16_t *>(A.nmask)[A.woff[q] + w];
+        const uint32_t ib = A.woff[q];
+        const uint16_t *iN16 = reinterpret_cast<const uint16_t *>(A.nmask);
+        for (uint32_t w = 0; w < nw; w++) { const uint32_t nb = iN16[ib + w]; oCodes[ob + w] = A.codes[ib + w]; oN16[ob + w] = (uint16_t) nb; anyN |= nb; }
     } else {
         const uint64_t r0 = A.aoff[q]; const uint32_t nRec = (uint32_t) (A.aoff[q + 1] - r0);
         VQuery Q; Q.a = &A; Q.q = q; Q.qLen0 = A.len[q]; Q.qw = A.woff[q]; Q.cand = A.cand + r0;
         Q.leftL = A.lists + 4 * r0 + 2 * (uint64_t) nRec; Q.rightL = Q.leftL + nRec; Q.nL = A.nLeft[q]; Q.nR = A.nRight[q]; Q.leftTotal = A.leftTotal[q]; Q.total = L; Q.plain = false;
-        for (uint32_t j = 0; j < cnt;) {       // piece by piece: a word rarely spans more than two
-            uint32_t t, tp, run;
-            Q.spanAt(w * 16 + j, t, tp, run);
-            const uint32_t m = min(run, cnt - j), tw = A.woff[t];
-            if (!A.hasN[t]) {
-                const uint32_t bits = cdm_window16(A.codes, tw, tp, (A.len[t] + 15) / 16 - 1);
-                code |= ((m < 16) ? (bits & ((1u << (2 * m)) - 1u)) : bits) << (2 * j);
-            } else {
-                for (uint32_t i = 0; i < m; i++) {
-                    uint32_t c = cdm_base(A.codes, tw, tp + i);
-                    if (cdm_isN(A.nmask, tw, tp + i)) { nb |= 1u << (j + i); c = 0; }
-                    code |= c << (2 * (j + i));
+        for (uint32_t w = 0; w < nw; w++) {
+            const uint32_t cnt = min(16u, L - w * 16u);
+            uint32_t code = 0, nb = 0;
+            for (uint32_t j = 0; j < cnt;) {       // piece by piece: a word rarely spans more than two
+                uint32_t t, tp, run;
+                Q.spanAt(w * 16 + j, t, tp, run);
+                const uint32_t m = min(run, cnt - j), tw = A.woff[t];
+                if (!A.hasN[t]) {
+                    const uint32_t bits = cdm_window16(A.codes, tw, tp, (A.len[t] + 15) / 16 - 1);
+                    code |= ((m < 16) ? (bits & ((1u << (2 * m)) - 1u)) : bits) << (2 * j);
+                } else {
+                    for (uint32_t i = 0; i < m; i++) {
+                        uint32_t c = cdm_base(A.codes, tw, tp + i);
+                        if (cdm_isN(A.nmask, tw, tp + i)) { nb |= 1u << (j + i); c = 0; }
+                        code |= c << (2 * (j + i));
+                    }
                 }
+                j += m;
             }
-            j += m;
+            oCodes[ob + w] = code; oN16[ob + w] = (uint16_t) nb; anyN |= nb;
         }
     }
-    oCodes[gw] = code;
-    reinterpret_cast<uint16_t *>(oNmask)[gw] = (uint16_t) nb;
-    if (nb) oHasN[q] = 1;
+    if (anyN) oHasN[q] = 1;
 }
 
 
@@ -501,7 +502,7 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     if (cdmMalloc(&o->codes, ((size_t) words + 2) * 4) != hipSuccess || cdmMalloc(&o->nmask, maskWords * 4) != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP; }
     hipMemcpyAsync(o->key, db->key, (size_t) n * 4, hipMemcpyDeviceToDevice, s);
     hipMemsetAsync(o->hasN, 0, n, s);
-    if (words) hipLaunchKernelGGL(k_write, dim3((unsigned) (((uint64_t) words + 255) / 256)), dim3(256), 0, s, A, o->woff, o->len, n, (uint64_t) words, o->codes, o->nmask, o->hasN);
+    if (words) hipLaunchKernelGGL(k_write, dim3((n + 255) / 256), dim3(256), 0, s, A, o->woff, o->len, n, o->codes, o->nmask, o->hasN);
     if (scores) hipMemcpyAsync(scores, dScores.p, alns->count * 8, hipMemcpyDeviceToHost, s);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: output kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     *out = o;
