@@ -169,7 +169,7 @@ def main():
         # HBM traffic of that kernel from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc runs of
         # this very command at the default size; profiles/r01_pmc_50M.json) - only quoted for the workload it was measured on
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_50M_k.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_50M_l.json")
         if n == 50_000_000 and L == 100 and os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc))["kernels"]["rocprim onesweep_iteration 9-bit <u64, u32>"]["hbm_bytes_per_launch"]
