@@ -151,10 +151,25 @@ __global__ void k_count_valid(const uint64_t *__restrict__ off, const uint8_t *_
     for (uint64_t h = off[q]; h < off[q + 1]; h++) c += valid[h];
     cnt[q] = c;
 }
-__global__ void k_scatter(const uint64_t *__restrict__ off, const uint8_t *__restrict__ valid, const AlnRec *__restrict__ tmp, const uint16_t *__restrict__ tmpRy, uint32_t n,
-                          const uint64_t *__restrict__ outOff, AlnRec *__restrict__ out, uint16_t *__restrict__ outRy) {
+// Valid candidate records move to their query's output slice, keeping their order.  A thread per record (its rank = valid
+// records of the same query in front of it, a short look back) keeps loads and stores coalesced; queries with more than
+// SCATTER_SMALL records (deep pile-ups) are left to a thread per query so that the look back stays short.
+constexpr uint32_t SCATTER_SMALL = 256;
+__global__ void k_scatter(const uint64_t *__restrict__ off, const uint32_t *__restrict__ owner, const uint8_t *__restrict__ valid, const AlnRec *__restrict__ tmp,
+                          const uint16_t *__restrict__ tmpRy, uint64_t nHits, const uint64_t *__restrict__ outOff, AlnRec *__restrict__ out, uint16_t *__restrict__ outRy) {
+    const uint64_t h = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nHits || !valid[h]) return;
+    const uint32_t q = owner[h];
+    const uint64_t first = off[q];
+    if (off[q + 1] - first > SCATTER_SMALL) return;
+    uint64_t o = outOff[q];
+    for (uint64_t j = first; j < h; j++) o += valid[j];
+    out[o] = tmp[h]; outRy[o] = tmpRy[h];
+}
+__global__ void k_scatter_big(const uint64_t *__restrict__ off, const uint8_t *__restrict__ valid, const AlnRec *__restrict__ tmp, const uint16_t *__restrict__ tmpRy, uint32_t n,
+                              const uint64_t *__restrict__ outOff, AlnRec *__restrict__ out, uint16_t *__restrict__ outRy) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
+    if (q >= n || off[q + 1] - off[q] <= SCATTER_SMALL) return;
     uint64_t o = outOff[q];
     for (uint64_t h = off[q]; h < off[q + 1]; h++) if (valid[h]) { out[o] = tmp[h]; outRy[o] = tmpRy[h]; o++; }
 }
@@ -215,7 +230,8 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     res->count = total;
     if (cdmMalloc(&res->rec, (total + 1) * sizeof(AlnRec)) != hipSuccess || cdmMalloc(&res->ryMism, (total + 1) * sizeof(uint16_t)) != hipSuccess) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
     res->rySerial = db->serial;
-    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid.p, tmp.p, tmpRy.p, n, res->off, res->rec, res->ryMism);
+    if (nHits) hipLaunchKernelGGL(k_scatter, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, s, hits->off, (const uint32_t *) owner.p, valid.p, tmp.p, tmpRy.p, (uint64_t) nHits, res->off, res->rec, res->ryMism);
+    hipLaunchKernelGGL(k_scatter_big, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid.p, tmp.p, tmpRy.p, n, res->off, res->rec, res->ryMism);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_rescore: compaction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     hipEventElapsedTime(&ctx->lastMs[1], ctx->ev0, ctx->ev1);
     guard.armed = false;
