@@ -332,7 +332,7 @@ extern "C" int cdm_seqdb_synth(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, ui
 }
 
 // ------------------------------------------------------------------------------------------------ multi-GPU hand-off
-#include <hipcub/hipcub.hpp>
+#include "scan.h"
 namespace {
 __global__ void k_sel_words(const uint32_t *__restrict__ len, const uint8_t *__restrict__ ext, uint32_t n, uint32_t *__restrict__ selWords, uint32_t *__restrict__ selOne) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -379,11 +379,10 @@ extern "C" int cdm_seqdb_select_ext(cdm_ctx *ctx, const cdm_seqdb *db, cdm_seqdb
     if (cdmMalloc(&selWords, ((size_t) n + 1) * 4) != hipSuccess || cdmMalloc(&selOne, ((size_t) n + 1) * 4) != hipSuccess ||
         cdmMalloc(&wordOff, ((size_t) n + 1) * 4) != hipSuccess || cdmMalloc(&rank, ((size_t) n + 1) * 4) != hipSuccess) { cdm_set_error("cdm_seqdb_select_ext: out of device memory"); return CDM_ERR_HIP; }
     hipLaunchKernelGGL(k_sel_words, dim3((n + 256) / 256), dim3(256), 0, s, db->len, db->ext, n, selWords, selOne);
-    size_t sb = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, sb, selWords, wordOff, (int) (n + 1), s);
-    if (cdmMalloc(&tmp, sb + 256) != hipSuccess) { cdm_set_error("cdm_seqdb_select_ext: out of device memory"); return CDM_ERR_HIP; }
-    hipcub::DeviceScan::ExclusiveSum(tmp, sb, selWords, wordOff, (int) (n + 1), s);
-    hipcub::DeviceScan::ExclusiveSum(tmp, sb, selOne, rank, (int) (n + 1), s);
+    cdmscan::ScanTemp st1, st2;
+    if (cdmscan::exclusiveScan<uint32_t>(s, st1, selWords, wordOff, (size_t) n + 1) != CDM_OK || cdmscan::exclusiveScan<uint32_t>(s, st2, selOne, rank, (size_t) n + 1) != CDM_OK) {
+        cdmFree(selWords); cdmFree(selOne); cdmFree(wordOff); cdmFree(rank); return CDM_ERR_HIP;
+    }
     uint32_t m = 0, words = 0;
     hipMemcpyAsync(&m, rank + n, 4, hipMemcpyDeviceToHost, s);
     hipMemcpyAsync(&words, wordOff + n, 4, hipMemcpyDeviceToHost, s);
@@ -424,16 +423,15 @@ extern "C" int cdm_seqdb_from_packed(cdm_ctx *ctx, const void *codes, const void
     if (rc == CDM_OK) rc = seqdb_alloc_codes(o, words);
     if (rc != CDM_OK) { if (o) cdm_seqdb_free(o); return rc; }
     uint32_t *w = nullptr; void *tmp = nullptr;
-    size_t sb = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, sb, w, o->woff, (int) (n + 1), s);
-    if (cdmMalloc(&w, (n + 1) * 4) != hipSuccess || cdmMalloc(&tmp, sb + 256) != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_from_packed: out of device memory"); return CDM_ERR_HIP; }
+    cdmscan::ScanTemp st;
+    if (cdmMalloc(&w, (n + 1) * 4) != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_from_packed: out of device memory"); return CDM_ERR_HIP; }
     hipMemcpyAsync(o->len, lengths, n * 4, hipMemcpyDeviceToDevice, s);
     hipMemcpyAsync(o->key, keys, n * 4, hipMemcpyDeviceToDevice, s);
     hipMemcpyAsync(o->codes, codes, words * 4, hipMemcpyDeviceToDevice, s);
     hipMemsetAsync(o->nmask, 0, (((uint64_t) words * 16 + 31) / 32 + 1) * 4, s);
     hipMemcpyAsync(o->nmask, nmask16, words * 2, hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(k_words_of, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, s, o->len, (uint32_t) n, w, o->ext, extValue, o->hasN);
-    hipcub::DeviceScan::ExclusiveSum(tmp, sb, w, o->woff, (int) (n + 1), s);
+    if (cdmscan::exclusiveScan<uint32_t>(s, st, w, o->woff, (size_t) n + 1) != CDM_OK) { cdmFree(w); cdm_seqdb_free(o); return CDM_ERR_HIP; }
     if (words) hipLaunchKernelGGL(k_mark_hasN, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, s, o->woff, o->nmask, (uint32_t) n, words, o->hasN);
     std::vector<uint32_t> l(n);
     hipMemcpyAsync(l.data(), o->len, n * 4, hipMemcpyDeviceToHost, s);

@@ -71,7 +71,8 @@ __device__ __forceinline__ int lastSetIn(const WaveLds &w, int lo, int hi) {
 struct BigList {
     unsigned long long *list;       // (start, end) of every range left to the caller
     unsigned int *cnt;
-    __device__ __forceinline__ void add(uint64_t s, uint64_t e) const { const unsigned int q = atomicAdd(cnt, 1u); list[2 * (size_t) q] = s; list[2 * (size_t) q + 1] = e; }
+    // list == NULL: the caller knows the big ranges already (segmentedSortKeys) and handles them itself
+    __device__ __forceinline__ void add(uint64_t s, uint64_t e) const { if (!list) return; const unsigned int q = atomicAdd(cnt, 1u); list[2 * (size_t) q] = s; list[2 * (size_t) q + 1] = e; }
 };
 
 // value of lane (lane ^ M): DPP lane permutations inside a row of 16 (no LDS round trip), ds_swizzle across rows of a half,
@@ -273,6 +274,95 @@ __global__ __launch_bounds__(BK_NT) void k_bucket_sort(SortArgs a) {
                     for (int r = 0; r < R; r++) { const int p = lane * R + r; if (p < gm) a.out[r0 + (uint64_t) (g0 + p)] = sKey[(int) (v[r] & ((1u << WV_IDX) - 1u))]; }
                 });
         });
+}
+
+// ---- segments too long for one wave's registers: a block of WAVES wavefronts, 512 elements per wave
+// Bitonic network over N = 512 WAVES words, element i = wave * 512 + lane * 8 + r: exchanges at distance < 8 stay inside a lane,
+// < 512 go through lane permutations (as in bitonicRegs), the few at distance >= 512 through LDS (sX: N words; the image is
+// laid out [r][wave][lane], so that both sides of an exchange are conflict-free).
+template <int WAVES, typename W>
+__device__ __forceinline__ void bitonicBlock(W (&v)[8], int lane, int wave, W *sX) {
+    constexpr int R = 8, N = 64 * R * WAVES;
+    const int base = wave * 64 * R + lane * R;
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64 * R) {
+                const int pw = wave ^ (j / (64 * R));           // the partner has the same lane and register in another wave
+#pragma unroll
+                for (int r = 0; r < R; r++) sX[(r * WAVES + wave) * 64 + lane] = v[r];
+                __syncthreads();
+                const bool lower = ((base & j) == 0);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const bool up = (((base + r) & k) == 0);
+                    const W a = v[r], b = sX[(r * WAVES + pw) * 64 + lane];
+                    v[r] = ((b < a) == (up == lower)) ? b : a;
+                }
+                __syncthreads();
+            } else if (j >= R) {
+                const bool lower = ((lane & (j / R)) == 0);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const bool up = (((base + r) & k) == 0);
+                    const W a = v[r], b = xorLane<W>(a, j / R);
+                    v[r] = ((b < a) == (up == lower)) ? b : a;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int p = r ^ j;
+                    if (p > r) {
+                        const bool up = (((base + r) & k) == 0);
+                        const W a = v[r], b = v[p];
+                        const bool sw = (b < a) == up;
+                        v[r] = sw ? b : a; v[p] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
+}
+constexpr int BLK_IDX = 12;             // bits of an element index inside a block-sorted segment (<= 4096 elements)
+struct BlockSortArgs {
+    const uint64_t *in; uint64_t *out;
+    const unsigned long long *list;     // (start, end) of every segment of this size class
+    const unsigned int *count;          // device-side number of segments
+    int shiftHi, ign;                   // as SortArgs: all elements of a segment agree above shiftHi; bits below ign ride along
+};
+// one block per listed segment of at most 512 WAVES elements: out = in with the segment stably sorted on bits [ign, shiftHi)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_block_sort(BlockSortArgs a) {
+    constexpr int R = 8, N = 64 * R * WAVES, NT = 64 * WAVES;
+    __shared__ uint64_t sKeys[N];
+    __shared__ uint64_t sX[N];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lowMask = (1ull << a.shiftHi) - 1ull;
+    const unsigned int cnt = *a.count;
+    for (unsigned int q = blockIdx.x; q < cnt; q += gridDim.x) {
+        const uint64_t s = a.list[2 * (size_t) q];
+        const int n = (int) min((unsigned long long) N, a.list[2 * (size_t) q + 1] - s);     // (longer ones are not listed here)
+        for (int i = threadIdx.x; i < n; i += NT) sKeys[i] = a.in[s + (uint64_t) i];
+        __syncthreads();
+        uint64_t v[R];
+        // network position (wave, lane, r) starts with input element r * NT + wave * 64 + lane: conflict-free LDS reads; the
+        // element index is the low part of the word, so the order of equal keys is their input order whatever the start
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = r * NT + wave * 64 + lane;
+            v[r] = (i < n) ? ((((sKeys[i] & lowMask) >> a.ign) << BLK_IDX) | (uint64_t) i) : ~0ull;
+        }
+        bitonicBlock<WAVES, uint64_t>(v, lane, wave, sX);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int p = wave * 64 * R + lane * R + r;
+            if (p < n) sX[p] = sKeys[(int) (v[r] & ((1u << BLK_IDX) - 1u))];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += NT) a.out[s + (uint64_t) i] = sX[i];
+        __syncthreads();
+    }
 }
 
 // copies the listed ranges between the array and a dense staging buffer (ranges sorted by start, off = prefix sums of sizes)

@@ -94,6 +94,36 @@ __device__ __forceinline__ uint32_t cdm_block_append(unsigned int *counter, bool
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------- block sum / scan
+// Wave-level inclusive sum (DPP-free shuffles; 6 steps), then one LDS step across the waves of the block.  Every thread of
+// the block must call these; blockDim.x is a multiple of 64, at most 1024.
+template <typename T> __device__ __forceinline__ T cdm_shfl_up_t(T v, int d) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit integers");
+    if (sizeof(T) == 4) return (T) (unsigned int) __shfl_up((int) v, d, 64);
+    const unsigned long long x = (unsigned long long) v;
+    return (T) (((unsigned long long) (unsigned int) __shfl_up((int) (x >> 32), d, 64) << 32) | (unsigned int) __shfl_up((int) (unsigned int) x, d, 64));
+}
+template <typename T> __device__ __forceinline__ T cdm_wave_incl_sum(T v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const T o = cdm_shfl_up_t<T>(v, d); if (lane >= d) v += o; }
+    return v;
+}
+// exclusive prefix sum of v over the block; total = sum over the block (valid in every thread)
+template <typename T> __device__ __forceinline__ T cdm_block_excl_sum(T v, T &total) {
+    __shared__ T sWave[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const T incl = cdm_wave_incl_sum<T>(v);
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    T base = 0, tot = 0;
+    for (int w = 0; w < nw; w++) { const T c = sWave[w]; if (w < wave) base += c; tot += c; }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+template <typename T> __device__ __forceinline__ T cdm_block_sum(T v) { T tot; (void) cdm_block_excl_sum<T>(v, tot); return tot; }
+
 // ---------------------------------------------------------------------------------------------- x87 extended precision
 // Software model of the x87 80-bit format (64-bit significand, round to nearest even), for the `long double`
 // accumulators of the reference (src/assembler/correction.cpp:82,110-111; nuclassembleUtil.cpp:212,279).  Only what

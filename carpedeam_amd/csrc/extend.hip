@@ -17,7 +17,7 @@
 // Reverse-strand records can never pass the reference's end-overlap test, which is evaluated on the raw coordinates
 // where q_start > q_end encodes the strand (:204-213: rightStart needs q_end == qLen-1 < q_start, leftStart needs
 // q_start == 0 > q_end), so useReverse[] stays false and no fragment is ever reverse-complemented on this path.
-#include <hipcub/hipcub.hpp>
+#include "scan.h"
 
 #include <cmath>
 
@@ -486,12 +486,9 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     int rc = cdm_seqdb_alloc(ctx, n, &o);
     if (rc) return rc;
     hipLaunchKernelGGL(k_out_meta, dim3((n + 1023) / 1024), dim3(1024), 0, s, db->len, db->ext, newLen.p, n, o->len, o->ext, oWords.p, stats.p);
-    size_t sb = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, sb, oWords.p, o->woff, (int) (n + 1), s);
-    DevBuf<char> tmp;
-    if (!tmp.alloc(sb + 256)) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP; }
+    cdmscan::ScanTemp tmp;
     hipMemsetAsync(oWords.p + n, 0, 4, s);
-    hipcub::DeviceScan::ExclusiveSum(tmp.p, sb, oWords.p, o->woff, (int) (n + 1), s);
+    if (cdmscan::exclusiveScan<uint32_t>(s, tmp, oWords.p, o->woff, (size_t) n + 1) != CDM_OK) { cdm_seqdb_free(o); return CDM_ERR_HIP; }
     uint32_t words = 0; unsigned long long hstats[2] = {0, 0};
     hipMemcpyAsync(&words, o->woff + n, 4, hipMemcpyDeviceToHost, s);
     hipMemcpyAsync(hstats, stats.p, 16, hipMemcpyDeviceToHost, s);

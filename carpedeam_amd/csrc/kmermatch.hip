@@ -19,11 +19,12 @@
 // (:875-887).
 #include <cstring>
 #include <rocprim/rocprim.hpp>
-#include <hipcub/hipcub.hpp>
 
 #include "common.h"
 #include "devutil.h"
 #include "bucket.h"
+#include "scan.h"
+#include "runsort.h"
 
 namespace {
 
@@ -786,9 +787,7 @@ __global__ __launch_bounds__(256) void k_seg_count(VoteArgs a, unsigned long lon
         uint32_t rep, target;
         if (i < a.n && validStart(a, i, rep, target)) { c++; atomicAdd(&a.perRep[rep], 1ull); }
     }
-    typedef hipcub::BlockReduce<unsigned int, 256> BR;
-    __shared__ typename BR::TempStorage tmp;
-    const unsigned int tot = BR(tmp).Sum(c);
+    const unsigned int tot = cdm_block_sum<unsigned int>(c);
     if (threadIdx.x == 0) tileCnt[blockIdx.x] = tot;
 }
 // vote of the segment starting at tile-local index li, reading the tile from LDS and whatever lies beyond it from memory
@@ -859,10 +858,8 @@ __global__ __launch_bounds__(256) void k_seg_place(VoteArgs a, const unsigned lo
         if (first && (uint32_t) (seg & idMask) != (uint32_t) (seg >> a.idBits)) { c++; mask |= 1u << j; }
     }
     sFirst[threadIdx.x] = (uint16_t) firstBits;
-    typedef hipcub::BlockScan<unsigned int, 256> BS;
-    __shared__ typename BS::TempStorage tmp;
-    unsigned int pre;
-    BS(tmp).ExclusiveSum(c, pre);       // (its barriers also publish sFirst)
+    unsigned int pre, totC;
+    pre = cdm_block_excl_sum<unsigned int>(c, totC);       // (its barriers also publish sFirst)
     unsigned long long rank = tileOff[blockIdx.x] + pre;   // number of hit-producing segments before this one, whole array
     const unsigned long long *firstWords = reinterpret_cast<const unsigned long long *>(sFirst);
 #pragma unroll 1
@@ -929,9 +926,7 @@ __global__ void k_slot_scatter(const uint32_t *__restrict__ order, const unsigne
 __global__ __launch_bounds__(256) void k_reduce_stats(const unsigned long long *__restrict__ stripes, unsigned long long *__restrict__ out) {
     unsigned long long c = 0;
     for (int i = threadIdx.x; i < STAT_STRIPES; i += 256) c += stripes[i];
-    typedef hipcub::BlockReduce<unsigned long long, 256> BR;
-    __shared__ typename BR::TempStorage tmp;
-    c = BR(tmp).Sum(c);
+    c = cdm_block_sum<unsigned long long>(c);
     if (threadIdx.x == 0) out[0] = c;
 }
 // number of keys in front of the unused / dropped ones (key ~0) once the array is sorted on bits up to `bit`, which is set
@@ -1005,6 +1000,11 @@ __global__ __launch_bounds__(256) void k_stale_tail(StaleArgs<LY> a) {
     }
     if (threadIdx.x == 0) { a.out[0] = cnt; a.out[1] = target; }
 }
+// smallest index at which the two arrays differ (atomicMin; *out starts as ~0)
+__global__ void k_first_diff(const uint64_t *__restrict__ a, const uint64_t *__restrict__ b, uint64_t n, unsigned long long *__restrict__ out) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+        if (a[i] != b[i]) { atomicMin(out, (unsigned long long) i); return; }
+}
 inline uint32_t bitsFor(uint64_t v) { uint32_t b = 1; while ((1ull << b) < v) b++; return b; }
 
 template <typename LY>
@@ -1040,15 +1040,14 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
         if (!lk0.alloc(n) || !lk1.alloc(n) || !lv0.alloc(n) || !lv1.alloc(n) || !ordOff.alloc((size_t) n + 1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
         hipLaunchKernelGGL(k_len_keys, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, db->maxLen, lk0.p, lv0.p);
         rocprim::double_buffer<uint32_t> lk(lk0.p, lk1.p), lv(lv0.p, lv1.p);
-        size_t sb0 = 0, sb1 = 0;
+        size_t sb0 = 0;
         const unsigned lenBits = bitsFor((uint64_t) db->maxLen + 2);
         rocprim::radix_sort_pairs(nullptr, sb0, lk, lv, (size_t) n, 0, lenBits, s);
-        hipcub::DeviceScan::ExclusiveSum(nullptr, sb1, slots.p, ordOff.p, (int) (n + 1), s);
-        DevBuf<char> t0;
-        if (!t0.alloc(std::max(sb0, sb1) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+        DevBuf<char> t0; cdmscan::ScanTemp st;
+        if (!t0.alloc(sb0 + 256)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
         rocprim::radix_sort_pairs(t0.p, sb0, lk, lv, (size_t) n, 0, lenBits, s);
         hipLaunchKernelGGL(k_slot_counts, dim3((n + 256) / 256), dim3(256), 0, s, db->len, lv.current(), n, k, slots.p);
-        hipcub::DeviceScan::ExclusiveSum(t0.p, sb1, slots.p, ordOff.p, (int) (n + 1), s);
+        if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, st, slots.p, ordOff.p, (size_t) n + 1)) return rc;
         hipLaunchKernelGGL(k_slot_scatter, dim3((n + 256) / 256), dim3(256), 0, s, lv.current(), ordOff.p, n, slotOff.p, rankOf.p);
         hipMemcpyAsync(&capacity, ordOff.p + n, 8, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: slot layout failed"); return CDM_ERR_HIP; }
@@ -1244,31 +1243,98 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     }
     float msSort1 = 0; hipEventElapsedTime(&msSort1, ctx->ev0, ctx->ev1);
 
-    // ---- sort 2: by (rep, id, diagonal) = key bits 1.., stable; strand bit 0 rides along.  No compaction before it: dropped
-    // members carry the key ~0, and bit top2 (the first bit above the key fields) is set only there, so sorting on bits up to and
-    // including top2 moves them behind all kept members, in the order the reference's (rep, id, diagonal) sort leaves the
-    // kept ones.  The top 32 of those bits go through global radix passes, the rest is finished bucket by bucket on chip
-    // (bucket.h); CDM_KMER_SORT=lsd keeps the all-global sort (A/B).
+    // ---- sort 2: by (rep, id, diagonal) = key bits 1.., stable; strand bit 0 rides along.
+    // Default ("runs", runsort.h): the k-mer runs are sorted by representative, not the tuples - records of (rep, start, length),
+    // a stable radix sort of those, an expanding gather that also drops the ~0 keys, then a segmented sort of every
+    // representative's tuples on (id, diagonal) on chip.
+    // CDM_KMER_SORT2=radix (A/B; also what CDM_KMER_SORT=lsd uses): no compaction, dropped members carry the key ~0, and bit top2
+    // (the first bit above the key fields) is set only there, so sorting on bits up to and including top2 moves them behind all
+    // kept members; the top 32 of those bits go through global radix passes, the rest is finished bucket by bucket on chip
+    // (bucket.h).  CDM_KMER_SORT2=check runs both and compares the two arrays on the device.
     v0.free(); v1.free();                                                    // the tuple values are dead after k_groups
-    rocprim::double_buffer<uint64_t> g((uint64_t *) startIo, keys.current());
     const int top2 = (int) (2 * idBits + diagBits + 1);
-    const int shiftHi2 = lsdOnly ? 1 : std::max(1, top2 + 1 - 32);
-    size_t tmpBytes2 = 0;
-    rocprim::radix_sort_keys(nullptr, tmpBytes2, g, (size_t) nTuples, shiftHi2, top2 + 1, s);
-    DevBuf<char> tmp3;
-    if (!tmp3.alloc(tmpBytes2 + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
-    hipEventRecord(ctx->ev0, s);
-    if (rocprim::radix_sort_keys(tmp3.p, tmpBytes2, g, (size_t) nTuples, shiftHi2, top2 + 1, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+    const char *sort2Env = getenv("CDM_KMER_SORT2");
+    const bool sort2Check = sort2Env && !strcmp(sort2Env, "check");
+    const bool sort2Runs = !lsdOnly && (!sort2Env || !strcmp(sort2Env, "runs") || sort2Check);
+    if (sort2Env && strcmp(sort2Env, "runs") && strcmp(sort2Env, "radix") && !sort2Check) { cdm_set_error("cdm_kmermatch: CDM_KMER_SORT2 must be runs, radix or check"); return CDM_ERR_INVALID; }
     unsigned long long nGroup = 0;
-    if (nTuples) {
-        hipLaunchKernelGGL(k_live_count, dim3(1), dim3(1), 0, s, (const uint64_t *) g.current(), (uint64_t) nTuples, top2, counters.p + 2);
-        hipMemcpyAsync(&nGroup, counters.p + 2, 8, hipMemcpyDeviceToHost, s);
-        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+    const uint64_t *sorted2 = nullptr;
+    DevBuf<uint64_t> runsOut, runsTmp;       // "check" mode: the run-based result next to the radix one
+    hipEventRecord(ctx->ev0, s);
+    if (sort2Runs) {
+        using namespace runsort;
+        const uint64_t *gk = (const uint64_t *) startIo;
+        uint64_t *gathered = keys.current(), *sortedOut = (uint64_t *) startIo;
+        if (sort2Check) {
+            if (!runsOut.alloc(nTuples) || !runsTmp.alloc(nTuples)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2 check)"); return CDM_ERR_HIP; }
+            gathered = runsTmp.p; sortedOut = runsOut.p;
+        }
+        const uint64_t tiles = (nTuples + RUN_TILE - 1) / RUN_TILE;
+        DevBuf<unsigned long long> tileCnt, tileOff;
+        if (!tileCnt.alloc(tiles + 1) || !tileOff.alloc(tiles + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2)"); return CDM_ERR_HIP; }
+        RunArgs ra; ra.keys = gk; ra.n = nTuples; ra.skipLo = live; ra.skipHi = kmerSlots; ra.repShift = (int) (idBits + diagBits + 1);
+        hipMemsetAsync(tileCnt.p + tiles, 0, 8, s);
+        if (tiles) hipLaunchKernelGGL(k_run_count, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, tileCnt.p);
+        cdmscan::ScanTemp stA, stB;
+        if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, stA, tileCnt.p, tileOff.p, (size_t) tiles + 1)) return rc;
+        unsigned long long nRec = 0;
+        hipMemcpyAsync(&nRec, tileOff.p + tiles, 8, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: sort 2 (records) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+        DevBuf<uint32_t> rr0, rr1; DevBuf<uint64_t> rv0, rv1; DevBuf<unsigned long long> dst;
+        if (!rr0.alloc(nRec) || !rr1.alloc(nRec) || !rv0.alloc(nRec) || !rv1.alloc(nRec) || !dst.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
+        if (nRec) {
+            hipLaunchKernelGGL(k_run_write, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, (const unsigned long long *) tileOff.p, rr0.p, rv0.p);
+            rocprim::double_buffer<uint32_t> rk(rr0.p, rr1.p); rocprim::double_buffer<uint64_t> rv(rv0.p, rv1.p);
+            size_t tb = 0;
+            rocprim::radix_sort_pairs(nullptr, tb, rk, rv, (size_t) nRec, 0, idBits, s);
+            DevBuf<char> t1;
+            if (!t1.alloc(tb + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2)"); return CDM_ERR_HIP; }
+            if (rocprim::radix_sort_pairs(t1.p, tb, rk, rv, (size_t) nRec, 0, idBits, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: record sort failed"); return CDM_ERR_HIP; }
+            // (the scan reads one element past the records: the value buffers have nRec + 1 entries, the last one's length is not used)
+            hipMemsetAsync(rv.current() + nRec, 0, 8, s);
+            if (int rc = cdmscan::exclusiveScanFn<unsigned long long, RunLen>(s, stB, RunLen{rv.current()}, dst.p, (size_t) nRec + 1)) return rc;
+            hipMemcpyAsync(&nGroup, dst.p + nRec, 8, hipMemcpyDeviceToHost, s);
+            hipLaunchKernelGGL(k_run_gather, dim3((unsigned) ((nRec + 255) / 256)), dim3(256), 0, s, gk, (const uint64_t *) rv.current(), (const unsigned long long *) dst.p, (uint64_t) nRec, gathered);
+            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: sort 2 (gather) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+            if (segmentedSortKeys(s, ctx->cuCount, gathered, sortedOut, nGroup, (int) (idBits + diagBits + 1), 1, top2, rk.current(), dst.p, nRec) != CDM_OK) {
+                cdm_set_error("cdm_kmermatch: segmented sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP;
+            }
+        }
+        sorted2 = sortedOut;
     }
-    const uint64_t *sorted2 = g.current();
-    if (shiftHi2 > 1) {
-        if (bucket::bucketSortKeys(s, g.current(), g.alternate(), nGroup, shiftHi2, 1, top2) != CDM_OK) { cdm_set_error("cdm_kmermatch: bucket sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
-        sorted2 = g.alternate();
+    if (!sort2Runs || sort2Check) {
+        rocprim::double_buffer<uint64_t> g((uint64_t *) startIo, keys.current());
+        const int shiftHi2 = lsdOnly ? 1 : std::max(1, top2 + 1 - 32);
+        size_t tmpBytes2 = 0;
+        rocprim::radix_sort_keys(nullptr, tmpBytes2, g, (size_t) nTuples, shiftHi2, top2 + 1, s);
+        DevBuf<char> tmp3;
+        if (!tmp3.alloc(tmpBytes2 + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
+        if (rocprim::radix_sort_keys(tmp3.p, tmpBytes2, g, (size_t) nTuples, shiftHi2, top2 + 1, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+        unsigned long long nGroupR = 0;
+        if (nTuples) {
+            hipLaunchKernelGGL(k_live_count, dim3(1), dim3(1), 0, s, (const uint64_t *) g.current(), (uint64_t) nTuples, top2, counters.p + 2);
+            hipMemcpyAsync(&nGroupR, counters.p + 2, 8, hipMemcpyDeviceToHost, s);
+            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+        }
+        const uint64_t *sortedR = g.current();
+        if (shiftHi2 > 1) {
+            if (bucket::bucketSortKeys(s, g.current(), g.alternate(), nGroupR, shiftHi2, 1, top2) != CDM_OK) { cdm_set_error("cdm_kmermatch: bucket sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+            sortedR = g.alternate();
+        }
+        if (sort2Check) {
+            if (nGroupR != nGroup) { cdm_set_error("cdm_kmermatch: sort 2 check: %llu kept tuples by runs, %llu by radix", nGroup, nGroupR); return CDM_ERR_HIP; }
+            hipMemsetAsync(counters.p + 5, 0xFF, 8, s);
+            if (nGroup) hipLaunchKernelGGL(k_first_diff, dim3((unsigned) std::min<uint64_t>((nGroup + 255) / 256, 65535)), dim3(256), 0, s, sorted2, sortedR, (uint64_t) nGroup, counters.p + 5);
+            unsigned long long firstDiff = ~0ull, pair[2] = {0, 0};
+            hipMemcpyAsync(&firstDiff, counters.p + 5, 8, hipMemcpyDeviceToHost, s);
+            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: sort 2 check failed"); return CDM_ERR_HIP; }
+            if (firstDiff != ~0ull) {
+                hipMemcpy(&pair[0], sorted2 + firstDiff, 8, hipMemcpyDeviceToHost); hipMemcpy(&pair[1], sortedR + firstDiff, 8, hipMemcpyDeviceToHost);
+                cdm_set_error("cdm_kmermatch: sort 2 check: first difference at %llu of %llu: runs %016llx radix %016llx (idBits %u diagBits %u)", firstDiff, nGroup, pair[0], pair[1], idBits, diagBits);
+                return CDM_ERR_HIP;
+            }
+        }
+        nGroup = nGroupR; sorted2 = sortedR;
     }
     hipEventRecord(ctx->ev1, s);
 
@@ -1285,13 +1351,9 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     va.stale = staleBuf.p;
     va.keys = sorted2; va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.perRep = perRep.p;
     if (nGroup) hipLaunchKernelGGL(k_seg_count, dim3((unsigned) vTiles), dim3(256), 0, s, va, vTileCnt.p);
-    size_t sb1 = 0, sb2 = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, sb1, perRep.p, perRepScan.p, (int) (n + 1), s);
-    hipcub::DeviceScan::ExclusiveSum(nullptr, sb2, vTileCnt.p, vTileOff.p, (int) (vTiles + 1), s);
-    DevBuf<char> tmp4;
-    if (!tmp4.alloc(std::max(sb1, sb2) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (scan temp)"); return CDM_ERR_HIP; }
-    hipcub::DeviceScan::ExclusiveSum(tmp4.p, sb1, perRep.p, perRepScan.p, (int) (n + 1), s);
-    hipcub::DeviceScan::ExclusiveSum(tmp4.p, sb2, vTileCnt.p, vTileOff.p, (int) (vTiles + 1), s);
+    cdmscan::ScanTemp st4a, st4b;
+    if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, st4a, perRep.p, perRepScan.p, (size_t) n + 1)) return rc;
+    if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, st4b, vTileCnt.p, vTileOff.p, (size_t) vTiles + 1)) return rc;
     cdm_hits *res = new cdm_hits(); res->n = n;
     if (cdmMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { delete res; cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipLaunchKernelGGL(k_offsets, dim3((n + 256) / 256), dim3(256), 0, s, perRepScan.p, n, res->off);

@@ -8,7 +8,7 @@
 //   reverse-strand coordinate encoding (:294-297).
 // One thread per hit; sequences are compared 16 bases at a time on the 2-bit words (XOR + popcount).  Hits whose two
 // sequences contain an N take a per-base path.  Survivors are compacted per query with a prefix sum.
-#include <hipcub/hipcub.hpp>
+#include "scan.h"
 
 #include <cfloat>
 #include <climits>
@@ -185,7 +185,7 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     const uint32_t n = (uint32_t) db->n;
     const uint64_t nHits = hits->count;
     if (db->maxLen >= (1u << 30)) { cdm_set_error("cdm_rescore: sequence too long"); return CDM_ERR_UNSUPPORTED; }
-    DevBuf<uint32_t> dPresent, owner; DevBuf<int32_t> dMin; DevBuf<AlnRec> tmp; DevBuf<uint16_t> tmpRy; DevBuf<uint8_t> valid; DevBuf<uint64_t> cnt; DevBuf<char> scanTmp;
+    DevBuf<uint32_t> dPresent, owner; DevBuf<int32_t> dMin; DevBuf<AlnRec> tmp; DevBuf<uint16_t> tmpRy; DevBuf<uint8_t> valid; DevBuf<uint64_t> cnt;
     if (!dPresent.alloc(db->maxLen + 1) || !dMin.alloc(db->maxLen + 1) || !owner.alloc(nHits) || !tmp.alloc(nHits) || !tmpRy.alloc(nHits) || !valid.alloc(nHits) || !cnt.alloc((size_t) n + 1)) {
         cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP;
     }
@@ -219,11 +219,9 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     cdm_alns *res = new cdm_alns(); res->n = n;
     struct Guard { cdm_alns *&r; bool armed = true; ~Guard() { if (armed && r) { cdm_alns_free(r); r = nullptr; } } } guard{res};
     if (cdmMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
-    size_t tmpBytes = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cnt.p, res->off, n + 1, s);
-    if (!scanTmp.alloc(tmpBytes + 16)) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
+    cdmscan::ScanTemp scanTmp;
     CDM_HIP(hipMemsetAsync(cnt.p + n, 0, 8, s));
-    hipcub::DeviceScan::ExclusiveSum(scanTmp.p, tmpBytes, cnt.p, res->off, n + 1, s);
+    if (int rc = cdmscan::exclusiveScan<uint64_t>(s, scanTmp, cnt.p, res->off, (size_t) n + 1)) return rc;
     uint64_t total = 0;
     CDM_HIP(hipMemcpyAsync(&total, res->off + n, 8, hipMemcpyDeviceToHost, s));
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_rescore: kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }

@@ -1,6 +1,6 @@
 // Device-side synthetic read generator: the counter-based generator specified in carpedeam_amd/synth.py.
 // The genome is never stored: base i is a hash of (seed, i).  One thread per 16-base output word.
-#include <hipcub/hipcub.hpp>
+#include "scan.h"
 
 #include "common.h"
 #include "devutil.h"
@@ -68,16 +68,14 @@ int cdm_synth_impl(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, uint64_t n, ui
     cdm_seqdb *db = nullptr;
     int rc = cdm_seqdb_alloc(ctx, n, &db);
     if (rc) return rc;
-    uint32_t *wordsPer = nullptr; void *tmp = nullptr;
+    uint32_t *wordsPer = nullptr;
+    cdmscan::ScanTemp scanTmp;
     int ret = CDM_OK;
     do {
         if (cdmMalloc(&wordsPer, (n + 1) * 4) != hipSuccess) { cdm_set_error("cdm_seqdb_synth: out of device memory"); ret = CDM_ERR_HIP; break; }
         hipLaunchKernelGGL(k_synth_len, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, a, db->len, wordsPer, db->key);
         hipMemsetAsync(wordsPer + n, 0, 4, s);
-        size_t sb = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, sb, wordsPer, db->woff, (int) (n + 1), s);
-        if (cdmMalloc(&tmp, sb + 256) != hipSuccess) { cdm_set_error("cdm_seqdb_synth: out of device memory"); ret = CDM_ERR_HIP; break; }
-        hipcub::DeviceScan::ExclusiveSum(tmp, sb, wordsPer, db->woff, (int) (n + 1), s);
+        if ((ret = cdmscan::exclusiveScan<uint32_t>(s, scanTmp, wordsPer, db->woff, (size_t) n + 1)) != CDM_OK) break;
         uint32_t words = 0;
         hipMemcpyAsync(&words, db->woff + n, 4, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_seqdb_synth: length kernel failed"); ret = CDM_ERR_HIP; break; }
@@ -99,7 +97,7 @@ int cdm_synth_impl(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, uint64_t n, ui
             db->residues = t; db->maxLen = mx;
         }
     } while (0);
-    cdmFree(wordsPer); cdmFree(tmp);
+    cdmFree(wordsPer);
     if (ret != CDM_OK) { cdm_seqdb_free(db); return ret; }
     *out = db;
     return CDM_OK;

@@ -110,7 +110,11 @@ def test_kmermatch_bucket_sort_paths_agree(ctx, oracle_bin, tmp_path, monkeypatc
     run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
     want = strip_ext(mmdb.read_db(t("pref")))
     for env in ({}, {"CDM_BUCKET_CAP": "64"}, {"CDM_BUCKET_CAP": "5"}, {"CDM_BUCKET_CAP": "3,17"}, {"CDM_BUCKET_CAP": "1"}, {"CDM_BUCKET_CAP": "512,40"},
-                {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_BUCKET_CAP": "6,100"}):
+                {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_BUCKET_CAP": "6,100"},
+                # sort 2: the all-radix variant, both variants compared on the device, the block sorters on short segments
+                # (wave capacity 5), rocPRIM beyond 8 tuples, and every segment through rocPRIM
+                {"CDM_KMER_SORT2": "radix"}, {"CDM_KMER_SORT2": "check"}, {"CDM_KMER_SORT2": "check", "CDM_BUCKET_CAP": "5"},
+                {"CDM_KMER_SORT2": "check", "CDM_BUCKET_CAP": "5", "CDM_BLOCK_CAP": "8"}, {"CDM_BUCKET_CAP": "2,9", "CDM_BLOCK_CAP": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         assert not diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), want), env
@@ -123,7 +127,8 @@ def test_kmermatch_variants_identical_at_scale(ctx, monkeypatch):
     radix sort and the two tuple layouts return identical hit arrays."""
     db = ctx.synth(1_000_000, 100, 100, 5)
     ref = None
-    for env in ({}, {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_KMER_SORT": "lsd"}, {"CDM_BUCKET_CAP": "48"}):
+    for env in ({}, {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_KMER_SORT": "lsd"}, {"CDM_BUCKET_CAP": "48"},
+                {"CDM_KMER_SORT2": "radix"}, {"CDM_KMER_SORT2": "check"}, {"CDM_KMER_SORT2": "check", "CDM_BUCKET_CAP": "300"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         off, rec = ctx.kmermatch(db).download()
@@ -136,7 +141,7 @@ def test_kmermatch_variants_identical_at_scale(ctx, monkeypatch):
             assert np.array_equal(off, ref[0]) and np.array_equal(rec, ref[1]), env
 
 
-def test_kmermatch_high_multiplicity_buckets(ctx, oracle_bin, tmp_path):
+def test_kmermatch_high_multiplicity_buckets(ctx, oracle_bin, tmp_path, monkeypatch):
     """Hundreds of identical / overlapping reads: k-mer buckets of 257..512 tuples (the 8-words-per-lane network), buckets
     beyond 512 (gathered and sorted globally) and representatives with tens of thousands of group tuples, all at the default
     capacities."""
@@ -152,6 +157,10 @@ def test_kmermatch_high_multiplicity_buckets(ctx, oracle_bin, tmp_path):
     mmdb.write_seqdb(t("in"), seqs)
     run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
     assert not diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), strip_ext(mmdb.read_db(t("pref"))))
+    # sort 2 at the default capacities: segments for the wave sorter, for all three block sorters and for rocPRIM
+    monkeypatch.setenv("CDM_KMER_SORT2", "check")
+    assert not diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), strip_ext(mmdb.read_db(t("pref"))))
+    monkeypatch.delenv("CDM_KMER_SORT2")
 
 
 @pytest.mark.parametrize("seqs", [["ACGTTGCAAGGCTTAACGGATCCGATTACAGGCATCGA"], ["ACG", "TTGCA", "", "ACGTACGTAC"],
