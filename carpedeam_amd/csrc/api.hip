@@ -84,6 +84,7 @@ extern "C" int cdm_ctx_create(int device, cdm_ctx **out) {
     c->cuCount = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
         hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess ||
+        hipEventCreate(&c->evS0) != hipSuccess || hipEventCreate(&c->evS1) != hipSuccess ||
         cdmMalloc(&c->lutDev, sizeof(DamageLut)) != hipSuccess) {
         cdm_set_error("context resource creation failed"); delete c; return CDM_ERR_HIP;
     }
@@ -98,13 +99,15 @@ extern "C" void cdm_ctx_destroy(cdm_ctx *c) {
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ev2) hipEventDestroy(c->ev2);
     if (c->ev3) hipEventDestroy(c->ev3);
+    if (c->evS0) hipEventDestroy(c->evS0);
+    if (c->evS1) hipEventDestroy(c->evS1);
     if (c->lutDev) cdmFree(c->lutDev);
     cdmPoolTrim();
     delete c;
 }
 extern "C" int cdm_ctx_sync(cdm_ctx *c) { CDM_HIP(hipSetDevice(c->device)); CDM_HIP(hipStreamSynchronize(c->stream)); return CDM_OK; }
 extern "C" void *cdm_ctx_stream(cdm_ctx *c) { return (void *) c->stream; }
-extern "C" float cdm_ctx_last_kernel_ms(cdm_ctx *c, int which) { return (which >= 0 && which < 8) ? c->lastMs[which] : -1.f; }
+extern "C" float cdm_ctx_last_kernel_ms(cdm_ctx *c, int which) { return (which >= 0 && which < 16) ? c->lastMs[which] : -1.f; }
 
 extern "C" int cdm_damage_load(cdm_ctx *c, const char *prefix) {
     std::string err;
@@ -523,6 +526,12 @@ extern "C" int cdm_alns_download(cdm_ctx *ctx, const cdm_alns *a, uint64_t *offs
 extern "C" void cdm_alns_free(cdm_alns *a) { if (!a) return; cdmFree(a->off); cdmFree(a->rec); if (a->ryMism) cdmFree(a->ryMism); delete a; }
 
 // ------------------------------------------------------------------------------------------------ stage wrappers
+// device time of the whole stage call (HIP events on the context stream around everything the call launched, host round
+// trips between its kernels included): lastMs[8..11] = kmermatcher, rescorediagonal, ancient_correction, ancient_read_assemble
+static void stageDone(cdm_ctx *ctx, int slot) {
+    hipEventRecord(ctx->evS1, ctx->stream);
+    if (hipEventSynchronize(ctx->evS1) == hipSuccess) hipEventElapsedTime(&ctx->lastMs[slot], ctx->evS0, ctx->evS1);
+}
 extern "C" int cdm_correct(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out) {
     if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_correct: NULL argument"); return CDM_ERR_INVALID; }
     if (!ctx->haveDamage) { cdm_set_error("cdm_correct: call cdm_damage_load first"); return CDM_ERR_INVALID; }
@@ -531,8 +540,10 @@ extern "C" int cdm_correct(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *al
     cdm_seqdb *o = nullptr;
     int rc = cdm_seqdb_alloc_like(ctx, db, &o);
     if (rc) return rc;
+    hipEventRecord(ctx->evS0, ctx->stream);
     rc = cdm_correct_impl(ctx, db, alns, par, o);
     if (rc) { cdm_seqdb_free(o); return rc; }
+    stageDone(ctx, 10);
     *out = o;
     return CDM_OK;
 }
@@ -541,17 +552,26 @@ extern "C" int cdm_rescore(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hi
     if (hits->n != db->n) { cdm_set_error("cdm_rescore: hit CSR / DB size mismatch"); return CDM_ERR_INVALID; }
     if (par->seq_id_mode != 0) { cdm_set_error("cdm_rescore: only --seq-id-mode 0 is implemented"); return CDM_ERR_UNSUPPORTED; }
     CDM_HIP(hipSetDevice(ctx->device));
-    return cdm_rescore_impl(ctx, db, hits, par, out);
+    hipEventRecord(ctx->evS0, ctx->stream);
+    const int rc = cdm_rescore_impl(ctx, db, hits, par, out);
+    if (rc == CDM_OK) stageDone(ctx, 9);
+    return rc;
 }
 extern "C" int cdm_kmermatch(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
     if (!ctx || !db || !par || !out) { cdm_set_error("cdm_kmermatch: NULL argument"); return CDM_ERR_INVALID; }
     CDM_HIP(hipSetDevice(ctx->device));
-    return cdm_kmermatch_impl(ctx, db, par, out);
+    hipEventRecord(ctx->evS0, ctx->stream);
+    const int rc = cdm_kmermatch_impl(ctx, db, par, out);
+    if (rc == CDM_OK) stageDone(ctx, 8);
+    return rc;
 }
 extern "C" int cdm_extend(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out, double *scores) {
     if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_extend: NULL argument"); return CDM_ERR_INVALID; }
     if (!ctx->haveDamage) { cdm_set_error("cdm_extend: call cdm_damage_load first"); return CDM_ERR_INVALID; }
     if (par->unsafe) { cdm_set_error("cdm_extend: --unsafe 1 (consensus mode) is not implemented on the device path"); return CDM_ERR_UNSUPPORTED; }
     CDM_HIP(hipSetDevice(ctx->device));
-    return cdm_extend_impl(ctx, db, alns, par, out, scores);
+    hipEventRecord(ctx->evS0, ctx->stream);
+    const int rc = cdm_extend_impl(ctx, db, alns, par, out, scores);
+    if (rc == CDM_OK) stageDone(ctx, 11);
+    return rc;
 }

@@ -227,7 +227,7 @@ __device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, ui
     }
     int g0 = p0;
     while (g0 < eOwn) {
-        const int lim = min(g0 + BK_GROUP, eOwn);
+        const int lim = min(g0 + min(BK_GROUP, (int) maxBucket), eOwn);       // (a group of several buckets never exceeds the capacity either)
         int e = (lim == eOwn) ? eOwn : lastSetIn(w, g0, lim);
         if (e < 0) { e = firstSetFrom(w, g0 + 1, eOwn); if (e < 0) e = eOwn; }     // one bucket larger than a group
         const int gm = e - g0;

@@ -65,12 +65,12 @@ int cdm_build_damage(const char *prefix, long double mats[2][11][4][4], DamageLu
 struct cdm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, evS0 = nullptr, evS1 = nullptr;
     bool haveDamage = false;
     long double mats[2][11][4][4];
     DamageLut lutHost;
     DamageLut *lutDev = nullptr;
-    float lastMs[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    float lastMs[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
     int cuCount = 256;
 };
 

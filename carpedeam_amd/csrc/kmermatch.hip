@@ -1296,7 +1296,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
             hipMemcpyAsync(&nGroup, dst.p + nRec, 8, hipMemcpyDeviceToHost, s);
             hipLaunchKernelGGL(k_run_gather, dim3((unsigned) ((nRec + 255) / 256)), dim3(256), 0, s, gk, (const uint64_t *) rv.current(), (const unsigned long long *) dst.p, (uint64_t) nRec, gathered);
             if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: sort 2 (gather) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
-            if (segmentedSortKeys(s, ctx->cuCount, gathered, sortedOut, nGroup, (int) (idBits + diagBits + 1), 1, top2, rk.current(), dst.p, nRec) != CDM_OK) {
+            if (segmentedSortKeys(s, ctx->cuCount, gathered, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, rk.current(), dst.p, nRec) != CDM_OK) {
                 cdm_set_error("cdm_kmermatch: segmented sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP;
             }
         }

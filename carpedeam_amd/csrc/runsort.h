@@ -10,9 +10,10 @@
 //   3. k_run_gather                expands the sorted records: the tuples of a representative become contiguous, still in
 //                                  k-mer order (what the reference's stable sort leaves for equal (rep, id, diagonal));
 //                                  dropped tuples (~0) vanish on the way, so this is also the compaction
-//   4. segmentedSortKeys           each representative's segment is sorted on (id, diagonal): by a wavefront in registers
-//                                  (bucket.h, segments up to 512 tuples), by a block of 2/4/8 wavefronts (k_block_sort, up to
-//                                  4096), by rocPRIM beyond that (deep pile-ups).
+//   4. segmentedSortKeys           each representative's segment is sorted on (id, diagonal): k_unit_sort (an LDS counting split
+//                                  on a monotone function of (rep, id), then register networks per group of sub-buckets) for
+//                                  segments up to 3072 tuples, a block-wide bitonic network (k_block_sort) up to 4096, rocPRIM
+//                                  beyond that (deep pile-ups).
 // The tuple array is read three times and written twice here (count, write, gather; local sort), against 10 reads and
 // 9 writes of the 4 radix passes + bucket finish this replaces.
 #pragma once
@@ -150,54 +151,204 @@ __global__ __launch_bounds__(1024) void k_seg_list(SegListArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- k_unit_sort
+// The segmented sort proper.  The array is cut into ranges of U_T slots; a block owns the segments (representatives) that START
+// in its range - its "unit", at most U_CAP tuples, all staged in LDS.  Representatives are replaced by their ordinal in the unit
+// (a prefix popcount over the segment-start bits), so a tuple's sort key is h = (ordinal, id), diagonal - a few dozen bits
+// whatever the ids of the representatives are.  The unit is first split on the top bits of h into 256 sub-buckets with an LDS
+// counting sort (a representative with 2000 tuples has members spread over the whole id range: ~8 tuples per sub-bucket), then
+// every wavefront sorts its 64 sub-buckets (as one group if they hold at most 512 tuples, else in groups of consecutive
+// sub-buckets) with the register network of bucket.h on words (h, diagonal, index in the unit): concatenated, the sorted groups
+// are the sorted unit, ties in input order.  A segment of more than maxSeg = U_CAP - U_T tuples never fits for sure and is left
+// to the caller (k_seg_list lists it); a unit with a sub-bucket beyond 512 tuples goes to the `hard` list (sorted by rocPRIM).
+constexpr int U_NT = 256, U_WAVES = U_NT / 64, U_T = 1024, U_CAP = 3328, U_FIRST = 2048, U_NB = 256, U_IDXB = 12, U_ORDB = 11;
+struct UnitArgs {
+    const uint64_t *in; uint64_t *out; uint64_t n;
+    int repShift;               // segment id = key >> repShift
+    int hiShift;                // (rep, id) = key >> hiShift; the bits below are sorted inside the sub-buckets, bit 0 rides along
+    uint32_t maxSeg;
+    uint32_t maxSub;            // largest sub-bucket a wave finishes (bucket::BK_MAXB; tests lower it to reach the hard path)
+    bucket::BigList hard;
+};
+// first set bit in [from, limit) / last set bit in [0, below) of the 64 words (one per lane), -1 if none.  Wave-uniform result.
+__device__ __forceinline__ int unitFirstSet(const unsigned long long *bits, int lane, int from, int limit) {
+    unsigned long long m = bits[lane];
+    if (lane == (from >> 6)) m &= ~0ull << (from & 63);
+    if (lane < (from >> 6) || lane * 64 >= limit) m = 0;
+    const unsigned long long any = __ballot(m != 0ull);
+    if (!any) return -1;
+    const int w = __ffsll(any) - 1;
+    const unsigned long long mw = bucket::readLane64(m, w);
+    const int p = w * 64 + __ffsll(mw) - 1;
+    return p < limit ? p : -1;
+}
+__device__ __forceinline__ int unitLastSet(const unsigned long long *bits, int lane, int below) {
+    unsigned long long m = bits[lane];
+    if (lane * 64 >= below) m = 0;
+    else if (lane == ((below - 1) >> 6) && (below & 63)) m &= (1ull << (below & 63)) - 1ull;
+    const unsigned long long any = __ballot(m != 0ull);
+    if (!any) return -1;
+    const int w = 63 - __clzll(any);
+    return w * 64 + 63 - __clzll(bucket::readLane64(m, w));
+}
+__global__ __launch_bounds__(U_NT) void k_unit_sort(UnitArgs a) {
+    __shared__ uint64_t sKeys[U_CAP];           // the window; the unit's part is rewritten with the ordinal in place of the representative
+    __shared__ uint16_t sPerm[U_CAP];
+    __shared__ unsigned long long sBits[64];
+    __shared__ unsigned int sPre[64];
+    __shared__ unsigned int sCnt[U_NB];
+    __shared__ unsigned int sOff[U_NB + 1];
+    __shared__ uint32_t sRep[U_T + 2];          // representative of the unit's segments by ordinal
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t base = (uint64_t) blockIdx.x * U_T;
+    const uint64_t prevKey = base ? a.in[base - 1] : 0ull;
+    // stage [LO, LO + ROUNDS * U_NT) of the window - all loads in flight together - and flag the segment starts in it (one
+    // ballot word per wave and round)
+    auto stage = [&](auto loTag, auto roundsTag) {
+        constexpr int LO = decltype(loTag)::value, ROUNDS = decltype(roundsTag)::value;
+        uint64_t k[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) { const uint64_t g = base + (uint64_t) (LO + r * U_NT + tid); k[r] = g < a.n ? a.in[g] : ~0ull; }   // behind the array: a representative of its own
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) sKeys[LO + r * U_NT + tid] = k[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) {
+            const int i = LO + r * U_NT + tid;
+            const uint64_t p = i ? sKeys[i - 1] : prevKey;
+            const unsigned long long m = __ballot((base + (uint64_t) i == 0) || ((k[r] >> a.repShift) != (p >> a.repShift)));
+            if (lane == 0) sBits[i >> 6] = m;
+        }
+        __syncthreads();
+    };
+    if (tid < 64) sBits[tid] = 0ull;
+    __syncthreads();
+    stage(std::integral_constant<int, 0>(), std::integral_constant<int, U_FIRST / U_NT>());
+    const int u0 = unitFirstSet(sBits, lane, 0, U_T);
+    if (u0 < 0 || base + (uint64_t) u0 >= a.n) return;          // no segment starts in this range (block-uniform)
+    int uEnd = unitFirstSet(sBits, lane, U_T, U_FIRST);
+    if (uEnd < 0) {
+        stage(std::integral_constant<int, U_FIRST>(), std::integral_constant<int, (U_CAP - U_FIRST) / U_NT>());
+        uEnd = unitFirstSet(sBits, lane, U_FIRST, U_CAP);
+    }
+    const int lastStart = unitLastSet(sBits, lane, U_T);
+    if (uEnd < 0 || (uint32_t) (uEnd - lastStart) > a.maxSeg) uEnd = lastStart;     // the last segment does not fit: the caller's
+    const int m = uEnd - u0;
+    if (m <= 0) return;
+    // ordinal of every segment: number of start bits in front of each word (wave 0), then a masked popcount per tuple
+    if (wave == 0) {
+        const unsigned int c = (unsigned int) __popcll(sBits[lane]);
+        sPre[lane] = cdm_wave_incl_sum<unsigned int>(c) - c;
+    }
+    sCnt[tid] = 0;                              // U_NB == U_NT
+    __syncthreads();
+    const int idBits = a.repShift - a.hiShift;
+    const unsigned int ord0 = sPre[u0 >> 6] + (unsigned int) __popcll(sBits[u0 >> 6] & ((2ull << (u0 & 63)) - 1ull));          // ordinal + 1 of the unit's first segment
+    const unsigned int nSeg = sPre[(uEnd - 1) >> 6] + (unsigned int) __popcll(sBits[(uEnd - 1) >> 6] & ((2ull << ((uEnd - 1) & 63)) - 1ull)) - ord0 + 1;
+    const uint64_t range = ((uint64_t) nSeg << idBits) - 1ull;
+    const int bl = range ? 64 - __clzll((long long) range) : 0, sh = max(0, bl - 8) + a.hiShift;       // sub-bucket = t >> sh
+    const uint64_t lowRep = (1ull << a.repShift) - 1ull;
+    // t = the key with the representative replaced by its ordinal in the unit (bit 0, the strand, still rides along); count
+    for (int i = u0 + tid; i < uEnd; i += U_NT) {
+        const unsigned long long w = sBits[i >> 6];
+        const unsigned int o = sPre[i >> 6] + (unsigned int) __popcll(w & ((2ull << (i & 63)) - 1ull)) - ord0;
+        const uint64_t k = sKeys[i];
+        if ((w >> (i & 63)) & 1ull) sRep[o] = (uint32_t) (k >> a.repShift);
+        const uint64_t t = ((uint64_t) o << a.repShift) | (k & lowRep);
+        sKeys[i] = t;
+        atomicAdd(&sCnt[(unsigned int) (t >> sh)], 1u);
+    }
+    __syncthreads();
+    const unsigned int c = sCnt[tid];
+    unsigned int tot;
+    const unsigned int ex = cdm_block_excl_sum<unsigned int>(c, tot);
+    sOff[tid] = ex;
+    if (tid == 0) sOff[U_NB] = tot;
+    const bool hard = __syncthreads_or(c > a.maxSub);
+    if (hard) { if (tid == 0) a.hard.add(base + (uint64_t) u0, base + (uint64_t) uEnd); return; }
+    sCnt[tid] = ex;                             // (cursor of the scatter; the order inside a sub-bucket does not matter: the
+    __syncthreads();                            //  word carries the tuple's index)
+    for (int i = u0 + tid; i < uEnd; i += U_NT) sPerm[atomicAdd(&sCnt[(unsigned int) (sKeys[i] >> sh)], 1u)] = (uint16_t) i;
+    __syncthreads();
+    // ---- every wave sorts its 64 sub-buckets
+    constexpr int PER = U_NB / U_WAVES;
+    const uint64_t outBase = base + (uint64_t) u0;
+    auto sortRange = [&](int g0, int gm) {
+        bucket::sortGroup<uint64_t>(gm, lane,
+            [&](int i) { const int e = sPerm[g0 + i]; return ((sKeys[e] >> 1) << U_IDXB) | (uint64_t) e; },
+            [&](auto &v) {
+                constexpr int R = sizeof(v) / sizeof(v[0]);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int p = lane * R + r;
+                    if (p < gm) { const uint64_t t = sKeys[(int) (v[r] & ((1u << U_IDXB) - 1u))]; a.out[outBase + (uint64_t) (g0 + p)] = ((uint64_t) sRep[t >> a.repShift] << a.repShift) | (t & lowRep); }
+                }
+            });
+    };
+    int b = wave * PER;
+    const int bLast = b + PER;
+    const int w0 = (int) sOff[b], wm = (int) sOff[bLast] - w0;
+    if (wm <= bucket::BK_MAXB) { if (wm > 0) sortRange(w0, wm); return; }
+    while (b < bLast) {
+        const int g0 = (int) sOff[b];
+        int bE = b + 1;
+        while (bE < bLast && (int) sOff[bE + 1] - g0 <= bucket::BK_GROUP) bE++;
+        const int gm = (int) sOff[bE] - g0;
+        if (gm > 0) sortRange(g0, gm);
+        b = bE;
+    }
+}
+
 // `in` holds the tuples grouped by representative (bits >= shiftHi), each group in k-mer order; `out` = every group stably
-// sorted on bits [ign, shiftHi).  recRep / dst / nRec describe the groups (sorted records and their output offsets).
-inline int segmentedSortKeys(hipStream_t s, int cuCount, const uint64_t *in, uint64_t *out, uint64_t n, int shiftHi, int ign, int top,
+// sorted on bits [1, shiftHi) (bit 0 rides along).  recRep / dst / nRec describe the groups (sorted records and their output
+// offsets); hiShift = diagonal bits + 1.  CDM_UNIT_CAP / CDM_BLOCK_CAP lower the capacities (tests).
+inline int segmentedSortKeys(hipStream_t s, int cuCount, const uint64_t *in, uint64_t *out, uint64_t n, int shiftHi, int hiShift, int top,
                              const uint32_t *recRep, const unsigned long long *dst, uint64_t nRec) {
     using namespace bucket;
     if (n == 0) return CDM_OK;
-    int own; uint32_t maxBucket; capacities(own, maxBucket);
-    uint32_t cap[3] = {1024, 2048, 4096};
-    if (const char *e = getenv("CDM_BLOCK_CAP")) { const long m = atol(e); if (m >= 1 && m <= 4096) { cap[2] = (uint32_t) m; cap[1] = std::min(cap[1], cap[2]); cap[0] = std::min(cap[0], cap[1]); } }
-    if (shiftHi - ign + BLK_IDX > 64) cap[0] = cap[1] = cap[2] = 0;       // the block sorter's word does not hold such keys: everything long goes to rocPRIM
-    // wave-sized segments
-    {
-        SortArgs a; a.in = in; a.out = out; a.n = n; a.shiftHi = shiftHi; a.ign = ign; a.own = own; a.maxBucket = maxBucket; a.big.list = nullptr; a.big.cnt = nullptr;
-        const uint64_t perBlock = (uint64_t) own * BK_WAVES;
-        hipLaunchKernelGGL(k_bucket_sort, dim3((unsigned) ((n + perBlock - 1) / perBlock)), dim3(BK_NT), 0, s, a);
-    }
-    // the longer ones, listed by size class
-    const size_t listCap = (size_t) (n / ((uint64_t) maxBucket + 1) + 2);
-    DevBuf<unsigned long long> lists[SEG_CLASSES]; DevBuf<unsigned int> cnt;
-    if (!cnt.alloc(SEG_CLASSES)) return CDM_ERR_HIP;
-    for (int c = 0; c < SEG_CLASSES; c++) if (!lists[c].alloc(2 * listCap)) return CDM_ERR_HIP;
-    hipMemsetAsync(cnt.p, 0, SEG_CLASSES * 4, s);
-    SegListArgs la; la.recRep = recRep; la.dst = dst; la.nRec = nRec; la.maxWave = maxBucket;
-    for (int c = 0; c < 3; c++) la.cap[c] = cap[c];
-    for (int c = 0; c < SEG_CLASSES; c++) la.list[c] = lists[c].p;
+    uint32_t maxSeg = U_CAP - U_T, blockCap = 4096;
+    if (const char *e = getenv("CDM_UNIT_CAP")) { const long m = atol(e); if (m >= 1 && m <= U_CAP - U_T) maxSeg = (uint32_t) m; }
+    if (const char *e = getenv("CDM_BLOCK_CAP")) { const long m = atol(e); if (m >= 0 && m <= 4096) blockCap = (uint32_t) m; }
+    uint32_t maxSub = BK_MAXB;
+    if (const char *e = getenv("CDM_UNIT_SUB")) { const long m = atol(e); if (m >= 1 && m <= BK_MAXB) maxSub = (uint32_t) m; }
+    if (shiftHi - 1 + BLK_IDX > 64) blockCap = 0;       // the block sorter's word does not hold such keys: rocPRIM takes them
+    if (U_ORDB + shiftHi - 1 + U_IDXB > 64) maxSeg = 0; // nor does the unit sorter's (ordinal, id, diagonal, index): everything goes to rocPRIM
+    const uint64_t units = (n + U_T - 1) / U_T;
+    const size_t listCap = (size_t) (n / ((uint64_t) maxSeg + 1) + 2);
+    DevBuf<unsigned long long> lists[SEG_CLASSES], hardList; DevBuf<unsigned int> cnt;
+    if (!cnt.alloc(SEG_CLASSES + 1) || !hardList.alloc(2 * (size_t) (units + 1))) return CDM_ERR_HIP;
+    for (int c = 2; c < SEG_CLASSES; c++) if (!lists[c].alloc(2 * (listCap + (c == 3 ? (size_t) units + 1 : 0)))) return CDM_ERR_HIP;
+    hipMemsetAsync(cnt.p, 0, (SEG_CLASSES + 1) * 4, s);
+    UnitArgs ua; ua.in = in; ua.out = out; ua.n = n; ua.repShift = shiftHi; ua.hiShift = hiShift; ua.maxSeg = maxSeg; ua.maxSub = maxSub; ua.hard.list = hardList.p; ua.hard.cnt = cnt.p + SEG_CLASSES;
+    if (maxSeg) hipLaunchKernelGGL(k_unit_sort, dim3((unsigned) units), dim3(U_NT), 0, s, ua);
+    // the segments no unit can hold, listed by size class: one block of 8 waves (bitonic network, bucket.h) up to 4096, rocPRIM beyond
+    SegListArgs la; la.recRep = recRep; la.dst = dst; la.nRec = nRec; la.maxWave = maxSeg;
+    la.cap[0] = 0; la.cap[1] = 0; la.cap[2] = blockCap;
+    for (int c = 0; c < SEG_CLASSES; c++) la.list[c] = lists[c].p;      // (classes 0 and 1 stay empty: their capacities are 0)
     la.cnt = cnt.p;
     hipLaunchKernelGGL(k_seg_list, dim3((unsigned) ((nRec + 1023) / 1024)), dim3(1024), 0, s, la);
-    BlockSortArgs ba; ba.in = in; ba.out = out; ba.shiftHi = shiftHi; ba.ign = ign;
-    const unsigned int grid = (unsigned int) std::min<uint64_t>((uint64_t) cuCount * 8, listCap);
-    ba.list = lists[0].p; ba.count = cnt.p + 0; hipLaunchKernelGGL(k_block_sort<2>, dim3(grid), dim3(128), 0, s, ba);
-    ba.list = lists[1].p; ba.count = cnt.p + 1; hipLaunchKernelGGL(k_block_sort<4>, dim3(grid), dim3(256), 0, s, ba);
-    ba.list = lists[2].p; ba.count = cnt.p + 2; hipLaunchKernelGGL(k_block_sort<8>, dim3(grid), dim3(512), 0, s, ba);
-    unsigned int hc[SEG_CLASSES] = {0, 0, 0, 0};
-    if (hipMemcpyAsync(hc, cnt.p, SEG_CLASSES * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
-    if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "segmentedSortKeys: n %llu, %llu records: segments > %u: %u (<= %u), %u (<= %u), %u (<= %u), %u longer\n",
-                                            (unsigned long long) n, (unsigned long long) nRec, maxBucket, hc[0], cap[0], hc[1], cap[1], hc[2], cap[2], hc[3]);
-    if (hc[3] == 0) return CDM_OK;
-    // deep pile-ups: gather, sort on the whole key with rocPRIM (stable), scatter
+    BlockSortArgs ba; ba.in = in; ba.out = out; ba.shiftHi = shiftHi; ba.ign = 1;
+    ba.list = lists[2].p; ba.count = cnt.p + 2;
+    if (blockCap) hipLaunchKernelGGL(k_block_sort<8>, dim3((unsigned int) std::min<uint64_t>((uint64_t) cuCount * 8, listCap)), dim3(512), 0, s, ba);
+    unsigned int hc[SEG_CLASSES + 1] = {0, 0, 0, 0, 0};
+    if (hipMemcpyAsync(hc, cnt.p, (SEG_CLASSES + 1) * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
+    if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "segmentedSortKeys: n %llu, %llu records, %llu units: segments > %u: %u (<= %u, block sort), %u longer (rocPRIM); %u hard units (rocPRIM)\n",
+                                            (unsigned long long) n, (unsigned long long) nRec, (unsigned long long) units, maxSeg, hc[2], blockCap, hc[3], hc[SEG_CLASSES]);
+    const unsigned int nBig = hc[3] + hc[SEG_CLASSES];
+    if (nBig == 0) return CDM_OK;
+    // deep pile-ups and hard units: gather, sort on the whole key with rocPRIM (stable), scatter.  (The ranges are disjoint and
+    // the array is grouped by representative, so one sort of their concatenation on the whole key sorts each of them.)
+    if (hc[SEG_CLASSES]) hipMemcpyAsync(lists[3].p + 2 * (size_t) hc[3], hardList.p, 2 * (size_t) hc[SEG_CLASSES] * 8, hipMemcpyDeviceToDevice, s);
     DevBuf<unsigned long long> ranges; uint64_t total = 0;
-    if (int rc = loadBigList(s, lists[3].p, hc[3], ranges, total)) return rc;
+    if (int rc = loadBigList(s, lists[3].p, nBig, ranges, total)) return rc;
     DevBuf<uint64_t> d0, d1; DevBuf<char> tmp; size_t tb = 0;
     if (!d0.alloc(total) || !d1.alloc(total)) return CDM_ERR_HIP;
-    const unsigned int g = bigCopyGrid(hc[3]);
-    hipLaunchKernelGGL((k_big_copy<uint64_t, true>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, hc[3], const_cast<uint64_t *>(in), d0.p);
+    const unsigned int g = bigCopyGrid(nBig);
+    hipLaunchKernelGGL((k_big_copy<uint64_t, true>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(in), d0.p);
     rocprim::double_buffer<uint64_t> db(d0.p, d1.p);
-    if (rocprim::radix_sort_keys(nullptr, tb, db, (size_t) total, ign, top, s) != hipSuccess || !tmp.alloc(tb + 256)) return CDM_ERR_HIP;
-    if (rocprim::radix_sort_keys(tmp.p, tb, db, (size_t) total, ign, top, s) != hipSuccess) return CDM_ERR_HIP;
-    hipLaunchKernelGGL((k_big_copy<uint64_t, false>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, hc[3], out, db.current());
+    if (rocprim::radix_sort_keys(nullptr, tb, db, (size_t) total, 1, top, s) != hipSuccess || !tmp.alloc(tb + 256)) return CDM_ERR_HIP;
+    if (rocprim::radix_sort_keys(tmp.p, tb, db, (size_t) total, 1, top, s) != hipSuccess) return CDM_ERR_HIP;
+    hipLaunchKernelGGL((k_big_copy<uint64_t, false>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, out, db.current());
     if (hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
     return CDM_OK;
 }

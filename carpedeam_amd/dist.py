@@ -1,14 +1,32 @@
 """One-process-per-GPU scaling of the hot path (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in CPU tests).
 
-The read corpus partitions into independent shards (north star: "reads shard trivially"): every rank runs the four stages
-on its own shard with no data-path collective, then ONE all-gather hands every rank the contigs of all shards.
+Two ways to spread ONE read corpus over W ranks (BASELINE.json configs[3]):
+
+* scheme "reads" (the north star's "reads shard trivially"): rank r owns the reads [r n/W, (r+1) n/W) and runs the four
+  stages on them alone - no data-path collective - then ONE all-gather hands every rank the contigs of all shards.  Overlaps
+  between reads of different shards are not seen, so the result differs from the single-device run (tests/test_gpu_shards.py
+  measures by how much); it equals the reference run shard by shard.
+* scheme "exact" (SURVEY.md 8(e)): every rank holds the whole packed read DB; kmermatcher is split by k-mer range (the
+  reference's MPI split, lib/mmseqs/src/linclust/kmermatcher.cpp:634-663), the (rep, id, diagonal) group tuples go to the
+  owner of their representative in ONE all-to-all, rescore / correction / extension run on the rank's query range, and the
+  new sequences are all-gathered.  Bit-identical to the single-device result (carpedeam_amd/shard.py).
+
+`scaling` says what N ranks share: "strong" = one corpus of n reads split over the ranks (default, config 4), "weak" = every
+rank gets its own n-read corpus (generator seed + rank).
 """
 import numpy as np
 
 
-def shard_plan(rank, world, reads_per_gpu, seed):
-    """Weak-scaling plan: rank r works on its own corpus of reads_per_gpu reads (generator seed + r)."""
-    return {"rank": rank, "world": world, "n": int(reads_per_gpu), "seed": int(seed) + int(rank)}
+def shard_plan(rank, world, n_reads, seed, scaling="strong"):
+    """Which reads rank `rank` of `world` generates / owns: {n_total, first, n, seed} for cdm_seqdb_synth."""
+    n_reads, rank, world = int(n_reads), int(rank), int(world)
+    if scaling == "weak":
+        return {"rank": rank, "world": world, "n_total": n_reads, "first": 0, "n": n_reads, "seed": int(seed) + rank, "scaling": "weak"}
+    if scaling != "strong":
+        raise ValueError("scaling must be strong or weak")
+    first = rank * n_reads // world
+    last = (rank + 1) * n_reads // world
+    return {"rank": rank, "world": world, "n_total": n_reads, "first": first, "n": last - first, "seed": int(seed), "scaling": "strong"}
 
 
 def max_over_ranks(dist, seconds, device="cpu"):
@@ -19,9 +37,53 @@ def max_over_ranks(dist, seconds, device="cpu"):
     return float(t.item())
 
 
+# ------------------------------------------------------------------------------------------------ one buffer, one all-gather
+# A rank's contig set travels as ONE int32 buffer: [codes: words][N planes, 16 bit per code word: ceil(words/2)][lengths: n]
+# [keys: n].  The sizes (n, words, key base) go ahead in a 3-number all-gather; then a single all_gather moves the padded
+# buffers - the "single RCCL all-gather of per-shard contigs" of the north star.
+def packed_layout(n, words):
+    """offsets (in int32 elements) of the four sections and the total"""
+    o_codes = 0
+    o_mask = o_codes + words
+    o_len = o_mask + (words + 1) // 2
+    o_key = o_len + n
+    return o_codes, o_mask, o_len, o_key, o_key + n
+
+
+def allgather_packed(dist, buf, n, words, key_base, world):
+    """buf: this rank's packed int32 buffer (packed_layout(n, words)).  Returns [(buf_r, n_r, words_r, key_base_r)] for all
+    ranks.  Two collectives: the sizes (3 int64) and the data."""
+    import torch
+    meta = torch.tensor([int(n), int(words), int(key_base)], dtype=torch.int64, device=buf.device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    metas = [[int(v) for v in m.tolist()] for m in metas]
+    mx = max(packed_layout(m[0], m[1])[4] for m in metas)
+    pad = torch.zeros(max(mx, 1), dtype=torch.int32, device=buf.device)
+    pad[: buf.numel()] = buf
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return [(p[: packed_layout(m[0], m[1])[4]], m[0], m[1], m[2]) for p, m in zip(parts, metas)]
+
+
+def merge_packed(parts):
+    """Concatenate the ranks' packed sets into (codes int32[words], nmask int16[words], lens int32[n], keys int64[n]);
+    keys become key_base_r + key so that they stay unique and ordered across the shards."""
+    import torch
+    codes, masks, lens, keys = [], [], [], []
+    for buf, n, words, base in parts:
+        oc, om, ol, ok, _ = packed_layout(n, words)
+        codes.append(buf[oc: oc + words])
+        masks.append(buf[om: ol].view(torch.int16)[:words])
+        lens.append(buf[ol: ol + n])
+        keys.append(buf[ok: ok + n].to(torch.int64) + int(base))
+    return torch.cat(codes), torch.cat(masks), torch.cat(lens), torch.cat(keys)
+
+
 def allgather_variable(dist, tensors, world):
-    """All-gather a tuple of 1-D tensors whose lengths differ between ranks (padding to the maximum, ONE size exchange and
-    one all_gather per tensor).  Returns, per tensor, the list of the ranks' un-padded parts."""
+    """All-gather a tuple of 1-D tensors whose lengths differ between ranks (padding to the maximum; one size exchange and
+    one all_gather per tensor).  Generic helper (shard.py's group-tuple exchange on gloo uses it); the contig hand-off uses
+    the single-buffer form above."""
     import torch
     sizes = torch.tensor([int(t.numel()) for t in tensors], dtype=torch.int64, device=tensors[0].device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
@@ -37,32 +99,36 @@ def allgather_variable(dist, tensors, world):
     return out
 
 
-def merge_contig_parts(codes, nmask, lens, keys, key_stride):
-    """Concatenate the ranks' packed contig sets; keys become rank * key_stride + key so they stay unique and ordered."""
-    import torch
-    k = [kk.to(torch.int64) + r * int(key_stride) for r, kk in enumerate(keys)]
-    return torch.cat(codes), torch.cat(nmask), torch.cat(lens), torch.cat(k)
-
-
-def allgather_contigs(dist, ctx, asm_db, world, key_stride):
-    """GPU path: contigs (wasExtended == 1) of this rank's assembled DB -> packed device tensors -> RCCL all-gather -> one
-    device DB holding the contigs of every shard (on every rank)."""
+def pack_contigs(ctx, asm_db):
+    """The contigs (wasExtended == 1) of an assembled DB as one packed int32 device tensor -> (buf, n, words)."""
     import torch
     contigs = asm_db.select_ext()
     n, words = contigs.n, contigs.words
     dev = torch.device("cuda", torch.cuda.current_device())
-    codes = torch.zeros(max(words, 1), dtype=torch.int32, device=dev)
-    nmask = torch.zeros(max(words, 1), dtype=torch.int16, device=dev)
-    lens = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
-    keys = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
-    contigs.copy_packed(codes.data_ptr(), nmask.data_ptr(), lens.data_ptr(), keys.data_ptr())
-    # the N bit planes travel widened to int32 (gloo, used by the CPU tests of this path, has no 16-bit integer type)
-    g = allgather_variable(dist, (codes[:words], nmask[:words].to(torch.int32), lens[:n], keys[:n]), world)
-    c, m, l, k = merge_contig_parts(*g, key_stride=key_stride)
-    m = m.to(torch.int16)
-    if int(k.max().item()) >= 2 ** 32 if k.numel() else False:
+    oc, om, ol, ok, total = packed_layout(n, words)
+    buf = torch.zeros(max(total, 1), dtype=torch.int32, device=dev)
+    # the library copies on its own (non-blocking) stream: torch's zero fill has to be complete before it starts
+    torch.cuda.synchronize()
+    base = buf.data_ptr()
+    contigs.copy_packed(base + 4 * oc, base + 4 * om, base + 4 * ol, base + 4 * ok)     # (synchronises the library's stream)
+    return buf[:total], n, words
+
+
+def unpack_to_db(ctx, parts, ext_value=1):
+    """merged device DB from allgather_packed's parts"""
+    import torch
+    c, m, l, k = merge_packed(parts)
+    if k.numel() and int(k.max().item()) >= 2 ** 32:
         raise ValueError("contig keys overflow 32 bits")
     k32 = k.to(torch.int32).contiguous()
     c, m, l = c.contiguous(), m.contiguous(), l.contiguous()
-    torch.cuda.synchronize()
-    return ctx.from_packed(c.data_ptr(), m.data_ptr(), l.data_ptr(), k32.data_ptr(), int(l.numel()), int(c.numel()), 1)
+    torch.cuda.synchronize()     # torch's stream wrote the merged tensors; the library reads them on its own stream
+    return ctx.from_packed(c.data_ptr(), m.data_ptr(), l.data_ptr(), k32.data_ptr(), int(l.numel()), int(c.numel()), ext_value)
+
+
+def allgather_contigs(dist, ctx, asm_db, world, key_base):
+    """GPU path of scheme "reads": contigs of this rank's assembled DB -> one packed device buffer -> ONE RCCL all-gather ->
+    a device DB holding the contigs of every shard (on every rank)."""
+    buf, n, words = pack_contigs(ctx, asm_db)
+    parts = allgather_packed(dist, buf, n, words, key_base, world)
+    return unpack_to_db(ctx, parts)

@@ -111,10 +111,12 @@ def test_kmermatch_bucket_sort_paths_agree(ctx, oracle_bin, tmp_path, monkeypatc
     want = strip_ext(mmdb.read_db(t("pref")))
     for env in ({}, {"CDM_BUCKET_CAP": "64"}, {"CDM_BUCKET_CAP": "5"}, {"CDM_BUCKET_CAP": "3,17"}, {"CDM_BUCKET_CAP": "1"}, {"CDM_BUCKET_CAP": "512,40"},
                 {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_BUCKET_CAP": "6,100"},
-                # sort 2: the all-radix variant, both variants compared on the device, the block sorters on short segments
-                # (wave capacity 5), rocPRIM beyond 8 tuples, and every segment through rocPRIM
-                {"CDM_KMER_SORT2": "radix"}, {"CDM_KMER_SORT2": "check"}, {"CDM_KMER_SORT2": "check", "CDM_BUCKET_CAP": "5"},
-                {"CDM_KMER_SORT2": "check", "CDM_BUCKET_CAP": "5", "CDM_BLOCK_CAP": "8"}, {"CDM_BUCKET_CAP": "2,9", "CDM_BLOCK_CAP": "1"}):
+                # sort 2: the all-radix variant; both variants compared on the device; the unit sorter limited to segments of 5
+                # tuples (the rest through the block-wide network), rocPRIM beyond 8 tuples, every segment through rocPRIM, units with
+                # a sub-bucket of more than 3 tuples through the hard list
+                {"CDM_KMER_SORT2": "radix"}, {"CDM_KMER_SORT2": "check"}, {"CDM_KMER_SORT2": "check", "CDM_UNIT_CAP": "5"},
+                {"CDM_KMER_SORT2": "check", "CDM_UNIT_CAP": "5", "CDM_BLOCK_CAP": "8"}, {"CDM_UNIT_CAP": "1", "CDM_BLOCK_CAP": "0"},
+                {"CDM_KMER_SORT2": "check", "CDM_UNIT_SUB": "3"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         assert not diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), want), env
@@ -128,7 +130,7 @@ def test_kmermatch_variants_identical_at_scale(ctx, monkeypatch):
     db = ctx.synth(1_000_000, 100, 100, 5)
     ref = None
     for env in ({}, {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_KMER_SORT": "lsd"}, {"CDM_BUCKET_CAP": "48"},
-                {"CDM_KMER_SORT2": "radix"}, {"CDM_KMER_SORT2": "check"}, {"CDM_KMER_SORT2": "check", "CDM_BUCKET_CAP": "300"}):
+                {"CDM_KMER_SORT2": "radix"}, {"CDM_KMER_SORT2": "check"}, {"CDM_KMER_SORT2": "check", "CDM_UNIT_CAP": "700"}, {"CDM_KMER_SORT2": "check", "CDM_UNIT_SUB": "12"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         off, rec = ctx.kmermatch(db).download()

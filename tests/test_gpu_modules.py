@@ -54,16 +54,26 @@ def test_error_behaviour(tmp_path):
     assert r.returncode != 0 and "Profile not 12 fields" in r.stderr
 
 
-def test_fused_reads_loop_equals_stage_by_stage(tmp_path, dhigh_prefix):
-    """`ancient_reads_loop` (all iterations in one process, intermediates in HBM) ends in the same sequence DB as the
-    reference's stage-by-stage goldens after 3 iterations."""
+def test_fused_reads_loop_equals_stage_by_stage(tmp_path, dhigh_prefix, oracle_bin):
+    """`ancient_reads_loop` (all iterations in one process, intermediates in HBM) ends in exactly the sequence DB the oracle's
+    stage-by-stage chain (3 iterations x 4 modules on DB files, the deterministic strand-tie rule of DESIGN.md N1) ends in;
+    against the reference's goldens - which chain the reference's own prefilter DBs with its run-dependent tie - only the
+    sequences a sign-only prefilter difference can reach may differ, and that set is checked to be what the oracle differs in."""
     from carpedeam_amd import build
+    from gpuutil import run_oracle
     build.build()
     t = lambda s: str(tmp_path / s)
     mmdb.write_from_keyed(t("in"), gold("mixed3k", "reads"), mmdb.DBTYPE_NUCLEOTIDES)
     run("ancient_reads_loop", t("in"), t("out"), "--ancient-damage", dhigh_prefix, "--num-iter-reads-only", "3")
-    got, exp = mmdb.read_db(t("out")), gold("mixed3k", "asm", 2)
-    bad = diff_keys(got, exp)
-    # the goldens chain the reference's own prefilter DBs, which may carry its run-dependent strand tie (N1): compare
-    # with the oracle chain too when anything differs
-    assert len(bad) <= 2, bad[:5]
+    got = mmdb.read_db(t("out"))
+    cur = t("in")
+    for it in range(3):
+        nxt = t("o%d" % it)
+        run_oracle(oracle_bin, "kmermatcher", cur, t("opref"), *K_FLAGS, "--threads", "4")
+        run_oracle(oracle_bin, "rescorediagonal", cur, cur, t("opref"), t("oaln"), *R_FLAGS, "--threads", "4")
+        run_oracle(oracle_bin, "ancient_correction", cur, t("oaln"), t("ocorr"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "4")
+        run_oracle(oracle_bin, "ancient_read_assemble", t("ocorr"), t("oaln"), nxt, *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "4")
+        cur = nxt
+    want = mmdb.read_db(cur)
+    assert not diff_keys(got, want)
+    assert diff_keys(got, gold("mixed3k", "asm", 2)) == diff_keys(want, gold("mixed3k", "asm", 2))
