@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
 """Headline benchmark: corrected bases/s of the MI355X hot path on synthetic dhigh reads (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--len L]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--len L] [--config 2|3] [--scaling strong|weak]
 
-A "step" is one pass of  kmermatcher -> rescorediagonal -> ancient_correction -> ancient_read_assemble  over one batch of
-R synthetic reads per GPU that is already resident in HBM (generated on the device before the timed region).  Ranks are
-independent partitions (weak scaling: every rank gets its own R-read corpus, seed + rank); after the last timed step the
-per-shard contigs are all-gathered over RCCL (N > 1).  Rank 0 prints ONE JSON line.
+A "step" is one pass of  kmermatcher -> rescorediagonal -> ancient_correction -> ancient_read_assemble  (--config 3, default:
+BASELINE.json configs[2]; with N > 1 configs[3]) or of ancient_correction alone (--config 2: configs[1], 5 M reads) over
+synthetic reads that are already resident in HBM (generated on the device before the timed region).
+
+N > 1 (one process per GPU; the driver launches them with torch.distributed.run, `--gpus N` alone spawns them): ONE corpus of R
+reads is split over the ranks (--scaling strong, default: rank r owns reads [r R/N, (r+1) R/N); --scaling weak gives every rank
+its own R-read corpus, seed + rank); every rank runs the stages on its shard with no data-path collective (scheme "reads",
+carpedeam_amd/dist.py) and after the last timed step the per-shard contigs are all-gathered over RCCL in ONE collective.
+Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes
+import csv
+import glob
 import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -21,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# algorithmic bytes per base, SURVEY.md 8(d) (L = 100, k = 20): kmermatcher, rescorediagonal, ancient_correction, extender
+ALG_B_PER_BASE = {"kmermatcher": 26.8, "rescorediagonal": 2.1, "ancient_correction": 2.0, "ancient_read_assemble": 1.3}
 
 
 def baseline_metric():
@@ -28,47 +37,91 @@ def baseline_metric():
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
-        return "corrected bases/sec on 50M\u00d7100bp synthetic reads (dhigh), 1/2/4/8 GPU"
+        return "corrected bases/sec on 50M×100bp synthetic reads (dhigh), 1/2/4/8 GPU"
 
 
-def cpu_baseline(n_reads, L, seed, threads):
-    """Time the four stages of the reference's own object code (oracle/_ref, built by oracle/Makefile.ref) - or, when that
-    binary is absent, the CPU restatement oracle/cdm_oracle.cpp - on a bounded sample of the same synthetic workload."""
-    from carpedeam_amd import capi, mmdb, synth
+def stage_cmds(p, exe_threads, dmg):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
+    th = ["--threads", str(exe_threads)]
+    return [("kmermatcher", [p("reads"), p("pref")] + K_FLAGS + th),
+            ("rescorediagonal", [p("reads"), p("reads"), p("pref"), p("aln")] + R_FLAGS + th),
+            ("ancient_correction", [p("reads"), p("aln"), p("corr")] + A_FLAGS + dmg + th),
+            ("ancient_read_assemble", [p("corr"), p("aln"), p("asm")] + A_FLAGS + dmg + th)]
+
+
+def module_walls(n_reads, L, seed, threads):
+    """Module-wall figures on DB FILES of one bounded sample: the four stages of the reference's own
+    object code (oracle/_ref; the CPU restatement oracle/cdm_oracle.cpp when that binary is absent) on `threads` host threads
+    = cpu_baseline, and the same four modules + the fused reads loop of the MI355X host binary carpedeam_amd/carpedeam
+    (DB read/parse, upload, kernels, download, text, DB write all inside) = gpu_module_wall."""
+    from carpedeam_amd import capi, mmdb, synth
     ref = os.path.join(ROOT, "oracle", "_ref", "carpedeam_ref")
-    kind = "reference"
-    exe = ref
+    kind, exe = "reference", ref
     if not os.path.exists(ref):
-        kind = "port"
-        exe = os.path.join(ROOT, "oracle", "_build", "cdm_oracle")
+        kind, exe = "port", os.path.join(ROOT, "oracle", "_build", "cdm_oracle")
         if not os.path.exists(exe):
             subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    gpu_bin = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
     ctx = capi.Ctx(0)
     seqs, _, _ = ctx.synth(n_reads, L, L, seed).download()
     del ctx
+    out = {}
     with tempfile.TemporaryDirectory() as d:
         p = lambda s: os.path.join(d, s)
         mmdb.write_seqdb(p("reads"), seqs)
         synth.write_dhigh_profiles(p("dhigh"))
-        th = ["--threads", str(threads)]
         dmg = ["--ancient-damage", p("dhigh")]
-        stages = [("kmermatcher", [p("reads"), p("pref")] + K_FLAGS + th),
-                  ("rescorediagonal", [p("reads"), p("reads"), p("pref"), p("aln")] + R_FLAGS + th),
-                  ("ancient_correction", [p("reads"), p("aln"), p("corr")] + A_FLAGS + dmg + th),
-                  ("ancient_read_assemble", [p("corr"), p("aln"), p("asm")] + A_FLAGS + dmg + th)]
-        times = {}
-        for name, args in stages:
-            t0 = time.perf_counter()
-            r = subprocess.run([exe, name] + args, capture_output=True, text=True)
-            if r.returncode != 0:
-                raise RuntimeError("cpu baseline stage %s failed: %s" % (name, r.stderr[-500:]))
-            times[name] = time.perf_counter() - t0
-    total = sum(times.values())
-    return {"value": n_reads * L / total, "unit": "corrected bases/s", "cores": threads, "kind": kind,
-            "sample": "%d synthetic %d bp dhigh reads (seed %d, 20x coverage), four-stage chain incl. DB read/parse/write, %d threads; stage s: %s"
-                      % (n_reads, L, seed, threads, ", ".join("%s %.2f" % (k, v) for k, v in times.items()))}
+        for label, binary in (("cpu", exe), ("gpu", gpu_bin)):
+            times = {}
+            for name, a in stage_cmds(p, threads, dmg):
+                t0 = time.perf_counter()
+                r = subprocess.run([binary, name] + a, capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError("%s module %s failed: %s" % (label, name, r.stderr[-400:]))
+                times[name] = time.perf_counter() - t0
+            out[label] = times
+        t0 = time.perf_counter()
+        r = subprocess.run([gpu_bin, "ancient_reads_loop", p("reads"), p("loop_out")] + dmg + ["--num-iter-reads-only", "1"], capture_output=True, text=True)
+        loop_s = time.perf_counter() - t0 if r.returncode == 0 else None
+    fmt = lambda t: ", ".join("%s %.2f" % kv for kv in t.items())
+    sample = "%d synthetic %d bp dhigh reads (seed %d, 20x coverage), four modules on DB files incl. DB read/parse/write" % (n_reads, L, seed)
+    cpu = {"value": n_reads * L / sum(out["cpu"].values()), "unit": "corrected bases/s", "cores": threads, "kind": kind,
+           "sample": sample + ", %d threads; stage s: %s" % (threads, fmt(out["cpu"])),
+           "ancient_correction_only_value": n_reads * L / out["cpu"]["ancient_correction"]}
+    gpu = {"value": n_reads * L / sum(out["gpu"].values()), "unit": "corrected bases/s", "what": "carpedeam_amd/carpedeam, one process per module (context creation, DB files, upload, text codecs included)",
+           "sample": sample + "; stage s: %s" % fmt(out["gpu"]),
+           "fused_reads_loop_value": (n_reads * L / loop_s) if loop_s else None}
+    return cpu, gpu
+
+
+def profile_ratio():
+    """histogram launch / iteration launch duration of sort 1's rocPRIM kernels, from the committed rocprofv3 summary of this
+    command (profiles/r02_bench50M_kernel_stats.csv); used to take the one histogram launch out of the HIP-event time of the
+    sort call"""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench50M_kernel_stats.csv"))):
+        it = hist = None
+        for r in csv.DictReader(open(f)):
+            n = r["Name"]
+            if "rocprim" not in n or not re.search(r">, 9u, \(rocprim", n):
+                continue
+            if "onesweep_iteration" in n:
+                it = float(r["AverageNs"])
+            elif "onesweep_global_offsets" in n:
+                hist = float(r["AverageNs"])
+        if it and hist:
+            best = (hist / it, os.path.basename(f))
+    return best or (1.31, "default")
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (before anything touches the GPU) and exit with their code"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
 
 
 def main():
@@ -76,16 +129,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("CDM_BENCH_READS", 50_000_000)), help="reads per GPU")
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3), help="BASELINE.json configs index + 1: 2 = ancient_correction only on 5 M reads, 3 = full chain on 50 M reads")
+    ap.add_argument("--reads", type=int, default=None, help="reads of the corpus (strong scaling) / per GPU (weak)")
     ap.add_argument("--len", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
     ap.add_argument("--cpu-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.reads is None:
+        args.reads = int(os.environ.get("CDM_BENCH_READS", 5_000_000 if args.config == 2 else 50_000_000))
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE is %d: running on %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
     import torch
     dist = None
     if world > 1 or os.environ.get("CDM_FORCE_DIST"):   # CDM_FORCE_DIST: exercise the collective path on one GPU
@@ -101,21 +162,30 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         synth.write_dhigh_profiles(os.path.join(d, "dhigh"))
         ctx.damage_load(os.path.join(d, "dhigh"))
-    n, L = args.reads, args.len
+    L = args.len
     from carpedeam_amd import dist as cd
-    plan = cd.shard_plan(rank, world, n, args.seed)
-    db = ctx.synth(plan["n"], L, L, plan["seed"])      # resident in HBM before the timed region
+    plan = cd.shard_plan(rank, world, args.reads, args.seed, args.scaling)
+    db = ctx.synth(plan["n"], L, L, plan["seed"], n_total=plan["n_total"], first=plan["first"])      # resident in HBM before the timed region
+    n = plan["n"]
     residues = db.residues
 
+    pre = None
+    if args.config == 2:      # the alignment set ancient_correction works on, made once outside the timed region
+        hits = ctx.kmermatch(db)
+        pre = ctx.rescore(db, hits)
+        del hits
+
     def step():
+        if args.config == 2:
+            corr = ctx.correct(db, pre)
+            return corr, (0, pre.count), [ctx.last_kernel_ms(i) for i in range(12)]
         hits = ctx.kmermatch(db)
         alns = ctx.rescore(db, hits)
         stats = (hits.count, alns.count)
         del hits
         corr = ctx.correct(db, alns)
         asm = ctx.extend(corr, alns)
-        ms = [ctx.last_kernel_ms(i) for i in range(8)]
-        return asm, stats, ms
+        return asm, stats, [ctx.last_kernel_ms(i) for i in range(12)]
 
     def sync():
         if dist is not None:
@@ -127,7 +197,7 @@ def main():
         del out
     sync()
     t0 = time.perf_counter()
-    kernel_ms = [0.0] * 8
+    kernel_ms = [0.0] * 12
     stats = (0, 0)
     asm = None
     for _ in range(args.steps):
@@ -137,67 +207,94 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     gathered = None
+    total_bases = residues * args.steps
     if dist is not None:
         dt = cd.max_over_ranks(dist, dt, device="cuda")
-        # the single data-path collective of the north star: RCCL all-gather of the per-shard contigs (packed bases,
-        # lengths, keys); every rank ends up holding the contigs of all shards as one device DB
-        t1 = time.perf_counter()
-        allc = cd.allgather_contigs(dist, ctx, asm, world, key_stride=n)
-        torch.cuda.synchronize()
-        gathered = {"contigs": allc.n, "bases": allc.residues, "seconds": time.perf_counter() - t1}
+        tb = torch.tensor([float(total_bases)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tb)
+        total_bases = float(tb.item())
+        if args.config == 3:
+            # the single data-path collective of the north star: RCCL all-gather of the per-shard contigs (packed bases, N
+            # planes, lengths, keys in ONE buffer); every rank ends up holding the contigs of all shards as one device DB
+            t1 = time.perf_counter()
+            allc = cd.allgather_contigs(dist, ctx, asm, world, key_base=plan["first"] if args.scaling == "strong" else rank * args.reads)
+            torch.cuda.synchronize()
+            gathered = {"contigs": allc.n, "bases": allc.residues, "seconds": time.perf_counter() - t1}
     if rank == 0:
-        total_bases = residues * args.steps * world
         k_ms = [m / args.steps for m in kernel_ms]
-        # Dominant kernel (rocprofv3 --stats, profiles/): rocPRIM's radix_sort_onesweep_iteration<u64 key, u32 value> in the 9-bit
-        # configuration kmermatcher's sort 1 uses on the packed 12-byte tuples of the k-mer slots: the top 27 of their
-        # 2k + 1 = 41 sort bits go through 3 passes (the low 14 bits are finished on chip by k_bucket_groups); rocPRIM sorts at
-        # most 2^30 items per launch, so a pass is ceil(items / 2^30) launches.  (The n whole-sequence hash tuples are sorted by
-        # the default 8-bit configuration, a different kernel: 8 short launches, 3 ms per step.)
-        # Algorithmic bytes of one launch: its 12-byte tuples read once and written once.  The average launch
-        # duration comes from the HIP-event time of the sort call on the library's stream; the call also runs one histogram
-        # launch per 2^30 items, which costs about half an iteration launch (it reads the 8-byte keys once).
-        tuples_per_read = L - 20 + 2
-        n1 = tuples_per_read * n
-        c1 = -(-n1 // (1 << 30))
-        p1 = -(-min(27, 2 * 20 + 1) // 9)
-        launches = p1 * c1
-        t1 = k_ms[5] * launches / (launches + 0.5 * c1) if k_ms[5] > 0 else 0.0      # ms spent in the iteration launches
-        bytes_all = 2.0 * 12.0 * p1 * n1                                   # summed over this kernel's launches in one step
-        iter_ms = t1 / launches if launches else 0.0                       # = rocprof's AverageNs for this kernel
-        sort_bytes = bytes_all / launches if launches else 0.0
-        achieved = bytes_all / (t1 * 1e-3) / 1e9 if t1 > 0 else 0.0
-        # HBM traffic of that kernel from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc runs of
-        # this very command at the default size; profiles/r01_pmc_50M.json) - only quoted for the workload it was measured on
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_50M_l.json")
-        if n == 50_000_000 and L == 100 and os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc))["kernels"]["rocprim onesweep_iteration 9-bit <u64, u32>"]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        step_ms = 1e3 * dt / args.steps
+        bases_step = n * L
+        gbs = lambda b_per_base, ms: (b_per_base * bases_step / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
+        if args.config == 2:
+            # ancient_correction only: the dominant kernel is k_correct_fast (one launch per step, HIP events around it on the
+            # context stream); algorithmic bytes 2.0 B/base
+            ach = gbs(ALG_B_PER_BASE["ancient_correction"], k_ms[0])
+            roof = {"bound": "hbm", "kernel": "k_correct_fast (pile-up + per-base call, one launch per step)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k_ms[0], "launches_per_step": 1,
+                    "algorithmic_bytes_per_launch": ALG_B_PER_BASE["ancient_correction"] * bases_step,
+                    "stage_level": {"ancient_correction": {"ms": k_ms[10], "achieved": gbs(ALG_B_PER_BASE["ancient_correction"], k_ms[10]), "unit": "GB/s"}}}
+            workload = "%d synthetic %d bp reads, dhigh, ancient_correction only on the alignments of one kmermatcher + rescorediagonal pass (BASELINE.json configs[1])" % (n, L)
+        else:
+            # Dominant kernel by rocprofv3 --stats (profiles/): rocPRIM's radix_sort_onesweep_iteration<u64 key, u32 value> in the
+            # 9-bit configuration of kmermatcher's sort 1: 3 passes over the packed 12-byte tuples of the k-mer slots, at most
+            # 2^30 items per launch.  Algorithmic bytes of one launch: its tuples read once + written once.  Its average launch
+            # time: the HIP-event time of the sort call on the library's stream holds those launches + ONE digit-histogram
+            # launch over all keys; the histogram's share is taken out with the histogram/iteration duration ratio of the
+            # committed rocprofv3 summary of this same command.
+            tuples_per_read = L - 20 + 2
+            n1 = tuples_per_read * n
+            c1 = -(-n1 // (1 << 30))
+            p1 = -(-min(27, 2 * 20 + 1) // 9)
+            launches = p1 * c1
+            ratio, ratio_src = profile_ratio()
+            iter_ms = k_ms[5] / (launches + ratio) if k_ms[5] > 0 else 0.0
+            sort_bytes = 2.0 * 12.0 * n1 / c1
+            achieved = sort_bytes / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
+            traffic, traffic_total = None, None
+            pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_50M*.json")))
+            if n == 50_000_000 and L == 100 and world == 1 and pmcs:
+                try:
+                    pj = json.load(open(pmcs[-1]))
+                    traffic = pj["kernels"]["rocprim onesweep_iteration 9-bit <u64, u32>"]["hbm_bytes_per_launch"]
+                    traffic_total = {"file": os.path.basename(pmcs[-1]), "hbm_bytes_per_step": pj.get("stages")}
+                except Exception:
+                    traffic = None
+            stages = {"kmermatcher": k_ms[8], "rescorediagonal": k_ms[9], "ancient_correction": k_ms[10], "ancient_read_assemble": k_ms[11]}
+            roof = {"bound": "hbm", "kernel": "rocprim radix_sort_onesweep_iteration<u64 key, u32 value> (9-bit configuration; kmermatcher sort 1: 3 passes over the k-mer slots)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "avg_launch_ms": iter_ms, "launches_per_step": launches, "algorithmic_bytes_per_launch": sort_bytes,
+                    "how": "sort-1 call %.2f ms (HIP events) / (%d iteration launches + 1 histogram launch x %.2f [%s])" % (k_ms[5], launches, ratio, ratio_src),
+                    # the figures that price the radix passes as overhead (the tuple array is written once and read
+                    # once): every stage's whole call (HIP events on the context stream around everything it launched) against its
+                    # algorithmic bytes, and the chain against 32.2 B/base
+                    "stage_level": {s: {"ms": ms, "achieved": gbs(ALG_B_PER_BASE[s], ms), "unit": "GB/s", "frac": gbs(ALG_B_PER_BASE[s], ms) / HBM_PEAK_GBS} for s, ms in stages.items()},
+                    "chain": {"alg_bytes_per_base": sum(ALG_B_PER_BASE.values()), "achieved": gbs(sum(ALG_B_PER_BASE.values()), step_ms), "unit": "GB/s",
+                              "frac": gbs(sum(ALG_B_PER_BASE.values()), step_ms) / HBM_PEAK_GBS},
+                    "traffic_total": traffic_total}
+            workload = "%d synthetic %d bp reads%s, dhigh, full correction + kmermatcher/rescorediagonal/ancient_read_assemble (BASELINE.json configs[%d])" % (
+                args.reads, L, (" split over %d GPUs (%d per GPU)" % (world, n)) if world > 1 and args.scaling == "strong" else (" per GPU" if world > 1 else ""), 3 if world > 1 else 2)
         line = {
             "metric": baseline_metric(), "value": total_bases / dt, "unit": "corrected bases/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8 (2-bit packed bases; int32 scores; software x87 f80 likelihood sums)", "data": "synthetic",
-            "config": {"workload": "%d synthetic %d bp reads per GPU, dhigh, full correction + kmermatcher/rescorediagonal/ancient_read_assemble (BASELINE.json configs[2])" % (n, L),
-                       "reads_per_gpu": n, "read_len": L, "seed": args.seed, "prefilter_hits": stats[0], "alignments": stats[1],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "u8 (2-bit packed bases; int32 scores; software x87 f80 likelihood sums)", "data": "synthetic",
+            "config": {"workload": workload, "reads_rank0": n, "read_len": L, "seed": args.seed, "prefilter_hits": stats[0], "alignments": stats[1],
+                       "multi_gpu_scheme": ("reads: every rank runs the stages on its own read shard, no data-path collective, one all-gather of contigs at the end" if world > 1 else None),
+                       "value_is": "kernel-resident: reads already in HBM, no DB files (the module-wall figure is gpu_module_wall)",
                        "stage_kernel_ms": {"kmer_extract": k_ms[3], "kmer_sort1_call": k_ms[5], "kmer_sort1_hash_call": k_ms[7], "kmer_sort2_call": k_ms[6], "rescore": k_ms[1],
                                            "correct": k_ms[0], "extend": k_ms[4]}},
-            "roofline": {"bound": "hbm", "kernel": "rocprim radix_sort_onesweep_iteration<u64 key, u32 value> (9-bit configuration; kmermatcher sort 1: 3 passes over the k-mer slots)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": iter_ms, "launches_per_step": launches, "algorithmic_bytes_per_launch": sort_bytes,
-                         "stage_level": {"what": "whole kmermatcher stage against its algorithmic bytes (26.8 B/base, SURVEY.md 8(d))",
-                                         "achieved": 26.8 * n * L / ((k_ms[3] + k_ms[5] + k_ms[6] + k_ms[7]) * 1e-3) / 1e9 if (k_ms[3] + k_ms[5] + k_ms[6]) > 0 else 0.0,
-                                         "unit": "GB/s"}},
+            "roofline": roof,
         }
         if gathered is not None:
             line["config"]["allgather_contigs"] = gathered
         if not args.no_cpu_baseline and world == 1:
             try:
                 # the pool gives a one-GPU job 16 host cores; the reference's kmermatcher slows down when oversubscribed
-                line["cpu_baseline"] = cpu_baseline(args.cpu_reads, L, args.seed, min(os.cpu_count() or 1, int(os.environ.get("CDM_CPU_THREADS", 16))))
+                cpu, gpu = module_walls(args.cpu_reads, L, args.seed, min(os.cpu_count() or 1, int(os.environ.get("CDM_CPU_THREADS", 16))))
+                line["cpu_baseline"] = cpu
+                line["gpu_module_wall"] = gpu
             except Exception as e:   # the baseline is reported, never required for the GPU number
-                line["cpu_baseline"] = {"value": None, "unit": "corrected bases/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": str(e)[:200]}
+                line["cpu_baseline"] = {"value": None, "unit": "corrected bases/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": str(e)[:300]}
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -37,6 +37,47 @@ Args parse(int argc, char **argv) {
     }
     return a;
 }
+// Per-module flag tables (the reference's own lists: lib/mmseqs/src/commons/Parameters.cpp:871-892 kmermatcher, :422-439
+// rescorediagonal, src/commons/LocalParameters.h:155-171 assembleresults = ancient_correction / ancient_read_assemble).
+//   'U' used by the MI355X path;  'N' accepted, no effect on this path in the reference either (or only on resources);
+//   'V' accepted only with one of the listed values (anything else would be computed differently: refused).
+// A flag that is not in the module's list is an error, as in Parameters::parseParameters (:1703 "Unrecognized parameter").
+struct FlagSpec { const char *name; char kind; const char *allowed; const char *why; };
+const FlagSpec KMERMATCHER_FLAGS[] = {
+    {"--kmer-per-seq", 'U', 0, 0}, {"--kmer-per-seq-scale", 'U', 0, 0}, {"--cov-mode", 'U', 0, 0}, {"-k", 'U', 0, 0}, {"-c", 'U', 0, 0}, {"--hash-shift", 'U', 0, 0},
+    {"--include-only-extendable", 'U', 0, 0}, {"--ignore-multi-kmer", 'U', 0, 0},
+    {"--alph-size", 'N', 0, "nucleotide k-mers are never reduced (kmermatcher.cpp:604)"}, {"--min-seq-id", 'N', 0, "not read by kmermatcher"},
+    {"--max-seq-len", 'N', 0, "buffer sizing"}, {"--split-memory-limit", 'N', 0, "the device path is single-split"}, {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0},
+    {"--sub-mat", 'V', "*nucleotide.out*", "only the nucleotide matrix"}, {"--mask", 'V', "0", "tantan masking is not implemented"},
+    {"--mask-lower-case", 'V', "0", "lower-case masking is not implemented"}, {"--spaced-kmer-mode", 'V', "0", "spaced k-mers are not implemented"},
+    {"--spaced-kmer-pattern", 'V', "", "spaced k-mers are not implemented"}, {"--adjust-kmer-len", 'V', "0", "k-mer length adjustment is not implemented"},
+    {"--compressed", 'V', "0", "compressed DBs are not implemented"}, {0, 0, 0, 0}};
+const FlagSpec RESCORE_FLAGS[] = {
+    {"-e", 'U', 0, 0}, {"-c", 'U', 0, 0}, {"--cov-mode", 'U', 0, 0}, {"--min-seq-id", 'U', 0, 0}, {"--min-aln-len", 'U', 0, 0},
+    {"--add-self-matches", 'N', 0, "query DB == target DB: self matches are kept anyway (rescorediagonal.cpp:205)"}, {"--db-load-mode", 'N', 0, 0}, {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0},
+    {"--seq-id-mode", 'V', "0", "only alignment-length normalisation"}, {"--rescore-mode", 'V', "3", "only the end-to-end ungapped mode CarpeDeam uses"},
+    {"--wrapped-scoring", 'V', "0", "not implemented"}, {"--filter-hits", 'V', "0", "not implemented"}, {"-a", 'V', "0", "no backtrace in mode 3"},
+    {"--sort-results", 'V', "0", "not implemented"}, {"--sub-mat", 'V', "*nucleotide.out*", "only the nucleotide matrix"}, {"--compressed", 'V', "0", "compressed DBs are not implemented"}, {0, 0, 0, 0}};
+const FlagSpec ANCIENT_FLAGS[] = {
+    {"--min-seq-id", 'U', 0, 0}, {"--max-seq-len", 'U', 0, 0}, {"--ext-random-align", 'U', 0, 0}, {"--excess-penalty", 'U', 0, 0}, {"--min-ryseq-id-corr-reads", 'U', 0, 0},
+    {"--likelihood-ratio-threshold", 'U', 0, 0}, {"--ancient-damage", 'U', 0, 0}, {"--unsafe", 'U', 0, 0}, {"--min-cov-safe", 'U', 0, 0},
+    {"--keep-target", 'N', 0, "not read by these modules"}, {"--min-seqid-corr-reads", 'N', 0, "not read by these modules"}, {"--min-merge-seq-id", 'N', 0, "contig merging only"},
+    {"--min-seqid-corr-contigs", 'N', 0, "contig correction only"}, {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0},
+    {"--rescore-mode", 'V', "3", "re-alignment of parked candidates is end-to-end ungapped (ancientReadsResults.cpp:502)"}, {0, 0, 0, 0}};
+void checkFlags(const char *module, const Args &a, const FlagSpec *spec, const char *const *extra = NULL) {
+    for (const auto &kv : a.flag) {
+        const FlagSpec *f = spec;
+        while (f->name && kv.first != f->name) f++;
+        bool known = f->name != NULL;
+        for (const char *const *e = extra; !known && e && *e; e++) known = kv.first == *e;
+        if (!known) die("Unrecognized parameter \"" + kv.first + "\"");
+        if (f->name && f->kind == 'V') {
+            const std::string al = f->allowed;
+            const bool ok = (al.size() >= 2 && al[0] == '*') ? kv.second.find(al.substr(1, al.size() - 2)) != std::string::npos : kv.second == al;
+            if (!ok) die(std::string(module) + ": " + kv.first + " " + kv.second + " is not supported by the MI355X path (" + f->why + "; accepted: " + (al.empty() ? "\"\"" : al) + ")");
+        }
+    }
+}
 float fflag(Args &a, const char *n, float d) { return a.flag.count(n) ? strtof(a.flag[n].c_str(), NULL) : d; }
 long iflag(Args &a, const char *n, long d) { return a.flag.count(n) ? strtol(a.flag[n].c_str(), NULL, 10) : d; }
 
@@ -113,6 +154,7 @@ cdm_ancient_params ancientParams(Args &a) {
 
 int kmermatcher(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam kmermatcher <i:sequenceDB> <o:prefilterDB>");
+    checkFlags("kmermatcher", a, KMERMATCHER_FLAGS);
     MmDb seq; std::string err; if (!seq.load(a.pos[0], &err)) die(err);
     cdm_ctx *ctx = openCtx();
     cdm_seqdb *db = uploadSeqDb(ctx, seq);
@@ -142,8 +184,9 @@ int kmermatcher(Args &a) {
 
 int rescorediagonal(Args &a) {
     if (a.pos.size() < 4) die("Usage: carpedeam rescorediagonal <i:queryDB> <i:targetDB> <i:prefilterDB> <o:resultDB>");
+    checkFlags("rescorediagonal", a, RESCORE_FLAGS);
     if (a.pos[0] != a.pos[1]) die("rescorediagonal: query and target DB must be the same on the MI355X path");
-    if (iflag(a, "--rescore-mode", 3) != 3) die("rescorediagonal: only --rescore-mode 3 is implemented on the MI355X path");
+    if (!a.flag.count("--rescore-mode")) die("rescorediagonal: --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
     MmDb seq, pref; std::string err; if (!seq.load(a.pos[1], &err) || !pref.load(a.pos[2], &err)) die(err);
     cdm_ctx *ctx = openCtx();
     cdm_seqdb *db = uploadSeqDb(ctx, seq);
@@ -200,6 +243,8 @@ int rescorediagonal(Args &a) {
 
 int ancientModule(Args &a, bool assemble) {
     if (a.pos.size() < 3) die(std::string("Usage: carpedeam ") + (assemble ? "ancient_read_assemble" : "ancient_correction") + " <i:sequenceDB> <i:alnResult> <o:reprSeqDB>");
+    checkFlags(assemble ? "ancient_read_assemble" : "ancient_correction", a, ANCIENT_FLAGS);
+    if (assemble && !a.flag.count("--rescore-mode")) die("ancient_read_assemble: --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
     MmDb seq, aln; std::string err; if (!seq.load(a.pos[0], &err) || !aln.load(a.pos[1], &err)) die(err);
     cdm_ctx *ctx = openCtx();
     check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");
@@ -221,6 +266,11 @@ int ancientModule(Args &a, bool assemble) {
 // Not a module of the reference; the per-stage modules above remain the drop-in surface.
 int readsLoop(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam ancient_reads_loop <i:sequenceDB> <o:sequenceDB> --ancient-damage <prefix> [--num-iter-reads-only N]");
+    {   // the workflow's own flags for the reads loop (src/commons/LocalParameters.h:283-318) on top of the stage lists
+        static const char *const LOOP_FLAGS[] = {"--k-ancient-reads", "--kmer-per-seq-ancient", "--kmer-per-seq-scale-ancient", "--hash-shift", "--include-only-extendable-ancient-reads",
+                                                 "-e", "--num-iter-reads-only", NULL};
+        checkFlags("ancient_reads_loop", a, ANCIENT_FLAGS, LOOP_FLAGS);
+    }
     MmDb seq; std::string err; if (!seq.load(a.pos[0], &err)) die(err);
     cdm_ctx *ctx = openCtx();
     check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");

@@ -78,3 +78,33 @@ def test_host_binary_fails_loudly_without_gpu(libpath, tmp_path):
     mmdb.write_seqdb(str(tmp_path / "s"), ["ACGT" * 10, "ACGTT" * 8])
     r = subprocess.run([exe, "kmermatcher", str(tmp_path / "s"), str(tmp_path / "p"), "-k", "20"], capture_output=True, text=True)
     assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_host_binary_flag_lists(libpath, tmp_path):
+    """Flags are checked against the reference's per-module lists before anything else happens (no GPU needed): an unknown flag
+    is "Unrecognized parameter" (Parameters.cpp:1703), a known flag with a value the MI355X path would compute differently is
+    refused with a message, a flag the path really has no use for is accepted."""
+    import subprocess
+    from carpedeam_amd import mmdb
+    exe = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
+    mmdb.write_seqdb(str(tmp_path / "s"), ["ACGT" * 10, "ACGTT" * 8])
+    s, p = str(tmp_path / "s"), str(tmp_path / "p")
+
+    def run(*a):
+        r = subprocess.run([exe] + list(a), capture_output=True, text=True)
+        return r.returncode, r.stderr
+
+    for mod, args, bad in (("kmermatcher", [s, p], ["--frobnicate", "1"]), ("kmermatcher", [s, p], ["--min-aln-len", "3"]),       # rescorediagonal's flag
+                           ("rescorediagonal", [s, s, p, p + "2"], ["--kmer-per-seq", "20"]), ("ancient_correction", [s, p, p + "3"], ["-k", "20"]),
+                           ("ancient_read_assemble", [s, p, p + "3"], ["--sort-results", "0"])):
+        rc, err = run(mod, *args, *bad)
+        assert rc != 0 and 'Unrecognized parameter "%s"' % bad[0] in err, (mod, bad, err)
+    for mod, args, bad in (("kmermatcher", [s, p], ["--mask", "1"]), ("kmermatcher", [s, p], ["--spaced-kmer-mode", "1"]), ("kmermatcher", [s, p], ["--adjust-kmer-len", "1"]),
+                           ("kmermatcher", [s, p], ["--sub-mat", "blosum62.out"]), ("rescorediagonal", [s, s, p, p + "2"], ["--rescore-mode", "2"]),
+                           ("rescorediagonal", [s, s, p, p + "2"], ["--rescore-mode", "3", "--sort-results", "1"]), ("rescorediagonal", [s, s, p, p + "2"], ["--rescore-mode", "3", "-a", "1"]),
+                           ("rescorediagonal", [s, s, p, p + "2"], ["--rescore-mode", "3", "--filter-hits", "1"]), ("ancient_read_assemble", [s, p, p + "3"], ["--rescore-mode", "0"])):
+        rc, err = run(mod, *args, *bad)
+        assert rc != 0 and "is not supported by the MI355X path" in err, (mod, bad, err)
+    # accepted flags get as far as the device (or, with a GPU, through): the error, if any, is not about flags
+    rc, err = run("kmermatcher", s, p, "-k", "20", "--mask", "0", "--alph-size", "21", "--threads", "3", "--sub-mat", "nucl:nucleotide.out,aa:blosum62.out", "--split-memory-limit", "1G")
+    assert "Unrecognized" not in err and "not supported" not in err

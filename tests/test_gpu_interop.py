@@ -1,0 +1,73 @@
+"""Interop in the other direction: DB files WRITTEN by the MI355X modules are read by the reference's own object code
+(oracle/_ref/carpedeam_ref, skipped when that build is absent), and the reference module's result on them equals the MI355X
+module's result on the same files.  Plus the dispatcher of INTEGRATION.md (scripts/carpedeam-gpu) over one iteration of the
+reads loop of data/nuclassemble.sh:100-146."""
+import os
+import subprocess
+
+import pytest
+
+from carpedeam_amd import mmdb
+from gpuutil import diff_keys, gold, stage_input
+from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
+from test_oracle_golden import pref_sign_ties
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GPU = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
+REF = os.path.join(ROOT, "oracle", "_ref", "carpedeam_ref")
+WRAP = os.path.join(ROOT, "scripts", "carpedeam-gpu")
+
+
+def run(exe, *args, env=None):
+    r = subprocess.run([exe] + list(args), capture_output=True, text=True, env=env)
+    assert r.returncode == 0, (exe, args[0], r.stderr[-1500:])
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref (the reference's object code) is not built here")
+@pytest.mark.parametrize("name,it", [("synth2k", 0), ("mixed3k", 2), ("example", 0)])
+def test_reference_modules_read_gpu_written_dbs(tmp_path, dhigh_prefix, name, it):
+    from carpedeam_amd import build
+    build.build()
+    t = lambda s: str(tmp_path / s)
+    dmg = ["--ancient-damage", dhigh_prefix, "--threads", "4"]
+    mmdb.write_from_keyed(t("in"), stage_input(name, it), mmdb.DBTYPE_NUCLEOTIDES)
+    # prefilter DB written by the MI355X kmermatcher -> the reference's rescorediagonal
+    run(GPU, "kmermatcher", t("in"), t("pref_g"), *K_FLAGS, "--threads", "4")
+    run(REF, "rescorediagonal", t("in"), t("in"), t("pref_g"), t("aln_r"), *R_FLAGS, "--threads", "4")
+    run(GPU, "rescorediagonal", t("in"), t("in"), t("pref_g"), t("aln_g"), *R_FLAGS, "--threads", "4")
+    assert not diff_keys(mmdb.read_db(t("aln_r")), mmdb.read_db(t("aln_g")))
+    # alignment DB written by the MI355X rescorediagonal -> the reference's ancient_correction
+    run(REF, "ancient_correction", t("in"), t("aln_g"), t("corr_r"), *A_FLAGS, *dmg)
+    run(GPU, "ancient_correction", t("in"), t("aln_g"), t("corr_g"), *A_FLAGS, *dmg)
+    assert not diff_keys(mmdb.read_db(t("corr_r")), mmdb.read_db(t("corr_g")))
+    # sequence DB written by the MI355X ancient_correction (+ that alignment DB) -> the reference's ancient_read_assemble
+    run(REF, "ancient_read_assemble", t("corr_g"), t("aln_g"), t("asm_r"), *A_FLAGS, *dmg)
+    run(GPU, "ancient_read_assemble", t("corr_g"), t("aln_g"), t("asm_g"), *A_FLAGS, *dmg)
+    assert not diff_keys(mmdb.read_db(t("asm_r")), mmdb.read_db(t("asm_g")))
+    # the extended sequence DB (wasExtended flags in the index) written by the MI355X module -> the reference's kmermatcher
+    run(REF, "kmermatcher", t("asm_g"), t("pref2_r"), *K_FLAGS, "--threads", "4")
+    run(GPU, "kmermatcher", t("asm_g"), t("pref2_g"), *K_FLAGS, "--threads", "4")
+    ties, bad = pref_sign_ties(mmdb.canon(mmdb.read_db(t("pref2_g"))), mmdb.canon(mmdb.read_db(t("pref2_r"))))
+    assert not bad and sum(n for _, n in ties) <= 1          # (the reference's own run-dependent strand tie)
+
+
+def test_dispatcher_script_runs_one_reads_loop_iteration(tmp_path, dhigh_prefix):
+    """$MMSEQS = scripts/carpedeam-gpu: the loop body of data/nuclassemble.sh:100-146, module by module on DB files."""
+    from carpedeam_amd import build
+    build.build()
+    t = lambda s: str(tmp_path / s)
+    env = dict(os.environ, CARPEDEAM_GPU_BIN=GPU, CARPEDEAM_REF_BIN=REF if os.path.exists(REF) else "/bin/false")
+    dmg = ["--ancient-damage", dhigh_prefix, "--threads", "4"]
+    mmdb.write_from_keyed(t("in"), gold("synth2k", "reads"), mmdb.DBTYPE_NUCLEOTIDES)
+    run(WRAP, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4", env=env)
+    run(WRAP, "rescorediagonal", t("in"), t("in"), t("pref"), t("aln"), *R_FLAGS, "--threads", "4", env=env)
+    run(WRAP, "ancient_correction", t("in"), t("aln"), t("corr"), *A_FLAGS, *dmg, env=env)
+    run(WRAP, "ancient_read_assemble", t("corr"), t("aln"), t("asm"), *A_FLAGS, *dmg, env=env)
+    ties, bad = pref_sign_ties(mmdb.canon(mmdb.read_db(t("pref"))), mmdb.canon(gold("synth2k", "pref", 0)))
+    assert not bad and sum(n for _, n in ties) <= 1
+    if not ties:
+        assert not diff_keys(mmdb.read_db(t("asm")), gold("synth2k", "asm", 0))
+    # a module that is not one of the four goes to the reference binary
+    r = subprocess.run([WRAP, "not_a_hot_path_module"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0
