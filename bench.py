@@ -107,9 +107,9 @@ def profile_ratio():
             if "rocprim" not in n or not re.search(r">, 9u, \(rocprim", n):
                 continue
             if "onesweep_iteration" in n:
-                it = float(r["AverageNs"])
-            elif "onesweep_global_offsets" in n:
-                hist = float(r["AverageNs"])
+                it = max(it or 0.0, float(r["AverageNs"]))
+            elif "onesweep_global_offsets" in n:          # (the same template also runs a microsecond-sized scan of the histograms)
+                hist = max(hist or 0.0, float(r["AverageNs"]))
         if it and hist:
             best = (hist / it, os.path.basename(f))
     return best or (1.31, "default")

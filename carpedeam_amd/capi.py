@@ -50,6 +50,8 @@ EXPORTS = [
     "cdm_seqdb_download", "cdm_seqdb_free", "cdm_seqdb_select_ext", "cdm_seqdb_words", "cdm_seqdb_copy_packed", "cdm_seqdb_from_packed", "cdm_damage_load", "cdm_damage_get", "cdm_kmermatch", "cdm_hits_upload", "cdm_hits_count",
     "cdm_hits_download", "cdm_hits_free", "cdm_rescore", "cdm_alns_upload", "cdm_alns_count", "cdm_alns_download", "cdm_alns_free",
     "cdm_evalue", "cdm_bit_score", "cdm_correct", "cdm_extend",
+    "cdm_kmermatch_part", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_finish", "cdm_kpart_free", "cdm_dev_copy",
+    "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext",
 ]
 
 
@@ -107,6 +109,16 @@ def lib():
         l.cdm_bit_score.argtypes = [C.c_double]
         l.cdm_correct.argtypes = [vp, vp, vp, C.POINTER(AncientParams), C.POINTER(vp)]
         l.cdm_extend.argtypes = [vp, vp, vp, C.POINTER(AncientParams), C.POINTER(vp), vp]
+        l.cdm_kmermatch_part.argtypes = [vp, vp, C.POINTER(KmerParams), C.c_int, C.c_int, C.POINTER(vp)]
+        l.cdm_kpart_info.argtypes = [vp, vp]
+        l.cdm_kpart_stale.argtypes = [vp, vp, C.c_uint64, vp]
+        l.cdm_kpart_gather.argtypes = [vp, vp, C.c_int, vp, C.POINTER(vp)]
+        l.cdm_kpart_finish.argtypes = [vp, vp, vp, C.c_uint64, vp, C.POINTER(vp)]
+        l.cdm_kpart_free.argtypes = [vp]
+        l.cdm_kpart_free.restype = None
+        l.cdm_dev_copy.argtypes = [vp, vp, vp, C.c_uint64]
+        l.cdm_seqdb_from_packed_ext.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+        l.cdm_seqdb_copy_ext.argtypes = [vp, vp, vp]
         _lib = l
     return _lib
 
@@ -146,6 +158,9 @@ class SeqDb:
         h = C.c_void_p()
         _check(lib().cdm_seqdb_select_ext(self.ctx.h, self.h, C.byref(h)))
         return SeqDb(self.ctx, h)
+
+    def copy_ext(self, ext_ptr):
+        _check(lib().cdm_seqdb_copy_ext(self.ctx.h, self.h, ext_ptr))
 
     def copy_packed(self, codes_ptr, nmask_ptr, len_ptr, key_ptr):
         """copy the packed form into DEVICE buffers (raw pointers, e.g. torch tensor .data_ptr())"""
@@ -203,6 +218,41 @@ class Alns(_Csr):
     free, count_fn, download_fn, dtype = "cdm_alns_free", "cdm_alns_count", "cdm_alns_download", ALN_DTYPE
 
 
+class KPart:
+    """One k-mer range of a split kmermatcher run (cdm_kpart)."""
+
+    def __init__(self, ctx, handle, db):
+        self.ctx, self.h, self.db = ctx, handle, db
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().cdm_kpart_free(self.h)
+            self.h = None
+
+    def info(self):
+        a = np.zeros(4, np.uint64)
+        _check(lib().cdm_kpart_info(self.h, _ptr(a)))
+        return {"real": int(a[0]), "kept": int(a[1]), "any_below": bool(a[2]), "n": int(a[3])}
+
+    def stale(self, j):
+        a = np.zeros(67, np.uint32)
+        _check(lib().cdm_kpart_stale(self.ctx.h, self.h, int(j), _ptr(a)))
+        return a
+
+    def gather(self, nranks):
+        """-> (offsets[nranks + 1], device pointer of the group keys grouped by representative)"""
+        off = np.zeros(nranks + 1, np.uint64)
+        p = C.c_void_p()
+        _check(lib().cdm_kpart_gather(self.ctx.h, self.h, nranks, _ptr(off), C.byref(p)))
+        return off, p.value or 0
+
+    def finish(self, keys_ptr, n_keys, stale):
+        st = np.ascontiguousarray(stale[:65], np.uint32)
+        h = C.c_void_p()
+        _check(lib().cdm_kpart_finish(self.ctx.h, self.h, keys_ptr, int(n_keys), _ptr(st), C.byref(h)))
+        return Hits(self.ctx, h, self.db.n)
+
+
 class Ctx:
     def __init__(self, device=0):
         h = C.c_void_p()
@@ -257,6 +307,21 @@ class Ctx:
         h = C.c_void_p()
         _check(lib().cdm_seqdb_from_packed(self.h, codes_ptr, nmask_ptr, len_ptr, key_ptr, n, words, ext_value, C.byref(h)))
         return SeqDb(self, h)
+
+    def from_packed_ext(self, codes_ptr, nmask_ptr, len_ptr, key_ptr, ext_ptr, n, words):
+        h = C.c_void_p()
+        _check(lib().cdm_seqdb_from_packed_ext(self.h, codes_ptr, nmask_ptr, len_ptr, key_ptr, ext_ptr, n, words, C.byref(h)))
+        return SeqDb(self, h)
+
+    def dev_copy(self, dst_ptr, src_ptr, nbytes):
+        _check(lib().cdm_dev_copy(self.h, dst_ptr, src_ptr, nbytes))
+
+    def kmermatch_part(self, db, part, nparts, par=None):
+        """phase A of kmermatcher on k-mer range part/nparts (multi-GPU runs, carpedeam_amd/shard.py)"""
+        par = par or KmerParams.reads_default()
+        h = C.c_void_p()
+        _check(lib().cdm_kmermatch_part(self.h, db.h, C.byref(par), part, nparts, C.byref(h)))
+        return KPart(self, h, db)
 
     # ---- containers
     def upload_hits(self, db, off, rec):

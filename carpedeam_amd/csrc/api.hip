@@ -449,6 +449,26 @@ extern "C" int cdm_seqdb_from_packed(cdm_ctx *ctx, const void *codes, const void
     return CDM_OK;
 }
 
+extern "C" int cdm_seqdb_copy_ext(cdm_ctx *ctx, const cdm_seqdb *db, void *devExt) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    if (db->n) CDM_HIP(hipMemcpyAsync(devExt, db->ext, db->n, hipMemcpyDeviceToDevice, ctx->stream));
+    CDM_HIP(hipStreamSynchronize(ctx->stream));
+    return CDM_OK;
+}
+extern "C" int cdm_seqdb_from_packed_ext(cdm_ctx *ctx, const void *codes, const void *nmask16, const void *lengths, const void *keys, const void *devExt, uint64_t n,
+                                         uint64_t words, cdm_seqdb **out) {
+    cdm_seqdb *o = nullptr;
+    int rc = cdm_seqdb_from_packed(ctx, codes, nmask16, lengths, keys, n, words, 0, &o);
+    if (rc != CDM_OK) return rc;
+    if (devExt && n) {
+        if (hipMemcpyAsync(o->ext, devExt, n, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_from_packed_ext: copying the wasExtended flags failed"); return CDM_ERR_HIP;
+        }
+    }
+    *out = o;
+    return CDM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ hits / alignments
 template <typename H, typename R>
 static int csr_upload(cdm_ctx *ctx, uint64_t n, const uint64_t *offsets, const R *recs, H **out) {

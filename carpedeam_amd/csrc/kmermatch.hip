@@ -122,14 +122,29 @@ template <typename LY> struct ExtractArgs {
     // than every key of region 2, so the concatenation is the array the reference sorts on the full key.
     uint64_t hashBase; const uint32_t *rankOf;
     TupleGeom geom;
+    // Multi-GPU runs split the k-mer space into ranges (the reference's MPI split, kmermatcher.cpp:634-663, by value instead of
+    // by hash so that the ranges are in k-mer order): only tuples with kLo <= key < kHi are stored, the others leave their slot
+    // empty; the whole-sequence hash tuples of region 2 belong to the last range.  belowFlag is set when a real tuple lies
+    // below the range (the array's very first run is then not in it).  Single-GPU: kLo = 0, kHi = ~0, lastPart = 1.
+    uint64_t kLo, kHi; int lastPart; unsigned int *belowFlag;
 };
+template <typename LY> __device__ __forceinline__ bool inRange(const ExtractArgs<LY> &a, uint64_t km) { return km >= a.kLo && km < a.kHi; }
+template <typename LY> __device__ __forceinline__ void noteBelow(const ExtractArgs<LY> &a, bool below) {       // whole wave
+    if (__ballot(below) != 0ull && (threadIdx.x & 63) == 0 && a.belowFlag[0] == 0u) a.belowFlag[0] = 1u;
+}
 template <typename LY>
 __device__ __forceinline__ void putSeqHashTuple(const ExtractArgs<LY> &a, uint32_t seq, uint32_t L, uint64_t base, uint64_t h) {
     const uint64_t key = xxh64_u64(h, a.seed);
     const uint64_t hslot = a.hashBase + a.rankOf[seq];
     const bool small = (key & ~BIT63) < (1ull << (2 * a.k));
-    if (small) { LY::storeHash(a.keys, a.vals, base, key, seq, L, a.geom); LY::storeEmpty(a.keys, a.vals, hslot); }
-    else { LY::storeEmpty(a.keys, a.vals, base); LY::storeHash(a.keys, a.vals, hslot, key, seq, L, a.geom); }
+    if (small) {
+        if (inRange(a, key & ~BIT63)) LY::storeHash(a.keys, a.vals, base, key, seq, L, a.geom); else LY::storeEmpty(a.keys, a.vals, base);
+        if ((key & ~BIT63) < a.kLo && a.belowFlag[0] == 0u) a.belowFlag[0] = 1u;
+        LY::storeEmpty(a.keys, a.vals, hslot);
+    } else {
+        LY::storeEmpty(a.keys, a.vals, base);
+        if (a.lastPart) LY::storeHash(a.keys, a.vals, hslot, key, seq, L, a.geom); else LY::storeEmpty(a.keys, a.vals, hslot);
+    }
 }
 
 // 2k-bit window of the sequence starting at base pos, MMseqs2 coding (A,C,T,G), first base in the LOW bits
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
         for (uint32_t i = lane; i < tsize; i += 64) table[i] = ~0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
         const uint32_t lastWord = (L + 15) / 16 - 1;
-        bool dup = false;
+        bool dup = false, below = false;
         const uint64_t kmask = (1ull << (2 * k)) - 1ull;
         // canonical k-mer of the window w (idx = the same k-mer in Indexer order) at position pos: insert, store
         auto emit = [&](uint64_t w, uint64_t idx, uint32_t pos, bool x) {
@@ -225,7 +240,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
                         h = (h + 1) & tmask;
                     }
                 }
-                LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom);
+                below |= km < a.kLo;
+                if (inRange(a, km)) LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom); else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
             } else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
         };
         if (hasN) {
@@ -249,6 +265,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
             }
         }
         if (__ballot(dup) != 0ull && lane == 0) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;   // rewritten by k_extract
+        noteBelow(a, below);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_pair(ExtractArgs<LY
         if (have && !elig && hl == 0) a.single[atomicAdd(&a.slowCnt[2], 1u)] = seq;
         for (int i = hl; i < PAIR_TABLE; i += 32) table[i] = ~0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
-        bool dup = false;
+        bool dup = false, below = false;
         auto emit = [&](uint64_t w, uint64_t idx, uint32_t pos) {
             const uint64_t rc = (w ^ 0xAAAAAAAAAAAAAAAAull) & kmask;     // Util::revComplement(idx): window order, complemented
             if (rc != idx) {
@@ -294,7 +311,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_pair(ExtractArgs<LY
                         h = (h + 1) & (PAIR_TABLE - 1);
                     }
                 }
-                LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom);
+                below |= km < a.kLo;
+                if (inRange(a, km)) LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom); else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
             } else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
         };
         const uint32_t pos = 3u * (uint32_t) hl;
@@ -310,6 +328,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_pair(ExtractArgs<LY
         }
         const unsigned long long dm = __ballot(dup);
         if ((half ? (dm >> 32) : (dm & 0xFFFFFFFFull)) != 0ull && hl == 0) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;   // rewritten by k_extract
+        noteBelow(a, below);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -544,9 +563,12 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
             // selected tuples first (their order within the sequence does not matter: a global sort follows), then sentinels
             for (uint32_t i = tid; i < n; i += NT) {
                 if (!sel[i]) continue;
-                const uint32_t o = atomicAdd(&sCursor, 1u);
                 const SeqPos e = sp[i];
-                LY::store(a.keys, a.vals, base + 1 + o, spKmer63(e), (e.b & 1ull) != 0, seq, L, spPos(e), a.geom);
+                const uint64_t km = spKmer63(e);
+                if (km < a.kLo && a.belowFlag[0] == 0u) a.belowFlag[0] = 1u;
+                if (!inRange(a, km)) continue;              // another rank's k-mer range
+                const uint32_t o = atomicAdd(&sCursor, 1u);
+                LY::store(a.keys, a.vals, base + 1 + o, km, (e.b & 1ull) != 0, seq, L, spPos(e), a.geom);
             }
             __syncthreads();
             for (uint32_t i = sCursor + tid; i < nPos; i += NT) LY::storeEmpty(a.keys, a.vals, base + 1 + i);
@@ -936,6 +958,12 @@ __global__ void k_live_count(const uint64_t *__restrict__ keys, uint64_t n, int 
     while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((keys[mid] >> kbits) & 1ull) hi = mid; else lo = mid + 1; }
     *out = lo;
 }
+// number of real tuples in region 2 (sorted on the low 63 bits; the empty slots, key ~0, are last)
+__global__ void k_count_hash_tuples(const uint64_t *__restrict__ keys, uint64_t n, unsigned long long *__restrict__ out) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (keys[mid] == ~0ull) hi = mid; else lo = mid + 1; }
+    *out = lo;
+}
 // The tuples the reference's last per-target scan runs into (see VoteArgs): k-mer-ordered real tuples from index J = nGroup on
 // while their sequence id is `target`.  Region 1 is only sorted on its high bits in memory (unless `sorted`): the bucket that
 // holds index J is ranked here (all pairs, one block); buckets larger than STALE_BUCKET were finished through the big-bucket
@@ -1007,25 +1035,53 @@ __global__ void k_first_diff(const uint64_t *__restrict__ a, const uint64_t *__r
 }
 inline uint32_t bitsFor(uint64_t v) { uint32_t b = 1; while ((1ull << b) < v) b++; return b; }
 
+// One kmermatcher run, in phases so that a multi-GPU run can exchange between them (shard.py / cdm_kmermatch_part):
+//   phaseA     extraction (of this rank's k-mer range), sort 1, grouping -> group keys in k-mer order (startIo), live, nKept
+//   staleTail  the left-over tuples behind global k-mer-order index J (the reference's run-past-the-end scan)
+//   phaseB     sort 2 + vote -> prefilter hits
+struct KmerJobBase {
+    virtual ~KmerJobBase() {}
+    virtual int phaseA() = 0;
+    virtual int staleTail(unsigned long long J, bool fromStart) = 0;
+    virtual int phaseB(cdm_hits **out) = 0;
+    virtual int gatherByRep() = 0;
+    virtual int phaseBFrom(const uint64_t *devKeys, uint64_t nKeys, const uint32_t *staleHost, cdm_hits **out) = 0;
+    cdm_ctx *ctx = nullptr; const cdm_seqdb *db = nullptr; cdm_kmer_params parCopy; const cdm_kmer_params *par = nullptr;
+    int part = 0, nparts = 1;           // this rank's k-mer range (nparts == 1: everything)
+    unsigned long long live = 0, nKept = 0, regionTwo = 0;      // real tuples of region 1 in this range; kept group tuples; real tuples of region 2
+    bool anyBelow = false;              // a real tuple with a k-mer below this range exists (then the array's very first run is not here)
+    uint64_t *gathered = nullptr;       // gatherByRep: the kept group keys grouped by representative, k-mer order inside (device)
+    uint32_t staleHost[64 + 3] = {0};   // staleTail's result: [0] count, [1] sequence id, [2..] positions, [66] = 1 if the scan reached the end of this range's tuples
+};
 template <typename LY>
-int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+struct KmerJob : KmerJobBase {
     typedef typename LY::V V;
-    hipStream_t s = ctx->stream;
-    const uint32_t n = (uint32_t) db->n;
-    const int k = par->kmer_size;
-    if (k < 4 || k > 31) { cdm_set_error("cdm_kmermatch: k must be in 4..31 (got %d)", k); return CDM_ERR_INVALID; }
-    if (db->maxLen + 2 >= 32767u) { cdm_set_error("cdm_kmermatch: sequences of 32765 letters or more (the reference's `int` position path) are not implemented on the device yet"); return CDM_ERR_UNSUPPORTED; }
-    constexpr uint32_t SHORT_CAP = 256, LONG_CAP = 4096;
-    const uint32_t idBits = bitsFor(n), diagBits = bitsFor(2ull * db->maxLen + 2);
-    if (2 * idBits + diagBits + 1 > 63) { cdm_set_error("cdm_kmermatch: %u sequences x max length %u do not fit the 64-bit (rep,id,diagonal) sort key", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
-    const int diagBias = (int) db->maxLen + 1;
-    const char *sortEnv = getenv("CDM_KMER_SORT");
-    const bool lsdOnly = sortEnv && !strcmp(sortEnv, "lsd");
-
+    hipStream_t s = nullptr; uint32_t n = 0; int k = 0;
+    uint32_t idBits = 0, diagBits = 0; int diagBias = 0; const char *sortEnv = nullptr; bool lsdOnly = false;
     DevBuf<unsigned long long> counters;      // scratch counters ([2] = number of kept group tuples)
     DevBuf<unsigned int> cls;                 // slow-path list sizes
     DevBuf<uint32_t> listShort, listLong, listSingle, listHuge;
     DevBuf<unsigned long long> slots; DevBuf<uint64_t> slotOff; DevBuf<uint32_t> rankOf;
+    uint64_t kmerSlots = 0; unsigned long long nTuples = 0;
+    rocprim::double_buffer<uint64_t> keys; rocprim::double_buffer<V> vals;
+    DevBuf<uint64_t> k0, k1; DevBuf<V> v0, v1;
+    TupleGeom geom; int lowBits = 0;
+    GroupArgs<LY> ga; DevBuf<unsigned long long> statStripes; unsigned long long *startIo = nullptr; DevBuf<uint32_t> staleBuf;
+    float msSort1 = 0;
+    KmerJob(cdm_ctx *c, const cdm_seqdb *d, const cdm_kmer_params *p) { ctx = c; db = d; parCopy = *p; par = &parCopy; }
+int phaseA() override {
+    s = ctx->stream;
+    n = (uint32_t) db->n;
+    k = par->kmer_size;
+    if (k < 4 || k > 31) { cdm_set_error("cdm_kmermatch: k must be in 4..31 (got %d)", k); return CDM_ERR_INVALID; }
+    if (db->maxLen + 2 >= 32767u) { cdm_set_error("cdm_kmermatch: sequences of 32765 letters or more (the reference's `int` position path) are not implemented on the device yet"); return CDM_ERR_UNSUPPORTED; }
+    constexpr uint32_t SHORT_CAP = 256, LONG_CAP = 4096;
+    idBits = bitsFor(n); diagBits = bitsFor(2ull * db->maxLen + 2);
+    if (2 * idBits + diagBits + 1 > 63) { cdm_set_error("cdm_kmermatch: %u sequences x max length %u do not fit the 64-bit (rep,id,diagonal) sort key", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
+    diagBias = (int) db->maxLen + 1;
+    sortEnv = getenv("CDM_KMER_SORT");
+    lsdOnly = sortEnv && !strcmp(sortEnv, "lsd");
+
     if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !listSingle.alloc(n) || !listHuge.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1) || !rankOf.alloc(n)) {
         cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP;
     }
@@ -1052,22 +1108,26 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
         hipMemcpyAsync(&capacity, ordOff.p + n, 8, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: slot layout failed"); return CDM_ERR_HIP; }
     }
-    const uint64_t kmerSlots = capacity;             // region 1: k-mer slots (+ slot 0 per sequence)
+    kmerSlots = capacity;                            // region 1: k-mer slots (+ slot 0 per sequence)
     capacity += n;                                   // region 2: whole-sequence hash tuples
-    const unsigned long long nTuples = capacity;
+    nTuples = capacity;
 
-    rocprim::double_buffer<uint64_t> keys; rocprim::double_buffer<V> vals;
-    DevBuf<uint64_t> k0, k1; DevBuf<V> v0, v1;
     if (!k0.alloc(capacity) || !k1.alloc(capacity) || !v0.alloc(capacity) || !v1.alloc(capacity)) {
         cdm_set_error("cdm_kmermatch: out of device memory for %llu k-mer tuples (%.1f GB)", (unsigned long long) capacity, capacity * (16.0 + 2 * sizeof(V)) / 1e9); return CDM_ERR_HIP;
     }
-    TupleGeom geom; geom.kbits = 2 * k; geom.lb = (int) bitsFor((uint64_t) db->maxLen + 1); geom.kmerSlots = kmerSlots; geom.lenArr = db->len;
+    geom.kbits = 2 * k; geom.lb = (int) bitsFor((uint64_t) db->maxLen + 1); geom.kmerSlots = kmerSlots; geom.lenArr = db->len;
     ExtractArgs<LY> ea; ea.geom = geom;
     ea.woff = db->woff; ea.len = db->len; ea.codes = db->codes; ea.nmask = db->nmask; ea.hasN = db->hasN;
     ea.k = k; ea.kmersPerSeq = par->kmers_per_seq; ea.scale = par->kmers_per_seq_scale; ea.seed = par->hash_shift; ea.ignoreMultiKmer = par->ignore_multi_kmer;
     ea.keys = k0.p; ea.vals = v0.p; ea.slotOff = slotOff.p; ea.slowShort = listShort.p; ea.slowLong = listLong.p; ea.slowHuge = listHuge.p; ea.slowCnt = cls.p; ea.n = n;
     ea.hugeSp = nullptr; ea.hugeSel = nullptr; ea.hugeCap = 0;
     ea.list = nullptr; ea.nList = 0; ea.hashBase = kmerSlots; ea.rankOf = rankOf.p;
+    {   // this rank's k-mer range: equal slices of the 2k-bit k-mer space, in k-mer order
+        const unsigned __int128 space = (unsigned __int128) 1 << (2 * k);
+        ea.kLo = (uint64_t) (space * (unsigned) part / (unsigned) nparts);
+        ea.kHi = (part == nparts - 1) ? ~0ull : (uint64_t) (space * (unsigned) (part + 1) / (unsigned) nparts);
+        ea.lastPart = (part == nparts - 1) ? 1 : 0; ea.belowFlag = cls.p + 5;
+    }
     hipEventRecord(ctx->ev0, s);
     hipLaunchKernelGGL(k_seq_hash<LY>, dim3((n + 255) / 256), dim3(256), 0, s, ea);
     ea.single = listSingle.p; ea.listCount = nullptr;
@@ -1098,7 +1158,10 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
         hipLaunchKernelGGL((k_extract<LY, 0, 256>), dim3(blocks), dim3(256), 0, s, ea);
     }
     hipEventRecord(ctx->ev1, s);
+    unsigned int belowHost = 0;
+    hipMemcpyAsync(&belowHost, cls.p + 5, 4, hipMemcpyDeviceToHost, s);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction (general path) failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    anyBelow = belowHost != 0;
     hipEventElapsedTime(&ctx->lastMs[3], ctx->ev0, ctx->ev1);
 
     // ---- sort 1: stable LSD radix sort by k-mer.  Region 1 (k-mer slots) on the 2k key bits, region 2 (whole-sequence hashes)
@@ -1112,7 +1175,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                        rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 16>, rocprim::kernel_config<512, 16>, 9, rocprim::block_radix_rank_algorithm::match>> Sort1Config;
     const bool fourPasses = sortEnv && !strcmp(sortEnv, "4x8");      // CDM_KMER_SORT=4x8: rocPRIM's default 8-bit passes over 32 bits (A/B)
-    const int lowBits = lsdOnly ? 0 : std::max(0, 2 * k + 1 - (fourPasses ? 32 : 27));
+    lowBits = lsdOnly ? 0 : std::max(0, 2 * k + 1 - (fourPasses ? 32 : 27));
     const int sortTop = lowBits ? 2 * k + 1 : 2 * k;
     size_t tmpBytes = 0, tmpBytesH = 0;
     if (lsdOnly || fourPasses) rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s);
@@ -1138,16 +1201,15 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     hipEventRecord(ctx->ev3, s);
     // ---- K3: group keys per slot (fused bucket kernel for region 1, run-start max-scan + k_groups elsewhere), then the
     // order-preserving compaction
-    GroupArgs<LY> ga; ga.geom = geom;
+    ga.geom = geom;
     ga.keys = keys.current(); ga.vals = vals.current(); ga.n = nTuples; ga.onlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode;
-    ga.covThr = par->cov_thr; ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias; ga.first = 0; ga.firstRunIdx = 0;
-    DevBuf<unsigned long long> statStripes;
+    ga.covThr = par->cov_thr; ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias; ga.first = 0;
+    ga.firstRunIdx = anyBelow ? ~0ull : 0ull;      // the very first run of the (global) array is in the lowest k-mer range that has tuples
     if (!statStripes.alloc(STAT_STRIPES)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipMemsetAsync(statStripes.p, 0, STAT_STRIPES * 8, s);
     ga.stat = statStripes.p;
-    unsigned long long *startIo = (unsigned long long *) keys.alternate();   // free after the sort
-    unsigned long long live = 0, nKept = 0;
-    DevBuf<uint32_t> staleBuf;
+    startIo = (unsigned long long *) keys.alternate();   // free after the sort
+    live = 0; nKept = 0;
     if (!staleBuf.alloc(STALE_MAX + 3)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipMemsetAsync(staleBuf.p, 0, (STALE_MAX + 3) * 4, s);
     {
@@ -1212,7 +1274,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
                         hipLaunchKernelGGL((bucket::k_big_copy<V, false>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<V *>(ga.vals), dv.current());
                         GroupArgs<LY> gd = ga; gd.keys = dk.current(); gd.vals = dv.current(); gd.n = total; gd.first = 0;
                         gd.geom.kmerSlots = ~0ull;                                   // every tuple of the dense view is a region-1 tuple
-                        gd.firstRunIdx = (firstStart == 0) ? 0ull : ~0ull;           // dense index 0 is the array's first tuple only then
+                        gd.firstRunIdx = (firstStart == 0 && !anyBelow) ? 0ull : ~0ull;           // dense index 0 is the array's first tuple only then
                         rc = scanGroups(gd, ds.p);
                     }
                     if (rc == CDM_OK) {
@@ -1226,22 +1288,44 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
         hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, s, (const unsigned long long *) statStripes.p, counters.p + 4);
         hipMemcpyAsync(&nKept, counters.p + 4, 8, hipMemcpyDeviceToHost, s);
         { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
-        if (nKept) {
-            // the tuples behind the kept ones that the reference's last per-target scan may run into (VoteArgs, k_stale_tail)
-            StaleArgs<LY> sa;
-            sa.keys = ga.keys; sa.vals = ga.vals; sa.geom = geom; sa.live = live; sa.kmerSlots = kmerSlots; sa.nTuples = nTuples; sa.J = nKept;
-            sa.lowBits = lowBits; sa.sorted = (lowBits == 0); sa.out = staleBuf.p;
-            hipLaunchKernelGGL(k_stale_tail<LY>, dim3(1), dim3(256), 0, s, sa);
-            uint32_t nStale = 0;
-            hipMemcpyAsync(&nStale, staleBuf.p, 4, hipMemcpyDeviceToHost, s);
-            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed"); return CDM_ERR_HIP; }
-            if (nStale >= (uint32_t) STALE_MAX) {
-                cdm_set_error("cdm_kmermatch: the reference's last per-target scan could run over %d or more left-over tuples of one sequence; not reproduced on the device", STALE_MAX);
-                return CDM_ERR_UNSUPPORTED;
-            }
-        }
     }
-    float msSort1 = 0; hipEventElapsedTime(&msSort1, ctx->ev0, ctx->ev1);
+    hipEventElapsedTime(&msSort1, ctx->ev0, ctx->ev1);
+    regionTwo = 0;
+    if (nparts > 1 && part == nparts - 1 && n) {        // real whole-sequence hash tuples (they sort in front of the empty slots of region 2)
+        hipLaunchKernelGGL(k_count_hash_tuples, dim3(1), dim3(1), 0, s, (const uint64_t *) ga.keys + kmerSlots, (uint64_t) n, counters.p + 6);
+        hipMemcpyAsync(&regionTwo, counters.p + 6, 8, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed"); return CDM_ERR_HIP; }
+    }
+    return CDM_OK;
+}
+// The tuples behind the kept ones that the reference's last per-target scan may run into (VoteArgs, k_stale_tail): the real
+// tuples of this range from k-mer-order index J on (fromStart: from the range's first tuple, for a scan that comes in from the
+// range in front), while they belong to one sequence.  Result in staleBuf (device) and staleHost.
+int staleTail(unsigned long long J, bool fromStart) override {
+    memset(staleHost, 0, sizeof(staleHost));
+    hipMemsetAsync(staleBuf.p, 0, (STALE_MAX + 3) * 4, s);
+    const unsigned long long realTuples = live + regionTwo;       // (regionTwo is only counted for multi-range runs)
+    if (nparts > 1 && J >= realTuples) { staleHost[STALE_MAX + 4] = 1; return hipStreamSynchronize(s) == hipSuccess ? CDM_OK : CDM_ERR_HIP; }
+    (void) fromStart;
+    StaleArgs<LY> sa;
+    sa.keys = ga.keys; sa.vals = ga.vals; sa.geom = geom; sa.live = live; sa.kmerSlots = kmerSlots; sa.nTuples = nTuples; sa.J = J;
+    sa.lowBits = lowBits; sa.sorted = (lowBits == 0); sa.out = staleBuf.p;
+    hipLaunchKernelGGL(k_stale_tail<LY>, dim3(1), dim3(256), 0, s, sa);
+    hipMemcpyAsync(staleHost, staleBuf.p, (STALE_MAX + 3) * 4, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed"); return CDM_ERR_HIP; }
+    if (staleHost[0] >= (uint32_t) STALE_MAX) {
+        cdm_set_error("cdm_kmermatch: the reference's last per-target scan could run over %d or more left-over tuples of one sequence; not reproduced on the device", STALE_MAX);
+        return CDM_ERR_UNSUPPORTED;
+    }
+    staleHost[STALE_MAX + 4] = (J + staleHost[0] >= realTuples) ? 1u : 0u;     // the scan consumed every tuple up to the end of this range
+    return CDM_OK;
+}
+int phaseB(cdm_hits **out) override {
+    return sort2Vote((const uint64_t *) startIo, nTuples, live, kmerSlots, keys.current(), (uint64_t *) startIo, true, out);
+}
+// kept group keys of [keysIn, keysIn + nIn) (~0 = dropped; [skipLo, skipHi) holds only ~0) -> sort 2 -> vote -> hits.
+// bufA / bufB: two buffers of nIn keys (bufB may be keysIn itself).
+int sort2Vote(const uint64_t *keysIn, unsigned long long nIn, unsigned long long skipLo, unsigned long long skipHi, uint64_t *bufA, uint64_t *bufB, bool ownBuffers, cdm_hits **out) {
 
     // ---- sort 2: by (rep, id, diagonal) = key bits 1.., stable; strand bit 0 rides along.
     // Default ("runs", runsort.h): the k-mer runs are sorted by representative, not the tuples - records of (rep, start, length),
@@ -1251,7 +1335,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     // (the first bit above the key fields) is set only there, so sorting on bits up to and including top2 moves them behind all
     // kept members; the top 32 of those bits go through global radix passes, the rest is finished bucket by bucket on chip
     // (bucket.h).  CDM_KMER_SORT2=check runs both and compares the two arrays on the device.
-    v0.free(); v1.free();                                                    // the tuple values are dead after k_groups
+    if (ownBuffers) { v0.free(); v1.free(); }                                // the tuple values are dead after k_groups
     const int top2 = (int) (2 * idBits + diagBits + 1);
     const char *sort2Env = getenv("CDM_KMER_SORT2");
     const bool sort2Check = sort2Env && !strcmp(sort2Env, "check");
@@ -1263,16 +1347,16 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     hipEventRecord(ctx->ev0, s);
     if (sort2Runs) {
         using namespace runsort;
-        const uint64_t *gk = (const uint64_t *) startIo;
-        uint64_t *gathered = keys.current(), *sortedOut = (uint64_t *) startIo;
+        const uint64_t *gk = keysIn;
+        uint64_t *gatheredBuf = bufA, *sortedOut = bufB;
         if (sort2Check) {
-            if (!runsOut.alloc(nTuples) || !runsTmp.alloc(nTuples)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2 check)"); return CDM_ERR_HIP; }
-            gathered = runsTmp.p; sortedOut = runsOut.p;
+            if (!runsOut.alloc(nIn) || !runsTmp.alloc(nIn)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2 check)"); return CDM_ERR_HIP; }
+            gatheredBuf = runsTmp.p; sortedOut = runsOut.p;
         }
-        const uint64_t tiles = (nTuples + RUN_TILE - 1) / RUN_TILE;
+        const uint64_t tiles = (nIn + RUN_TILE - 1) / RUN_TILE;
         DevBuf<unsigned long long> tileCnt, tileOff;
         if (!tileCnt.alloc(tiles + 1) || !tileOff.alloc(tiles + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2)"); return CDM_ERR_HIP; }
-        RunArgs ra; ra.keys = gk; ra.n = nTuples; ra.skipLo = live; ra.skipHi = kmerSlots; ra.repShift = (int) (idBits + diagBits + 1);
+        RunArgs ra; ra.keys = gk; ra.n = nIn; ra.skipLo = skipLo; ra.skipHi = skipHi; ra.repShift = (int) (idBits + diagBits + 1);
         hipMemsetAsync(tileCnt.p + tiles, 0, 8, s);
         if (tiles) hipLaunchKernelGGL(k_run_count, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, tileCnt.p);
         cdmscan::ScanTemp stA, stB;
@@ -1294,25 +1378,25 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
             hipMemsetAsync(rv.current() + nRec, 0, 8, s);
             if (int rc = cdmscan::exclusiveScanFn<unsigned long long, RunLen>(s, stB, RunLen{rv.current()}, dst.p, (size_t) nRec + 1)) return rc;
             hipMemcpyAsync(&nGroup, dst.p + nRec, 8, hipMemcpyDeviceToHost, s);
-            hipLaunchKernelGGL(k_run_gather, dim3((unsigned) ((nRec + 255) / 256)), dim3(256), 0, s, gk, (const uint64_t *) rv.current(), (const unsigned long long *) dst.p, (uint64_t) nRec, gathered);
+            hipLaunchKernelGGL(k_run_gather, dim3((unsigned) ((nRec + 255) / 256)), dim3(256), 0, s, gk, (const uint64_t *) rv.current(), (const unsigned long long *) dst.p, (uint64_t) nRec, gatheredBuf);
             if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: sort 2 (gather) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
-            if (segmentedSortKeys(s, ctx->cuCount, gathered, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, rk.current(), dst.p, nRec) != CDM_OK) {
+            if (segmentedSortKeys(s, ctx->cuCount, gatheredBuf, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, rk.current(), dst.p, nRec) != CDM_OK) {
                 cdm_set_error("cdm_kmermatch: segmented sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP;
             }
         }
         sorted2 = sortedOut;
     }
     if (!sort2Runs || sort2Check) {
-        rocprim::double_buffer<uint64_t> g((uint64_t *) startIo, keys.current());
+        rocprim::double_buffer<uint64_t> g(const_cast<uint64_t *>(keysIn), bufA);      // (radix variant: keysIn is sorted in place, bufB == keysIn)
         const int shiftHi2 = lsdOnly ? 1 : std::max(1, top2 + 1 - 32);
         size_t tmpBytes2 = 0;
-        rocprim::radix_sort_keys(nullptr, tmpBytes2, g, (size_t) nTuples, shiftHi2, top2 + 1, s);
+        rocprim::radix_sort_keys(nullptr, tmpBytes2, g, (size_t) nIn, shiftHi2, top2 + 1, s);
         DevBuf<char> tmp3;
         if (!tmp3.alloc(tmpBytes2 + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
-        if (rocprim::radix_sort_keys(tmp3.p, tmpBytes2, g, (size_t) nTuples, shiftHi2, top2 + 1, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+        if (rocprim::radix_sort_keys(tmp3.p, tmpBytes2, g, (size_t) nIn, shiftHi2, top2 + 1, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
         unsigned long long nGroupR = 0;
-        if (nTuples) {
-            hipLaunchKernelGGL(k_live_count, dim3(1), dim3(1), 0, s, (const uint64_t *) g.current(), (uint64_t) nTuples, top2, counters.p + 2);
+        if (nIn) {
+            hipLaunchKernelGGL(k_live_count, dim3(1), dim3(1), 0, s, (const uint64_t *) g.current(), (uint64_t) nIn, top2, counters.p + 2);
             hipMemcpyAsync(&nGroupR, counters.p + 2, 8, hipMemcpyDeviceToHost, s);
             if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
         }
@@ -1347,7 +1431,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     hipMemsetAsync(perRep.p, 0, ((size_t) n + 1) * 8, s);
     hipMemsetAsync(vTileCnt.p, 0, (vTiles + 1) * 8, s);
     VoteArgs va;
-    if (nGroup != nKept) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu sorted", nKept, nGroup); return CDM_ERR_HIP; }
+    if (ownBuffers && nGroup != nKept) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu sorted", nKept, nGroup); return CDM_ERR_HIP; }
     va.stale = staleBuf.p;
     va.keys = sorted2; va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.perRep = perRep.p;
     if (nGroup) hipLaunchKernelGGL(k_seg_count, dim3((unsigned) vTiles), dim3(256), 0, s, va, vTileCnt.p);
@@ -1369,12 +1453,134 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     ctx->lastMs[2] = msSort1 + msSort2;
     ctx->lastMs[5] = msSort1;   // sort 1 call alone (1 histogram + ceil(63/8) onesweep launches)
     ctx->lastMs[6] = msSort2;
-    hipEventElapsedTime(&ctx->lastMs[7], ctx->ev2, ctx->ev3);   // sort 1, region 2 (whole-sequence hash tuples)
+    if (ownBuffers) hipEventElapsedTime(&ctx->lastMs[7], ctx->ev2, ctx->ev3);   // sort 1, region 2 (whole-sequence hash tuples)
     *out = res;
     return CDM_OK;
 }
+// Multi-GPU hand-off: the kept group keys of this range grouped by representative (k-mer order inside a representative), in
+// `gathered` (the first nKept entries of the buffer the sorted tuple keys were in): run records, their stable sort by rep, the
+// expanding gather (runsort.h).  Slices of it by representative range are what the ranks exchange.
+int gatherByRep() override {
+    using namespace runsort;
+    v0.free(); v1.free();
+    const uint64_t tiles = (nTuples + RUN_TILE - 1) / RUN_TILE;
+    DevBuf<unsigned long long> tileCnt, tileOff; cdmscan::ScanTemp stA, stB;
+    if (!tileCnt.alloc(tiles + 1) || !tileOff.alloc(tiles + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2)"); return CDM_ERR_HIP; }
+    RunArgs ra; ra.keys = (const uint64_t *) startIo; ra.n = nTuples; ra.skipLo = live; ra.skipHi = kmerSlots; ra.repShift = (int) (idBits + diagBits + 1);
+    hipMemsetAsync(tileCnt.p + tiles, 0, 8, s);
+    if (tiles) hipLaunchKernelGGL(k_run_count, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, tileCnt.p);
+    if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, stA, tileCnt.p, tileOff.p, (size_t) tiles + 1)) return rc;
+    unsigned long long nRec = 0, nOut = 0;
+    hipMemcpyAsync(&nRec, tileOff.p + tiles, 8, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: gather by representative failed"); return CDM_ERR_HIP; }
+    gathered = keys.current();
+    if (nRec == 0) return CDM_OK;
+    DevBuf<uint32_t> rr0, rr1; DevBuf<uint64_t> rv0, rv1; DevBuf<unsigned long long> dst; DevBuf<char> t1; size_t tb = 0;
+    if (!rr0.alloc(nRec) || !rr1.alloc(nRec) || !rv0.alloc(nRec) || !rv1.alloc(nRec) || !dst.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
+    hipLaunchKernelGGL(k_run_write, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, (const unsigned long long *) tileOff.p, rr0.p, rv0.p);
+    rocprim::double_buffer<uint32_t> rk(rr0.p, rr1.p); rocprim::double_buffer<uint64_t> rv(rv0.p, rv1.p);
+    rocprim::radix_sort_pairs(nullptr, tb, rk, rv, (size_t) nRec, 0, idBits, s);
+    if (!t1.alloc(tb + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2)"); return CDM_ERR_HIP; }
+    if (rocprim::radix_sort_pairs(t1.p, tb, rk, rv, (size_t) nRec, 0, idBits, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: record sort failed"); return CDM_ERR_HIP; }
+    hipMemsetAsync(rv.current() + nRec, 0, 8, s);
+    if (int rc = cdmscan::exclusiveScanFn<unsigned long long, RunLen>(s, stB, RunLen{rv.current()}, dst.p, (size_t) nRec + 1)) return rc;
+    hipMemcpyAsync(&nOut, dst.p + nRec, 8, hipMemcpyDeviceToHost, s);
+    hipLaunchKernelGGL(k_run_gather, dim3((unsigned) ((nRec + 255) / 256)), dim3(256), 0, s, (const uint64_t *) startIo, (const uint64_t *) rv.current(), (const unsigned long long *) dst.p, (uint64_t) nRec, gathered);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: gather by representative failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    if (nOut != nKept) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu gathered", nKept, nOut); return CDM_ERR_HIP; }
+    return CDM_OK;
+}
+// sort 2 + vote on group keys received from all ranks (device buffer; concatenated in rank = k-mer order, so that the stable
+// sort by representative leaves every representative's tuples in global k-mer order); staleIn: the combined left-over list
+int phaseBFrom(const uint64_t *devKeys, uint64_t nKeys, const uint32_t *staleIn, cdm_hits **out) override {
+    k0.free(); k1.free(); v0.free(); v1.free();             // phase A's tuple buffers are not needed any more
+    if (hipMemcpyAsync(staleBuf.p, staleIn, (STALE_MAX + 3) * 4, hipMemcpyHostToDevice, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: stale list upload failed"); return CDM_ERR_HIP; }
+    DevBuf<uint64_t> a, b;
+    if (!a.alloc(nKeys) || !b.alloc(nKeys)) { cdm_set_error("cdm_kmermatch: out of device memory for %llu received group tuples", (unsigned long long) nKeys); return CDM_ERR_HIP; }
+    if (nKeys) hipMemcpyAsync(b.p, devKeys, nKeys * 8, hipMemcpyDeviceToDevice, s);
+    return sort2Vote(b.p, nKeys, 0, 0, a.p, b.p, false, out);
+}
+};
+
+template <typename LY>
+int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+    KmerJob<LY> job(ctx, db, par);
+    if (int rc = job.phaseA()) return rc;
+    if (job.nKept) if (int rc = job.staleTail(job.nKept, false)) return rc;
+    return job.phaseB(out);
+}
 
 }  // namespace
+
+static bool packedLayoutFits(const cdm_seqdb *db, int k) { return 2 * k + 1 + 2 * (int) bitsFor((uint64_t) db->maxLen + 1) <= 63; }
+
+// ---- multi-GPU: kmermatcher in two phases with an exchange in between (include/carpedeam_hip.h, carpedeam_amd/shard.py)
+struct cdm_kpart { KmerJobBase *job = nullptr; uint64_t nSeq = 0; uint32_t repShift = 0; };
+namespace {
+// first index of `keys` (sorted by representative) whose representative is >= bound[t]
+__global__ void k_rep_bounds(const uint64_t *__restrict__ keys, uint64_t n, int repShift, const uint64_t *__restrict__ bound, int nb, unsigned long long *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb) return;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((keys[mid] >> repShift) < bound[t]) lo = mid + 1; else hi = mid; }
+    out[t] = lo;
+}
+}  // namespace
+extern "C" int cdm_kmermatch_part(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int part, int nparts, cdm_kpart **out) {
+    if (!ctx || !db || !par || !out || nparts < 1 || part < 0 || part >= nparts) { cdm_set_error("cdm_kmermatch_part: invalid argument"); return CDM_ERR_INVALID; }
+    if (getenv("CDM_KMER_SORT") || getenv("CDM_KMER_SORT2")) { cdm_set_error("cdm_kmermatch_part: the A/B switches CDM_KMER_SORT / CDM_KMER_SORT2 apply to the single-device path only"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    cdm_kpart *h = new cdm_kpart();
+    if (packedLayoutFits(db, par->kmer_size)) h->job = new KmerJob<LayoutPacked>(ctx, db, par); else h->job = new KmerJob<LayoutWide>(ctx, db, par);
+    h->job->part = part; h->job->nparts = nparts; h->nSeq = db->n;
+    h->repShift = bitsFor(db->n) + bitsFor(2ull * db->maxLen + 2) + 1;
+    const int rc = h->job->phaseA();
+    if (rc != CDM_OK) { cdm_kpart_free(h); return rc; }
+    *out = h;
+    return CDM_OK;
+}
+extern "C" void cdm_kpart_free(cdm_kpart *h) { if (!h) return; delete h->job; delete h; }
+extern "C" int cdm_kpart_info(const cdm_kpart *h, uint64_t info[4]) {
+    info[0] = h->job->live + h->job->regionTwo; info[1] = h->job->nKept; info[2] = h->job->anyBelow ? 1 : 0; info[3] = h->nSeq;
+    return CDM_OK;
+}
+extern "C" int cdm_kpart_stale(cdm_ctx *ctx, cdm_kpart *h, uint64_t J, uint32_t out[67]) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    const int rc = h->job->staleTail(J, false);
+    if (rc != CDM_OK) return rc;
+    memcpy(out, h->job->staleHost, 67 * sizeof(uint32_t));
+    return CDM_OK;
+}
+extern "C" int cdm_kpart_gather(cdm_ctx *ctx, cdm_kpart *h, int nranks, uint64_t *offsets, const void **devKeys) {
+    if (nranks < 1 || !offsets || !devKeys) { cdm_set_error("cdm_kpart_gather: invalid argument"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    const int rc = h->job->gatherByRep();
+    if (rc != CDM_OK) return rc;
+    std::vector<uint64_t> bound(nranks + 1);
+    for (int r = 0; r <= nranks; r++) bound[r] = (uint64_t) ((unsigned __int128) h->nSeq * (unsigned) r / (unsigned) nranks);
+    DevBuf<uint64_t> dBound; DevBuf<unsigned long long> dOut;
+    if (!dBound.alloc(nranks + 1) || !dOut.alloc(nranks + 1)) { cdm_set_error("cdm_kpart_gather: out of device memory"); return CDM_ERR_HIP; }
+    CDM_HIP(hipMemcpyAsync(dBound.p, bound.data(), (nranks + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_rep_bounds, dim3((nranks + 64) / 64), dim3(64), 0, ctx->stream, (const uint64_t *) h->job->gathered, (uint64_t) h->job->nKept, (int) h->repShift, (const uint64_t *) dBound.p, nranks + 1, dOut.p);
+    std::vector<unsigned long long> o(nranks + 1);
+    CDM_HIP(hipMemcpyAsync(o.data(), dOut.p, (nranks + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CDM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r <= nranks; r++) offsets[r] = o[r];
+    offsets[nranks] = h->job->nKept;
+    *devKeys = h->job->gathered;
+    return CDM_OK;
+}
+extern "C" int cdm_kpart_finish(cdm_ctx *ctx, cdm_kpart *h, const void *devKeys, uint64_t nKeys, const uint32_t *stale, cdm_hits **out) {
+    if (!out || !stale || (nKeys && !devKeys)) { cdm_set_error("cdm_kpart_finish: invalid argument"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    return h->job->phaseBFrom((const uint64_t *) devKeys, nKeys, stale, out);
+}
+extern "C" int cdm_dev_copy(cdm_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    if (bytes) CDM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    CDM_HIP(hipStreamSynchronize(ctx->stream));
+    return CDM_OK;
+}
 
 int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
     // packed 12-byte tuples when k-mer, position and length share 63 key bits; CDM_KMER_LAYOUT=wide|packed pins one (tests)

@@ -1,0 +1,251 @@
+"""Scheme "exact" of the multi-GPU run: one reads-loop iteration spread over W ranks with results that are
+bit-identical to the single-device run.
+
+Every rank holds the whole packed sequence DB.  Per iteration:
+  1. kmermatcher, first half, on the rank's k-mer RANGE (cdm_kmermatch_part: the reference's MPI split of the k-mer space,
+     lib/mmseqs/src/linclust/kmermatcher.cpp:634-663, by value so that rank order is k-mer order)
+  2. a few integers per rank are all-gathered (tuple counts; the candidates of the reference's run-past-the-end scan)
+  3. ONE all-to-all moves every (rep, id, diagonal, strand) group key to the rank that owns its representative
+     (representatives [r n/W, (r+1) n/W) belong to rank r); received slices are concatenated in rank = k-mer order, which is
+     what keeps the reference's tie order
+  4. kmermatcher, second half (cdm_kpart_finish): hits of the owned representatives
+  5. rescorediagonal, ancient_correction on the owned queries (the other queries carry their self hit only); the corrected
+     owned ranges are all-gathered so that every rank holds the corrected DB the extension stage looks targets up in
+  6. ancient_read_assemble on the owned queries; the new owned ranges are all-gathered: every rank holds the next iteration's DB
+
+The collectives go through a small `Comm` interface: TorchComm (torch.distributed: RCCL on GPUs, gloo in the CPU tests) and
+ThreadComm (W ranks as threads of one process on one GPU: what tests/test_gpu_shards.py uses to check the scheme against the
+single-device result without a multi-GPU box).
+"""
+import threading
+
+import numpy as np
+
+STALE_MAX = 62          # csrc/kmermatch.hip
+STALE_LEN = 67          # [0] count, [1] sequence id, [2..63] positions, [66] the scan reached the end of the range
+
+
+# ------------------------------------------------------------------------------------------------ pure logic (CPU-testable)
+def owned_range(rank, world, n):
+    return rank * n // world, (rank + 1) * n // world
+
+
+def stale_plan(infos):
+    """infos: per range, in k-mer order, {"real": real tuples, "kept": kept group keys}.  The reference's last per-target scan
+    runs from index J = (all kept group keys) of the k-mer-ordered tuple array on.  -> (holder range or None, local index)"""
+    j = sum(i["kept"] for i in infos)
+    base = 0
+    for h, i in enumerate(infos):
+        if j < base + i["real"]:
+            return h, j - base
+        base += i["real"]
+    return None, 0
+
+
+def combine_stale(lists, holder):
+    """lists[p]: range p's 67-value list (the holder's from its local index, the later ranges' from their first tuple).
+    The scan collects tuples while they belong to one sequence; it goes on into the next range when it consumed the current one."""
+    out = np.zeros(STALE_LEN, np.uint32)
+    if holder is None:
+        return out
+    cnt, target, pos = 0, None, []
+    for p in range(holder, len(lists)):
+        l = lists[p]
+        c = int(l[0])
+        if c:
+            if target is None:
+                target = int(l[1])
+            elif int(l[1]) != target:
+                break
+            pos.extend(int(x) for x in l[2:2 + c])
+            cnt += c
+        if not int(l[66]):
+            break
+    if cnt >= STALE_MAX:
+        raise RuntimeError("the reference's last per-target scan would run over %d or more left-over tuples; not reproduced" % STALE_MAX)
+    out[0] = cnt
+    out[1] = target if target is not None else 0
+    out[2:2 + cnt] = pos
+    return out
+
+
+def seq_section_layout(n, words):
+    """one int32 buffer for a range of sequences: [codes: words][N planes: ceil(words/2)][lengths: n][keys: n][ext: ceil(n/4)]"""
+    o_codes = 0
+    o_mask = o_codes + words
+    o_len = o_mask + (words + 1) // 2
+    o_key = o_len + n
+    o_ext = o_key + n
+    return o_codes, o_mask, o_len, o_key, o_ext, o_ext + (n + 3) // 4
+
+
+# ------------------------------------------------------------------------------------------------ communicators
+class TorchComm:
+    def __init__(self, dist, rank, world, device):
+        self.dist, self.rank, self.world, self.device = dist, rank, world, device
+        self.backend = dist.get_backend()
+
+    def all_gather_array(self, a):
+        """a: 1-D numpy array of the same length and dtype (<= 8 bytes per element) on every rank -> list of arrays"""
+        import torch
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a.astype(np.int64)).to(self.device)
+        parts = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return [p.cpu().numpy().astype(a.dtype) for p in parts]
+
+    def exchange(self, send, offsets):
+        """send: 1-D tensor, offsets[r]..offsets[r+1] goes to rank r -> what this rank receives, concatenated in rank order.
+        One all_to_all_single on RCCL; gloo (CPU tests) has no all-to-all: an all-gather of the padded buffers stands in."""
+        import torch
+        offsets = [int(x) for x in offsets]
+        counts = np.array([offsets[r + 1] - offsets[r] for r in range(self.world)], np.int64)
+        all_counts = self.all_gather_array(counts)                 # all_counts[p][r] = what p sends to r
+        recv_counts = [int(all_counts[p][self.rank]) for p in range(self.world)]
+        if self.backend == "nccl":
+            recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=send.device)
+            self.dist.all_to_all_single(recv, send[: offsets[-1]].contiguous(), output_split_sizes=recv_counts, input_split_sizes=[int(c) for c in counts])
+            return recv
+        mx = max(1, max(int(c.sum()) for c in all_counts))
+        pad = torch.zeros(mx, dtype=send.dtype, device=send.device)
+        pad[: offsets[-1]] = send[: offsets[-1]]
+        bufs = [torch.zeros_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(bufs, pad)
+        out = []
+        for p in range(self.world):
+            o = np.concatenate([[0], np.cumsum(all_counts[p])])
+            out.append(bufs[p][int(o[self.rank]): int(o[self.rank + 1])])
+        return torch.cat(out)
+
+    def all_gather_tensor(self, t):
+        """variable-length 1-D tensors -> list of the ranks' tensors (sizes first, then ONE padded all_gather)"""
+        import torch
+        sizes = self.all_gather_array(np.array([t.numel()], np.int64))
+        mx = max(1, max(int(s[0]) for s in sizes))
+        pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+        pad[: t.numel()] = t
+        bufs = [torch.empty_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(bufs, pad)
+        return [b[: int(s[0])] for b, s in zip(bufs, sizes)]
+
+
+class ThreadComm:
+    """W ranks as threads of one process (one GPU): collectives are slots of a shared list between two barriers."""
+
+    class Shared:
+        def __init__(self, world):
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.world = shared, rank, shared.world
+
+    def _gather(self, x):
+        self.sh.slots[self.rank] = x
+        self.sh.barrier.wait()
+        out = list(self.sh.slots)
+        self.sh.barrier.wait()
+        return out
+
+    def all_gather_array(self, a):
+        return [np.array(x) for x in self._gather(np.ascontiguousarray(a).copy())]
+
+    def exchange(self, send, offsets):
+        import torch
+        offsets = [int(x) for x in offsets]
+        parts = self._gather((send, offsets))
+        torch.cuda.synchronize()
+        out = torch.cat([s[o[self.rank]: o[self.rank + 1]] for s, o in parts]).clone()
+        torch.cuda.synchronize()
+        self.sh.barrier.wait()          # nobody frees its send buffer before everybody has copied
+        return out
+
+    def all_gather_tensor(self, t):
+        import torch
+        parts = self._gather(t)
+        torch.cuda.synchronize()
+        out = [p.clone() for p in parts]
+        torch.cuda.synchronize()
+        self.sh.barrier.wait()
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ the stages
+def kmermatch_exact(ctx, db, comm, par=None):
+    """kmermatcher over comm.world ranks: the hits of the representatives this rank owns (self hits for all other sequences);
+    the union over the ranks is the single-device result."""
+    import torch
+    part = ctx.kmermatch_part(db, comm.rank, comm.world, par)
+    info = part.info()
+    infos = [{"real": int(a[0]), "kept": int(a[1])} for a in comm.all_gather_array(np.array([info["real"], info["kept"]], np.uint64))]
+    holder, j_local = stale_plan(infos)
+    mine = np.zeros(STALE_LEN, np.uint32)
+    if holder is not None and comm.rank >= holder:
+        mine = part.stale(j_local if comm.rank == holder else 0)
+    stale = combine_stale(comm.all_gather_array(mine), holder)
+    off, ptr = part.gather(comm.world)
+    kept = int(off[-1])
+    send = torch.empty(max(kept, 1), dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+    torch.cuda.synchronize()
+    if kept:
+        ctx.dev_copy(send.data_ptr(), ptr, kept * 8)
+    recv = comm.exchange(send[:kept], off)                         # the all-to-all of the group keys
+    torch.cuda.synchronize()
+    return part.finish(recv.data_ptr() if recv.numel() else None, recv.numel(), stale)
+
+
+def pack_owned(ctx, db, lo, hi):
+    """sequences [lo, hi) of a device DB as one int32 device tensor (seq_section_layout) -> (buf, n, words)"""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n, words = db.n, db.words
+    codes = torch.empty(max(words, 1), dtype=torch.int32, device=dev)
+    mask = torch.empty(max(words, 1), dtype=torch.int16, device=dev)
+    lens = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    keys = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    ext = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    db.copy_packed(codes.data_ptr(), mask.data_ptr(), lens.data_ptr(), keys.data_ptr())
+    db.copy_ext(ext.data_ptr())
+    woff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    woff[1:] = torch.cumsum((lens[:n].to(torch.int64) + 15) // 16, 0)
+    w0, w1 = int(woff[lo].item()), int(woff[hi].item())
+    m, w = hi - lo, w1 - w0
+    oc, om, ol, ok, oe, total = seq_section_layout(m, w)
+    buf = torch.zeros(max(total, 1), dtype=torch.int32, device=dev)
+    buf[oc: oc + w] = codes[w0:w1]
+    buf[om: ol].view(torch.int16)[:w] = mask[w0:w1]
+    buf[ol: ol + m] = lens[lo:hi]
+    buf[ok: ok + m] = keys[lo:hi]
+    buf[oe: total].view(torch.uint8)[:m] = ext[lo:hi]
+    return buf[:total], m, w
+
+
+def merge_owned(ctx, db_local, comm):
+    """All-gather the owned sequence ranges of the ranks' result DBs (same number of sequences everywhere) into the full DB."""
+    import torch
+    n = db_local.n
+    lo, hi = owned_range(comm.rank, comm.world, n)
+    buf, m, w = pack_owned(ctx, db_local, lo, hi)
+    metas = comm.all_gather_array(np.array([m, w], np.int64))
+    bufs = comm.all_gather_tensor(buf)
+    codes, masks, lens, keys, exts = [], [], [], [], []
+    for b, (mm, ww) in zip(bufs, metas):
+        mm, ww = int(mm), int(ww)
+        oc, om, ol, ok, oe, total = seq_section_layout(mm, ww)
+        codes.append(b[oc: oc + ww]); masks.append(b[om: ol].view(torch.int16)[:ww]); lens.append(b[ol: ol + mm]); keys.append(b[ok: ok + mm])
+        exts.append(b[oe: total].view(torch.uint8)[:mm])
+    c, k16, l, k, e = (torch.cat(x).contiguous() for x in (codes, masks, lens, keys, exts))
+    torch.cuda.synchronize()
+    return ctx.from_packed_ext(c.data_ptr(), k16.data_ptr(), l.data_ptr(), k.data_ptr(), e.data_ptr(), int(l.numel()), int(c.numel()))
+
+
+def exact_iteration(ctx, db, comm, kpar=None, rpar=None, apar=None):
+    """One iteration of the reads loop (data/nuclassemble.sh:100-146) over comm.world ranks -> (hits, alns, corrected DB, next DB),
+    the two DBs complete on every rank and identical to the single-device ones."""
+    hits = kmermatch_exact(ctx, db, comm, kpar)
+    alns = ctx.rescore(db, hits, rpar)
+    corr = merge_owned(ctx, ctx.correct(db, alns, apar), comm)
+    asm = merge_owned(ctx, ctx.extend(corr, alns, apar), comm)
+    return hits, alns, corr, asm

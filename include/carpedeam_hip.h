@@ -95,6 +95,11 @@ uint64_t cdm_seqdb_words(const cdm_seqdb *db);
 int cdm_seqdb_copy_packed(cdm_ctx *ctx, const cdm_seqdb *db, void *dev_codes, void *dev_nmask16, void *dev_lengths, void *dev_keys);
 int cdm_seqdb_from_packed(cdm_ctx *ctx, const void *dev_codes, const void *dev_nmask16, const void *dev_lengths, const void *dev_keys,
                           uint64_t n, uint64_t words, uint8_t ext_value, cdm_seqdb **out);
+/* the same with one wasExtended flag per sequence (device array of n bytes, NULL = all 0), and the flags of a DB copied out:
+ * the query-sharded stages of a multi-GPU run hand whole DB slices around, flags included */
+int cdm_seqdb_from_packed_ext(cdm_ctx *ctx, const void *dev_codes, const void *dev_nmask16, const void *dev_lengths, const void *dev_keys,
+                              const void *dev_ext, uint64_t n, uint64_t words, cdm_seqdb **out);
+int cdm_seqdb_copy_ext(cdm_ctx *ctx, const cdm_seqdb *db, void *dev_ext);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Damage model.  Replaces the per-thread initDeamProbabilities + getSeqErrorProf calls
@@ -136,6 +141,33 @@ int cdm_hits_upload(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *offsets, 
 uint64_t cdm_hits_count(const cdm_hits *h);
 int cdm_hits_download(cdm_ctx *ctx, const cdm_hits *h, uint64_t *offsets, cdm_hit *hits);
 void cdm_hits_free(cdm_hits *h);
+
+/* kmermatcher split over several GPUs without changing its result (the reference's MPI path splits the k-mer
+ * space the same way, lib/mmseqs/src/linclust/kmermatcher.cpp:634-663, but merges per-split results lossily - here the
+ * single-split semantics are kept).  Every rank holds the whole sequence DB.
+ *   cdm_kmermatch_part   doComputation's first half (:391-430) on the k-mer range part/nparts (ranges are equal slices of the
+ *                        2k-bit k-mer space in k-mer order; the whole-sequence hash tuples belong to the last range): extraction,
+ *                        sort 1, assignGroup -> (rep, id, diagonal, strand) group keys of this range
+ *   cdm_kpart_info       info[0] real tuples of the range, [1] kept group keys, [2] 1 if a real tuple lies below the range, [3] n
+ *   cdm_kpart_stale      the left-over list of the reference's run-past-the-end scan (kmermatcher.cpp:875-887) from local
+ *                        k-mer-order index J of this range: out[0] count, out[1] sequence id, out[2..63] positions, out[66] = 1 if
+ *                        the scan consumed every tuple up to the end of the range (then it goes on in the next range)
+ *   cdm_kpart_gather     the group keys grouped by representative (k-mer order inside); offsets[r]..offsets[r+1] is the slice
+ *                        for the rank that owns representatives [r n/nranks, (r+1) n/nranks); *dev_keys is a DEVICE pointer
+ *                        owned by the handle (send buffer of the all-to-all)
+ *   cdm_kpart_finish     second half (:431 sort 2, writeKmerMatcherResult :815-930) on the keys received from all ranks,
+ *                        concatenated in rank order (device buffer): hits of the representatives this rank owns (every other
+ *                        sequence gets its self hit only); stale = the combined left-over list (65 values as above)
+ */
+typedef struct cdm_kpart cdm_kpart;
+int cdm_kmermatch_part(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int part, int nparts, cdm_kpart **out);
+int cdm_kpart_info(const cdm_kpart *h, uint64_t info[4]);
+int cdm_kpart_stale(cdm_ctx *ctx, cdm_kpart *h, uint64_t J, uint32_t out[67]);
+int cdm_kpart_gather(cdm_ctx *ctx, cdm_kpart *h, int nranks, uint64_t *offsets, const void **dev_keys);
+int cdm_kpart_finish(cdm_ctx *ctx, cdm_kpart *h, const void *dev_keys, uint64_t n_keys, const uint32_t *stale, cdm_hits **out);
+void cdm_kpart_free(cdm_kpart *h);
+/* device-to-device copy on the context's stream (synchronises it): moves library-owned buffers into caller tensors */
+int cdm_dev_copy(cdm_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 
 /* ---------------------------------------------------------------------------------------------------------
  * rescorediagonal (--rescore-mode 3, query DB == target DB).  Replaces the loop at

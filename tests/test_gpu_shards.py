@@ -77,3 +77,97 @@ def test_price_of_read_sharding(ctx, oracle_bin, dhigh_prefix, tmp_path):
           % ((N_READS, len(full)) + report[2] + report[4]))
     # sharding is NOT equivalent: the test documents the size of the effect and guards against it being mistaken for exact
     assert report[2][1] > 0 and report[4][1] > report[2][1] * 0.5
+
+
+# ------------------------------------------------------------------------------------------------ scheme "exact" (shard.py)
+def run_ranks(world, fn):
+    """fn(rank, comm) on `world` threads of this process (carpedeam_amd.shard.ThreadComm); returns the per-rank results"""
+    import threading
+    from carpedeam_amd import shard
+    sh = shard.ThreadComm.Shared(world)
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            out[r] = fn(r, shard.ThreadComm(sh, r))
+        except BaseException as e:          # noqa: BLE001 - reported below; a dead rank must not leave the others waiting forever
+            err[r] = e
+            sh.barrier.abort()
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    first = [e for e in err if e is not None and not isinstance(e, threading.BrokenBarrierError)] or [e for e in err if e is not None]
+    if first:
+        raise first[0]
+    return out
+
+
+def merged_hits(per_rank, n):
+    """rows of the owned representatives from every rank's CSR -> (offsets, records) of the whole prefilter result"""
+    from carpedeam_amd import shard
+    offs, recs = [0], []
+    for r, (off, rec) in enumerate(per_rank):
+        lo, hi = shard.owned_range(r, len(per_rank), n)
+        for q in range(lo, hi):
+            recs.append(rec[int(off[q]):int(off[q + 1])])
+            offs.append(offs[-1] + int(off[q + 1] - off[q]))
+    return np.array(offs, np.uint64), np.concatenate(recs)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exact_scheme_equals_single_device(dhigh_prefix, world):
+    """200 k reads (mixed lengths): the k-mer-range split + group-key exchange + query-sharded stages give exactly the hits,
+    the corrected DB and the next iteration's DB of the single-device run."""
+    from carpedeam_amd import shard
+    ref = capi.Ctx(0)
+    ref.damage_load(dhigh_prefix)
+    db = ref.synth(N_READS, 60, 150, 3)
+    hits = ref.kmermatch(db); alns = ref.rescore(db, hits); corr = ref.correct(db, alns); asm = ref.extend(corr, alns)
+    want_hits = hits.download()
+    want_corr, want_asm = corr.download(), asm.download()
+    del hits, alns, corr, asm
+
+    def rank_fn(rank, comm):
+        c = capi.Ctx(0)
+        c.damage_load(dhigh_prefix)
+        d = c.synth(N_READS, 60, 150, 3)
+        h, a, co, nx = shard.exact_iteration(c, d, comm)
+        return h.download(), co.download(), nx.download()
+
+    res = run_ranks(world, rank_fn)
+    off, rec = merged_hits([r[0] for r in res], N_READS)
+    assert np.array_equal(off, want_hits[0]) and np.array_equal(rec, want_hits[1])
+    for r in res:                                   # the two DBs are complete and identical on every rank
+        for got, want in ((r[1], want_corr), (r[2], want_asm)):
+            assert [bytes(x) for x in got[0]] == [bytes(x) for x in want[0]]
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+
+
+def test_exact_kmermatcher_on_small_databases(dhigh_prefix):
+    """Tiny random databases, where the reference's quirks decide records (the first group's strand, the run-past-the-end
+    scan, identical sequences = whole-sequence hash groups): 2, 3 and 5 k-mer ranges against the single-device result."""
+    from carpedeam_amd import shard
+    rng = np.random.default_rng(77)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    ref = capi.Ctx(0)
+    for case in range(24):
+        genome = rng.integers(0, 4, 260)
+        seqs = []
+        for _ in range(int(rng.integers(3, 50))):
+            L = int(rng.integers(18, 110)); st = int(rng.integers(0, 260 - L))
+            c = genome[st:st + L].copy()
+            if rng.random() < 0.5:
+                c = (3 - c)[::-1]
+            seqs.append(letters[c].tobytes())
+        seqs += [seqs[0]] * int(rng.integers(0, 3)) + [b"ACG", b""][: int(rng.integers(0, 3))]
+        db = ref.upload_seqs(seqs)
+        want = ref.kmermatch(db).download()
+        for world in (2, 3, 5):
+            def rank_fn(rank, comm, seqs=seqs):
+                c = capi.Ctx(0)
+                return shard.kmermatch_exact(c, c.upload_seqs(seqs), comm).download()
+            off, rec = merged_hits(run_ranks(world, rank_fn), len(seqs))
+            assert np.array_equal(off, want[0]) and np.array_equal(rec, want[1]), (case, world)
