@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--len", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
+    ap.add_argument("--scheme", default="reads", choices=("reads", "exact"),
+                    help="N > 1: reads = every rank runs the stages on its own read shard (north star; not equivalent to the single-device run); "
+                         "exact = k-mer-range split + all-to-all of group keys + query-sharded stages, bit-identical to one device (carpedeam_amd/shard.py)")
     ap.add_argument("--cpu-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -165,6 +168,11 @@ def main():
     L = args.len
     from carpedeam_amd import dist as cd
     plan = cd.shard_plan(rank, world, args.reads, args.seed, args.scaling)
+    exact = args.scheme == "exact" and dist is not None and args.config == 3
+    if exact:      # every rank holds the whole corpus; the work is split inside the stages
+        plan = dict(plan, first=0, n=plan["n_total"])
+        from carpedeam_amd import shard
+        comm = shard.TorchComm(dist, rank, world, torch.device("cuda", local_rank))
     db = ctx.synth(plan["n"], L, L, plan["seed"], n_total=plan["n_total"], first=plan["first"])      # resident in HBM before the timed region
     n = plan["n"]
     residues = db.residues
@@ -176,6 +184,9 @@ def main():
         del hits
 
     def step():
+        if exact:
+            hits, alns, corr, asm = shard.exact_iteration(ctx, db, comm)
+            return asm, (hits.count, alns.count), [ctx.last_kernel_ms(i) for i in range(12)]
         if args.config == 2:
             corr = ctx.correct(db, pre)
             return corr, (0, pre.count), [ctx.last_kernel_ms(i) for i in range(12)]
@@ -210,10 +221,11 @@ def main():
     total_bases = residues * args.steps
     if dist is not None:
         dt = cd.max_over_ranks(dist, dt, device="cuda")
-        tb = torch.tensor([float(total_bases)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tb)
-        total_bases = float(tb.item())
-        if args.config == 3:
+        if not exact:       # (exact: every rank counted the one shared corpus)
+            tb = torch.tensor([float(total_bases)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tb)
+            total_bases = float(tb.item())
+        if args.config == 3 and not exact:
             # the single data-path collective of the north star: RCCL all-gather of the per-shard contigs (packed bases, N
             # planes, lengths, keys in ONE buffer); every rank ends up holding the contigs of all shards as one device DB
             t1 = time.perf_counter()
@@ -279,7 +291,9 @@ def main():
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8 (2-bit packed bases; int32 scores; software x87 f80 likelihood sums)", "data": "synthetic",
             "config": {"workload": workload, "reads_rank0": n, "read_len": L, "seed": args.seed, "prefilter_hits": stats[0], "alignments": stats[1],
-                       "multi_gpu_scheme": ("reads: every rank runs the stages on its own read shard, no data-path collective, one all-gather of contigs at the end" if world > 1 else None),
+                       "multi_gpu_scheme": (None if world == 1 and not exact else
+                                            "exact: k-mer-range kmermatcher + one all-to-all of group keys + query-sharded stages + all-gathers of the new sequences; bit-identical to one device" if exact else
+                                            "reads: every rank runs the stages on its own read shard, no data-path collective, one all-gather of contigs at the end"),
                        "value_is": "kernel-resident: reads already in HBM, no DB files (the module-wall figure is gpu_module_wall)",
                        "stage_kernel_ms": {"kmer_extract": k_ms[3], "kmer_sort1_call": k_ms[5], "kmer_sort1_hash_call": k_ms[7], "kmer_sort2_call": k_ms[6], "rescore": k_ms[1],
                                            "correct": k_ms[0], "extend": k_ms[4]}},

@@ -50,7 +50,7 @@ EXPORTS = [
     "cdm_seqdb_download", "cdm_seqdb_free", "cdm_seqdb_select_ext", "cdm_seqdb_words", "cdm_seqdb_copy_packed", "cdm_seqdb_from_packed", "cdm_damage_load", "cdm_damage_get", "cdm_kmermatch", "cdm_hits_upload", "cdm_hits_count",
     "cdm_hits_download", "cdm_hits_free", "cdm_rescore", "cdm_alns_upload", "cdm_alns_count", "cdm_alns_download", "cdm_alns_free",
     "cdm_evalue", "cdm_bit_score", "cdm_correct", "cdm_extend",
-    "cdm_kmermatch_part", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_finish", "cdm_kpart_free", "cdm_dev_copy",
+    "cdm_kmermatch_part", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_sort", "cdm_kpart_vote", "cdm_kpart_cont_cap", "cdm_kpart_free", "cdm_dev_copy",
     "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext",
 ]
 
@@ -113,7 +113,8 @@ def lib():
         l.cdm_kpart_info.argtypes = [vp, vp]
         l.cdm_kpart_stale.argtypes = [vp, vp, C.c_uint64, vp]
         l.cdm_kpart_gather.argtypes = [vp, vp, C.c_int, vp, C.POINTER(vp)]
-        l.cdm_kpart_finish.argtypes = [vp, vp, vp, C.c_uint64, vp, C.POINTER(vp)]
+        l.cdm_kpart_sort.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
+        l.cdm_kpart_vote.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
         l.cdm_kpart_free.argtypes = [vp]
         l.cdm_kpart_free.restype = None
         l.cdm_dev_copy.argtypes = [vp, vp, vp, C.c_uint64]
@@ -246,10 +247,18 @@ class KPart:
         _check(lib().cdm_kpart_gather(self.ctx.h, self.h, nranks, _ptr(off), C.byref(p)))
         return off, p.value or 0
 
-    def finish(self, keys_ptr, n_keys, stale):
+    def sort(self, keys_ptr, n_keys):
+        """sort 2 on the received keys -> (head list, sorted tuples, target id of the last one)"""
+        head = np.zeros(lib().cdm_kpart_cont_cap() + 3, np.uint32)
+        info = np.zeros(2, np.uint64)
+        _check(lib().cdm_kpart_sort(self.ctx.h, self.h, keys_ptr, int(n_keys), _ptr(head), _ptr(info)))
+        return head, int(info[0]), int(info[1])
+
+    def vote(self, cont, stale):
         st = np.ascontiguousarray(stale[:65], np.uint32)
+        ct = None if cont is None else np.ascontiguousarray(cont, np.uint32)
         h = C.c_void_p()
-        _check(lib().cdm_kpart_finish(self.ctx.h, self.h, keys_ptr, int(n_keys), _ptr(st), C.byref(h)))
+        _check(lib().cdm_kpart_vote(self.ctx.h, self.h, _ptr(ct), _ptr(st), C.byref(h)))
         return Hits(self.ctx, h, self.db.n)
 
 

@@ -790,8 +790,13 @@ struct VoteArgs {
     // stale[0] = number of such tuples, stale[1] = their sequence id, stale[2..] their positions (k_stale_tail); their k-mer
     // field is UINT64_MAX by then, so they count as forward.
     const uint32_t *stale;
+    // Multi-GPU runs (every rank votes on the representatives it owns): what the scan of this rank's LAST segment runs into is
+    // the head of the next rank's sorted array - cont[0] entries (cont[3 + j] = biased diagonal | "reverse" << 31) that apply if
+    // the target is cont[1]; only if cont[2] is set does the scan go on into the left-over tuples (`stale`) after them.  NULL on
+    // a single device.
+    const uint32_t *cont;
 };
-constexpr int STALE_MAX = 62;
+constexpr int STALE_MAX = 62, CONT_CAP = 2048;
 // a (rep, target != rep) segment starts at i
 __device__ __forceinline__ bool validStart(const VoteArgs &a, uint64_t i, uint32_t &rep, uint32_t &target) {
     const uint64_t seg = a.keys[i] >> (a.diagBits + 1);
@@ -839,7 +844,20 @@ __device__ __forceinline__ HitRec voteSegmentTile(const VoteArgs &a, const uint6
             prevDiag = d; top++;
         }
     }
-    if (!done && target == a.stale[1]) {        // the scan reached the end of the group tuples: on into the left-over ones
+    bool intoStale = !done;
+    if (!done && a.cont) {                      // the scan reached the end of this rank's group tuples: on into the next ranks'
+        if (target == a.cont[1]) {
+            const uint32_t m = a.cont[0];
+            for (uint32_t j = 0; j < m; j++) {
+                const uint32_t e = a.cont[3 + j], d = e & 0x7FFFFFFFu;
+                if (prevDiag == d) diagCnt++; else diagCnt = 1;
+                if (diagCnt >= maxDiag) { diagonal = d; maxDiag = diagCnt; bestRev = (int) (e >> 31); }
+                prevDiag = d; top++;
+            }
+        }
+        intoStale = a.cont[2] != 0u;
+    }
+    if (intoStale && target == a.stale[1]) {    // the scan reached the end of all group tuples: on into the left-over ones
         const uint32_t m = a.stale[0];
         for (uint32_t j = 0; j < m; j++) {
             const uint32_t d = a.stale[2 + j] + (uint32_t) a.diagBias;
@@ -916,6 +934,21 @@ __global__ __launch_bounds__(256) void k_seg_place(VoteArgs a, const unsigned lo
         out[off[rep] + 1 + (rank - perRepScan[rep])] = h;
         rank++;
     }
+}
+// The head of a sorted group-key array: the tuples from its start on while they have the target id of the first one, whatever
+// their representative (what a scan coming in from the rank in front runs through, kmermatcher.cpp:875-887).
+// out[0] = count (CONT_CAP + 1: longer than the list), out[1] = that id, out[2] = 1 if the head is the whole array, out[3..] entries
+__global__ void k_head_segment(const uint64_t *__restrict__ keys, uint64_t n, uint32_t idBits, uint32_t diagBits, uint32_t *__restrict__ out) {
+    const uint64_t idMask = (1ull << idBits) - 1ull, diagMask = (1ull << diagBits) - 1ull;
+    if (n == 0) { out[0] = 0; out[1] = 0; out[2] = 1; return; }
+    const uint32_t id = (uint32_t) ((keys[0] >> (diagBits + 1)) & idMask);
+    uint64_t c = 0;
+    for (; c < n && c <= (uint64_t) CONT_CAP; c++) {
+        const uint64_t k2 = keys[c];
+        if ((uint32_t) ((k2 >> (diagBits + 1)) & idMask) != id) break;
+        if (c < (uint64_t) CONT_CAP) out[3 + c] = (uint32_t) ((k2 >> 1) & diagMask) | ((k2 & 1ull) ? 0u : 1u << 31);
+    }
+    out[0] = (uint32_t) c; out[1] = id; out[2] = (c == n) ? 1u : 0u;
 }
 __global__ void k_offsets(const unsigned long long *__restrict__ perRepScan, uint32_t n, uint64_t *__restrict__ off) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1045,7 +1078,8 @@ struct KmerJobBase {
     virtual int staleTail(unsigned long long J, bool fromStart) = 0;
     virtual int phaseB(cdm_hits **out) = 0;
     virtual int gatherByRep() = 0;
-    virtual int phaseBFrom(const uint64_t *devKeys, uint64_t nKeys, const uint32_t *staleHost, cdm_hits **out) = 0;
+    virtual int sortFrom(const uint64_t *devKeys, uint64_t nKeys, uint32_t *head, uint64_t info[2]) = 0;
+    virtual int voteWith(const uint32_t *cont, const uint32_t *staleIn, cdm_hits **out) = 0;
     cdm_ctx *ctx = nullptr; const cdm_seqdb *db = nullptr; cdm_kmer_params parCopy; const cdm_kmer_params *par = nullptr;
     int part = 0, nparts = 1;           // this rank's k-mer range (nparts == 1: everything)
     unsigned long long live = 0, nKept = 0, regionTwo = 0;      // real tuples of region 1 in this range; kept group tuples; real tuples of region 2
@@ -1067,6 +1101,9 @@ struct KmerJob : KmerJobBase {
     DevBuf<uint64_t> k0, k1; DevBuf<V> v0, v1;
     TupleGeom geom; int lowBits = 0;
     GroupArgs<LY> ga; DevBuf<unsigned long long> statStripes; unsigned long long *startIo = nullptr; DevBuf<uint32_t> staleBuf;
+    DevBuf<uint64_t> runsOut, runsTmp;       // sort 2 "check" mode: the run-based result next to the radix one
+    DevBuf<uint64_t> recvA, recvB; DevBuf<uint32_t> contBuf;      // multi-GPU second half: received keys / their sorted form, the continuation list
+    const uint64_t *sorted2M = nullptr; unsigned long long nGroupM = 0;
     float msSort1 = 0;
     KmerJob(cdm_ctx *c, const cdm_seqdb *d, const cdm_kmer_params *p) { ctx = c; db = d; parCopy = *p; par = &parCopy; }
 int phaseA() override {
@@ -1321,11 +1358,12 @@ int staleTail(unsigned long long J, bool fromStart) override {
     return CDM_OK;
 }
 int phaseB(cdm_hits **out) override {
-    return sort2Vote((const uint64_t *) startIo, nTuples, live, kmerSlots, keys.current(), (uint64_t *) startIo, true, out);
+    if (int rc = sort2((const uint64_t *) startIo, nTuples, live, kmerSlots, keys.current(), (uint64_t *) startIo, true)) return rc;
+    return vote(nullptr, true, out);
 }
 // kept group keys of [keysIn, keysIn + nIn) (~0 = dropped; [skipLo, skipHi) holds only ~0) -> sort 2 -> vote -> hits.
 // bufA / bufB: two buffers of nIn keys (bufB may be keysIn itself).
-int sort2Vote(const uint64_t *keysIn, unsigned long long nIn, unsigned long long skipLo, unsigned long long skipHi, uint64_t *bufA, uint64_t *bufB, bool ownBuffers, cdm_hits **out) {
+int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long skipLo, unsigned long long skipHi, uint64_t *bufA, uint64_t *bufB, bool ownBuffers) {
 
     // ---- sort 2: by (rep, id, diagonal) = key bits 1.., stable; strand bit 0 rides along.
     // Default ("runs", runsort.h): the k-mer runs are sorted by representative, not the tuples - records of (rep, start, length),
@@ -1343,7 +1381,6 @@ int sort2Vote(const uint64_t *keysIn, unsigned long long nIn, unsigned long long
     if (sort2Env && strcmp(sort2Env, "runs") && strcmp(sort2Env, "radix") && !sort2Check) { cdm_set_error("cdm_kmermatch: CDM_KMER_SORT2 must be runs, radix or check"); return CDM_ERR_INVALID; }
     unsigned long long nGroup = 0;
     const uint64_t *sorted2 = nullptr;
-    DevBuf<uint64_t> runsOut, runsTmp;       // "check" mode: the run-based result next to the radix one
     hipEventRecord(ctx->ev0, s);
     if (sort2Runs) {
         using namespace runsort;
@@ -1421,8 +1458,12 @@ int sort2Vote(const uint64_t *keysIn, unsigned long long nIn, unsigned long long
         nGroup = nGroupR; sorted2 = sortedR;
     }
     hipEventRecord(ctx->ev1, s);
-
-    // ---- K4: count hit-producing segments (per tile and per representative), scan, vote + place
+    sorted2M = sorted2; nGroupM = nGroup;
+    return CDM_OK;
+}
+// ---- K4: count hit-producing segments (per tile and per representative), scan, vote + place.  contDev: VoteArgs::cont
+int vote(const uint32_t *contDev, bool ownBuffers, cdm_hits **out) {
+    const uint64_t *sorted2 = sorted2M; const unsigned long long nGroup = nGroupM;
     DevBuf<unsigned long long> perRep, perRepScan, vTileCnt, vTileOff;
     const uint64_t vTiles = (nGroup + CP_TILE - 1) / CP_TILE;
     if (!perRep.alloc((size_t) n + 1) || !perRepScan.alloc((size_t) n + 1) || !vTileCnt.alloc(vTiles + 1) || !vTileOff.alloc(vTiles + 1)) {
@@ -1432,7 +1473,7 @@ int sort2Vote(const uint64_t *keysIn, unsigned long long nIn, unsigned long long
     hipMemsetAsync(vTileCnt.p, 0, (vTiles + 1) * 8, s);
     VoteArgs va;
     if (ownBuffers && nGroup != nKept) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu sorted", nKept, nGroup); return CDM_ERR_HIP; }
-    va.stale = staleBuf.p;
+    va.stale = staleBuf.p; va.cont = contDev;
     va.keys = sorted2; va.n = nGroup; va.idBits = idBits; va.diagBits = diagBits; va.diagBias = diagBias; va.perRep = perRep.p;
     if (nGroup) hipLaunchKernelGGL(k_seg_count, dim3((unsigned) vTiles), dim3(256), 0, s, va, vTileCnt.p);
     cdmscan::ScanTemp st4a, st4b;
@@ -1490,15 +1531,31 @@ int gatherByRep() override {
     if (nOut != nKept) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu gathered", nKept, nOut); return CDM_ERR_HIP; }
     return CDM_OK;
 }
-// sort 2 + vote on group keys received from all ranks (device buffer; concatenated in rank = k-mer order, so that the stable
-// sort by representative leaves every representative's tuples in global k-mer order); staleIn: the combined left-over list
-int phaseBFrom(const uint64_t *devKeys, uint64_t nKeys, const uint32_t *staleIn, cdm_hits **out) override {
+// second half on group keys received from all ranks (device buffer; concatenated in rank = k-mer order, so that the stable
+// sort by representative leaves every representative's tuples in global k-mer order): sort 2, then the head of the sorted array
+// for the rank in front (head: CONT_CAP + 3 values, k_head_segment; info[0] = tuples, info[1] = target id of the last one)
+int sortFrom(const uint64_t *devKeys, uint64_t nKeys, uint32_t *head, uint64_t info[2]) override {
     k0.free(); k1.free(); v0.free(); v1.free();             // phase A's tuple buffers are not needed any more
+    if (!recvA.alloc(nKeys) || !recvB.alloc(nKeys) || !contBuf.alloc(CONT_CAP + 4)) { cdm_set_error("cdm_kmermatch: out of device memory for %llu received group tuples", (unsigned long long) nKeys); return CDM_ERR_HIP; }
+    if (nKeys) hipMemcpyAsync(recvB.p, devKeys, nKeys * 8, hipMemcpyDeviceToDevice, s);
+    if (int rc = sort2(recvB.p, nKeys, 0, 0, recvA.p, recvB.p, false)) return rc;
+    hipLaunchKernelGGL(k_head_segment, dim3(1), dim3(1), 0, s, sorted2M, (uint64_t) nGroupM, idBits, diagBits, contBuf.p);
+    uint64_t last = 0;
+    hipMemcpyAsync(head, contBuf.p, (CONT_CAP + 3) * 4, hipMemcpyDeviceToHost, s);
+    if (nGroupM) hipMemcpyAsync(&last, sorted2M + nGroupM - 1, 8, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: second half (sort) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    info[0] = nGroupM; info[1] = (last >> (diagBits + 1)) & ((1ull << idBits) - 1ull);
+    return CDM_OK;
+}
+// the vote: cont = what this rank's last scan runs into (VoteArgs::cont: count, target, into-the-left-overs flag, entries; NULL:
+// nothing behind this rank's tuples but the left-over list), staleIn = the combined left-over list
+int voteWith(const uint32_t *cont, const uint32_t *staleIn, cdm_hits **out) override {
     if (hipMemcpyAsync(staleBuf.p, staleIn, (STALE_MAX + 3) * 4, hipMemcpyHostToDevice, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: stale list upload failed"); return CDM_ERR_HIP; }
-    DevBuf<uint64_t> a, b;
-    if (!a.alloc(nKeys) || !b.alloc(nKeys)) { cdm_set_error("cdm_kmermatch: out of device memory for %llu received group tuples", (unsigned long long) nKeys); return CDM_ERR_HIP; }
-    if (nKeys) hipMemcpyAsync(b.p, devKeys, nKeys * 8, hipMemcpyDeviceToDevice, s);
-    return sort2Vote(b.p, nKeys, 0, 0, a.p, b.p, false, out);
+    if (cont) {
+        if (cont[0] > (uint32_t) CONT_CAP) { cdm_set_error("cdm_kmermatch: the scan of this rank's last target runs over more than %d tuples of the next ranks; not reproduced", CONT_CAP); return CDM_ERR_UNSUPPORTED; }
+        if (hipMemcpyAsync(contBuf.p, cont, (3 + (size_t) cont[0]) * 4, hipMemcpyHostToDevice, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: continuation list upload failed"); return CDM_ERR_HIP; }
+    }
+    return vote(cont ? contBuf.p : nullptr, false, out);
 }
 };
 
@@ -1570,11 +1627,17 @@ extern "C" int cdm_kpart_gather(cdm_ctx *ctx, cdm_kpart *h, int nranks, uint64_t
     *devKeys = h->job->gathered;
     return CDM_OK;
 }
-extern "C" int cdm_kpart_finish(cdm_ctx *ctx, cdm_kpart *h, const void *devKeys, uint64_t nKeys, const uint32_t *stale, cdm_hits **out) {
-    if (!out || !stale || (nKeys && !devKeys)) { cdm_set_error("cdm_kpart_finish: invalid argument"); return CDM_ERR_INVALID; }
+extern "C" int cdm_kpart_sort(cdm_ctx *ctx, cdm_kpart *h, const void *devKeys, uint64_t nKeys, uint32_t *head, uint64_t info[2]) {
+    if (!head || !info || (nKeys && !devKeys)) { cdm_set_error("cdm_kpart_sort: invalid argument"); return CDM_ERR_INVALID; }
     CDM_HIP(hipSetDevice(ctx->device));
-    return h->job->phaseBFrom((const uint64_t *) devKeys, nKeys, stale, out);
+    return h->job->sortFrom((const uint64_t *) devKeys, nKeys, head, info);
 }
+extern "C" int cdm_kpart_vote(cdm_ctx *ctx, cdm_kpart *h, const uint32_t *cont, const uint32_t *stale, cdm_hits **out) {
+    if (!out || !stale) { cdm_set_error("cdm_kpart_vote: invalid argument"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    return h->job->voteWith(cont, stale, out);
+}
+extern "C" int cdm_kpart_cont_cap(void) { return CONT_CAP; }
 extern "C" int cdm_dev_copy(cdm_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     CDM_HIP(hipSetDevice(ctx->device));
     if (bytes) CDM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));

@@ -8,7 +8,9 @@ Every rank holds the whole packed sequence DB.  Per iteration:
   3. ONE all-to-all moves every (rep, id, diagonal, strand) group key to the rank that owns its representative
      (representatives [r n/W, (r+1) n/W) belong to rank r); received slices are concatenated in rank = k-mer order, which is
      what keeps the reference's tie order
-  4. kmermatcher, second half (cdm_kpart_finish): hits of the owned representatives
+  4. kmermatcher, second half: sort 2 (cdm_kpart_sort), one more small all-gather (the heads of the sorted arrays: the
+     reference's per-target scan runs on into the next representative's tuples, i.e. across rank boundaries), then the vote
+     (cdm_kpart_vote): hits of the owned representatives
   5. rescorediagonal, ancient_correction on the owned queries (the other queries carry their self hit only); the corrected
      owned ranges are all-gathered so that every rank holds the corrected DB the extension stage looks targets up in
   6. ancient_read_assemble on the owned queries; the new owned ranges are all-gathered: every rank holds the next iteration's DB
@@ -67,6 +69,31 @@ def combine_stale(lists, holder):
     out[1] = target if target is not None else 0
     out[2:2 + cnt] = pos
     return out
+
+
+def build_cont(rank, counts, last_targets, heads):
+    """What the per-target scan of rank `rank`'s last segment runs into (VoteArgs::cont of csrc/kmermatch.hip): the heads of the
+    later ranks' sorted arrays while they carry the same target id and are consumed completely; [0] entries, [1] the target id,
+    [2] = 1 if the scan then reaches the left-over list, [3..] entries.  None: no tuples on this rank."""
+    if counts[rank] == 0:
+        return None
+    t = int(last_targets[rank])
+    entries, then_stale = [], 1
+    for p in range(rank + 1, len(counts)):
+        if counts[p] == 0:
+            continue
+        h = heads[p]
+        if int(h[1]) != t:
+            then_stale = 0
+            break
+        c = int(h[0])
+        if c > len(h) - 3:
+            raise RuntimeError("the scan of a rank's last target runs over more than %d tuples of the next rank; not reproduced" % (len(h) - 3))
+        entries.extend(int(x) for x in h[3:3 + c])
+        if not int(h[2]):
+            then_stale = 0
+            break
+    return np.array([len(entries), t, then_stale] + entries, np.uint32)
 
 
 def seq_section_layout(n, words):
@@ -192,7 +219,12 @@ def kmermatch_exact(ctx, db, comm, par=None):
         ctx.dev_copy(send.data_ptr(), ptr, kept * 8)
     recv = comm.exchange(send[:kept], off)                         # the all-to-all of the group keys
     torch.cuda.synchronize()
-    return part.finish(recv.data_ptr() if recv.numel() else None, recv.numel(), stale)
+    head, count, last_target = part.sort(recv.data_ptr() if recv.numel() else None, recv.numel())
+    # the reference's per-target scan does not stop at a representative's last tuple (kmermatcher.cpp:875-887): a rank's last scan
+    # runs into the next rank's first tuples, so the heads of the sorted arrays go round once more (a few KB per rank)
+    heads = comm.all_gather_array(np.concatenate([np.array([count, last_target], np.uint64), head.astype(np.uint64)]))
+    cont = build_cont(comm.rank, [int(h[0]) for h in heads], [int(h[1]) for h in heads], [h[2:].astype(np.uint32) for h in heads])
+    return part.vote(cont, stale)
 
 
 def pack_owned(ctx, db, lo, hi):

@@ -155,16 +155,25 @@ void cdm_hits_free(cdm_hits *h);
  *   cdm_kpart_gather     the group keys grouped by representative (k-mer order inside); offsets[r]..offsets[r+1] is the slice
  *                        for the rank that owns representatives [r n/nranks, (r+1) n/nranks); *dev_keys is a DEVICE pointer
  *                        owned by the handle (send buffer of the all-to-all)
- *   cdm_kpart_finish     second half (:431 sort 2, writeKmerMatcherResult :815-930) on the keys received from all ranks,
- *                        concatenated in rank order (device buffer): hits of the representatives this rank owns (every other
- *                        sequence gets its self hit only); stale = the combined left-over list (65 values as above)
+ *   cdm_kpart_sort       second half, sort 2 (:431), on the keys received from all ranks, concatenated in rank order (device
+ *                        buffer).  head (cdm_kpart_cont_cap() + 3 values): the start of the sorted array while the target id
+ *                        stays that of the first tuple - what the per-target scan of the rank in front runs into
+ *                        (head[0] count, head[1] that id, head[2] = 1 if it is the whole array, head[3..] entries);
+ *                        info[0] = sorted tuples, info[1] = target id of the last one
+ *   cdm_kpart_vote       writeKmerMatcherResult (:815-930): hits of the representatives this rank owns (every other sequence gets
+ *                        its self hit only).  cont: what this rank's last scan runs into, built from the later ranks' heads
+ *                        (cont[0] entries, cont[1] = this rank's last target id, cont[2] = 1 if the scan then goes on into the
+ *                        left-over list, cont[3..] entries; NULL = nothing but the left-over list behind this rank's tuples);
+ *                        stale = the combined left-over list (65 values as above)
  */
 typedef struct cdm_kpart cdm_kpart;
 int cdm_kmermatch_part(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int part, int nparts, cdm_kpart **out);
 int cdm_kpart_info(const cdm_kpart *h, uint64_t info[4]);
 int cdm_kpart_stale(cdm_ctx *ctx, cdm_kpart *h, uint64_t J, uint32_t out[67]);
 int cdm_kpart_gather(cdm_ctx *ctx, cdm_kpart *h, int nranks, uint64_t *offsets, const void **dev_keys);
-int cdm_kpart_finish(cdm_ctx *ctx, cdm_kpart *h, const void *dev_keys, uint64_t n_keys, const uint32_t *stale, cdm_hits **out);
+int cdm_kpart_sort(cdm_ctx *ctx, cdm_kpart *h, const void *dev_keys, uint64_t n_keys, uint32_t *head, uint64_t info[2]);
+int cdm_kpart_vote(cdm_ctx *ctx, cdm_kpart *h, const uint32_t *cont, const uint32_t *stale, cdm_hits **out);
+int cdm_kpart_cont_cap(void);
 void cdm_kpart_free(cdm_kpart *h);
 /* device-to-device copy on the context's stream (synchronises it): moves library-owned buffers into caller tensors */
 int cdm_dev_copy(cdm_ctx *ctx, void *dst, const void *src, uint64_t bytes);

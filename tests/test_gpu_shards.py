@@ -171,3 +171,25 @@ def test_exact_kmermatcher_on_small_databases(dhigh_prefix):
                 return shard.kmermatch_exact(c, c.upload_seqs(seqs), comm).download()
             off, rec = merged_hits(run_ranks(world, rank_fn), len(seqs))
             assert np.array_equal(off, want[0]) and np.array_equal(rec, want[1]), (case, world)
+
+
+def test_exact_scheme_over_rccl_with_one_rank(dhigh_prefix):
+    """The torch.distributed flavour of the collectives (TorchComm: all_to_all_single / all_gather over RCCL) on a one-rank group:
+    same result as the plain single-device calls."""
+    import os
+    import torch.distributed as dist
+    from carpedeam_amd import shard
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        c = capi.Ctx(0)
+        c.damage_load(dhigh_prefix)
+        db = c.synth(50_000, 100, 100, 9)
+        h, a, co, nx = shard.exact_iteration(c, db, shard.TorchComm(dist, 0, 1, torch.device("cuda", 0)))
+        h0 = c.kmermatch(db); a0 = c.rescore(db, h0); c0 = c.correct(db, a0); n0 = c.extend(c0, a0)
+        assert all(np.array_equal(x, y) for x, y in zip(h.download(), h0.download()))
+        for got, want in ((co.download(), c0.download()), (nx.download(), n0.download())):
+            assert [bytes(x) for x in got[0]] == [bytes(x) for x in want[0]] and np.array_equal(got[2], want[2])
+    finally:
+        dist.destroy_process_group()

@@ -81,3 +81,19 @@ def test_two_rank_exchange_keeps_rank_order():
         assert (recv == exp).all()
         assert [list(x) for x in g] == [[0, 1, 2], [10, 11, 12, 13]]
         assert [list(x) for x in a] == [[0, 2 ** 40], [1, 2 ** 40 + 1]]
+
+
+def test_build_cont_follows_the_scan_across_ranks():
+    cap = 8
+    def head(cnt, target, whole, entries):
+        a = np.zeros(cap + 3, np.uint32); a[0], a[1], a[2] = cnt, target, whole; a[3:3 + len(entries)] = entries
+        return a
+    heads = [head(1, 3, 0, [7]), head(2, 5, 1, [10, 11]), head(0, 0, 1, []), head(1, 5, 0, [12])]
+    counts, last = [4, 2, 0, 9], [5, 5, 0, 2]
+    # rank 0's last target 5: all of rank 1 (two tuples of target 5, the whole array), rank 2 is empty, one tuple of rank 3, then another target
+    assert list(shard.build_cont(0, counts, last, heads)) == [3, 5, 0, 10, 11, 12]
+    # rank 1's last target 5: rank 3's head, which is not its whole array -> the left-over list is not reached
+    assert list(shard.build_cont(1, counts, last, heads)) == [1, 5, 0, 12]
+    assert shard.build_cont(2, counts, last, heads) is None
+    assert list(shard.build_cont(3, counts, last, heads)) == [0, 2, 1]                 # nothing behind the last rank: on into the left-overs
+    assert list(shard.build_cont(0, [4, 0, 0, 9], [6, 0, 0, 2], heads)) == [0, 6, 0]   # next tuples have another target: the scan stops
