@@ -67,7 +67,7 @@ def build(verbose=False):
         srcs = [os.path.join(hostdir, f) for f in sorted(os.listdir(hostdir)) if f.endswith(".cpp") and f not in host_lib_srcs]
         if any(_newer(s, BIN, headers) for s in srcs) or _newer(LIB, BIN):
             cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-Wall", "-I" + os.path.join(os.path.dirname(HERE), "include"), "-o", BIN] + srcs + [
-                "-L" + HERE, "-lcarpedeam_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + HERE]
+                "-L" + HERE, "-lcarpedeam_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + HERE]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode:
                 sys.stderr.write(r.stdout + r.stderr)

@@ -17,11 +17,20 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <omp.h>
+#include <sys/stat.h>
 #include <string>
 #include <vector>
 
 #include "carpedeam_hip.h"
 #include "mmdb.h"
+
+// host/ingest.cpp
+bool readFastxAsDb(const std::vector<std::string> &files, bool shuffle, std::string &blob, std::vector<uint32_t> &key, std::vector<uint64_t> &off,
+                   std::vector<uint32_t> &len, std::string *err);
+int createdbModule(const std::vector<std::string> &files, const std::string &outPath, bool shuffle, std::string *err);
+int convert2fastaModule(const std::string &dbPath, const std::string &outPath, std::string *err);
+int createhdbModule(const std::string &seqPath, const std::string &cyclePath, const std::string &outPath, std::string *err);
 
 namespace {
 [[noreturn]] void die(const std::string &msg) { fprintf(stderr, "%s\n", msg.c_str()); exit(EXIT_FAILURE); }
@@ -91,20 +100,19 @@ cdm_seqdb *uploadSeqDb(cdm_ctx *ctx, const MmDb &db) {
     std::vector<uint32_t> lens(db.size());
     for (size_t i = 0; i < db.size(); i++) lens[i] = db.len[i] >= 2 ? (uint32_t) (db.len[i] - 2) : 0;   // DBReader::getSeqLen
     cdm_seqdb *h = NULL;
-    check(cdm_seqdb_upload(ctx, db.data.data(), db.off.data(), lens.data(), db.key.data(), db.ext.data(), db.size(), &h), "Can not load the sequence DB");
+    check(cdm_seqdb_upload(ctx, db.data(), db.off.data(), lens.data(), db.key.data(), db.ext.data(), db.size(), &h), "Can not load the sequence DB");
     return h;
 }
 void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) {
     const uint64_t n = cdm_seqdb_size(h);
     std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
     check(cdm_seqdb_meta(ctx, h, lens.data(), keys.data(), ext.data()), "meta");
-    std::vector<uint64_t> offs(n); uint64_t tot = 0;
-    for (uint64_t i = 0; i < n; i++) { offs[i] = tot; tot += lens[i] + 1; }
+    // the download buffer has the data file's layout already: "SEQ\n\0" per entry (the NULs are the buffer's zero fill)
+    std::vector<uint64_t> offs(n); std::vector<uint32_t> elen(n); uint64_t tot = 0;
+    for (uint64_t i = 0; i < n; i++) { offs[i] = tot; elen[i] = lens[i] + 2; tot += lens[i] + 2; }
     std::string buf(tot, '\0');
     check(cdm_seqdb_download(ctx, h, &buf[0], offs.data()), "download");
-    MmDbWriter w(path, dbtype);
-    for (uint64_t i = 0; i < n; i++) w.add(keys[i], buf.substr(offs[i], lens[i] + 1), ext[i]);
-    std::string err; if (!w.close(&err)) die(err);
+    std::string err; if (!mmdbWriteBlob(path, dbtype, buf.data(), buf.size(), keys, offs, elen, ext, &err)) die(err);
 }
 // ---- text codecs
 char *utoa(unsigned long long v, char *p) { char b[24]; int n = 0; do { b[n++] = '0' + v % 10; v /= 10; } while (v); while (n) *p++ = b[--n]; return p; }
@@ -116,13 +124,39 @@ char *seqIdText(float s, char *p) {   // Util::fastSeqIdToBuffer + the tab overw
     if (s < 0.01) *p++ = '0';
     return itoa((int) (s * 1000), p);
 }
+// contiguous slice [lo, hi) of n items for thread t of T
+inline void sliceOf(size_t n, int t, int T, size_t &lo, size_t &hi) { lo = n * (size_t) t / T; hi = n * (size_t) (t + 1) / T; }
+// concatenates the threads' record vectors (thread t holds the records of the queries of its slice, cnt[q] per query)
+template <typename R>
+void gatherParts(std::vector<std::vector<R>> &parts, const std::vector<uint32_t> &cnt, std::vector<uint64_t> &off, std::vector<R> &rec) {
+    const size_t n = cnt.size();
+    off.assign(n + 1, 0);
+    for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + cnt[i];
+    rec.resize(off[n]);
+    const int T = (int) parts.size();
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        size_t lo, hi; sliceOf(n, t, T, lo, hi);
+        if (!parts[t].empty()) memcpy(&rec[off[lo]], parts[t].data(), parts[t].size() * sizeof(R));
+        std::vector<R>().swap(parts[t]);
+    }
+}
 void parseAlnDb(const MmDb &aln, const MmDb &seq, std::vector<uint64_t> &off, std::vector<cdm_aln> &rec) {   // Matcher.cpp:274-353
-    off.assign(seq.size() + 1, 0);
     const double lam = 0x1.4478764a1b24ap-1, logk = log(0x1.a1c1e68ea2ab1p-2);
-    for (size_t i = 0; i < seq.size(); i++) {
-        const int64_t a = aln.idOf(seq.key[i]);
-        if (a >= 0) {
+    const int T = std::max(1, omp_get_max_threads());
+    std::vector<std::vector<cdm_aln>> parts(T); std::vector<uint32_t> cnt(seq.size(), 0);
+    long badKey = -1;
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        size_t lo, hi; sliceOf(seq.size(), t, T, lo, hi);
+        std::vector<cdm_aln> &out = parts[t];
+        for (size_t i = lo; i < hi; i++) {
+            const int64_t a = aln.idOf(seq.key[i]);
+            if (a < 0) continue;
             const char *d = aln.entry(a);
+            const size_t before = out.size();
             while (*d) {
                 char *e; cdm_aln r;
                 const uint32_t tkey = strtoul(d, &e, 10); d = e + 1;
@@ -131,17 +165,23 @@ void parseAlnDb(const MmDb &aln, const MmDb &seq, std::vector<uint64_t> &off, st
                 strtod(d, &e); d = e + 1;
                 r.q_start = strtol(d, &e, 10); d = e + 1; r.q_end = strtol(d, &e, 10); d = e + 1; strtol(d, &e, 10); d = e + 1;
                 r.db_start = strtol(d, &e, 10); d = e + 1; r.db_end = strtol(d, &e, 10); d = e + 1; strtol(d, &e, 10); d = e;
-                const int64_t t = seq.idOf(tkey);
-                if (t < 0) die("Invalid database read for key " + std::to_string(tkey));
-                r.target = (uint32_t) t; r.ident = -1;
+                const int64_t tt = seq.idOf(tkey);
+                if (tt < 0) {
+#pragma omp critical
+                    badKey = (long) tkey;
+                    break;
+                }
+                r.target = (uint32_t) tt; r.ident = -1;
                 r.raw_score = static_cast<int>((logk + bits * std::log(2.0)) / lam + 0.5);   // computeRawScoreFromBitScore as the consumers do
-                rec.push_back(r);
+                out.push_back(r);
                 while (*d && *d != '\n') d++;
                 if (*d == '\n') d++;
             }
+            cnt[i] = (uint32_t) (out.size() - before);
         }
-        off[i + 1] = rec.size();
     }
+    if (badKey >= 0) die("Invalid database read for key " + std::to_string(badKey));
+    gatherParts(parts, cnt, off, rec);
 }
 cdm_ancient_params ancientParams(Args &a) {
     cdm_ancient_params p;
@@ -166,18 +206,25 @@ int kmermatcher(Args &a) {
     check(cdm_kmermatch(ctx, db, &p, &hits), "kmermatcher");
     std::vector<uint64_t> off(seq.size() + 1); std::vector<cdm_hit> rec(cdm_hits_count(hits));
     check(cdm_hits_download(ctx, hits, off.data(), rec.data()), "download");
-    MmDbWriter w(a.pos[1], 14);   // DBTYPE_PREFILTER_REV_RES (kmermatcher.cpp:682)
-    char b[64];
-    for (size_t i = 0; i < seq.size(); i++) {
-        std::string out;
-        for (uint64_t h = off[i]; h < off[i + 1]; h++) {   // QueryMatcher::prefilterHitToBuffer
-            char *p2 = utoa(seq.key[rec[h].target], b); *p2++ = '\t'; p2 = itoa(rec[h].score, p2); *p2++ = '\t'; p2 = itoa((short) rec[h].diagonal, p2); *p2++ = '\n';
-            out.append(b, p2 - b);
+    const int T = std::max(1, omp_get_max_threads());
+    std::vector<OutChunk> chunks(T);
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        size_t lo, hi; sliceOf(seq.size(), t, T, lo, hi);
+        OutChunk &c = chunks[t];
+        std::string out; char b[64];
+        for (size_t i = lo; i < hi; i++) {
+            out.clear();
+            for (uint64_t h = off[i]; h < off[i + 1]; h++) {   // QueryMatcher::prefilterHitToBuffer
+                char *p2 = utoa(seq.key[rec[h].target], b); *p2++ = '\t'; p2 = itoa(rec[h].score, p2); *p2++ = '\t'; p2 = itoa((short) rec[h].diagonal, p2); *p2++ = '\n';
+                out.append(b, p2 - b);
+            }
+            // representatives' records carry wasExtended 0, fill-in records the sequence's flag (kmermatcher.cpp:727, DBWriter default)
+            c.add(seq.key[i], out.data(), out.size(), (off[i + 1] - off[i] > 1) ? 0 : seq.ext[i]);
         }
-        // representatives' records carry wasExtended 0, fill-in records the sequence's flag (kmermatcher.cpp:727, DBWriter default)
-        w.add(seq.key[i], std::move(out), (off[i + 1] - off[i] > 1) ? 0 : seq.ext[i]);
     }
-    if (!w.close(&err)) die(err);
+    if (!mmdbWriteChunks(a.pos[1], 14, chunks, &err)) die(err);   // DBTYPE_PREFILTER_REV_RES (kmermatcher.cpp:682)
     cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
@@ -190,22 +237,39 @@ int rescorediagonal(Args &a) {
     MmDb seq, pref; std::string err; if (!seq.load(a.pos[1], &err) || !pref.load(a.pos[2], &err)) die(err);
     cdm_ctx *ctx = openCtx();
     cdm_seqdb *db = uploadSeqDb(ctx, seq);
-    std::vector<uint64_t> off(seq.size() + 1, 0); std::vector<cdm_hit> rec;
-    for (size_t i = 0; i < seq.size(); i++) {   // QueryMatcher::parsePrefilterHits
-        const int64_t pi = pref.idOf(seq.key[i]);
-        if (pi >= 0) {
-            const char *d = pref.entry(pi);
-            while (*d) {
-                char *e; cdm_hit h;
-                const uint32_t tkey = strtoul(d, &e, 10); d = e + 1; h.score = strtol(d, &e, 10); d = e + 1; h.diagonal = (short) strtol(d, &e, 10); d = e;
-                const int64_t t = seq.idOf(tkey);
-                if (t < 0) die("Invalid database read for key " + std::to_string(tkey));
-                h.target = (uint32_t) t; rec.push_back(h);
-                while (*d && *d != '\n') d++;
-                if (*d == '\n') d++;
+    std::vector<uint64_t> off; std::vector<cdm_hit> rec;
+    const int T = std::max(1, omp_get_max_threads());
+    {
+        std::vector<std::vector<cdm_hit>> parts(T); std::vector<uint32_t> cnt(seq.size(), 0);
+        long badKey = -1;
+#pragma omp parallel num_threads(T)
+        {
+            const int t = omp_get_thread_num();
+            size_t lo, hi; sliceOf(seq.size(), t, T, lo, hi);
+            std::vector<cdm_hit> &out = parts[t];
+            for (size_t i = lo; i < hi; i++) {   // QueryMatcher::parsePrefilterHits
+                const int64_t pi = pref.idOf(seq.key[i]);
+                if (pi < 0) continue;
+                const char *d = pref.entry(pi);
+                const size_t before = out.size();
+                while (*d) {
+                    char *e; cdm_hit h;
+                    const uint32_t tkey = strtoul(d, &e, 10); d = e + 1; h.score = strtol(d, &e, 10); d = e + 1; h.diagonal = (short) strtol(d, &e, 10); d = e;
+                    const int64_t tt = seq.idOf(tkey);
+                    if (tt < 0) {
+#pragma omp critical
+                        badKey = (long) tkey;
+                        break;
+                    }
+                    h.target = (uint32_t) tt; out.push_back(h);
+                    while (*d && *d != '\n') d++;
+                    if (*d == '\n') d++;
+                }
+                cnt[i] = (uint32_t) (out.size() - before);
             }
         }
-        off[i + 1] = rec.size();
+        if (badKey >= 0) die("Invalid database read for key " + std::to_string(badKey));
+        gatherParts(parts, cnt, off, rec);
     }
     cdm_hits *hits = NULL; cdm_alns *alns = NULL;
     check(cdm_hits_upload(ctx, db, off.data(), rec.data(), &hits), "upload");
@@ -216,27 +280,33 @@ int rescorediagonal(Args &a) {
     std::vector<uint64_t> aoff(seq.size() + 1); std::vector<cdm_aln> arec(cdm_alns_count(alns));
     check(cdm_alns_download(ctx, alns, aoff.data(), arec.data()), "download");
     const uint64_t dbRes = cdm_seqdb_residues(db);
-    MmDbWriter w(a.pos[3], 5);
-    char b[256];
-    for (size_t i = 0; i < seq.size(); i++) {
-        if (pref.idOf(seq.key[i]) < 0) continue;
-        std::string out;
-        const int qLen = (int) (seq.len[i] - 2);
-        for (uint64_t r = aoff[i]; r < aoff[i + 1]; r++) {   // Matcher::resultToBuffer (Matcher.cpp:356-404)
-            const cdm_aln &x = arec[r];
-            const int alnLen = std::max(abs(x.q_end - x.q_start), abs(x.db_end - x.db_start)) + 1;
-            const float sid = static_cast<float>(x.ident) / static_cast<float>(alnLen);
-            char *p2 = utoa(seq.key[x.target], b); *p2++ = '\t';
-            p2 = itoa(cdm_bit_score(x.raw_score), p2); *p2++ = '\t';
-            p2 = seqIdText(sid, p2); *p2++ = '\t';
-            p2 += sprintf(p2, "%.3E", cdm_evalue(x.raw_score, qLen, dbRes)); *p2++ = '\t';
-            p2 = itoa(x.q_start, p2); *p2++ = '\t'; p2 = itoa(x.q_end, p2); *p2++ = '\t'; p2 = itoa(qLen, p2); *p2++ = '\t';
-            p2 = itoa(x.db_start, p2); *p2++ = '\t'; p2 = itoa(x.db_end, p2); *p2++ = '\t'; p2 = itoa((int) (seq.len[x.target] - 2), p2); *p2++ = '\n';
-            out.append(b, p2 - b);
+    std::vector<OutChunk> chunks(T);
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        size_t lo, hi; sliceOf(seq.size(), t, T, lo, hi);
+        OutChunk &c = chunks[t];
+        std::string out; char b[256];
+        for (size_t i = lo; i < hi; i++) {
+            if (pref.idOf(seq.key[i]) < 0) continue;
+            out.clear();
+            const int qLen = (int) (seq.len[i] - 2);
+            for (uint64_t r = aoff[i]; r < aoff[i + 1]; r++) {   // Matcher::resultToBuffer (Matcher.cpp:356-404)
+                const cdm_aln &x = arec[r];
+                const int alnLen = std::max(abs(x.q_end - x.q_start), abs(x.db_end - x.db_start)) + 1;
+                const float sid = static_cast<float>(x.ident) / static_cast<float>(alnLen);
+                char *p2 = utoa(seq.key[x.target], b); *p2++ = '\t';
+                p2 = itoa(cdm_bit_score(x.raw_score), p2); *p2++ = '\t';
+                p2 = seqIdText(sid, p2); *p2++ = '\t';
+                p2 += sprintf(p2, "%.3E", cdm_evalue(x.raw_score, qLen, dbRes)); *p2++ = '\t';
+                p2 = itoa(x.q_start, p2); *p2++ = '\t'; p2 = itoa(x.q_end, p2); *p2++ = '\t'; p2 = itoa(qLen, p2); *p2++ = '\t';
+                p2 = itoa(x.db_start, p2); *p2++ = '\t'; p2 = itoa(x.db_end, p2); *p2++ = '\t'; p2 = itoa((int) (seq.len[x.target] - 2), p2); *p2++ = '\n';
+                out.append(b, p2 - b);
+            }
+            c.add(seq.key[i], out.data(), out.size(), 0);
         }
-        w.add(seq.key[i], std::move(out), 0);
     }
-    if (!w.close(&err)) die(err);
+    if (!mmdbWriteChunks(a.pos[3], 5, chunks, &err)) die(err);
     cdm_alns_free(alns); cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
@@ -268,13 +338,28 @@ int readsLoop(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam ancient_reads_loop <i:sequenceDB> <o:sequenceDB> --ancient-damage <prefix> [--num-iter-reads-only N]");
     {   // the workflow's own flags for the reads loop (src/commons/LocalParameters.h:283-318) on top of the stage lists
         static const char *const LOOP_FLAGS[] = {"--k-ancient-reads", "--kmer-per-seq-ancient", "--kmer-per-seq-scale-ancient", "--hash-shift", "--include-only-extendable-ancient-reads",
-                                                 "-e", "--num-iter-reads-only", NULL};
+                                                 "-e", "--num-iter-reads-only", "--shuffle", NULL};
         checkFlags("ancient_reads_loop", a, ANCIENT_FLAGS, LOOP_FLAGS);
     }
-    MmDb seq; std::string err; if (!seq.load(a.pos[0], &err)) die(err);
-    cdm_ctx *ctx = openCtx();
+    // input: a sequence DB, or - when there is no <input>.index - FASTA/FASTQ[.gz] reads, parsed and laid out as createdb would
+    // (createdb.cpp:150-280, --shuffle 1 by default) and uploaded without a DB on disk in between
+    MmDb seq; std::string err;
+    int dbtype = 1;
+    cdm_ctx *ctx = NULL; cdm_seqdb *db = NULL;
+    struct stat st;
+    if (stat((a.pos[0] + ".index").c_str(), &st) == 0) {
+        if (!seq.load(a.pos[0], &err)) die(err);
+        dbtype = seq.dbtype;
+        ctx = openCtx();
+        db = uploadSeqDb(ctx, seq);
+    } else {
+        std::string blob; std::vector<uint32_t> key, len; std::vector<uint64_t> off;
+        if (!readFastxAsDb(std::vector<std::string>(1, a.pos[0]), iflag(a, "--shuffle", 1) != 0, blob, key, off, len, &err)) die(err);
+        for (auto &l : len) l -= 2;
+        ctx = openCtx();
+        check(cdm_seqdb_upload(ctx, blob.data(), off.data(), len.data(), key.data(), NULL, key.size(), &db), "Can not load the reads");
+    }
     check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");
-    cdm_seqdb *db = uploadSeqDb(ctx, seq);
     cdm_kmer_params kp;
     kp.kmer_size = (int) iflag(a, "--k-ancient-reads", 20); kp.kmers_per_seq = (int) iflag(a, "--kmer-per-seq-ancient", 200);
     kp.kmers_per_seq_scale = fflag(a, "--kmer-per-seq-scale-ancient", 0.2f); kp.hash_shift = (uint64_t) iflag(a, "--hash-shift", 67);
@@ -297,16 +382,52 @@ int readsLoop(Args &a) {
         cdm_alns_free(alns); cdm_seqdb_free(corr); cdm_seqdb_free(db);
         db = next;
     }
-    writeSeqDb(ctx, db, a.pos[1], seq.dbtype);
+    writeSeqDb(ctx, db, a.pos[1], dbtype);
     cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
 }  // namespace
 
+namespace {
+const FlagSpec CREATEDB_FLAGS[] = {   // Parameters.cpp:733-737 createdb
+    {"--shuffle", 'U', 0, 0}, {"--dbtype", 'V', "2", "nucleotide input only (0 = auto is not implemented)"}, {"--createdb-mode", 'V', "0", "only the copying mode"},
+    {"--write-lookup", 'V', "1", "the .lookup file is always written"}, {"--id-offset", 'V', "0", "not implemented"}, {"--compressed", 'V', "0", "compressed DBs are not implemented"},
+    {"-v", 'N', 0, 0}, {"--threads", 'N', 0, 0}, {0, 0, 0, 0}};
+const FlagSpec PLAIN_FLAGS[] = {{"-v", 'N', 0, 0}, {"--threads", 'N', 0, 0}, {"--compressed", 'V', "0", "compressed DBs are not implemented"}, {"--use-fasta-header", 'V', "0", "not implemented"}, {0, 0, 0, 0}};
+int createdb(Args &a) {
+    if (a.pos.size() < 2) die("Usage: carpedeam createdb <i:fastaFile1[.gz]> ... <i:fastaFileN[.gz]> <o:sequenceDB>");
+    checkFlags("createdb", a, CREATEDB_FLAGS);
+    std::vector<std::string> files(a.pos.begin(), a.pos.end() - 1);
+    std::string err;
+    if (createdbModule(files, a.pos.back(), iflag(a, "--shuffle", 1) != 0, &err)) die(err);
+    return EXIT_SUCCESS;
+}
+int convert2fasta(Args &a) {
+    if (a.pos.size() < 2) die("Usage: carpedeam convert2fasta <i:sequenceDB> <o:fastaFile>");
+    checkFlags("convert2fasta", a, PLAIN_FLAGS);
+    std::string err;
+    if (convert2fastaModule(a.pos[0], a.pos[1], &err)) die(err);
+    return EXIT_SUCCESS;
+}
+int createhdb(Args &a) {
+    if (a.pos.size() < 2) die("Usage: carpedeam createhdb <i:sequenceDB> [<i:sequenceDBcycle>] <o:headerDB>");
+    checkFlags("createhdb", a, PLAIN_FLAGS);
+    std::string err;
+    if (createhdbModule(a.pos[0], a.pos.size() > 2 ? a.pos[1] : "", a.pos.back(), &err)) die(err);
+    return EXIT_SUCCESS;
+}
+}  // namespace
+
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: carpedeam <kmermatcher|rescorediagonal|ancient_correction|ancient_read_assemble|ancient_reads_loop> <args>\n"); return EXIT_FAILURE; }
+    if (argc < 2) { fprintf(stderr, "usage: carpedeam <kmermatcher|rescorediagonal|ancient_correction|ancient_read_assemble|ancient_reads_loop|createdb|convert2fasta|createhdb> <args>\n"); return EXIT_FAILURE; }
     const std::string cmd = argv[1];
     Args a = parse(argc - 2, argv + 2);
+    {   // --threads / MMSEQS_NUM_THREADS as in Parameters.cpp:2121-2132: the host side (DB parsing, text codecs) uses them
+        long th = a.flag.count("--threads") ? strtol(a.flag["--threads"].c_str(), NULL, 10) : 0;
+        if (th <= 0) if (const char *e = getenv("MMSEQS_NUM_THREADS")) th = strtol(e, NULL, 10);
+        omp_set_dynamic(0);      // every slice of the per-thread loops below has its thread
+        if (th > 0) omp_set_num_threads((int) th);
+    }
     auto t0 = std::chrono::steady_clock::now();
     int rc;
     if (cmd == "kmermatcher") rc = kmermatcher(a);
@@ -314,6 +435,9 @@ int main(int argc, char **argv) {
     else if (cmd == "ancient_correction") rc = ancientModule(a, false);
     else if (cmd == "ancient_read_assemble") rc = ancientModule(a, true);
     else if (cmd == "ancient_reads_loop") rc = readsLoop(a);
+    else if (cmd == "createdb") rc = createdb(a);
+    else if (cmd == "convert2fasta") rc = convert2fasta(a);
+    else if (cmd == "createhdb") rc = createhdb(a);
     else { fprintf(stderr, "Invalid Command: %s\n", cmd.c_str()); return EXIT_FAILURE; }
     fprintf(stderr, "Time for processing: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return rc;

@@ -27,6 +27,9 @@
 // lib/mmseqs/src/CommandDeclarations.h:57,86 (that header also declares `map`, which clashes with libgab's `using namespace std`)
 extern int kmermatcher(int argc, const char **argv, const Command &command);
 extern int rescorediagonal(int argc, const char **argv, const Command &command);
+// lib/mmseqs/src/CommandDeclarations.h:33,29 - the steps either side of the hot path
+extern int createdb(int argc, const char **argv, const Command &command);
+extern int convert2fasta(int argc, const char **argv, const Command &command);
 
 const char* binary_name = "carpedeam_ref";
 const char* tool_name = "CarpeDeam (reference objects, oracle driver)";
@@ -55,6 +58,17 @@ std::vector<struct Command> commands = {
 };
 
 std::vector<struct Command> baseCommands = {
+    {"createdb", createdb, &localPar.createdb, COMMAND_DATABASE_CREATION, "", NULL, "", "<i:fastaFile1[.gz]> ... <o:sequenceDB>", 0,
+        {{"fast[a|q]File[.gz|bz2]|stdin", DbType::ACCESS_MODE_INPUT, DbType::NEED_DATA | DbType::VARIADIC, &DbValidator::flatfileStdinAndGeneric},
+         {"sequenceDB", DbType::ACCESS_MODE_OUTPUT, DbType::NEED_DATA, &DbValidator::flatfile}}},
+    {"convert2fasta", convert2fasta, &localPar.convert2fasta, COMMAND_FORMAT_CONVERSION, "", NULL, "", "<i:sequenceDB> <o:fastaFile>", 0,
+        {{"sequenceDB", DbType::ACCESS_MODE_INPUT, DbType::NEED_DATA | DbType::NEED_HEADER, &DbValidator::allDb},
+         {"fastaFile", DbType::ACCESS_MODE_OUTPUT, DbType::NEED_DATA, &DbValidator::flatfile}}},
+    {"createhdb", createhdb, &localPar.createhdb, COMMAND_HIDDEN, "", NULL, "", "<i:sequenceDB> [<i:sequenceDBcycle>] <o:headerDB>", 0,
+        {{"sequenceDB", DbType::ACCESS_MODE_INPUT, DbType::NEED_DATA, NULL}}},
+    {"cyclecheck", cyclecheck, &localPar.cyclecheck, COMMAND_HIDDEN, "", NULL, "", "<i:sequenceDB> <o:sequenceDBcycle>", 0,
+        {{"sequenceDB", DbType::ACCESS_MODE_INPUT, DbType::NEED_DATA, &DbValidator::nuclDb},
+         {"cycleResult", DbType::ACCESS_MODE_OUTPUT, DbType::NEED_DATA, &DbValidator::nuclDb}}},
     {"kmermatcher", kmermatcher, &localPar.kmermatcher, COMMAND_PREFILTER, "", NULL, "", "<i:sequenceDB> <o:prefilterDB>", 0,
         {{"sequenceDB", DbType::ACCESS_MODE_INPUT, DbType::NEED_DATA, &DbValidator::sequenceDb},
          {"prefilterDB", DbType::ACCESS_MODE_OUTPUT, DbType::NEED_DATA, &DbValidator::prefilterDb}}},

@@ -170,5 +170,44 @@ def main():
         chain(tmp, "example", seqs, 1, prefix, 4)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "createdb"):
     main()
+
+
+def createdb_digests():
+    """tests/golden/example/createdb_digests.json: sha256 of what the reference's createdb / createhdb / convert2fasta write for
+    the inputs tests/test_ingest.py builds (run separately: python tests/golden/make_golden.py createdb)"""
+    import gzip as gz
+    import hashlib
+    import json
+    import pathlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_ingest as T
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        d = pathlib.Path(d)
+        fq, seqs = T.example_fastq(d)
+        fa = T.tricky_fasta(d)
+        second = str(d / "second.fq.gz")
+        with gz.open(second, "wt") as f:
+            for i, s in enumerate(seqs[:100]):
+                f.write("@gz_%d\n%s\n+\n%s\n" % (i, s, "#" * len(s)))
+        for sh in ("1", "0"):
+            T.run(T.REF, "createdb", fq, fa, second, str(d / ("ref" + sh)), "--shuffle", sh, "-v", "0")
+            out["shuffle" + sh] = {ext: T.digest(str(d / ("ref" + sh)) + ext) for ext in T.DB_FILES}
+        T.run(T.REF, "createdb", fq, str(d / "db"), "--shuffle", "1", "-v", "0")
+        T.run(T.REF, "convert2fasta", str(d / "db"), str(d / "mine.fasta"), "-v", "0")
+        mmdb.write_seqdb(str(d / "asm"), seqs[:50])
+        mmdb.write_db(str(d / "cyc"), [(3, b"x\n"), (17, b"y\n")], mmdb.DBTYPE_NUCLEOTIDES)
+        T.run(T.REF, "createhdb", str(d / "asm"), str(d / "asm"), "-v", "0")
+        T.run(T.REF, "convert2fasta", str(d / "asm"), str(d / "asm.fasta"), "-v", "0")
+        fasta = {"mine.fasta": T.digest(str(d / "mine.fasta")), "asm.fasta": T.digest(str(d / "asm.fasta"))}
+        T.run(T.REF, "createhdb", str(d / "asm"), str(d / "cyc"), str(d / "asm"), "-v", "0")
+        T.run(T.REF, "convert2fasta", str(d / "asm"), str(d / "asm_cyc.fasta"), "-v", "0")
+        fasta.update({"asm_cyc.fasta": T.digest(str(d / "asm_cyc.fasta")), "asm_h": T.digest(str(d / "asm_h")), "asm_h.index": T.digest(str(d / "asm_h.index"))})
+        out["fasta"] = fasta
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "example", "createdb_digests.json"), "w"), indent=1)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "createdb":
+    createdb_digests()

@@ -77,3 +77,24 @@ def test_fused_reads_loop_equals_stage_by_stage(tmp_path, dhigh_prefix, oracle_b
     want = mmdb.read_db(cur)
     assert not diff_keys(got, want)
     assert diff_keys(got, gold("mixed3k", "asm", 2)) == diff_keys(want, gold("mixed3k", "asm", 2))
+
+
+def test_reads_loop_takes_fastq(tmp_path, dhigh_prefix):
+    """`ancient_reads_loop <reads.fq>`: FASTQ parsed on the host straight into the upload (no sequence DB on disk), laid out
+    as createdb would - same result as createdb + the loop on the DB."""
+    import gzip
+    from carpedeam_amd import build
+    build.build()
+    t = lambda s: str(tmp_path / s)
+    reads = gold("synth2k", "reads")
+    with gzip.open(t("r.fq.gz"), "wt") as f:
+        for k in sorted(reads):
+            s = reads[k][0].decode().strip()
+            f.write("@r%d\n%s\n+\n%s\n" % (k, s, "F" * len(s)))
+    run("createdb", t("r.fq.gz"), t("db"))
+    run("ancient_reads_loop", t("db"), t("out_db"), "--ancient-damage", dhigh_prefix, "--num-iter-reads-only", "2")
+    run("ancient_reads_loop", t("r.fq.gz"), t("out_fq"), "--ancient-damage", dhigh_prefix, "--num-iter-reads-only", "2")
+    assert not diff_keys(mmdb.read_db(t("out_fq")), mmdb.read_db(t("out_db")))
+    run("createhdb", t("out_fq"), t("out_fq"))
+    run("convert2fasta", t("out_fq"), t("out.fasta"))
+    assert open(t("out.fasta")).read().count(">") == len(reads)
