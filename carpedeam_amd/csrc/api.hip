@@ -588,7 +588,6 @@ extern "C" int cdm_kmermatch(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_p
 extern "C" int cdm_extend(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out, double *scores) {
     if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_extend: NULL argument"); return CDM_ERR_INVALID; }
     if (!ctx->haveDamage) { cdm_set_error("cdm_extend: call cdm_damage_load first"); return CDM_ERR_INVALID; }
-    if (par->unsafe) { cdm_set_error("cdm_extend: --unsafe 1 (consensus mode) is not implemented on the device path"); return CDM_ERR_UNSUPPORTED; }
     CDM_HIP(hipSetDevice(ctx->device));
     hipEventRecord(ctx->evS0, ctx->stream);
     const int rc = cdm_extend_impl(ctx, db, alns, par, out, scores);

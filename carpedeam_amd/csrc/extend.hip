@@ -50,6 +50,8 @@ struct ExtArgs {
     float excessLog, randLog;   // logf(excessPenal), logf(randAlnPenal) from the host
     double ratioLogit;          // log(1/thr - 1): sRatio > thr  <=>  randAln - likMod < ratioLogit
     uint64_t maxSeqLen;
+    int unsafe; uint32_t minCov;        // --unsafe 1: consensusCaller's majority vote over the extending targets (--min-cov-safe)
+    unsigned int *flags;                // [0] set when an unsafe-mode consensus would write outside its 3 qLen letters (undefined in the reference)
 };
 
 // ---- the query as it grows: pieces to the left (most recent first), the original, pieces to the right
@@ -94,6 +96,42 @@ __device__ __forceinline__ void targetBaseAt(const ExtArgs &A, uint32_t t, uint3
     isN = A.hasN[t] && cdm_isN(A.nmask, w, p);
 }
 
+// ---- consensusCaller, unsafe mode (nuclassembleUtil.cpp:570-702 + calculateConsensus :535-567).  The consensus has 3 qLen
+// letters: the query in the middle third; elsewhere the majority letter of the alignments that extend the query and cover the
+// position, where at least minCov of them do (uncovered, below the coverage and tied positions are 'N').  The letter is worked
+// out on demand from the list consensusCaller was called with (all candidates at first, the re-aligned parked hits later):
+// the mode is not the default and a pile-up is a handful of records.
+struct ConsList { const Cand *cand; const uint32_t *idx; uint32_t n; uint32_t qKey; };
+__device__ void consensusAt(const ExtArgs &A, const VQuery &Q, const ConsList &L, uint32_t x, uint32_t &code, bool &isN) {
+    const uint32_t qLen = Q.total;
+    if (x >= qLen && x < 2 * qLen) { Q.baseAt(x - qLen, code, isN); return; }
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < L.n; i++) {
+        const Cand &c = L.cand[L.idx ? L.idx[i] : i];
+        const bool rs = c.ds == 0 && (c.de != static_cast<int>(c.dbLen) - 1), ls = c.qs == 0 && (c.qe != static_cast<int>(c.qLen) - 1);
+        if (!(rs || ls) || A.key[c.target] == L.qKey) continue;
+        const uint32_t tLen = A.len[c.target];
+        long long start;
+        if (c.ds == 0 && (uint32_t) c.qe == qLen - 1) start = (long long) qLen + c.qs;                                  // right extension
+        else if (c.qs == 0 && (uint32_t) c.de == tLen - 1) start = (long long) qLen - (long long) (c.dbLen - c.alnLen);   // left extension
+        else continue;
+        // (a target that reaches beyond the 3 qLen letters makes the reference write outside its coverage vector - undefined, but
+        // never read back: only positions inside the consensus are looked at, here as there)
+        if ((long long) x < start || (long long) x >= start + (long long) c.dbLen) continue;
+        uint32_t tc; bool tn;
+        targetBaseAt(A, c.target, (uint32_t) ((long long) x - start), tc, tn);
+        cnt[tn ? 0u : tc]++;                        // nucleotideMap[c]: any letter outside ACGT counts as 'A'
+    }
+    code = 0; isN = true;
+    if (cnt[0] + cnt[1] + cnt[2] + cnt[3] < A.minCov) return;
+    uint32_t mx = 0; int nMax = 0;
+    for (uint32_t j = 0; j < 4; j++) {
+        if (cnt[j] > mx) { mx = cnt[j]; code = j; nMax = 1; } else if (cnt[j] == mx && mx > 0) nMax++;
+    }
+    isN = nMax != 1;
+    if (isN) code = 0;
+}
+
 // identical / same-RY-class columns of q[q0..q0+n) vs t[t0..t0+n), 16 bases per XOR (neither sequence has an N)
 __device__ __forceinline__ void countMatchesWords(const ExtArgs &A, uint32_t q, uint32_t q0, uint32_t t, uint32_t t0, uint32_t n, int &idCnt, int &idRy) {
     const uint32_t qw = A.woff[q], tw = A.woff[t];
@@ -110,11 +148,26 @@ __device__ __forceinline__ void countMatchesWords(const ExtArgs &A, uint32_t q, 
 }
 
 // updateSeqIdConsensusReads for one candidate on the current query (nuclassembleUtil.cpp:377-500, safe-mode consensus)
-__device__ void updateIds(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t &maxLeft, uint32_t &maxRight) {
+__device__ void updateIds(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t &maxLeft, uint32_t &maxRight, const ConsList *cons = nullptr) {
     const uint32_t qLen = Q.total;
     const bool rightStart = (uint32_t) c.ds == 0 && (uint32_t) c.qe == (qLen - 1);
     const bool leftStart = (uint32_t) c.qs == 0 && (uint32_t) c.de == (c.dbLen - 1);
     int idCnt = 0, idRy = 0; uint32_t tot = 0;
+    if (cons && (leftStart || rightStart)) {
+        // unsafe mode: the padded target against the whole consensus, overhang included (:389-437); target letter j sits at
+        // consensus index c0 + j
+        const uint32_t offset = c.dbLen - c.alnLen;
+        if (offset > qLen) A.flags[0] = 1u;         // the reference pads with qLen - offset letters: undefined
+        else {
+            const uint32_t c0 = leftStart ? (qLen - offset) : (2 * qLen - c.alnLen);
+            for (uint32_t j = 0; j < c.dbLen && c0 + j < 3 * qLen; j++) {
+                uint32_t qc, tc; bool qn, tn;
+                consensusAt(A, Q, *cons, c0 + j, qc, qn); targetBaseAt(A, c.target, j, tc, tn);
+                if (qn || tn) continue;
+                idCnt += (qc == tc); idRy += ((qc & 1u) == (tc & 1u)); tot++;
+            }
+        }
+    } else
     if (leftStart || rightStart) {
         // padded target against N^L query N^L: the columns where both are defined are the overlap itself
         const uint32_t offset = c.dbLen - c.alnLen;
@@ -135,7 +188,8 @@ __device__ void updateIds(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t &
 }
 
 // calcLikelihoodConsensus via r_s_pair; returns sRatio > threshold, sets c.sLenNorm
-__device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t maxLeft, uint32_t maxRight, const double *logLik /* [11][4][4] fwd */) {
+__device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t maxLeft, uint32_t maxRight, const double *logLik /* [11][4][4] fwd */,
+                          const ConsList *cons = nullptr) {
     const uint32_t qLen = Q.total;
     uint32_t maxAln = maxRight;
     if ((uint32_t) c.qs == 0 && (uint32_t) c.de == (c.dbLen - 1)) maxAln = maxLeft;
@@ -143,6 +197,27 @@ __device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t m
     const bool leftStart = (uint32_t) c.qs == 0 && (uint32_t) c.de == (c.dbLen - 1);
     X87 lik = x87_zero();
     uint32_t alnCount = 0;
+    if (cons && (leftStart || rightStart)) {
+        // unsafe mode: every target letter against the consensus letter above it (:225-330), flanks included
+        const uint32_t offset = c.dbLen - c.alnLen;
+        if (offset > qLen) A.flags[0] = 1u;
+        else {
+            const uint32_t c0 = leftStart ? (qLen - offset) : (2 * qLen - c.alnLen);
+            uint32_t tIdx = 0;
+            for (uint32_t j = 0; j < c.dbLen && c0 + j < 3 * qLen; j++) {
+                uint32_t qc, tc; bool qn, tn;
+                targetBaseAt(A, c.target, j, tc, tn);
+                if (!tn) tIdx++;
+                if (tn) continue;
+                consensusAt(A, Q, *cons, c0 + j, qc, qn);
+                if (qn) continue;
+                alnCount++;
+                const uint32_t ti = tIdx - 1;
+                const uint32_t cls = ti < 5 ? ti : (ti >= c.dbLen - 5 ? 6 + (ti - (c.dbLen - 5)) : 5);
+                lik = x87_add(lik, x87_from_double(logLik[(cls * 4 + qc) * 4 + tc]));
+            }
+        }
+    } else
     if (leftStart || rightStart) {
         const uint32_t offset = c.dbLen - c.alnLen;
         uint32_t q0, t0, ncol;
@@ -265,9 +340,12 @@ __global__ __launch_bounds__(64) void k_extend(ExtArgs A) {
     }
     if (nCand == 0) { A.newLen[q] = 0; return; }
     uint32_t maxLeft = 0, maxRight = 0;
+    ConsList consAll; consAll.cand = cand; consAll.idx = nullptr; consAll.n = nCand; consAll.qKey = qKey;
+    const ConsList *cons0 = A.unsafe ? &consAll : nullptr;
     for (uint32_t k = 0; k < nCand; k++) {
         Cand &c = cand[k];
-        if (Q.plain && !A.hasN[c.target] && c.target != qKey) {      // (the candidate pass compares the target id with the query key)
+        if (A.unsafe) updateIds(A, Q, c, maxLeft, maxRight, cons0);
+        else if (Q.plain && !A.hasN[c.target] && c.target != qKey) {      // (the candidate pass compares the target id with the query key)
             // updateSeqIdConsensusReads would count the very columns the candidate pass above just counted (an end overlap of
             // two sequences without N): seqId / rySeqId stand, only the longest overlap per side is updated
             const bool rightStart = (uint32_t) c.ds == 0 && (uint32_t) c.qe == (qLen0 - 1);
@@ -284,7 +362,7 @@ __global__ __launch_bounds__(64) void k_extend(ExtArgs A) {
         const bool notInside = c.dbLen != c.alnLen;
         const bool rightStart = c.ds == 0, leftStart = c.qs == 0, notId = A.key[c.target] != qKey;
         if ((rightStart || leftStart) && notInside && notId && c.rySeqId >= A.rySeqIdThr && c.seqId >= A.seqIdThr) {
-            const bool pass = scoreCand(A, Q, c, maxLeft, maxRight, sLogLik);
+            const bool pass = scoreCand(A, Q, c, maxLeft, maxRight, sLogLik, cons0);
             if (A.scores) A.scores[r0 + c.pieceStart] = c.sLenNorm;
             if (pass) heap.push(k);
         }
@@ -363,13 +441,15 @@ __global__ __launch_bounds__(64) void k_extend(ExtArgs A) {
             (void) score;
             c.qs = qs2; c.qe = qe2; c.ds = ds2; c.de = de2;
         }
-        for (uint32_t i = 0; i < nPark; i++) updateIds(A, Q, cand[parkL[i]], maxLeft, maxRight);
+        ConsList consPark; consPark.cand = cand; consPark.idx = parkL; consPark.n = nPark; consPark.qKey = qKey;
+        const ConsList *cons1 = A.unsafe ? &consPark : nullptr;
+        for (uint32_t i = 0; i < nPark; i++) updateIds(A, Q, cand[parkL[i]], maxLeft, maxRight, cons1);
         for (uint32_t i = 0; i < nPark; i++) {
             Cand &c = cand[parkL[i]];
             const bool notInside = c.dbLen != c.alnLen;
             const bool rightStart = c.ds == 0, leftStart = c.qs == 0, notId = A.key[c.target] != qKey;
             if (c.seqId >= A.seqIdThr && (rightStart || leftStart) && notId && notInside) {
-                if (scoreCand(A, Q, c, maxLeft, maxRight, sLogLik)) heap.push(parkL[i]);
+                if (scoreCand(A, Q, c, maxLeft, maxRight, sLogLik, cons1)) heap.push(parkL[i]);
             }
         }
     }
@@ -456,12 +536,13 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     const uint32_t n = (uint32_t) db->n;
     if (alns->n != db->n) { cdm_set_error("cdm_extend: alignment CSR / DB size mismatch"); return CDM_ERR_INVALID; }
     DevBuf<uint32_t> active, lists, newLen, nLeft, nRight, leftTotal, oWords;
-    DevBuf<unsigned int> nActive; DevBuf<Cand> cand; DevBuf<double> dScores; DevBuf<unsigned long long> stats;
+    DevBuf<unsigned int> nActive, flags; DevBuf<Cand> cand; DevBuf<double> dScores; DevBuf<unsigned long long> stats;
     if (!active.alloc(n) || !lists.alloc(4 * alns->count) || !newLen.alloc(n) || !nLeft.alloc(n) || !nRight.alloc(n) || !leftTotal.alloc(n) ||
-        !oWords.alloc(n) || !nActive.alloc(2) || !cand.alloc(alns->count) || !stats.alloc(2) || (scores && !dScores.alloc(alns->count))) {
+        !oWords.alloc(n) || !nActive.alloc(2) || !flags.alloc(2) || !cand.alloc(alns->count) || !stats.alloc(2) || (scores && !dScores.alloc(alns->count))) {
         cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP;
     }
     hipMemsetAsync(nActive.p, 0, 8, s);
+    hipMemsetAsync(flags.p, 0, 8, s);
     hipMemsetAsync(stats.p, 0, 16, s);
     if (scores) hipMemsetAsync(dScores.p, 0xFF, alns->count * 8, s);   // all-ones = NaN: records of inactive queries
     hipLaunchKernelGGL(k_mark_active2, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, n, active.p, nActive.p, newLen.p);
@@ -478,6 +559,7 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     A.excessLog = std::log(par->excess_penal); A.randLog = std::log(par->rand_align_penal);   // std::log(float): float, as in the reference
     A.ratioLogit = (double) logl(1.0L / (long double) par->likelihood_threshold - 1.0L);
     A.maxSeqLen = par->max_seq_len;
+    A.unsafe = par->unsafe ? 1 : 0; A.minCov = (uint32_t) std::max(0, par->min_cov_safe); A.flags = flags.p;
     hipEventRecord(ctx->ev0, s);
     if (hAct) hipLaunchKernelGGL(k_extend, dim3((hAct + 63) / 64), dim3(64), 0, s, A);
     hipEventRecord(ctx->ev1, s);
@@ -489,11 +571,20 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     cdmscan::ScanTemp tmp;
     hipMemsetAsync(oWords.p + n, 0, 4, s);
     if (cdmscan::exclusiveScan<uint32_t>(s, tmp, oWords.p, o->woff, (size_t) n + 1) != CDM_OK) { cdm_seqdb_free(o); return CDM_ERR_HIP; }
-    uint32_t words = 0; unsigned long long hstats[2] = {0, 0};
+    uint32_t words = 0; unsigned long long hstats[2] = {0, 0}; unsigned int hflags[2] = {0, 0};
+    hipMemcpyAsync(hflags, flags.p, 8, hipMemcpyDeviceToHost, s);
     hipMemcpyAsync(&words, o->woff + n, 4, hipMemcpyDeviceToHost, s);
     hipMemcpyAsync(hstats, stats.p, 16, hipMemcpyDeviceToHost, s);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: extension kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     hipEventElapsedTime(&ctx->lastMs[4], ctx->ev0, ctx->ev1);
+    if (hflags[0]) {
+        cdm_seqdb_free(o);
+        cdm_set_error("cdm_extend: --unsafe 1: a target overhangs the query by more than the query's length; the reference pads it with a negative number of letters there (undefined behaviour), not reproduced");
+        return CDM_ERR_UNSUPPORTED;
+    }
+    if (hstats[0] / 16 + n >= 0xFFFFFFF0ull) {     // (the word offsets are 32-bit: an extended DB beyond 2^32 code words would wrap)
+        cdm_seqdb_free(o); cdm_set_error("cdm_extend: the extended sequences need more than 2^32 code words (68 G bases) in one DB"); return CDM_ERR_UNSUPPORTED;
+    }
     o->words = words; o->residues = hstats[0]; o->maxLen = (uint32_t) hstats[1];
     const uint64_t maskWords = ((uint64_t) words * 16 + 31) / 32 + 1;
     if (cdmMalloc(&o->codes, ((size_t) words + 2) * 4) != hipSuccess || cdmMalloc(&o->nmask, maskWords * 4) != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP; }

@@ -52,14 +52,19 @@ bool MmDb::load(const std::string &path, std::string *err) {
     struct E { uint32_t k; uint64_t o, l; uint8_t e; };
     const int T = std::max(1, omp_get_max_threads());
     std::vector<std::vector<E>> parts(T);
+    std::vector<size_t> bound(T + 1, ixBytes);       // slice t = the lines that start in [bound[t], bound[t + 1]); bounds sit on line starts
+    for (int t = 0; t < T; t++) {
+        size_t b = ixBytes * (size_t) t / T;
+        while (b > 0 && b < ixBytes && ix[b - 1] != '\n') b++;
+        bound[t] = b;
+    }
 #pragma omp parallel num_threads(T)
     {
         const int t = omp_get_thread_num();
-        size_t lo = ixBytes * (size_t) t / T, hi = ixBytes * (size_t) (t + 1) / T;
-        if (t > 0) { while (lo < ixBytes && ix[lo - 1] != '\n') lo++; }
+        const size_t hi = bound[t + 1];
         std::vector<E> &es = parts[t];
-        size_t p = lo;
-        while (p < hi && p < ixBytes) {
+        size_t p = bound[t];
+        while (p < hi) {
             unsigned long long v[4] = {0, 0, 0, 0}; int f = 0;
             while (p < ixBytes && ix[p] != '\n') {
                 if (ix[p] >= '0' && ix[p] <= '9') { if (f < 4) v[f] = v[f] * 10 + (unsigned) (ix[p] - '0'); }

@@ -222,7 +222,7 @@ typedef struct cdm_ancient_params {
     float rand_align_penal;      /* --ext-random-align */
     float excess_penal;          /* --excess-penalty */
     float likelihood_threshold;  /* --likelihood-ratio-threshold */
-    int32_t unsafe;              /* --unsafe (0 only on the device path) */
+    int32_t unsafe;              /* --unsafe: 1 = consensusCaller's majority vote over the extending targets (nuclassembleUtil.cpp:570-702) */
     int32_t min_cov_safe;        /* --min-cov-safe */
     uint64_t max_seq_len;        /* --max-seq-len */
 } cdm_ancient_params;

@@ -100,3 +100,45 @@ def test_extension_deep_coverage_many_rounds(ctx, oracle_bin, dhigh_prefix, tmp_
         exp = mmdb.read_db(t("in%d" % (it + 1)))
         assert not diff_keys(got, exp), it
         assert sum(v[1] for v in exp.values()) > 100
+
+
+@pytest.mark.parametrize("name,it,min_cov", [("synth2k", 0, 1), ("synth2k", 1, 2), ("mixed3k", 0, 5), ("mixed3k", 2, 1), ("example", 0, 2)])
+def test_unsafe_mode_consensus_matches_oracle(ctx, oracle_bin, dhigh_prefix, tmp_path, name, it, min_cov):
+    """--unsafe 1 (consensusCaller's majority vote over the extending targets, nuclassembleUtil.cpp:570-702): the oracle's unsafe
+    mode is pinned to the reference's object code in tests/test_oracle_golden.py; the result differs from the safe mode's in
+    dozens to hundreds of sequences on these inputs, so the comparison below is not vacuous."""
+    corr, aln = gold(name, "corr", it), gold(name, "aln", it)
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_from_keyed(t("corr"), corr, mmdb.DBTYPE_NUCLEOTIDES)
+    mmdb.write_from_keyed(t("aln"), aln, mmdb.DBTYPE_ALIGNMENT_RES)
+    flags = " ".join(A_FLAGS).replace("--unsafe 0", "--unsafe 1").replace("--min-cov-safe 5", "--min-cov-safe %d" % min_cov).split()
+    run_oracle(oracle_bin, "ancient_read_assemble", t("corr"), t("aln"), t("asm"), *flags, "--ancient-damage", dhigh_prefix, "--threads", "4")
+    db = ctx.upload_keyed_seqdb(corr)
+    _, keys, _ = db.meta()
+    off, rec = capi.parse_aln_db(aln, keys)
+    par = capi.AncientParams.default()
+    par.unsafe, par.min_cov_safe = 1, min_cov
+    got = seqdb_to_keyed(*ctx.extend(db, ctx.upload_alns(db, off, rec), par).download())
+    exp = mmdb.read_db(t("asm"))
+    assert not diff_keys(got, exp)
+    assert len(diff_keys(exp, gold(name, "asm", it))) > 20          # (unsafe != safe on this input)
+
+
+def test_unsafe_mode_deep_coverage_rounds(ctx, oracle_bin, dhigh_prefix, tmp_path):
+    """100x coverage: coverage well above --min-cov-safe everywhere, several re-alignment rounds, each with its own consensus."""
+    from carpedeam_amd import synth
+    seqs = synth.generate_strings(3000, L=100, seed=29, coverage=100)
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
+    run_oracle(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref"), t("aln"), *R_FLAGS, "--threads", "4")
+    run_oracle(oracle_bin, "ancient_correction", t("in"), t("aln"), t("corr"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "4")
+    flags = " ".join(A_FLAGS).replace("--unsafe 0", "--unsafe 1").split()
+    run_oracle(oracle_bin, "ancient_read_assemble", t("corr"), t("aln"), t("asm"), *flags, "--ancient-damage", dhigh_prefix, "--threads", "4")
+    db = ctx.upload_keyed_seqdb(mmdb.read_db(t("corr")))
+    _, keys, _ = db.meta()
+    off, rec = capi.parse_aln_db(mmdb.read_db(t("aln")), keys)
+    par = capi.AncientParams.default()
+    par.unsafe = 1
+    got = seqdb_to_keyed(*ctx.extend(db, ctx.upload_alns(db, off, rec), par).download())
+    assert not diff_keys(got, mmdb.read_db(t("asm")))

@@ -251,3 +251,20 @@ def test_kmermatcher_palindromic_repeats_against_reference_binary(oracle_bin, tm
         assert not bad, (case, seqs, bad[:3])
         for f in os.listdir(tmp_path):
             os.remove(t(f))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref (the reference's own object code) not built")
+@pytest.mark.parametrize("name,it,min_cov", [("synth2k", 0, 1), ("synth2k", 1, 5), ("mixed3k", 0, 2), ("mixed3k", 2, 1), ("example", 0, 2)])
+def test_unsafe_mode_against_reference_binary(oracle_bin, dhigh_prefix, tmp_path, name, it, min_cov):
+    """ancient_read_assemble --unsafe 1 (consensusCaller's majority vote, nuclassembleUtil.cpp:535-702): oracle == reference."""
+    from gpuutil import gold
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_from_keyed(t("corr"), gold(name, "corr", it), mmdb.DBTYPE_NUCLEOTIDES)
+    mmdb.write_from_keyed(t("aln"), gold(name, "aln", it), mmdb.DBTYPE_ALIGNMENT_RES)
+    flags = " ".join(A_FLAGS).replace("--unsafe 0", "--unsafe 1").replace("--min-cov-safe 5", "--min-cov-safe %d" % min_cov).split()
+    for exe, out in ((oracle_bin, "o"), (REF_BIN, "r")):
+        run(exe, "ancient_read_assemble", t("corr"), t("aln"), t(out), *flags, "--ancient-damage", dhigh_prefix, "--threads", "2")
+    a, b = mmdb.canon(mmdb.read_db(t("o"))), mmdb.canon(mmdb.read_db(t("r")))
+    assert a == b
+    safe = mmdb.canon(gold(name, "asm", it))
+    assert sum(1 for k in safe if a.get(k) != safe[k]) > 20
