@@ -59,23 +59,29 @@ struct TupleGeom {
     uint64_t kmerSlots;         // size of region 1
     const uint32_t *lenArr;     // sequence lengths (region-2 tuples of the packed layout look their length up)
 };
-// 16 bytes: u64 key = k-mer | strand << 63, u64 value = id << 32 | len << 16 | pos.  Always applicable.
-struct LayoutWide {
+// 16 bytes: u64 key = k-mer | strand << 63, u64 value = id << 2 FB | len << FB | pos.  FB = 16: any DB with sequences below
+// 65 536 letters (ids up to 2^32); FB = 20: sequences up to 2^20 letters (the reference's `int` position path,
+// kmermatcher.cpp:803-808: contigs), ids up to 2^24.
+template <int FB>
+struct LayoutWideT {
     typedef uint64_t V;
+    static constexpr uint64_t FM = (1ull << FB) - 1ull;
     __device__ static void store(uint64_t *keys, V *vals, uint64_t slot, uint64_t kmer63, bool fwd, uint32_t seq, uint32_t L, uint32_t pos, const TupleGeom &) {
-        keys[slot] = kmer63 | (fwd ? BIT63 : 0ull); vals[slot] = ((uint64_t) seq << 32) | ((uint64_t) L << 16) | pos;
+        keys[slot] = kmer63 | (fwd ? BIT63 : 0ull); vals[slot] = ((uint64_t) seq << (2 * FB)) | ((uint64_t) L << FB) | pos;
     }
     __device__ static void storeHash(uint64_t *keys, V *vals, uint64_t slot, uint64_t hash64, uint32_t seq, uint32_t L, const TupleGeom &) {
-        keys[slot] = hash64; vals[slot] = ((uint64_t) seq << 32) | ((uint64_t) L << 16);
+        keys[slot] = hash64; vals[slot] = ((uint64_t) seq << (2 * FB)) | ((uint64_t) L << FB);
     }
     __device__ static void storeEmpty(uint64_t *keys, V *vals, uint64_t slot) { keys[slot] = ~0ull; vals[slot] = 0; }
     __device__ static uint64_t kmerOf(uint64_t key, uint64_t, const TupleGeom &) { return key & ~BIT63; }
-    __device__ static uint32_t seqOf(V v) { return (uint32_t) (v >> 32); }
-    __device__ static uint32_t lenOf(uint64_t, V v, uint64_t, const TupleGeom &) { return (uint32_t) ((v >> 16) & 0xFFFF); }
-    __device__ static uint32_t posOf(uint64_t, V v, uint64_t, const TupleGeom &) { return (uint32_t) (v & 0xFFFF); }
+    __device__ static uint32_t seqOf(V v) { return (uint32_t) (v >> (2 * FB)); }
+    __device__ static uint32_t lenOf(uint64_t, V v, uint64_t, const TupleGeom &) { return (uint32_t) ((v >> FB) & FM); }
+    __device__ static uint32_t posOf(uint64_t, V v, uint64_t, const TupleGeom &) { return (uint32_t) (v & FM); }
     // length and position of a region-1 tuple
-    __device__ static void unpackR1(uint64_t, V v, const TupleGeom &, uint32_t &len, uint32_t &pos) { const uint32_t lo = (uint32_t) v; pos = lo & 0xFFFFu; len = lo >> 16; }
+    __device__ static void unpackR1(uint64_t, V v, const TupleGeom &, uint32_t &len, uint32_t &pos) { pos = (uint32_t) (v & FM); len = (uint32_t) ((v >> FB) & FM); }
 };
+typedef LayoutWideT<16> LayoutWide;
+typedef LayoutWideT<20> LayoutLong;
 // 12 bytes: u64 key = k-mer | pos << (2k + 1) | len << (2k + 1 + lb) | strand << 63, u32 value = id.  Needs 2k + 1 + 2 lb <= 63
 // (k = 20: sequences up to 2047 letters); a quarter less traffic in every radix pass.  Bit 2k stays clear in every real tuple
 // of region 1 (in both layouts): it is set only in the unused-slot key ~0, so sorting region 1 on bits up to and including
@@ -634,12 +640,14 @@ __device__ __forceinline__ uint64_t groupKeyCore(const GroupParams &a, uint32_t 
     else if (repIsReverse && targetIsReverse) { qPos = (queryLen - 1) - repPos; tPos = (tLen - 1) - tPos0; qRev = false; }
     else if (!repIsReverse && targetIsReverse) { qPos = (queryLen - 1) - repPos; tPos = (tLen - 1) - tPos0; qRev = true; }
     else { qPos = repPos; tPos = tPos0; qRev = false; }
-    const int diagonal = (int) (short) qPos - (int) (short) tPos;
+    // (the reference holds positions and the diagonal in `short` below 32 765 letters and in `int` above, kmermatcher.cpp:803-808;
+    // below that limit the casts never change a value, so one expression serves both paths)
+    const int diagonal = qPos - tPos;
     const bool canBeExtended = diagonal < 0 || (diagonal > (queryLen - tLen));
     // coverage modes 0-2 with a threshold <= 0 hold for any two positive lengths: skip the divisions
     const bool cbc = (a.covThr <= 0.0f && a.covMode <= 2 && queryLen > 0 && tLen > 0) ? true : canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) tLen);
     const bool keep = (a.onlyExtendable == 0 && cbc) || (canBeExtended && a.onlyExtendable != 0);
-    return keep ? packGroupKey(a, repId, id, (int) (short) diagonal, !qRev) : ~0ull;
+    return keep ? packGroupKey(a, repId, id, diagonal, !qRev) : ~0ull;
 }
 template <typename LY>
 __device__ __forceinline__ uint64_t groupKeyOf(const GroupParams &a, const TupleGeom &geom, uint64_t repKey, typename LY::V repVal, uint64_t repSlot, uint32_t repPos0,
@@ -1111,7 +1119,6 @@ int phaseA() override {
     n = (uint32_t) db->n;
     k = par->kmer_size;
     if (k < 4 || k > 31) { cdm_set_error("cdm_kmermatch: k must be in 4..31 (got %d)", k); return CDM_ERR_INVALID; }
-    if (db->maxLen + 2 >= 32767u) { cdm_set_error("cdm_kmermatch: sequences of 32765 letters or more (the reference's `int` position path) are not implemented on the device yet"); return CDM_ERR_UNSUPPORTED; }
     constexpr uint32_t SHORT_CAP = 256, LONG_CAP = 4096;
     idBits = bitsFor(n); diagBits = bitsFor(2ull * db->maxLen + 2);
     if (2 * idBits + diagBits + 1 > 63) { cdm_set_error("cdm_kmermatch: %u sequences x max length %u do not fit the 64-bit (rep,id,diagonal) sort key", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
@@ -1588,7 +1595,10 @@ extern "C" int cdm_kmermatch_part(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_k
     if (getenv("CDM_KMER_SORT") || getenv("CDM_KMER_SORT2")) { cdm_set_error("cdm_kmermatch_part: the A/B switches CDM_KMER_SORT / CDM_KMER_SORT2 apply to the single-device path only"); return CDM_ERR_INVALID; }
     CDM_HIP(hipSetDevice(ctx->device));
     cdm_kpart *h = new cdm_kpart();
-    if (packedLayoutFits(db, par->kmer_size)) h->job = new KmerJob<LayoutPacked>(ctx, db, par); else h->job = new KmerJob<LayoutWide>(ctx, db, par);
+    if (packedLayoutFits(db, par->kmer_size)) h->job = new KmerJob<LayoutPacked>(ctx, db, par);
+    else if (db->maxLen < 65535u) h->job = new KmerJob<LayoutWide>(ctx, db, par);
+    else if (db->maxLen < (1u << 20) - 1u && db->n < (1ull << 24)) h->job = new KmerJob<LayoutLong>(ctx, db, par);
+    else { delete h; cdm_set_error("cdm_kmermatch_part: sequences of 2^20 letters or more, or longer than 65 534 letters in a DB of 2^24 sequences or more, are not implemented"); return CDM_ERR_UNSUPPORTED; }
     h->job->part = part; h->job->nparts = nparts; h->nSeq = db->n;
     h->repShift = bitsFor(db->n) + bitsFor(2ull * db->maxLen + 2) + 1;
     const int rc = h->job->phaseA();
@@ -1656,5 +1666,9 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
             if (!fits) { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT=packed needs 2k + 1 + 2 x length bits <= 63 (k %d, max length %u)", k, db->maxLen); return CDM_ERR_INVALID; }
         } else { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT must be wide or packed"); return CDM_ERR_INVALID; }
     }
-    return packed ? kmermatchT<LayoutPacked>(ctx, db, par, out) : kmermatchT<LayoutWide>(ctx, db, par, out);
+    if (packed) return kmermatchT<LayoutPacked>(ctx, db, par, out);
+    if (db->maxLen < 65535u) return kmermatchT<LayoutWide>(ctx, db, par, out);
+    if (db->maxLen < (1u << 20) - 1u && db->n < (1ull << 24)) return kmermatchT<LayoutLong>(ctx, db, par, out);
+    cdm_set_error("cdm_kmermatch: sequences of 2^20 letters or more, or longer than 65 534 letters in a DB of 2^24 sequences or more, are not implemented");
+    return CDM_ERR_UNSUPPORTED;
 }

@@ -187,3 +187,31 @@ def test_contig_handoff_roundtrip(ctx):
     assert [(int(k), s) for s, k in zip(s2, k2)] == exp and (e2 == 1).all()
     for p in (codes, nmask, lens, kk):
         hip.hipFree(p)
+
+
+def test_chain_with_contig_sized_sequences(ctx, oracle_bin, dhigh_prefix, tmp_path):
+    """Sequences of tens of thousands of letters (the reference's `int` position path) next to reads, through all four stages."""
+    rng = np.random.default_rng(37)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    genome = rng.integers(0, 4, 90_000)
+    text = lambda c: letters[c].tobytes().decode()
+    rc = lambda c: (3 - c)[::-1]
+    seqs = [text(genome[0:40_000]), text(rc(genome[30_000:72_000])), text(genome[70_000:89_000])]
+    for _ in range(1500):
+        L = int(rng.integers(60, 151)); st = int(rng.integers(0, 90_000 - L))
+        c = genome[st:st + L].copy()
+        if c[0] == 1 and rng.random() < 0.3:
+            c[0] = 3
+        seqs.append(text(rc(c) if rng.random() < 0.5 else c))
+    seqs = [seqs[i] for i in rng.permutation(len(seqs))]
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    i = t("in")
+    run_oracle(oracle_bin, "kmermatcher", i, t("pref"), *K_FLAGS, "--threads", "8")
+    run_oracle(oracle_bin, "rescorediagonal", i, i, t("pref"), t("aln"), *R_FLAGS, "--threads", "8")
+    run_oracle(oracle_bin, "ancient_correction", i, t("aln"), t("corr"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "8")
+    run_oracle(oracle_bin, "ancient_read_assemble", t("corr"), t("aln"), t("asm"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "8")
+    db = ctx.upload_seqs(seqs)
+    hits, alns, corr, asm = chain(ctx, db)
+    assert not diff_keys(seqdb_to_keyed(*corr.download()), mmdb.read_db(t("corr")))
+    assert not diff_keys(seqdb_to_keyed(*asm.download()), mmdb.read_db(t("asm")))

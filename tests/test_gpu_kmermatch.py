@@ -268,6 +268,34 @@ def test_kmermatch_sequences_beyond_4096_positions(ctx, oracle_bin, tmp_path):
         assert not diff_keys(got, strip_ext(mmdb.read_db(t("pref")))), k
 
 
-def test_kmermatch_rejects_what_it_does_not_implement(ctx):
-    with pytest.raises(capi.CdmError):
-        kmermatch_text(ctx, {0: (b"ACGT" * 8200 + b"\n", 0), 1: (b"ACGTTGCA" * 1000 + b"\n", 0)})   # >= 32 765 letters: the reference's `int` position path
+def test_kmermatch_long_sequences_int_position_path(ctx, oracle_bin, tmp_path):
+    """Sequences of 32 765 letters and more: the reference switches to `int` positions (kmermatcher.cpp:803-808; diagonals beyond
+    the short range, written truncated and probed +-65 536 by rescorediagonal).  Contigs of 33 k, 70 k (16-byte tuples with 20-bit
+    fields) and 40 k letters that overlap each other by tens of thousands of letters, plus reads of both strands on them; then the
+    rescored alignments."""
+    rng = np.random.default_rng(31)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    genome = rng.integers(0, 4, 120_000)
+    text = lambda c: letters[c].tobytes().decode()
+    rc = lambda c: (3 - c)[::-1]
+    seqs = [text(genome[0:33_000]), text(genome[20_000:90_000]), text(rc(genome[60_000:100_000])), text(genome[85_000:119_000])]
+    for _ in range(300):
+        L = int(rng.integers(60, 151)); st = int(rng.integers(0, 120_000 - L))
+        c = genome[st:st + L]
+        seqs.append(text(rc(c) if rng.random() < 0.5 else c))
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4")
+    got = kmermatch_text(ctx, mmdb.read_db(t("in")))
+    want = strip_ext(mmdb.read_db(t("pref")))
+    assert not diff_keys(got, want)
+    assert any(abs(int(l.split(b"\t")[1])) > 3000 for v in want.values() for l in v[0].split(b"\n") if l)      # contig-contig hits with thousands of shared k-mers
+    # and through rescorediagonal (the truncated diagonals are probed back)
+    from stageflags import R_FLAGS
+    run_oracle(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref"), t("aln"), *R_FLAGS, "--threads", "4")
+    db = ctx.upload_keyed_seqdb(mmdb.read_db(t("in")))
+    lens, keys, _ = db.meta()
+    aoff, arec = ctx.rescore(db, ctx.kmermatch(db)).download()
+    assert not diff_keys({k: (v, 0) for k, v in capi.alns_to_text(aoff, arec, keys, lens, db.residues).items()}, mmdb.read_db(t("aln")))
