@@ -42,12 +42,12 @@ def build(verbose=False):
             if _newer(src, obj, headers):
                 jobs.append([HIPCC] + HIP_FLAGS + ["-c", src, "-o", obj])
     hostdir = os.path.join(CSRC, "host")
-    host_lib_srcs = ["damage.cpp", "evalue.cpp"]
+    host_lib_srcs = ["damage.cpp", "evalue.cpp", "contigmerge.cpp"]
     for f in host_lib_srcs:
         src, obj = os.path.join(hostdir, f), os.path.join(OBJ, f + ".o")
         objs.append(obj)
         if _newer(src, obj, headers):
-            jobs.append(["g++"] + GXX_FLAGS + ["-c", src, "-o", obj])
+            jobs.append(["g++"] + GXX_FLAGS + ["-fopenmp", "-c", src, "-o", obj])
     procs = [(j, subprocess.Popen(j, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)) for j in jobs]
     for j, p in procs:
         out, _ = p.communicate()
@@ -56,7 +56,7 @@ def build(verbose=False):
         if p.returncode:
             raise RuntimeError("compile failed: " + " ".join(j))
     if jobs or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lgomp"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             sys.stderr.write(r.stdout + r.stderr)

@@ -51,7 +51,7 @@ EXPORTS = [
     "cdm_hits_download", "cdm_hits_free", "cdm_rescore", "cdm_alns_upload", "cdm_alns_count", "cdm_alns_download", "cdm_alns_free",
     "cdm_evalue", "cdm_bit_score", "cdm_correct", "cdm_extend",
     "cdm_kmermatch_part", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_sort", "cdm_kpart_vote", "cdm_kpart_cont_cap", "cdm_kpart_free", "cdm_dev_copy",
-    "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext",
+    "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge",
 ]
 
 
@@ -120,6 +120,7 @@ def lib():
         l.cdm_dev_copy.argtypes = [vp, vp, vp, C.c_uint64]
         l.cdm_seqdb_from_packed_ext.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]
         l.cdm_seqdb_copy_ext.argtypes = [vp, vp, vp]
+        l.cdm_contig_merge.argtypes = [vp, vp, vp, C.POINTER(AncientParams), C.c_float, C.POINTER(vp)]
         _lib = l
     return _lib
 
@@ -315,6 +316,12 @@ class Ctx:
     def from_packed(self, codes_ptr, nmask_ptr, len_ptr, key_ptr, n, words, ext_value=1):
         h = C.c_void_p()
         _check(lib().cdm_seqdb_from_packed(self.h, codes_ptr, nmask_ptr, len_ptr, key_ptr, n, words, ext_value, C.byref(h)))
+        return SeqDb(self, h)
+
+    def contig_merge(self, db, alns, par=None, merge_seq_id=0.99):
+        par = par or AncientParams.default()
+        h = C.c_void_p()
+        _check(lib().cdm_contig_merge(self.h, db.h, alns.h, C.byref(par), merge_seq_id, C.byref(h)))
         return SeqDb(self, h)
 
     def from_packed_ext(self, codes_ptr, nmask_ptr, len_ptr, key_ptr, ext_ptr, n, words):

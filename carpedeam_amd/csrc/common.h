@@ -125,6 +125,15 @@ struct cdm_alns {
 int cdm_seqdb_alloc_like(cdm_ctx *ctx, const cdm_seqdb *src, cdm_seqdb **out);  // same n/lengths/layout, codes uninitialised
 int cdm_seqdb_alloc(cdm_ctx *ctx, uint64_t n, cdm_seqdb **out);
 
+// ancient_contig_merge: what the device counts per alignment record (contig.hip) for the host part (host/contigmerge.cpp)
+struct ContigStat {            // per alignment record, oriented as :193-214 does
+    int32_t qs, qe, ds, de;
+    int32_t rev;
+    int32_t idCnt, idRy;       // identical / same-RY-class letters over [qs, qe] (:217-223; N == N counts)
+    int32_t nnTot, nnId, nnRy; // the same over the columns where neither letter is N (what the consensus loops see, safe mode)
+    int32_t nCT, nGA;          // query C over target T, query G over target A among those (ancientMatchCount's dimers)
+};
+
 // stage implementations (one .hip file each)
 int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb *out);
 int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, const cdm_rescore_params *par, cdm_alns **out);

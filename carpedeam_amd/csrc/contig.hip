@@ -1,0 +1,120 @@
+// ancient_contig_merge (src/assembler/ancientContigsResults.cpp:94-509), SURVEY.md 8(f) rank 1.
+//
+// Split: the per-alignment work that touches every aligned column - orientation, identities against the query, the counts
+// updateSeqIdConsensus and ancientMatchCount take over the consensus (nuclassembleUtil.cpp:705-790, 1047-1181) - runs on the
+// device, a wavefront per alignment record on 2-bit words.  What follows is order-dependent arithmetic on a handful of numbers
+// per query: the Beta-posterior comparator (:25-70; lgammaf / logf / exp of the C library decide the order and it is not a
+// strict weak ordering, so the queue is libstdc++'s std::priority_queue with that very comparator), the extension loop and the
+// re-alignment of parked hits - host code of the library (host/contigmerge.cpp), compiled like the reference.
+#include "common.h"
+#include "devutil.h"
+
+namespace {
+struct StatArgs {
+    const SeqMeta *meta; const uint32_t *codes, *nmask;
+    const uint64_t *aoff; const AlnRec *rec; const uint32_t *owner;   // owner[r] = query of record r
+    uint64_t nRec;
+    ContigStat *out;
+};
+__device__ __forceinline__ void letterAt(const StatArgs &a, uint32_t w0, uint32_t len, bool hasN, bool rev, uint32_t pos, uint32_t &code, bool &isN) {
+    const uint32_t p = rev ? (len - 1u - pos) : pos;
+    const uint32_t c = cdm_base(a.codes, w0, p);
+    isN = hasN && cdm_isN(a.nmask, w0, p);
+    code = rev ? (3u - c) : c;      // getNuclRevFragment maps X to 'N': an N stays an N
+}
+__global__ __launch_bounds__(256) void k_contig_stats(StatArgs a) {
+    const uint64_t r = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (r >= a.nRec) return;
+    const AlnRec rec = a.rec[r];
+    const uint32_t q = a.owner[r];
+    const SeqMeta qm = a.meta[q], tm = a.meta[rec.target];
+    ContigStat s;
+    s.rev = rec.qStart > rec.qEnd;
+    if (s.rev) { s.qs = rec.qEnd; s.qe = rec.qStart; s.ds = (int) tm.len - rec.dbEnd - 1; s.de = (int) tm.len - rec.dbStart - 1; }
+    else { s.qs = rec.qStart; s.qe = rec.qEnd; s.ds = rec.dbStart; s.de = rec.dbEnd; }
+    int idCnt = 0, idRy = 0, nnTot = 0, nnId = 0, nnRy = 0, nCT = 0, nGA = 0;
+    const bool qHasN = (qm.flags & 1u) != 0, tHasN = (tm.flags & 1u) != 0;
+    const int n = s.qe - s.qs + 1;
+    if (!qHasN && !tHasN && !s.rev) {
+        // 16 columns per lane and step: XOR of the two windows
+        const uint32_t qLast = (qm.len + 15) / 16 - 1, tLast = (tm.len + 15) / 16 - 1;
+        for (int c0 = lane * 16; c0 < n; c0 += 64 * 16) {
+            const uint32_t qw = cdm_window16(a.codes, qm.woff, (uint32_t) (s.qs + c0), qLast), tw = cdm_window16(a.codes, tm.woff, (uint32_t) (s.ds + c0), tLast);
+            const uint32_t x = qw ^ tw;
+            uint32_t any = (x | (x >> 1)) & 0x55555555u, low = x & 0x55555555u;
+            // query C (01) over target T (11): x = 10, query low bit set; query G (10) over target A (00): x = 10, query low bit clear
+            uint32_t hiOnly = (x >> 1) & ~x & 0x55555555u, ct = hiOnly & qw & ~(qw >> 1), ga = hiOnly & ~qw & (qw >> 1);
+            const int rem = n - c0;
+            if (rem < 16) { const uint32_t m = (1u << (2 * rem)) - 1u; any &= m; low &= m; ct &= m; ga &= m; }
+            const int cols = min(16, rem);
+            idCnt += cols - __popc(any); idRy += cols - __popc(low); nCT += __popc(ct); nGA += __popc(ga);
+        }
+        idCnt = cdm_wave_sum(idCnt); idRy = cdm_wave_sum(idRy); nCT = cdm_wave_sum(nCT); nGA = cdm_wave_sum(nGA);
+        nnTot = n; nnId = idCnt; nnRy = idRy;
+    } else {
+        for (int c = lane; c < n; c += 64) {
+            uint32_t qc, tc; bool qn, tn;
+            letterAt(a, qm.woff, qm.len, qHasN, false, (uint32_t) (s.qs + c), qc, qn);
+            letterAt(a, tm.woff, tm.len, tHasN, s.rev != 0, (uint32_t) (s.ds + c), tc, tn);
+            const uint32_t ql = qn ? 4u : qc, tl = tn ? 4u : tc;
+            idCnt += (ql == tl);
+            idRy += (((qn ? 0u : qc) & 1u) == ((tn ? 0u : tc) & 1u));       // ryMap of a letter outside ACGT is 0
+            if (!qn && !tn) { nnTot++; nnId += (qc == tc); nnRy += ((qc & 1u) == (tc & 1u)); nCT += (qc == 1u && tc == 3u); nGA += (qc == 2u && tc == 0u); }
+        }
+        idCnt = cdm_wave_sum(idCnt); idRy = cdm_wave_sum(idRy); nnTot = cdm_wave_sum(nnTot); nnId = cdm_wave_sum(nnId); nnRy = cdm_wave_sum(nnRy);
+        nCT = cdm_wave_sum(nCT); nGA = cdm_wave_sum(nGA);
+    }
+    if (lane == 0) { s.idCnt = idCnt; s.idRy = idRy; s.nnTot = nnTot; s.nnId = nnId; s.nnRy = nnRy; s.nCT = nCT; s.nGA = nGA; a.out[r] = s; }
+}
+__global__ void k_rec_owner(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t *__restrict__ owner) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    for (uint64_t r = aoff[q]; r < aoff[q + 1]; r++) owner[r] = q;
+}
+}  // namespace
+
+// host/contigmerge.cpp
+int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
+                          const std::vector<cdm_aln> &recs, const std::vector<ContigStat> &stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
+                          float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::string *err);
+
+extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float mergeSeqIdThr, cdm_seqdb **out) {
+    if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_contig_merge: NULL argument"); return CDM_ERR_INVALID; }
+    if (!ctx->haveDamage) { cdm_set_error("cdm_contig_merge: call cdm_damage_load first"); return CDM_ERR_INVALID; }
+    if (alns->n != db->n) { cdm_set_error("cdm_contig_merge: alignment CSR / DB size mismatch"); return CDM_ERR_INVALID; }
+    if (par->unsafe) { cdm_set_error("cdm_contig_merge: --unsafe 1 is not implemented for the contig phase"); return CDM_ERR_UNSUPPORTED; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t) db->n;
+    const uint64_t nRec = alns->count;
+    DevBuf<SeqMeta> meta; DevBuf<uint32_t> owner; DevBuf<ContigStat> dStats;
+    if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
+    if (!owner.alloc(nRec) || !dStats.alloc(nRec)) { cdm_set_error("cdm_contig_merge: out of device memory"); return CDM_ERR_HIP; }
+    if (n) hipLaunchKernelGGL(k_rec_owner, dim3((n + 255) / 256), dim3(256), 0, s, alns->off, n, owner.p);
+    StatArgs a; a.meta = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.aoff = alns->off; a.rec = alns->rec; a.owner = owner.p; a.nRec = nRec; a.out = dStats.p;
+    hipEventRecord(ctx->ev0, s);
+    if (nRec) hipLaunchKernelGGL(k_contig_stats, dim3((unsigned) ((nRec * 64 + 255) / 256)), dim3(256), 0, s, a);
+    hipEventRecord(ctx->ev1, s);
+    // everything else is per-query bookkeeping on the host: sequences, records and the per-record statistics come down once
+    std::vector<ContigStat> stats(nRec); std::vector<uint64_t> aoff(n + 1); std::vector<cdm_aln> recs(nRec);
+    std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
+    CDM_HIP(hipMemcpyAsync(stats.data(), dStats.p, nRec * sizeof(ContigStat), hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipMemcpyAsync(aoff.data(), alns->off, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (nRec) CDM_HIP(hipMemcpyAsync(recs.data(), alns->rec, nRec * sizeof(cdm_aln), hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipStreamSynchronize(s));
+    hipEventElapsedTime(&ctx->lastMs[12], ctx->ev0, ctx->ev1);
+    if (int rc = cdm_seqdb_meta(ctx, db, lens.data(), keys.data(), ext.data())) return rc;
+    std::vector<uint64_t> offs(n); uint64_t tot = 0;
+    for (uint32_t i = 0; i < n; i++) { offs[i] = tot; tot += lens[i] + 1; }
+    std::string blob(tot, '\0');
+    if (int rc = cdm_seqdb_download(ctx, db, &blob[0], offs.data())) return rc;
+    std::vector<std::string> seqs(n), outSeqs; std::vector<uint8_t> outExt;
+    for (uint32_t i = 0; i < n; i++) seqs[i].assign(blob, offs[i], lens[i]);
+    std::string err;
+    if (int rc = cdm_contig_merge_host(seqs, keys, ext, aoff, recs, stats, ctx->mats, par, mergeSeqIdThr, outSeqs, outExt, &err)) { cdm_set_error("%s", err.c_str()); return rc; }
+    // the result goes back up as a DB (same keys, new lengths and flags)
+    std::string data; std::vector<uint64_t> oOff(n); std::vector<uint32_t> oLen(n);
+    for (uint32_t i = 0; i < n; i++) { oOff[i] = data.size(); oLen[i] = (uint32_t) outSeqs[i].size(); data += outSeqs[i]; data += "\n"; data.push_back('\0'); }
+    return cdm_seqdb_upload(ctx, data.data(), oOff.data(), oLen.data(), keys.data(), outExt.data(), n, out);
+}

@@ -1,0 +1,215 @@
+// Host part of ancient_contig_merge (src/assembler/ancientContigsResults.cpp:94-509): per query, from the per-record counts the
+// device took (contig.hip), the contig filter, the consensus-based identities (updateSeqIdConsensus, safe mode), the damage-aware
+// match count (ancientMatchCount / deamMatches, nuclassembleUtil.cpp:1009-1181), the priority queue ordered by the
+// Beta-posterior comparator (:25-70) and the extension loop with the re-alignment of parked hits (:276-470).
+// This file is compiled with g++ at the reference recipe's flags (carpedeam_amd/build.py): the comparator's lgammaf / logf /
+// exp come from the same C library, and the queue is the same libstdc++ std::priority_queue - the comparator is not a strict
+// weak ordering, so the order it produces is defined by that implementation and nothing else.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <omp.h>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "../common.h"
+
+namespace {
+struct Res {            // Matcher::result_t, the fields this module uses (M/alignment/Matcher.h:33-56)
+    uint32_t target = 0, dbKey = 0;
+    float seqId = 0, rySeqId = 0, deamMatch = 0;
+    unsigned alnLength = 0, alnLengthCons = 0;
+    int qStartPos = 0, qEndPos = 0, dbStartPos = 0, dbEndPos = 0;
+    unsigned qLen = 0, dbLen = 0;
+    bool isRev = false;
+};
+// ancientContigsResults.cpp:25-70 - arithmetic and overloads as there (`using namespace std` is in force in the reference:
+// lgamma / log of float arguments are the float functions)
+struct CompareByScoreContigs {
+    bool operator()(const Res &r1, const Res &r2) const {
+        float mm_count1 = r1.alnLengthCons - r1.deamMatch;
+        float mm_count2 = r2.alnLengthCons - r2.deamMatch;
+        float alpha1 = mm_count1 + 1;
+        float alpha2 = mm_count2 + 1;
+        float beta1 = r1.deamMatch + 1;
+        float beta2 = r2.deamMatch + 1;
+        double log_c = (std::lgamma(beta1 + beta2) + std::lgamma(alpha1 + beta1)) - (std::lgamma(alpha1 + beta1 + beta2) + std::lgamma(beta1));
+        double log_r = 0.0;
+        double p = 0.0;
+        for (size_t idx = 0; idx < alpha2; idx++) {
+            p += std::exp(log_r + log_c);
+            log_r = std::log(alpha1 + idx) + std::log(beta2 + idx) - (std::log(idx + 1) + std::log(idx + alpha1 + beta1 + beta2)) + log_r;
+        }
+        if (p < 0.45) return true;
+        if (p > 0.55) return false;
+        if (r1.alnLengthCons < r2.alnLengthCons) return true;
+        if (r1.alnLengthCons > r2.alnLengthCons) return false;
+        return true;
+    }
+};
+typedef std::priority_queue<Res, std::vector<Res>, CompareByScoreContigs> Queue;
+
+inline int ryClass(char c) { return (c == 'C' || c == 'T') ? 1 : 0; }              // ryMap[c]; any other letter: 0
+std::string revComp(const char *s, size_t n) {                                    // getNuclRevFragment (nuclassembleUtil.cpp:67-76)
+    std::string r(n, 'N');
+    for (size_t i = 0; i < n; i++) { const char c = s[n - 1 - i]; r[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+    return r;
+}
+// deamMatches (nuclassembleUtil.cpp:1009-1044)
+double deamMatches(unsigned alnLength, unsigned scoreAln, double matchLik) {
+    const double logAdjustmentConstant = std::log(1.4e-9);
+    unsigned maxLength = 1e5;
+    auto logPower = [logAdjustmentConstant](unsigned length) { return logAdjustmentConstant - 3.0 * std::log(length); };
+    double logMin = logPower(10);
+    double logMax = logPower(maxLength);
+    double logLength = logPower(std::min(alnLength, maxLength));
+    double fractionLength = (static_cast<double>(std::abs(logLength) - std::abs(logMax))) / static_cast<double>((std::abs(logMin) - std::abs(logMax)));
+    double priorAln = 1 - fractionLength;
+    double pMatch = 0.5f * ((((static_cast<double>(scoreAln) + 3.0f * alnLength) / 5.0f) + 0.9f) / (alnLength + 1)) + 0.5f * priorAln;
+    double LikNoMatch = 1 - pMatch;
+    double oddsRatio = LikNoMatch / matchLik;
+    double odds = (1 - pMatch) / pMatch;
+    return 1 / (1 + oddsRatio * odds);
+}
+// selectNuclFragmentToExtendContigs (:73-91)
+bool selectFragment(Queue &q, uint32_t queryKey, Res &out) {
+    while (!q.empty()) {
+        Res r = q.top(); q.pop();
+        const bool notBoth = !(r.dbStartPos == 0 && r.qStartPos == 0);
+        const bool rightStart = r.dbStartPos == 0 && (r.dbEndPos != static_cast<int>(r.dbLen) - 1);
+        const bool leftStart = r.qStartPos == 0 && (r.qEndPos != static_cast<int>(r.qLen) - 1);
+        if ((rightStart || leftStart) && notBoth && r.dbKey != queryKey) { out = r; return true; }
+    }
+    return false;
+}
+}  // namespace
+
+int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
+                          const std::vector<cdm_aln> &recs, const std::vector<ContigStat> &stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
+                          float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::string *err) {
+    const size_t n = seqs.size();
+    outSeqs.assign(n, std::string()); outExt.assign(n, 0);
+    const float ryThr = par->ry_seq_id_thr;
+    bool undefinedCase = false;
+#pragma omp parallel
+    {
+        std::vector<Res> contigs, parked;
+        std::vector<uint8_t> useReverse(n, 0);          // per thread, last writer wins within a query (:136-137,198,212)
+#pragma omp for schedule(dynamic, 100)
+        for (size_t id = 0; id < n; id++) {
+            const uint32_t queryKey = keys[id];
+            const std::string &q0 = seqs[id];
+            unsigned qLen = (unsigned) q0.size();
+            std::string query = q0;
+            contigs.clear();
+            Queue queue;
+            // :187-235 orientation, identities (from the device), contig filter
+            for (uint64_t r = aoff[id]; r < aoff[id + 1]; r++) {
+                const cdm_aln &a = recs[r]; const ContigStat &st = stats[r];
+                Res x; x.target = a.target; x.dbKey = keys[a.target];
+                x.qLen = qLen; x.dbLen = (unsigned) seqs[a.target].size();
+                x.alnLength = (unsigned) std::max(std::abs(a.q_end - a.q_start), std::abs(a.db_end - a.db_start)) + 1u;     // Matcher::computeAlnLength
+                x.qStartPos = st.qs; x.qEndPos = st.qe; x.dbStartPos = st.ds; x.dbEndPos = st.de; x.isRev = st.rev != 0;
+                useReverse[a.target] = x.isRev ? 1 : 0;
+                x.seqId = static_cast<float>(st.idCnt) / x.alnLength;
+                x.rySeqId = static_cast<float>(st.idRy) / x.alnLength;
+                if (x.seqId >= mergeSeqIdThr && x.rySeqId >= ryThr && queryKey != x.dbKey) {
+                    // :243 updateSeqIdConsensus against N^L query N^L (safe mode): the columns where both letters are defined
+                    const bool rightStart = (unsigned) x.dbStartPos == 0 && (unsigned) x.qEndPos == (qLen - 1);
+                    const bool leftStart = (unsigned) x.qStartPos == 0 && (unsigned) x.dbEndPos == (x.dbLen - 1);
+                    int tot = 0, idc = 0, idr = 0;
+                    if (leftStart || rightStart) {
+                        if (x.dbLen - x.alnLength > qLen) undefinedCase = true;     // the reference pads with qLen - offset letters
+                        tot = st.nnTot; idc = st.nnId; idr = st.nnRy;
+                    }
+                    if (tot != 0) { x.seqId = static_cast<float>(idc) / tot; x.rySeqId = static_cast<float>(idr) / tot; }
+                    x.alnLengthCons = (unsigned) tot;
+                    // :249-270
+                    unsigned minAlnLen = 500;
+                    minAlnLen = (x.alnLength < minAlnLen) ? std::min(minAlnLen, static_cast<unsigned>(0.2 * x.dbLen)) : minAlnLen;
+                    if (x.seqId >= mergeSeqIdThr && x.rySeqId >= ryThr && x.alnLength >= minAlnLen) {
+                        // ancientMatchCount (nuclassembleUtil.cpp:1047-1181): the C->T / G->A columns each add the same posterior
+                        float mCT = 0, mGA = 0;
+                        unsigned mmCons = (1 - x.seqId) * x.alnLengthCons + 0.5;
+                        unsigned mCons = x.alnLengthCons - mmCons;
+                        unsigned scoreAln = mCons * 2 + mmCons * (-3);
+                        if (leftStart || rightStart) {
+                            const long double (*D)[4][4] = mats[x.isRev ? 1 : 0];
+                            const double likCT = D[5][1][3], likGA = D[5][2][0];
+                            if (likCT > 0) { const double v = deamMatches(x.alnLength, scoreAln, likCT); for (int i = 0; i < st.nCT; i++) mCT += v; }
+                            if (likGA > 0) { const double v = deamMatches(x.alnLength, scoreAln, likGA); for (int i = 0; i < st.nGA; i++) mGA += v; }
+                        }
+                        x.deamMatch = ((static_cast<float>(scoreAln) + 3.0f * x.alnLengthCons) / 5.0f) + mCT + mGA;
+                        queue.push(x);
+                    }
+                }
+            }
+            // :276-470 extension
+            bool couldExtend = false;
+            while (!queue.empty()) {
+                unsigned leftOff = 0, rightOff = 0;
+                parked.clear();
+                Res best;
+                while (selectFragment(queue, queryKey, best)) {
+                    const std::string &t = seqs[best.target];
+                    const unsigned tLen = (unsigned) t.size();
+                    if (best.dbStartPos == 0) { if ((tLen - (best.dbEndPos + 1)) <= rightOff) continue; }
+                    else if (best.qStartPos == 0) { if (best.dbStartPos <= static_cast<int>(leftOff)) continue; }
+                    const unsigned ds = best.dbStartPos, de = best.dbEndPos, qs = best.qStartPos, qe = best.qEndPos;
+                    if (ds == 0 && qe == (qLen - 1)) {
+                        if (rightOff > 0) { parked.push_back(best); continue; }
+                        const unsigned fragLen = tLen - (de + 1);
+                        if (query.size() + fragLen >= par->max_seq_len) break;
+                        query += useReverse[best.target] ? revComp(t.data(), fragLen) : t.substr(de + 1, fragLen);
+                        rightOff += fragLen;
+                    } else if (qs == 0 && de == (tLen - 1)) {
+                        if (leftOff > 0) { parked.push_back(best); continue; }
+                        const unsigned fragLen = ds;
+                        if (query.size() + fragLen >= par->max_seq_len) break;
+                        query = (useReverse[best.target] ? revComp(t.data() + (tLen - ds), fragLen) : t.substr(0, fragLen)) + query;
+                        leftOff += fragLen;
+                    }
+                }
+                if (leftOff > 0 || rightOff > 0) couldExtend = true;
+                if (!queue.empty()) break;
+                qLen = (unsigned) query.size();
+                // :404-455 the parked hits on the grown query: ungappedAlignmentByDiagonal (mode 3), updateNuclAlignment, getRYSeqId
+                for (Res &a : parked) {
+                    std::string tmp; const std::string *tp = &seqs[a.target];
+                    if (useReverse[a.target]) { tmp = revComp(tp->data(), tp->size()); tp = &tmp; }
+                    const char *ts = tp->data(); const unsigned tLen = (unsigned) tp->size();
+                    const int diag = (a.qStartPos + (int) leftOff) - a.dbStartPos;
+                    const unsigned md = (unsigned) std::abs(diag);
+                    int startPos = -1, endPos = -1; unsigned diagonalLen = 0;
+                    const char *qa = nullptr; unsigned m = 0;
+                    if (diag >= 0 && md < qLen) { m = std::min(tLen, qLen - md); qa = query.data() + md; }
+                    else if (diag < 0 && md < tLen) { m = std::min(tLen - md, qLen); qa = query.data(); }
+                    if (qa) {       // computeSubstitutionStartEndDistance: the whole overlap ('*' ends do not occur in nucleotide DBs)
+                        diagonalLen = m; startPos = 0; endPos = (int) m - 1;
+                    }
+                    // updateNuclAlignment (nuclassembleUtil.cpp:9-47)
+                    const int dist = (int) md;
+                    int qs2, qe2, ds2, de2;
+                    if (diag >= 0) { qs2 = startPos + dist; qe2 = endPos + dist; ds2 = startPos; de2 = endPos; }
+                    else { qs2 = startPos; qe2 = endPos; ds2 = startPos + dist; de2 = endPos + dist; }
+                    int idCnt = 0;
+                    for (int i = qs2; i < qe2; i++) idCnt += (query[i] == ts[ds2 + (i - qs2)]) ? 1 : 0;
+                    a.seqId = static_cast<float>(idCnt) / (static_cast<float>(qe2) - static_cast<float>(qs2));
+                    a.qLen = qLen; a.dbLen = tLen; a.alnLength = diagonalLen;
+                    a.qStartPos = qs2; a.qEndPos = qe2; a.dbStartPos = ds2; a.dbEndPos = de2;
+                    int idRy = 0;                                               // getRYSeqId (nuclassembleUtil.cpp:78-92)
+                    if (qa)     // (no overlap left on that diagonal: the identity above is 0/0 and the hit is dropped whatever this count is)
+                        for (int i = a.qStartPos; i <= a.qEndPos; i++) idRy += (ryClass(query[i]) == ryClass(ts[a.dbStartPos + (i - a.qStartPos)])) ? 1 : 0;
+                    a.rySeqId = static_cast<float>(idRy) / a.alnLength;
+                    if (a.seqId >= mergeSeqIdThr && a.rySeqId >= ryThr) queue.push(a);
+                }
+            }
+            if (couldExtend) { outSeqs[id] = query; outExt[id] = 1; }
+            else { outSeqs[id] = q0; outExt[id] = ext[id]; }
+        }
+    }
+    if (undefinedCase) { *err = "cdm_contig_merge: a target overhangs its query by more than the query's length; the reference pads it with a negative number of letters there (undefined behaviour), not reproduced"; return CDM_ERR_UNSUPPORTED; }
+    return CDM_OK;
+}

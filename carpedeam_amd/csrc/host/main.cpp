@@ -70,7 +70,7 @@ const FlagSpec RESCORE_FLAGS[] = {
 const FlagSpec ANCIENT_FLAGS[] = {
     {"--min-seq-id", 'U', 0, 0}, {"--max-seq-len", 'U', 0, 0}, {"--ext-random-align", 'U', 0, 0}, {"--excess-penalty", 'U', 0, 0}, {"--min-ryseq-id-corr-reads", 'U', 0, 0},
     {"--likelihood-ratio-threshold", 'U', 0, 0}, {"--ancient-damage", 'U', 0, 0}, {"--unsafe", 'U', 0, 0}, {"--min-cov-safe", 'U', 0, 0},
-    {"--keep-target", 'N', 0, "not read by these modules"}, {"--min-seqid-corr-reads", 'N', 0, "not read by these modules"}, {"--min-merge-seq-id", 'N', 0, "contig merging only"},
+    {"--keep-target", 'N', 0, "not read by these modules"}, {"--min-seqid-corr-reads", 'N', 0, "not read by these modules"}, {"--min-merge-seq-id", 'U', 0, 0},
     {"--min-seqid-corr-contigs", 'N', 0, "contig correction only"}, {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0},
     {"--rescore-mode", 'V', "3", "re-alignment of parked candidates is end-to-end ungapped (ancientReadsResults.cpp:502)"}, {0, 0, 0, 0}};
 void checkFlags(const char *module, const Args &a, const FlagSpec *spec, const char *const *extra = NULL) {
@@ -311,10 +311,12 @@ int rescorediagonal(Args &a) {
     return EXIT_SUCCESS;
 }
 
-int ancientModule(Args &a, bool assemble) {
-    if (a.pos.size() < 3) die(std::string("Usage: carpedeam ") + (assemble ? "ancient_read_assemble" : "ancient_correction") + " <i:sequenceDB> <i:alnResult> <o:reprSeqDB>");
-    checkFlags(assemble ? "ancient_read_assemble" : "ancient_correction", a, ANCIENT_FLAGS);
-    if (assemble && !a.flag.count("--rescore-mode")) die("ancient_read_assemble: --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
+int ancientModule(Args &a, int mode) {      // 0 ancient_correction, 1 ancient_read_assemble, 2 ancient_contig_merge
+    const bool assemble = mode == 1;
+    const char *name = mode == 0 ? "ancient_correction" : mode == 1 ? "ancient_read_assemble" : "ancient_contig_merge";
+    if (a.pos.size() < 3) die(std::string("Usage: carpedeam ") + name + " <i:sequenceDB> <i:alnResult> <o:reprSeqDB>");
+    checkFlags(name, a, ANCIENT_FLAGS);
+    if (mode >= 1 && !a.flag.count("--rescore-mode")) die(std::string(name) + ": --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
     MmDb seq, aln; std::string err; if (!seq.load(a.pos[0], &err) || !aln.load(a.pos[1], &err)) die(err);
     cdm_ctx *ctx = openCtx();
     check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");
@@ -325,6 +327,7 @@ int ancientModule(Args &a, bool assemble) {
     check(cdm_alns_upload(ctx, db, off.data(), rec.data(), &alns), "upload");
     cdm_ancient_params p = ancientParams(a);
     if (assemble) check(cdm_extend(ctx, db, alns, &p, &out, NULL), "ancient_read_assemble");
+    else if (mode == 2) check(cdm_contig_merge(ctx, db, alns, &p, fflag(a, "--min-merge-seq-id", 0.99f), &out), "ancient_contig_merge");
     else check(cdm_correct(ctx, db, alns, &p, &out), "ancient_correction");
     writeSeqDb(ctx, out, a.pos[2], seq.dbtype);
     cdm_seqdb_free(out); cdm_alns_free(alns); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
@@ -432,8 +435,9 @@ int main(int argc, char **argv) {
     int rc;
     if (cmd == "kmermatcher") rc = kmermatcher(a);
     else if (cmd == "rescorediagonal") rc = rescorediagonal(a);
-    else if (cmd == "ancient_correction") rc = ancientModule(a, false);
-    else if (cmd == "ancient_read_assemble") rc = ancientModule(a, true);
+    else if (cmd == "ancient_correction") rc = ancientModule(a, 0);
+    else if (cmd == "ancient_read_assemble") rc = ancientModule(a, 1);
+    else if (cmd == "ancient_contig_merge") rc = ancientModule(a, 2);
     else if (cmd == "ancient_reads_loop") rc = readsLoop(a);
     else if (cmd == "createdb") rc = createdb(a);
     else if (cmd == "convert2fasta") rc = convert2fasta(a);

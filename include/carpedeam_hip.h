@@ -239,6 +239,17 @@ int cdm_correct(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const c
 int cdm_extend(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out,
                double *scores);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * ancient_contig_merge (contig phase of the workflow, data/nuclassemble.sh:148-196).  Replaces the loop at
+ * src/assembler/ancientContigsResults.cpp:94-509.  db must be the corrected contig DB.  The per-alignment column work
+ * (orientation, identities, the counts of updateSeqIdConsensus / ancientMatchCount) runs on the device; the queue order - a
+ * Beta-posterior comparator built on the C library's lgammaf / logf (:25-70), not a strict weak ordering - and the extension
+ * loop run in the library's host code, which uses the same libstdc++ priority queue as the reference.
+ * merge_seq_id_thr is --min-merge-seq-id; par->ry_seq_id_thr, max_seq_len, unsafe (0 only) are used from par.
+ */
+int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float merge_seq_id_thr,
+                     cdm_seqdb **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,6 +171,7 @@ struct Aln {  // M/alignment/Matcher.h:33-56 (fields the path uses)
     uint32_t dbKey = 0; int score = 0; float seqId = 0; double eval = 0; unsigned alnLength = 0;
     int qStartPos = 0, qEndPos = 0; unsigned qLen = 0; int dbStartPos = 0, dbEndPos = 0; unsigned dbLen = 0;
     bool isRev = false; float rySeqId = 0;
+    float deamMatch = 0; unsigned alnLengthCons = 0;   // the fork's additions (Matcher.h:55-56), used by ancient_contig_merge
 };
 // M/alignment/Matcher.cpp:356-404
 static void alnToBuf(std::string &out, const Aln &r) {
@@ -335,6 +336,7 @@ static float rySeqIdOf(const Aln &r, const char *q, const char *t) {
 struct AncientPar {
     float seqIdThr = 0.9f, randAlnPenal = 0.85f, excessPenal = 0.0625f, corrReadsRySeqId = 0.99f, likelihoodThreshold = 0.5f, rySeqIdThr = 0.99f;
     bool unsafe = false; int minCovSafe = 5; size_t maxSeqLen = 200000; std::string damage; int threads = 1;
+    float mergeSeqIdThr = 0.99f;   // --min-merge-seq-id (LocalParameters.h:141,302)
 };
 
 // ----------------------------------------------------------------------------- C: ancient_correction
@@ -735,6 +737,221 @@ static int doAssemble(const std::string &seqPath, const std::string &alnPath, co
     return 0;
 }
 
+// ----------------------------------------------------------------------------- F1: ancient_contig_merge
+// src/assembler/ancientContigsResults.cpp:25-70.  NOT a strict weak ordering (the fall-through `return true`); the queue below is
+// libstdc++'s std::priority_queue with this very comparator, as in the reference.  Overload resolution as there (libgab.h has
+// `using namespace std`): lgamma and log of float arguments are the float functions.
+struct CmpContigs {
+    bool operator()(const Aln &r1, const Aln &r2) const {
+        float mm_count1 = r1.alnLengthCons - r1.deamMatch;
+        float mm_count2 = r2.alnLengthCons - r2.deamMatch;
+        float alpha1 = mm_count1 + 1;
+        float alpha2 = mm_count2 + 1;
+        float beta1 = r1.deamMatch + 1;
+        float beta2 = r2.deamMatch + 1;
+        double log_c = (std::lgamma(beta1 + beta2) + std::lgamma(alpha1 + beta1)) - (std::lgamma(alpha1 + beta1 + beta2) + std::lgamma(beta1));
+        double log_r = 0.0;
+        double p = 0.0;
+        for (size_t idx = 0; idx < alpha2; idx++) {
+            p += std::exp(log_r + log_c);
+            log_r = std::log(alpha1 + idx) + std::log(beta2 + idx) - (std::log(idx + 1) + std::log(idx + alpha1 + beta1 + beta2)) + log_r;
+        }
+        if (p < 0.45) return true;
+        if (p > 0.55) return false;
+        if (r1.alnLengthCons < r2.alnLengthCons) return true;
+        if (r1.alnLengthCons > r2.alnLengthCons) return false;
+        return true;
+    }
+};
+typedef std::priority_queue<Aln, std::vector<Aln>, CmpContigs> QueueContigs;
+// :73-91
+static bool selectFragmentContigs(QueueContigs &qu, uint32_t qKey, Aln &out) {
+    while (!qu.empty()) {
+        Aln res = qu.top(); qu.pop();
+        const bool notBoth = !(res.dbStartPos == 0 && res.qStartPos == 0);
+        const bool rightStart = res.dbStartPos == 0 && (res.dbEndPos != static_cast<int>(res.dbLen) - 1);
+        const bool leftStart = res.qStartPos == 0 && (res.qEndPos != static_cast<int>(res.qLen) - 1);
+        if ((rightStart || leftStart) && notBoth && res.dbKey != qKey) { out = res; return true; }
+    }
+    return false;
+}
+// nuclassembleUtil.cpp:705-790 (updateSeqIdConsensus: like the reads flavour, plus alnLengthCons)
+static void updateSeqIdConsensus(std::vector<Aln> &alns, const Db &seq, const std::string &cons, unsigned qLen) {
+    for (Aln &a : alns) {
+        size_t tid = seq.getId(a.dbKey); unsigned tLen = seq.seqLen(tid);
+        std::string t = a.isRev ? nuclRevFragment(seq.getData(tid), tLen) : std::string(seq.getData(tid), tLen);
+        unsigned dbStart = a.dbStartPos, dbEnd = a.dbEndPos, qStart = a.qStartPos, qEnd = a.qEndPos;
+        const bool rightStart = dbStart == 0 && qEnd == (qLen - 1);
+        const bool leftStart = qStart == 0 && dbEnd == (a.dbLen - 1);
+        int idCnt = 0, idRy = 0, tot = 0;
+        if (leftStart) {
+            unsigned offset = a.dbLen - a.alnLength;
+            t = std::string(qLen - offset, 'N') + t;
+            for (unsigned i = 0; i < t.size(); i++)
+                if (!(cons[i] == 'N' || t[i] == 'N')) { idCnt += (cons[i] == t[i]); idRy += (ryMap(cons[i]) == ryMap(t[i])); tot++; }
+        } else if (rightStart) {
+            unsigned offset = a.dbLen - a.alnLength;
+            t = t + std::string(qLen - offset, 'N');
+            for (unsigned i = 0; i < t.size(); i++) {
+                unsigned ci = cons.size() - t.size() + i;
+                if (!(cons[ci] == 'N' || t[i] == 'N')) { idCnt += (cons[ci] == t[i]); idRy += (ryMap(cons[ci]) == ryMap(t[i])); tot++; }
+            }
+        }
+        float sid = a.seqId, rid = a.rySeqId;
+        if (tot != 0) { sid = static_cast<float>(idCnt) / tot; rid = static_cast<float>(idRy) / tot; }
+        a.seqId = sid; a.alnLengthCons = tot; a.rySeqId = rid;
+    }
+}
+// nuclassembleUtil.cpp:1009-1044
+static double deamMatches(const Aln &res, unsigned scoreAln, double matchLik) {
+    const double logAdjustmentConstant = std::log(1.4e-9);
+    unsigned maxLength = 1e5;
+    auto logPower = [logAdjustmentConstant](unsigned length) { return logAdjustmentConstant - 3.0 * std::log(length); };
+    double logMin = logPower(10);
+    double logMax = logPower(maxLength);
+    double logLength = logPower(std::min(res.alnLength, maxLength));
+    double fractionLength = (static_cast<double>(std::abs(logLength) - std::abs(logMax))) / static_cast<double>((std::abs(logMin) - std::abs(logMax)));
+    double priorAln = 1 - fractionLength;
+    double pMatch = 0.5f * ((((static_cast<double>(scoreAln) + 3.0f * res.alnLength) / 5.0f) + 0.9f) / (res.alnLength + 1)) + 0.5f * priorAln;
+    double LikNoMatch = 1 - pMatch;
+    double oddsRatio = LikNoMatch / matchLik;
+    double odds = (1 - pMatch) / pMatch;
+    double posterior = 1 / (1 + oddsRatio * odds);
+    return posterior;
+}
+// nuclassembleUtil.cpp:1047-1181
+static float ancientMatchCount(const Aln &res, const std::string &cons, unsigned qLen, const std::vector<DiNuc> &Dsel, const Db &seq) {
+    float mCT = 0, mGA = 0;
+    unsigned mmCons = (1 - res.seqId) * res.alnLengthCons + 0.5;
+    unsigned mCons = res.alnLengthCons - mmCons;
+    unsigned scoreAln = mCons * 2 + mmCons * (-3);
+    size_t tid = seq.getId(res.dbKey); unsigned tLen = seq.seqLen(tid);
+    std::string t = res.isRev ? nuclRevFragment(seq.getData(tid), tLen) : std::string(seq.getData(tid), tLen);
+    unsigned dbStart = res.dbStartPos, dbEnd = res.dbEndPos, qStart = res.qStartPos, qEnd = res.qEndPos;
+    const bool rightStart = dbStart == 0 && qEnd == (qLen - 1);
+    const bool leftStart = qStart == 0 && dbEnd == (res.dbLen - 1);
+    auto column = [&](char cq, char ct) {
+        int qBase = nucMap(cq), tBase = nucMap(ct);
+        bool dimerCT = ((4 * qBase + tBase) == 7), dimerGA = ((4 * qBase + tBase) == 8);
+        double matchLik = Dsel[5].p[qBase][tBase];
+        if (dimerCT && matchLik > 0) mCT += deamMatches(res, scoreAln, matchLik);
+        else if (dimerGA && matchLik > 0) mGA += deamMatches(res, scoreAln, matchLik);
+    };
+    if (leftStart) {
+        unsigned offset = res.dbLen - res.alnLength;
+        t = std::string(qLen - offset, 'N') + t;
+        for (unsigned i = 0; i < t.size(); i++) if (!(cons[i] == 'N' || t[i] == 'N')) column(cons[i], t[i]);
+    } else if (rightStart) {
+        unsigned offset = res.dbLen - res.alnLength;
+        t = t + std::string(qLen - offset, 'N');
+        for (unsigned i = 0; i < t.size(); i++) { unsigned ci = cons.size() - t.size() + i; if (!(cons[ci] == 'N' || t[i] == 'N')) column(cons[ci], t[i]); }
+    }
+    float matches = ((static_cast<float>(scoreAln) + 3.0f * res.alnLengthCons) / 5.0f) + mCT + mGA;
+    return matches;
+}
+// nuclassembleUtil.cpp:78-92
+static float getRYSeqId(const Aln &res, const char *q, const char *t) {
+    int idRy = 0;
+    for (int i = res.qStartPos; i <= res.qEndPos; i++) idRy += (ryMap(q[i]) == ryMap(t[res.dbStartPos + (i - res.qStartPos)])) ? 1 : 0;
+    return static_cast<float>(idRy) / res.alnLength;
+}
+// src/assembler/ancientContigsResults.cpp:94-496
+static int doContigMerge(const std::string &seqPath, const std::string &alnPath, const std::string &outPath, const AncientPar &par) {
+    Db seq, aln; seq.load(seqPath); aln.load(alnPath);
+    DbOut out; out.init(seq.size());
+    std::vector<uint8_t> wasExtended(seq.size(), 0);
+    std::vector<DiNuc> D, Drev; initDeam(par.damage + "5p.prof", par.damage + "3p.prof", D, Drev);
+#pragma omp parallel num_threads(par.threads)
+    {
+        std::vector<Aln> alns, contigs, tmpAl;
+        std::vector<uint8_t> useReverse(seq.size(), 0);
+#pragma omp for schedule(dynamic, 100)
+        for (size_t id = 0; id < seq.size(); id++) {
+            uint32_t qKey = seq.key[id];
+            const char *q = seq.getData(id);
+            unsigned qLen = seq.seqLen(id);
+            std::string query(q, qLen);
+            alns.clear(); contigs.clear();
+            size_t aid = aln.getId(qKey);
+            if (aid != (size_t) UINT_MAX) parseAlns(aln.getData(aid), alns);
+            bool couldExtend = false;
+            QueueContigs queue;
+            for (Aln &a : alns) {  // :187-235
+                size_t tid = seq.getId(a.dbKey); unsigned tLen = seq.seqLen(tid);
+                std::string t;
+                if (a.qStartPos > a.qEndPos) {
+                    useReverse[tid] = 1; a.isRev = true;
+                    std::swap(a.qStartPos, a.qEndPos);
+                    unsigned s0 = a.dbStartPos; a.dbStartPos = a.dbLen - a.dbEndPos - 1; a.dbEndPos = a.dbLen - s0 - 1;
+                    t = nuclRevFragment(seq.getData(tid), tLen);
+                } else { t = std::string(seq.getData(tid), tLen); useReverse[tid] = 0; a.isRev = false; }
+                int idCnt = 0, idRy = 0;
+                for (int i = a.qStartPos; i <= a.qEndPos; i++) {
+                    char tc = t[a.dbStartPos + (i - a.qStartPos)];
+                    idCnt += (q[i] == tc) ? 1 : 0; idRy += (ryMap(q[i]) == ryMap(tc)) ? 1 : 0;
+                }
+                a.seqId = static_cast<float>(idCnt) / a.alnLength; a.rySeqId = static_cast<float>(idRy) / a.alnLength;
+                if (a.seqId >= par.mergeSeqIdThr && a.rySeqId >= par.rySeqIdThr && qKey != a.dbKey) contigs.push_back(a);
+            }
+            std::string cons(3 * qLen, 'N');
+            consensusCaller(cons, contigs, seq, q, qLen, qKey, par);
+            updateSeqIdConsensus(contigs, seq, cons, qLen);
+            for (Aln &c : contigs) {  // :249-270
+                unsigned minAlnLen = 500;
+                minAlnLen = (c.alnLength < minAlnLen) ? std::min(minAlnLen, static_cast<unsigned>(0.2 * c.dbLen)) : minAlnLen;
+                if (c.seqId >= par.mergeSeqIdThr && c.rySeqId >= par.rySeqIdThr && c.alnLength >= minAlnLen) {
+                    c.deamMatch = ancientMatchCount(c, cons, qLen, c.isRev ? Drev : D, seq);
+                    queue.push(c);
+                }
+            }
+            const char *qp = q;
+            while (!queue.empty()) {  // :276-470
+                unsigned leftOff = 0, rightOff = 0;
+                tmpAl.clear();
+                Aln best;
+                while (selectFragmentContigs(queue, qKey, best)) {
+                    size_t tid = seq.getId(best.dbKey);
+                    const char *ts = seq.getData(tid); unsigned tLen = seq.seqLen(tid);
+                    if (best.dbStartPos == 0) { if ((tLen - (best.dbEndPos + 1)) <= rightOff) continue; }
+                    else if (best.qStartPos == 0) { if (best.dbStartPos <= static_cast<int>(leftOff)) continue; }
+                    unsigned ds = best.dbStartPos, de = best.dbEndPos, qs = best.qStartPos, qe = best.qEndPos;
+                    if (ds == 0 && qe == (qLen - 1)) {
+                        if (rightOff > 0) { tmpAl.push_back(best); continue; }
+                        unsigned fragLen = tLen - (de + 1);
+                        if (query.size() + fragLen >= par.maxSeqLen) break;
+                        std::string frag = useReverse[tid] ? nuclRevFragment(ts, fragLen) : std::string(ts + de + 1, fragLen);
+                        query += frag; rightOff += fragLen;
+                    } else if (qs == 0 && de == (tLen - 1)) {
+                        if (leftOff > 0) { tmpAl.push_back(best); continue; }
+                        unsigned fragLen = ds;
+                        if (query.size() + fragLen >= par.maxSeqLen) break;
+                        std::string frag = useReverse[tid] ? nuclRevFragment(ts + (tLen - ds), fragLen) : std::string(ts, fragLen);
+                        query = frag + query; leftOff += fragLen;
+                    }
+                }
+                if (leftOff > 0 || rightOff > 0) couldExtend = true;
+                if (!queue.empty()) break;
+                qLen = query.length(); qp = query.c_str();
+                for (Aln &a : tmpAl) {  // :404-455
+                    size_t tid = seq.getId(a.dbKey); unsigned tLen = seq.seqLen(tid);
+                    const char *ts = seq.getData(tid); std::string tmp;
+                    if (useReverse[tid]) { tmp = nuclRevFragment(ts, tLen); ts = tmp.data(); }
+                    int diag = (a.qStartPos + leftOff) - a.dbStartPos;
+                    LocalAln al = ungappedByDiagonal(qp, qLen, ts, tLen, diag);
+                    updateNuclAlignment(a, al, qp, qLen, ts, tLen);
+                    a.rySeqId = getRYSeqId(a, qp, ts);
+                    if (a.seqId >= par.mergeSeqIdThr && a.rySeqId >= par.rySeqIdThr) queue.push(a);
+                }
+            }
+            if (couldExtend) { query.push_back('\n'); wasExtended[id] |= 0x20; out.set(id, qKey, query, 1); }
+        }
+    }
+    for (size_t id = 0; id < seq.size(); id++)  // :473-487
+        if (!(wasExtended[id] & 0x20)) out.set(id, seq.key[id], std::string(seq.getData(id), seq.len[id] - 1), seq.ext[id]);
+    out.write(outPath, seq.dbtype);
+    return 0;
+}
+
 // ----------------------------------------------------------------------------- E-value (R3)
 // M/alignment/EvalueComputation.h:18-24,36-40,125-128 -> lib/mmseqs/lib/alp/sls_alignment_evaluer.cpp:989-1025,
 // sls_pvalues.cpp:366-541, sls_basic.hpp:195-198.  The gapless Gumbel parameters ALP derives for
@@ -1087,6 +1304,7 @@ static AncientPar ancientPar(std::map<std::string, std::string> &f) {
     if (f.count("--min-ryseq-id")) p.rySeqIdThr = strtof(f["--min-ryseq-id"].c_str(), NULL);
     if (f.count("--likelihood-ratio-threshold")) p.likelihoodThreshold = strtof(f["--likelihood-ratio-threshold"].c_str(), NULL);
     if (f.count("--unsafe")) p.unsafe = atoi(f["--unsafe"].c_str()) != 0;
+    if (f.count("--min-merge-seq-id")) p.mergeSeqIdThr = strtof(f["--min-merge-seq-id"].c_str(), NULL);
     if (f.count("--min-cov-safe")) p.minCovSafe = atoi(f["--min-cov-safe"].c_str());
     if (f.count("--max-seq-len")) p.maxSeqLen = strtoull(f["--max-seq-len"].c_str(), NULL, 10);
     if (f.count("--ancient-damage")) p.damage = f["--ancient-damage"];
@@ -1179,6 +1397,8 @@ int main(int argc, char **argv) {
         AncientPar p = ancientPar(flags); rc = doCorrection(pos[0], pos[1], pos[2], p);
     } else if (cmd == "ancient_read_assemble" && pos.size() >= 3) {
         AncientPar p = ancientPar(flags); rc = doAssemble(pos[0], pos[1], pos[2], p);
+    } else if (cmd == "ancient_contig_merge" && pos.size() >= 3) {
+        AncientPar p = ancientPar(flags); rc = doContigMerge(pos[0], pos[1], pos[2], p);
     } else { fprintf(stderr, "unknown/incomplete command %s\n", cmd.c_str()); return 2; }
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "Time for processing: %.3fs\n", sec);

@@ -170,8 +170,33 @@ def main():
         chain(tmp, "example", seqs, 1, prefix, 4)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "createdb"):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("createdb", "contigs")):
     main()
+
+
+def contig_goldens(threads=4):
+    """tests/golden/<name>/c{pref,aln,corr,merge}_<step>.keyed.gz: the contig phase (kmermatcher -k 22 --include-only-extendable 1,
+    rescorediagonal, ancient_correction, ancient_contig_merge) run by the reference's own object code, starting from the last
+    reads-loop golden of the data set (python tests/golden/make_golden.py contigs)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpuutil import gold
+    from stageflags import AC_FLAGS, KC_FLAGS
+    with tempfile.TemporaryDirectory() as tmp:
+        prefix = os.path.join(tmp, "dhigh")
+        synth.write_dhigh_profiles(prefix)
+        for name, last_it, steps in (("mixed3k", 2, 2), ("synth2k", 1, 2)):
+            d = os.path.join(OUT, name)
+            cur = os.path.join(tmp, name + "_c0")
+            mmdb.write_from_keyed(cur, gold(name, "asm", last_it), mmdb.DBTYPE_NUCLEOTIDES)
+            for step in range(steps):
+                p = lambda s: os.path.join(tmp, "%s_%s_%d" % (name, s, step))
+                run("kmermatcher", cur, p("cpref"), *KC_FLAGS, "--threads", "1")
+                run("rescorediagonal", cur, cur, p("cpref"), p("caln"), *R_FLAGS, "--threads", str(threads))
+                run("ancient_correction", cur, p("caln"), p("ccorr"), *AC_FLAGS, "--ancient-damage", prefix, "--threads", str(threads))
+                run("ancient_contig_merge", p("ccorr"), p("caln"), p("cmerge"), *AC_FLAGS, "--ancient-damage", prefix, "--threads", str(threads))
+                for s_ in ("cpref", "caln", "ccorr", "cmerge"):
+                    gz_write(os.path.join(d, "%s_%d.keyed.gz" % (s_, step)), mmdb.dump_keyed(p(s_)))
+                cur = p("cmerge")
 
 
 def createdb_digests():
@@ -211,3 +236,5 @@ def createdb_digests():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "createdb":
     createdb_digests()
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "contigs":
+    contig_goldens()

@@ -5,3 +5,7 @@ R_FLAGS = ("--rescore-mode 3 -e 0.001 --min-seq-id 0.9 --seq-id-mode 0 --sort-re
            "--cov-mode 1 -c 0").split()
 A_FLAGS = ("--rescore-mode 3 --max-seq-len 200000 --min-seq-id 0.9 --ext-random-align 0.85 --excess-penalty 0.0625 "
            "--min-ryseq-id-corr-reads 0.99 --likelihood-ratio-threshold 0.5 --unsafe 0 --min-cov-safe 5").split()
+# the contig phase (data/nuclassemble.sh:148-196; Nuclassembler.cpp:118-126): -k 22, only extendable overlaps, --min-merge-seq-id
+KC_FLAGS = [x if x != "20" else "22" for x in K_FLAGS]
+KC_FLAGS[KC_FLAGS.index("--include-only-extendable") + 1] = "1"
+AC_FLAGS = A_FLAGS + ["--min-merge-seq-id", "0.99"]

@@ -1,0 +1,90 @@
+"""The contig phase (data/nuclassemble.sh:148-196): kmermatcher with the contig parameters, rescorediagonal,
+ancient_correction on contigs and ancient_contig_merge.  CPU: the oracle against goldens made by the reference's object code
+(tests/golden/make_golden.py contigs).  -m gpu: the device path against the same goldens, through the C ABI and the host binary."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from carpedeam_amd import mmdb
+from gpuutil import diff_keys, gold, run_oracle
+from stageflags import AC_FLAGS, KC_FLAGS, R_FLAGS
+from test_oracle_golden import pref_sign_ties
+
+CASES = [("mixed3k", 2, 0), ("mixed3k", 2, 1), ("synth2k", 1, 0), ("synth2k", 1, 1)]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cgold(name, stage, step):
+    return mmdb.load_keyed(os.path.join(ROOT, "tests", "golden", name, "%s_%d.keyed.gz" % (stage, step)))
+
+
+def contig_input(name, last_it, step):
+    return gold(name, "asm", last_it) if step == 0 else cgold(name, "cmerge", step - 1)
+
+
+@pytest.mark.parametrize("name,last_it,step", CASES)
+def test_oracle_contig_phase_matches_reference_goldens(oracle_bin, dhigh_prefix, tmp_path, name, last_it, step):
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_from_keyed(t("in"), contig_input(name, last_it, step), mmdb.DBTYPE_NUCLEOTIDES)
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *KC_FLAGS, "--threads", "2")
+    strip = lambda db: mmdb.canon({k: (v[0], 0) for k, v in db.items()})
+    ties, bad = pref_sign_ties(strip(mmdb.read_db(t("pref"))), strip(cgold(name, "cpref", step)))
+    assert not bad and sum(n for _, n in ties) <= 1
+    mmdb.write_from_keyed(t("pref_ref"), cgold(name, "cpref", step), mmdb.DBTYPE_PREFILTER_REV_RES)
+    mmdb.write_from_keyed(t("aln_ref"), cgold(name, "caln", step), mmdb.DBTYPE_ALIGNMENT_RES)
+    mmdb.write_from_keyed(t("corr_ref"), cgold(name, "ccorr", step), mmdb.DBTYPE_NUCLEOTIDES)
+    dmg = ["--ancient-damage", dhigh_prefix, "--threads", "2"]
+    run_oracle(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref_ref"), t("aln"), *R_FLAGS, "--threads", "2")
+    assert not diff_keys(mmdb.read_db(t("aln")), cgold(name, "caln", step))
+    run_oracle(oracle_bin, "ancient_correction", t("in"), t("aln_ref"), t("corr"), *AC_FLAGS, *dmg)
+    assert not diff_keys(mmdb.read_db(t("corr")), cgold(name, "ccorr", step))
+    run_oracle(oracle_bin, "ancient_contig_merge", t("corr_ref"), t("aln_ref"), t("merge"), *AC_FLAGS, *dmg)
+    want = cgold(name, "cmerge", step)
+    assert not diff_keys(mmdb.read_db(t("merge")), want)
+    assert len(diff_keys(want, cgold(name, "ccorr", step))) > 50          # contigs were merged in this step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,last_it,step", CASES)
+def test_device_contig_phase_matches_reference_goldens(dhigh_prefix, tmp_path, name, last_it, step):
+    from carpedeam_amd import capi
+    from gpuutil import seqdb_to_keyed
+    ctx = capi.Ctx(0)
+    ctx.damage_load(dhigh_prefix)
+    db = ctx.upload_keyed_seqdb(contig_input(name, last_it, step))
+    lens, keys, _ = db.meta()
+    kp = capi.KmerParams.reads_default()
+    kp.kmer_size, kp.include_only_extendable = 22, 1
+    hoff, hrec = ctx.kmermatch(db, kp).download()
+    strip = lambda db_: mmdb.canon({k: (v[0], 0) for k, v in db_.items()})
+    ties, bad = pref_sign_ties(mmdb.canon({k: (v, 0) for k, v in capi.hits_to_text(hoff, hrec, keys).items()}), strip(cgold(name, "cpref", step)))
+    assert not bad and sum(n for _, n in ties) <= 1
+    # downstream stages consume the reference's own upstream DBs (stage isolation)
+    off, rec = capi.parse_pref_db(cgold(name, "cpref", step), keys)
+    alns = ctx.rescore(db, ctx.upload_hits(db, off, rec))
+    aoff, arec = alns.download()
+    assert not diff_keys({k: (v, 0) for k, v in capi.alns_to_text(aoff, arec, keys, lens, db.residues).items()}, cgold(name, "caln", step))
+    aoff, arec = capi.parse_aln_db(cgold(name, "caln", step), keys)
+    alns = ctx.upload_alns(db, aoff, arec)
+    assert not diff_keys(seqdb_to_keyed(*ctx.correct(db, alns).download()), cgold(name, "ccorr", step))
+    corr = ctx.upload_keyed_seqdb(cgold(name, "ccorr", step))
+    merged = ctx.contig_merge(corr, ctx.upload_alns(corr, aoff, arec))
+    assert not diff_keys(seqdb_to_keyed(*merged.download()), cgold(name, "cmerge", step))
+
+
+@pytest.mark.gpu
+def test_contig_merge_module_on_db_files(dhigh_prefix, tmp_path):
+    from carpedeam_amd import build
+    build.build()
+    exe = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_from_keyed(t("corr"), cgold("mixed3k", "ccorr", 1), mmdb.DBTYPE_NUCLEOTIDES)
+    mmdb.write_from_keyed(t("aln"), cgold("mixed3k", "caln", 1), mmdb.DBTYPE_ALIGNMENT_RES)
+    r = subprocess.run([exe, "ancient_contig_merge", t("corr"), t("aln"), t("out"), *AC_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert not diff_keys(mmdb.read_db(t("out")), cgold("mixed3k", "cmerge", 1))
+    r = subprocess.run([exe, "ancient_contig_merge", t("corr"), t("aln"), t("out2"), *[f if f != "0" or i == 0 or AC_FLAGS[i - 1] != "--unsafe" else "1" for i, f in enumerate(AC_FLAGS)],
+                        "--ancient-damage", dhigh_prefix], capture_output=True, text=True)
+    assert r.returncode != 0 and "--unsafe 1 is not implemented for the contig phase" in r.stderr
