@@ -341,7 +341,7 @@ int readsLoop(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam ancient_reads_loop <i:sequenceDB> <o:sequenceDB> --ancient-damage <prefix> [--num-iter-reads-only N]");
     {   // the workflow's own flags for the reads loop (src/commons/LocalParameters.h:283-318) on top of the stage lists
         static const char *const LOOP_FLAGS[] = {"--k-ancient-reads", "--kmer-per-seq-ancient", "--kmer-per-seq-scale-ancient", "--hash-shift", "--include-only-extendable-ancient-reads",
-                                                 "-e", "--num-iter-reads-only", "--shuffle", NULL};
+                                                 "-e", "--num-iter-reads-only", "--shuffle", "--num-iterations", "--k-ancient-contigs", "--include-only-extendable-ancient-contigs", NULL};
         checkFlags("ancient_reads_loop", a, ANCIENT_FLAGS, LOOP_FLAGS);
     }
     // input: a sequence DB, or - when there is no <input>.index - FASTA/FASTQ[.gz] reads, parsed and laid out as createdb would
@@ -373,13 +373,22 @@ int readsLoop(Args &a) {
     cdm_ancient_params ap = ancientParams(a);
     if (!a.flag.count("--max-seq-len")) ap.max_seq_len = 200000;   // setGuidedNuclAssemblerWorkflowDefaults (GuidedNuclassembler.cpp:29)
     const long iters = iflag(a, "--num-iter-reads-only", 5);       // LocalParameters.h:304
-    for (long it = 0; it < iters; it++) {
+    // --num-iterations N > --num-iter-reads-only M: the contig phase of the workflow loop (data/nuclassemble.sh:148-196) for the
+    // remaining N - M iterations - kmermatcher with the contig parameters (Nuclassembler.cpp:118-126), rescorediagonal,
+    // ancient_correction, ancient_contig_merge - without the cyclecheck step (not built: circular contigs stay in the DB)
+    const long total = std::max(iters, iflag(a, "--num-iterations", iters));
+    cdm_kmer_params kc = kp;
+    kc.kmer_size = (int) iflag(a, "--k-ancient-contigs", 22); kc.include_only_extendable = (int) iflag(a, "--include-only-extendable-ancient-contigs", 1);
+    const float mergeThr = fflag(a, "--min-merge-seq-id", 0.99f);
+    for (long it = 0; it < total; it++) {
         cdm_hits *hits = NULL; cdm_alns *alns = NULL; cdm_seqdb *corr = NULL, *next = NULL;
-        check(cdm_kmermatch(ctx, db, &kp, &hits), "kmermatcher");
+        const bool contigs = it >= iters;
+        check(cdm_kmermatch(ctx, db, contigs ? &kc : &kp, &hits), "kmermatcher");
         check(cdm_rescore(ctx, db, hits, &rp, &alns), "rescorediagonal");
         cdm_hits_free(hits);
         check(cdm_correct(ctx, db, alns, &ap, &corr), "ancient_correction");
-        check(cdm_extend(ctx, corr, alns, &ap, &next, NULL), "ancient_read_assemble");
+        if (contigs) check(cdm_contig_merge(ctx, corr, alns, &ap, mergeThr, &next), "ancient_contig_merge");
+        else check(cdm_extend(ctx, corr, alns, &ap, &next, NULL), "ancient_read_assemble");
         fprintf(stderr, "STEP: %ld  sequences %llu  residues %llu -> %llu  alignments %llu\n", it, (unsigned long long) cdm_seqdb_size(db),
                 (unsigned long long) cdm_seqdb_residues(db), (unsigned long long) cdm_seqdb_residues(next), (unsigned long long) cdm_alns_count(alns));
         cdm_alns_free(alns); cdm_seqdb_free(corr); cdm_seqdb_free(db);

@@ -88,3 +88,33 @@ def test_contig_merge_module_on_db_files(dhigh_prefix, tmp_path):
     r = subprocess.run([exe, "ancient_contig_merge", t("corr"), t("aln"), t("out2"), *[f if f != "0" or i == 0 or AC_FLAGS[i - 1] != "--unsafe" else "1" for i, f in enumerate(AC_FLAGS)],
                         "--ancient-damage", dhigh_prefix], capture_output=True, text=True)
     assert r.returncode != 0 and "--unsafe 1 is not implemented for the contig phase" in r.stderr
+
+
+@pytest.mark.gpu
+def test_fused_loop_through_both_phases(dhigh_prefix, tmp_path):
+    """`ancient_reads_loop --num-iter-reads-only 3 --num-iterations 5`: three reads iterations and two contig iterations in one process,
+    every intermediate in HBM, ends in the reference's own contig-phase golden (which chains its own DBs the same way)."""
+    from carpedeam_amd import build
+    build.build()
+    exe = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_from_keyed(t("in"), gold("mixed3k", "reads"), mmdb.DBTYPE_NUCLEOTIDES)
+    r = subprocess.run([exe, "ancient_reads_loop", t("in"), t("out"), "--ancient-damage", dhigh_prefix, "--num-iter-reads-only", "3", "--num-iterations", "5"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1000:]
+    bad = diff_keys(mmdb.read_db(t("out")), cgold("mixed3k", "cmerge", 1))
+    # the goldens chain the reference's own prefilter DBs (its run-dependent strand tie, DESIGN.md N1): what differs, if anything,
+    # must be what the oracle chain - the deterministic rule - differs in as well
+    if bad:
+        from gpuutil import run_oracle as ro
+        from conftest import ROOT as R2
+        oracle = os.path.join(R2, "oracle", "_build", "cdm_oracle")
+        from stageflags import A_FLAGS, K_FLAGS
+        cur = t("in")
+        for it in range(5):
+            kf, af = (K_FLAGS, A_FLAGS) if it < 3 else (KC_FLAGS, AC_FLAGS)
+            ro(oracle, "kmermatcher", cur, t("p"), *kf, "--threads", "4")
+            ro(oracle, "rescorediagonal", cur, cur, t("p"), t("a"), *R_FLAGS, "--threads", "4")
+            ro(oracle, "ancient_correction", cur, t("a"), t("c"), *af, "--ancient-damage", dhigh_prefix, "--threads", "4")
+            ro(oracle, "ancient_read_assemble" if it < 3 else "ancient_contig_merge", t("c"), t("a"), t("n%d" % it), *af, "--ancient-damage", dhigh_prefix, "--threads", "4")
+            cur = t("n%d" % it)
+        assert not diff_keys(mmdb.read_db(t("out")), mmdb.read_db(cur))
