@@ -51,7 +51,7 @@ EXPORTS = [
     "cdm_hits_download", "cdm_hits_free", "cdm_rescore", "cdm_alns_upload", "cdm_alns_count", "cdm_alns_download", "cdm_alns_free",
     "cdm_evalue", "cdm_bit_score", "cdm_correct", "cdm_extend",
     "cdm_kmermatch_part", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_sort", "cdm_kpart_vote", "cdm_kpart_cont_cap", "cdm_kpart_free", "cdm_dev_copy",
-    "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge",
+    "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck",
 ]
 
 
@@ -121,6 +121,7 @@ def lib():
         l.cdm_seqdb_from_packed_ext.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.POINTER(vp)]
         l.cdm_seqdb_copy_ext.argtypes = [vp, vp, vp]
         l.cdm_contig_merge.argtypes = [vp, vp, vp, C.POINTER(AncientParams), C.c_float, C.POINTER(vp)]
+        l.cdm_cyclecheck.argtypes = [vp, vp, C.c_uint32, C.c_int, C.POINTER(vp), C.POINTER(vp), vp]
         _lib = l
     return _lib
 
@@ -176,6 +177,8 @@ class SeqDb:
 
     def download(self):
         """-> (list of bytes sequences, keys, ext)"""
+        if self.n == 0:
+            return [], np.zeros(0, np.uint32), np.zeros(0, np.uint8)
         lens, keys, ext = self.meta()
         offs = np.zeros(self.n, np.uint64)
         offs[1:] = np.cumsum(lens[:-1].astype(np.uint64) + 1)
@@ -323,6 +326,14 @@ class Ctx:
         h = C.c_void_p()
         _check(lib().cdm_contig_merge(self.h, db.h, alns.h, C.byref(par), merge_seq_id, C.byref(h)))
         return SeqDb(self, h)
+
+    def cyclecheck(self, db, max_seq_len=65535, chop_cycle=False):
+        """(cyclic contigs [cut at the split diagonal if chop_cycle], the other contigs, split diagonal per contig)"""
+        import numpy as np
+        c, r = C.c_void_p(), C.c_void_p()
+        split = np.zeros(max(db.n, 1), dtype=np.uint32)
+        _check(lib().cdm_cyclecheck(self.h, db.h, max_seq_len, 1 if chop_cycle else 0, C.byref(c), C.byref(r), split.ctypes.data))
+        return SeqDb(self, c), SeqDb(self, r), split[:db.n]
 
     def from_packed_ext(self, codes_ptr, nmask_ptr, len_ptr, key_ptr, ext_ptr, n, words):
         h = C.c_void_p()

@@ -337,26 +337,32 @@ extern "C" int cdm_seqdb_synth(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, ui
 // ------------------------------------------------------------------------------------------------ multi-GPU hand-off
 #include "scan.h"
 namespace {
-__global__ void k_sel_words(const uint32_t *__restrict__ len, const uint8_t *__restrict__ ext, uint32_t n, uint32_t *__restrict__ selWords, uint32_t *__restrict__ selOne) {
+__global__ void k_sel_from_ext(const uint32_t *__restrict__ len, const uint8_t *__restrict__ ext, uint32_t n, uint32_t *__restrict__ sel) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sel[i] = ext[i] == 1 ? len[i] : 0xFFFFFFFFu;
+}
+__global__ void k_sel_words(const uint32_t *__restrict__ sel, uint32_t n, uint32_t *__restrict__ selWords, uint32_t *__restrict__ selOne) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
-    const bool s = i < n && ext[i] == 1;
-    selWords[i] = s ? (len[i] + 15) / 16 : 0; selOne[i] = s ? 1 : 0;
+    const bool s = i < n && sel[i] != 0xFFFFFFFFu;
+    selWords[i] = s ? (sel[i] + 15) / 16 : 0; selOne[i] = s ? 1 : 0;
 }
-__global__ void k_sel_meta(const cdm_seqdb src, const uint32_t *__restrict__ rank, const uint32_t *__restrict__ wordOff, uint32_t n, cdm_seqdb dst) {
+__global__ void k_sel_meta(const cdm_seqdb src, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ rank, const uint32_t *__restrict__ wordOff, uint32_t n, int extValue, cdm_seqdb dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || src.ext[i] != 1) return;
+    if (i >= n || sel[i] == 0xFFFFFFFFu) return;
     const uint32_t r = rank[i];
-    dst.len[r] = src.len[i]; dst.key[r] = src.key[i]; dst.ext[r] = 1; dst.hasN[r] = src.hasN[i]; dst.woff[r] = wordOff[i];
+    dst.len[r] = sel[i]; dst.key[r] = src.key[i]; dst.ext[r] = extValue < 0 ? src.ext[i] : (uint8_t) extValue; dst.hasN[r] = 0; dst.woff[r] = wordOff[i];
 }
-__global__ void k_sel_copy(const cdm_seqdb src, const uint32_t *__restrict__ wordOff, uint32_t n, cdm_seqdb dst) {
-    // one wave per selected sequence
+__global__ void k_sel_copy(const cdm_seqdb src, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ wordOff, uint32_t n, cdm_seqdb dst) {
+    // one wave per selected sequence; the kept prefix ends inside its last word: the letters behind it are cleared
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (i >= n || src.ext[i] != 1) return;
-    const uint32_t w = (src.len[i] + 15) / 16, s0 = src.woff[i], d0 = wordOff[i];
+    if (i >= n || sel[i] == 0xFFFFFFFFu) return;
+    const uint32_t L = sel[i], w = (L + 15) / 16, s0 = src.woff[i], d0 = wordOff[i], tail = L & 15u;
     for (uint32_t j = lane; j < w; j += 64) {
-        dst.codes[d0 + j] = src.codes[s0 + j];
-        reinterpret_cast<uint16_t *>(dst.nmask)[d0 + j] = reinterpret_cast<const uint16_t *>(src.nmask)[s0 + j];
+        uint32_t c = src.codes[s0 + j], m = reinterpret_cast<const uint16_t *>(src.nmask)[s0 + j];
+        if (j == w - 1 && tail) { c &= (1u << (2 * tail)) - 1u; m &= (1u << tail) - 1u; }
+        dst.codes[d0 + j] = c;
+        reinterpret_cast<uint16_t *>(dst.nmask)[d0 + j] = (uint16_t) m;
     }
 }
 __global__ void k_words_of(const uint32_t *__restrict__ len, uint32_t n, uint32_t *__restrict__ w, uint8_t *__restrict__ ext, uint8_t extValue, uint8_t *__restrict__ hasN) {
@@ -374,38 +380,46 @@ __global__ void k_mark_hasN(const uint32_t *__restrict__ woff, const uint32_t *_
 }
 }  // namespace
 extern "C" uint64_t cdm_seqdb_words(const cdm_seqdb *db) { return db->words; }
-extern "C" int cdm_seqdb_select_ext(cdm_ctx *ctx, const cdm_seqdb *db, cdm_seqdb **out) {
+// Sub-DB: sel[i] = 0xFFFFFFFF drops sequence i, any other value keeps its first sel[i] letters (<= len[i]); extValue < 0 keeps the
+// wasExtended flags.  The order of the kept sequences is kept.
+int cdm_seqdb_select(cdm_ctx *ctx, const cdm_seqdb *db, const uint32_t *sel, int extValue, cdm_seqdb **out) {
     CDM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t) db->n;
-    uint32_t *selWords = nullptr, *selOne = nullptr, *wordOff = nullptr, *rank = nullptr; void *tmp = nullptr;
-    if (cdmMalloc(&selWords, ((size_t) n + 1) * 4) != hipSuccess || cdmMalloc(&selOne, ((size_t) n + 1) * 4) != hipSuccess ||
-        cdmMalloc(&wordOff, ((size_t) n + 1) * 4) != hipSuccess || cdmMalloc(&rank, ((size_t) n + 1) * 4) != hipSuccess) { cdm_set_error("cdm_seqdb_select_ext: out of device memory"); return CDM_ERR_HIP; }
-    hipLaunchKernelGGL(k_sel_words, dim3((n + 256) / 256), dim3(256), 0, s, db->len, db->ext, n, selWords, selOne);
+    DevBuf<uint32_t> selWords, selOne, wordOff, rank;
+    if (!selWords.alloc((size_t) n + 1) || !selOne.alloc((size_t) n + 1) || !wordOff.alloc((size_t) n + 1) || !rank.alloc((size_t) n + 1)) { cdm_set_error("cdm_seqdb_select: out of device memory"); return CDM_ERR_HIP; }
+    hipLaunchKernelGGL(k_sel_words, dim3((n + 256) / 256), dim3(256), 0, s, sel, n, selWords.p, selOne.p);
     cdmscan::ScanTemp st1, st2;
-    if (cdmscan::exclusiveScan<uint32_t>(s, st1, selWords, wordOff, (size_t) n + 1) != CDM_OK || cdmscan::exclusiveScan<uint32_t>(s, st2, selOne, rank, (size_t) n + 1) != CDM_OK) {
-        cdmFree(selWords); cdmFree(selOne); cdmFree(wordOff); cdmFree(rank); return CDM_ERR_HIP;
-    }
+    if (cdmscan::exclusiveScan<uint32_t>(s, st1, selWords.p, wordOff.p, (size_t) n + 1) != CDM_OK || cdmscan::exclusiveScan<uint32_t>(s, st2, selOne.p, rank.p, (size_t) n + 1) != CDM_OK) return CDM_ERR_HIP;
     uint32_t m = 0, words = 0;
-    hipMemcpyAsync(&m, rank + n, 4, hipMemcpyDeviceToHost, s);
-    hipMemcpyAsync(&words, wordOff + n, 4, hipMemcpyDeviceToHost, s);
-    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_seqdb_select_ext failed"); return CDM_ERR_HIP; }
+    hipMemcpyAsync(&m, rank.p + n, 4, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(&words, wordOff.p + n, 4, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_seqdb_select failed"); return CDM_ERR_HIP; }
     cdm_seqdb *o = nullptr;
     int rc = cdm_seqdb_alloc(ctx, m, &o);
     if (rc == CDM_OK) rc = seqdb_alloc_codes(o, words);
-    if (rc != CDM_OK) { cdmFree(selWords); cdmFree(selOne); cdmFree(wordOff); cdmFree(rank); cdmFree(tmp); if (o) cdm_seqdb_free(o); return rc; }
-    hipLaunchKernelGGL(k_sel_meta, dim3((n + 255) / 256), dim3(256), 0, s, *db, rank, wordOff, n, *o);
-    hipLaunchKernelGGL(k_sel_copy, dim3((unsigned) (((uint64_t) n * 64 + 255) / 256)), dim3(256), 0, s, *db, wordOff, n, *o);
+    if (rc != CDM_OK) { if (o) cdm_seqdb_free(o); return rc; }
+    hipMemsetAsync(o->nmask, 0, (((uint64_t) words * 16 + 31) / 32 + 1) * 4, s);
+    if (n) hipLaunchKernelGGL(k_sel_meta, dim3((n + 255) / 256), dim3(256), 0, s, *db, sel, rank.p, wordOff.p, n, extValue, *o);
+    if (n) hipLaunchKernelGGL(k_sel_copy, dim3((unsigned) (((uint64_t) n * 64 + 255) / 256)), dim3(256), 0, s, *db, sel, wordOff.p, n, *o);
     hipMemcpyAsync(o->woff + m, &words, 4, hipMemcpyHostToDevice, s);
+    if (words && m) hipLaunchKernelGGL(k_mark_hasN, dim3((unsigned) (((uint64_t) words + 255) / 256)), dim3(256), 0, s, o->woff, o->nmask, m, (uint64_t) words, o->hasN);
     // residues / max length on the host (contig lists are small next to the read DB)
     std::vector<uint32_t> l(m);
     hipMemcpyAsync(l.data(), o->len, (size_t) m * 4, hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
-    cdmFree(selWords); cdmFree(selOne); cdmFree(wordOff); cdmFree(rank); cdmFree(tmp);
-    if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_select_ext: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
+    if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_select: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
     for (uint32_t v : l) { o->residues += v; o->maxLen = std::max(o->maxLen, v); }
     *out = o;
     return CDM_OK;
+}
+extern "C" int cdm_seqdb_select_ext(cdm_ctx *ctx, const cdm_seqdb *db, cdm_seqdb **out) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    const uint32_t n = (uint32_t) db->n;
+    DevBuf<uint32_t> sel;
+    if (!sel.alloc((size_t) n + 1)) { cdm_set_error("cdm_seqdb_select_ext: out of device memory"); return CDM_ERR_HIP; }
+    if (n) hipLaunchKernelGGL(k_sel_from_ext, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, db->len, db->ext, n, sel.p);
+    return cdm_seqdb_select(ctx, db, sel.p, 1, out);
 }
 extern "C" int cdm_seqdb_copy_packed(cdm_ctx *ctx, const cdm_seqdb *db, void *codes, void *nmask16, void *lengths, void *keys) {
     CDM_HIP(hipSetDevice(ctx->device));

@@ -124,6 +124,8 @@ struct cdm_alns {
 
 int cdm_seqdb_alloc_like(cdm_ctx *ctx, const cdm_seqdb *src, cdm_seqdb **out);  // same n/lengths/layout, codes uninitialised
 int cdm_seqdb_alloc(cdm_ctx *ctx, uint64_t n, cdm_seqdb **out);
+// sub-DB: sel[i] (device) = 0xFFFFFFFF drops sequence i, else keeps its first sel[i] letters; extValue < 0 keeps the wasExtended flags
+int cdm_seqdb_select(cdm_ctx *ctx, const cdm_seqdb *db, const uint32_t *sel, int extValue, cdm_seqdb **out);
 
 // ancient_contig_merge: what the device counts per alignment record (contig.hip) for the host part (host/contigmerge.cpp)
 struct ContigStat {            // per alignment record, oriented as :193-214 does

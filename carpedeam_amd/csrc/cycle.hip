@@ -1,0 +1,160 @@
+// cyclecheck (src/assembler/cyclecheck.cpp:30-269), SURVEY.md 8(f) rank 4: which contigs close on themselves.
+//
+// The reference cuts a contig into thirds by k-mer position, sorts the three k-mer lists and merges them: every middle/back
+// occurrence of a 22-mer against the FIRST front occurrence, every back occurrence against the FIRST middle occurrence, a hit
+// counter per diagonal >= L/3, then the first diagonal whose 1 % band holds more than 0.24 hits per possible k-mer.
+// Here: ONE stable radix sort of all contigs' (k-mer, global ordinal) pairs - the ordinals ascend with (contig, position), so a
+// contig's occurrences of a k-mer end up adjacent and in position order - and a thread per occurrence that looks BACK in its run:
+// the run head (gallop + bisect) is the first front occurrence, a bisect finds the first middle one.  No per-contig sort, no
+// LDS limit on the contig length.  Quirks kept (the oracle lists them): position 0 belongs to no third that matters, N is
+// letter 4 of a base-4 index (collisions included), the band arithmetic runs in the reference's types.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+#include "devutil.h"
+#include "scan.h"
+
+namespace {
+typedef unsigned long long u64;
+constexpr uint32_t CYC_K = 22;
+
+struct CycArgs {
+    const uint32_t *codes, *nmask, *woff, *len; const uint8_t *hasN;
+    uint32_t n, maxSeqLen;
+    const u64 *koff, *hoff;      // [n+1] first k-mer ordinal / first diagonal counter of each contig
+    u64 totalK, totalH;
+    u64 *keys; uint32_t *vals;   // sorted: (k-mer index, ordinal)
+    uint32_t *hits, *split;
+};
+__global__ void k_cyc_sizes(const uint32_t *__restrict__ len, uint32_t n, uint32_t maxSeqLen, u64 *__restrict__ nk, u64 *__restrict__ nh) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const uint32_t L = i < n ? len[i] : 0;
+    const bool use = i < n && L >= CYC_K && L < maxSeqLen;          // :107-112: too long a contig is skipped
+    nk[i] = use ? L - CYC_K + 1 : 0; nh[i] = use ? 2 * (L / 3) + 1 : 0;
+}
+__device__ __forceinline__ uint32_t ownerOf(const u64 *__restrict__ off, uint32_t n, u64 g) {     // last i with off[i] <= g
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
+    return lo;
+}
+// Indexer::int2index over alphabetSize - 1 = 4 (Indexer.h:76-80): sum of letter_j * 4^j, letters in MMseqs2's order A,C,T,G = 0..3, N = 4
+__global__ __launch_bounds__(256) void k_cyc_kmers(CycArgs a) {
+    const u64 g = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.totalK) return;
+    const uint32_t i = ownerOf(a.koff, a.n, g), pos = (uint32_t) (g - a.koff[i]);
+    const uint32_t w0 = a.woff[i], last = (a.len[i] + 15) / 16 - 1;
+    u64 x = (u64) cdm_window16(a.codes, w0, pos, last) | ((u64) (cdm_window16(a.codes, w0, pos + 16, last) & 0xFFFu) << 32);
+    x ^= (x >> 1) & 0x5555555555555555ull;                         // A,C,G,T -> A,C,T,G
+    if (a.hasN[i]) {
+        const u64 bit = (u64) w0 * 16u + pos;
+        const u64 m = (u64) a.nmask[bit >> 5] | ((u64) a.nmask[(bit >> 5) + 1] << 32);
+        const uint32_t nw = (uint32_t) (m >> (bit & 31u)) & 0x3FFFFFu;
+        const u64 sp = (u64) cdm_spread16(nw) | ((u64) cdm_spread16(nw >> 16) << 32);
+        x = (x & ~(sp * 3u)) + (sp << 2);
+    }
+    a.keys[g] = x; a.vals[g] = (uint32_t) g;
+}
+__global__ __launch_bounds__(256) void k_cyc_hits(CycArgs a) {
+    const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 || i >= a.totalK) return;
+    const u64 key = a.keys[i];
+    if (a.keys[i - 1] != key) return;
+    const uint32_t g = a.vals[i], c = ownerOf(a.koff, a.n, g);
+    const uint32_t base = (uint32_t) a.koff[c], pos = g - base, L = a.len[c], third = L / 3;
+    if (pos < third + 2 || a.vals[i - 1] < base) return;           // a front occurrence (or position 0) matches nothing before it; alone in its run
+    // head of the run (same k-mer, same contig): gallop back, then bisect.  in(j) is monotone on [0, i]
+    u64 lo = i - 1, step = 1, out = ~0ull;                         // lo: known inside; out: known outside (or -1)
+    while (true) {
+        if (lo < step) { out = ~0ull; break; }
+        const u64 j = lo - step;
+        if (a.keys[j] == key && a.vals[j] >= base) { lo = j; step <<= 1; } else { out = j; break; }
+    }
+    while (lo - out > 1) { const u64 mid = out + ((lo - out) >> 1); if (a.keys[mid] == key && a.vals[mid] >= base) lo = mid; else out = mid; }   // ~0 + 1 wraps to 0: fine
+    u64 first = lo;
+    uint32_t pf = a.vals[first] - base;
+    if (pf == 0) { first++; pf = a.vals[first] - base; }            // first <= i
+    uint32_t *hits = a.hits + a.hoff[c];
+    if (pf >= 1 && pf <= third + 1 && pos - pf >= third) atomicAdd(&hits[pos - pf - third], 1u);
+    if (pos >= 2 * third + 2) {                                      // a back occurrence: also against the first middle one
+        u64 l = first, h = i;                                        // first j in [first, i) with position >= third + 2
+        while (l < h) { const u64 mid = l + ((h - l) >> 1); if (a.vals[mid] - base >= third + 2) h = mid; else l = mid + 1; }
+        if (l < i) {
+            const uint32_t pm = a.vals[l] - base;
+            if (pm <= 2 * third + 1 && pos - pm >= third) atomicAdd(&hits[pos - pm - third], 1u);
+        }
+    }
+}
+// :225-245: the first diagonal whose band of +-1 % of the diagonal's length holds more than 0.24 hits per k-mer position
+__global__ __launch_bounds__(256) void k_cyc_band(CycArgs a) {
+    const u64 x = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= a.totalH) return;
+    const uint32_t hd = a.hits[x];
+    if (hd == 0) return;
+    const uint32_t c = ownerOf(a.hoff, a.n, x), d = (uint32_t) (x - a.hoff[c]), L = a.len[c], third = L / 3;
+    if (d >= 2 * third) return;
+    const uint32_t *hits = a.hits + a.hoff[c];
+    const uint32_t diag = d + third, diaglen = L - diag;
+    const uint32_t gap = (uint32_t) ((double) diaglen * 0.01);
+    const uint32_t lower = (uint32_t) max(0, (int) (d - gap)), upper = min(d + gap, 2 * third);
+    uint32_t band = 0;
+    for (uint32_t y = lower; y <= upper; y++) { const uint32_t h = hits[y]; if (h <= hd) band += h; }
+    const float rate = __fdiv_rn((float) band, (float) (u64) (diaglen - CYC_K + 1));
+    if ((double) rate > 0.24) atomicMin(&a.split[c], d);
+}
+__global__ void k_cyc_select(const uint32_t *__restrict__ len, const uint32_t *__restrict__ split, uint32_t n, int chop, uint32_t *__restrict__ selCyc, uint32_t *__restrict__ selRest,
+                             uint32_t *__restrict__ splitOut) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool cyc = split[i] != 0xFFFFFFFFu;
+    const uint32_t at = cyc ? split[i] + len[i] / 3 : 0;
+    selCyc[i] = cyc ? (chop ? at : len[i]) : 0xFFFFFFFFu;
+    selRest[i] = cyc ? 0xFFFFFFFFu : len[i];
+    splitOut[i] = at;
+}
+}  // namespace
+
+extern "C" int cdm_cyclecheck(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t maxSeqLen, int chopCycle, cdm_seqdb **cyclic, cdm_seqdb **rest, uint32_t *splitHost) {
+    if (!ctx || !db || !cyclic) { cdm_set_error("cdm_cyclecheck: NULL argument"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t) db->n;
+    DevBuf<u64> nk, nh, koff, hoff;
+    DevBuf<uint32_t> split, selCyc, selRest, splitOut;
+    if (!nk.alloc((size_t) n + 1) || !nh.alloc((size_t) n + 1) || !koff.alloc((size_t) n + 1) || !hoff.alloc((size_t) n + 1) || !split.alloc(n) || !selCyc.alloc(n) ||
+        !selRest.alloc(n) || !splitOut.alloc(n)) { cdm_set_error("cdm_cyclecheck: out of device memory"); return CDM_ERR_HIP; }
+    hipLaunchKernelGGL(k_cyc_sizes, dim3((n + 256) / 256), dim3(256), 0, s, db->len, n, maxSeqLen, nk.p, nh.p);
+    cdmscan::ScanTemp st1, st2;
+    if (cdmscan::exclusiveScan<u64>(s, st1, nk.p, koff.p, (size_t) n + 1) != CDM_OK || cdmscan::exclusiveScan<u64>(s, st2, nh.p, hoff.p, (size_t) n + 1) != CDM_OK) return CDM_ERR_HIP;
+    u64 totalK = 0, totalH = 0;
+    hipMemcpyAsync(&totalK, koff.p + n, 8, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(&totalH, hoff.p + n, 8, hipMemcpyDeviceToHost, s);
+    CDM_HIP(hipStreamSynchronize(s));
+    if (totalK >= 0xFFFFFFFFull) { cdm_set_error("cdm_cyclecheck: more than 2^32-1 k-mer positions (%llu)", totalK); return CDM_ERR_UNSUPPORTED; }
+    CDM_HIP(hipMemsetAsync(split.p, 0xFF, (size_t) n * 4 + 4, s));
+    DevBuf<u64> k0, k1; DevBuf<uint32_t> v0, v1, hits; DevBuf<char> tmp;
+    CycArgs a = {db->codes, db->nmask, db->woff, db->len, db->hasN, n, maxSeqLen, koff.p, hoff.p, totalK, totalH, nullptr, nullptr, nullptr, split.p};
+    if (totalK) {
+        if (!k0.alloc(totalK) || !k1.alloc(totalK) || !v0.alloc(totalK) || !v1.alloc(totalK) || !hits.alloc(totalH)) { cdm_set_error("cdm_cyclecheck: out of device memory"); return CDM_ERR_HIP; }
+        CDM_HIP(hipMemsetAsync(hits.p, 0, (totalH + 1) * 4, s));
+        a.keys = k0.p; a.vals = v0.p; a.hits = hits.p;
+        hipLaunchKernelGGL(k_cyc_kmers, dim3((unsigned) ((totalK + 255) / 256)), dim3(256), 0, s, a);
+        rocprim::double_buffer<u64> kb(k0.p, k1.p); rocprim::double_buffer<uint32_t> vb(v0.p, v1.p);
+        size_t tb = 0;
+        if (rocprim::radix_sort_pairs(nullptr, tb, kb, vb, (size_t) totalK, 0, 2 * CYC_K + 2, s) != hipSuccess || !tmp.alloc(tb + 256)) { cdm_set_error("cdm_cyclecheck: sort set-up failed"); return CDM_ERR_HIP; }
+        if (rocprim::radix_sort_pairs(tmp.p, tb, kb, vb, (size_t) totalK, 0, 2 * CYC_K + 2, s) != hipSuccess) { cdm_set_error("cdm_cyclecheck: sort failed"); return CDM_ERR_HIP; }
+        a.keys = kb.current(); a.vals = vb.current();
+        hipLaunchKernelGGL(k_cyc_hits, dim3((unsigned) ((totalK + 255) / 256)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_cyc_band, dim3((unsigned) ((totalH + 255) / 256)), dim3(256), 0, s, a);
+    }
+    if (n) hipLaunchKernelGGL(k_cyc_select, dim3((n + 255) / 256), dim3(256), 0, s, db->len, split.p, n, chopCycle, selCyc.p, selRest.p, splitOut.p);
+    if (splitHost && n) CDM_HIP(hipMemcpyAsync(splitHost, splitOut.p, (size_t) n * 4, hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipStreamSynchronize(s));
+    cdm_seqdb *c = nullptr, *r = nullptr;
+    int rc = cdm_seqdb_select(ctx, db, selCyc.p, 0, &c);            // DBWriter::writeData's default: wasExtended = false (:251)
+    if (rc == CDM_OK && rest) rc = cdm_seqdb_select(ctx, db, selRest.p, -1, &r);
+    if (rc != CDM_OK) { if (c) cdm_seqdb_free(c); if (r) cdm_seqdb_free(r); return rc; }
+    *cyclic = c; if (rest) *rest = r;
+    return CDM_OK;
+}

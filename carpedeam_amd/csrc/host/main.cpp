@@ -103,8 +103,21 @@ cdm_seqdb *uploadSeqDb(cdm_ctx *ctx, const MmDb &db) {
     check(cdm_seqdb_upload(ctx, db.data(), db.off.data(), lens.data(), db.key.data(), db.ext.data(), db.size(), &h), "Can not load the sequence DB");
     return h;
 }
+// the entries of a device DB as DB payloads ("SEQ\n"), appended to c
+void appendEntries(cdm_ctx *ctx, cdm_seqdb *h, OutChunk &c) {
+    const uint64_t n = cdm_seqdb_size(h);
+    if (n == 0) return;
+    std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
+    check(cdm_seqdb_meta(ctx, h, lens.data(), keys.data(), ext.data()), "meta");
+    std::vector<uint64_t> offs(n); uint64_t tot = 0;
+    for (uint64_t i = 0; i < n; i++) { offs[i] = tot; tot += lens[i] + 2; }
+    std::string buf(tot, '\0');
+    check(cdm_seqdb_download(ctx, h, &buf[0], offs.data()), "download");
+    for (uint64_t i = 0; i < n; i++) c.add(keys[i], buf.data() + offs[i], lens[i] + 1, ext[i]);
+}
 void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) {
     const uint64_t n = cdm_seqdb_size(h);
+    if (n == 0) { std::string err; if (!mmdbWriteChunks(path, dbtype, std::vector<OutChunk>(1), &err)) die(err); return; }
     std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
     check(cdm_seqdb_meta(ctx, h, lens.data(), keys.data(), ext.data()), "meta");
     // the download buffer has the data file's layout already: "SEQ\n\0" per entry (the NULs are the buffer's zero fill)
@@ -333,6 +346,21 @@ int ancientModule(Args &a, int mode) {      // 0 ancient_correction, 1 ancient_r
     cdm_seqdb_free(out); cdm_alns_free(alns); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
+// cyclecheck <i:sequenceDB> <o:sequenceDBcycle> (src/assembler/cyclecheck.cpp:30-269; flags: LocalParameters.h:183-187)
+const FlagSpec CYCLECHECK_FLAGS[] = {{"--max-seq-len", 'U', 0, 0}, {"--chop-cycle", 'U', 0, 0}, {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0}, {0, 0, 0, 0}};
+int cyclecheck(Args &a) {
+    if (a.pos.size() < 2) die("Usage: carpedeam cyclecheck <i:sequenceDB> <o:sequenceDBcycle>");
+    checkFlags("cyclecheck", a, CYCLECHECK_FLAGS);
+    MmDb seq; std::string err; if (!seq.load(a.pos[0], &err)) die(err);
+    if ((seq.dbtype & 0x7FFFFFFF) != 1) die("Module cyclecheck only supports nucleotide input database");
+    cdm_ctx *ctx = openCtx();
+    cdm_seqdb *db = uploadSeqDb(ctx, seq), *cyc = NULL;
+    const long maxLen = std::min(iflag(a, "--max-seq-len", 65535), 0xFFFFFFFFl);
+    check(cdm_cyclecheck(ctx, db, (uint32_t) maxLen, iflag(a, "--chop-cycle", 0) != 0, &cyc, NULL, NULL), "cyclecheck");
+    writeSeqDb(ctx, cyc, a.pos[1], 1);
+    cdm_seqdb_free(cyc); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
+    return EXIT_SUCCESS;
+}
 // Fused reads loop: the body of `while [ $STEP -lt $NUM_IT_READS ]` of data/nuclassemble.sh:100-146
 // - kmermatcher, rescorediagonal, ancient_correction, ancient_read_assemble per iteration - in one process with every
 // intermediate resident in HBM; no prefilter/alignment/correction text DB is written, only the final sequence DB.
@@ -341,7 +369,8 @@ int readsLoop(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam ancient_reads_loop <i:sequenceDB> <o:sequenceDB> --ancient-damage <prefix> [--num-iter-reads-only N]");
     {   // the workflow's own flags for the reads loop (src/commons/LocalParameters.h:283-318) on top of the stage lists
         static const char *const LOOP_FLAGS[] = {"--k-ancient-reads", "--kmer-per-seq-ancient", "--kmer-per-seq-scale-ancient", "--hash-shift", "--include-only-extendable-ancient-reads",
-                                                 "-e", "--num-iter-reads-only", "--shuffle", "--num-iterations", "--k-ancient-contigs", "--include-only-extendable-ancient-contigs", NULL};
+                                                 "-e", "--num-iter-reads-only", "--shuffle", "--num-iterations", "--k-ancient-contigs", "--include-only-extendable-ancient-contigs",
+                                                 "--cycle-check", "--chop-cycle", NULL};
         checkFlags("ancient_reads_loop", a, ANCIENT_FLAGS, LOOP_FLAGS);
     }
     // input: a sequence DB, or - when there is no <input>.index - FASTA/FASTQ[.gz] reads, parsed and laid out as createdb would
@@ -375,12 +404,16 @@ int readsLoop(Args &a) {
     const long iters = iflag(a, "--num-iter-reads-only", 5);       // LocalParameters.h:304
     // --num-iterations N > --num-iter-reads-only M: the contig phase of the workflow loop (data/nuclassemble.sh:148-196) for the
     // remaining N - M iterations - kmermatcher with the contig parameters (Nuclassembler.cpp:118-126), rescorediagonal,
-    // ancient_correction, ancient_contig_merge - without the cyclecheck step (not built: circular contigs stay in the DB)
+    // ancient_correction, ancient_contig_merge, and the script's cyclecheck() (:19-60; --cycle-check / --chop-cycle, both on by default
+    // as setNuclAssemblerWorkflowDefaults has them): circular contigs leave the loop, cut at their split diagonal, and join the output
+    // at the end (concatdbs, :204-212)
     const long total = std::max(iters, iflag(a, "--num-iterations", iters));
     cdm_kmer_params kc = kp;
     kc.kmer_size = (int) iflag(a, "--k-ancient-contigs", 22); kc.include_only_extendable = (int) iflag(a, "--include-only-extendable-ancient-contigs", 1);
     const float mergeThr = fflag(a, "--min-merge-seq-id", 0.99f);
-    for (long it = 0; it < total; it++) {
+    const bool cycleCheck = iflag(a, "--cycle-check", 1) != 0, chopCycle = iflag(a, "--chop-cycle", 1) != 0;
+    OutChunk cyclic;
+    for (long it = 0; it < total && cdm_seqdb_size(db) > 0; it++) {
         cdm_hits *hits = NULL; cdm_alns *alns = NULL; cdm_seqdb *corr = NULL, *next = NULL;
         const bool contigs = it >= iters;
         check(cdm_kmermatch(ctx, db, contigs ? &kc : &kp, &hits), "kmermatcher");
@@ -393,8 +426,30 @@ int readsLoop(Args &a) {
                 (unsigned long long) cdm_seqdb_residues(db), (unsigned long long) cdm_seqdb_residues(next), (unsigned long long) cdm_alns_count(alns));
         cdm_alns_free(alns); cdm_seqdb_free(corr); cdm_seqdb_free(db);
         db = next;
+        if (contigs && cycleCheck) {
+            cdm_seqdb *cyc = NULL, *rest = NULL;
+            check(cdm_cyclecheck(ctx, db, (uint32_t) std::min<uint64_t>(ap.max_seq_len, 0xFFFFFFFFull), chopCycle, &cyc, &rest, NULL), "cyclecheck");
+            if (cdm_seqdb_size(cyc)) fprintf(stderr, "         %llu circular contigs set aside\n", (unsigned long long) cdm_seqdb_size(cyc));
+            appendEntries(ctx, cyc, cyclic);
+            cdm_seqdb_free(cyc); cdm_seqdb_free(db);
+            db = rest;
+        }
     }
-    writeSeqDb(ctx, db, a.pos[1], dbtype);
+    if (cyclic.key.empty()) writeSeqDb(ctx, db, a.pos[1], dbtype);
+    else {   // concatdbs --preserve-keys of the linear and the circular contigs, written in key order
+        OutChunk all; appendEntries(ctx, db, all);
+        std::vector<std::pair<uint32_t, std::pair<const OutChunk *, size_t>>> order;
+        std::vector<size_t> offA(all.key.size() + 1, 0), offC(cyclic.key.size() + 1, 0);
+        for (size_t i = 0; i < all.key.size(); i++) { offA[i + 1] = offA[i] + all.len[i]; order.push_back({all.key[i], {&all, i}}); }
+        for (size_t i = 0; i < cyclic.key.size(); i++) { offC[i + 1] = offC[i] + cyclic.len[i]; order.push_back({cyclic.key[i], {&cyclic, i}}); }
+        std::stable_sort(order.begin(), order.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+        std::vector<OutChunk> merged(1);
+        for (const auto &o : order) {
+            const OutChunk &c = *o.second.first; const size_t i = o.second.second;
+            merged[0].add(o.first, c.data.data() + (&c == &all ? offA[i] : offC[i]), c.len[i] - 1, c.ext[i]);
+        }
+        if (!mmdbWriteChunks(a.pos[1], dbtype, merged, &err)) die(err);
+    }
     cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
@@ -431,7 +486,7 @@ int createhdb(Args &a) {
 }  // namespace
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: carpedeam <kmermatcher|rescorediagonal|ancient_correction|ancient_read_assemble|ancient_reads_loop|createdb|convert2fasta|createhdb> <args>\n"); return EXIT_FAILURE; }
+    if (argc < 2) { fprintf(stderr, "usage: carpedeam <kmermatcher|rescorediagonal|ancient_correction|ancient_read_assemble|ancient_contig_merge|cyclecheck|ancient_reads_loop|createdb|convert2fasta|createhdb> <args>\n"); return EXIT_FAILURE; }
     const std::string cmd = argv[1];
     Args a = parse(argc - 2, argv + 2);
     {   // --threads / MMSEQS_NUM_THREADS as in Parameters.cpp:2121-2132: the host side (DB parsing, text codecs) uses them
@@ -451,6 +506,7 @@ int main(int argc, char **argv) {
     else if (cmd == "createdb") rc = createdb(a);
     else if (cmd == "convert2fasta") rc = convert2fasta(a);
     else if (cmd == "createhdb") rc = createhdb(a);
+    else if (cmd == "cyclecheck") rc = cyclecheck(a);
     else { fprintf(stderr, "Invalid Command: %s\n", cmd.c_str()); return EXIT_FAILURE; }
     fprintf(stderr, "Time for processing: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return rc;

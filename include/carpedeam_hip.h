@@ -250,6 +250,15 @@ int cdm_extend(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cd
 int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float merge_seq_id_thr,
                      cdm_seqdb **out);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * cyclecheck (data/nuclassemble.sh:19-60, after every contig iteration).  Replaces the loop at src/assembler/cyclecheck.cpp:75-258
+ * (k = 22 as setCycleCheckDefaults fixes it): *cyclic receives the contigs the module writes - cut at the split diagonal when
+ * chop_cycle (--chop-cycle) is set, whole otherwise, wasExtended 0 - and, if rest is not NULL, *rest the others (what the workflow's
+ * "_noneCycle" index selects), both in the order of db.  Contigs of max_seq_len (--max-seq-len) letters or more are never cyclic
+ * (:107-112).  split (host, db size entries, may be NULL) receives the split diagonal of every contig, 0 = not cyclic.
+ */
+int cdm_cyclecheck(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t max_seq_len, int chop_cycle, cdm_seqdb **cyclic, cdm_seqdb **rest, uint32_t *split);
+
 #ifdef __cplusplus
 }
 #endif

@@ -737,6 +737,78 @@ static int doAssemble(const std::string &seqPath, const std::string &alnPath, co
     return 0;
 }
 
+// ----------------------------------------------------------------------------- F4: cyclecheck
+// src/assembler/cyclecheck.cpp:30-269.  Kept literally: the k-mer at sequence position 0 is filed under "back" (getCurrentPosition() is -1
+// before the first nextKmer() and is compared as unsigned, :117-140); only the FIRST front / middle occurrence of a k-mer is matched
+// (:167-169, :190-192); the index is the arithmetic sum of letter * 4^i with N = 4 (Indexer over alphabetSize-1, :88), so k-mers with N can
+// collide with others; the band test runs in the reference's types (unsigned / size_t / float / double, :216-238).
+static int doCycleCheck(const std::string &seqPath, const std::string &outPath, size_t maxSeqLen, bool chopCycle) {
+    Db seq; seq.load(seqPath);
+    DbOut out; out.init(seq.size());
+    const size_t kmerSize = 22;
+    struct KP { size_t kmer; unsigned pos; };
+    auto byKmer = [](const KP &a, const KP &b) { if (a.kmer < b.kmer) return true; if (b.kmer < a.kmer) return false; return a.pos < b.pos; };
+    std::vector<KP> front, middle, back; std::vector<unsigned> diagHits;
+    for (size_t id = 0; id < seq.size(); id++) {
+        const char *nucl = seq.getData(id);
+        unsigned seqLen = seq.seqLen(id);
+        if (seqLen >= maxSeqLen) continue;                                         // :107-112 (a warning, the entry is skipped)
+        front.clear(); middle.clear(); back.clear();
+        unsigned thirdSeqLen = seqLen / 3;
+        for (int cur = -1; (size_t) ((cur + 1) + (int) kmerSize) <= (size_t) seqLen; ) {   // Sequence::hasNextKmer / nextKmer
+            unsigned pos = (unsigned) cur;                                          // getCurrentPosition() BEFORE nextKmer()
+            cur++;
+            size_t idx = 0, pw = 1;
+            for (size_t i = 0; i < kmerSize; i++) { idx += (size_t) AA2NUM[(unsigned char) nucl[cur + i]] * pw; pw *= 4; }
+            KP e = {idx, (unsigned) cur};
+            if (pos < thirdSeqLen + 1) front.push_back(e); else if (pos < 2 * thirdSeqLen + 1) middle.push_back(e); else back.push_back(e);
+        }
+        std::sort(front.begin(), front.end(), byKmer); std::sort(middle.begin(), middle.end(), byKmer); std::sort(back.begin(), back.end(), byKmer);
+        unsigned kmermatches = 0;
+        diagHits.assign(2 * (size_t) thirdSeqLen + 1, 0);
+        size_t i = 0, j = 0, k = 0;
+        while (i < front.size() && (j < back.size() || k < middle.size())) {       // :152-193
+            size_t km = front[i].kmer; unsigned pos = front[i].pos;
+            while (j < back.size() && back[j].kmer < km) j++;
+            while (k < middle.size() && middle[k].kmer < km) k++;
+            while (j < back.size() && km == back[j].kmer) { int diag = back[j].pos - pos; if (diag >= static_cast<int>(seqLen / 3)) { diagHits[diag - seqLen / 3]++; kmermatches++; } j++; }
+            while (k < middle.size() && km == middle[k].kmer) { int diag = middle[k].pos - pos; if (diag >= static_cast<int>(seqLen / 3)) { diagHits[diag - seqLen / 3]++; kmermatches++; } k++; }
+            i++;
+            while (i < front.size() && km == front[i].kmer) i++;
+        }
+        j = 0; k = 0;
+        while (k < middle.size() && j < back.size()) {                             // :196-220
+            if (middle[k].kmer < back[j].kmer) k++;
+            else if (middle[k].kmer > back[j].kmer) j++;
+            else {
+                size_t km = middle[k].kmer; unsigned pos = middle[k].pos;
+                while (j < back.size() && km == back[j].kmer) { int diag = back[j].pos - pos; if (diag >= static_cast<int>(seqLen / 3)) { diagHits[diag - seqLen / 3]++; kmermatches++; } j++; }
+                while (k < middle.size() && km == middle[k].kmer) k++;
+            }
+        }
+        unsigned splitDiagonal = 0;
+        if (kmermatches > 0) {
+            for (unsigned d = 0; d < 2 * thirdSeqLen; d++) {                       // :225-245
+                if (diagHits[d] == 0) continue;
+                unsigned diag = d + thirdSeqLen, diaglen = seqLen - diag;
+                unsigned gapwindow = diaglen * 0.01;
+                unsigned lower = std::max(0, static_cast<int>(d - gapwindow));
+                unsigned upper = std::min(d + gapwindow, 2 * thirdSeqLen);
+                unsigned band = 0;
+                for (size_t x = lower; x <= upper; x++) if (diagHits[x] <= diagHits[d]) band += diagHits[x];
+                float rate = static_cast<float>(band) / (diaglen - kmerSize + 1);
+                if (rate > 0.24) { splitDiagonal = diag; break; }
+            }
+        }
+        if (splitDiagonal != 0) {
+            std::string payload = chopCycle ? std::string(nucl, splitDiagonal) + "\n" : std::string(nucl, seq.len[id] - 1);
+            out.set(id, seq.key[id], payload, 0);
+        }
+    }
+    out.write(outPath, 1);
+    return 0;
+}
+
 // ----------------------------------------------------------------------------- F1: ancient_contig_merge
 // src/assembler/ancientContigsResults.cpp:25-70.  NOT a strict weak ordering (the fall-through `return true`); the queue below is
 // libstdc++'s std::priority_queue with this very comparator, as in the reference.  Overload resolution as there (libgab.h has
@@ -1399,6 +1471,9 @@ int main(int argc, char **argv) {
         AncientPar p = ancientPar(flags); rc = doAssemble(pos[0], pos[1], pos[2], p);
     } else if (cmd == "ancient_contig_merge" && pos.size() >= 3) {
         AncientPar p = ancientPar(flags); rc = doContigMerge(pos[0], pos[1], pos[2], p);
+    } else if (cmd == "cyclecheck" && pos.size() >= 2) {
+        size_t maxSeqLen = flags.count("--max-seq-len") ? strtoull(flags["--max-seq-len"].c_str(), NULL, 10) : 65535;
+        rc = doCycleCheck(pos[0], pos[1], maxSeqLen, flags.count("--chop-cycle") && atoi(flags["--chop-cycle"].c_str()) != 0);
     } else { fprintf(stderr, "unknown/incomplete command %s\n", cmd.c_str()); return 2; }
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "Time for processing: %.3fs\n", sec);

@@ -170,7 +170,7 @@ def main():
         chain(tmp, "example", seqs, 1, prefix, 4)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("createdb", "contigs")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("createdb", "contigs", "cycle")):
     main()
 
 
@@ -238,3 +238,60 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "createdb":
     createdb_digests()
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "contigs":
     contig_goldens()
+
+
+def cycle_goldens(threads=4):
+    """tests/golden/cycle/: the reference's cyclecheck on the contig set of tests/cyclecases.py (whole / chopped / with a
+    --max-seq-len that skips contigs), and tests/golden/circ/: reads from circular genomes through 3 read iterations and 4 contig
+    iterations of the workflow loop INCLUDING the script's cyclecheck() step (data/nuclassemble.sh:19-60: circular contigs are cut,
+    set aside and concatenated to the result at the end).  python tests/golden/make_golden.py cycle"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cyclecases
+    from stageflags import AC_FLAGS, KC_FLAGS
+    d = os.path.join(OUT, "cycle")
+    os.makedirs(d, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        t = lambda s: os.path.join(tmp, s)
+        mmdb.write_seqdb(t("in"), cyclecases.cases())
+        gz_write(os.path.join(d, "in.keyed.gz"), mmdb.dump_keyed(t("in")))
+        for name, flags in (("whole", ["--chop-cycle", "0", "--max-seq-len", "300000"]), ("chop", ["--chop-cycle", "1", "--max-seq-len", "300000"]),
+                            ("chop_max3000", ["--chop-cycle", "1", "--max-seq-len", "3000"]), ("defaults", [])):
+            run("cyclecheck", t("in"), t(name), *flags, "--threads", str(threads))
+            gz_write(os.path.join(d, name + ".keyed.gz"), mmdb.dump_keyed(t(name)))
+        # the loop
+        d = os.path.join(OUT, "circ")
+        os.makedirs(d, exist_ok=True)
+        prefix = t("dhigh")
+        synth.write_dhigh_profiles(prefix)
+        cur = t("reads")
+        mmdb.write_seqdb(cur, cyclecases.circular_reads())
+        gz_write(os.path.join(d, "reads.keyed.gz"), mmdb.dump_keyed(cur))
+        dmg = ["--ancient-damage", prefix, "--threads", str(threads)]
+        cyc_all = {}
+        for it in range(7):
+            p = lambda s: t("%s_%d" % (s, it))
+            contigs = it >= 3
+            run("kmermatcher", cur, p("pref"), *(KC_FLAGS if contigs else K_FLAGS), "--threads", "1")
+            run("rescorediagonal", cur, cur, p("pref"), p("aln"), *R_FLAGS, "--threads", str(threads))
+            run("ancient_correction", cur, p("aln"), p("corr"), *(AC_FLAGS if contigs else A_FLAGS), *dmg)
+            if not contigs:
+                run("ancient_read_assemble", p("corr"), p("aln"), p("asm"), *A_FLAGS, *dmg)
+                cur = p("asm")
+                continue
+            run("ancient_contig_merge", p("corr"), p("aln"), p("asm"), *AC_FLAGS, *dmg)
+            run("cyclecheck", p("asm"), p("cyc"), "--chop-cycle", "1", "--max-seq-len", "200000", "--threads", str(threads))
+            gz_write(os.path.join(d, "cyc_%d.keyed.gz" % it), mmdb.dump_keyed(p("cyc")))
+            cyc = mmdb.read_db(p("cyc"))
+            cyc_all.update(cyc)
+            rest = {k: v for k, v in mmdb.read_db(p("asm")).items() if k not in cyc}      # the "_noneCycle" index of the script
+            mmdb.write_from_keyed(p("rest"), rest, mmdb.DBTYPE_NUCLEOTIDES)
+            cur = p("rest")
+        final = dict(mmdb.read_db(cur))
+        final.update(cyc_all)                                                           # concatdbs --preserve-keys
+        mmdb.write_from_keyed(t("final"), final, mmdb.DBTYPE_NUCLEOTIDES)
+        gz_write(os.path.join(d, "final.keyed.gz"), mmdb.dump_keyed(t("final")))
+        print("circ: %d circular contigs set aside, %d entries in the result" % (len(cyc_all), len(final)))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "cycle":
+    cycle_goldens()
