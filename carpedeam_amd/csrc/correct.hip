@@ -105,9 +105,10 @@ __device__ __forceinline__ uint32_t callBase(const double *sLogT, const double *
     keep = total <= 1;
     if (keep) return qb;
     if (!qWasExt) {
-        const double ct = static_cast<double>(cov[3]) / (cov[1] + cov[3] + cov[0] + cov[2]);
-        const double ga = static_cast<double>(cov[0]) / (cov[1] + cov[3] + cov[0] + cov[2]);
-        if (ct >= 0.4 || ga >= 0.4) return qb;
+        // :27-33 compares double(cov) / double(total) with 0.4.  In integers: a / b >= 2 / 5.  The double 0.4 lies 2.2e-17 above 2/5, less
+        // than half an ulp, so the rounded quotient of a / b == 2/5 IS that double (>= holds); any other a / b with b < 2^18 is further
+        // than 1 / (5 b) > 7e-7 from 2/5, far beyond the rounding - the two tests agree on every input.
+        if (5u * cov[3] >= 2u * total || 5u * cov[0] >= 2u * total) return qb;
     }
     int qcls;
     if (qWasExt) qcls = 11;
@@ -257,25 +258,32 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Fast kernel for queries with at most 64 alignment records (all but the heaviest pile-ups): lane = record in the gate
-// phase (RY identity on 16-base words, XOR + popcount), accepted records parked in LDS, lane = position in the pile-up.
-// Same arithmetic as k_correct; 8-bit pile-up counters (a slot cannot exceed the 64 records).
+// phase (RY identity on 16-base words, XOR + popcount) and keeps the record, lane = position in the pile-up.
+// Same arithmetic as k_correct; 8-bit (4-bit) pile-up counters (a slot cannot exceed the 64 (15) records).
 constexpr int FAST_WAVES = 4;
-struct RecInfo { uint32_t tw, tLen; int qs, qe, ds; uint32_t flags; };   // flags: 1 rev, 2 target has N
 
-__global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a, const uint32_t *__restrict__ list, const unsigned int *__restrict__ nList) {
+// MAXREC: most records of a query on this instance (64, or 15 with CT = uint8_t: two 4-bit fields per counter and a quarter of the
+// record slots - less LDS per block, more waves per CU; the kernel is bound by the latency of its dependent gathers, so the
+// occupancy is what it runs on).  MINW: waves per SIMD the register allocation has to leave room for.
+template <int MAXREC, typename CT, int MINW>
+__global__ __launch_bounds__(64 * FAST_WAVES, MINW) void k_correct_fast(CorrectArgs a, const uint32_t *__restrict__ list, const unsigned int *__restrict__ nList) {
+    constexpr int HB = sizeof(CT) * 4;                  // bits per field: total | reverse << HB
+    constexpr int PER = 4 / sizeof(CT);                 // counters per LDS dword
     __shared__ double sLogT[16], sLogQ[12 * 16], sLogD[2 * 11 * 16];
-    __shared__ uint16_t sCnt[FAST_WAVES][SLOTS][64];
-    __shared__ RecInfo sRec[FAST_WAVES][64];
+    __shared__ uint32_t sCnt[FAST_WAVES][SLOTS * (64 / PER)];      // counter [slot][lane], PER lanes to a word
     for (int i = threadIdx.x; i < 16; i += blockDim.x) sLogT[i] = (&a.lut->logT[0][0])[i];
     for (int i = threadIdx.x; i < 12 * 16; i += blockDim.x) sLogQ[i] = (&a.lut->logQ[0][0][0])[i];
     for (int i = threadIdx.x; i < 2 * 11 * 16; i += blockDim.x) sLogD[i] = (&a.lut->logD[0][0][0][0])[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned int nItems = *nList;
-    uint16_t (*cnt)[64] = sCnt[wave];
-    RecInfo *recs = sRec[wave];
-#pragma unroll 4
-    for (int s = 0; s < SLOTS; s++) cnt[s][lane] = 0;       // a lane clears the slots it touched after every call
+    // the pile-up adds to a counter with ONE LDS atomic on the word that holds it (the lanes that share the word are serialised by
+    // the LDS): word index of this lane's counter inside a slot row, and the lane's increments shifted to its place in the word
+    uint32_t *cntWords = sCnt[wave];
+    const uint32_t laneWord = (uint32_t) lane / PER, laneShift = ((uint32_t) lane % PER) * (8 * sizeof(CT));
+    const uint32_t incFwd = 1u << laneShift, incRev = (1u | (1u << HB)) << laneShift;
+    const uint32_t laneClear = ~((uint32_t) (CT) ~(CT) 0 << laneShift);
+    for (int s = lane; s < SLOTS * (64 / PER); s += 64) cntWords[s] = 0;       // a lane clears the slots it touched after every call
     for (unsigned int item = blockIdx.x * FAST_WAVES + wave; item < nItems; item += gridDim.x * FAST_WAVES) {
         const uint32_t q = list[item];
         const uint32_t qLen = a.len[q], qw = a.woff[q];
@@ -288,7 +296,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
         const bool have = (uint32_t) lane < nRec;
         if (have) { rec = a.rec[r0 + lane]; aLen = alnLength(rec); }
         const float avCov = static_cast<float>(static_cast<float>(cdm_wave_sum((int) aLen))) / qLen;
-        bool ok = false; RecInfo info;
+        bool ok = false;
+        uint32_t iTw = 0, iLenFlags = 0, iQs = 0, iSpan = 0, iDs = 0;     // the record as the pile-up needs it, kept in this lane's registers
         if (have) {
             const uint32_t t = rec.target, tLen = a.len[t], tw = a.woff[t];
             const bool tHasN = a.hasN[t] != 0;
@@ -324,31 +333,37 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
                 const bool left = o.qs == 0 && (uint32_t) o.de == (tLen - 1);
                 ok = (ryId >= thr) && (right || left || (avCov < 50)) && rec.seqId >= a.seqIdThr && aLen >= 30;
             }
-            info.tw = tw; info.tLen = tLen; info.qs = o.qs; info.qe = o.qe; info.ds = o.ds; info.flags = (o.rev ? 1u : 0u) | (tHasN ? 2u : 0u);
+            // sequences on this path are shorter than 2^30 letters (the DB's word offsets are 32 bit)
+            iTw = tw; iLenFlags = tLen | (o.rev ? 0x80000000u : 0u) | (tHasN ? 0x40000000u : 0u); iQs = (uint32_t) o.qs; iSpan = (uint32_t) (o.qe - o.qs); iDs = (uint32_t) o.ds;
         }
-        // compact the accepted records into LDS, keeping record order (the pile-up is order independent anyway)
         const uint64_t okMask = __ballot(ok);
-        const int nAcc = __popcll(okMask);
-        if (ok) recs[__popcll(okMask & ((1ull << lane) - 1ull))] = info;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
 
-        // ---- pile-up + call, 64 positions at a time
+        // ---- pile-up + call, 64 positions at a time.  The record fields are wave-uniform: they are read out of the owning lane into
+        // scalar registers, the per-lane work is the target letter, its damage class and one LDS add.
         const uint32_t lastWord = (qLen + 15) / 16;
         for (uint32_t base = 0; base < qLen; base += 64) {
             const uint32_t p = base + lane;
             uint64_t touched = 0;       // slots of this lane's column that are non-zero
-            uint64_t covPacked = 0;     // records per target base (16 bits each), counted on the way
-            for (int r = 0; r < nAcc; r++) {
-                const RecInfo ri = recs[r];
-                if ((uint32_t) ri.qe < base || (uint32_t) ri.qs >= base + 64) continue;   // wave uniform
-                if (p >= (uint32_t) ri.qs && p <= (uint32_t) ri.qe && p < qLen) {
-                    const uint32_t tpos = (uint32_t) ri.ds + (p - (uint32_t) ri.qs);
-                    const uint32_t tb = targetBase(a, ri.tw, ri.tLen, (ri.flags & 2u) != 0, (ri.flags & 1u) != 0, tpos);
-                    const uint32_t cls = tpos < 5 ? tpos : (tpos >= ri.tLen - 5 ? 6 + (tpos - (ri.tLen - 5)) : 5);
-                    const uint32_t slot = tb * 11 + cls;
-                    cnt[slot][lane] += (uint16_t) (1u + ((ri.flags & 1u) ? 0x100u : 0u));
+            uint32_t cov4 = 0;          // records per target base (8 bits each: at most 64 records), counted on the way
+            for (uint64_t m = okMask; m; m &= m - 1) {
+                const int r = __ffsll((unsigned long long) m) - 1;
+                const uint32_t qs = (uint32_t) __builtin_amdgcn_readlane((int) iQs, r), span = (uint32_t) __builtin_amdgcn_readlane((int) iSpan, r);
+                if (qs + span < base || qs >= base + 64) continue;   // wave uniform
+                const uint32_t lf = (uint32_t) __builtin_amdgcn_readlane((int) iLenFlags, r), tw = (uint32_t) __builtin_amdgcn_readlane((int) iTw, r);
+                const uint32_t ds = (uint32_t) __builtin_amdgcn_readlane((int) iDs, r), tLen = lf & 0x3FFFFFFFu;
+                const uint32_t d = p - qs;
+                if (d <= span) {
+                    const uint32_t tpos = ds + d;                            // position on the oriented target
+                    uint32_t tb;
+                    if (lf & 0x40000000u) tb = targetBase(a, tw, tLen, true, (lf & 0x80000000u) != 0, tpos);
+                    else if (lf & 0x80000000u) tb = 3u - cdm_base(a.codes, tw, tLen - 1u - tpos);
+                    else tb = cdm_base(a.codes, tw, tpos);
+                    // damage class 0..4 from the 5' end, 6..10 at the 3' end, 5 inside (accepted records are at least 30 columns long)
+                    const uint32_t cls = min(tpos, 5u) + (uint32_t) max((int) tpos - (int) (tLen - 6u), 0);
+                    const uint32_t slot = tb * 11u + cls;
+                    atomicAdd(&cntWords[slot * (64 / PER) + laneWord], (lf & 0x80000000u) ? incRev : incFwd);
                     touched |= 1ull << slot;
-                    covPacked += 1ull << (16 * tb);
+                    cov4 += 1u << (8u * tb);
                 }
             }
             uint32_t newCode = 0; bool keep = true;
@@ -356,10 +371,12 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
                 uint32_t qb = cdm_base(a.codes, qw, p);
                 const bool qIsN = qHasN && cdm_isN(a.nmask, qw, p);
                 if (qIsN) qb = 0;
+                const uint64_t covPacked = (uint64_t) (cov4 & 0xFFu) | ((uint64_t) ((cov4 >> 8) & 0xFFu) << 16) | ((uint64_t) ((cov4 >> 16) & 0xFFu) << 32) | ((uint64_t) (cov4 >> 24) << 48);
                 newCode = callBase(sLogT, sLogQ, sLogD, qb, p, qLen, qWasExt,
-                                   [&](int slot) { const uint32_t v = cnt[slot][lane]; return (v & 0xFFu) | ((v >> 8) << 16); }, touched, keep, covPacked);
+                                   [&](int slot) { const uint32_t v = cntWords[slot * (64 / PER) + laneWord] >> laneShift; return (v & ((1u << HB) - 1u)) | (((v >> HB) & ((1u << HB) - 1u)) << 16); },
+                                   touched, keep, covPacked);
             }
-            for (uint64_t m = touched; m; m &= m - 1) cnt[__ffsll((unsigned long long) m) - 1][lane] = 0;
+            for (uint64_t m = touched; m; m &= m - 1) atomicAnd(&cntWords[(__ffsll((unsigned long long) m) - 1) * (64 / PER) + laneWord], laneClear);
             const uint64_t b0 = cdm_ballot((newCode & 1u) != 0), b1 = cdm_ballot((newCode & 2u) != 0);
             uint64_t nb = 0;
             if (qHasN) nb = cdm_ballot(p < qLen && keep && cdm_isN(a.nmask, qw, p));
@@ -376,13 +393,13 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_correct_fast(CorrectArgs a,
     }
 }
 
-// queries with more than one alignment record: up to 64 records -> fast list, more -> general list
-__global__ void k_mark_active(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t *__restrict__ active, uint32_t *__restrict__ activeFast,
-                              unsigned int *__restrict__ counters) {
+// queries with more than one alignment record: up to smallMax records -> small list, up to 64 -> fast list, more -> general list
+__global__ void k_mark_active(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t smallMax, uint32_t *__restrict__ active, uint32_t *__restrict__ activeFast,
+                              uint32_t *__restrict__ activeSmall, unsigned int *__restrict__ counters) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t c = (q < n) ? aoff[q + 1] - aoff[q] : 0;
-    const uint32_t s0 = cdm_wave_append(&counters[0], c > 64), s2 = cdm_block_append(&counters[2], c > 1 && c <= 64);
-    if (c > 64) active[s0] = q; else if (c > 1) activeFast[s2] = q;
+    const uint32_t s0 = cdm_wave_append(&counters[0], c > 64), s2 = cdm_block_append(&counters[2], c > smallMax && c <= 64), s3 = cdm_block_append(&counters[3], c > 1 && c <= smallMax);
+    if (c > 64) active[s0] = q; else if (c > smallMax) activeFast[s2] = q; else if (c > 1) activeSmall[s3] = q;
 }
 
 
@@ -422,13 +439,16 @@ extern "C" int cdm_debug_call_bases(cdm_ctx *ctx, const uint32_t *vectors, uint3
 int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb *out) {
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t) db->n;
-    DevBuf<uint32_t> active, activeFast; DevBuf<unsigned int> counters; DevBuf<uint8_t> accept;
-    if (!active.alloc(n) || !activeFast.alloc(n) || !counters.alloc(4) || !accept.alloc(alns->count)) { cdm_set_error("out of device memory in cdm_correct"); return CDM_ERR_HIP; }
+    DevBuf<uint32_t> active, activeFast, activeSmall; DevBuf<unsigned int> counters; DevBuf<uint8_t> accept;
+    if (!active.alloc(n) || !activeFast.alloc(n) || !activeSmall.alloc(n) || !counters.alloc(4) || !accept.alloc(alns->count)) { cdm_set_error("out of device memory in cdm_correct"); return CDM_ERR_HIP; }
     // coverage <= 1 everywhere unless the kernels overwrite: start from a copy of the input bases
     CDM_HIP(hipMemcpyAsync(out->codes, db->codes, db->words * 4, hipMemcpyDeviceToDevice, s));
     CDM_HIP(hipMemcpyAsync(out->nmask, db->nmask, ((db->words * 16 + 31) / 32) * 4, hipMemcpyDeviceToDevice, s));
     CDM_HIP(hipMemsetAsync(counters.p, 0, 16, s));   // [0] queries for the general kernel, [1] error flag, [2] queries for the fast kernel
-    hipLaunchKernelGGL(k_mark_active, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, n, active.p, activeFast.p, counters.p);
+    // CDM_CORRECT_VARIANT (experiments): "0" = one fast instance for up to 64 records; "s<W>" = small instance (<= 15 records) with W waves per SIMD
+    const char *varEnv = getenv("CDM_CORRECT_VARIANT");
+    const int smallW = (varEnv && varEnv[0] == 's') ? atoi(varEnv + 1) : (varEnv && varEnv[0] == '0' ? 0 : 6);
+    hipLaunchKernelGGL(k_mark_active, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, n, smallW ? 15u : 0u, active.p, activeFast.p, activeSmall.p, counters.p);
     DevBuf<SeqMeta> meta;
     if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
     CorrectArgs a;
@@ -437,7 +457,12 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
     a.outCodes = out->codes; a.outNmask = out->nmask; a.lut = ctx->lutDev; a.seqIdThr = par->seq_id_thr; a.corrRy = par->corr_reads_ry_seq_id;
     const int blocks = ctx->cuCount * 8;
     hipEventRecord(ctx->ev0, s);
-    hipLaunchKernelGGL(k_correct_fast, dim3(blocks), dim3(64 * FAST_WAVES), 0, s, a, activeFast.p, counters.p + 2);
+    const char *padEnv = getenv("CDM_LDS_PAD");          // experiments: dynamic LDS that lowers the occupancy
+    const unsigned pad = padEnv ? (unsigned) atoi(padEnv) : 0u;
+    if (smallW == 8) hipLaunchKernelGGL((k_correct_fast<15, uint8_t, 8>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeSmall.p, counters.p + 3);
+    else if (smallW == 5) hipLaunchKernelGGL((k_correct_fast<15, uint8_t, 5>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeSmall.p, counters.p + 3);
+    else if (smallW) hipLaunchKernelGGL((k_correct_fast<15, uint8_t, 6>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeSmall.p, counters.p + 3);
+    hipLaunchKernelGGL((k_correct_fast<64, uint16_t, 4>), dim3(blocks), dim3(64 * FAST_WAVES), pad, s, a, activeFast.p, counters.p + 2);
     hipLaunchKernelGGL(k_correct, dim3(blocks / 4), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
     hipEventRecord(ctx->ev1, s);
     CDM_LAUNCH_CHECK();

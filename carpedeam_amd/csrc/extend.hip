@@ -289,7 +289,8 @@ struct Heap {
     }
 };
 
-__global__ __launch_bounds__(64) void k_extend(ExtArgs A) {
+template <int MINW>
+__global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
     __shared__ double sLogLik[11 * 16];
     for (int i = threadIdx.x; i < 11 * 16; i += blockDim.x) sLogLik[i] = (&A.lut->logLik[0][0][0][0])[i];
     __syncthreads();
@@ -561,7 +562,13 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     A.maxSeqLen = par->max_seq_len;
     A.unsafe = par->unsafe ? 1 : 0; A.minCov = (uint32_t) std::max(0, par->min_cov_safe); A.flags = flags.p;
     hipEventRecord(ctx->ev0, s);
-    if (hAct) hipLaunchKernelGGL(k_extend, dim3((hAct + 63) / 64), dim3(64), 0, s, A);
+    const char *padEnv = getenv("CDM_LDS_PAD");          // experiments: dynamic LDS that lowers the occupancy
+    const char *wEnv = getenv("CDM_EXTEND_WAVES");        // experiments: waves per SIMD the register allocation leaves room for
+    const int minW = wEnv ? atoi(wEnv) : 8;
+    const unsigned padB = padEnv ? (unsigned) atoi(padEnv) : 0u;
+    if (hAct && minW == 8) hipLaunchKernelGGL(k_extend<8>, dim3((hAct + 63) / 64), dim3(64), padB, s, A);
+    else if (hAct && minW == 6) hipLaunchKernelGGL(k_extend<6>, dim3((hAct + 63) / 64), dim3(64), padB, s, A);
+    else if (hAct) hipLaunchKernelGGL(k_extend<5>, dim3((hAct + 63) / 64), dim3(64), padB, s, A);
     hipEventRecord(ctx->ev1, s);
     // ---- output DB
     cdm_seqdb *o = nullptr;
