@@ -43,12 +43,13 @@ __device__ __forceinline__ void waveLdsSync() {
 }
 
 // per-wave bookkeeping in LDS: "starts a bucket" bit per window slot (written with ballots) and the ordinal of every slot's bucket
-struct WaveLds {
-    unsigned long long bits[WV_WORDS];
-    uint16_t ord[WV_WIN];
+template <int WIN> struct WaveLdsT {
+    unsigned long long bits[WIN / 64];
+    uint16_t ord[WIN];
 };
+typedef WaveLdsT<WV_WIN> WaveLds;
 // first set bit in [from, limit), -1 if none.  Wave-uniform.
-__device__ __forceinline__ int firstSetFrom(const WaveLds &w, int from, int limit) {
+template <typename WL> __device__ __forceinline__ int firstSetFrom(const WL &w, int from, int limit) {
     for (int word = from >> 6; word * 64 < limit; word++) {
         unsigned long long m = w.bits[word];
         if (word == (from >> 6)) m &= ~0ull << (from & 63);
@@ -57,7 +58,7 @@ __device__ __forceinline__ int firstSetFrom(const WaveLds &w, int from, int limi
     return -1;
 }
 // last set bit in (lo, hi], -1 if none.  Wave-uniform.
-__device__ __forceinline__ int lastSetIn(const WaveLds &w, int lo, int hi) {
+template <typename WL> __device__ __forceinline__ int lastSetIn(const WL &w, int lo, int hi) {
     const int wl = (lo + 1) >> 6;
     for (int word = hi >> 6; word >= wl; word--) {
         unsigned long long m = w.bits[word];
@@ -172,9 +173,11 @@ __device__ __forceinline__ uint64_t readLane64(uint64_t a, int l) {
 // it in window slot i and returns its key, keyAt(g) returns the key of the tuple at g; two tuples are in the same bucket when
 // their keys agree in the bits of hiMask.  groupFn(g0, gm) finishes the group of whole buckets in the window slots
 // [g0, g0 + gm).  w.ord[i] = ordinal of slot i's bucket in the window.
-template <typename T, typename Fetch, typename Put, typename KeyAt, typename GroupFn>
-__device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, uint32_t maxBucket, uint64_t hiMask, const BigList &big, WaveLds &w, int lane,
+// WIN / FIRST: slots of the window / of its first batch (the defaults are WV_WIN / WV_FIRST).
+template <typename T, int WIN = WV_WIN, int FIRST = WV_FIRST, typename Fetch, typename Put, typename KeyAt, typename GroupFn>
+__device__ __forceinline__ void waveBuckets(uint64_t r0, uint64_t n, int own, uint32_t maxBucket, uint64_t hiMask, const BigList &big, WaveLdsT<WIN> &w, int lane,
                                             const Fetch &fetch, const Put &put, const KeyAt &keyAt, const GroupFn &groupFn) {
+    constexpr int WV_WIN = WIN, WV_FIRST = FIRST, WV_WORDS = WIN / 64;      // (shadow the defaults)
     const int avail = (int) min((uint64_t) WV_WIN, n - r0);
     uint64_t carry = r0 ? keyAt(r0 - 1) : 0ull;     // key in front of the row being flagged (wave-uniform)
     int ordBase = -1;

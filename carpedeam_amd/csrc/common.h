@@ -20,6 +20,9 @@ void cdmPoolTrim();   // give every cached block back to the driver
 template <typename T> inline hipError_t cdmMalloc(T **p, size_t bytes) { return cdmMallocRaw(reinterpret_cast<void **>(p), bytes); }
 
 // RAII device buffer from the caching allocator (freed on every exit path of a stage function)
+// experiments: dynamic LDS (bytes, from the environment) added to a launch to lower its occupancy
+inline unsigned cdm_lds_pad(const char *name) { const char *e = getenv(name); return e ? (unsigned) atoi(e) : 0u; }
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     DevBuf() = default;

@@ -695,25 +695,36 @@ struct BucketGroupArgs : GroupParams {
     int lowBits;                    // k-mer bits the global passes left unsorted
     int own; uint32_t maxBucket; bucket::BigList big;
 };
+// Geometry of the grouping kernel: a smaller window than bucket.h's default - the kernel runs on the latency of its loads and LDS
+// round trips (its time scales with 1 / waves per CU), so the LDS a wave needs decides its speed; k-mer buckets are ~40 tuples.
+#ifndef CDM_GK_OWN
+#define CDM_GK_OWN 128
+#define CDM_GK_WIN 384
+#define CDM_GK_FIRST 256
+#endif
+constexpr int GK_OWN = CDM_GK_OWN, GK_WIN = CDM_GK_WIN, GK_FIRST = CDM_GK_FIRST, GK_MAXB = GK_WIN - GK_OWN;
+// (the network writes all 64 R slots of ss, R = 1, 2, 4, 8: the largest bucket is one of those sizes)
+static_assert(GK_WIN % 64 == 0 && GK_FIRST % 64 == 0 && GK_FIRST < GK_WIN && GK_OWN <= GK_FIRST && GK_WIN <= (1 << bucket::WV_IDX) &&
+              (GK_MAXB == 64 || GK_MAXB == 128 || GK_MAXB == 256 || GK_MAXB == 512), "grouping kernel geometry");
 template <typename LY, typename W>
 __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs<LY, W> a) {
     using namespace bucket;
     typedef typename LY::V V;
-    __shared__ uint64_t sKeyAll[BK_WAVES][WV_WIN];
-    __shared__ V sValAll[BK_WAVES][WV_WIN];
-    __shared__ uint32_t sSAll[BK_WAVES][BK_MAXB];
-    __shared__ WaveLds wAll[BK_WAVES];
+    __shared__ uint64_t sKeyAll[BK_WAVES][GK_WIN];
+    __shared__ V sValAll[BK_WAVES][GK_WIN];
+    __shared__ uint32_t sSAll[BK_WAVES][GK_MAXB];
+    __shared__ WaveLdsT<GK_WIN> wAll[BK_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t r0 = ((uint64_t) blockIdx.x * BK_WAVES + wave) * (uint64_t) a.own;
     if (r0 >= a.n) return;      // (whole wave)
     uint64_t *sKey = sKeyAll[wave]; V *sVal = sValAll[wave]; uint32_t *ss = sSAll[wave];
-    WaveLds &w = wAll[wave];
+    WaveLdsT<GK_WIN> &w = wAll[wave];
     const uint64_t hmask = (2ull << a.geom.kbits) - 1ull, lowMask = (1ull << a.lowBits) - 1ull;   // k-mer bits + the unused-slot bit
     const int lowBits = a.lowBits;
     struct Tup { uint64_t k; V v; };
     constexpr uint32_t IDXM = (1u << WV_IDX) - 1u;
     uint32_t keptCnt = 0;       // wave-uniform
-    waveBuckets<Tup>(r0, a.n, a.own, a.maxBucket, hmask & ~lowMask, a.big, w, lane,
+    waveBuckets<Tup, GK_WIN, GK_FIRST>(r0, a.n, a.own, a.maxBucket, hmask & ~lowMask, a.big, w, lane,
         [&](uint64_t g) { Tup t; t.k = a.keys[g]; t.v = a.vals[g]; return t; },
         [&](int i, const Tup &t) { sKey[i] = t.k; sVal[i] = t.v; return t.k; },
         [&](uint64_t g) { return a.keys[g]; },
@@ -1280,6 +1291,7 @@ int phaseA() override {
         if (lowBits == 0) rc = scanGroups(ga, startIo);
         else {
             int own; uint32_t maxBucket; bucket::capacities(own, maxBucket);
+            own = std::min(own, GK_OWN); maxBucket = std::min<uint32_t>(maxBucket, GK_MAXB);
             DevBuf<unsigned long long> bigList; DevBuf<unsigned int> bigCnt;
             if (!bigList.alloc(bucket::bigListSlots(kmerSlots, maxBucket)) || !bigCnt.alloc(1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
             hipMemsetAsync(bigCnt.p, 0, 4, s);
@@ -1291,7 +1303,7 @@ int phaseA() override {
                 ba.keys = ga.keys; ba.vals = ga.vals; ba.geom = geom; ba.out = startIo; ba.lowBits = lowBits; ba.own = own; ba.maxBucket = maxBucket;
                 ba.big.list = bigList.p; ba.big.cnt = bigCnt.p;
                 const uint64_t perBlock = (uint64_t) own * bucket::BK_WAVES;
-                if (live) hipLaunchKernelGGL((k_bucket_groups<LY, W>), dim3((unsigned) ((live + perBlock - 1) / perBlock)), dim3(bucket::BK_NT), 0, s, ba);
+                if (live) hipLaunchKernelGGL((k_bucket_groups<LY, W>), dim3((unsigned) ((live + perBlock - 1) / perBlock)), dim3(bucket::BK_NT), cdm_lds_pad("CDM_LDS_PAD_GROUPS"), s, ba);
             };
             if (lowBits <= 15) launchFused(uint32_t()); else launchFused(uint64_t());   // 8 bits of bucket ordinal + low bits + 9 of position in one word
             unsigned int nBig = 0;

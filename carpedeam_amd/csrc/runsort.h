@@ -161,7 +161,15 @@ __global__ __launch_bounds__(1024) void k_seg_list(SegListArgs a) {
 // sub-buckets) with the register network of bucket.h on words (h, diagonal, index in the unit): concatenated, the sorted groups
 // are the sorted unit, ties in input order.  A segment of more than maxSeg = U_CAP - U_T tuples never fits for sure and is left
 // to the caller (k_seg_list lists it); a unit with a sub-bucket beyond 512 tuples goes to the `hard` list (sorted by rocPRIM).
-constexpr int U_NT = 256, U_WAVES = U_NT / 64, U_T = 1024, U_CAP = 3328, U_FIRST = 2048, U_NB = 256, U_IDXB = 12, U_ORDB = 11;
+#ifndef CDM_U_NT
+#define CDM_U_NT 512
+#endif
+#ifndef CDM_U_CAP
+#define CDM_U_CAP 3072
+#endif
+// eight waves share one unit's LDS: the kernel runs on the latency of its LDS / global round trips, the waves per CU decide its speed
+constexpr int U_NT = CDM_U_NT, U_WAVES = U_NT / 64, U_T = 1024, U_CAP = CDM_U_CAP, U_FIRST = 2048, U_NB = 256, U_IDXB = 12, U_ORDB = 11;
+static_assert(U_FIRST % U_NT == 0 && (U_CAP - U_FIRST) % U_NT == 0 && U_NB <= U_NT && U_NB % U_WAVES == 0, "unit sorter geometry");
 struct UnitArgs {
     const uint64_t *in; uint64_t *out; uint64_t n;
     int repShift;               // segment id = key >> repShift
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(U_NT) void k_unit_sort(UnitArgs a) {
         const unsigned int c = (unsigned int) __popcll(sBits[lane]);
         sPre[lane] = cdm_wave_incl_sum<unsigned int>(c) - c;
     }
-    sCnt[tid] = 0;                              // U_NB == U_NT
+    if (tid < U_NB) sCnt[tid] = 0;
     __syncthreads();
     const int idBits = a.repShift - a.hiShift;
     const unsigned int ord0 = sPre[u0 >> 6] + (unsigned int) __popcll(sBits[u0 >> 6] & ((2ull << (u0 & 63)) - 1ull));          // ordinal + 1 of the unit's first segment
@@ -259,14 +267,14 @@ __global__ __launch_bounds__(U_NT) void k_unit_sort(UnitArgs a) {
         atomicAdd(&sCnt[(unsigned int) (t >> sh)], 1u);
     }
     __syncthreads();
-    const unsigned int c = sCnt[tid];
+    const unsigned int c = tid < U_NB ? sCnt[tid] : 0u;
     unsigned int tot;
     const unsigned int ex = cdm_block_excl_sum<unsigned int>(c, tot);
-    sOff[tid] = ex;
+    if (tid < U_NB) sOff[tid] = ex;
     if (tid == 0) sOff[U_NB] = tot;
     const bool hard = __syncthreads_or(c > a.maxSub);
     if (hard) { if (tid == 0) a.hard.add(base + (uint64_t) u0, base + (uint64_t) uEnd); return; }
-    sCnt[tid] = ex;                             // (cursor of the scatter; the order inside a sub-bucket does not matter: the
+    if (tid < U_NB) sCnt[tid] = ex;             // (cursor of the scatter; the order inside a sub-bucket does not matter: the
     __syncthreads();                            //  word carries the tuple's index)
     for (int i = u0 + tid; i < uEnd; i += U_NT) sPerm[atomicAdd(&sCnt[(unsigned int) (sKeys[i] >> sh)], 1u)] = (uint16_t) i;
     __syncthreads();
@@ -320,7 +328,7 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, const uint64_t *in, uin
     for (int c = 2; c < SEG_CLASSES; c++) if (!lists[c].alloc(2 * (listCap + (c == 3 ? (size_t) units + 1 : 0)))) return CDM_ERR_HIP;
     hipMemsetAsync(cnt.p, 0, (SEG_CLASSES + 1) * 4, s);
     UnitArgs ua; ua.in = in; ua.out = out; ua.n = n; ua.repShift = shiftHi; ua.hiShift = hiShift; ua.maxSeg = maxSeg; ua.maxSub = maxSub; ua.hard.list = hardList.p; ua.hard.cnt = cnt.p + SEG_CLASSES;
-    if (maxSeg) hipLaunchKernelGGL(k_unit_sort, dim3((unsigned) units), dim3(U_NT), 0, s, ua);
+    if (maxSeg) hipLaunchKernelGGL(k_unit_sort, dim3((unsigned) units), dim3(U_NT), cdm_lds_pad("CDM_LDS_PAD_UNIT"), s, ua);
     // the segments no unit can hold, listed by size class: one block of 8 waves (bitonic network, bucket.h) up to 4096, rocPRIM beyond
     SegListArgs la; la.recRep = recRep; la.dst = dst; la.nRec = nRec; la.maxWave = maxSeg;
     la.cap[0] = 0; la.cap[1] = 0; la.cap[2] = blockCap;
