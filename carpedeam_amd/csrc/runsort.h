@@ -164,146 +164,180 @@ __global__ __launch_bounds__(1024) void k_seg_list(SegListArgs a) {
 #ifndef CDM_U_NT
 #define CDM_U_NT 512
 #endif
-#ifndef CDM_U_CAP
-#define CDM_U_CAP 3072
+// eight waves share one unit's LDS.  The kernel runs on the latency of its LDS / global round trips - its time goes with
+// 1 / (units in flight per CU) - so the units are listed by size beforehand (k_unit_bounds, k_unit_classes) and every size class
+// runs the instance whose LDS is just large enough.
+#ifndef CDM_U_NT0
+#define CDM_U_NT0 256
+#define CDM_U_NT1 256
 #endif
-// eight waves share one unit's LDS: the kernel runs on the latency of its LDS / global round trips, the waves per CU decide its speed
-constexpr int U_NT = CDM_U_NT, U_WAVES = U_NT / 64, U_T = 1024, U_CAP = CDM_U_CAP, U_FIRST = 2048, U_NB = 256, U_IDXB = 12, U_ORDB = 11;
-static_assert(U_FIRST % U_NT == 0 && (U_CAP - U_FIRST) % U_NT == 0 && U_NB <= U_NT && U_NB % U_WAVES == 0, "unit sorter geometry");
+constexpr int U_T = 1024, U_MAXSEG = 2048, U_CAP = U_T + U_MAXSEG, U_NB = 256, U_IDXB = 12, U_ORDB = 11;
+constexpr int U_CLASSES = 3;
+constexpr int U_CLASS_CAP[U_CLASSES] = {1536, 2048, U_CAP};
+constexpr int U_CLASS_NT[U_CLASSES] = {CDM_U_NT0, CDM_U_NT1, CDM_U_NT};
+static_assert(U_CAP <= (1 << U_IDXB) && U_T <= (1 << U_ORDB), "unit sorter geometry");
+
+// ---- the units: unit u = the segments that start in [u U_T, (u + 1) U_T), i.e. the tuples [uStart[u], uStart[u + 1]) - minus its
+// last segment if that one is longer than maxSeg (then it ends at uEnd[u], the segment is listed by k_seg_list).
+struct UnitBoundArgs {
+    const uint32_t *recRep; const unsigned long long *dst; uint64_t nRec;
+    uint32_t maxSeg; uint64_t units;
+    unsigned long long *uStart, *uEnd;      // [units + 1], [units]
+};
+// one thread per record; a record with a unit boundary B in (dst[r], dst[r + 1]] finds the end (and, if need be, the start) of its
+// segment: the unit that begins at B starts where the segment ends
+__global__ __launch_bounds__(1024) void k_unit_bounds(UnitBoundArgs a) {
+    const uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.nRec) return;
+    const unsigned long long d0 = a.dst[r], d1 = a.dst[r + 1];
+    const uint64_t uLo = d0 / U_T + 1, uHi = (r == a.nRec - 1) ? a.units : d1 / U_T;       // (the end of the array closes the last unit)
+    if (r == 0) a.uStart[0] = 0;
+    if (uLo > uHi) return;
+    const uint32_t rep = a.recRep[r];
+    uint64_t lo = r, step = 1;                              // last record of the segment: gallop, then bisect
+    while (lo + step < a.nRec && a.recRep[lo + step] == rep) { lo += step; step <<= 1; }
+    uint64_t hi = min(lo + step, a.nRec);
+    while (hi - lo > 1) { const uint64_t mid = lo + ((hi - lo) >> 1); if (a.recRep[mid] == rep) lo = mid; else hi = mid; }
+    const unsigned long long e = a.dst[hi];
+    uint64_t first = r, out = ~0ull, st = 1;                // first record of the segment: `first` is inside, `out` outside (or -1)
+    while (first >= st) { if (a.recRep[first - st] == rep) { first -= st; st <<= 1; } else { out = first - st; break; } }
+    while (first - out > 1) { const uint64_t mid = out + ((first - out) >> 1); if (a.recRep[mid] == rep) first = mid; else out = mid; }
+    const unsigned long long sSeg = a.dst[first];
+    for (uint64_t u = uLo; u <= uHi; u++) {
+        if (u <= a.units) a.uStart[u] = e;
+        // the unit in front of boundary u: this segment is its last one if it starts in that unit's range
+        const bool mine = sSeg >= (u - 1) * (unsigned long long) U_T;
+        if (u >= 1 && u - 1 < a.units) a.uEnd[u - 1] = (mine && e - sSeg > a.maxSeg) ? sSeg : e;
+    }
+}
+struct UnitClassArgs {
+    const unsigned long long *uStart, *uEnd; uint64_t units, n;
+    uint32_t cap[U_CLASSES];
+    unsigned long long *list[U_CLASSES]; unsigned int *cnt;        // (start, end) per unit of the class
+};
+__global__ __launch_bounds__(1024) void k_unit_classes(UnitClassArgs a) {
+    const uint64_t u = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1; unsigned long long s = 0, e = 0;
+    if (u < a.units) {
+        s = a.uStart[u]; e = a.uEnd[u];
+        const unsigned long long m = e > s ? e - s : 0;
+        if (m) cls = m <= a.cap[0] ? 0 : m <= a.cap[1] ? 1 : 2;
+    }
+#pragma unroll
+    for (int c = 0; c < U_CLASSES; c++) {
+        const uint32_t q = cdm_block_append(a.cnt + c, cls == c);
+        if (cls == c) { a.list[c][2 * (size_t) q] = s; a.list[c][2 * (size_t) q + 1] = e; }
+    }
+}
+
 struct UnitArgs {
     const uint64_t *in; uint64_t *out; uint64_t n;
     int repShift;               // segment id = key >> repShift
     int hiShift;                // (rep, id) = key >> hiShift; the bits below are sorted inside the sub-buckets, bit 0 rides along
-    uint32_t maxSeg;
     uint32_t maxSub;            // largest sub-bucket a wave finishes (bucket::BK_MAXB; tests lower it to reach the hard path)
+    const unsigned long long *list; const unsigned int *count;     // the units of this size class
     bucket::BigList hard;
 };
-// first set bit in [from, limit) / last set bit in [0, below) of the 64 words (one per lane), -1 if none.  Wave-uniform result.
-__device__ __forceinline__ int unitFirstSet(const unsigned long long *bits, int lane, int from, int limit) {
-    unsigned long long m = bits[lane];
-    if (lane == (from >> 6)) m &= ~0ull << (from & 63);
-    if (lane < (from >> 6) || lane * 64 >= limit) m = 0;
-    const unsigned long long any = __ballot(m != 0ull);
-    if (!any) return -1;
-    const int w = __ffsll(any) - 1;
-    const unsigned long long mw = bucket::readLane64(m, w);
-    const int p = w * 64 + __ffsll(mw) - 1;
-    return p < limit ? p : -1;
-}
-__device__ __forceinline__ int unitLastSet(const unsigned long long *bits, int lane, int below) {
-    unsigned long long m = bits[lane];
-    if (lane * 64 >= below) m = 0;
-    else if (lane == ((below - 1) >> 6) && (below & 63)) m &= (1ull << (below & 63)) - 1ull;
-    const unsigned long long any = __ballot(m != 0ull);
-    if (!any) return -1;
-    const int w = 63 - __clzll(any);
-    return w * 64 + 63 - __clzll(bucket::readLane64(m, w));
-}
+template <int CAP, int U_NT>
 __global__ __launch_bounds__(U_NT) void k_unit_sort(UnitArgs a) {
-    __shared__ uint64_t sKeys[U_CAP];           // the window; the unit's part is rewritten with the ordinal in place of the representative
-    __shared__ uint16_t sPerm[U_CAP];
-    __shared__ unsigned long long sBits[64];
-    __shared__ unsigned int sPre[64];
+    constexpr int ROUNDS = (CAP + U_NT - 1) / U_NT, U_WAVES = U_NT / 64;
+    static_assert(U_NB <= U_NT && U_NB % U_WAVES == 0 && CAP % U_NT == 0, "unit sorter geometry");
+    __shared__ uint64_t sKeys[CAP];             // the unit; rewritten with the ordinal in place of the representative
+    __shared__ uint16_t sPerm[CAP];
+    __shared__ unsigned long long sBits[ROUNDS * U_NT / 64];
+    __shared__ unsigned int sPre[ROUNDS * U_NT / 64];
     __shared__ unsigned int sCnt[U_NB];
     __shared__ unsigned int sOff[U_NB + 1];
     __shared__ uint32_t sRep[U_T + 2];          // representative of the unit's segments by ordinal
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t base = (uint64_t) blockIdx.x * U_T;
-    const uint64_t prevKey = base ? a.in[base - 1] : 0ull;
-    // stage [LO, LO + ROUNDS * U_NT) of the window - all loads in flight together - and flag the segment starts in it (one
-    // ballot word per wave and round)
-    auto stage = [&](auto loTag, auto roundsTag) {
-        constexpr int LO = decltype(loTag)::value, ROUNDS = decltype(roundsTag)::value;
-        uint64_t k[ROUNDS];
+    const unsigned int nUnits = *a.count;
+    for (unsigned int item = blockIdx.x; item < nUnits; item += gridDim.x) {
+        const uint64_t base = a.list[2 * (size_t) item];
+        const int m = (int) (a.list[2 * (size_t) item + 1] - base);          // 1 .. CAP; the unit starts with a segment start
+        // stage the unit - all loads in flight together - and flag the segment starts (one ballot word per wave and round)
+        {
+            uint64_t k[ROUNDS];
 #pragma unroll
-        for (int r = 0; r < ROUNDS; r++) { const uint64_t g = base + (uint64_t) (LO + r * U_NT + tid); k[r] = g < a.n ? a.in[g] : ~0ull; }   // behind the array: a representative of its own
+            for (int r = 0; r < ROUNDS; r++) { const int i = r * U_NT + tid; k[r] = i < m ? a.in[base + (uint64_t) i] : ~0ull; }
 #pragma unroll
-        for (int r = 0; r < ROUNDS; r++) sKeys[LO + r * U_NT + tid] = k[r];
-        __syncthreads();
+            for (int r = 0; r < ROUNDS; r++) { const int i = r * U_NT + tid; if (i < CAP) sKeys[i] = k[r]; }
+            if (tid < U_NB) sCnt[tid] = 0;
+            __syncthreads();
 #pragma unroll
-        for (int r = 0; r < ROUNDS; r++) {
-            const int i = LO + r * U_NT + tid;
-            const uint64_t p = i ? sKeys[i - 1] : prevKey;
-            const unsigned long long m = __ballot((base + (uint64_t) i == 0) || ((k[r] >> a.repShift) != (p >> a.repShift)));
-            if (lane == 0) sBits[i >> 6] = m;
+            for (int r = 0; r < ROUNDS; r++) {
+                const int i = r * U_NT + tid;
+                const uint64_t p = (i && i < CAP + 1) ? sKeys[i - 1] : 0ull;
+                const unsigned long long bm = __ballot(i < m && (i == 0 || (k[r] >> a.repShift) != (p >> a.repShift)));
+                if (lane == 0) sBits[i >> 6] = bm;
+            }
+            __syncthreads();
+        }
+        // ordinal of every segment: number of start bits in front of each word (wave 0), then a masked popcount per tuple
+        if (wave == 0) {
+            unsigned int run = 0;
+#pragma unroll
+            for (int w0 = 0; w0 < ROUNDS * U_NT / 64; w0 += 64) {
+                const unsigned int c = (w0 + lane < ROUNDS * U_NT / 64) ? (unsigned int) __popcll(sBits[w0 + lane]) : 0u;
+                const unsigned int incl = cdm_wave_incl_sum<unsigned int>(c);
+                if (w0 + lane < ROUNDS * U_NT / 64) sPre[w0 + lane] = run + incl - c;
+                run += __shfl(incl, 63, 64);
+            }
         }
         __syncthreads();
-    };
-    if (tid < 64) sBits[tid] = 0ull;
-    __syncthreads();
-    stage(std::integral_constant<int, 0>(), std::integral_constant<int, U_FIRST / U_NT>());
-    const int u0 = unitFirstSet(sBits, lane, 0, U_T);
-    if (u0 < 0 || base + (uint64_t) u0 >= a.n) return;          // no segment starts in this range (block-uniform)
-    int uEnd = unitFirstSet(sBits, lane, U_T, U_FIRST);
-    if (uEnd < 0) {
-        stage(std::integral_constant<int, U_FIRST>(), std::integral_constant<int, (U_CAP - U_FIRST) / U_NT>());
-        uEnd = unitFirstSet(sBits, lane, U_FIRST, U_CAP);
-    }
-    const int lastStart = unitLastSet(sBits, lane, U_T);
-    if (uEnd < 0 || (uint32_t) (uEnd - lastStart) > a.maxSeg) uEnd = lastStart;     // the last segment does not fit: the caller's
-    const int m = uEnd - u0;
-    if (m <= 0) return;
-    // ordinal of every segment: number of start bits in front of each word (wave 0), then a masked popcount per tuple
-    if (wave == 0) {
-        const unsigned int c = (unsigned int) __popcll(sBits[lane]);
-        sPre[lane] = cdm_wave_incl_sum<unsigned int>(c) - c;
-    }
-    if (tid < U_NB) sCnt[tid] = 0;
-    __syncthreads();
-    const int idBits = a.repShift - a.hiShift;
-    const unsigned int ord0 = sPre[u0 >> 6] + (unsigned int) __popcll(sBits[u0 >> 6] & ((2ull << (u0 & 63)) - 1ull));          // ordinal + 1 of the unit's first segment
-    const unsigned int nSeg = sPre[(uEnd - 1) >> 6] + (unsigned int) __popcll(sBits[(uEnd - 1) >> 6] & ((2ull << ((uEnd - 1) & 63)) - 1ull)) - ord0 + 1;
-    const uint64_t range = ((uint64_t) nSeg << idBits) - 1ull;
-    const int bl = range ? 64 - __clzll((long long) range) : 0, sh = max(0, bl - 8) + a.hiShift;       // sub-bucket = t >> sh
-    const uint64_t lowRep = (1ull << a.repShift) - 1ull;
-    // t = the key with the representative replaced by its ordinal in the unit (bit 0, the strand, still rides along); count
-    for (int i = u0 + tid; i < uEnd; i += U_NT) {
-        const unsigned long long w = sBits[i >> 6];
-        const unsigned int o = sPre[i >> 6] + (unsigned int) __popcll(w & ((2ull << (i & 63)) - 1ull)) - ord0;
-        const uint64_t k = sKeys[i];
-        if ((w >> (i & 63)) & 1ull) sRep[o] = (uint32_t) (k >> a.repShift);
-        const uint64_t t = ((uint64_t) o << a.repShift) | (k & lowRep);
-        sKeys[i] = t;
-        atomicAdd(&sCnt[(unsigned int) (t >> sh)], 1u);
-    }
-    __syncthreads();
-    const unsigned int c = tid < U_NB ? sCnt[tid] : 0u;
-    unsigned int tot;
-    const unsigned int ex = cdm_block_excl_sum<unsigned int>(c, tot);
-    if (tid < U_NB) sOff[tid] = ex;
-    if (tid == 0) sOff[U_NB] = tot;
-    const bool hard = __syncthreads_or(c > a.maxSub);
-    if (hard) { if (tid == 0) a.hard.add(base + (uint64_t) u0, base + (uint64_t) uEnd); return; }
-    if (tid < U_NB) sCnt[tid] = ex;             // (cursor of the scatter; the order inside a sub-bucket does not matter: the
-    __syncthreads();                            //  word carries the tuple's index)
-    for (int i = u0 + tid; i < uEnd; i += U_NT) sPerm[atomicAdd(&sCnt[(unsigned int) (sKeys[i] >> sh)], 1u)] = (uint16_t) i;
-    __syncthreads();
-    // ---- every wave sorts its 64 sub-buckets
-    constexpr int PER = U_NB / U_WAVES;
-    const uint64_t outBase = base + (uint64_t) u0;
-    auto sortRange = [&](int g0, int gm) {
-        bucket::sortGroup<uint64_t>(gm, lane,
-            [&](int i) { const int e = sPerm[g0 + i]; return ((sKeys[e] >> 1) << U_IDXB) | (uint64_t) e; },
-            [&](auto &v) {
-                constexpr int R = sizeof(v) / sizeof(v[0]);
+        const int idBits = a.repShift - a.hiShift;
+        const unsigned int nSeg = sPre[(m - 1) >> 6] + (unsigned int) __popcll(sBits[(m - 1) >> 6] & ((2ull << ((m - 1) & 63)) - 1ull));
+        const uint64_t range = ((uint64_t) nSeg << idBits) - 1ull;
+        const int bl = range ? 64 - __clzll((long long) range) : 0, sh = max(0, bl - 8) + a.hiShift;       // sub-bucket = t >> sh
+        const uint64_t lowRep = (1ull << a.repShift) - 1ull;
+        // t = the key with the representative replaced by its ordinal in the unit (bit 0, the strand, still rides along); count
+        for (int i = tid; i < m; i += U_NT) {
+            const unsigned long long w = sBits[i >> 6];
+            const unsigned int o = sPre[i >> 6] + (unsigned int) __popcll(w & ((2ull << (i & 63)) - 1ull)) - 1u;
+            const uint64_t k = sKeys[i];
+            if ((w >> (i & 63)) & 1ull) sRep[o] = (uint32_t) (k >> a.repShift);
+            const uint64_t t = ((uint64_t) o << a.repShift) | (k & lowRep);
+            sKeys[i] = t;
+            atomicAdd(&sCnt[(unsigned int) (t >> sh)], 1u);
+        }
+        __syncthreads();
+        const unsigned int c = tid < U_NB ? sCnt[tid] : 0u;
+        unsigned int tot;
+        const unsigned int ex = cdm_block_excl_sum<unsigned int>(c, tot);
+        if (tid < U_NB) sOff[tid] = ex;
+        if (tid == 0) sOff[U_NB] = tot;
+        const bool hard = __syncthreads_or(c > a.maxSub);
+        if (hard) { if (tid == 0) a.hard.add(base, base + (uint64_t) m); continue; }       // (block-uniform)
+        if (tid < U_NB) sCnt[tid] = ex;             // (cursor of the scatter; the order inside a sub-bucket does not matter: the
+        __syncthreads();                            //  word carries the tuple's index)
+        for (int i = tid; i < m; i += U_NT) sPerm[atomicAdd(&sCnt[(unsigned int) (sKeys[i] >> sh)], 1u)] = (uint16_t) i;
+        __syncthreads();
+        // ---- every wave sorts its share of the sub-buckets
+        constexpr int PER = U_NB / U_WAVES;
+        auto sortRange = [&](int g0, int gm) {
+            bucket::sortGroup<uint64_t>(gm, lane,
+                [&](int i) { const int e = sPerm[g0 + i]; return ((sKeys[e] >> 1) << U_IDXB) | (uint64_t) e; },
+                [&](auto &v) {
+                    constexpr int R = sizeof(v) / sizeof(v[0]);
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int p = lane * R + r;
-                    if (p < gm) { const uint64_t t = sKeys[(int) (v[r] & ((1u << U_IDXB) - 1u))]; a.out[outBase + (uint64_t) (g0 + p)] = ((uint64_t) sRep[t >> a.repShift] << a.repShift) | (t & lowRep); }
-                }
-            });
-    };
-    int b = wave * PER;
-    const int bLast = b + PER;
-    const int w0 = (int) sOff[b], wm = (int) sOff[bLast] - w0;
-    if (wm <= bucket::BK_MAXB) { if (wm > 0) sortRange(w0, wm); return; }
-    while (b < bLast) {
-        const int g0 = (int) sOff[b];
-        int bE = b + 1;
-        while (bE < bLast && (int) sOff[bE + 1] - g0 <= bucket::BK_GROUP) bE++;
-        const int gm = (int) sOff[bE] - g0;
-        if (gm > 0) sortRange(g0, gm);
-        b = bE;
+                    for (int r = 0; r < R; r++) {
+                        const int p = lane * R + r;
+                        if (p < gm) { const uint64_t t = sKeys[(int) (v[r] & ((1u << U_IDXB) - 1u))]; a.out[base + (uint64_t) (g0 + p)] = ((uint64_t) sRep[t >> a.repShift] << a.repShift) | (t & lowRep); }
+                    }
+                });
+        };
+        int b = wave * PER;
+        const int bLast = b + PER;
+        const int w0 = (int) sOff[b], wm = (int) sOff[bLast] - w0;
+        if (wm <= bucket::BK_MAXB) { if (wm > 0) sortRange(w0, wm); }
+        else while (b < bLast) {
+            const int g0 = (int) sOff[b];
+            int bE = b + 1;
+            while (bE < bLast && (int) sOff[bE + 1] - g0 <= bucket::BK_GROUP) bE++;
+            const int gm = (int) sOff[bE] - g0;
+            if (gm > 0) sortRange(g0, gm);
+            b = bE;
+        }
+        __syncthreads();        // the next unit reuses the LDS
     }
 }
 
@@ -314,8 +348,8 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, const uint64_t *in, uin
                              const uint32_t *recRep, const unsigned long long *dst, uint64_t nRec) {
     using namespace bucket;
     if (n == 0) return CDM_OK;
-    uint32_t maxSeg = U_CAP - U_T, blockCap = 4096;
-    if (const char *e = getenv("CDM_UNIT_CAP")) { const long m = atol(e); if (m >= 1 && m <= U_CAP - U_T) maxSeg = (uint32_t) m; }
+    uint32_t maxSeg = U_MAXSEG, blockCap = 4096;
+    if (const char *e = getenv("CDM_UNIT_CAP")) { const long m = atol(e); if (m >= 1 && m <= U_MAXSEG) maxSeg = (uint32_t) m; }
     if (const char *e = getenv("CDM_BLOCK_CAP")) { const long m = atol(e); if (m >= 0 && m <= 4096) blockCap = (uint32_t) m; }
     uint32_t maxSub = BK_MAXB;
     if (const char *e = getenv("CDM_UNIT_SUB")) { const long m = atol(e); if (m >= 1 && m <= BK_MAXB) maxSub = (uint32_t) m; }
@@ -323,12 +357,28 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, const uint64_t *in, uin
     if (U_ORDB + shiftHi - 1 + U_IDXB > 64) maxSeg = 0; // nor does the unit sorter's (ordinal, id, diagonal, index): everything goes to rocPRIM
     const uint64_t units = (n + U_T - 1) / U_T;
     const size_t listCap = (size_t) (n / ((uint64_t) maxSeg + 1) + 2);
-    DevBuf<unsigned long long> lists[SEG_CLASSES], hardList; DevBuf<unsigned int> cnt;
-    if (!cnt.alloc(SEG_CLASSES + 1) || !hardList.alloc(2 * (size_t) (units + 1))) return CDM_ERR_HIP;
+    DevBuf<unsigned long long> lists[SEG_CLASSES], hardList, uStart, uEnd, uList[U_CLASSES]; DevBuf<unsigned int> cnt;
+    constexpr int NCNT = SEG_CLASSES + 1 + U_CLASSES;
+    if (!cnt.alloc(NCNT) || !hardList.alloc(2 * (size_t) (units + 1)) || !uStart.alloc(units + 2) || !uEnd.alloc(units + 1)) return CDM_ERR_HIP;
+    for (int c = 0; c < U_CLASSES; c++) if (!uList[c].alloc(2 * (size_t) (units + 1))) return CDM_ERR_HIP;
     for (int c = 2; c < SEG_CLASSES; c++) if (!lists[c].alloc(2 * (listCap + (c == 3 ? (size_t) units + 1 : 0)))) return CDM_ERR_HIP;
-    hipMemsetAsync(cnt.p, 0, (SEG_CLASSES + 1) * 4, s);
-    UnitArgs ua; ua.in = in; ua.out = out; ua.n = n; ua.repShift = shiftHi; ua.hiShift = hiShift; ua.maxSeg = maxSeg; ua.maxSub = maxSub; ua.hard.list = hardList.p; ua.hard.cnt = cnt.p + SEG_CLASSES;
-    if (maxSeg) hipLaunchKernelGGL(k_unit_sort, dim3((unsigned) units), dim3(U_NT), cdm_lds_pad("CDM_LDS_PAD_UNIT"), s, ua);
+    hipMemsetAsync(cnt.p, 0, NCNT * 4, s);
+    if (maxSeg) {
+        // a boundary no record reaches (there is none: the records tile [0, n)) would leave its unit empty
+        hipMemsetAsync(uStart.p, 0, (units + 2) * 8, s); hipMemsetAsync(uEnd.p, 0, (units + 1) * 8, s);
+        UnitBoundArgs ub; ub.recRep = recRep; ub.dst = dst; ub.nRec = nRec; ub.maxSeg = maxSeg; ub.units = units; ub.uStart = uStart.p; ub.uEnd = uEnd.p;
+        hipLaunchKernelGGL(k_unit_bounds, dim3((unsigned) ((nRec + 1023) / 1024)), dim3(1024), 0, s, ub);
+        UnitClassArgs uc; uc.uStart = uStart.p; uc.uEnd = uEnd.p; uc.units = units; uc.n = n;
+        for (int c = 0; c < U_CLASSES; c++) { uc.cap[c] = (uint32_t) U_CLASS_CAP[c]; uc.list[c] = uList[c].p; }
+        uc.cnt = cnt.p + SEG_CLASSES + 1;
+        hipLaunchKernelGGL(k_unit_classes, dim3((unsigned) ((units + 1023) / 1024)), dim3(1024), 0, s, uc);
+        UnitArgs ua; ua.in = in; ua.out = out; ua.n = n; ua.repShift = shiftHi; ua.hiShift = hiShift; ua.maxSub = maxSub; ua.hard.list = hardList.p; ua.hard.cnt = cnt.p + SEG_CLASSES;
+        const unsigned int pad = cdm_lds_pad("CDM_LDS_PAD_UNIT");
+        const unsigned int grid = (unsigned int) std::min<uint64_t>(units, (uint64_t) cuCount * 64);
+        ua.list = uList[0].p; ua.count = cnt.p + SEG_CLASSES + 1; hipLaunchKernelGGL((k_unit_sort<U_CLASS_CAP[0], U_CLASS_NT[0]>), dim3(grid), dim3(U_CLASS_NT[0]), pad, s, ua);
+        ua.list = uList[1].p; ua.count = cnt.p + SEG_CLASSES + 2; hipLaunchKernelGGL((k_unit_sort<U_CLASS_CAP[1], U_CLASS_NT[1]>), dim3(grid), dim3(U_CLASS_NT[1]), pad, s, ua);
+        ua.list = uList[2].p; ua.count = cnt.p + SEG_CLASSES + 3; hipLaunchKernelGGL((k_unit_sort<U_CLASS_CAP[2], U_CLASS_NT[2]>), dim3(grid), dim3(U_CLASS_NT[2]), pad, s, ua);
+    }
     // the segments no unit can hold, listed by size class: one block of 8 waves (bitonic network, bucket.h) up to 4096, rocPRIM beyond
     SegListArgs la; la.recRep = recRep; la.dst = dst; la.nRec = nRec; la.maxWave = maxSeg;
     la.cap[0] = 0; la.cap[1] = 0; la.cap[2] = blockCap;
@@ -338,10 +388,10 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, const uint64_t *in, uin
     BlockSortArgs ba; ba.in = in; ba.out = out; ba.shiftHi = shiftHi; ba.ign = 1;
     ba.list = lists[2].p; ba.count = cnt.p + 2;
     if (blockCap) hipLaunchKernelGGL(k_block_sort<8>, dim3((unsigned int) std::min<uint64_t>((uint64_t) cuCount * 8, listCap)), dim3(512), 0, s, ba);
-    unsigned int hc[SEG_CLASSES + 1] = {0, 0, 0, 0, 0};
-    if (hipMemcpyAsync(hc, cnt.p, (SEG_CLASSES + 1) * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
-    if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "segmentedSortKeys: n %llu, %llu records, %llu units: segments > %u: %u (<= %u, block sort), %u longer (rocPRIM); %u hard units (rocPRIM)\n",
-                                            (unsigned long long) n, (unsigned long long) nRec, (unsigned long long) units, maxSeg, hc[2], blockCap, hc[3], hc[SEG_CLASSES]);
+    unsigned int hc[NCNT] = {0};
+    if (hipMemcpyAsync(hc, cnt.p, NCNT * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
+    if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "segmentedSortKeys: n %llu, %llu records, %llu units (%u / %u / %u by size class): segments > %u: %u (<= %u, block sort), %u longer (rocPRIM); %u hard units (rocPRIM)\n",
+                                            (unsigned long long) n, (unsigned long long) nRec, (unsigned long long) units, hc[SEG_CLASSES + 1], hc[SEG_CLASSES + 2], hc[SEG_CLASSES + 3], maxSeg, hc[2], blockCap, hc[3], hc[SEG_CLASSES]);
     const unsigned int nBig = hc[3] + hc[SEG_CLASSES];
     if (nBig == 0) return CDM_OK;
     // deep pile-ups and hard units: gather, sort on the whole key with rocPRIM (stable), scatter.  (The ranges are disjoint and
