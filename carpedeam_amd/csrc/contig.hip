@@ -6,6 +6,9 @@
 // per query: the Beta-posterior comparator (:25-70; lgammaf / logf / exp of the C library decide the order and it is not a
 // strict weak ordering, so the queue is libstdc++'s std::priority_queue with that very comparator), the extension loop and the
 // re-alignment of parked hits - host code of the library (host/contigmerge.cpp), compiled like the reference.
+#include <chrono>
+#include <memory>
+
 #include "common.h"
 #include "devutil.h"
 
@@ -75,9 +78,13 @@ __global__ void k_rec_owner(const uint64_t *__restrict__ aoff, uint32_t n, uint3
 }  // namespace
 
 // host/contigmerge.cpp
+// (host/contigmerge.cpp, OpenMP) the DB blob as one string per sequence / the strings as one DB blob "SEQ\n\0..."
+void cdm_host_split(const std::string &blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<std::string> &seqs);
+void cdm_host_pack(const std::vector<std::string> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, std::unique_ptr<char[]> &data,
+                   std::vector<uint64_t> &off, std::vector<uint32_t> &len);
 int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
                           const std::vector<cdm_aln> &recs, const std::vector<ContigStat> &stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
-                          float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::string *err);
+                          float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::vector<uint8_t> &changed, std::string *err);
 
 extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float mergeSeqIdThr, cdm_seqdb **out) {
     if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_contig_merge: NULL argument"); return CDM_ERR_INVALID; }
@@ -97,6 +104,10 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     if (nRec) hipLaunchKernelGGL(k_contig_stats, dim3((unsigned) ((nRec * 64 + 255) / 256)), dim3(256), 0, s, a);
     hipEventRecord(ctx->ev1, s);
     // everything else is per-query bookkeeping on the host: sequences, records and the per-record statistics come down once
+    const bool timing = getenv("CDM_TIMING") != nullptr;
+    auto tNow = [] { return std::chrono::steady_clock::now(); };
+    auto tPrev = tNow();
+    auto lap = [&](const char *what) { if (timing) { const auto t = tNow(); fprintf(stderr, "  contig merge: %-28s %.3f s\n", what, std::chrono::duration<double>(t - tPrev).count()); tPrev = t; } };
     std::vector<ContigStat> stats(nRec); std::vector<uint64_t> aoff(n + 1); std::vector<cdm_aln> recs(nRec);
     std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
     CDM_HIP(hipMemcpyAsync(stats.data(), dStats.p, nRec * sizeof(ContigStat), hipMemcpyDeviceToHost, s));
@@ -108,13 +119,22 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     std::vector<uint64_t> offs(n); uint64_t tot = 0;
     for (uint32_t i = 0; i < n; i++) { offs[i] = tot; tot += lens[i] + 1; }
     std::string blob(tot, '\0');
+    lap("statistics + records down");
     if (int rc = cdm_seqdb_download(ctx, db, &blob[0], offs.data())) return rc;
-    std::vector<std::string> seqs(n), outSeqs; std::vector<uint8_t> outExt;
-    for (uint32_t i = 0; i < n; i++) seqs[i].assign(blob, offs[i], lens[i]);
+    lap("sequences down");
+    std::vector<std::string> seqs(n), outSeqs; std::vector<uint8_t> outExt, changed;
+    cdm_host_split(blob, offs, lens, seqs);
+    { std::string().swap(blob); }
+    lap("split");
     std::string err;
-    if (int rc = cdm_contig_merge_host(seqs, keys, ext, aoff, recs, stats, ctx->mats, par, mergeSeqIdThr, outSeqs, outExt, &err)) { cdm_set_error("%s", err.c_str()); return rc; }
+    if (int rc = cdm_contig_merge_host(seqs, keys, ext, aoff, recs, stats, ctx->mats, par, mergeSeqIdThr, outSeqs, outExt, changed, &err)) { cdm_set_error("%s", err.c_str()); return rc; }
+    lap("queues + extension (host)");
     // the result goes back up as a DB (same keys, new lengths and flags)
-    std::string data; std::vector<uint64_t> oOff(n); std::vector<uint32_t> oLen(n);
-    for (uint32_t i = 0; i < n; i++) { oOff[i] = data.size(); oLen[i] = (uint32_t) outSeqs[i].size(); data += outSeqs[i]; data += "\n"; data.push_back('\0'); }
-    return cdm_seqdb_upload(ctx, data.data(), oOff.data(), oLen.data(), keys.data(), outExt.data(), n, out);
+    std::vector<uint64_t> oOff; std::vector<uint32_t> oLen; std::unique_ptr<char[]> data;
+    cdm_host_pack(seqs, outSeqs, changed, data, oOff, oLen);
+    { std::vector<std::string>().swap(outSeqs); std::vector<std::string>().swap(seqs); }
+    lap("pack");
+    const int rcUp = cdm_seqdb_upload(ctx, data.get(), oOff.data(), oLen.data(), keys.data(), outExt.data(), n, out);
+    lap("upload");
+    return rcUp;
 }

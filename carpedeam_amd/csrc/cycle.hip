@@ -25,6 +25,7 @@ struct CycArgs {
     const u64 *koff, *hoff;      // [n+1] first k-mer ordinal / first diagonal counter of each contig
     u64 totalK, totalH;
     u64 *keys; uint32_t *vals;   // sorted: (k-mer index, ordinal)
+    uint32_t *owner;             // contig of every ordinal (the k-mers of different contigs interleave in the sorted array)
     uint32_t *hits, *split;
 };
 __global__ void k_cyc_sizes(const uint32_t *__restrict__ len, uint32_t n, uint32_t maxSeqLen, u64 *__restrict__ nk, u64 *__restrict__ nh) {
@@ -54,14 +55,14 @@ __global__ __launch_bounds__(256) void k_cyc_kmers(CycArgs a) {
         const u64 sp = (u64) cdm_spread16(nw) | ((u64) cdm_spread16(nw >> 16) << 32);
         x = (x & ~(sp * 3u)) + (sp << 2);
     }
-    a.keys[g] = x; a.vals[g] = (uint32_t) g;
+    a.keys[g] = x; a.vals[g] = (uint32_t) g; a.owner[g] = i;
 }
 __global__ __launch_bounds__(256) void k_cyc_hits(CycArgs a) {
     const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 || i >= a.totalK) return;
     const u64 key = a.keys[i];
     if (a.keys[i - 1] != key) return;
-    const uint32_t g = a.vals[i], c = ownerOf(a.koff, a.n, g);
+    const uint32_t g = a.vals[i], c = a.owner[g];
     const uint32_t base = (uint32_t) a.koff[c], pos = g - base, L = a.len[c], third = L / 3;
     if (pos < third + 2 || a.vals[i - 1] < base) return;           // a front occurrence (or position 0) matches nothing before it; alone in its run
     // head of the run (same k-mer, same contig): gallop back, then bisect.  in(j) is monotone on [0, i]
@@ -133,12 +134,12 @@ extern "C" int cdm_cyclecheck(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t maxSeq
     CDM_HIP(hipStreamSynchronize(s));
     if (totalK >= 0xFFFFFFFFull) { cdm_set_error("cdm_cyclecheck: more than 2^32-1 k-mer positions (%llu)", totalK); return CDM_ERR_UNSUPPORTED; }
     CDM_HIP(hipMemsetAsync(split.p, 0xFF, (size_t) n * 4 + 4, s));
-    DevBuf<u64> k0, k1; DevBuf<uint32_t> v0, v1, hits; DevBuf<char> tmp;
-    CycArgs a = {db->codes, db->nmask, db->woff, db->len, db->hasN, n, maxSeqLen, koff.p, hoff.p, totalK, totalH, nullptr, nullptr, nullptr, split.p};
+    DevBuf<u64> k0, k1; DevBuf<uint32_t> v0, v1, hits, owner; DevBuf<char> tmp;
+    CycArgs a = {db->codes, db->nmask, db->woff, db->len, db->hasN, n, maxSeqLen, koff.p, hoff.p, totalK, totalH, nullptr, nullptr, nullptr, nullptr, split.p};
     if (totalK) {
-        if (!k0.alloc(totalK) || !k1.alloc(totalK) || !v0.alloc(totalK) || !v1.alloc(totalK) || !hits.alloc(totalH)) { cdm_set_error("cdm_cyclecheck: out of device memory"); return CDM_ERR_HIP; }
+        if (!k0.alloc(totalK) || !k1.alloc(totalK) || !v0.alloc(totalK) || !v1.alloc(totalK) || !hits.alloc(totalH) || !owner.alloc(totalK)) { cdm_set_error("cdm_cyclecheck: out of device memory"); return CDM_ERR_HIP; }
         CDM_HIP(hipMemsetAsync(hits.p, 0, (totalH + 1) * 4, s));
-        a.keys = k0.p; a.vals = v0.p; a.hits = hits.p;
+        a.keys = k0.p; a.vals = v0.p; a.hits = hits.p; a.owner = owner.p;
         hipLaunchKernelGGL(k_cyc_kmers, dim3((unsigned) ((totalK + 255) / 256)), dim3(256), 0, s, a);
         rocprim::double_buffer<u64> kb(k0.p, k1.p); rocprim::double_buffer<uint32_t> vb(v0.p, v1.p);
         size_t tb = 0;

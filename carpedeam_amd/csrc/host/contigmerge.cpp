@@ -11,6 +11,7 @@
 #include <cstring>
 #include <omp.h>
 #include <queue>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -86,11 +87,28 @@ bool selectFragment(Queue &q, uint32_t queryKey, Res &out) {
 }
 }  // namespace
 
+void cdm_host_split(const std::string &blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<std::string> &seqs) {
+    const long n = (long) offs.size();
+    seqs.resize(n);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) seqs[i].assign(blob, offs[i], lens[i]);
+}
+// changed[i] != 0: sequence i is grown[i], otherwise still seqs[i].  The blob is written by all threads (first touch included).
+void cdm_host_pack(const std::vector<std::string> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, std::unique_ptr<char[]> &data,
+                   std::vector<uint64_t> &off, std::vector<uint32_t> &len) {
+    const long n = (long) seqs.size();
+    off.resize(n); len.resize(n);
+    uint64_t total = 0;
+    for (long i = 0; i < n; i++) { const std::string &x = changed[i] ? grown[i] : seqs[i]; off[i] = total; len[i] = (uint32_t) x.size(); total += x.size() + 2; }
+    data.reset(new char[total + 1]);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) { const std::string &x = changed[i] ? grown[i] : seqs[i]; char *d = data.get() + off[i]; memcpy(d, x.data(), x.size()); d[x.size()] = '\n'; d[x.size() + 1] = '\0'; }
+}
 int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
                           const std::vector<cdm_aln> &recs, const std::vector<ContigStat> &stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
-                          float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::string *err) {
+                          float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::vector<uint8_t> &changed, std::string *err) {
     const size_t n = seqs.size();
-    outSeqs.assign(n, std::string()); outExt.assign(n, 0);
+    outSeqs.assign(n, std::string()); outExt.assign(n, 0); changed.assign(n, 0);
     const float ryThr = par->ry_seq_id_thr;
     bool undefinedCase = false;
 #pragma omp parallel
@@ -102,7 +120,7 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
             const uint32_t queryKey = keys[id];
             const std::string &q0 = seqs[id];
             unsigned qLen = (unsigned) q0.size();
-            std::string query = q0;
+            std::string query;                              // working copy, made once a candidate exists
             contigs.clear();
             Queue queue;
             // :187-235 orientation, identities (from the device), contig filter
@@ -147,6 +165,8 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
                 }
             }
             // :276-470 extension
+            if (queue.empty()) { outExt[id] = ext[id]; continue; }
+            query = q0;
             bool couldExtend = false;
             while (!queue.empty()) {
                 unsigned leftOff = 0, rightOff = 0;
@@ -206,8 +226,8 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
                     if (a.seqId >= mergeSeqIdThr && a.rySeqId >= ryThr) queue.push(a);
                 }
             }
-            if (couldExtend) { outSeqs[id] = query; outExt[id] = 1; }
-            else { outSeqs[id] = q0; outExt[id] = ext[id]; }
+            if (couldExtend) { outSeqs[id].swap(query); outExt[id] = 1; changed[id] = 1; }
+            else outExt[id] = ext[id];
         }
     }
     if (undefinedCase) { *err = "cdm_contig_merge: a target overhangs its query by more than the query's length; the reference pads it with a negative number of letters there (undefined behaviour), not reproduced"; return CDM_ERR_UNSUPPORTED; }

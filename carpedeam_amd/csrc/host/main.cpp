@@ -416,14 +416,17 @@ int readsLoop(Args &a) {
     for (long it = 0; it < total && cdm_seqdb_size(db) > 0; it++) {
         cdm_hits *hits = NULL; cdm_alns *alns = NULL; cdm_seqdb *corr = NULL, *next = NULL;
         const bool contigs = it >= iters;
+        const auto tIt = std::chrono::steady_clock::now();
         check(cdm_kmermatch(ctx, db, contigs ? &kc : &kp, &hits), "kmermatcher");
         check(cdm_rescore(ctx, db, hits, &rp, &alns), "rescorediagonal");
         cdm_hits_free(hits);
         check(cdm_correct(ctx, db, alns, &ap, &corr), "ancient_correction");
         if (contigs) check(cdm_contig_merge(ctx, corr, alns, &ap, mergeThr, &next), "ancient_contig_merge");
         else check(cdm_extend(ctx, corr, alns, &ap, &next, NULL), "ancient_read_assemble");
-        fprintf(stderr, "STEP: %ld  sequences %llu  residues %llu -> %llu  alignments %llu\n", it, (unsigned long long) cdm_seqdb_size(db),
-                (unsigned long long) cdm_seqdb_residues(db), (unsigned long long) cdm_seqdb_residues(next), (unsigned long long) cdm_alns_count(alns));
+        fprintf(stderr, "STEP: %ld  sequences %llu  residues %llu -> %llu  alignments %llu  (%.3f s; device stages: kmermatcher %.0f, rescorediagonal %.0f, ancient_correction %.0f, %s %.0f ms)\n",
+                it, (unsigned long long) cdm_seqdb_size(db), (unsigned long long) cdm_seqdb_residues(db), (unsigned long long) cdm_seqdb_residues(next), (unsigned long long) cdm_alns_count(alns),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - tIt).count(), cdm_ctx_last_kernel_ms(ctx, 8), cdm_ctx_last_kernel_ms(ctx, 9), cdm_ctx_last_kernel_ms(ctx, 10),
+                contigs ? "contig statistics" : "ancient_read_assemble", cdm_ctx_last_kernel_ms(ctx, contigs ? 12 : 11));
         cdm_alns_free(alns); cdm_seqdb_free(corr); cdm_seqdb_free(db);
         db = next;
         if (contigs && cycleCheck) {

@@ -463,6 +463,10 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
     SeqPos *sp = CAP ? sSp : a.hugeSp + (size_t) blockIdx.x * a.hugeCap;
     uint8_t *sel = CAP ? sSel : a.hugeSel + (size_t) blockIdx.x * a.hugeCap;
     __shared__ uint32_t sN, sCursor;
+    // CAP = 0: the head of the sorted records is copied to LDS for the serial selection walk (one thread chasing through global
+    // scratch took milliseconds per contig; the walk ends after ~0.2 n + 200 records)
+    constexpr uint32_t HEADN = CAP ? 1 : 3072;
+    __shared__ SeqPos sHead[HEADN];
     const int tid = threadIdx.x;
     for (uint32_t item = blockIdx.x; item < a.nList; item += gridDim.x) {
         const uint32_t seq = a.list[item];
@@ -513,6 +517,9 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
         }
         // ---- selection (kmermatcher.cpp:224-240, 277-350)
         const size_t considered = min((size_t) (float) ((float) (a.kmersPerSeq - 1) + (a.scale * (float) L)), (size_t) n);
+        uint32_t headN = 0;
+        if (CAP == 0) { headN = min(n, HEADN); for (uint32_t i = tid; i < headN; i += NT) sHead[i] = sp[i]; }
+        auto at = [&](size_t i) -> SeqPos { return (CAP == 0 && i < headN) ? sHead[i] : sp[i]; };
         // fast path test: no two equal k-mers next to each other, and every k-mer is taken
         int dup = 0;
         for (uint32_t i = tid; i + 1 < n; i += NT) dup |= (spKmer63(sp[i]) == spKmer63(sp[i + 1]));
@@ -526,12 +533,12 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
                 // threshold = (score of the considered-th smallest) + 1, inBins = #(score < threshold)  [:224-240]
                 uint32_t threshold = 0; size_t inBins = 0;
                 if (considered > 0) {
-                    threshold = spScore(sp[considered - 1]) + 1;
+                    threshold = spScore(at(considered - 1)) + 1;
                     inBins = considered;
-                    while (inBins < n && spScore(sp[inBins]) < threshold) inBins++;
+                    while (inBins < n && spScore(at(inBins)) < threshold) inBins++;
                 } else {
                     // the reference's loops leave threshold at the start of the first non-empty 512-bin and subtract that bin
-                    threshold = (spScore(sp[0]) >> 9) * 512; inBins = 0;
+                    threshold = (spScore(at(0)) >> 9) * 512; inBins = 0;
                 }
                 int tooMuch = (int) (inBins - considered);
                 size_t selected = 0;
@@ -540,20 +547,22 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
                     // order they were generated; the threshold above only needed the score distribution
                     uint32_t m = 0;
                     for (uint32_t pos = 0; pos < nPos; pos++) { SeqPos e; if (makeSeqPos(a, w0, L, lastWord, hasN, k, pos, e)) sp[m++] = e; }
+                    headN = 0;      // (the LDS copy holds the sorted order)
                 }
                 for (size_t ki = 0; ki < n && selected < considered; ki++) {
                     if (a.ignoreMultiKmer) {
-                        const uint64_t km = spKmer63(sp[ki]);
+                        const uint64_t km = spKmer63(at(ki));
                         if (ki + 1 < n) {
-                            uint64_t nx = spKmer63(sp[ki + 1]);
+                            uint64_t nx = spKmer63(at(ki + 1));
                             if (km == nx) {
-                                while (km == nx && ki < n) { ki++; if (ki >= n) break; nx = spKmer63(sp[ki]); }
+                                while (km == nx && ki < n) { ki++; if (ki >= n) break; nx = spKmer63(at(ki)); }
                             }
                         }
                         if (ki >= n) break;
                     }
-                    if (spScore(sp[ki]) < threshold) {
-                        if (spScore(sp[ki]) == (threshold - 1) && tooMuch) { tooMuch--; threshold -= (tooMuch == 0) ? 1 : 0; }
+                    const uint32_t sc = spScore(at(ki));
+                    if (sc < threshold) {
+                        if (sc == (threshold - 1) && tooMuch) { tooMuch--; threshold -= (tooMuch == 0) ? 1 : 0; }
                         selected++;
                         sel[ki] = 1;
                     }
@@ -1207,7 +1216,7 @@ int phaseA() override {
     DevBuf<SeqPos> hugeSp; DevBuf<uint8_t> hugeSel;
     if (hcls[3]) {
         uint32_t cap = LONG_CAP; while (cap < db->maxLen) cap <<= 1;
-        const uint32_t blocks = std::min<uint32_t>(hcls[3], 64);
+        const uint32_t blocks = std::min<uint32_t>(hcls[3], (uint32_t) ctx->cuCount * 4);       // (17 bytes of scratch per record: 2.2 MB per block for 100 k-letter contigs)
         if (!hugeSp.alloc((size_t) blocks * cap) || !hugeSel.alloc((size_t) blocks * cap)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
         ea.list = listHuge.p; ea.nList = hcls[3]; ea.hugeSp = hugeSp.p; ea.hugeSel = hugeSel.p; ea.hugeCap = cap;
         hipLaunchKernelGGL((k_extract<LY, 0, 256>), dim3(blocks), dim3(256), 0, s, ea);
