@@ -1418,21 +1418,13 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
             if (!runsOut.alloc(nIn) || !runsTmp.alloc(nIn)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2 check)"); return CDM_ERR_HIP; }
             gatheredBuf = runsTmp.p; sortedOut = runsOut.p;
         }
-        const uint64_t tiles = (nIn + RUN_TILE - 1) / RUN_TILE;
-        DevBuf<unsigned long long> tileCnt, tileOff;
-        if (!tileCnt.alloc(tiles + 1) || !tileOff.alloc(tiles + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2)"); return CDM_ERR_HIP; }
         RunArgs ra; ra.keys = gk; ra.n = nIn; ra.skipLo = skipLo; ra.skipHi = skipHi; ra.repShift = (int) (idBits + diagBits + 1);
-        hipMemsetAsync(tileCnt.p + tiles, 0, 8, s);
-        if (tiles) hipLaunchKernelGGL(k_run_count, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, tileCnt.p);
-        cdmscan::ScanTemp stA, stB;
-        if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, stA, tileCnt.p, tileOff.p, (size_t) tiles + 1)) return rc;
+        cdmscan::ScanTemp stB;
         unsigned long long nRec = 0;
-        hipMemcpyAsync(&nRec, tileOff.p + tiles, 8, hipMemcpyDeviceToHost, s);
-        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: sort 2 (records) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
         DevBuf<uint32_t> rr0, rr1; DevBuf<uint64_t> rv0, rv1; DevBuf<unsigned long long> dst;
-        if (!rr0.alloc(nRec) || !rr1.alloc(nRec) || !rv0.alloc(nRec) || !rv1.alloc(nRec) || !dst.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
+        if (int rc = makeRunRecords(s, ra, rr0, rr1, rv0, rv1, nRec)) return rc;
+        if (!dst.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
         if (nRec) {
-            hipLaunchKernelGGL(k_run_write, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, (const unsigned long long *) tileOff.p, rr0.p, rv0.p);
             rocprim::double_buffer<uint32_t> rk(rr0.p, rr1.p); rocprim::double_buffer<uint64_t> rv(rv0.p, rv1.p);
             size_t tb = 0;
             rocprim::radix_sort_pairs(nullptr, tb, rk, rv, (size_t) nRec, 0, idBits, s);
@@ -1532,21 +1524,14 @@ int vote(const uint32_t *contDev, bool ownBuffers, cdm_hits **out) {
 int gatherByRep() override {
     using namespace runsort;
     v0.free(); v1.free();
-    const uint64_t tiles = (nTuples + RUN_TILE - 1) / RUN_TILE;
-    DevBuf<unsigned long long> tileCnt, tileOff; cdmscan::ScanTemp stA, stB;
-    if (!tileCnt.alloc(tiles + 1) || !tileOff.alloc(tiles + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2)"); return CDM_ERR_HIP; }
+    cdmscan::ScanTemp stB;
     RunArgs ra; ra.keys = (const uint64_t *) startIo; ra.n = nTuples; ra.skipLo = live; ra.skipHi = kmerSlots; ra.repShift = (int) (idBits + diagBits + 1);
-    hipMemsetAsync(tileCnt.p + tiles, 0, 8, s);
-    if (tiles) hipLaunchKernelGGL(k_run_count, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, tileCnt.p);
-    if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, stA, tileCnt.p, tileOff.p, (size_t) tiles + 1)) return rc;
     unsigned long long nRec = 0, nOut = 0;
-    hipMemcpyAsync(&nRec, tileOff.p + tiles, 8, hipMemcpyDeviceToHost, s);
-    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: gather by representative failed"); return CDM_ERR_HIP; }
+    DevBuf<uint32_t> rr0, rr1; DevBuf<uint64_t> rv0, rv1; DevBuf<unsigned long long> dst; DevBuf<char> t1; size_t tb = 0;
+    if (int rc = makeRunRecords(s, ra, rr0, rr1, rv0, rv1, nRec)) return rc;
     gathered = keys.current();
     if (nRec == 0) return CDM_OK;
-    DevBuf<uint32_t> rr0, rr1; DevBuf<uint64_t> rv0, rv1; DevBuf<unsigned long long> dst; DevBuf<char> t1; size_t tb = 0;
-    if (!rr0.alloc(nRec) || !rr1.alloc(nRec) || !rv0.alloc(nRec) || !rv1.alloc(nRec) || !dst.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
-    hipLaunchKernelGGL(k_run_write, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, (const unsigned long long *) tileOff.p, rr0.p, rv0.p);
+    if (!dst.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
     rocprim::double_buffer<uint32_t> rk(rr0.p, rr1.p); rocprim::double_buffer<uint64_t> rv(rv0.p, rv1.p);
     rocprim::radix_sort_pairs(nullptr, tb, rk, rv, (size_t) nRec, 0, idBits, s);
     if (!t1.alloc(tb + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2)"); return CDM_ERR_HIP; }

@@ -92,6 +92,74 @@ __global__ __launch_bounds__(RUN_NT) void k_run_write(RunArgs a, const unsigned 
         rank++;
     }
 }
+// ---- count and write in ONE pass over the keys: a tile learns where its records go from the tiles in front of it through a
+// chained scan with decoupled look-back (status word per tile: 2 bits of state | 62 bits of count - the word is the whole message,
+// relaxed atomics do; tiles are numbered by a ticket
+// taken at start, so a tile only ever waits for tiles that already run).  cap = room in recRep / recVal: a tile that would write
+// beyond it raises the flag and writes nothing (the caller falls back to k_run_count / k_run_write with exact sizes).
+constexpr unsigned long long RS_AGG = 1ull << 62, RS_PREFIX = 2ull << 62, RS_MASK = (1ull << 62) - 1ull;
+struct RunScan { unsigned long long *status; unsigned int *ticket; unsigned long long *total; unsigned int *overflow; unsigned long long cap; unsigned long long tiles; };
+__global__ __launch_bounds__(RUN_NT) void k_run_records(RunArgs a, RunScan sc, uint32_t *__restrict__ recRep, uint64_t *__restrict__ recVal) {
+    __shared__ uint64_t sKeys[RUN_LDS];
+    __shared__ __align__(8) uint16_t sBound[RUN_TILE / 16 + 4];
+    __shared__ unsigned int sTile;
+    __shared__ unsigned long long sPrefix;
+    if (threadIdx.x == 0) sTile = atomicAdd(sc.ticket, 1u);
+    __syncthreads();
+    const unsigned long long tile = sTile;
+    const uint64_t base = (uint64_t) tile * RUN_TILE;
+    unsigned int sb, bb;
+    runFlags(a, base, sKeys, sb, bb);
+    sBound[threadIdx.x] = (uint16_t) bb;
+    if (threadIdx.x < 4) sBound[RUN_TILE / 16 + threadIdx.x] = 0;
+    unsigned int tot;
+    const unsigned int ex = cdm_block_excl_sum<unsigned int>((unsigned int) __popc(sb), tot);        // (its barriers publish sBound)
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        unsigned long long excl = 0;
+        if (tile == 0) { if (lane == 0) __hip_atomic_store(&sc.status[0], RS_PREFIX | (unsigned long long) tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else {
+            if (lane == 0) __hip_atomic_store(&sc.status[tile], RS_AGG | (unsigned long long) tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long t0 = (long long) tile - 1;                    // lane l looks at tile t0 - l
+            while (true) {
+                const long long t = t0 - lane;
+                unsigned long long v = RS_PREFIX;                   // in front of tile 0: nothing
+                if (t >= 0) do { v = __hip_atomic_load(&sc.status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 62) == 0ull);
+                const unsigned long long pm = __ballot((v >> 62) == 2ull);
+                const int first = pm ? __ffsll(pm) - 1 : 63;       // the nearest tile with a full prefix closes the sum
+                const unsigned long long part = cdm_wave_incl_sum<unsigned long long>(lane <= first ? (v & RS_MASK) : 0ull);
+                excl += (unsigned long long) __shfl((long long) part, 63, 64);
+                if (pm) break;
+                t0 -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(&sc.status[tile], RS_PREFIX | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            sPrefix = excl;
+            if (tile + 1 == sc.tiles) *sc.total = excl + tot;
+            if (excl + tot > sc.cap) *sc.overflow = 1u;
+        }
+    }
+    __syncthreads();
+    unsigned long long rank = sPrefix + ex;
+    if (sPrefix + tot > sc.cap) return;
+    const unsigned long long *words = reinterpret_cast<const unsigned long long *>(sBound);
+#pragma unroll 1
+    while (sb) {
+        const int j = __ffs(sb) - 1;
+        sb &= sb - 1;
+        const int li = threadIdx.x * RUN_ITEMS + j;
+        int e = RUN_TILE;                                        // end = next boundary behind li (tile end if none)
+        for (int w = (li + 1) >> 6; w < RUN_TILE / 64; w++) {
+            unsigned long long m = words[w];
+            if (w == ((li + 1) >> 6)) m &= ~0ull << ((li + 1) & 63);
+            if (m) { e = w * 64 + __ffsll(m) - 1; break; }
+        }
+        recRep[rank] = (uint32_t) (sKeys[runPad(li)] >> a.repShift);
+        recVal[rank] = ((base + (uint64_t) li) << RUN_CNT_BITS) | (uint64_t) (e - li);
+        rank++;
+    }
+}
 struct RunLen { const uint64_t *recVal; __device__ __forceinline__ unsigned long long operator()(size_t j) const { return recVal[j] & ((1ull << RUN_CNT_BITS) - 1ull); } };
 
 // expands the sorted records: out[dst[j] ..] = the tuples of record j.  A wave takes 64 consecutive records; their tuples
@@ -408,6 +476,39 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, const uint64_t *in, uin
     if (rocprim::radix_sort_keys(tmp.p, tb, db, (size_t) total, 1, top, s) != hipSuccess) return CDM_ERR_HIP;
     hipLaunchKernelGGL((k_big_copy<uint64_t, false>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, out, db.current());
     if (hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
+    return CDM_OK;
+}
+
+// The run records of `ra.keys` (k_run_records; k_run_count + k_run_write if there are more than one per eight slots): recRep / recVal
+// get room for two buffers each (the sort's double buffers).  Synchronises the stream.
+inline int makeRunRecords(hipStream_t s, const RunArgs &ra, DevBuf<uint32_t> &rr0, DevBuf<uint32_t> &rr1, DevBuf<uint64_t> &rv0, DevBuf<uint64_t> &rv1, unsigned long long &nRec) {
+    const uint64_t tiles = (ra.n + RUN_TILE - 1) / RUN_TILE;
+    nRec = 0;
+    if (tiles == 0) return CDM_OK;
+    const char *mode = getenv("CDM_RUN_RECORDS");          // "twopass": the fallback only (tests)
+    unsigned long long cap = ra.n / 8 + 4096;
+    if (const char *e = getenv("CDM_RUN_CAP")) cap = strtoull(e, nullptr, 10);       // tests: force the overflow path
+    if (!(mode && !strcmp(mode, "twopass"))) {
+        DevBuf<unsigned long long> status, total; DevBuf<unsigned int> flags;
+        if (!status.alloc(tiles) || !total.alloc(1) || !flags.alloc(2) || !rr0.alloc(cap) || !rr1.alloc(cap) || !rv0.alloc(cap + 1) || !rv1.alloc(cap + 1)) { cdm_set_error("run records: out of device memory"); return CDM_ERR_HIP; }
+        hipMemsetAsync(status.p, 0, tiles * 8, s); hipMemsetAsync(total.p, 0, 8, s); hipMemsetAsync(flags.p, 0, 8, s);
+        RunScan sc; sc.status = status.p; sc.ticket = flags.p; sc.overflow = flags.p + 1; sc.total = total.p; sc.cap = cap; sc.tiles = tiles;
+        hipLaunchKernelGGL(k_run_records, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, sc, rr0.p, rv0.p);
+        unsigned int fl[2] = {0, 0};
+        hipMemcpyAsync(&nRec, total.p, 8, hipMemcpyDeviceToHost, s); hipMemcpyAsync(fl, flags.p, 8, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("run records failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+        if (!fl[1]) return CDM_OK;
+        rr0.free(); rr1.free(); rv0.free(); rv1.free();
+    }
+    DevBuf<unsigned long long> tileCnt, tileOff; cdmscan::ScanTemp st;
+    if (!tileCnt.alloc(tiles + 1) || !tileOff.alloc(tiles + 1)) { cdm_set_error("run records: out of device memory"); return CDM_ERR_HIP; }
+    hipMemsetAsync(tileCnt.p + tiles, 0, 8, s);
+    hipLaunchKernelGGL(k_run_count, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, tileCnt.p);
+    if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, st, tileCnt.p, tileOff.p, (size_t) tiles + 1)) return rc;
+    hipMemcpyAsync(&nRec, tileOff.p + tiles, 8, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("run records failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    if (!rr0.alloc(nRec) || !rr1.alloc(nRec) || !rv0.alloc(nRec + 1) || !rv1.alloc(nRec + 1)) { cdm_set_error("run records: out of device memory (%llu records)", nRec); return CDM_ERR_HIP; }
+    if (nRec) hipLaunchKernelGGL(k_run_write, dim3((unsigned) tiles), dim3(RUN_NT), 0, s, ra, (const unsigned long long *) tileOff.p, rr0.p, rv0.p);
     return CDM_OK;
 }
 

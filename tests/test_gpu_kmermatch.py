@@ -116,7 +116,7 @@ def test_kmermatch_bucket_sort_paths_agree(ctx, oracle_bin, tmp_path, monkeypatc
                 # a sub-bucket of more than 3 tuples through the hard list
                 {"CDM_KMER_SORT2": "radix"}, {"CDM_KMER_SORT2": "check"}, {"CDM_KMER_SORT2": "check", "CDM_UNIT_CAP": "5"},
                 {"CDM_KMER_SORT2": "check", "CDM_UNIT_CAP": "5", "CDM_BLOCK_CAP": "8"}, {"CDM_UNIT_CAP": "1", "CDM_BLOCK_CAP": "0"},
-                {"CDM_KMER_SORT2": "check", "CDM_UNIT_SUB": "3"}):
+                {"CDM_KMER_SORT2": "check", "CDM_UNIT_SUB": "3"}, {"CDM_RUN_RECORDS": "twopass"}, {"CDM_KMER_SORT2": "check", "CDM_RUN_CAP": "10"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         assert not diff_keys(kmermatch_text(ctx, mmdb.read_db(t("in"))), want), env
@@ -130,7 +130,8 @@ def test_kmermatch_variants_identical_at_scale(ctx, monkeypatch):
     db = ctx.synth(1_000_000, 100, 100, 5)
     ref = None
     for env in ({}, {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_KMER_SORT": "lsd"}, {"CDM_BUCKET_CAP": "48"},
-                {"CDM_KMER_SORT2": "radix"}, {"CDM_KMER_SORT2": "check"}, {"CDM_KMER_SORT2": "check", "CDM_UNIT_CAP": "700"}, {"CDM_KMER_SORT2": "check", "CDM_UNIT_SUB": "12"}):
+                {"CDM_KMER_SORT2": "radix"}, {"CDM_KMER_SORT2": "check"}, {"CDM_KMER_SORT2": "check", "CDM_UNIT_CAP": "700"}, {"CDM_KMER_SORT2": "check", "CDM_UNIT_SUB": "12"},
+                {"CDM_RUN_RECORDS": "twopass"}, {"CDM_RUN_CAP": "1000"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         off, rec = ctx.kmermatch(db).download()
