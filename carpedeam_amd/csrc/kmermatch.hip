@@ -1413,10 +1413,12 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
     if (sort2Runs) {
         using namespace runsort;
         const uint64_t *gk = keysIn;
-        uint64_t *gatheredBuf = bufA, *sortedOut = bufB;
+        // the sorters read the records' tuples from keysIn while they write: the sorted array goes to the OTHER buffer (bufB may be
+        // keysIn); the few segments no unit holds are expanded into their final place first and sorted there
+        uint64_t *sortedOut = bufA;
         if (sort2Check) {
-            if (!runsOut.alloc(nIn) || !runsTmp.alloc(nIn)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2 check)"); return CDM_ERR_HIP; }
-            gatheredBuf = runsTmp.p; sortedOut = runsOut.p;
+            if (!runsOut.alloc(nIn)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2 check)"); return CDM_ERR_HIP; }
+            sortedOut = runsOut.p;
         }
         RunArgs ra; ra.keys = gk; ra.n = nIn; ra.skipLo = skipLo; ra.skipHi = skipHi; ra.repShift = (int) (idBits + diagBits + 1);
         cdmscan::ScanTemp stB;
@@ -1435,9 +1437,11 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
             hipMemsetAsync(rv.current() + nRec, 0, 8, s);
             if (int rc = cdmscan::exclusiveScanFn<unsigned long long, RunLen>(s, stB, RunLen{rv.current()}, dst.p, (size_t) nRec + 1)) return rc;
             hipMemcpyAsync(&nGroup, dst.p + nRec, 8, hipMemcpyDeviceToHost, s);
-            hipLaunchKernelGGL(k_run_gather, dim3((unsigned) ((nRec + 255) / 256)), dim3(256), 0, s, gk, (const uint64_t *) rv.current(), (const unsigned long long *) dst.p, (uint64_t) nRec, gatheredBuf);
-            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: sort 2 (gather) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
-            if (segmentedSortKeys(s, ctx->cuCount, gatheredBuf, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, rk.current(), dst.p, nRec) != CDM_OK) {
+            // (the expansion of the records - k_run_gather - is not run as a pass of its own: the unit sorter expands its records
+            // into LDS, the few longer segments are expanded on demand)
+            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: sort 2 (records) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+            if (segmentedSortKeys(s, ctx->cuCount, sortedOut, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, rk.current(), dst.p, nRec, gk,
+                                  (const uint64_t *) rv.current()) != CDM_OK) {
                 cdm_set_error("cdm_kmermatch: segmented sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP;
             }
         }

@@ -162,29 +162,56 @@ __global__ __launch_bounds__(RUN_NT) void k_run_records(RunArgs a, RunScan sc, u
 }
 struct RunLen { const uint64_t *recVal; __device__ __forceinline__ unsigned long long operator()(size_t j) const { return recVal[j] & ((1ull << RUN_CNT_BITS) - 1ull); } };
 
-// expands the sorted records: out[dst[j] ..] = the tuples of record j.  A wave takes 64 consecutive records; their tuples
-// are consecutive in `out`, so the writes are whole lines and the reads are the records' 8-byte x length stretches.
-__global__ __launch_bounds__(256) void k_run_gather(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ recVal, const unsigned long long *__restrict__ dst,
-                                                    uint64_t nRec, uint64_t *__restrict__ out) {
-    __shared__ uint32_t sOffAll[4][64];
-    __shared__ uint64_t sStartAll[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *sOff = sOffAll[wave]; uint64_t *sStart = sStartAll[wave];
-    const uint64_t j0 = ((uint64_t) blockIdx.x * 4 + wave) * 64;
-    if (j0 >= nRec) return;      // (whole wave)
+// The tuples of the sorted records [j0, j0 + 64) that start in front of `end` (gathered coordinates): put(offset behind dst[j0],
+// tuple).  The reads are the records' 8-byte x length stretches of `keys`.  Returns the number of tuples (wave-uniform).
+template <typename Put>
+__device__ __forceinline__ unsigned int waveGatherRecords(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ recVal, const unsigned long long *__restrict__ dst,
+                                                          uint64_t nRec, uint64_t j0, unsigned long long end, int lane, uint32_t *sOff, uint64_t *sStart, const Put &put) {
     const uint64_t j = j0 + lane;
-    const uint64_t rv = (j < nRec) ? recVal[j] : 0ull;
+    const bool valid = j < nRec && dst[j] < end;
+    const uint64_t rv = valid ? recVal[j] : 0ull;
     const unsigned int cnt = (unsigned int) (rv & ((1ull << RUN_CNT_BITS) - 1ull));
     const unsigned int incl = cdm_wave_incl_sum<unsigned int>(cnt);
     sOff[lane] = incl - cnt; sStart[lane] = rv >> RUN_CNT_BITS;
     const unsigned int total = (unsigned int) __shfl((int) incl, 63, 64);
-    const unsigned long long d0 = dst[j0];
     bucket::waveLdsSync();
     for (unsigned int e = lane; e < total; e += 64) {
         int r = 0;                                               // last record with sOff[r] <= e (empty padding records have cnt 0)
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) if (sOff[r + s] <= e) r += s;
-        out[d0 + e] = keys[sStart[r] + (e - sOff[r])];
+        put(e, keys[sStart[r] + (e - sOff[r])]);
+    }
+    bucket::waveLdsSync();
+    return total;
+}
+// expands the sorted records: out[dst[j] ..] = the tuples of record j.  A wave takes 64 consecutive records; their tuples
+// are consecutive in `out`, so the writes are whole lines.
+__global__ __launch_bounds__(256) void k_run_gather(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ recVal, const unsigned long long *__restrict__ dst,
+                                                    uint64_t nRec, uint64_t *__restrict__ out) {
+    __shared__ uint32_t sOffAll[4][64];
+    __shared__ uint64_t sStartAll[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t j0 = ((uint64_t) blockIdx.x * 4 + wave) * 64;
+    if (j0 >= nRec) return;      // (whole wave)
+    const unsigned long long d0 = dst[j0];
+    waveGatherRecords(keys, recVal, dst, nRec, j0, ~0ull, lane, sOffAll[wave], sStartAll[wave], [&](unsigned int e, uint64_t t) { out[d0 + e] = t; });
+}
+// the same for listed ranges [s, e) of the gathered array only (both record boundaries): one block per range
+__global__ __launch_bounds__(256) void k_gather_ranges(const unsigned long long *__restrict__ list, const unsigned int *__restrict__ count, const uint64_t *__restrict__ keys,
+                                                       const uint64_t *__restrict__ recVal, const unsigned long long *__restrict__ dst, uint64_t nRec, uint64_t *__restrict__ out) {
+    __shared__ uint32_t sOffAll[4][64];
+    __shared__ uint64_t sStartAll[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int n = *count;
+    for (unsigned int item = blockIdx.x; item < n; item += gridDim.x) {
+        const unsigned long long s = list[2 * (size_t) item], e = list[2 * (size_t) item + 1];
+        uint64_t lo = 0, hi = nRec;                              // first record with dst >= s (it starts at s)
+        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (dst[mid] < s) lo = mid + 1; else hi = mid; }
+        for (uint64_t j0 = lo + 64ull * wave; j0 < nRec; j0 += 256) {
+            const unsigned long long d0 = dst[j0];
+            if (d0 >= e) break;
+            waveGatherRecords(keys, recVal, dst, nRec, j0, e, lane, sOffAll[wave], sStartAll[wave], [&](unsigned int x, uint64_t t) { out[d0 + x] = t; });
+        }
     }
 }
 
@@ -250,7 +277,7 @@ static_assert(U_CAP <= (1 << U_IDXB) && U_T <= (1 << U_ORDB), "unit sorter geome
 struct UnitBoundArgs {
     const uint32_t *recRep; const unsigned long long *dst; uint64_t nRec;
     uint32_t maxSeg; uint64_t units;
-    unsigned long long *uStart, *uEnd;      // [units + 1], [units]
+    unsigned long long *uStart, *uEnd, *uRec;       // [units + 1], [units], [units + 1]: first tuple / end / first record of a unit
 };
 // one thread per record; a record with a unit boundary B in (dst[r], dst[r + 1]] finds the end (and, if need be, the start) of its
 // segment: the unit that begins at B starts where the segment ends
@@ -259,7 +286,7 @@ __global__ __launch_bounds__(1024) void k_unit_bounds(UnitBoundArgs a) {
     if (r >= a.nRec) return;
     const unsigned long long d0 = a.dst[r], d1 = a.dst[r + 1];
     const uint64_t uLo = d0 / U_T + 1, uHi = (r == a.nRec - 1) ? a.units : d1 / U_T;       // (the end of the array closes the last unit)
-    if (r == 0) a.uStart[0] = 0;
+    if (r == 0) { a.uStart[0] = 0; a.uRec[0] = 0; }
     if (uLo > uHi) return;
     const uint32_t rep = a.recRep[r];
     uint64_t lo = r, step = 1;                              // last record of the segment: gallop, then bisect
@@ -272,40 +299,43 @@ __global__ __launch_bounds__(1024) void k_unit_bounds(UnitBoundArgs a) {
     while (first - out > 1) { const uint64_t mid = out + ((first - out) >> 1); if (a.recRep[mid] == rep) first = mid; else out = mid; }
     const unsigned long long sSeg = a.dst[first];
     for (uint64_t u = uLo; u <= uHi; u++) {
-        if (u <= a.units) a.uStart[u] = e;
+        if (u <= a.units) { a.uStart[u] = e; a.uRec[u] = hi; }
         // the unit in front of boundary u: this segment is its last one if it starts in that unit's range
         const bool mine = sSeg >= (u - 1) * (unsigned long long) U_T;
         if (u >= 1 && u - 1 < a.units) a.uEnd[u - 1] = (mine && e - sSeg > a.maxSeg) ? sSeg : e;
     }
 }
 struct UnitClassArgs {
-    const unsigned long long *uStart, *uEnd; uint64_t units, n;
+    const unsigned long long *uStart, *uEnd, *uRec; uint64_t units, n;
     uint32_t cap[U_CLASSES];
-    unsigned long long *list[U_CLASSES]; unsigned int *cnt;        // (start, end) per unit of the class
+    unsigned long long *list[U_CLASSES]; unsigned int *cnt;        // (start, end, first record) per unit of the class
 };
 __global__ __launch_bounds__(1024) void k_unit_classes(UnitClassArgs a) {
     const uint64_t u = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    int cls = -1; unsigned long long s = 0, e = 0;
+    int cls = -1; unsigned long long s = 0, e = 0, r0 = 0;
     if (u < a.units) {
-        s = a.uStart[u]; e = a.uEnd[u];
+        s = a.uStart[u]; e = a.uEnd[u]; r0 = a.uRec[u];
         const unsigned long long m = e > s ? e - s : 0;
         if (m) cls = m <= a.cap[0] ? 0 : m <= a.cap[1] ? 1 : 2;
     }
 #pragma unroll
     for (int c = 0; c < U_CLASSES; c++) {
         const uint32_t q = cdm_block_append(a.cnt + c, cls == c);
-        if (cls == c) { a.list[c][2 * (size_t) q] = s; a.list[c][2 * (size_t) q + 1] = e; }
+        if (cls == c) { a.list[c][3 * (size_t) q] = s; a.list[c][3 * (size_t) q + 1] = e; a.list[c][3 * (size_t) q + 2] = r0; }
     }
 }
 
 struct UnitArgs {
-    const uint64_t *in; uint64_t *out; uint64_t n;
+    const uint64_t *keys; const uint64_t *recVal; const unsigned long long *dst; uint64_t nRec;     // the k-mer-ordered keys and the sorted records: a unit is gathered straight from them
+    uint64_t *out; uint64_t n;
     int repShift;               // segment id = key >> repShift
     int hiShift;                // (rep, id) = key >> hiShift; the bits below are sorted inside the sub-buckets, bit 0 rides along
     uint32_t maxSub;            // largest sub-bucket a wave finishes (bucket::BK_MAXB; tests lower it to reach the hard path)
     const unsigned long long *list; const unsigned int *count;     // the units of this size class
     bucket::BigList hard;
 };
+// start (gathered coordinates) of record j, the end of everything if there is none
+__device__ __forceinline__ unsigned long long j0Next(const unsigned long long *__restrict__ dst, uint64_t nRec, uint64_t j) { return dst[min(j, nRec)]; }
 template <int CAP, int U_NT>
 __global__ __launch_bounds__(U_NT) void k_unit_sort(UnitArgs a) {
     constexpr int ROUNDS = (CAP + U_NT - 1) / U_NT, U_WAVES = U_NT / 64;
@@ -317,25 +347,45 @@ __global__ __launch_bounds__(U_NT) void k_unit_sort(UnitArgs a) {
     __shared__ unsigned int sCnt[U_NB];
     __shared__ unsigned int sOff[U_NB + 1];
     __shared__ uint32_t sRep[U_T + 2];          // representative of the unit's segments by ordinal
+    __shared__ uint32_t sGOff[U_NT];
+    __shared__ uint64_t sGStart[U_NT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned int nUnits = *a.count;
     for (unsigned int item = blockIdx.x; item < nUnits; item += gridDim.x) {
-        const uint64_t base = a.list[2 * (size_t) item];
-        const int m = (int) (a.list[2 * (size_t) item + 1] - base);          // 1 .. CAP; the unit starts with a segment start
-        // stage the unit - all loads in flight together - and flag the segment starts (one ballot word per wave and round)
+        const uint64_t base = a.list[3 * (size_t) item];
+        const int m = (int) (a.list[3 * (size_t) item + 1] - base);          // 1 .. CAP; the unit starts with a segment start
+        const uint64_t rec0 = a.list[3 * (size_t) item + 2];
+        // stage the unit: its records (whole ones: a unit begins and ends with a segment) expanded straight into LDS - the gathered
+        // copy of the array is never written for it - then flag the segment starts (one ballot word per wave and round)
         {
-            uint64_t k[ROUNDS];
-#pragma unroll
-            for (int r = 0; r < ROUNDS; r++) { const int i = r * U_NT + tid; k[r] = i < m ? a.in[base + (uint64_t) i] : ~0ull; }
-#pragma unroll
-            for (int r = 0; r < ROUNDS; r++) { const int i = r * U_NT + tid; if (i < CAP) sKeys[i] = k[r]; }
             if (tid < U_NB) sCnt[tid] = 0;
+            // U_NT records at a time: their offsets in the unit (dst is the prefix sum already) and source positions go to LDS, then
+            // every thread fetches tuples - a binary search over the chunk's offsets finds a tuple's record
+            const unsigned long long endG = base + (uint64_t) m;
+            for (uint64_t c0 = rec0; c0 < a.nRec; c0 += U_NT) {
+                const uint64_t j = c0 + tid;
+                const unsigned long long d = j < a.nRec ? a.dst[j] : ~0ull;
+                const bool valid = d < endG;
+                sGOff[tid] = valid ? (uint32_t) (d - base) : (uint32_t) m;
+                sGStart[tid] = valid ? (a.recVal[j] >> RUN_CNT_BITS) : 0ull;
+                const int nr = __syncthreads_count(valid);              // the records of this chunk (they are the first nr of it)
+                if (nr == 0) break;
+                const int e0 = (int) sGOff[0], e1 = (nr == U_NT) ? (int) min((unsigned long long) m, (j0Next(a.dst, a.nRec, c0 + U_NT) - base)) : m;
+                for (int e = e0 + tid; e < e1; e += U_NT) {
+                    int r = 0;
+#pragma unroll
+                    for (int st = U_NT / 2; st > 0; st >>= 1) if (r + st < nr && (int) sGOff[r + st] <= e) r += st;
+                    sKeys[e] = a.keys[sGStart[r] + (uint64_t) (e - (int) sGOff[r])];
+                }
+                __syncthreads();
+                if (nr < U_NT) break;
+            }
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < ROUNDS; r++) {
                 const int i = r * U_NT + tid;
-                const uint64_t p = (i && i < CAP + 1) ? sKeys[i - 1] : 0ull;
-                const unsigned long long bm = __ballot(i < m && (i == 0 || (k[r] >> a.repShift) != (p >> a.repShift)));
+                const uint64_t k = i < m ? sKeys[i] : ~0ull, p = (i && i < m) ? sKeys[i - 1] : 0ull;
+                const unsigned long long bm = __ballot(i < m && (i == 0 || (k >> a.repShift) != (p >> a.repShift)));
                 if (lane == 0) sBits[i >> 6] = bm;
             }
             __syncthreads();
@@ -412,8 +462,10 @@ __global__ __launch_bounds__(U_NT) void k_unit_sort(UnitArgs a) {
 // `in` holds the tuples grouped by representative (bits >= shiftHi), each group in k-mer order; `out` = every group stably
 // sorted on bits [1, shiftHi) (bit 0 rides along).  recRep / dst / nRec describe the groups (sorted records and their output
 // offsets); hiShift = diagonal bits + 1.  CDM_UNIT_CAP / CDM_BLOCK_CAP lower the capacities (tests).
-inline int segmentedSortKeys(hipStream_t s, int cuCount, const uint64_t *in, uint64_t *out, uint64_t n, int shiftHi, int hiShift, int top,
-                             const uint32_t *recRep, const unsigned long long *dst, uint64_t nRec) {
+// srcKeys / recVal: the k-mer-ordered keys and the sorted records `in` is the expansion of.  `in` itself may be unwritten: the unit
+// sorter gathers from the records, and the ranges the other sorters need are expanded into `in` here (k_gather_ranges).
+inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t *out, uint64_t n, int shiftHi, int hiShift, int top,
+                             const uint32_t *recRep, const unsigned long long *dst, uint64_t nRec, const uint64_t *srcKeys, const uint64_t *recVal) {
     using namespace bucket;
     if (n == 0) return CDM_OK;
     uint32_t maxSeg = U_MAXSEG, blockCap = 4096;
@@ -425,22 +477,22 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, const uint64_t *in, uin
     if (U_ORDB + shiftHi - 1 + U_IDXB > 64) maxSeg = 0; // nor does the unit sorter's (ordinal, id, diagonal, index): everything goes to rocPRIM
     const uint64_t units = (n + U_T - 1) / U_T;
     const size_t listCap = (size_t) (n / ((uint64_t) maxSeg + 1) + 2);
-    DevBuf<unsigned long long> lists[SEG_CLASSES], hardList, uStart, uEnd, uList[U_CLASSES]; DevBuf<unsigned int> cnt;
+    DevBuf<unsigned long long> lists[SEG_CLASSES], hardList, uStart, uEnd, uRec, uList[U_CLASSES]; DevBuf<unsigned int> cnt;
     constexpr int NCNT = SEG_CLASSES + 1 + U_CLASSES;
-    if (!cnt.alloc(NCNT) || !hardList.alloc(2 * (size_t) (units + 1)) || !uStart.alloc(units + 2) || !uEnd.alloc(units + 1)) return CDM_ERR_HIP;
-    for (int c = 0; c < U_CLASSES; c++) if (!uList[c].alloc(2 * (size_t) (units + 1))) return CDM_ERR_HIP;
+    if (!cnt.alloc(NCNT) || !hardList.alloc(2 * (size_t) (units + 1)) || !uStart.alloc(units + 2) || !uEnd.alloc(units + 1) || !uRec.alloc(units + 2)) return CDM_ERR_HIP;
+    for (int c = 0; c < U_CLASSES; c++) if (!uList[c].alloc(3 * (size_t) (units + 1))) return CDM_ERR_HIP;
     for (int c = 2; c < SEG_CLASSES; c++) if (!lists[c].alloc(2 * (listCap + (c == 3 ? (size_t) units + 1 : 0)))) return CDM_ERR_HIP;
     hipMemsetAsync(cnt.p, 0, NCNT * 4, s);
     if (maxSeg) {
         // a boundary no record reaches (there is none: the records tile [0, n)) would leave its unit empty
-        hipMemsetAsync(uStart.p, 0, (units + 2) * 8, s); hipMemsetAsync(uEnd.p, 0, (units + 1) * 8, s);
-        UnitBoundArgs ub; ub.recRep = recRep; ub.dst = dst; ub.nRec = nRec; ub.maxSeg = maxSeg; ub.units = units; ub.uStart = uStart.p; ub.uEnd = uEnd.p;
+        hipMemsetAsync(uStart.p, 0, (units + 2) * 8, s); hipMemsetAsync(uEnd.p, 0, (units + 1) * 8, s); hipMemsetAsync(uRec.p, 0, (units + 2) * 8, s);
+        UnitBoundArgs ub; ub.recRep = recRep; ub.dst = dst; ub.nRec = nRec; ub.maxSeg = maxSeg; ub.units = units; ub.uStart = uStart.p; ub.uEnd = uEnd.p; ub.uRec = uRec.p;
         hipLaunchKernelGGL(k_unit_bounds, dim3((unsigned) ((nRec + 1023) / 1024)), dim3(1024), 0, s, ub);
-        UnitClassArgs uc; uc.uStart = uStart.p; uc.uEnd = uEnd.p; uc.units = units; uc.n = n;
+        UnitClassArgs uc; uc.uStart = uStart.p; uc.uEnd = uEnd.p; uc.uRec = uRec.p; uc.units = units; uc.n = n;
         for (int c = 0; c < U_CLASSES; c++) { uc.cap[c] = (uint32_t) U_CLASS_CAP[c]; uc.list[c] = uList[c].p; }
         uc.cnt = cnt.p + SEG_CLASSES + 1;
         hipLaunchKernelGGL(k_unit_classes, dim3((unsigned) ((units + 1023) / 1024)), dim3(1024), 0, s, uc);
-        UnitArgs ua; ua.in = in; ua.out = out; ua.n = n; ua.repShift = shiftHi; ua.hiShift = hiShift; ua.maxSub = maxSub; ua.hard.list = hardList.p; ua.hard.cnt = cnt.p + SEG_CLASSES;
+        UnitArgs ua; ua.keys = srcKeys; ua.recVal = recVal; ua.dst = dst; ua.nRec = nRec; ua.out = out; ua.n = n; ua.repShift = shiftHi; ua.hiShift = hiShift; ua.maxSub = maxSub; ua.hard.list = hardList.p; ua.hard.cnt = cnt.p + SEG_CLASSES;
         const unsigned int pad = cdm_lds_pad("CDM_LDS_PAD_UNIT");
         const unsigned int grid = (unsigned int) std::min<uint64_t>(units, (uint64_t) cuCount * 64);
         ua.list = uList[0].p; ua.count = cnt.p + SEG_CLASSES + 1; hipLaunchKernelGGL((k_unit_sort<U_CLASS_CAP[0], U_CLASS_NT[0]>), dim3(grid), dim3(U_CLASS_NT[0]), pad, s, ua);
@@ -453,8 +505,10 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, const uint64_t *in, uin
     for (int c = 0; c < SEG_CLASSES; c++) la.list[c] = lists[c].p;      // (classes 0 and 1 stay empty: their capacities are 0)
     la.cnt = cnt.p;
     hipLaunchKernelGGL(k_seg_list, dim3((unsigned) ((nRec + 1023) / 1024)), dim3(1024), 0, s, la);
+    const unsigned int gatherGrid = (unsigned int) std::min<uint64_t>((uint64_t) cuCount * 8, listCap + units + 1);
     BlockSortArgs ba; ba.in = in; ba.out = out; ba.shiftHi = shiftHi; ba.ign = 1;
     ba.list = lists[2].p; ba.count = cnt.p + 2;
+    if (blockCap) hipLaunchKernelGGL(k_gather_ranges, dim3(gatherGrid), dim3(256), 0, s, (const unsigned long long *) lists[2].p, (const unsigned int *) (cnt.p + 2), srcKeys, recVal, dst, nRec, in);
     if (blockCap) hipLaunchKernelGGL(k_block_sort<8>, dim3((unsigned int) std::min<uint64_t>((uint64_t) cuCount * 8, listCap)), dim3(512), 0, s, ba);
     unsigned int hc[NCNT] = {0};
     if (hipMemcpyAsync(hc, cnt.p, NCNT * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
@@ -465,6 +519,13 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, const uint64_t *in, uin
     // deep pile-ups and hard units: gather, sort on the whole key with rocPRIM (stable), scatter.  (The ranges are disjoint and
     // the array is grouped by representative, so one sort of their concatenation on the whole key sorts each of them.)
     if (hc[SEG_CLASSES]) hipMemcpyAsync(lists[3].p + 2 * (size_t) hc[3], hardList.p, 2 * (size_t) hc[SEG_CLASSES] * 8, hipMemcpyDeviceToDevice, s);
+    {   // their tuples, expanded into `in`
+        DevBuf<unsigned int> nb;
+        if (!nb.alloc(1)) return CDM_ERR_HIP;
+        hipMemcpyAsync(nb.p, &nBig, 4, hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL(k_gather_ranges, dim3(gatherGrid), dim3(256), 0, s, (const unsigned long long *) lists[3].p, (const unsigned int *) nb.p, srcKeys, recVal, dst, nRec, in);
+        if (hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
+    }
     DevBuf<unsigned long long> ranges; uint64_t total = 0;
     if (int rc = loadBigList(s, lists[3].p, nBig, ranges, total)) return rc;
     DevBuf<uint64_t> d0, d1; DevBuf<char> tmp; size_t tb = 0;
