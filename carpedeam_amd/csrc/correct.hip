@@ -29,13 +29,13 @@ struct CorrectArgs {
     const uint32_t *active;
     const unsigned int *nActive;
     uint8_t *accept;          // [alignment count] scratch
-    unsigned int *errFlag;    // set when a query has more records than the 16-bit pile-up counters hold
+    unsigned int *errFlag;    // (unused: the general kernel's counters are 64 bit)
     uint32_t *outCodes, *outNmask;
     const DamageLut *lut;
     float seqIdThr, corrRy;
 };
 
-constexpr int WAVES_PER_BLOCK = 4;
+constexpr int WAVES_PER_BLOCK = 2;      // general kernel: 64-bit counters (any number of records piles up), 22.5 KB of LDS per wave
 constexpr int SLOTS = 44;
 
 __device__ __forceinline__ uint32_t alnLength(const AlnRec &r) {   // Matcher::computeAlnLength, M/alignment/Matcher.cpp:204-206
@@ -68,8 +68,8 @@ __device__ __noinline__ uint32_t callBaseExact(const double *lt, const double *l
 #pragma unroll 1
         for (uint64_t m = mask; m; m &= m - 1) {        // ascending slots, the reference's loop order (:60-110)
             const int slot = __ffsll((unsigned long long) m) - 1;
-            const uint32_t v = counts(slot);
-            const int c = (int) (v & 0xFFFFu), nr = (int) (v >> 16);
+            const uint64_t v = counts(slot);
+            const int c = (int) (uint32_t) v, nr = (int) (v >> 32);
             if (c == 0) continue;
             const int tb = slot / 11, l = slot - tb * 11;
             const double base2 = __dadd_rn(lt[tb], lq[qq]);
@@ -84,23 +84,24 @@ __device__ __noinline__ uint32_t callBaseExact(const double *lt, const double *l
 }
 
 // mostLikeliBaseRead (src/assembler/correction.cpp:7-123) for one query position.  counts(slot) returns
-// total | reverse << 16 for slot = tBase * 11 + damage class; mask has a bit for every slot that may be non-zero (a pile-up
+// total | (uint64) reverse << 32 for slot = tBase * 11 + damage class; mask has a bit for every slot that may be non-zero (a pile-up
 // touches a handful of the 44).  keep is set when coverage <= 1 (:418-420).
 constexpr uint64_t ALL_SLOTS = (1ull << 44) - 1ull;
 template <typename F>
 __device__ __forceinline__ uint32_t callBase(const double *sLogT, const double *sLogQ, const double *sLogD, uint32_t qb, uint32_t p, uint32_t qLen,
-                                             bool qWasExt, F counts, uint64_t mask, bool &keep, uint64_t covPacked = ~0ull) {
-    // covPacked: four 16-bit coverage counters, target base tb in bits 16 tb .. (at most 65535 records pile up); callers that
-    // counted them while piling up pass them in, ~0 = sum the slots here
-    if (covPacked == ~0ull) {
-        covPacked = 0;
+                                             bool qWasExt, F counts, uint64_t mask, bool &keep, uint32_t cov4 = ~0u) {
+    // cov4: records per target base, 8 bits each (callers with at most 64 records count them while piling up); ~0 = sum the slots here
+    uint32_t cov[4];
+    if (cov4 == ~0u) {
+        cov[0] = cov[1] = cov[2] = cov[3] = 0;
 #pragma unroll 1
         for (uint64_t m = mask; m; m &= m - 1) {
             const int slot = __ffsll((unsigned long long) m) - 1;
-            covPacked += (uint64_t) (counts(slot) & 0xFFFFu) << (16 * (slot / 11));
+            const uint32_t c = (uint32_t) counts(slot);
+            const int tb = slot / 11;
+            cov[0] += tb == 0 ? c : 0u; cov[1] += tb == 1 ? c : 0u; cov[2] += tb == 2 ? c : 0u; cov[3] += tb == 3 ? c : 0u;
         }
-    }
-    const uint32_t cov[4] = {(uint32_t) (covPacked & 0xFFFF), (uint32_t) ((covPacked >> 16) & 0xFFFF), (uint32_t) ((covPacked >> 32) & 0xFFFF), (uint32_t) (covPacked >> 48)};
+    } else { cov[0] = cov4 & 0xFFu; cov[1] = (cov4 >> 8) & 0xFFu; cov[2] = (cov4 >> 16) & 0xFFu; cov[3] = cov4 >> 24; }
     const uint32_t total = cov[0] + cov[1] + cov[2] + cov[3];
     keep = total <= 1;
     if (keep) return qb;
@@ -125,8 +126,8 @@ __device__ __forceinline__ uint32_t callBase(const double *sLogT, const double *
 #pragma unroll 1
     for (uint64_t m = mask; m; m &= m - 1) {
         const int slot = __ffsll((unsigned long long) m) - 1;
-        const uint32_t v = counts(slot);
-        const int c = (int) (v & 0xFFFFu), nr = (int) (v >> 16);
+        const uint64_t v = counts(slot);
+        const int c = (int) (uint32_t) v, nr = (int) (v >> 32);
         if (c == 0) continue;
         const int tb = slot / 11, l = slot - tb * 11;
 #pragma unroll
@@ -149,9 +150,9 @@ __device__ __forceinline__ uint32_t callBase(const double *sLogT, const double *
     return callBaseExact(lt, lq, sLogD, counts, mask);
 }
 
-__global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_correct(CorrectArgs a) {
     __shared__ double sLogT[16], sLogQ[12 * 16], sLogD[2 * 11 * 16];
-    __shared__ uint32_t sCnt[WAVES_PER_BLOCK][SLOTS][64];
+    __shared__ uint64_t sCnt[WAVES_PER_BLOCK][SLOTS][64];       // total | reverse << 32
     for (int i = threadIdx.x; i < 16; i += blockDim.x) sLogT[i] = (&a.lut->logT[0][0])[i];
     for (int i = threadIdx.x; i < 12 * 16; i += blockDim.x) sLogQ[i] = (&a.lut->logQ[0][0][0])[i];
     for (int i = threadIdx.x; i < 2 * 11 * 16; i += blockDim.x) sLogD[i] = (&a.lut->logD[0][0][0][0])[i];
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned int nAct = *a.nActive;
-    uint32_t (*cnt)[64] = sCnt[wave];
+    uint64_t (*cnt)[64] = sCnt[wave];
 
     for (unsigned int item = blockIdx.x * WAVES_PER_BLOCK + wave; item < nAct; item += gridDim.x * WAVES_PER_BLOCK) {
         const uint32_t q = a.active[item];
@@ -167,7 +168,6 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {
         const bool qHasN = a.hasN[q] != 0;
         const bool qWasExt = a.ext[q] != 0;
         const uint64_t r0 = a.aoff[q], r1 = a.aoff[q + 1];
-        if (r1 - r0 > 65535) { if (lane == 0) atomicOr(a.errFlag, 1u); continue; }
 
         // ---- pass 0: average coverage (float sum of small integers: exact, order independent)
         int sumLen = 0;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs a) {
                     const uint32_t tpos = (uint32_t) o.ds + (p - (uint32_t) o.qs);
                     const uint32_t tb = targetBase(a, tw, tLen, a.hasN[t] != 0, o.rev, tpos);
                     const uint32_t cls = tpos < 5 ? tpos : (tpos >= tLen - 5 ? 6 + (tpos - (tLen - 5)) : 5);
-                    cnt[tb * 11 + cls][lane] += 1u + (o.rev ? 0x10000u : 0u);
+                    cnt[tb * 11 + cls][lane] += 1ull + (o.rev ? (1ull << 32) : 0ull);
                 }
             }
             // ---- call
@@ -371,10 +371,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES, MINW) void k_correct_fast(CorrectA
                 uint32_t qb = cdm_base(a.codes, qw, p);
                 const bool qIsN = qHasN && cdm_isN(a.nmask, qw, p);
                 if (qIsN) qb = 0;
-                const uint64_t covPacked = (uint64_t) (cov4 & 0xFFu) | ((uint64_t) ((cov4 >> 8) & 0xFFu) << 16) | ((uint64_t) ((cov4 >> 16) & 0xFFu) << 32) | ((uint64_t) (cov4 >> 24) << 48);
                 newCode = callBase(sLogT, sLogQ, sLogD, qb, p, qLen, qWasExt,
-                                   [&](int slot) { const uint32_t v = cntWords[slot * (64 / PER) + laneWord] >> laneShift; return (v & ((1u << HB) - 1u)) | (((v >> HB) & ((1u << HB) - 1u)) << 16); },
-                                   touched, keep, covPacked);
+                                   [&](int slot) { const uint32_t v = cntWords[slot * (64 / PER) + laneWord] >> laneShift; return (uint64_t) (v & ((1u << HB) - 1u)) | ((uint64_t) ((v >> HB) & ((1u << HB) - 1u)) << 32); },
+                                   touched, keep, cov4);
             }
             for (uint64_t m = touched; m; m &= m - 1) atomicAnd(&cntWords[(__ffsll((unsigned long long) m) - 1) * (64 / PER) + laneWord], laneClear);
             const uint64_t b0 = cdm_ballot((newCode & 1u) != 0), b1 = cdm_ballot((newCode & 2u) != 0);
@@ -414,7 +413,7 @@ __global__ void k_debug_call(const DamageLut *lut, const uint32_t *vec, uint32_t
     if (i >= n) return;
     const uint32_t *v = vec + (size_t) i * 48;
     bool keep;
-    out[i] = (uint8_t) callBase(sLogT, sLogQ, sLogD, v[0], v[1], v[2], v[3] != 0, [&](int slot) { return v[4 + slot]; }, ALL_SLOTS, keep);
+    out[i] = (uint8_t) callBase(sLogT, sLogQ, sLogD, v[0], v[1], v[2], v[3] != 0, [&](int slot) { const uint32_t x = v[4 + slot]; return (uint64_t) (x & 0xFFFFu) | ((uint64_t) (x >> 16) << 32); }, ALL_SLOTS, keep);
 }
 
 }  // namespace
@@ -463,13 +462,12 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
     else if (smallW == 5) hipLaunchKernelGGL((k_correct_fast<15, uint8_t, 5>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeSmall.p, counters.p + 3);
     else if (smallW) hipLaunchKernelGGL((k_correct_fast<15, uint8_t, 6>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeSmall.p, counters.p + 3);
     hipLaunchKernelGGL((k_correct_fast<64, uint16_t, 4>), dim3(blocks), dim3(64 * FAST_WAVES), pad, s, a, activeFast.p, counters.p + 2);
-    hipLaunchKernelGGL(k_correct, dim3(blocks / 4), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(k_correct, dim3(blocks / 2), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
     hipEventRecord(ctx->ev1, s);
     CDM_LAUNCH_CHECK();
     unsigned int flags[2] = {0, 0};
     CDM_HIP(hipMemcpyAsync(flags, counters.p, 8, hipMemcpyDeviceToHost, s));
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("ancient_correction kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     hipEventElapsedTime(&ctx->lastMs[0], ctx->ev0, ctx->ev1);
-    if (flags[1]) { cdm_set_error("ancient_correction: a query has more than 65535 alignment records (unsupported)"); return CDM_ERR_UNSUPPORTED; }
     return CDM_OK;
 }

@@ -215,3 +215,44 @@ def test_chain_with_contig_sized_sequences(ctx, oracle_bin, dhigh_prefix, tmp_pa
     hits, alns, corr, asm = chain(ctx, db)
     assert not diff_keys(seqdb_to_keyed(*corr.download()), mmdb.read_db(t("corr")))
     assert not diff_keys(seqdb_to_keyed(*asm.download()), mmdb.read_db(t("asm")))
+
+
+def test_pile_up_beyond_65535_records(ctx, oracle_bin, dhigh_prefix, tmp_path):
+    """One long read on top of 70 000 shorter ones from the same 170 bp stretch: it is the representative of every k-mer group it is
+    in, its query gets ~70 000 prefilter hits and alignment records, and correction piles them all up (64-bit counters in the general
+    kernel; round 1 refused more than 65 535).  Every stage against the oracle."""
+    rng = np.random.default_rng(65536)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    comp = np.array([3, 2, 1, 0])
+    genome = rng.integers(0, 4, 170)
+    seqs = [letters[genome[20:150]].tobytes().decode()]                  # 130 letters: the longest sequence = the representative
+    for _ in range(70000):
+        L = int(rng.integers(60, 101))
+        s = int(rng.integers(0, 170 - L + 1))
+        r = genome[s:s + L].copy()
+        if rng.random() < 0.5:
+            r = comp[r][::-1]
+        for k, p in enumerate((0.3, 0.12, 0.05)):                       # end damage
+            if r[k] == 1 and rng.random() < p:
+                r[k] = 3
+            if r[L - 1 - k] == 2 and rng.random() < p:
+                r[L - 1 - k] = 0
+        if rng.random() < 0.02:
+            r[int(rng.integers(0, L))] = int(rng.integers(0, 4))
+        seqs.append(letters[r].tobytes().decode())
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    db = ctx.upload_seqs([s.encode() for s in seqs], list(range(len(seqs))), [0] * len(seqs))
+    hits, alns, corr, asm = chain(ctx, db)
+    aoff, arec = alns.download()
+    assert int((aoff[1:] - aoff[:-1]).max()) > 65535
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "8")
+    run_oracle(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref"), t("aln"), *R_FLAGS, "--threads", "8")
+    run_oracle(oracle_bin, "ancient_correction", t("in"), t("aln"), t("corr"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "8")
+    run_oracle(oracle_bin, "ancient_read_assemble", t("corr"), t("aln"), t("asm"), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "8")
+    lens, keys, _ = db.meta()
+    hoff, hrec = hits.download()
+    assert not diff_keys({k: (v, 0) for k, v in capi.hits_to_text(hoff, hrec, keys).items()}, {k: (v[0], 0) for k, v in mmdb.read_db(t("pref")).items()})
+    assert not diff_keys({k: (v, 0) for k, v in capi.alns_to_text(aoff, arec, keys, lens, db.residues).items()}, mmdb.read_db(t("aln")))
+    assert not diff_keys(seqdb_to_keyed(*corr.download()), mmdb.read_db(t("corr")))
+    assert not diff_keys(seqdb_to_keyed(*asm.download()), mmdb.read_db(t("asm")))
