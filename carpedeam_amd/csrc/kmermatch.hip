@@ -25,6 +25,7 @@
 #include "bucket.h"
 #include "scan.h"
 #include "runsort.h"
+#include "radix.h"
 
 namespace {
 
@@ -1247,8 +1248,15 @@ int phaseA() override {
     rocprim::radix_sort_pairs(nullptr, tmpBytesH, k0.p + kmerSlots, k1.p + kmerSlots, v0.p + kmerSlots, v1.p + kmerSlots, (size_t) n, 0, 63, s);
     DevBuf<char> tmp1;
     if (!tmp1.alloc(std::max(tmpBytes, tmpBytesH) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
+    // The passes themselves: the hand-written onesweep of radix.h (CDM_KMER_SORT1=rocprim: rocPRIM's, for A/B runs and the tests).
+    const char *sort1Env = getenv("CDM_KMER_SORT1");
+    const bool ownRadix = !(lsdOnly || fourPasses) && !(sort1Env && !strcmp(sort1Env, "rocprim"));
     hipEventRecord(ctx->ev0, s);
-    if (((lsdOnly || fourPasses) ? rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)
+    if (ownRadix) {
+        bool inFirst = true;
+        if (int rc = rx::sortPairs<V>(s, ctx->cuCount, k0.p, k1.p, v0.p, v1.p, (uint64_t) kmerSlots, lowBits, sortTop, inFirst)) return rc;
+        keys = rocprim::double_buffer<uint64_t>(inFirst ? k0.p : k1.p, inFirst ? k1.p : k0.p); vals = rocprim::double_buffer<V>(inFirst ? v0.p : v1.p, inFirst ? v1.p : v0.p);
+    } else if (((lsdOnly || fourPasses) ? rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)
                  : rocprim::radix_sort_pairs<Sort1Config>(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev1, s);
     hipEventRecord(ctx->ev2, s);
