@@ -1254,17 +1254,23 @@ int phaseA() override {
     hipEventRecord(ctx->ev0, s);
     if (ownRadix) {
         bool inFirst = true;
-        if (int rc = rx::sortPairs<V>(s, ctx->cuCount, k0.p, k1.p, v0.p, v1.p, (uint64_t) kmerSlots, lowBits, sortTop, inFirst)) return rc;
+        if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, k0.p, k1.p, v0.p, v1.p, (uint64_t) kmerSlots, lowBits, sortTop, inFirst, &ctx->lastMs[13])) return rc;
+        ctx->lastMs[14] = (float) ((sortTop - lowBits + rx::BITS - 1) / rx::BITS);     // its launches
         keys = rocprim::double_buffer<uint64_t>(inFirst ? k0.p : k1.p, inFirst ? k1.p : k0.p); vals = rocprim::double_buffer<V>(inFirst ? v0.p : v1.p, inFirst ? v1.p : v0.p);
     } else if (((lsdOnly || fourPasses) ? rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)
                  : rocprim::radix_sort_pairs<Sort1Config>(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
     hipEventRecord(ctx->ev1, s);
     hipEventRecord(ctx->ev2, s);
     {
-        // region 2 goes to wherever region 1 ended up (explicit in/out form: input is always the extraction buffers k0/v0)
+        // region 2 goes to wherever region 1 ended up (the input is always the extraction buffers k0/v0)
         uint64_t *kOut = keys.current() + kmerSlots, *kIn = k0.p + kmerSlots;
         V *vOut = vals.current() + kmerSlots, *vIn = v0.p + kmerSlots;
-        if (kOut == kIn) {   // region 1 finished in the extraction buffers: sort region 2 via the alternate buffers and copy back
+        if (ownRadix) {
+            bool inFirst = true;
+            if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, kIn, k1.p + kmerSlots, vIn, v1.p + kmerSlots, (uint64_t) n, 0, 63, inFirst)) return rc;
+            uint64_t *kRes = inFirst ? kIn : k1.p + kmerSlots; V *vRes = inFirst ? vIn : v1.p + kmerSlots;
+            if (kRes != kOut) { hipMemcpyAsync(kOut, kRes, (size_t) n * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(vOut, vRes, (size_t) n * sizeof(V), hipMemcpyDeviceToDevice, s); }
+        } else if (kOut == kIn) {   // region 1 finished in the extraction buffers: sort region 2 via the alternate buffers and copy back
             if (rocprim::radix_sort_pairs(tmp1.p, tmpBytesH, kIn, k1.p + kmerSlots, vIn, v1.p + kmerSlots, (size_t) n, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
             hipMemcpyAsync(kOut, k1.p + kmerSlots, (size_t) n * 8, hipMemcpyDeviceToDevice, s);
             hipMemcpyAsync(vOut, v1.p + kmerSlots, (size_t) n * sizeof(V), hipMemcpyDeviceToDevice, s);
@@ -1435,12 +1441,9 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
         if (int rc = makeRunRecords(s, ra, rr0, rr1, rv0, rv1, nRec)) return rc;
         if (!dst.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
         if (nRec) {
-            rocprim::double_buffer<uint32_t> rk(rr0.p, rr1.p); rocprim::double_buffer<uint64_t> rv(rv0.p, rv1.p);
-            size_t tb = 0;
-            rocprim::radix_sort_pairs(nullptr, tb, rk, rv, (size_t) nRec, 0, idBits, s);
-            DevBuf<char> t1;
-            if (!t1.alloc(tb + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2)"); return CDM_ERR_HIP; }
-            if (rocprim::radix_sort_pairs(t1.p, tb, rk, rv, (size_t) nRec, 0, idBits, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: record sort failed"); return CDM_ERR_HIP; }
+            bool recFirst = true;
+            if (int rc = rx::sortPairs<uint32_t, uint64_t>(s, ctx->cuCount, rr0.p, rr1.p, rv0.p, rv1.p, (uint64_t) nRec, 0, (int) idBits, recFirst)) return rc;
+            rocprim::double_buffer<uint32_t> rk(recFirst ? rr0.p : rr1.p, recFirst ? rr1.p : rr0.p); rocprim::double_buffer<uint64_t> rv(recFirst ? rv0.p : rv1.p, recFirst ? rv1.p : rv0.p);
             // (the scan reads one element past the records: the value buffers have nRec + 1 entries, the last one's length is not used)
             hipMemsetAsync(rv.current() + nRec, 0, 8, s);
             if (int rc = cdmscan::exclusiveScanFn<unsigned long long, RunLen>(s, stB, RunLen{rv.current()}, dst.p, (size_t) nRec + 1)) return rc;
@@ -1544,10 +1547,9 @@ int gatherByRep() override {
     gathered = keys.current();
     if (nRec == 0) return CDM_OK;
     if (!dst.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
-    rocprim::double_buffer<uint32_t> rk(rr0.p, rr1.p); rocprim::double_buffer<uint64_t> rv(rv0.p, rv1.p);
-    rocprim::radix_sort_pairs(nullptr, tb, rk, rv, (size_t) nRec, 0, idBits, s);
-    if (!t1.alloc(tb + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort 2)"); return CDM_ERR_HIP; }
-    if (rocprim::radix_sort_pairs(t1.p, tb, rk, rv, (size_t) nRec, 0, idBits, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: record sort failed"); return CDM_ERR_HIP; }
+    bool recFirst = true;
+    if (int rc = rx::sortPairs<uint32_t, uint64_t>(s, ctx->cuCount, rr0.p, rr1.p, rv0.p, rv1.p, (uint64_t) nRec, 0, (int) idBits, recFirst)) return rc;
+    rocprim::double_buffer<uint32_t> rk(recFirst ? rr0.p : rr1.p, recFirst ? rr1.p : rr0.p); rocprim::double_buffer<uint64_t> rv(recFirst ? rv0.p : rv1.p, recFirst ? rv1.p : rv0.p);
     hipMemsetAsync(rv.current() + nRec, 0, 8, s);
     if (int rc = cdmscan::exclusiveScanFn<unsigned long long, RunLen>(s, stB, RunLen{rv.current()}, dst.p, (size_t) nRec + 1)) return rc;
     hipMemcpyAsync(&nOut, dst.p + nRec, 8, hipMemcpyDeviceToHost, s);

@@ -1,4 +1,4 @@
-// Stable LSD radix sort of (64-bit key, value) pairs for kmermatcher's sort 1 (the reference: ips4o on the k-mer tuples,
+// Stable LSD radix sort of (key, value) pairs (32- or 64-bit each) for kmermatcher's sort 1 (the reference: ips4o on the k-mer tuples,
 // lib/mmseqs/src/linclust/kmermatcher.cpp:412; any stable order-by-key is the same array).  Hand-written "onesweep":
 //
 //   k_rx_hist     one read of the keys: digit counts of ALL passes (LDS histograms, one flush per block)
@@ -23,10 +23,11 @@ namespace rx {
 constexpr int NT = 512, WAVES = NT / 64, IPT = 16, TILE = NT * IPT, BITS = 9, BINS = 1 << BITS, MAXPASS = 8;
 constexpr unsigned long long ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = (1ull << 62) - 1ull;
 
-struct HistArgs { const uint64_t *keys; uint64_t n; int beginBit, endBit, passes; unsigned long long *hist; };      // hist[pass][digit]
-__device__ __forceinline__ uint32_t digitOf(uint64_t key, int shift, uint32_t mask) { return (uint32_t) (key >> shift) & mask; }
+template <typename K> struct HistArgs { const K *keys; uint64_t n; int beginBit, endBit, passes; unsigned long long *hist; };      // hist[pass][digit]
+template <typename K> __device__ __forceinline__ uint32_t digitOf(K key, int shift, uint32_t mask) { return (uint32_t) (key >> shift) & mask; }
 
-__global__ __launch_bounds__(NT) void k_rx_hist(HistArgs a) {
+template <typename K>
+__global__ __launch_bounds__(NT) void k_rx_hist(HistArgs<K> a) {
     __shared__ unsigned int sHist[MAXPASS][BINS];
     for (int i = threadIdx.x; i < a.passes * BINS; i += NT) (&sHist[0][0])[i] = 0u;
     __syncthreads();
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(NT) void k_rx_hist(HistArgs a) {
         for (int j = 0; j < IPT; j++) {
             const uint64_t i = base + (uint64_t) j * NT + threadIdx.x;
             if (i >= a.n) break;
-            const uint64_t k = a.keys[i];
+            const K k = a.keys[i];
             for (int p = 0; p < a.passes; p++) {
                 const int shift = a.beginBit + p * BITS, bits = min(BITS, a.endBit - shift);
                 atomicAdd(&sHist[p][digitOf(k, shift, (1u << bits) - 1u)], 1u);
@@ -57,16 +58,16 @@ __global__ __launch_bounds__(BINS) void k_rx_offsets(unsigned long long *hist, i
     }
 }
 
-template <typename V>
+template <typename K, typename V>
 struct PassArgs {
-    const uint64_t *kin; uint64_t *kout; const V *vin; V *vout; uint64_t n;
+    const K *kin; K *kout; const V *vin; V *vout; uint64_t n;
     int shift, bits;
     const unsigned long long *digitBase;        // [BINS]
     unsigned long long *status;                 // [tiles][BINS], zeroed
     unsigned int *ticket;                       // zeroed
 };
-template <typename V>
-__global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<V> a) {
+template <typename K, typename V>
+__global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
     // one 64 KB exchange buffer, used for the keys and then for the values: two blocks per CU
     __shared__ uint64_t sBuf[TILE];
     __shared__ uint16_t sCnt[WAVES][BINS];
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<V> a) {
     const int items = (int) min((uint64_t) TILE, a.n - base);
     const uint32_t mask = (1u << a.bits) - 1u;
     // ---- load: wave w owns [w * 64 IPT, (w + 1) * 64 IPT), round j its j-th 64 pairs
-    uint64_t key[IPT]; V val[IPT]; uint16_t pos[IPT];
+    K key[IPT]; V val[IPT]; uint16_t pos[IPT];
     const int w0 = wave * 64 * IPT + lane;
 #pragma unroll
     for (int j = 0; j < IPT; j++) { const int li = w0 + 64 * j; if (li < items) { key[j] = a.kin[base + li]; val[j] = a.vin[base + li]; } else { key[j] = 0; val[j] = 0; } }
@@ -133,13 +134,14 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<V> a) {
         sGlobal[tid] = a.digitBase[tid] + exclG - ex;       // output position of the pair at exchange slot p with this digit: sGlobal + p
     }
     __syncthreads();
+    K *sK = reinterpret_cast<K *>(sBuf);
     // ---- the keys through the exchange buffer: slot = digits in front + waves in front + rank; then runs of consecutive addresses
 #pragma unroll
     for (int j = 0; j < IPT; j++) {
         if (w0 + 64 * j < items) {
             const uint32_t d = digitOf(key[j], a.shift, mask);
             pos[j] = (uint16_t) ((uint32_t) sTileOff[d] + (uint32_t) sCnt[wave][d] + (uint32_t) pos[j]);
-            sBuf[pos[j]] = key[j];
+            sK[pos[j]] = key[j];
         }
     }
     __syncthreads();
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<V> a) {
     for (int r = 0; r < IPT; r++) {
         const int p = tid + NT * r;
         if (p < items) {
-            const uint64_t k = sBuf[p];
+            const K k = sK[p];
             dig[r] = (uint16_t) digitOf(k, a.shift, mask);
             a.kout[sGlobal[dig[r]] + (unsigned long long) p] = k;
         }
@@ -168,8 +170,9 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<V> a) {
 
 // Sorts the n pairs on key bits [beginBit, endBit), stable.  (k0, v0) hold the input; the passes alternate between the two buffer
 // pairs; inFirst tells where the result is.  Asynchronous on s except for the allocations.
-template <typename V>
-inline int sortPairs(hipStream_t s, int cuCount, uint64_t *k0, uint64_t *k1, V *v0, V *v1, uint64_t n, int beginBit, int endBit, bool &inFirst) {
+// passMs (may be NULL): HIP-event time of the pass launches alone, summed.
+template <typename K, typename V>
+inline int sortPairs(hipStream_t s, int cuCount, K *k0, K *k1, V *v0, V *v1, uint64_t n, int beginBit, int endBit, bool &inFirst, float *passMs = nullptr) {
     inFirst = true;
     if (n == 0 || endBit <= beginBit) return CDM_OK;
     const int passes = (endBit - beginBit + BITS - 1) / BITS;
@@ -179,19 +182,29 @@ inline int sortPairs(hipStream_t s, int cuCount, uint64_t *k0, uint64_t *k1, V *
     if (!hist.alloc((size_t) passes * BINS) || !status.alloc(tiles * BINS) || !ticket.alloc(passes)) { cdm_set_error("radix sort: out of device memory"); return CDM_ERR_HIP; }
     hipMemsetAsync(hist.p, 0, (size_t) passes * BINS * 8, s);
     hipMemsetAsync(ticket.p, 0, (size_t) passes * 4, s);
-    HistArgs ha; ha.keys = k0; ha.n = n; ha.beginBit = beginBit; ha.endBit = endBit; ha.passes = passes; ha.hist = hist.p;
-    hipLaunchKernelGGL(k_rx_hist, dim3((unsigned) std::min<uint64_t>(tiles, (uint64_t) cuCount * 8)), dim3(NT), 0, s, ha);
+    HistArgs<K> ha; ha.keys = k0; ha.n = n; ha.beginBit = beginBit; ha.endBit = endBit; ha.passes = passes; ha.hist = hist.p;
+    hipLaunchKernelGGL(k_rx_hist<K>, dim3((unsigned) std::min<uint64_t>(tiles, (uint64_t) cuCount * 8)), dim3(NT), 0, s, ha);
     hipLaunchKernelGGL(k_rx_offsets, dim3(1), dim3(BINS), 0, s, hist.p, passes);
+    hipEvent_t ev[2 * MAXPASS];
+    if (passMs) for (int i = 0; i < 2 * passes; i++) hipEventCreate(&ev[i]);
     for (int p = 0; p < passes; p++) {
         hipMemsetAsync(status.p, 0, tiles * BINS * 8, s);
-        PassArgs<V> pa;
+        PassArgs<K, V> pa;
         pa.kin = inFirst ? k0 : k1; pa.kout = inFirst ? k1 : k0; pa.vin = inFirst ? v0 : v1; pa.vout = inFirst ? v1 : v0; pa.n = n;
         pa.shift = beginBit + p * BITS; pa.bits = std::min(BITS, endBit - pa.shift);
         pa.digitBase = hist.p + (size_t) p * BINS; pa.status = status.p; pa.ticket = ticket.p + p;
-        hipLaunchKernelGGL(k_rx_pass<V>, dim3((unsigned) tiles), dim3(NT), 0, s, pa);
+        if (passMs) hipEventRecord(ev[2 * p], s);
+        hipLaunchKernelGGL((k_rx_pass<K, V>), dim3((unsigned) tiles), dim3(NT), 0, s, pa);
+        if (passMs) hipEventRecord(ev[2 * p + 1], s);
         inFirst = !inFirst;
     }
-    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("radix sort failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    const hipError_t e = hipStreamSynchronize(s);
+    if (passMs) {
+        *passMs = 0.f;
+        for (int p = 0; p < passes; p++) { float ms = 0.f; if (e == hipSuccess) hipEventElapsedTime(&ms, ev[2 * p], ev[2 * p + 1]); *passMs += ms; }
+        for (int i = 0; i < 2 * passes; i++) hipEventDestroy(ev[i]);
+    }
+    if (e != hipSuccess) { cdm_set_error("radix sort failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
     return CDM_OK;
 }
 
