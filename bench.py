@@ -95,26 +95,6 @@ def module_walls(n_reads, L, seed, threads):
     return cpu, gpu
 
 
-def profile_ratio():
-    """histogram launch / iteration launch duration of sort 1's rocPRIM kernels, from the committed rocprofv3 summary of this
-    command (profiles/r02_bench50M_kernel_stats.csv); used to take the one histogram launch out of the HIP-event time of the
-    sort call"""
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench50M_kernel_stats.csv"))):
-        it = hist = None
-        for r in csv.DictReader(open(f)):
-            n = r["Name"]
-            if "rocprim" not in n or not re.search(r">, 9u, \(rocprim", n):
-                continue
-            if "onesweep_iteration" in n:
-                it = max(it or 0.0, float(r["AverageNs"]))
-            elif "onesweep_global_offsets" in n:          # (the same template also runs a microsecond-sized scan of the histograms)
-                hist = max(hist or 0.0, float(r["AverageNs"]))
-        if it and hist:
-            best = (hist / it, os.path.basename(f))
-    return best or (1.31, "default")
-
-
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks (before anything touches the GPU) and exit with their code"""
     import socket
@@ -186,17 +166,17 @@ def main():
     def step():
         if exact:
             hits, alns, corr, asm = shard.exact_iteration(ctx, db, comm)
-            return asm, (hits.count, alns.count), [ctx.last_kernel_ms(i) for i in range(12)]
+            return asm, (hits.count, alns.count), [ctx.last_kernel_ms(i) for i in range(16)]
         if args.config == 2:
             corr = ctx.correct(db, pre)
-            return corr, (0, pre.count), [ctx.last_kernel_ms(i) for i in range(12)]
+            return corr, (0, pre.count), [ctx.last_kernel_ms(i) for i in range(16)]
         hits = ctx.kmermatch(db)
         alns = ctx.rescore(db, hits)
         stats = (hits.count, alns.count)
         del hits
         corr = ctx.correct(db, alns)
         asm = ctx.extend(corr, alns)
-        return asm, stats, [ctx.last_kernel_ms(i) for i in range(12)]
+        return asm, stats, [ctx.last_kernel_ms(i) for i in range(16)]
 
     def sync():
         if dist is not None:
@@ -208,7 +188,7 @@ def main():
         del out
     sync()
     t0 = time.perf_counter()
-    kernel_ms = [0.0] * 12
+    kernel_ms = [0.0] * 16
     stats = (0, 0)
     asm = None
     for _ in range(args.steps):
@@ -247,35 +227,31 @@ def main():
                     "stage_level": {"ancient_correction": {"ms": k_ms[10], "achieved": gbs(ALG_B_PER_BASE["ancient_correction"], k_ms[10]), "unit": "GB/s"}}}
             workload = "%d synthetic %d bp reads, dhigh, ancient_correction only on the alignments of one kmermatcher + rescorediagonal pass (BASELINE.json configs[1])" % (n, L)
         else:
-            # Dominant kernel by rocprofv3 --stats (profiles/): rocPRIM's radix_sort_onesweep_iteration<u64 key, u32 value> in the
-            # 9-bit configuration of kmermatcher's sort 1: 3 passes over the packed 12-byte tuples of the k-mer slots, at most
-            # 2^30 items per launch.  Algorithmic bytes of one launch: its tuples read once + written once.  Its average launch
-            # time: the HIP-event time of the sort call on the library's stream holds those launches + ONE digit-histogram
-            # launch over all keys; the histogram's share is taken out with the histogram/iteration duration ratio of the
-            # committed rocprofv3 summary of this same command.
+            # Dominant kernel by rocprofv3 --stats (profiles/): rx::k_rx_pass<u64 key, u32 value> (carpedeam_amd/csrc/radix.h), the
+            # hand-written onesweep pass of kmermatcher's sort 1: 3 launches per step (27 high k-mer bits, 9 per pass), each reads
+            # and writes every 12-byte tuple of the k-mer slots once - that is a launch's algorithmic traffic.  Its launch time is
+            # measured live: HIP events on the library's stream around each pass launch, summed by the library
+            # (cdm_ctx_last_kernel_ms(13); (14) = number of launches).
             tuples_per_read = L - 20 + 2
             n1 = tuples_per_read * n
-            c1 = -(-n1 // (1 << 30))
-            p1 = -(-min(27, 2 * 20 + 1) // 9)
-            launches = p1 * c1
-            ratio, ratio_src = profile_ratio()
-            iter_ms = k_ms[5] / (launches + ratio) if k_ms[5] > 0 else 0.0
-            sort_bytes = 2.0 * 12.0 * n1 / c1
+            launches = max(1, int(round(k_ms[14]))) if k_ms[14] > 0 else 3
+            iter_ms = k_ms[13] / launches if k_ms[13] > 0 else 0.0
+            sort_bytes = 2.0 * 12.0 * n1
             achieved = sort_bytes / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
             traffic, traffic_total = None, None
             pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_50M*.json")))
             if n == 50_000_000 and L == 100 and world == 1 and pmcs:
                 try:
                     pj = json.load(open(pmcs[-1]))
-                    traffic = pj["kernels"]["rocprim onesweep_iteration 9-bit <u64, u32>"]["hbm_bytes_per_launch"]
+                    traffic = [v for k, v in pj["kernels"].items() if k.startswith("rx::k_rx_pass<unsigned long, unsigned int>")][0]["hbm_bytes_per_launch"]
                     traffic_total = {"file": os.path.basename(pmcs[-1]), "hbm_bytes_per_step": pj.get("stages")}
                 except Exception:
                     traffic = None
             stages = {"kmermatcher": k_ms[8], "rescorediagonal": k_ms[9], "ancient_correction": k_ms[10], "ancient_read_assemble": k_ms[11]}
-            roof = {"bound": "hbm", "kernel": "rocprim radix_sort_onesweep_iteration<u64 key, u32 value> (9-bit configuration; kmermatcher sort 1: 3 passes over the k-mer slots)",
+            roof = {"bound": "hbm", "kernel": "rx::k_rx_pass<u64 key, u32 value> (hand-written onesweep radix pass, 9 bits; kmermatcher sort 1: 3 passes over the k-mer slots)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_ms": iter_ms, "launches_per_step": launches, "algorithmic_bytes_per_launch": sort_bytes,
-                    "how": "sort-1 call %.2f ms (HIP events) / (%d iteration launches + 1 histogram launch x %.2f [%s])" % (k_ms[5], launches, ratio, ratio_src),
+                    "how": "HIP events around the %d pass launches of a step: %.2f ms in total (the whole sort-1 call incl. histogram and status resets: %.2f ms)" % (launches, k_ms[13], k_ms[5]),
                     # the figures that price the radix passes as overhead (the tuple array is written once and read
                     # once): every stage's whole call (HIP events on the context stream around everything it launched) against its
                     # algorithmic bytes, and the chain against 32.2 B/base
