@@ -243,7 +243,7 @@ def main():
             if n == 50_000_000 and L == 100 and world == 1 and pmcs:
                 try:
                     pj = json.load(open(pmcs[-1]))
-                    traffic = [v for k, v in pj["kernels"].items() if k.startswith("rx::k_rx_pass<unsigned long, unsigned int>")][0]["hbm_bytes_per_launch"]
+                    traffic = pj["kernels"]["rx::k_rx_pass<unsigned long, unsigned int>"]["hbm_bytes_per_launch"]
                     traffic_total = {"file": os.path.basename(pmcs[-1]), "hbm_bytes_per_step": pj.get("stages")}
                 except Exception:
                     traffic = None

@@ -22,6 +22,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "common.h"
+#include "radix.h"
 
 namespace bucket {
 
@@ -404,12 +405,12 @@ inline int loadBigList(hipStream_t s, const unsigned long long *bigList, unsigne
     if (!s0.alloc(cnt) || !s1.alloc(cnt) || !e0.alloc(cnt) || !e1.alloc(cnt) || !sz.alloc((size_t) cnt + 1) || !off.alloc((size_t) cnt + 1) || !ranges.alloc(3 * (size_t) cnt)) return CDM_ERR_HIP;
     const unsigned int g = (cnt + 256) / 256;
     hipLaunchKernelGGL(k_big_split, dim3(g), dim3(256), 0, s, bigList, cnt, s0.p, e0.p);
-    rocprim::double_buffer<unsigned long long> ks(s0.p, s1.p), vs(e0.p, e1.p);
-    size_t tb = 0, tb2 = 0;
-    if (rocprim::radix_sort_pairs(nullptr, tb, ks, vs, (size_t) cnt, 0, 64, s) != hipSuccess) return CDM_ERR_HIP;
+    bool inFirst = true;
+    if (int rc = rx::sortPairs<unsigned long long, unsigned long long>(s, 256, s0.p, s1.p, e0.p, e1.p, (uint64_t) cnt, 0, 64, inFirst)) return rc;
+    rocprim::double_buffer<unsigned long long> ks(inFirst ? s0.p : s1.p, inFirst ? s1.p : s0.p), vs(inFirst ? e0.p : e1.p, inFirst ? e1.p : e0.p);
+    size_t tb2 = 0;
     if (rocprim::exclusive_scan(nullptr, tb2, sz.p, off.p, 0ull, (size_t) cnt + 1, rocprim::plus<unsigned long long>(), s) != hipSuccess) return CDM_ERR_HIP;
-    if (!tmp.alloc(std::max(tb, tb2) + 256)) return CDM_ERR_HIP;
-    if (rocprim::radix_sort_pairs(tmp.p, tb, ks, vs, (size_t) cnt, 0, 64, s) != hipSuccess) return CDM_ERR_HIP;
+    if (!tmp.alloc(tb2 + 256)) return CDM_ERR_HIP;
     hipLaunchKernelGGL(k_big_sizes, dim3(g), dim3(256), 0, s, (const unsigned long long *) ks.current(), (const unsigned long long *) vs.current(), cnt, sz.p);
     if (rocprim::exclusive_scan(tmp.p, tb2, sz.p, off.p, 0ull, (size_t) cnt + 1, rocprim::plus<unsigned long long>(), s) != hipSuccess) return CDM_ERR_HIP;
     hipLaunchKernelGGL(k_big_pack, dim3(g), dim3(256), 0, s, (const unsigned long long *) ks.current(), (const unsigned long long *) vs.current(), (const unsigned long long *) off.p, cnt, ranges.p);
@@ -449,14 +450,13 @@ inline int bucketSortKeys(hipStream_t s, const uint64_t *in, uint64_t *out, uint
     DevBuf<unsigned long long> ranges; uint64_t total = 0;
     if (int rc = loadBigList(s, bigList.p, cnt, ranges, total)) return rc;
     if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "bucketSortKeys: n %llu shiftHi %d: %u big buckets, %llu elements\n", (unsigned long long) n, shiftHi, cnt, (unsigned long long) total);
-    DevBuf<uint64_t> d0, d1; DevBuf<char> tmp; size_t tb = 0;
+    DevBuf<uint64_t> d0, d1;
     if (!d0.alloc(total) || !d1.alloc(total)) return CDM_ERR_HIP;
     const unsigned int grid = bigCopyGrid(cnt);
     hipLaunchKernelGGL((k_big_copy<uint64_t, true>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, cnt, const_cast<uint64_t *>(in), d0.p);
-    rocprim::double_buffer<uint64_t> db(d0.p, d1.p);
-    if (rocprim::radix_sort_keys(nullptr, tb, db, (size_t) total, ign, top, s) != hipSuccess || !tmp.alloc(tb + 256)) return CDM_ERR_HIP;
-    if (rocprim::radix_sort_keys(tmp.p, tb, db, (size_t) total, ign, top, s) != hipSuccess) return CDM_ERR_HIP;
-    hipLaunchKernelGGL((k_big_copy<uint64_t, false>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, cnt, out, db.current());
+    bool inFirst = true;
+    if (int rc = rx::sortKeys<uint64_t>(s, 256, d0.p, d1.p, total, ign, top, inFirst)) return rc;
+    hipLaunchKernelGGL((k_big_copy<uint64_t, false>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, cnt, out, inFirst ? d0.p : d1.p);
     if (hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
     return CDM_OK;
 }

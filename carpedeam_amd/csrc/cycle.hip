@@ -3,17 +3,17 @@
 // The reference cuts a contig into thirds by k-mer position, sorts the three k-mer lists and merges them: every middle/back
 // occurrence of a 22-mer against the FIRST front occurrence, every back occurrence against the FIRST middle occurrence, a hit
 // counter per diagonal >= L/3, then the first diagonal whose 1 % band holds more than 0.24 hits per possible k-mer.
-// Here: ONE stable radix sort of all contigs' (k-mer, global ordinal) pairs - the ordinals ascend with (contig, position), so a
+// Here: ONE stable radix sort (radix.h) of all contigs' (k-mer, global ordinal) pairs - the ordinals ascend with (contig, position), so a
 // contig's occurrences of a k-mer end up adjacent and in position order - and a thread per occurrence that looks BACK in its run:
 // the run head (gallop + bisect) is the first front occurrence, a bisect finds the first middle one.  No per-contig sort, no
 // LDS limit on the contig length.  Quirks kept (the oracle lists them): position 0 belongs to no third that matters, N is
 // letter 4 of a base-4 index (collisions included), the band arithmetic runs in the reference's types.
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "common.h"
 #include "devutil.h"
 #include "scan.h"
+#include "radix.h"
 
 namespace {
 typedef unsigned long long u64;
@@ -134,18 +134,16 @@ extern "C" int cdm_cyclecheck(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t maxSeq
     CDM_HIP(hipStreamSynchronize(s));
     if (totalK >= 0xFFFFFFFFull) { cdm_set_error("cdm_cyclecheck: more than 2^32-1 k-mer positions (%llu)", totalK); return CDM_ERR_UNSUPPORTED; }
     CDM_HIP(hipMemsetAsync(split.p, 0xFF, (size_t) n * 4 + 4, s));
-    DevBuf<u64> k0, k1; DevBuf<uint32_t> v0, v1, hits, owner; DevBuf<char> tmp;
+    DevBuf<u64> k0, k1; DevBuf<uint32_t> v0, v1, hits, owner;
     CycArgs a = {db->codes, db->nmask, db->woff, db->len, db->hasN, n, maxSeqLen, koff.p, hoff.p, totalK, totalH, nullptr, nullptr, nullptr, nullptr, split.p};
     if (totalK) {
         if (!k0.alloc(totalK) || !k1.alloc(totalK) || !v0.alloc(totalK) || !v1.alloc(totalK) || !hits.alloc(totalH) || !owner.alloc(totalK)) { cdm_set_error("cdm_cyclecheck: out of device memory"); return CDM_ERR_HIP; }
         CDM_HIP(hipMemsetAsync(hits.p, 0, (totalH + 1) * 4, s));
         a.keys = k0.p; a.vals = v0.p; a.hits = hits.p; a.owner = owner.p;
         hipLaunchKernelGGL(k_cyc_kmers, dim3((unsigned) ((totalK + 255) / 256)), dim3(256), 0, s, a);
-        rocprim::double_buffer<u64> kb(k0.p, k1.p); rocprim::double_buffer<uint32_t> vb(v0.p, v1.p);
-        size_t tb = 0;
-        if (rocprim::radix_sort_pairs(nullptr, tb, kb, vb, (size_t) totalK, 0, 2 * CYC_K + 2, s) != hipSuccess || !tmp.alloc(tb + 256)) { cdm_set_error("cdm_cyclecheck: sort set-up failed"); return CDM_ERR_HIP; }
-        if (rocprim::radix_sort_pairs(tmp.p, tb, kb, vb, (size_t) totalK, 0, 2 * CYC_K + 2, s) != hipSuccess) { cdm_set_error("cdm_cyclecheck: sort failed"); return CDM_ERR_HIP; }
-        a.keys = kb.current(); a.vals = vb.current();
+        bool inFirst = true;            // stable radix sort on the 46 index bits (radix.h)
+        if (int rc = rx::sortPairs<uint64_t, uint32_t>(s, ctx->cuCount, reinterpret_cast<uint64_t *>(k0.p), reinterpret_cast<uint64_t *>(k1.p), v0.p, v1.p, (uint64_t) totalK, 0, 2 * CYC_K + 2, inFirst)) return rc;
+        a.keys = inFirst ? k0.p : k1.p; a.vals = inFirst ? v0.p : v1.p;
         hipLaunchKernelGGL(k_cyc_hits, dim3((unsigned) ((totalK + 255) / 256)), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_cyc_band, dim3((unsigned) ((totalH + 255) / 256)), dim3(256), 0, s, a);
     }

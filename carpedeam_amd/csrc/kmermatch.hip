@@ -1160,13 +1160,11 @@ int phaseA() override {
         DevBuf<uint32_t> lk0, lk1, lv0, lv1; DevBuf<unsigned long long> ordOff;
         if (!lk0.alloc(n) || !lk1.alloc(n) || !lv0.alloc(n) || !lv1.alloc(n) || !ordOff.alloc((size_t) n + 1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
         hipLaunchKernelGGL(k_len_keys, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, db->maxLen, lk0.p, lv0.p);
-        rocprim::double_buffer<uint32_t> lk(lk0.p, lk1.p), lv(lv0.p, lv1.p);
-        size_t sb0 = 0;
         const unsigned lenBits = bitsFor((uint64_t) db->maxLen + 2);
-        rocprim::radix_sort_pairs(nullptr, sb0, lk, lv, (size_t) n, 0, lenBits, s);
-        DevBuf<char> t0; cdmscan::ScanTemp st;
-        if (!t0.alloc(sb0 + 256)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
-        rocprim::radix_sort_pairs(t0.p, sb0, lk, lv, (size_t) n, 0, lenBits, s);
+        cdmscan::ScanTemp st;
+        bool lenFirst = true;
+        if (int rc = rx::sortPairs<uint32_t, uint32_t>(s, ctx->cuCount, lk0.p, lk1.p, lv0.p, lv1.p, (uint64_t) n, 0, (int) lenBits, lenFirst)) return rc;
+        rocprim::double_buffer<uint32_t> lk(lenFirst ? lk0.p : lk1.p, lenFirst ? lk1.p : lk0.p), lv(lenFirst ? lv0.p : lv1.p, lenFirst ? lv1.p : lv0.p);
         hipLaunchKernelGGL(k_slot_counts, dim3((n + 256) / 256), dim3(256), 0, s, db->len, lv.current(), n, k, slots.p);
         if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, st, slots.p, ordOff.p, (size_t) n + 1)) return rc;
         hipLaunchKernelGGL(k_slot_scatter, dim3((n + 256) / 256), dim3(256), 0, s, lv.current(), ordOff.p, n, slotOff.p, rankOf.p);
@@ -1344,9 +1342,9 @@ int phaseA() override {
                     const unsigned int grid = bucket::bigCopyGrid(nBig);
                     hipLaunchKernelGGL((bucket::k_big_copy<uint64_t, true>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(ga.keys), dk0.p);
                     hipLaunchKernelGGL((bucket::k_big_copy<V, true>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<V *>(ga.vals), dv0.p);
-                    rocprim::double_buffer<uint64_t> dk(dk0.p, dk1.p); rocprim::double_buffer<V> dv(dv0.p, dv1.p);
-                    if (rocprim::radix_sort_pairs(nullptr, tb, dk, dv, (size_t) total, 0, 2 * k, s) != hipSuccess || !t.alloc(tb + 256) ||
-                        rocprim::radix_sort_pairs(t.p, tb, dk, dv, (size_t) total, 0, 2 * k, s) != hipSuccess) rc = CDM_ERR_HIP;
+                    bool bigFirst = true;
+                    rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, dk0.p, dk1.p, dv0.p, dv1.p, (uint64_t) total, 0, 2 * k, bigFirst);
+                    rocprim::double_buffer<uint64_t> dk(bigFirst ? dk0.p : dk1.p, bigFirst ? dk1.p : dk0.p); rocprim::double_buffer<V> dv(bigFirst ? dv0.p : dv1.p, bigFirst ? dv1.p : dv0.p);
                     if (rc == CDM_OK) {
                         // the sorted tuples go back in place too: k_stale_tail indexes big buckets directly
                         hipLaunchKernelGGL((bucket::k_big_copy<uint64_t, false>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(ga.keys), dk.current());

@@ -23,6 +23,9 @@ namespace rx {
 constexpr int NT = 512, WAVES = NT / 64, IPT = 16, TILE = NT * IPT, BITS = 9, BINS = 1 << BITS, MAXPASS = 8;
 constexpr unsigned long long ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = (1ull << 62) - 1ull;
 
+struct NoValue {};      // V = NoValue: keys only
+template <typename V> struct HasValue { static constexpr bool value = true; };
+template <> struct HasValue<NoValue> { static constexpr bool value = false; };
 template <typename K> struct HistArgs { const K *keys; uint64_t n; int beginBit, endBit, passes; unsigned long long *hist; };      // hist[pass][digit]
 template <typename K> __device__ __forceinline__ uint32_t digitOf(K key, int shift, uint32_t mask) { return (uint32_t) (key >> shift) & mask; }
 
@@ -49,6 +52,7 @@ __global__ __launch_bounds__(NT) void k_rx_hist(HistArgs<K> a) {
     for (int i = threadIdx.x; i < a.passes * BINS; i += NT) { const unsigned int c = (&sHist[0][0])[i]; if (c) atomicAdd(&a.hist[i], (unsigned long long) c); }
 }
 // in place: hist[pass][digit] -> first output position of the digit
+template <int UNUSED = 0>        // (a template: the header is included by several translation units)
 __global__ __launch_bounds__(BINS) void k_rx_offsets(unsigned long long *hist, int passes) {
     for (int p = 0; p < passes; p++) {
         const unsigned long long c = hist[p * BINS + threadIdx.x];
@@ -85,7 +89,10 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
     K key[IPT]; V val[IPT]; uint16_t pos[IPT];
     const int w0 = wave * 64 * IPT + lane;
 #pragma unroll
-    for (int j = 0; j < IPT; j++) { const int li = w0 + 64 * j; if (li < items) { key[j] = a.kin[base + li]; val[j] = a.vin[base + li]; } else { key[j] = 0; val[j] = 0; } }
+    for (int j = 0; j < IPT; j++) {
+        const int li = w0 + 64 * j;
+        if (li < items) { key[j] = a.kin[base + li]; if constexpr (HasValue<V>::value) val[j] = a.vin[base + li]; } else key[j] = 0;
+    }
     // ---- rank inside the wave's stream, round by round
     uint16_t *cntW = sCnt[wave];
 #pragma unroll
@@ -155,16 +162,18 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
             a.kout[sGlobal[dig[r]] + (unsigned long long) p] = k;
         }
     }
-    __syncthreads();
-    // ---- the values the same way
-    V *sV = reinterpret_cast<V *>(sBuf);
+    if constexpr (HasValue<V>::value) {
+        __syncthreads();
+        // ---- the values the same way
+        V *sV = reinterpret_cast<V *>(sBuf);
 #pragma unroll
-    for (int j = 0; j < IPT; j++) if (w0 + 64 * j < items) sV[pos[j]] = val[j];
-    __syncthreads();
+        for (int j = 0; j < IPT; j++) if (w0 + 64 * j < items) sV[pos[j]] = val[j];
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < IPT; r++) {
-        const int p = tid + NT * r;
-        if (p < items) a.vout[sGlobal[dig[r]] + (unsigned long long) p] = sV[p];
+        for (int r = 0; r < IPT; r++) {
+            const int p = tid + NT * r;
+            if (p < items) a.vout[sGlobal[dig[r]] + (unsigned long long) p] = sV[p];
+        }
     }
 }
 
@@ -184,7 +193,7 @@ inline int sortPairs(hipStream_t s, int cuCount, K *k0, K *k1, V *v0, V *v1, uin
     hipMemsetAsync(ticket.p, 0, (size_t) passes * 4, s);
     HistArgs<K> ha; ha.keys = k0; ha.n = n; ha.beginBit = beginBit; ha.endBit = endBit; ha.passes = passes; ha.hist = hist.p;
     hipLaunchKernelGGL(k_rx_hist<K>, dim3((unsigned) std::min<uint64_t>(tiles, (uint64_t) cuCount * 8)), dim3(NT), 0, s, ha);
-    hipLaunchKernelGGL(k_rx_offsets, dim3(1), dim3(BINS), 0, s, hist.p, passes);
+    hipLaunchKernelGGL(k_rx_offsets<0>, dim3(1), dim3(BINS), 0, s, hist.p, passes);
     hipEvent_t ev[2 * MAXPASS];
     if (passMs) for (int i = 0; i < 2 * passes; i++) hipEventCreate(&ev[i]);
     for (int p = 0; p < passes; p++) {
@@ -206,6 +215,12 @@ inline int sortPairs(hipStream_t s, int cuCount, K *k0, K *k1, V *v0, V *v1, uin
     }
     if (e != hipSuccess) { cdm_set_error("radix sort failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
     return CDM_OK;
+}
+
+// keys only
+template <typename K>
+inline int sortKeys(hipStream_t s, int cuCount, K *k0, K *k1, uint64_t n, int beginBit, int endBit, bool &inFirst) {
+    return sortPairs<K, NoValue>(s, cuCount, k0, k1, (NoValue *) nullptr, (NoValue *) nullptr, n, beginBit, endBit, inFirst);
 }
 
 }  // namespace rx

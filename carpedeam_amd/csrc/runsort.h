@@ -528,14 +528,13 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
     }
     DevBuf<unsigned long long> ranges; uint64_t total = 0;
     if (int rc = loadBigList(s, lists[3].p, nBig, ranges, total)) return rc;
-    DevBuf<uint64_t> d0, d1; DevBuf<char> tmp; size_t tb = 0;
+    DevBuf<uint64_t> d0, d1;
     if (!d0.alloc(total) || !d1.alloc(total)) return CDM_ERR_HIP;
     const unsigned int g = bigCopyGrid(nBig);
     hipLaunchKernelGGL((k_big_copy<uint64_t, true>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(in), d0.p);
-    rocprim::double_buffer<uint64_t> db(d0.p, d1.p);
-    if (rocprim::radix_sort_keys(nullptr, tb, db, (size_t) total, 1, top, s) != hipSuccess || !tmp.alloc(tb + 256)) return CDM_ERR_HIP;
-    if (rocprim::radix_sort_keys(tmp.p, tb, db, (size_t) total, 1, top, s) != hipSuccess) return CDM_ERR_HIP;
-    hipLaunchKernelGGL((k_big_copy<uint64_t, false>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, out, db.current());
+    bool inFirst = true;
+    if (int rc = rx::sortKeys<uint64_t>(s, cuCount, d0.p, d1.p, total, 1, top, inFirst)) return rc;
+    hipLaunchKernelGGL((k_big_copy<uint64_t, false>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, out, inFirst ? d0.p : d1.p);
     if (hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
     return CDM_OK;
 }

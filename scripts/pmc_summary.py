@@ -42,12 +42,19 @@ def short(name):
 
 
 def load(path, counter):
+    """-> (bytes per kernel, launches per kernel).  Launches of one kernel whose grid is less than a quarter of its largest
+    grid are kept apart ("<name> [small launches]"): the radix pass runs on the 4 G k-mer slots and on the 50 M hash tuples."""
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    big = collections.defaultdict(float)
+    for r in rows:
+        k = short(r["Kernel_Name"])
+        big[k] = max(big[k], float(r.get("Grid_Size", 0) or 0))
     tot = collections.defaultdict(float)
     launches = collections.defaultdict(set)
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
-            continue
+    for r in rows:
         k = short(r["Kernel_Name"])
+        if float(r.get("Grid_Size", 0) or 0) * 4 < big[k]:
+            k += " [small launches]"
         tot[k] += float(r["Counter_Value"]) * 1024.0
         launches[k].add(r["Dispatch_Id"])
     return tot, {k: len(v) for k, v in launches.items()}
