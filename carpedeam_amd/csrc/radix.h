@@ -20,7 +20,12 @@
 
 namespace rx {
 
-constexpr int NT = 512, WAVES = NT / 64, IPT = 16, TILE = NT * IPT, BITS = 9, BINS = 1 << BITS, MAXPASS = 8;
+#ifndef CDM_RX_NT
+#define CDM_RX_NT 512
+#define CDM_RX_IPT 16
+#endif
+constexpr int NT = CDM_RX_NT, WAVES = NT / 64, IPT = CDM_RX_IPT, TILE = NT * IPT, BITS = 9, BINS = 1 << BITS, MAXPASS = 8;
+static_assert(NT >= BINS && TILE <= 65536, "radix pass geometry");
 constexpr unsigned long long ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = (1ull << 62) - 1ull;
 
 struct NoValue {};      // V = NoValue: keys only
@@ -117,15 +122,19 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
     __syncthreads();
     // ---- per digit (thread = digit): the waves in front, the digits in front (tile), the tiles in front (look-back)
     {
+        const bool isDigit = tid < BINS;
         uint32_t run = 0;
+        if (isDigit) {
 #pragma unroll
-        for (int w = 0; w < WAVES; w++) { const uint32_t c = sCnt[w][tid]; sCnt[w][tid] = (uint16_t) run; run += c; }
+            for (int w = 0; w < WAVES; w++) { const uint32_t c = sCnt[w][tid]; sCnt[w][tid] = (uint16_t) run; run += c; }
+        }
         uint32_t tot;
         const uint32_t ex = cdm_block_excl_sum<uint32_t>(run, tot);
-        sTileOff[tid] = (uint16_t) ex;
+        if (isDigit) sTileOff[tid] = (uint16_t) ex;
         unsigned long long *st = a.status + tile * BINS + tid;
         unsigned long long exclG = 0;
-        if (tile == 0) __hip_atomic_store(st, ST_PREFIX | (unsigned long long) run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!isDigit) {}
+        else if (tile == 0) __hip_atomic_store(st, ST_PREFIX | (unsigned long long) run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else {
             __hip_atomic_store(st, ST_AGG | (unsigned long long) run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long *q = st - BINS;
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
             }
             __hip_atomic_store(st, ST_PREFIX | (exclG + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        sGlobal[tid] = a.digitBase[tid] + exclG - ex;       // output position of the pair at exchange slot p with this digit: sGlobal + p
+        if (isDigit) sGlobal[tid] = a.digitBase[tid] + exclG - ex;       // output position of the pair at exchange slot p with this digit: sGlobal + p
     }
     __syncthreads();
     K *sK = reinterpret_cast<K *>(sBuf);
