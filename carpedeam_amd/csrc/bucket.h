@@ -2,7 +2,8 @@
 //
 // Both sorts of kmermatcher (kmermatcher.cpp:412 by k-mer, :431 by (rep, id, diagonal)) order a few 10^9 tuples.  A
 // least-significant-digit radix sort streams the whole array through HBM once per 8 key bits.  Here only the TOP bits (27 for the
-// k-mer sort, 32 for the group-key sort) go through those global passes (rocPRIM onesweep); what is left are runs of equal high bits ("buckets") that are contiguous in
+// k-mer sort; 32 for the group-key sort in its radix variant) go through those global passes (the onesweep of radix.h); what is left are runs
+// of equal high bits ("buckets") that are contiguous in
 // memory, and they are finished on chip: a wavefront takes a group of consecutive whole buckets (up to 256 elements, or one
 // bucket of up to 512), builds one word per element = (bucket ordinal, low key bits, position) and sorts the words with a
 // bitonic network held in registers (exchanges between lanes are DPP row permutations / ds_swizzle).  The position is part of the compared word, so the
@@ -12,7 +13,7 @@
 // buckets that START in its range, stages a window of WV_WIN slots (its range plus the longest bucket it can finish) in its
 // private part of the LDS, finds the bucket starts with ballots and walks them group by group.  A bucket that does not fit
 // (more than BK_MAXB elements) is appended to a list and finished by the caller: the listed ranges are gathered, sorted on the
-// complete key by rocPRIM and scattered back (bucketSortKeys below, the fused k-mer kernel's fallback in kmermatch.hip).
+// complete key by the global radix sort and scattered back (bucketSortKeys below, the fused k-mer kernel's fallback in kmermatch.hip).
 #pragma once
 #include <algorithm>
 #include <cstdio>

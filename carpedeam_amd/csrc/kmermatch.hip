@@ -4,12 +4,13 @@
 //   K1 k_seq_hash, k_extract_pair, k_extract_fast, k_extract   fillKmerPositionArray :77-388  per sequence: canonical k-mers, XXH64 16-bit
 //                     min-hash, per-sequence ordering by (hash, k-mer, pos) for the repeated-k-mer skipping and the bottom-m
 //                     selection, + the whole-sequence hash tuple
-//   K2 sort 1         :412   stable sort on the k-mer: the top 27 sort bits by rocPRIM radix passes, the low bits per bucket on chip
+//   K2 sort 1         :412   stable sort on the k-mer: the top 27 sort bits by three onesweep radix passes (radix.h), the low bits per
+//                     bucket on chip
 //   K3 k_bucket_groups (k_groups)   assignGroup :453-562  first sequence of every k-mer run by (length desc, id, pos) is the
 //                     representative; members become (rep, id, diagonal, strand); singletons dropped.  Fused with the
 //                     on-chip part of sort 1 (bucket.h)
-//   K2 sort 2         :431   stable sort on (rep, id, diagonal) packed into one 64-bit key: radix passes on the top 32 bits,
-//                     k_bucket_sort on the rest
+//   K2 sort 2         :431   stable sort on (rep, id, diagonal) packed into one 64-bit key: the k-mer RUNS are sorted by
+//                     representative (run records, runsort.h), every representative's tuples then on chip (k_unit_sort)
 //   K4 k_seg_count/place   writeKmerMatcherResult :815-930  per (rep, target): shared k-mer count, most frequent diagonal
 //                     (last maximum wins), strand of that diagonal's last tuple; every sequence gets a record that starts
 //                     with its self hit (fill-in :717-729)
@@ -1336,7 +1337,7 @@ int phaseA() override {
                 DevBuf<unsigned long long> ranges; uint64_t total = 0; unsigned long long firstStart = ~0ull;
                 rc = bucket::loadBigList(s, bigList.p, nBig, ranges, total, &firstStart);
                 if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "kmermatch sort 1: %llu slots, low bits %d: %u big buckets, %llu tuples\n", (unsigned long long) kmerSlots, lowBits, nBig, (unsigned long long) total);
-                DevBuf<uint64_t> dk0, dk1; DevBuf<V> dv0, dv1; DevBuf<unsigned long long> ds; DevBuf<char> t; size_t tb = 0;
+                DevBuf<uint64_t> dk0, dk1; DevBuf<V> dv0, dv1; DevBuf<unsigned long long> ds;
                 if (rc == CDM_OK && (!dk0.alloc(total) || !dk1.alloc(total) || !dv0.alloc(total) || !dv1.alloc(total) || !ds.alloc(total))) rc = CDM_ERR_HIP;
                 if (rc == CDM_OK) {
                     const unsigned int grid = bucket::bigCopyGrid(nBig);
@@ -1540,7 +1541,7 @@ int gatherByRep() override {
     cdmscan::ScanTemp stB;
     RunArgs ra; ra.keys = (const uint64_t *) startIo; ra.n = nTuples; ra.skipLo = live; ra.skipHi = kmerSlots; ra.repShift = (int) (idBits + diagBits + 1);
     unsigned long long nRec = 0, nOut = 0;
-    DevBuf<uint32_t> rr0, rr1; DevBuf<uint64_t> rv0, rv1; DevBuf<unsigned long long> dst; DevBuf<char> t1; size_t tb = 0;
+    DevBuf<uint32_t> rr0, rr1; DevBuf<uint64_t> rv0, rv1; DevBuf<unsigned long long> dst;
     if (int rc = makeRunRecords(s, ra, rr0, rr1, rv0, rv1, nRec)) return rc;
     gathered = keys.current();
     if (nRec == 0) return CDM_OK;

@@ -3,19 +3,20 @@
 //
 // After assignGroup the tuples sit in k-mer order, and every k-mer run is a stretch of tuples with ONE representative: the
 // array is run-length compressible on the very field the sort starts with.  So the runs are sorted, not the tuples:
-//   1. k_run_count / k_run_write   one record (rep, start, length) per maximal stretch of kept tuples with the same
+//   1. k_run_records               one record (rep, start, length) per maximal stretch of kept tuples with the same
 //                                  representative (a stretch never crosses a 4096-tuple tile, so a length fits 13 bits);
-//                                  12 bytes per ~16 tuples
-//   2. a stable radix sort of the records by rep (they are written in k-mer order): 1/12 of the tuples' bytes per pass
-//   3. k_run_gather                expands the sorted records: the tuples of a representative become contiguous, still in
-//                                  k-mer order (what the reference's stable sort leaves for equal (rep, id, diagonal));
-//                                  dropped tuples (~0) vanish on the way, so this is also the compaction
-//   4. segmentedSortKeys           each representative's segment is sorted on (id, diagonal): k_unit_sort (an LDS counting split
-//                                  on a monotone function of (rep, id), then register networks per group of sub-buckets) for
-//                                  segments up to 3072 tuples, a block-wide bitonic network (k_block_sort) up to 4096, rocPRIM
-//                                  beyond that (deep pile-ups).
-// The tuple array is read three times and written twice here (count, write, gather; local sort), against 10 reads and
-// 9 writes of the 4 radix passes + bucket finish this replaces.
+//                                  12 bytes per ~16 tuples.  One pass (chained scan over the tiles); k_run_count + k_run_write
+//                                  if the record buffer turns out too small
+//   2. a stable radix sort of the records by rep (radix.h; they are written in k-mer order): 1/12 of the tuples' bytes per pass
+//   3. expanding the sorted records makes the tuples of a representative contiguous, still in k-mer order (what the reference's
+//      stable sort leaves for equal (rep, id, diagonal)); dropped tuples (~0) vanish on the way, so this is also the compaction.
+//      k_run_gather does it for the whole array (multi-GPU hand-off); on one device the expansion happens inside step 4
+//   4. segmentedSortKeys           each representative's segment is sorted on (id, diagonal): k_unit_sort (expands the unit's
+//                                  records into LDS, an LDS counting split on a monotone function of (rep, id), then register
+//                                  networks per group of sub-buckets) for segments up to 2048 tuples, a block-wide bitonic
+//                                  network (k_block_sort) up to 4096, the global radix sort beyond that (deep pile-ups).
+// The tuple array is read twice and written once here (records; local sort), against 10 reads and 9 writes of the 4 radix
+// passes + bucket finish this replaces.
 #pragma once
 #include "bucket.h"
 #include "devutil.h"
