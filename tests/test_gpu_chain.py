@@ -155,6 +155,36 @@ def test_chain_properties_at_scale(ctx):
     assert 0.05 * n < (e2 == 1).sum() < 0.3 * n
 
 
+def test_full_size_invariants(ctx, monkeypatch):
+    """BASELINE.json configs[2] at full size - 50 M x 100 bp, no oracle there: kmermatcher with its two independent sort-2 pipelines
+    (run records + on-chip sorters vs radix passes + bucket finish) cross-checked on the device over all 4 G tuples, the library's
+    own radix sort against rocPRIM's on the same data (equal hit sets), and the structural invariants that need only counts
+    and per-sequence metadata (no 5 GB downloads into Python objects)."""
+    n, L = 50_000_000, 100
+    db = ctx.synth(n, L, L, 1)
+    monkeypatch.setenv("CDM_KMER_SORT2", "check")            # a mismatch between the two pipelines is an error of the call
+    hits = ctx.kmermatch(db)
+    monkeypatch.delenv("CDM_KMER_SORT2")
+    monkeypatch.setenv("CDM_KMER_SORT1", "rocprim")
+    hits_lib = ctx.kmermatch(db)
+    monkeypatch.delenv("CDM_KMER_SORT1")
+    assert hits.count == hits_lib.count
+    del hits_lib
+    alns = ctx.rescore(db, hits)
+    assert n <= alns.count <= hits.count and hits.count > 3 * n
+    del hits
+    corr = ctx.correct(db, alns)
+    l1, k1, e1 = corr.meta()
+    assert (l1 == L).all() and (e1 == 0).all() and (k1 == np.arange(n, dtype=np.uint32)).all() and corr.residues == n * L
+    asm = ctx.extend(corr, alns)
+    l2, k2, e2 = asm.meta()
+    assert (k2 == k1).all() and (l2 >= L).all() and (l2 < 3 * L + 3).all() and ((l2 > L) == (e2 == 1)).all()
+    assert 0.05 * n < int((e2 == 1).sum()) < 0.3 * n and asm.residues == int(l2.astype(np.int64).sum())
+    # the same corpus in two halves of the read range gives the halves of the per-sequence generator (shards of ONE corpus)
+    part = ctx.synth(1000, L, L, 1, n_total=n, first=n - 1000)
+    assert part.n == 1000 and part.residues == 1000 * L
+
+
 def test_contig_handoff_roundtrip(ctx):
     """select_ext -> packed DEVICE buffers -> from_packed: what the RCCL all-gather of bench.py --gpus N moves.
     (device buffers come straight from the HIP runtime here; bench.py passes torch tensors' data_ptr())"""
