@@ -1251,7 +1251,22 @@ int phaseA() override {
     const char *sort1Env = getenv("CDM_KMER_SORT1");
     const bool ownRadix = !(lsdOnly || fourPasses) && !(sort1Env && !strcmp(sort1Env, "rocprim"));
     hipEventRecord(ctx->ev0, s);
-    if (ownRadix) {
+    if (ownRadix && nparts > 1 && kmerSlots) {
+        // a k-mer RANGE: most slots are empty.  The real tuples are compacted (stable) into the other buffers first, so that the
+        // passes run over this rank's share only; behind them the result holds empty slots again, as if all had been sorted.
+        DevBuf<unsigned long long> cnt;
+        if (!cnt.alloc(1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+        if (int rc = rx::compactPairs<uint64_t, V>(s, k0.p, v0.p, (uint64_t) kmerSlots, k1.p, v1.p, cnt.p)) return rc;
+        unsigned long long m = 0;
+        hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: compaction failed"); return CDM_ERR_HIP; }
+        bool inFirst = true;        // "first" = (k1, v1) here
+        if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, k1.p, k0.p, v1.p, v0.p, (uint64_t) m, lowBits, sortTop, inFirst, &ctx->lastMs[13])) return rc;
+        ctx->lastMs[14] = (float) ((sortTop - lowBits + rx::BITS - 1) / rx::BITS);
+        uint64_t *kRes = inFirst ? k1.p : k0.p; V *vRes = inFirst ? v1.p : v0.p;
+        hipMemsetAsync(kRes + m, 0xFF, (size_t) (kmerSlots - m) * 8, s);        // (the values of empty slots are never read)
+        keys = rocprim::double_buffer<uint64_t>(kRes, inFirst ? k0.p : k1.p); vals = rocprim::double_buffer<V>(vRes, inFirst ? v0.p : v1.p);
+    } else if (ownRadix) {
         bool inFirst = true;
         if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, k0.p, k1.p, v0.p, v1.p, (uint64_t) kmerSlots, lowBits, sortTop, inFirst, &ctx->lastMs[13])) return rc;
         ctx->lastMs[14] = (float) ((sortTop - lowBits + rx::BITS - 1) / rx::BITS);     // its launches

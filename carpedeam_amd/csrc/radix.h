@@ -186,6 +186,85 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
     }
 }
 
+// ---- stable compaction: the pairs whose key is not ~0 (empty slot), in order, to the front of (kout, vout); *total = how many.
+// One pass: per wave and round of 64 pairs a ballot ranks the kept ones, the tiles chain their counts with the same look-back.
+// (kmermatcher with a k-mer RANGE per rank leaves most slots empty: compacting first makes sort 1 as short as the range.)
+constexpr int CP_NT = 256, CP_WAVES = CP_NT / 64, CP_TILE = CP_NT * IPT;
+template <typename K, typename V>
+struct CompactArgs { const K *kin; const V *vin; uint64_t n; K *kout; V *vout; unsigned long long *status; unsigned int *ticket; unsigned long long *total; };
+template <typename K, typename V>
+__global__ __launch_bounds__(CP_NT) void k_rx_compact(CompactArgs<K, V> a) {
+    __shared__ unsigned int sTile, sWave[CP_WAVES];
+    __shared__ unsigned long long sPrefix;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sTile = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const uint64_t tile = sTile, base = tile * CP_TILE;
+    const int items = (int) min((uint64_t) CP_TILE, a.n - base);
+    K key[IPT]; V val[IPT]; uint16_t pos[IPT];
+    const int w0 = wave * 64 * IPT + lane;
+    uint32_t kept = 0;          // bit j: pair j of this lane is kept
+    uint32_t run = 0;           // wave-uniform: kept pairs of the wave so far
+#pragma unroll
+    for (int j = 0; j < IPT; j++) { const int li = w0 + 64 * j; key[j] = li < items ? a.kin[base + li] : (K) ~(K) 0; }
+#pragma unroll
+    for (int j = 0; j < IPT; j++) if (key[j] != (K) ~(K) 0) val[j] = a.vin[base + w0 + 64 * j];       // (the values of the kept pairs only)
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const bool k = key[j] != (K) ~(K) 0;
+        const unsigned long long m = __ballot(k);
+        pos[j] = (uint16_t) (run + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)));
+        if (k) kept |= 1u << j;
+        run += (uint32_t) __popcll(m);
+    }
+    if (lane == 0) sWave[wave] = run;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < CP_WAVES; w++) { const uint32_t c = sWave[w]; if (w < wave) before += c; tot += c; }
+    if (wave == 0) {
+        unsigned long long excl = 0;
+        if (tile == 0) { if (lane == 0) __hip_atomic_store(&a.status[0], ST_PREFIX | (unsigned long long) tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else {
+            if (lane == 0) __hip_atomic_store(&a.status[tile], ST_AGG | (unsigned long long) tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long t0 = (long long) tile - 1;
+            while (true) {
+                const long long t = t0 - lane;
+                unsigned long long v = ST_PREFIX;
+                if (t >= 0) do { v = __hip_atomic_load(&a.status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 62) == 0ull);
+                const unsigned long long pm = __ballot((v >> 62) == 2ull);
+                const int first = pm ? __ffsll(pm) - 1 : 63;
+                const unsigned long long part = cdm_wave_incl_sum<unsigned long long>(lane <= first ? (v & ST_MASK) : 0ull);
+                excl += (unsigned long long) __shfl((long long) part, 63, 64);
+                if (pm) break;
+                t0 -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(&a.status[tile], ST_PREFIX | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) { sPrefix = excl; if ((tile + 1) * CP_TILE >= a.n) *a.total = excl + tot; }
+    }
+    __syncthreads();
+    const unsigned long long o = sPrefix + before;
+#pragma unroll
+    for (int j = 0; j < IPT; j++) if (kept & (1u << j)) { a.kout[o + pos[j]] = key[j]; a.vout[o + pos[j]] = val[j]; }
+}
+// asynchronous on s; *totalDev (device) receives the count
+template <typename K, typename V>
+inline int compactPairs(hipStream_t s, const K *kin, const V *vin, uint64_t n, K *kout, V *vout, unsigned long long *totalDev) {
+    const uint64_t tiles = (n + CP_TILE - 1) / CP_TILE;
+    hipMemsetAsync(totalDev, 0, 8, s);
+    if (tiles == 0) return CDM_OK;
+    unsigned long long *status = nullptr; unsigned int *ticket = nullptr;
+    if (cdmMalloc(&status, tiles * 8 + 8) != hipSuccess || cdmMalloc(&ticket, 8) != hipSuccess) { if (status) cdmFree(status); cdm_set_error("compaction: out of device memory"); return CDM_ERR_HIP; }
+    hipMemsetAsync(status, 0, tiles * 8, s); hipMemsetAsync(ticket, 0, 4, s);
+    CompactArgs<K, V> a; a.kin = kin; a.vin = vin; a.n = n; a.kout = kout; a.vout = vout; a.status = status; a.ticket = ticket; a.total = totalDev;
+    hipLaunchKernelGGL((k_rx_compact<K, V>), dim3((unsigned) tiles), dim3(CP_NT), 0, s, a);
+    const hipError_t e = hipStreamSynchronize(s);       // (the scratch goes back to the pool)
+    cdmFree(status); cdmFree(ticket);
+    if (e != hipSuccess) { cdm_set_error("compaction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
+    return CDM_OK;
+}
+
 // Sorts the n pairs on key bits [beginBit, endBit), stable.  (k0, v0) hold the input; the passes alternate between the two buffer
 // pairs; inFirst tells where the result is.  Asynchronous on s except for the allocations.
 // passMs (may be NULL): HIP-event time of the pass launches alone, summed.
