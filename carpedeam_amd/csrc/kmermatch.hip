@@ -803,7 +803,15 @@ __global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs
 }
 
 // tiles of the vote kernels: 4096 keys (256 threads x 16 consecutive items)
-constexpr int CP_ITEMS = 16, CP_TILE = 256 * CP_ITEMS;
+// (2048 keys: the place kernel runs on blocks in flight - 35 KB of LDS per block gave 4 per CU and 19 ms)
+#ifndef CDM_CP_ITEMS
+#define CDM_CP_ITEMS 8
+#endif
+constexpr int CP_ITEMS = CDM_CP_ITEMS, CP_TILE = 256 * CP_ITEMS;
+static_assert(CP_ITEMS == 8 || CP_ITEMS == 16, "vote tile: the start bits of a thread are one byte or one 16-bit word");
+template <int N> struct BitsOf { typedef uint16_t T; };
+template <> struct BitsOf<8> { typedef uint8_t T; };
+typedef BitsOf<CP_ITEMS>::T CpBits;
 // LDS index with one pad slot per 16 items: thread t walks items 16t..16t+15 without bank conflicts
 __device__ __forceinline__ int padIdx(int i) { return i + (i >> 4); }
 constexpr int CP_LDS = CP_TILE + CP_TILE / 16 + 1;
@@ -906,12 +914,12 @@ __global__ __launch_bounds__(256) void k_seg_place(VoteArgs a, const unsigned lo
                                                    const uint64_t *__restrict__ off, HitRec *__restrict__ out) {
     __shared__ uint64_t sKeys[CP_LDS];
     __shared__ uint64_t sPrev;
-    __shared__ __align__(8) uint16_t sFirst[CP_TILE / 16 + 4];       // "starts a (rep, target) segment" bits, 16 per thread = one bit array
+    __shared__ __align__(8) CpBits sFirst[256 + 32 / sizeof(CpBits)];       // "starts a (rep, target) segment" bits, CP_ITEMS per thread = one bit array
     const uint64_t base = (uint64_t) blockIdx.x * CP_TILE;
 #pragma unroll
     for (int j = 0; j < CP_ITEMS; j++) { const int li = threadIdx.x + 256 * j; const uint64_t i = base + li; sKeys[padIdx(li)] = (i < a.n) ? a.keys[i] : ~0ull; }
     if (threadIdx.x == 0) sPrev = base ? a.keys[base - 1] : ~0ull;
-    if (threadIdx.x < 4) sFirst[CP_TILE / 16 + threadIdx.x] = 0;
+    if (threadIdx.x < 32 / sizeof(CpBits)) sFirst[256 + threadIdx.x] = 0;
     __syncthreads();
     const int shift = a.diagBits + 1;
     const uint64_t idMask = (1ull << a.idBits) - 1, diagMask = (1ull << a.diagBits) - 1;
@@ -927,7 +935,7 @@ __global__ __launch_bounds__(256) void k_seg_place(VoteArgs a, const unsigned lo
         if (first) firstBits |= 1u << j;
         if (first && (uint32_t) (seg & idMask) != (uint32_t) (seg >> a.idBits)) { c++; mask |= 1u << j; }
     }
-    sFirst[threadIdx.x] = (uint16_t) firstBits;
+    sFirst[threadIdx.x] = (CpBits) firstBits;
     unsigned int pre, totC;
     pre = cdm_block_excl_sum<unsigned int>(c, totC);       // (its barriers also publish sFirst)
     unsigned long long rank = tileOff[blockIdx.x] + pre;   // number of hit-producing segments before this one, whole array
@@ -1537,7 +1545,7 @@ int vote(const uint32_t *contDev, bool ownBuffers, cdm_hits **out) {
     res->count = total;
     if (cdmMalloc(&res->rec, (total + 1) * sizeof(HitRec)) != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipLaunchKernelGGL(k_self, dim3((n + 255) / 256), dim3(256), 0, s, res->off, n, res->rec);
-    if (nGroup) hipLaunchKernelGGL(k_seg_place, dim3((unsigned) vTiles), dim3(256), 0, s, va, vTileOff.p, perRepScan.p, res->off, res->rec);
+    if (nGroup) hipLaunchKernelGGL(k_seg_place, dim3((unsigned) vTiles), dim3(256), cdm_lds_pad("CDM_LDS_PAD_VOTE"), s, va, vTileOff.p, perRepScan.p, res->off, res->rec);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: placing hits failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     float msSort2 = 0; hipEventElapsedTime(&msSort2, ctx->ev0, ctx->ev1);
     ctx->lastMs[2] = msSort1 + msSort2;
