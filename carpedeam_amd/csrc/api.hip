@@ -25,7 +25,10 @@ struct Pool {
     std::multimap<size_t, void *> freeBlocks;
     std::unordered_map<void *, size_t> sizes;
 };
-Pool &poolOf(int dev) { static Pool pools[64]; return pools[dev & 63]; }
+// One cache per host thread and device: a context belongs to one host thread, and a block freed by one thread's
+// stream must not be handed to another thread's stream without synchronisation (ranks as threads of one process in the tests).  A
+// block freed by another thread than its allocator's is simply released.
+Pool &poolOf(int dev) { static thread_local Pool pools[64]; return pools[dev & 63]; }
 }  // namespace
 hipError_t cdmMallocRaw(void **p, size_t bytes) {
     int dev = 0; hipGetDevice(&dev);

@@ -23,7 +23,14 @@
 
 namespace runsort {
 
-constexpr int RUN_ITEMS = 16, RUN_NT = 256, RUN_TILE = RUN_NT * RUN_ITEMS;      // 4096 tuples per tile
+#ifndef CDM_RUN_ITEMS
+#define CDM_RUN_ITEMS 16
+#endif
+constexpr int RUN_ITEMS = CDM_RUN_ITEMS, RUN_NT = 256, RUN_TILE = RUN_NT * RUN_ITEMS;      // 4096 tuples per tile (2048 is slower: 124 instead of 117 ms for sort 2)
+static_assert(RUN_ITEMS == 8 || RUN_ITEMS == 16, "the boundary bits of a thread are one byte or one 16-bit word");
+template <int N> struct RunBitsOf { typedef uint16_t T; };
+template <> struct RunBitsOf<8> { typedef uint8_t T; };
+typedef RunBitsOf<RUN_ITEMS>::T RunBits;
 constexpr int RUN_CNT_BITS = 13;                                                 // a record's length <= RUN_TILE
 
 struct RunArgs {
@@ -68,12 +75,12 @@ __global__ __launch_bounds__(RUN_NT) void k_run_count(RunArgs a, unsigned long l
 // record j: recRep[j] = representative, recVal[j] = start << 13 | length
 __global__ __launch_bounds__(RUN_NT) void k_run_write(RunArgs a, const unsigned long long *__restrict__ tileOff, uint32_t *__restrict__ recRep, uint64_t *__restrict__ recVal) {
     __shared__ uint64_t sKeys[RUN_LDS];
-    __shared__ __align__(8) uint16_t sBound[RUN_TILE / 16 + 4];
+    __shared__ __align__(8) RunBits sBound[RUN_NT + 32 / sizeof(RunBits)];
     const uint64_t base = (uint64_t) blockIdx.x * RUN_TILE;
     unsigned int sb, bb;
     runFlags(a, base, sKeys, sb, bb);
-    sBound[threadIdx.x] = (uint16_t) bb;
-    if (threadIdx.x < 4) sBound[RUN_TILE / 16 + threadIdx.x] = 0;
+    sBound[threadIdx.x] = (RunBits) bb;
+    if (threadIdx.x < 32 / sizeof(RunBits)) sBound[RUN_NT + threadIdx.x] = 0;
     unsigned int tot;
     unsigned long long rank = tileOff[blockIdx.x] + cdm_block_excl_sum<unsigned int>((unsigned int) __popc(sb), tot);     // (its barriers publish sBound)
     const unsigned long long *words = reinterpret_cast<const unsigned long long *>(sBound);
@@ -102,7 +109,7 @@ constexpr unsigned long long RS_AGG = 1ull << 62, RS_PREFIX = 2ull << 62, RS_MAS
 struct RunScan { unsigned long long *status; unsigned int *ticket; unsigned long long *total; unsigned int *overflow; unsigned long long cap; unsigned long long tiles; };
 __global__ __launch_bounds__(RUN_NT) void k_run_records(RunArgs a, RunScan sc, uint32_t *__restrict__ recRep, uint64_t *__restrict__ recVal) {
     __shared__ uint64_t sKeys[RUN_LDS];
-    __shared__ __align__(8) uint16_t sBound[RUN_TILE / 16 + 4];
+    __shared__ __align__(8) RunBits sBound[RUN_NT + 32 / sizeof(RunBits)];
     __shared__ unsigned int sTile;
     __shared__ unsigned long long sPrefix;
     if (threadIdx.x == 0) sTile = atomicAdd(sc.ticket, 1u);
@@ -111,8 +118,8 @@ __global__ __launch_bounds__(RUN_NT) void k_run_records(RunArgs a, RunScan sc, u
     const uint64_t base = (uint64_t) tile * RUN_TILE;
     unsigned int sb, bb;
     runFlags(a, base, sKeys, sb, bb);
-    sBound[threadIdx.x] = (uint16_t) bb;
-    if (threadIdx.x < 4) sBound[RUN_TILE / 16 + threadIdx.x] = 0;
+    sBound[threadIdx.x] = (RunBits) bb;
+    if (threadIdx.x < 32 / sizeof(RunBits)) sBound[RUN_NT + threadIdx.x] = 0;
     unsigned int tot;
     const unsigned int ex = cdm_block_excl_sum<unsigned int>((unsigned int) __popc(sb), tot);        // (its barriers publish sBound)
     if (threadIdx.x < 64) {
