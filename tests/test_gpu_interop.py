@@ -46,12 +46,13 @@ def test_reference_modules_read_gpu_written_dbs(tmp_path, dhigh_prefix, name, it
     run(GPU, "ancient_read_assemble", t("corr_g"), t("aln_g"), t("asm_g"), *A_FLAGS, *dmg)
     assert not diff_keys(mmdb.read_db(t("asm_r")), mmdb.read_db(t("asm_g")))
     # the extended sequence DB (wasExtended flags in the index) written by the MI355X module -> the reference's kmermatcher
-    # (the reference single-threaded: its parallel sort leaves the order of equal tuples - and with it the strand sign of a hit whose
-    # best diagonal carries both strands - run-dependent, DESIGN.md N1 and "Comparator ties")
+    # (a LIVE run of the reference: ips4o seeds its sampling from std::random_device, so the order of equal tuples - and with it the
+    # strand sign of the hits of the ONE k-mer group N1 is about, all in the list of that group's representative - changes from run
+    # to run even with one thread)
     run(REF, "kmermatcher", t("asm_g"), t("pref2_r"), *K_FLAGS, "--threads", "1")
     run(GPU, "kmermatcher", t("asm_g"), t("pref2_g"), *K_FLAGS, "--threads", "4")
     ties, bad = pref_sign_ties(mmdb.canon(mmdb.read_db(t("pref2_g"))), mmdb.canon(mmdb.read_db(t("pref2_r"))))
-    assert not bad and sum(n for _, n in ties) <= 1          # (the reference's own run-dependent strand tie)
+    assert not bad and len(ties) <= 1                       # sign-only differences, confined to one query's list
 
 
 def test_dispatcher_script_runs_one_reads_loop_iteration(tmp_path, dhigh_prefix):
