@@ -43,30 +43,33 @@ struct RunArgs {
 __device__ __forceinline__ int runPad(int i) { return i + (i >> 4); }
 constexpr int RUN_LDS = RUN_TILE + RUN_TILE / 16 + 1;
 
-// loads the tile into LDS (coalesced) and returns, for the 16 items of this thread, the bit masks "starts a record" and
+// loads the tile's representatives into LDS (coalesced; 0xFFFFFFFF = no kept tuple in the slot - 32 bits per slot instead of the key:
+// half the LDS, twice the tiles in flight) and returns, for the 16 items of this thread, the bit masks "starts a record" and
 // "ends the record in front of it" (= starts one, or is not kept)
-__device__ __forceinline__ void runFlags(const RunArgs &a, uint64_t base, uint64_t *sKeys, unsigned int &startBits, unsigned int &boundBits) {
+constexpr uint32_t RUN_NONE = 0xFFFFFFFFu;
+__device__ __forceinline__ void runFlags(const RunArgs &a, uint64_t base, uint32_t *sRep, unsigned int &startBits, unsigned int &boundBits) {
     const bool skip = base >= a.skipLo && base + RUN_TILE <= a.skipHi;      // block-uniform
 #pragma unroll
     for (int j = 0; j < RUN_ITEMS; j++) {
         const int li = threadIdx.x + RUN_NT * j; const uint64_t i = base + (uint64_t) li;
-        sKeys[runPad(li)] = (!skip && i < a.n && !(i >= a.skipLo && i < a.skipHi)) ? a.keys[i] : ~0ull;
+        const uint64_t k = (!skip && i < a.n && !(i >= a.skipLo && i < a.skipHi)) ? a.keys[i] : ~0ull;
+        sRep[runPad(li)] = k != ~0ull ? (uint32_t) (k >> a.repShift) : RUN_NONE;
     }
     __syncthreads();
     startBits = 0; boundBits = 0;
-    uint64_t prev = (threadIdx.x == 0) ? ~0ull : sKeys[runPad(threadIdx.x * RUN_ITEMS - 1)];     // a record never crosses a tile
+    uint32_t prev = (threadIdx.x == 0) ? RUN_NONE : sRep[runPad(threadIdx.x * RUN_ITEMS - 1)];     // a record never crosses a tile
 #pragma unroll
     for (int j = 0; j < RUN_ITEMS; j++) {
-        const uint64_t k = sKeys[runPad(threadIdx.x * RUN_ITEMS + j)];
-        const bool kept = k != ~0ull;
-        const bool start = kept && (prev == ~0ull || (prev >> a.repShift) != (k >> a.repShift));
+        const uint32_t r = sRep[runPad(threadIdx.x * RUN_ITEMS + j)];
+        const bool kept = r != RUN_NONE;
+        const bool start = kept && r != prev;
         if (start) startBits |= 1u << j;
         if (start || !kept) boundBits |= 1u << j;
-        prev = k;
+        prev = r;
     }
 }
 __global__ __launch_bounds__(RUN_NT) void k_run_count(RunArgs a, unsigned long long *__restrict__ tileCnt) {
-    __shared__ uint64_t sKeys[RUN_LDS];
+    __shared__ uint32_t sKeys[RUN_LDS];
     unsigned int sb, bb;
     runFlags(a, (uint64_t) blockIdx.x * RUN_TILE, sKeys, sb, bb);
     const unsigned int tot = cdm_block_sum<unsigned int>((unsigned int) __popc(sb));
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(RUN_NT) void k_run_count(RunArgs a, unsigned long l
 }
 // record j: recRep[j] = representative, recVal[j] = start << 13 | length
 __global__ __launch_bounds__(RUN_NT) void k_run_write(RunArgs a, const unsigned long long *__restrict__ tileOff, uint32_t *__restrict__ recRep, uint64_t *__restrict__ recVal) {
-    __shared__ uint64_t sKeys[RUN_LDS];
+    __shared__ uint32_t sKeys[RUN_LDS];
     __shared__ __align__(8) RunBits sBound[RUN_NT + 32 / sizeof(RunBits)];
     const uint64_t base = (uint64_t) blockIdx.x * RUN_TILE;
     unsigned int sb, bb;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(RUN_NT) void k_run_write(RunArgs a, const unsigned 
             if (w == ((li + 1) >> 6)) m &= ~0ull << ((li + 1) & 63);
             if (m) { e = w * 64 + __ffsll(m) - 1; break; }
         }
-        recRep[rank] = (uint32_t) (sKeys[runPad(li)] >> a.repShift);
+        recRep[rank] = sKeys[runPad(li)];
         recVal[rank] = ((base + (uint64_t) li) << RUN_CNT_BITS) | (uint64_t) (e - li);
         rank++;
     }
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(RUN_NT) void k_run_write(RunArgs a, const unsigned 
 constexpr unsigned long long RS_AGG = 1ull << 62, RS_PREFIX = 2ull << 62, RS_MASK = (1ull << 62) - 1ull;
 struct RunScan { unsigned long long *status; unsigned int *ticket; unsigned long long *total; unsigned int *overflow; unsigned long long cap; unsigned long long tiles; };
 __global__ __launch_bounds__(RUN_NT) void k_run_records(RunArgs a, RunScan sc, uint32_t *__restrict__ recRep, uint64_t *__restrict__ recVal) {
-    __shared__ uint64_t sKeys[RUN_LDS];
+    __shared__ uint32_t sKeys[RUN_LDS];
     __shared__ __align__(8) RunBits sBound[RUN_NT + 32 / sizeof(RunBits)];
     __shared__ unsigned int sTile;
     __shared__ unsigned long long sPrefix;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(RUN_NT) void k_run_records(RunArgs a, RunScan sc, u
             if (w == ((li + 1) >> 6)) m &= ~0ull << ((li + 1) & 63);
             if (m) { e = w * 64 + __ffsll(m) - 1; break; }
         }
-        recRep[rank] = (uint32_t) (sKeys[runPad(li)] >> a.repShift);
+        recRep[rank] = sKeys[runPad(li)];
         recVal[rank] = ((base + (uint64_t) li) << RUN_CNT_BITS) | (uint64_t) (e - li);
         rank++;
     }
