@@ -347,19 +347,27 @@ struct UnitArgs {
 };
 // start (gathered coordinates) of record j, the end of everything if there is none
 __device__ __forceinline__ unsigned long long j0Next(const unsigned long long *__restrict__ dst, uint64_t nRec, uint64_t j) { return dst[min(j, nRec)]; }
+#ifndef CDM_U_MINW
+#define CDM_U_MINW 6
+#endif
+// (waves per SIMD the register allocation leaves room for: without the bound the kernel takes 118 VGPRs - 4 blocks per CU - although
+// its LDS would let 7 run)
 template <int CAP, int U_NT>
-__global__ __launch_bounds__(U_NT) void k_unit_sort(UnitArgs a) {
+__global__ __launch_bounds__(U_NT, CDM_U_MINW) void k_unit_sort(UnitArgs a) {
     constexpr int ROUNDS = (CAP + U_NT - 1) / U_NT, U_WAVES = U_NT / 64;
     static_assert(U_NB <= U_NT && U_NB % U_WAVES == 0 && CAP % U_NT == 0, "unit sorter geometry");
     __shared__ uint64_t sKeys[CAP];             // the unit; rewritten with the ordinal in place of the representative
-    __shared__ uint16_t sPerm[CAP];
+    // the record table of the staging phase (sGOff, sGStart) and the permutation of the sort phase share their LDS: barriers separate the two
+    constexpr int SHARE_BYTES = (CAP * 2 > U_NT * 12) ? CAP * 2 : U_NT * 12;
+    __shared__ __align__(8) unsigned char sShare[SHARE_BYTES];
+    uint16_t *sPerm = reinterpret_cast<uint16_t *>(sShare);
+    uint64_t *sGStart = reinterpret_cast<uint64_t *>(sShare);
+    uint32_t *sGOff = reinterpret_cast<uint32_t *>(sShare + U_NT * 8);
     __shared__ unsigned long long sBits[ROUNDS * U_NT / 64];
     __shared__ unsigned int sPre[ROUNDS * U_NT / 64];
     __shared__ unsigned int sCnt[U_NB];
     __shared__ unsigned int sOff[U_NB + 1];
     __shared__ uint32_t sRep[U_T + 2];          // representative of the unit's segments by ordinal
-    __shared__ uint32_t sGOff[U_NT];
-    __shared__ uint64_t sGStart[U_NT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned int nUnits = *a.count;
     for (unsigned int item = blockIdx.x; item < nUnits; item += gridDim.x) {
