@@ -348,10 +348,10 @@ struct UnitArgs {
 // start (gathered coordinates) of record j, the end of everything if there is none
 __device__ __forceinline__ unsigned long long j0Next(const unsigned long long *__restrict__ dst, uint64_t nRec, uint64_t j) { return dst[min(j, nRec)]; }
 #ifndef CDM_U_MINW
-#define CDM_U_MINW 6
+#define CDM_U_MINW 5
 #endif
 // (waves per SIMD the register allocation leaves room for: without the bound the kernel takes 118 VGPRs - 4 blocks per CU - although
-// its LDS would let 7 run)
+// its LDS would let 7 run; measured for sort 2: 5 -> 102 ms, 6 -> 105, 7 -> 106, 8 -> 111, unbounded 113)
 template <int CAP, int U_NT>
 __global__ __launch_bounds__(U_NT, CDM_U_MINW) void k_unit_sort(UnitArgs a) {
     constexpr int ROUNDS = (CAP + U_NT - 1) / U_NT, U_WAVES = U_NT / 64;
