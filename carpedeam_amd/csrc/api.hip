@@ -138,7 +138,7 @@ int cdm_seqdb_alloc(cdm_ctx *ctx, uint64_t n, cdm_seqdb **out) {
     db->n = n; db->device = ctx->device;
     if (cdmMalloc(&db->woff, (n + 1) * sizeof(uint32_t)) != hipSuccess || cdmMalloc(&db->len, (n + 1) * sizeof(uint32_t)) != hipSuccess ||
         cdmMalloc(&db->key, (n + 1) * sizeof(uint32_t)) != hipSuccess || cdmMalloc(&db->ext, n + 1) != hipSuccess ||
-        cdmMalloc(&db->hasN, n + 1) != hipSuccess) {
+        cdmMalloc(&db->hasN, n + 8) != hipSuccess) {
         cdm_set_error("out of device memory allocating a %llu-entry sequence DB", (unsigned long long) n);
         cdm_seqdb_free(db); return CDM_ERR_HIP;
     }
@@ -153,12 +153,18 @@ static int seqdb_alloc_codes(cdm_seqdb *db, uint64_t words) {
     }
     return CDM_OK;
 }
+int cdm_seqdb_alloc_raw(cdm_seqdb *db) {
+    if (db->raw) return CDM_OK;
+    if (cdmMalloc(&db->raw, db->words * 16 + 16) != hipSuccess) { cdm_set_error("out of device memory allocating the original letters of %llu code words", (unsigned long long) db->words); return CDM_ERR_HIP; }
+    return CDM_OK;
+}
 int cdm_seqdb_alloc_like(cdm_ctx *ctx, const cdm_seqdb *src, cdm_seqdb **out) {
     cdm_seqdb *db = nullptr;
     int rc = cdm_seqdb_alloc(ctx, src->n, &db);
     if (rc) return rc;
     db->residues = src->residues; db->maxLen = src->maxLen; db->nCount = src->nCount;
     rc = seqdb_alloc_codes(db, src->words);
+    if (!rc && src->raw) rc = cdm_seqdb_alloc_raw(db);
     if (rc) { cdm_seqdb_free(db); return rc; }
     hipStream_t s = ctx->stream;
     CDM_HIP(hipMemcpyAsync(db->woff, src->woff, (src->n + 1) * 4, hipMemcpyDeviceToDevice, s));
@@ -172,14 +178,14 @@ int cdm_seqdb_alloc_like(cdm_ctx *ctx, const cdm_seqdb *src, cdm_seqdb **out) {
 extern "C" void cdm_seqdb_free(cdm_seqdb *db) {
     if (!db) return;
     hipSetDevice(db->device);
-    cdmFree(db->woff); cdmFree(db->len); cdmFree(db->key); cdmFree(db->ext); cdmFree(db->hasN); cdmFree(db->codes); cdmFree(db->nmask);
+    cdmFree(db->woff); cdmFree(db->len); cdmFree(db->key); cdmFree(db->ext); cdmFree(db->hasN); cdmFree(db->codes); cdmFree(db->nmask); cdmFree(db->raw);
     delete db;
 }
 __global__ void k_build_meta(const uint32_t *__restrict__ woff, const uint32_t *__restrict__ len, const uint8_t *__restrict__ hasN, const uint8_t *__restrict__ ext,
                              const uint32_t *__restrict__ key, uint32_t n, SeqMeta *__restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SeqMeta m; m.woff = woff[i]; m.len = len[i]; m.flags = (hasN[i] ? 1u : 0u) | (ext[i] ? 2u : 0u); m.key = key[i];
+    SeqMeta m; m.woff = woff[i]; m.len = len[i]; m.flags = (hasN[i] ? 1u : 0u) | (ext[i] ? 2u : 0u) | ((hasN[i] & 2u) ? 4u : 0u); m.key = key[i];
     out[i] = m;
 }
 int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out) {
@@ -208,14 +214,23 @@ __global__ void k_pack(const char *__restrict__ data, const uint64_t *__restrict
     const uint32_t L = len[i];
     const char *s = data + off[i] + (uint64_t) w * 16;
     const uint32_t cnt = min(16u, L - min(L, w * 16u));
-    uint32_t code = 0, nb = 0, bad = 0;
+    uint32_t code = 0, nb = 0, other = 0;
     for (uint32_t j = 0; j < cnt; j++) {
-        char c = s[j];
+        const char c = s[j];
         uint32_t v = 0;
         switch (c) {
             case 'A': v = 0; break; case 'C': v = 1; break; case 'G': v = 2; break; case 'T': v = 3; break;
             case 'N': nb |= 1u << j; break;
-            default: bad++; nb |= 1u << j; break;
+            default:            // NucleotideMatrix::setupLetterMapping (M/commons/NucleotideMatrix.cpp:17-61): toupper, IUPAC codes to one base, the rest to X
+                other++;
+                switch (c & ~0x20) {    // (the letters below have no non-letter twin under the case bit)
+                    case 'A': v = 0; break; case 'C': case 'M': case 'Y': case 'H': v = 1; break;
+                    case 'G': case 'K': case 'B': case 'D': case 'V': case 'R': case 'S': v = 2; break;
+                    case 'T': case 'U': case 'W': v = 3; break;
+                    default: nb |= 1u << j; break;
+                }
+                if (!((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'))) { v = 0; nb |= 1u << j; }
+                break;
         }
         code |= v << (2 * j);
     }
@@ -223,8 +238,24 @@ __global__ void k_pack(const char *__restrict__ data, const uint64_t *__restrict
     // two sequence words share one mask word; sequences start on code-word (16 bit) boundaries of the mask
     uint16_t *m16 = reinterpret_cast<uint16_t *>(nmask);
     m16[gw] = (uint16_t) nb;
-    if (nb) { hasN[i] = 1; atomicAdd(&counters[0], (unsigned long long) __popc(nb)); }
-    if (bad) atomicAdd(&counters[1], (unsigned long long) bad);
+    if (nb) atomicAdd(&counters[0], (unsigned long long) __popc(nb));
+    if (nb || other) atomicOr(reinterpret_cast<unsigned int *>(hasN + (i & ~3ull)), (1u | (other ? 2u : 0u)) << (8 * (i & 3u)));
+    if (other) atomicAdd(&counters[1], (unsigned long long) other);
+}
+// the original bytes of the sequences that carry letters beyond ACGTN, one thread per (sequence, word)
+__global__ void k_pack_raw(const char *__restrict__ data, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+                           const uint32_t *__restrict__ woff, uint64_t n, uint64_t words, const uint8_t *__restrict__ hasN, uint8_t *__restrict__ raw) {
+    uint64_t gw = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (gw >= words) return;
+    uint64_t lo = 0, hi = n;
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (woff[mid] <= gw) lo = mid; else hi = mid; }
+    const uint64_t i = lo;
+    if (!(hasN[i] & 2u)) return;
+    const uint32_t w = (uint32_t) (gw - woff[i]);
+    const uint32_t L = len[i];
+    const char *s = data + off[i] + (uint64_t) w * 16;
+    const uint32_t cnt = min(16u, L - min(L, w * 16u));
+    for (uint32_t j = 0; j < cnt; j++) raw[gw * 16 + j] = (uint8_t) s[j];
 }
 
 extern "C" int cdm_seqdb_upload(cdm_ctx *ctx, const char *data, const uint64_t *offsets, const uint32_t *lengths, const uint32_t *keys,
@@ -277,9 +308,11 @@ extern "C" int cdm_seqdb_upload(cdm_ctx *ctx, const char *data, const uint64_t *
         hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess) { cdm_set_error("sequence upload/packing failed: %s", hipGetErrorString(e)); ret = CDM_ERR_HIP; break; }
         db->nCount = cnt[0];
-        if (cnt[1]) {
-            cdm_set_error("sequence DB contains %llu letters other than A,C,G,T,N (lower case / IUPAC codes): not supported by the device path yet", cnt[1]);
-            ret = CDM_ERR_UNSUPPORTED; break;
+        if (cnt[1]) {       // lower case / IUPAC codes / other bytes: those sequences keep their original letters beside the mapped codes
+            if ((ret = cdm_seqdb_alloc_raw(db)) != CDM_OK) break;
+            hipLaunchKernelGGL(k_pack_raw, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, s, dData, dOff, db->len, db->woff, n, words, db->hasN, db->raw);
+            e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { cdm_set_error("sequence upload/packing failed: %s", hipGetErrorString(e)); ret = CDM_ERR_HIP; break; }
         }
     } while (0);
     cdmFree(dData); cdmFree(dOff); cdmFree(dCnt);
@@ -299,7 +332,8 @@ extern "C" int cdm_seqdb_meta(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t *lengt
 
 // one thread per (sequence, word): 16 letters + the trailing '\n' after the last base
 __global__ void k_unpack(const uint32_t *__restrict__ codes, const uint32_t *__restrict__ nmask, const uint32_t *__restrict__ woff,
-                         const uint32_t *__restrict__ len, const uint64_t *__restrict__ outOff, uint64_t n, uint64_t words, char *__restrict__ out) {
+                         const uint32_t *__restrict__ len, const uint64_t *__restrict__ outOff, uint64_t n, uint64_t words, char *__restrict__ out,
+                         const uint8_t *__restrict__ hasN, const uint8_t *__restrict__ raw) {
     uint64_t gw = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (gw >= words) return;
     uint64_t lo = 0, hi = n;
@@ -311,7 +345,8 @@ __global__ void k_unpack(const uint32_t *__restrict__ codes, const uint32_t *__r
     const uint32_t code = codes[gw];
     const uint32_t nb = reinterpret_cast<const uint16_t *>(nmask)[gw];
     char *o = out + outOff[i] + (uint64_t) w * 16;
-    for (uint32_t j = 0; j < cnt; j++) o[j] = ((nb >> j) & 1u) ? 'N' : "ACGT"[(code >> (2 * j)) & 3u];
+    if (raw && (hasN[i] & 2u)) for (uint32_t j = 0; j < cnt; j++) o[j] = (char) raw[gw * 16 + j];
+    else for (uint32_t j = 0; j < cnt; j++) o[j] = ((nb >> j) & 1u) ? 'N' : "ACGT"[(code >> (2 * j)) & 3u];
     if (w * 16u + cnt == L) o[cnt] = '\n';
 }
 extern "C" int cdm_seqdb_download(cdm_ctx *ctx, const cdm_seqdb *db, char *out, const uint64_t *outOffsets) {
@@ -325,7 +360,7 @@ extern "C" int cdm_seqdb_download(cdm_ctx *ctx, const cdm_seqdb *db, char *out, 
     hipMemsetAsync(dOut, 0, total, ctx->stream);
     hipMemcpyAsync(dOff, outOffsets, db->n * 8, hipMemcpyHostToDevice, ctx->stream);
     // zero-length sequences own no word: their '\n' is written by the host below
-    if (db->words) hipLaunchKernelGGL(k_unpack, dim3((unsigned) ((db->words + 255) / 256)), dim3(256), 0, ctx->stream, db->codes, db->nmask, db->woff, db->len, dOff, db->n, db->words, dOut);
+    if (db->words) hipLaunchKernelGGL(k_unpack, dim3((unsigned) ((db->words + 255) / 256)), dim3(256), 0, ctx->stream, db->codes, db->nmask, db->woff, db->len, dOff, db->n, db->words, dOut, db->hasN, db->raw);
     hipMemcpyAsync(out, dOut, total, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     cdmFree(dOut); cdmFree(dOff);
@@ -354,7 +389,7 @@ __global__ void k_sel_meta(const cdm_seqdb src, const uint32_t *__restrict__ sel
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || sel[i] == 0xFFFFFFFFu) return;
     const uint32_t r = rank[i];
-    dst.len[r] = sel[i]; dst.key[r] = src.key[i]; dst.ext[r] = extValue < 0 ? src.ext[i] : (uint8_t) extValue; dst.hasN[r] = 0; dst.woff[r] = wordOff[i];
+    dst.len[r] = sel[i]; dst.key[r] = src.key[i]; dst.ext[r] = extValue < 0 ? src.ext[i] : (uint8_t) extValue; dst.hasN[r] = (src.hasN[i] & 2u) ? 3 : 0; dst.woff[r] = wordOff[i];
 }
 __global__ void k_sel_copy(const cdm_seqdb src, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ wordOff, uint32_t n, cdm_seqdb dst) {
     // one wave per selected sequence; the kept prefix ends inside its last word: the letters behind it are cleared
@@ -367,6 +402,7 @@ __global__ void k_sel_copy(const cdm_seqdb src, const uint32_t *__restrict__ sel
         dst.codes[d0 + j] = c;
         reinterpret_cast<uint16_t *>(dst.nmask)[d0 + j] = (uint16_t) m;
     }
+    if (src.hasN[i] & 2u) for (uint32_t j = lane; j < L; j += 64) dst.raw[(uint64_t) d0 * 16 + j] = src.raw[(uint64_t) s0 * 16 + j];
 }
 __global__ void k_words_of(const uint32_t *__restrict__ len, uint32_t n, uint32_t *__restrict__ w, uint8_t *__restrict__ ext, uint8_t extValue, uint8_t *__restrict__ hasN) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -379,7 +415,7 @@ __global__ void k_mark_hasN(const uint32_t *__restrict__ woff, const uint32_t *_
     if (gw >= words || reinterpret_cast<const uint16_t *>(nmask)[gw] == 0) return;
     uint64_t lo = 0, hi = n;
     while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (woff[mid] <= gw) lo = mid; else hi = mid; }
-    hasN[lo] = 1;
+    if (!hasN[lo]) hasN[lo] = 1;      // (a sequence that brought its raw row along keeps its 3)
 }
 }  // namespace
 extern "C" uint64_t cdm_seqdb_words(const cdm_seqdb *db) { return db->words; }
@@ -401,6 +437,7 @@ int cdm_seqdb_select(cdm_ctx *ctx, const cdm_seqdb *db, const uint32_t *sel, int
     cdm_seqdb *o = nullptr;
     int rc = cdm_seqdb_alloc(ctx, m, &o);
     if (rc == CDM_OK) rc = seqdb_alloc_codes(o, words);
+    if (rc == CDM_OK && db->raw) rc = cdm_seqdb_alloc_raw(o);
     if (rc != CDM_OK) { if (o) cdm_seqdb_free(o); return rc; }
     hipMemsetAsync(o->nmask, 0, (((uint64_t) words * 16 + 31) / 32 + 1) * 4, s);
     if (n) hipLaunchKernelGGL(k_sel_meta, dim3((n + 255) / 256), dim3(256), 0, s, *db, sel, rank.p, wordOff.p, n, extValue, *o);
@@ -425,6 +462,7 @@ extern "C" int cdm_seqdb_select_ext(cdm_ctx *ctx, const cdm_seqdb *db, cdm_seqdb
     return cdm_seqdb_select(ctx, db, sel.p, 1, out);
 }
 extern "C" int cdm_seqdb_copy_packed(cdm_ctx *ctx, const cdm_seqdb *db, void *codes, void *nmask16, void *lengths, void *keys) {
+    if (db->raw && codes) { cdm_set_error("cdm_seqdb_copy_packed: the DB carries letters beyond ACGTN; the packed exchange format has no room for them"); return CDM_ERR_UNSUPPORTED; }
     CDM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     if (codes) CDM_HIP(hipMemcpyAsync(codes, db->codes, db->words * 4, hipMemcpyDeviceToDevice, s));

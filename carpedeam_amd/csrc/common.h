@@ -80,6 +80,12 @@ struct cdm_ctx {
 // Sequence DB in HBM.  Base codes A,C,G,T = 0..3 (CarpeDeam's own order, src/assembler/correction.cpp:170-174),
 // 16 bases per 32-bit word, little end first; every sequence starts on a word boundary.  'N' (any X-class letter)
 // is stored as code 0 plus a bit in nmask (bit index = 16 * woff[i] + pos).
+// Letters beyond upper-case ACGTN (lower case, IUPAC codes, anything else a DB may carry): codes/nmask hold what
+// NucleotideMatrix::setupLetterMapping (M/commons/NucleotideMatrix.cpp:17-61) maps the letter to - the view of kmermatcher, of the
+// diagonal score and of every reverse complement (getNuclRevFragment, nuclassembleUtil.cpp:67-76) - and the sequence gets a row of
+// the `raw` plane with its original bytes (index 16 * woff[i] + pos), which is what the forward-strand consumers look at
+// (nucleotideMap[c] = 0 for everything but C,G,T; == 'N' tests; letter identity; letters copied to the output).  hasN[i] bit 0 =
+// "not plain upper-case ACGT throughout" (all word-wise fast paths test it), bit 1 = the raw row is valid.
 struct cdm_seqdb {
     uint64_t n = 0;
     uint64_t words = 0;     // total code words
@@ -90,9 +96,10 @@ struct cdm_seqdb {
     uint32_t *len = nullptr;    // [n]
     uint32_t *key = nullptr;    // [n]
     uint8_t *ext = nullptr;     // [n] wasExtended flag
-    uint8_t *hasN = nullptr;    // [n] sequence contains an N
+    uint8_t *hasN = nullptr;    // [n] bit 0: sequence contains an N or any other letter beyond ACGT; bit 1: it has a row in raw
     uint32_t *codes = nullptr;  // [words]
     uint32_t *nmask = nullptr;  // [(words*16+31)/32]
+    uint8_t *raw = nullptr;     // [words*16] original bytes of the sequences with hasN bit 1, or NULL (no such sequence in the DB)
     int device = 0;
     uint64_t serial = 0;    // unique per handle (cdm_seqdb_alloc)
 };
@@ -100,12 +107,13 @@ struct cdm_seqdb {
 // Per-sequence metadata gathered by target id in rescore / correction / extension: one 16-byte record instead of four arrays
 // (a random target then costs one cache line, not four).  Built per call from the cdm_seqdb arrays (cdm_build_meta, api.hip);
 // the proxies keep the kernels' `a.len[t]` spelling.
-struct SeqMeta { uint32_t woff, len, flags, key; };      // flags: 1 = has N, 2 = wasExtended
+struct SeqMeta { uint32_t woff, len, flags, key; };      // flags: 1 = has N (not plain ACGT), 2 = wasExtended, 4 = has a raw row
 struct MetaWoff { const SeqMeta *m; __host__ __device__ uint32_t operator[](uint32_t i) const { return m[i].woff; } };
 struct MetaLen { const SeqMeta *m; __host__ __device__ uint32_t operator[](uint32_t i) const { return m[i].len; } };
 struct MetaHasN { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) (m[i].flags & 1u); } };
 struct MetaKey { const SeqMeta *m; __host__ __device__ uint32_t operator[](uint32_t i) const { return m[i].key; } };
 struct MetaExt { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) ((m[i].flags >> 1) & 1u); } };
+struct MetaRaw { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) ((m[i].flags >> 2) & 1u); } };
 int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out);      // cdmFree the result
 
 struct HitRec { uint32_t target; int32_t score; int32_t diagonal; };  // == cdm_hit
@@ -127,6 +135,7 @@ struct cdm_alns {
 
 int cdm_seqdb_alloc_like(cdm_ctx *ctx, const cdm_seqdb *src, cdm_seqdb **out);  // same n/lengths/layout, codes uninitialised
 int cdm_seqdb_alloc(cdm_ctx *ctx, uint64_t n, cdm_seqdb **out);
+int cdm_seqdb_alloc_raw(cdm_seqdb *db);      // the raw plane for db->words code words (contents undefined)
 // sub-DB: sel[i] (device) = 0xFFFFFFFF drops sequence i, else keeps its first sel[i] letters; extValue < 0 keeps the wasExtended flags
 int cdm_seqdb_select(cdm_ctx *ctx, const cdm_seqdb *db, const uint32_t *sel, int extValue, cdm_seqdb **out);
 

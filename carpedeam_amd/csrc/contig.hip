@@ -14,17 +14,26 @@
 
 namespace {
 struct StatArgs {
-    const SeqMeta *meta; const uint32_t *codes, *nmask;
+    const SeqMeta *meta; const uint32_t *codes, *nmask; const uint8_t *raw;
     const uint64_t *aoff; const AlnRec *rec; const uint32_t *owner;   // owner[r] = query of record r
     uint64_t nRec;
     ContigStat *out;
 };
-__device__ __forceinline__ void letterAt(const StatArgs &a, uint32_t w0, uint32_t len, bool hasN, bool rev, uint32_t pos, uint32_t &code, bool &isN) {
+// hasRaw: the sequence carries letters beyond ACGTN.  Forward, the reference looks at the original byte (letter identity, == 'N',
+// ryMap / nucleotideMap = 0 for what they do not hold): such a letter comes back as 0x100 | byte; reversed, at the complement of what
+// NucleotideMatrix maps it to (codes / nmask)
+__device__ __forceinline__ void letterAt(const StatArgs &a, uint32_t w0, uint32_t len, bool hasN, bool rev, uint32_t pos, uint32_t &code, bool &isN, bool hasRaw = false) {
     const uint32_t p = rev ? (len - 1u - pos) : pos;
     const uint32_t c = cdm_base(a.codes, w0, p);
     isN = hasN && cdm_isN(a.nmask, w0, p);
     code = rev ? (3u - c) : c;      // getNuclRevFragment maps X to 'N': an N stays an N
+    if (hasRaw && !rev) {
+        const uint8_t r = cdm_raw_at(a.raw, w0, p);
+        isN = r == 'N';
+        if (isN) code = 0; else if (!(r == 'A' || r == 'C' || r == 'G' || r == 'T')) code = 0x100u | r;
+    }
 }
+__device__ __forceinline__ uint32_t ryOf(uint32_t code) { return code < 4u ? (code & 1u) : 0u; }
 __global__ __launch_bounds__(256) void k_contig_stats(StatArgs a) {
     const uint64_t r = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -58,12 +67,12 @@ __global__ __launch_bounds__(256) void k_contig_stats(StatArgs a) {
     } else {
         for (int c = lane; c < n; c += 64) {
             uint32_t qc, tc; bool qn, tn;
-            letterAt(a, qm.woff, qm.len, qHasN, false, (uint32_t) (s.qs + c), qc, qn);
-            letterAt(a, tm.woff, tm.len, tHasN, s.rev != 0, (uint32_t) (s.ds + c), tc, tn);
+            letterAt(a, qm.woff, qm.len, qHasN, false, (uint32_t) (s.qs + c), qc, qn, a.raw && (qm.flags & 4u));
+            letterAt(a, tm.woff, tm.len, tHasN, s.rev != 0, (uint32_t) (s.ds + c), tc, tn, a.raw && (tm.flags & 4u));
             const uint32_t ql = qn ? 4u : qc, tl = tn ? 4u : tc;
             idCnt += (ql == tl);
-            idRy += (((qn ? 0u : qc) & 1u) == ((tn ? 0u : tc) & 1u));       // ryMap of a letter outside ACGT is 0
-            if (!qn && !tn) { nnTot++; nnId += (qc == tc); nnRy += ((qc & 1u) == (tc & 1u)); nCT += (qc == 1u && tc == 3u); nGA += (qc == 2u && tc == 0u); }
+            idRy += (ryOf(qn ? 0u : qc) == ryOf(tn ? 0u : tc));       // ryMap of a letter outside ACGT is 0
+            if (!qn && !tn) { nnTot++; nnId += (qc == tc); nnRy += (ryOf(qc) == ryOf(tc)); nCT += (qc == 1u && tc == 3u); nGA += (qc == 2u && tc == 0u); }
         }
         idCnt = cdm_wave_sum(idCnt); idRy = cdm_wave_sum(idRy); nnTot = cdm_wave_sum(nnTot); nnId = cdm_wave_sum(nnId); nnRy = cdm_wave_sum(nnRy);
         nCT = cdm_wave_sum(nCT); nGA = cdm_wave_sum(nGA);
@@ -99,7 +108,7 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
     if (!owner.alloc(nRec) || !dStats.alloc(nRec)) { cdm_set_error("cdm_contig_merge: out of device memory"); return CDM_ERR_HIP; }
     if (n) hipLaunchKernelGGL(k_rec_owner, dim3((n + 255) / 256), dim3(256), 0, s, alns->off, n, owner.p);
-    StatArgs a; a.meta = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.aoff = alns->off; a.rec = alns->rec; a.owner = owner.p; a.nRec = nRec; a.out = dStats.p;
+    StatArgs a; a.meta = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.raw = db->raw; a.aoff = alns->off; a.rec = alns->rec; a.owner = owner.p; a.nRec = nRec; a.out = dStats.p;
     hipEventRecord(ctx->ev0, s);
     if (nRec) hipLaunchKernelGGL(k_contig_stats, dim3((unsigned) ((nRec * 64 + 255) / 256)), dim3(256), 0, s, a);
     hipEventRecord(ctx->ev1, s);

@@ -21,8 +21,8 @@
 namespace {
 
 struct CorrectArgs {
-    MetaWoff woff; MetaLen len; MetaHasN hasN; MetaExt ext;      // per-sequence metadata, one record per sequence
-    const uint32_t *codes, *nmask;
+    MetaWoff woff; MetaLen len; MetaHasN hasN; MetaExt ext; MetaRaw hasRaw;      // per-sequence metadata, one record per sequence
+    const uint32_t *codes, *nmask; const uint8_t *raw; uint8_t *outRaw;      // raw: original letters (general kernel only), or NULL
     const uint64_t *aoff;
     const AlnRec *rec;
     const uint16_t *ry;       // purine/pyrimidine mismatches per record from cdm_rescore (0xFFFF = count here), or NULL
@@ -57,6 +57,12 @@ __device__ __forceinline__ uint32_t targetBase(const CorrectArgs &a, uint32_t tw
     uint32_t c = cdm_base(a.codes, tw, p);
     if (tHasN && cdm_isN(a.nmask, tw, p)) return 0u;
     return rev ? (3u - c) : c;
+}
+// the same for a target that may carry letters beyond ACGTN (general kernel): forward, nucleotideMap[original byte] ('c' is 0);
+// reversed, the complement of what NucleotideMatrix maps the letter to ('c' -> G), as getNuclRevFragment spells it
+__device__ __forceinline__ uint32_t targetBaseRaw(const CorrectArgs &a, uint32_t t, uint32_t tw, uint32_t tLen, bool tHasN, bool rev, uint32_t tpos) {
+    if (tHasN && !rev && a.raw && a.hasRaw[t]) return cdm_raw_base(cdm_raw_at(a.raw, tw, tpos));
+    return targetBase(a, tw, tLen, tHasN, rev, tpos);
 }
 
 // exact arg-max in software x87, one accumulator at a time (keeps the register footprint of the callers small)
@@ -166,6 +172,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_correct(CorrectArgs a)
         const uint32_t q = a.active[item];
         const uint32_t qLen = a.len[q], qw = a.woff[q];
         const bool qHasN = a.hasN[q] != 0;
+        const bool qRaw = qHasN && a.raw && a.hasRaw[q] != 0;
         const bool qWasExt = a.ext[q] != 0;
         const uint64_t r0 = a.aoff[q], r1 = a.aoff[q + 1];
 
@@ -192,7 +199,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_correct(CorrectArgs a)
                 for (uint32_t c = lane; c < aLen; c += 64) {
                     uint32_t qb = cdm_base(a.codes, qw, o.qs + c);
                     if (qHasN && cdm_isN(a.nmask, qw, o.qs + c)) qb = 0;
-                    uint32_t tb = targetBase(a, tw, tLen, tHasN, o.rev, o.ds + c);
+                    if (qRaw) qb = cdm_raw_base(cdm_raw_at(a.raw, qw, o.qs + c));
+                    uint32_t tb = targetBaseRaw(a, t, tw, tLen, tHasN, o.rev, o.ds + c);
                     mism += ((qb & 1u) != (tb & 1u));             // RY class = low bit of the A,C,G,T = 0..3 code
                 }
                 mism = cdm_wave_sum(mism);
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_correct(CorrectArgs a)
                 if ((uint32_t) o.qe < base || (uint32_t) o.qs >= base + 64) continue;   // wave uniform
                 if (p >= (uint32_t) o.qs && p <= (uint32_t) o.qe && p < qLen) {
                     const uint32_t tpos = (uint32_t) o.ds + (p - (uint32_t) o.qs);
-                    const uint32_t tb = targetBase(a, tw, tLen, a.hasN[t] != 0, o.rev, tpos);
+                    const uint32_t tb = targetBaseRaw(a, t, tw, tLen, a.hasN[t] != 0, o.rev, tpos);
                     const uint32_t cls = tpos < 5 ? tpos : (tpos >= tLen - 5 ? 6 + (tpos - (tLen - 5)) : 5);
                     cnt[tb * 11 + cls][lane] += 1ull + (o.rev ? (1ull << 32) : 0ull);
                 }
@@ -237,7 +245,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_correct(CorrectArgs a)
                 uint32_t qb = cdm_base(a.codes, qw, p);
                 const bool qIsN = qHasN && cdm_isN(a.nmask, qw, p);
                 if (qIsN) qb = 0;
+                const uint32_t mapped = qb;
+                uint8_t orig = 0;
+                if (qRaw) { orig = cdm_raw_at(a.raw, qw, p); qb = cdm_raw_base(orig); }
                 newCode = callBase(sLogT, sLogQ, sLogD, qb, p, qLen, qWasExt, [&](int slot) { return cnt[slot][lane]; }, ALL_SLOTS, keep);
+                if (qRaw) {     // coverage <= 1 keeps the original byte (:418-420) and with it what the letter maps to
+                    if (keep) newCode = mapped;
+                    a.outRaw[(uint64_t) qw * 16u + p] = keep ? orig : (uint8_t) "ACGT"[newCode];
+                }
             }
             // ---- write 64 positions = 4 code words (+ N bits): lanes 0..3 assemble one word each from ballots
             const uint64_t b0 = cdm_ballot((newCode & 1u) != 0), b1 = cdm_ballot((newCode & 2u) != 0);
@@ -402,6 +417,21 @@ __global__ void k_mark_active(const uint64_t *__restrict__ aoff, uint32_t n, uin
 }
 
 
+// the same for a DB with letters beyond ACGTN: a query that carries such letters, or one of whose targets does, goes to the general kernel
+__global__ void k_mark_active_raw(const uint64_t *__restrict__ aoff, const AlnRec *__restrict__ rec, const uint8_t *__restrict__ hasN, uint32_t n, uint32_t smallMax,
+                                  uint32_t *__restrict__ active, uint32_t *__restrict__ activeFast, uint32_t *__restrict__ activeSmall, unsigned int *__restrict__ counters) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t c = (q < n) ? aoff[q + 1] - aoff[q] : 0;
+    if (c > 1 && c <= 64) {
+        bool odd = (hasN[q] & 2u) != 0;
+        for (uint64_t r = aoff[q]; r < aoff[q + 1] && !odd; r++) odd = (hasN[rec[r].target] & 2u) != 0;
+        if (odd) c = 65;
+    }
+    const uint32_t s0 = cdm_wave_append(&counters[0], c > 64), s2 = cdm_block_append(&counters[2], c > smallMax && c <= 64), s3 = cdm_block_append(&counters[3], c > 1 && c <= smallMax);
+    if (c > 64) active[s0] = q; else if (c > smallMax) activeFast[s2] = q; else if (c > 1) activeSmall[s3] = q;
+}
+
+
 // test hook: one thread per count vector {qBase, qIter, qLen, wasCorr, 44 x (total | reverse << 16)}
 __global__ void k_debug_call(const DamageLut *lut, const uint32_t *vec, uint32_t n, uint8_t *out) {
     __shared__ double sLogT[16], sLogQ[12 * 16], sLogD[2 * 11 * 16];
@@ -447,11 +477,15 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
     // CDM_CORRECT_VARIANT (experiments): "0" = one fast instance for up to 64 records; "s<W>" = small instance (<= 15 records) with W waves per SIMD
     const char *varEnv = getenv("CDM_CORRECT_VARIANT");
     const int smallW = (varEnv && varEnv[0] == 's') ? atoi(varEnv + 1) : (varEnv && varEnv[0] == '0' ? 0 : 6);
+    if (db->raw) {
+        CDM_HIP(hipMemcpyAsync(out->raw, db->raw, db->words * 16, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_mark_active_raw, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, alns->rec, db->hasN, n, smallW ? 15u : 0u, active.p, activeFast.p, activeSmall.p, counters.p);
+    } else
     hipLaunchKernelGGL(k_mark_active, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, n, smallW ? 15u : 0u, active.p, activeFast.p, activeSmall.p, counters.p);
     DevBuf<SeqMeta> meta;
     if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
     CorrectArgs a;
-    a.woff.m = a.len.m = a.hasN.m = a.ext.m = meta.p; a.codes = db->codes; a.nmask = db->nmask;
+    a.woff.m = a.len.m = a.hasN.m = a.ext.m = a.hasRaw.m = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.raw = db->raw; a.outRaw = out->raw;
     a.aoff = alns->off; a.rec = alns->rec; a.ry = (alns->ryMism && alns->rySerial == db->serial) ? alns->ryMism : nullptr; a.active = active.p; a.nActive = counters.p; a.accept = accept.p; a.errFlag = counters.p + 1;
     a.outCodes = out->codes; a.outNmask = out->nmask; a.lut = ctx->lutDev; a.seqIdThr = par->seq_id_thr; a.corrRy = par->corr_reads_ry_seq_id;
     const int blocks = ctx->cuCount * 8;

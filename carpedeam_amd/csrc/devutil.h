@@ -15,6 +15,11 @@ __device__ __forceinline__ uint32_t cdm_isN(const uint32_t *__restrict__ nmask, 
     uint64_t bit = (uint64_t) woff * 16u + pos;
     return (nmask[bit >> 5] >> (bit & 31u)) & 1u;
 }
+// original byte of base pos of a sequence with a row in the raw plane (same index space as the N bits)
+__device__ __forceinline__ uint8_t cdm_raw_at(const uint8_t *__restrict__ raw, uint32_t woff, uint32_t pos) { return raw[(uint64_t) woff * 16u + pos]; }
+// nucleotideMap[c] of the assembler modules (an unordered_map<char,int> holding A,C,G,T: operator[] gives 0 for every other byte;
+// src/assembler/correction.cpp:170-174)
+__device__ __forceinline__ uint32_t cdm_raw_base(uint8_t r) { return r == 'C' ? 1u : r == 'G' ? 2u : r == 'T' ? 3u : 0u; }
 // 16 bases starting at base position pos (may straddle two words); positions beyond the sequence are garbage
 __device__ __forceinline__ uint32_t cdm_window16(const uint32_t *__restrict__ codes, uint32_t woff, uint32_t pos, uint32_t lastWord) {
     uint32_t w = pos >> 4, sh = (pos & 15u) * 2u;

@@ -35,8 +35,8 @@ struct Cand {
 };
 
 struct ExtArgs {
-    MetaWoff woff; MetaLen len; MetaHasN hasN; MetaExt ext; MetaKey key;      // per-sequence metadata, one record per sequence
-    const uint32_t *codes, *nmask;
+    MetaWoff woff; MetaLen len; MetaHasN hasN; MetaExt ext; MetaKey key; MetaRaw hasRaw;      // per-sequence metadata, one record per sequence
+    const uint32_t *codes, *nmask; const uint8_t *raw;
     const uint64_t *aoff;
     const AlnRec *rec;
     const uint32_t *active; const unsigned int *nActive;
@@ -53,6 +53,25 @@ struct ExtArgs {
     int unsafe; uint32_t minCov;        // --unsafe 1: consensusCaller's majority vote over the extending targets (--min-cov-safe)
     unsigned int *flags;                // [0] set when an unsafe-mode consensus would write outside its 3 qLen letters (undefined in the reference)
 };
+
+// Letter of a sequence as this module sees it.  The reference works on the original bytes: == 'N' tests, letter identity
+// (nuclassembleUtil.cpp:431-433), ryMap[c] and nucleotideMap[c] (unordered_maps: 0 for everything they do not hold).  code = 0..3 for
+// A,C,G,T; a letter beyond ACGTN (sequences with a row in the raw plane only) comes back as 0x100 | byte, so that == is the
+// reference's letter comparison, and goes through fwdBase()/ryClass() wherever a table is indexed.
+__device__ __forceinline__ void letterOf(const ExtArgs &A, uint32_t t, uint32_t w, uint32_t p, uint32_t &code, bool &isN) {
+    code = cdm_base(A.codes, w, p);
+    isN = false;
+    if (A.hasN[t]) {
+        isN = cdm_isN(A.nmask, w, p);
+        if (A.raw && A.hasRaw[t]) {
+            const uint8_t r = cdm_raw_at(A.raw, w, p);
+            isN = r == 'N';
+            if (isN) code = 0; else if (!(r == 'A' || r == 'C' || r == 'G' || r == 'T')) code = 0x100u | r;
+        }
+    }
+}
+__device__ __forceinline__ uint32_t fwdBase(uint32_t code) { return code < 4u ? code : 0u; }
+__device__ __forceinline__ uint32_t ryClass(uint32_t code) { return code < 4u ? (code & 1u) : 0u; }
 
 // ---- the query as it grows: pieces to the left (most recent first), the original, pieces to the right
 struct VQuery {
@@ -72,9 +91,7 @@ struct VQuery {
             uint32_t acc = leftTotal + qLen0; t = 0; tp = 0;
             for (uint32_t i = 0; i < nR; i++) { const Cand &c = cand[rightL[i]]; if (p < acc + c.pieceLen) { t = c.target; tp = c.pieceStart + (p - acc); break; } acc += c.pieceLen; }
         }
-        const uint32_t w = A.woff[t];
-        code = cdm_base(A.codes, w, tp);
-        isN = A.hasN[t] && cdm_isN(A.nmask, w, tp);
+        letterOf(A, t, A.woff[t], tp, code, isN);
     }
     // source (sequence t, position tp) of position p and the number of positions from p on that come from the same piece
     __device__ void spanAt(uint32_t p, uint32_t &t, uint32_t &tp, uint32_t &run) const {
@@ -91,9 +108,7 @@ struct VQuery {
 };
 
 __device__ __forceinline__ void targetBaseAt(const ExtArgs &A, uint32_t t, uint32_t p, uint32_t &code, bool &isN) {
-    const uint32_t w = A.woff[t];
-    code = cdm_base(A.codes, w, p);
-    isN = A.hasN[t] && cdm_isN(A.nmask, w, p);
+    letterOf(A, t, A.woff[t], p, code, isN);
 }
 
 // ---- consensusCaller, unsafe mode (nuclassembleUtil.cpp:570-702 + calculateConsensus :535-567).  The consensus has 3 qLen
@@ -120,7 +135,7 @@ __device__ void consensusAt(const ExtArgs &A, const VQuery &Q, const ConsList &L
         if ((long long) x < start || (long long) x >= start + (long long) c.dbLen) continue;
         uint32_t tc; bool tn;
         targetBaseAt(A, c.target, (uint32_t) ((long long) x - start), tc, tn);
-        cnt[tn ? 0u : tc]++;                        // nucleotideMap[c]: any letter outside ACGT counts as 'A'
+        cnt[tn ? 0u : fwdBase(tc)]++;               // nucleotideMap[c]: any letter outside ACGT counts as 'A'
     }
     code = 0; isN = true;
     if (cnt[0] + cnt[1] + cnt[2] + cnt[3] < A.minCov) return;
@@ -164,7 +179,7 @@ __device__ void updateIds(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t &
                 uint32_t qc, tc; bool qn, tn;
                 consensusAt(A, Q, *cons, c0 + j, qc, qn); targetBaseAt(A, c.target, j, tc, tn);
                 if (qn || tn) continue;
-                idCnt += (qc == tc); idRy += ((qc & 1u) == (tc & 1u)); tot++;
+                idCnt += (qc == tc); idRy += (ryClass(qc) == ryClass(tc)); tot++;
             }
         }
     } else
@@ -180,7 +195,7 @@ __device__ void updateIds(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t &
             uint32_t qc, tc; bool qn, tn;
             Q.baseAt(q0 + i, qc, qn); targetBaseAt(A, c.target, t0 + i, tc, tn);
             if (qn || tn) continue;
-            idCnt += (qc == tc); idRy += ((qc & 1u) == (tc & 1u)); tot++;
+            idCnt += (qc == tc); idRy += (ryClass(qc) == ryClass(tc)); tot++;
         }
     }
     if (tot != 0) { c.seqId = static_cast<float>(idCnt) / tot; c.rySeqId = static_cast<float>(idRy) / tot; }
@@ -214,7 +229,7 @@ __device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t m
                 alnCount++;
                 const uint32_t ti = tIdx - 1;
                 const uint32_t cls = ti < 5 ? ti : (ti >= c.dbLen - 5 ? 6 + (ti - (c.dbLen - 5)) : 5);
-                lik = x87_add(lik, x87_from_double(logLik[(cls * 4 + qc) * 4 + tc]));
+                lik = x87_add(lik, x87_from_double(logLik[(cls * 4 + fwdBase(qc)) * 4 + fwdBase(tc)]));
             }
         }
     } else
@@ -251,7 +266,7 @@ __device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t m
             alnCount++;
             const uint32_t ti = tIdx - 1;
             const uint32_t cls = ti < 5 ? ti : (ti >= c.dbLen - 5 ? 6 + (ti - (c.dbLen - 5)) : 5);
-            lik = x87_add(lik, x87_from_double(logLik[(cls * 4 + qc) * 4 + tc]));
+            lik = x87_add(lik, x87_from_double(logLik[(cls * 4 + fwdBase(qc)) * 4 + fwdBase(tc)]));
         }
         }
     }
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
                 // letters are compared: N == N; N maps to purine (0) in ryMap
                 const uint32_t ql = qn ? 4u : qc, tl = tn ? 4u : tc;
                 idCnt += (ql == tl);
-                idRy += (((qn ? 0u : qc) & 1u) == ((tn ? 0u : tc) & 1u));
+                idRy += (ryClass(qn ? 0u : qc) == ryClass(tn ? 0u : tc));
             }
             seqId = static_cast<float>(idCnt) / alnLen; rySeqId = static_cast<float>(idRy) / alnLen;
         }
@@ -426,6 +441,13 @@ __global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
                     sc += (!qn && !tn && qc == tc) ? 2 : -3;
                 }
                 score = sc > 0 ? (unsigned) sc : 0u; startPos = 0; endPos = (int) m - 1;
+                if (A.raw) {        // a '*' at either end of the overlap is left out (DistanceCalculator.h:204-220)
+                    constexpr uint32_t STAR = 0x100u | '*';
+                    uint32_t x0, y0, x1, y1; bool n0;
+                    Q.baseAt(qOff, x0, n0); targetBaseAt(A, c.target, tOff, y0, n0); Q.baseAt(qOff + m - 1, x1, n0); targetBaseAt(A, c.target, tOff + m - 1, y1, n0);
+                    if (x0 == STAR || y0 == STAR) startPos = 1;
+                    if (m > 1 && (x1 == STAR || y1 == STAR)) endPos--;
+                }
             }
             // updateNuclAlignment (nuclassembleUtil.cpp:9-47)
             int qs2, qe2, ds2, de2; const int dist = (int) md;
@@ -529,6 +551,33 @@ __global__ __launch_bounds__(256) void k_write(ExtArgs A, const uint32_t *__rest
     if (anyN) oHasN[q] = 1;
 }
 
+// DBs with letters beyond ACGTN: an output sequence any of whose sources (the query, the donating targets) has a row of original
+// letters gets one too - every letter is copied from its source as it stands (:425-470 append the target's own bytes)
+__global__ __launch_bounds__(256) void k_write_raw(ExtArgs A, const uint32_t *__restrict__ oWoff, const uint32_t *__restrict__ oLen, uint32_t n,
+                                                   uint8_t *__restrict__ oRaw, uint8_t *__restrict__ oHasN) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const uint32_t L = oLen[q];
+    uint8_t *o = oRaw + (uint64_t) oWoff[q] * 16u;
+    VQuery Q; Q.a = &A; Q.q = q; Q.qLen0 = A.len[q]; Q.qw = A.woff[q]; Q.nL = 0; Q.nR = 0; Q.leftTotal = 0; Q.total = L; Q.plain = false;
+    Q.cand = nullptr; Q.leftL = Q.rightL = nullptr;
+    if (A.newLen[q] != 0) {
+        const uint64_t r0 = A.aoff[q]; const uint32_t nRec = (uint32_t) (A.aoff[q + 1] - r0);
+        Q.cand = A.cand + r0; Q.leftL = A.lists + 4 * r0 + 2 * (uint64_t) nRec; Q.rightL = Q.leftL + nRec; Q.nL = A.nLeft[q]; Q.nR = A.nRight[q]; Q.leftTotal = A.leftTotal[q];
+    }
+    bool any = false;
+    for (uint32_t p = 0; p < L;) { uint32_t t, tp, run; Q.spanAt(p, t, tp, run); any = any || A.hasRaw[t]; p += run; }
+    if (!any) return;
+    for (uint32_t p = 0; p < L;) {
+        uint32_t t, tp, run;
+        Q.spanAt(p, t, tp, run);
+        const uint32_t tw = A.woff[t], m = min(run, L - p);
+        if (A.hasRaw[t]) for (uint32_t i = 0; i < m; i++) o[p + i] = cdm_raw_at(A.raw, tw, tp + i);
+        else for (uint32_t i = 0; i < m; i++) o[p + i] = (A.hasN[t] && cdm_isN(A.nmask, tw, tp + i)) ? 'N' : (uint8_t) "ACGT"[cdm_base(A.codes, tw, tp + i)];
+        p += m;
+    }
+    oHasN[q] = 3;
+}
 
 }  // namespace
 
@@ -553,7 +602,7 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     DevBuf<SeqMeta> meta;
     if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
     ExtArgs A;
-    A.woff.m = A.len.m = A.hasN.m = A.ext.m = A.key.m = meta.p; A.codes = db->codes; A.nmask = db->nmask;
+    A.woff.m = A.len.m = A.hasN.m = A.ext.m = A.key.m = A.hasRaw.m = meta.p; A.codes = db->codes; A.nmask = db->nmask; A.raw = db->raw;
     A.aoff = alns->off; A.rec = alns->rec; A.active = active.p; A.nActive = nActive.p; A.lut = ctx->lutDev; A.cand = cand.p; A.lists = lists.p;
     A.newLen = newLen.p; A.nLeft = nLeft.p; A.nRight = nRight.p; A.leftTotal = leftTotal.p; A.scores = scores ? dScores.p : nullptr;
     A.seqIdThr = par->seq_id_thr; A.rySeqIdThr = par->ry_seq_id_thr; A.likelihoodThr = par->likelihood_threshold;
@@ -598,6 +647,10 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     hipMemcpyAsync(o->key, db->key, (size_t) n * 4, hipMemcpyDeviceToDevice, s);
     hipMemsetAsync(o->hasN, 0, n, s);
     if (words) hipLaunchKernelGGL(k_write, dim3((n + 255) / 256), dim3(256), 0, s, A, o->woff, o->len, n, o->codes, o->nmask, o->hasN);
+    if (words && db->raw) {
+        if (int rc2 = cdm_seqdb_alloc_raw(o)) { cdm_seqdb_free(o); return rc2; }
+        hipLaunchKernelGGL(k_write_raw, dim3((n + 255) / 256), dim3(256), 0, s, A, o->woff, o->len, n, o->raw, o->hasN);
+    }
     if (scores) hipMemcpyAsync(scores, dScores.p, alns->count * 8, hipMemcpyDeviceToHost, s);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: output kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     *out = o;

@@ -53,9 +53,29 @@ struct CompareByScoreContigs {
 typedef std::priority_queue<Res, std::vector<Res>, CompareByScoreContigs> Queue;
 
 inline int ryClass(char c) { return (c == 'C' || c == 'T') ? 1 : 0; }              // ryMap[c]; any other letter: 0
-std::string revComp(const char *s, size_t n) {                                    // getNuclRevFragment (nuclassembleUtil.cpp:67-76)
+// getNuclRevFragment (nuclassembleUtil.cpp:67-76): the complement of what NucleotideMatrix::setupLetterMapping
+// (M/commons/NucleotideMatrix.cpp:17-61) maps the letter to - lower case folds, IUPAC codes stand for one base, the rest is X -> 'N'
+struct RevTable {
+    char t[256];
+    RevTable() {
+        for (int c = 0; c < 256; c++) {
+            char r = 'N';
+            if ((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'))
+                switch (c & ~0x20) {
+                    case 'A': r = 'T'; break;
+                    case 'C': case 'M': case 'Y': case 'H': r = 'G'; break;
+                    case 'G': case 'K': case 'B': case 'D': case 'V': case 'R': case 'S': r = 'C'; break;
+                    case 'T': case 'U': case 'W': r = 'A'; break;
+                    default: break;
+                }
+            t[c] = r;
+        }
+    }
+};
+std::string revComp(const char *s, size_t n) {
+    static const RevTable tab;
     std::string r(n, 'N');
-    for (size_t i = 0; i < n; i++) { const char c = s[n - 1 - i]; r[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+    for (size_t i = 0; i < n; i++) r[i] = tab.t[(unsigned char) s[n - 1 - i]];
     return r;
 }
 // deamMatches (nuclassembleUtil.cpp:1009-1044)
@@ -206,8 +226,10 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
                     const char *qa = nullptr; unsigned m = 0;
                     if (diag >= 0 && md < qLen) { m = std::min(tLen, qLen - md); qa = query.data() + md; }
                     else if (diag < 0 && md < tLen) { m = std::min(tLen - md, qLen); qa = query.data(); }
-                    if (qa) {       // computeSubstitutionStartEndDistance: the whole overlap ('*' ends do not occur in nucleotide DBs)
-                        diagonalLen = m; startPos = 0; endPos = (int) m - 1;
+                    if (qa) {       // computeGlobalSubstitutionStartEndDistance: the whole overlap, but for a '*' at either end (DistanceCalculator.h:204-220)
+                        const char *ta = ts + (diag < 0 ? md : 0);
+                        diagonalLen = m; startPos = (qa[0] == '*' || ta[0] == '*') ? 1 : 0; endPos = (int) m - 1;
+                        if (endPos > 0 && (qa[m - 1] == '*' || ta[m - 1] == '*')) endPos--;
                     }
                     // updateNuclAlignment (nuclassembleUtil.cpp:9-47)
                     const int dist = (int) md;

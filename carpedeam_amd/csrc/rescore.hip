@@ -19,8 +19,8 @@
 namespace {
 
 struct RescoreArgs {
-    MetaWoff woff; MetaLen len; MetaHasN hasN;      // per-sequence metadata, one record per sequence
-    const uint32_t *codes, *nmask;
+    MetaWoff woff; MetaLen len; MetaHasN hasN; MetaRaw hasRaw;      // per-sequence metadata, one record per sequence
+    const uint32_t *codes, *nmask; const uint8_t *raw;
     const uint64_t *hoff;
     const HitRec *hit;
     const int32_t *minScore;   // [maxLen+1]
@@ -59,17 +59,25 @@ __device__ __forceinline__ void orientedBase(const RescoreArgs &a, uint32_t w0, 
     if (rc) code = 3u - code;
 }
 
-struct Diag { unsigned score; unsigned diagLen; unsigned dist; int diagonal; unsigned ident; unsigned ry; bool any; };
+struct Diag { unsigned score; unsigned diagLen; unsigned dist; int diagonal; unsigned ident; unsigned ry; bool any; unsigned first, last; };
 
 // ungappedAlignmentByDiagonal + computeGlobalSubstitutionStartEndDistance for one real diagonal
 __device__ __forceinline__ void scoreDiagonal(const RescoreArgs &a, uint32_t qw, uint32_t qLen, bool qN, bool rc, uint32_t tw, uint32_t tLen, bool tN,
-                                              int diagonal, Diag &best) {
+                                              int diagonal, Diag &best, bool qRaw = false, bool tRaw = false) {
     const unsigned md = (unsigned) abs(diagonal);
     uint32_t qOff, tOff, m;
     if (diagonal >= 0 && md < qLen) { qOff = md; tOff = 0; m = min(tLen, qLen - md); }
     else if (diagonal < 0 && md < tLen) { qOff = 0; tOff = md; m = min(tLen - md, qLen); }
     else return;   // res.score stays 0: never beats max (strict >)
     unsigned mism = 0, identN = 0, ry = 0xFFFFu;
+    uint32_t first = 0, last = m - 1;
+    if (qRaw || tRaw) {
+        // computeGlobalSubstitutionStartEndDistance (DistanceCalculator.h:204-220) leaves a '*' at either end of the overlap out
+        const uint8_t q0 = (qRaw && !rc) ? cdm_raw_at(a.raw, qw, qOff) : 0, t0 = tRaw ? cdm_raw_at(a.raw, tw, tOff) : 0;
+        const uint8_t q1 = (qRaw && !rc) ? cdm_raw_at(a.raw, qw, qOff + m - 1) : 0, t1 = tRaw ? cdm_raw_at(a.raw, tw, tOff + m - 1) : 0;
+        first = (q0 == '*' || t0 == '*') ? 1u : 0u;
+        if (last > 0 && (q1 == '*' || t1 == '*')) last--;
+    }
     if (!qN && !tN) {
         ry = 0;
         const uint32_t qLast = (qLen + 15) / 16 - 1, tLast = (tLen + 15) / 16 - 1;
@@ -82,19 +90,29 @@ __device__ __forceinline__ void scoreDiagonal(const RescoreArgs &a, uint32_t qw,
             mism += __popc(mm); ry += __popc(rr);
         }
     } else {
-        for (uint32_t k = 0; k < m; k++) {
+        for (uint32_t k = first; k <= last && k < m; k++) {
             uint32_t qc, tc; bool qn, tn;
             orientedBase(a, qw, qLen, qN, rc, qOff + k, qc, qn);
             orientedBase(a, tw, tLen, tN, false, tOff + k, tc, tn);
             const bool match = !qn && !tn && qc == tc;
             mism += !match;
             // identity count compares letters: forward N == N; the reversed query spells N as 'X' (rescorediagonal.cpp:173-179)
-            identN += (qn && tn && !rc);
+            if (!qRaw && !tRaw) identN += (qn && tn && !rc);
+            else {
+                // letters beyond ACGTN: the score above is on the mapped codes (createAsciiSubMat), the identity count on the
+                // case-folded original bytes (:278-282) - of the target always, of the query on the forward strand; the reversed
+                // query is spelled in mapped, complemented upper-case letters (:173-179)
+                uint8_t ql = qn ? (rc ? 'X' : 'N') : (uint8_t) "ACGT"[qc], tl = tn ? 'N' : (uint8_t) "ACGT"[tc];
+                if (qRaw && !rc) ql = cdm_raw_at(a.raw, qw, qOff + k);
+                if (tRaw) tl = cdm_raw_at(a.raw, tw, tOff + k);
+                identN += ((ql & 0xDFu) == (tl & 0xDFu)) - (int) match;
+            }
         }
     }
-    const long long sc = 2ll * (m - mism) - 3ll * mism;
+    const uint32_t cols = last + 1u >= first ? last + 1u - first : 0u;
+    const long long sc = 2ll * (cols - mism) - 3ll * mism;
     const unsigned score = sc > 0 ? (unsigned) sc : 0u;
-    if (score > best.score) { best.score = score; best.diagLen = m; best.dist = md; best.diagonal = diagonal; best.ident = (m - mism) + identN; best.ry = ry; best.any = true; }
+    if (score > best.score) { best.score = score; best.diagLen = m; best.dist = md; best.diagonal = diagonal; best.ident = (cols - mism) + identN; best.ry = ry; best.any = true; best.first = first; best.last = last; }
 }
 
 __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, const uint32_t *__restrict__ hitQuery) {
@@ -105,17 +123,18 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, const uint32_t *
     const uint32_t t = hit.target;
     const uint32_t qLen = a.len[q], tLen = a.len[t], qw = a.woff[q], tw = a.woff[t];
     const bool qN = a.hasN[q] != 0, tN = a.hasN[t] != 0;
+    const bool qRaw = qN && a.hasRaw[q] != 0, tRaw = tN && a.hasRaw[t] != 0;
     const bool isReverse = hit.score < 0;
     const bool isIdentity = (q == t);
     a.valid[h] = 0;
     if (!canBeCovered(a.covThr, a.covMode, (float) qLen, (float) tLen)) return;
     // computeUngappedAlignment (DistanceCalculator.h:93-113) on the 16-bit diagonal
     const unsigned short u = (unsigned short) (short) hit.diagonal;
-    Diag best; best.score = 0; best.diagLen = 0; best.dist = 0; best.diagonal = 0; best.ident = 0; best.ry = 0xFFFFu; best.any = false;
-    for (unsigned d = 1; d <= 1 + tLen / 32768; d++) scoreDiagonal(a, qw, qLen, qN, isReverse, tw, tLen, tN, (int) (-(int) d * 65536 + (int) u), best);
-    for (unsigned d = 0; d <= qLen / 65536; d++) scoreDiagonal(a, qw, qLen, qN, isReverse, tw, tLen, tN, (int) (d * 65536 + u), best);
+    Diag best; best.score = 0; best.diagLen = 0; best.dist = 0; best.diagonal = 0; best.ident = 0; best.ry = 0xFFFFu; best.any = false; best.first = 0; best.last = 0;
+    for (unsigned d = 1; d <= 1 + tLen / 32768; d++) scoreDiagonal(a, qw, qLen, qN, isReverse, tw, tLen, tN, (int) (-(int) d * 65536 + (int) u), best, qRaw, tRaw);
+    for (unsigned d = 0; d <= qLen / 65536; d++) scoreDiagonal(a, qw, qLen, qN, isReverse, tw, tLen, tN, (int) (d * 65536 + u), best, qRaw, tRaw);
     if (!best.any) return;   // score 0 on every probe: E-value(0) never passes; (identity of an all-N sequence is not representable)
-    const int startPos = 0, endPos = (int) best.diagLen - 1;
+    const int startPos = (int) best.first, endPos = (int) best.last;
     const int alnLen = (endPos - startPos) + 1;
     int qs, qe, ds, de;
     if (best.diagonal >= 0) { qs = startPos + (int) best.dist; qe = endPos + (int) best.dist; ds = startPos; de = endPos; }
@@ -208,7 +227,7 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     DevBuf<SeqMeta> meta;
     if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
     RescoreArgs a;
-    a.woff.m = a.len.m = a.hasN.m = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.hoff = hits->off; a.hit = hits->rec;
+    a.woff.m = a.len.m = a.hasN.m = a.hasRaw.m = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.raw = db->raw; a.hoff = hits->off; a.hit = hits->rec;
     a.minScore = dMin.p; a.nHits = nHits; a.n = n; a.seqIdThr = par->seq_id_thr; a.covThr = par->cov_thr; a.covMode = par->cov_mode;
     a.minAlnLen = par->min_aln_len; a.tmp = tmp.p; a.tmpRy = tmpRy.p; a.valid = valid.p;
     hipEventRecord(ctx->ev0, s);

@@ -66,8 +66,11 @@ float cdm_ctx_last_kernel_ms(cdm_ctx *ctx, int which);
  * offsets[i]: byte offset of entry i in data;  lengths[i]: sequence length WITHOUT "\n\0"
  * keys[i]   : DB key of entry i; entries must be ordered by key (the order DBReader's index has after open()).
  * ext[i]    : the fork's 4th index column "wasExtended" (DBReader.cpp:808-817); may be NULL (= all 0)
- * Letters other than A,C,G,T are kept as 'N' exceptions (side bit plane); any letter other than ACGTN
- * (lower case, IUPAC codes) is rejected with CDM_ERR_UNSUPPORTED in this round.
+ * 'N' is kept as an exception bit beside the 2-bit codes.  Any other byte (lower case, IUPAC codes, ...) is mapped as
+ * NucleotideMatrix::setupLetterMapping does (lib/mmseqs/src/commons/NucleotideMatrix.cpp:17-61) for kmermatcher, the
+ * diagonal score and reverse complements, and the sequence keeps its original bytes in a side plane for the consumers
+ * that look at them (nucleotideMap[c] of the assembler modules, letter identity, the letters copied to the output);
+ * cdm_seqdb_download gives them back.  cdm_seqdb_copy_packed (the multi-GPU exchange format) refuses such a DB.
  */
 int cdm_seqdb_upload(cdm_ctx *ctx, const char *data, const uint64_t *offsets, const uint32_t *lengths,
                      const uint32_t *keys, const uint8_t *ext, uint64_t n, cdm_seqdb **out);

@@ -3,7 +3,7 @@
 modes: small, deep (100x+ pile-ups, > 64 records per query), repeats (low-complexity / tandem repeats), contigparams (k = 22,
 include-only-extendable), longreads (up to 600 bp: general extraction kernel), nrich (N letters), verylong (wide tuple layout), tiling (chains of
 extensions), tiny (reads around and below k), palrepeats (tandem repeats of reverse-palindromic
-units: comparator ties in the per-sequence k-mer sort)."""
+units: comparator ties in the per-sequence k-mer sort), letters (lower-case stretches, IUPAC codes, bytes that are no letters)."""
 import os
 import subprocess
 import sys
@@ -36,7 +36,7 @@ fails = 0
 ties = 0
 unsupported = 0
 for case in range(cases):
-    G = {"small": 300, "deep": 150, "repeats": 200, "contigparams": 400, "longreads": 1500, "palrepeats": 700, "nrich": 300, "verylong": 6000, "tiling": 600, "tiny": 60}[mode]
+    G = {"small": 300, "deep": 150, "repeats": 200, "contigparams": 400, "longreads": 1500, "palrepeats": 700, "nrich": 300, "verylong": 6000, "tiling": 600, "tiny": 60, "letters": 300}[mode]
     genome = rng.integers(0, 4, G)
     if mode == "repeats":
         unit = rng.integers(0, 4, int(rng.integers(1, 9)))
@@ -46,8 +46,8 @@ for case in range(cases):
         for _ in range(2):
             u = np.array(["ACGT".index(ch) for ch in units[int(rng.integers(0, len(units)))]])
             ln = int(rng.integers(60, 300)); a = int(rng.integers(0, G - ln)); genome[a:a + ln] = np.resize(u, ln)
-    nreads = {"small": (6, 61), "deep": (150, 400), "repeats": (10, 80), "contigparams": (10, 80), "longreads": (10, 60), "palrepeats": (8, 50), "nrich": (10, 80), "verylong": (6, 30), "tiling": (30, 120), "tiny": (2, 40)}[mode]
-    lr = {"small": (30, 121), "deep": (40, 101), "repeats": (30, 121), "contigparams": (40, 200), "longreads": (100, 600), "palrepeats": (30, 320), "nrich": (30, 150), "verylong": (600, 3000), "tiling": (40, 90), "tiny": (5, 45)}[mode]
+    nreads = {"small": (6, 61), "deep": (150, 400), "repeats": (10, 80), "contigparams": (10, 80), "longreads": (10, 60), "palrepeats": (8, 50), "nrich": (10, 80), "verylong": (6, 30), "tiling": (30, 120), "tiny": (2, 40), "letters": (8, 70)}[mode]
+    lr = {"small": (30, 121), "deep": (40, 101), "repeats": (30, 121), "contigparams": (40, 200), "longreads": (100, 600), "palrepeats": (30, 320), "nrich": (30, 150), "verylong": (600, 3000), "tiling": (40, 90), "tiny": (5, 45), "letters": (30, 140)}[mode]
     seqs = []
     for _ in range(int(rng.integers(*nreads))):
         L = int(rng.integers(*lr)); L = min(L, G - 1); st = int(rng.integers(0, G - L))
@@ -66,6 +66,19 @@ for case in range(cases):
         if rng.random() < nprob:
             for _n in range(int(rng.integers(1, 6)) if mode == "nrich" else 1):
                 k = int(rng.integers(0, L)); sq = sq[:k] + "N" + sq[k + 1:]
+        if mode == "letters":
+            r = rng.random()
+            b = bytearray(sq.encode())
+            if r < 0.25:
+                a0 = int(rng.integers(0, L)); a1 = min(L, a0 + int(rng.integers(1, 50)))
+                b[a0:a1] = bytes(b[a0:a1]).lower()
+            elif r < 0.35:
+                b = bytearray(bytes(b).lower())
+            elif r < 0.65:
+                for _n in range(int(rng.integers(1, 5))):
+                    odd = b"RYSWKMBDHVUNXryswkmbdhvunx*-.1acgt"
+                    b[int(rng.integers(0, L))] = odd[int(rng.integers(0, len(odd)))]
+            sq = b.decode()
         seqs.append(sq)
     if rng.random() < 0.4:
         seqs.append(seqs[int(rng.integers(0, len(seqs)))])

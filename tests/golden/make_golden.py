@@ -170,7 +170,7 @@ def main():
         chain(tmp, "example", seqs, 1, prefix, 4)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("createdb", "contigs", "cycle")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("createdb", "contigs", "cycle", "letters")):
     main()
 
 
@@ -184,7 +184,9 @@ def contig_goldens(threads=4):
     with tempfile.TemporaryDirectory() as tmp:
         prefix = os.path.join(tmp, "dhigh")
         synth.write_dhigh_profiles(prefix)
-        for name, last_it, steps in (("mixed3k", 2, 2), ("synth2k", 1, 2)):
+        for name, last_it, steps in (("mixed3k", 2, 2), ("synth2k", 1, 2), ("letters", 2, 2)):
+            if len(sys.argv) > 2 and name not in sys.argv[2:]:      # (make_golden.py contigs <name>...: only those data sets)
+                continue
             d = os.path.join(OUT, name)
             cur = os.path.join(tmp, name + "_c0")
             mmdb.write_from_keyed(cur, gold(name, "asm", last_it), mmdb.DBTYPE_NUCLEOTIDES)
@@ -295,3 +297,40 @@ def cycle_goldens(threads=4):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "cycle":
     cycle_goldens()
+
+
+def letter_reads(n=1500, seed=5):
+    """synthetic reads carrying what real FASTA carries beside ACGTN: soft-masked (lower case) stretches, whole lower-case reads,
+    IUPAC ambiguity codes in both cases, U, X, and a few bytes that are no nucleotide letters at all"""
+    rng = np.random.RandomState(seed)
+    seqs = synth.generate_strings(n, seed=seed, mixed=(60, 150))
+    iupac = "RYSWKMBDHVUNXryswkmbdhvunx"
+    out = []
+    for s in seqs:
+        b = bytearray(s.encode())
+        r = rng.rand()
+        if r < 0.10:                                     # a soft-masked stretch
+            a = rng.randint(0, len(b) - 10); e = a + rng.randint(5, min(60, len(b) - a))
+            b[a:e] = bytes(b[a:e]).lower()
+        elif r < 0.14:                                   # an entirely lower-case read
+            b = bytearray(bytes(b).lower())
+        elif r < 0.30:                                   # one to three ambiguity codes
+            for _ in range(rng.randint(1, 4)):
+                b[rng.randint(0, len(b))] = ord(iupac[rng.randint(0, len(iupac))])
+        elif r < 0.32:                                   # bytes that are not letters
+            b[rng.randint(0, len(b))] = ord("*-.1"[rng.randint(0, 4)])
+        out.append(b.decode())
+    return out
+
+
+def letters_goldens():
+    """tests/golden/letters/: the reads loop of the reference's own object code on reads with lower-case and IUPAC letters
+    (python tests/golden/make_golden.py letters)"""
+    with tempfile.TemporaryDirectory() as tmp:
+        prefix = os.path.join(tmp, "dhigh")
+        synth.write_dhigh_profiles(prefix)
+        chain(tmp, "letters", letter_reads(), 3, prefix, 4)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "letters":
+    letters_goldens()

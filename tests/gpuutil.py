@@ -5,7 +5,7 @@ import subprocess
 from carpedeam_amd import mmdb
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-DATASETS = [("synth2k", 2), ("mixed3k", 3), ("example", 1)]
+DATASETS = [("synth2k", 2), ("mixed3k", 3), ("example", 1), ("letters", 3)]
 
 
 def gold(name, stage, it=None):

@@ -12,7 +12,7 @@ from gpuutil import diff_keys, gold, run_oracle
 from stageflags import AC_FLAGS, KC_FLAGS, R_FLAGS
 from test_oracle_golden import pref_sign_ties
 
-CASES = [("mixed3k", 2, 0), ("mixed3k", 2, 1), ("synth2k", 1, 0), ("synth2k", 1, 1)]
+CASES = [("mixed3k", 2, 0), ("mixed3k", 2, 1), ("synth2k", 1, 0), ("synth2k", 1, 1), ("letters", 2, 0), ("letters", 2, 1)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

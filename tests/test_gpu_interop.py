@@ -25,7 +25,7 @@ def run(exe, *args, env=None):
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref (the reference's object code) is not built here")
-@pytest.mark.parametrize("name,it", [("synth2k", 0), ("mixed3k", 2), ("example", 0)])
+@pytest.mark.parametrize("name,it", [("synth2k", 0), ("mixed3k", 2), ("example", 0), ("letters", 1)])
 def test_reference_modules_read_gpu_written_dbs(tmp_path, dhigh_prefix, name, it):
     from carpedeam_amd import build
     build.build()

@@ -19,7 +19,7 @@ def run(*args):
     assert r.returncode == 0, r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("name,it", [("synth2k", 0), ("synth2k", 1), ("mixed3k", 2), ("example", 0)])
+@pytest.mark.parametrize("name,it", [("synth2k", 0), ("synth2k", 1), ("mixed3k", 2), ("example", 0), ("letters", 0), ("letters", 2)])
 def test_modules_reproduce_reference_dbs(tmp_path, dhigh_prefix, name, it):
     from carpedeam_amd import build
     build.build()

@@ -268,3 +268,9 @@ def test_unsafe_mode_against_reference_binary(oracle_bin, dhigh_prefix, tmp_path
     assert a == b
     safe = mmdb.canon(gold(name, "asm", it))
     assert sum(1 for k in safe if a.get(k) != safe[k]) > 20
+
+
+def test_chain_letters(oracle_bin, dhigh_prefix, tmp_path):
+    """reads with lower-case stretches, IUPAC codes and non-letters (NucleotideMatrix.cpp:17-61 maps them for kmermatcher and the
+    score; correction/extension see nucleotideMap[c], i.e. base 0 for everything that is not ACGT; output keeps the original byte)"""
+    _stage_chain(oracle_bin, dhigh_prefix, tmp_path, "letters", 3)
