@@ -81,3 +81,25 @@ def circular_reads(seed=11, genomes=(420, 610, 800, 1500), coverage=30, lo=60, h
             reads.append(bytes(bytearray(r)).decode("ascii"))
     order = rs.permutation(len(reads))
     return [reads[i] for i in order]
+
+
+def letter_cases(seed=9):
+    """the contig set above (another seed, half the size) with what real FASTA carries beside ACGTN: soft-masked stretches,
+    IUPAC codes, a few bytes that are no letters (cyclecheck indexes what NucleotideMatrix maps them to and writes them out as
+    they are)"""
+    rs = np.random.RandomState(seed)
+    odd = b"RYSWKMBDHVUNXryswkmbdhvunx*-.1"
+    out = []
+    for s in cases(seed=seed, scale=0.5):
+        b = bytearray(s.encode())
+        r = rs.random_sample()
+        if b and r < 0.4:
+            a = rs.randint(0, len(b)); e = min(len(b), a + rs.randint(1, 400))
+            b[a:e] = bytes(b[a:e]).lower()
+        elif b and r < 0.7:
+            for _ in range(rs.randint(1, 6)):
+                b[rs.randint(0, len(b))] = odd[rs.randint(0, len(odd))]
+        elif r < 0.8:
+            b = bytearray(bytes(b).lower())
+        out.append(b.decode("ascii"))
+    return out

@@ -67,6 +67,39 @@ def test_device_cyclecheck_matches_reference_goldens(name, flags):
         assert all(len(want[keys[i]][0]) - 1 == split[i] for i in range(len(keys)) if split[i])
 
 
+REF = os.path.join(ROOT, "oracle", "_ref", "carpedeam_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref (the reference's object code) is not built here")
+@pytest.mark.parametrize("name,flags", VARIANTS)
+def test_oracle_cyclecheck_on_letters_matches_reference(oracle_bin, tmp_path, name, flags):
+    """contigs with lower-case stretches, IUPAC codes and non-letters: the oracle against a live run of the reference's object code"""
+    import cyclecases
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), cyclecases.letter_cases())
+    run_oracle(oracle_bin, "cyclecheck", t("in"), t("o"), *flags)
+    run_oracle(REF, "cyclecheck", t("in"), t("r"), *flags, "--threads", "2")
+    assert mmdb.read_db(t("r")) and not diff_keys(mmdb.read_db(t("o")), mmdb.read_db(t("r")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,flags", VARIANTS)
+def test_device_cyclecheck_on_letters_matches_oracle(oracle_bin, tmp_path, name, flags):
+    import cyclecases
+    from carpedeam_amd import capi
+    from gpuutil import seqdb_to_keyed
+    t = lambda s: str(tmp_path / s)
+    seqs = cyclecases.letter_cases()
+    mmdb.write_seqdb(t("in"), seqs)
+    run_oracle(oracle_bin, "cyclecheck", t("in"), t("o"), *flags)
+    ctx = capi.Ctx(0)
+    f = dict(zip(flags[::2], flags[1::2]))
+    cyc, rest, split = ctx.cyclecheck(ctx.upload_seqs(seqs), int(f.get("--max-seq-len", 65535)), f.get("--chop-cycle", "0") == "1")
+    want = mmdb.read_db(t("o"))
+    assert want and not diff_keys(seqdb_to_keyed(*cyc.download()), want)
+    assert not diff_keys(seqdb_to_keyed(*rest.download()), {k: v for k, v in mmdb.read_db(t("in")).items() if k not in want})
+
+
 @pytest.mark.gpu
 def test_cyclecheck_module_on_db_files(tmp_path):
     from carpedeam_amd import build
