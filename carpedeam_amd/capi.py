@@ -51,7 +51,7 @@ EXPORTS = [
     "cdm_hits_download", "cdm_hits_free", "cdm_rescore", "cdm_alns_upload", "cdm_alns_count", "cdm_alns_download", "cdm_alns_free",
     "cdm_evalue", "cdm_bit_score", "cdm_correct", "cdm_extend",
     "cdm_kmermatch_part", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_sort", "cdm_kpart_vote", "cdm_kpart_cont_cap", "cdm_kpart_free", "cdm_dev_copy",
-    "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck",
+    "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
 ]
 
 
@@ -95,6 +95,9 @@ def lib():
         l.cdm_seqdb_words.argtypes = [vp]
         l.cdm_seqdb_words.restype = C.c_uint64
         l.cdm_seqdb_copy_packed.argtypes = [vp, vp, vp, vp, vp, vp]
+        l.cdm_seqdb_has_raw.argtypes = [vp]
+        l.cdm_seqdb_copy_raw.argtypes = [vp, vp, vp, vp]
+        l.cdm_seqdb_attach_raw.argtypes = [vp, vp, vp, vp]
         l.cdm_seqdb_from_packed.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint8, C.POINTER(vp)]
         l.cdm_damage_load.argtypes = [vp, C.c_char_p]
         l.cdm_damage_get.argtypes = [vp, vp]
@@ -168,6 +171,17 @@ class SeqDb:
     def copy_packed(self, codes_ptr, nmask_ptr, len_ptr, key_ptr):
         """copy the packed form into DEVICE buffers (raw pointers, e.g. torch tensor .data_ptr())"""
         _check(lib().cdm_seqdb_copy_packed(self.ctx.h, self.h, codes_ptr, nmask_ptr, len_ptr, key_ptr))
+
+    @property
+    def has_raw(self):
+        """the DB carries letters beyond ACGTN (their original bytes travel beside the packed form: copy_raw / attach_raw)"""
+        return bool(lib().cdm_seqdb_has_raw(self.h))
+
+    def copy_raw(self, raw_ptr, flags_ptr):
+        _check(lib().cdm_seqdb_copy_raw(self.ctx.h, self.h, raw_ptr, flags_ptr))
+
+    def attach_raw(self, raw_ptr, flags_ptr):
+        _check(lib().cdm_seqdb_attach_raw(self.ctx.h, self.h, raw_ptr, flags_ptr))
 
     def meta(self):
         n = self.n

@@ -461,8 +461,36 @@ extern "C" int cdm_seqdb_select_ext(cdm_ctx *ctx, const cdm_seqdb *db, cdm_seqdb
     if (n) hipLaunchKernelGGL(k_sel_from_ext, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, db->len, db->ext, n, sel.p);
     return cdm_seqdb_select(ctx, db, sel.p, 1, out);
 }
+namespace {
+__global__ void k_raw_flags(const uint8_t *__restrict__ hasN, uint64_t n, uint8_t *__restrict__ flags) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (hasN[i] & 2u) ? 1 : 0;
+}
+__global__ void k_raw_attach(const uint8_t *__restrict__ flags, uint64_t n, uint8_t *__restrict__ hasN) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flags[i]) hasN[i] = 3;
+}
+}  // namespace
+extern "C" int cdm_seqdb_has_raw(const cdm_seqdb *db) { return db->raw ? 1 : 0; }
+extern "C" int cdm_seqdb_copy_raw(cdm_ctx *ctx, const cdm_seqdb *db, void *raw, void *flags) {
+    if (!db->raw) { cdm_set_error("cdm_seqdb_copy_raw: the DB has no letters beyond ACGTN"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    CDM_HIP(hipMemcpyAsync(raw, db->raw, db->words * 16, hipMemcpyDeviceToDevice, s));
+    if (db->n) hipLaunchKernelGGL(k_raw_flags, dim3((unsigned) ((db->n + 255) / 256)), dim3(256), 0, s, db->hasN, db->n, (uint8_t *) flags);
+    CDM_HIP(hipStreamSynchronize(s));
+    return CDM_OK;
+}
+extern "C" int cdm_seqdb_attach_raw(cdm_ctx *ctx, cdm_seqdb *db, const void *raw, const void *flags) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    if (int rc = cdm_seqdb_alloc_raw(db)) return rc;
+    hipStream_t s = ctx->stream;
+    CDM_HIP(hipMemcpyAsync(db->raw, raw, db->words * 16, hipMemcpyDeviceToDevice, s));
+    if (db->n) hipLaunchKernelGGL(k_raw_attach, dim3((unsigned) ((db->n + 255) / 256)), dim3(256), 0, s, (const uint8_t *) flags, db->n, db->hasN);
+    CDM_HIP(hipStreamSynchronize(s));
+    return CDM_OK;
+}
 extern "C" int cdm_seqdb_copy_packed(cdm_ctx *ctx, const cdm_seqdb *db, void *codes, void *nmask16, void *lengths, void *keys) {
-    if (db->raw && codes) { cdm_set_error("cdm_seqdb_copy_packed: the DB carries letters beyond ACGTN; the packed exchange format has no room for them"); return CDM_ERR_UNSUPPORTED; }
     CDM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     if (codes) CDM_HIP(hipMemcpyAsync(codes, db->codes, db->words * 4, hipMemcpyDeviceToDevice, s));

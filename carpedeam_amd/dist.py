@@ -50,20 +50,28 @@ def packed_layout(n, words):
     return o_codes, o_mask, o_len, o_key, o_key + n
 
 
+def raw_layout(n, words):
+    """a contig set with letters beyond ACGTN (lower case, IUPAC codes) carries two more sections behind packed_layout's:
+    [original bytes, 16 per code word: 4 * words][one byte per sequence, 1 = its row counts: ceil(n/4)] -> (o_raw, o_flags, total)"""
+    o_raw = packed_layout(n, words)[4]
+    o_flags = o_raw + 4 * words
+    return o_raw, o_flags, o_flags + (n + 3) // 4
+
+
 def allgather_packed(dist, buf, n, words, key_base, world):
-    """buf: this rank's packed int32 buffer (packed_layout(n, words)).  Returns [(buf_r, n_r, words_r, key_base_r)] for all
-    ranks.  Two collectives: the sizes (3 int64) and the data."""
+    """buf: this rank's packed int32 buffer (packed_layout(n, words), or raw_layout's longer form).  Returns [(buf_r, n_r, words_r,
+    key_base_r)] for all ranks.  Two collectives: the sizes (4 int64) and the data."""
     import torch
-    meta = torch.tensor([int(n), int(words), int(key_base)], dtype=torch.int64, device=buf.device)
+    meta = torch.tensor([int(n), int(words), int(key_base), int(buf.numel())], dtype=torch.int64, device=buf.device)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta)
     metas = [[int(v) for v in m.tolist()] for m in metas]
-    mx = max(packed_layout(m[0], m[1])[4] for m in metas)
+    mx = max(m[3] for m in metas)
     pad = torch.zeros(max(mx, 1), dtype=torch.int32, device=buf.device)
     pad[: buf.numel()] = buf
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
-    return [(p[: packed_layout(m[0], m[1])[4]], m[0], m[1], m[2]) for p, m in zip(parts, metas)]
+    return [(p[: m[3]], m[0], m[1], m[2]) for p, m in zip(parts, metas)]
 
 
 def merge_packed(parts):
@@ -78,6 +86,24 @@ def merge_packed(parts):
         lens.append(buf[ol: ol + n])
         keys.append(buf[ok: ok + n].to(torch.int64) + int(base))
     return torch.cat(codes), torch.cat(masks), torch.cat(lens), torch.cat(keys)
+
+
+def merge_raw(parts):
+    """(original bytes uint8[16 * words], row flags uint8[n]) of the merged set, or None when no rank's contigs carry letters
+    beyond ACGTN (a rank without such letters contributes rows that do not count)"""
+    import torch
+    if not any(buf.numel() > packed_layout(n, words)[4] for buf, n, words, _ in parts):
+        return None
+    raws, flags = [], []
+    for buf, n, words, _ in parts:
+        if buf.numel() > packed_layout(n, words)[4]:
+            o_raw, o_flags, total = raw_layout(n, words)
+            raws.append(buf[o_raw: o_flags].view(torch.uint8)[: 16 * words])
+            flags.append(buf[o_flags: total].view(torch.uint8)[:n])
+        else:
+            raws.append(torch.zeros(16 * words, dtype=torch.uint8, device=buf.device))
+            flags.append(torch.zeros(n, dtype=torch.uint8, device=buf.device))
+    return torch.cat(raws), torch.cat(flags)
 
 
 def allgather_variable(dist, tensors, world):
@@ -106,11 +132,16 @@ def pack_contigs(ctx, asm_db):
     n, words = contigs.n, contigs.words
     dev = torch.device("cuda", torch.cuda.current_device())
     oc, om, ol, ok, total = packed_layout(n, words)
+    o_raw, o_flags, total_raw = raw_layout(n, words)
+    if contigs.has_raw:
+        total = total_raw
     buf = torch.zeros(max(total, 1), dtype=torch.int32, device=dev)
     # the library copies on its own (non-blocking) stream: torch's zero fill has to be complete before it starts
     torch.cuda.synchronize()
     base = buf.data_ptr()
     contigs.copy_packed(base + 4 * oc, base + 4 * om, base + 4 * ol, base + 4 * ok)     # (synchronises the library's stream)
+    if contigs.has_raw:
+        contigs.copy_raw(base + 4 * o_raw, base + 4 * o_flags)
     return buf[:total], n, words
 
 
@@ -122,8 +153,14 @@ def unpack_to_db(ctx, parts, ext_value=1):
         raise ValueError("contig keys overflow 32 bits")
     k32 = k.to(torch.int32).contiguous()
     c, m, l = c.contiguous(), m.contiguous(), l.contiguous()
+    raw = merge_raw(parts)
+    if raw is not None:
+        raw = (raw[0].contiguous(), raw[1].contiguous())
     torch.cuda.synchronize()     # torch's stream wrote the merged tensors; the library reads them on its own stream
-    return ctx.from_packed(c.data_ptr(), m.data_ptr(), l.data_ptr(), k32.data_ptr(), int(l.numel()), int(c.numel()), ext_value)
+    db = ctx.from_packed(c.data_ptr(), m.data_ptr(), l.data_ptr(), k32.data_ptr(), int(l.numel()), int(c.numel()), ext_value)
+    if raw is not None and int(c.numel()):
+        db.attach_raw(raw[0].data_ptr(), raw[1].data_ptr())
+    return db
 
 
 def allgather_contigs(dist, ctx, asm_db, world, key_base):

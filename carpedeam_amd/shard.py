@@ -245,7 +245,17 @@ def pack_owned(ctx, db, lo, hi):
     w0, w1 = int(woff[lo].item()), int(woff[hi].item())
     m, w = hi - lo, w1 - w0
     oc, om, ol, ok, oe, total = seq_section_layout(m, w)
+    has_raw = db.has_raw
+    if has_raw:         # letters beyond ACGTN: [original bytes, 16 per code word: 4 * w][row flags: ceil(m/4)] behind the rest
+        o_raw, o_flags, total = total, total + 4 * w, total + 4 * w + (m + 3) // 4
     buf = torch.zeros(max(total, 1), dtype=torch.int32, device=dev)
+    if has_raw:
+        raw = torch.empty(max(16 * words, 1), dtype=torch.uint8, device=dev)
+        flags = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        db.copy_raw(raw.data_ptr(), flags.data_ptr())
+        buf[o_raw: o_flags].view(torch.uint8)[: 16 * w] = raw[16 * w0: 16 * w1]
+        buf[o_flags: total].view(torch.uint8)[:m] = flags[lo:hi]
     buf[oc: oc + w] = codes[w0:w1]
     buf[om: ol].view(torch.int16)[:w] = mask[w0:w1]
     buf[ol: ol + m] = lens[lo:hi]
@@ -260,17 +270,27 @@ def merge_owned(ctx, db_local, comm):
     n = db_local.n
     lo, hi = owned_range(comm.rank, comm.world, n)
     buf, m, w = pack_owned(ctx, db_local, lo, hi)
-    metas = comm.all_gather_array(np.array([m, w], np.int64))
+    metas = comm.all_gather_array(np.array([m, w, int(buf.numel())], np.int64))
     bufs = comm.all_gather_tensor(buf)
-    codes, masks, lens, keys, exts = [], [], [], [], []
-    for b, (mm, ww) in zip(bufs, metas):
+    codes, masks, lens, keys, exts, raws, flags = [], [], [], [], [], [], []
+    any_raw = any(int(sz) > seq_section_layout(int(mm), int(ww))[5] for mm, ww, sz in metas)
+    for b, (mm, ww, sz) in zip(bufs, metas):
         mm, ww = int(mm), int(ww)
         oc, om, ol, ok, oe, total = seq_section_layout(mm, ww)
         codes.append(b[oc: oc + ww]); masks.append(b[om: ol].view(torch.int16)[:ww]); lens.append(b[ol: ol + mm]); keys.append(b[ok: ok + mm])
         exts.append(b[oe: total].view(torch.uint8)[:mm])
+        if int(sz) > total:
+            raws.append(b[total: total + 4 * ww].view(torch.uint8)[: 16 * ww]); flags.append(b[total + 4 * ww: total + 4 * ww + (mm + 3) // 4].view(torch.uint8)[:mm])
+        elif any_raw:
+            raws.append(torch.zeros(16 * ww, dtype=torch.uint8, device=b.device)); flags.append(torch.zeros(mm, dtype=torch.uint8, device=b.device))
     c, k16, l, k, e = (torch.cat(x).contiguous() for x in (codes, masks, lens, keys, exts))
+    if any_raw:
+        r8, f8 = torch.cat(raws).contiguous(), torch.cat(flags).contiguous()
     torch.cuda.synchronize()
-    return ctx.from_packed_ext(c.data_ptr(), k16.data_ptr(), l.data_ptr(), k.data_ptr(), e.data_ptr(), int(l.numel()), int(c.numel()))
+    out = ctx.from_packed_ext(c.data_ptr(), k16.data_ptr(), l.data_ptr(), k.data_ptr(), e.data_ptr(), int(l.numel()), int(c.numel()))
+    if any_raw and int(c.numel()):
+        out.attach_raw(r8.data_ptr(), f8.data_ptr())
+    return out
 
 
 def exact_iteration(ctx, db, comm, kpar=None, rpar=None, apar=None):

@@ -70,7 +70,7 @@ float cdm_ctx_last_kernel_ms(cdm_ctx *ctx, int which);
  * NucleotideMatrix::setupLetterMapping does (lib/mmseqs/src/commons/NucleotideMatrix.cpp:17-61) for kmermatcher, the
  * diagonal score and reverse complements, and the sequence keeps its original bytes in a side plane for the consumers
  * that look at them (nucleotideMap[c] of the assembler modules, letter identity, the letters copied to the output);
- * cdm_seqdb_download gives them back.  cdm_seqdb_copy_packed (the multi-GPU exchange format) refuses such a DB.
+ * cdm_seqdb_download gives them back; the multi-GPU exchange carries them in a section of its own (cdm_seqdb_copy_raw).
  */
 int cdm_seqdb_upload(cdm_ctx *ctx, const char *data, const uint64_t *offsets, const uint32_t *lengths,
                      const uint32_t *keys, const uint8_t *ext, uint64_t n, cdm_seqdb **out);
@@ -98,6 +98,13 @@ uint64_t cdm_seqdb_words(const cdm_seqdb *db);
 int cdm_seqdb_copy_packed(cdm_ctx *ctx, const cdm_seqdb *db, void *dev_codes, void *dev_nmask16, void *dev_lengths, void *dev_keys);
 int cdm_seqdb_from_packed(cdm_ctx *ctx, const void *dev_codes, const void *dev_nmask16, const void *dev_lengths, const void *dev_keys,
                           uint64_t n, uint64_t words, uint8_t ext_value, cdm_seqdb **out);
+/* A DB with letters beyond ACGTN (cdm_seqdb_has_raw != 0) has more to hand over than the packed form holds: the original bytes,
+ * 16 per code word (dev_raw: words * 16 bytes; rows of sequences without such letters are undefined), and one byte per sequence
+ * saying whether its row counts (dev_flags: n bytes).  cdm_seqdb_attach_raw gives them to a DB rebuilt by cdm_seqdb_from_packed*;
+ * an exchange that leaves them out would silently turn 'acgt' into what NucleotideMatrix maps it to. */
+int cdm_seqdb_has_raw(const cdm_seqdb *db);
+int cdm_seqdb_copy_raw(cdm_ctx *ctx, const cdm_seqdb *db, void *dev_raw, void *dev_flags);
+int cdm_seqdb_attach_raw(cdm_ctx *ctx, cdm_seqdb *db, const void *dev_raw, const void *dev_flags);
 /* the same with one wasExtended flag per sequence (device array of n bytes, NULL = all 0), and the flags of a DB copied out:
  * the query-sharded stages of a multi-GPU run hand whole DB slices around, flags included */
 int cdm_seqdb_from_packed_ext(cdm_ctx *ctx, const void *dev_codes, const void *dev_nmask16, const void *dev_lengths, const void *dev_keys,

@@ -146,6 +146,47 @@ def test_exact_scheme_equals_single_device(dhigh_prefix, world):
             assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
 
 
+def test_letters_travel_through_both_exchanges(ctx, oracle_bin, dhigh_prefix, tmp_path):
+    """reads with lower-case stretches and IUPAC codes (tests/golden/letters): the contigs of two read shards merged through the
+    packed exchange equal the oracle's on the same shards, letter for letter, and the exact scheme on two ranks gives the
+    single-device DBs - the original bytes travel in a section of their own (cdm_seqdb_copy_raw / attach_raw)"""
+    from carpedeam_amd import shard
+    from gpuutil import gold
+    reads = gold("letters", "reads")
+    seqs = [reads[k][0].rstrip(b"\n") for k in sorted(reads)]
+    t = lambda s: str(tmp_path / s)
+    parts, want = [], {}
+    for rank in range(2):
+        lo, hi = rank * len(seqs) // 2, (rank + 1) * len(seqs) // 2
+        db = ctx.upload_seqs(seqs[lo:hi])
+        alns = ctx.rescore(db, ctx.kmermatch(db))
+        asm = ctx.extend(ctx.correct(db, alns), alns)
+        buf, n, words = cd.pack_contigs(ctx, asm)
+        parts.append((buf.clone(), n, words, lo))
+        for k, (payload, ext) in oracle_chain(oracle_bin, dhigh_prefix, t, "l%d" % rank, seqs[lo:hi]).items():
+            if ext == 1:
+                want[k + lo] = payload
+    got_seqs, keys, _ = cd.unpack_to_db(ctx, parts).download()
+    got = {int(k): bytes(s) + b"\n" for s, k in zip(got_seqs, keys)}
+    assert len(want) > 100 and any(c in b"acgtRYKMn" for v in want.values() for c in v)
+    assert got == want
+    # exact scheme
+    db = ctx.upload_seqs(seqs)
+    alns = ctx.rescore(db, ctx.kmermatch(db)); corr = ctx.correct(db, alns); asm = ctx.extend(corr, alns)
+    want_corr, want_asm = corr.download(), asm.download()
+
+    def rank_fn(rank, comm):
+        c = capi.Ctx(0)
+        c.damage_load(dhigh_prefix)
+        h, a, co, nx = shard.exact_iteration(c, c.upload_seqs(seqs), comm)
+        return co.download(), nx.download()
+
+    for r in run_ranks(2, rank_fn):
+        for got, exp in ((r[0], want_corr), (r[1], want_asm)):
+            assert [bytes(x) for x in got[0]] == [bytes(x) for x in exp[0]]
+            assert np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2])
+
+
 def test_exact_kmermatcher_on_small_databases(dhigh_prefix):
     """Tiny random databases, where the reference's quirks decide records (the first group's strand, the run-past-the-end
     scan, identical sequences = whole-sequence hash groups): 2, 3 and 5 k-mer ranges against the single-device result."""
