@@ -495,7 +495,11 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
     if (smallW == 8) hipLaunchKernelGGL((k_correct_fast<15, uint8_t, 8>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeSmall.p, counters.p + 3);
     else if (smallW == 5) hipLaunchKernelGGL((k_correct_fast<15, uint8_t, 5>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeSmall.p, counters.p + 3);
     else if (smallW) hipLaunchKernelGGL((k_correct_fast<15, uint8_t, 6>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeSmall.p, counters.p + 3);
-    hipLaunchKernelGGL((k_correct_fast<64, uint16_t, 4>), dim3(blocks), dim3(64 * FAST_WAVES), pad, s, a, activeFast.p, counters.p + 2);
+    const char *bigEnv = getenv("CDM_CORRECT_BIGW");     // experiments: waves per SIMD of the 16..64-record instance
+    const int bigW = bigEnv ? atoi(bigEnv) : 5;
+    if (bigW == 6) hipLaunchKernelGGL((k_correct_fast<64, uint16_t, 6>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeFast.p, counters.p + 2);
+    else if (bigW == 5) hipLaunchKernelGGL((k_correct_fast<64, uint16_t, 5>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeFast.p, counters.p + 2);
+    else hipLaunchKernelGGL((k_correct_fast<64, uint16_t, 4>), dim3(blocks), dim3(64 * FAST_WAVES), pad, s, a, activeFast.p, counters.p + 2);
     hipLaunchKernelGGL(k_correct, dim3(blocks / 2), dim3(64 * WAVES_PER_BLOCK), 0, s, a);
     hipEventRecord(ctx->ev1, s);
     CDM_LAUNCH_CHECK();
