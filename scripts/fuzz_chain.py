@@ -3,7 +3,8 @@
 modes: small, deep (100x+ pile-ups, > 64 records per query), repeats (low-complexity / tandem repeats), contigparams (k = 22,
 include-only-extendable), longreads (up to 600 bp: general extraction kernel), nrich (N letters), verylong (wide tuple layout), tiling (chains of
 extensions), tiny (reads around and below k), palrepeats (tandem repeats of reverse-palindromic
-units: comparator ties in the per-sequence k-mer sort), letters (lower-case stretches, IUPAC codes, bytes that are no letters)."""
+units: comparator ties in the per-sequence k-mer sort), letters (lower-case stretches, IUPAC codes, bytes that are no letters;
+FUZZ_LETTERS=1 in the environment puts them on top of any other mode)."""
 import os
 import subprocess
 import sys
@@ -66,7 +67,7 @@ for case in range(cases):
         if rng.random() < nprob:
             for _n in range(int(rng.integers(1, 6)) if mode == "nrich" else 1):
                 k = int(rng.integers(0, L)); sq = sq[:k] + "N" + sq[k + 1:]
-        if mode == "letters":
+        if mode == "letters" or os.environ.get("FUZZ_LETTERS"):      # FUZZ_LETTERS=1: the letters of that mode on top of any other mode
             r = rng.random()
             b = bytearray(sq.encode())
             if r < 0.25:
