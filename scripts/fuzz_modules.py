@@ -1,5 +1,7 @@
 """Fuzz the drop-in surface: the `carpedeam` host binary, module by module on DB files, against the oracle's DB files (and the
-ancient_reads_loop against the stage-by-stage chain).  Test infrastructure; run on a GPU box:
+ancient_reads_loop against the stage-by-stage chain): two iterations of the reads loop, then two of the contig phase (kmermatcher
+-k 22, rescorediagonal, ancient_correction, ancient_contig_merge, cyclecheck).  FUZZ_LETTERS=1 adds lower-case stretches, IUPAC
+codes and non-letters to the reads.  Test infrastructure; run on a GPU box:
     python scripts/fuzz_modules.py <cases> <seed>"""
 import os
 import subprocess
@@ -13,7 +15,7 @@ import numpy as np
 
 from carpedeam_amd import mmdb, synth
 from gpuutil import diff_keys
-from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
+from stageflags import A_FLAGS, AC_FLAGS, K_FLAGS, KC_FLAGS, R_FLAGS
 from test_oracle_golden import pref_sign_ties
 
 cases, seed = int(sys.argv[1]), int(sys.argv[2])
@@ -50,6 +52,16 @@ for case in range(cases):
         sq = letters[c].tobytes().decode()
         if rng.random() < 0.1:
             k = int(rng.integers(0, L)); sq = sq[:k] + "N" + sq[k + 1:]
+        if os.environ.get("FUZZ_LETTERS") and rng.random() < 0.5:
+            b = bytearray(sq.encode())
+            if rng.random() < 0.5:
+                a0 = int(rng.integers(0, L)); a1 = min(L, a0 + int(rng.integers(1, 60)))
+                b[a0:a1] = bytes(b[a0:a1]).lower()
+            else:
+                odd = b"RYSWKMBDHVUNXryswkmbdhvunx*-.1acgt"
+                for _n in range(int(rng.integers(1, 4))):
+                    b[int(rng.integers(0, L))] = odd[int(rng.integers(0, len(odd)))]
+            sq = b.decode()
         seqs.append(sq)
     # keys need not be 0..n-1: the modules look sequences up by key
     keys = sorted(rng.choice(np.arange(0, 4 * len(seqs)), len(seqs), replace=False).tolist()) if rng.random() < 0.5 else list(range(len(seqs)))
@@ -80,6 +92,36 @@ for case in range(cases):
                 fails += 1
                 print("FAIL case", case, "iter", it, bad, flush=True)
                 break
+        else:
+            # the contig phase (data/nuclassemble.sh:148-232), module by module; every module starts from the oracle's upstream DBs
+            dmg = ["--ancient-damage", t("dhigh"), "--threads", "1"]
+            for it in range(2, 4):
+                i, o = t("in%d" % it), t("in%d" % (it + 1))
+                th = ["--threads", "1"]
+                bad = []
+                run(ORACLE, "kmermatcher", i, t("prefO"), *KC_FLAGS, *th); run(BIN, "kmermatcher", i, t("pref"), *KC_FLAGS, *th)
+                gp, ep = mmdb.canon(mmdb.read_db(t("pref"))), mmdb.canon(mmdb.read_db(t("prefO")))
+                if gp != ep and pref_sign_ties(gp, ep)[1]:
+                    bad.append(("cpref", str(pref_sign_ties(gp, ep)[1])[:200]))
+                run(ORACLE, "rescorediagonal", i, i, t("prefO"), t("alnO"), *R_FLAGS, *th); run(BIN, "rescorediagonal", i, i, t("prefO"), t("aln"), *R_FLAGS, *th)
+                if diff_keys(mmdb.read_db(t("aln")), mmdb.read_db(t("alnO"))):
+                    bad.append(("caln", str(diff_keys(mmdb.read_db(t("aln")), mmdb.read_db(t("alnO"))))[:200]))
+                run(ORACLE, "ancient_correction", i, t("alnO"), t("corrO"), *AC_FLAGS, *dmg); run(BIN, "ancient_correction", i, t("alnO"), t("corr"), *AC_FLAGS, *dmg)
+                if diff_keys(mmdb.read_db(t("corr")), mmdb.read_db(t("corrO"))):
+                    bad.append(("ccorr", ""))
+                run(ORACLE, "ancient_contig_merge", t("corrO"), t("alnO"), o, *AC_FLAGS, *dmg); run(BIN, "ancient_contig_merge", t("corrO"), t("alnO"), t("mrg"), *AC_FLAGS, *dmg)
+                if diff_keys(mmdb.read_db(t("mrg")), mmdb.read_db(o)):
+                    bad.append(("cmerge", str(diff_keys(mmdb.read_db(t("mrg")), mmdb.read_db(o)))[:200]))
+                cyc = ["--chop-cycle", str(int(rng.integers(0, 2))), "--max-seq-len", "200000"]
+                run(ORACLE, "cyclecheck", o, t("cycO"), *cyc); run(BIN, "cyclecheck", o, t("cyc"), *cyc)
+                if diff_keys(mmdb.read_db(t("cyc")), mmdb.read_db(t("cycO"))):
+                    bad.append(("cyclecheck", str(diff_keys(mmdb.read_db(t("cyc")), mmdb.read_db(t("cycO"))))[:200]))
+                if bad:
+                    fails += 1
+                    print("FAIL case", case, "iter", it, bad, flush=True)
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    mmdb.write_db(os.path.join(ROOT, "gpurun_out", "fuzzm_fail_%d_%d" % (seed, case)), [(k, v[0]) for k, v in sorted(mmdb.read_db(i).items())], mmdb.DBTYPE_NUCLEOTIDES)
+                    break
     except RuntimeError as e:
         fails += 1
         print("ERROR case", case, str(e)[:500], flush=True)
