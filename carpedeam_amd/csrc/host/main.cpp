@@ -90,6 +90,16 @@ void checkFlags(const char *module, const Args &a, const FlagSpec *spec, const c
 float fflag(Args &a, const char *n, float d) { return a.flag.count(n) ? strtof(a.flag[n].c_str(), NULL) : d; }
 long iflag(Args &a, const char *n, long d) { return a.flag.count(n) ? strtol(a.flag[n].c_str(), NULL, 10) : d; }
 
+// CDM_TIMING=1: where a module's wall time goes (stderr)
+struct Laps {
+    bool on; std::chrono::steady_clock::time_point t;
+    Laps() : on(getenv("CDM_TIMING") != NULL), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "  %-32s %.3f s\n", what, std::chrono::duration<double>(n - t).count()); t = n;
+    }
+};
 cdm_ctx *openCtx() {
     cdm_ctx *ctx = NULL;
     const char *dev = getenv("CARPEDEAM_DEVICE");
@@ -130,6 +140,22 @@ void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype)
 // ---- text codecs
 char *utoa(unsigned long long v, char *p) { char b[24]; int n = 0; do { b[n++] = '0' + v % 10; v /= 10; } while (v); while (n) *p++ = b[--n]; return p; }
 char *itoa(long long v, char *p) { if (v < 0) { *p++ = '-'; return utoa((unsigned long long) -v, p); } return utoa(v, p); }
+// ---- parsers for the tab-separated records (strtol / strtod walk the locale machinery: 10x the time of these)
+// unsigned / signed decimal at d; d moves behind the digits (no digits: 0, as strtol gives)
+inline unsigned long parseU(const char *&d) { unsigned long v = 0; while (*d >= '0' && *d <= '9') v = v * 10 + (unsigned long) (*d++ - '0'); return v; }
+inline long parseI(const char *&d) { bool neg = false; if (*d == '-') { neg = true; d++; } else if (*d == '+') d++; const long v = (long) parseU(d); return neg ? -v : v; }
+// a plain decimal "digits[.digits]" with at most 15 significant digits is mantissa / 10^k, both exact doubles: the division is
+// correctly rounded, i.e. the very double strtod returns.  Anything else (exponents, inf, nan, long mantissas) goes to strtod.
+inline double parseDecimal(const char *&d) {
+    static const double P10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+    const char *p = d; unsigned long m = 0; int digits = 0, frac = 0;
+    while (*p >= '0' && *p <= '9') { m = m * 10 + (unsigned long) (*p++ - '0'); digits++; }
+    if (*p == '.') { p++; while (*p >= '0' && *p <= '9') { m = m * 10 + (unsigned long) (*p++ - '0'); digits++; frac++; } }
+    if (digits == 0 || digits > 15 || *p == 'e' || *p == 'E' || (*p != '\t' && *p != '\n' && *p != '\0')) { char *e; const double v = strtod(d, &e); d = e; return v; }
+    d = p;
+    return (double) m / P10[frac];
+}
+inline void skipField(const char *&d) { while (*d && *d != '\t' && *d != '\n') d++; }
 char *seqIdText(float s, char *p) {   // Util::fastSeqIdToBuffer + the tab overwriting its last char (Util.cpp:278-307, Matcher.cpp:362-363)
     if (s == 1.0) { memcpy(p, "1.00", 4); return p + 4; }
     *p++ = '0'; *p++ = '.';
@@ -156,7 +182,7 @@ void gatherParts(std::vector<std::vector<R>> &parts, const std::vector<uint32_t>
     }
 }
 void parseAlnDb(const MmDb &aln, const MmDb &seq, std::vector<uint64_t> &off, std::vector<cdm_aln> &rec) {   // Matcher.cpp:274-353
-    const double lam = 0x1.4478764a1b24ap-1, logk = log(0x1.a1c1e68ea2ab1p-2);
+    const double lam = 0x1.4478764a1b24ap-1, logk = log(0x1.a1c1e68ea2ab1p-2), LN2 = std::log(2.0);
     const int T = std::max(1, omp_get_max_threads());
     std::vector<std::vector<cdm_aln>> parts(T); std::vector<uint32_t> cnt(seq.size(), 0);
     long badKey = -1;
@@ -165,19 +191,21 @@ void parseAlnDb(const MmDb &aln, const MmDb &seq, std::vector<uint64_t> &off, st
         const int t = omp_get_thread_num();
         size_t lo, hi; sliceOf(seq.size(), t, T, lo, hi);
         std::vector<cdm_aln> &out = parts[t];
+        out.reserve(aln.dataSize() / 36 / (size_t) T + 1024);              // (a record is 36+ characters)
         for (size_t i = lo; i < hi; i++) {
             const int64_t a = aln.idOf(seq.key[i]);
             if (a < 0) continue;
             const char *d = aln.entry(a);
             const size_t before = out.size();
             while (*d) {
-                char *e; cdm_aln r;
-                const uint32_t tkey = strtoul(d, &e, 10); d = e + 1;
-                const int bits = strtol(d, &e, 10); d = e + 1;
-                r.seq_id = (float) strtod(d, &e); d = e + 1;
-                strtod(d, &e); d = e + 1;
-                r.q_start = strtol(d, &e, 10); d = e + 1; r.q_end = strtol(d, &e, 10); d = e + 1; strtol(d, &e, 10); d = e + 1;
-                r.db_start = strtol(d, &e, 10); d = e + 1; r.db_end = strtol(d, &e, 10); d = e + 1; strtol(d, &e, 10); d = e;
+                cdm_aln r;
+                auto tab = [&] { if (*d == '\t') d++; };
+                const uint32_t tkey = (uint32_t) parseU(d); tab();
+                const int bits = (int) parseI(d); tab();
+                r.seq_id = (float) parseDecimal(d); tab();
+                skipField(d); tab();                                   // the E-value is not read back
+                r.q_start = (int) parseI(d); tab(); r.q_end = (int) parseI(d); tab(); skipField(d); tab();
+                r.db_start = (int) parseI(d); tab(); r.db_end = (int) parseI(d); tab(); skipField(d);
                 const int64_t tt = seq.idOf(tkey);
                 if (tt < 0) {
 #pragma omp critical
@@ -185,7 +213,7 @@ void parseAlnDb(const MmDb &aln, const MmDb &seq, std::vector<uint64_t> &off, st
                     break;
                 }
                 r.target = (uint32_t) tt; r.ident = -1;
-                r.raw_score = static_cast<int>((logk + bits * std::log(2.0)) / lam + 0.5);   // computeRawScoreFromBitScore as the consumers do
+                r.raw_score = static_cast<int>((logk + bits * LN2) / lam + 0.5);   // computeRawScoreFromBitScore as the consumers do
                 out.push_back(r);
                 while (*d && *d != '\n') d++;
                 if (*d == '\n') d++;
@@ -208,9 +236,11 @@ cdm_ancient_params ancientParams(Args &a) {
 int kmermatcher(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam kmermatcher <i:sequenceDB> <o:prefilterDB>");
     checkFlags("kmermatcher", a, KMERMATCHER_FLAGS);
+    Laps laps;
     MmDb seq; std::string err; if (!seq.load(a.pos[0], &err)) die(err);
-    cdm_ctx *ctx = openCtx();
-    cdm_seqdb *db = uploadSeqDb(ctx, seq);
+    laps.lap("DB files mapped");
+    cdm_ctx *ctx = openCtx(); laps.lap("device context");
+    cdm_seqdb *db = uploadSeqDb(ctx, seq); laps.lap("sequences up");
     cdm_kmer_params p;
     p.kmer_size = (int) iflag(a, "-k", 15); p.kmers_per_seq = (int) iflag(a, "--kmer-per-seq", 21); p.kmers_per_seq_scale = fflag(a, "--kmer-per-seq-scale", 0.2f);
     p.hash_shift = (uint64_t) iflag(a, "--hash-shift", 67); p.ignore_multi_kmer = (int) iflag(a, "--ignore-multi-kmer", 0);
@@ -219,6 +249,7 @@ int kmermatcher(Args &a) {
     check(cdm_kmermatch(ctx, db, &p, &hits), "kmermatcher");
     std::vector<uint64_t> off(seq.size() + 1); std::vector<cdm_hit> rec(cdm_hits_count(hits));
     check(cdm_hits_download(ctx, hits, off.data(), rec.data()), "download");
+    laps.lap("kernels, hits down");
     const int T = std::max(1, omp_get_max_threads());
     std::vector<OutChunk> chunks(T);
 #pragma omp parallel num_threads(T)
@@ -237,7 +268,9 @@ int kmermatcher(Args &a) {
             c.add(seq.key[i], out.data(), out.size(), (off[i + 1] - off[i] > 1) ? 0 : seq.ext[i]);
         }
     }
+    laps.lap("prefilter text formatted");
     if (!mmdbWriteChunks(a.pos[1], 14, chunks, &err)) die(err);   // DBTYPE_PREFILTER_REV_RES (kmermatcher.cpp:682)
+    laps.lap("result DB written");
     cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
@@ -248,8 +281,9 @@ int rescorediagonal(Args &a) {
     if (a.pos[0] != a.pos[1]) die("rescorediagonal: query and target DB must be the same on the MI355X path");
     if (!a.flag.count("--rescore-mode")) die("rescorediagonal: --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
     MmDb seq, pref; std::string err; if (!seq.load(a.pos[1], &err) || !pref.load(a.pos[2], &err)) die(err);
-    cdm_ctx *ctx = openCtx();
-    cdm_seqdb *db = uploadSeqDb(ctx, seq);
+    Laps laps; laps.lap("DB files mapped");
+    cdm_ctx *ctx = openCtx(); laps.lap("device context");
+    cdm_seqdb *db = uploadSeqDb(ctx, seq); laps.lap("sequences up");
     std::vector<uint64_t> off; std::vector<cdm_hit> rec;
     const int T = std::max(1, omp_get_max_threads());
     {
@@ -260,14 +294,15 @@ int rescorediagonal(Args &a) {
             const int t = omp_get_thread_num();
             size_t lo, hi; sliceOf(seq.size(), t, T, lo, hi);
             std::vector<cdm_hit> &out = parts[t];
+            out.reserve(pref.dataSize() / 8 / (size_t) T + 1024);
             for (size_t i = lo; i < hi; i++) {   // QueryMatcher::parsePrefilterHits
                 const int64_t pi = pref.idOf(seq.key[i]);
                 if (pi < 0) continue;
                 const char *d = pref.entry(pi);
                 const size_t before = out.size();
                 while (*d) {
-                    char *e; cdm_hit h;
-                    const uint32_t tkey = strtoul(d, &e, 10); d = e + 1; h.score = strtol(d, &e, 10); d = e + 1; h.diagonal = (short) strtol(d, &e, 10); d = e;
+                    cdm_hit h;
+                    const uint32_t tkey = (uint32_t) parseU(d); if (*d == '\t') d++; h.score = (int) parseI(d); if (*d == '\t') d++; h.diagonal = (short) parseI(d);
                     const int64_t tt = seq.idOf(tkey);
                     if (tt < 0) {
 #pragma omp critical
@@ -284,6 +319,7 @@ int rescorediagonal(Args &a) {
         if (badKey >= 0) die("Invalid database read for key " + std::to_string(badKey));
         gatherParts(parts, cnt, off, rec);
     }
+    laps.lap("prefilter text parsed");
     cdm_hits *hits = NULL; cdm_alns *alns = NULL;
     check(cdm_hits_upload(ctx, db, off.data(), rec.data(), &hits), "upload");
     cdm_rescore_params p;
@@ -292,6 +328,7 @@ int rescorediagonal(Args &a) {
     check(cdm_rescore(ctx, db, hits, &p, &alns), "rescorediagonal");
     std::vector<uint64_t> aoff(seq.size() + 1); std::vector<cdm_aln> arec(cdm_alns_count(alns));
     check(cdm_alns_download(ctx, alns, aoff.data(), arec.data()), "download");
+    laps.lap("hits up, kernels, records down");
     const uint64_t dbRes = cdm_seqdb_residues(db);
     std::vector<OutChunk> chunks(T);
 #pragma omp parallel num_threads(T)
@@ -300,6 +337,9 @@ int rescorediagonal(Args &a) {
         size_t lo, hi; sliceOf(seq.size(), t, T, lo, hi);
         OutChunk &c = chunks[t];
         std::string out; char b[256];
+        // the E-value text and bit score of (raw score, query length) recur all over a read set: formatted once per thread
+        struct EvalText { int qLen = -1, score = -1, bits = 0; unsigned char n = 0; char txt[15]; };
+        std::vector<EvalText> cache(1u << 14);
         for (size_t i = lo; i < hi; i++) {
             if (pref.idOf(seq.key[i]) < 0) continue;
             out.clear();
@@ -309,9 +349,14 @@ int rescorediagonal(Args &a) {
                 const int alnLen = std::max(abs(x.q_end - x.q_start), abs(x.db_end - x.db_start)) + 1;
                 const float sid = static_cast<float>(x.ident) / static_cast<float>(alnLen);
                 char *p2 = utoa(seq.key[x.target], b); *p2++ = '\t';
-                p2 = itoa(cdm_bit_score(x.raw_score), p2); *p2++ = '\t';
+                EvalText &ev = cache[((uint32_t) x.raw_score * 2654435761u ^ (uint32_t) qLen * 40503u) >> 18];
+                if (ev.qLen != qLen || ev.score != x.raw_score) {
+                    ev.qLen = qLen; ev.score = x.raw_score; ev.bits = cdm_bit_score(x.raw_score);
+                    ev.n = (unsigned char) snprintf(ev.txt, sizeof(ev.txt), "%.3E", cdm_evalue(x.raw_score, qLen, dbRes));
+                }
+                p2 = itoa(ev.bits, p2); *p2++ = '\t';
                 p2 = seqIdText(sid, p2); *p2++ = '\t';
-                p2 += sprintf(p2, "%.3E", cdm_evalue(x.raw_score, qLen, dbRes)); *p2++ = '\t';
+                memcpy(p2, ev.txt, ev.n); p2 += ev.n; *p2++ = '\t';
                 p2 = itoa(x.q_start, p2); *p2++ = '\t'; p2 = itoa(x.q_end, p2); *p2++ = '\t'; p2 = itoa(qLen, p2); *p2++ = '\t';
                 p2 = itoa(x.db_start, p2); *p2++ = '\t'; p2 = itoa(x.db_end, p2); *p2++ = '\t'; p2 = itoa((int) (seq.len[x.target] - 2), p2); *p2++ = '\n';
                 out.append(b, p2 - b);
@@ -319,7 +364,9 @@ int rescorediagonal(Args &a) {
             c.add(seq.key[i], out.data(), out.size(), 0);
         }
     }
+    laps.lap("alignment text formatted");
     if (!mmdbWriteChunks(a.pos[3], 5, chunks, &err)) die(err);
+    laps.lap("result DB written");
     cdm_alns_free(alns); cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
@@ -331,18 +378,20 @@ int ancientModule(Args &a, int mode) {      // 0 ancient_correction, 1 ancient_r
     checkFlags(name, a, ANCIENT_FLAGS);
     if (mode >= 1 && !a.flag.count("--rescore-mode")) die(std::string(name) + ": --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
     MmDb seq, aln; std::string err; if (!seq.load(a.pos[0], &err) || !aln.load(a.pos[1], &err)) die(err);
-    cdm_ctx *ctx = openCtx();
+    Laps laps; laps.lap("DB files mapped");
+    cdm_ctx *ctx = openCtx(); laps.lap("device context");
     check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");
-    cdm_seqdb *db = uploadSeqDb(ctx, seq);
+    cdm_seqdb *db = uploadSeqDb(ctx, seq); laps.lap("damage tables, sequences up");
     std::vector<uint64_t> off; std::vector<cdm_aln> rec;
-    parseAlnDb(aln, seq, off, rec);
+    parseAlnDb(aln, seq, off, rec); laps.lap("alignment text parsed");
     cdm_alns *alns = NULL; cdm_seqdb *out = NULL;
     check(cdm_alns_upload(ctx, db, off.data(), rec.data(), &alns), "upload");
     cdm_ancient_params p = ancientParams(a);
     if (assemble) check(cdm_extend(ctx, db, alns, &p, &out, NULL), "ancient_read_assemble");
     else if (mode == 2) check(cdm_contig_merge(ctx, db, alns, &p, fflag(a, "--min-merge-seq-id", 0.99f), &out), "ancient_contig_merge");
     else check(cdm_correct(ctx, db, alns, &p, &out), "ancient_correction");
-    writeSeqDb(ctx, out, a.pos[2], seq.dbtype);
+    laps.lap("records up, kernels");
+    writeSeqDb(ctx, out, a.pos[2], seq.dbtype); laps.lap("sequences down, DB written");
     cdm_seqdb_free(out); cdm_alns_free(alns); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }

@@ -91,6 +91,7 @@ bool MmDb::load(const std::string &path, std::string *err) {
     return true;
 }
 int64_t MmDb::idOf(uint32_t k) const {
+    if (k < key.size() && key[k] == k) return (int64_t) k;      // dense keys 0..n-1 (what createdb writes): no search
     auto it = std::lower_bound(key.begin(), key.end(), k);
     return (it == key.end() || *it != k) ? -1 : (int64_t) (it - key.begin());
 }
