@@ -99,7 +99,6 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_contig_merge: NULL argument"); return CDM_ERR_INVALID; }
     if (!ctx->haveDamage) { cdm_set_error("cdm_contig_merge: call cdm_damage_load first"); return CDM_ERR_INVALID; }
     if (alns->n != db->n) { cdm_set_error("cdm_contig_merge: alignment CSR / DB size mismatch"); return CDM_ERR_INVALID; }
-    if (par->unsafe) { cdm_set_error("cdm_contig_merge: --unsafe 1 is not implemented for the contig phase"); return CDM_ERR_UNSUPPORTED; }
     CDM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const uint32_t n = (uint32_t) db->n;

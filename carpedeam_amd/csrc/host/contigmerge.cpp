@@ -6,6 +6,7 @@
 // exp come from the same C library, and the queue is the same libstdc++ std::priority_queue - the comparator is not a strict
 // weak ordering, so the order it produces is defined by that implementation and nothing else.
 #include <algorithm>
+#include <array>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -105,6 +106,59 @@ bool selectFragment(Queue &q, uint32_t queryKey, Res &out) {
     }
     return false;
 }
+inline int nucMap(char c) { return c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0; }      // nucleotideMap[c]; any other letter: 0
+// --unsafe 1 (not the workflow's default; the device statistics are the safe mode's, so this mode works on the host strings):
+// consensusCaller's majority vote over the candidates that extend the query (nuclassembleUtil.cpp:570-702, calculateConsensus
+// :535-567) - 3 qLen letters, the query in the middle third, elsewhere the majority letter where at least minCov candidates cover
+// the position ('N' below that and on ties)
+std::string unsafeConsensus(const std::vector<Res> &cands, const std::vector<std::string> &seqs, const std::string &q, uint32_t queryKey, unsigned minCov, bool &undefinedCase) {
+    const unsigned qLen = (unsigned) q.size();
+    std::vector<std::array<unsigned, 4>> cov(3 * (size_t) qLen, std::array<unsigned, 4>{{0, 0, 0, 0}});
+    for (const Res &c : cands) {
+        const bool rightStart = c.dbStartPos == 0 && (c.dbEndPos != static_cast<int>(c.dbLen) - 1);
+        const bool leftStart = c.qStartPos == 0 && (c.qEndPos != static_cast<int>(c.qLen) - 1);
+        if (!(rightStart || leftStart) || c.dbKey == queryKey) continue;
+        const std::string &t0 = seqs[c.target];
+        const unsigned tLen = (unsigned) t0.size();
+        long start;
+        if ((unsigned) c.dbStartPos == 0 && (unsigned) c.qEndPos == (qLen - 1)) start = (long) qLen + c.qStartPos;
+        else if ((unsigned) c.qStartPos == 0 && (unsigned) c.dbEndPos == (tLen - 1)) start = (long) qLen - (long) (c.dbLen - c.alnLength);
+        else continue;
+        if (start < 0) { undefinedCase = true; continue; }          // the reference indexes its coverage vector with a negative number there
+        const std::string t = c.isRev ? revComp(t0.data(), tLen) : std::string();
+        const char *ts = c.isRev ? t.data() : t0.data();
+        // (a target that reaches beyond the 3 qLen letters makes the reference write behind its vector; those letters are never read back)
+        for (unsigned p = 0; p < c.dbLen && (size_t) start + p < cov.size(); p++) cov[(size_t) start + p][nucMap(ts[p])] += 1;
+    }
+    std::string cons(3 * (size_t) qLen, 'N');
+    for (size_t i = 0; i < cov.size(); i++) {
+        const unsigned tot = cov[i][0] + cov[i][1] + cov[i][2] + cov[i][3];
+        if (tot < minCov) continue;
+        unsigned mx = 0; char nuc = 'N'; int nMax = 0;
+        for (int j = 0; j < 4; j++) { if (cov[i][j] > mx) { mx = cov[i][j]; nuc = "ACGT"[j]; nMax = 1; } else if (cov[i][j] == mx && mx > 0) nMax++; }
+        cons[i] = nMax > 1 ? 'N' : nuc;
+    }
+    for (unsigned p = 0; p < qLen; p++) cons[qLen + p] = q[p];
+    return cons;
+}
+// the columns updateSeqIdConsensus (:705-790) and ancientMatchCount (:1047-1181) walk in that mode: the padded target against the
+// whole consensus, flanks included -> defined columns, identical, same RY class, consensus C over target T, consensus G over target A
+void unsafeColumns(const Res &c, const std::string &cons, const std::string &t0, unsigned qLen, bool leftStart, int &tot, int &idc, int &idr, int &nCT, int &nGA) {
+    const unsigned tLen = (unsigned) t0.size();
+    const std::string t = c.isRev ? revComp(t0.data(), tLen) : std::string();
+    const char *ts = c.isRev ? t.data() : t0.data();
+    const unsigned offset = c.dbLen - c.alnLength;
+    // leftStart: N^(qLen - offset) target against cons[0..); rightStart: target N^(qLen - offset) against the end of cons
+    const size_t c0 = leftStart ? (size_t) (qLen - offset) : cons.size() - ((size_t) tLen + (qLen - offset));
+    tot = idc = idr = nCT = nGA = 0;
+    for (unsigned j = 0; j < tLen && c0 + j < cons.size(); j++) {
+        const char cq = cons[c0 + j], ct = ts[j];
+        if (cq == 'N' || ct == 'N') continue;
+        tot++; idc += (cq == ct); idr += (ryClass(cq) == ryClass(ct));
+        const int qb = nucMap(cq), tb = nucMap(ct);
+        nCT += (qb == 1 && tb == 3); nGA += (qb == 2 && tb == 0);
+    }
+}
 }  // namespace
 
 void cdm_host_split(const std::string &blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<std::string> &seqs) {
@@ -144,6 +198,22 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
             contigs.clear();
             Queue queue;
             // :187-235 orientation, identities (from the device), contig filter
+            const bool unsafeMode = par->unsafe != 0;
+            std::string cons;                               // --unsafe 1: the majority-vote consensus of this query's candidates
+            if (unsafeMode) {
+                contigs.clear();
+                for (uint64_t r = aoff[id]; r < aoff[id + 1]; r++) {
+                    const cdm_aln &a = recs[r]; const ContigStat &st = stats[r];
+                    Res x; x.target = a.target; x.dbKey = keys[a.target]; x.qLen = qLen; x.dbLen = (unsigned) seqs[a.target].size();
+                    x.alnLength = (unsigned) std::max(std::abs(a.q_end - a.q_start), std::abs(a.db_end - a.db_start)) + 1u;
+                    x.qStartPos = st.qs; x.qEndPos = st.qe; x.dbStartPos = st.ds; x.dbEndPos = st.de; x.isRev = st.rev != 0;
+                    x.seqId = static_cast<float>(st.idCnt) / x.alnLength; x.rySeqId = static_cast<float>(st.idRy) / x.alnLength;
+                    if (x.seqId >= mergeSeqIdThr && x.rySeqId >= ryThr && queryKey != x.dbKey) contigs.push_back(x);
+                }
+                bool undef = false;
+                if (!contigs.empty()) cons = unsafeConsensus(contigs, seqs, q0, queryKey, (unsigned) std::max(0, par->min_cov_safe), undef);
+                if (undef) undefinedCase = true;
+            }
             for (uint64_t r = aoff[id]; r < aoff[id + 1]; r++) {
                 const cdm_aln &a = recs[r]; const ContigStat &st = stats[r];
                 Res x; x.target = a.target; x.dbKey = keys[a.target];
@@ -157,10 +227,11 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
                     // :243 updateSeqIdConsensus against N^L query N^L (safe mode): the columns where both letters are defined
                     const bool rightStart = (unsigned) x.dbStartPos == 0 && (unsigned) x.qEndPos == (qLen - 1);
                     const bool leftStart = (unsigned) x.qStartPos == 0 && (unsigned) x.dbEndPos == (x.dbLen - 1);
-                    int tot = 0, idc = 0, idr = 0;
+                    int tot = 0, idc = 0, idr = 0, nCT = st.nCT, nGA = st.nGA;
                     if (leftStart || rightStart) {
                         if (x.dbLen - x.alnLength > qLen) undefinedCase = true;     // the reference pads with qLen - offset letters
-                        tot = st.nnTot; idc = st.nnId; idr = st.nnRy;
+                        else if (unsafeMode) unsafeColumns(x, cons, seqs[x.target], qLen, leftStart, tot, idc, idr, nCT, nGA);
+                        else { tot = st.nnTot; idc = st.nnId; idr = st.nnRy; }
                     }
                     if (tot != 0) { x.seqId = static_cast<float>(idc) / tot; x.rySeqId = static_cast<float>(idr) / tot; }
                     x.alnLengthCons = (unsigned) tot;
@@ -176,8 +247,8 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
                         if (leftStart || rightStart) {
                             const long double (*D)[4][4] = mats[x.isRev ? 1 : 0];
                             const double likCT = D[5][1][3], likGA = D[5][2][0];
-                            if (likCT > 0) { const double v = deamMatches(x.alnLength, scoreAln, likCT); for (int i = 0; i < st.nCT; i++) mCT += v; }
-                            if (likGA > 0) { const double v = deamMatches(x.alnLength, scoreAln, likGA); for (int i = 0; i < st.nGA; i++) mGA += v; }
+                            if (likCT > 0) { const double v = deamMatches(x.alnLength, scoreAln, likCT); for (int i = 0; i < nCT; i++) mCT += v; }
+                            if (likGA > 0) { const double v = deamMatches(x.alnLength, scoreAln, likGA); for (int i = 0; i < nGA; i++) mGA += v; }
                         }
                         x.deamMatch = ((static_cast<float>(scoreAln) + 3.0f * x.alnLengthCons) / 5.0f) + mCT + mGA;
                         queue.push(x);

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <omp.h>
+#include <unistd.h>
 #include <sys/stat.h>
 #include <string>
 #include <vector>
@@ -561,5 +562,8 @@ int main(int argc, char **argv) {
     else if (cmd == "cyclecheck") rc = cyclecheck(a);
     else { fprintf(stderr, "Invalid Command: %s\n", cmd.c_str()); return EXIT_FAILURE; }
     fprintf(stderr, "Time for processing: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    return rc;
+    // Every output file is written and closed, every handle and the context released: leave without the static destructors (the
+    // HIP runtime's own tear-down is where one module run in ~1 500 of the fuzz campaigns ended with a signal after its work was done)
+    fflush(stdout); fflush(stderr);
+    _exit(rc);
 }

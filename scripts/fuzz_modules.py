@@ -31,7 +31,7 @@ BIN = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
 def run(exe, *a):
     r = subprocess.run([exe] + list(a), capture_output=True, text=True)
     if r.returncode:
-        raise RuntimeError(exe + " " + " ".join(a) + "\n" + r.stderr[-600:])
+        raise RuntimeError("exit code %d: " % r.returncode + exe + " " + " ".join(a) + "\n" + r.stderr[-600:])
 
 
 fails = 0
@@ -95,6 +95,9 @@ for case in range(cases):
         else:
             # the contig phase (data/nuclassemble.sh:148-232), module by module; every module starts from the oracle's upstream DBs
             dmg = ["--ancient-damage", t("dhigh"), "--threads", "1"]
+            acf = AC_FLAGS
+            if rng.random() < 0.4:      # the contig merge's --unsafe 1 mode (majority-vote consensus), any --min-cov-safe
+                acf = " ".join(AC_FLAGS).replace("--unsafe 0", "--unsafe 1").replace("--min-cov-safe 5", "--min-cov-safe %d" % int(rng.integers(1, 6))).split()
             for it in range(2, 4):
                 i, o = t("in%d" % it), t("in%d" % (it + 1))
                 th = ["--threads", "1"]
@@ -109,7 +112,7 @@ for case in range(cases):
                 run(ORACLE, "ancient_correction", i, t("alnO"), t("corrO"), *AC_FLAGS, *dmg); run(BIN, "ancient_correction", i, t("alnO"), t("corr"), *AC_FLAGS, *dmg)
                 if diff_keys(mmdb.read_db(t("corr")), mmdb.read_db(t("corrO"))):
                     bad.append(("ccorr", ""))
-                run(ORACLE, "ancient_contig_merge", t("corrO"), t("alnO"), o, *AC_FLAGS, *dmg); run(BIN, "ancient_contig_merge", t("corrO"), t("alnO"), t("mrg"), *AC_FLAGS, *dmg)
+                run(ORACLE, "ancient_contig_merge", t("corrO"), t("alnO"), o, *acf, *dmg); run(BIN, "ancient_contig_merge", t("corrO"), t("alnO"), t("mrg"), *acf, *dmg)
                 if diff_keys(mmdb.read_db(t("mrg")), mmdb.read_db(o)):
                     bad.append(("cmerge", str(diff_keys(mmdb.read_db(t("mrg")), mmdb.read_db(o)))[:200]))
                 cyc = ["--chop-cycle", str(int(rng.integers(0, 2))), "--max-seq-len", "200000"]
@@ -128,4 +131,6 @@ for case in range(cases):
     for f in os.listdir(d):
         if not f.startswith("dhigh"):
             os.remove(t(f))
+    if case % 10 == 9:
+        print("  %d cases, %d failures so far" % (case + 1, fails), flush=True)
 print("module fuzz: cases", cases, "failures", fails, flush=True)

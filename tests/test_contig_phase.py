@@ -85,9 +85,47 @@ def test_contig_merge_module_on_db_files(dhigh_prefix, tmp_path):
     r = subprocess.run([exe, "ancient_contig_merge", t("corr"), t("aln"), t("out"), *AC_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "4"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-1000:]
     assert not diff_keys(mmdb.read_db(t("out")), cgold("mixed3k", "cmerge", 1))
-    r = subprocess.run([exe, "ancient_contig_merge", t("corr"), t("aln"), t("out2"), *[f if f != "0" or i == 0 or AC_FLAGS[i - 1] != "--unsafe" else "1" for i, f in enumerate(AC_FLAGS)],
-                        "--ancient-damage", dhigh_prefix], capture_output=True, text=True)
-    assert r.returncode != 0 and "--unsafe 1 is not implemented for the contig phase" in r.stderr
+
+
+REF = os.path.join(ROOT, "oracle", "_ref", "carpedeam_ref")
+UNSAFE_CASES = [("mixed3k", 0, 1), ("mixed3k", 1, 5), ("synth2k", 0, 2), ("synth2k", 1, 1), ("letters", 0, 1), ("letters", 1, 2)]
+
+
+def unsafe_flags(min_cov):
+    return " ".join(AC_FLAGS).replace("--unsafe 0", "--unsafe 1").replace("--min-cov-safe 5", "--min-cov-safe %d" % min_cov).split()
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref (the reference's object code) is not built here")
+@pytest.mark.parametrize("name,step,min_cov", UNSAFE_CASES)
+def test_oracle_unsafe_contig_merge_against_reference_binary(oracle_bin, dhigh_prefix, tmp_path, name, step, min_cov):
+    """ancient_contig_merge --unsafe 1 (consensusCaller's majority vote over the extending contigs): oracle == a live run of the
+    reference's object code, and the mode is not vacuous on these inputs"""
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_from_keyed(t("corr"), cgold(name, "ccorr", step), mmdb.DBTYPE_NUCLEOTIDES)
+    mmdb.write_from_keyed(t("aln"), cgold(name, "caln", step), mmdb.DBTYPE_ALIGNMENT_RES)
+    for exe, out in ((oracle_bin, "o"), (REF, "r")):
+        run_oracle(exe, "ancient_contig_merge", t("corr"), t("aln"), t(out), *unsafe_flags(min_cov), "--ancient-damage", dhigh_prefix, "--threads", "2")
+    a, b = mmdb.canon(mmdb.read_db(t("o"))), mmdb.canon(mmdb.read_db(t("r")))
+    assert a == b
+    safe = mmdb.canon(cgold(name, "cmerge", step))
+    assert sum(1 for k in safe if a.get(k) != safe[k]) > 15
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,step,min_cov", UNSAFE_CASES)
+def test_contig_merge_unsafe_mode_matches_oracle(oracle_bin, dhigh_prefix, tmp_path, name, step, min_cov):
+    """the module with --unsafe 1 (the consensus is worked out on the host strings in that mode) against the oracle"""
+    from carpedeam_amd import build
+    build.build()
+    exe = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_from_keyed(t("corr"), cgold(name, "ccorr", step), mmdb.DBTYPE_NUCLEOTIDES)
+    mmdb.write_from_keyed(t("aln"), cgold(name, "caln", step), mmdb.DBTYPE_ALIGNMENT_RES)
+    run_oracle(oracle_bin, "ancient_contig_merge", t("corr"), t("aln"), t("o"), *unsafe_flags(min_cov), "--ancient-damage", dhigh_prefix, "--threads", "2")
+    r = subprocess.run([exe, "ancient_contig_merge", t("corr"), t("aln"), t("g"), *unsafe_flags(min_cov), "--ancient-damage", dhigh_prefix, "--threads", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert not diff_keys(mmdb.read_db(t("g")), mmdb.read_db(t("o")))
+    assert diff_keys(mmdb.read_db(t("g")), cgold(name, "cmerge", step))
 
 
 @pytest.mark.gpu
