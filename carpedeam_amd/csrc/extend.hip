@@ -304,8 +304,10 @@ struct Heap {
     }
 };
 
-template <int MINW>
+// RAW = false: the DB has no letters beyond ACGTN - the raw-plane branches of letterOf() fold away (a null pointer the compiler knows)
+template <int MINW, bool RAW = false>
 __global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
+    if (!RAW) A.raw = nullptr;
     __shared__ double sLogLik[11 * 16];
     for (int i = threadIdx.x; i < 11 * 16; i += blockDim.x) sLogLik[i] = (&A.lut->logLik[0][0][0][0])[i];
     __syncthreads();
@@ -615,7 +617,8 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     const char *wEnv = getenv("CDM_EXTEND_WAVES");        // experiments: waves per SIMD the register allocation leaves room for
     const int minW = wEnv ? atoi(wEnv) : 8;
     const unsigned padB = padEnv ? (unsigned) atoi(padEnv) : 0u;
-    if (hAct && minW == 8) hipLaunchKernelGGL(k_extend<8>, dim3((hAct + 63) / 64), dim3(64), padB, s, A);
+    if (hAct && db->raw) hipLaunchKernelGGL((k_extend<8, true>), dim3((hAct + 63) / 64), dim3(64), padB, s, A);
+    else if (hAct && minW == 8) hipLaunchKernelGGL(k_extend<8>, dim3((hAct + 63) / 64), dim3(64), padB, s, A);
     else if (hAct && minW == 6) hipLaunchKernelGGL(k_extend<6>, dim3((hAct + 63) / 64), dim3(64), padB, s, A);
     else if (hAct) hipLaunchKernelGGL(k_extend<5>, dim3((hAct + 63) / 64), dim3(64), padB, s, A);
     hipEventRecord(ctx->ev1, s);
