@@ -185,8 +185,12 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
     outSeqs.assign(n, std::string()); outExt.assign(n, 0); changed.assign(n, 0);
     const float ryThr = par->ry_seq_id_thr;
     bool undefinedCase = false;
+    const bool timing = getenv("CDM_TIMING") != nullptr;       // per-thread seconds in: candidate gate, queue pops, string growth, parked hits
+    double tSum[4] = {0, 0, 0, 0}, tMax[4] = {0, 0, 0, 0};
 #pragma omp parallel
     {
+        double tl[4] = {0, 0, 0, 0}; double tm = timing ? omp_get_wtime() : 0;
+        auto lap = [&](int k) { if (timing) { const double n2 = omp_get_wtime(); tl[k] += n2 - tm; tm = n2; } };
         std::vector<Res> contigs, parked;
         std::vector<uint8_t> useReverse(n, 0);          // per thread, last writer wins within a query (:136-137,198,212)
 #pragma omp for schedule(dynamic, 100)
@@ -255,6 +259,7 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
                     }
                 }
             }
+            lap(0);
             // :276-470 extension
             if (queue.empty()) { outExt[id] = ext[id]; continue; }
             query = q0;
@@ -283,6 +288,7 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
                         leftOff += fragLen;
                     }
                 }
+                lap(1);
                 if (leftOff > 0 || rightOff > 0) couldExtend = true;
                 if (!queue.empty()) break;
                 qLen = (unsigned) query.size();
@@ -318,11 +324,19 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
                     a.rySeqId = static_cast<float>(idRy) / a.alnLength;
                     if (a.seqId >= mergeSeqIdThr && a.rySeqId >= ryThr) queue.push(a);
                 }
+                lap(3);
             }
             if (couldExtend) { outSeqs[id].swap(query); outExt[id] = 1; changed[id] = 1; }
             else outExt[id] = ext[id];
+            lap(2);
+        }
+        if (timing) {
+#pragma omp critical
+            for (int k = 0; k < 4; k++) { tSum[k] += tl[k]; tMax[k] = std::max(tMax[k], tl[k]); }
         }
     }
+    if (timing) fprintf(stderr, "  contig merge host threads (sum / max s): gate %.2f / %.2f, queue + growth %.2f / %.2f, parked hits %.2f / %.2f, rest %.2f / %.2f\n",
+                        tSum[0], tMax[0], tSum[1], tMax[1], tSum[3], tMax[3], tSum[2], tMax[2]);
     if (undefinedCase) { *err = "cdm_contig_merge: a target overhangs its query by more than the query's length; the reference pads it with a negative number of letters there (undefined behaviour), not reproduced"; return CDM_ERR_UNSUPPORTED; }
     return CDM_OK;
 }

@@ -26,7 +26,7 @@ with tempfile.TemporaryDirectory() as d:
     os.environ["CDM_TIMING"] = "1"
     r = subprocess.run([exe, "ancient_reads_loop", d + "/reads", d + "/out", "--ancient-damage", d + "/dhigh", "--num-iter-reads-only", "5", "--num-iterations", "12",
                         "--threads", threads], capture_output=True, text=True)
-    print(r.stderr[-4000:])
+    print(r.stderr[-9000:])
     print("exit %d, %.1f s" % (r.returncode, time.time() - t0))
     if r.returncode == 0:
         lens = sorted((int(l.split()[2]) - 2 for l in open(d + "/out.index")), reverse=True)
