@@ -26,21 +26,27 @@ struct Res {            // Matcher::result_t, the fields this module uses (M/ali
     int qStartPos = 0, qEndPos = 0, dbStartPos = 0, dbEndPos = 0;
     unsigned qLen = 0, dbLen = 0;
     bool isRev = false;
+    // the comparator's two lgamma terms that depend on this record alone (same float arithmetic as there), set by cacheTerms()
+    float lgBeta = 0, lgAlphaBeta = 0;
+    void cacheTerms() { const float mm = alnLengthCons - deamMatch, alpha = mm + 1, beta = deamMatch + 1; lgBeta = std::lgamma(beta); lgAlphaBeta = std::lgamma(alpha + beta); }
 };
 // ancientContigsResults.cpp:25-70 - arithmetic and overloads as there (`using namespace std` is in force in the reference:
 // lgamma / log of float arguments are the float functions)
+thread_local unsigned long long tlCompares = 0, tlSeriesTerms = 0;     // CDM_TIMING statistics
 struct CompareByScoreContigs {
     bool operator()(const Res &r1, const Res &r2) const {
+        tlCompares++;
         float mm_count1 = r1.alnLengthCons - r1.deamMatch;
         float mm_count2 = r2.alnLengthCons - r2.deamMatch;
         float alpha1 = mm_count1 + 1;
         float alpha2 = mm_count2 + 1;
         float beta1 = r1.deamMatch + 1;
         float beta2 = r2.deamMatch + 1;
-        double log_c = (std::lgamma(beta1 + beta2) + std::lgamma(alpha1 + beta1)) - (std::lgamma(alpha1 + beta1 + beta2) + std::lgamma(beta1));
+        double log_c = (std::lgamma(beta1 + beta2) + r1.lgAlphaBeta) - (std::lgamma(alpha1 + beta1 + beta2) + r1.lgBeta);       // (= lgamma(alpha1 + beta1), lgamma(beta1))
         double log_r = 0.0;
         double p = 0.0;
         for (size_t idx = 0; idx < alpha2; idx++) {
+            tlSeriesTerms++;
             p += std::exp(log_r + log_c);
             log_r = std::log(alpha1 + idx) + std::log(beta2 + idx) - (std::log(idx + 1) + std::log(idx + alpha1 + beta1 + beta2)) + log_r;
         }
@@ -73,8 +79,10 @@ struct RevTable {
         }
     }
 };
+static const RevTable REV_TABLE;
+inline char revLetter(char c) { return REV_TABLE.t[(unsigned char) c]; }
 std::string revComp(const char *s, size_t n) {
-    static const RevTable tab;
+    const RevTable &tab = REV_TABLE;
     std::string r(n, 'N');
     for (size_t i = 0; i < n; i++) r[i] = tab.t[(unsigned char) s[n - 1 - i]];
     return r;
@@ -186,12 +194,13 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
     const float ryThr = par->ry_seq_id_thr;
     bool undefinedCase = false;
     const bool timing = getenv("CDM_TIMING") != nullptr;       // per-thread seconds in: candidate gate, queue pops, string growth, parked hits
-    double tSum[4] = {0, 0, 0, 0}, tMax[4] = {0, 0, 0, 0};
+    double tSum[4] = {0, 0, 0, 0}, tMax[4] = {0, 0, 0, 0}; unsigned long long nCmp = 0, nTerms = 0;
 #pragma omp parallel
     {
         double tl[4] = {0, 0, 0, 0}; double tm = timing ? omp_get_wtime() : 0;
         auto lap = [&](int k) { if (timing) { const double n2 = omp_get_wtime(); tl[k] += n2 - tm; tm = n2; } };
         std::vector<Res> contigs, parked;
+        std::string revBuf;
         std::vector<uint8_t> useReverse(n, 0);          // per thread, last writer wins within a query (:136-137,198,212)
 #pragma omp for schedule(dynamic, 100)
         for (size_t id = 0; id < n; id++) {
@@ -255,6 +264,7 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
                             if (likGA > 0) { const double v = deamMatches(x.alnLength, scoreAln, likGA); for (int i = 0; i < nGA; i++) mGA += v; }
                         }
                         x.deamMatch = ((static_cast<float>(scoreAln) + 3.0f * x.alnLengthCons) / 5.0f) + mCT + mGA;
+                        x.cacheTerms();
                         queue.push(x);
                     }
                 }
@@ -294,34 +304,45 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
                 qLen = (unsigned) query.size();
                 // :404-455 the parked hits on the grown query: ungappedAlignmentByDiagonal (mode 3), updateNuclAlignment, getRYSeqId
                 for (Res &a : parked) {
-                    std::string tmp; const std::string *tp = &seqs[a.target];
-                    if (useReverse[a.target]) { tmp = revComp(tp->data(), tp->size()); tp = &tmp; }
-                    const char *ts = tp->data(); const unsigned tLen = (unsigned) tp->size();
+                    // the target as the reference holds it here: its own letters, or getNuclRevFragment's (letter j = complement of letter tLen-1-j)
+                    const std::string &t0 = seqs[a.target];
+                    const unsigned tLen = (unsigned) t0.size();
+                    const bool rev = useReverse[a.target] != 0;
                     const int diag = (a.qStartPos + (int) leftOff) - a.dbStartPos;
                     const unsigned md = (unsigned) std::abs(diag);
                     int startPos = -1, endPos = -1; unsigned diagonalLen = 0;
                     const char *qa = nullptr; unsigned m = 0;
                     if (diag >= 0 && md < qLen) { m = std::min(tLen, qLen - md); qa = query.data() + md; }
                     else if (diag < 0 && md < tLen) { m = std::min(tLen - md, qLen); qa = query.data(); }
+                    // the overlap's m letters of the target start at ta; of a reversed target only they are spelled out (not the whole contig)
+                    const size_t ta = diag < 0 ? md : 0;
+                    const char *ov = t0.data() + ta;       // ov[j] = letter ta + j of the target as the reference holds it
+                    if (rev && qa) {
+                        revBuf.resize(m);
+                        const char *fw = t0.data() + (tLen - 1 - ta);
+                        for (unsigned j = 0; j < m; j++) revBuf[j] = revLetter(*(fw - j));
+                        ov = revBuf.data();
+                    }
                     if (qa) {       // computeGlobalSubstitutionStartEndDistance: the whole overlap, but for a '*' at either end (DistanceCalculator.h:204-220)
-                        const char *ta = ts + (diag < 0 ? md : 0);
-                        diagonalLen = m; startPos = (qa[0] == '*' || ta[0] == '*') ? 1 : 0; endPos = (int) m - 1;
-                        if (endPos > 0 && (qa[m - 1] == '*' || ta[m - 1] == '*')) endPos--;
+                        diagonalLen = m; startPos = (qa[0] == '*' || ov[0] == '*') ? 1 : 0; endPos = (int) m - 1;
+                        if (endPos > 0 && (qa[m - 1] == '*' || ov[m - 1] == '*')) endPos--;
                     }
                     // updateNuclAlignment (nuclassembleUtil.cpp:9-47)
                     const int dist = (int) md;
                     int qs2, qe2, ds2, de2;
                     if (diag >= 0) { qs2 = startPos + dist; qe2 = endPos + dist; ds2 = startPos; de2 = endPos; }
                     else { qs2 = startPos; qe2 = endPos; ds2 = startPos + dist; de2 = endPos + dist; }
-                    int idCnt = 0;
-                    for (int i = qs2; i < qe2; i++) idCnt += (query[i] == ts[ds2 + (i - qs2)]) ? 1 : 0;
+                    int idCnt = 0, idRy = 0;
+                    if (qa) {
+                        const char *qp = query.data() + qs2, *tp = ov + ((size_t) ds2 - ta);
+                        const int cols = qe2 - qs2;
+                        for (int i = 0; i < cols; i++) idCnt += (qp[i] == tp[i]) ? 1 : 0;                                      // :28-31, [qs2, qe2)
+                        for (int i = 0; i <= cols; i++) idRy += (ryClass(qp[i]) == ryClass(tp[i])) ? 1 : 0;                    // getRYSeqId (:78-92), [qs2, qe2]
+                    }
                     a.seqId = static_cast<float>(idCnt) / (static_cast<float>(qe2) - static_cast<float>(qs2));
                     a.qLen = qLen; a.dbLen = tLen; a.alnLength = diagonalLen;
                     a.qStartPos = qs2; a.qEndPos = qe2; a.dbStartPos = ds2; a.dbEndPos = de2;
-                    int idRy = 0;                                               // getRYSeqId (nuclassembleUtil.cpp:78-92)
-                    if (qa)     // (no overlap left on that diagonal: the identity above is 0/0 and the hit is dropped whatever this count is)
-                        for (int i = a.qStartPos; i <= a.qEndPos; i++) idRy += (ryClass(query[i]) == ryClass(ts[a.dbStartPos + (i - a.qStartPos)])) ? 1 : 0;
-                    a.rySeqId = static_cast<float>(idRy) / a.alnLength;
+                    a.rySeqId = static_cast<float>(idRy) / a.alnLength;     // (no overlap left on that diagonal: 0/0 above, the hit is dropped whatever this is)
                     if (a.seqId >= mergeSeqIdThr && a.rySeqId >= ryThr) queue.push(a);
                 }
                 lap(3);
@@ -332,11 +353,13 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
         }
         if (timing) {
 #pragma omp critical
-            for (int k = 0; k < 4; k++) { tSum[k] += tl[k]; tMax[k] = std::max(tMax[k], tl[k]); }
+            { for (int k = 0; k < 4; k++) { tSum[k] += tl[k]; tMax[k] = std::max(tMax[k], tl[k]); } nCmp += tlCompares; nTerms += tlSeriesTerms; }
+            tlCompares = tlSeriesTerms = 0;
         }
     }
     if (timing) fprintf(stderr, "  contig merge host threads (sum / max s): gate %.2f / %.2f, queue + growth %.2f / %.2f, parked hits %.2f / %.2f, rest %.2f / %.2f\n",
                         tSum[0], tMax[0], tSum[1], tMax[1], tSum[3], tMax[3], tSum[2], tMax[2]);
+    if (timing) fprintf(stderr, "  contig merge comparator: %llu calls, %llu series terms\n", nCmp, nTerms);
     if (undefinedCase) { *err = "cdm_contig_merge: a target overhangs its query by more than the query's length; the reference pads it with a negative number of letters there (undefined behaviour), not reproduced"; return CDM_ERR_UNSUPPORTED; }
     return CDM_OK;
 }

@@ -521,7 +521,6 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
         const size_t considered = min((size_t) (float) ((float) (a.kmersPerSeq - 1) + (a.scale * (float) L)), (size_t) n);
         uint32_t headN = 0;
         if (CAP == 0) { headN = min(n, HEADN); for (uint32_t i = tid; i < headN; i += NT) sHead[i] = sp[i]; }
-        auto at = [&](size_t i) -> SeqPos { return (CAP == 0 && i < headN) ? sHead[i] : sp[i]; };
         // fast path test: no two equal k-mers next to each other, and every k-mer is taken
         int dup = 0;
         for (uint32_t i = tid; i + 1 < n; i += NT) dup |= (spKmer63(sp[i]) == spKmer63(sp[i + 1]));
@@ -531,44 +530,69 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
         } else {
             for (uint32_t i = tid; i < n; i += NT) sel[i] = 0;
             __syncthreads();
-            if (tid == 0 && n > 0) {
-                // threshold = (score of the considered-th smallest) + 1, inBins = #(score < threshold)  [:224-240]
-                uint32_t threshold = 0; size_t inBins = 0;
-                if (considered > 0) {
-                    threshold = spScore(at(considered - 1)) + 1;
-                    inBins = considered;
-                    while (inBins < n && spScore(at(inBins)) < threshold) inBins++;
-                } else {
-                    // the reference's loops leave threshold at the start of the first non-empty 512-bin and subtract that bin
-                    threshold = (spScore(at(0)) >> 9) * 512; inBins = 0;
+            // The selection walk is serial (one thread), its reads are not: with the records in global scratch (CAP = 0) the block
+            // stages the next HEADN records in LDS, thread 0 walks them, and so on until the walk is done (it ends after about
+            // 0.2 n + 200 records; chasing them one by one through global memory took ~1 us each).
+            __shared__ uint32_t wThreshold, wDone; __shared__ int wTooMuch; __shared__ unsigned long long wKi, wSelected;
+            uint32_t winLo = 0, winN = headN;                 // [winLo, winLo + winN) of the sorted records is in sHead
+            auto at = [&](size_t i) -> SeqPos { return (CAP == 0 && i >= winLo && i < (size_t) winLo + winN) ? sHead[i - winLo] : sp[i]; };
+            if (tid == 0) {
+                wDone = (n == 0) ? 1u : 0u; wKi = 0; wSelected = 0; wThreshold = 0; wTooMuch = 0;
+                if (n > 0) {
+                    // threshold = (score of the considered-th smallest) + 1, inBins = #(score < threshold)  [:224-240]
+                    uint32_t threshold = 0; size_t inBins = 0;
+                    if (considered > 0) {
+                        threshold = spScore(at(considered - 1)) + 1;
+                        inBins = considered;
+                        while (inBins < n && spScore(at(inBins)) < threshold) inBins++;
+                    } else {
+                        // the reference's loops leave threshold at the start of the first non-empty 512-bin and subtract that bin
+                        threshold = (spScore(at(0)) >> 9) * 512; inBins = 0;
+                    }
+                    wThreshold = threshold; wTooMuch = (int) (inBins - considered);
+                    if (!a.ignoreMultiKmer) {
+                        // without --ignore-multi-kmer the reference does not sort (:269-275): the selection walks the k-mers in the
+                        // order they were generated; the threshold above only needed the score distribution
+                        uint32_t m = 0;
+                        for (uint32_t pos = 0; pos < nPos; pos++) { SeqPos e; if (makeSeqPos(a, w0, L, lastWord, hasN, k, pos, e)) sp[m++] = e; }
+                    }
                 }
-                int tooMuch = (int) (inBins - considered);
-                size_t selected = 0;
-                if (!a.ignoreMultiKmer) {
-                    // without --ignore-multi-kmer the reference does not sort (:269-275): the selection walks the k-mers in the
-                    // order they were generated; the threshold above only needed the score distribution
-                    uint32_t m = 0;
-                    for (uint32_t pos = 0; pos < nPos; pos++) { SeqPos e; if (makeSeqPos(a, w0, L, lastWord, hasN, k, pos, e)) sp[m++] = e; }
-                    headN = 0;      // (the LDS copy holds the sorted order)
-                }
-                for (size_t ki = 0; ki < n && selected < considered; ki++) {
-                    if (a.ignoreMultiKmer) {
-                        const uint64_t km = spKmer63(at(ki));
-                        if (ki + 1 < n) {
-                            uint64_t nx = spKmer63(at(ki + 1));
-                            if (km == nx) {
-                                while (km == nx && ki < n) { ki++; if (ki >= n) break; nx = spKmer63(at(ki)); }
+            }
+            __syncthreads();
+            if (CAP == 0 && !a.ignoreMultiKmer) { winN = min(n, HEADN); for (uint32_t i = tid; i < winN; i += NT) sHead[i] = sp[i]; __syncthreads(); }   // (the LDS copy held the sorted order)
+            while (!wDone) {
+                if (tid == 0) {
+                    uint32_t threshold = wThreshold; int tooMuch = wTooMuch; size_t ki = (size_t) wKi, selected = (size_t) wSelected;
+                    // walk while the record and its successor are staged (CAP != 0: everything is)
+                    const size_t stop = (CAP == 0) ? ((size_t) winLo + winN >= n ? n : (size_t) winLo + winN - 1) : n;
+                    for (; ki < n && selected < considered; ki++) {
+                        if (ki >= stop) break;
+                        if (a.ignoreMultiKmer) {
+                            const uint64_t km = spKmer63(at(ki));
+                            if (ki + 1 < n) {
+                                uint64_t nx = spKmer63(at(ki + 1));
+                                if (km == nx) {
+                                    while (km == nx && ki < n) { ki++; if (ki >= n) break; nx = spKmer63(at(ki)); }
+                                }
                             }
+                            if (ki >= n) break;
                         }
-                        if (ki >= n) break;
+                        const uint32_t sc = spScore(at(ki));
+                        if (sc < threshold) {
+                            if (sc == (threshold - 1) && tooMuch) { tooMuch--; threshold -= (tooMuch == 0) ? 1 : 0; }
+                            selected++;
+                            sel[ki] = 1;
+                        }
                     }
-                    const uint32_t sc = spScore(at(ki));
-                    if (sc < threshold) {
-                        if (sc == (threshold - 1) && tooMuch) { tooMuch--; threshold -= (tooMuch == 0) ? 1 : 0; }
-                        selected++;
-                        sel[ki] = 1;
-                    }
+                    wThreshold = threshold; wTooMuch = tooMuch; wKi = ki; wSelected = selected;
+                    wDone = (ki >= n || selected >= considered) ? 1u : 0u;
                 }
+                __syncthreads();
+                if (CAP == 0 && !wDone) {      // next window starts at the record the walk stopped at
+                    winLo = (uint32_t) wKi; winN = min(n - winLo, HEADN);
+                    for (uint32_t i = tid; i < winN; i += NT) sHead[i] = sp[winLo + i];
+                }
+                __syncthreads();
             }
         }
         __syncthreads();
