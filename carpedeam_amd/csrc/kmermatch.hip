@@ -742,7 +742,10 @@ constexpr int GK_OWN = CDM_GK_OWN, GK_WIN = CDM_GK_WIN, GK_FIRST = CDM_GK_FIRST,
 static_assert(GK_WIN % 64 == 0 && GK_FIRST % 64 == 0 && GK_FIRST < GK_WIN && GK_OWN <= GK_FIRST && GK_WIN <= (1 << bucket::WV_IDX) &&
               (GK_MAXB == 64 || GK_MAXB == 128 || GK_MAXB == 256 || GK_MAXB == 512), "grouping kernel geometry");
 template <typename LY, typename W>
-__global__ __launch_bounds__(bucket::BK_NT) void k_bucket_groups(BucketGroupArgs<LY, W> a) {
+#ifndef CDM_GK_MINW
+#define CDM_GK_MINW 1      // waves per SIMD the register allocation of the grouping kernel leaves room for (scripts/build_variant.py sweeps it)
+#endif
+__global__ __launch_bounds__(bucket::BK_NT, CDM_GK_MINW) void k_bucket_groups(BucketGroupArgs<LY, W> a) {
     using namespace bucket;
     typedef typename LY::V V;
     __shared__ uint64_t sKeyAll[BK_WAVES][GK_WIN];
