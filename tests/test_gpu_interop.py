@@ -74,3 +74,19 @@ def test_dispatcher_script_runs_one_reads_loop_iteration(tmp_path, dhigh_prefix)
     # a module that is not one of the four goes to the reference binary
     r = subprocess.run([WRAP, "not_a_hot_path_module"], capture_output=True, text=True, env=env)
     assert r.returncode != 0
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref (the reference's object code) is not built here")
+def test_whole_workflow_against_reference_object_code():
+    """scripts/loop_vs_ref.py on 20 000 mixed-length reads: 5 read + 7 contig iterations with cyclecheck through `ancient_reads_loop`
+    and through the reference's own modules chained as data/nuclassemble.sh chains them.  The reference's sort breaks strand ties
+    differently from run to run (about 40 of a million result sequences over the twelve iterations, 0 in the 100 k-read
+    runs kept under profiles/), hence the small allowance; anything systematic shows up as hundreds."""
+    import re
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "loop_vs_ref.py"), "20000", "4"], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
+    m = re.search(r"result (\d+) sequences, (\d+) residues, \d+ circular set aside; (\d+) sequences differ", r.stdout)
+    assert m, r.stdout[-800:]
+    assert int(m.group(1)) == 20000 and int(m.group(2)) > 4_000_000     # (the contigs grew: 20 000 reads are 2.1 M letters)
+    assert int(m.group(3)) <= 10
