@@ -8,6 +8,7 @@
 // (without line ends) up to a line that starts with '>', '+' or '@'; after '+' as many quality characters as sequence letters
 // are skipped.
 #include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -132,10 +133,25 @@ bool readFastxAsDb(const std::vector<std::string> &files, bool shuffle, std::str
     return true;
 }
 
-int createdbModule(const std::vector<std::string> &files, const std::string &outPath, bool shuffle, std::string *err) {
+// dbType: 2 = nucleotides, 0 = createdb's own guess (M/util/createdb.cpp:175-199, 253-258): the first ten entries are looked at (the
+// sample counter stops there: `sampleCount % 100 == 0` is never reached again), and the DB is a nucleotide DB iff more than 90 % of
+// the letters of EACH of them are A, C, G, T, U or N in either case (an empty sequence gives 0/0: not a nucleotide sequence)
+int createdbModule(const std::vector<std::string> &files, const std::string &outPath, bool shuffle, int dbType, std::string *err) {
     Entries e;
     if (!parseAll(files, e, err)) return 1;
     const size_t n = e.seqOff.size();
+    int seqDbType = 1;      // DBTYPE_NUCLEOTIDES
+    if (dbType == 0) {
+        size_t isNucl = 0, sampled = 0;
+        for (size_t i = 0; i < n && sampled < 10; i++, sampled++) {
+            const char *q = e.seqBlob.data() + e.seqOff[i]; const size_t L = e.seqLen[i] - 2;
+            size_t cnt = 0;
+            for (size_t j = 0; j < L; j++) { const int c = toupper(q[j]); cnt += (c == 'T' || c == 'A' || c == 'G' || c == 'C' || c == 'U' || c == 'N'); }
+            const float frac = static_cast<float>(cnt) / static_cast<float>(L);
+            if (frac > 0.9) isNucl++;
+        }
+        if (isNucl != sampled) seqDbType = 0;       // DBTYPE_AMINO_ACIDS: written as the reference writes it; the modules of this path refuse such a DB
+    }
     const std::vector<uint32_t> order = entryOrder(n, shuffle);
     std::string sBlob, hBlob; sBlob.reserve(e.seqBlob.size()); hBlob.reserve(e.hdrBlob.size());
     std::vector<uint32_t> key(n), sLen(n), hLen(n); std::vector<uint64_t> sOff(n), hOff(n); std::vector<uint8_t> ext(n, 0);
@@ -148,7 +164,7 @@ int createdbModule(const std::vector<std::string> &files, const std::string &out
         lookup += std::to_string(j); lookup.push_back('\t'); lookup += fastaId(e.hdrBlob.c_str() + e.hdrOff[i]); lookup.push_back('\t');
         lookup += std::to_string(e.file[i]); lookup.push_back('\n');
     }
-    if (!mmdbWriteBlob(outPath, 1 /* DBTYPE_NUCLEOTIDES */, sBlob.data(), sBlob.size(), key, sOff, sLen, ext, err)) return 1;
+    if (!mmdbWriteBlob(outPath, seqDbType, sBlob.data(), sBlob.size(), key, sOff, sLen, ext, err)) return 1;
     if (!mmdbWriteBlob(outPath + "_h", 12 /* DBTYPE_GENERIC_DB */, hBlob.data(), hBlob.size(), key, hOff, hLen, ext, err)) return 1;
     FILE *lf = fopen((outPath + ".lookup").c_str(), "w"), *sf = fopen((outPath + ".source").c_str(), "w");
     if (!lf || !sf) { *err = "Cannot open " + outPath + ".lookup for writing"; return 1; }

@@ -29,7 +29,7 @@
 // host/ingest.cpp
 bool readFastxAsDb(const std::vector<std::string> &files, bool shuffle, std::string &blob, std::vector<uint32_t> &key, std::vector<uint64_t> &off,
                    std::vector<uint32_t> &len, std::string *err);
-int createdbModule(const std::vector<std::string> &files, const std::string &outPath, bool shuffle, std::string *err);
+int createdbModule(const std::vector<std::string> &files, const std::string &outPath, bool shuffle, int dbType, std::string *err);
 int convert2fastaModule(const std::string &dbPath, const std::string &outPath, std::string *err);
 int createhdbModule(const std::string &seqPath, const std::string &cyclePath, const std::string &outPath, std::string *err);
 
@@ -108,6 +108,7 @@ cdm_ctx *openCtx() {
     return ctx;
 }
 cdm_seqdb *uploadSeqDb(cdm_ctx *ctx, const MmDb &db) {
+    if ((db.dbtype & 0x7FFFFFFF) != 1) die("The MI355X path works on nucleotide sequence DBs only (dbtype " + std::to_string(db.dbtype & 0x7FFFFFFF) + " given)");
     std::vector<uint32_t> lens(db.size());
     for (size_t i = 0; i < db.size(); i++) lens[i] = db.len[i] >= 2 ? (uint32_t) (db.len[i] - 2) : 0;   // DBReader::getSeqLen
     cdm_seqdb *h = NULL;
@@ -510,7 +511,7 @@ int readsLoop(Args &a) {
 
 namespace {
 const FlagSpec CREATEDB_FLAGS[] = {   // Parameters.cpp:733-737 createdb
-    {"--shuffle", 'U', 0, 0}, {"--dbtype", 'V', "2", "nucleotide input only (0 = auto is not implemented)"}, {"--createdb-mode", 'V', "0", "only the copying mode"},
+    {"--shuffle", 'U', 0, 0}, {"--dbtype", 'U', 0, 0}, {"--createdb-mode", 'V', "0", "only the copying mode"},
     {"--write-lookup", 'V', "1", "the .lookup file is always written"}, {"--id-offset", 'V', "0", "not implemented"}, {"--compressed", 'V', "0", "compressed DBs are not implemented"},
     {"-v", 'N', 0, 0}, {"--threads", 'N', 0, 0}, {0, 0, 0, 0}};
 const FlagSpec PLAIN_FLAGS[] = {{"-v", 'N', 0, 0}, {"--threads", 'N', 0, 0}, {"--compressed", 'V', "0", "compressed DBs are not implemented"}, {"--use-fasta-header", 'V', "0", "not implemented"}, {0, 0, 0, 0}};
@@ -519,7 +520,9 @@ int createdb(Args &a) {
     checkFlags("createdb", a, CREATEDB_FLAGS);
     std::vector<std::string> files(a.pos.begin(), a.pos.end() - 1);
     std::string err;
-    if (createdbModule(files, a.pos.back(), iflag(a, "--shuffle", 1) != 0, &err)) die(err);
+    const long dbType = iflag(a, "--dbtype", 0);        // 0 = guess from the first entries, as createdb does (createdb.cpp:40-45)
+    if (dbType != 0 && dbType != 2) die("createdb: --dbtype " + std::to_string(dbType) + " is not supported by the MI355X path (nucleotide sequences only; accepted: 0, 2)");
+    if (createdbModule(files, a.pos.back(), iflag(a, "--shuffle", 1) != 0, (int) dbType, &err)) die(err);
     return EXIT_SUCCESS;
 }
 int convert2fasta(Args &a) {

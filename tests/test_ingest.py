@@ -111,3 +111,29 @@ def test_createdb_errors(exe, tmp_path):
     assert r.returncode != 0 and "have no entry" in r.stderr
     r = subprocess.run([exe, "createdb", str(tmp_path / "empty.fa"), str(tmp_path / "db"), "--dbtype", "1"], capture_output=True, text=True)
     assert r.returncode != 0 and "not supported" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref (the reference's object code) is not built here")
+def test_ingest_keeps_letters_beyond_acgtn(exe, tmp_path):
+    """soft-masked lower case, IUPAC codes, U and stray bytes go into the DB as they stand (the modules map them):
+    createdb on FASTA and FASTQ and convert2fasta, byte for byte the reference's files"""
+    t = lambda s: str(tmp_path / s)
+    with open(t("in.fa"), "w") as f:
+        f.write(">r1 soft-masked\n" + "ACGTacgtNN" * 3 + "RY\nacgtnnnn\n>r2\n" + "GGGGccccTTTTaaaa" * 2 + "*\n>r3\nACGU\n>r4 x\n" + "acgt" * 20 + "swbdhvK\n")
+    with open(t("in.fq"), "w") as f:      # (the first read has 2 of 11 letters beyond ACGTUN: createdb's guess says amino acids, dbtype 0)
+        f.write("@q1\nacgtACGTNRY\n+\nIIIIIIIIIII\n@q2\nGGGGcccc\n+\nIIIIIIII\n")
+    for src in ("in.fa", "in.fq"):
+        run(exe, "createdb", t(src), t("g_" + src), "-v", "0")
+        run(REF, "createdb", t(src), t("r_" + src), "-v", "0")
+        for ext in ("", ".index", "_h", "_h.index", ".lookup", ".dbtype"):
+            assert open(t("g_" + src) + ext, "rb").read() == open(t("r_" + src) + ext, "rb").read(), (src, ext)
+    assert ("ACGTacgtNN" * 3 + "RYacgtnnnn\n\0").encode() in open(t("g_in.fa"), "rb").read()
+    assert open(t("g_in.fa.dbtype"), "rb").read()[0] == 1 and open(t("g_in.fq.dbtype"), "rb").read()[0] == 0
+    # the modules of this path refuse what is not a nucleotide DB (the reference would run its protein mode on it)
+    r = subprocess.run([exe, "kmermatcher", t("g_in.fq"), t("pref"), "-k", "20"], capture_output=True, text=True)
+    assert r.returncode != 0 and ("nucleotide sequence DBs only" in r.stderr or "MI355X device" in r.stderr)
+    run(exe, "createdb", t("in.fq"), t("g2"), "--dbtype", "2", "-v", "0")
+    assert open(t("g2.dbtype"), "rb").read()[0] == 1
+    run(exe, "convert2fasta", t("g_in.fa"), t("g.fasta"), "-v", "0")
+    run(REF, "convert2fasta", t("r_in.fa"), t("r.fasta"), "-v", "0")
+    assert open(t("g.fasta"), "rb").read() == open(t("r.fasta"), "rb").read()
