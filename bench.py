@@ -24,6 +24,10 @@ import sys
 import tempfile
 import time
 
+# The host side of the library (the contig phase's queue, the text codecs of the module legs) runs OpenMP loops: a GPU box shows all
+# of the machine's hardware threads (256) but gives one GPU's job a share of 16 cores - without a cap every loop oversubscribes it
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -169,10 +169,21 @@ void unsafeColumns(const Res &c, const std::string &cons, const std::string &t0,
 }
 }  // namespace
 
+// Threads of the host loops of the library.  A caller that set OMP_NUM_THREADS (or the module binary's --threads, which sets it) is
+// taken at its word; without it a GPU box would hand every loop all of the machine's hardware threads - hundreds, of which one GPU's
+// job owns a share (the contig phase of `bench.py --config 5` took 36 s that way and 23 s on 16 threads) - so the default is capped.
+static int cdm_host_threads() {
+    static const int n = [] {
+        if (const char *e = getenv("CDM_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+        const int m = std::max(1, omp_get_max_threads());
+        return getenv("OMP_NUM_THREADS") ? m : std::min(m, 16);
+    }();
+    return n;
+}
 void cdm_host_split(const std::string &blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<std::string> &seqs) {
     const long n = (long) offs.size();
     seqs.resize(n);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(cdm_host_threads())
     for (long i = 0; i < n; i++) seqs[i].assign(blob, offs[i], lens[i]);
 }
 // changed[i] != 0: sequence i is grown[i], otherwise still seqs[i].  The blob is written by all threads (first touch included).
@@ -183,7 +194,7 @@ void cdm_host_pack(const std::vector<std::string> &seqs, const std::vector<std::
     uint64_t total = 0;
     for (long i = 0; i < n; i++) { const std::string &x = changed[i] ? grown[i] : seqs[i]; off[i] = total; len[i] = (uint32_t) x.size(); total += x.size() + 2; }
     data.reset(new char[total + 1]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(cdm_host_threads())
     for (long i = 0; i < n; i++) { const std::string &x = changed[i] ? grown[i] : seqs[i]; char *d = data.get() + off[i]; memcpy(d, x.data(), x.size()); d[x.size()] = '\n'; d[x.size() + 1] = '\0'; }
 }
 int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
@@ -195,7 +206,7 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
     bool undefinedCase = false;
     const bool timing = getenv("CDM_TIMING") != nullptr;       // per-thread seconds in: candidate gate, queue pops, string growth, parked hits
     double tSum[4] = {0, 0, 0, 0}, tMax[4] = {0, 0, 0, 0}; unsigned long long nCmp = 0, nTerms = 0;
-#pragma omp parallel
+#pragma omp parallel num_threads(cdm_host_threads())
     {
         double tl[4] = {0, 0, 0, 0}; double tm = timing ? omp_get_wtime() : 0;
         auto lap = [&](int k) { if (timing) { const double n2 = omp_get_wtime(); tl[k] += n2 - tm; tm = n2; } };

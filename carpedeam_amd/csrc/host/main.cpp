@@ -549,7 +549,7 @@ int main(int argc, char **argv) {
         long th = a.flag.count("--threads") ? strtol(a.flag["--threads"].c_str(), NULL, 10) : 0;
         if (th <= 0) if (const char *e = getenv("MMSEQS_NUM_THREADS")) th = strtol(e, NULL, 10);
         omp_set_dynamic(0);      // every slice of the per-thread loops below has its thread
-        if (th > 0) omp_set_num_threads((int) th);
+        if (th > 0) { omp_set_num_threads((int) th); setenv("OMP_NUM_THREADS", std::to_string(th).c_str(), 1); }      // (the library's own loops read it)
     }
     auto t0 = std::chrono::steady_clock::now();
     int rc;
