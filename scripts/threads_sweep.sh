@@ -1,0 +1,10 @@
+#!/bin/bash
+# wall time of the workflow loop on <reads> reads for several host thread counts: scripts/threads_sweep.sh <reads> <t1> <t2> ...
+n=$1; shift
+d=$(mktemp -d)
+python scripts/write_reads_db.py $n 60 150 $d/in || exit 1
+for th in "$@"; do
+  carpedeam_amd/carpedeam ancient_reads_loop $d/in $d/out --ancient-damage $d/in_dhigh --num-iter-reads-only 5 --num-iterations 12 --threads $th 2> $d/log
+  echo "threads $th: $(grep 'Time for processing' $d/log)"
+done
+rm -rf $d
