@@ -19,6 +19,10 @@
 #include "../common.h"
 
 namespace {
+// lgammaf's value without its side effect: std::lgamma(float) also stores the sign in the C library's global `signgam`, one cache
+// line that every comparator call of every thread then writes - the host merge spent most of its time passing that line around
+// (16 threads did the work of one in a quarter of its time).  lgammaf_r is the same function with the sign in a local.
+inline float lgammaQuiet(float x) { int sign; return lgammaf_r(x, &sign); }
 struct Res {            // Matcher::result_t, the fields this module uses (M/alignment/Matcher.h:33-56)
     uint32_t target = 0, dbKey = 0;
     float seqId = 0, rySeqId = 0, deamMatch = 0;
@@ -28,7 +32,7 @@ struct Res {            // Matcher::result_t, the fields this module uses (M/ali
     bool isRev = false;
     // the comparator's two lgamma terms that depend on this record alone (same float arithmetic as there), set by cacheTerms()
     float lgBeta = 0, lgAlphaBeta = 0;
-    void cacheTerms() { const float mm = alnLengthCons - deamMatch, alpha = mm + 1, beta = deamMatch + 1; lgBeta = std::lgamma(beta); lgAlphaBeta = std::lgamma(alpha + beta); }
+    void cacheTerms() { const float mm = alnLengthCons - deamMatch, alpha = mm + 1, beta = deamMatch + 1; lgBeta = lgammaQuiet(beta); lgAlphaBeta = lgammaQuiet(alpha + beta); }
 };
 // ancientContigsResults.cpp:25-70 - arithmetic and overloads as there (`using namespace std` is in force in the reference:
 // lgamma / log of float arguments are the float functions)
@@ -42,7 +46,7 @@ struct CompareByScoreContigs {
         float alpha2 = mm_count2 + 1;
         float beta1 = r1.deamMatch + 1;
         float beta2 = r2.deamMatch + 1;
-        double log_c = (std::lgamma(beta1 + beta2) + r1.lgAlphaBeta) - (std::lgamma(alpha1 + beta1 + beta2) + r1.lgBeta);       // (= lgamma(alpha1 + beta1), lgamma(beta1))
+        double log_c = (lgammaQuiet(beta1 + beta2) + r1.lgAlphaBeta) - (lgammaQuiet(alpha1 + beta1 + beta2) + r1.lgBeta);       // (= lgamma(alpha1 + beta1), lgamma(beta1))
         double log_r = 0.0;
         double p = 0.0;
         for (size_t idx = 0; idx < alpha2; idx++) {
