@@ -139,6 +139,14 @@ int cdm_seqdb_alloc_raw(cdm_seqdb *db);      // the raw plane for db->words code
 // sub-DB: sel[i] (device) = 0xFFFFFFFF drops sequence i, else keeps its first sel[i] letters; extValue < 0 keeps the wasExtended flags
 int cdm_seqdb_select(cdm_ctx *ctx, const cdm_seqdb *db, const uint32_t *sel, int extValue, cdm_seqdb **out);
 
+// a sequence of the downloaded DB blob as the host part of ancient_contig_merge sees it (no copy, no allocation per sequence)
+struct SeqView {
+    const char *p = nullptr; size_t n = 0;
+    size_t size() const { return n; }
+    const char *data() const { return p; }
+    char operator[](size_t i) const { return p[i]; }
+    std::string substr(size_t a, size_t l) const { return std::string(p + a, l); }
+};
 // ancient_contig_merge: what the device counts per alignment record (contig.hip) for the host part (host/contigmerge.cpp)
 struct ContigStat {            // per alignment record, oriented as :193-214 does
     int32_t qs, qe, ds, de;

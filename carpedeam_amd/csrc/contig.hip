@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_contig_stats(StatArgs a) {
             const uint32_t ql = qn ? 4u : qc, tl = tn ? 4u : tc;
             idCnt += (ql == tl);
             idRy += (ryOf(qn ? 0u : qc) == ryOf(tn ? 0u : tc));       // ryMap of a letter outside ACGT is 0
-            if (!qn && !tn) { nnTot++; nnId += (qc == tc); nnRy += (ryOf(qc) == ryOf(tc)); nCT += (qc == 1u && tc == 3u); nGA += (qc == 2u && tc == 0u); }
+            if (!qn && !tn) { nnTot++; nnId += (qc == tc); nnRy += (ryOf(qc) == ryOf(tc)); nCT += (qc == 1u && tc == 3u); nGA += (qc == 2u && (tc == 0u || tc >= 4u)); }      // nucleotideMap: every target letter beyond ACGT is base 0, so G over 'a' or 'R' is a G->A column too
         }
         idCnt = cdm_wave_sum(idCnt); idRy = cdm_wave_sum(idRy); nnTot = cdm_wave_sum(nnTot); nnId = cdm_wave_sum(nnId); nnRy = cdm_wave_sum(nnRy);
         nCT = cdm_wave_sum(nCT); nGA = cdm_wave_sum(nGA);
@@ -88,10 +88,10 @@ __global__ void k_rec_owner(const uint64_t *__restrict__ aoff, uint32_t n, uint3
 
 // host/contigmerge.cpp
 // (host/contigmerge.cpp, OpenMP) the DB blob as one string per sequence / the strings as one DB blob "SEQ\n\0..."
-void cdm_host_split(const std::string &blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<std::string> &seqs);
-void cdm_host_pack(const std::vector<std::string> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, std::unique_ptr<char[]> &data,
+void cdm_host_split(const std::string &blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<SeqView> &seqs);
+void cdm_host_pack(const std::vector<SeqView> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, std::unique_ptr<char[]> &data,
                    std::vector<uint64_t> &off, std::vector<uint32_t> &len);
-int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
+int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
                           const std::vector<cdm_aln> &recs, const std::vector<ContigStat> &stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
                           float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::vector<uint8_t> &changed, std::string *err);
 
@@ -130,9 +130,8 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     lap("statistics + records down");
     if (int rc = cdm_seqdb_download(ctx, db, &blob[0], offs.data())) return rc;
     lap("sequences down");
-    std::vector<std::string> seqs(n), outSeqs; std::vector<uint8_t> outExt, changed;
-    cdm_host_split(blob, offs, lens, seqs);
-    { std::string().swap(blob); }
+    std::vector<SeqView> seqs(n); std::vector<std::string> outSeqs; std::vector<uint8_t> outExt, changed;
+    cdm_host_split(blob, offs, lens, seqs);      // views into the blob, which stays until the result is packed
     lap("split");
     std::string err;
     if (int rc = cdm_contig_merge_host(seqs, keys, ext, aoff, recs, stats, ctx->mats, par, mergeSeqIdThr, outSeqs, outExt, changed, &err)) { cdm_set_error("%s", err.c_str()); return rc; }
@@ -140,7 +139,7 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     // the result goes back up as a DB (same keys, new lengths and flags)
     std::vector<uint64_t> oOff; std::vector<uint32_t> oLen; std::unique_ptr<char[]> data;
     cdm_host_pack(seqs, outSeqs, changed, data, oOff, oLen);
-    { std::vector<std::string>().swap(outSeqs); std::vector<std::string>().swap(seqs); }
+    { std::vector<std::string>().swap(outSeqs); std::vector<SeqView>().swap(seqs); std::string().swap(blob); }
     lap("pack");
     const int rcUp = cdm_seqdb_upload(ctx, data.get(), oOff.data(), oLen.data(), keys.data(), outExt.data(), n, out);
     lap("upload");

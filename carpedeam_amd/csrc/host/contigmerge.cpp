@@ -123,14 +123,14 @@ inline int nucMap(char c) { return c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 
 // consensusCaller's majority vote over the candidates that extend the query (nuclassembleUtil.cpp:570-702, calculateConsensus
 // :535-567) - 3 qLen letters, the query in the middle third, elsewhere the majority letter where at least minCov candidates cover
 // the position ('N' below that and on ties)
-std::string unsafeConsensus(const std::vector<Res> &cands, const std::vector<std::string> &seqs, const std::string &q, uint32_t queryKey, unsigned minCov, bool &undefinedCase) {
+std::string unsafeConsensus(const std::vector<Res> &cands, const std::vector<SeqView> &seqs, const SeqView &q, uint32_t queryKey, unsigned minCov, bool &undefinedCase) {
     const unsigned qLen = (unsigned) q.size();
     std::vector<std::array<unsigned, 4>> cov(3 * (size_t) qLen, std::array<unsigned, 4>{{0, 0, 0, 0}});
     for (const Res &c : cands) {
         const bool rightStart = c.dbStartPos == 0 && (c.dbEndPos != static_cast<int>(c.dbLen) - 1);
         const bool leftStart = c.qStartPos == 0 && (c.qEndPos != static_cast<int>(c.qLen) - 1);
         if (!(rightStart || leftStart) || c.dbKey == queryKey) continue;
-        const std::string &t0 = seqs[c.target];
+        const SeqView &t0 = seqs[c.target];
         const unsigned tLen = (unsigned) t0.size();
         long start;
         if ((unsigned) c.dbStartPos == 0 && (unsigned) c.qEndPos == (qLen - 1)) start = (long) qLen + c.qStartPos;
@@ -155,7 +155,7 @@ std::string unsafeConsensus(const std::vector<Res> &cands, const std::vector<std
 }
 // the columns updateSeqIdConsensus (:705-790) and ancientMatchCount (:1047-1181) walk in that mode: the padded target against the
 // whole consensus, flanks included -> defined columns, identical, same RY class, consensus C over target T, consensus G over target A
-void unsafeColumns(const Res &c, const std::string &cons, const std::string &t0, unsigned qLen, bool leftStart, int &tot, int &idc, int &idr, int &nCT, int &nGA) {
+void unsafeColumns(const Res &c, const std::string &cons, const SeqView &t0, unsigned qLen, bool leftStart, int &tot, int &idc, int &idr, int &nCT, int &nGA) {
     const unsigned tLen = (unsigned) t0.size();
     const std::string t = c.isRev ? revComp(t0.data(), tLen) : std::string();
     const char *ts = c.isRev ? t.data() : t0.data();
@@ -184,24 +184,27 @@ static int cdm_host_threads() {
     }();
     return n;
 }
-void cdm_host_split(const std::string &blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<std::string> &seqs) {
+void cdm_host_split(const std::string &blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<SeqView> &seqs) {
     const long n = (long) offs.size();
     seqs.resize(n);
-#pragma omp parallel for schedule(static) num_threads(cdm_host_threads())
-    for (long i = 0; i < n; i++) seqs[i].assign(blob, offs[i], lens[i]);
+#pragma omp parallel for schedule(dynamic, 512) num_threads(cdm_host_threads())
+    for (long i = 0; i < n; i++) { seqs[i].p = blob.data() + offs[i]; seqs[i].n = lens[i]; }
 }
 // changed[i] != 0: sequence i is grown[i], otherwise still seqs[i].  The blob is written by all threads (first touch included).
-void cdm_host_pack(const std::vector<std::string> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, std::unique_ptr<char[]> &data,
+void cdm_host_pack(const std::vector<SeqView> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, std::unique_ptr<char[]> &data,
                    std::vector<uint64_t> &off, std::vector<uint32_t> &len) {
     const long n = (long) seqs.size();
     off.resize(n); len.resize(n);
     uint64_t total = 0;
-    for (long i = 0; i < n; i++) { const std::string &x = changed[i] ? grown[i] : seqs[i]; off[i] = total; len[i] = (uint32_t) x.size(); total += x.size() + 2; }
+    for (long i = 0; i < n; i++) { const size_t L = changed[i] ? grown[i].size() : seqs[i].size(); off[i] = total; len[i] = (uint32_t) L; total += L + 2; }
     data.reset(new char[total + 1]);
-#pragma omp parallel for schedule(static) num_threads(cdm_host_threads())
-    for (long i = 0; i < n; i++) { const std::string &x = changed[i] ? grown[i] : seqs[i]; char *d = data.get() + off[i]; memcpy(d, x.data(), x.size()); d[x.size()] = '\n'; d[x.size() + 1] = '\0'; }
+#pragma omp parallel for schedule(dynamic, 512) num_threads(cdm_host_threads())
+    for (long i = 0; i < n; i++) {
+        const char *x = changed[i] ? grown[i].data() : seqs[i].data(); const size_t L = len[i];
+        char *d = data.get() + off[i]; memcpy(d, x, L); d[L] = '\n'; d[L + 1] = '\0';
+    }
 }
-int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
+int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
                           const std::vector<cdm_aln> &recs, const std::vector<ContigStat> &stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
                           float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::vector<uint8_t> &changed, std::string *err) {
     const size_t n = seqs.size();
@@ -220,7 +223,7 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
 #pragma omp for schedule(dynamic, 100)
         for (size_t id = 0; id < n; id++) {
             const uint32_t queryKey = keys[id];
-            const std::string &q0 = seqs[id];
+            const SeqView &q0 = seqs[id];
             unsigned qLen = (unsigned) q0.size();
             std::string query;                              // working copy, made once a candidate exists
             contigs.clear();
@@ -287,14 +290,14 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
             lap(0);
             // :276-470 extension
             if (queue.empty()) { outExt[id] = ext[id]; continue; }
-            query = q0;
+            query.assign(q0.data(), q0.size());
             bool couldExtend = false;
             while (!queue.empty()) {
                 unsigned leftOff = 0, rightOff = 0;
                 parked.clear();
                 Res best;
                 while (selectFragment(queue, queryKey, best)) {
-                    const std::string &t = seqs[best.target];
+                    const SeqView &t = seqs[best.target];
                     const unsigned tLen = (unsigned) t.size();
                     if (best.dbStartPos == 0) { if ((tLen - (best.dbEndPos + 1)) <= rightOff) continue; }
                     else if (best.qStartPos == 0) { if (best.dbStartPos <= static_cast<int>(leftOff)) continue; }
@@ -320,7 +323,7 @@ int cdm_contig_merge_host(const std::vector<std::string> &seqs, const std::vecto
                 // :404-455 the parked hits on the grown query: ungappedAlignmentByDiagonal (mode 3), updateNuclAlignment, getRYSeqId
                 for (Res &a : parked) {
                     // the target as the reference holds it here: its own letters, or getNuclRevFragment's (letter j = complement of letter tLen-1-j)
-                    const std::string &t0 = seqs[a.target];
+                    const SeqView &t0 = seqs[a.target];
                     const unsigned tLen = (unsigned) t0.size();
                     const bool rev = useReverse[a.target] != 0;
                     const int diag = (a.qStartPos + (int) leftOff) - a.dbStartPos;

@@ -129,6 +129,27 @@ def test_contig_merge_unsafe_mode_matches_oracle(oracle_bin, dhigh_prefix, tmp_p
 
 
 @pytest.mark.gpu
+def test_contig_merge_counts_g_over_exotic_letter_as_g_to_a(oracle_bin, dhigh_prefix, tmp_path):
+    """a database the module fuzzer found (seed 71, case 21): contigs with lower-case / IUPAC letters where a consensus G stands over a
+    target letter that nucleotideMap sends to base 0 - ancientMatchCount counts that as a G->A column (nuclassembleUtil.cpp:1122-1140),
+    which decides the order of the queue and with it which contig donates the extension"""
+    from carpedeam_amd import build
+    build.build()
+    exe = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_from_keyed(t("in"), mmdb.load_keyed(os.path.join(ROOT, "tests", "golden", "fuzzcases", "contig_ga_letters.keyed.gz")), mmdb.DBTYPE_NUCLEOTIDES)
+    dmg = ["--ancient-damage", dhigh_prefix, "--threads", "2"]
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *KC_FLAGS, "--threads", "1")
+    run_oracle(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref"), t("aln"), *R_FLAGS, "--threads", "2")
+    run_oracle(oracle_bin, "ancient_correction", t("in"), t("aln"), t("corr"), *AC_FLAGS, *dmg)
+    run_oracle(oracle_bin, "ancient_contig_merge", t("corr"), t("aln"), t("o"), *AC_FLAGS, *dmg)
+    r = subprocess.run([exe, "ancient_contig_merge", t("corr"), t("aln"), t("g"), *AC_FLAGS, *dmg], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert not diff_keys(mmdb.read_db(t("g")), mmdb.read_db(t("o")))
+    assert diff_keys(mmdb.read_db(t("g")), mmdb.read_db(t("corr")))        # (something is merged at all)
+
+
+@pytest.mark.gpu
 def test_fused_loop_through_both_phases(dhigh_prefix, tmp_path):
     """`ancient_reads_loop --num-iter-reads-only 3 --num-iterations 5`: three reads iterations and two contig iterations in one process,
     every intermediate in HBM, ends in the reference's own contig-phase golden (which chains its own DBs the same way)."""
