@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 from carpedeam_amd import capi, mmdb, synth
-from gpuutil import diff_keys, run_oracle, seqdb_to_keyed
+from gpuutil import OracleCrash, diff_keys, run_oracle, seqdb_to_keyed
 from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
 from test_oracle_golden import pref_sign_ties
 
@@ -36,6 +36,7 @@ if mode == "contigparams":
 fails = 0
 ties = 0
 unsupported = 0
+undefined = 0
 for case in range(cases):
     G = {"small": 300, "deep": 150, "repeats": 200, "contigparams": 400, "longreads": 1500, "palrepeats": 700, "nrich": 300, "verylong": 6000, "tiling": 600, "tiny": 60, "letters": 300}[mode]
     genome = rng.integers(0, 4, G)
@@ -117,9 +118,13 @@ for case in range(cases):
                 print("  reads saved:", fn, len(seqs), flush=True)
                 break
             db = asm
+    except OracleCrash as e:
+        # e.g. a sequence whose self alignment scores 0 on every diagonal ("-*CGT"): the reference writes coordinates -1 into its
+        # identity record and its own ancient_correction indexes the sequence with them; nothing to compare with
+        undefined += 1
     except capi.CdmError as e:
         if "not implemented" in str(e):
             unsupported += 1                    # a documented limit of the device path (refused, never computed differently)
         else:
             print("ERROR", mode, "case", case, str(e)[:300], flush=True); fails += 1
-print("mode", mode, "cases", cases, "failures", fails, "sign-tie cases skipped", ties, "refused as unsupported", unsupported, flush=True)
+print("mode", mode, "cases", cases, "failures", fails, "sign-tie cases skipped", ties, "refused as unsupported", unsupported, "undefined in the reference (it crashes)", undefined, flush=True)

@@ -18,8 +18,14 @@ def stage_input(name, it):
     return gold(name, "reads") if it == 0 else gold(name, "asm", it - 1)
 
 
+class OracleCrash(AssertionError):
+    """the oracle (or the reference binary) ended with a signal: an input on which the reference's behaviour is undefined"""
+
+
 def run_oracle(exe, *args):
     r = subprocess.run([exe] + list(args), capture_output=True, text=True)
+    if r.returncode < 0:
+        raise OracleCrash("%s %s ended with signal %d" % (os.path.basename(exe), args[0], -r.returncode))
     assert r.returncode == 0, r.stderr[-2000:]
 
 
