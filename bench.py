@@ -57,7 +57,7 @@ def stage_cmds(p, exe_threads, dmg):
 def module_walls(n_reads, L, seed, threads):
     """Module-wall figures on DB FILES of one bounded sample: the four stages of the reference's own
     object code (oracle/_ref; the CPU restatement oracle/cdm_oracle.cpp when that binary is absent) on `threads` host threads
-    = cpu_baseline, and the same four modules + the fused reads loop of the MI355X host binary carpedeam_amd/carpedeam
+    = cpu_baseline, and the same four modules + the fused reads loop of the MI355X host binary carpedeam_amd/carpedeam_mi355x
     (DB read/parse, upload, kernels, download, text, DB write all inside) = gpu_module_wall."""
     from carpedeam_amd import capi, mmdb, synth
     ref = os.path.join(ROOT, "oracle", "_ref", "carpedeam_ref")
@@ -66,7 +66,7 @@ def module_walls(n_reads, L, seed, threads):
         kind, exe = "port", os.path.join(ROOT, "oracle", "_build", "cdm_oracle")
         if not os.path.exists(exe):
             subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
-    gpu_bin = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
+    gpu_bin = os.path.join(ROOT, "carpedeam_amd", "carpedeam_mi355x")
     ctx = capi.Ctx(0)
     seqs, _, _ = ctx.synth(n_reads, L, L, seed).download()
     del ctx
@@ -93,7 +93,7 @@ def module_walls(n_reads, L, seed, threads):
     cpu = {"value": n_reads * L / sum(out["cpu"].values()), "unit": "corrected bases/s", "cores": threads, "kind": kind,
            "sample": sample + ", %d threads; stage s: %s" % (threads, fmt(out["cpu"])),
            "ancient_correction_only_value": n_reads * L / out["cpu"]["ancient_correction"]}
-    gpu = {"value": n_reads * L / sum(out["gpu"].values()), "unit": "corrected bases/s", "what": "carpedeam_amd/carpedeam, one process per module (context creation, DB files, upload, text codecs included)",
+    gpu = {"value": n_reads * L / sum(out["gpu"].values()), "unit": "corrected bases/s", "what": "carpedeam_amd/carpedeam_mi355x, one process per module (context creation, DB files, upload, text codecs included)",
            "sample": sample + "; stage s: %s" % fmt(out["gpu"]),
            "fused_reads_loop_value": (n_reads * L / loop_s) if loop_s else None}
     return cpu, gpu
@@ -145,6 +145,8 @@ def run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch):
                 break
         return bases, db, per_it, circular
 
+    gather_info = {}
+
     def sync():
         if dist is not None:
             dist.barrier()
@@ -192,7 +194,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(2, 3, 5), help="BASELINE.json configs index + 1: 2 = ancient_correction only on 5 M reads, 3 = full chain on 50 M reads, 5 = the 12-iteration loop (5 read + 7 contig iterations with cyclecheck) on mixed-length reads, 2 M per GPU unless --reads says otherwise")
     ap.add_argument("--reads", type=int, default=None, help="reads of the corpus (strong scaling) / per GPU (weak)")
     ap.add_argument("--len", type=int, default=100)
-    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=None, help="generator seed (default: 1, and 2 for --config 5, as SURVEY.md 8(d) specifies the corpora)")
     ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
     ap.add_argument("--scheme", default="reads", choices=("reads", "exact"),
                     help="N > 1: reads = every rank runs the stages on its own read shard (north star; not equivalent to the single-device run); "
@@ -200,6 +202,8 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.seed is None:
+        args.seed = 2 if args.config == 5 else 1
     if args.steps is None:
         args.steps = 1 if args.config == 5 else 3
     if args.warmup is None:
@@ -212,8 +216,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if args.gpus != world and rank == 0:
-        print("bench.py: --gpus %d but WORLD_SIZE is %d: running on %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
+    if args.gpus != world:      # a line that says n_gpus = N must come from N ranks
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     import torch
     dist = None
     if world > 1 or os.environ.get("CDM_FORCE_DIST"):   # CDM_FORCE_DIST: exercise the collective path on one GPU
@@ -262,7 +266,18 @@ def main():
         del hits
         corr = ctx.correct(db, alns)
         asm = ctx.extend(corr, alns)
-        return asm, stats, [ctx.last_kernel_ms(i) for i in range(16)]
+        ms = [ctx.last_kernel_ms(i) for i in range(16)]
+        if dist is not None:
+            # configs[3]: the single data-path collective of the north star is part of the step - RCCL all-gather of the per-shard
+            # contigs (packed bases, N planes, lengths, keys in ONE buffer); every rank ends the step holding the contigs of all shards
+            t1 = time.perf_counter()
+            allc = cd.allgather_contigs(dist, ctx, asm, world, key_base=plan["first"] if args.scaling == "strong" else rank * args.reads)
+            torch.cuda.synchronize()
+            gather_info.update(contigs=allc.n, bases=allc.residues, seconds=gather_info.get("seconds", 0.0) + time.perf_counter() - t1, calls=gather_info.get("calls", 0) + 1)
+            del allc
+        return asm, stats, ms
+
+    gather_info = {}
 
     def sync():
         if dist is not None:
@@ -272,6 +287,7 @@ def main():
     for _ in range(args.warmup):
         out = step()
         del out
+    gather_info.clear()
     sync()
     t0 = time.perf_counter()
     kernel_ms = [0.0] * 16
@@ -291,13 +307,9 @@ def main():
             tb = torch.tensor([float(total_bases)], dtype=torch.float64, device="cuda")
             dist.all_reduce(tb)
             total_bases = float(tb.item())
-        if args.config == 3 and not exact:
-            # the single data-path collective of the north star: RCCL all-gather of the per-shard contigs (packed bases, N
-            # planes, lengths, keys in ONE buffer); every rank ends up holding the contigs of all shards as one device DB
-            t1 = time.perf_counter()
-            allc = cd.allgather_contigs(dist, ctx, asm, world, key_base=plan["first"] if args.scaling == "strong" else rank * args.reads)
-            torch.cuda.synchronize()
-            gathered = {"contigs": allc.n, "bases": allc.residues, "seconds": time.perf_counter() - t1}
+        if args.config == 3 and not exact and gather_info:
+            gathered = {"contigs": gather_info["contigs"], "bases": gather_info["bases"], "seconds_per_step": gather_info["seconds"] / max(1, gather_info["calls"]),
+                        "inside_timed_region": True}
     if rank == 0:
         k_ms = [m / args.steps for m in kernel_ms]
         step_ms = 1e3 * dt / args.steps

@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcarpedeam_hip.so")
-BIN = os.path.join(HERE, "carpedeam")
+BIN = os.path.join(HERE, "carpedeam_mi355x")     # the device module binary (host/main.cpp)
+FRONT = os.path.join(HERE, "carpedeam")          # the front end that takes the reference binary's place (host/front.c; no HIP inside)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ROCM_INC = "/opt/rocm/include"
 
@@ -72,6 +73,12 @@ def build(verbose=False):
             if r.returncode:
                 sys.stderr.write(r.stdout + r.stderr)
                 raise RuntimeError("host binary link failed")
+    front_src = os.path.join(hostdir, "front.c")
+    if os.path.exists(front_src) and _newer(front_src, FRONT):
+        r = subprocess.run(["gcc", "-O2", "-Wall", "-o", FRONT, front_src], capture_output=True, text=True)
+        if r.returncode:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("front end build failed")
     return LIB
 
 

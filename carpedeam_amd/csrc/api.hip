@@ -19,51 +19,70 @@ extern "C" const char *cdm_last_error(void) { return g_err; }
 #include <map>
 #include <mutex>
 #include <unordered_map>
+#include <sys/syscall.h>
+#include <unistd.h>
 namespace {
-struct Pool {
+// One cache of free blocks per host thread and device: a context belongs to one host thread, and a block freed by
+// one thread's stream must not be handed to another thread's stream without synchronisation (ranks as threads of one process in
+// the tests).  Which block has which size and whose it is lives in ONE process-wide registry: a block freed by another thread than
+// its allocator's is released and forgotten there, so no cache can meet its address again with a stale size.
+struct Pool;
+struct Registry {
     std::mutex m;
-    std::multimap<size_t, void *> freeBlocks;
-    std::unordered_map<void *, size_t> sizes;
+    std::unordered_map<void *, std::pair<size_t, Pool *>> blocks;
 };
-// One cache per host thread and device: a context belongs to one host thread, and a block freed by one thread's
-// stream must not be handed to another thread's stream without synchronisation (ranks as threads of one process in the tests).  A
-// block freed by another thread than its allocator's is simply released.
-Pool &poolOf(int dev) { static thread_local Pool pools[64]; return pools[dev & 63]; }
+Registry &registry() { static Registry *r = new Registry(); return *r; }      // (never destroyed: thread_local pools may outlive statics)
+struct Pool {
+    std::multimap<size_t, void *> freeBlocks;                                  // touched by the owning thread only
+    void trim() {
+        Registry &r = registry();
+        std::lock_guard<std::mutex> g(r.m);
+        for (auto &kv : freeBlocks) { r.blocks.erase(kv.second); (void) hipFree(kv.second); }
+        freeBlocks.clear();
+    }
+};
+struct Pools {
+    Pool p[64];
+    // a thread that ends without cdm_ctx_destroy gives its blocks back (not the main thread: its end is the end of the process, and
+    // the HIP runtime may be half-way through its own tear-down by then)
+    ~Pools() { if (getpid() != (pid_t) syscall(SYS_gettid)) for (Pool &q : p) if (!q.freeBlocks.empty()) q.trim(); }
+};
+Pool &poolOf(int dev) { static thread_local Pools pools; return pools.p[dev & 63]; }
 }  // namespace
 hipError_t cdmMallocRaw(void **p, size_t bytes) {
     int dev = 0; hipGetDevice(&dev);
     Pool &pool = poolOf(dev);
     bytes = (bytes + 255) & ~(size_t) 255;
     if (bytes == 0) bytes = 256;
-    {
-        std::lock_guard<std::mutex> g(pool.m);
-        auto it = pool.freeBlocks.lower_bound(bytes);
-        if (it != pool.freeBlocks.end() && it->first <= bytes + bytes / 8) { *p = it->second; pool.freeBlocks.erase(it); return hipSuccess; }
-    }
+    auto it = pool.freeBlocks.lower_bound(bytes);
+    if (it != pool.freeBlocks.end() && it->first <= bytes + bytes / 8) { *p = it->second; pool.freeBlocks.erase(it); return hipSuccess; }
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) {   // out of memory with blocks parked in the cache: release them and retry once
         (void) hipGetLastError();
         cdmPoolTrim();
         e = hipMalloc(p, bytes);
     }
-    if (e == hipSuccess) { std::lock_guard<std::mutex> g(pool.m); pool.sizes[*p] = bytes; }
+    if (e == hipSuccess) { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); r.blocks[*p] = {bytes, &pool}; }
     return e;
 }
 void cdmFree(void *p) {
     if (!p) return;
     int dev = 0; hipGetDevice(&dev);
     Pool &pool = poolOf(dev);
-    std::lock_guard<std::mutex> g(pool.m);
-    auto it = pool.sizes.find(p);
-    if (it == pool.sizes.end()) { hipFree(p); return; }
-    pool.freeBlocks.emplace(it->second, p);
+    size_t bytes = 0;
+    {
+        Registry &r = registry();
+        std::lock_guard<std::mutex> g(r.m);
+        auto it = r.blocks.find(p);
+        if (it != r.blocks.end() && it->second.second == &pool) bytes = it->second.first;
+        else if (it != r.blocks.end()) r.blocks.erase(it);
+    }
+    if (bytes) pool.freeBlocks.emplace(bytes, p);
+    else (void) hipFree(p);
 }
 void cdmPoolTrim() {
     int dev = 0; hipGetDevice(&dev);
-    Pool &pool = poolOf(dev);
-    std::lock_guard<std::mutex> g(pool.m);
-    for (auto &kv : pool.freeBlocks) { pool.sizes.erase(kv.second); hipFree(kv.second); }
-    pool.freeBlocks.clear();
+    poolOf(dev).trim();
 }
 
 // ------------------------------------------------------------------------------------------------ context

@@ -243,7 +243,10 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
                 }
                 bool undef = false;
                 if (!contigs.empty()) cons = unsafeConsensus(contigs, seqs, q0, queryKey, (unsigned) std::max(0, par->min_cov_safe), undef);
-                if (undef) undefinedCase = true;
+                if (undef) {
+#pragma omp atomic write
+                    undefinedCase = true;
+                }
             }
             for (uint64_t r = aoff[id]; r < aoff[id + 1]; r++) {
                 const cdm_aln &a = recs[r]; const ContigStat &st = stats[r];
@@ -260,7 +263,10 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
                     const bool leftStart = (unsigned) x.qStartPos == 0 && (unsigned) x.dbEndPos == (x.dbLen - 1);
                     int tot = 0, idc = 0, idr = 0, nCT = st.nCT, nGA = st.nGA;
                     if (leftStart || rightStart) {
-                        if (x.dbLen - x.alnLength > qLen) undefinedCase = true;     // the reference pads with qLen - offset letters
+                        if (x.dbLen - x.alnLength > qLen) {                         // the reference pads with qLen - offset letters
+#pragma omp atomic write
+                            undefinedCase = true;
+                        }
                         else if (unsafeMode) unsafeColumns(x, cons, seqs[x.target], qLen, leftStart, tot, idc, idr, nCT, nGA);
                         else { tot = st.nnTot; idc = st.nnId; idr = st.nnRy; }
                     }

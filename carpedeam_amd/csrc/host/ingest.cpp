@@ -190,10 +190,12 @@ int convert2fastaModule(const std::string &dbPath, const std::string &outPath, s
 }
 
 int createhdbModule(const std::string &seqPath, const std::string &cyclePath, const std::string &outPath, std::string *err) {
+    // both DBs are opened with USE_INDEX only (createhdb.cpp:21-31): the workflow hands over a cycle "DB" that is nothing but an
+    // index file written by awk (data/nuclassemble.sh:222-241), and lengths come from the index anyway
     MmDb db, cyc;
-    if (!db.load(seqPath, err)) return 1;
+    if (!db.load(seqPath, err, true)) return 1;
     const bool hasCycle = !cyclePath.empty();
-    if (hasCycle && !cyc.load(cyclePath, err)) return 1;
+    if (hasCycle && !cyc.load(cyclePath, err, true)) return 1;
     OutChunk c;
     for (size_t id = 0; id < db.size(); id++) {      // createhdb.cpp: "<id> len:<len>[ cycle:<0|1>]\n" under the sequence's key
         std::string h = std::to_string(id) + " len:" + std::to_string(db.len[id] >= 2 ? db.len[id] - 2 : 0);

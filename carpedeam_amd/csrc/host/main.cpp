@@ -1,4 +1,5 @@
-// carpedeam (MI355X build): the module surface of the reference's hot path.
+// carpedeam_mi355x: the module surface of the reference's hot path on the device (reached through the front end `carpedeam`,
+// host/front.c, which also forwards every other command to the reference's binary when a deployment has one).
 //
 //   carpedeam kmermatcher           <seqDB> <prefDB> [flags]                  lib/mmseqs/src/linclust/kmermatcher.cpp:786
 //   carpedeam rescorediagonal       <qDB> <tDB> <prefDB> <alnDB> [flags]      lib/mmseqs/src/alignment/rescorediagonal.cpp:381
@@ -35,6 +36,9 @@ int createhdbModule(const std::string &seqPath, const std::string &cyclePath, co
 
 namespace {
 [[noreturn]] void die(const std::string &msg) { fprintf(stderr, "%s\n", msg.c_str()); exit(EXIT_FAILURE); }
+// a call the device path does not implement, found before any work was done: status 77 tells the front end (host/front.c) that the
+// reference binary - if the deployment has one - may take this call instead
+[[noreturn]] void unsupported(const std::string &msg) { fprintf(stderr, "%s\n", msg.c_str()); exit(77); }
 void check(int rc, const char *what) { if (rc != CDM_OK) die(std::string(what) + ": " + cdm_last_error()); }
 
 struct Args { std::vector<std::string> pos; std::map<std::string, std::string> flag; };
@@ -72,7 +76,7 @@ const FlagSpec ANCIENT_FLAGS[] = {
     {"--min-seq-id", 'U', 0, 0}, {"--max-seq-len", 'U', 0, 0}, {"--ext-random-align", 'U', 0, 0}, {"--excess-penalty", 'U', 0, 0}, {"--min-ryseq-id-corr-reads", 'U', 0, 0},
     {"--likelihood-ratio-threshold", 'U', 0, 0}, {"--ancient-damage", 'U', 0, 0}, {"--unsafe", 'U', 0, 0}, {"--min-cov-safe", 'U', 0, 0},
     {"--keep-target", 'N', 0, "not read by these modules"}, {"--min-seqid-corr-reads", 'N', 0, "not read by these modules"}, {"--min-merge-seq-id", 'U', 0, 0},
-    {"--min-seqid-corr-contigs", 'N', 0, "contig correction only"}, {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0},
+    {"--min-seqid-corr-contigs", 'N', 0, "a workflow flag: it becomes the contig phase's --min-seq-id (Nuclassembler.cpp:124-126); ancient_reads_loop reads it"}, {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0},
     {"--rescore-mode", 'V', "3", "re-alignment of parked candidates is end-to-end ungapped (ancientReadsResults.cpp:502)"}, {0, 0, 0, 0}};
 void checkFlags(const char *module, const Args &a, const FlagSpec *spec, const char *const *extra = NULL) {
     for (const auto &kv : a.flag) {
@@ -84,7 +88,7 @@ void checkFlags(const char *module, const Args &a, const FlagSpec *spec, const c
         if (f->name && f->kind == 'V') {
             const std::string al = f->allowed;
             const bool ok = (al.size() >= 2 && al[0] == '*') ? kv.second.find(al.substr(1, al.size() - 2)) != std::string::npos : kv.second == al;
-            if (!ok) die(std::string(module) + ": " + kv.first + " " + kv.second + " is not supported by the MI355X path (" + f->why + "; accepted: " + (al.empty() ? "\"\"" : al) + ")");
+            if (!ok) unsupported(std::string(module) + ": " + kv.first + " " + kv.second + " is not supported by the MI355X path (" + f->why + "; accepted: " + (al.empty() ? "\"\"" : al) + ")");
         }
     }
 }
@@ -108,7 +112,7 @@ cdm_ctx *openCtx() {
     return ctx;
 }
 cdm_seqdb *uploadSeqDb(cdm_ctx *ctx, const MmDb &db) {
-    if ((db.dbtype & 0x7FFFFFFF) != 1) die("The MI355X path works on nucleotide sequence DBs only (dbtype " + std::to_string(db.dbtype & 0x7FFFFFFF) + " given)");
+    if ((db.dbtype & 0x7FFFFFFF) != 1) unsupported("The MI355X path works on nucleotide sequence DBs only (dbtype " + std::to_string(db.dbtype & 0x7FFFFFFF) + " given)");
     std::vector<uint32_t> lens(db.size());
     for (size_t i = 0; i < db.size(); i++) lens[i] = db.len[i] >= 2 ? (uint32_t) (db.len[i] - 2) : 0;   // DBReader::getSeqLen
     cdm_seqdb *h = NULL;
@@ -280,8 +284,8 @@ int kmermatcher(Args &a) {
 int rescorediagonal(Args &a) {
     if (a.pos.size() < 4) die("Usage: carpedeam rescorediagonal <i:queryDB> <i:targetDB> <i:prefilterDB> <o:resultDB>");
     checkFlags("rescorediagonal", a, RESCORE_FLAGS);
-    if (a.pos[0] != a.pos[1]) die("rescorediagonal: query and target DB must be the same on the MI355X path");
-    if (!a.flag.count("--rescore-mode")) die("rescorediagonal: --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
+    if (a.pos[0] != a.pos[1]) unsupported("rescorediagonal: query and target DB must be the same on the MI355X path");
+    if (!a.flag.count("--rescore-mode")) unsupported("rescorediagonal: --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
     MmDb seq, pref; std::string err; if (!seq.load(a.pos[1], &err) || !pref.load(a.pos[2], &err)) die(err);
     Laps laps; laps.lap("DB files mapped");
     cdm_ctx *ctx = openCtx(); laps.lap("device context");
@@ -378,7 +382,7 @@ int ancientModule(Args &a, int mode) {      // 0 ancient_correction, 1 ancient_r
     const char *name = mode == 0 ? "ancient_correction" : mode == 1 ? "ancient_read_assemble" : "ancient_contig_merge";
     if (a.pos.size() < 3) die(std::string("Usage: carpedeam ") + name + " <i:sequenceDB> <i:alnResult> <o:reprSeqDB>");
     checkFlags(name, a, ANCIENT_FLAGS);
-    if (mode >= 1 && !a.flag.count("--rescore-mode")) die(std::string(name) + ": --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
+    if (mode >= 1 && !a.flag.count("--rescore-mode")) unsupported(std::string(name) + ": --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
     MmDb seq, aln; std::string err; if (!seq.load(a.pos[0], &err) || !aln.load(a.pos[1], &err)) die(err);
     Laps laps; laps.lap("DB files mapped");
     cdm_ctx *ctx = openCtx(); laps.lap("device context");
@@ -462,6 +466,10 @@ int readsLoop(Args &a) {
     cdm_kmer_params kc = kp;
     kc.kmer_size = (int) iflag(a, "--k-ancient-contigs", 22); kc.include_only_extendable = (int) iflag(a, "--include-only-extendable-ancient-contigs", 1);
     const float mergeThr = fflag(a, "--min-merge-seq-id", 0.99f);
+    // the workflow builds the contig phase's rescorediagonal / assembler parameter strings after `par.seqIdThr = par.corrContigSeqId`
+    // (Nuclassembler.cpp:124-126): there --min-seq-id IS --min-seqid-corr-contigs (LocalParameters.h default 0.9)
+    cdm_rescore_params rc = rp; cdm_ancient_params ac = ap;
+    rc.seq_id_thr = ac.seq_id_thr = fflag(a, "--min-seqid-corr-contigs", 0.9f);
     const bool cycleCheck = iflag(a, "--cycle-check", 1) != 0, chopCycle = iflag(a, "--chop-cycle", 1) != 0;
     OutChunk cyclic;
     for (long it = 0; it < total && cdm_seqdb_size(db) > 0; it++) {
@@ -469,10 +477,10 @@ int readsLoop(Args &a) {
         const bool contigs = it >= iters;
         const auto tIt = std::chrono::steady_clock::now();
         check(cdm_kmermatch(ctx, db, contigs ? &kc : &kp, &hits), "kmermatcher");
-        check(cdm_rescore(ctx, db, hits, &rp, &alns), "rescorediagonal");
+        check(cdm_rescore(ctx, db, hits, contigs ? &rc : &rp, &alns), "rescorediagonal");
         cdm_hits_free(hits);
-        check(cdm_correct(ctx, db, alns, &ap, &corr), "ancient_correction");
-        if (contigs) check(cdm_contig_merge(ctx, corr, alns, &ap, mergeThr, &next), "ancient_contig_merge");
+        check(cdm_correct(ctx, db, alns, contigs ? &ac : &ap, &corr), "ancient_correction");
+        if (contigs) check(cdm_contig_merge(ctx, corr, alns, &ac, mergeThr, &next), "ancient_contig_merge");
         else check(cdm_extend(ctx, corr, alns, &ap, &next, NULL), "ancient_read_assemble");
         fprintf(stderr, "STEP: %ld  sequences %llu  residues %llu -> %llu  alignments %llu  (%.3f s; device stages: kmermatcher %.0f, rescorediagonal %.0f, ancient_correction %.0f, %s %.0f ms)\n",
                 it, (unsigned long long) cdm_seqdb_size(db), (unsigned long long) cdm_seqdb_residues(db), (unsigned long long) cdm_seqdb_residues(next), (unsigned long long) cdm_alns_count(alns),
@@ -521,7 +529,7 @@ int createdb(Args &a) {
     std::vector<std::string> files(a.pos.begin(), a.pos.end() - 1);
     std::string err;
     const long dbType = iflag(a, "--dbtype", 0);        // 0 = guess from the first entries, as createdb does (createdb.cpp:40-45)
-    if (dbType != 0 && dbType != 2) die("createdb: --dbtype " + std::to_string(dbType) + " is not supported by the MI355X path (nucleotide sequences only; accepted: 0, 2)");
+    if (dbType != 0 && dbType != 2) unsupported("createdb: --dbtype " + std::to_string(dbType) + " is not supported by the MI355X path (nucleotide sequences only; accepted: 0, 2)");
     if (createdbModule(files, a.pos.back(), iflag(a, "--shuffle", 1) != 0, (int) dbType, &err)) die(err);
     return EXIT_SUCCESS;
 }

@@ -29,8 +29,9 @@ static void *mapFile(const std::string &p, size_t *bytes) {
 
 MmDb::~MmDb() { if (mapped) munmap(mapped, mappedBytes); }
 
-bool MmDb::load(const std::string &path, std::string *err) {
-    if (exists(path)) {
+bool MmDb::load(const std::string &path, std::string *err, bool indexOnly) {
+    if (indexOnly) { owned.assign(1, '\0'); base = owned.data(); bytes = 0; }
+    else if (exists(path)) {
         size_t sz = 0;
         mapped = mapFile(path, &sz);
         if (!mapped && sz) { *err = "Could not open data file " + path; return false; }
@@ -85,7 +86,7 @@ bool MmDb::load(const std::string &path, std::string *err) {
     if (!sorted) std::stable_sort(es.begin(), es.end(), [](const E &a, const E &b) { return a.k < b.k; });
     key.resize(n); off.resize(n); len.resize(n); ext.resize(n);
     for (size_t i = 0; i < n; i++) {
-        if (es[i].o + es[i].l > bytes) { *err = "index entry beyond the data file in " + path; return false; }
+        if (!indexOnly && es[i].o + es[i].l > bytes) { *err = "index entry beyond the data file in " + path; return false; }
         key[i] = es[i].k; off[i] = es[i].o; len[i] = es[i].l; ext[i] = es[i].e;
     }
     return true;

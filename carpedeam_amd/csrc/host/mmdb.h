@@ -19,7 +19,7 @@ struct MmDb {
     MmDb(const MmDb &) = delete;
     MmDb &operator=(const MmDb &) = delete;
     ~MmDb();
-    bool load(const std::string &path, std::string *err);
+    bool load(const std::string &path, std::string *err, bool indexOnly = false);   // indexOnly: DBReader's USE_INDEX - no data file is opened (createhdb.cpp:21-31)
     size_t size() const { return key.size(); }
     const char *data() const { return base; }
     size_t dataSize() const { return bytes; }

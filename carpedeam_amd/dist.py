@@ -63,15 +63,18 @@ def allgather_packed(dist, buf, n, words, key_base, world):
     key_base_r)] for all ranks.  Two collectives: the sizes (4 int64) and the data."""
     import torch
     meta = torch.tensor([int(n), int(words), int(key_base), int(buf.numel())], dtype=torch.int64, device=buf.device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    metas = [[int(v) for v in m.tolist()] for m in metas]
-    mx = max(m[3] for m in metas)
-    pad = torch.zeros(max(mx, 1), dtype=torch.int32, device=buf.device)
-    pad[: buf.numel()] = buf
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad)
-    return [(p[: m[3]], m[0], m[1], m[2]) for p, m in zip(parts, metas)]
+    metas = torch.zeros(world * 4, dtype=torch.int64, device=buf.device)
+    dist.all_gather_into_tensor(metas, meta)
+    metas = [[int(v) for v in m] for m in metas.view(world, 4).tolist()]
+    mx = max(max(m[3] for m in metas), 1)
+    if buf.numel() == mx:
+        pad = buf.contiguous()
+    else:
+        pad = torch.zeros(mx, dtype=torch.int32, device=buf.device)
+        pad[: buf.numel()] = buf
+    flat = torch.empty(world * mx, dtype=torch.int32, device=buf.device)      # ONE receive buffer, no per-rank tensor list
+    dist.all_gather_into_tensor(flat, pad)
+    return [(flat[r * mx: r * mx + m[3]], m[0], m[1], m[2]) for r, m in enumerate(metas)]
 
 
 def merge_packed(parts):

@@ -5,5 +5,5 @@ n=${1:-1000000}; tag=${2:-lp}
 R=$PWD; d=$(mktemp -d)
 python scripts/write_reads_db.py $n 60 150 $d/in || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_loopprof -o p --output-format csv -- $R/carpedeam_amd/carpedeam ancient_reads_loop $d/in $d/out --ancient-damage $d/in_dhigh --num-iter-reads-only 5 --num-iterations 12 --threads 16 2>&1 | grep -v "^[EW]2026" | tail -15
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_loopprof -o p --output-format csv -- $R/carpedeam_amd/carpedeam_mi355x ancient_reads_loop $d/in $d/out --ancient-damage $d/in_dhigh --num-iter-reads-only 5 --num-iterations 12 --threads 16 2>&1 | grep -v "^[EW]2026" | tail -15
 rm -f $R/gpurun_out/${tag}_loopprof/p_kernel_trace.csv; rm -rf $d

@@ -170,7 +170,7 @@ def main():
         chain(tmp, "example", seqs, 1, prefix, 4)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("createdb", "contigs", "cycle", "letters")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("createdb", "contigs", "cycle", "letters", "workflow")):
     main()
 
 
@@ -334,3 +334,27 @@ def letters_goldens():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "letters":
     letters_goldens()
+
+
+def workflow_golden(threads=8):
+    """tests/golden/example/{test_data.fq.gz, ancient_assemble.fasta}: BASELINE config 1 - the reference's whole program
+    (oracle/_ref/carpedeam_full: its own main, command tables, workflow drivers and scripts) run as
+    `ancient_assemble example/test_data.fq.gz out.fa tmp --ancient-damage example/dhigh`; the reads file is the reference's example
+    data set, kept next to the result so the test runs where /root/reference is absent (python tests/golden/make_golden.py workflow)"""
+    import shutil
+    full = os.path.join(ROOT, "oracle", "_ref", "carpedeam_full")
+    ex = "/root/reference/example"
+    d = os.path.join(OUT, "example")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "out.fa")
+        r = subprocess.run([full, "ancient_assemble", os.path.join(ex, "test_data.fq.gz"), out, os.path.join(tmp, "tmp"),
+                            "--ancient-damage", os.path.join(ex, "dhigh"), "--threads", str(threads)], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.exit("reference workflow failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
+        shutil.copyfile(out, os.path.join(d, "ancient_assemble.fasta"))
+    shutil.copyfile(os.path.join(ex, "test_data.fq.gz"), os.path.join(d, "test_data.fq.gz"))
+    print("workflow golden: %d contigs" % open(os.path.join(d, "ancient_assemble.fasta")).read().count(">"))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "workflow":
+    workflow_golden()

@@ -105,9 +105,11 @@ def test_chain_fuzz_small_databases(ctx, oracle_bin, dhigh_prefix, tmp_path):
             db = asm
 
 
-def test_chain_properties_at_scale(ctx):
-    """2 M reads (no oracle at this size): structural invariants of every stage."""
-    n, L = 2_000_000, 100
+@pytest.mark.parametrize("n", [2_000_000, 5_000_000])
+def test_chain_properties_at_scale(ctx, n):
+    """2 M reads, and 5 M = BASELINE.json configs[1] (seed 1, 100 bp, dhigh: the reads `bench.py --config 2` corrects) - no oracle at
+    these sizes: structural invariants of every stage, those of ancient_correction among them."""
+    L = 100
     db = ctx.synth(n, L, L, 1)
     hits, alns, corr, asm = chain(ctx, db)
     hoff, hrec = hits.download()

@@ -1,7 +1,7 @@
 """Interop in the other direction: DB files WRITTEN by the MI355X modules are read by the reference's own object code
 (oracle/_ref/carpedeam_ref, skipped when that build is absent), and the reference module's result on them equals the MI355X
-module's result on the same files.  Plus the dispatcher of INTEGRATION.md (scripts/carpedeam-gpu) over one iteration of the
-reads loop of data/nuclassemble.sh:100-146."""
+module's result on the same files.  Plus the front end of INTEGRATION.md (carpedeam_amd/carpedeam, csrc/host/front.c) over one
+iteration of the reads loop of data/nuclassemble.sh:100-146 (the whole workflow through it: tests/test_workflow.py)."""
 import os
 import subprocess
 
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GPU = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
 REF = os.path.join(ROOT, "oracle", "_ref", "carpedeam_ref")
-WRAP = os.path.join(ROOT, "scripts", "carpedeam-gpu")
+WRAP = GPU      # the front end: modules of the hot path -> carpedeam_mi355x, anything else -> $CARPEDEAM_REF_BIN
 
 
 def run(exe, *args, env=None):
@@ -56,11 +56,11 @@ def test_reference_modules_read_gpu_written_dbs(tmp_path, dhigh_prefix, name, it
 
 
 def test_dispatcher_script_runs_one_reads_loop_iteration(tmp_path, dhigh_prefix):
-    """$MMSEQS = scripts/carpedeam-gpu: the loop body of data/nuclassemble.sh:100-146, module by module on DB files."""
+    """$MMSEQS = carpedeam_amd/carpedeam: the loop body of data/nuclassemble.sh:100-146, module by module on DB files."""
     from carpedeam_amd import build
     build.build()
     t = lambda s: str(tmp_path / s)
-    env = dict(os.environ, CARPEDEAM_GPU_BIN=GPU, CARPEDEAM_REF_BIN=REF if os.path.exists(REF) else "/bin/false")
+    env = dict(os.environ, CARPEDEAM_REF_BIN=REF if os.path.exists(REF) else "/bin/false")
     dmg = ["--ancient-damage", dhigh_prefix, "--threads", "4"]
     mmdb.write_from_keyed(t("in"), gold("synth2k", "reads"), mmdb.DBTYPE_NUCLEOTIDES)
     run(WRAP, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4", env=env)
@@ -90,3 +90,29 @@ def test_whole_workflow_against_reference_object_code():
     assert m, r.stdout[-800:]
     assert int(m.group(1)) == 20000 and int(m.group(2)) > 4_000_000     # (the contigs grew: 20 000 reads are 2.1 M letters)
     assert int(m.group(3)) <= 10
+
+
+def loop_vs(*args):
+    import re
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "loop_vs_ref.py")] + list(args), capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
+    m = re.search(r"result (\d+) sequences, (\d+) residues, (\d+) circular set aside; (\d+) sequences differ", r.stdout)
+    assert m, r.stdout[-800:]
+    return [int(x) for x in m.groups()]
+
+
+def test_twelve_iterations_against_the_oracle_chain():
+    """100 000 mixed-length reads through all twelve iterations of the workflow loop (5 read + 7 contig iterations, the script's
+    cyclecheck step after each contig iteration): `ancient_reads_loop` against the ORACLE's modules chained through DB files as
+    data/nuclassemble.sh chains them.  The oracle has one deterministic strand-tie rule, so nothing may differ."""
+    n, residues, _, differ = loop_vs("100000", "16", "oracle")
+    assert n == 100000 and residues > 20_000_000
+    assert differ == 0
+
+
+def test_contig_phase_takes_its_identity_threshold_from_the_workflow_flag():
+    """--min-seqid-corr-contigs is the contig phase's --min-seq-id (Nuclassembler.cpp:124-126: `par.seqIdThr = par.corrContigSeqId`
+    before the contig parameter strings are made), --min-seq-id the read phase's; non-default values on both sides, zero tolerance."""
+    n, _, _, differ = loop_vs("20000", "16", "oracle", "contigid=0.96", "seqid=0.93")
+    assert n == 20000 and differ == 0

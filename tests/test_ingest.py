@@ -92,6 +92,15 @@ def test_createhdb_and_convert2fasta_equal_reference(exe, tmp_path):
     lines = open(str(tmp_path / "asm_cyc.fasta")).read().split("\n")
     assert lines[0] == ">0 len:%d cycle:0" % len(seqs[0]) and lines[6] == ">3 len:%d cycle:1" % len(seqs[3])
     got = {k: digest(str(tmp_path / k)) for k in ("mine.fasta", "asm.fasta", "asm_cyc.fasta", "asm_h", "asm_h.index")}
+    # what the workflow really hands over (data/nuclassemble.sh:222-241): a cycle "DB" that is nothing but an index file written by
+    # awk - createhdb opens both DBs with USE_INDEX only (src/util/createhdb.cpp:21-31)
+    mmdb.write_seqdb(str(tmp_path / "asm2"), seqs[:50])
+    open(str(tmp_path / "cyc_only.index"), "w").write(open(str(tmp_path / "cyc.index")).read())
+    run(exe, "createhdb", str(tmp_path / "asm2"), str(tmp_path / "cyc_only"), str(tmp_path / "asm2"))
+    assert digest(str(tmp_path / "asm2_h")) == got["asm_h"] and digest(str(tmp_path / "asm2_h.index")) == got["asm_h.index"]
+    os.remove(str(tmp_path / "asm2"))                       # ... and the sequence DB's data file is not opened either
+    run(exe, "createhdb", str(tmp_path / "asm2"), str(tmp_path / "cyc_only"), str(tmp_path / "asm2"))
+    assert digest(str(tmp_path / "asm2_h")) == got["asm_h"]
     assert got == json.load(open(os.path.join(GOLD, "example", "createdb_digests.json")))["fasta"]
     if os.path.exists(REF):
         run(REF, "convert2fasta", str(tmp_path / "db"), str(tmp_path / "ref.fasta"), "-v", "0")

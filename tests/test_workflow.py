@@ -1,0 +1,97 @@
+"""BASELINE config 1: `carpedeam ancient_assemble` on the reference's example reads, through the front end (carpedeam_amd/carpedeam,
+csrc/host/front.c) that takes the reference binary's place.  The reference's own workflow drivers and scripts run
+(oracle/_ref/carpedeam_full = the reference's whole program compiled in place by oracle/Makefile.ref), and because the front end
+starts it with argv[0] = itself, every "$MMSEQS" <module> call of those scripts (Application.cpp:198, data/nuclassemble.sh:105-136,
+data/guidedNuclAssemble.sh, linclust.sh) comes back through it: the modules of the hot path go to the device binary, the rest to
+the reference.  Golden: tests/golden/example/ancient_assemble.fasta (make_golden.py workflow).
+
+CPU part: the routing alone, with the reference's own modules (oracle/_ref/carpedeam_ref) standing in for the device binary.
+GPU part: the real thing."""
+import collections
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FRONT = os.path.join(ROOT, "carpedeam_amd", "carpedeam")
+MODULES = os.path.join(ROOT, "carpedeam_amd", "carpedeam_mi355x")
+REF_MODULES = os.path.join(ROOT, "oracle", "_ref", "carpedeam_ref")
+REF_FULL = os.path.join(ROOT, "oracle", "_ref", "carpedeam_full")
+EXAMPLE = os.path.join(ROOT, "tests", "golden", "example")
+OWNED = ["kmermatcher", "rescorediagonal", "ancient_correction", "ancient_read_assemble", "ancient_contig_merge", "cyclecheck", "createdb", "createhdb",
+         "convert2fasta"]
+
+
+def fasta_records(path):
+    recs, name = [], None
+    for line in open(path):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            name = line
+            recs.append([name, ""])
+        elif recs:
+            recs[-1][1] += line
+    return recs
+
+
+def assemble(tmp_path, dhigh_prefix, modules):
+    from carpedeam_amd import build
+    build.build()
+    log = str(tmp_path / "dispatch.log")
+    env = dict(os.environ, CARPEDEAM_GPU_BIN=modules, CARPEDEAM_REF_BIN=REF_FULL, CARPEDEAM_DISPATCH_LOG=log)
+    out = str(tmp_path / "out.fasta")
+    r = subprocess.run([FRONT, "ancient_assemble", os.path.join(EXAMPLE, "test_data.fq.gz"), out, str(tmp_path / "tmp"), "--ancient-damage", dhigh_prefix,
+                        "--threads", "8"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    calls = collections.Counter(tuple(l.split()) for l in open(log))
+    return fasta_records(out), calls
+
+
+def check_routing(calls, fallbacks):
+    # the workflow's defaults: 5 read iterations + 5 contig iterations (log of the reference run: STEP 0..9), then linclust
+    assert calls[("ref", "ancient_assemble")] == 1 and calls[("ref", "nuclassemble")] == 1 and calls[("ref", "linclust")] == 1
+    for m in OWNED:
+        assert calls[("ref", m)] == 0, m                      # not one call of an owned module went around the front end
+    gpu = {m: calls[("gpu", m)] for m in OWNED}
+    assert gpu["ancient_correction"] == 10 and gpu["ancient_read_assemble"] == 5 and gpu["ancient_contig_merge"] == 5 and gpu["cyclecheck"] == 5
+    assert gpu["createdb"] == 1 and gpu["createhdb"] == 1 and gpu["convert2fasta"] == 1
+    assert gpu["kmermatcher"] == 11                            # 10 of the loop + linclust's
+    # linclust's Hamming-distance pre-clustering pass (linclust.sh:31-35: --rescore-mode 0 --wrapped-scoring 1) is not a mode of the
+    # device path: the module refuses it before doing any work (status 77) and the front end hands that one call to the reference
+    assert gpu["rescorediagonal"] + calls[("fallback", "rescorediagonal")] == 11 and calls[("fallback", "rescorediagonal")] == fallbacks
+    assert sum(n for (where, _), n in calls.items() if where == "fallback") == fallbacks
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_FULL) and os.path.exists(REF_MODULES)), reason="oracle/_ref (the reference's object code) is not built here")
+def test_front_end_routes_every_module_call_of_the_reference_workflow(tmp_path, dhigh_prefix):
+    recs, calls = assemble(tmp_path, dhigh_prefix, REF_MODULES)
+    check_routing(calls, fallbacks=0)
+    assert recs == fasta_records(os.path.join(EXAMPLE, "ancient_assemble.fasta"))
+
+
+def test_front_end_without_a_reference_binary(tmp_path):
+    from carpedeam_amd import build
+    build.build()
+    env = {k: v for k, v in os.environ.items() if k != "CARPEDEAM_REF_BIN"}
+    r = subprocess.run([FRONT, "ancient_assemble", "a", "b", "c"], capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and "Invalid Command: ancient_assemble" in r.stderr and "CARPEDEAM_REF_BIN" in r.stderr
+    # a refusal of the device binary (status 77 inside) stays a plain failure when nothing can take the call
+    r = subprocess.run([FRONT, "rescorediagonal", "a", "a", "p", "o", "--rescore-mode", "0"], capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and "not supported by the MI355X path" in r.stderr
+    r = subprocess.run([MODULES, "rescorediagonal", "a", "a", "p", "o", "--rescore-mode", "0"], capture_output=True, text=True, env=env)
+    assert r.returncode == 77
+    # ... and goes to the reference binary when there is one (/bin/echo stands in: it prints its arguments)
+    env["CARPEDEAM_REF_BIN"] = "/bin/echo"
+    r = subprocess.run([FRONT, "rescorediagonal", "a", "a", "p", "o", "--rescore-mode", "0"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.strip() == "rescorediagonal a a p o --rescore-mode 0" and "handed to the reference binary" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_FULL), reason="oracle/_ref (the reference's object code) is not built here")
+def test_ancient_assemble_on_the_example_reads(tmp_path, dhigh_prefix):
+    recs, calls = assemble(tmp_path, dhigh_prefix, MODULES)
+    check_routing(calls, fallbacks=1)
+    exp = fasta_records(os.path.join(EXAMPLE, "ancient_assemble.fasta"))
+    assert sorted(s for _, s in recs) == sorted(s for _, s in exp)
+    assert recs == exp
