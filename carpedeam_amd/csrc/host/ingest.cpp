@@ -164,8 +164,8 @@ int createdbModule(const std::vector<std::string> &files, const std::string &out
         lookup += std::to_string(j); lookup.push_back('\t'); lookup += fastaId(e.hdrBlob.c_str() + e.hdrOff[i]); lookup.push_back('\t');
         lookup += std::to_string(e.file[i]); lookup.push_back('\n');
     }
-    if (!mmdbWriteBlob(outPath, seqDbType, sBlob.data(), sBlob.size(), key, sOff, sLen, ext, err)) return 1;
-    if (!mmdbWriteBlob(outPath + "_h", 12 /* DBTYPE_GENERIC_DB */, hBlob.data(), hBlob.size(), key, hOff, hLen, ext, err)) return 1;
+    if (!mmdbWriteBlob(outPath, seqDbType, sBlob.data(), sBlob.size(), key.data(), sOff.data(), sLen.data(), ext.data(), n, err)) return 1;
+    if (!mmdbWriteBlob(outPath + "_h", 12 /* DBTYPE_GENERIC_DB */, hBlob.data(), hBlob.size(), key.data(), hOff.data(), hLen.data(), ext.data(), n, err)) return 1;
     FILE *lf = fopen((outPath + ".lookup").c_str(), "w"), *sf = fopen((outPath + ".source").c_str(), "w");
     if (!lf || !sf) { *err = "Cannot open " + outPath + ".lookup for writing"; return 1; }
     fwrite(lookup.data(), 1, lookup.size(), lf); fclose(lf);

@@ -127,8 +127,9 @@ void appendEntries(cdm_ctx *ctx, cdm_seqdb *h, OutChunk &c) {
     check(cdm_seqdb_meta(ctx, h, lens.data(), keys.data(), ext.data()), "meta");
     std::vector<uint64_t> offs(n); uint64_t tot = 0;
     for (uint64_t i = 0; i < n; i++) { offs[i] = tot; tot += lens[i] + 2; }
-    std::string buf(tot, '\0');
-    check(cdm_seqdb_download(ctx, h, &buf[0], offs.data()), "download");
+    HVec<char> buf(tot);
+    check(cdm_seqdb_download(ctx, h, buf.data(), offs.data()), "download");
+    c.reserve(c.key.size() + n, c.data.size() + tot);
     for (uint64_t i = 0; i < n; i++) c.add(keys[i], buf.data() + offs[i], lens[i] + 1, ext[i]);
 }
 void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) {
@@ -137,14 +138,25 @@ void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype)
     std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
     check(cdm_seqdb_meta(ctx, h, lens.data(), keys.data(), ext.data()), "meta");
     // the download buffer has the data file's layout already: "SEQ\n\0" per entry (the NULs are the buffer's zero fill)
-    std::vector<uint64_t> offs(n); std::vector<uint32_t> elen(n); uint64_t tot = 0;
+    HVec<uint64_t> offs(n); HVec<uint32_t> elen(n); uint64_t tot = 0;
     for (uint64_t i = 0; i < n; i++) { offs[i] = tot; elen[i] = lens[i] + 2; tot += lens[i] + 2; }
-    std::string buf(tot, '\0');
-    check(cdm_seqdb_download(ctx, h, &buf[0], offs.data()), "download");
-    std::string err; if (!mmdbWriteBlob(path, dbtype, buf.data(), buf.size(), keys, offs, elen, ext, &err)) die(err);
+    HVec<char> buf(tot);            // fresh zero pages: the NULs between the entries
+    check(cdm_seqdb_download(ctx, h, buf.data(), offs.data()), "download");
+    std::string err; if (!mmdbWriteBlob(path, dbtype, buf.data(), buf.size(), keys.data(), offs.data(), elen.data(), ext.data(), n, &err)) die(err);
 }
 // ---- text codecs
-char *utoa(unsigned long long v, char *p) { char b[24]; int n = 0; do { b[n++] = '0' + v % 10; v /= 10; } while (v); while (n) *p++ = b[--n]; return p; }
+// decimal text, two digits per division
+char *utoa(unsigned long long v, char *p) {
+    static const char D2[] = "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+                             "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+    if (v < 10) { *p++ = (char) ('0' + v); return p; }
+    if (v < 100) { memcpy(p, D2 + 2 * v, 2); return p + 2; }
+    char b[24]; int n = 24;
+    while (v >= 100) { const unsigned r = (unsigned) (v % 100); v /= 100; n -= 2; memcpy(b + n, D2 + 2 * r, 2); }
+    if (v >= 10) { n -= 2; memcpy(b + n, D2 + 2 * v, 2); } else b[--n] = (char) ('0' + v);
+    memcpy(p, b + n, (size_t) (24 - n));
+    return p + (24 - n);
+}
 char *itoa(long long v, char *p) { if (v < 0) { *p++ = '-'; return utoa((unsigned long long) -v, p); } return utoa(v, p); }
 // ---- parsers for the tab-separated records (strtol / strtod walk the locale machinery: 10x the time of these)
 // unsigned / signed decimal at d; d moves behind the digits (no digits: 0, as strtol gives)
@@ -171,39 +183,55 @@ char *seqIdText(float s, char *p) {   // Util::fastSeqIdToBuffer + the tab overw
 }
 // contiguous slice [lo, hi) of n items for thread t of T
 inline void sliceOf(size_t n, int t, int T, size_t &lo, size_t &hi) { lo = n * (size_t) t / T; hi = n * (size_t) (t + 1) / T; }
-// concatenates the threads' record vectors (thread t holds the records of the queries of its slice, cnt[q] per query)
-template <typename R>
-void gatherParts(std::vector<std::vector<R>> &parts, const std::vector<uint32_t> &cnt, std::vector<uint64_t> &off, std::vector<R> &rec) {
-    const size_t n = cnt.size();
-    off.assign(n + 1, 0);
-    for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + cnt[i];
-    rec.resize(off[n]);
-    const int T = (int) parts.size();
-#pragma omp parallel num_threads(T)
-    {
-        const int t = omp_get_thread_num();
-        size_t lo, hi; sliceOf(n, t, T, lo, hi);
-        if (!parts[t].empty()) memcpy(&rec[off[lo]], parts[t].data(), parts[t].size() * sizeof(R));
-        std::vector<R>().swap(parts[t]);
+// Slices of the queries that carry about the same number of RECORDS each (off = CSR offsets of the records; a query costs one more
+// unit).  The record lists are anything but even: kmermatcher's representatives - the longest, lowest-id sequences - hold the hits of
+// whole k-mer groups, so at 10 M reads the first sixteenth of the queries owned most of the text and threads beyond the first
+// added nothing.
+inline std::vector<size_t> balancedSlices(const uint64_t *off, size_t n, int T) {
+    std::vector<size_t> b(T + 1, n);
+    b[0] = 0;
+    const uint64_t total = off[n] + n;
+    for (int t = 1; t < T; t++) {
+        const uint64_t want = total / (uint64_t) T * (uint64_t) t;
+        size_t lo = b[t - 1], hi = n;
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (off[mid] + mid < want) lo = mid + 1; else hi = mid; }
+        b[t] = lo;
     }
+    return b;
 }
-void parseAlnDb(const MmDb &aln, const MmDb &seq, std::vector<uint64_t> &off, std::vector<cdm_aln> &rec) {   // Matcher.cpp:274-353
+// number of records (= lines) of entry i of a result DB
+inline uint32_t countLines(const MmDb &db, int64_t i) {
+    if (i < 0) return 0;
+    const char *d = db.entry((size_t) i), *e = d + (db.len[(size_t) i] ? db.len[(size_t) i] - 1 : 0);
+    uint32_t n = 0;
+    while (d < e) { const char *nl = (const char *) memchr(d, '\n', (size_t) (e - d)); n++; d = nl ? nl + 1 : e; }
+    return n;
+}
+// CSR offsets of the queries' record lists: the lines are counted first (memchr speed), the records then go straight to their place
+void countRecords(const MmDb &res, const MmDb &seq, HVec<uint64_t> &off) {
+    const size_t n = seq.size();
+    off.resize(n + 1);
+    off[0] = 0;
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (size_t i = 0; i < n; i++) off[i + 1] = countLines(res, res.idOf(seq.key[i]));
+    for (size_t i = 0; i < n; i++) off[i + 1] += off[i];
+}
+void parseAlnDb(const MmDb &aln, const MmDb &seq, HVec<uint64_t> &off, HVec<cdm_aln> &rec) {   // Matcher.cpp:274-353
     const double lam = 0x1.4478764a1b24ap-1, logk = log(0x1.a1c1e68ea2ab1p-2), LN2 = std::log(2.0);
     const int T = std::max(1, omp_get_max_threads());
-    std::vector<std::vector<cdm_aln>> parts(T); std::vector<uint32_t> cnt(seq.size(), 0);
+    countRecords(aln, seq, off);
+    rec.resize(off[seq.size()]);
     long badKey = -1;
+    const std::vector<size_t> cut = balancedSlices(off.data(), seq.size(), T);
 #pragma omp parallel num_threads(T)
     {
         const int t = omp_get_thread_num();
-        size_t lo, hi; sliceOf(seq.size(), t, T, lo, hi);
-        std::vector<cdm_aln> &out = parts[t];
-        out.reserve(aln.dataSize() / 36 / (size_t) T + 1024);              // (a record is 36+ characters)
+        const size_t lo = cut[t], hi = cut[t + 1];
         for (size_t i = lo; i < hi; i++) {
-            const int64_t a = aln.idOf(seq.key[i]);
-            if (a < 0) continue;
-            const char *d = aln.entry(a);
-            const size_t before = out.size();
-            while (*d) {
+            if (off[i + 1] == off[i]) continue;
+            const char *d = aln.entry((size_t) aln.idOf(seq.key[i]));
+            cdm_aln *out = rec.data() + off[i], *const end = rec.data() + off[i + 1];
+            while (*d && out < end) {
                 cdm_aln r;
                 auto tab = [&] { if (*d == '\t') d++; };
                 const uint32_t tkey = (uint32_t) parseU(d); tab();
@@ -220,15 +248,13 @@ void parseAlnDb(const MmDb &aln, const MmDb &seq, std::vector<uint64_t> &off, st
                 }
                 r.target = (uint32_t) tt; r.ident = -1;
                 r.raw_score = static_cast<int>((logk + bits * LN2) / lam + 0.5);   // computeRawScoreFromBitScore as the consumers do
-                out.push_back(r);
+                *out++ = r;
                 while (*d && *d != '\n') d++;
                 if (*d == '\n') d++;
             }
-            cnt[i] = (uint32_t) (out.size() - before);
         }
     }
     if (badKey >= 0) die("Invalid database read for key " + std::to_string(badKey));
-    gatherParts(parts, cnt, off, rec);
 }
 cdm_ancient_params ancientParams(Args &a) {
     cdm_ancient_params p;
@@ -237,6 +263,100 @@ cdm_ancient_params ancientParams(Args &a) {
     p.likelihood_threshold = fflag(a, "--likelihood-ratio-threshold", 0.5f); p.unsafe = (int) iflag(a, "--unsafe", 0);
     p.min_cov_safe = (int) iflag(a, "--min-cov-safe", 5); p.max_seq_len = (uint64_t) iflag(a, "--max-seq-len", 65535);
     return p;
+}
+
+// QueryMatcher::prefilterHitToBuffer per hit, one DB entry per query (kmermatcher.cpp:815-930)
+void formatPrefDb(const MmDb &seq, const uint64_t *off, const cdm_hit *rec, std::vector<OutChunk> &chunks) {
+    const int T = std::max(1, omp_get_max_threads());
+    chunks.clear(); chunks.resize(T);
+    const size_t MAXREC = 10 + 1 + 11 + 1 + 6 + 1;      // "%u\t%d\t%d\n" with a short diagonal
+    const std::vector<size_t> cut = balancedSlices(off, seq.size(), T);
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        const size_t lo = cut[t], hi = cut[t + 1];
+        OutChunk &c = chunks[t];
+        c.reserve(hi - lo, (off[hi] - off[lo]) * MAXREC + (hi - lo));
+        for (size_t i = lo; i < hi; i++) {
+            char *const w0 = c.open((off[i + 1] - off[i]) * MAXREC), *w = w0;
+            for (uint64_t h = off[i]; h < off[i + 1]; h++) {   // QueryMatcher::prefilterHitToBuffer
+                w = utoa(seq.key[rec[h].target], w); *w++ = '\t'; w = itoa(rec[h].score, w); *w++ = '\t'; w = itoa((short) rec[h].diagonal, w); *w++ = '\n';
+            }
+            // representatives' records carry wasExtended 0, fill-in records the sequence's flag (kmermatcher.cpp:727, DBWriter default)
+            c.close(seq.key[i], w0, w, (off[i + 1] - off[i] > 1) ? 0 : seq.ext[i]);
+        }
+    }
+}
+// QueryMatcher::parsePrefilterHits: the prefilter text as CSR over the query ids
+void parsePrefDb(const MmDb &pref, const MmDb &seq, HVec<uint64_t> &off, HVec<cdm_hit> &rec) {
+    const int T = std::max(1, omp_get_max_threads());
+    countRecords(pref, seq, off);
+    rec.resize(off[seq.size()]);
+    long badKey = -1;
+    const std::vector<size_t> cut = balancedSlices(off.data(), seq.size(), T);
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        const size_t lo = cut[t], hi = cut[t + 1];
+        for (size_t i = lo; i < hi; i++) {
+            if (off[i + 1] == off[i]) continue;
+            const char *d = pref.entry((size_t) pref.idOf(seq.key[i]));
+            cdm_hit *out = rec.data() + off[i], *const end = rec.data() + off[i + 1];
+            while (*d && out < end) {
+                cdm_hit h;
+                const uint32_t tkey = (uint32_t) parseU(d); if (*d == '\t') d++; h.score = (int) parseI(d); if (*d == '\t') d++; h.diagonal = (short) parseI(d);
+                const int64_t tt = seq.idOf(tkey);
+                if (tt < 0) {
+#pragma omp critical
+                    badKey = (long) tkey;
+                    break;
+                }
+                h.target = (uint32_t) tt; *out++ = h;
+                while (*d && *d != '\n') d++;
+                if (*d == '\n') d++;
+            }
+        }
+    }
+    if (badKey >= 0) die("Invalid database read for key " + std::to_string(badKey));
+}
+// Matcher::resultToBuffer per record, one DB entry per query that has a prefilter entry (rescorediagonal.cpp:145-356)
+void formatAlnDb(const MmDb &seq, const MmDb &pref, const uint64_t *aoff, const cdm_aln *arec, uint64_t dbRes, std::vector<OutChunk> &chunks) {
+    const int T = std::max(1, omp_get_max_threads());
+    chunks.clear(); chunks.resize(T);
+    const size_t MAXREC = 10 + 11 + 5 + 14 + 6 * 11 + 10;      // key, bits, seq.id., E-value, six coordinates, separators
+    const std::vector<size_t> cut = balancedSlices(aoff, seq.size(), T);
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        const size_t lo = cut[t], hi = cut[t + 1];
+        OutChunk &c = chunks[t];
+        c.reserve(hi - lo, (aoff[hi] - aoff[lo]) * MAXREC + (hi - lo));
+        // the E-value text and bit score of (raw score, query length) recur all over a read set: formatted once per thread
+        struct EvalText { int qLen = -1, score = -1, bits = 0; unsigned char n = 0; char txt[15]; };
+        std::vector<EvalText> cache(1u << 14);
+        for (size_t i = lo; i < hi; i++) {
+            if (pref.idOf(seq.key[i]) < 0) continue;
+            const int qLen = (int) (seq.len[i] - 2);
+            char *const w0 = c.open((aoff[i + 1] - aoff[i]) * MAXREC), *w = w0;
+            for (uint64_t r = aoff[i]; r < aoff[i + 1]; r++) {   // Matcher::resultToBuffer (Matcher.cpp:356-404)
+                const cdm_aln &x = arec[r];
+                const int alnLen = std::max(abs(x.q_end - x.q_start), abs(x.db_end - x.db_start)) + 1;
+                const float sid = static_cast<float>(x.ident) / static_cast<float>(alnLen);
+                w = utoa(seq.key[x.target], w); *w++ = '\t';
+                EvalText &ev = cache[((uint32_t) x.raw_score * 2654435761u ^ (uint32_t) qLen * 40503u) >> 18];
+                if (ev.qLen != qLen || ev.score != x.raw_score) {
+                    ev.qLen = qLen; ev.score = x.raw_score; ev.bits = cdm_bit_score(x.raw_score);
+                    ev.n = (unsigned char) snprintf(ev.txt, sizeof(ev.txt), "%.3E", cdm_evalue(x.raw_score, qLen, dbRes));
+                }
+                w = itoa(ev.bits, w); *w++ = '\t';
+                w = seqIdText(sid, w); *w++ = '\t';
+                memcpy(w, ev.txt, ev.n); w += ev.n; *w++ = '\t';
+                w = itoa(x.q_start, w); *w++ = '\t'; w = itoa(x.q_end, w); *w++ = '\t'; w = itoa(qLen, w); *w++ = '\t';
+                w = itoa(x.db_start, w); *w++ = '\t'; w = itoa(x.db_end, w); *w++ = '\t'; w = itoa((int) (seq.len[x.target] - 2), w); *w++ = '\n';
+            }
+            c.close(seq.key[i], w0, w, 0);
+        }
+    }
 }
 
 int kmermatcher(Args &a) {
@@ -253,27 +373,11 @@ int kmermatcher(Args &a) {
     p.include_only_extendable = (int) iflag(a, "--include-only-extendable", 0); p.cov_mode = (int) iflag(a, "--cov-mode", 0); p.cov_thr = fflag(a, "-c", 0.8f);
     cdm_hits *hits = NULL;
     check(cdm_kmermatch(ctx, db, &p, &hits), "kmermatcher");
-    std::vector<uint64_t> off(seq.size() + 1); std::vector<cdm_hit> rec(cdm_hits_count(hits));
+    HVec<uint64_t> off(seq.size() + 1); HVec<cdm_hit> rec(cdm_hits_count(hits));
     check(cdm_hits_download(ctx, hits, off.data(), rec.data()), "download");
     laps.lap("kernels, hits down");
-    const int T = std::max(1, omp_get_max_threads());
-    std::vector<OutChunk> chunks(T);
-#pragma omp parallel num_threads(T)
-    {
-        const int t = omp_get_thread_num();
-        size_t lo, hi; sliceOf(seq.size(), t, T, lo, hi);
-        OutChunk &c = chunks[t];
-        std::string out; char b[64];
-        for (size_t i = lo; i < hi; i++) {
-            out.clear();
-            for (uint64_t h = off[i]; h < off[i + 1]; h++) {   // QueryMatcher::prefilterHitToBuffer
-                char *p2 = utoa(seq.key[rec[h].target], b); *p2++ = '\t'; p2 = itoa(rec[h].score, p2); *p2++ = '\t'; p2 = itoa((short) rec[h].diagonal, p2); *p2++ = '\n';
-                out.append(b, p2 - b);
-            }
-            // representatives' records carry wasExtended 0, fill-in records the sequence's flag (kmermatcher.cpp:727, DBWriter default)
-            c.add(seq.key[i], out.data(), out.size(), (off[i + 1] - off[i] > 1) ? 0 : seq.ext[i]);
-        }
-    }
+    std::vector<OutChunk> chunks;
+    formatPrefDb(seq, off.data(), rec.data(), chunks);
     laps.lap("prefilter text formatted");
     if (!mmdbWriteChunks(a.pos[1], 14, chunks, &err)) die(err);   // DBTYPE_PREFILTER_REV_RES (kmermatcher.cpp:682)
     laps.lap("result DB written");
@@ -290,41 +394,8 @@ int rescorediagonal(Args &a) {
     Laps laps; laps.lap("DB files mapped");
     cdm_ctx *ctx = openCtx(); laps.lap("device context");
     cdm_seqdb *db = uploadSeqDb(ctx, seq); laps.lap("sequences up");
-    std::vector<uint64_t> off; std::vector<cdm_hit> rec;
-    const int T = std::max(1, omp_get_max_threads());
-    {
-        std::vector<std::vector<cdm_hit>> parts(T); std::vector<uint32_t> cnt(seq.size(), 0);
-        long badKey = -1;
-#pragma omp parallel num_threads(T)
-        {
-            const int t = omp_get_thread_num();
-            size_t lo, hi; sliceOf(seq.size(), t, T, lo, hi);
-            std::vector<cdm_hit> &out = parts[t];
-            out.reserve(pref.dataSize() / 8 / (size_t) T + 1024);
-            for (size_t i = lo; i < hi; i++) {   // QueryMatcher::parsePrefilterHits
-                const int64_t pi = pref.idOf(seq.key[i]);
-                if (pi < 0) continue;
-                const char *d = pref.entry(pi);
-                const size_t before = out.size();
-                while (*d) {
-                    cdm_hit h;
-                    const uint32_t tkey = (uint32_t) parseU(d); if (*d == '\t') d++; h.score = (int) parseI(d); if (*d == '\t') d++; h.diagonal = (short) parseI(d);
-                    const int64_t tt = seq.idOf(tkey);
-                    if (tt < 0) {
-#pragma omp critical
-                        badKey = (long) tkey;
-                        break;
-                    }
-                    h.target = (uint32_t) tt; out.push_back(h);
-                    while (*d && *d != '\n') d++;
-                    if (*d == '\n') d++;
-                }
-                cnt[i] = (uint32_t) (out.size() - before);
-            }
-        }
-        if (badKey >= 0) die("Invalid database read for key " + std::to_string(badKey));
-        gatherParts(parts, cnt, off, rec);
-    }
+    HVec<uint64_t> off; HVec<cdm_hit> rec;
+    parsePrefDb(pref, seq, off, rec);
     laps.lap("prefilter text parsed");
     cdm_hits *hits = NULL; cdm_alns *alns = NULL;
     check(cdm_hits_upload(ctx, db, off.data(), rec.data(), &hits), "upload");
@@ -332,44 +403,11 @@ int rescorediagonal(Args &a) {
     p.seq_id_thr = fflag(a, "--min-seq-id", 0.0f); p.eval_thr = a.flag.count("-e") ? strtod(a.flag["-e"].c_str(), NULL) : 0.001;
     p.cov_mode = (int) iflag(a, "--cov-mode", 0); p.cov_thr = fflag(a, "-c", 0.0f); p.seq_id_mode = (int) iflag(a, "--seq-id-mode", 0); p.min_aln_len = (int) iflag(a, "--min-aln-len", 0);
     check(cdm_rescore(ctx, db, hits, &p, &alns), "rescorediagonal");
-    std::vector<uint64_t> aoff(seq.size() + 1); std::vector<cdm_aln> arec(cdm_alns_count(alns));
+    HVec<uint64_t> aoff(seq.size() + 1); HVec<cdm_aln> arec(cdm_alns_count(alns));
     check(cdm_alns_download(ctx, alns, aoff.data(), arec.data()), "download");
     laps.lap("hits up, kernels, records down");
-    const uint64_t dbRes = cdm_seqdb_residues(db);
-    std::vector<OutChunk> chunks(T);
-#pragma omp parallel num_threads(T)
-    {
-        const int t = omp_get_thread_num();
-        size_t lo, hi; sliceOf(seq.size(), t, T, lo, hi);
-        OutChunk &c = chunks[t];
-        std::string out; char b[256];
-        // the E-value text and bit score of (raw score, query length) recur all over a read set: formatted once per thread
-        struct EvalText { int qLen = -1, score = -1, bits = 0; unsigned char n = 0; char txt[15]; };
-        std::vector<EvalText> cache(1u << 14);
-        for (size_t i = lo; i < hi; i++) {
-            if (pref.idOf(seq.key[i]) < 0) continue;
-            out.clear();
-            const int qLen = (int) (seq.len[i] - 2);
-            for (uint64_t r = aoff[i]; r < aoff[i + 1]; r++) {   // Matcher::resultToBuffer (Matcher.cpp:356-404)
-                const cdm_aln &x = arec[r];
-                const int alnLen = std::max(abs(x.q_end - x.q_start), abs(x.db_end - x.db_start)) + 1;
-                const float sid = static_cast<float>(x.ident) / static_cast<float>(alnLen);
-                char *p2 = utoa(seq.key[x.target], b); *p2++ = '\t';
-                EvalText &ev = cache[((uint32_t) x.raw_score * 2654435761u ^ (uint32_t) qLen * 40503u) >> 18];
-                if (ev.qLen != qLen || ev.score != x.raw_score) {
-                    ev.qLen = qLen; ev.score = x.raw_score; ev.bits = cdm_bit_score(x.raw_score);
-                    ev.n = (unsigned char) snprintf(ev.txt, sizeof(ev.txt), "%.3E", cdm_evalue(x.raw_score, qLen, dbRes));
-                }
-                p2 = itoa(ev.bits, p2); *p2++ = '\t';
-                p2 = seqIdText(sid, p2); *p2++ = '\t';
-                memcpy(p2, ev.txt, ev.n); p2 += ev.n; *p2++ = '\t';
-                p2 = itoa(x.q_start, p2); *p2++ = '\t'; p2 = itoa(x.q_end, p2); *p2++ = '\t'; p2 = itoa(qLen, p2); *p2++ = '\t';
-                p2 = itoa(x.db_start, p2); *p2++ = '\t'; p2 = itoa(x.db_end, p2); *p2++ = '\t'; p2 = itoa((int) (seq.len[x.target] - 2), p2); *p2++ = '\n';
-                out.append(b, p2 - b);
-            }
-            c.add(seq.key[i], out.data(), out.size(), 0);
-        }
-    }
+    std::vector<OutChunk> chunks;
+    formatAlnDb(seq, pref, aoff.data(), arec.data(), cdm_seqdb_residues(db), chunks);
     laps.lap("alignment text formatted");
     if (!mmdbWriteChunks(a.pos[3], 5, chunks, &err)) die(err);
     laps.lap("result DB written");
@@ -388,7 +426,7 @@ int ancientModule(Args &a, int mode) {      // 0 ancient_correction, 1 ancient_r
     cdm_ctx *ctx = openCtx(); laps.lap("device context");
     check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");
     cdm_seqdb *db = uploadSeqDb(ctx, seq); laps.lap("damage tables, sequences up");
-    std::vector<uint64_t> off; std::vector<cdm_aln> rec;
+    HVec<uint64_t> off; HVec<cdm_aln> rec;
     parseAlnDb(aln, seq, off, rec); laps.lap("alignment text parsed");
     cdm_alns *alns = NULL; cdm_seqdb *out = NULL;
     check(cdm_alns_upload(ctx, db, off.data(), rec.data(), &alns), "upload");

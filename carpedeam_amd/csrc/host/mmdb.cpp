@@ -2,9 +2,11 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
 #include <fstream>
+#include <new>
 #include <numeric>
 #include <omp.h>
 #include <sys/mman.h>
@@ -12,10 +14,19 @@
 #include <unistd.h>
 
 static bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
-static void slurp(const std::string &p, std::string &out) {
-    std::ifstream f(p, std::ios::binary);
-    out.append(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+static size_t fileSize(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 ? (size_t) st.st_size : 0; }
+
+static const size_t HUGE_MIN = 4u << 20;     // below this the C library's allocator is as good
+void *hugeAlloc(size_t bytes) {
+    if (bytes < HUGE_MIN) { void *p = malloc(bytes ? bytes : 1); if (!p) throw std::bad_alloc(); return p; }
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) throw std::bad_alloc();
+    static const bool plain = getenv("CDM_NO_HUGEPAGE") != nullptr;      // (A/B switch for measurements)
+    if (!plain) madvise(p, bytes, MADV_HUGEPAGE);
+    return p;
 }
+void hugeFree(void *p, size_t bytes) { if (bytes < HUGE_MIN) free(p); else munmap(p, bytes); }
+
 static void *mapFile(const std::string &p, size_t *bytes) {
     const int fd = open(p.c_str(), O_RDONLY);
     if (fd < 0) return nullptr;
@@ -25,6 +36,20 @@ static void *mapFile(const std::string &p, size_t *bytes) {
     void *m = *bytes ? mmap(nullptr, *bytes, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
     close(fd);
     return (m == MAP_FAILED) ? nullptr : m;
+}
+// a whole file into dst, read by all threads in 8 MB pieces
+static bool readInto(const std::string &p, char *dst, size_t bytes) {
+    const int fd = open(p.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    const size_t piece = 8u << 20, pieces = (bytes + piece - 1) / piece;
+    bool ok = true;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t i = 0; i < pieces; i++) {
+        size_t at = i * piece; const size_t end = std::min(bytes, at + piece);
+        while (at < end) { const ssize_t r = pread(fd, dst + at, end - at, (off_t) at); if (r <= 0) { ok = false; break; } at += (size_t) r; }
+    }
+    close(fd);
+    return ok;
 }
 
 MmDb::~MmDb() { if (mapped) munmap(mapped, mappedBytes); }
@@ -37,11 +62,13 @@ bool MmDb::load(const std::string &path, std::string *err, bool indexOnly) {
         if (!mapped && sz) { *err = "Could not open data file " + path; return false; }
         mappedBytes = sz; base = (const char *) mapped; bytes = sz;
         if (!base) { owned.assign(1, '\0'); base = owned.data(); bytes = 0; }
-    } else {
-        int i = 0;
-        for (; exists(path + "." + std::to_string(i)); i++) slurp(path + "." + std::to_string(i), owned);
-        if (i == 0) { *err = "Could not open data file " + path; return false; }
-        base = owned.data(); bytes = owned.size();
+    } else {            // split data files X.0 .. X.n (DBWriter's per-thread files left unmerged): offsets are global over their concatenation
+        std::vector<std::string> parts; std::vector<size_t> at(1, 0);
+        for (int i = 0; exists(path + "." + std::to_string(i)); i++) { parts.push_back(path + "." + std::to_string(i)); at.push_back(at.back() + fileSize(parts.back())); }
+        if (parts.empty()) { *err = "Could not open data file " + path; return false; }
+        owned.resize(at.back() + 1);
+        for (size_t i = 0; i < parts.size(); i++) if (!readInto(parts[i], owned.data() + at[i], at[i + 1] - at[i])) { *err = "Could not read data file " + parts[i]; return false; }
+        base = owned.data(); bytes = at.back();
     }
     { std::ifstream t(path + ".dbtype", std::ios::binary); int32_t v = 0; if (t.good()) t.read((char *) &v, 4); dbtype = v; }
     size_t ixBytes = 0;
@@ -49,22 +76,30 @@ bool MmDb::load(const std::string &path, std::string *err, bool indexOnly) {
     void *ixMap = mapFile(path + ".index", &ixBytes);
     if (!ixMap && ixBytes) { *err = "Could not open index file " + path + ".index"; return false; }
     const char *ix = (const char *) ixMap;
-    // every thread parses the lines that START in its slice of the file
-    struct E { uint32_t k; uint64_t o, l; uint8_t e; };
+    // every thread takes the lines that START in its slice of the file: counted first, then parsed straight into the columns
     const int T = std::max(1, omp_get_max_threads());
-    std::vector<std::vector<E>> parts(T);
-    std::vector<size_t> bound(T + 1, ixBytes);       // slice t = the lines that start in [bound[t], bound[t + 1]); bounds sit on line starts
+    std::vector<size_t> bound(T + 1, ixBytes), first(T + 1, 0);       // slice t = the lines that start in [bound[t], bound[t + 1]); bounds sit on line starts
     for (int t = 0; t < T; t++) {
         size_t b = ixBytes * (size_t) t / T;
         while (b > 0 && b < ixBytes && ix[b - 1] != '\n') b++;
         bound[t] = b;
     }
+    bool sorted = true, inside = true;
 #pragma omp parallel num_threads(T)
     {
         const int t = omp_get_thread_num();
-        const size_t hi = bound[t + 1];
-        std::vector<E> &es = parts[t];
-        size_t p = bound[t];
+        const size_t lo = bound[t], hi = bound[t + 1];
+        size_t lines = 0;
+        for (const char *q = ix + lo, *e = ix + hi; q < e; lines++) { const char *nl = (const char *) memchr(q, '\n', (size_t) (e - q)); q = nl ? nl + 1 : e; }
+        first[t + 1] = lines;
+#pragma omp barrier
+#pragma omp single
+        {
+            for (int i = 0; i < T; i++) first[i + 1] += first[i];
+            key.resize(first[T]); off.resize(first[T]); len.resize(first[T]); ext.resize(first[T]);
+        }
+        size_t p = lo, at = first[t];
+        bool ok = true, in = true;
         while (p < hi) {
             unsigned long long v[4] = {0, 0, 0, 0}; int f = 0;
             while (p < ixBytes && ix[p] != '\n') {
@@ -73,21 +108,32 @@ bool MmDb::load(const std::string &path, std::string *err, bool indexOnly) {
                 p++;
             }
             p++;
-            if (f >= 2) es.push_back({(uint32_t) v[0], v[1], v[2], (uint8_t) v[3]});
+            // (a line without its three columns - not something a DBWriter leaves - reads as an empty entry of key 0 and fails the order check)
+            key[at] = (uint32_t) v[0]; off[at] = v[1]; len[at] = v[2]; ext[at] = (uint8_t) v[3];
+            if (at > first[t] && key[at - 1] > key[at]) ok = false;
+            if (v[1] + v[2] > bytes) in = false;
+            at++;
+        }
+        if (!ok) {
+#pragma omp atomic write
+            sorted = false;
+        }
+        if (!in) {
+#pragma omp atomic write
+            inside = false;
         }
     }
     if (ixMap) munmap(ixMap, ixBytes);
-    size_t n = 0;
-    for (auto &v : parts) n += v.size();
-    std::vector<E> es; es.reserve(n);
-    for (auto &v : parts) es.insert(es.end(), v.begin(), v.end());
-    bool sorted = true;
-    for (size_t i = 1; i < n && sorted; i++) sorted = es[i - 1].k <= es[i].k;
-    if (!sorted) std::stable_sort(es.begin(), es.end(), [](const E &a, const E &b) { return a.k < b.k; });
-    key.resize(n); off.resize(n); len.resize(n); ext.resize(n);
-    for (size_t i = 0; i < n; i++) {
-        if (!indexOnly && es[i].o + es[i].l > bytes) { *err = "index entry beyond the data file in " + path; return false; }
-        key[i] = es[i].k; off[i] = es[i].o; len[i] = es[i].l; ext[i] = es[i].e;
+    const size_t n = key.size();
+    for (int t = 1; t < T && sorted; t++) if (first[t] > 0 && first[t] < n && key[first[t] - 1] > key[first[t]]) sorted = false;
+    if (!indexOnly && !inside) { *err = "index entry beyond the data file in " + path; return false; }
+    if (!sorted) {      // DBReader::sortIndex: by key, entries of equal keys in file order
+        std::vector<uint32_t> perm(n);
+        for (size_t i = 0; i < n; i++) perm[i] = (uint32_t) i;
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+        HVec<uint32_t> k2(n); HVec<uint64_t> o2(n), l2(n); HVec<uint8_t> e2(n);
+        for (size_t i = 0; i < n; i++) { k2[i] = key[perm[i]]; o2[i] = off[perm[i]]; l2[i] = len[perm[i]]; e2[i] = ext[perm[i]]; }
+        key.swap(k2); off.swap(o2); len.swap(l2); ext.swap(e2);
     }
     return true;
 }
@@ -114,38 +160,69 @@ static void indexText(std::string &out, const uint32_t *key, const uint32_t *len
         base += len[i];
     }
 }
+// data and index go out with one pwrite per chunk / per thread, all at once: every writer knows its offsets beforehand
+static bool pwriteAll(int fd, const char *p, size_t n, uint64_t at) {
+    while (n) { const ssize_t w = pwrite(fd, p, n, (off_t) at); if (w <= 0) return false; p += w; n -= (size_t) w; at += (uint64_t) w; }
+    return true;
+}
 bool mmdbWriteChunks(const std::string &path, int dbtype, const std::vector<OutChunk> &chunks, std::string *err) {
-    FILE *d = fopen(path.c_str(), "wb"), *ix = fopen((path + ".index").c_str(), "w");
-    if (!d || !ix) { *err = "Could not open " + path + " for writing"; return false; }
-    std::vector<uint64_t> base(chunks.size() + 1, 0);
-    for (size_t c = 0; c < chunks.size(); c++) base[c + 1] = base[c] + chunks[c].data.size();
-    std::vector<std::string> ixText(chunks.size());
-#pragma omp parallel for schedule(dynamic, 1)
-    for (size_t c = 0; c < chunks.size(); c++) indexText(ixText[c], chunks[c].key.data(), chunks[c].len.data(), chunks[c].ext.data(), chunks[c].key.size(), base[c]);
-    for (size_t c = 0; c < chunks.size(); c++) {
-        if (!chunks[c].data.empty()) fwrite(chunks[c].data.data(), 1, chunks[c].data.size(), d);
-        if (!ixText[c].empty()) fwrite(ixText[c].data(), 1, ixText[c].size(), ix);
+    const int d = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644), ix = open((path + ".index").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (d < 0 || ix < 0) { if (d >= 0) close(d); if (ix >= 0) close(ix); *err = "Could not open " + path + " for writing"; return false; }
+    const size_t C = chunks.size();
+    std::vector<uint64_t> base(C + 1, 0), ixBase(C + 1, 0);
+    for (size_t c = 0; c < C; c++) base[c + 1] = base[c] + chunks[c].data.size();
+    std::vector<std::string> ixText(C);
+    bool ok = true;
+#pragma omp parallel
+    {
+#pragma omp for schedule(dynamic, 1)
+        for (size_t c = 0; c < C; c++) {
+            indexText(ixText[c], chunks[c].key.data(), chunks[c].len.data(), chunks[c].ext.data(), chunks[c].key.size(), base[c]);
+            if (!chunks[c].data.empty() && !pwriteAll(d, chunks[c].data.data(), chunks[c].data.size(), base[c])) {
+#pragma omp atomic write
+                ok = false;
+            }
+        }
+#pragma omp single
+        for (size_t c = 0; c < C; c++) ixBase[c + 1] = ixBase[c] + ixText[c].size();
+#pragma omp for schedule(dynamic, 1)
+        for (size_t c = 0; c < C; c++)
+            if (!ixText[c].empty() && !pwriteAll(ix, ixText[c].data(), ixText[c].size(), ixBase[c])) {
+#pragma omp atomic write
+                ok = false;
+            }
     }
-    const bool ok = fclose(d) == 0 && fclose(ix) == 0 && writeDbtype(path, dbtype);
+    ok = (close(d) == 0) & (close(ix) == 0) & ok;
+    ok = ok && writeDbtype(path, dbtype);
     if (!ok) *err = "Could not write " + path;
     return ok;
 }
-bool mmdbWriteBlob(const std::string &path, int dbtype, const char *blob, size_t blobBytes, const std::vector<uint32_t> &key, const std::vector<uint64_t> &off,
-                   const std::vector<uint32_t> &len, const std::vector<uint8_t> &ext, std::string *err) {
-    FILE *d = fopen(path.c_str(), "wb"), *ix = fopen((path + ".index").c_str(), "w");
-    if (!d || !ix) { *err = "Could not open " + path + " for writing"; return false; }
-    if (blobBytes) fwrite(blob, 1, blobBytes, d);
-    const size_t n = key.size();
+bool mmdbWriteBlob(const std::string &path, int dbtype, const char *blob, size_t blobBytes, const uint32_t *key, const uint64_t *off,
+                   const uint32_t *len, const uint8_t *ext, size_t n, std::string *err) {
+    const int d = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644), ix = open((path + ".index").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (d < 0 || ix < 0) { if (d >= 0) close(d); if (ix >= 0) close(ix); *err = "Could not open " + path + " for writing"; return false; }
     const int T = std::max(1, omp_get_max_threads());
     std::vector<std::string> ixText(T);
+    std::vector<uint64_t> ixBase(T + 1, 0);
+    bool ok = true;
 #pragma omp parallel num_threads(T)
     {
         const int t = omp_get_thread_num();
         const size_t lo = n * (size_t) t / T, hi = n * (size_t) (t + 1) / T;
-        if (hi > lo) indexText(ixText[t], key.data() + lo, len.data() + lo, ext.data() + lo, hi - lo, off[lo]);
+        if (hi > lo) indexText(ixText[t], key + lo, len + lo, ext + lo, hi - lo, off[lo]);
+        const size_t bLo = blobBytes * (size_t) t / T, bHi = blobBytes * (size_t) (t + 1) / T;
+        bool mine = bHi <= bLo || pwriteAll(d, blob + bLo, bHi - bLo, bLo);
+#pragma omp barrier
+#pragma omp single
+        for (int i = 0; i < T; i++) ixBase[i + 1] = ixBase[i] + ixText[i].size();
+        if (!ixText[t].empty()) mine = pwriteAll(ix, ixText[t].data(), ixText[t].size(), ixBase[t]) && mine;
+        if (!mine) {
+#pragma omp atomic write
+            ok = false;
+        }
     }
-    for (auto &s : ixText) if (!s.empty()) fwrite(s.data(), 1, s.size(), ix);
-    const bool ok = fclose(d) == 0 && fclose(ix) == 0 && writeDbtype(path, dbtype);
+    ok = (close(d) == 0) & (close(ix) == 0) & ok;
+    ok = ok && writeDbtype(path, dbtype);
     if (!ok) *err = "Could not write " + path;
     return ok;
 }

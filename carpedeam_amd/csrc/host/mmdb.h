@@ -7,13 +7,35 @@
 // merge at close (DBWriter.cpp:135-188,239-241), without the temporary files.
 #pragma once
 #include <cstdint>
+#include <algorithm>
+#include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
+// Large host arrays (index columns, record arrays, output text) come straight from mmap with MADV_HUGEPAGE and without reserve
+// accounting: a module touches gigabytes of fresh memory once, and on 4 KB pages the page faults - not the parsing or formatting -
+// were its wall time (16 threads formatted alignment text no faster than one).  Capacity is reserved by upper bound and never
+// grown, so nothing is copied by a reallocation either; untouched capacity costs address space only.
+void *hugeAlloc(size_t bytes);
+void hugeFree(void *p, size_t bytes);
+template <typename T> struct HugeAlloc {
+    typedef T value_type;
+    HugeAlloc() = default;
+    template <typename U> HugeAlloc(const HugeAlloc<U> &) {}
+    T *allocate(size_t n) { return (T *) hugeAlloc(n * sizeof(T)); }
+    void deallocate(T *p, size_t n) { hugeFree(p, n * sizeof(T)); }
+    // resize() leaves trivially constructible elements as the kernel hands them out (zero pages): no fill pass over fresh memory
+    template <typename U, typename... A> void construct(U *p, A &&...a) { if (sizeof...(A) != 0 || !std::is_trivially_default_constructible<U>::value) ::new ((void *) p) U(std::forward<A>(a)...); }
+    template <typename U> bool operator==(const HugeAlloc<U> &) const { return true; }
+    template <typename U> bool operator!=(const HugeAlloc<U> &) const { return false; }
+};
+template <typename T> using HVec = std::vector<T, HugeAlloc<T>>;
+
 struct MmDb {
-    std::vector<uint32_t> key;       // ordered by key (DBReader::sortIndex, DBReader.cpp:238-)
-    std::vector<uint64_t> off, len;  // len includes the trailing NUL
-    std::vector<uint8_t> ext;
+    HVec<uint32_t> key;       // ordered by key (DBReader::sortIndex, DBReader.cpp:238-)
+    HVec<uint64_t> off, len;  // len includes the trailing NUL
+    HVec<uint8_t> ext;
     int dbtype = 0;
     MmDb() = default;
     MmDb(const MmDb &) = delete;
@@ -28,18 +50,23 @@ struct MmDb {
 private:
     const char *base = nullptr; size_t bytes = 0;
     void *mapped = nullptr; size_t mappedBytes = 0;   // mmap of a single data file
-    std::string owned;                                // concatenation of split data files
+    HVec<char> owned;                                 // concatenation of split data files
 };
 
 // entries of consecutive keys, filled by one thread: data = "payload\0" per entry
-struct OutChunk {
-    std::string data;
-    std::vector<uint32_t> key, len;   // len includes the NUL
-    std::vector<uint8_t> ext;
-    void add(uint32_t k, const char *p, size_t n, uint8_t e) { data.append(p, n); data.push_back('\0'); key.push_back(k); len.push_back((uint32_t) n + 1); ext.push_back(e); }
+struct alignas(128) OutChunk {     // (a cache line of its own: the threads update their chunks' vector ends on every entry)
+    HVec<char> data;
+    HVec<uint32_t> key, len;   // len includes the NUL
+    HVec<uint8_t> ext;
+    // upper bounds of what the chunk will hold (entries, payload bytes incl. the NULs): reserved once, never grown by the writers below
+    void reserve(size_t entries, size_t bytes) { data.reserve(bytes); key.reserve(entries); len.reserve(entries); ext.reserve(entries); }
+    void add(uint32_t k, const char *p, size_t n, uint8_t e) { data.insert(data.end(), p, p + n); data.push_back('\0'); key.push_back(k); len.push_back((uint32_t) n + 1); ext.push_back(e); }
+    // in-place writing of one entry: w = open(maxBytes); ... write at w ...; close(key, end, ext) - no staging copy
+    char *open(size_t maxBytes) { const size_t at = data.size(); if (data.capacity() - at < maxBytes + 1) data.reserve(std::max(data.capacity() * 2, at + maxBytes + 1)); data.resize(at + maxBytes + 1); return data.data() + at; }
+    void close(uint32_t k, char *start, char *end, uint8_t e) { *end++ = '\0'; data.resize((size_t) (end - data.data())); key.push_back(k); len.push_back((uint32_t) (end - start)); ext.push_back(e); }
 };
 // chunks in increasing key order (chunk i holds smaller keys than chunk i + 1)
 bool mmdbWriteChunks(const std::string &path, int dbtype, const std::vector<OutChunk> &chunks, std::string *err);
 // one blob that already has the data file's layout: entry i at off[i], len[i] bytes incl. the NUL
-bool mmdbWriteBlob(const std::string &path, int dbtype, const char *blob, size_t blobBytes, const std::vector<uint32_t> &key, const std::vector<uint64_t> &off,
-                   const std::vector<uint32_t> &len, const std::vector<uint8_t> &ext, std::string *err);
+bool mmdbWriteBlob(const std::string &path, int dbtype, const char *blob, size_t blobBytes, const uint32_t *key, const uint64_t *off,
+                   const uint32_t *len, const uint8_t *ext, size_t n, std::string *err);

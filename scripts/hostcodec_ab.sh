@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B of the host text codecs on the GPU box: scripts/hostcodec_ab.sh <reads>   (needs scripts/_hc_old, scripts/_hc_new built beforehand)
+n=${1:-10000000}; th=16
+d=$(mktemp -d); bin=carpedeam_amd/carpedeam_mi355x
+python scripts/write_reads_db.py $n 100 100 $d/in || exit 1
+K="--kmer-per-seq 200 --kmer-per-seq-scale 0.2 --hash-shift 67 --ignore-multi-kmer 1 --mask 0 --adjust-kmer-len 0 --cov-mode 1 -c 0 --include-only-extendable 0 -k 20"
+R="--rescore-mode 3 -e 0.001 --min-seq-id 0.9 --seq-id-mode 0 --sort-results 0 -a 0 --filter-hits 0 --cov-mode 1 -c 0"
+$bin kmermatcher $d/in $d/pref $K --threads $th 2>/dev/null
+$bin rescorediagonal $d/in $d/in $d/pref $d/aln $R --threads $th 2>/dev/null
+mkdir -p $d/o
+for v in new; do for t in 16 4 1; do echo "== $v, $t threads"; scripts/_hc_$v $d/in $d/pref $d/aln $d/o $t; done; done
+echo "== new without MADV_HUGEPAGE, 16 threads"; CDM_NO_HUGEPAGE=1 scripts/_hc_new $d/in $d/pref $d/aln $d/o 16
+cmp $d/o/pref $d/pref && cmp $d/o/pref.index $d/pref.index && echo "re-serialised DBs identical"
+rm -rf $d
