@@ -11,72 +11,171 @@
 #include <cctype>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+#include <omp.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "mmdb.h"
 
 namespace {
-struct LineReader {
-    gzFile f = nullptr; std::vector<char> buf; size_t pos = 0, end = 0; bool eof = false;
-    bool open(const std::string &p) { f = gzopen(p.c_str(), "rb"); if (f) gzbuffer(f, 1 << 20); buf.resize(1 << 22); return f != nullptr; }
-    ~LineReader() { if (f) gzclose(f); }
-    // next line without its line end ('\n', and a '\r' in front of it); false at the end of the file
-    bool line(std::string &out) {
-        out.clear();
-        while (true) {
-            if (pos == end) {
-                if (eof) return !out.empty();
-                const int n = gzread(f, buf.data(), (unsigned) buf.size());
-                if (n <= 0) { eof = true; return !out.empty(); }
-                pos = 0; end = (size_t) n;
-            }
-            const char *nl = (const char *) memchr(buf.data() + pos, '\n', end - pos);
-            if (nl) {
-                out.append(buf.data() + pos, nl - (buf.data() + pos));
-                pos = (size_t) (nl - buf.data()) + 1;
-                if (!out.empty() && out.back() == '\r') out.pop_back();
-                return true;
-            }
-            out.append(buf.data() + pos, end - pos);
-            pos = end;
-        }
-    }
-};
 struct Entries {
-    std::string seqBlob, hdrBlob;               // "SEQ\n\0" / "header\n\0" per entry, in input order
-    std::vector<uint64_t> seqOff, hdrOff; std::vector<uint32_t> seqLen, hdrLen, file;
+    HVec<char> seqBlob, hdrBlob;               // "SEQ\n\0" / "header\n\0" per entry, in input order
+    HVec<uint64_t> seqOff, hdrOff; HVec<uint32_t> seqLen, hdrLen, file;
 };
-bool parseFile(const std::string &path, uint32_t fileIdx, Entries &e, std::string *err) {
-    LineReader r;
-    if (!r.open(path)) { *err = "Cannot open " + path; return false; }
-    std::string line, seq, header;
-    bool have = r.line(line);
-    while (have) {
-        if (line.empty() || (line[0] != '>' && line[0] != '@')) { have = r.line(line); continue; }
-        const bool fastq = line[0] == '@';
-        // name + comment: kseq separates them at the first white space and createdb joins them with one blank again
-        size_t ne = 1;
-        while (ne < line.size() && line[ne] != ' ' && line[ne] != '\t') ne++;
-        if (ne == 1) { *err = "Fasta entry " + std::to_string(e.seqOff.size()) + " is invalid"; return false; }
-        header.assign(line, 1, ne - 1);
-        if (ne + 1 <= line.size() && ne < line.size()) { const std::string comment = line.substr(ne + 1); if (!comment.empty()) { header.push_back(' '); header += comment; } }
-        header.push_back('\n');
-        seq.clear();
-        have = r.line(line);
-        while (have && !(line.size() && (line[0] == '>' || line[0] == '+' || line[0] == '@'))) { seq += line; have = r.line(line); }
-        if (fastq && have && line[0] == '+') {          // quality: as many characters as the sequence has
-            size_t q = 0;
-            have = r.line(line);
-            while (have && q < seq.size()) { q += line.size(); have = r.line(line); if (q >= seq.size()) break; }
+template <typename V> inline void appendBytes(V &v, const char *p, size_t n) {
+    if (v.capacity() - v.size() < n) v.reserve(std::max(v.capacity() * 2, v.size() + n + (64u << 20)));
+    const size_t at = v.size(); v.resize(at + n); memcpy(v.data() + at, p, n);
+}
+// kseq_read (lib/mmseqs/lib/ksw2/kseq.h:184-233) as a state machine over blocks of the (inflated) file, so that reading / inflating
+// runs in a thread of its own while this one parses; sequence letters go straight into the blob.  What is kept of kseq, malformed
+// input included: the first record - and the one after a quality block - starts at the next '>' or '@' wherever it stands (:190-191);
+// the name ends at any white space (isspace, :199), the comment is the rest of the line (:200); a sequence / quality line loses one
+// trailing '\r' when more than one character has accumulated (:145); lines are sequence until one starts with '>', '@' or '+'
+// (:206); quality lines are read until they hold as many characters as the sequence, and a record whose quality is longer or cut
+// short by the end of the file ENDS the reading of that file (:227-231 return -2, KSeqWrapper.cpp:20-22).
+struct FastxParser {
+    Entries &e; const uint32_t fileIdx;
+    enum State { SEEK, HEADER, SEQ, PLUS, QUAL, STOP } st = SEEK;
+    bool midLine = false;                       // SEQ / PLUS / QUAL: the current line began in an earlier block
+    size_t recSeq = 0, recHdr = 0;              // where the current record's letters / header start in the blobs
+    std::string header, qual;
+    bool invalidEntry = false; size_t invalidAt = 0;
+    FastxParser(Entries &en, uint32_t f) : e(en), fileIdx(f) {}
+    void beginRecord(const char *h, size_t n) {         // h = the header line behind '>' / '@', without its line end
+        size_t ne = 0;
+        while (ne < n && !isspace((unsigned char) h[ne])) ne++;
+        if (ne == 0 && !invalidEntry) { invalidEntry = true; invalidAt = e.seqOff.size(); }
+        header.assign(h, ne);
+        if (ne < n && h[ne] != '\n') {                  // (the delimiter is consumed; it is never '\n' here: the line end is not part of h)
+            size_t cs = ne + 1, cl = n - cs;
+            if (cl > 1 && h[cs + cl - 1] == '\r') cl--;
+            if (cl > 0) { header.push_back(' '); header.append(h + cs, cl); }
         }
-        e.seqOff.push_back(e.seqBlob.size()); e.seqLen.push_back((uint32_t) seq.size() + 2);
-        e.seqBlob += seq; e.seqBlob.push_back('\n'); e.seqBlob.push_back('\0');
-        e.hdrOff.push_back(e.hdrBlob.size()); e.hdrLen.push_back((uint32_t) header.size() + 1);
-        e.hdrBlob += header; e.hdrBlob.push_back('\0');
+        header.push_back('\n');
+        recSeq = e.seqBlob.size(); recHdr = e.hdrBlob.size();
+        appendBytes(e.hdrBlob, header.data(), header.size()); e.hdrBlob.push_back('\0');
+    }
+    void dropRecord() { e.seqBlob.resize(recSeq); e.hdrBlob.resize(recHdr); }
+    void endRecord() {
+        const size_t L = e.seqBlob.size() - recSeq;
+        e.seqOff.push_back(recSeq); e.seqLen.push_back((uint32_t) L + 2);
+        e.seqBlob.push_back('\n'); e.seqBlob.push_back('\0');
+        e.hdrOff.push_back(recHdr); e.hdrLen.push_back((uint32_t) header.size() + 1);
         e.file.push_back(fileIdx);
     }
+    // one (piece of a) line for the sequence / the quality; done = its line end was seen
+    void seqPiece(const char *p, size_t n, bool done) {
+        appendBytes(e.seqBlob, p, n);
+        if (done && e.seqBlob.size() - recSeq > 1 && e.seqBlob.back() == '\r') e.seqBlob.pop_back();
+    }
+    // consumes [p, end) and returns how much of it is done with; what is left (an incomplete header line only) has to come again in
+    // front of the next block.  eof: no more data follows.
+    size_t feed(const char *const begin, const char *const end, bool eof) {
+        const char *p = begin;
+        while (st != STOP) {
+            if (st == SEEK) {
+                const char *q = p;
+                while (q < end && *q != '>' && *q != '@') q++;
+                if (q == end) return (size_t) (end - begin);
+                p = q + 1; st = HEADER;
+            } else if (st == HEADER) {
+                const char *nl = (const char *) memchr(p, '\n', (size_t) (end - p));
+                if (!nl && !eof) return (size_t) (p - begin);
+                if (!nl && p == end) { st = STOP; break; }                  // '>' was the last character: ks_getuntil returns -1 (:199)
+                const char *le = nl ? nl : end;
+                beginRecord(p, (size_t) (le - p));
+                p = nl ? nl + 1 : end; st = SEQ; midLine = false;
+            } else if (st == SEQ) {
+                if (p == end) { if (eof) { endRecord(); st = STOP; } return (size_t) (end - begin); }
+                if (!midLine) {
+                    const char c = *p;
+                    if (c == '>' || c == '@') { endRecord(); p++; st = HEADER; continue; }
+                    if (c == '+') { st = PLUS; midLine = false; p++; continue; }
+                    if (c == '\n') { p++; continue; }
+                }
+                const char *nl = (const char *) memchr(p, '\n', (size_t) (end - p));
+                if (nl) { seqPiece(p, (size_t) (nl - p), true); p = nl + 1; midLine = false; }
+                else { seqPiece(p, (size_t) (end - p), eof); p = end; midLine = !eof; }
+            } else if (st == PLUS) {
+                const char *nl = (const char *) memchr(p, '\n', (size_t) (end - p));
+                if (nl) { p = nl + 1; st = QUAL; qual.clear(); midLine = false; }
+                else { if (eof) { dropRecord(); st = STOP; } return (size_t) (end - begin); }      // no quality string: -2
+            } else {   // QUAL
+                const size_t L = e.seqBlob.size() - recSeq;
+                if (p == end) {
+                    if (!eof) return (size_t) (end - begin);
+                    if (qual.size() == L) endRecord(); else dropRecord();
+                    st = STOP; break;
+                }
+                const char *nl = (const char *) memchr(p, '\n', (size_t) (end - p));
+                const char *le = nl ? nl : end;
+                qual.append(p, (size_t) (le - p));
+                p = nl ? nl + 1 : end;
+                if (!nl && !eof) { midLine = true; continue; }
+                midLine = false;
+                if (qual.size() > 1 && qual.back() == '\r') qual.pop_back();
+                if (qual.size() < L && !(p == end && eof)) continue;
+                if (qual.size() != L) { dropRecord(); st = STOP; break; }
+                endRecord(); st = SEEK;
+            }
+        }
+        return (size_t) (end - begin);
+    }
+};
+// reads / inflates a file block by block in a thread of its own; the parser takes the blocks in order
+struct BlockReader {
+    static const size_t BLOCK = 32u << 20, HEAD = 1u << 20;      // HEAD: room in front of a block for the parser's unfinished header line
+    struct Block { HVec<char> buf; size_t n = 0; bool last = false; };
+    gzFile f = nullptr; Block blk[2]; int filled[2] = {0, 0}; bool failed = false, stop = false;
+    std::mutex m; std::condition_variable cv; std::thread th;
+    bool open(const std::string &p) {
+        f = gzopen(p.c_str(), "rb");
+        if (!f) return false;
+        gzbuffer(f, 4u << 20);
+        for (auto &b : blk) b.buf.resize(HEAD + BLOCK);
+        th = std::thread([this] {
+            for (int i = 0;; i ^= 1) {
+                { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return filled[i] == 0 || stop; }); if (stop) return; }
+                size_t got = 0; bool last = false;
+                while (got < BLOCK) { const int r = gzread(f, blk[i].buf.data() + HEAD + got, (unsigned) std::min<size_t>(BLOCK - got, 1u << 30)); if (r < 0) failed = true; if (r <= 0) { last = true; break; } got += (size_t) r; }
+                blk[i].n = got; blk[i].last = last;
+                { std::lock_guard<std::mutex> l(m); filled[i] = 1; }
+                cv.notify_all();
+                if (last) return;
+            }
+        });
+        return true;
+    }
+    Block &take(int i) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return filled[i] == 1; }); return blk[i]; }
+    void release(int i) { { std::lock_guard<std::mutex> l(m); filled[i] = 0; } cv.notify_all(); }
+    ~BlockReader() { if (th.joinable()) { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_all(); th.join(); } if (f) gzclose(f); }
+};
+bool parseFile(const std::string &path, uint32_t fileIdx, Entries &e, std::string *err) {
+    BlockReader r;
+    if (!r.open(path)) { *err = "Cannot open " + path; return false; }
+    FastxParser ps(e, fileIdx);
+    std::string carry;
+    for (int i = 0;; i ^= 1) {
+        BlockReader::Block &b = r.take(i);
+        if (carry.size() > BlockReader::HEAD) { *err = "Header line of more than 1 MB in " + path; return false; }
+        char *begin = b.buf.data() + BlockReader::HEAD - carry.size();
+        memcpy(begin, carry.data(), carry.size());
+        const char *end = b.buf.data() + BlockReader::HEAD + b.n;
+        const size_t used = ps.feed(begin, end, b.last);
+        carry.assign(begin + used, (size_t) (end - (begin + used)));
+        const bool last = b.last;
+        if (ps.st == FastxParser::STOP) break;          // the rest of the file is not looked at (see above)
+        r.release(i);
+        if (last) break;
+    }
+    if (r.failed) { *err = "Cannot read " + path; return false; }
+    if (ps.invalidEntry) { *err = "Fasta entry " + std::to_string(ps.invalidAt) + " is invalid"; return false; }
     return true;
 }
 // Util::parseFastaHeader (Util.cpp:173-256): the identifier part of a header
@@ -117,19 +216,17 @@ bool parseAll(const std::vector<std::string> &files, Entries &e, std::string *er
 std::string baseName(const std::string &p) { const size_t s = p.find_last_of('/'); return s == std::string::npos ? p : p.substr(s + 1); }
 }  // namespace
 
-// parsed reads in createdb's order as an in-memory sequence DB (blob in data-file layout): keys 0..n-1, wasExtended 0
-bool readFastxAsDb(const std::vector<std::string> &files, bool shuffle, std::string &blob, std::vector<uint32_t> &key, std::vector<uint64_t> &off,
-                   std::vector<uint32_t> &len, std::string *err) {
+// parsed reads in createdb's order as an in-memory sequence DB: keys 0..n-1, wasExtended 0.  The blob stays in input order - the
+// shuffle is a permutation of the offsets, nothing is copied a second time.
+bool readFastxAsDb(const std::vector<std::string> &files, bool shuffle, FastxDb &out, std::string *err) {
     Entries e;
     if (!parseAll(files, e, err)) return false;
     const std::vector<uint32_t> order = entryOrder(e.seqOff.size(), shuffle);
-    blob.clear(); blob.reserve(e.seqBlob.size());
-    key.resize(order.size()); off.resize(order.size()); len.resize(order.size());
-    for (size_t j = 0; j < order.size(); j++) {
-        const uint32_t i = order[j];
-        key[j] = (uint32_t) j; off[j] = blob.size(); len[j] = e.seqLen[i];
-        blob.append(e.seqBlob, e.seqOff[i], e.seqLen[i]);
-    }
+    const size_t n = order.size();
+    out.key.resize(n); out.off.resize(n); out.len.resize(n);
+#pragma omp parallel for schedule(static)
+    for (size_t j = 0; j < n; j++) { const uint32_t i = order[j]; out.key[j] = (uint32_t) j; out.off[j] = e.seqOff[i]; out.len[j] = e.seqLen[i]; }
+    out.blob.swap(e.seqBlob);
     return true;
 }
 
@@ -153,22 +250,31 @@ int createdbModule(const std::vector<std::string> &files, const std::string &out
         if (isNucl != sampled) seqDbType = 0;       // DBTYPE_AMINO_ACIDS: written as the reference writes it; the modules of this path refuse such a DB
     }
     const std::vector<uint32_t> order = entryOrder(n, shuffle);
-    std::string sBlob, hBlob; sBlob.reserve(e.seqBlob.size()); hBlob.reserve(e.hdrBlob.size());
-    std::vector<uint32_t> key(n), sLen(n), hLen(n); std::vector<uint64_t> sOff(n), hOff(n); std::vector<uint8_t> ext(n, 0);
-    std::string lookup;
-    for (size_t j = 0; j < n; j++) {
-        const uint32_t i = order[j];
-        key[j] = (uint32_t) j;
-        sOff[j] = sBlob.size(); sLen[j] = e.seqLen[i]; sBlob.append(e.seqBlob, e.seqOff[i], e.seqLen[i]);
-        hOff[j] = hBlob.size(); hLen[j] = e.hdrLen[i]; hBlob.append(e.hdrBlob, e.hdrOff[i], e.hdrLen[i]);
-        lookup += std::to_string(j); lookup.push_back('\t'); lookup += fastaId(e.hdrBlob.c_str() + e.hdrOff[i]); lookup.push_back('\t');
-        lookup += std::to_string(e.file[i]); lookup.push_back('\n');
+    // the data files hold the entries in createdb's order: gathered by all threads, every slice straight to its place in the blob
+    HVec<uint32_t> key(n), sLen(n), hLen(n); HVec<uint64_t> sOff(n + 1), hOff(n + 1); HVec<uint8_t> ext(n);
+    sOff[0] = hOff[0] = 0;
+    for (size_t j = 0; j < n; j++) { const uint32_t i = order[j]; key[j] = (uint32_t) j; ext[j] = 0; sLen[j] = e.seqLen[i]; hLen[j] = e.hdrLen[i]; sOff[j + 1] = sOff[j] + sLen[j]; hOff[j + 1] = hOff[j] + hLen[j]; }
+    HVec<char> sBlob(sOff[n]), hBlob(hOff[n]);
+    const int T = std::max(1, omp_get_max_threads());
+    std::vector<std::string> lookupPart(T);
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        std::string &lk = lookupPart[t];
+        for (size_t j = n * (size_t) t / T, hi = n * (size_t) (t + 1) / T; j < hi; j++) {
+            const uint32_t i = order[j];
+            memcpy(sBlob.data() + sOff[j], e.seqBlob.data() + e.seqOff[i], sLen[j]);
+            memcpy(hBlob.data() + hOff[j], e.hdrBlob.data() + e.hdrOff[i], hLen[j]);
+            lk += std::to_string(j); lk.push_back('\t'); lk += fastaId(e.hdrBlob.data() + e.hdrOff[i]); lk.push_back('\t');
+            lk += std::to_string(e.file[i]); lk.push_back('\n');
+        }
     }
     if (!mmdbWriteBlob(outPath, seqDbType, sBlob.data(), sBlob.size(), key.data(), sOff.data(), sLen.data(), ext.data(), n, err)) return 1;
     if (!mmdbWriteBlob(outPath + "_h", 12 /* DBTYPE_GENERIC_DB */, hBlob.data(), hBlob.size(), key.data(), hOff.data(), hLen.data(), ext.data(), n, err)) return 1;
     FILE *lf = fopen((outPath + ".lookup").c_str(), "w"), *sf = fopen((outPath + ".source").c_str(), "w");
     if (!lf || !sf) { *err = "Cannot open " + outPath + ".lookup for writing"; return 1; }
-    fwrite(lookup.data(), 1, lookup.size(), lf); fclose(lf);
+    for (const std::string &lk : lookupPart) fwrite(lk.data(), 1, lk.size(), lf);
+    fclose(lf);
     for (size_t f = 0; f < files.size(); f++) fprintf(sf, "%zu\t%s\n", f, baseName(files[f]).c_str());
     fclose(sf);
     return 0;

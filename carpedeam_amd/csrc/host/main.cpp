@@ -28,8 +28,6 @@
 #include "mmdb.h"
 
 // host/ingest.cpp
-bool readFastxAsDb(const std::vector<std::string> &files, bool shuffle, std::string &blob, std::vector<uint32_t> &key, std::vector<uint64_t> &off,
-                   std::vector<uint32_t> &len, std::string *err);
 int createdbModule(const std::vector<std::string> &files, const std::string &outPath, bool shuffle, int dbType, std::string *err);
 int convert2fastaModule(const std::string &dbPath, const std::string &outPath, std::string *err);
 int createhdbModule(const std::string &seqPath, const std::string &cyclePath, const std::string &outPath, std::string *err);
@@ -478,11 +476,11 @@ int readsLoop(Args &a) {
         ctx = openCtx();
         db = uploadSeqDb(ctx, seq);
     } else {
-        std::string blob; std::vector<uint32_t> key, len; std::vector<uint64_t> off;
-        if (!readFastxAsDb(std::vector<std::string>(1, a.pos[0]), iflag(a, "--shuffle", 1) != 0, blob, key, off, len, &err)) die(err);
-        for (auto &l : len) l -= 2;
+        FastxDb fx;
+        if (!readFastxAsDb(std::vector<std::string>(1, a.pos[0]), iflag(a, "--shuffle", 1) != 0, fx, &err)) die(err);
+        for (auto &l : fx.len) l -= 2;
         ctx = openCtx();
-        check(cdm_seqdb_upload(ctx, blob.data(), off.data(), len.data(), key.data(), NULL, key.size(), &db), "Can not load the reads");
+        check(cdm_seqdb_upload(ctx, fx.blob.data(), fx.off.data(), fx.len.data(), fx.key.data(), NULL, fx.key.size(), &db), "Can not load the reads");
     }
     check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");
     cdm_kmer_params kp;

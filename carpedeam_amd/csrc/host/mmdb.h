@@ -70,3 +70,7 @@ bool mmdbWriteChunks(const std::string &path, int dbtype, const std::vector<OutC
 // one blob that already has the data file's layout: entry i at off[i], len[i] bytes incl. the NUL
 bool mmdbWriteBlob(const std::string &path, int dbtype, const char *blob, size_t blobBytes, const uint32_t *key, const uint64_t *off,
                    const uint32_t *len, const uint8_t *ext, size_t n, std::string *err);
+
+// host/ingest.cpp: FASTA/FASTQ[.gz] reads as an in-memory sequence DB (what createdb would write, without the files)
+struct FastxDb { HVec<char> blob; HVec<uint32_t> key, len; HVec<uint64_t> off; };     // entry j: blob[off[j] .. off[j] + len[j]) = "SEQ\n\0"
+bool readFastxAsDb(const std::vector<std::string> &files, bool shuffle, FastxDb &out, std::string *err);

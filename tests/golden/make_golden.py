@@ -233,6 +233,12 @@ def createdb_digests():
         T.run(T.REF, "convert2fasta", str(d / "asm"), str(d / "asm_cyc.fasta"), "-v", "0")
         fasta.update({"asm_cyc.fasta": T.digest(str(d / "asm_cyc.fasta")), "asm_h": T.digest(str(d / "asm_h")), "asm_h.index": T.digest(str(d / "asm_h.index"))})
         out["fasta"] = fasta
+        odd = {}
+        for p in T.odd_inputs(d):
+            name = os.path.basename(p)
+            T.run(T.REF, "createdb", p, str(d / ("r_" + name)), "--shuffle", "0", "--dbtype", "2", "-v", "0")
+            odd[name] = {ext: T.digest(str(d / ("r_" + name)) + ext) for ext in T.DB_FILES}
+        out["odd"] = odd
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "example", "createdb_digests.json"), "w"), indent=1)
 
 

@@ -50,6 +50,51 @@ def tricky_fasta(tmp_path):
     return p
 
 
+def odd_inputs(tmp_path):
+    """malformed and unusual FASTA/FASTQ, one file per case: what kseq (lib/mmseqs/lib/ksw2/kseq.h:184-233) makes of it is the contract"""
+    cases = {
+        "ws_in_names.fa": ">n1\vvertical tab ends the name\nACGT\n>n2\fform feed\nGGCC\n>n3\rcarriage return inside\nTTAA\n>n4\tt\nAC\n>n5 \r\nACGTAC\n>n6  two blanks\nAC\n",
+        "garbage_before_first.fa": "junk line\nmore junk >mid-line start\nACGT\nAC\n>real one\nGGGG\n",
+        "crlf_multiline.fa": ">a x\r\nACGT\r\nAC\r\n\r\nGT\r\n>b\r\nA\r\n>c\r\n\r\n>d\r\nACGTNN\r\n",
+        "multiline.fq": "@q1 c\nACGT\nACGT\n+\nIIII\nIIII\n@q2\nGG\n+q2 again\nII\n\n\n@q3\nTTTT\n+\nII\nII\n",
+        "qual_too_long.fq": "@ok1\nACGT\n+\nIIII\n@bad\nACGT\n+\nIIIIII\n@never_seen\nGGGG\n+\nIIII\n",
+        "qual_cut_short.fq": "@ok1\nACGT\n+\nIIII\n@ok2\nAC\n+\nII\n@cut\nACGTACGT\n+\nIII",
+        "at_in_quality.fq": "@r1\nACGTACGT\n+\n@@@@IIII\n@r2\nGGGG\n+\n@III\n",
+        "junk_after_quality.fq": "@r1\nACGT\n+\nIIII\nstray text then @r2 header mid-line\nGGCC\n+\nIIII\n",
+        "no_final_newline.fa": ">x\nACGT\n>y only a header",
+        "plus_at_end.fq": "@r1\nACGT\n+\nIIII\n@r2\nGG\n+",
+    }
+    paths = []
+    for name, text in cases.items():
+        p = str(tmp_path / name)
+        open(p, "wb").write(text.encode("latin1"))
+        paths.append(p)
+    return paths
+
+
+def test_createdb_on_odd_inputs_equals_reference(exe, tmp_path):
+    want = json.load(open(os.path.join(GOLD, "example", "createdb_digests.json")))["odd"]
+    for p in odd_inputs(tmp_path):
+        name = os.path.basename(p)
+        run(exe, "createdb", p, str(tmp_path / ("m_" + name)), "--shuffle", "0", "--dbtype", "2")
+        got = {ext: digest(str(tmp_path / ("m_" + name)) + ext) for ext in DB_FILES}
+        assert got == want[name], name
+        if os.path.exists(REF):
+            run(REF, "createdb", p, str(tmp_path / ("r_" + name)), "--shuffle", "0", "--dbtype", "2", "-v", "0")
+            assert got == {ext: digest(str(tmp_path / ("r_" + name)) + ext) for ext in DB_FILES}, name
+
+
+def test_createdb_rejects_an_entry_without_a_name(exe, tmp_path):
+    """a '>' followed by white space is an entry with an empty name: "Fasta entry N is invalid" and a non-zero exit (createdb.cpp:154-157)"""
+    p = str(tmp_path / "bad.fa")
+    open(p, "w").write(">ok\nACGT\njunk > not a name\nACGT\n")      # (the second '>' is found character-wise after... no: line-wise, it is sequence)
+    run(exe, "createdb", p, str(tmp_path / "fine"), "--dbtype", "2")
+    open(p, "w").write("junk > no name here\nACGT\n>ok\nACGT\n")
+    for binary in [exe] + ([REF] if os.path.exists(REF) else []):
+        r = subprocess.run([binary, "createdb", p, str(tmp_path / "out"), "--dbtype", "2"], capture_output=True, text=True)
+        assert r.returncode != 0 and "Fasta entry 0 is invalid" in (r.stdout + r.stderr)
+
+
 @pytest.mark.parametrize("shuffle", ["1", "0"])
 def test_createdb_equals_reference(exe, tmp_path, shuffle):
     fq, seqs = example_fastq(tmp_path)
