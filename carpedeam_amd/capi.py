@@ -189,6 +189,10 @@ class SeqDb:
         _check(lib().cdm_seqdb_meta(self.ctx.h, self.h, _ptr(lens), _ptr(keys), _ptr(ext)))
         return lens, keys, ext
 
+    def download_into(self, buf, offs):
+        """sequence i as "SEQ\\n" at buf[offs[i]:] (uint8 / uint64 numpy arrays owned by the caller; the library writes the whole range up to the last entry's end: bytes between entries come out as NUL)"""
+        _check(lib().cdm_seqdb_download(self.ctx.h, self.h, _ptr(buf), _ptr(offs)))
+
     def download(self):
         """-> (list of bytes sequences, keys, ext)"""
         if self.n == 0:

@@ -18,6 +18,8 @@
 #include <vector>
 #include <omp.h>
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -46,6 +48,9 @@ struct FastxParser {
     size_t recSeq = 0, recHdr = 0;              // where the current record's letters / header start in the blobs
     std::string header, qual;
     bool invalidEntry = false; size_t invalidAt = 0;
+    // parallel parsing of a plain file: a parser owns the records that START in front of `limit` and stops - `stoppedAt` - where the
+    // first one behind it starts
+    const char *limit = nullptr, *stoppedAt = nullptr;
     FastxParser(Entries &en, uint32_t f) : e(en), fileIdx(f) {}
     void beginRecord(const char *h, size_t n) {         // h = the header line behind '>' / '@', without its line end
         size_t ne = 0;
@@ -61,7 +66,8 @@ struct FastxParser {
         recSeq = e.seqBlob.size(); recHdr = e.hdrBlob.size();
         appendBytes(e.hdrBlob, header.data(), header.size()); e.hdrBlob.push_back('\0');
     }
-    void dropRecord() { e.seqBlob.resize(recSeq); e.hdrBlob.resize(recHdr); }
+    bool refused = false;                       // a record kseq returns -2 for: the reading of the file ends there
+    void dropRecord() { e.seqBlob.resize(recSeq); e.hdrBlob.resize(recHdr); refused = true; }
     void endRecord() {
         const size_t L = e.seqBlob.size() - recSeq;
         e.seqOff.push_back(recSeq); e.seqLen.push_back((uint32_t) L + 2);
@@ -83,6 +89,7 @@ struct FastxParser {
                 const char *q = p;
                 while (q < end && *q != '>' && *q != '@') q++;
                 if (q == end) return (size_t) (end - begin);
+                if (limit && q >= limit) { stoppedAt = q; st = STOP; break; }
                 p = q + 1; st = HEADER;
             } else if (st == HEADER) {
                 const char *nl = (const char *) memchr(p, '\n', (size_t) (end - p));
@@ -95,7 +102,11 @@ struct FastxParser {
                 if (p == end) { if (eof) { endRecord(); st = STOP; } return (size_t) (end - begin); }
                 if (!midLine) {
                     const char c = *p;
-                    if (c == '>' || c == '@') { endRecord(); p++; st = HEADER; continue; }
+                    if (c == '>' || c == '@') {
+                        endRecord();
+                        if (limit && p >= limit) { stoppedAt = p; st = STOP; break; }
+                        p++; st = HEADER; continue;
+                    }
                     if (c == '+') { st = PLUS; midLine = false; p++; continue; }
                     if (c == '\n') { p++; continue; }
                 }
@@ -156,7 +167,88 @@ struct BlockReader {
     void release(int i) { { std::lock_guard<std::mutex> l(m); filled[i] = 0; } cv.notify_all(); }
     ~BlockReader() { if (th.joinable()) { { std::lock_guard<std::mutex> l(m); stop = true; } cv.notify_all(); th.join(); } if (f) gzclose(f); }
 };
+// A plain (not compressed) file is parsed by all threads at once, each on a stretch of the mapped file.  Where a stretch starts is a
+// guess - a line that begins with '>', or with '@' when the line after the next begins with '+' - and the guess is CHECKED: the
+// parser of the stretch in front, run exactly like the serial one, has to arrive at that very byte looking for a record start.
+// Any disagreement, any record kseq would refuse, and the file is parsed serially instead: the result is the serial one either way.
+bool parsePlainParallel(const std::string &path, uint32_t fileIdx, Entries &e) {
+    const int T = std::max(1, omp_get_max_threads());
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    static const size_t minBytes = getenv("CDM_INGEST_PAR_MIN") ? strtoull(getenv("CDM_INGEST_PAR_MIN"), nullptr, 10) : (64u << 20);      // (tests lower it)
+    if (fstat(fd, &st) != 0 || (size_t) st.st_size < std::max<size_t>(minBytes, 2) || T < 2) { close(fd); return false; }
+    const size_t S = (size_t) st.st_size;
+    const char *m = (const char *) mmap(nullptr, S, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return false;
+    bool ok = !(S >= 2 && (unsigned char) m[0] == 0x1f && (unsigned char) m[1] == 0x8b);      // gzip: the serial, inflating path
+    std::vector<size_t> start(T + 1, S);
+    start[0] = 0;
+    for (int t = 1; t < T && ok; t++) {
+        size_t p = S * (size_t) t / T; const size_t stop = std::min(S, p + (4u << 20));
+        bool found = false;
+        while (p < stop && !found) {
+            const char *nl = (const char *) memchr(m + p, '\n', stop - p);
+            if (!nl) break;
+            p = (size_t) (nl - m) + 1;
+            if (p >= S) break;
+            if (m[p] == '>') found = true;
+            else if (m[p] == '@') {
+                const char *l2 = (const char *) memchr(m + p, '\n', S - p);
+                const char *l3 = l2 ? (const char *) memchr(l2 + 1, '\n', S - (size_t) (l2 + 1 - m)) : nullptr;
+                if (l3 && (size_t) (l3 + 1 - m) < S && l3[1] == '+') found = true;
+            }
+        }
+        if (!found) ok = false;
+        start[t] = p;
+    }
+    for (int t = 1; t < T && ok; t++) if (start[t] <= start[t - 1]) ok = false;
+    std::vector<Entries> part(ok ? T : 0);
+    if (ok) {
+        std::vector<char> good(T, 0);
+#pragma omp parallel num_threads(T)
+        {
+            const int t = omp_get_thread_num();
+            Entries &pe = part[t];
+            const size_t span = start[t + 1] - start[t];
+            pe.seqBlob.reserve(span + 2); pe.hdrBlob.reserve(span / 2 + 2);
+            const size_t guess = span / 128 + 16;
+            pe.seqOff.reserve(guess); pe.hdrOff.reserve(guess); pe.seqLen.reserve(guess); pe.hdrLen.reserve(guess); pe.file.reserve(guess);
+            FastxParser ps(pe, fileIdx);
+            ps.limit = t + 1 < T ? m + start[t + 1] : nullptr;
+            ps.feed(m + start[t], m + S, true);
+            // arrived exactly where the next stretch was guessed to start (the last one: at the end of the file), nothing refused
+            good[t] = !ps.invalidEntry && !ps.refused && (t + 1 < T ? ps.stoppedAt == m + start[t + 1] : ps.stoppedAt == nullptr);
+        }
+        for (int t = 0; t < T; t++) ok = ok && good[t];
+    }
+    if (ok) {
+        std::vector<size_t> cnt(T + 1, 0), sb(T + 1, 0), hb(T + 1, 0);
+        for (int t = 0; t < T; t++) { cnt[t + 1] = cnt[t] + part[t].seqOff.size(); sb[t + 1] = sb[t] + part[t].seqBlob.size(); hb[t + 1] = hb[t] + part[t].hdrBlob.size(); }
+        const size_t n0 = e.seqOff.size(), s0 = e.seqBlob.size(), h0 = e.hdrBlob.size();
+        if (e.seqBlob.capacity() < s0 + sb[T]) e.seqBlob.reserve(s0 + sb[T]);
+        if (e.hdrBlob.capacity() < h0 + hb[T]) e.hdrBlob.reserve(h0 + hb[T]);
+        e.seqBlob.resize(s0 + sb[T]); e.hdrBlob.resize(h0 + hb[T]);
+        e.seqOff.resize(n0 + cnt[T]); e.hdrOff.resize(n0 + cnt[T]); e.seqLen.resize(n0 + cnt[T]); e.hdrLen.resize(n0 + cnt[T]); e.file.resize(n0 + cnt[T]);
+#pragma omp parallel num_threads(T)
+        {
+            const int t = omp_get_thread_num();
+            const Entries &pe = part[t];
+            memcpy(e.seqBlob.data() + s0 + sb[t], pe.seqBlob.data(), pe.seqBlob.size());
+            memcpy(e.hdrBlob.data() + h0 + hb[t], pe.hdrBlob.data(), pe.hdrBlob.size());
+            for (size_t i = 0, k = n0 + cnt[t]; i < pe.seqOff.size(); i++, k++) {
+                e.seqOff[k] = pe.seqOff[i] + s0 + sb[t]; e.hdrOff[k] = pe.hdrOff[i] + h0 + hb[t];
+                e.seqLen[k] = pe.seqLen[i]; e.hdrLen[k] = pe.hdrLen[i]; e.file[k] = fileIdx;
+            }
+        }
+    }
+    munmap((void *) m, S);
+    if (getenv("CDM_TIMING")) fprintf(stderr, "  %s: %s\n", path.c_str(), ok ? "parsed by all threads (every stretch start confirmed)" : "parsed serially");
+    return ok;
+}
 bool parseFile(const std::string &path, uint32_t fileIdx, Entries &e, std::string *err) {
+    if (!getenv("CDM_INGEST_SERIAL") && parsePlainParallel(path, fileIdx, e)) return true;
     BlockReader r;
     if (!r.open(path)) { *err = "Cannot open " + path; return false; }
     FastxParser ps(e, fileIdx);

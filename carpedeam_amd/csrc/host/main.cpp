@@ -136,11 +136,15 @@ void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype)
     std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
     check(cdm_seqdb_meta(ctx, h, lens.data(), keys.data(), ext.data()), "meta");
     // the download buffer has the data file's layout already: "SEQ\n\0" per entry (the NULs are the buffer's zero fill)
+    Laps laps;
     HVec<uint64_t> offs(n); HVec<uint32_t> elen(n); uint64_t tot = 0;
     for (uint64_t i = 0; i < n; i++) { offs[i] = tot; elen[i] = lens[i] + 2; tot += lens[i] + 2; }
     HVec<char> buf(tot);            // fresh zero pages: the NULs between the entries
+    laps.lap("    (lengths down, offsets)");
     check(cdm_seqdb_download(ctx, h, buf.data(), offs.data()), "download");
+    laps.lap("    (letters unpacked and down)");
     std::string err; if (!mmdbWriteBlob(path, dbtype, buf.data(), buf.size(), keys.data(), offs.data(), elen.data(), ext.data(), n, &err)) die(err);
+    laps.lap("    (data + index files written)");
 }
 // ---- text codecs
 // decimal text, two digits per division
@@ -470,17 +474,21 @@ int readsLoop(Args &a) {
     int dbtype = 1;
     cdm_ctx *ctx = NULL; cdm_seqdb *db = NULL;
     struct stat st;
+    Laps laps;
     if (stat((a.pos[0] + ".index").c_str(), &st) == 0) {
         if (!seq.load(a.pos[0], &err)) die(err);
         dbtype = seq.dbtype;
-        ctx = openCtx();
-        db = uploadSeqDb(ctx, seq);
+        laps.lap("DB files mapped");
+        ctx = openCtx(); laps.lap("device context");
+        db = uploadSeqDb(ctx, seq); laps.lap("sequences up");
     } else {
         FastxDb fx;
         if (!readFastxAsDb(std::vector<std::string>(1, a.pos[0]), iflag(a, "--shuffle", 1) != 0, fx, &err)) die(err);
         for (auto &l : fx.len) l -= 2;
-        ctx = openCtx();
+        laps.lap("reads file parsed");
+        ctx = openCtx(); laps.lap("device context");
         check(cdm_seqdb_upload(ctx, fx.blob.data(), fx.off.data(), fx.len.data(), fx.key.data(), NULL, fx.key.size(), &db), "Can not load the reads");
+        laps.lap("sequences up");
     }
     check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");
     cdm_kmer_params kp;
@@ -533,7 +541,8 @@ int readsLoop(Args &a) {
             db = rest;
         }
     }
-    if (cyclic.key.empty()) writeSeqDb(ctx, db, a.pos[1], dbtype);
+    laps.lap("iterations");
+    if (cyclic.key.empty()) { writeSeqDb(ctx, db, a.pos[1], dbtype); laps.lap("sequences down, DB written"); }
     else {   // concatdbs --preserve-keys of the linear and the circular contigs, written in key order
         OutChunk all; appendEntries(ctx, db, all);
         std::vector<std::pair<uint32_t, std::pair<const OutChunk *, size_t>>> order;

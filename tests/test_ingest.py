@@ -84,6 +84,28 @@ def test_createdb_on_odd_inputs_equals_reference(exe, tmp_path):
             assert got == {ext: digest(str(tmp_path / ("r_" + name)) + ext) for ext in DB_FILES}, name
 
 
+@pytest.mark.parametrize("threads", ["2", "5", "16"])
+def test_parallel_parse_equals_serial(exe, tmp_path, threads, monkeypatch):
+    """plain files are parsed by all threads on stretches of the file whose starts are guessed and then confirmed by the parser of
+    the stretch in front (host/ingest.cpp: parsePlainParallel); forced here on small files: whatever the guesses hit, the DB is the serial one"""
+    fq, seqs = example_fastq(tmp_path)
+    fa = tricky_fasta(tmp_path)
+    want = json.load(open(os.path.join(GOLD, "example", "createdb_digests.json")))
+    monkeypatch.setenv("CDM_INGEST_PAR_MIN", "1")
+    monkeypatch.setenv("CDM_TIMING", "1")
+    r = subprocess.run([exe, "createdb", fq, str(tmp_path / "p"), "--shuffle", "1", "--threads", threads], capture_output=True, text=True)
+    assert r.returncode == 0 and "parsed by all threads" in r.stderr            # (well-formed four-line FASTQ: the parallel path holds)
+    monkeypatch.delenv("CDM_INGEST_PAR_MIN")
+    run(exe, "createdb", fq, str(tmp_path / "s"), "--shuffle", "1", "--threads", threads)
+    assert {x: digest(str(tmp_path / "p") + x) for x in DB_FILES} == {x: digest(str(tmp_path / "s") + x) for x in DB_FILES}
+    monkeypatch.setenv("CDM_INGEST_PAR_MIN", "1")
+    for p in odd_inputs(tmp_path) + [fa]:
+        name = os.path.basename(p)
+        run(exe, "createdb", p, str(tmp_path / ("m_" + name)), "--shuffle", "0", "--dbtype", "2", "--threads", threads)
+        if name in want["odd"]:
+            assert {ext: digest(str(tmp_path / ("m_" + name)) + ext) for ext in DB_FILES} == want["odd"][name], name
+
+
 def test_createdb_rejects_an_entry_without_a_name(exe, tmp_path):
     """a '>' followed by white space is an entry with an empty name: "Fasta entry N is invalid" and a non-zero exit (createdb.cpp:154-157)"""
     p = str(tmp_path / "bad.fa")
