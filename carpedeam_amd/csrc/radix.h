@@ -26,6 +26,10 @@ namespace rx {
 #endif
 constexpr int NT = CDM_RX_NT, WAVES = NT / 64, IPT = CDM_RX_IPT, TILE = NT * IPT, BITS = 9, BINS = 1 << BITS, MAXPASS = 8;
 static_assert(NT >= BINS && TILE <= 65536, "radix pass geometry");
+#ifndef CDM_RX_LB
+#define CDM_RX_LB 4
+#endif
+constexpr int LB = CDM_RX_LB;
 constexpr unsigned long long ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = (1ull << 62) - 1ull;
 
 struct NoValue {};      // V = NoValue: keys only
@@ -120,38 +124,23 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
         pos[j] = (uint16_t) (before + rank);
     }
     __syncthreads();
-    // ---- per digit (thread = digit): the waves in front, the digits in front (tile), the tiles in front (look-back)
-    {
-        const bool isDigit = tid < BINS;
-        uint32_t run = 0;
-        if (isDigit) {
+    // ---- per digit (thread = digit): the waves in front, the digits in front (tile); the tile's count is published at once
+    const bool isDigit = tid < BINS;
+    uint32_t run = 0;
+    if (isDigit) {
 #pragma unroll
-            for (int w = 0; w < WAVES; w++) { const uint32_t c = sCnt[w][tid]; sCnt[w][tid] = (uint16_t) run; run += c; }
-        }
-        uint32_t tot;
-        const uint32_t ex = cdm_block_excl_sum<uint32_t>(run, tot);
-        if (isDigit) sTileOff[tid] = (uint16_t) ex;
-        unsigned long long *st = a.status + tile * BINS + tid;
-        unsigned long long exclG = 0;
-        if (!isDigit) {}
-        else if (tile == 0) __hip_atomic_store(st, ST_PREFIX | (unsigned long long) run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else {
-            __hip_atomic_store(st, ST_AGG | (unsigned long long) run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long *q = st - BINS;
-            while (true) {
-                unsigned long long v;
-                do { v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 62) == 0ull);
-                exclG += v & ST_MASK;
-                if ((v >> 62) == 2ull) break;
-                q -= BINS;
-            }
-            __hip_atomic_store(st, ST_PREFIX | (exclG + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (isDigit) sGlobal[tid] = a.digitBase[tid] + exclG - ex;       // output position of the pair at exchange slot p with this digit: sGlobal + p
+        for (int w = 0; w < WAVES; w++) { const uint32_t c = sCnt[w][tid]; sCnt[w][tid] = (uint16_t) run; run += c; }
+    }
+    uint32_t tot;
+    const uint32_t ex = cdm_block_excl_sum<uint32_t>(run, tot);
+    unsigned long long *st = a.status + tile * BINS + tid;
+    if (isDigit) {
+        sTileOff[tid] = (uint16_t) ex;
+        __hip_atomic_store(st, (tile == 0 ? ST_PREFIX : ST_AGG) | (unsigned long long) run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     K *sK = reinterpret_cast<K *>(sBuf);
-    // ---- the keys through the exchange buffer: slot = digits in front + waves in front + rank; then runs of consecutive addresses
+    // ---- the keys into the exchange buffer: slot = digits in front + waves in front + rank (needs nothing of the other tiles)
 #pragma unroll
     for (int j = 0; j < IPT; j++) {
         if (w0 + 64 * j < items) {
@@ -159,6 +148,32 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
             pos[j] = (uint16_t) ((uint32_t) sTileOff[d] + (uint32_t) sCnt[wave][d] + (uint32_t) pos[j]);
             sK[pos[j]] = key[j];
         }
+    }
+    // ---- the tiles in front: chained scan with decoupled look-back, after the exchange so that the tiles in front had that time to
+    // publish their prefix; LB status words are fetched per round trip
+    if (isDigit) {
+        unsigned long long exclG = 0;
+        if (tile != 0) {
+            const unsigned long long *q = st - BINS;
+            uint64_t left = tile;
+            bool done = false;
+            while (!done) {
+                unsigned long long v[LB];
+#pragma unroll
+                for (int u = 0; u < LB; u++) v[u] = (uint64_t) u < left ? __hip_atomic_load(q - (size_t) u * BINS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_PREFIX;
+#pragma unroll
+                for (int u = 0; u < LB; u++) {
+                    if (done) break;
+                    unsigned long long x = v[u];
+                    while ((x >> 62) == 0ull) x = __hip_atomic_load(q - (size_t) u * BINS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    exclG += x & ST_MASK;
+                    if ((x >> 62) == 2ull) done = true;
+                }
+                q -= LB * (size_t) BINS; left = left > LB ? left - LB : 0;
+            }
+            __hip_atomic_store(st, ST_PREFIX | (exclG + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sGlobal[tid] = a.digitBase[tid] + exclG - ex;       // output position of the pair at exchange slot p with this digit: sGlobal + p
     }
     __syncthreads();
     uint16_t dig[IPT];

@@ -120,3 +120,19 @@ def write_dhigh_profiles(prefix, p5=P5_DHIGH, p3=P3_DHIGH):
         f.write(PROF_HEADER + "\n")
         for p in p3:
             f.write("\t".join(["0"] * 6 + [repr(p)] + ["0"] * 5) + "\n")
+
+
+def write_fastq_device(ctx, n, L, path, seed=1, chunk=10_000_000):
+    """The n synthetic reads of (L, seed) - generated on the device by cdm_seqdb_synth, the same reads generate() makes - as a FASTQ
+    file built in numpy buffers (no Python object per read: 50 M reads take seconds).  Every record is "@r\\nSEQ\\n+\\nIII...\\n"."""
+    row = np.frombuffer(b"@r\n" + b"N" * L + b"\n+\n" + b"I" * L + b"\n", np.uint8)
+    with open(path, "wb") as f:
+        for first in range(0, n, chunk):
+            m = min(chunk, n - first)
+            db = ctx.synth(m, L, L, seed, n_total=n, first=first)
+            tight = np.empty(m * (L + 1), np.uint8)            # "SEQ\n" per read (the library writes the whole range it is given)
+            db.download_into(tight, np.arange(m, dtype=np.uint64) * np.uint64(L + 1))
+            buf = np.tile(row, m).reshape(m, row.size)
+            buf[:, 3:3 + L] = tight.reshape(m, L + 1)[:, :L]
+            buf.tofile(f)
+            del db, buf, tight
