@@ -655,6 +655,7 @@ static void stageDone(cdm_ctx *ctx, int slot) {
     if (hipEventSynchronize(ctx->evS1) == hipSuccess) hipEventElapsedTime(&ctx->lastMs[slot], ctx->evS0, ctx->evS1);
 }
 extern "C" int cdm_correct(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out) {
+    if (alns) CDM_REFUSE_UNDEFINED_ALNS(alns, "cdm_correct");
     if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_correct: NULL argument"); return CDM_ERR_INVALID; }
     if (!ctx->haveDamage) { cdm_set_error("cdm_correct: call cdm_damage_load first"); return CDM_ERR_INVALID; }
     if (alns->n != db->n) { cdm_set_error("cdm_correct: alignment CSR has %llu queries, DB has %llu", (unsigned long long) alns->n, (unsigned long long) db->n); return CDM_ERR_INVALID; }
@@ -688,6 +689,7 @@ extern "C" int cdm_kmermatch(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_p
     return rc;
 }
 extern "C" int cdm_extend(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out, double *scores) {
+    if (alns) CDM_REFUSE_UNDEFINED_ALNS(alns, "cdm_extend");
     if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_extend: NULL argument"); return CDM_ERR_INVALID; }
     if (!ctx->haveDamage) { cdm_set_error("cdm_extend: call cdm_damage_load first"); return CDM_ERR_INVALID; }
     CDM_HIP(hipSetDevice(ctx->device));

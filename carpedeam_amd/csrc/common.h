@@ -116,6 +116,8 @@ struct MetaExt { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32
 struct MetaRaw { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) ((m[i].flags >> 2) & 1u); } };
 int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out);      // cdmFree the result
 
+// (the consumers of an alignment set call this first)
+#define CDM_REFUSE_UNDEFINED_ALNS(alns, who) do { if ((alns)->undefinedRecords) { cdm_set_error("%s: %llu identity record(s) carry the coordinates -1 (a sequence that scores 0 against itself: more than 40 %% N); the reference indexes the sequence with them here - undefined, not reproduced", who, (unsigned long long) (alns)->undefinedRecords); return CDM_ERR_UNSUPPORTED; } } while (0)
 struct HitRec { uint32_t target; int32_t score; int32_t diagonal; };  // == cdm_hit
 struct cdm_hits {
     uint64_t n = 0, count = 0;
@@ -126,6 +128,10 @@ struct cdm_hits {
 struct AlnRec { uint32_t target; int32_t rawScore; int32_t ident; int32_t qStart, qEnd, dbStart, dbEnd; float seqId; };  // == cdm_aln
 struct cdm_alns {
     uint64_t n = 0, count = 0;
+    // identity records of sequences that score 0 against themselves on every probed diagonal (more than 40 % N): written with the
+    // coordinates -1, as the reference writes them (rescore.hip).  The reference's downstream modules index the sequence with those
+    // coordinates (undefined; a segmentation fault in practice) - cdm_correct / cdm_extend / cdm_contig_merge refuse such a set.
+    uint64_t undefinedRecords = 0;
     uint64_t *off = nullptr;  // [n+1]
     AlnRec *rec = nullptr;    // [count]
     // by-product of cdm_rescore, which walks the very columns ancient_correction's RY gate looks at: purine/pyrimidine

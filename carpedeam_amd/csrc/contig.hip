@@ -97,6 +97,7 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
 
 extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float mergeSeqIdThr, cdm_seqdb **out) {
     if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_contig_merge: NULL argument"); return CDM_ERR_INVALID; }
+    CDM_REFUSE_UNDEFINED_ALNS(alns, "cdm_contig_merge");
     if (!ctx->haveDamage) { cdm_set_error("cdm_contig_merge: call cdm_damage_load first"); return CDM_ERR_INVALID; }
     if (alns->n != db->n) { cdm_set_error("cdm_contig_merge: alignment CSR / DB size mismatch"); return CDM_ERR_INVALID; }
     CDM_HIP(hipSetDevice(ctx->device));

@@ -34,31 +34,31 @@ struct Res {            // Matcher::result_t, the fields this module uses (M/ali
     float lgBeta = 0, lgAlphaBeta = 0;
     void cacheTerms() { const float mm = alnLengthCons - deamMatch, alpha = mm + 1, beta = deamMatch + 1; lgBeta = lgammaQuiet(beta); lgAlphaBeta = lgammaQuiet(alpha + beta); }
 };
-// ancientContigsResults.cpp:25-70 - arithmetic and overloads as there (`using namespace std` is in force in the reference:
-// lgamma / log of float arguments are the float functions)
+// The queue's order (ancientContigsResults.cpp:25-70): "is x a worse overlap than y?".  Every record stands for a Beta posterior over
+// its mismatch rate - mismatches + 1 and damage-aware matches + 1 as the two shape parameters - and x counts as worse when the
+// probability that x's rate lies below y's, a finite series in the shape parameters, is under 0.45; between 0.45 and 0.55 the
+// shorter consensus overlap loses and equal ones count as worse too - which is why this is no strict weak ordering and the order
+// it produces belongs to libstdc++'s heap.  The arithmetic keeps the reference's types term by term, because its last bits decide:
+// shapes and their sums in float (`using namespace std` makes lgamma / log of a float the float functions), the series in double,
+// the summation index a size_t that is ADDED to a float before the float log is taken.
 thread_local unsigned long long tlCompares = 0, tlSeriesTerms = 0;     // CDM_TIMING statistics
 struct CompareByScoreContigs {
-    bool operator()(const Res &r1, const Res &r2) const {
+    static float mismatches(const Res &r) { return r.alnLengthCons - r.deamMatch; }
+    bool operator()(const Res &x, const Res &y) const {
         tlCompares++;
-        float mm_count1 = r1.alnLengthCons - r1.deamMatch;
-        float mm_count2 = r2.alnLengthCons - r2.deamMatch;
-        float alpha1 = mm_count1 + 1;
-        float alpha2 = mm_count2 + 1;
-        float beta1 = r1.deamMatch + 1;
-        float beta2 = r2.deamMatch + 1;
-        double log_c = (lgammaQuiet(beta1 + beta2) + r1.lgAlphaBeta) - (lgammaQuiet(alpha1 + beta1 + beta2) + r1.lgBeta);       // (= lgamma(alpha1 + beta1), lgamma(beta1))
-        double log_r = 0.0;
-        double p = 0.0;
-        for (size_t idx = 0; idx < alpha2; idx++) {
+        const float xMis = mismatches(x) + 1, yMis = mismatches(y) + 1;         // first shape parameter of either posterior
+        const float xHit = x.deamMatch + 1, yHit = y.deamMatch + 1;             // second
+        // log B(xMis + 0, xHit + yHit) - log B(xMis, xHit) written as four lgamma values; the two that depend on x alone are cached
+        const double logScale = (lgammaQuiet(xHit + yHit) + x.lgAlphaBeta) - (lgammaQuiet(xMis + xHit + yHit) + x.lgBeta);
+        double logTerm = 0.0, below = 0.0;
+        for (size_t k = 0; k < yMis; k++) {
             tlSeriesTerms++;
-            p += std::exp(log_r + log_c);
-            log_r = std::log(alpha1 + idx) + std::log(beta2 + idx) - (std::log(idx + 1) + std::log(idx + alpha1 + beta1 + beta2)) + log_r;
+            below += std::exp(logTerm + logScale);
+            logTerm = std::log(xMis + k) + std::log(yHit + k) - (std::log(k + 1) + std::log(k + xMis + xHit + yHit)) + logTerm;
         }
-        if (p < 0.45) return true;
-        if (p > 0.55) return false;
-        if (r1.alnLengthCons < r2.alnLengthCons) return true;
-        if (r1.alnLengthCons > r2.alnLengthCons) return false;
-        return true;
+        if (below < 0.45) return true;
+        if (below > 0.55) return false;
+        return !(x.alnLengthCons > y.alnLengthCons);
     }
 };
 typedef std::priority_queue<Res, std::vector<Res>, CompareByScoreContigs> Queue;
@@ -91,21 +91,22 @@ std::string revComp(const char *s, size_t n) {
     for (size_t i = 0; i < n; i++) r[i] = tab.t[(unsigned char) s[n - 1 - i]];
     return r;
 }
-// deamMatches (nuclassembleUtil.cpp:1009-1044)
-double deamMatches(unsigned alnLength, unsigned scoreAln, double matchLik) {
-    const double logAdjustmentConstant = std::log(1.4e-9);
-    unsigned maxLength = 1e5;
-    auto logPower = [logAdjustmentConstant](unsigned length) { return logAdjustmentConstant - 3.0 * std::log(length); };
-    double logMin = logPower(10);
-    double logMax = logPower(maxLength);
-    double logLength = logPower(std::min(alnLength, maxLength));
-    double fractionLength = (static_cast<double>(std::abs(logLength) - std::abs(logMax))) / static_cast<double>((std::abs(logMin) - std::abs(logMax)));
-    double priorAln = 1 - fractionLength;
-    double pMatch = 0.5f * ((((static_cast<double>(scoreAln) + 3.0f * alnLength) / 5.0f) + 0.9f) / (alnLength + 1)) + 0.5f * priorAln;
-    double LikNoMatch = 1 - pMatch;
-    double oddsRatio = LikNoMatch / matchLik;
-    double odds = (1 - pMatch) / pMatch;
-    return 1 / (1 + oddsRatio * odds);
+// What one C->T / G->A column is worth as a match (deamMatches, nuclassembleUtil.cpp:1009-1044): the posterior odds that the column
+// is damage rather than a true mismatch.  The prior for "the two sequences match here" mixes the overlap's own match rate with a
+// length prior that falls off as 1.4e-9 / length^3 between 10 and 1e5 letters (in logs); the likelihood of the observed letter
+// under damage comes from the damage matrix.  Float literals and double variables alternate exactly as in the reference.
+double deamMatches(unsigned overlap, unsigned score, double damageLik) {
+    const double logConst = std::log(1.4e-9);
+    const unsigned longest = 1e5;
+    auto logPrior = [logConst](unsigned len) { return logConst - 3.0 * std::log(len); };
+    const double atShortest = logPrior(10), atLongest = logPrior(longest), here = logPrior(std::min(overlap, longest));
+    const double shareOfRange = (static_cast<double>(std::abs(here) - std::abs(atLongest))) / static_cast<double>((std::abs(atShortest) - std::abs(atLongest)));
+    const double lengthPrior = 1 - shareOfRange;
+    const double pMatch = 0.5f * ((((static_cast<double>(score) + 3.0f * overlap) / 5.0f) + 0.9f) / (overlap + 1)) + 0.5f * lengthPrior;
+    const double pMismatch = 1 - pMatch;
+    const double likelihoodRatio = pMismatch / damageLik;
+    const double priorOdds = (1 - pMatch) / pMatch;
+    return 1 / (1 + likelihoodRatio * priorOdds);
 }
 // selectNuclFragmentToExtendContigs (:73-91)
 bool selectFragment(Queue &q, uint32_t queryKey, Res &out) {

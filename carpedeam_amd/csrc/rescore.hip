@@ -31,6 +31,7 @@ struct RescoreArgs {
     AlnRec *tmp;               // [nHits] candidate records
     uint16_t *tmpRy;           // [nHits] purine/pyrimidine mismatches of the candidate (0xFFFF = not counted)
     uint8_t *valid;            // [nHits]
+    unsigned int *undef;       // [1] number of identity records written with the coordinates -1 (see k_rescore)
 };
 
 __device__ __forceinline__ bool canBeCovered(float covThr, int covMode, float ql, float tl) {   // M/commons/Util.cpp:533-550
@@ -133,7 +134,18 @@ __global__ __launch_bounds__(256) void k_rescore(RescoreArgs a, const uint32_t *
     Diag best; best.score = 0; best.diagLen = 0; best.dist = 0; best.diagonal = 0; best.ident = 0; best.ry = 0xFFFFu; best.any = false; best.first = 0; best.last = 0;
     for (unsigned d = 1; d <= 1 + tLen / 32768; d++) scoreDiagonal(a, qw, qLen, qN, isReverse, tw, tLen, tN, (int) (-(int) d * 65536 + (int) u), best, qRaw, tRaw);
     for (unsigned d = 0; d <= qLen / 65536; d++) scoreDiagonal(a, qw, qLen, qN, isReverse, tw, tLen, tN, (int) (d * 65536 + u), best, qRaw, tRaw);
-    if (!best.any) return;   // score 0 on every probe: E-value(0) never passes; (identity of an all-N sequence is not representable)
+    if (!best.any) {
+        // Score 0 on every probe: E-value(0) never passes, but the identity record is written whatever its score (:304).  The
+        // reference's alignment then still holds its constructor's values - start = end = -1, distance 0 (DistanceCalculator.h:50) - so
+        // the record carries the coordinates -1, an alignment length of 1 and, the one compared "column" being the byte in FRONT of
+        // the sequence in both operands (query and target are the same DB entry), identity 1/1.  rescorediagonal's own DB is that
+        // record; what indexes a sequence with it downstream is undefined in the reference, and refused here (cdm_alns::undefinedRecords).
+        if (!isIdentity) return;
+        AlnRec r; r.target = t; r.rawScore = 0; r.ident = 1; r.qStart = r.qEnd = r.dbStart = r.dbEnd = -1; r.seqId = 1.0f;
+        a.tmp[h] = r; a.tmpRy[h] = 0xFFFFu; a.valid[h] = 1;
+        atomicAdd(a.undef, 1u);
+        return;
+    }
     const int startPos = (int) best.first, endPos = (int) best.last;
     const int alnLen = (endPos - startPos) + 1;
     int qs, qe, ds, de;
@@ -204,6 +216,9 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     const uint32_t n = (uint32_t) db->n;
     const uint64_t nHits = hits->count;
     if (db->maxLen >= (1u << 30)) { cdm_set_error("cdm_rescore: sequence too long"); return CDM_ERR_UNSUPPORTED; }
+    DevBuf<unsigned int> undef;
+    if (!undef.alloc(2)) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
+    CDM_HIP(hipMemsetAsync(undef.p, 0, 8, s));
     DevBuf<uint32_t> dPresent, owner; DevBuf<int32_t> dMin; DevBuf<AlnRec> tmp; DevBuf<uint16_t> tmpRy; DevBuf<uint8_t> valid; DevBuf<uint64_t> cnt;
     if (!dPresent.alloc(db->maxLen + 1) || !dMin.alloc(db->maxLen + 1) || !owner.alloc(nHits) || !tmp.alloc(nHits) || !tmpRy.alloc(nHits) || !valid.alloc(nHits) || !cnt.alloc((size_t) n + 1)) {
         cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP;
@@ -229,7 +244,7 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     RescoreArgs a;
     a.woff.m = a.len.m = a.hasN.m = a.hasRaw.m = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.raw = db->raw; a.hoff = hits->off; a.hit = hits->rec;
     a.minScore = dMin.p; a.nHits = nHits; a.n = n; a.seqIdThr = par->seq_id_thr; a.covThr = par->cov_thr; a.covMode = par->cov_mode;
-    a.minAlnLen = par->min_aln_len; a.tmp = tmp.p; a.tmpRy = tmpRy.p; a.valid = valid.p;
+    a.minAlnLen = par->min_aln_len; a.tmp = tmp.p; a.tmpRy = tmpRy.p; a.valid = valid.p; a.undef = undef.p;
     hipEventRecord(ctx->ev0, s);
     if (nHits) hipLaunchKernelGGL(k_rescore, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, s, a, owner.p);
     hipEventRecord(ctx->ev1, s);
@@ -241,10 +256,11 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     cdmscan::ScanTemp scanTmp;
     CDM_HIP(hipMemsetAsync(cnt.p + n, 0, 8, s));
     if (int rc = cdmscan::exclusiveScan<uint64_t>(s, scanTmp, cnt.p, res->off, (size_t) n + 1)) return rc;
-    uint64_t total = 0;
+    uint64_t total = 0; unsigned int nUndef = 0;
     CDM_HIP(hipMemcpyAsync(&total, res->off + n, 8, hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipMemcpyAsync(&nUndef, undef.p, 4, hipMemcpyDeviceToHost, s));
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_rescore: kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
-    res->count = total;
+    res->count = total; res->undefinedRecords = nUndef;
     if (cdmMalloc(&res->rec, (total + 1) * sizeof(AlnRec)) != hipSuccess || cdmMalloc(&res->ryMism, (total + 1) * sizeof(uint16_t)) != hipSuccess) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
     res->rySerial = db->serial;
     if (nHits) hipLaunchKernelGGL(k_scatter, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, s, hits->off, (const uint32_t *) owner.p, valid.p, tmp.p, tmpRy.p, (uint64_t) nHits, res->off, res->rec, res->ryMism);

@@ -62,6 +62,9 @@ def allgather_packed(dist, buf, n, words, key_base, world):
     """buf: this rank's packed int32 buffer (packed_layout(n, words), or raw_layout's longer form).  Returns [(buf_r, n_r, words_r,
     key_base_r)] for all ranks.  Two collectives: the sizes (4 int64) and the data."""
     import torch
+    home = buf.device
+    if buf.is_cuda and dist.get_backend() == "gloo":       # gloo moves host memory: stage the buffer (tests: two ranks on one GPU)
+        buf = buf.cpu()
     meta = torch.tensor([int(n), int(words), int(key_base), int(buf.numel())], dtype=torch.int64, device=buf.device)
     metas = torch.zeros(world * 4, dtype=torch.int64, device=buf.device)
     dist.all_gather_into_tensor(metas, meta)
@@ -74,6 +77,8 @@ def allgather_packed(dist, buf, n, words, key_base, world):
         pad[: buf.numel()] = buf
     flat = torch.empty(world * mx, dtype=torch.int32, device=buf.device)      # ONE receive buffer, no per-rank tensor list
     dist.all_gather_into_tensor(flat, pad)
+    if flat.device != home:
+        flat = flat.to(home)
     return [(flat[r * mx: r * mx + m[3]], m[0], m[1], m[2]) for r, m in enumerate(metas)]
 
 

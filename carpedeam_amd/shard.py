@@ -111,12 +111,23 @@ class TorchComm:
     def __init__(self, dist, rank, world, device):
         self.dist, self.rank, self.world, self.device = dist, rank, world, device
         self.backend = dist.get_backend()
+        # gloo moves host memory: device tensors are staged through the host around every collective (two ranks sharing ONE GPU in
+        # the tests - RCCL wants a device per rank - and any deployment without RCCL)
+        self.stage = self.backend == "gloo" and getattr(device, "type", str(device)) == "cuda"
+
+    def _out(self, t):
+        return t.cpu() if self.stage and t.is_cuda else t
+
+    def _back(self, t):
+        return t.to(self.device) if self.stage else t
 
     def all_gather_array(self, a):
         """a: 1-D numpy array of the same length and dtype (<= 8 bytes per element) on every rank -> list of arrays"""
         import torch
         a = np.ascontiguousarray(a)
-        t = torch.from_numpy(a.astype(np.int64)).to(self.device)
+        t = torch.from_numpy(a.astype(np.int64))
+        if not self.stage:
+            t = t.to(self.device)
         parts = [torch.zeros_like(t) for _ in range(self.world)]
         self.dist.all_gather(parts, t)
         return [p.cpu().numpy().astype(a.dtype) for p in parts]
@@ -134,26 +145,28 @@ class TorchComm:
             self.dist.all_to_all_single(recv, send[: offsets[-1]].contiguous(), output_split_sizes=recv_counts, input_split_sizes=[int(c) for c in counts])
             return recv
         mx = max(1, max(int(c.sum()) for c in all_counts))
-        pad = torch.zeros(mx, dtype=send.dtype, device=send.device)
-        pad[: offsets[-1]] = send[: offsets[-1]]
+        src = self._out(send[: offsets[-1]])
+        pad = torch.zeros(mx, dtype=send.dtype, device=src.device)
+        pad[: offsets[-1]] = src
         bufs = [torch.zeros_like(pad) for _ in range(self.world)]
         self.dist.all_gather(bufs, pad)
         out = []
         for p in range(self.world):
             o = np.concatenate([[0], np.cumsum(all_counts[p])])
             out.append(bufs[p][int(o[self.rank]): int(o[self.rank + 1])])
-        return torch.cat(out)
+        return self._back(torch.cat(out))
 
     def all_gather_tensor(self, t):
         """variable-length 1-D tensors -> list of the ranks' tensors (sizes first, then ONE padded all_gather)"""
         import torch
         sizes = self.all_gather_array(np.array([t.numel()], np.int64))
         mx = max(1, max(int(s[0]) for s in sizes))
-        pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
-        pad[: t.numel()] = t
+        src = self._out(t)
+        pad = torch.zeros(mx, dtype=t.dtype, device=src.device)
+        pad[: t.numel()] = src
         bufs = [torch.empty_like(pad) for _ in range(self.world)]
         self.dist.all_gather(bufs, pad)
-        return [b[: int(s[0])] for b, s in zip(bufs, sizes)]
+        return [self._back(b[: int(s[0])]) for b, s in zip(bufs, sizes)]
 
 
 class ThreadComm:

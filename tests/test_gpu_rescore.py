@@ -64,3 +64,35 @@ def test_uploads_are_range_checked(ctx):
     with pytest.raises(capi.CdmError):
         ctx.upload_alns(db, off, np.array([(1, 10, 5, 0, 20, 0, 30, 1.0)], capi.ALN_DTYPE))      # spans differ: not ungapped
     ctx.upload_alns(db, off, np.array([(1, 10, 5, 0, 20, 5, 25, 1.0)], capi.ALN_DTYPE))
+
+
+def test_identity_record_of_a_sequence_that_scores_zero_against_itself(ctx, oracle_bin, tmp_path, dhigh_prefix):
+    """More than 40 % N: the self alignment scores 0 on every probed diagonal (N columns cost 3, the sum is clamped at 0), the E-value
+    gate fails, but the identity record is written whatever its score (rescorediagonal.cpp:304) - with the untouched constructor
+    values of the alignment: coordinates -1, identity 1.00.  The device writes that record (the oracle restates the reference and
+    writes it too); the modules that would index a sequence with it refuse the set (the reference faults there)."""
+    from carpedeam_amd import synth
+    seqs = synth.generate_strings(300, seed=4, mixed=(40, 120))
+    rng = np.random.default_rng(5)
+    heavy = [3, 77, 150, 299]
+    for i in heavy:                                   # half of the letters of a few reads become N
+        s = list(seqs[i])
+        for j in rng.choice(len(s), size=len(s) // 2 + 3, replace=False):
+            s[j] = "N"
+        seqs[i] = "".join(s)
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_seqdb(t("in"), seqs)
+    run_oracle(oracle_bin, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "2")
+    run_oracle(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref"), t("aln"), *R_FLAGS, "--threads", "2")
+    want = mmdb.read_db(t("aln"))
+    assert all(b"\t-1\t-1\t" in want[i][0] for i in heavy)        # (the input does reach the case)
+    db = ctx.upload_keyed_seqdb(mmdb.read_db(t("in")))
+    lens, keys, _ = db.meta()
+    off, rec = capi.parse_pref_db(mmdb.read_db(t("pref")), keys)
+    alns = ctx.rescore(db, ctx.upload_hits(db, off, rec))
+    aoff, arec = alns.download()
+    got = {k: (v, 0) for k, v in capi.alns_to_text(aoff, arec, keys, lens, db.residues).items()}
+    assert not diff_keys(got, want)
+    for stage in (lambda: ctx.correct(db, alns), lambda: ctx.extend(db, alns)):
+        with pytest.raises(capi.CdmError, match="coordinates -1"):
+            stage()
