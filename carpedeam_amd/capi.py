@@ -143,7 +143,7 @@ class SeqDb:
         self.ctx, self.h = ctx, handle
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:      # (at interpreter shutdown the module's globals are gone already)
             lib().cdm_seqdb_free(self.h)
             self.h = None
 
@@ -218,7 +218,7 @@ class _Csr:
         self.ctx, self.h, self.n = ctx, handle, n
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             getattr(lib(), self.free)(self.h)
             self.h = None
 
@@ -248,7 +248,7 @@ class KPart:
         self.ctx, self.h, self.db = ctx, handle, db
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib().cdm_kpart_free(self.h)
             self.h = None
 
@@ -291,7 +291,7 @@ class Ctx:
         self.h = h
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib().cdm_ctx_destroy(self.h)
             self.h = None
 
