@@ -572,6 +572,28 @@ extern "C" int cdm_seqdb_from_packed_ext(cdm_ctx *ctx, const void *codes, const 
 }
 
 // ------------------------------------------------------------------------------------------------ hits / alignments
+// fn(lo, hi) over [0, n) on a few host threads; with `weight` (n + 1 prefix sums) the ranges carry about the same weight each
+#include <thread>
+template <typename F>
+static void cdmHostParallel(uint64_t n, F fn, const uint64_t *weight = nullptr) {
+    unsigned T = std::thread::hardware_concurrency();
+    if (const char *e = getenv("OMP_NUM_THREADS")) { const int v = atoi(e); if (v > 0) T = (unsigned) v; }
+    T = std::max(1u, std::min(T, 16u));
+    if (n < 100000 || T == 1) { fn(0, n); return; }
+    std::vector<uint64_t> cut(T + 1, n);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; t++) {
+        if (!weight) { cut[t] = n * t / T; continue; }
+        const uint64_t want = (weight[n] + n) / T * t;
+        uint64_t lo = cut[t - 1], hi = n;
+        while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (weight[mid] + mid < want) lo = mid + 1; else hi = mid; }
+        cut[t] = lo;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back([&, t] { fn(cut[t], cut[t + 1]); });
+    fn(cut[0], cut[1]);
+    for (auto &x : th) x.join();
+}
 template <typename H, typename R>
 static int csr_upload(cdm_ctx *ctx, uint64_t n, const uint64_t *offsets, const R *recs, H **out) {
     CDM_HIP(hipSetDevice(ctx->device));
@@ -596,12 +618,20 @@ static int fetchLens(cdm_ctx *ctx, const cdm_seqdb *db, std::vector<uint32_t> &l
 extern "C" int cdm_hits_upload(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *offsets, const cdm_hit *hits, cdm_hits **out) {
     static_assert(sizeof(cdm_hit) == sizeof(HitRec), "layout");
     if (!ctx || !db || !offsets || !out || (offsets[db->n] && !hits)) { cdm_set_error("cdm_hits_upload: NULL argument"); return CDM_ERR_INVALID; }
-    for (uint64_t i = 0; i < offsets[db->n]; i++)
-        if (hits[i].target >= db->n || hits[i].diagonal < -32768 || hits[i].diagonal > 32767) {
+    {   // checked by several threads (a file of 10 M reads brings 37 M records)
+        const uint64_t total = offsets[db->n];
+        std::atomic<uint64_t> bad{UINT64_MAX};
+        cdmHostParallel(total, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t i = lo; i < hi; i++)
+                if (hits[i].target >= db->n || hits[i].diagonal < -32768 || hits[i].diagonal > 32767) { uint64_t cur = bad.load(); while (i < cur && !bad.compare_exchange_weak(cur, i)) {} return; }
+        });
+        const uint64_t i = bad.load();
+        if (i != UINT64_MAX) {
             cdm_set_error("cdm_hits_upload: record %llu is out of range (target %u of %llu sequences, diagonal %d)", (unsigned long long) i, hits[i].target,
                           (unsigned long long) db->n, hits[i].diagonal);
             return CDM_ERR_INVALID;
         }
+    }
     return csr_upload<cdm_hits, HitRec>(ctx, db->n, offsets, reinterpret_cast<const HitRec *>(hits), out);
 }
 extern "C" uint64_t cdm_hits_count(const cdm_hits *h) { return h->count; }
@@ -622,18 +652,27 @@ extern "C" int cdm_alns_upload(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t
         std::vector<uint32_t> lens;
         int rc = fetchLens(ctx, db, lens);
         if (rc) return rc;
-        for (uint64_t q = 0; q < db->n; q++)
-            for (uint64_t i = offsets[q]; i < offsets[q + 1] && offsets[q + 1] >= offsets[q]; i++) {
+        std::atomic<uint64_t> badQ{UINT64_MAX};
+        auto okRec = [&](uint64_t q, const cdm_aln &r) {
+            return r.target < db->n && r.q_start >= 0 && r.q_end >= 0 && (uint32_t) r.q_start < lens[q] && (uint32_t) r.q_end < lens[q] &&
+                   r.db_start >= 0 && r.db_end >= r.db_start && (uint32_t) r.db_end < lens[r.target < db->n ? r.target : 0] &&
+                   abs(r.q_end - r.q_start) == r.db_end - r.db_start;   // ungapped: both spans have the same length
+        };
+        cdmHostParallel(db->n, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t q = lo; q < hi; q++)
+                for (uint64_t i = offsets[q]; i < offsets[q + 1] && offsets[q + 1] >= offsets[q]; i++)
+                    if (!okRec(q, alns[i])) { uint64_t cur = badQ.load(); while (q < cur && !badQ.compare_exchange_weak(cur, q)) {} return; }
+        }, offsets);
+        if (badQ.load() != UINT64_MAX) {
+            const uint64_t q = badQ.load();
+            for (uint64_t i = offsets[q]; i < offsets[q + 1]; i++) {
                 const cdm_aln &r = alns[i];
-                const bool ok = r.target < db->n && r.q_start >= 0 && r.q_end >= 0 && (uint32_t) r.q_start < lens[q] && (uint32_t) r.q_end < lens[q] &&
-                                r.db_start >= 0 && r.db_end >= r.db_start && (uint32_t) r.db_end < lens[r.target < db->n ? r.target : 0] &&
-                                abs(r.q_end - r.q_start) == r.db_end - r.db_start;   // ungapped: both spans have the same length
-                if (!ok) {
-                    cdm_set_error("cdm_alns_upload: alignment record %llu of query %llu does not fit the sequence DB (target %u, q %d-%d of %u, db %d-%d)",
-                                  (unsigned long long) i, (unsigned long long) q, r.target, r.q_start, r.q_end, lens[q], r.db_start, r.db_end);
-                    return CDM_ERR_INVALID;
-                }
+                if (okRec(q, r)) continue;
+                cdm_set_error("cdm_alns_upload: alignment record %llu of query %llu does not fit the sequence DB (target %u, q %d-%d of %u, db %d-%d)",
+                              (unsigned long long) i, (unsigned long long) q, r.target, r.q_start, r.q_end, lens[q], r.db_start, r.db_end);
+                return CDM_ERR_INVALID;
             }
+        }
     }
     return csr_upload<cdm_alns, AlnRec>(ctx, db->n, offsets, reinterpret_cast<const AlnRec *>(alns), out);
 }

@@ -22,6 +22,7 @@
 #include <unistd.h>
 #include <sys/stat.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "carpedeam_hip.h"
@@ -33,10 +34,12 @@ int convert2fastaModule(const std::string &dbPath, const std::string &outPath, s
 int createhdbModule(const std::string &seqPath, const std::string &cyclePath, const std::string &outPath, std::string *err);
 
 namespace {
-[[noreturn]] void die(const std::string &msg) { fprintf(stderr, "%s\n", msg.c_str()); exit(EXIT_FAILURE); }
+std::thread *g_deviceThread = NULL;          // a module's device start-up running beside the main thread (DeviceStart): joined before any exit
+void quiesce() { if (g_deviceThread && g_deviceThread->joinable() && g_deviceThread->get_id() != std::this_thread::get_id()) g_deviceThread->join(); }
+[[noreturn]] void die(const std::string &msg) { quiesce(); fprintf(stderr, "%s\n", msg.c_str()); exit(EXIT_FAILURE); }
 // a call the device path does not implement, found before any work was done: status 77 tells the front end (host/front.c) that the
 // reference binary - if the deployment has one - may take this call instead
-[[noreturn]] void unsupported(const std::string &msg) { fprintf(stderr, "%s\n", msg.c_str()); exit(77); }
+[[noreturn]] void unsupported(const std::string &msg) { quiesce(); fprintf(stderr, "%s\n", msg.c_str()); exit(77); }
 void check(int rc, const char *what) { if (rc != CDM_OK) die(std::string(what) + ": " + cdm_last_error()); }
 
 struct Args { std::vector<std::string> pos; std::map<std::string, std::string> flag; };
@@ -109,6 +112,32 @@ cdm_ctx *openCtx() {
     check(cdm_ctx_create(dev ? atoi(dev) : 0, &ctx), "Can not initialise the MI355X device");
     return ctx;
 }
+// The device side of a module's start - runtime initialisation and context (0.1-0.2 s), damage tables, sequence upload - in a thread
+// of its own, while the main thread maps and parses the module's text DBs.  Errors are kept and raised by join() on the main thread.
+struct DeviceStart {
+    std::thread th; cdm_ctx *ctx = NULL; cdm_seqdb *db = NULL;
+    std::string err; int code = 0;
+    void fail(int c, const std::string &m) { code = c; err = m; }
+    void begin(const MmDb *seq, const std::string *damagePrefix) {
+        th = std::thread([this, seq, damagePrefix] {
+            const char *dev = getenv("CARPEDEAM_DEVICE");
+            if (cdm_ctx_create(dev ? atoi(dev) : 0, &ctx) != CDM_OK) return fail(EXIT_FAILURE, std::string("Can not initialise the MI355X device: ") + cdm_last_error());
+            if (damagePrefix && cdm_damage_load(ctx, damagePrefix->c_str()) != CDM_OK) return fail(EXIT_FAILURE, std::string("Profile not 12 fields: ") + cdm_last_error());
+            if (!seq) return;
+            if ((seq->dbtype & 0x7FFFFFFF) != 1) return fail(77, "The MI355X path works on nucleotide sequence DBs only (dbtype " + std::to_string(seq->dbtype & 0x7FFFFFFF) + " given)");
+            std::vector<uint32_t> lens(seq->size());
+            for (size_t i = 0; i < seq->size(); i++) lens[i] = seq->len[i] >= 2 ? (uint32_t) (seq->len[i] - 2) : 0;   // DBReader::getSeqLen
+            if (cdm_seqdb_upload(ctx, seq->data(), seq->off.data(), lens.data(), seq->key.data(), seq->ext.data(), seq->size(), &db) != CDM_OK)
+                return fail(EXIT_FAILURE, std::string("Can not load the sequence DB: ") + cdm_last_error());
+        });
+        g_deviceThread = &th;
+    }
+    void join() {
+        if (th.joinable()) th.join();
+        g_deviceThread = NULL;
+        if (code) { fprintf(stderr, "%s\n", err.c_str()); exit(code); }
+    }
+};
 cdm_seqdb *uploadSeqDb(cdm_ctx *ctx, const MmDb &db) {
     if ((db.dbtype & 0x7FFFFFFF) != 1) unsupported("The MI355X path works on nucleotide sequence DBs only (dbtype " + std::to_string(db.dbtype & 0x7FFFFFFF) + " given)");
     std::vector<uint32_t> lens(db.size());
@@ -365,9 +394,10 @@ int kmermatcher(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam kmermatcher <i:sequenceDB> <o:prefilterDB>");
     checkFlags("kmermatcher", a, KMERMATCHER_FLAGS);
     Laps laps;
+    DeviceStart dev; dev.begin(NULL, NULL);                 // (the context comes up while the DB is mapped and its index parsed)
     MmDb seq; std::string err; if (!seq.load(a.pos[0], &err)) die(err);
     laps.lap("DB files mapped");
-    cdm_ctx *ctx = openCtx(); laps.lap("device context");
+    dev.join(); cdm_ctx *ctx = dev.ctx; laps.lap("device context");
     cdm_seqdb *db = uploadSeqDb(ctx, seq); laps.lap("sequences up");
     cdm_kmer_params p;
     p.kmer_size = (int) iflag(a, "-k", 15); p.kmers_per_seq = (int) iflag(a, "--kmer-per-seq", 21); p.kmers_per_seq_scale = fflag(a, "--kmer-per-seq-scale", 0.2f);
@@ -392,13 +422,15 @@ int rescorediagonal(Args &a) {
     checkFlags("rescorediagonal", a, RESCORE_FLAGS);
     if (a.pos[0] != a.pos[1]) unsupported("rescorediagonal: query and target DB must be the same on the MI355X path");
     if (!a.flag.count("--rescore-mode")) unsupported("rescorediagonal: --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
-    MmDb seq, pref; std::string err; if (!seq.load(a.pos[1], &err) || !pref.load(a.pos[2], &err)) die(err);
-    Laps laps; laps.lap("DB files mapped");
-    cdm_ctx *ctx = openCtx(); laps.lap("device context");
-    cdm_seqdb *db = uploadSeqDb(ctx, seq); laps.lap("sequences up");
+    Laps laps;
+    MmDb seq, pref; std::string err; if (!seq.load(a.pos[1], &err)) die(err);
+    DeviceStart dev; dev.begin(&seq, NULL);                 // context + sequence upload while the prefilter text is mapped and parsed
+    if (!pref.load(a.pos[2], &err)) die(err);
+    laps.lap("DB files mapped");
     HVec<uint64_t> off; HVec<cdm_hit> rec;
     parsePrefDb(pref, seq, off, rec);
     laps.lap("prefilter text parsed");
+    dev.join(); cdm_ctx *ctx = dev.ctx; cdm_seqdb *db = dev.db; laps.lap("(device context, sequences up: waited)");
     cdm_hits *hits = NULL; cdm_alns *alns = NULL;
     check(cdm_hits_upload(ctx, db, off.data(), rec.data(), &hits), "upload");
     cdm_rescore_params p;
@@ -423,13 +455,15 @@ int ancientModule(Args &a, int mode) {      // 0 ancient_correction, 1 ancient_r
     if (a.pos.size() < 3) die(std::string("Usage: carpedeam ") + name + " <i:sequenceDB> <i:alnResult> <o:reprSeqDB>");
     checkFlags(name, a, ANCIENT_FLAGS);
     if (mode >= 1 && !a.flag.count("--rescore-mode")) unsupported(std::string(name) + ": --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
-    MmDb seq, aln; std::string err; if (!seq.load(a.pos[0], &err) || !aln.load(a.pos[1], &err)) die(err);
-    Laps laps; laps.lap("DB files mapped");
-    cdm_ctx *ctx = openCtx(); laps.lap("device context");
-    check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");
-    cdm_seqdb *db = uploadSeqDb(ctx, seq); laps.lap("damage tables, sequences up");
+    Laps laps;
+    MmDb seq, aln; std::string err; if (!seq.load(a.pos[0], &err)) die(err);
+    const std::string damage = a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"] : "";
+    DeviceStart dev; dev.begin(&seq, &damage);              // context, damage tables, sequence upload while the alignment text is parsed
+    if (!aln.load(a.pos[1], &err)) die(err);
+    laps.lap("DB files mapped");
     HVec<uint64_t> off; HVec<cdm_aln> rec;
     parseAlnDb(aln, seq, off, rec); laps.lap("alignment text parsed");
+    dev.join(); cdm_ctx *ctx = dev.ctx; cdm_seqdb *db = dev.db; laps.lap("(device context, damage tables, sequences up: waited)");
     cdm_alns *alns = NULL; cdm_seqdb *out = NULL;
     check(cdm_alns_upload(ctx, db, off.data(), rec.data(), &alns), "upload");
     cdm_ancient_params p = ancientParams(a);

@@ -8,7 +8,7 @@ R="--rescore-mode 3 -e 0.001 --min-seq-id 0.9 --seq-id-mode 0 --sort-results 0 -
 $bin kmermatcher $d/in $d/pref $K --threads $th 2>/dev/null
 $bin rescorediagonal $d/in $d/in $d/pref $d/aln $R --threads $th 2>/dev/null
 mkdir -p $d/o
-for v in new; do for t in 16 4 1; do echo "== $v, $t threads"; scripts/_hc_$v $d/in $d/pref $d/aln $d/o $t; done; done
+for rep in 1 2; do echo "== mapped writes, 16 threads"; scripts/_hc_new $d/in $d/pref $d/aln $d/o 16 | grep write; echo "== pwrite, 16 threads"; CDM_NO_MMAP_WRITE=1 scripts/_hc_new $d/in $d/pref $d/aln $d/o 16 | grep write; done
 echo "== new without MADV_HUGEPAGE, 16 threads"; CDM_NO_HUGEPAGE=1 scripts/_hc_new $d/in $d/pref $d/aln $d/o 16
 cmp $d/o/pref $d/pref && cmp $d/o/pref.index $d/pref.index && echo "re-serialised DBs identical"
 rm -rf $d
