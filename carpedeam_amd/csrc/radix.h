@@ -27,7 +27,7 @@ namespace rx {
 constexpr int NT = CDM_RX_NT, WAVES = NT / 64, IPT = CDM_RX_IPT, TILE = NT * IPT, BITS = 9, BINS = 1 << BITS, MAXPASS = 8;
 static_assert(NT >= BINS && TILE <= 65536, "radix pass geometry");
 #ifndef CDM_RX_LB
-#define CDM_RX_LB 4
+#define CDM_RX_LB 2
 #endif
 constexpr int LB = CDM_RX_LB;
 constexpr unsigned long long ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = (1ull << 62) - 1ull;

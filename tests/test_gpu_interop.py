@@ -84,13 +84,17 @@ def test_whole_workflow_against_reference_object_code():
     runs kept under profiles/), hence the small allowance; anything systematic shows up as hundreds."""
     import re
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "loop_vs_ref.py"), "20000", "4"], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "loop_vs_ref.py"), "20000", "4", "twice"], capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
     m = re.search(r"result (\d+) sequences, (\d+) residues, \d+ circular set aside; (\d+) sequences differ", r.stdout)
-    assert m, r.stdout[-800:]
+    m2 = re.search(r"the reference against its own second run: (\d+) sequences differ; MI355X against the second run: (\d+)", r.stdout)
+    assert m and m2, r.stdout[-800:]
     assert int(m.group(1)) == 20000 and int(m.group(2)) > 4_000_000     # (the contigs grew: 20 000 reads are 2.1 M letters)
-    assert int(m.group(3)) <= 10
-
+    # two runs of the reference itself differ by `spread` sequences (one strand tie early on grows into some twenty by iteration 12); the
+    # device result has to lie as close to one of them as they lie to each other.  The zero-tolerance check of the same twelve
+    # iterations is test_twelve_iterations_against_the_oracle_chain below.
+    d_first, spread, d_second = int(m.group(3)), int(m2.group(1)), int(m2.group(2))
+    assert min(d_first, d_second) <= max(10, spread), (d_first, d_second, spread)
 
 def loop_vs(*args):
     import re
