@@ -26,6 +26,7 @@
 #include "bucket.h"
 #include "scan.h"
 #include "runsort.h"
+#include "aggvote.h"
 #include "radix.h"
 
 namespace {
@@ -1169,6 +1170,9 @@ struct KmerJob : KmerJobBase {
     DevBuf<uint64_t> runsOut, runsTmp;       // sort 2 "check" mode: the run-based result next to the radix one
     DevBuf<uint64_t> recvA, recvB; DevBuf<uint32_t> contBuf;      // multi-GPU second half: received keys / their sorted form, the continuation list
     const uint64_t *sorted2M = nullptr; unsigned long long nGroupM = 0;
+    // the aggregated form of sort 2's result (aggvote.h): entries per representative segment; set when sort2 took that way
+    bool haveEntries = false; uint64_t nSegM = 0;
+    DevBuf<uint32_t> agSegOfRec, agSegRep, agEntCnt, agPending; DevBuf<unsigned long long> agSegFirstRec, agEntOff, agPerRep, agCursor; DevBuf<aggv::Ent> agEnt; DevBuf<unsigned int> agFlags;
     float msSort1 = 0;
     KmerJob(cdm_ctx *c, const cdm_seqdb *d, const cdm_kmer_params *p) { ctx = c; db = d; parCopy = *p; par = &parCopy; }
 int phaseA() override {
@@ -1500,7 +1504,18 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
             // (the expansion of the records - k_run_gather - is not run as a pass of its own: the unit sorter expands its records
             // into LDS, the few longer segments are expanded on demand)
             if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: sort 2 (records) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
-            if (segmentedSortKeys(s, ctx->cuCount, sortedOut, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, rk.current(), dst.p, nRec, gk,
+            // Default on one device: the representatives' tuples are aggregated, not sorted (aggvote.h).  The tuple path below stays for
+            // the multi-GPU split (its ranks exchange heads of the sorted array), for keys too wide for the aggregation's sort word,
+            // under CDM_KMER_VOTE=tuples, and as the fallback when the entry buffer overflows.
+            const char *voteEnv = getenv("CDM_KMER_VOTE");
+            bool aggregated = ownBuffers && !sort2Check && !(voteEnv && !strcmp(voteEnv, "tuples")) && aggv::AG_ORD + idBits + diagBits + aggv::AG_IDX <= 64;
+            if (aggregated) {
+                int rc = aggregate(sortedOut, nGroup, rk.current(), (const uint64_t *) rv.current(), dst.p, nRec, gk, top2);
+                if (rc == CDM_ERR_UNSUPPORTED) aggregated = false;      // (entry buffer too small for this input: the tuple path)
+                else if (rc) return rc;
+            }
+            haveEntries = aggregated;
+            if (!aggregated && segmentedSortKeys(s, ctx->cuCount, sortedOut, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, rk.current(), dst.p, nRec, gk,
                                   (const uint64_t *) rv.current()) != CDM_OK) {
                 cdm_set_error("cdm_kmermatch: segmented sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP;
             }
@@ -1545,8 +1560,91 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
     sorted2M = sorted2; nGroupM = nGroup;
     return CDM_OK;
 }
+// K4 on entries: the per-representative hit counts are known already (aggregate); offsets, self hits, then one thread per segment
+int voteEntries(cdm_hits **out) {
+    DevBuf<unsigned long long> perRepScan;
+    if (!perRepScan.alloc((size_t) n + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (vote)"); return CDM_ERR_HIP; }
+    cdmscan::ScanTemp st4a;
+    if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, st4a, agPerRep.p, perRepScan.p, (size_t) n + 1)) return rc;
+    cdm_hits *res = new cdm_hits(); res->n = n;
+    if (cdmMalloc(&res->off, ((size_t) n + 1) * 8) != hipSuccess) { delete res; cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    hipLaunchKernelGGL(k_offsets, dim3((n + 256) / 256), dim3(256), 0, s, perRepScan.p, n, res->off);
+    uint64_t total = 0;
+    hipMemcpyAsync(&total, res->off + n, 8, hipMemcpyDeviceToHost, s);
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: vote failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    res->count = total;
+    if (cdmMalloc(&res->rec, (total + 1) * sizeof(HitRec)) != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    hipLaunchKernelGGL(k_self, dim3((n + 255) / 256), dim3(256), 0, s, res->off, n, res->rec);
+    aggv::VoteEntArgs va; va.ent = agEnt.p; va.entOff = agEntOff.p; va.entCnt = agEntCnt.p; va.segRep = agSegRep.p; va.nSeg = nSegM; va.hitOff = res->off; va.stale = staleBuf.p; va.diagBias = diagBias;
+    if (nSegM) hipLaunchKernelGGL(aggv::k_vote_entries<HitRec>, dim3((unsigned) ((nSegM + 255) / 256)), dim3(256), 0, s, va, res->rec);
+    { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: placing hits failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    float msSort2 = 0; hipEventElapsedTime(&msSort2, ctx->ev0, ctx->ev1);
+    ctx->lastMs[2] = msSort1 + msSort2; ctx->lastMs[5] = msSort1; ctx->lastMs[6] = msSort2;
+    hipEventElapsedTime(&ctx->lastMs[7], ctx->ev2, ctx->ev3);
+    agEnt.free(); agEntOff.free(); agEntCnt.free(); agSegRep.free(); agSegOfRec.free(); agSegFirstRec.free(); agPerRep.free(); agPending.free();
+    *out = res;
+    return CDM_OK;
+}
+// sort 2 on aggregated tuples (aggvote.h): segments, k_unit_agg in k_unit_sort's place, the tuple sorters for what no table holds,
+// k_rle_segment for those.  CDM_ERR_UNSUPPORTED: the entry buffer was too small (the caller takes the tuple path).
+static void aggUnitHook(hipStream_t st, unsigned int grid, const unsigned long long *list, const unsigned int *count, bucket::BigList hard, void *user) {
+    aggv::AggArgs *u = reinterpret_cast<aggv::AggArgs *>(user);
+    aggv::AggArgs a = *u;
+    a.list = list; a.count = count; a.hard = hard;
+    const int cls = (int) (u->nextClass++ % runsort::U_CLASSES);       // (called once per size class, smallest first)
+    if (cls == 0) hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[0] / 256>), dim3(grid), dim3(256), 0, st, a);
+    else if (cls == 1) hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[1] / 256>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[2] / 256>), dim3(grid), dim3(256), 0, st, a);
+}
+int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *recRep, const uint64_t *recVal, const unsigned long long *dst, unsigned long long nRec,
+              const uint64_t *gk, int top2) {
+    using namespace aggv;
+    cdmscan::ScanTemp st;
+    unsigned long long capEnt = nGroup / 6 + (4ull << 20);
+    if (const char *e = getenv("CDM_AGG_CAP")) capEnt = strtoull(e, nullptr, 10);      // tests: force the overflow fallback
+    if (!agSegOfRec.alloc(nRec + 2) || !agPerRep.alloc((size_t) n + 1) || !agCursor.alloc(2) || !agFlags.alloc(4)) { cdm_set_error("cdm_kmermatch: out of device memory (aggregation)"); return CDM_ERR_HIP; }
+    hipLaunchKernelGGL(k_seg_flags, dim3((unsigned) ((nRec + 1024) / 1024)), dim3(1024), 0, s, recRep, (uint64_t) nRec, agSegOfRec.p);
+    if (int rc = cdmscan::exclusiveScan<uint32_t>(s, st, agSegOfRec.p, agSegOfRec.p, (size_t) nRec + 1)) return rc;
+    uint32_t nSeg = 0;
+    hipMemcpyAsync(&nSeg, agSegOfRec.p + nRec, 4, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: aggregation (segments) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    if (!agSegRep.alloc(nSeg + 1) || !agSegFirstRec.alloc((size_t) nSeg + 2) || !agEntOff.alloc((size_t) nSeg + 1) || !agEntCnt.alloc((size_t) nSeg + 1) || !agPending.alloc((size_t) nSeg + 1) ||
+        !agEnt.alloc(capEnt + 1)) {
+        agEnt.free(); cdm_set_error("cdm_kmermatch: out of device memory (aggregation)"); return CDM_ERR_HIP;
+    }
+    hipLaunchKernelGGL(k_seg_fill, dim3((unsigned) ((nRec + 1024) / 1024)), dim3(1024), 0, s, recRep, (uint64_t) nRec, agSegOfRec.p, agSegRep.p, agSegFirstRec.p, agEntCnt.p);
+    hipMemsetAsync(agPerRep.p, 0, ((size_t) n + 1) * 8, s);
+    hipMemsetAsync(agCursor.p, 0, 16, s); hipMemsetAsync(agFlags.p, 0, 16, s);
+    AggArgs a;
+    a.keys = gk; a.recVal = recVal; a.dst = dst; a.nRec = nRec; a.segOfRec = agSegOfRec.p; a.segRep = agSegRep.p; a.segFirstRec = agSegFirstRec.p; a.nSeg = nSeg;
+    a.entOff = agEntOff.p; a.entCnt = agEntCnt.p; a.perRep = agPerRep.p; a.ent = agEnt.p; a.cursor = agCursor.p; a.cap = capEnt; a.overflow = agFlags.p;
+    a.maxD = AG_D;
+    if (const char *e = getenv("CDM_AGG_D")) { const long v = atol(e); if (v >= 1 && v <= AG_D) a.maxD = (uint32_t) v; }
+    a.repShift = (int) (idBits + diagBits + 1); a.diagBits = (int) diagBits; a.idBits = idBits; a.sorted = sortedOut; a.list = nullptr; a.count = nullptr; a.hard.list = nullptr; a.hard.cnt = nullptr;
+    if (runsort::segmentedSortKeys(s, ctx->cuCount, sortedOut, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, recRep, dst, nRec, gk, recVal, aggUnitHook, &a) != CDM_OK) {
+        cdm_set_error("cdm_kmermatch: segmented sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP;
+    }
+    // the segments the tuple sorters finished (deep pile-ups, units with too many distinct triples)
+    hipLaunchKernelGGL(k_pending_list, dim3((unsigned) (((uint64_t) nSeg + 1023) / 1024)), dim3(1024), 0, s, (const uint32_t *) agEntCnt.p, (uint64_t) nSeg, agPending.p, agFlags.p + 1);
+    unsigned int fl[4] = {0, 0, 0, 0};
+    hipMemcpyAsync(fl, agFlags.p, 16, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: aggregation failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    if (fl[1] && !fl[0]) {
+        hipLaunchKernelGGL(k_rle_segment, dim3(std::min<unsigned int>(fl[1], (unsigned int) ctx->cuCount * 16)), dim3(256), 0, s, a, (const uint32_t *) agPending.p, (const unsigned int *) (agFlags.p + 1));
+        hipMemcpyAsync(fl, agFlags.p, 16, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: aggregation (segments of the tuple sorters) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    }
+    unsigned long long used = 0;
+    hipMemcpy(&used, agCursor.p, 8, hipMemcpyDeviceToHost);
+    if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "aggregate: %llu group tuples, %u segments, %llu entries (room for %llu), %u segments through the tuple sorters%s\n", nGroup, nSeg, used, capEnt, fl[1],
+                                            fl[0] ? "; entry buffer overflow" : "");
+    if (fl[0]) { agEnt.free(); return CDM_ERR_UNSUPPORTED; }
+    nSegM = nSeg;
+    return CDM_OK;
+}
 // ---- K4: count hit-producing segments (per tile and per representative), scan, vote + place.  contDev: VoteArgs::cont
 int vote(const uint32_t *contDev, bool ownBuffers, cdm_hits **out) {
+    if (haveEntries) return voteEntries(out);
     const uint64_t *sorted2 = sorted2M; const unsigned long long nGroup = nGroupM;
     DevBuf<unsigned long long> perRep, perRepScan, vTileCnt, vTileOff;
     const uint64_t vTiles = (nGroup + CP_TILE - 1) / CP_TILE;

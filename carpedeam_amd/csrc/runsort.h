@@ -483,8 +483,11 @@ __global__ __launch_bounds__(U_NT, CDM_U_MINW) void k_unit_sort(UnitArgs a) {
 // offsets); hiShift = diagonal bits + 1.  CDM_UNIT_CAP / CDM_BLOCK_CAP lower the capacities (tests).
 // srcKeys / recVal: the k-mer-ordered keys and the sorted records `in` is the expansion of.  `in` itself may be unwritten: the unit
 // sorter gathers from the records, and the ranges the other sorters need are expanded into `in` here (k_gather_ranges).
+// unitHook (aggvote.h): takes the units in k_unit_sort's place - it is handed each size class's list and the hard list it may add to
+typedef void (*UnitHook)(hipStream_t s, unsigned int grid, const unsigned long long *list, const unsigned int *count, bucket::BigList hard, void *user);
 inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t *out, uint64_t n, int shiftHi, int hiShift, int top,
-                             const uint32_t *recRep, const unsigned long long *dst, uint64_t nRec, const uint64_t *srcKeys, const uint64_t *recVal) {
+                             const uint32_t *recRep, const unsigned long long *dst, uint64_t nRec, const uint64_t *srcKeys, const uint64_t *recVal,
+                             UnitHook unitHook = nullptr, void *hookUser = nullptr) {
     using namespace bucket;
     if (n == 0) return CDM_OK;
     uint32_t maxSeg = U_MAXSEG, blockCap = 4096;
@@ -514,9 +517,13 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
         UnitArgs ua; ua.keys = srcKeys; ua.recVal = recVal; ua.dst = dst; ua.nRec = nRec; ua.out = out; ua.n = n; ua.repShift = shiftHi; ua.hiShift = hiShift; ua.maxSub = maxSub; ua.hard.list = hardList.p; ua.hard.cnt = cnt.p + SEG_CLASSES;
         const unsigned int pad = cdm_lds_pad("CDM_LDS_PAD_UNIT");
         const unsigned int grid = (unsigned int) std::min<uint64_t>(units, (uint64_t) cuCount * 64);
+        if (unitHook) {
+            for (int c = 0; c < U_CLASSES; c++) unitHook(s, grid, uList[c].p, cnt.p + SEG_CLASSES + 1 + c, ua.hard, hookUser);
+        } else {
         ua.list = uList[0].p; ua.count = cnt.p + SEG_CLASSES + 1; hipLaunchKernelGGL((k_unit_sort<U_CLASS_CAP[0], U_CLASS_NT[0]>), dim3(grid), dim3(U_CLASS_NT[0]), pad, s, ua);
         ua.list = uList[1].p; ua.count = cnt.p + SEG_CLASSES + 2; hipLaunchKernelGGL((k_unit_sort<U_CLASS_CAP[1], U_CLASS_NT[1]>), dim3(grid), dim3(U_CLASS_NT[1]), pad, s, ua);
         ua.list = uList[2].p; ua.count = cnt.p + SEG_CLASSES + 3; hipLaunchKernelGGL((k_unit_sort<U_CLASS_CAP[2], U_CLASS_NT[2]>), dim3(grid), dim3(U_CLASS_NT[2]), pad, s, ua);
+        }
     }
     // the segments no unit can hold, listed by size class: one block of 8 waves (bitonic network, bucket.h) up to 4096, rocPRIM beyond
     SegListArgs la; la.recRep = recRep; la.dst = dst; la.nRec = nRec; la.maxWave = maxSeg;
@@ -531,8 +538,8 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
     if (blockCap) hipLaunchKernelGGL(k_block_sort<8>, dim3((unsigned int) std::min<uint64_t>((uint64_t) cuCount * 8, listCap)), dim3(512), 0, s, ba);
     unsigned int hc[NCNT] = {0};
     if (hipMemcpyAsync(hc, cnt.p, NCNT * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
-    if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "segmentedSortKeys: n %llu, %llu records, %llu units (%u / %u / %u by size class): segments > %u: %u (<= %u, block sort), %u longer (rocPRIM); %u hard units (rocPRIM)\n",
-                                            (unsigned long long) n, (unsigned long long) nRec, (unsigned long long) units, hc[SEG_CLASSES + 1], hc[SEG_CLASSES + 2], hc[SEG_CLASSES + 3], maxSeg, hc[2], blockCap, hc[3], hc[SEG_CLASSES]);
+    if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "segmentedSortKeys%s: n %llu, %llu records, %llu units (%u / %u / %u by size class): segments > %u: %u (<= %u, block sort), %u longer (rocPRIM); %u hard units (rocPRIM)\n",
+                                            unitHook ? " (units aggregated)" : "", (unsigned long long) n, (unsigned long long) nRec, (unsigned long long) units, hc[SEG_CLASSES + 1], hc[SEG_CLASSES + 2], hc[SEG_CLASSES + 3], maxSeg, hc[2], blockCap, hc[3], hc[SEG_CLASSES]);
     const unsigned int nBig = hc[3] + hc[SEG_CLASSES];
     if (nBig == 0) return CDM_OK;
     // deep pile-ups and hard units: gather, sort on the whole key with rocPRIM (stable), scatter.  (The ranges are disjoint and
