@@ -57,8 +57,14 @@ static_assert((1 << AG_IDX) >= AG_D && (1 << AG_ORD) > runsort::U_T, "aggregatio
 __device__ __forceinline__ uint32_t aggHash(uint64_t k) { return (uint32_t) ((k * 0x9E3779B97F4A7C15ull) >> 40); }
 
 // ITEMS: tuples a thread fetches before it starts inserting (all loads of a round are in flight together; CAP / NT of the size class)
+#ifndef CDM_AGG_MINW
+#define CDM_AGG_MINW 4
+#endif
+// (waves per SIMD the register allocation leaves room for: unbounded the kernel takes 112-130 VGPRs - the register network of the
+// entry sort - and runs 3-4 waves per SIMD where its LDS allows 5; swept 3 / 4 / 5 / 6: 85.3 / 83.8 / 87.0 / 84.6 ms of sort 2 - within the noise; halving the
+// occupancy with an LDS pad costs 30 ms: the kernel runs on the latency of its gathers and LDS round trips)
 template <int NT, int ITEMS>
-__global__ __launch_bounds__(NT) void k_unit_agg(AggArgs a) {
+__global__ __launch_bounds__(NT, CDM_AGG_MINW) void k_unit_agg(AggArgs a) {
     using namespace runsort;
     // the hash table; once its entries are compacted the same memory holds the per-ordinal directory of the unit
     __shared__ __align__(8) unsigned char sTab[AG_H * 16];

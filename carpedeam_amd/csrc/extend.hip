@@ -162,6 +162,19 @@ __device__ __forceinline__ void countMatchesWords(const ExtArgs &A, uint32_t q, 
     idCnt = (int) (n - mm); idRy = (int) (n - ry);
 }
 
+// the same on metadata the caller holds already (no gather of the two sequences' records)
+__device__ __forceinline__ void countMatchesWordsAt(const uint32_t *__restrict__ codes, uint32_t qw, uint32_t qLast, uint32_t q0, uint32_t tw, uint32_t tLast, uint32_t t0, uint32_t n, int &idCnt, int &idRy) {
+    uint32_t mm = 0, ry = 0;
+    for (uint32_t k = 0; k < n; k += 16) {
+        const uint32_t x = cdm_window16(codes, qw, q0 + k, qLast) ^ cdm_window16(codes, tw, t0 + k, tLast);
+        uint32_t any = (x | (x >> 1)) & 0x55555555u, lowbit = x & 0x55555555u;
+        const uint32_t rem = n - k;
+        if (rem < 16) { const uint32_t m = (1u << (2 * rem)) - 1u; any &= m; lowbit &= m; }
+        mm += __popc(any); ry += __popc(lowbit);
+    }
+    idCnt = (int) (n - mm); idRy = (int) (n - ry);
+}
+
 // updateSeqIdConsensusReads for one candidate on the current query (nuclassembleUtil.cpp:377-500, safe-mode consensus)
 __device__ void updateIds(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t &maxLeft, uint32_t &maxRight, const ConsList *cons = nullptr) {
     const uint32_t qLen = Q.total;
@@ -322,12 +335,17 @@ __global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
     VQuery Q; Q.a = &A; Q.q = q; Q.qLen0 = qLen0; Q.qw = A.woff[q]; Q.cand = cand; Q.leftL = leftL; Q.rightL = rightL;
     Q.nL = 0; Q.nR = 0; Q.leftTotal = 0; Q.total = qLen0; Q.plain = A.hasN[q] == 0;
 
-    // ---- A-C: candidates ("notContig"), in record order
+    // ---- A-C: candidates ("notContig"), in record order.  The loop is a chain of dependent gathers - record, the target's metadata,
+    // its letters - per lane: the next record and its target's metadata are fetched while the current one is worked on.
     uint32_t nCand = 0;   // candidate k lives at cand[k] (compacted), keeping the record index for the score output
+    const SeqMeta *meta = A.len.m;
+    const uint32_t qLastW = (qLen0 + 15) / 16 - 1;
+    AlnRec recN = A.rec[r0]; SeqMeta tmN = meta[recN.target];
     for (uint32_t r = 0; r < nRec; r++) {
-        const AlnRec rec = A.rec[r0 + r];
+        const AlnRec rec = recN; const SeqMeta tm = tmN;
+        if (r + 1 < nRec) { recN = A.rec[r0 + r + 1]; tmN = meta[recN.target]; }
         if (A.scores) A.scores[r0 + r] = NAN;
-        const uint32_t tLen = A.len[rec.target];
+        const uint32_t tLen = tm.len;
         const uint32_t ds = (uint32_t) rec.dbStart, de = (uint32_t) rec.dbEnd, qs = (uint32_t) rec.qStart, qe = (uint32_t) rec.qEnd;
         const bool rightStart = ds == 0 && qe == (qLen0 - 1);
         const bool leftStart = qs == 0 && de == (tLen - 1);
@@ -337,7 +355,7 @@ __global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
         float seqId = rec.seqId, rySeqId = 0.f;
         if (rec.target != qKey) {   // the reference compares the target's *id* with the query's *key* (:264)
             int idCnt = 0, idRy = 0;
-            if (Q.plain && !A.hasN[rec.target]) countMatchesWords(A, q, (uint32_t) rec.qStart, rec.target, (uint32_t) rec.dbStart, (uint32_t) (rec.qEnd - rec.qStart + 1), idCnt, idRy);
+            if (Q.plain && !(tm.flags & 1u)) countMatchesWordsAt(A.codes, Q.qw, qLastW, (uint32_t) rec.qStart, tm.woff, (tLen + 15) / 16 - 1, (uint32_t) rec.dbStart, (uint32_t) (rec.qEnd - rec.qStart + 1), idCnt, idRy);
             else
             for (int i = rec.qStart; i <= rec.qEnd; i++) {
                 uint32_t qc, tc; bool qn, tn;
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
             seqId = static_cast<float>(idCnt) / alnLen; rySeqId = static_cast<float>(idRy) / alnLen;
         }
         const bool noOffset = (tLen - alnLen) == 0;
-        if (A.ext[rec.target] == 0 && alnLen >= 30 && seqId >= A.seqIdThr && !noOffset) {
+        if (((tm.flags >> 1) & 1u) == 0 && alnLen >= 30 && seqId >= A.seqIdThr && !noOffset) {
             Cand c; c.qs = rec.qStart; c.qe = rec.qEnd; c.ds = rec.dbStart; c.de = rec.dbEnd; c.target = rec.target; c.alnLen = alnLen; c.dbLen = tLen;
             c.qLen = qLen0; c.seqId = seqId; c.rySeqId = rySeqId; c.sLenNorm = 0; c.pieceStart = r; c.pieceLen = 0;   // pieceStart keeps the record index until used
             cand[nCand++] = c;

@@ -1592,9 +1592,10 @@ static void aggUnitHook(hipStream_t st, unsigned int grid, const unsigned long l
     aggv::AggArgs a = *u;
     a.list = list; a.count = count; a.hard = hard;
     const int cls = (int) (u->nextClass++ % runsort::U_CLASSES);       // (called once per size class, smallest first)
-    if (cls == 0) hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[0] / 256>), dim3(grid), dim3(256), 0, st, a);
-    else if (cls == 1) hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[1] / 256>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[2] / 256>), dim3(grid), dim3(256), 0, st, a);
+    const unsigned int pad = cdm_lds_pad("CDM_LDS_PAD_AGG");
+    if (cls == 0) hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[0] / 256>), dim3(grid), dim3(256), pad, st, a);
+    else if (cls == 1) hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[1] / 256>), dim3(grid), dim3(256), pad, st, a);
+    else hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[2] / 256>), dim3(grid), dim3(256), pad, st, a);
 }
 int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *recRep, const uint64_t *recVal, const unsigned long long *dst, unsigned long long nRec,
               const uint64_t *gk, int top2) {
