@@ -73,7 +73,7 @@ def main():
         out["kernels"][k] = {"launches": n, "fetch_bytes": f, "write_bytes": w, "hbm_bytes_per_launch": (f + w) / n}
     # per-stage totals of the chain (one step: the PMC passes run `bench.py --steps 1 --warmup 0`)
     stage_of = (("kmermatcher", ("k_seq_hash", "k_extract", "rocprim", "rx::", "k_bucket_groups", "k_groups", "runsort::", "k_unit_sort", "k_block_sort", "k_bucket_sort", "k_seg_",
-                                 "k_self", "k_offsets", "k_len_keys", "k_slot_", "k_live_count", "k_stale_tail", "k_reduce_stats", "k_big_", "k_head_segment", "k_count_hash", "cdmscan")),
+                                 "aggv::", "k_self", "k_offsets", "k_len_keys", "k_slot_", "k_live_count", "k_stale_tail", "k_reduce_stats", "k_big_", "k_head_segment", "k_count_hash", "cdmscan")),
                 ("rescorediagonal", ("k_rescore", "k_expand", "k_count_valid", "k_scatter", "k_min_score")),
                 ("ancient_correction", ("k_correct", "k_mark_active<", "k_mark_active(")),
                 ("ancient_read_assemble", ("k_extend", "k_write", "k_out_meta", "k_mark_active2")))
