@@ -411,7 +411,7 @@ int kmermatcher(Args &a) {
     std::vector<OutChunk> chunks;
     formatPrefDb(seq, off.data(), rec.data(), chunks);
     laps.lap("prefilter text formatted");
-    if (!mmdbWriteChunks(a.pos[1], 14, chunks, &err)) die(err);   // DBTYPE_PREFILTER_REV_RES (kmermatcher.cpp:682)
+    if (!mmdbWriteChunks(a.pos[1], 14, chunks, &err, true)) die(err);   // DBTYPE_PREFILTER_REV_RES (kmermatcher.cpp:682)
     laps.lap("result DB written");
     cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
@@ -443,7 +443,7 @@ int rescorediagonal(Args &a) {
     std::vector<OutChunk> chunks;
     formatAlnDb(seq, pref, aoff.data(), arec.data(), cdm_seqdb_residues(db), chunks);
     laps.lap("alignment text formatted");
-    if (!mmdbWriteChunks(a.pos[3], 5, chunks, &err)) die(err);
+    if (!mmdbWriteChunks(a.pos[3], 5, chunks, &err, true)) die(err);
     laps.lap("result DB written");
     cdm_alns_free(alns); cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;

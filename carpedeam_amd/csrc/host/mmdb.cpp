@@ -182,23 +182,47 @@ static bool writePieces(int fd, uint64_t total, const std::vector<Piece> &pieces
     }
     return ok;
 }
-bool mmdbWriteChunks(const std::string &path, int dbtype, const std::vector<OutChunk> &chunks, std::string *err) {
-    const int d = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644), ix = open((path + ".index").c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
-    if (d < 0 || ix < 0) { if (d >= 0) close(d); if (ix >= 0) close(ix); *err = "Could not open " + path + " for writing"; return false; }
+bool mmdbWriteChunks(const std::string &path, int dbtype, const std::vector<OutChunk> &chunks, std::string *err, bool splitData) {
     const size_t C = chunks.size();
     std::vector<uint64_t> base(C + 1, 0), ixBase(C + 1, 0);
     for (size_t c = 0; c < C; c++) base[c + 1] = base[c] + chunks[c].data.size();
+    // Result DBs (prefilter hits, alignments) of some size go out as the reference's DBWriter leaves them: one data file per writer
+    // thread, X.0 .. X.T-1, the index offsets global over their concatenation (DBWriter.cpp:135-188; DBReader.cpp:108-133 reads them
+    // back, as host/mmdb.cpp does).  Buffered writes to ONE file are serialised by the file system whatever the threads; to T files
+    // they are not.  Sequence DBs stay one file: the workflow scripts test and link their data file by name.
+    static const uint64_t splitMin = getenv("CDM_SPLIT_MIN") ? strtoull(getenv("CDM_SPLIT_MIN"), nullptr, 10) : (64u << 20);     // (tests lower it)
+    const bool split = splitData && C > 1 && base[C] >= splitMin && !getenv("CDM_SINGLE_DATA_FILE");
+    const int ix = open((path + ".index").c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    const int d = split ? -1 : open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (ix < 0 || (!split && d < 0)) { if (d >= 0) close(d); if (ix >= 0) close(ix); *err = "Could not open " + path + " for writing"; return false; }
+    bool ok = true;
+    if (split) unlink(path.c_str());                          // (a single-file DB of an earlier run must not shadow the parts)
+    else for (int i = 0; i < 4096; i++) { const std::string part = path + "." + std::to_string(i); if (unlink(part.c_str()) != 0) break; }
     std::vector<std::string> ixText(C);
 #pragma omp parallel for schedule(dynamic, 1)
-    for (size_t c = 0; c < C; c++) indexText(ixText[c], chunks[c].key.data(), chunks[c].len.data(), chunks[c].ext.data(), chunks[c].key.size(), base[c]);
+    for (size_t c = 0; c < C; c++) {
+        indexText(ixText[c], chunks[c].key.data(), chunks[c].len.data(), chunks[c].ext.data(), chunks[c].key.size(), base[c]);
+        if (split) {
+            const int f = open((path + "." + std::to_string(c)).c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            bool mine = f >= 0 && (chunks[c].data.empty() || pwriteAll(f, chunks[c].data.data(), chunks[c].data.size(), 0));
+            if (f >= 0) mine = (close(f) == 0) && mine;
+            if (!mine) {
+#pragma omp atomic write
+                ok = false;
+            }
+        }
+    }
+    if (split) for (size_t c = C; c < 4096; c++) { const std::string part = path + "." + std::to_string(c); if (unlink(part.c_str()) != 0) break; }
     std::vector<Piece> dataPieces, ixPieces;
     for (size_t c = 0; c < C; c++) {
         ixBase[c + 1] = ixBase[c] + ixText[c].size();
-        if (!chunks[c].data.empty()) dataPieces.push_back({chunks[c].data.data(), chunks[c].data.size(), base[c]});
+        if (!split && !chunks[c].data.empty()) dataPieces.push_back({chunks[c].data.data(), chunks[c].data.size(), base[c]});
         if (!ixText[c].empty()) ixPieces.push_back({ixText[c].data(), ixText[c].size(), ixBase[c]});
     }
-    bool ok = writePieces(d, base[C], dataPieces) && writePieces(ix, ixBase[C], ixPieces);
-    ok = (close(d) == 0) & (close(ix) == 0) & ok;
+    if (!split) ok = writePieces(d, base[C], dataPieces) && ok;
+    ok = writePieces(ix, ixBase[C], ixPieces) && ok;
+    if (d >= 0) ok = (close(d) == 0) && ok;
+    ok = (close(ix) == 0) && ok;
     ok = ok && writeDbtype(path, dbtype);
     if (!ok) *err = "Could not write " + path;
     return ok;

@@ -66,7 +66,8 @@ struct alignas(128) OutChunk {     // (a cache line of its own: the threads upda
     void close(uint32_t k, char *start, char *end, uint8_t e) { *end++ = '\0'; data.resize((size_t) (end - data.data())); key.push_back(k); len.push_back((uint32_t) (end - start)); ext.push_back(e); }
 };
 // chunks in increasing key order (chunk i holds smaller keys than chunk i + 1)
-bool mmdbWriteChunks(const std::string &path, int dbtype, const std::vector<OutChunk> &chunks, std::string *err);
+// splitData: a large DB may be written as X.0 .. X.n, one data file per chunk (result DBs; never sequence DBs)
+bool mmdbWriteChunks(const std::string &path, int dbtype, const std::vector<OutChunk> &chunks, std::string *err, bool splitData = false);
 // one blob that already has the data file's layout: entry i at off[i], len[i] bytes incl. the NUL
 bool mmdbWriteBlob(const std::string &path, int dbtype, const char *blob, size_t blobBytes, const uint32_t *key, const uint64_t *off,
                    const uint32_t *len, const uint8_t *ext, size_t n, std::string *err);

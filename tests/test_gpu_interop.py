@@ -25,10 +25,12 @@ def run(exe, *args, env=None):
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref (the reference's object code) is not built here")
-@pytest.mark.parametrize("name,it", [("synth2k", 0), ("mixed3k", 2), ("example", 0), ("letters", 1)])
-def test_reference_modules_read_gpu_written_dbs(tmp_path, dhigh_prefix, name, it):
+@pytest.mark.parametrize("name,it,split", [("synth2k", 0, False), ("mixed3k", 2, False), ("example", 0, False), ("letters", 1, False), ("mixed3k", 1, True), ("example", 0, True)])
+def test_reference_modules_read_gpu_written_dbs(tmp_path, dhigh_prefix, name, it, split, monkeypatch):
     from carpedeam_amd import build
     build.build()
+    if split:       # large result DBs are written as X.0 .. X.n like the reference's own (host/mmdb.cpp); forced here on small ones
+        monkeypatch.setenv("CDM_SPLIT_MIN", "1")
     t = lambda s: str(tmp_path / s)
     dmg = ["--ancient-damage", dhigh_prefix, "--threads", "4"]
     mmdb.write_from_keyed(t("in"), stage_input(name, it), mmdb.DBTYPE_NUCLEOTIDES)
@@ -36,6 +38,7 @@ def test_reference_modules_read_gpu_written_dbs(tmp_path, dhigh_prefix, name, it
     run(GPU, "kmermatcher", t("in"), t("pref_g"), *K_FLAGS, "--threads", "4")
     run(REF, "rescorediagonal", t("in"), t("in"), t("pref_g"), t("aln_r"), *R_FLAGS, "--threads", "4")
     run(GPU, "rescorediagonal", t("in"), t("in"), t("pref_g"), t("aln_g"), *R_FLAGS, "--threads", "4")
+    assert os.path.exists(t("aln_g.0")) == split and os.path.exists(t("pref_g.3")) == split
     assert not diff_keys(mmdb.read_db(t("aln_r")), mmdb.read_db(t("aln_g")))
     # alignment DB written by the MI355X rescorediagonal -> the reference's ancient_correction
     run(REF, "ancient_correction", t("in"), t("aln_g"), t("corr_r"), *A_FLAGS, *dmg)
