@@ -493,6 +493,61 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
         uint32_t np2 = 1; while (np2 < n) np2 <<= 1;
         for (uint32_t i = n + tid; i < np2; i += NT) { sp[i].a = ~0ull; sp[i].b = ~0ull; }
         __syncthreads();
+        if constexpr (CAP == 0) {
+            // The records are in global scratch.  The same bitonic network, but every exchange over a distance below CH happens in
+            // LDS: the array is taken CH records at a time (sHead's memory - it holds the head of the sorted records only later), all
+            // the network's stages that stay inside such a stretch run there, and only the exchanges over CH records or more go
+            // through memory - 28 passes over the array instead of 153 for a 100 k-letter contig (this kernel was half of the
+            // device time of the workflow loop's contig iterations).
+            constexpr uint32_t CH = 2048;
+            static_assert(CH <= HEADN, "the chunk lives in sHead");
+            const uint32_t cs = min(np2, CH);
+            auto ldsStages = [&](uint32_t c0, uint32_t size, uint32_t strideFrom) {      // stages of `size` with stride <= strideFrom on [c0, c0 + cs)
+                for (uint32_t i = tid; i < cs; i += NT) sHead[i] = sp[c0 + i];
+                __syncthreads();
+                for (uint32_t stride = strideFrom; stride > 0; stride >>= 1) {
+                    for (uint32_t t = tid; t < cs / 2; t += NT) {
+                        const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                        const bool up = ((c0 + lo) & size) == 0;
+                        SeqPos x = sHead[lo], y = sHead[hi];
+                        if (spLess(y, x) == up) { sHead[lo] = y; sHead[hi] = x; }
+                    }
+                    __syncthreads();
+                }
+            };
+            for (uint32_t c0 = 0; c0 < np2; c0 += cs) {          // sizes up to the chunk: wholly in LDS
+                for (uint32_t i = tid; i < cs; i += NT) sHead[i] = sp[c0 + i];
+                __syncthreads();
+                for (uint32_t size = 2; size <= cs; size <<= 1)
+                    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                        for (uint32_t t = tid; t < cs / 2; t += NT) {
+                            const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                            const bool up = ((c0 + lo) & size) == 0;
+                            SeqPos x = sHead[lo], y = sHead[hi];
+                            if (spLess(y, x) == up) { sHead[lo] = y; sHead[hi] = x; }
+                        }
+                        __syncthreads();
+                    }
+                for (uint32_t i = tid; i < cs; i += NT) sp[c0 + i] = sHead[i];
+                __syncthreads();
+            }
+            for (uint32_t size = 2 * cs; size <= np2 && size != 0; size <<= 1) {
+                for (uint32_t stride = size >> 1; stride >= cs; stride >>= 1) {
+                    for (uint32_t t = tid; t < np2 / 2; t += NT) {
+                        const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                        const bool up = (lo & size) == 0;
+                        SeqPos x = sp[lo], y = sp[hi];
+                        if (spLess(y, x) == up) { sp[lo] = y; sp[hi] = x; }
+                    }
+                    __syncthreads();
+                }
+                for (uint32_t c0 = 0; c0 < np2; c0 += cs) {
+                    ldsStages(c0, size, cs >> 1);
+                    for (uint32_t i = tid; i < cs; i += NT) sp[c0 + i] = sHead[i];
+                    __syncthreads();
+                }
+            }
+        } else
         for (uint32_t size = 2; size <= np2; size <<= 1)
             for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
                 for (uint32_t t = tid; t < np2 / 2; t += NT) {
