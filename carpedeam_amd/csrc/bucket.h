@@ -24,6 +24,7 @@
 
 #include "common.h"
 #include "radix.h"
+#include "scan.h"
 
 namespace bucket {
 
@@ -402,18 +403,16 @@ __global__ void k_big_split(const unsigned long long *__restrict__ list, unsigne
 }
 inline int loadBigList(hipStream_t s, const unsigned long long *bigList, unsigned int cnt, DevBuf<unsigned long long> &ranges, uint64_t &total,
                        unsigned long long *firstStart = nullptr) {
-    DevBuf<unsigned long long> s0, s1, e0, e1, sz, off; DevBuf<char> tmp;
+    DevBuf<unsigned long long> s0, s1, e0, e1, sz, off;
     if (!s0.alloc(cnt) || !s1.alloc(cnt) || !e0.alloc(cnt) || !e1.alloc(cnt) || !sz.alloc((size_t) cnt + 1) || !off.alloc((size_t) cnt + 1) || !ranges.alloc(3 * (size_t) cnt)) return CDM_ERR_HIP;
     const unsigned int g = (cnt + 256) / 256;
     hipLaunchKernelGGL(k_big_split, dim3(g), dim3(256), 0, s, bigList, cnt, s0.p, e0.p);
     bool inFirst = true;
     if (int rc = rx::sortPairs<unsigned long long, unsigned long long>(s, 256, s0.p, s1.p, e0.p, e1.p, (uint64_t) cnt, 0, 64, inFirst)) return rc;
     rocprim::double_buffer<unsigned long long> ks(inFirst ? s0.p : s1.p, inFirst ? s1.p : s0.p), vs(inFirst ? e0.p : e1.p, inFirst ? e1.p : e0.p);
-    size_t tb2 = 0;
-    if (rocprim::exclusive_scan(nullptr, tb2, sz.p, off.p, 0ull, (size_t) cnt + 1, rocprim::plus<unsigned long long>(), s) != hipSuccess) return CDM_ERR_HIP;
-    if (!tmp.alloc(tb2 + 256)) return CDM_ERR_HIP;
+    cdmscan::ScanTemp scanTmp;                                                // alive until the synchronise below
     hipLaunchKernelGGL(k_big_sizes, dim3(g), dim3(256), 0, s, (const unsigned long long *) ks.current(), (const unsigned long long *) vs.current(), cnt, sz.p);
-    if (rocprim::exclusive_scan(tmp.p, tb2, sz.p, off.p, 0ull, (size_t) cnt + 1, rocprim::plus<unsigned long long>(), s) != hipSuccess) return CDM_ERR_HIP;
+    if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, scanTmp, sz.p, off.p, (size_t) cnt + 1)) return rc;
     hipLaunchKernelGGL(k_big_pack, dim3(g), dim3(256), 0, s, (const unsigned long long *) ks.current(), (const unsigned long long *) vs.current(), (const unsigned long long *) off.p, cnt, ranges.p);
     unsigned long long tot = 0, first = ~0ull;
     hipMemcpyAsync(&tot, off.p + cnt, 8, hipMemcpyDeviceToHost, s);

@@ -718,7 +718,10 @@ template <typename LY> struct StartIndex {
         return start ? i : 0ull;
     }
 };
-struct MaxU64 { __host__ __device__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; } };
+template <typename LY> struct StartFrom {      // the scan's index starts at 0, the tuples at `first`
+    StartIndex<LY> f;
+    __device__ __forceinline__ unsigned long long operator()(size_t i) const { return f(f.first + (unsigned long long) i); }
+};
 
 // K3, one thread per tuple.  The tuple array was filled in (sequence length descending, id ascending, position) order and
 // the radix sort is stable, so the first tuple of a k-mer run is the reference's representative (sort order
@@ -1403,15 +1406,10 @@ int phaseA() override {
         auto scanGroups = [&](GroupArgs<LY> g, unsigned long long *io) -> int {
             const size_t cnt = (size_t) (g.n - g.first);
             if (cnt == 0) return CDM_OK;
-            auto startIt = rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned long long>((unsigned long long) g.first),
-                                                            StartIndex<LY>{g.keys, g.geom, (unsigned long long) g.first});
-            size_t sb = 0;
-            rocprim::inclusive_scan(nullptr, sb, startIt, io + g.first, cnt, MaxU64(), s);
-            DevBuf<char> t;
-            if (!t.alloc(sb + 256)) return CDM_ERR_HIP;
-            if (rocprim::inclusive_scan(t.p, sb, startIt, io + g.first, cnt, MaxU64(), s) != hipSuccess) return CDM_ERR_HIP;
+            cdmscan::ScanTemp t;                                                  // alive until the synchronise below
+            if (int rc = cdmscan::inclusiveMaxScanFn(s, t, StartFrom<LY>{StartIndex<LY>{g.keys, g.geom, (unsigned long long) g.first}}, io + g.first, cnt)) return rc;
             hipLaunchKernelGGL(k_groups<LY>, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, s, g, io);
-            return hipStreamSynchronize(s) == hipSuccess ? CDM_OK : CDM_ERR_HIP;      // t is released on return
+            return hipStreamSynchronize(s) == hipSuccess ? CDM_OK : CDM_ERR_HIP;
         };
         int rc = CDM_OK;
         if (kmerSlots) {        // real tuples of region 1 (the unused slots sort behind them in both variants)
