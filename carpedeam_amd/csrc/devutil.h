@@ -210,6 +210,23 @@ __device__ __forceinline__ X87 x87_add(X87 a, X87 b) {
     if (lz) { hi = (hi << lz) | (lo >> (64 - lz)); lo <<= lz; e -= lz; }
     return x87_round(hi, lo, e, a.s);
 }
+// a + b as x87_add gives it, for the running sums: the common case there - same sign, the sum's exponent above the term's by
+// 1..63, so |a| > |b| - skips the ordering and the general alignment
+__device__ __forceinline__ X87 x87_acc(const X87 &a, const X87 &b) {
+    const uint32_t d = (uint32_t) (a.e - b.e);
+    if (!(a.s == b.s && (d - 1u) < 63u && a.m != 0 && b.m != 0)) return x87_add(a, b);
+    // (without branches: the lanes of a wave take the carry and the round-up cases at random)
+    const uint64_t bhi = b.m >> d, lo = b.m << (64u - d);
+    const uint64_t hi = a.m + bhi;
+    const bool c = hi < a.m;                              // carry out of bit 63: the sum moves down one bit
+    const uint32_t guard = c ? (uint32_t) (hi & 1ull) : (uint32_t) (lo >> 63);
+    const bool sticky = c ? (lo != 0) : ((lo << 1) != 0);
+    uint64_t m = c ? ((hi >> 1) | (1ull << 63)) : hi;
+    m += guard & ((uint32_t) sticky | (uint32_t) (m & 1ull));   // round to nearest even
+    const bool ovf = m == 0;                              // all ones + 1
+    X87 r; r.m = ovf ? (1ull << 63) : m; r.e = a.e + (int) c + (int) ovf; r.s = a.s;
+    return r;
+}
 // a < b
 __device__ __forceinline__ bool x87_lt(const X87 &a, const X87 &b) {
     if (a.m == 0 && b.m == 0) return false;

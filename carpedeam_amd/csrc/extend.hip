@@ -20,6 +20,7 @@
 #include "scan.h"
 
 #include <cmath>
+#include <cstring>
 
 #include "common.h"
 #include "devutil.h"
@@ -217,7 +218,7 @@ __device__ void updateIds(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t &
 
 // calcLikelihoodConsensus via r_s_pair; returns sRatio > threshold, sets c.sLenNorm
 __device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t maxLeft, uint32_t maxRight, const double *logLik /* [11][4][4] fwd */,
-                          const ConsList *cons = nullptr) {
+                          const ConsList *cons = nullptr, const X87 *logLikX = nullptr /* the same table, converted once */) {
     const uint32_t qLen = Q.total;
     uint32_t maxAln = maxRight;
     if ((uint32_t) c.qs == 0 && (uint32_t) c.de == (c.dbLen - 1)) maxAln = maxLeft;
@@ -258,13 +259,28 @@ __device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t m
             // no N anywhere: tIdx - 1 is the target position itself; walk the two sequences a 16-base word at a time
             const uint32_t qw = A.woff[Q.q], tw = A.woff[c.target];
             const uint32_t qLast = (Q.qLen0 + 15) / 16 - 1, tLast = (c.dbLen + 15) / 16 - 1;
+            const uint32_t tailFrom = c.dbLen - 5;
+            if (logLikX) {
+            uint32_t qNext = cdm_window16(A.codes, qw, q0, qLast), tNext = cdm_window16(A.codes, tw, t0, tLast);
+            for (uint32_t k = 0; k < ncol; k += 16) {
+                uint32_t qwin = qNext, twin = tNext;          // (the next 16 columns are on their way while these are summed)
+                if (k + 16 < ncol) { qNext = cdm_window16(A.codes, qw, q0 + k + 16, qLast); tNext = cdm_window16(A.codes, tw, t0 + k + 16, tLast); }
+                const uint32_t m = min(16u, ncol - k);
+                for (uint32_t j = 0; j < m; j++) {
+                    const uint32_t ti = t0 + k + j;
+                    const uint32_t cls = ti < 5 ? ti : (ti >= tailFrom ? 6 + (ti - tailFrom) : 5);
+                    lik = x87_acc(lik, logLikX[(cls * 4 + (qwin & 3u)) * 4 + (twin & 3u)]);
+                    qwin >>= 2; twin >>= 2;
+                }
+            }
+            } else
             for (uint32_t k = 0; k < ncol; k += 16) {
                 uint32_t qwin = cdm_window16(A.codes, qw, q0 + k, qLast), twin = cdm_window16(A.codes, tw, t0 + k, tLast);
                 const uint32_t m = min(16u, ncol - k);
                 for (uint32_t j = 0; j < m; j++) {
                     const uint32_t ti = t0 + k + j;
-                    const uint32_t cls = ti < 5 ? ti : (ti >= c.dbLen - 5 ? 6 + (ti - (c.dbLen - 5)) : 5);
-                    lik = x87_add(lik, x87_from_double(logLik[(cls * 4 + (qwin & 3u)) * 4 + (twin & 3u)]));
+                    const uint32_t cls = ti < 5 ? ti : (ti >= tailFrom ? 6 + (ti - tailFrom) : 5);
+                    lik = x87_acc(lik, x87_from_double(logLik[(cls * 4 + (qwin & 3u)) * 4 + (twin & 3u)]));
                     qwin >>= 2; twin >>= 2;
                 }
             }
@@ -317,93 +333,10 @@ struct Heap {
     }
 };
 
-// RAW = false: the DB has no letters beyond ACGTN - the raw-plane branches of letterOf() fold away (a null pointer the compiler knows)
-template <int MINW, bool RAW = false>
-__global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
-    if (!RAW) A.raw = nullptr;
-    __shared__ double sLogLik[11 * 16];
-    for (int i = threadIdx.x; i < 11 * 16; i += blockDim.x) sLogLik[i] = (&A.lut->logLik[0][0][0][0])[i];
-    __syncthreads();
-    const unsigned int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= *A.nActive) return;
-    const uint32_t q = A.active[item];
-    const uint64_t r0 = A.aoff[q], r1 = A.aoff[q + 1];
-    const uint32_t nRec = (uint32_t) (r1 - r0);
-    const uint32_t qLen0 = A.len[q], qKey = A.key[q];
-    Cand *cand = A.cand + r0;
-    uint32_t *heapL = A.lists + 4 * r0, *parkL = heapL + nRec, *leftL = parkL + nRec, *rightL = leftL + nRec;
-    VQuery Q; Q.a = &A; Q.q = q; Q.qLen0 = qLen0; Q.qw = A.woff[q]; Q.cand = cand; Q.leftL = leftL; Q.rightL = rightL;
-    Q.nL = 0; Q.nR = 0; Q.leftTotal = 0; Q.total = qLen0; Q.plain = A.hasN[q] == 0;
-
-    // ---- A-C: candidates ("notContig"), in record order.  The loop is a chain of dependent gathers - record, the target's metadata,
-    // its letters - per lane: the next record and its target's metadata are fetched while the current one is worked on.
-    uint32_t nCand = 0;   // candidate k lives at cand[k] (compacted), keeping the record index for the score output
-    const SeqMeta *meta = A.len.m;
-    const uint32_t qLastW = (qLen0 + 15) / 16 - 1;
-    AlnRec recN = A.rec[r0]; SeqMeta tmN = meta[recN.target];
-    for (uint32_t r = 0; r < nRec; r++) {
-        const AlnRec rec = recN; const SeqMeta tm = tmN;
-        if (r + 1 < nRec) { recN = A.rec[r0 + r + 1]; tmN = meta[recN.target]; }
-        if (A.scores) A.scores[r0 + r] = NAN;
-        const uint32_t tLen = tm.len;
-        const uint32_t ds = (uint32_t) rec.dbStart, de = (uint32_t) rec.dbEnd, qs = (uint32_t) rec.qStart, qe = (uint32_t) rec.qEnd;
-        const bool rightStart = ds == 0 && qe == (qLen0 - 1);
-        const bool leftStart = qs == 0 && de == (tLen - 1);
-        if (!rightStart && !leftStart) continue;
-        if (rec.qStart > rec.qEnd) continue;   // cannot happen given the test above; reverse strand never extends
-        const uint32_t alnLen = (uint32_t) max(abs(rec.qEnd - rec.qStart), abs(rec.dbEnd - rec.dbStart)) + 1u;
-        float seqId = rec.seqId, rySeqId = 0.f;
-        if (rec.target != qKey) {   // the reference compares the target's *id* with the query's *key* (:264)
-            int idCnt = 0, idRy = 0;
-            if (Q.plain && !(tm.flags & 1u)) countMatchesWordsAt(A.codes, Q.qw, qLastW, (uint32_t) rec.qStart, tm.woff, (tLen + 15) / 16 - 1, (uint32_t) rec.dbStart, (uint32_t) (rec.qEnd - rec.qStart + 1), idCnt, idRy);
-            else
-            for (int i = rec.qStart; i <= rec.qEnd; i++) {
-                uint32_t qc, tc; bool qn, tn;
-                Q.baseAt((uint32_t) i, qc, qn); targetBaseAt(A, rec.target, (uint32_t) (rec.dbStart + (i - rec.qStart)), tc, tn);
-                // letters are compared: N == N; N maps to purine (0) in ryMap
-                const uint32_t ql = qn ? 4u : qc, tl = tn ? 4u : tc;
-                idCnt += (ql == tl);
-                idRy += (ryClass(qn ? 0u : qc) == ryClass(tn ? 0u : tc));
-            }
-            seqId = static_cast<float>(idCnt) / alnLen; rySeqId = static_cast<float>(idRy) / alnLen;
-        }
-        const bool noOffset = (tLen - alnLen) == 0;
-        if (((tm.flags >> 1) & 1u) == 0 && alnLen >= 30 && seqId >= A.seqIdThr && !noOffset) {
-            Cand c; c.qs = rec.qStart; c.qe = rec.qEnd; c.ds = rec.dbStart; c.de = rec.dbEnd; c.target = rec.target; c.alnLen = alnLen; c.dbLen = tLen;
-            c.qLen = qLen0; c.seqId = seqId; c.rySeqId = rySeqId; c.sLenNorm = 0; c.pieceStart = r; c.pieceLen = 0;   // pieceStart keeps the record index until used
-            cand[nCand++] = c;
-        }
-    }
-    if (nCand == 0) { A.newLen[q] = 0; return; }
-    uint32_t maxLeft = 0, maxRight = 0;
-    ConsList consAll; consAll.cand = cand; consAll.idx = nullptr; consAll.n = nCand; consAll.qKey = qKey;
-    const ConsList *cons0 = A.unsafe ? &consAll : nullptr;
-    for (uint32_t k = 0; k < nCand; k++) {
-        Cand &c = cand[k];
-        if (A.unsafe) updateIds(A, Q, c, maxLeft, maxRight, cons0);
-        else if (Q.plain && !A.hasN[c.target] && c.target != qKey) {      // (the candidate pass compares the target id with the query key)
-            // updateSeqIdConsensusReads would count the very columns the candidate pass above just counted (an end overlap of
-            // two sequences without N): seqId / rySeqId stand, only the longest overlap per side is updated
-            const bool rightStart = (uint32_t) c.ds == 0 && (uint32_t) c.qe == (qLen0 - 1);
-            const bool leftStart = (uint32_t) c.qs == 0 && (uint32_t) c.de == (c.dbLen - 1);
-            const uint32_t offset = c.dbLen - c.alnLen;
-            const uint32_t tot = leftStart ? min(c.dbLen - offset, qLen0) : (rightStart ? min(c.alnLen, c.dbLen) : 0u);
-            if (leftStart && tot > maxLeft) maxLeft = tot; else if (rightStart && tot > maxRight) maxRight = tot;
-        } else updateIds(A, Q, c, maxLeft, maxRight);
-    }
-    // ---- D
-    Heap heap; heap.h = heapL; heap.n = 0; heap.cand = cand;
-    for (uint32_t k = 0; k < nCand; k++) {
-        Cand &c = cand[k];
-        const bool notInside = c.dbLen != c.alnLen;
-        const bool rightStart = c.ds == 0, leftStart = c.qs == 0, notId = A.key[c.target] != qKey;
-        if ((rightStart || leftStart) && notInside && notId && c.rySeqId >= A.rySeqIdThr && c.seqId >= A.seqIdThr) {
-            const bool pass = scoreCand(A, Q, c, maxLeft, maxRight, sLogLik, cons0);
-            if (A.scores) A.scores[r0 + c.pieceStart] = c.sLenNorm;
-            if (pass) heap.push(k);
-        }
-    }
-    // ---- E
+// ---- E: the extension loop of one query (ancientReadsResults.cpp:374-546) on its heap of scored candidates; writes the query's
+// result (new length, piece lists).  Shared by the two forms of the kernel below.
+__device__ void extendLoop(const ExtArgs &A, VQuery &Q, Cand *cand, Heap &heap, uint32_t *parkL, uint32_t *leftL, uint32_t *rightL,
+                           uint32_t maxLeft, uint32_t maxRight, const double *sLogLik, uint32_t qKey, uint32_t q) {
     bool couldExtend = false;
     while (heap.n > 0) {
         uint32_t leftOff = 0, rightOff = 0, nPark = 0;
@@ -498,6 +431,293 @@ __global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
     }
     A.newLen[q] = couldExtend ? Q.total : 0;
     A.nLeft[q] = Q.nL; A.nRight[q] = Q.nR; A.leftTotal[q] = Q.leftTotal;
+}
+
+// RAW = false: the DB has no letters beyond ACGTN - the raw-plane branches of letterOf() fold away (a null pointer the compiler knows)
+template <int MINW, bool RAW = false>
+__global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
+    if (!RAW) A.raw = nullptr;
+    __shared__ double sLogLik[11 * 16];
+    for (int i = threadIdx.x; i < 11 * 16; i += blockDim.x) sLogLik[i] = (&A.lut->logLik[0][0][0][0])[i];
+    __syncthreads();
+    const unsigned int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= *A.nActive) return;
+    const uint32_t q = A.active[item];
+    const uint64_t r0 = A.aoff[q], r1 = A.aoff[q + 1];
+    const uint32_t nRec = (uint32_t) (r1 - r0);
+    const uint32_t qLen0 = A.len[q], qKey = A.key[q];
+    Cand *cand = A.cand + r0;
+    uint32_t *heapL = A.lists + 4 * r0, *parkL = heapL + nRec, *leftL = parkL + nRec, *rightL = leftL + nRec;
+    VQuery Q; Q.a = &A; Q.q = q; Q.qLen0 = qLen0; Q.qw = A.woff[q]; Q.cand = cand; Q.leftL = leftL; Q.rightL = rightL;
+    Q.nL = 0; Q.nR = 0; Q.leftTotal = 0; Q.total = qLen0; Q.plain = A.hasN[q] == 0;
+
+    // ---- A-C: candidates ("notContig"), in record order.  The loop is a chain of dependent gathers - record, the target's metadata,
+    // its letters - per lane: the next record and its target's metadata are fetched while the current one is worked on.
+    uint32_t nCand = 0;   // candidate k lives at cand[k] (compacted), keeping the record index for the score output
+    const SeqMeta *meta = A.len.m;
+    const uint32_t qLastW = (qLen0 + 15) / 16 - 1;
+    AlnRec recN = A.rec[r0]; SeqMeta tmN = meta[recN.target];
+    for (uint32_t r = 0; r < nRec; r++) {
+        const AlnRec rec = recN; const SeqMeta tm = tmN;
+        if (r + 1 < nRec) { recN = A.rec[r0 + r + 1]; tmN = meta[recN.target]; }
+        if (A.scores) A.scores[r0 + r] = NAN;
+        const uint32_t tLen = tm.len;
+        const uint32_t ds = (uint32_t) rec.dbStart, de = (uint32_t) rec.dbEnd, qs = (uint32_t) rec.qStart, qe = (uint32_t) rec.qEnd;
+        const bool rightStart = ds == 0 && qe == (qLen0 - 1);
+        const bool leftStart = qs == 0 && de == (tLen - 1);
+        if (!rightStart && !leftStart) continue;
+        if (rec.qStart > rec.qEnd) continue;   // cannot happen given the test above; reverse strand never extends
+        const uint32_t alnLen = (uint32_t) max(abs(rec.qEnd - rec.qStart), abs(rec.dbEnd - rec.dbStart)) + 1u;
+        float seqId = rec.seqId, rySeqId = 0.f;
+        if (rec.target != qKey) {   // the reference compares the target's *id* with the query's *key* (:264)
+            int idCnt = 0, idRy = 0;
+            if (Q.plain && !(tm.flags & 1u)) countMatchesWordsAt(A.codes, Q.qw, qLastW, (uint32_t) rec.qStart, tm.woff, (tLen + 15) / 16 - 1, (uint32_t) rec.dbStart, (uint32_t) (rec.qEnd - rec.qStart + 1), idCnt, idRy);
+            else
+            for (int i = rec.qStart; i <= rec.qEnd; i++) {
+                uint32_t qc, tc; bool qn, tn;
+                Q.baseAt((uint32_t) i, qc, qn); targetBaseAt(A, rec.target, (uint32_t) (rec.dbStart + (i - rec.qStart)), tc, tn);
+                // letters are compared: N == N; N maps to purine (0) in ryMap
+                const uint32_t ql = qn ? 4u : qc, tl = tn ? 4u : tc;
+                idCnt += (ql == tl);
+                idRy += (ryClass(qn ? 0u : qc) == ryClass(tn ? 0u : tc));
+            }
+            seqId = static_cast<float>(idCnt) / alnLen; rySeqId = static_cast<float>(idRy) / alnLen;
+        }
+        const bool noOffset = (tLen - alnLen) == 0;
+        if (((tm.flags >> 1) & 1u) == 0 && alnLen >= 30 && seqId >= A.seqIdThr && !noOffset) {
+            Cand c; c.qs = rec.qStart; c.qe = rec.qEnd; c.ds = rec.dbStart; c.de = rec.dbEnd; c.target = rec.target; c.alnLen = alnLen; c.dbLen = tLen;
+            c.qLen = qLen0; c.seqId = seqId; c.rySeqId = rySeqId; c.sLenNorm = 0; c.pieceStart = r; c.pieceLen = 0;   // pieceStart keeps the record index until used
+            cand[nCand++] = c;
+        }
+    }
+    if (nCand == 0) { A.newLen[q] = 0; return; }
+    uint32_t maxLeft = 0, maxRight = 0;
+    ConsList consAll; consAll.cand = cand; consAll.idx = nullptr; consAll.n = nCand; consAll.qKey = qKey;
+    const ConsList *cons0 = A.unsafe ? &consAll : nullptr;
+    for (uint32_t k = 0; k < nCand; k++) {
+        Cand &c = cand[k];
+        if (A.unsafe) updateIds(A, Q, c, maxLeft, maxRight, cons0);
+        else if (Q.plain && !A.hasN[c.target] && c.target != qKey) {      // (the candidate pass compares the target id with the query key)
+            // updateSeqIdConsensusReads would count the very columns the candidate pass above just counted (an end overlap of
+            // two sequences without N): seqId / rySeqId stand, only the longest overlap per side is updated
+            const bool rightStart = (uint32_t) c.ds == 0 && (uint32_t) c.qe == (qLen0 - 1);
+            const bool leftStart = (uint32_t) c.qs == 0 && (uint32_t) c.de == (c.dbLen - 1);
+            const uint32_t offset = c.dbLen - c.alnLen;
+            const uint32_t tot = leftStart ? min(c.dbLen - offset, qLen0) : (rightStart ? min(c.alnLen, c.dbLen) : 0u);
+            if (leftStart && tot > maxLeft) maxLeft = tot; else if (rightStart && tot > maxRight) maxRight = tot;
+        } else updateIds(A, Q, c, maxLeft, maxRight);
+    }
+    // ---- D
+    Heap heap; heap.h = heapL; heap.n = 0; heap.cand = cand;
+    for (uint32_t k = 0; k < nCand; k++) {
+        Cand &c = cand[k];
+        const bool notInside = c.dbLen != c.alnLen;
+        const bool rightStart = c.ds == 0, leftStart = c.qs == 0, notId = A.key[c.target] != qKey;
+        if ((rightStart || leftStart) && notInside && notId && c.rySeqId >= A.rySeqIdThr && c.seqId >= A.seqIdThr) {
+            const bool pass = scoreCand(A, Q, c, maxLeft, maxRight, sLogLik, cons0);
+            if (A.scores) A.scores[r0 + c.pieceStart] = c.sLenNorm;
+            if (pass) heap.push(k);
+        }
+    }
+    // ---- E
+    extendLoop(A, Q, cand, heap, parkL, leftL, rightL, maxLeft, maxRight, sLogLik, qKey, q);
+}
+
+// ---------------------------------------------------------------------------------------------- A-D, one thread per RECORD
+// k_extend above walks a query's records in one lane: a pile-up of 20 records is 20 dependent rounds of (record, target metadata,
+// target letters) gathers per lane, each of which pulls a whole line for 16-32 useful bytes, twice (candidate pass, scoring pass),
+// and a wave is as slow as its deepest query.  The candidate test, the identities and the likelihood of a record depend on nothing
+// but that record and its query - except for the longest overlap per side (maxAlnLeft/Right), a maximum over the query's
+// candidates.  So, for the default mode (safe consensus, no raw plane):
+//   k_xr_windows   the records are cut into windows of XR_T; a block owns the queries whose FIRST record lies in its window
+//   k_xr_score     per block: pass 1 - one thread per record: candidate test + identities (:202-315, updateSeqIdConsensusReads),
+//                  maximum per side into LDS; pass 2 - eligibility + calcLikelihoodConsensus per record (:317-372), sLenNorm of the
+//                  records that enter the queue to sLen[] (NaN otherwise); queries with at least one such record to the work list
+//   k_xr_extend    one thread per query of the work list: queue in record order (the push order of the reference), extendLoop()
+// Same arithmetic, same order of pushes; a candidate that is a left AND a right overlap at once (whose contribution to the two
+// maxima depends on the order of the records in the reference) sets X.fallback and the call is redone by k_extend.
+constexpr int XR_NT = 512, XR_T = 448, XR_QCAP = 512, XR_LCAP = 1024, XR_BINS = 32;
+struct XrArgs {
+    const uint32_t *winQ;      // [windows + 1] first query of every window
+    float2 *lite;              // [alignment count] (seqId, rySeqId) of a candidate record; seqId = NaN: not a candidate
+    double *sLen;              // [alignment count] sLenNorm of a record that enters the queue, NaN otherwise
+    uint32_t *qMax;            // [2 n] maxAlnLeft, maxAlnRight of the queries on the work list
+    uint32_t *elig;            // [alignment count] scratch: the records of a block that are scored (pass 1 -> pass 2)
+    uint32_t *pushBits;        // [alignment count / 32 + 1] bit r: record r enters the queue
+    uint32_t *work; unsigned int *nWork, *fallback;
+};
+__global__ void k_xr_windows(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t nWin, uint32_t *__restrict__ winQ) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nWin) return;
+    const uint64_t x = (uint64_t) b * XR_T;
+    uint32_t lo = 0, hi = n;                 // first q in [0, n) with aoff[q] >= x, n if none
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (aoff[mid] < x) lo = mid + 1; else hi = mid; }
+    winQ[b] = lo;
+}
+__device__ __forceinline__ void xrFill(Cand &c, const AlnRec &rec, uint32_t alnLen, uint32_t tLen, uint32_t qLen0, float seqId, float rySeqId, uint32_t r) {
+    c.qs = rec.qStart; c.qe = rec.qEnd; c.ds = rec.dbStart; c.de = rec.dbEnd; c.target = rec.target; c.alnLen = alnLen; c.dbLen = tLen;
+    c.qLen = qLen0; c.seqId = seqId; c.rySeqId = rySeqId; c.sLenNorm = 0; c.pieceStart = r; c.pieceLen = 0;
+}
+__device__ __forceinline__ uint32_t xrAlnLen(const AlnRec &rec) { return (uint32_t) max(abs(rec.qEnd - rec.qStart), abs(rec.dbEnd - rec.dbStart)) + 1u; }
+__device__ __forceinline__ void xrQuery(VQuery &Q, const ExtArgs &A, uint32_t q, const SeqMeta &qm) {
+    Q.a = &A; Q.q = q; Q.qLen0 = qm.len; Q.qw = qm.woff; Q.cand = nullptr; Q.leftL = nullptr; Q.rightL = nullptr;
+    Q.nL = 0; Q.nR = 0; Q.leftTotal = 0; Q.total = qm.len; Q.plain = (qm.flags & 1u) == 0;
+}
+
+__global__ __launch_bounds__(XR_NT) void k_xr_score(ExtArgs A, XrArgs X) {
+    A.raw = nullptr;
+    __shared__ double sLogLik[11 * 16];
+    __shared__ X87 sLogLikX[11 * 16];
+    __shared__ uint32_t sOff[XR_QCAP + 1], sMaxL[XR_QCAP], sMaxR[XR_QCAP], sCnt[XR_QCAP];
+    // the scored records of the block, ordered by the number of columns (classes of 8) so that the lanes of a wave walk overlaps
+    // of about the same length; beyond XR_LCAP of them: unordered, through the scratch list
+    __shared__ uint32_t sListA[XR_LCAP], sListB[XR_LCAP];
+    __shared__ uint8_t sBinOf[XR_LCAP];
+    __shared__ unsigned int sElig, sBinCnt[XR_BINS], sBinBase[XR_BINS];
+    for (int i = threadIdx.x; i < 11 * 16; i += XR_NT) { const double v = (&A.lut->logLik[0][0][0][0])[i]; sLogLik[i] = v; sLogLikX[i] = x87_from_double(v); }
+    const uint32_t qFirst = X.winQ[blockIdx.x], qEnd = X.winQ[blockIdx.x + 1];
+    const SeqMeta *meta = A.len.m;
+    for (uint32_t qb = qFirst; qb < qEnd; qb += XR_QCAP) {      // (more than XR_QCAP queries in a window: only when some have no record)
+        const uint32_t nq = min((uint32_t) XR_QCAP, qEnd - qb);
+        __syncthreads();
+        const uint64_t ra = A.aoff[qb];
+        for (uint32_t i = threadIdx.x; i <= nq; i += XR_NT) sOff[i] = (uint32_t) (A.aoff[qb + i] - ra);
+        for (uint32_t i = threadIdx.x; i < nq; i += XR_NT) { sMaxL[i] = 0; sMaxR[i] = 0; sCnt[i] = 0; }
+        if (threadIdx.x == 0) sElig = 0;
+        if (threadIdx.x < XR_BINS) sBinCnt[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t nr = sOff[nq];
+        // ---- pass 1: candidates (A-C) and the longest overlap per side
+        for (uint32_t base = 0; base < nr; base += XR_NT) {
+            const uint32_t i = base + threadIdx.x;
+            if (i >= nr) continue;
+            uint32_t lo = 0, hi = nq;                           // owner: the last ordinal with sOff[ord] <= i
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (sOff[mid] <= i) lo = mid; else hi = mid; }
+            const uint32_t ord = lo, q = qb + ord;
+            float2 out = make_float2(NAN, 0.f);
+            if (sOff[ord + 1] - sOff[ord] > 1) {
+                const AlnRec rec = A.rec[ra + i]; const SeqMeta tm = meta[rec.target], qm = meta[q];
+                const uint32_t qLen0 = qm.len, qKey = qm.key, tLen = tm.len;
+                const uint32_t ds = (uint32_t) rec.dbStart, de = (uint32_t) rec.dbEnd, qs = (uint32_t) rec.qStart, qe = (uint32_t) rec.qEnd;
+                const bool rightStart = ds == 0 && qe == (qLen0 - 1);
+                const bool leftStart = qs == 0 && de == (tLen - 1);
+                if ((rightStart || leftStart) && !(rec.qStart > rec.qEnd)) {
+                    const uint32_t alnLen = xrAlnLen(rec);
+                    const bool plain = (qm.flags & 1u) == 0 && (tm.flags & 1u) == 0;
+                    float seqId = rec.seqId, rySeqId = 0.f;
+                    if (rec.target != qKey) {
+                        int idCnt = 0, idRy = 0;
+                        if (plain) countMatchesWordsAt(A.codes, qm.woff, (qLen0 + 15) / 16 - 1, (uint32_t) rec.qStart, tm.woff, (tLen + 15) / 16 - 1, (uint32_t) rec.dbStart, (uint32_t) (rec.qEnd - rec.qStart + 1), idCnt, idRy);
+                        else
+                        for (int j = rec.qStart; j <= rec.qEnd; j++) {
+                            uint32_t qc, tc; bool qn, tn;
+                            letterOf(A, q, qm.woff, (uint32_t) j, qc, qn); letterOf(A, rec.target, tm.woff, (uint32_t) (rec.dbStart + (j - rec.qStart)), tc, tn);
+                            const uint32_t ql = qn ? 4u : qc, tl = tn ? 4u : tc;
+                            idCnt += (ql == tl);
+                            idRy += (ryClass(qn ? 0u : qc) == ryClass(tn ? 0u : tc));
+                        }
+                        seqId = static_cast<float>(idCnt) / alnLen; rySeqId = static_cast<float>(idRy) / alnLen;
+                    }
+                    const bool noOffset = (tLen - alnLen) == 0;
+                    if (((tm.flags >> 1) & 1u) == 0 && alnLen >= 30 && seqId >= A.seqIdThr && !noOffset) {
+                        if (leftStart && rightStart) X.fallback[0] = 1u;
+                        uint32_t mL = 0, mR = 0;
+                        if (plain && rec.target != qKey) {
+                            const uint32_t offset = tLen - alnLen;
+                            const uint32_t tot = leftStart ? min(tLen - offset, qLen0) : min(alnLen, tLen);
+                            if (leftStart) mL = tot; else mR = tot;
+                        } else {
+                            Cand c; xrFill(c, rec, alnLen, tLen, qLen0, seqId, rySeqId, i);
+                            VQuery Q; xrQuery(Q, A, q, qm);
+                            updateIds(A, Q, c, mL, mR);
+                            seqId = c.seqId; rySeqId = c.rySeqId;
+                        }
+                        if (mL) atomicMax(&sMaxL[ord], mL);
+                        if (mR) atomicMax(&sMaxR[ord], mR);
+                        out = make_float2(seqId, rySeqId);
+                        // D's gate (:317-330) needs nothing of the other records: the scored ones go to the block's list
+                        const bool notInside = tLen != alnLen, notId = tm.key != qKey;
+                        if ((rec.dbStart == 0 || rec.qStart == 0) && notInside && notId && rySeqId >= A.rySeqIdThr && seqId >= A.seqIdThr) {
+                            const uint32_t slot = atomicAdd(&sElig, 1u);
+                            if (slot < XR_LCAP) {
+                                const uint32_t bin = min((uint32_t) XR_BINS - 1u, alnLen >> 3);
+                                sListA[slot] = i; sBinOf[slot] = (uint8_t) bin; atomicAdd(&sBinCnt[bin], 1u);
+                            } else X.elig[ra + slot] = i;
+                        }
+                    }
+                }
+            }
+            X.lite[ra + i] = out;
+            X.sLen[ra + i] = NAN;
+            if (A.scores && sOff[ord + 1] - sOff[ord] > 1) A.scores[ra + i] = NAN;
+        }
+        __syncthreads();
+        // ---- pass 2: D - the likelihood of the scored candidates, densely over the list; those above the threshold enter the queue
+        const uint32_t nElig = sElig, nListed = min(nElig, (uint32_t) XR_LCAP);
+        if (threadIdx.x == 0) { unsigned int acc = 0; for (int b = 0; b < XR_BINS; b++) { sBinBase[b] = acc; acc += sBinCnt[b]; } }
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < nListed; k += XR_NT) sListB[atomicAdd(&sBinBase[sBinOf[k]], 1u)] = sListA[k];
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < nElig; k += XR_NT) {
+            const uint32_t i = k < XR_LCAP ? sListB[k] : X.elig[ra + k];
+            uint32_t lo = 0, hi = nq;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (sOff[mid] <= i) lo = mid; else hi = mid; }
+            const uint32_t ord = lo, q = qb + ord;
+            const float2 l = X.lite[ra + i];
+            const AlnRec rec = A.rec[ra + i]; const SeqMeta tm = meta[rec.target], qm = meta[q];
+            Cand c; xrFill(c, rec, xrAlnLen(rec), tm.len, qm.len, l.x, l.y, i);
+            VQuery Q; xrQuery(Q, A, q, qm);
+            const bool pass = scoreCand(A, Q, c, sMaxL[ord], sMaxR[ord], sLogLik, nullptr, sLogLikX);
+            if (A.scores) A.scores[ra + i] = c.sLenNorm;
+            if (pass) {
+                X.sLen[ra + i] = c.sLenNorm;
+                atomicAdd(&sCnt[ord], 1u);
+                atomicOr(&X.pushBits[(ra + i) >> 5], 1u << ((ra + i) & 31u));
+            }
+        }
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < nq; i0 += XR_NT) {
+            const uint32_t i = i0 + threadIdx.x;
+            const bool has = i < nq && sCnt[i] != 0;
+            const uint32_t slot = cdm_block_append(X.nWork, has);
+            if (has) { X.work[slot] = qb + i; X.qMax[2 * (size_t) (qb + i)] = sMaxL[i]; X.qMax[2 * (size_t) (qb + i) + 1] = sMaxR[i]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64, 8) void k_xr_extend(ExtArgs A, XrArgs X) {
+    A.raw = nullptr;
+    __shared__ double sLogLik[11 * 16];
+    for (int i = threadIdx.x; i < 11 * 16; i += blockDim.x) sLogLik[i] = (&A.lut->logLik[0][0][0][0])[i];
+    __syncthreads();
+    const unsigned int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= *X.nWork) return;
+    const uint32_t q = X.work[item];
+    const SeqMeta *meta = A.len.m;
+    const SeqMeta qm = meta[q];
+    const uint64_t r0 = A.aoff[q];
+    const uint32_t nRec = (uint32_t) (A.aoff[q + 1] - r0);
+    Cand *cand = A.cand + r0;
+    uint32_t *heapL = A.lists + 4 * r0, *parkL = heapL + nRec, *leftL = parkL + nRec, *rightL = leftL + nRec;
+    VQuery Q; xrQuery(Q, A, q, qm); Q.cand = cand; Q.leftL = leftL; Q.rightL = rightL;
+    Heap heap; heap.h = heapL; heap.n = 0; heap.cand = cand;
+    uint32_t nCand = 0;
+    for (uint64_t w = r0 >> 5; w <= (r0 + nRec - 1) >> 5; w++) {          // the records that enter the queue, in record order
+        uint32_t bits = X.pushBits[w];
+        if (w == (r0 >> 5)) bits &= ~0u << (r0 & 31u);
+        if (w == ((r0 + nRec) >> 5)) bits &= ~(~0u << ((r0 + nRec) & 31u));
+        while (bits) {
+            const uint32_t b = (uint32_t) __ffs((int) bits) - 1u;
+            bits &= bits - 1u;
+            const uint64_t ri = (w << 5) + b;
+            const AlnRec rec = A.rec[ri]; const float2 l = X.lite[ri];
+            Cand c; xrFill(c, rec, xrAlnLen(rec), meta[rec.target].len, qm.len, l.x, l.y, (uint32_t) (ri - r0));
+            c.sLenNorm = X.sLen[ri];
+            cand[nCand] = c;
+            heap.push(nCand++);
+        }
+    }
+    extendLoop(A, Q, cand, heap, parkL, leftL, rightL, X.qMax[2 * (size_t) q], X.qMax[2 * (size_t) q + 1], sLogLik, qm.key, q);
 }
 
 __global__ void k_mark_active2(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t *__restrict__ active, unsigned int *__restrict__ nActive,
@@ -633,9 +853,30 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     hipEventRecord(ctx->ev0, s);
     const char *padEnv = getenv("CDM_LDS_PAD");          // experiments: dynamic LDS that lowers the occupancy
     const char *wEnv = getenv("CDM_EXTEND_WAVES");        // experiments: waves per SIMD the register allocation leaves room for
+    const char *formEnv = getenv("CDM_EXTEND");           // "queries": k_extend (one lane per query) for every call
     const int minW = wEnv ? atoi(wEnv) : 8;
     const unsigned padB = padEnv ? (unsigned) atoi(padEnv) : 0u;
-    if (hAct && db->raw) hipLaunchKernelGGL((k_extend<8, true>), dim3((hAct + 63) / 64), dim3(64), padB, s, A);
+    // one thread per record for A-D (k_xr_*) where that form applies: the default mode, no raw plane
+    bool perRecord = hAct && !db->raw && !A.unsafe && alns->count < 0xFFFFFFFFull / 2 && !(formEnv && !strcmp(formEnv, "queries"));
+    DevBuf<uint32_t> winQ, qMax, work, elig, pushBits; DevBuf<float2> lite; DevBuf<double> sLen;
+    if (perRecord) {
+        const uint32_t nWin = (uint32_t) ((alns->count + XR_T - 1) / XR_T);
+        if (!winQ.alloc((size_t) nWin + 1) || !qMax.alloc(2 * (size_t) n) || !work.alloc(hAct) || !lite.alloc(alns->count) || !sLen.alloc(alns->count) ||
+            !elig.alloc(alns->count) || !pushBits.alloc(alns->count / 32 + 2)) {
+            cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP;
+        }
+        hipMemsetAsync(pushBits.p, 0, (alns->count / 32 + 2) * 4, s);
+        XrArgs X; X.elig = elig.p; X.pushBits = pushBits.p; X.winQ = winQ.p; X.lite = lite.p; X.sLen = sLen.p; X.qMax = qMax.p; X.work = work.p; X.nWork = nActive.p + 1; X.fallback = flags.p + 1;
+        hipLaunchKernelGGL(k_xr_windows, dim3(nWin / 256 + 1), dim3(256), 0, s, alns->off, n, nWin, winQ.p);
+        hipLaunchKernelGGL(k_xr_score, dim3(nWin), dim3(XR_NT), 0, s, A, X);
+        unsigned int fb = 0;
+        hipMemcpyAsync(&fb, flags.p + 1, 4, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_extend: scoring kernel failed"); return CDM_ERR_HIP; }
+        if (fb) perRecord = false;          // a candidate that overlaps on both sides at once: the maxima depend on the record order
+        else hipLaunchKernelGGL(k_xr_extend, dim3((hAct + 63) / 64), dim3(64), padB, s, A, X);
+    }
+    if (perRecord) {}
+    else if (hAct && db->raw) hipLaunchKernelGGL((k_extend<8, true>), dim3((hAct + 63) / 64), dim3(64), padB, s, A);
     else if (hAct && minW == 8) hipLaunchKernelGGL(k_extend<8>, dim3((hAct + 63) / 64), dim3(64), padB, s, A);
     else if (hAct && minW == 6) hipLaunchKernelGGL(k_extend<6>, dim3((hAct + 63) / 64), dim3(64), padB, s, A);
     else if (hAct) hipLaunchKernelGGL(k_extend<5>, dim3((hAct + 63) / 64), dim3(64), padB, s, A);

@@ -76,7 +76,7 @@ def main():
                                  "aggv::", "k_self", "k_offsets", "k_len_keys", "k_slot_", "k_live_count", "k_stale_tail", "k_reduce_stats", "k_big_", "k_head_segment", "k_count_hash", "cdmscan")),
                 ("rescorediagonal", ("k_rescore", "k_expand", "k_count_valid", "k_scatter", "k_min_score")),
                 ("ancient_correction", ("k_correct", "k_mark_active<", "k_mark_active(")),
-                ("ancient_read_assemble", ("k_extend", "k_write", "k_out_meta", "k_mark_active2")))
+                ("ancient_read_assemble", ("k_extend", "k_xr_", "k_write", "k_out_meta", "k_mark_active2")))
     stages = {name: 0.0 for name, _ in stage_of}
     stages["other (synthetic reads, metadata, copies)"] = 0.0
     for k in fetch:

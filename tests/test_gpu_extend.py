@@ -18,6 +18,15 @@ def ctx(dhigh_prefix):
     return c
 
 
+@pytest.fixture(params=["records", "queries"])
+def form(request, monkeypatch):
+    """The two forms of the extension kernel (extend.hip): A-D with one thread per record (k_xr_*, the default where it applies) and
+    one lane per query for everything (k_extend; CDM_EXTEND=queries)."""
+    if request.param == "queries":
+        monkeypatch.setenv("CDM_EXTEND", "queries")
+    return request.param
+
+
 def extend(ctx, corr_keyed, aln_keyed, want_scores=False):
     db = ctx.upload_keyed_seqdb(corr_keyed)
     _, keys, _ = db.meta()
@@ -30,7 +39,7 @@ def extend(ctx, corr_keyed, aln_keyed, want_scores=False):
 
 
 @pytest.mark.parametrize("name,its", DATASETS)
-def test_extension_matches_golden_and_scores_match_oracle(ctx, oracle_bin, dhigh_prefix, tmp_path, name, its):
+def test_extension_matches_golden_and_scores_match_oracle(ctx, oracle_bin, dhigh_prefix, tmp_path, name, its, form):
     for it in range(its):
         corr, aln = gold(name, "corr", it), gold(name, "aln", it)
         got, (off, rec, keys, scores) = extend(ctx, corr, aln, want_scores=True)
@@ -59,7 +68,7 @@ def test_extension_matches_golden_and_scores_match_oracle(ctx, oracle_bin, dhigh
         assert not bad, (name, it, bad[:3], [(got_scores[k], exp[k]) for k in bad[:3]])
 
 
-def test_extension_with_N_and_max_seq_len(ctx, oracle_bin, dhigh_prefix, tmp_path):
+def test_extension_with_N_and_max_seq_len(ctx, oracle_bin, dhigh_prefix, tmp_path, form):
     from carpedeam_amd import synth
     rng = np.random.default_rng(21)
     seqs = synth.generate_strings(1500, seed=13, mixed=(40, 150))
@@ -83,7 +92,7 @@ def test_extension_with_N_and_max_seq_len(ctx, oracle_bin, dhigh_prefix, tmp_pat
         assert sum(v[1] for v in exp.values()) > 50
 
 
-def test_extension_deep_coverage_many_rounds(ctx, oracle_bin, dhigh_prefix, tmp_path):
+def test_extension_deep_coverage_many_rounds(ctx, oracle_bin, dhigh_prefix, tmp_path, form):
     """100x coverage, two iterations: dozens of candidates per query, many equal scores (heap tie order), several
     re-alignment rounds per query, and extended sequences as queries in the second iteration."""
     from carpedeam_amd import synth
@@ -100,6 +109,27 @@ def test_extension_deep_coverage_many_rounds(ctx, oracle_bin, dhigh_prefix, tmp_
         exp = mmdb.read_db(t("in%d" % (it + 1)))
         assert not diff_keys(got, exp), it
         assert sum(v[1] for v in exp.values()) > 100
+
+
+def test_both_forms_identical_at_scale(ctx, monkeypatch):
+    """1 M reads at 20x coverage and a mixed-length set with pile-ups of hundreds of records: sequences, flags and every likelihood
+    score of the record-parallel form equal those of the lane-per-query form."""
+    for n, lo, hi, seed in ((1_000_000, 100, 100, 5), (300_000, 40, 150, 9)):
+        db = ctx.synth(n, lo, hi, seed)
+        alns = ctx.rescore(db, ctx.kmermatch(db))
+        corr = ctx.correct(db, alns)
+        out = {}
+        for f in ("records", "queries"):
+            if f == "queries":
+                monkeypatch.setenv("CDM_EXTEND", "queries")
+            asm, scores = ctx.extend(corr, alns, want_scores=True)
+            monkeypatch.delenv("CDM_EXTEND", raising=False)
+            seqs, keys, ext = asm.download()
+            out[f] = (seqs, keys, ext, scores)
+        a, b = out["records"], out["queries"]
+        assert int((~np.isnan(b[3])).sum()) > n // 2 and int(b[2].sum()) > n // 20
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(a[3], b[3], equal_nan=True)
 
 
 @pytest.mark.parametrize("name,it,min_cov", [("synth2k", 0, 1), ("synth2k", 1, 2), ("mixed3k", 0, 5), ("mixed3k", 2, 1), ("example", 0, 2)])
