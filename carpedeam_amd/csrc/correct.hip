@@ -276,6 +276,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void k_correct(CorrectArgs a)
 // phase (RY identity on 16-base words, XOR + popcount) and keeps the record, lane = position in the pile-up.
 // Same arithmetic as k_correct; 8-bit (4-bit) pile-up counters (a slot cannot exceed the 64 (15) records).
 constexpr int FAST_WAVES = 4;
+// Target words staged in LDS per record (lane = record loads the words its aligned span covers, all records at once): the pile-up
+// then takes its letters from LDS instead of one dependent global load per record and 64 positions.  12 words hold a span of 177
+// columns wherever it starts; longer spans and targets with N keep the global path.
+constexpr int STAGE_WORDS = 12;
 
 // MAXREC: most records of a query on this instance (64, or 15 with CT = uint8_t: two 4-bit fields per counter and a quarter of the
 // record slots - less LDS per block, more waves per CU; the kernel is bound by the latency of its dependent gathers, so the
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, MINW) void k_correct_fast(CorrectA
     constexpr int PER = 4 / sizeof(CT);                 // counters per LDS dword
     __shared__ double sLogT[16], sLogQ[12 * 16], sLogD[2 * 11 * 16];
     __shared__ uint32_t sCnt[FAST_WAVES][SLOTS * (64 / PER)];      // counter [slot][lane], PER lanes to a word
+    __shared__ uint32_t sStage[FAST_WAVES][(MAXREC == 64 ? 64 : 16) * STAGE_WORDS];
     for (int i = threadIdx.x; i < 16; i += blockDim.x) sLogT[i] = (&a.lut->logT[0][0])[i];
     for (int i = threadIdx.x; i < 12 * 16; i += blockDim.x) sLogQ[i] = (&a.lut->logQ[0][0][0])[i];
     for (int i = threadIdx.x; i < 2 * 11 * 16; i += blockDim.x) sLogD[i] = (&a.lut->logD[0][0][0][0])[i];
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, MINW) void k_correct_fast(CorrectA
     const unsigned int nItems = *nList;
     // the pile-up adds to a counter with ONE LDS atomic on the word that holds it (the lanes that share the word are serialised by
     // the LDS): word index of this lane's counter inside a slot row, and the lane's increments shifted to its place in the word
-    uint32_t *cntWords = sCnt[wave];
+    uint32_t *cntWords = sCnt[wave], *stage = sStage[wave];
     const uint32_t laneWord = (uint32_t) lane / PER, laneShift = ((uint32_t) lane % PER) * (8 * sizeof(CT));
     const uint32_t incFwd = 1u << laneShift, incRev = (1u | (1u << HB)) << laneShift;
     const uint32_t laneClear = ~((uint32_t) (CT) ~(CT) 0 << laneShift);
@@ -313,6 +318,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, MINW) void k_correct_fast(CorrectA
         const float avCov = static_cast<float>(static_cast<float>(cdm_wave_sum((int) aLen))) / qLen;
         bool ok = false;
         uint32_t iTw = 0, iLenFlags = 0, iQs = 0, iSpan = 0, iDs = 0;     // the record as the pile-up needs it, kept in this lane's registers
+        uint32_t iW0 = 0;                                                 // bit 31: the span's words are staged, from this word of the target on
         if (have) {
             const uint32_t t = rec.target, tLen = a.len[t], tw = a.woff[t];
             const bool tHasN = a.hasN[t] != 0;
@@ -350,8 +356,17 @@ __global__ __launch_bounds__(64 * FAST_WAVES, MINW) void k_correct_fast(CorrectA
             }
             // sequences on this path are shorter than 2^30 letters (the DB's word offsets are 32 bit)
             iTw = tw; iLenFlags = tLen | (o.rev ? 0x80000000u : 0u) | (tHasN ? 0x40000000u : 0u); iQs = (uint32_t) o.qs; iSpan = (uint32_t) (o.qe - o.qs); iDs = (uint32_t) o.ds;
+            if (ok && !tHasN) {
+                const uint32_t fLo = o.rev ? tLen - 1u - (iDs + iSpan) : iDs;       // the span on the target as stored
+                const uint32_t w0 = fLo >> 4, nW = ((fLo + iSpan) >> 4) - w0 + 1u;
+                if (nW <= (uint32_t) STAGE_WORDS) {
+                    for (uint32_t j = 0; j < nW; j++) stage[lane * STAGE_WORDS + j] = a.codes[tw + w0 + j];
+                    iW0 = w0 | 0x80000000u;
+                }
+            }
         }
         const uint64_t okMask = __ballot(ok);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // ---- pile-up + call, 64 positions at a time.  The record fields are wave-uniform: they are read out of the owning lane into
         // scalar registers, the per-lane work is the target letter, its damage class and one LDS add.
@@ -366,11 +381,17 @@ __global__ __launch_bounds__(64 * FAST_WAVES, MINW) void k_correct_fast(CorrectA
                 if (qs + span < base || qs >= base + 64) continue;   // wave uniform
                 const uint32_t lf = (uint32_t) __builtin_amdgcn_readlane((int) iLenFlags, r), tw = (uint32_t) __builtin_amdgcn_readlane((int) iTw, r);
                 const uint32_t ds = (uint32_t) __builtin_amdgcn_readlane((int) iDs, r), tLen = lf & 0x3FFFFFFFu;
+                const uint32_t w0f = (uint32_t) __builtin_amdgcn_readlane((int) iW0, r);
                 const uint32_t d = p - qs;
                 if (d <= span) {
                     const uint32_t tpos = ds + d;                            // position on the oriented target
                     uint32_t tb;
-                    if (lf & 0x40000000u) tb = targetBase(a, tw, tLen, true, (lf & 0x80000000u) != 0, tpos);
+                    if (w0f & 0x80000000u) {
+                        const bool rev = (lf & 0x80000000u) != 0;
+                        const uint32_t f = rev ? tLen - 1u - tpos : tpos;
+                        tb = (stage[(uint32_t) r * STAGE_WORDS + (f >> 4) - (w0f & 0x7FFFFFFFu)] >> ((f & 15u) * 2u)) & 3u;
+                        if (rev) tb = 3u - tb;
+                    } else if (lf & 0x40000000u) tb = targetBase(a, tw, tLen, true, (lf & 0x80000000u) != 0, tpos);
                     else if (lf & 0x80000000u) tb = 3u - cdm_base(a.codes, tw, tLen - 1u - tpos);
                     else tb = cdm_base(a.codes, tw, tpos);
                     // damage class 0..4 from the 5' end, 6..10 at the 3' end, 5 inside (accepted records are at least 30 columns long)
