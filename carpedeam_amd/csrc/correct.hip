@@ -304,17 +304,36 @@ __global__ __launch_bounds__(64 * FAST_WAVES, MINW) void k_correct_fast(CorrectA
     const uint32_t incFwd = 1u << laneShift, incRev = (1u | (1u << HB)) << laneShift;
     const uint32_t laneClear = ~((uint32_t) (CT) ~(CT) 0 << laneShift);
     for (int s = lane; s < SLOTS * (64 / PER); s += 64) cntWords[s] = 0;       // a lane clears the slots it touched after every call
-    for (unsigned int item = blockIdx.x * FAST_WAVES + wave; item < nItems; item += gridDim.x * FAST_WAVES) {
-        const uint32_t q = list[item];
-        const uint32_t qLen = a.len[q], qw = a.woff[q];
-        const bool qHasN = a.hasN[q] != 0, qWasExt = a.ext[q] != 0;
-        const uint64_t r0 = a.aoff[q];
-        const uint32_t nRec = (uint32_t) (a.aoff[q + 1] - r0);
+    // The chain list -> record offsets + query metadata -> records is walked one query AHEAD: the next query's offsets and metadata are
+    // requested at the top of an iteration, its records (one per lane) and their RY counts once the gate of the current query is through,
+    // so that they arrive while the pile-up runs.  (Wave-uniform values are moved to scalar registers.)
+    const unsigned int stride = gridDim.x * FAST_WAVES;
+    unsigned int item = blockIdx.x * FAST_WAVES + wave;
+    const SeqMeta *meta = a.len.m;
+    auto uni = [](uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); };
+    uint32_t qCur = 0, qNext = 0; SeqMeta qmCur = {0, 0, 0, 0}; uint64_t r0Cur = 0; uint32_t nRecCur = 0; AlnRec recCur = {}; uint32_t ryCur = 0xFFFFu;
+    if (item < nItems) {
+        qCur = uni(list[item]); qmCur = meta[qCur]; r0Cur = a.aoff[qCur]; nRecCur = (uint32_t) (a.aoff[qCur + 1] - r0Cur);
+        if ((uint32_t) lane < nRecCur) { recCur = a.rec[r0Cur + lane]; if (a.ry) ryCur = a.ry[r0Cur + lane]; }
+        if (item + stride < nItems) qNext = uni(list[item + stride]);
+    }
+    for (; item < nItems; item += stride) {
+        const uint32_t q = qCur;
+        const uint32_t qLen = uni(qmCur.len), qw = uni(qmCur.woff);
+        const bool qHasN = (uni(qmCur.flags) & 1u) != 0, qWasExt = (uni(qmCur.flags) & 2u) != 0;
+        const uint64_t r0 = ((uint64_t) uni((uint32_t) (r0Cur >> 32)) << 32) | uni((uint32_t) r0Cur);
+        const uint32_t nRec = uni(nRecCur);
         const uint32_t qLast = (qLen + 15) / 16 - 1;
+        const bool hasNext = item + stride < nItems;
+        const uint32_t qN = qNext;
+        SeqMeta qmN = {0, 0, 0, 0}; uint64_t r0N = 0, r1N = 0;
+        if (hasNext) { qmN = meta[qN]; r0N = a.aoff[qN]; r1N = a.aoff[qN + 1]; }
+        if (item + 2 * stride < nItems) qNext = uni(list[item + 2 * stride]);
         // ---- gate phase, lane = record
-        AlnRec rec; uint32_t aLen = 0;
+        const AlnRec rec = recCur; uint32_t aLen = 0;
+        const uint32_t ryOfRec = ryCur;
         const bool have = (uint32_t) lane < nRec;
-        if (have) { rec = a.rec[r0 + lane]; aLen = alnLength(rec); }
+        if (have) aLen = alnLength(rec);
         const float avCov = static_cast<float>(static_cast<float>(cdm_wave_sum((int) aLen))) / qLen;
         bool ok = false;
         uint32_t iTw = 0, iLenFlags = 0, iQs = 0, iSpan = 0, iDs = 0;     // the record as the pile-up needs it, kept in this lane's registers
@@ -325,7 +344,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, MINW) void k_correct_fast(CorrectA
             const Oriented o = orient(rec, tLen);
             ok = a.ext[t] == 0;
             if (ok) {
-                uint32_t mism = a.ry ? a.ry[r0 + lane] : 0xFFFFu;
+                uint32_t mism = ryOfRec;
                 if (mism != 0xFFFFu) {
                     // counted by cdm_rescore on the same columns
                 } else if (!qHasN && !tHasN) {
@@ -367,6 +386,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES, MINW) void k_correct_fast(CorrectA
         }
         const uint64_t okMask = __ballot(ok);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the next query's records, on their way during the pile-up
+        qCur = qN; qmCur = qmN; r0Cur = r0N; nRecCur = (uint32_t) (r1N - r0N); ryCur = 0xFFFFu;
+        if (hasNext && (uint32_t) lane < nRecCur) { recCur = a.rec[r0N + lane]; if (a.ry) ryCur = a.ry[r0N + lane]; }
 
         // ---- pile-up + call, 64 positions at a time.  The record fields are wave-uniform: they are read out of the owning lane into
         // scalar registers, the per-lane work is the target letter, its damage class and one LDS add.
