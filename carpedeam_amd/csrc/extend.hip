@@ -33,6 +33,7 @@ struct Cand {
     float seqId, rySeqId;
     double sLenNorm;
     uint32_t pieceStart, pieceLen;   // set when the candidate donated a fragment
+    uint32_t tKey;                   // the target's DB key (the extension loop compares it with the query's at every pop)
 };
 
 struct ExtArgs {
@@ -50,6 +51,7 @@ struct ExtArgs {
     float seqIdThr, rySeqIdThr, likelihoodThr;
     float excessLog, randLog;   // logf(excessPenal), logf(randAlnPenal) from the host
     double ratioLogit;          // log(1/thr - 1): sRatio > thr  <=>  randAln - likMod < ratioLogit
+    float marginScale;          // 1 (CDM_EXTEND_MARGIN, tests: scales the error bounds of the plain-double likelihoods)
     uint64_t maxSeqLen;
     int unsafe; uint32_t minCov;        // --unsafe 1: consensusCaller's majority vote over the extending targets (--min-cov-safe)
     unsigned int *flags;                // [0] set when an unsafe-mode consensus would write outside its 3 qLen letters (undefined in the reference)
@@ -309,6 +311,49 @@ __device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t m
     return x < A.ratioLogit;
 }
 
+// The same for an end overlap of two sequences without N, in plain double - with a bound on how far that can be from what
+// scoreCand() returns, so that the caller knows when the cheap sum decides.  The reference adds the alnCount column terms and the
+// excess penalty one by one into a long double (64-bit significand, error <= 2^-64 per addition relative to the running sum) and
+// rounds once to double; the plain sum errs by <= 2^-53 per addition.  With S = the sum of the |terms| (every running sum is
+// below it), both sums lie within (alnCount + 2) * 2^-53 * S of the exact one; bound = (alnCount + 8) * 2^-52 * S is more than
+// twice that.  Returns 1 / 0 when randAln - sum lies outside ratioLogit +- bound (scoreCand's answer is then the same), -1 when not;
+// sLenNorm = the plain sum, bound as above.
+__device__ int scoreCandApprox(const ExtArgs &A, const VQuery &Q, const Cand &c, uint32_t maxLeft, uint32_t maxRight, const double *logLik, double &sLenNorm, float &bound) {
+    const uint32_t qLen = Q.total;
+    const bool leftStart = (uint32_t) c.qs == 0 && (uint32_t) c.de == (c.dbLen - 1);
+    const uint32_t maxAln = leftStart ? maxLeft : maxRight;
+    const uint32_t offset = c.dbLen - c.alnLen;
+    uint32_t q0, t0, ncol;
+    if (leftStart) { t0 = offset; q0 = 0; ncol = min(c.dbLen - offset, qLen); }
+    else { t0 = 0; q0 = qLen - c.alnLen; ncol = min(c.alnLen, c.dbLen); }
+    const uint32_t qw = A.woff[Q.q], tw = A.woff[c.target];
+    const uint32_t qLast = (Q.qLen0 + 15) / 16 - 1, tLast = (c.dbLen + 15) / 16 - 1, tailFrom = c.dbLen - 5;
+    double sum = 0.0, mag = 0.0;
+    uint32_t qNext = cdm_window16(A.codes, qw, q0, qLast), tNext = cdm_window16(A.codes, tw, t0, tLast);
+    for (uint32_t k = 0; k < ncol; k += 16) {
+        uint32_t qwin = qNext, twin = tNext;
+        if (k + 16 < ncol) { qNext = cdm_window16(A.codes, qw, q0 + k + 16, qLast); tNext = cdm_window16(A.codes, tw, t0 + k + 16, tLast); }
+        const uint32_t m = min(16u, ncol - k);
+        for (uint32_t j = 0; j < m; j++) {
+            const uint32_t ti = t0 + k + j;
+            const uint32_t cls = ti < 5 ? ti : (ti >= tailFrom ? 6 + (ti - tailFrom) : 5);
+            const double t = logLik[(cls * 4 + (qwin & 3u)) * 4 + (twin & 3u)];
+            sum = __dadd_rn(sum, t); mag = __dadd_rn(mag, fabs(t));
+            qwin >>= 2; twin >>= 2;
+        }
+    }
+    const uint32_t excess = maxAln - ncol;
+    const double pen = (double) ((float) excess * A.excessLog);
+    sum = __dadd_rn(sum, pen); mag = __dadd_rn(mag, fabs(pen));
+    const double randAln = (double) ((float) maxAln * A.randLog);
+    const double b = (double) (ncol + 8u) * 0x1p-52 * (mag + fabs(randAln)) * (double) A.marginScale;
+    sLenNorm = sum; bound = (float) b * 1.0000002f + 1e-37f;       // (rounded up: the float is what the queue's near-tie test adds)
+    const double x = __dadd_rn(randAln, -sum);
+    if (x < A.ratioLogit - b) return 1;
+    if (x > A.ratioLogit + b) return 0;
+    return -1;
+}
+
 // ---- std::priority_queue<scorePerRes, vector, CompareNuclResultByScoreReads> on candidate indices (libstdc++ heap order)
 struct Heap {
     uint32_t *h; uint32_t n; const Cand *cand;
@@ -350,11 +395,11 @@ __device__ void extendLoop(const ExtArgs &A, VQuery &Q, Cand *cand, Heap &heap, 
                 const bool notBoth = !(c.ds == 0 && c.qs == 0);
                 const bool rightStart = c.ds == 0 && (c.de != static_cast<int>(c.dbLen) - 1);
                 const bool leftStart = c.qs == 0 && (c.qe != static_cast<int>(c.qLen) - 1);
-                if ((rightStart || leftStart) && notBoth && A.key[c.target] != qKey) { found = true; bi = k; break; }
+                if ((rightStart || leftStart) && notBoth && c.tKey != qKey) { found = true; bi = k; break; }
             }
             if (!found) break;
             Cand &b = cand[bi];
-            const uint32_t tLen = A.len[b.target];
+            const uint32_t tLen = b.dbLen;                   // (= the target's length, since the candidate was made)
             if (b.ds == 0) { if ((tLen - (uint32_t) (b.de + 1)) <= rightOff) continue; }
             else if (b.qs == 0) { if (b.ds <= static_cast<int>(leftOff)) continue; }
             const uint32_t ds = (uint32_t) b.ds, de = (uint32_t) b.de, qs = (uint32_t) b.qs, qe = (uint32_t) b.qe;
@@ -423,7 +468,7 @@ __device__ void extendLoop(const ExtArgs &A, VQuery &Q, Cand *cand, Heap &heap, 
         for (uint32_t i = 0; i < nPark; i++) {
             Cand &c = cand[parkL[i]];
             const bool notInside = c.dbLen != c.alnLen;
-            const bool rightStart = c.ds == 0, leftStart = c.qs == 0, notId = A.key[c.target] != qKey;
+            const bool rightStart = c.ds == 0, leftStart = c.qs == 0, notId = c.tKey != qKey;
             if (c.seqId >= A.seqIdThr && (rightStart || leftStart) && notId && notInside) {
                 if (scoreCand(A, Q, c, maxLeft, maxRight, sLogLik, cons1)) heap.push(parkL[i]);
             }
@@ -487,6 +532,7 @@ __global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
         if (((tm.flags >> 1) & 1u) == 0 && alnLen >= 30 && seqId >= A.seqIdThr && !noOffset) {
             Cand c; c.qs = rec.qStart; c.qe = rec.qEnd; c.ds = rec.dbStart; c.de = rec.dbEnd; c.target = rec.target; c.alnLen = alnLen; c.dbLen = tLen;
             c.qLen = qLen0; c.seqId = seqId; c.rySeqId = rySeqId; c.sLenNorm = 0; c.pieceStart = r; c.pieceLen = 0;   // pieceStart keeps the record index until used
+            c.tKey = tm.key;
             cand[nCand++] = c;
         }
     }
@@ -512,7 +558,7 @@ __global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
     for (uint32_t k = 0; k < nCand; k++) {
         Cand &c = cand[k];
         const bool notInside = c.dbLen != c.alnLen;
-        const bool rightStart = c.ds == 0, leftStart = c.qs == 0, notId = A.key[c.target] != qKey;
+        const bool rightStart = c.ds == 0, leftStart = c.qs == 0, notId = c.tKey != qKey;
         if ((rightStart || leftStart) && notInside && notId && c.rySeqId >= A.rySeqIdThr && c.seqId >= A.seqIdThr) {
             const bool pass = scoreCand(A, Q, c, maxLeft, maxRight, sLogLik, cons0);
             if (A.scores) A.scores[r0 + c.pieceStart] = c.sLenNorm;
@@ -532,7 +578,7 @@ __global__ __launch_bounds__(64, MINW) void k_extend(ExtArgs A) {
 //   k_xr_windows   the records are cut into windows of XR_T; a block owns the queries whose FIRST record lies in its window
 //   k_xr_score     per block: pass 1 - one thread per record: candidate test + identities (:202-315, updateSeqIdConsensusReads),
 //                  maximum per side into LDS; pass 2 - eligibility + calcLikelihoodConsensus per record (:317-372), sLenNorm of the
-//                  records that enter the queue to sLen[] (NaN otherwise); queries with at least one such record to the work list
+//                  records that enter the queue to sLen[]; queries with at least one such record to the work list
 //   k_xr_extend    one thread per query of the work list: queue in record order (the push order of the reference), extendLoop()
 // Same arithmetic, same order of pushes; a candidate that is a left AND a right overlap at once (whose contribution to the two
 // maxima depends on the order of the records in the reference) sets X.fallback and the call is redone by k_extend.
@@ -540,7 +586,8 @@ constexpr int XR_NT = 512, XR_T = 448, XR_QCAP = 512, XR_LCAP = 1024, XR_BINS = 
 struct XrArgs {
     const uint32_t *winQ;      // [windows + 1] first query of every window
     float2 *lite;              // [alignment count] (seqId, rySeqId) of a candidate record; seqId = NaN: not a candidate
-    double *sLen;              // [alignment count] sLenNorm of a record that enters the queue, NaN otherwise
+    double *sLen;              // [alignment count] sLenNorm of a record that enters the queue (bit set in pushBits)
+    float *sBound;             // [alignment count] 0: sLen is scoreCand's value; > 0: the plain-double sum, within this of it (scoreCandApprox)
     uint32_t *qMax;            // [2 n] maxAlnLeft, maxAlnRight of the queries on the work list
     uint32_t *elig;            // [alignment count] scratch: the records of a block that are scored (pass 1 -> pass 2)
     uint32_t *pushBits;        // [alignment count / 32 + 1] bit r: record r enters the queue
@@ -554,7 +601,8 @@ __global__ void k_xr_windows(const uint64_t *__restrict__ aoff, uint32_t n, uint
     while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (aoff[mid] < x) lo = mid + 1; else hi = mid; }
     winQ[b] = lo;
 }
-__device__ __forceinline__ void xrFill(Cand &c, const AlnRec &rec, uint32_t alnLen, uint32_t tLen, uint32_t qLen0, float seqId, float rySeqId, uint32_t r) {
+__device__ __forceinline__ void xrFill(Cand &c, const AlnRec &rec, uint32_t alnLen, const SeqMeta &tm, uint32_t qLen0, float seqId, float rySeqId, uint32_t r) {
+    const uint32_t tLen = tm.len; c.tKey = tm.key;
     c.qs = rec.qStart; c.qe = rec.qEnd; c.ds = rec.dbStart; c.de = rec.dbEnd; c.target = rec.target; c.alnLen = alnLen; c.dbLen = tLen;
     c.qLen = qLen0; c.seqId = seqId; c.rySeqId = rySeqId; c.sLenNorm = 0; c.pieceStart = r; c.pieceLen = 0;
 }
@@ -627,7 +675,7 @@ __global__ __launch_bounds__(XR_NT) void k_xr_score(ExtArgs A, XrArgs X) {
                             const uint32_t tot = leftStart ? min(tLen - offset, qLen0) : min(alnLen, tLen);
                             if (leftStart) mL = tot; else mR = tot;
                         } else {
-                            Cand c; xrFill(c, rec, alnLen, tLen, qLen0, seqId, rySeqId, i);
+                            Cand c; xrFill(c, rec, alnLen, tm, qLen0, seqId, rySeqId, i);
                             VQuery Q; xrQuery(Q, A, q, qm);
                             updateIds(A, Q, c, mL, mR);
                             seqId = c.seqId; rySeqId = c.rySeqId;
@@ -647,8 +695,7 @@ __global__ __launch_bounds__(XR_NT) void k_xr_score(ExtArgs A, XrArgs X) {
                     }
                 }
             }
-            X.lite[ra + i] = out;
-            X.sLen[ra + i] = NAN;
+            if (out.x == out.x) X.lite[ra + i] = out;              // (read back for the records on the block's list / with a push bit only)
             if (A.scores && sOff[ord + 1] - sOff[ord] > 1) A.scores[ra + i] = NAN;
         }
         __syncthreads();
@@ -665,12 +712,17 @@ __global__ __launch_bounds__(XR_NT) void k_xr_score(ExtArgs A, XrArgs X) {
             const uint32_t ord = lo, q = qb + ord;
             const float2 l = X.lite[ra + i];
             const AlnRec rec = A.rec[ra + i]; const SeqMeta tm = meta[rec.target], qm = meta[q];
-            Cand c; xrFill(c, rec, xrAlnLen(rec), tm.len, qm.len, l.x, l.y, i);
+            Cand c; xrFill(c, rec, xrAlnLen(rec), tm, qm.len, l.x, l.y, i);
             VQuery Q; xrQuery(Q, A, q, qm);
-            const bool pass = scoreCand(A, Q, c, sMaxL[ord], sMaxR[ord], sLogLik, nullptr, sLogLikX);
+            // the plain-double sum decides unless it lies within its error bound of the threshold (or the scores are asked for)
+            bool pass; float bnd = 0.f;
+            int quick = -1;
+            if (!A.scores && Q.plain && (tm.flags & 1u) == 0) { double sl; quick = scoreCandApprox(A, Q, c, sMaxL[ord], sMaxR[ord], sLogLik, sl, bnd); c.sLenNorm = sl; }
+            if (quick < 0) { pass = scoreCand(A, Q, c, sMaxL[ord], sMaxR[ord], sLogLik, nullptr, sLogLikX); bnd = 0.f; }
+            else pass = quick != 0;
             if (A.scores) A.scores[ra + i] = c.sLenNorm;
             if (pass) {
-                X.sLen[ra + i] = c.sLenNorm;
+                X.sLen[ra + i] = c.sLenNorm; X.sBound[ra + i] = bnd;
                 atomicAdd(&sCnt[ord], 1u);
                 atomicOr(&X.pushBits[(ra + i) >> 5], 1u << ((ra + i) & 31u));
             }
@@ -702,6 +754,7 @@ __global__ __launch_bounds__(64, 8) void k_xr_extend(ExtArgs A, XrArgs X) {
     VQuery Q; xrQuery(Q, A, q, qm); Q.cand = cand; Q.leftL = leftL; Q.rightL = rightL;
     Heap heap; heap.h = heapL; heap.n = 0; heap.cand = cand;
     uint32_t nCand = 0;
+    const uint32_t maxL0 = X.qMax[2 * (size_t) q], maxR0 = X.qMax[2 * (size_t) q + 1];
     for (uint64_t w = r0 >> 5; w <= (r0 + nRec - 1) >> 5; w++) {          // the records that enter the queue, in record order
         uint32_t bits = X.pushBits[w];
         if (w == (r0 >> 5)) bits &= ~0u << (r0 & 31u);
@@ -711,13 +764,30 @@ __global__ __launch_bounds__(64, 8) void k_xr_extend(ExtArgs A, XrArgs X) {
             bits &= bits - 1u;
             const uint64_t ri = (w << 5) + b;
             const AlnRec rec = A.rec[ri]; const float2 l = X.lite[ri];
-            Cand c; xrFill(c, rec, xrAlnLen(rec), meta[rec.target].len, qm.len, l.x, l.y, (uint32_t) (ri - r0));
+            Cand c; xrFill(c, rec, xrAlnLen(rec), meta[rec.target], qm.len, l.x, l.y, (uint32_t) (ri - r0));
             c.sLenNorm = X.sLen[ri];
-            cand[nCand] = c;
-            heap.push(nCand++);
+            c.pieceLen = __float_as_uint(X.sBound[ri]);                  // (until the queue is built)
+            cand[nCand++] = c;
         }
     }
-    extendLoop(A, Q, cand, heap, parkL, leftL, rightL, X.qMax[2 * (size_t) q], X.qMax[2 * (size_t) q + 1], sLogLik, qm.key, q);
+    // The queue orders by sLenNorm.  Where two plain-double sums lie within their error bounds of each other, their order (or their
+    // equality) under scoreCand's values is open: those candidates are scored again, exactly.  The query has no pieces yet, and the
+    // longest overlaps are the ones the first scores were taken with, so scoreCand() returns what it would have then.
+    if (nCand > 1) {
+        for (uint32_t i = 0; i < nCand; i++) {
+            const float bi = __uint_as_float(cand[i].pieceLen);
+            if (!(bi > 0.f)) continue;
+            bool open = nCand > 32;                                       // (a deep pile-up: all of them, instead of all pairs)
+            const double si = cand[i].sLenNorm;
+            for (uint32_t j = 0; j < nCand && !open; j++)
+                if (j != i) open = fabs(si - cand[j].sLenNorm) <= (double) bi + (double) fabsf(__uint_as_float(cand[j].pieceLen));
+            if (open) cand[i].pieceLen |= 0x80000000u;                   // (bounds are positive floats: the sign bit is free)
+        }
+        for (uint32_t i = 0; i < nCand; i++)
+            if (cand[i].pieceLen & 0x80000000u) { Cand c = cand[i]; c.pieceLen = 0; (void) scoreCand(A, Q, c, maxL0, maxR0, sLogLik); cand[i].sLenNorm = c.sLenNorm; }
+    }
+    for (uint32_t k = 0; k < nCand; k++) { cand[k].pieceLen = 0; heap.push(k); }
+    extendLoop(A, Q, cand, heap, parkL, leftL, rightL, maxL0, maxR0, sLogLik, qm.key, q);
 }
 
 __global__ void k_mark_active2(const uint64_t *__restrict__ aoff, uint32_t n, uint32_t *__restrict__ active, unsigned int *__restrict__ nActive,
@@ -848,6 +918,7 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     A.seqIdThr = par->seq_id_thr; A.rySeqIdThr = par->ry_seq_id_thr; A.likelihoodThr = par->likelihood_threshold;
     A.excessLog = std::log(par->excess_penal); A.randLog = std::log(par->rand_align_penal);   // std::log(float): float, as in the reference
     A.ratioLogit = (double) logl(1.0L / (long double) par->likelihood_threshold - 1.0L);
+    A.marginScale = getenv("CDM_EXTEND_MARGIN") ? (float) atof(getenv("CDM_EXTEND_MARGIN")) : 1.0f;
     A.maxSeqLen = par->max_seq_len;
     A.unsafe = par->unsafe ? 1 : 0; A.minCov = (uint32_t) std::max(0, par->min_cov_safe); A.flags = flags.p;
     hipEventRecord(ctx->ev0, s);
@@ -858,15 +929,15 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     const unsigned padB = padEnv ? (unsigned) atoi(padEnv) : 0u;
     // one thread per record for A-D (k_xr_*) where that form applies: the default mode, no raw plane
     bool perRecord = hAct && !db->raw && !A.unsafe && alns->count < 0xFFFFFFFFull / 2 && !(formEnv && !strcmp(formEnv, "queries"));
-    DevBuf<uint32_t> winQ, qMax, work, elig, pushBits; DevBuf<float2> lite; DevBuf<double> sLen;
+    DevBuf<uint32_t> winQ, qMax, work, elig, pushBits; DevBuf<float2> lite; DevBuf<double> sLen; DevBuf<float> sBound;
     if (perRecord) {
         const uint32_t nWin = (uint32_t) ((alns->count + XR_T - 1) / XR_T);
         if (!winQ.alloc((size_t) nWin + 1) || !qMax.alloc(2 * (size_t) n) || !work.alloc(hAct) || !lite.alloc(alns->count) || !sLen.alloc(alns->count) ||
-            !elig.alloc(alns->count) || !pushBits.alloc(alns->count / 32 + 2)) {
+            !elig.alloc(alns->count) || !pushBits.alloc(alns->count / 32 + 2) || !sBound.alloc(alns->count)) {
             cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP;
         }
         hipMemsetAsync(pushBits.p, 0, (alns->count / 32 + 2) * 4, s);
-        XrArgs X; X.elig = elig.p; X.pushBits = pushBits.p; X.winQ = winQ.p; X.lite = lite.p; X.sLen = sLen.p; X.qMax = qMax.p; X.work = work.p; X.nWork = nActive.p + 1; X.fallback = flags.p + 1;
+        XrArgs X; X.sBound = sBound.p; X.elig = elig.p; X.pushBits = pushBits.p; X.winQ = winQ.p; X.lite = lite.p; X.sLen = sLen.p; X.qMax = qMax.p; X.work = work.p; X.nWork = nActive.p + 1; X.fallback = flags.p + 1;
         hipLaunchKernelGGL(k_xr_windows, dim3(nWin / 256 + 1), dim3(256), 0, s, alns->off, n, nWin, winQ.p);
         hipLaunchKernelGGL(k_xr_score, dim3(nWin), dim3(XR_NT), 0, s, A, X);
         unsigned int fb = 0;

@@ -18,12 +18,16 @@ def ctx(dhigh_prefix):
     return c
 
 
-@pytest.fixture(params=["records", "queries"])
+@pytest.fixture(params=["records", "records-wide-margins", "queries"])
 def form(request, monkeypatch):
-    """The two forms of the extension kernel (extend.hip): A-D with one thread per record (k_xr_*, the default where it applies) and
-    one lane per query for everything (k_extend; CDM_EXTEND=queries)."""
+    """The forms of the extension kernel (extend.hip): A-D with one thread per record (k_xr_*, the default where it applies; it takes
+    the likelihoods in plain double wherever their error bound decides and in software x87 elsewhere - CDM_EXTEND_MARGIN widens the
+    bounds, so that many more candidates go through the exact second scoring) and one lane per query for everything (k_extend;
+    CDM_EXTEND=queries)."""
     if request.param == "queries":
         monkeypatch.setenv("CDM_EXTEND", "queries")
+    if request.param == "records-wide-margins":
+        monkeypatch.setenv("CDM_EXTEND_MARGIN", "3e11")
     return request.param
 
 
@@ -119,17 +123,21 @@ def test_both_forms_identical_at_scale(ctx, monkeypatch):
         alns = ctx.rescore(db, ctx.kmermatch(db))
         corr = ctx.correct(db, alns)
         out = {}
-        for f in ("records", "queries"):
-            if f == "queries":
-                monkeypatch.setenv("CDM_EXTEND", "queries")
-            asm, scores = ctx.extend(corr, alns, want_scores=True)
-            monkeypatch.delenv("CDM_EXTEND", raising=False)
+        for f, env, want in (("records", {}, False), ("margins", {"CDM_EXTEND_MARGIN": "3e11"}, False), ("exact", {}, True), ("queries", {"CDM_EXTEND": "queries"}, True)):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            res = ctx.extend(corr, alns, want_scores=want)      # (asking for the scores takes every likelihood in software x87)
+            for k in env:
+                monkeypatch.delenv(k)
+            asm, scores = res if want else (res, None)
             seqs, keys, ext = asm.download()
             out[f] = (seqs, keys, ext, scores)
-        a, b = out["records"], out["queries"]
+        b = out["queries"]
         assert int((~np.isnan(b[3])).sum()) > n // 2 and int(b[2].sum()) > n // 20
-        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-        assert np.array_equal(a[3], b[3], equal_nan=True)
+        for f in ("records", "margins", "exact"):
+            a = out[f]
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), f
+        assert np.array_equal(out["exact"][3], b[3], equal_nan=True)
 
 
 @pytest.mark.parametrize("name,it,min_cov", [("synth2k", 0, 1), ("synth2k", 1, 2), ("mixed3k", 0, 5), ("mixed3k", 2, 1), ("example", 0, 2)])
