@@ -66,7 +66,8 @@ def build(verbose=False):
     main_src = os.path.join(hostdir, "main.cpp")
     if os.path.exists(main_src):
         srcs = [os.path.join(hostdir, f) for f in sorted(os.listdir(hostdir)) if f.endswith(".cpp") and f not in host_lib_srcs]
-        if any(_newer(s, BIN, headers) for s in srcs) or _newer(LIB, BIN):
+        host_headers = headers + tuple(os.path.join(hostdir, h) for h in os.listdir(hostdir) if h.endswith(".h"))
+        if any(_newer(s, BIN, host_headers) for s in srcs) or _newer(LIB, BIN):
             cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-Wall", "-I" + os.path.join(os.path.dirname(HERE), "include"), "-o", BIN] + srcs + [
                 "-L" + HERE, "-lcarpedeam_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + HERE]
             r = subprocess.run(cmd, capture_output=True, text=True)

@@ -311,7 +311,7 @@ void formatPrefDb(const MmDb &seq, const uint64_t *off, const cdm_hit *rec, std:
         for (size_t i = lo; i < hi; i++) {
             char *const w0 = c.open((off[i + 1] - off[i]) * MAXREC), *w = w0;
             for (uint64_t h = off[i]; h < off[i + 1]; h++) {   // QueryMatcher::prefilterHitToBuffer
-                w = utoa(seq.key[rec[h].target], w); *w++ = '\t'; w = itoa(rec[h].score, w); *w++ = '\t'; w = itoa((short) rec[h].diagonal, w); *w++ = '\n';
+                w = utoa(seq.keyOf(rec[h].target), w); *w++ = '\t'; w = itoa(rec[h].score, w); *w++ = '\t'; w = itoa((short) rec[h].diagonal, w); *w++ = '\n';
             }
             // representatives' records carry wasExtended 0, fill-in records the sequence's flag (kmermatcher.cpp:727, DBWriter default)
             c.close(seq.key[i], w0, w, (off[i + 1] - off[i] > 1) ? 0 : seq.ext[i]);
@@ -371,9 +371,10 @@ void formatAlnDb(const MmDb &seq, const MmDb &pref, const uint64_t *aoff, const 
             char *const w0 = c.open((aoff[i + 1] - aoff[i]) * MAXREC), *w = w0;
             for (uint64_t r = aoff[i]; r < aoff[i + 1]; r++) {   // Matcher::resultToBuffer (Matcher.cpp:356-404)
                 const cdm_aln &x = arec[r];
+                if (r + 16 < aoff[hi]) __builtin_prefetch(&seq.len[arec[r + 16].target]);      // (a random look-up per record: on its way 16 records ahead)
                 const int alnLen = std::max(abs(x.q_end - x.q_start), abs(x.db_end - x.db_start)) + 1;
                 const float sid = static_cast<float>(x.ident) / static_cast<float>(alnLen);
-                w = utoa(seq.key[x.target], w); *w++ = '\t';
+                w = utoa(seq.keyOf(x.target), w); *w++ = '\t';
                 EvalText &ev = cache[((uint32_t) x.raw_score * 2654435761u ^ (uint32_t) qLen * 40503u) >> 18];
                 if (ev.qLen != qLen || ev.score != x.raw_score) {
                     ev.qLen = qLen; ev.score = x.raw_score; ev.bits = cdm_bit_score(x.raw_score);

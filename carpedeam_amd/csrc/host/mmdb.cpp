@@ -135,10 +135,18 @@ bool MmDb::load(const std::string &path, std::string *err, bool indexOnly) {
         for (size_t i = 0; i < n; i++) { k2[i] = key[perm[i]]; o2[i] = off[perm[i]]; l2[i] = len[perm[i]]; e2[i] = ext[perm[i]]; }
         key.swap(k2); off.swap(o2); len.swap(l2); ext.swap(e2);
     }
+    noteDense();
     return true;
 }
-int64_t MmDb::idOf(uint32_t k) const {
-    if (k < key.size() && key[k] == k) return (int64_t) k;      // dense keys 0..n-1 (what createdb writes): no search
+void MmDb::noteDense() {
+    const size_t n = key.size();
+    bool all = true;
+#pragma omp parallel for reduction(&& : all) schedule(static)
+    for (size_t i = 0; i < n; i++) all = all && key[i] == (uint32_t) i;
+    dense = all && n > 0;
+}
+int64_t MmDb::idOfSearch(uint32_t k) const {
+    if (k < key.size() && key[k] == k) return (int64_t) k;      // (mostly dense keys)
     auto it = std::lower_bound(key.begin(), key.end(), k);
     return (it == key.end() || *it != k) ? -1 : (int64_t) (it - key.begin());
 }

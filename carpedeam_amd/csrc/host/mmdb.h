@@ -37,6 +37,7 @@ struct MmDb {
     HVec<uint64_t> off, len;  // len includes the trailing NUL
     HVec<uint8_t> ext;
     int dbtype = 0;
+    bool dense = false;       // key[i] == i for every entry (what createdb and the modules write): idOf / keyOf need no look-up
     MmDb() = default;
     MmDb(const MmDb &) = delete;
     MmDb &operator=(const MmDb &) = delete;
@@ -46,8 +47,14 @@ struct MmDb {
     const char *data() const { return base; }
     size_t dataSize() const { return bytes; }
     const char *entry(size_t i) const { return base + off[i]; }
-    int64_t idOf(uint32_t k) const;  // -1 when absent
+    int64_t idOf(uint32_t k) const {  // -1 when absent
+        if (dense) return k < key.size() ? (int64_t) k : -1;
+        return idOfSearch(k);
+    }
+    uint32_t keyOf(size_t i) const { return dense ? (uint32_t) i : key[i]; }
+    void noteDense();                // sets `dense` from the keys
 private:
+    int64_t idOfSearch(uint32_t k) const;
     const char *base = nullptr; size_t bytes = 0;
     void *mapped = nullptr; size_t mappedBytes = 0;   // mmap of a single data file
     HVec<char> owned;                                 // concatenation of split data files

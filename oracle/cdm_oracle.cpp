@@ -683,7 +683,7 @@ static int doAssemble(const std::string &seqPath, const std::string &alnPath, co
                     const char *ts = seq.getData(tid); unsigned tLen = seq.seqLen(tid);
                     if (best.dbStartPos == 0) { if ((tLen - (best.dbEndPos + 1)) <= rightOff) continue; }
                     else if (best.qStartPos == 0) { if (best.dbStartPos <= static_cast<int>(leftOff)) continue; }
-                    wasExtended[tid] |= 0x10;
+                    __sync_or_and_fetch(&wasExtended[tid], (uint8_t) 0x10);   // (atomic, as the reference does it at :402: other threads set bits of the same byte)
                     if (getenv("ORACLE_TRACE") && (uint32_t) atoi(getenv("ORACLE_TRACE")) == qKey) fprintf(stderr, "E pop %u q[%d,%d] t[%d,%d] lo %u ro %u qLen %u\n", best.dbKey, best.qStartPos, best.qEndPos, best.dbStartPos, best.dbEndPos, leftOff, rightOff, qLen);
                     unsigned ds = best.dbStartPos, de = best.dbEndPos, qs = best.qStartPos, qe = best.qEndPos;
                     if (ds == 0 && qe == (qLen - 1)) {
@@ -727,7 +727,7 @@ static int doAssemble(const std::string &seqPath, const std::string &alnPath, co
                     }
                 }
             }
-            if (couldExtend) { query.push_back('\n'); wasExtended[id] |= 0x20; out.set(id, qKey, query, 1); }
+            if (couldExtend) { query.push_back('\n'); __sync_or_and_fetch(&wasExtended[id], (uint8_t) 0x20); out.set(id, qKey, query, 1); }
         }
     }
     if (scoreLog) fclose(scoreLog);
@@ -1015,7 +1015,7 @@ static int doContigMerge(const std::string &seqPath, const std::string &alnPath,
                     if (a.seqId >= par.mergeSeqIdThr && a.rySeqId >= par.rySeqIdThr) queue.push(a);
                 }
             }
-            if (couldExtend) { query.push_back('\n'); wasExtended[id] |= 0x20; out.set(id, qKey, query, 1); }
+            if (couldExtend) { query.push_back('\n'); __sync_or_and_fetch(&wasExtended[id], (uint8_t) 0x20); out.set(id, qKey, query, 1); }
         }
     }
     for (size_t id = 0; id < seq.size(); id++)  // :473-487

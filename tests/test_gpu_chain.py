@@ -1,6 +1,8 @@
 """End-to-end on the device: synthetic reads generated in HBM, then kmermatcher -> rescorediagonal -> ancient_correction ->
 ancient_read_assemble through the C ABI with every intermediate resident on the device, against the oracle run on the
 same reads (DB files) -- plus size-independent properties at a larger size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -103,6 +105,36 @@ def test_chain_fuzz_small_databases(ctx, oracle_bin, dhigh_prefix, tmp_path):
             assert not diff_keys(seqdb_to_keyed(*corr.download()), mmdb.read_db(t("corr"))), ctxt
             assert not diff_keys(seqdb_to_keyed(*asm.download()), mmdb.read_db(o)), ctxt
             db = asm
+
+
+def test_saved_fuzz_cases_replayed(ctx, oracle_bin, dhigh_prefix, tmp_path):
+    """Read sets a fuzz campaign saved when a stage differed from the oracle (tests/golden/fuzz/*.txt, one read per line; replayed by
+    hand with scripts/fuzz_replay.py): three iterations, every stage against the oracle, each set three times in the same process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz", "*.txt")))
+    assert files
+    t = lambda s: str(tmp_path / s)
+    for fn in files:
+        seqs = [l.rstrip("\n") for l in open(fn) if l.strip()]
+        mmdb.write_seqdb(t("in0"), seqs)
+        for it in range(3):
+            i, o = t("in%d" % it), t("in%d" % (it + 1))
+            run_oracle(oracle_bin, "kmermatcher", i, t("pref%d" % it), *K_FLAGS, "--threads", "1")
+            run_oracle(oracle_bin, "rescorediagonal", i, i, t("pref%d" % it), t("aln%d" % it), *R_FLAGS, "--threads", "1")
+            run_oracle(oracle_bin, "ancient_correction", i, t("aln%d" % it), t("corr%d" % it), *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "1")
+            run_oracle(oracle_bin, "ancient_read_assemble", t("corr%d" % it), t("aln%d" % it), o, *A_FLAGS, "--ancient-damage", dhigh_prefix, "--threads", "1")
+        for rep in range(3):
+            db = ctx.upload_seqs(seqs)
+            for it in range(3):
+                hits, alns, corr, asm = chain(ctx, db)
+                lens, keys, _ = db.meta()
+                hoff, hrec = hits.download(); aoff, arec = alns.download()
+                where = (os.path.basename(fn), rep, it)
+                assert not diff_keys({k: (v, 0) for k, v in capi.hits_to_text(hoff, hrec, keys).items()}, {k: (v[0], 0) for k, v in mmdb.read_db(t("pref%d" % it)).items()}), where
+                assert not diff_keys({k: (v, 0) for k, v in capi.alns_to_text(aoff, arec, keys, lens, db.residues).items()}, mmdb.read_db(t("aln%d" % it))), where
+                assert not diff_keys(seqdb_to_keyed(*corr.download()), mmdb.read_db(t("corr%d" % it))), where
+                assert not diff_keys(seqdb_to_keyed(*asm.download()), mmdb.read_db(t("in%d" % (it + 1)))), where
+                db = asm
 
 
 @pytest.mark.parametrize("n", [2_000_000, 5_000_000])
