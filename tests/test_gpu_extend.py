@@ -140,6 +140,40 @@ def test_both_forms_identical_at_scale(ctx, monkeypatch):
         assert np.array_equal(out["exact"][3], b[3], equal_nan=True)
 
 
+def test_sparse_alignment_sets_through_both_forms(ctx, monkeypatch):
+    """Alignment sets in which most queries have NO record (an uploaded set need not hold one for every sequence): hundreds of queries
+    start inside one window of the record-parallel kernel - more than it takes in one go -, then sets with a single surviving query
+    and with none.  Sequences, flags and scores equal those of the lane-per-query form."""
+    db = ctx.synth(200_000, 100, 100, 11)
+    alns = ctx.rescore(db, ctx.kmermatch(db))
+    corr = ctx.correct(db, alns)
+    off, rec = alns.download()
+    cnt = np.diff(off.astype(np.int64))
+    n = len(cnt)
+    rng = np.random.default_rng(5)
+    busiest = int(np.argmax(cnt))
+    for keep in (rng.random(n) < 0.01, rng.random(n) < 0.2, np.arange(n) == busiest, np.zeros(n, bool)):
+        kept = np.where(keep, cnt, 0)
+        off2 = np.zeros(n + 1, np.uint64)
+        off2[1:] = np.cumsum(kept)
+        rec2 = rec[np.repeat(keep, cnt)]
+        assert len(rec2) == int(off2[-1])
+        sparse = ctx.upload_alns(corr, off2, rec2)
+        out = {}
+        for f in ("records", "queries"):
+            if f == "queries":
+                monkeypatch.setenv("CDM_EXTEND", "queries")
+            asm, scores = ctx.extend(corr, sparse, want_scores=True)
+            monkeypatch.delenv("CDM_EXTEND", raising=False)
+            plain = ctx.extend(corr, sparse) if f == "records" else None      # (without the scores: the plain-double likelihoods)
+            out[f] = asm.download() + (scores,) + ((plain.download(),) if plain else ())
+        a, b = out["records"], out["queries"]
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3], equal_nan=True)
+        assert a[4][0] == b[0] and np.array_equal(a[4][2], b[2])
+        if keep.sum() > 1000:
+            assert int(b[2].sum()) > 50
+
+
 @pytest.mark.parametrize("name,it,min_cov", [("synth2k", 0, 1), ("synth2k", 1, 2), ("mixed3k", 0, 5), ("mixed3k", 2, 1), ("example", 0, 2)])
 def test_unsafe_mode_consensus_matches_oracle(ctx, oracle_bin, dhigh_prefix, tmp_path, name, it, min_cov):
     """--unsafe 1 (consensusCaller's majority vote over the extending targets, nuclassembleUtil.cpp:570-702): the oracle's unsafe
