@@ -34,6 +34,16 @@ class RescoreParams(C.Structure):
         return cls(0.9, 0.001, 1, 0.0, 0, 0)
 
 
+class HammingParams(C.Structure):
+    _fields_ = [("seq_id_thr", C.c_float), ("eval_thr", C.c_double), ("cov_mode", C.c_int32), ("cov_thr", C.c_float),
+                ("seq_id_mode", C.c_int32), ("min_aln_len", C.c_int32), ("reverse_prefilter", C.c_int32)]
+
+    @classmethod
+    def linclust(cls):
+        """what `ancient_assemble` passes to linclust's pre-clustering (GuidedNuclassembler.cpp:176-181, Linclust.cpp:103-112)"""
+        return cls(0.97, 0.001, 1, 0.99, 0, 0, 1)
+
+
 class AncientParams(C.Structure):
     _fields_ = [("seq_id_thr", C.c_float), ("corr_reads_ry_seq_id", C.c_float), ("ry_seq_id_thr", C.c_float), ("rand_align_penal", C.c_float),
                 ("excess_penal", C.c_float), ("likelihood_threshold", C.c_float), ("unsafe", C.c_int32), ("min_cov_safe", C.c_int32),
@@ -52,6 +62,7 @@ EXPORTS = [
     "cdm_evalue", "cdm_bit_score", "cdm_correct", "cdm_extend",
     "cdm_kmermatch_part", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_sort", "cdm_kpart_vote", "cdm_kpart_cont_cap", "cdm_kpart_free", "cdm_dev_copy",
     "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
+    "cdm_rescore_hamming",
 ]
 
 
@@ -105,6 +116,7 @@ def lib():
         l.cdm_hits_upload.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
         l.cdm_hits_download.argtypes = [vp, vp, vp, vp]
         l.cdm_rescore.argtypes = [vp, vp, vp, C.POINTER(RescoreParams), C.POINTER(vp)]
+        l.cdm_rescore_hamming.argtypes = [vp, vp, vp, C.POINTER(HammingParams), C.POINTER(vp)]
         l.cdm_alns_upload.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
         l.cdm_alns_download.argtypes = [vp, vp, vp, vp]
         l.cdm_evalue.argtypes = [C.c_double, C.c_double, C.c_uint64]
@@ -395,6 +407,12 @@ class Ctx:
         h = C.c_void_p()
         _check(lib().cdm_rescore(self.h, db.h, hits.h, C.byref(par), C.byref(h)))
         return Alns(self, h, db.n)
+
+    def rescore_hamming(self, db, hits, par=None):
+        par = par or HammingParams.linclust()
+        h = C.c_void_p()
+        _check(lib().cdm_rescore_hamming(self.h, db.h, hits.h, C.byref(par), C.byref(h)))
+        return Hits(self, h, db.n)
 
     def correct(self, db, alns, par=None):
         par = par or AncientParams.default()

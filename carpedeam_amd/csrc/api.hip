@@ -719,6 +719,13 @@ extern "C" int cdm_rescore(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hi
     if (rc == CDM_OK) stageDone(ctx, 9);
     return rc;
 }
+extern "C" int cdm_rescore_hamming(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, const cdm_hamming_params *par, cdm_hits **out) {
+    if (!ctx || !db || !hits || !par || !out) { cdm_set_error("cdm_rescore_hamming: NULL argument"); return CDM_ERR_INVALID; }
+    if (hits->n != db->n) { cdm_set_error("cdm_rescore_hamming: hit CSR / DB size mismatch"); return CDM_ERR_INVALID; }
+    if (par->seq_id_mode < 0 || par->seq_id_mode > 2) { cdm_set_error("cdm_rescore_hamming: --seq-id-mode is 0, 1 or 2"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    return cdm_rescore_hamming_impl(ctx, db, hits, par, out);
+}
 extern "C" int cdm_kmermatch(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
     if (!ctx || !db || !par || !out) { cdm_set_error("cdm_kmermatch: NULL argument"); return CDM_ERR_INVALID; }
     CDM_HIP(hipSetDevice(ctx->device));

@@ -165,6 +165,7 @@ struct ContigStat {            // per alignment record, oriented as :193-214 doe
 // stage implementations (one .hip file each)
 int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb *out);
 int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, const cdm_rescore_params *par, cdm_alns **out);
+int cdm_rescore_hamming_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, const cdm_hamming_params *par, cdm_hits **out);
 int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out);
 int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, cdm_seqdb **out, double *scores);
 int cdm_synth_impl(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, uint64_t n, uint32_t lo, uint32_t hi, uint64_t seed, cdm_seqdb **out);

@@ -73,6 +73,13 @@ const FlagSpec RESCORE_FLAGS[] = {
     {"--seq-id-mode", 'V', "0", "only alignment-length normalisation"}, {"--rescore-mode", 'V', "3", "only the end-to-end ungapped mode CarpeDeam uses"},
     {"--wrapped-scoring", 'V', "0", "not implemented"}, {"--filter-hits", 'V', "0", "not implemented"}, {"-a", 'V', "0", "no backtrace in mode 3"},
     {"--sort-results", 'V', "0", "not implemented"}, {"--sub-mat", 'V', "*nucleotide.out*", "only the nucleotide matrix"}, {"--compressed", 'V', "0", "compressed DBs are not implemented"}, {0, 0, 0, 0}};
+// the module in linclust's pre-clustering mode (linclust.sh:27-31): --rescore-mode 0 --wrapped-scoring 1
+const FlagSpec RESCORE_HAMMING_FLAGS[] = {
+    {"-e", 'U', 0, 0}, {"-c", 'U', 0, 0}, {"--cov-mode", 'U', 0, 0}, {"--min-seq-id", 'U', 0, 0}, {"--min-aln-len", 'U', 0, 0}, {"--seq-id-mode", 'U', 0, 0},
+    {"--add-self-matches", 'N', 0, "query DB == target DB: self matches are kept anyway (rescorediagonal.cpp:205)"}, {"--db-load-mode", 'N', 0, 0}, {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0},
+    {"--rescore-mode", 'V', "0", "this table is the Hamming mode's"}, {"--wrapped-scoring", 'V', "1", "the Hamming mode is implemented with wrapped scoring only"},
+    {"--filter-hits", 'V', "0", "not implemented"}, {"-a", 'V', "0", "no backtrace in this mode"},
+    {"--sort-results", 'V', "0", "not implemented"}, {"--sub-mat", 'V', "*nucleotide.out*", "only the nucleotide matrix"}, {"--compressed", 'V', "0", "compressed DBs are not implemented"}, {0, 0, 0, 0}};
 const FlagSpec ANCIENT_FLAGS[] = {
     {"--min-seq-id", 'U', 0, 0}, {"--max-seq-len", 'U', 0, 0}, {"--ext-random-align", 'U', 0, 0}, {"--excess-penalty", 'U', 0, 0}, {"--min-ryseq-id-corr-reads", 'U', 0, 0},
     {"--likelihood-ratio-threshold", 'U', 0, 0}, {"--ancient-damage", 'U', 0, 0}, {"--unsafe", 'U', 0, 0}, {"--min-cov-safe", 'U', 0, 0},
@@ -391,6 +398,29 @@ void formatAlnDb(const MmDb &seq, const MmDb &pref, const uint64_t *aoff, const 
     }
 }
 
+// the same records for the result of the Hamming mode: one entry per query that has a prefilter entry (rescorediagonal.cpp:350), flag 0
+void formatRescoredPrefDb(const MmDb &seq, const MmDb &pref, const uint64_t *off, const cdm_hit *rec, std::vector<OutChunk> &chunks) {
+    const int T = std::max(1, omp_get_max_threads());
+    chunks.clear(); chunks.resize(T);
+    const size_t MAXREC = 10 + 1 + 11 + 1 + 6 + 1;
+    const std::vector<size_t> cut = balancedSlices(off, seq.size(), T);
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        const size_t lo = cut[t], hi = cut[t + 1];
+        OutChunk &c = chunks[t];
+        c.reserve(hi - lo, (off[hi] - off[lo]) * MAXREC + (hi - lo));
+        for (size_t i = lo; i < hi; i++) {
+            if (pref.idOf(seq.keyOf(i)) < 0) continue;
+            char *const w0 = c.open((off[i + 1] - off[i]) * MAXREC), *w = w0;
+            for (uint64_t h = off[i]; h < off[i + 1]; h++) {
+                w = utoa(seq.keyOf(rec[h].target), w); *w++ = '\t'; w = itoa(rec[h].score, w); *w++ = '\t'; w = itoa((short) rec[h].diagonal, w); *w++ = '\n';
+            }
+            c.close(seq.keyOf(i), w0, w, 0);
+        }
+    }
+}
+
 int kmermatcher(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam kmermatcher <i:sequenceDB> <o:prefilterDB>");
     checkFlags("kmermatcher", a, KMERMATCHER_FLAGS);
@@ -420,9 +450,32 @@ int kmermatcher(Args &a) {
 
 int rescorediagonal(Args &a) {
     if (a.pos.size() < 4) die("Usage: carpedeam rescorediagonal <i:queryDB> <i:targetDB> <i:prefilterDB> <o:resultDB>");
-    checkFlags("rescorediagonal", a, RESCORE_FLAGS);
+    const bool hamming = a.flag.count("--rescore-mode") && a.flag["--rescore-mode"] == "0" && a.flag.count("--wrapped-scoring") && a.flag["--wrapped-scoring"] == "1";
+    checkFlags("rescorediagonal", a, hamming ? RESCORE_HAMMING_FLAGS : RESCORE_FLAGS);
     if (a.pos[0] != a.pos[1]) unsupported("rescorediagonal: query and target DB must be the same on the MI355X path");
-    if (!a.flag.count("--rescore-mode")) unsupported("rescorediagonal: --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
+    if (hamming) {      // linclust's pre-clustering of the assembled contigs: prefilter records in, prefilter records out
+        MmDb seq, pref; std::string err; if (!seq.load(a.pos[1], &err)) die(err);
+        DeviceStart dev; dev.begin(&seq, NULL);
+        if (!pref.load(a.pos[2], &err)) die(err);
+        HVec<uint64_t> off; HVec<cdm_hit> rec;
+        parsePrefDb(pref, seq, off, rec);
+        dev.join(); cdm_ctx *ctx = dev.ctx; cdm_seqdb *db = dev.db;
+        cdm_hits *hits = NULL, *kept = NULL;
+        check(cdm_hits_upload(ctx, db, off.data(), rec.data(), &hits), "upload");
+        cdm_hamming_params p;
+        p.seq_id_thr = fflag(a, "--min-seq-id", 0.0f); p.eval_thr = a.flag.count("-e") ? strtod(a.flag["-e"].c_str(), NULL) : 0.001;
+        p.cov_mode = (int) iflag(a, "--cov-mode", 0); p.cov_thr = fflag(a, "-c", 0.0f); p.seq_id_mode = (int) iflag(a, "--seq-id-mode", 0); p.min_aln_len = (int) iflag(a, "--min-aln-len", 0);
+        p.reverse_prefilter = (pref.dbtype & 0x7FFFFFFF) == 14;
+        check(cdm_rescore_hamming(ctx, db, hits, &p, &kept), "rescorediagonal");
+        HVec<uint64_t> koff(seq.size() + 1); HVec<cdm_hit> krec(cdm_hits_count(kept));
+        check(cdm_hits_download(ctx, kept, koff.data(), krec.data()), "download");
+        std::vector<OutChunk> chunks;
+        formatRescoredPrefDb(seq, pref, koff.data(), krec.data(), chunks);
+        if (!mmdbWriteChunks(a.pos[3], pref.dbtype, chunks, &err, true)) die(err);
+        cdm_hits_free(kept); cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
+        return EXIT_SUCCESS;
+    }
+    if (!a.flag.count("--rescore-mode")) unsupported("rescorediagonal: --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is implemented with --wrapped-scoring 1 only on the MI355X path)");
     Laps laps;
     MmDb seq, pref; std::string err; if (!seq.load(a.pos[1], &err)) die(err);
     DeviceStart dev; dev.begin(&seq, NULL);                 // context + sequence upload while the prefilter text is mapped and parsed

@@ -213,6 +213,20 @@ typedef struct cdm_aln {
 } cdm_aln;
 
 int cdm_rescore(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, const cdm_rescore_params *par, cdm_alns **out);
+/* rescorediagonal --rescore-mode 0 --wrapped-scoring 1 (query DB == target DB): linclust's Hamming-distance pre-clustering of the
+ * assembled contigs (lib/mmseqs/data/workflow/linclust.sh:27-31; rescorediagonal.cpp:145-356 in that mode,
+ * DistanceCalculator::computeUngappedWrappedAlignment, DistanceCalculator.h:57-91).  Output: the hits that pass, as prefilter
+ * records (target, 100 * seq. id. signed by the strand, diagonal), same CSR over the queries. */
+typedef struct cdm_hamming_params {
+    float seq_id_thr;   /* --min-seq-id */
+    double eval_thr;    /* -e (the mode's E-value is 0: only a negative threshold drops everything) */
+    int32_t cov_mode;   /* --cov-mode */
+    float cov_thr;      /* -c */
+    int32_t seq_id_mode; /* --seq-id-mode 0 | 1 | 2 */
+    int32_t min_aln_len; /* --min-aln-len */
+    int32_t reverse_prefilter; /* the prefilter DB's type is DBTYPE_PREFILTER_REV_RES (kmermatcher's): a negative score = reverse-strand hit */
+} cdm_hamming_params;
+int cdm_rescore_hamming(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, const cdm_hamming_params *par, cdm_hits **out);
 int cdm_alns_upload(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *offsets, const cdm_aln *alns, cdm_alns **out);
 uint64_t cdm_alns_count(const cdm_alns *a);
 int cdm_alns_download(cdm_ctx *ctx, const cdm_alns *a, uint64_t *offsets, cdm_aln *alns);

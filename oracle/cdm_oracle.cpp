@@ -1070,7 +1070,7 @@ static double computeBitScore(double score) { return std::fma(G.lambda, score, -
 static double rawScoreFromBitScore(double bits) { return (log(G.K) + bits * std::log(2.0)) / G.lambda; }
 
 // ----------------------------------------------------------------------------- R: rescorediagonal
-struct RescorePar { float seqIdThr = 0.9f, covThr = 0.0f; double evalThr = 0.001; int covMode = 1, seqIdMode = 0, alnLenThr = 0; int threads = 1; };
+struct RescorePar { float seqIdThr = 0.9f, covThr = 0.0f; double evalThr = 0.001; int covMode = 1, seqIdMode = 0, alnLenThr = 0; int threads = 1; int rescoreMode = 3; bool wrapped = false; };
 static bool canBeCovered(float covThr, int covMode, float ql, float tl) {  // M/commons/Util.cpp:533-550
     switch (covMode) {
         case 0: return ((ql / tl >= covThr) && (tl / ql >= covThr));
@@ -1145,6 +1145,75 @@ static int doRescore(const std::string &qPath, const std::string &tPath, const s
         }
     }
     out.write(outPath, 5);
+    return 0;
+}
+
+// M/alignment/rescorediagonal.cpp:45-379 in the mode linclust's pre-clustering runs it (lib/mmseqs/data/workflow/linclust.sh:27-31,
+// src/workflow/GuidedNuclassembler.cpp:176-181): --rescore-mode 0 (Hamming: the score is the number of identical LETTERS on the
+// diagonal) with --wrapped-scoring 1 (the query is doubled, so a rotation of a circular contig still lines up).  Output = prefilter
+// records (key, 100 * seq. id. with the hit's strand as its sign, diagonal), dbtype of the input.
+static unsigned inverseHamming(const char *a, const char *b, unsigned n) { unsigned c = 0; for (unsigned i = 0; i < n; i++) c += (a[i] == b[i]); return c; }  // DistanceCalculator.h:276-296
+// DistanceCalculator.h:57-91; the loop conditions are unsigned arithmetic there and are kept as written
+static LocalAln wrappedHamming(const char *q2, unsigned q2Len, const char *t, unsigned tLen, unsigned short diagonal) {
+    LocalAln max; max.startPos = -1; max.endPos = -1; max.score = 0; max.diagonalLen = 0; max.distToDiagonal = 0; max.diagonal = 0;
+    const unsigned half = q2Len / 2;
+    auto probe = [&](int realDiagonal) {       // ungappedAlignmentByDiagonal(querySeq + realDiagonal, half, dbSeq, dbSeqLen, 0, ...), :116-128
+        LocalAln tmp; tmp.startPos = -1; tmp.endPos = -1; tmp.distToDiagonal = 0; tmp.diagonal = 0; tmp.score = 0; tmp.diagonalLen = 0;
+        if (0 < half) { const unsigned m = std::min(tLen, half); tmp.diagonalLen = m; tmp.score = (int) inverseHamming(q2 + realDiagonal, t, m); }
+        tmp.diagonal += realDiagonal; tmp.distToDiagonal = (unsigned) abs(realDiagonal);
+        if ((unsigned) tmp.score > (unsigned) max.score) max = tmp;
+    };
+    for (unsigned devisions = 1; (-devisions * 65536 + diagonal) > -tLen; devisions++) probe((int) (-devisions * 65536 + diagonal) + (int) half);
+    for (unsigned devisions = 0; (devisions * 65536 + diagonal) < half; devisions++) probe((int) (devisions * 65536 + diagonal));
+    max.diagonalLen = std::min(tLen, half);
+    return max;
+}
+static int doRescoreHamming(const std::string &qPath, const std::string &tPath, const std::string &prefPath, const std::string &outPath, const RescorePar &par) {
+    Db seq, pref; seq.load(tPath); pref.load(prefPath);
+    if (qPath != tPath) { fprintf(stderr, "oracle: rescorediagonal expects queryDB == targetDB on this path\n"); return 1; }
+    const bool revPref = (pref.dbtype & 0x7FFFFFFF) == 14;
+    DbOut out; out.init(pref.size());
+#pragma omp parallel num_threads(par.threads)
+    {
+        std::vector<Hit> hits; std::string buf, q2, qRev;
+#pragma omp for schedule(dynamic, 1)
+        for (size_t id = 0; id < pref.size(); id++) {
+            const char *data = pref.getData(id); uint32_t qKey = pref.key[id];
+            size_t qId = UINT_MAX; int qLen2 = -1, origLen = -1;
+            if (*data) {
+                qId = seq.getId(qKey); origLen = seq.seqLen(qId);
+                q2.assign(seq.getData(qId), origLen); q2 += q2; qLen2 = 2 * origLen;                      // :162-167
+                if (revPref) { qRev.assign(qLen2, 'X'); for (int p = qLen2 - 1; p > -1; p--) qRev[(qLen2 - 1) - p] = NUM2AA[REVRES[AA2NUM[(unsigned char) q2[p]]]]; }
+            }
+            hits.clear(); parseHits(data, hits); buf.clear();
+            for (const Hit &h : hits) {
+                const char *qa = q2.data(); bool isReverse = false;
+                if (revPref && h.prefScore < 0) { qa = qRev.data(); isReverse = true; }
+                size_t tId = seq.getId(h.seqId);
+                const bool isIdentity = (qId == tId);
+                const char *t = seq.getData(tId); int dbLen = seq.seqLen(tId);
+                if (!canBeCovered(par.covThr, par.covMode, (float) origLen, (float) dbLen)) continue;
+                if (dbLen > origLen) continue;                                                           // :216-220 (with a warning)
+                const float targetLength = static_cast<float>(dbLen);
+                LocalAln al = wrappedHamming(qa, (unsigned) qLen2, t, (unsigned) targetLength, h.diagonal);
+                const int diagonalLen = (int) al.diagonalLen, distance = al.score, diagonal = al.diagonal;
+                const float targetCov = static_cast<float>(diagonalLen) / static_cast<float>(dbLen), queryCov = static_cast<float>(diagonalLen) / static_cast<float>(origLen);
+                const int idCnt = (static_cast<float>(distance));
+                const double seqId = computeSeqId(par.seqIdMode, idCnt, origLen, dbLen, diagonalLen);
+                const int alnLen = diagonalLen;
+                const bool hasCov = hasCoverage(par.covThr, par.covMode, queryCov, targetCov);
+                const bool hasSeqId = seqId >= (par.seqIdThr - std::numeric_limits<float>::epsilon());
+                const bool hasEvalue = (0.0 <= par.evalThr);
+                const bool hasAlnLen = (alnLen >= par.alnLenThr);
+                if (isIdentity || (hasAlnLen && hasCov && hasSeqId && hasEvalue)) {
+                    Hit o; o.seqId = h.seqId; o.prefScore = 100 * seqId; o.prefScore = isReverse ? -o.prefScore : o.prefScore; o.diagonal = (unsigned short) diagonal;
+                    hitToBuf(buf, o);
+                }
+            }
+            out.set(id, qKey, buf, 0);
+        }
+    }
+    out.write(outPath, pref.dbtype);
     return 0;
 }
 
@@ -1463,8 +1532,11 @@ int main(int argc, char **argv) {
         if (flags.count("--seq-id-mode")) p.seqIdMode = atoi(flags["--seq-id-mode"].c_str());
         if (flags.count("--min-aln-len")) p.alnLenThr = atoi(flags["--min-aln-len"].c_str());
         if (flags.count("--threads")) p.threads = atoi(flags["--threads"].c_str());
-        if (flags.count("--rescore-mode") && atoi(flags["--rescore-mode"].c_str()) != 3) { fprintf(stderr, "oracle: only --rescore-mode 3\n"); return 1; }
-        rc = doRescore(pos[0], pos[1], pos[2], pos[3], p);
+        if (flags.count("--rescore-mode")) p.rescoreMode = atoi(flags["--rescore-mode"].c_str());
+        if (flags.count("--wrapped-scoring")) p.wrapped = atoi(flags["--wrapped-scoring"].c_str()) != 0;
+        if (p.rescoreMode == 0 && p.wrapped) rc = doRescoreHamming(pos[0], pos[1], pos[2], pos[3], p);
+        else if (p.rescoreMode != 3 || p.wrapped) { fprintf(stderr, "oracle: --rescore-mode 3, or --rescore-mode 0 with --wrapped-scoring 1\n"); return 1; }
+        else rc = doRescore(pos[0], pos[1], pos[2], pos[3], p);
     } else if (cmd == "ancient_correction" && pos.size() >= 3) {
         AncientPar p = ancientPar(flags); rc = doCorrection(pos[0], pos[1], pos[2], p);
     } else if (cmd == "ancient_read_assemble" && pos.size() >= 3) {

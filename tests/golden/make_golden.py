@@ -170,7 +170,7 @@ def main():
         chain(tmp, "example", seqs, 1, prefix, 4)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("createdb", "contigs", "cycle", "letters", "workflow")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("createdb", "contigs", "cycle", "letters", "workflow", "hamming")):
     main()
 
 
@@ -364,3 +364,75 @@ def workflow_golden(threads=8):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "workflow":
     workflow_golden()
+
+
+LINCLUST_K_FLAGS = ("--alph-size nucl:5,aa:13 --min-seq-id 0.97 --kmer-per-seq 200 --spaced-kmer-mode 0 --kmer-per-seq-scale 0.200 --adjust-kmer-len 0 --mask 0 "
+                    "--mask-lower-case 0 --cov-mode 1 -k 20 -c 0.99 --max-seq-len 200000 --hash-shift 67 --split-memory-limit 0 --include-only-extendable 0 "
+                    "--ignore-multi-kmer 1").split()
+HAMMING_FLAGS = ("--rescore-mode 0 --wrapped-scoring 1 --filter-hits 0 -e 0.001 -c 0.99 -a 0 --cov-mode 1 --min-seq-id 0.97 --min-aln-len 0 --seq-id-mode 0 "
+                 "--add-self-matches 0 --sort-results 0").split()
+
+
+def hamming_contigs(seed=31):
+    """A contig set for linclust's pre-clustering: random contigs of 150..4000 letters and, of some of them, exact copies, rotations
+    (a circular contig cut elsewhere), reverse complements, rotated reverse complements, copies with a few substitutions, shorter
+    pieces, copies with N / lower-case stretches / an IUPAC code; two rotated copies of a 70 000-letter contig (diagonals beyond 16 bit)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    L = np.frombuffer(b"ACGT", np.uint8)
+    rc = lambda s: s[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+    seqs = []
+    for i in range(260):
+        n = int(rng.integers(150, 4000)) if i else 70000
+        s = L[rng.integers(0, 4, n)].tobytes().decode()
+        seqs.append(s)
+        for _ in range(int(rng.integers(0, 4)) if i else 2):
+            r = rng.random()
+            t = s
+            if r < 0.2:
+                pass
+            elif r < 0.45:
+                k = int(rng.integers(1, n)); t = s[k:] + s[:k]
+            elif r < 0.6:
+                t = rc(s)
+            elif r < 0.75:
+                k = int(rng.integers(1, n)); t = rc(s[k:] + s[:k])
+            elif r < 0.85:
+                b = bytearray(s.encode())
+                for _m in range(int(rng.integers(1, max(2, n // 40)))):
+                    k = int(rng.integers(0, n)); b[k] = L[(int(np.searchsorted(L, b[k])) + 1) % 4]
+                t = b.decode()
+            elif r < 0.93:
+                a = int(rng.integers(0, n // 50 + 1)); t = s[a: n - int(rng.integers(0, n // 50 + 1))]
+            else:
+                b = bytearray(s.encode())
+                k = int(rng.integers(0, n)); b[k] = ord("N")
+                a = int(rng.integers(0, n - 20)); b[a: a + 20] = bytes(b[a: a + 20]).lower()
+                b[int(rng.integers(0, n))] = ord("R")
+                t = b.decode()
+            if rng.random() < 0.3 and r >= 0.2:
+                k = int(rng.integers(1, len(t))); t = t[k:] + t[:k]
+            seqs.append(t)
+    order = rng.permutation(len(seqs))
+    return [seqs[i] for i in order]
+
+
+def hamming_goldens(threads=4):
+    """tests/golden/hamming/: the reference's rescorediagonal in linclust's pre-clustering mode (--rescore-mode 0 --wrapped-scoring 1)
+    on hamming_contigs() and on kmermatcher's hits with linclust's flags.  python tests/golden/make_golden.py hamming"""
+    d = os.path.join(OUT, "hamming")
+    os.makedirs(d, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        t = lambda s: os.path.join(tmp, s)
+        mmdb.write_seqdb(t("in"), hamming_contigs())
+        run("kmermatcher", t("in"), t("pref"), *LINCLUST_K_FLAGS, "--threads", "1")
+        run("rescorediagonal", t("in"), t("in"), t("pref"), t("res"), *HAMMING_FLAGS, "--threads", str(threads))
+        for s in ("in", "pref", "res"):
+            gz_write(os.path.join(d, s + ".keyed.gz"), mmdb.dump_keyed(t(s)))
+        res = mmdb.read_db(t("res"))
+        lines = sum(v[0].count(b"\n") for v in res.values())
+        print("hamming: %d contigs, %d prefilter entries, %d records kept" % (len(mmdb.read_db(t("in"))), len(mmdb.read_db(t("pref"))), lines))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "hamming":
+    hamming_goldens()

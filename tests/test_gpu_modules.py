@@ -7,7 +7,7 @@ import pytest
 
 from carpedeam_amd import mmdb
 from gpuutil import diff_keys, gold, stage_input
-from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
+from stageflags import A_FLAGS, HAMMING_FLAGS, K_FLAGS, LINCLUST_K_FLAGS, R_FLAGS
 from test_oracle_golden import pref_sign_ties
 
 pytestmark = pytest.mark.gpu
@@ -111,3 +111,31 @@ def test_reads_loop_takes_fastq(tmp_path, dhigh_prefix):
     run("createhdb", t("out_fq"), t("out_fq"))
     run("convert2fasta", t("out_fq"), t("out.fasta"))
     assert open(t("out.fasta")).read().count(">") == len(reads)
+
+
+@pytest.mark.parametrize("extra", [[], ["--seq-id-mode", "1", "--cov-mode", "0", "-c", "0.9"], ["--min-seq-id", "0.999"], ["--seq-id-mode", "2", "--min-aln-len", "700", "--min-seq-id", "0.5"]])
+def test_hamming_mode_of_rescorediagonal_on_db_files(tmp_path, oracle_bin, extra):
+    """linclust's pre-clustering call of `ancient_assemble` through the host binary (lib/mmseqs/data/workflow/linclust.sh:21-31): its
+    kmermatcher, then rescorediagonal --rescore-mode 0 --wrapped-scoring 1; golden from the reference's object code for the workflow's
+    flags, the oracle for the other criteria."""
+    from carpedeam_amd import build
+    from gpuutil import GOLD, run_oracle
+    build.build()
+    g = os.path.join(GOLD, "hamming")
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_from_keyed(t("in"), mmdb.load_keyed(os.path.join(g, "in.keyed.gz")), mmdb.DBTYPE_NUCLEOTIDES)
+    run("kmermatcher", t("in"), t("pref"), *LINCLUST_K_FLAGS, "--threads", "4")
+    ties, bad = pref_sign_ties(mmdb.canon(mmdb.read_db(t("pref"))), mmdb.canon(mmdb.load_keyed(os.path.join(g, "pref.keyed.gz"))))
+    assert not bad and sum(n for _, n in ties) <= 1
+    mmdb.write_from_keyed(t("pref_ref"), mmdb.load_keyed(os.path.join(g, "pref.keyed.gz")), mmdb.DBTYPE_PREFILTER_REV_RES)
+    flags = list(HAMMING_FLAGS)
+    for k, v in zip(extra[::2], extra[1::2]):
+        flags[flags.index(k) + 1] = v
+    run("rescorediagonal", t("in"), t("in"), t("pref_ref"), t("res"), *flags, "--threads", "4")
+    assert mmdb.read_dbtype(t("res")) == mmdb.DBTYPE_PREFILTER_REV_RES
+    if not extra:
+        exp = mmdb.load_keyed(os.path.join(g, "res.keyed.gz"))
+    else:
+        run_oracle(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref_ref"), t("res_o"), *flags, "--threads", "4")
+        exp = mmdb.read_db(t("res_o"))
+    assert not diff_keys(mmdb.read_db(t("res")), exp)

@@ -96,3 +96,24 @@ def test_identity_record_of_a_sequence_that_scores_zero_against_itself(ctx, orac
     for stage in (lambda: ctx.correct(db, alns), lambda: ctx.extend(db, alns)):
         with pytest.raises(capi.CdmError, match="coordinates -1"):
             stage()
+
+
+def test_hamming_mode_matches_golden(ctx):
+    """cdm_rescore_hamming (linclust's pre-clustering: --rescore-mode 0 --wrapped-scoring 1) on tests/golden/hamming - the reference's
+    object code on contigs with copies, rotations, reverse complements, N / lower-case / IUPAC letters, diagonals beyond 16 bit."""
+    import os
+    from gpuutil import GOLD
+    g = os.path.join(GOLD, "hamming")
+    seq = mmdb.load_keyed(os.path.join(g, "in.keyed.gz"))
+    db = ctx.upload_keyed_seqdb(seq)
+    _, keys, _ = db.meta()
+    off, rec = capi.parse_pref_db(mmdb.load_keyed(os.path.join(g, "pref.keyed.gz")), keys)
+    kept = ctx.rescore_hamming(db, ctx.upload_hits(db, off, rec))
+    koff, krec = kept.download()
+    krec = krec.copy()
+    krec["diagonal"] = krec["diagonal"].astype(np.int16)          # (the text carries the diagonal as a short, QueryMatcher.h:121)
+    got = {k: (v, 0) for k, v in capi.hits_to_text(koff, krec, keys).items()}
+    exp = mmdb.load_keyed(os.path.join(g, "res.keyed.gz"))
+    assert not diff_keys(got, exp)
+    assert len(krec) > 1000
+    # other criteria: every --seq-id-mode, a coverage mode that looks at both sequences, a length threshold - against the oracle below

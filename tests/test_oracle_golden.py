@@ -274,3 +274,20 @@ def test_chain_letters(oracle_bin, dhigh_prefix, tmp_path):
     """reads with lower-case stretches, IUPAC codes and non-letters (NucleotideMatrix.cpp:17-61 maps them for kmermatcher and the
     score; correction/extension see nucleotideMap[c], i.e. base 0 for everything that is not ACGT; output keeps the original byte)"""
     _stage_chain(oracle_bin, dhigh_prefix, tmp_path, "letters", 3)
+
+
+def test_hamming_mode_of_rescorediagonal(oracle_bin, tmp_path):
+    """linclust's pre-clustering call (--rescore-mode 0 --wrapped-scoring 1) on tests/golden/hamming: 680 contigs with copies, rotations,
+    reverse complements, near copies, pieces, N / lower-case / IUPAC letters and two rotated 70 000-letter contigs; golden = the
+    reference's object code (make_golden.py hamming)."""
+    from stageflags import HAMMING_FLAGS
+    g = os.path.join(GOLD, "hamming")
+    t = lambda s: str(tmp_path / s)
+    mmdb.write_from_keyed(t("in"), mmdb.load_keyed(os.path.join(g, "in.keyed.gz")), mmdb.DBTYPE_NUCLEOTIDES)
+    mmdb.write_from_keyed(t("pref"), mmdb.load_keyed(os.path.join(g, "pref.keyed.gz")), mmdb.DBTYPE_PREFILTER_REV_RES)
+    run(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref"), t("res"), *HAMMING_FLAGS, "--threads", "4")
+    exp = mmdb.load_keyed(os.path.join(g, "res.keyed.gz"))
+    assert mmdb.canon(mmdb.read_db(t("res"))) == mmdb.canon(exp)
+    assert mmdb.read_dbtype(t("res")) == mmdb.DBTYPE_PREFILTER_REV_RES
+    recs = [l for v in exp.values() for l in v[0].decode().split("\n") if l]
+    assert len(recs) > 1000 and sum(1 for l in recs if l.split("\t")[2] != "0") > 300 and sum(1 for l in recs if l.split("\t")[1].startswith("-")) > 150

@@ -57,8 +57,8 @@ def check_routing(calls, fallbacks):
     assert gpu["ancient_correction"] == 10 and gpu["ancient_read_assemble"] == 5 and gpu["ancient_contig_merge"] == 5 and gpu["cyclecheck"] == 5
     assert gpu["createdb"] == 1 and gpu["createhdb"] == 1 and gpu["convert2fasta"] == 1
     assert gpu["kmermatcher"] == 11                            # 10 of the loop + linclust's
-    # linclust's Hamming-distance pre-clustering pass (linclust.sh:31-35: --rescore-mode 0 --wrapped-scoring 1) is not a mode of the
-    # device path: the module refuses it before doing any work (status 77) and the front end hands that one call to the reference
+    # (a module call the device path refuses - status 77 before any work - is handed to the reference: none in this workflow since
+    # linclust's Hamming-distance pre-clustering pass, linclust.sh:27-31, became a mode of the device module)
     assert gpu["rescorediagonal"] + calls[("fallback", "rescorediagonal")] == 11 and calls[("fallback", "rescorediagonal")] == fallbacks
     assert sum(n for (where, _), n in calls.items() if where == "fallback") == fallbacks
 
@@ -91,7 +91,7 @@ def test_front_end_without_a_reference_binary(tmp_path):
 @pytest.mark.skipif(not os.path.exists(REF_FULL), reason="oracle/_ref (the reference's object code) is not built here")
 def test_ancient_assemble_on_the_example_reads(tmp_path, dhigh_prefix):
     recs, calls = assemble(tmp_path, dhigh_prefix, MODULES)
-    check_routing(calls, fallbacks=1)
+    check_routing(calls, fallbacks=0)      # (linclust's Hamming-distance rescorediagonal runs on the device too)
     exp = fasta_records(os.path.join(EXAMPLE, "ancient_assemble.fasta"))
     assert sorted(s for _, s in recs) == sorted(s for _, s in exp)
     assert recs == exp
