@@ -10,6 +10,7 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <immintrin.h>
 #include <omp.h>
 #include <queue>
 #include <memory>
@@ -90,6 +91,48 @@ std::string revComp(const char *s, size_t n) {
     std::string r(n, 'N');
     for (size_t i = 0; i < n; i++) r[i] = tab.t[(unsigned char) s[n - 1 - i]];
     return r;
+}
+// Identical letters over [from, from + cols) and letters of the same RY class over [from, from + cols] of the query stretch qa against
+// the overlap's target letters (updateNuclAlignment :28-31, getRYSeqId :78-92 on a re-aligned parked hit).  The target letters are
+// fwd[j] (the target as stored) or, for a reversed target, revLetter(back[-j]) - spelled out on the fly, 32 letters at a time where
+// they are all upper-case ACGT (contigs are, but for the odd N), letter by letter elsewhere.  The parked hits of the long contigs of
+// the late iterations walk 1e10 columns; this loop was three passes over a copy of them.
+void overlapCounts(const char *qa, const char *fwd, const char *back, size_t from, size_t cols, int &idCnt, int &idRy) {
+    size_t i = from;
+    const size_t endId = from + cols, endRy = from + cols + 1;
+    long id = 0, ry = 0;
+#ifdef __AVX2__
+    const __m256i cC = _mm256_set1_epi8('C'), cT = _mm256_set1_epi8('T'), cA = _mm256_set1_epi8('A'), cG = _mm256_set1_epi8('G');
+    const __m256i flip = _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+    // complement by the low nibble of A (1), C (3), T (4), G (7)
+    const __m256i comp = _mm256_setr_epi8(0, 'T', 0, 'G', 'A', 0, 0, 'C', 0, 0, 0, 0, 0, 0, 0, 0, 0, 'T', 0, 'G', 'A', 0, 0, 'C', 0, 0, 0, 0, 0, 0, 0, 0);
+    for (; i + 32 <= endId; i += 32) {
+        const __m256i q = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(qa + i));
+        __m256i t;
+        if (fwd) t = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(fwd + i));
+        else {
+            // letters back[-i-31] .. back[-i], to be read backwards
+            __m256i raw = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(back - i - 31));
+            const __m256i acgt = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(raw, cA), _mm256_cmpeq_epi8(raw, cC)), _mm256_or_si256(_mm256_cmpeq_epi8(raw, cG), _mm256_cmpeq_epi8(raw, cT)));
+            if (_mm256_movemask_epi8(acgt) != -1) {     // a letter beyond ACGT in this block: the table, letter by letter
+                for (size_t j = i; j < i + 32; j++) { const char tc = revLetter(*(back - j)); id += (qa[j] == tc); ry += (ryClass(qa[j]) == ryClass(tc)); }
+                continue;
+            }
+            raw = _mm256_permute2x128_si256(raw, raw, 1);                       // swap the halves, then reverse inside each
+            raw = _mm256_shuffle_epi8(raw, flip);
+            t = _mm256_shuffle_epi8(comp, _mm256_and_si256(raw, _mm256_set1_epi8(0x0F)));
+        }
+        id += __builtin_popcount((unsigned) _mm256_movemask_epi8(_mm256_cmpeq_epi8(q, t)));
+        const __m256i qy = _mm256_or_si256(_mm256_cmpeq_epi8(q, cC), _mm256_cmpeq_epi8(q, cT)), ty = _mm256_or_si256(_mm256_cmpeq_epi8(t, cC), _mm256_cmpeq_epi8(t, cT));
+        ry += __builtin_popcount((unsigned) _mm256_movemask_epi8(_mm256_cmpeq_epi8(qy, ty)));
+    }
+#endif
+    for (; i < endRy; i++) {
+        const char tc = fwd ? fwd[i] : revLetter(*(back - i));
+        if (i < endId) id += (qa[i] == tc);
+        ry += (ryClass(qa[i]) == ryClass(tc));
+    }
+    idCnt = (int) id; idRy = (int) ry;
 }
 // What one C->T / G->A column is worth as a match (deamMatches, nuclassembleUtil.cpp:1009-1044): the posterior odds that the column
 // is damage rather than a true mismatch.  The prior for "the two sequences match here" mixes the overlap's own match rate with a
@@ -341,16 +384,13 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
                     else if (diag < 0 && md < tLen) { m = std::min(tLen - md, qLen); qa = query.data(); }
                     // the overlap's m letters of the target start at ta; of a reversed target only they are spelled out (not the whole contig)
                     const size_t ta = diag < 0 ? md : 0;
-                    const char *ov = t0.data() + ta;       // ov[j] = letter ta + j of the target as the reference holds it
-                    if (rev && qa) {
-                        revBuf.resize(m);
-                        const char *fw = t0.data() + (tLen - 1 - ta);
-                        for (unsigned j = 0; j < m; j++) revBuf[j] = revLetter(*(fw - j));
-                        ov = revBuf.data();
-                    }
+                    // ov[j] = letter ta + j of the target as the reference holds it here: fwd[j], or - of a reversed target, which is not
+                    // spelled out - revLetter(back[-j])
+                    const char *fwd = rev ? nullptr : t0.data() + ta, *back = t0.data() + (tLen - 1 - ta);
+                    auto ovAt = [&](size_t j) { return fwd ? fwd[j] : revLetter(*(back - j)); };
                     if (qa) {       // computeGlobalSubstitutionStartEndDistance: the whole overlap, but for a '*' at either end (DistanceCalculator.h:204-220)
-                        diagonalLen = m; startPos = (qa[0] == '*' || ov[0] == '*') ? 1 : 0; endPos = (int) m - 1;
-                        if (endPos > 0 && (qa[m - 1] == '*' || ov[m - 1] == '*')) endPos--;
+                        diagonalLen = m; startPos = (qa[0] == '*' || ovAt(0) == '*') ? 1 : 0; endPos = (int) m - 1;
+                        if (endPos > 0 && (qa[m - 1] == '*' || ovAt(m - 1) == '*')) endPos--;
                     }
                     // updateNuclAlignment (nuclassembleUtil.cpp:9-47)
                     const int dist = (int) md;
@@ -358,12 +398,8 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
                     if (diag >= 0) { qs2 = startPos + dist; qe2 = endPos + dist; ds2 = startPos; de2 = endPos; }
                     else { qs2 = startPos; qe2 = endPos; ds2 = startPos + dist; de2 = endPos + dist; }
                     int idCnt = 0, idRy = 0;
-                    if (qa) {
-                        const char *qp = query.data() + qs2, *tp = ov + ((size_t) ds2 - ta);
-                        const int cols = qe2 - qs2;
-                        for (int i = 0; i < cols; i++) idCnt += (qp[i] == tp[i]) ? 1 : 0;                                      // :28-31, [qs2, qe2)
-                        for (int i = 0; i <= cols; i++) idRy += (ryClass(qp[i]) == ryClass(tp[i])) ? 1 : 0;                    // getRYSeqId (:78-92), [qs2, qe2]
-                    }
+                    // [qs2, qe2) for the identities (:28-31), [qs2, qe2] for the RY classes (getRYSeqId :78-92): columns startPos .. of the overlap
+                    if (qa && endPos >= startPos) overlapCounts(qa, fwd, back, (size_t) startPos, (size_t) (endPos - startPos), idCnt, idRy);
                     a.seqId = static_cast<float>(idCnt) / (static_cast<float>(qe2) - static_cast<float>(qs2));
                     a.qLen = qLen; a.dbLen = tLen; a.alnLength = diagonalLen;
                     a.qStartPos = qs2; a.qEndPos = qe2; a.dbStartPos = ds2; a.dbEndPos = de2;
