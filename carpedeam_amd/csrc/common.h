@@ -145,6 +145,29 @@ int cdm_seqdb_alloc_raw(cdm_seqdb *db);      // the raw plane for db->words code
 // sub-DB: sel[i] (device) = 0xFFFFFFFF drops sequence i, else keeps its first sel[i] letters; extValue < 0 keeps the wasExtended flags
 int cdm_seqdb_select(cdm_ctx *ctx, const cdm_seqdb *db, const uint32_t *sel, int extValue, cdm_seqdb **out);
 
+// Host memory for what comes down from the device in bulk: anonymous pages, not initialised (a std::vector or std::string of that
+// size is written once by its constructor before the copy writes it again), huge pages where the system hands them out on advice.
+#include <sys/mman.h>
+template <typename T> struct HostBuf {
+    T *p = nullptr; size_t n = 0, bytes = 0;
+    HostBuf() = default;
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    ~HostBuf() { release(); }
+    void release() { if (p) munmap(p, bytes); p = nullptr; n = bytes = 0; }
+    bool alloc(size_t count) {
+        release();
+        bytes = ((count * sizeof(T) + 1) + (2u << 20) - 1) & ~(size_t) ((2u << 20) - 1);
+        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) { bytes = 0; return false; }
+        madvise(m, bytes, MADV_HUGEPAGE);
+        p = static_cast<T *>(m); n = count;
+        return true;
+    }
+    T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) const { return p[i]; }
+};
 // a sequence of the downloaded DB blob as the host part of ancient_contig_merge sees it (no copy, no allocation per sequence)
 struct SeqView {
     const char *p = nullptr; size_t n = 0;

@@ -88,11 +88,11 @@ __global__ void k_rec_owner(const uint64_t *__restrict__ aoff, uint32_t n, uint3
 
 // host/contigmerge.cpp
 // (host/contigmerge.cpp, OpenMP) the DB blob as one string per sequence / the strings as one DB blob "SEQ\n\0..."
-void cdm_host_split(const std::string &blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<SeqView> &seqs);
-void cdm_host_pack(const std::vector<SeqView> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, std::unique_ptr<char[]> &data,
+void cdm_host_split(const char *blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<SeqView> &seqs);
+bool cdm_host_pack(const std::vector<SeqView> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, HostBuf<char> &data,
                    std::vector<uint64_t> &off, std::vector<uint32_t> &len);
 int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
-                          const std::vector<cdm_aln> &recs, const std::vector<ContigStat> &stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
+                          const cdm_aln *recs, const ContigStat *stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
                           float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::vector<uint8_t> &changed, std::string *err);
 
 extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float mergeSeqIdThr, cdm_seqdb **out) {
@@ -117,7 +117,8 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     auto tNow = [] { return std::chrono::steady_clock::now(); };
     auto tPrev = tNow();
     auto lap = [&](const char *what) { if (timing) { const auto t = tNow(); fprintf(stderr, "  contig merge: %-28s %.3f s\n", what, std::chrono::duration<double>(t - tPrev).count()); tPrev = t; } };
-    std::vector<ContigStat> stats(nRec); std::vector<uint64_t> aoff(n + 1); std::vector<cdm_aln> recs(nRec);
+    HostBuf<ContigStat> stats; HostBuf<cdm_aln> recs; std::vector<uint64_t> aoff(n + 1);
+    if (!stats.alloc(nRec) || !recs.alloc(nRec)) { cdm_set_error("cdm_contig_merge: out of host memory"); return CDM_ERR_INVALID; }
     std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
     CDM_HIP(hipMemcpyAsync(stats.data(), dStats.p, nRec * sizeof(ContigStat), hipMemcpyDeviceToHost, s));
     CDM_HIP(hipMemcpyAsync(aoff.data(), alns->off, (n + 1) * 8, hipMemcpyDeviceToHost, s));
@@ -127,22 +128,23 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     if (int rc = cdm_seqdb_meta(ctx, db, lens.data(), keys.data(), ext.data())) return rc;
     std::vector<uint64_t> offs(n); uint64_t tot = 0;
     for (uint32_t i = 0; i < n; i++) { offs[i] = tot; tot += lens[i] + 1; }
-    std::string blob(tot, '\0');
+    HostBuf<char> blob;
+    if (!blob.alloc(tot)) { cdm_set_error("cdm_contig_merge: out of host memory"); return CDM_ERR_INVALID; }
     lap("statistics + records down");
-    if (int rc = cdm_seqdb_download(ctx, db, &blob[0], offs.data())) return rc;
+    if (int rc = cdm_seqdb_download(ctx, db, blob.data(), offs.data())) return rc;
     lap("sequences down");
     std::vector<SeqView> seqs(n); std::vector<std::string> outSeqs; std::vector<uint8_t> outExt, changed;
-    cdm_host_split(blob, offs, lens, seqs);      // views into the blob, which stays until the result is packed
+    cdm_host_split(blob.data(), offs, lens, seqs);      // views into the blob, which stays until the result is packed
     lap("split");
     std::string err;
-    if (int rc = cdm_contig_merge_host(seqs, keys, ext, aoff, recs, stats, ctx->mats, par, mergeSeqIdThr, outSeqs, outExt, changed, &err)) { cdm_set_error("%s", err.c_str()); return rc; }
+    if (int rc = cdm_contig_merge_host(seqs, keys, ext, aoff, recs.data(), stats.data(), ctx->mats, par, mergeSeqIdThr, outSeqs, outExt, changed, &err)) { cdm_set_error("%s", err.c_str()); return rc; }
     lap("queues + extension (host)");
     // the result goes back up as a DB (same keys, new lengths and flags)
-    std::vector<uint64_t> oOff; std::vector<uint32_t> oLen; std::unique_ptr<char[]> data;
-    cdm_host_pack(seqs, outSeqs, changed, data, oOff, oLen);
-    { std::vector<std::string>().swap(outSeqs); std::vector<SeqView>().swap(seqs); std::string().swap(blob); }
+    std::vector<uint64_t> oOff; std::vector<uint32_t> oLen; HostBuf<char> data;
+    if (!cdm_host_pack(seqs, outSeqs, changed, data, oOff, oLen)) { cdm_set_error("cdm_contig_merge: out of host memory"); return CDM_ERR_INVALID; }
+    { std::vector<std::string>().swap(outSeqs); std::vector<SeqView>().swap(seqs); blob.release(); stats.release(); recs.release(); }
     lap("pack");
-    const int rcUp = cdm_seqdb_upload(ctx, data.get(), oOff.data(), oLen.data(), keys.data(), outExt.data(), n, out);
+    const int rcUp = cdm_seqdb_upload(ctx, data.data(), oOff.data(), oLen.data(), keys.data(), outExt.data(), n, out);
     lap("upload");
     return rcUp;
 }

@@ -228,28 +228,29 @@ static int cdm_host_threads() {
     }();
     return n;
 }
-void cdm_host_split(const std::string &blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<SeqView> &seqs) {
+void cdm_host_split(const char *blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<SeqView> &seqs) {
     const long n = (long) offs.size();
     seqs.resize(n);
 #pragma omp parallel for schedule(dynamic, 512) num_threads(cdm_host_threads())
-    for (long i = 0; i < n; i++) { seqs[i].p = blob.data() + offs[i]; seqs[i].n = lens[i]; }
+    for (long i = 0; i < n; i++) { seqs[i].p = blob + offs[i]; seqs[i].n = lens[i]; }
 }
 // changed[i] != 0: sequence i is grown[i], otherwise still seqs[i].  The blob is written by all threads (first touch included).
-void cdm_host_pack(const std::vector<SeqView> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, std::unique_ptr<char[]> &data,
+bool cdm_host_pack(const std::vector<SeqView> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, HostBuf<char> &data,
                    std::vector<uint64_t> &off, std::vector<uint32_t> &len) {
     const long n = (long) seqs.size();
     off.resize(n); len.resize(n);
     uint64_t total = 0;
     for (long i = 0; i < n; i++) { const size_t L = changed[i] ? grown[i].size() : seqs[i].size(); off[i] = total; len[i] = (uint32_t) L; total += L + 2; }
-    data.reset(new char[total + 1]);
+    if (!data.alloc(total + 1)) return false;
 #pragma omp parallel for schedule(dynamic, 512) num_threads(cdm_host_threads())
     for (long i = 0; i < n; i++) {
         const char *x = changed[i] ? grown[i].data() : seqs[i].data(); const size_t L = len[i];
-        char *d = data.get() + off[i]; memcpy(d, x, L); d[L] = '\n'; d[L + 1] = '\0';
+        char *d = data.data() + off[i]; memcpy(d, x, L); d[L] = '\n'; d[L + 1] = '\0';
     }
+    return true;
 }
 int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
-                          const std::vector<cdm_aln> &recs, const std::vector<ContigStat> &stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
+                          const cdm_aln *recs, const ContigStat *stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
                           float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::vector<uint8_t> &changed, std::string *err) {
     const size_t n = seqs.size();
     outSeqs.assign(n, std::string()); outExt.assign(n, 0); changed.assign(n, 0);
