@@ -117,6 +117,7 @@ def run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch):
     iterations (kmermatcher -k 22 --include-only-extendable 1, rescorediagonal, ancient_correction, ancient_contig_merge,
     cyclecheck) - through the C ABI with every intermediate resident in HBM; a rank works on its shard of the reads.
     value = bases fed to ancient_correction over all iterations / wall time of the whole job."""
+    capi.lib().cdm_pool_headroom(1.6)      # the contig iterations' buffers grow ~1.5x per iteration (the loop binary does the same)
     n = plan["n"]
     db0 = ctx.synth(n, 60, 150, plan["seed"], n_total=plan["n_total"], first=plan["first"])
     kp = capi.KmerParams.reads_default()

@@ -62,7 +62,7 @@ EXPORTS = [
     "cdm_evalue", "cdm_bit_score", "cdm_correct", "cdm_extend",
     "cdm_kmermatch_part", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_sort", "cdm_kpart_vote", "cdm_kpart_cont_cap", "cdm_kpart_free", "cdm_dev_copy",
     "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
-    "cdm_rescore_hamming",
+    "cdm_rescore_hamming", "cdm_pool_headroom",
 ]
 
 
@@ -117,6 +117,8 @@ def lib():
         l.cdm_hits_download.argtypes = [vp, vp, vp, vp]
         l.cdm_rescore.argtypes = [vp, vp, vp, C.POINTER(RescoreParams), C.POINTER(vp)]
         l.cdm_rescore_hamming.argtypes = [vp, vp, vp, C.POINTER(HammingParams), C.POINTER(vp)]
+        l.cdm_pool_headroom.argtypes = [C.c_float]
+        l.cdm_pool_headroom.restype = None
         l.cdm_alns_upload.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
         l.cdm_alns_download.argtypes = [vp, vp, vp, vp]
         l.cdm_evalue.argtypes = [C.c_double, C.c_double, C.c_uint64]

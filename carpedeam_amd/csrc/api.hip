@@ -49,13 +49,27 @@ struct Pools {
 };
 Pool &poolOf(int dev) { static thread_local Pools pools; return pools.p[dev & 63]; }
 }  // namespace
+// Head room for workloads whose buffers GROW from call to call (the contig iterations of the workflow loop: sequences, tuples and
+// records get ~1.5x longer per iteration, so no cached block ever fits the next request and every iteration maps tens of GB anew -
+// which costs ~46 ms per GB on some hosts, 0.1-1.1 s per iteration at 1-2 M reads).  With a factor f > 1 a large block is allocated
+// f times the request and a cached block up to that much larger than a request is taken: the next iteration's buffers fit the
+// previous iteration's blocks.  Off (1) by default; `ancient_reads_loop` switches it on.
+static float g_poolHeadroom = 1.0f;
+extern "C" void cdm_pool_headroom(float factor) { g_poolHeadroom = factor > 1.0f ? std::min(factor, 4.0f) : 1.0f; }
 hipError_t cdmMallocRaw(void **p, size_t bytes) {
     int dev = 0; hipGetDevice(&dev);
     Pool &pool = poolOf(dev);
     bytes = (bytes + 255) & ~(size_t) 255;
     if (bytes == 0) bytes = 256;
+    const bool roomy = g_poolHeadroom > 1.0f && bytes >= ((size_t) 64 << 20);
+    const size_t take = roomy ? (size_t) ((double) bytes * g_poolHeadroom * 1.125) : bytes + bytes / 8;
     auto it = pool.freeBlocks.lower_bound(bytes);
-    if (it != pool.freeBlocks.end() && it->first <= bytes + bytes / 8) { *p = it->second; pool.freeBlocks.erase(it); return hipSuccess; }
+    if (it != pool.freeBlocks.end() && it->first <= take) { *p = it->second; pool.freeBlocks.erase(it); return hipSuccess; }
+    if (roomy) {
+        const size_t want = ((size_t) ((double) bytes * g_poolHeadroom) + 255) & ~(size_t) 255;
+        if (hipMalloc(p, want) == hipSuccess) { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); r.blocks[*p] = {want, &pool}; return hipSuccess; }
+        (void) hipGetLastError();       // (no room for the head room: the exact size below)
+    }
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) {   // out of memory with blocks parked in the cache: release them and retry once
         (void) hipGetLastError();

@@ -550,6 +550,8 @@ int cyclecheck(Args &a) {
 // Not a module of the reference; the per-stage modules above remain the drop-in surface.
 int readsLoop(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam ancient_reads_loop <i:sequenceDB> <o:sequenceDB> --ancient-damage <prefix> [--num-iter-reads-only N]");
+    // the contig iterations' buffers grow ~1.5x per iteration: head room in the device-memory cache lets them fit the previous iteration's blocks
+    cdm_pool_headroom(getenv("CDM_POOL_HEADROOM") ? (float) atof(getenv("CDM_POOL_HEADROOM")) : 1.6f);
     {   // the workflow's own flags for the reads loop (src/commons/LocalParameters.h:283-318) on top of the stage lists
         static const char *const LOOP_FLAGS[] = {"--k-ancient-reads", "--kmer-per-seq-ancient", "--kmer-per-seq-scale-ancient", "--hash-shift", "--include-only-extendable-ancient-reads",
                                                  "-e", "--num-iter-reads-only", "--shuffle", "--num-iterations", "--k-ancient-contigs", "--include-only-extendable-ancient-contigs",

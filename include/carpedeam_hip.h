@@ -185,6 +185,10 @@ int cdm_kpart_sort(cdm_ctx *ctx, cdm_kpart *h, const void *dev_keys, uint64_t n_
 int cdm_kpart_vote(cdm_ctx *ctx, cdm_kpart *h, const uint32_t *cont, const uint32_t *stale, cdm_hits **out);
 int cdm_kpart_cont_cap(void);
 void cdm_kpart_free(cdm_kpart *h);
+/* tuning: head room of the library's device-memory cache for callers whose inputs grow from call to call (the contig iterations of
+ * the workflow loop): large blocks are allocated `factor` times the request, so the next, larger request fits a cached block instead of
+ * mapping device memory anew.  1 = off (default); process-wide. */
+void cdm_pool_headroom(float factor);
 /* device-to-device copy on the context's stream (synchronises it): moves library-owned buffers into caller tensors */
 int cdm_dev_copy(cdm_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 
