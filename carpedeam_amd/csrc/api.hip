@@ -52,8 +52,8 @@ Pool &poolOf(int dev) { static thread_local Pools pools; return pools.p[dev & 63
 // Head room for workloads whose buffers GROW from call to call (the contig iterations of the workflow loop: sequences, tuples and
 // records get ~1.5x longer per iteration, so no cached block ever fits the next request and every iteration maps tens of GB anew -
 // which costs ~46 ms per GB on some hosts, 0.1-1.1 s per iteration at 1-2 M reads).  With a factor f > 1 a large block is allocated
-// f times the request and a cached block up to that much larger than a request is taken: the next iteration's buffers fit the
-// previous iteration's blocks.  Off (1) by default; `ancient_reads_loop` switches it on.
+// f times the request - where a cached block of at least half the size shows that the buffer grows - and a cached block up to that
+// much larger than a request is taken: the next iteration's buffers fit the previous iteration's blocks.  Off (1) by default; `ancient_reads_loop` switches it on.
 static float g_poolHeadroom = 1.0f;
 extern "C" void cdm_pool_headroom(float factor) { g_poolHeadroom = factor > 1.0f ? std::min(factor, 4.0f) : 1.0f; }
 hipError_t cdmMallocRaw(void **p, size_t bytes) {
@@ -61,10 +61,13 @@ hipError_t cdmMallocRaw(void **p, size_t bytes) {
     Pool &pool = poolOf(dev);
     bytes = (bytes + 255) & ~(size_t) 255;
     if (bytes == 0) bytes = 256;
-    const bool roomy = g_poolHeadroom > 1.0f && bytes >= ((size_t) 64 << 20);
+    bool roomy = g_poolHeadroom > 1.0f && bytes >= ((size_t) 64 << 20);
     const size_t take = roomy ? (size_t) ((double) bytes * g_poolHeadroom * 1.125) : bytes + bytes / 8;
     auto it = pool.freeBlocks.lower_bound(bytes);
     if (it != pool.freeBlocks.end() && it->first <= take) { *p = it->second; pool.freeBlocks.erase(it); return hipSuccess; }
+    // head room only where growth shows: a cached block that just fails to hold the request (at least half its size) is the trace of
+    // the same buffer one call earlier; a first allocation of its kind (the reads, a one-shot module) gets the exact size
+    if (roomy) roomy = it != pool.freeBlocks.begin() && std::prev(it)->first >= bytes / 2;
     if (roomy) {
         const size_t want = ((size_t) ((double) bytes * g_poolHeadroom) + 255) & ~(size_t) 255;
         if (hipMalloc(p, want) == hipSuccess) { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); r.blocks[*p] = {want, &pool}; return hipSuccess; }
