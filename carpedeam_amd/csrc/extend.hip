@@ -644,12 +644,18 @@ __global__ __launch_bounds__(XR_NT) void k_xr_score(ExtArgs A, XrArgs X) {
             const uint32_t ord = lo, q = qb + ord;
             float2 out = make_float2(NAN, 0.f);
             if (sOff[ord + 1] - sOff[ord] > 1) {
-                const AlnRec rec = A.rec[ra + i]; const SeqMeta tm = meta[rec.target], qm = meta[q];
-                const uint32_t qLen0 = qm.len, qKey = qm.key, tLen = tm.len;
+                const AlnRec rec = A.rec[ra + i]; const SeqMeta qm = meta[q];
+                const uint32_t qLen0 = qm.len, qKey = qm.key;
                 const uint32_t ds = (uint32_t) rec.dbStart, de = (uint32_t) rec.dbEnd, qs = (uint32_t) rec.qStart, qe = (uint32_t) rec.qEnd;
                 const bool rightStart = ds == 0 && qe == (qLen0 - 1);
-                const bool leftStart = qs == 0 && de == (tLen - 1);
-                if ((rightStart || leftStart) && !(rec.qStart > rec.qEnd)) {
+                // (the target's metadata - a random 16-byte read - only for a record that can still be an end overlap: forward strand, and
+                // either a right start or a query start at 0, which a left start needs)
+                SeqMeta tm = {0, 0, 0, 0};
+                const bool maybe = !(rec.qStart > rec.qEnd) && (rightStart || qs == 0);
+                if (maybe) tm = meta[rec.target];
+                const uint32_t tLen = tm.len;
+                const bool leftStart = maybe && qs == 0 && de == (tLen - 1);
+                if (maybe && (rightStart || leftStart)) {
                     const uint32_t alnLen = xrAlnLen(rec);
                     const bool plain = (qm.flags & 1u) == 0 && (tm.flags & 1u) == 0;
                     float seqId = rec.seqId, rySeqId = 0.f;
