@@ -743,7 +743,10 @@ __global__ __launch_bounds__(XR_NT) void k_xr_score(ExtArgs A, XrArgs X) {
     }
 }
 
-__global__ __launch_bounds__(64, 8) void k_xr_extend(ExtArgs A, XrArgs X) {
+#ifndef CDM_XRE_MINW
+#define CDM_XRE_MINW 8
+#endif
+__global__ __launch_bounds__(64, CDM_XRE_MINW) void k_xr_extend(ExtArgs A, XrArgs X) {
     A.raw = nullptr;
     __shared__ double sLogLik[11 * 16];
     for (int i = threadIdx.x; i < 11 * 16; i += blockDim.x) sLogLik[i] = (&A.lut->logLik[0][0][0][0])[i];
