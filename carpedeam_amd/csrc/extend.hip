@@ -612,7 +612,10 @@ __device__ __forceinline__ void xrQuery(VQuery &Q, const ExtArgs &A, uint32_t q,
     Q.nL = 0; Q.nR = 0; Q.leftTotal = 0; Q.total = qm.len; Q.plain = (qm.flags & 1u) == 0;
 }
 
-__global__ __launch_bounds__(XR_NT) void k_xr_score(ExtArgs A, XrArgs X) {
+#ifndef CDM_XRS_MINB
+#define CDM_XRS_MINB 3      // blocks per CU the record kernel's registers leave room for (1 / 3 / 4: 21.1 / 20.85 / 20.95 ms)
+#endif
+__global__ __launch_bounds__(XR_NT, CDM_XRS_MINB) void k_xr_score(ExtArgs A, XrArgs X) {
     A.raw = nullptr;
     __shared__ double sLogLik[11 * 16];
     __shared__ X87 sLogLikX[11 * 16];
