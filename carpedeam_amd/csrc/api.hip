@@ -63,14 +63,25 @@ hipError_t cdmMallocRaw(void **p, size_t bytes) {
     if (bytes == 0) bytes = 256;
     bool roomy = g_poolHeadroom > 1.0f && bytes >= ((size_t) 64 << 20);
     const size_t take = roomy ? (size_t) ((double) bytes * g_poolHeadroom * 1.125) : bytes + bytes / 8;
+    // CDM_POOL_POISON=<byte>: every block handed out is filled with that byte first (tests: a kernel that reads what it never wrote
+    // shows itself; fresh device memory is zero, a cached block holds its last owner's data)
+    static const int poison = getenv("CDM_POOL_POISON") ? (int) strtol(getenv("CDM_POOL_POISON"), NULL, 0) & 0xFF : -1;
     auto it = pool.freeBlocks.lower_bound(bytes);
-    if (it != pool.freeBlocks.end() && it->first <= take) { *p = it->second; pool.freeBlocks.erase(it); return hipSuccess; }
+    if (it != pool.freeBlocks.end() && it->first <= take) {
+        *p = it->second; const size_t have = it->first; pool.freeBlocks.erase(it);
+        if (poison >= 0) { (void) hipDeviceSynchronize(); (void) hipMemset(*p, poison, have); (void) hipDeviceSynchronize(); }
+        return hipSuccess;
+    }
     // head room only where growth shows: a cached block that just fails to hold the request (at least half its size) is the trace of
     // the same buffer one call earlier; a first allocation of its kind (the reads, a one-shot module) gets the exact size
     if (roomy) roomy = it != pool.freeBlocks.begin() && std::prev(it)->first >= bytes / 2;
     if (roomy) {
         const size_t want = ((size_t) ((double) bytes * g_poolHeadroom) + 255) & ~(size_t) 255;
-        if (hipMalloc(p, want) == hipSuccess) { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); r.blocks[*p] = {want, &pool}; return hipSuccess; }
+        if (hipMalloc(p, want) == hipSuccess) {
+            { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); r.blocks[*p] = {want, &pool}; }
+            if (poison >= 0) { (void) hipMemset(*p, poison, want); (void) hipDeviceSynchronize(); }
+            return hipSuccess;
+        }
         (void) hipGetLastError();       // (no room for the head room: the exact size below)
     }
     hipError_t e = hipMalloc(p, bytes);
@@ -80,6 +91,7 @@ hipError_t cdmMallocRaw(void **p, size_t bytes) {
         e = hipMalloc(p, bytes);
     }
     if (e == hipSuccess) { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); r.blocks[*p] = {bytes, &pool}; }
+    if (e == hipSuccess && poison >= 0) { (void) hipMemset(*p, poison, bytes); (void) hipDeviceSynchronize(); }
     return e;
 }
 void cdmFree(void *p) {
