@@ -9,14 +9,17 @@
  * --ancient-damage dhigh` runs the reference's own workflow drivers and scripts, and every kmermatcher / rescorediagonal /
  * ancient_correction / ancient_read_assemble / ancient_contig_merge / cyclecheck / createdb / createhdb / convert2fasta call of
  * those scripts comes back through this program and lands on the MI355X.  A module call whose flags the device path does not
- * implement (carpedeam_mi355x exits with status 77 before doing any work; e.g. linclust's Hamming-distance rescorediagonal)
- * is handed to the reference binary instead - when one is configured; otherwise the refusal stands.
+ * implement (carpedeam_mi355x exits with status 77 before doing any work) is REFUSED: this program exits with EXIT_FAILURE and the
+ * dispatch log gets a "refused <module>" line.  An owned module is never computed by the reference binary behind the caller's back;
+ * only a deployment that sets CARPEDEAM_ALLOW_REF_FALLBACK=1 (an A/B aid, off by default, announced on stderr and logged as
+ * "fallback <module>" every time) gets the old hand-over.
  *
  * This program never touches the GPU (it is plain C and links nothing of HIP), so it may exec; carpedeam_mi355x never execs.
  *
  *   CARPEDEAM_GPU_BIN        the device module binary   (default: carpedeam_mi355x next to this program)
  *   CARPEDEAM_REF_BIN        the reference binary       (default: none - unknown commands are "Invalid Command")
- *   CARPEDEAM_DISPATCH_LOG   append one line per call: "gpu|ref|fallback <module>"
+ *   CARPEDEAM_DISPATCH_LOG   append one line per call: "gpu|ref|refused|fallback <module>"
+ *   CARPEDEAM_ALLOW_REF_FALLBACK=1   hand a refused (status 77) owned module to the reference binary (default: the refusal stands)
  */
 #include <errno.h>
 #include <limits.h>
@@ -76,8 +79,15 @@ int main(int argc, char **argv) {
         int st = 0;
         while (waitpid(pid, &st, 0) < 0) if (errno != EINTR) { perror("carpedeam: waitpid"); return EXIT_FAILURE; }
         if (WIFSIGNALED(st)) { logLine("gpu", argv[1]); return 128 + WTERMSIG(st); }
-        if (WEXITSTATUS(st) != CDM_EXIT_UNSUPPORTED || !ref) { logLine("gpu", argv[1]); return WEXITSTATUS(st) == CDM_EXIT_UNSUPPORTED ? EXIT_FAILURE : WEXITSTATUS(st); }
-        fprintf(stderr, "carpedeam: %s handed to the reference binary (see the message above)\n", argv[1]);
+        if (WEXITSTATUS(st) != CDM_EXIT_UNSUPPORTED) { logLine("gpu", argv[1]); return WEXITSTATUS(st); }
+        const char *allow = getenv("CARPEDEAM_ALLOW_REF_FALLBACK");
+        if (!ref || !allow || strcmp(allow, "1") != 0) {
+            /* the refusal stands: an owned module is not computed by other code than the device path's */
+            fprintf(stderr, "carpedeam: %s refused by the MI355X path (see the message above); not handed to the reference binary\n", argv[1]);
+            logLine("refused", argv[1]);
+            return EXIT_FAILURE;
+        }
+        fprintf(stderr, "carpedeam: CARPEDEAM_ALLOW_REF_FALLBACK=1: %s handed to the REFERENCE binary (see the message above)\n", argv[1]);
         logLine("fallback", argv[1]);
     } else {
         if (!ref) {

@@ -207,9 +207,8 @@ bool parsePlainParallel(const std::string &path, uint32_t fileIdx, Entries &e) {
     std::vector<Entries> part(ok ? T : 0);
     if (ok) {
         std::vector<char> good(T, 0);
-#pragma omp parallel num_threads(T)
-        {
-            const int t = omp_get_thread_num();
+#pragma omp parallel for schedule(static, 1) num_threads(T)     // a loop over the slices: a smaller team still visits them all
+        for (int t = 0; t < T; t++) {
             Entries &pe = part[t];
             const size_t span = start[t + 1] - start[t];
             pe.seqBlob.reserve(span + 2); pe.hdrBlob.reserve(span / 2 + 2);
@@ -231,9 +230,8 @@ bool parsePlainParallel(const std::string &path, uint32_t fileIdx, Entries &e) {
         if (e.hdrBlob.capacity() < h0 + hb[T]) e.hdrBlob.reserve(h0 + hb[T]);
         e.seqBlob.resize(s0 + sb[T]); e.hdrBlob.resize(h0 + hb[T]);
         e.seqOff.resize(n0 + cnt[T]); e.hdrOff.resize(n0 + cnt[T]); e.seqLen.resize(n0 + cnt[T]); e.hdrLen.resize(n0 + cnt[T]); e.file.resize(n0 + cnt[T]);
-#pragma omp parallel num_threads(T)
-        {
-            const int t = omp_get_thread_num();
+#pragma omp parallel for schedule(static, 1) num_threads(T)     // a loop over the slices: a smaller team still visits them all
+        for (int t = 0; t < T; t++) {
             const Entries &pe = part[t];
             memcpy(e.seqBlob.data() + s0 + sb[t], pe.seqBlob.data(), pe.seqBlob.size());
             memcpy(e.hdrBlob.data() + h0 + hb[t], pe.hdrBlob.data(), pe.hdrBlob.size());
@@ -349,9 +347,8 @@ int createdbModule(const std::vector<std::string> &files, const std::string &out
     HVec<char> sBlob(sOff[n]), hBlob(hOff[n]);
     const int T = std::max(1, omp_get_max_threads());
     std::vector<std::string> lookupPart(T);
-#pragma omp parallel num_threads(T)
-    {
-        const int t = omp_get_thread_num();
+#pragma omp parallel for schedule(static, 1) num_threads(T)     // a loop over the slices: a smaller team still visits them all
+    for (int t = 0; t < T; t++) {
         std::string &lk = lookupPart[t];
         for (size_t j = n * (size_t) t / T, hi = n * (size_t) (t + 1) / T; j < hi; j++) {
             const uint32_t i = order[j];

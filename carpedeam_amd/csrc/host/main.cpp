@@ -175,7 +175,8 @@ void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype)
     Laps laps;
     HVec<uint64_t> offs(n); HVec<uint32_t> elen(n); uint64_t tot = 0;
     for (uint64_t i = 0; i < n; i++) { offs[i] = tot; elen[i] = lens[i] + 2; tot += lens[i] + 2; }
-    HVec<char> buf(tot);            // fresh zero pages: the NULs between the entries
+    HVec<char> buf(tot);
+    buf[tot - 1] = '\0';           // the download writes [0, tot - 1): "SEQ\n" per entry and the NULs between them; the last entry's NUL is ours
     laps.lap("    (lengths down, offsets)");
     check(cdm_seqdb_download(ctx, h, buf.data(), offs.data()), "download");
     laps.lap("    (letters unpacked and down)");
@@ -259,11 +260,10 @@ void parseAlnDb(const MmDb &aln, const MmDb &seq, HVec<uint64_t> &off, HVec<cdm_
     const int T = std::max(1, omp_get_max_threads());
     countRecords(aln, seq, off);
     rec.resize(off[seq.size()]);
-    long badKey = -1;
+    long badKey = -1, badEntry = -1;
     const std::vector<size_t> cut = balancedSlices(off.data(), seq.size(), T);
-#pragma omp parallel num_threads(T)
-    {
-        const int t = omp_get_thread_num();
+#pragma omp parallel for schedule(static, 1) num_threads(T)     // a loop over the slices: a smaller team still visits them all
+    for (int t = 0; t < T; t++) {
         const size_t lo = cut[t], hi = cut[t + 1];
         for (size_t i = lo; i < hi; i++) {
             if (off[i + 1] == off[i]) continue;
@@ -290,9 +290,15 @@ void parseAlnDb(const MmDb &aln, const MmDb &seq, HVec<uint64_t> &off, HVec<cdm_
                 while (*d && *d != '\n') d++;
                 if (*d == '\n') d++;
             }
+            // the index length and the entry's NUL must agree (an embedded NUL or a wrong length would leave records unparsed or unfilled)
+            if (badKey < 0 && (out != end || *d)) {
+#pragma omp critical
+                badEntry = (long) seq.key[i];
+            }
         }
     }
     if (badKey >= 0) die("Invalid database read for key " + std::to_string(badKey));
+    if (badEntry >= 0) die("Invalid database read: the entry of key " + std::to_string(badEntry) + " does not end where its index length says");
 }
 cdm_ancient_params ancientParams(Args &a) {
     cdm_ancient_params p;
@@ -309,9 +315,8 @@ void formatPrefDb(const MmDb &seq, const uint64_t *off, const cdm_hit *rec, std:
     chunks.clear(); chunks.resize(T);
     const size_t MAXREC = 10 + 1 + 11 + 1 + 6 + 1;      // "%u\t%d\t%d\n" with a short diagonal
     const std::vector<size_t> cut = balancedSlices(off, seq.size(), T);
-#pragma omp parallel num_threads(T)
-    {
-        const int t = omp_get_thread_num();
+#pragma omp parallel for schedule(static, 1) num_threads(T)     // a loop over the slices: a smaller team still visits them all
+    for (int t = 0; t < T; t++) {
         const size_t lo = cut[t], hi = cut[t + 1];
         OutChunk &c = chunks[t];
         c.reserve(hi - lo, (off[hi] - off[lo]) * MAXREC + (hi - lo));
@@ -330,11 +335,10 @@ void parsePrefDb(const MmDb &pref, const MmDb &seq, HVec<uint64_t> &off, HVec<cd
     const int T = std::max(1, omp_get_max_threads());
     countRecords(pref, seq, off);
     rec.resize(off[seq.size()]);
-    long badKey = -1;
+    long badKey = -1, badEntry = -1;
     const std::vector<size_t> cut = balancedSlices(off.data(), seq.size(), T);
-#pragma omp parallel num_threads(T)
-    {
-        const int t = omp_get_thread_num();
+#pragma omp parallel for schedule(static, 1) num_threads(T)     // a loop over the slices: a smaller team still visits them all
+    for (int t = 0; t < T; t++) {
         const size_t lo = cut[t], hi = cut[t + 1];
         for (size_t i = lo; i < hi; i++) {
             if (off[i + 1] == off[i]) continue;
@@ -353,9 +357,14 @@ void parsePrefDb(const MmDb &pref, const MmDb &seq, HVec<uint64_t> &off, HVec<cd
                 while (*d && *d != '\n') d++;
                 if (*d == '\n') d++;
             }
+            if (badKey < 0 && (out != end || *d)) {
+#pragma omp critical
+                badEntry = (long) seq.key[i];
+            }
         }
     }
     if (badKey >= 0) die("Invalid database read for key " + std::to_string(badKey));
+    if (badEntry >= 0) die("Invalid database read: the entry of key " + std::to_string(badEntry) + " does not end where its index length says");
 }
 // Matcher::resultToBuffer per record, one DB entry per query that has a prefilter entry (rescorediagonal.cpp:145-356)
 void formatAlnDb(const MmDb &seq, const MmDb &pref, const uint64_t *aoff, const cdm_aln *arec, uint64_t dbRes, std::vector<OutChunk> &chunks) {
@@ -363,9 +372,8 @@ void formatAlnDb(const MmDb &seq, const MmDb &pref, const uint64_t *aoff, const 
     chunks.clear(); chunks.resize(T);
     const size_t MAXREC = 10 + 11 + 5 + 14 + 6 * 11 + 10;      // key, bits, seq.id., E-value, six coordinates, separators
     const std::vector<size_t> cut = balancedSlices(aoff, seq.size(), T);
-#pragma omp parallel num_threads(T)
-    {
-        const int t = omp_get_thread_num();
+#pragma omp parallel for schedule(static, 1) num_threads(T)     // a loop over the slices: a smaller team still visits them all
+    for (int t = 0; t < T; t++) {
         const size_t lo = cut[t], hi = cut[t + 1];
         OutChunk &c = chunks[t];
         c.reserve(hi - lo, (aoff[hi] - aoff[lo]) * MAXREC + (hi - lo));
@@ -404,9 +412,8 @@ void formatRescoredPrefDb(const MmDb &seq, const MmDb &pref, const uint64_t *off
     chunks.clear(); chunks.resize(T);
     const size_t MAXREC = 10 + 1 + 11 + 1 + 6 + 1;
     const std::vector<size_t> cut = balancedSlices(off, seq.size(), T);
-#pragma omp parallel num_threads(T)
-    {
-        const int t = omp_get_thread_num();
+#pragma omp parallel for schedule(static, 1) num_threads(T)     // a loop over the slices: a smaller team still visits them all
+    for (int t = 0; t < T; t++) {
         const size_t lo = cut[t], hi = cut[t + 1];
         OutChunk &c = chunks[t];
         c.reserve(hi - lo, (off[hi] - off[lo]) * MAXREC + (hi - lo));

@@ -18,7 +18,7 @@ static size_t fileSize(const std::string &p) { struct stat st; return stat(p.c_s
 
 static const size_t HUGE_MIN = 4u << 20;     // below this the C library's allocator is as good
 void *hugeAlloc(size_t bytes) {
-    if (bytes < HUGE_MIN) { void *p = malloc(bytes ? bytes : 1); if (!p) throw std::bad_alloc(); return p; }
+    if (bytes < HUGE_MIN) { void *p = calloc(bytes ? bytes : 1, 1); if (!p) throw std::bad_alloc(); return p; }    // zeroed like fresh pages: one contract for every size
     void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (p == MAP_FAILED) throw std::bad_alloc();
     static const bool plain = getenv("CDM_NO_HUGEPAGE") != nullptr;      // (A/B switch for measurements)
@@ -67,6 +67,7 @@ bool MmDb::load(const std::string &path, std::string *err, bool indexOnly) {
         for (int i = 0; exists(path + "." + std::to_string(i)); i++) { parts.push_back(path + "." + std::to_string(i)); at.push_back(at.back() + fileSize(parts.back())); }
         if (parts.empty()) { *err = "Could not open data file " + path; return false; }
         owned.resize(at.back() + 1);
+        owned[at.back()] = '\0';      // the sentinel behind the last entry
         for (size_t i = 0; i < parts.size(); i++) if (!readInto(parts[i], owned.data() + at[i], at[i + 1] - at[i])) { *err = "Could not read data file " + parts[i]; return false; }
         base = owned.data(); bytes = at.back();
     }
@@ -85,20 +86,26 @@ bool MmDb::load(const std::string &path, std::string *err, bool indexOnly) {
         bound[t] = b;
     }
     bool sorted = true, inside = true;
-#pragma omp parallel num_threads(T)
-    {
-        const int t = omp_get_thread_num();
-        const size_t lo = bound[t], hi = bound[t + 1];
-        size_t lines = 0;
-        for (const char *q = ix + lo, *e = ix + hi; q < e; lines++) { const char *nl = (const char *) memchr(q, '\n', (size_t) (e - q)); q = nl ? nl + 1 : e; }
+    // a line is an entry when it has its three columns (DBReader skips anything shorter: a blank or cut-off line of a hand-made index);
+    // the slices are a loop, not a team: a smaller team than asked for still visits every slice
+    auto isEntry = [&](size_t p, size_t *next) {
+        int tabs = 0;
+        while (p < ixBytes && ix[p] != '\n') { tabs += ix[p] == '\t'; p++; }
+        *next = p + 1;
+        return tabs >= 2;
+    };
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < T; t++) {
+        size_t lines = 0, nx = 0;
+        for (size_t p = bound[t]; p < bound[t + 1]; p = nx) lines += isEntry(p, &nx);
         first[t + 1] = lines;
-#pragma omp barrier
-#pragma omp single
-        {
-            for (int i = 0; i < T; i++) first[i + 1] += first[i];
-            key.resize(first[T]); off.resize(first[T]); len.resize(first[T]); ext.resize(first[T]);
-        }
-        size_t p = lo, at = first[t];
+    }
+    for (int i = 0; i < T; i++) first[i + 1] += first[i];
+    key.resize(first[T]); off.resize(first[T]); len.resize(first[T]); ext.resize(first[T]);
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < T; t++) {
+        const size_t hi = bound[t + 1];
+        size_t p = bound[t], at = first[t];
         bool ok = true, in = true;
         while (p < hi) {
             unsigned long long v[4] = {0, 0, 0, 0}; int f = 0;
@@ -108,7 +115,7 @@ bool MmDb::load(const std::string &path, std::string *err, bool indexOnly) {
                 p++;
             }
             p++;
-            // (a line without its three columns - not something a DBWriter leaves - reads as an empty entry of key 0 and fails the order check)
+            if (f < 2) continue;
             key[at] = (uint32_t) v[0]; off[at] = v[1]; len[at] = v[2]; ext[at] = (uint8_t) v[3];
             if (at > first[t] && key[at - 1] > key[at]) ok = false;
             if (v[1] + v[2] > bytes) in = false;
@@ -242,9 +249,8 @@ bool mmdbWriteBlob(const std::string &path, int dbtype, const char *blob, size_t
     const int T = std::max(1, omp_get_max_threads());
     std::vector<std::string> ixText(T);
     std::vector<uint64_t> ixBase(T + 1, 0);
-#pragma omp parallel num_threads(T)
-    {
-        const int t = omp_get_thread_num();
+#pragma omp parallel for schedule(static, 1) num_threads(T)     // a loop over the slices: a smaller team still visits them all
+    for (int t = 0; t < T; t++) {
         const size_t lo = n * (size_t) t / T, hi = n * (size_t) (t + 1) / T;
         if (hi > lo) indexText(ixText[t], key + lo, len + lo, ext + lo, hi - lo, off[lo]);
     }

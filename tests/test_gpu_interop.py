@@ -63,7 +63,9 @@ def test_dispatcher_script_runs_one_reads_loop_iteration(tmp_path, dhigh_prefix)
     from carpedeam_amd import build
     build.build()
     t = lambda s: str(tmp_path / s)
-    env = dict(os.environ, CARPEDEAM_REF_BIN=REF if os.path.exists(REF) else "/bin/false")
+    log = t("dispatch.log")
+    env = dict(os.environ, CARPEDEAM_REF_BIN=REF if os.path.exists(REF) else "/bin/false", CARPEDEAM_DISPATCH_LOG=log)
+    env.pop("CARPEDEAM_ALLOW_REF_FALLBACK", None)
     dmg = ["--ancient-damage", dhigh_prefix, "--threads", "4"]
     mmdb.write_from_keyed(t("in"), gold("synth2k", "reads"), mmdb.DBTYPE_NUCLEOTIDES)
     run(WRAP, "kmermatcher", t("in"), t("pref"), *K_FLAGS, "--threads", "4", env=env)
@@ -74,9 +76,12 @@ def test_dispatcher_script_runs_one_reads_loop_iteration(tmp_path, dhigh_prefix)
     assert not bad and sum(n for _, n in ties) <= 1
     if not ties:
         assert not diff_keys(mmdb.read_db(t("asm")), gold("synth2k", "asm", 0))
+    # every one of the four calls ran on the device binary: no hand-over, no refusal, no owned module on the reference
+    assert [l.split() for l in open(log)] == [["gpu", m] for m in ("kmermatcher", "rescorediagonal", "ancient_correction", "ancient_read_assemble")]
     # a module that is not one of the four goes to the reference binary
     r = subprocess.run([WRAP, "not_a_hot_path_module"], capture_output=True, text=True, env=env)
     assert r.returncode != 0
+    assert [l.split() for l in open(log)][4:] == [["ref", "not_a_hot_path_module"]]
 
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref (the reference's object code) is not built here")

@@ -139,3 +139,31 @@ def test_hamming_mode_of_rescorediagonal_on_db_files(tmp_path, oracle_bin, extra
         run_oracle(oracle_bin, "rescorediagonal", t("in"), t("in"), t("pref_ref"), t("res_o"), *flags, "--threads", "4")
         exp = mmdb.read_db(t("res_o"))
     assert not diff_keys(mmdb.read_db(t("res")), exp)
+
+
+def test_sequence_db_data_files_end_with_their_nul_on_a_dirty_heap(tmp_path, dhigh_prefix, oracle_bin):
+    """Every entry of a sequence DB's data file is "SEQ\\n\\0" (DBWriter::writeEnd), the last one included.  The module's download
+    buffer is small here (below the huge-page threshold), so it comes from the C library's heap: MALLOC_PERTURB_ fills every block
+    malloc hands out with a non-zero byte, and the data FILES - not the keyed payloads - are compared byte for byte."""
+    from carpedeam_amd import build
+    from gpuutil import run_oracle
+    build.build()
+    t = lambda s: str(tmp_path / s)
+    env = dict(os.environ, MALLOC_PERTURB_="165")
+    mmdb.write_from_keyed(t("in"), gold("synth2k", "reads"), mmdb.DBTYPE_NUCLEOTIDES)
+    mmdb.write_from_keyed(t("aln"), gold("synth2k", "aln", 0), mmdb.DBTYPE_ALIGNMENT_RES)
+    dmg = ["--ancient-damage", dhigh_prefix, "--threads", "1"]
+    for mod, a, b in (("ancient_correction", "in", "corr"), ("ancient_read_assemble", "corr", "asm")):
+        r = subprocess.run([BIN, mod, t(a), t("aln"), t(b), *A_FLAGS, *dmg], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        run_oracle(oracle_bin, mod, t(a), t("aln"), t("o" + b), *A_FLAGS, *dmg)
+        data = open(t(b), "rb").read()
+        assert data[-2:] == b"\n\0"
+        # one writer thread on both sides: entries in key order, so the files themselves are equal
+        assert data == open(t("o" + b), "rb").read()
+        assert open(t(b) + ".index").read() == open(t("o" + b) + ".index").read()
+    # a result DB read back from split data files (X.0 .. X.n) keeps its sentinel as well: the parse ends at the entry's NUL
+    r = subprocess.run([BIN, "ancient_reads_loop", t("in"), t("loop"), "--ancient-damage", dhigh_prefix, "--num-iter-reads-only", "1"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(t("loop"), "rb").read()[-2:] == b"\n\0"

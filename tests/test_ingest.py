@@ -213,3 +213,19 @@ def test_ingest_keeps_letters_beyond_acgtn(exe, tmp_path):
     run(exe, "convert2fasta", t("g_in.fa"), t("g.fasta"), "-v", "0")
     run(REF, "convert2fasta", t("r_in.fa"), t("r.fasta"), "-v", "0")
     assert open(t("g.fasta"), "rb").read() == open(t("r.fasta"), "rb").read()
+
+
+def test_index_lines_without_three_columns_are_skipped(exe, tmp_path):
+    """A blank or cut-off line of a hand-made index is no entry (DBReader needs its three columns): the DB reads as without it,
+    whatever the number of reader threads (the index is parsed in slices)."""
+    db = str(tmp_path / "db")
+    run(exe, "createdb", example_fastq(tmp_path)[0], db)
+    run(exe, "convert2fasta", db, str(tmp_path / "clean.fasta"))
+    for name in ("db.index", "db_h.index"):
+        lines = open(str(tmp_path / name)).read().split("\n")
+        lines[3:3] = ["", "17"]                        # in the middle: a blank line and a line with one column
+        open(str(tmp_path / name), "w").write("\n".join(lines) + "\n\n")       # and a blank line behind the last entry
+    for threads in ("1", "3", "8"):
+        out = str(tmp_path / ("holes%s.fasta" % threads))
+        run(exe, "convert2fasta", db, out, "--threads", threads)
+        assert digest(out) == digest(str(tmp_path / "clean.fasta"))

@@ -57,10 +57,11 @@ def check_routing(calls, fallbacks):
     assert gpu["ancient_correction"] == 10 and gpu["ancient_read_assemble"] == 5 and gpu["ancient_contig_merge"] == 5 and gpu["cyclecheck"] == 5
     assert gpu["createdb"] == 1 and gpu["createhdb"] == 1 and gpu["convert2fasta"] == 1
     assert gpu["kmermatcher"] == 11                            # 10 of the loop + linclust's
-    # (a module call the device path refuses - status 77 before any work - is handed to the reference: none in this workflow since
-    # linclust's Hamming-distance pre-clustering pass, linclust.sh:27-31, became a mode of the device module)
-    assert gpu["rescorediagonal"] + calls[("fallback", "rescorediagonal")] == 11 and calls[("fallback", "rescorediagonal")] == fallbacks
-    assert sum(n for (where, _), n in calls.items() if where == "fallback") == fallbacks
+    # (a module call the device path refuses - status 77 before any work - is REFUSED by the front end, never handed to the reference,
+    # unless CARPEDEAM_ALLOW_REF_FALLBACK=1: none in this workflow - linclust's Hamming-distance pre-clustering pass, linclust.sh:27-31,
+    # is a mode of the device module)
+    assert gpu["rescorediagonal"] == 11
+    assert sum(n for (where, _), n in calls.items() if where in ("fallback", "refused")) == fallbacks == 0
 
 
 @pytest.mark.skipif(not (os.path.exists(REF_FULL) and os.path.exists(REF_MODULES)), reason="oracle/_ref (the reference's object code) is not built here")
@@ -81,10 +82,19 @@ def test_front_end_without_a_reference_binary(tmp_path):
     assert r.returncode == 1 and "not supported by the MI355X path" in r.stderr
     r = subprocess.run([MODULES, "rescorediagonal", "a", "a", "p", "o", "--rescore-mode", "0"], capture_output=True, text=True, env=env)
     assert r.returncode == 77
-    # ... and goes to the reference binary when there is one (/bin/echo stands in: it prints its arguments)
+    # ... and ALSO when there is a reference binary (/bin/echo stands in: it would print its arguments): an owned module is never
+    # computed by the reference behind the caller's back
+    log = str(tmp_path / "dispatch.log")
     env["CARPEDEAM_REF_BIN"] = "/bin/echo"
+    env["CARPEDEAM_DISPATCH_LOG"] = log
     r = subprocess.run([FRONT, "rescorediagonal", "a", "a", "p", "o", "--rescore-mode", "0"], capture_output=True, text=True, env=env)
-    assert r.returncode == 0 and r.stdout.strip() == "rescorediagonal a a p o --rescore-mode 0" and "handed to the reference binary" in r.stderr
+    assert r.returncode == 1 and r.stdout == "" and "not handed to the reference binary" in r.stderr
+    assert open(log).read().split() == ["refused", "rescorediagonal"]
+    # the hand-over exists only as an explicit opt-in, announced and logged
+    env["CARPEDEAM_ALLOW_REF_FALLBACK"] = "1"
+    r = subprocess.run([FRONT, "rescorediagonal", "a", "a", "p", "o", "--rescore-mode", "0"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.strip() == "rescorediagonal a a p o --rescore-mode 0" and "handed to the REFERENCE binary" in r.stderr
+    assert open(log).read().split() == ["refused", "rescorediagonal", "fallback", "rescorediagonal"]
 
 
 @pytest.mark.gpu
