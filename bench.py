@@ -44,6 +44,14 @@ def baseline_metric():
         return "corrected bases/sec on 50M×100bp synthetic reads (dhigh), 1/2/4/8 GPU"
 
 
+def host_ram():
+    try:
+        kb = {l.split(":")[0]: int(l.split()[1]) for l in open("/proc/meminfo") if l.split(":")[0] in ("MemTotal", "MemAvailable")}
+        return "%.0f GB total, %.0f GB available" % (kb["MemTotal"] / 1e6, kb["MemAvailable"] / 1e6)
+    except Exception:
+        return "unknown"
+
+
 def stage_cmds(p, exe_threads, dmg):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
@@ -340,18 +348,22 @@ def main():
             iter_ms = k_ms[13] / launches if k_ms[13] > 0 else 0.0
             sort_bytes = 2.0 * 12.0 * n1
             achieved = sort_bytes / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
-            traffic, traffic_total = None, None
+            traffic, traffic_total, traffic_from = None, None, None
             pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_50M*.json")))
             if n == 50_000_000 and L == 100 and world == 1 and pmcs:
                 try:
                     pj = json.load(open(pmcs[-1]))
                     traffic = pj["kernels"]["rx::k_rx_pass<unsigned long, unsigned int>"]["hbm_bytes_per_launch"]
                     traffic_total = {"file": os.path.basename(pmcs[-1]), "hbm_bytes_per_step": pj.get("stages")}
+                    traffic_from = "profiles/" + os.path.basename(pmcs[-1]) + " (rocprofv3 --pmc passes of this workload, committed; not collected in this run)"
                 except Exception:
                     traffic = None
             stages = {"kmermatcher": k_ms[8], "rescorediagonal": k_ms[9], "ancient_correction": k_ms[10], "ancient_read_assemble": k_ms[11]}
             roof = {"bound": "hbm", "kernel": "rx::k_rx_pass<u64 key, u32 value> (hand-written onesweep radix pass, 9 bits; kmermatcher sort 1: 3 passes over the k-mer slots)",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
+                    # frac is the dominant kernel's per-launch figure; frac_8d prices the whole step on SURVEY.md 8(d)'s bytes (32.2 B/base:
+                    # every radix pass beyond one write + one read of the tuples is overhead there) - the smaller, stricter number
+                    "frac_8d": gbs(sum(ALG_B_PER_BASE.values()), step_ms) / HBM_PEAK_GBS,
                     "avg_launch_ms": iter_ms, "launches_per_step": launches, "algorithmic_bytes_per_launch": sort_bytes,
                     "how": "HIP events around the %d pass launches of a step: %.2f ms in total (the whole sort-1 call incl. histogram and status resets: %.2f ms)" % (launches, k_ms[13], k_ms[5]),
                     # the figures that price the radix passes as overhead (the tuple array is written once and read
@@ -383,6 +395,12 @@ def main():
             try:
                 # the pool gives a one-GPU job 16 host cores; the reference's kmermatcher slows down when oversubscribed
                 cpu, gpu = module_walls(args.cpu_reads, L, args.seed, min(os.cpu_count() or 1, int(os.environ.get("CDM_CPU_THREADS", 16))))
+                if args.cpu_reads != args.reads:
+                    # why a sample and not the metric's own corpus: the contract bounds the CPU leg (10-30 s of CPU work per stage set, the
+                    # default run within minutes); the reference's four modules take ~6 s per million reads on 16 threads, i.e. ~5 min at
+                    # 50 M, and its kmermatcher alone wants 16 B x 81 tuples per read = 65 GB of host RAM there (--cpu-reads 50000000 runs it)
+                    cpu["sample_is"] = "%d of the workload's %d reads (same generator and seed); host RAM %s; --cpu-reads %d would run the whole corpus" % (
+                        args.cpu_reads, args.reads, host_ram(), args.reads)
                 line["cpu_baseline"] = cpu
                 line["gpu_module_wall"] = gpu
                 # like for like (same DB files, same host threads, DB read/parse/write inside both): what the north star's ">= 20x the CPU
