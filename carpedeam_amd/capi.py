@@ -62,7 +62,7 @@ EXPORTS = [
     "cdm_evalue", "cdm_bit_score", "cdm_correct", "cdm_extend",
     "cdm_kmermatch_part", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_sort", "cdm_kpart_vote", "cdm_kpart_cont_cap", "cdm_kpart_free", "cdm_dev_copy",
     "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
-    "cdm_rescore_hamming", "cdm_pool_headroom",
+    "cdm_rescore_hamming", "cdm_pool_headroom", "cdm_env_refresh",
 ]
 
 
@@ -139,8 +139,19 @@ def lib():
         l.cdm_seqdb_copy_ext.argtypes = [vp, vp, vp]
         l.cdm_contig_merge.argtypes = [vp, vp, vp, C.POINTER(AncientParams), C.c_float, C.POINTER(vp)]
         l.cdm_cyclecheck.argtypes = [vp, vp, C.c_uint32, C.c_int, C.POINTER(vp), C.POINTER(vp), vp]
+        l.cdm_env_refresh.restype = None
         _lib = l
+    # The library snapshots its CDM_* switches once per process (no getenv on its call paths, csrc/pool.h).  Tests and A/B runs change
+    # them between calls of one process: when os.environ's CDM_* entries differ from what the library last saw, it reads them again.
+    global _env_seen
+    env = {k: v for k, v in os.environ.items() if k.startswith("CDM_")}
+    if env != _env_seen:
+        _env_seen = env
+        _lib.cdm_env_refresh()
     return _lib
+
+
+_env_seen = None
 
 
 def _check(rc):

@@ -15,108 +15,43 @@ void cdm_set_error(const char *fmt, ...) {
 }
 extern "C" const char *cdm_last_error(void) { return g_err; }
 
-// ------------------------------------------------------------------------------------------------ caching allocator
-#include <map>
-#include <mutex>
-#include <unordered_map>
-#include <sys/syscall.h>
-#include <unistd.h>
-namespace {
-// One cache of free blocks per host thread and device: a context belongs to one host thread, and a block freed by
-// one thread's stream must not be handed to another thread's stream without synchronisation (ranks as threads of one process in
-// the tests).  Which block has which size and whose it is lives in ONE process-wide registry: a block freed by another thread than
-// its allocator's is released and forgotten there, so no cache can meet its address again with a stale size.
-struct Pool;
-struct Registry {
-    std::mutex m;
-    std::unordered_map<void *, std::pair<size_t, Pool *>> blocks;
-};
-Registry &registry() { static Registry *r = new Registry(); return *r; }      // (never destroyed: thread_local pools may outlive statics)
-struct Pool {
-    std::multimap<size_t, void *> freeBlocks;                                  // touched by the owning thread only
-    void trim() {
-        Registry &r = registry();
-        std::lock_guard<std::mutex> g(r.m);
-        for (auto &kv : freeBlocks) { r.blocks.erase(kv.second); (void) hipFree(kv.second); }
-        freeBlocks.clear();
-    }
-};
-struct Pools {
-    Pool p[64];
-    // a thread that ends without cdm_ctx_destroy gives its blocks back (not the main thread: its end is the end of the process, and
-    // the HIP runtime may be half-way through its own tear-down by then)
-    ~Pools() { if (getpid() != (pid_t) syscall(SYS_gettid)) for (Pool &q : p) if (!q.freeBlocks.empty()) q.trim(); }
-};
-Pool &poolOf(int dev) { static thread_local Pools pools; return pools.p[dev & 63]; }
-}  // namespace
-// Head room for workloads whose buffers GROW from call to call (the contig iterations of the workflow loop: sequences, tuples and
-// records get ~1.5x longer per iteration, so no cached block ever fits the next request and every iteration maps tens of GB anew -
-// which costs ~46 ms per GB on some hosts, 0.1-1.1 s per iteration at 1-2 M reads).  With a factor f > 1 a large block is allocated
-// f times the request - where a cached block of at least half the size shows that the buffer grows - and a cached block up to that
-// much larger than a request is taken: the next iteration's buffers fit the previous iteration's blocks.  Off (1) by default; `ancient_reads_loop` switches it on.
-static float g_poolHeadroom = 1.0f;
-extern "C" void cdm_pool_headroom(float factor) { g_poolHeadroom = factor > 1.0f ? std::min(factor, 4.0f) : 1.0f; }
-hipError_t cdmMallocRaw(void **p, size_t bytes) {
-    int dev = 0; hipGetDevice(&dev);
-    Pool &pool = poolOf(dev);
-    bytes = (bytes + 255) & ~(size_t) 255;
-    if (bytes == 0) bytes = 256;
-    bool roomy = g_poolHeadroom > 1.0f && bytes >= ((size_t) 64 << 20);
-    const size_t take = roomy ? (size_t) ((double) bytes * g_poolHeadroom * 1.125) : bytes + bytes / 8;
-    // CDM_POOL_POISON=<byte>: every block handed out is filled with that byte first (tests: a kernel that reads what it never wrote
-    // shows itself; fresh device memory is zero, a cached block holds its last owner's data)
-    static const int poison = getenv("CDM_POOL_POISON") ? (int) strtol(getenv("CDM_POOL_POISON"), NULL, 0) & 0xFF : -1;
-    auto it = pool.freeBlocks.lower_bound(bytes);
-    if (it != pool.freeBlocks.end() && it->first <= take) {
-        *p = it->second; const size_t have = it->first; pool.freeBlocks.erase(it);
-        if (poison >= 0) { (void) hipDeviceSynchronize(); (void) hipMemset(*p, poison, have); (void) hipDeviceSynchronize(); }
-        return hipSuccess;
-    }
-    // head room only where growth shows: a cached block that just fails to hold the request (at least half its size) is the trace of
-    // the same buffer one call earlier; a first allocation of its kind (the reads, a one-shot module) gets the exact size
-    if (roomy) roomy = it != pool.freeBlocks.begin() && std::prev(it)->first >= bytes / 2;
-    if (roomy) {
-        const size_t want = ((size_t) ((double) bytes * g_poolHeadroom) + 255) & ~(size_t) 255;
-        if (hipMalloc(p, want) == hipSuccess) {
-            { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); r.blocks[*p] = {want, &pool}; }
-            if (poison >= 0) { (void) hipMemset(*p, poison, want); (void) hipDeviceSynchronize(); }
-            return hipSuccess;
-        }
-        (void) hipGetLastError();       // (no room for the head room: the exact size below)
-    }
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess) {   // out of memory with blocks parked in the cache: release them and retry once
-        (void) hipGetLastError();
-        cdmPoolTrim();
-        e = hipMalloc(p, bytes);
-    }
-    if (e == hipSuccess) { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); r.blocks[*p] = {bytes, &pool}; }
-    if (e == hipSuccess && poison >= 0) { (void) hipMemset(*p, poison, bytes); (void) hipDeviceSynchronize(); }
-    return e;
-}
-void cdmFree(void *p) {
-    if (!p) return;
-    int dev = 0; hipGetDevice(&dev);
-    Pool &pool = poolOf(dev);
-    size_t bytes = 0;
-    {
-        Registry &r = registry();
-        std::lock_guard<std::mutex> g(r.m);
-        auto it = r.blocks.find(p);
-        if (it != r.blocks.end() && it->second.second == &pool) bytes = it->second.first;
-        else if (it != r.blocks.end()) r.blocks.erase(it);
-    }
-    if (bytes) pool.freeBlocks.emplace(bytes, p);
-    else (void) hipFree(p);
-}
-void cdmPoolTrim() {
-    int dev = 0; hipGetDevice(&dev);
-    poolOf(dev).trim();
-}
+// ------------------------------------------------------------------------------------------------ caching allocator, CDM_* switches
+#include "pool.h"
+const char *cdmGetenv(const char *name) { return cdmenv::get(name); }
+extern "C" void cdm_env_refresh(void) { (void) cdmenv::refresh(); }
+extern "C" void cdm_pool_headroom(float factor) { cdmpool::headroom().store(factor > 1.0f ? std::min(factor, 4.0f) : 1.0f, std::memory_order_relaxed); }
+hipError_t cdmMallocRaw(void **p, size_t bytes) { return cdmpool::allocate(p, bytes); }
+void cdmFree(void *p) { cdmpool::release(p); }
+void cdmPoolTrim() { cdmpool::trimMine(); }
 
 // ------------------------------------------------------------------------------------------------ context
+// CDM_SEGV_BACKTRACE=1 (diagnosis, scripts/stress_kpart.py): a SIGSEGV / SIGBUS / SIGABRT of the process prints the faulting thread's
+// native stack (backtrace_symbols_fd: async-signal-safe) before the default action takes its course.
+#include <execinfo.h>
+#include <signal.h>
+static void cdmFaultHandler(int sig, siginfo_t *info, void *) {
+    static const char head[] = "\n*** libcarpedeam_hip: fatal signal, native stack of the faulting thread:\n";
+    (void) !write(2, head, sizeof(head) - 1);
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    (void) info;
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static void cdmInstallFaultHandler() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (!cdmGetenv("CDM_SEGV_BACKTRACE")) return;
+        void *warm[4]; (void) backtrace(warm, 4);       // (loads libgcc now, not inside the handler)
+        struct sigaction sa; memset(&sa, 0, sizeof(sa));
+        sa.sa_sigaction = cdmFaultHandler; sa.sa_flags = SA_SIGINFO | SA_NODEFER | SA_RESETHAND;
+        sigaction(SIGSEGV, &sa, nullptr); sigaction(SIGBUS, &sa, nullptr); sigaction(SIGABRT, &sa, nullptr);
+    });
+}
 extern "C" int cdm_ctx_create(int device, cdm_ctx **out) {
     if (!out) { cdm_set_error("cdm_ctx_create: out is NULL"); return CDM_ERR_INVALID; }
+    cdmInstallFaultHandler();
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         cdm_set_error("no HIP device available: the carpedeam MI355X path has no CPU fallback");
@@ -606,7 +541,7 @@ extern "C" int cdm_seqdb_from_packed_ext(cdm_ctx *ctx, const void *codes, const 
 template <typename F>
 static void cdmHostParallel(uint64_t n, F fn, const uint64_t *weight = nullptr) {
     unsigned T = std::thread::hardware_concurrency();
-    if (const char *e = getenv("OMP_NUM_THREADS")) { const int v = atoi(e); if (v > 0) T = (unsigned) v; }
+    if (const char *e = cdmGetenv("OMP_NUM_THREADS")) { const int v = atoi(e); if (v > 0) T = (unsigned) v; }
     T = std::max(1u, std::min(T, 16u));
     if (n < 100000 || T == 1) { fn(0, n); return; }
     std::vector<uint64_t> cut(T + 1, n);

@@ -426,7 +426,7 @@ inline int loadBigList(hipStream_t s, const unsigned long long *bigList, unsigne
 // CDM_BUCKET_CAP=<largest bucket>[,<owned range>] lowers the capacities (tests: reach the big-bucket path on small inputs)
 inline void capacities(int &own, uint32_t &maxBucket) {
     own = WV_OWN; maxBucket = BK_MAXB;
-    if (const char *e = getenv("CDM_BUCKET_CAP")) {
+    if (const char *e = cdmGetenv("CDM_BUCKET_CAP")) {
         const long m = atol(e);
         if (m >= 1 && m <= BK_MAXB) maxBucket = (uint32_t) m;
         if (const char *comma = strchr(e, ',')) { const long v = atol(comma + 1); if (v >= 1 && v <= WV_OWN) own = (int) v; }
@@ -449,7 +449,7 @@ inline int bucketSortKeys(hipStream_t s, const uint64_t *in, uint64_t *out, uint
     if (cnt == 0) return CDM_OK;
     DevBuf<unsigned long long> ranges; uint64_t total = 0;
     if (int rc = loadBigList(s, bigList.p, cnt, ranges, total)) return rc;
-    if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "bucketSortKeys: n %llu shiftHi %d: %u big buckets, %llu elements\n", (unsigned long long) n, shiftHi, cnt, (unsigned long long) total);
+    if (cdmGetenv("CDM_BUCKET_STATS")) fprintf(stderr, "bucketSortKeys: n %llu shiftHi %d: %u big buckets, %llu elements\n", (unsigned long long) n, shiftHi, cnt, (unsigned long long) total);
     DevBuf<uint64_t> d0, d1;
     if (!d0.alloc(total) || !d1.alloc(total)) return CDM_ERR_HIP;
     const unsigned int grid = bigCopyGrid(cnt);

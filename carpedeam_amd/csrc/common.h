@@ -17,11 +17,13 @@ void cdm_set_error(const char *fmt, ...);
 hipError_t cdmMallocRaw(void **p, size_t bytes);
 void cdmFree(void *p);
 void cdmPoolTrim();   // give every cached block back to the driver
+// value of a CDM_* switch (or OMP_NUM_THREADS) from the library's snapshot of the environment (pool.h: never getenv on a call path)
+const char *cdmGetenv(const char *name);
 template <typename T> inline hipError_t cdmMalloc(T **p, size_t bytes) { return cdmMallocRaw(reinterpret_cast<void **>(p), bytes); }
 
 // RAII device buffer from the caching allocator (freed on every exit path of a stage function)
 // experiments: dynamic LDS (bytes, from the environment) added to a launch to lower its occupancy
-inline unsigned cdm_lds_pad(const char *name) { const char *e = getenv(name); return e ? (unsigned) atoi(e) : 0u; }
+inline unsigned cdm_lds_pad(const char *name) { const char *e = cdmGetenv(name); return e ? (unsigned) atoi(e) : 0u; }
 
 template <typename T> struct DevBuf {
     T *p = nullptr;

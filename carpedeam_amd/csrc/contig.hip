@@ -113,7 +113,7 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     if (nRec) hipLaunchKernelGGL(k_contig_stats, dim3((unsigned) ((nRec * 64 + 255) / 256)), dim3(256), 0, s, a);
     hipEventRecord(ctx->ev1, s);
     // everything else is per-query bookkeeping on the host: sequences, records and the per-record statistics come down once
-    const bool timing = getenv("CDM_TIMING") != nullptr;
+    const bool timing = cdmGetenv("CDM_TIMING") != nullptr;
     auto tNow = [] { return std::chrono::steady_clock::now(); };
     auto tPrev = tNow();
     auto lap = [&](const char *what) { if (timing) { const auto t = tNow(); fprintf(stderr, "  contig merge: %-28s %.3f s\n", what, std::chrono::duration<double>(t - tPrev).count()); tPrev = t; } };

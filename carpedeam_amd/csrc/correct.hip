@@ -518,7 +518,7 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
     CDM_HIP(hipMemcpyAsync(out->nmask, db->nmask, ((db->words * 16 + 31) / 32) * 4, hipMemcpyDeviceToDevice, s));
     CDM_HIP(hipMemsetAsync(counters.p, 0, 16, s));   // [0] queries for the general kernel, [1] error flag, [2] queries for the fast kernel
     // CDM_CORRECT_VARIANT (experiments): "0" = one fast instance for up to 64 records; "s<W>" = small instance (<= 15 records) with W waves per SIMD
-    const char *varEnv = getenv("CDM_CORRECT_VARIANT");
+    const char *varEnv = cdmGetenv("CDM_CORRECT_VARIANT");
     const int smallW = (varEnv && varEnv[0] == 's') ? atoi(varEnv + 1) : (varEnv && varEnv[0] == '0' ? 0 : 6);
     if (db->raw) {
         CDM_HIP(hipMemcpyAsync(out->raw, db->raw, db->words * 16, hipMemcpyDeviceToDevice, s));
@@ -533,12 +533,12 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
     a.outCodes = out->codes; a.outNmask = out->nmask; a.lut = ctx->lutDev; a.seqIdThr = par->seq_id_thr; a.corrRy = par->corr_reads_ry_seq_id;
     const int blocks = ctx->cuCount * 8;
     hipEventRecord(ctx->ev0, s);
-    const char *padEnv = getenv("CDM_LDS_PAD");          // experiments: dynamic LDS that lowers the occupancy
+    const char *padEnv = cdmGetenv("CDM_LDS_PAD");          // experiments: dynamic LDS that lowers the occupancy
     const unsigned pad = padEnv ? (unsigned) atoi(padEnv) : 0u;
     if (smallW == 8) hipLaunchKernelGGL((k_correct_fast<15, uint8_t, 8>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeSmall.p, counters.p + 3);
     else if (smallW == 5) hipLaunchKernelGGL((k_correct_fast<15, uint8_t, 5>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeSmall.p, counters.p + 3);
     else if (smallW) hipLaunchKernelGGL((k_correct_fast<15, uint8_t, 6>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeSmall.p, counters.p + 3);
-    const char *bigEnv = getenv("CDM_CORRECT_BIGW");     // experiments: waves per SIMD of the 16..64-record instance
+    const char *bigEnv = cdmGetenv("CDM_CORRECT_BIGW");     // experiments: waves per SIMD of the 16..64-record instance
     const int bigW = bigEnv ? atoi(bigEnv) : 5;
     if (bigW == 6) hipLaunchKernelGGL((k_correct_fast<64, uint16_t, 6>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeFast.p, counters.p + 2);
     else if (bigW == 5) hipLaunchKernelGGL((k_correct_fast<64, uint16_t, 5>), dim3(blocks * 2), dim3(64 * FAST_WAVES), pad, s, a, activeFast.p, counters.p + 2);

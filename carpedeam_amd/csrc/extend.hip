@@ -930,13 +930,13 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     A.seqIdThr = par->seq_id_thr; A.rySeqIdThr = par->ry_seq_id_thr; A.likelihoodThr = par->likelihood_threshold;
     A.excessLog = std::log(par->excess_penal); A.randLog = std::log(par->rand_align_penal);   // std::log(float): float, as in the reference
     A.ratioLogit = (double) logl(1.0L / (long double) par->likelihood_threshold - 1.0L);
-    A.marginScale = getenv("CDM_EXTEND_MARGIN") ? (float) atof(getenv("CDM_EXTEND_MARGIN")) : 1.0f;
+    A.marginScale = cdmGetenv("CDM_EXTEND_MARGIN") ? (float) atof(cdmGetenv("CDM_EXTEND_MARGIN")) : 1.0f;
     A.maxSeqLen = par->max_seq_len;
     A.unsafe = par->unsafe ? 1 : 0; A.minCov = (uint32_t) std::max(0, par->min_cov_safe); A.flags = flags.p;
     hipEventRecord(ctx->ev0, s);
-    const char *padEnv = getenv("CDM_LDS_PAD");          // experiments: dynamic LDS that lowers the occupancy
-    const char *wEnv = getenv("CDM_EXTEND_WAVES");        // experiments: waves per SIMD the register allocation leaves room for
-    const char *formEnv = getenv("CDM_EXTEND");           // "queries": k_extend (one lane per query) for every call
+    const char *padEnv = cdmGetenv("CDM_LDS_PAD");          // experiments: dynamic LDS that lowers the occupancy
+    const char *wEnv = cdmGetenv("CDM_EXTEND_WAVES");        // experiments: waves per SIMD the register allocation leaves room for
+    const char *formEnv = cdmGetenv("CDM_EXTEND");           // "queries": k_extend (one lane per query) for every call
     const int minW = wEnv ? atoi(wEnv) : 8;
     const unsigned padB = padEnv ? (unsigned) atoi(padEnv) : 0u;
     // one thread per record for A-D (k_xr_*) where that form applies: the default mode, no raw plane

@@ -222,9 +222,9 @@ void unsafeColumns(const Res &c, const std::string &cons, const SeqView &t0, uns
 // job owns a share (the contig phase of `bench.py --config 5` took 36 s that way and 23 s on 16 threads) - so the default is capped.
 static int cdm_host_threads() {
     static const int n = [] {
-        if (const char *e = getenv("CDM_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+        if (const char *e = cdmGetenv("CDM_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
         const int m = std::max(1, omp_get_max_threads());
-        return getenv("OMP_NUM_THREADS") ? m : std::min(m, 16);
+        return cdmGetenv("OMP_NUM_THREADS") ? m : std::min(m, 16);
     }();
     return n;
 }
@@ -256,7 +256,7 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
     outSeqs.assign(n, std::string()); outExt.assign(n, 0); changed.assign(n, 0);
     const float ryThr = par->ry_seq_id_thr;
     bool undefinedCase = false;
-    const bool timing = getenv("CDM_TIMING") != nullptr;       // per-thread seconds in: candidate gate, queue pops, string growth, parked hits
+    const bool timing = cdmGetenv("CDM_TIMING") != nullptr;       // per-thread seconds in: candidate gate, queue pops, string growth, parked hits
     double tSum[4] = {0, 0, 0, 0}, tMax[4] = {0, 0, 0, 0}; unsigned long long nCmp = 0, nTerms = 0;
 #pragma omp parallel num_threads(cdm_host_threads())
     {

@@ -1242,7 +1242,7 @@ int phaseA() override {
     idBits = bitsFor(n); diagBits = bitsFor(2ull * db->maxLen + 2);
     if (2 * idBits + diagBits + 1 > 63) { cdm_set_error("cdm_kmermatch: %u sequences x max length %u do not fit the 64-bit (rep,id,diagonal) sort key", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
     diagBias = (int) db->maxLen + 1;
-    sortEnv = getenv("CDM_KMER_SORT");
+    sortEnv = cdmGetenv("CDM_KMER_SORT");
     lsdOnly = sortEnv && !strcmp(sortEnv, "lsd");
 
     if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !listSingle.alloc(n) || !listHuge.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1) || !rankOf.alloc(n)) {
@@ -1345,7 +1345,7 @@ int phaseA() override {
     DevBuf<char> tmp1;
     if (!tmp1.alloc(std::max(tmpBytes, tmpBytesH) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
     // The passes themselves: the hand-written onesweep of radix.h (CDM_KMER_SORT1=rocprim: rocPRIM's, for A/B runs and the tests).
-    const char *sort1Env = getenv("CDM_KMER_SORT1");
+    const char *sort1Env = cdmGetenv("CDM_KMER_SORT1");
     const bool ownRadix = !(lsdOnly || fourPasses) && !(sort1Env && !strcmp(sort1Env, "rocprim"));
     hipEventRecord(ctx->ev0, s);
     if (ownRadix && nparts > 1 && kmerSlots) {
@@ -1443,7 +1443,7 @@ int phaseA() override {
                 // buckets the kernel left alone: gather them, sort on the whole k-mer, group, scatter the group keys back
                 DevBuf<unsigned long long> ranges; uint64_t total = 0; unsigned long long firstStart = ~0ull;
                 rc = bucket::loadBigList(s, bigList.p, nBig, ranges, total, &firstStart);
-                if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "kmermatch sort 1: %llu slots, low bits %d: %u big buckets, %llu tuples\n", (unsigned long long) kmerSlots, lowBits, nBig, (unsigned long long) total);
+                if (cdmGetenv("CDM_BUCKET_STATS")) fprintf(stderr, "kmermatch sort 1: %llu slots, low bits %d: %u big buckets, %llu tuples\n", (unsigned long long) kmerSlots, lowBits, nBig, (unsigned long long) total);
                 DevBuf<uint64_t> dk0, dk1; DevBuf<V> dv0, dv1; DevBuf<unsigned long long> ds;
                 if (rc == CDM_OK && (!dk0.alloc(total) || !dk1.alloc(total) || !dv0.alloc(total) || !dv1.alloc(total) || !ds.alloc(total))) rc = CDM_ERR_HIP;
                 if (rc == CDM_OK) {
@@ -1523,7 +1523,7 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
     // (bucket.h).  CDM_KMER_SORT2=check runs both and compares the two arrays on the device.
     if (ownBuffers) { v0.free(); v1.free(); }                                // the tuple values are dead after k_groups
     const int top2 = (int) (2 * idBits + diagBits + 1);
-    const char *sort2Env = getenv("CDM_KMER_SORT2");
+    const char *sort2Env = cdmGetenv("CDM_KMER_SORT2");
     const bool sort2Check = sort2Env && !strcmp(sort2Env, "check");
     const bool sort2Runs = !lsdOnly && (!sort2Env || !strcmp(sort2Env, "runs") || sort2Check);
     if (sort2Env && strcmp(sort2Env, "runs") && strcmp(sort2Env, "radix") && !sort2Check) { cdm_set_error("cdm_kmermatch: CDM_KMER_SORT2 must be runs, radix or check"); return CDM_ERR_INVALID; }
@@ -1560,7 +1560,7 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
             // Default on one device: the representatives' tuples are aggregated, not sorted (aggvote.h).  The tuple path below stays for
             // the multi-GPU split (its ranks exchange heads of the sorted array), for keys too wide for the aggregation's sort word,
             // under CDM_KMER_VOTE=tuples, and as the fallback when the entry buffer overflows.
-            const char *voteEnv = getenv("CDM_KMER_VOTE");
+            const char *voteEnv = cdmGetenv("CDM_KMER_VOTE");
             bool aggregated = ownBuffers && !sort2Check && !(voteEnv && !strcmp(voteEnv, "tuples")) && aggv::AG_ORD + idBits + diagBits + aggv::AG_IDX <= 64;
             if (aggregated) {
                 int rc = aggregate(sortedOut, nGroup, rk.current(), (const uint64_t *) rv.current(), dst.p, nRec, gk, top2);
@@ -1655,7 +1655,7 @@ int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *re
     using namespace aggv;
     cdmscan::ScanTemp st;
     unsigned long long capEnt = nGroup / 6 + (4ull << 20);
-    if (const char *e = getenv("CDM_AGG_CAP")) capEnt = strtoull(e, nullptr, 10);      // tests: force the overflow fallback
+    if (const char *e = cdmGetenv("CDM_AGG_CAP")) capEnt = strtoull(e, nullptr, 10);      // tests: force the overflow fallback
     if (!agSegOfRec.alloc(nRec + 2) || !agPerRep.alloc((size_t) n + 1) || !agCursor.alloc(2) || !agFlags.alloc(4)) { cdm_set_error("cdm_kmermatch: out of device memory (aggregation)"); return CDM_ERR_HIP; }
     hipLaunchKernelGGL(k_seg_flags, dim3((unsigned) ((nRec + 1024) / 1024)), dim3(1024), 0, s, recRep, (uint64_t) nRec, agSegOfRec.p);
     if (int rc = cdmscan::exclusiveScan<uint32_t>(s, st, agSegOfRec.p, agSegOfRec.p, (size_t) nRec + 1)) return rc;
@@ -1673,7 +1673,7 @@ int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *re
     a.keys = gk; a.recVal = recVal; a.dst = dst; a.nRec = nRec; a.segOfRec = agSegOfRec.p; a.segRep = agSegRep.p; a.segFirstRec = agSegFirstRec.p; a.nSeg = nSeg;
     a.entOff = agEntOff.p; a.entCnt = agEntCnt.p; a.perRep = agPerRep.p; a.ent = agEnt.p; a.cursor = agCursor.p; a.cap = capEnt; a.overflow = agFlags.p;
     a.maxD = AG_D;
-    if (const char *e = getenv("CDM_AGG_D")) { const long v = atol(e); if (v >= 1 && v <= AG_D) a.maxD = (uint32_t) v; }
+    if (const char *e = cdmGetenv("CDM_AGG_D")) { const long v = atol(e); if (v >= 1 && v <= AG_D) a.maxD = (uint32_t) v; }
     a.repShift = (int) (idBits + diagBits + 1); a.diagBits = (int) diagBits; a.idBits = idBits; a.sorted = sortedOut; a.list = nullptr; a.count = nullptr; a.hard.list = nullptr; a.hard.cnt = nullptr;
     if (runsort::segmentedSortKeys(s, ctx->cuCount, sortedOut, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, recRep, dst, nRec, gk, recVal, aggUnitHook, &a) != CDM_OK) {
         cdm_set_error("cdm_kmermatch: segmented sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP;
@@ -1690,7 +1690,7 @@ int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *re
     }
     unsigned long long used = 0;
     hipMemcpy(&used, agCursor.p, 8, hipMemcpyDeviceToHost);
-    if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "aggregate: %llu group tuples, %u segments, %llu entries (room for %llu), %u segments through the tuple sorters%s\n", nGroup, nSeg, used, capEnt, fl[1],
+    if (cdmGetenv("CDM_BUCKET_STATS")) fprintf(stderr, "aggregate: %llu group tuples, %u segments, %llu entries (room for %llu), %u segments through the tuple sorters%s\n", nGroup, nSeg, used, capEnt, fl[1],
                                             fl[0] ? "; entry buffer overflow" : "");
     if (fl[0]) { agEnt.free(); return CDM_ERR_UNSUPPORTED; }
     nSegM = nSeg;
@@ -1813,7 +1813,7 @@ __global__ void k_rep_bounds(const uint64_t *__restrict__ keys, uint64_t n, int 
 }  // namespace
 extern "C" int cdm_kmermatch_part(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int part, int nparts, cdm_kpart **out) {
     if (!ctx || !db || !par || !out || nparts < 1 || part < 0 || part >= nparts) { cdm_set_error("cdm_kmermatch_part: invalid argument"); return CDM_ERR_INVALID; }
-    if (getenv("CDM_KMER_SORT") || getenv("CDM_KMER_SORT2")) { cdm_set_error("cdm_kmermatch_part: the A/B switches CDM_KMER_SORT / CDM_KMER_SORT2 apply to the single-device path only"); return CDM_ERR_INVALID; }
+    if (cdmGetenv("CDM_KMER_SORT") || cdmGetenv("CDM_KMER_SORT2")) { cdm_set_error("cdm_kmermatch_part: the A/B switches CDM_KMER_SORT / CDM_KMER_SORT2 apply to the single-device path only"); return CDM_ERR_INVALID; }
     CDM_HIP(hipSetDevice(ctx->device));
     cdm_kpart *h = new cdm_kpart();
     if (packedLayoutFits(db, par->kmer_size)) h->job = new KmerJob<LayoutPacked>(ctx, db, par);
@@ -1881,7 +1881,7 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     const int k = par->kmer_size;
     const bool fits = 2 * k + 1 + 2 * (int) bitsFor((uint64_t) db->maxLen + 1) <= 63;
     bool packed = fits;
-    if (const char *e = getenv("CDM_KMER_LAYOUT")) {
+    if (const char *e = cdmGetenv("CDM_KMER_LAYOUT")) {
         if (!strcmp(e, "wide")) packed = false;
         else if (!strcmp(e, "packed")) {
             if (!fits) { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT=packed needs 2k + 1 + 2 x length bits <= 63 (k %d, max length %u)", k, db->maxLen); return CDM_ERR_INVALID; }

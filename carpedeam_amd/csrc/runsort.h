@@ -491,10 +491,10 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
     using namespace bucket;
     if (n == 0) return CDM_OK;
     uint32_t maxSeg = U_MAXSEG, blockCap = 4096;
-    if (const char *e = getenv("CDM_UNIT_CAP")) { const long m = atol(e); if (m >= 1 && m <= U_MAXSEG) maxSeg = (uint32_t) m; }
-    if (const char *e = getenv("CDM_BLOCK_CAP")) { const long m = atol(e); if (m >= 0 && m <= 4096) blockCap = (uint32_t) m; }
+    if (const char *e = cdmGetenv("CDM_UNIT_CAP")) { const long m = atol(e); if (m >= 1 && m <= U_MAXSEG) maxSeg = (uint32_t) m; }
+    if (const char *e = cdmGetenv("CDM_BLOCK_CAP")) { const long m = atol(e); if (m >= 0 && m <= 4096) blockCap = (uint32_t) m; }
     uint32_t maxSub = BK_MAXB;
-    if (const char *e = getenv("CDM_UNIT_SUB")) { const long m = atol(e); if (m >= 1 && m <= BK_MAXB) maxSub = (uint32_t) m; }
+    if (const char *e = cdmGetenv("CDM_UNIT_SUB")) { const long m = atol(e); if (m >= 1 && m <= BK_MAXB) maxSub = (uint32_t) m; }
     if (shiftHi - 1 + BLK_IDX > 64) blockCap = 0;       // the block sorter's word does not hold such keys: rocPRIM takes them
     if (U_ORDB + shiftHi - 1 + U_IDXB > 64) maxSeg = 0; // nor does the unit sorter's (ordinal, id, diagonal, index): everything goes to rocPRIM
     const uint64_t units = (n + U_T - 1) / U_T;
@@ -538,7 +538,7 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
     if (blockCap) hipLaunchKernelGGL(k_block_sort<8>, dim3((unsigned int) std::min<uint64_t>((uint64_t) cuCount * 8, listCap)), dim3(512), 0, s, ba);
     unsigned int hc[NCNT] = {0};
     if (hipMemcpyAsync(hc, cnt.p, NCNT * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
-    if (getenv("CDM_BUCKET_STATS")) fprintf(stderr, "segmentedSortKeys%s: n %llu, %llu records, %llu units (%u / %u / %u by size class): segments > %u: %u (<= %u, block sort), %u longer (rocPRIM); %u hard units (rocPRIM)\n",
+    if (cdmGetenv("CDM_BUCKET_STATS")) fprintf(stderr, "segmentedSortKeys%s: n %llu, %llu records, %llu units (%u / %u / %u by size class): segments > %u: %u (<= %u, block sort), %u longer (rocPRIM); %u hard units (rocPRIM)\n",
                                             unitHook ? " (units aggregated)" : "", (unsigned long long) n, (unsigned long long) nRec, (unsigned long long) units, hc[SEG_CLASSES + 1], hc[SEG_CLASSES + 2], hc[SEG_CLASSES + 3], maxSeg, hc[2], blockCap, hc[3], hc[SEG_CLASSES]);
     const unsigned int nBig = hc[3] + hc[SEG_CLASSES];
     if (nBig == 0) return CDM_OK;
@@ -571,9 +571,9 @@ inline int makeRunRecords(hipStream_t s, const RunArgs &ra, DevBuf<uint32_t> &rr
     const uint64_t tiles = (ra.n + RUN_TILE - 1) / RUN_TILE;
     nRec = 0;
     if (tiles == 0) return CDM_OK;
-    const char *mode = getenv("CDM_RUN_RECORDS");          // "twopass": the fallback only (tests)
+    const char *mode = cdmGetenv("CDM_RUN_RECORDS");          // "twopass": the fallback only (tests)
     unsigned long long cap = ra.n / 8 + 4096;
-    if (const char *e = getenv("CDM_RUN_CAP")) cap = strtoull(e, nullptr, 10);       // tests: force the overflow path
+    if (const char *e = cdmGetenv("CDM_RUN_CAP")) cap = strtoull(e, nullptr, 10);       // tests: force the overflow path
     if (!(mode && !strcmp(mode, "twopass"))) {
         DevBuf<unsigned long long> status, total; DevBuf<unsigned int> flags;
         if (!status.alloc(tiles) || !total.alloc(1) || !flags.alloc(2) || !rr0.alloc(cap) || !rr1.alloc(cap) || !rv0.alloc(cap + 1) || !rv1.alloc(cap + 1)) { cdm_set_error("run records: out of device memory"); return CDM_ERR_HIP; }

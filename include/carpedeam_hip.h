@@ -189,6 +189,10 @@ void cdm_kpart_free(cdm_kpart *h);
  * the workflow loop): large blocks are allocated `factor` times the request, so the next, larger request fits a cached block instead of
  * mapping device memory anew.  1 = off (default); process-wide. */
 void cdm_pool_headroom(float factor);
+/* The library reads its CDM_* switches (A/B and test aids) from the environment ONCE per process, not with getenv() on
+ * its call paths (getenv is not safe beside a setenv elsewhere in the process).  cdm_env_refresh() reads them again - for tests and A/B
+ * runs that change a switch inside one process; call it while no other thread is inside the library. */
+void cdm_env_refresh(void);
 /* device-to-device copy on the context's stream (synchronises it): moves library-owned buffers into caller tensors */
 int cdm_dev_copy(cdm_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 
