@@ -139,7 +139,10 @@ def lib():
         l.cdm_seqdb_copy_ext.argtypes = [vp, vp, vp]
         l.cdm_contig_merge.argtypes = [vp, vp, vp, C.POINTER(AncientParams), C.c_float, C.POINTER(vp)]
         l.cdm_cyclecheck.argtypes = [vp, vp, C.c_uint32, C.c_int, C.POINTER(vp), C.POINTER(vp), vp]
-        l.cdm_env_refresh.restype = None
+        try:
+            l.cdm_env_refresh.restype = None
+        except AttributeError:          # (CDM_LIB names an older build of the library - bisecting: it reads its switches with getenv)
+            pass
         _lib = l
     # The library snapshots its CDM_* switches once per process (no getenv on its call paths, csrc/pool.h).  Tests and A/B runs change
     # them between calls of one process: when os.environ's CDM_* entries differ from what the library last saw, it reads them again.
@@ -147,7 +150,8 @@ def lib():
     env = {k: v for k, v in os.environ.items() if k.startswith("CDM_")}
     if env != _env_seen:
         _env_seen = env
-        _lib.cdm_env_refresh()
+        if hasattr(_lib, "cdm_env_refresh"):
+            _lib.cdm_env_refresh()
     return _lib
 
 

@@ -51,6 +51,7 @@ struct AggArgs {
     const unsigned long long *list; const unsigned int *count;      // the units of this size class (start, end, first record)
     bucket::BigList hard;
     unsigned int nextClass = 0;     // (host side: which size class the next launch is for)
+    int wideWord = 0;               // (host side: the entry sort needs the 128-bit word)
 };
 constexpr int AG_H = 1024, AG_D = 512, AG_IDX = 9, AG_ORD = 11;
 static_assert((1 << AG_IDX) >= AG_D && (1 << AG_ORD) > runsort::U_T, "aggregation geometry");
@@ -63,7 +64,8 @@ __device__ __forceinline__ uint32_t aggHash(uint64_t k) { return (uint32_t) ((k 
 // (waves per SIMD the register allocation leaves room for: unbounded the kernel takes 112-130 VGPRs - the register network of the
 // entry sort - and runs 3-4 waves per SIMD where its LDS allows 5; swept 3 / 4 / 5 / 6: 85.3 / 83.8 / 87.0 / 84.6 ms of sort 2 - within the noise; halving the
 // occupancy with an LDS pad costs 30 ms: the kernel runs on the latency of its gathers and LDS round trips)
-template <int NT, int ITEMS>
+// W: word of the entry sort, (ordinal, id, diagonal, index in the compacted table) - 64 bits while that fits, 128 beyond
+template <int NT, int ITEMS, typename W = uint64_t>
 __global__ __launch_bounds__(NT, CDM_AGG_MINW) void k_unit_agg(AggArgs a) {
     using namespace runsort;
     // the hash table; once its entries are compacted the same memory holds the per-ordinal directory of the unit
@@ -153,12 +155,12 @@ __global__ __launch_bounds__(NT, CDM_AGG_MINW) void k_unit_agg(AggArgs a) {
         __syncthreads();
         // ---- sort the D entries by (ordinal, id, diagonal): one wave, the register network of bucket.h
         if (wave == 0) {
-            bucket::sortGroup<uint64_t>((int) D, lane,
-                [&](int i) { return (dKey[i] << AG_IDX) | (uint64_t) i; },
+            bucket::sortGroup<W>((int) D, lane,
+                [&](int i) { return ((W) dKey[i] << AG_IDX) | (W) i; },
                 [&](auto &v) {
                     constexpr int R = sizeof(v) / sizeof(v[0]);
 #pragma unroll
-                    for (int r = 0; r < R; r++) { const int p = lane * R + r; if (p < (int) D) sPerm[p] = (uint16_t) (v[r] & ((1u << AG_IDX) - 1u)); }
+                    for (int r = 0; r < R; r++) { const int p = lane * R + r; if (p < (int) D) sPerm[p] = (uint16_t) ((uint32_t) v[r] & ((1u << AG_IDX) - 1u)); }
                 });
         }
         const unsigned int nOrd = sMaxOrd + 1u;

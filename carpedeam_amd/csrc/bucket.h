@@ -98,6 +98,10 @@ template <int M> struct XorLane<uint32_t, M> { __device__ static __forceinline__
 template <int M> struct XorLane<uint64_t, M> {
     __device__ static __forceinline__ uint64_t get(uint64_t a) { return ((uint64_t) xorLane32<M>((uint32_t) (a >> 32)) << 32) | xorLane32<M>((uint32_t) a); }
 };
+typedef unsigned __int128 u128;         // sort word of the aggregation when (ordinal, id, diagonal, index) needs more than 64 bits
+template <int M> struct XorLane<u128, M> {
+    __device__ static __forceinline__ u128 get(u128 a) { return ((u128) XorLane<uint64_t, M>::get((uint64_t) (a >> 64)) << 64) | XorLane<uint64_t, M>::get((uint64_t) a); }
+};
 // d is a constant once the network loops are unrolled: the switch folds away
 template <typename W> __device__ __forceinline__ W xorLane(W a, int d) {
     switch (d) {

@@ -85,6 +85,21 @@ struct LayoutWideT {
 };
 typedef LayoutWideT<16> LayoutWide;
 typedef LayoutWideT<20> LayoutLong;
+// 16 bytes for any DB: u64 key = k-mer | strand << 63, u64 value = id << 32 | pos; the sequence's length is looked up (a DB of 2^24
+// sequences or more with one of them beyond 65 534 letters: the contig iterations of a 25 M-read run, BASELINE config 5)
+struct LayoutHuge {
+    typedef uint64_t V;
+    __device__ static void store(uint64_t *keys, V *vals, uint64_t slot, uint64_t kmer63, bool fwd, uint32_t seq, uint32_t, uint32_t pos, const TupleGeom &) {
+        keys[slot] = kmer63 | (fwd ? BIT63 : 0ull); vals[slot] = ((uint64_t) seq << 32) | pos;
+    }
+    __device__ static void storeHash(uint64_t *keys, V *vals, uint64_t slot, uint64_t hash64, uint32_t seq, uint32_t, const TupleGeom &) { keys[slot] = hash64; vals[slot] = (uint64_t) seq << 32; }
+    __device__ static void storeEmpty(uint64_t *keys, V *vals, uint64_t slot) { keys[slot] = ~0ull; vals[slot] = 0; }
+    __device__ static uint64_t kmerOf(uint64_t key, uint64_t, const TupleGeom &) { return key & ~BIT63; }
+    __device__ static uint32_t seqOf(V v) { return (uint32_t) (v >> 32); }
+    __device__ static uint32_t lenOf(uint64_t, V v, uint64_t, const TupleGeom &g) { return g.lenArr[(uint32_t) (v >> 32)]; }
+    __device__ static uint32_t posOf(uint64_t, V v, uint64_t, const TupleGeom &) { return (uint32_t) v; }
+    __device__ static void unpackR1(uint64_t, V v, const TupleGeom &g, uint32_t &len, uint32_t &pos) { pos = (uint32_t) v; len = g.lenArr[(uint32_t) (v >> 32)]; }
+};
 // 12 bytes: u64 key = k-mer | pos << (2k + 1) | len << (2k + 1 + lb) | strand << 63, u32 value = id.  Needs 2k + 1 + 2 lb <= 63
 // (k = 20: sequences up to 2047 letters); a quarter less traffic in every radix pass.  Bit 2k stays clear in every real tuple
 // of region 1 (in both layouts): it is set only in the unused-slot key ~0, so sorting region 1 on bits up to and including
@@ -679,6 +694,7 @@ struct GroupParams {
     uint64_t n;
     int onlyExtendable, covMode; float covThr;
     uint32_t idBits, diagBits; int diagBias;
+    int wide;                   // group keys without the representative (runsort.h: GK_START / GK_DROPPED mark the run starts)
     uint64_t first;             // the kernel covers the tuples [first, n)
     uint64_t firstRunIdx;       // index of the array's very first tuple in this view (0; ~0 if the view does not hold it)
     unsigned long long *stat;   // STAT_STRIPES counters: members kept
@@ -704,9 +720,15 @@ __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float q
         default: return true;
     }
 }
-// key layout of the second sort: [ rep | id | diagonal + bias | strand ] , strand (1 = query needs no reversal) in bit 0
+// key layout of the second sort: [ rep | id | diagonal + bias | strand ] , strand (1 = query needs no reversal) in bit 0; the wide form
+// (DBs whose ids and diagonals do not leave room for the representative in 63 bits) is [ id | diagonal + bias | strand ]
 __device__ __forceinline__ uint64_t packGroupKey(const GroupParams &a, uint32_t rep, uint32_t id, int diag, bool noRev) {
-    return ((((uint64_t) rep << a.idBits) | id) << (a.diagBits + 1)) | ((uint64_t) (uint32_t) (diag + a.diagBias) << 1) | (noRev ? 1ull : 0ull);
+    const uint64_t hi = a.wide ? (uint64_t) id : (((uint64_t) rep << a.idBits) | id);
+    return (hi << (a.diagBits + 1)) | ((uint64_t) (uint32_t) (diag + a.diagBias) << 1) | (noRev ? 1ull : 0ull);
+}
+// wide form: the first slot of a k-mer run with members names the representative (its own tuple: id == rep), kept or not
+__device__ __forceinline__ uint64_t markRunStart(const GroupParams &a, uint64_t gk, uint32_t rep) {
+    return (runsort::gkKept(gk) ? gk : (runsort::GK_DROPPED | ((uint64_t) rep << (a.diagBits + 1)))) | runsort::GK_START;
 }
 // run start index of every tuple = inclusive max-scan of (start ? i : 0); fed to the scan through this functor
 template <typename LY> struct StartIndex {
@@ -772,11 +794,12 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs<LY> a, unsigned long l
                     if (pe < bestPos) { bestPos = pe; bestKey = a.keys[e]; }
                 }
                 gk = groupKeyOf<LY>(a, a.geom, bestKey, best, st, bestPos, st == a.firstRunIdx, key, a.vals[i], i);
+                if (a.wide && st == i) gk = markRunStart(a, gk, repId);
             }
         }
         startIo[i] = gk;
     }
-    waveGroupStats(a.stat, (uint32_t) __popcll(__ballot(gk != ~0ull)));
+    waveGroupStats(a.stat, (uint32_t) __popcll(__ballot(runsort::gkKept(gk))));
 }
 
 // K2b + K3 fused for region 1 when only the top bits of the k-mer went through the global radix passes (bucket.h): a wave
@@ -879,9 +902,10 @@ __global__ __launch_bounds__(bucket::BK_NT, CDM_GK_MINW) void k_bucket_groups(Bu
                     LY::unpackR1(key, val, a.geom, tLen, tPos);
                     const bool firstRun = r0 + (uint64_t) (g0 + s0) == a.firstRunIdx;
                     gk = groupKeyCore(a, repId, (int) repLen, (int) bestPos, firstRun ? false : ((bestKey & BIT63) == 0), LY::seqOf(val), (int) tLen, (int) tPos, (key & BIT63) == 0);
+                    if (a.wide && s0 == p) gk = markRunStart(a, gk, repId);
                 }
                 a.out[r0 + (uint64_t) (g0 + p)] = gk;
-                keptCnt += (uint32_t) __popcll(__ballot(gk != ~0ull));
+                keptCnt += (uint32_t) __popcll(__ballot(runsort::gkKept(gk)));
             }
             waveLdsSync();      // ss is reused by the next group
         });
@@ -1216,6 +1240,7 @@ struct KmerJob : KmerJobBase {
     typedef typename LY::V V;
     hipStream_t s = nullptr; uint32_t n = 0; int k = 0;
     uint32_t idBits = 0, diagBits = 0; int diagBias = 0; const char *sortEnv = nullptr; bool lsdOnly = false;
+    bool wide = false;                        // group keys without the representative (runsort.h RunArgs; packGroupKey)
     DevBuf<unsigned long long> counters;      // scratch counters ([2] = number of kept group tuples)
     DevBuf<unsigned int> cls;                 // slow-path list sizes
     DevBuf<uint32_t> listShort, listLong, listSingle, listHuge;
@@ -1240,7 +1265,14 @@ int phaseA() override {
     if (k < 4 || k > 31) { cdm_set_error("cdm_kmermatch: k must be in 4..31 (got %d)", k); return CDM_ERR_INVALID; }
     constexpr uint32_t SHORT_CAP = 256, LONG_CAP = 4096;
     idBits = bitsFor(n); diagBits = bitsFor(2ull * db->maxLen + 2);
-    if (2 * idBits + diagBits + 1 > 63) { cdm_set_error("cdm_kmermatch: %u sequences x max length %u do not fit the 64-bit (rep,id,diagonal) sort key", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
+    // (rep, id, diagonal, strand) in one word while it fits 63 bits - 2 M sequences with contigs of 500 k letters, 50 M reads of 2 k
+    // letters; beyond that (25 M sequences with contigs: BASELINE config 5) the representative leaves the key (the wide form:
+    // runsort.h RunArgs) and sort 2 + vote run on aggregated entries only.  CDM_FORCE_WIDE_KEY=1: the wide form for any DB (tests).
+    wide = 2 * idBits + diagBits + 1 > 63 || cdmGetenv("CDM_FORCE_WIDE_KEY") != nullptr;
+    if (wide && (int) (aggv::AG_ORD + idBits + diagBits) > 64) {
+        cdm_set_error("cdm_kmermatch: %u sequences x max length %u: ids and diagonals beyond %d bits are not implemented", n, db->maxLen, 64 - aggv::AG_ORD); return CDM_ERR_UNSUPPORTED;
+    }
+    if (wide && nparts > 1) { cdm_set_error("cdm_kmermatch_part: %u sequences x max length %u need the wide group key, which the k-mer-range split does not carry yet", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
     diagBias = (int) db->maxLen + 1;
     sortEnv = cdmGetenv("CDM_KMER_SORT");
     lsdOnly = sortEnv && !strcmp(sortEnv, "lsd");
@@ -1392,7 +1424,7 @@ int phaseA() override {
     // order-preserving compaction
     ga.geom = geom;
     ga.keys = keys.current(); ga.vals = vals.current(); ga.n = nTuples; ga.onlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode;
-    ga.covThr = par->cov_thr; ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias; ga.first = 0;
+    ga.covThr = par->cov_thr; ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias; ga.first = 0; ga.wide = wide ? 1 : 0;
     ga.firstRunIdx = anyBelow ? ~0ull : 0ull;      // the very first run of the (global) array is in the lowest k-mer range that has tuples
     if (!statStripes.alloc(STAT_STRIPES)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipMemsetAsync(statStripes.p, 0, STAT_STRIPES * 8, s);
@@ -1522,10 +1554,11 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
     // kept members; the top 32 of those bits go through global radix passes, the rest is finished bucket by bucket on chip
     // (bucket.h).  CDM_KMER_SORT2=check runs both and compares the two arrays on the device.
     if (ownBuffers) { v0.free(); v1.free(); }                                // the tuple values are dead after k_groups
-    const int top2 = (int) (2 * idBits + diagBits + 1);
+    const int top2 = (int) ((wide ? idBits : 2 * idBits) + diagBits + 1);
     const char *sort2Env = cdmGetenv("CDM_KMER_SORT2");
     const bool sort2Check = sort2Env && !strcmp(sort2Env, "check");
     const bool sort2Runs = !lsdOnly && (!sort2Env || !strcmp(sort2Env, "runs") || sort2Check);
+    if (wide && (!sort2Runs || sort2Check || !ownBuffers)) { cdm_set_error("cdm_kmermatch: the wide group key runs on the default pipeline only (run records + aggregated entries)"); return CDM_ERR_UNSUPPORTED; }
     if (sort2Env && strcmp(sort2Env, "runs") && strcmp(sort2Env, "radix") && !sort2Check) { cdm_set_error("cdm_kmermatch: CDM_KMER_SORT2 must be runs, radix or check"); return CDM_ERR_INVALID; }
     unsigned long long nGroup = 0;
     const uint64_t *sorted2 = nullptr;
@@ -1541,6 +1574,7 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
             sortedOut = runsOut.p;
         }
         RunArgs ra; ra.keys = gk; ra.n = nIn; ra.skipLo = skipLo; ra.skipHi = skipHi; ra.repShift = (int) (idBits + diagBits + 1);
+        ra.wide = wide ? 1 : 0; ra.idShift = (int) diagBits + 1; ra.idMask = (1ull << idBits) - 1ull;
         cdmscan::ScanTemp stB;
         unsigned long long nRec = 0;
         DevBuf<uint32_t> rr0, rr1; DevBuf<uint64_t> rv0, rv1; DevBuf<unsigned long long> dst;
@@ -1561,10 +1595,19 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
             // the multi-GPU split (its ranks exchange heads of the sorted array), for keys too wide for the aggregation's sort word,
             // under CDM_KMER_VOTE=tuples, and as the fallback when the entry buffer overflows.
             const char *voteEnv = cdmGetenv("CDM_KMER_VOTE");
-            bool aggregated = ownBuffers && !sort2Check && !(voteEnv && !strcmp(voteEnv, "tuples")) && aggv::AG_ORD + idBits + diagBits + aggv::AG_IDX <= 64;
+            const bool wordFits = aggv::AG_ORD + idBits + diagBits + aggv::AG_IDX <= 64 && !(wide && cdmGetenv("CDM_FORCE_WIDE_WORD"));    // (tests: the 128-bit entry sort word for any DB)
+            bool aggregated = wide || (ownBuffers && !sort2Check && !(voteEnv && !strcmp(voteEnv, "tuples")) && wordFits);
+            if (wide && ownBuffers && nGroup != nKept) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu in the run records", nKept, nGroup); return CDM_ERR_HIP; }
             if (aggregated) {
-                int rc = aggregate(sortedOut, nGroup, rk.current(), (const uint64_t *) rv.current(), dst.p, nRec, gk, top2);
-                if (rc == CDM_ERR_UNSUPPORTED) aggregated = false;      // (entry buffer too small for this input: the tuple path)
+                // (the wide form has no tuple path to fall back to: an entry buffer that proves too small is tried again, larger)
+                unsigned long long capEnt = nGroup / 6 + (4ull << 20);
+                if (const char *e = cdmGetenv("CDM_AGG_CAP")) capEnt = strtoull(e, nullptr, 10);      // tests: force the overflow fallback
+                int rc = aggregate(sortedOut, nGroup, rk.current(), (const uint64_t *) rv.current(), dst.p, nRec, gk, top2, capEnt, !wordFits);
+                while (rc == CDM_ERR_UNSUPPORTED && wide && capEnt < nGroup + 1) {
+                    capEnt = std::min<unsigned long long>(nGroup + 1, std::max<unsigned long long>(capEnt * 3, 1024));
+                    rc = aggregate(sortedOut, nGroup, rk.current(), (const uint64_t *) rv.current(), dst.p, nRec, gk, top2, capEnt, !wordFits);
+                }
+                if (rc == CDM_ERR_UNSUPPORTED && !wide) aggregated = false;      // (entry buffer too small for this input: the tuple path)
                 else if (rc) return rc;
             }
             haveEntries = aggregated;
@@ -1646,16 +1689,21 @@ static void aggUnitHook(hipStream_t st, unsigned int grid, const unsigned long l
     a.list = list; a.count = count; a.hard = hard;
     const int cls = (int) (u->nextClass++ % runsort::U_CLASSES);       // (called once per size class, smallest first)
     const unsigned int pad = cdm_lds_pad("CDM_LDS_PAD_AGG");
+    if (u->wideWord) {
+        if (cls == 0) hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[0] / 256, bucket::u128>), dim3(grid), dim3(256), pad, st, a);
+        else if (cls == 1) hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[1] / 256, bucket::u128>), dim3(grid), dim3(256), pad, st, a);
+        else hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[2] / 256, bucket::u128>), dim3(grid), dim3(256), pad, st, a);
+        return;
+    }
     if (cls == 0) hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[0] / 256>), dim3(grid), dim3(256), pad, st, a);
     else if (cls == 1) hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[1] / 256>), dim3(grid), dim3(256), pad, st, a);
     else hipLaunchKernelGGL((aggv::k_unit_agg<256, runsort::U_CLASS_CAP[2] / 256>), dim3(grid), dim3(256), pad, st, a);
 }
 int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *recRep, const uint64_t *recVal, const unsigned long long *dst, unsigned long long nRec,
-              const uint64_t *gk, int top2) {
+              const uint64_t *gk, int top2, unsigned long long capEnt, bool wideWord) {
     using namespace aggv;
     cdmscan::ScanTemp st;
-    unsigned long long capEnt = nGroup / 6 + (4ull << 20);
-    if (const char *e = cdmGetenv("CDM_AGG_CAP")) capEnt = strtoull(e, nullptr, 10);      // tests: force the overflow fallback
+    agEnt.free(); agSegOfRec.free(); agPerRep.free(); agCursor.free(); agFlags.free(); agSegRep.free(); agSegFirstRec.free(); agEntOff.free(); agEntCnt.free(); agPending.free();     // (a second try)
     if (!agSegOfRec.alloc(nRec + 2) || !agPerRep.alloc((size_t) n + 1) || !agCursor.alloc(2) || !agFlags.alloc(4)) { cdm_set_error("cdm_kmermatch: out of device memory (aggregation)"); return CDM_ERR_HIP; }
     hipLaunchKernelGGL(k_seg_flags, dim3((unsigned) ((nRec + 1024) / 1024)), dim3(1024), 0, s, recRep, (uint64_t) nRec, agSegOfRec.p);
     if (int rc = cdmscan::exclusiveScan<uint32_t>(s, st, agSegOfRec.p, agSegOfRec.p, (size_t) nRec + 1)) return rc;
@@ -1675,7 +1723,8 @@ int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *re
     a.maxD = AG_D;
     if (const char *e = cdmGetenv("CDM_AGG_D")) { const long v = atol(e); if (v >= 1 && v <= AG_D) a.maxD = (uint32_t) v; }
     a.repShift = (int) (idBits + diagBits + 1); a.diagBits = (int) diagBits; a.idBits = idBits; a.sorted = sortedOut; a.list = nullptr; a.count = nullptr; a.hard.list = nullptr; a.hard.cnt = nullptr;
-    if (runsort::segmentedSortKeys(s, ctx->cuCount, sortedOut, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, recRep, dst, nRec, gk, recVal, aggUnitHook, &a) != CDM_OK) {
+    a.wideWord = wideWord ? 1 : 0;
+    if (runsort::segmentedSortKeys(s, ctx->cuCount, sortedOut, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, recRep, dst, nRec, gk, recVal, aggUnitHook, &a, wide) != CDM_OK) {
         cdm_set_error("cdm_kmermatch: segmented sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP;
     }
     // the segments the tuple sorters finished (deep pile-ups, units with too many distinct triples)
@@ -1797,6 +1846,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
 
 }  // namespace
 
+constexpr uint32_t MAX_SEQ_LETTERS = 1u << 22;        // (diagonals of 24 bits: a tuple position is 32 bits wide, the group key's diagonal field is what bounds it)
 static bool packedLayoutFits(const cdm_seqdb *db, int k) { return 2 * k + 1 + 2 * (int) bitsFor((uint64_t) db->maxLen + 1) <= 63; }
 
 // ---- multi-GPU: kmermatcher in two phases with an exchange in between (include/carpedeam_hip.h, carpedeam_amd/shard.py)
@@ -1819,7 +1869,8 @@ extern "C" int cdm_kmermatch_part(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_k
     if (packedLayoutFits(db, par->kmer_size)) h->job = new KmerJob<LayoutPacked>(ctx, db, par);
     else if (db->maxLen < 65535u) h->job = new KmerJob<LayoutWide>(ctx, db, par);
     else if (db->maxLen < (1u << 20) - 1u && db->n < (1ull << 24)) h->job = new KmerJob<LayoutLong>(ctx, db, par);
-    else { delete h; cdm_set_error("cdm_kmermatch_part: sequences of 2^20 letters or more, or longer than 65 534 letters in a DB of 2^24 sequences or more, are not implemented"); return CDM_ERR_UNSUPPORTED; }
+    else if (db->maxLen < MAX_SEQ_LETTERS) h->job = new KmerJob<LayoutHuge>(ctx, db, par);
+    else { delete h; cdm_set_error("cdm_kmermatch_part: sequences of %u letters or more are not implemented", MAX_SEQ_LETTERS); return CDM_ERR_UNSUPPORTED; }
     h->job->part = part; h->job->nparts = nparts; h->nSeq = db->n;
     h->repShift = bitsFor(db->n) + bitsFor(2ull * db->maxLen + 2) + 1;
     const int rc = h->job->phaseA();
@@ -1888,8 +1939,9 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
         } else { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT must be wide or packed"); return CDM_ERR_INVALID; }
     }
     if (packed) return kmermatchT<LayoutPacked>(ctx, db, par, out);
-    if (db->maxLen < 65535u) return kmermatchT<LayoutWide>(ctx, db, par, out);
-    if (db->maxLen < (1u << 20) - 1u && db->n < (1ull << 24)) return kmermatchT<LayoutLong>(ctx, db, par, out);
-    cdm_set_error("cdm_kmermatch: sequences of 2^20 letters or more, or longer than 65 534 letters in a DB of 2^24 sequences or more, are not implemented");
+    if (db->maxLen < 65535u && !cdmGetenv("CDM_FORCE_HUGE_LAYOUT")) return kmermatchT<LayoutWide>(ctx, db, par, out);
+    if (db->maxLen < (1u << 20) - 1u && db->n < (1ull << 24) && !cdmGetenv("CDM_FORCE_HUGE_LAYOUT")) return kmermatchT<LayoutLong>(ctx, db, par, out);
+    if (db->maxLen < MAX_SEQ_LETTERS) return kmermatchT<LayoutHuge>(ctx, db, par, out);       // (CDM_FORCE_HUGE_LAYOUT=1 with CDM_KMER_LAYOUT=wide: this layout for any DB, tests)
+    cdm_set_error("cdm_kmermatch: sequences of %u letters or more are not implemented", MAX_SEQ_LETTERS);
     return CDM_ERR_UNSUPPORTED;
 }

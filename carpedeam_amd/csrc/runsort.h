@@ -33,11 +33,20 @@ template <> struct RunBitsOf<8> { typedef uint8_t T; };
 typedef RunBitsOf<RUN_ITEMS>::T RunBits;
 constexpr int RUN_CNT_BITS = 13;                                                 // a record's length <= RUN_TILE
 
+// Group keys come in two forms (kmermatch.hip, packGroupKey).  Narrow: [rep | id | diagonal | strand] in one word - while that fits 63
+// bits.  Wide (any DB: 2^32 sequences, contigs of millions of letters): [START | DROPPED | id | diagonal | strand] - the representative
+// is not in the member's key.  It does not have to be: the first tuple of a k-mer run IS the representative's own tuple, so the first
+// slot of every run with members carries GK_START and, in its id field, the representative - with GK_DROPPED if that tuple itself is
+// not kept (a self tuple under --include-only-extendable).  A slot's representative is the id of the nearest START at or in front
+// of it; from the run records on, the representative lives in the records (recRep / segRep), never in a key.
+constexpr uint64_t GK_START = 1ull << 62, GK_DROPPED = 1ull << 63;
+__host__ __device__ __forceinline__ bool gkKept(uint64_t k) { return (k >> 63) == 0ull; }      // (~0 and a dropped run start are not; narrow keys end below bit 63)
 struct RunArgs {
     const uint64_t *keys;       // group keys in k-mer order, ~0 = dropped / unused slot
     uint64_t n;                 // slots
     uint64_t skipLo, skipHi;    // [skipLo, skipHi) holds only unused slots (the tail of region 1): not read
-    int repShift;               // rep = key >> repShift
+    int repShift;               // narrow: rep = key >> repShift
+    int wide = 0, idShift = 0; uint64_t idMask = 0;        // wide: id = (key >> idShift) & idMask
 };
 // LDS image of a tile, one pad per 16 items (thread t walks items 16 t .. 16 t + 15 without bank conflicts)
 __device__ __forceinline__ int runPad(int i) { return i + (i >> 4); }
@@ -47,13 +56,85 @@ constexpr int RUN_LDS = RUN_TILE + RUN_TILE / 16 + 1;
 // half the LDS, twice the tiles in flight) and returns, for the 16 items of this thread, the bit masks "starts a record" and
 // "ends the record in front of it" (= starts one, or is not kept)
 constexpr uint32_t RUN_NONE = 0xFFFFFFFFu;
+// wide keys: the tile's representatives from its START slots.  sRep gets the id of every START slot first (RUN_NONE elsewhere), sKept
+// one bit per slot; every thread then walks its 16 consecutive slots with the id of the last START in front of them (a scan over the
+// threads' last ids: wave shuffles, then the four wave tails), and what the tile's first slots need from the tiles in front - the run
+// they belong to began there - is looked up in memory by wave 0: backwards from the tile, 64 slots at a time, to the nearest START
+// (a run's length away; only when a kept slot stands in front of the tile's first START).
+__device__ __forceinline__ void runRepsWide(const RunArgs &a, uint64_t base, bool skip, uint32_t *sRep) {
+    __shared__ unsigned long long sKept[RUN_TILE / 64];
+    __shared__ uint32_t sWaveLast[RUN_NT / 64], sCarry;
+    __shared__ int sNeed;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { sNeed = 0; sCarry = RUN_NONE; }
+#pragma unroll
+    for (int j = 0; j < RUN_ITEMS; j++) {
+        const int li = threadIdx.x + RUN_NT * j; const uint64_t i = base + (uint64_t) li;
+        const uint64_t k = (!skip && i < a.n && !(i >= a.skipLo && i < a.skipHi)) ? a.keys[i] : ~0ull;
+        const bool start = k != ~0ull && (k & GK_START) != 0ull;
+        sRep[runPad(li)] = start ? (uint32_t) ((k >> a.idShift) & a.idMask) : RUN_NONE;
+        const unsigned long long kb = __ballot(gkKept(k));
+        if (lane == 0) sKept[(RUN_NT * j + 64 * wave) >> 6] = kb;
+    }
+    __syncthreads();
+    // last START id among this thread's slots, then among the slots of the threads in front
+    uint32_t mine = RUN_NONE;
+#pragma unroll
+    for (int j = 0; j < RUN_ITEMS; j++) { const uint32_t r = sRep[runPad(threadIdx.x * RUN_ITEMS + j)]; if (r != RUN_NONE) mine = r; }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t) __shfl_up((int) incl, d, 64); if (lane >= d && incl == RUN_NONE) incl = o; }
+    if (lane == 63) sWaveLast[wave] = incl;
+    uint32_t carry = (uint32_t) __shfl_up((int) incl, 1, 64);
+    if (lane == 0) carry = RUN_NONE;
+    __syncthreads();
+    for (int w = wave - 1; w >= 0 && carry == RUN_NONE; w--) carry = sWaveLast[w];
+    // the walk: START slots keep their id, kept slots behind them take it, everything else is RUN_NONE
+    uint32_t cur = carry; bool need = false;
+    const unsigned int keptBits = (unsigned int) ((sKept[(threadIdx.x * RUN_ITEMS) >> 6] >> ((threadIdx.x * RUN_ITEMS) & 63)) & ((1u << RUN_ITEMS) - 1u));
+    uint32_t out[RUN_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RUN_ITEMS; j++) {
+        const uint32_t r = sRep[runPad(threadIdx.x * RUN_ITEMS + j)];
+        if (r != RUN_NONE) cur = r;
+        const bool kept = (keptBits >> j) & 1u;
+        out[j] = kept ? cur : RUN_NONE;
+        need |= kept && cur == RUN_NONE;
+    }
+    if (need) sNeed = 1;
+    __syncthreads();
+    if (sNeed) {      // (block-uniform) a kept slot in front of the tile's first START: its run starts in a tile in front
+        if (wave == 0) {
+            uint64_t hi = base;                                  // slots [hi - 64, hi) are looked at next
+            uint32_t found = RUN_NONE;
+            while (hi > 0) {
+                const uint64_t i = hi - 1 - (uint64_t) lane;
+                const uint64_t k = (hi > (uint64_t) lane) ? a.keys[i] : ~0ull;
+                const unsigned long long sm = __ballot(k != ~0ull && (k & GK_START) != 0ull);
+                if (sm) { const int l = __ffsll(sm) - 1; found = (uint32_t) ((bucket::readLane64(k, l) >> a.idShift) & a.idMask); break; }
+                hi = hi > 64 ? hi - 64 : 0;
+            }
+            if (lane == 0) sCarry = found;
+        }
+        __syncthreads();
+        const uint32_t c = sCarry;
+#pragma unroll
+        for (int j = 0; j < RUN_ITEMS; j++) if (((keptBits >> j) & 1u) && out[j] == RUN_NONE) out[j] = c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RUN_ITEMS; j++) sRep[runPad(threadIdx.x * RUN_ITEMS + j)] = out[j];
+}
 __device__ __forceinline__ void runFlags(const RunArgs &a, uint64_t base, uint32_t *sRep, unsigned int &startBits, unsigned int &boundBits) {
     const bool skip = base >= a.skipLo && base + RUN_TILE <= a.skipHi;      // block-uniform
+    if (a.wide) runRepsWide(a, base, skip, sRep);
+    else {
 #pragma unroll
     for (int j = 0; j < RUN_ITEMS; j++) {
         const int li = threadIdx.x + RUN_NT * j; const uint64_t i = base + (uint64_t) li;
         const uint64_t k = (!skip && i < a.n && !(i >= a.skipLo && i < a.skipHi)) ? a.keys[i] : ~0ull;
         sRep[runPad(li)] = k != ~0ull ? (uint32_t) (k >> a.repShift) : RUN_NONE;
+    }
     }
     __syncthreads();
     startBits = 0; boundBits = 0;
@@ -484,19 +565,31 @@ __global__ __launch_bounds__(U_NT, CDM_U_MINW) void k_unit_sort(UnitArgs a) {
 // srcKeys / recVal: the k-mer-ordered keys and the sorted records `in` is the expansion of.  `in` itself may be unwritten: the unit
 // sorter gathers from the records, and the ranges the other sorters need are expanded into `in` here (k_gather_ranges).
 // unitHook (aggvote.h): takes the units in k_unit_sort's place - it is handed each size class's list and the hard list it may add to
+// wide (keys without the representative, RunArgs): the units go to unitHook (there is no k_unit_sort for such keys), no block sorter;
+// what is left - long segments, units the hook hands back - is sorted as (key bits [1, shiftHi), range ordinal) pairs in two stable
+// radix sorts, and comes out with the START / DROPPED marks cleared.
+// (a wave per listed range: its keys masked to the member bits, its ordinal next to every key)
+__global__ __launch_bounds__(256) void k_big_ordinals(const unsigned long long *__restrict__ ranges /* start, end, off */, unsigned int cnt, uint64_t keyMask, uint64_t *__restrict__ dense, uint32_t *__restrict__ ord) {
+    const unsigned int lane = threadIdx.x & 63, wavesPerGrid = gridDim.x * 4;
+    for (unsigned int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < cnt; r += wavesPerGrid) {
+        const unsigned long long len = ranges[3 * (size_t) r + 1] - ranges[3 * (size_t) r], o = ranges[3 * (size_t) r + 2];
+        for (unsigned long long i = lane; i < len; i += 64) { dense[o + i] &= keyMask; ord[o + i] = r; }
+    }
+}
 typedef void (*UnitHook)(hipStream_t s, unsigned int grid, const unsigned long long *list, const unsigned int *count, bucket::BigList hard, void *user);
 inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t *out, uint64_t n, int shiftHi, int hiShift, int top,
                              const uint32_t *recRep, const unsigned long long *dst, uint64_t nRec, const uint64_t *srcKeys, const uint64_t *recVal,
-                             UnitHook unitHook = nullptr, void *hookUser = nullptr) {
+                             UnitHook unitHook = nullptr, void *hookUser = nullptr, bool wide = false) {
     using namespace bucket;
     if (n == 0) return CDM_OK;
-    uint32_t maxSeg = U_MAXSEG, blockCap = 4096;
+    if (wide && !unitHook) { cdm_set_error("segmented sort: keys without the representative need the aggregating unit kernel"); return CDM_ERR_UNSUPPORTED; }
+    uint32_t maxSeg = U_MAXSEG, blockCap = wide ? 0 : 4096;
     if (const char *e = cdmGetenv("CDM_UNIT_CAP")) { const long m = atol(e); if (m >= 1 && m <= U_MAXSEG) maxSeg = (uint32_t) m; }
     if (const char *e = cdmGetenv("CDM_BLOCK_CAP")) { const long m = atol(e); if (m >= 0 && m <= 4096) blockCap = (uint32_t) m; }
     uint32_t maxSub = BK_MAXB;
     if (const char *e = cdmGetenv("CDM_UNIT_SUB")) { const long m = atol(e); if (m >= 1 && m <= BK_MAXB) maxSub = (uint32_t) m; }
     if (shiftHi - 1 + BLK_IDX > 64) blockCap = 0;       // the block sorter's word does not hold such keys: rocPRIM takes them
-    if (U_ORDB + shiftHi - 1 + U_IDXB > 64) maxSeg = 0; // nor does the unit sorter's (ordinal, id, diagonal, index): everything goes to rocPRIM
+    if (!unitHook && U_ORDB + shiftHi - 1 + U_IDXB > 64) maxSeg = 0; // nor does the unit sorter's (ordinal, id, diagonal, index): everything goes to the radix sort
     const uint64_t units = (n + U_T - 1) / U_T;
     const size_t listCap = (size_t) (n / ((uint64_t) maxSeg + 1) + 2);
     DevBuf<unsigned long long> lists[SEG_CLASSES], hardList, uStart, uEnd, uRec, uList[U_CLASSES]; DevBuf<unsigned int> cnt;
@@ -559,8 +652,21 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
     const unsigned int g = bigCopyGrid(nBig);
     hipLaunchKernelGGL((k_big_copy<uint64_t, true>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(in), d0.p);
     bool inFirst = true;
+    if (wide) {
+        // no representative in the keys: (member bits, ordinal of the range) - stable on the member bits, then stable on the ordinal
+        DevBuf<uint32_t> o0, o1;
+        if (!o0.alloc(total) || !o1.alloc(total)) return CDM_ERR_HIP;
+        hipLaunchKernelGGL(k_big_ordinals, dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, (1ull << shiftHi) - 1ull, d0.p, o0.p);
+        if (int rc = rx::sortPairs<uint64_t, uint32_t>(s, cuCount, d0.p, d1.p, o0.p, o1.p, total, 1, shiftHi, inFirst)) return rc;
+        uint64_t *kA = inFirst ? d0.p : d1.p, *kB = inFirst ? d1.p : d0.p; uint32_t *oA = inFirst ? o0.p : o1.p, *oB = inFirst ? o1.p : o0.p;
+        int ordBits = 1; while ((1ull << ordBits) < (uint64_t) nBig) ordBits++;
+        bool second = true;
+        if (int rc = rx::sortPairs<uint32_t, uint64_t>(s, cuCount, oA, oB, kA, kB, total, 0, ordBits, second)) return rc;
+        hipLaunchKernelGGL((k_big_copy<uint64_t, false>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, out, second ? kA : kB);
+    } else {
     if (int rc = rx::sortKeys<uint64_t>(s, cuCount, d0.p, d1.p, total, 1, top, inFirst)) return rc;
     hipLaunchKernelGGL((k_big_copy<uint64_t, false>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, out, inFirst ? d0.p : d1.p);
+    }
     if (hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
     return CDM_OK;
 }

@@ -29,7 +29,10 @@ def main():
     from carpedeam_amd import capi, shard
     from test_gpu_shards import merged_hits, run_ranks
     stop = threading.Event()
-    if race:
+
+    def start_churn():
+        # (started after the first databases: the HIP runtime itself calls getenv while it initialises - the first run of this script,
+        # with the setenv thread up from the start, died inside libamdhip64's getenv under cdm_ctx_create)
         libc = ctypes.CDLL(None)
         libc.setenv.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
 
@@ -38,14 +41,19 @@ def main():
             while not stop.is_set():
                 libc.setenv(b"STRESS_VAR_%d" % i, b"x" * 64, 1)
                 i += 1
-                if i % 512 == 0:
-                    time.sleep(0.001)
+                if i % 64 == 0:
+                    time.sleep(0.0005)
         threading.Thread(target=churn, daemon=True).start()
     rng = np.random.default_rng(1234)
     letters = np.frombuffer(b"ACGT", np.uint8)
     ref = capi.Ctx(0)
+    import torch
+    torch.zeros(4, device="cuda").sum().item()
     t0, cases, calls = time.time(), 0, 0
     while time.time() - t0 < seconds:
+        if race and cases == 3:
+            start_churn()
+            print("stress_kpart: setenv thread started", flush=True)
         genome = rng.integers(0, 4, 400)
         seqs = []
         for _ in range(int(rng.integers(3, 80))):
