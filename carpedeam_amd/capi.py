@@ -63,7 +63,19 @@ EXPORTS = [
     "cdm_kmermatch_part", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_sort", "cdm_kpart_vote", "cdm_kpart_cont_cap", "cdm_kpart_free", "cdm_dev_copy",
     "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
     "cdm_rescore_hamming", "cdm_pool_headroom", "cdm_env_refresh",
+    "cdm_comm_unique_id", "cdm_comm_create_rccl", "cdm_comm_create_ops", "cdm_comm_free", "cdm_comm_rank", "cdm_comm_world", "cdm_kmermatch_dist",
+    "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist",
 ]
+
+
+AG_HOST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+A2A_DEV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p)
+AG_DEV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p)
+
+
+class CommOps(C.Structure):
+    """cdm_comm_ops (include/carpedeam_hip.h): the collectives of a caller-supplied transport"""
+    _fields_ = [("user", C.c_void_p), ("all_gather_host", AG_HOST_FN), ("all_to_all_dev", A2A_DEV_FN), ("all_gather_dev", AG_DEV_FN)]
 
 
 class CdmError(RuntimeError):
@@ -139,6 +151,15 @@ def lib():
         l.cdm_seqdb_copy_ext.argtypes = [vp, vp, vp]
         l.cdm_contig_merge.argtypes = [vp, vp, vp, C.POINTER(AncientParams), C.c_float, C.POINTER(vp)]
         l.cdm_cyclecheck.argtypes = [vp, vp, C.c_uint32, C.c_int, C.POINTER(vp), C.POINTER(vp), vp]
+        if hasattr(l, "cdm_comm_create_ops"):
+            l.cdm_comm_unique_id.argtypes = [vp]
+            l.cdm_comm_create_rccl.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+            l.cdm_comm_create_ops.argtypes = [vp, C.c_int, C.c_int, C.POINTER(CommOps), C.POINTER(vp)]
+            l.cdm_comm_free.argtypes = [vp]
+            l.cdm_comm_free.restype = None
+            l.cdm_kmermatch_dist.argtypes = [vp, vp, vp, C.POINTER(KmerParams), C.POINTER(vp)]
+            l.cdm_seqdb_allgather_owned.argtypes = [vp, vp, vp, C.POINTER(vp)]
+            l.cdm_reads_iteration_dist.argtypes = [vp, vp, vp, C.POINTER(KmerParams), C.POINTER(RescoreParams), C.POINTER(AncientParams), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         try:
             l.cdm_env_refresh.restype = None
         except AttributeError:          # (CDM_LIB names an older build of the library - bisecting: it reads its switches with getenv)
@@ -444,6 +465,89 @@ class Ctx:
         _check(lib().cdm_extend(self.h, db.h, alns.h, C.byref(par), C.byref(h), _ptr(scores)))
         out = SeqDb(self, h)
         return (out, scores) if want_scores else out
+
+
+class Comm:
+    """cdm_comm: a rank's communicator for the library's own multi-GPU calls (csrc/dist.hip)."""
+
+    def __init__(self, ctx, handle, rank, world, keep=None):
+        self.ctx, self.h, self.rank, self.world, self._keep = ctx, handle, rank, world, keep
+
+    def __del__(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().cdm_comm_free(self.h)
+            self.h = None
+
+    @staticmethod
+    def unique_id():
+        """rank 0: the 128 bytes every rank's Comm.rccl() needs (ncclGetUniqueId)"""
+        b = C.create_string_buffer(128)
+        _check(lib().cdm_comm_unique_id(b))
+        return b.raw
+
+    @classmethod
+    def rccl(cls, ctx, rank, world, unique_id):
+        """RCCL, called by the library itself (one device per rank)"""
+        h = C.c_void_p()
+        _check(lib().cdm_comm_create_rccl(ctx.h, rank, world, C.create_string_buffer(bytes(unique_id), 128), C.byref(h)))
+        return cls(ctx, h, rank, world)
+
+    @classmethod
+    def from_transport(cls, ctx, rank, world, t):
+        """A transport written in Python (tests: several ranks on ONE device): t.all_gather_host(bytes) -> list of the ranks' bytes;
+        t.all_to_all_dev(send_ptr, send_off, recv_ptr, recv_off) and t.all_gather_dev(send_ptr, send_bytes, recv_ptr, recv_off) move
+        device memory (byte offsets, world + 1 of them) and return when the data has arrived."""
+        def ag_host(user, send, recv, nbytes):
+            try:
+                parts = t.all_gather_host(C.string_at(send, nbytes))
+                for p, b in enumerate(parts):
+                    C.memmove(recv + p * nbytes, b, nbytes)
+                return 0
+            except BaseException as e:      # noqa: BLE001 - an exception must not cross the C frames
+                t.error = e
+                return -1
+
+        def a2a(user, send, soff, recv, roff, stream):
+            try:
+                ctx.sync()
+                t.all_to_all_dev(send or 0, [int(soff[i]) for i in range(world + 1)], recv or 0, [int(roff[i]) for i in range(world + 1)])
+                return 0
+            except BaseException as e:      # noqa: BLE001
+                t.error = e
+                return -1
+
+        def ag_dev(user, send, nbytes, recv, roff, stream):
+            try:
+                ctx.sync()
+                t.all_gather_dev(send or 0, int(nbytes), recv or 0, [int(roff[i]) for i in range(world + 1)])
+                return 0
+            except BaseException as e:      # noqa: BLE001
+                t.error = e
+                return -1
+
+        ops = CommOps(None, AG_HOST_FN(ag_host), A2A_DEV_FN(a2a), AG_DEV_FN(ag_dev))
+        h = C.c_void_p()
+        _check(lib().cdm_comm_create_ops(ctx.h, rank, world, C.byref(ops), C.byref(h)))
+        return cls(ctx, h, rank, world, keep=(ops, t))
+
+    def kmermatch(self, db, par=None):
+        """kmermatcher over the ranks: this rank's share of the hits (its representatives' rows; self hits elsewhere)"""
+        par = par or KmerParams.reads_default()
+        h = C.c_void_p()
+        _check(lib().cdm_kmermatch_dist(self.ctx.h, self.h, db.h, C.byref(par), C.byref(h)))
+        return Hits(self.ctx, h, db.n)
+
+    def allgather_owned(self, db_local):
+        h = C.c_void_p()
+        _check(lib().cdm_seqdb_allgather_owned(self.ctx.h, self.h, db_local.h, C.byref(h)))
+        return SeqDb(self.ctx, h)
+
+    def reads_iteration(self, db, kpar=None, rpar=None, apar=None):
+        """one iteration of the reads loop over the ranks -> (hits, alns, corrected DB, next DB); the DBs are complete on every rank"""
+        kpar, rpar, apar = kpar or KmerParams.reads_default(), rpar or RescoreParams.default(), apar or AncientParams.default()
+        hh, ah, ch, nh = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().cdm_reads_iteration_dist(self.ctx.h, self.h, db.h, C.byref(kpar), C.byref(rpar), C.byref(apar), C.byref(hh), C.byref(ah), C.byref(ch), C.byref(nh)))
+        return Hits(self.ctx, hh, db.n), Alns(self.ctx, ah, db.n), SeqDb(self.ctx, ch), SeqDb(self.ctx, nh)
 
 
 # ------------------------------------------------------------------------------------------------ text codecs (tests)

@@ -21,6 +21,8 @@ void cdmPoolTrim();   // give every cached block back to the driver
 const char *cdmGetenv(const char *name);
 template <typename T> inline hipError_t cdmMalloc(T **p, size_t bytes) { return cdmMallocRaw(reinterpret_cast<void **>(p), bytes); }
 
+// most left-over tuples the reference's last per-target scan may run over on the device (kmermatch.hip k_stale_tail; dist.hip)
+constexpr int CDM_STALE_MAX = 62;
 // RAII device buffer from the caching allocator (freed on every exit path of a stage function)
 // experiments: dynamic LDS (bytes, from the environment) added to a launch to lower its occupancy
 inline unsigned cdm_lds_pad(const char *name) { const char *e = cdmGetenv(name); return e ? (unsigned) atoi(e) : 0u; }

@@ -1,0 +1,314 @@
+// Multi-GPU inside the library: one rank per device (a process, or a host thread of one process), RCCL over xGMI called directly.
+//
+// The reference shards INSIDE its modules (kmermatcher's k-mer split lib/mmseqs/src/linclust/kmermatcher.cpp:634-663 + merge :742-784,
+// rescorediagonal's query split lib/mmseqs/src/alignment/rescorediagonal.cpp:399-421); so does this file, with the exact scheme of
+// DESIGN.md section 6 - bit-identical to the single-device run:
+//   cdm_kmermatch_dist         rank r runs kmermatcher's first half on the r-th k-mer range (cdm_kmermatch_part), ONE all-to-all moves
+//                              every group key to the owner of its representative, the second half (sort 2 + vote) runs there; three
+//                              small all-gathers carry what the reference's quirks need across ranks (the left-over list of the
+//                              run-past-the-end scan :875-887, the heads of the sorted arrays, the tuple counts)
+//   cdm_seqdb_allgather_owned  the stages behind it work on the owned queries; the owned ranges of their result DBs are all-gathered
+//   cdm_reads_iteration_dist   one iteration of the reads loop (data/nuclassemble.sh:100-146) that way
+// Transports: RCCL (librccl, loaded on first use - it is half a gigabyte, and a one-device module must not pay for it), or a table
+// of functions the caller supplies (cdm_comm_create_ops: the tests run W ranks on ONE device through it, where RCCL wants a device per
+// rank; another collective library could be bound the same way).  carpedeam_amd/shard.py holds the same calling sequence in Python;
+// it stays as the reference the tests compare this file with.
+#include <dlfcn.h>
+#include <mutex>
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "devutil.h"
+
+// ------------------------------------------------------------------------------------------------ RCCL, bound at run time
+namespace {
+struct Rccl {
+    typedef int (*GetUniqueId)(void *);
+    typedef int (*CommInitRank)(void **, int, /* ncclUniqueId by value: 128 bytes */ struct Id128, int);
+    void *lib = nullptr;
+    int (*getUniqueId)(void *) = nullptr;
+    void *commInitRank = nullptr;
+    int (*commDestroy)(void *) = nullptr;
+    int (*allGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*groupStart)() = nullptr;
+    int (*groupEnd)() = nullptr;
+    const char *(*errorString)(int) = nullptr;
+};
+struct Id128 { char b[128]; };      // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128), passed by value as the API does
+constexpr int NCCL_CHAR = 0;        // ncclInt8 / ncclChar
+Rccl *rccl(std::string *err) {
+    static Rccl *r = nullptr; static std::string why; static std::once_flag once;
+    std::call_once(once, [] {
+        Rccl *t = new Rccl();
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { t->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (t->lib) break; }
+        if (!t->lib) { why = std::string("librccl.so not found: ") + dlerror(); return; }
+        auto sym = [&](const char *n) { void *p = dlsym(t->lib, n); if (!p && why.empty()) why = std::string("librccl has no ") + n; return p; };
+        t->getUniqueId = (int (*)(void *)) sym("ncclGetUniqueId"); t->commInitRank = sym("ncclCommInitRank"); t->commDestroy = (int (*)(void *)) sym("ncclCommDestroy");
+        t->allGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t)) sym("ncclAllGather");
+        t->send = (int (*)(const void *, size_t, int, int, void *, hipStream_t)) sym("ncclSend");
+        t->recv = (int (*)(void *, size_t, int, int, void *, hipStream_t)) sym("ncclRecv");
+        t->groupStart = (int (*)()) sym("ncclGroupStart"); t->groupEnd = (int (*)()) sym("ncclGroupEnd");
+        t->errorString = (const char *(*)(int)) sym("ncclGetErrorString");
+        if (why.empty()) r = t;
+    });
+    if (!r && err) *err = why;
+    return r;
+}
+}  // namespace
+
+struct cdm_comm {
+    cdm_ctx *ctx = nullptr; int rank = 0, world = 1;
+    cdm_comm_ops ops;                   // the transport (RCCL's functions below, or the caller's)
+    void *nccl = nullptr;               // ncclComm_t of the RCCL transport
+    void *stage = nullptr; size_t stageBytes = 0;       // device staging of the host all-gather (RCCL transport)
+};
+#define CDM_NCCL(call, what) do { const int e_ = (call); if (e_ != 0) { cdm_set_error("RCCL %s failed: %s", what, rccl(nullptr)->errorString ? rccl(nullptr)->errorString(e_) : "?"); return CDM_ERR_HIP; } } while (0)
+
+// ---- RCCL transport
+namespace {
+int rcclAllGatherHost(void *user, const void *send, void *recv, uint64_t bytes) {
+    cdm_comm *c = (cdm_comm *) user; Rccl *r = rccl(nullptr);
+    const size_t need = (size_t) bytes * (size_t) (c->world + 1);
+    if (need > c->stageBytes) { if (c->stage) cdmFree(c->stage); c->stage = nullptr; c->stageBytes = 0; if (cdmMalloc((char **) &c->stage, need + 256) != hipSuccess) { cdm_set_error("all-gather: out of device memory"); return CDM_ERR_HIP; } c->stageBytes = need; }
+    char *dSend = (char *) c->stage, *dRecv = dSend + bytes;
+    hipStream_t s = c->ctx->stream;
+    CDM_HIP(hipMemcpyAsync(dSend, send, bytes, hipMemcpyHostToDevice, s));
+    CDM_NCCL(r->allGather(dSend, dRecv, bytes, NCCL_CHAR, c->nccl, s), "all-gather");
+    CDM_HIP(hipMemcpyAsync(recv, dRecv, bytes * (size_t) c->world, hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipStreamSynchronize(s));
+    return CDM_OK;
+}
+// peer p gets send[sendOff[p], sendOff[p + 1]) and fills recv[recvOff[p], recvOff[p + 1]): grouped point-to-point transfers - over xGMI
+// every pair of devices has its own link, so the W - 1 transfers of a rank run side by side
+int rcclAllToAllDev(void *user, const void *send, const uint64_t *sendOff, void *recv, const uint64_t *recvOff, void *stream) {
+    cdm_comm *c = (cdm_comm *) user; Rccl *r = rccl(nullptr);
+    hipStream_t s = (hipStream_t) stream;
+    CDM_NCCL(r->groupStart(), "group start");
+    for (int p = 0; p < c->world; p++) {
+        const uint64_t ns = sendOff[p + 1] - sendOff[p], nr = recvOff[p + 1] - recvOff[p];
+        if (ns) CDM_NCCL(r->send((const char *) send + sendOff[p], ns, NCCL_CHAR, p, c->nccl, s), "send");
+        if (nr) CDM_NCCL(r->recv((char *) recv + recvOff[p], nr, NCCL_CHAR, p, c->nccl, s), "recv");
+    }
+    CDM_NCCL(r->groupEnd(), "group end");
+    return CDM_OK;
+}
+// every rank contributes sendBytes (they differ): recv[recvOff[p], recvOff[p + 1]) = rank p's
+int rcclAllGatherDev(void *user, const void *send, uint64_t sendBytes, void *recv, const uint64_t *recvOff, void *stream) {
+    cdm_comm *c = (cdm_comm *) user; Rccl *r = rccl(nullptr);
+    hipStream_t s = (hipStream_t) stream;
+    CDM_NCCL(r->groupStart(), "group start");
+    for (int p = 0; p < c->world; p++) {
+        const uint64_t nr = recvOff[p + 1] - recvOff[p];
+        if (sendBytes) CDM_NCCL(r->send(send, sendBytes, NCCL_CHAR, p, c->nccl, s), "send");
+        if (nr) CDM_NCCL(r->recv((char *) recv + recvOff[p], nr, NCCL_CHAR, p, c->nccl, s), "recv");
+    }
+    CDM_NCCL(r->groupEnd(), "group end");
+    return CDM_OK;
+}
+}  // namespace
+
+extern "C" int cdm_comm_unique_id(void *id128) {
+    std::string err; Rccl *r = rccl(&err);
+    if (!r) { cdm_set_error("%s", err.c_str()); return CDM_ERR_UNSUPPORTED; }
+    CDM_NCCL(r->getUniqueId(id128), "unique id");
+    return CDM_OK;
+}
+extern "C" int cdm_comm_create_rccl(cdm_ctx *ctx, int rank, int world, const void *id128, cdm_comm **out) {
+    if (!ctx || !out || !id128 || world < 1 || rank < 0 || rank >= world) { cdm_set_error("cdm_comm_create_rccl: invalid argument"); return CDM_ERR_INVALID; }
+    std::string err; Rccl *r = rccl(&err);
+    if (!r) { cdm_set_error("%s", err.c_str()); return CDM_ERR_UNSUPPORTED; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    cdm_comm *c = new cdm_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    Id128 id; memcpy(id.b, id128, sizeof(id.b));
+    const int e = ((int (*)(void **, int, Id128, int)) r->commInitRank)(&c->nccl, world, id, rank);
+    if (e != 0) { delete c; cdm_set_error("ncclCommInitRank(rank %d of %d on device %d) failed: %s", rank, world, ctx->device, r->errorString ? r->errorString(e) : "?"); return CDM_ERR_HIP; }
+    c->ops.user = c; c->ops.all_gather_host = rcclAllGatherHost; c->ops.all_to_all_dev = rcclAllToAllDev; c->ops.all_gather_dev = rcclAllGatherDev;
+    *out = c;
+    return CDM_OK;
+}
+extern "C" int cdm_comm_create_ops(cdm_ctx *ctx, int rank, int world, const cdm_comm_ops *ops, cdm_comm **out) {
+    if (!ctx || !out || !ops || !ops->all_gather_host || !ops->all_to_all_dev || !ops->all_gather_dev || world < 1 || rank < 0 || rank >= world) { cdm_set_error("cdm_comm_create_ops: invalid argument"); return CDM_ERR_INVALID; }
+    cdm_comm *c = new cdm_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world; c->ops = *ops;
+    *out = c;
+    return CDM_OK;
+}
+extern "C" void cdm_comm_free(cdm_comm *c) {
+    if (!c) return;
+    if (c->stage) cdmFree(c->stage);
+    if (c->nccl) { Rccl *r = rccl(nullptr); if (r) (void) r->commDestroy(c->nccl); }
+    delete c;
+}
+extern "C" int cdm_comm_rank(const cdm_comm *c) { return c->rank; }
+extern "C" int cdm_comm_world(const cdm_comm *c) { return c->world; }
+
+// ------------------------------------------------------------------------------------------------ kmermatcher over W ranks
+namespace {
+constexpr int STALE_LEN = CDM_STALE_MAX + 5;       // [0] count, [1] sequence id, [2..63] positions, [66] = the scan reached the end of the range
+struct PartGuard { cdm_kpart *p = nullptr; ~PartGuard() { if (p) cdm_kpart_free(p); } };
+}  // namespace
+extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+    if (!ctx || !cm || !db || !par || !out) { cdm_set_error("cdm_kmermatch_dist: invalid argument"); return CDM_ERR_INVALID; }
+    const int W = cm->world, R = cm->rank;
+    const cdm_comm_ops &op = cm->ops;
+    PartGuard g;
+    if (int rc = cdm_kmermatch_part(ctx, db, par, R, W, &g.p)) return rc;
+    uint64_t info[4];
+    cdm_kpart_info(g.p, info);
+    // ---- the left-over list of the reference's last per-target scan: it starts at k-mer-order index J = number of ALL kept group keys
+    // (assignGroup's compaction, :875-887) - which range holds that index, and what the ranges behind it begin with
+    std::vector<uint64_t> infos(2 * (size_t) W);
+    { const uint64_t mine[2] = {info[0], info[1]}; if (int rc = op.all_gather_host(op.user, mine, infos.data(), 16)) return rc; }
+    uint64_t J = 0; for (int p = 0; p < W; p++) J += infos[2 * p + 1];
+    int holder = -1; uint64_t jLocal = 0;
+    { uint64_t base = 0; for (int p = 0; p < W; p++) { if (J < base + infos[2 * p]) { holder = p; jLocal = J - base; break; } base += infos[2 * p]; } }
+    uint32_t mineStale[STALE_LEN]; memset(mineStale, 0, sizeof(mineStale));
+    if (holder >= 0 && R >= holder) if (int rc = cdm_kpart_stale(ctx, g.p, R == holder ? jLocal : 0, mineStale)) return rc;
+    std::vector<uint32_t> lists((size_t) W * STALE_LEN);
+    if (int rc = op.all_gather_host(op.user, mineStale, lists.data(), sizeof(mineStale))) return rc;
+    uint32_t stale[STALE_LEN]; memset(stale, 0, sizeof(stale));
+    if (holder >= 0) {      // the scan collects tuples while they belong to one sequence; it goes on into the next range when it consumed the current one
+        uint32_t cnt = 0; bool have = false; uint32_t target = 0;
+        for (int p = holder; p < W; p++) {
+            const uint32_t *l = lists.data() + (size_t) p * STALE_LEN;
+            const uint32_t c = l[0];
+            if (c) {
+                if (!have) { target = l[1]; have = true; } else if (l[1] != target) break;
+                for (uint32_t j = 0; j < c && cnt < (uint32_t) CDM_STALE_MAX; j++) stale[2 + cnt++] = l[2 + j];
+            }
+            if (!l[CDM_STALE_MAX + 4]) break;
+        }
+        if (cnt >= (uint32_t) CDM_STALE_MAX) { cdm_set_error("cdm_kmermatch_dist: the reference's last per-target scan would run over %d or more left-over tuples; not reproduced", CDM_STALE_MAX); return CDM_ERR_UNSUPPORTED; }
+        stale[0] = cnt; stale[1] = have ? target : 0;
+    }
+    // ---- the all-to-all of the group keys: slice p of the keys grouped by representative goes to the owner of those representatives
+    std::vector<uint64_t> off((size_t) W + 1);
+    const void *keys = nullptr;
+    if (int rc = cdm_kpart_gather(ctx, g.p, W, off.data(), &keys)) return rc;
+    std::vector<uint64_t> counts((size_t) W), matrix((size_t) W * W);
+    for (int p = 0; p < W; p++) counts[p] = off[p + 1] - off[p];
+    if (int rc = op.all_gather_host(op.user, counts.data(), matrix.data(), (uint64_t) W * 8)) return rc;
+    std::vector<uint64_t> sendOff((size_t) W + 1), recvOff((size_t) W + 1, 0);
+    for (int p = 0; p <= W; p++) sendOff[p] = off[p] * 8;
+    for (int p = 0; p < W; p++) recvOff[p + 1] = recvOff[p] + matrix[(size_t) p * W + R] * 8;      // rank p's slice for me, in rank = k-mer order
+    const uint64_t nRecv = recvOff[W] / 8;
+    DevBuf<uint64_t> recv;
+    if (!recv.alloc(nRecv)) { cdm_set_error("cdm_kmermatch_dist: out of device memory for %llu received group keys", (unsigned long long) nRecv); return CDM_ERR_HIP; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    if (int rc = op.all_to_all_dev(op.user, keys, sendOff.data(), recv.p, recvOff.data(), ctx->stream)) return rc;
+    CDM_HIP(hipStreamSynchronize(ctx->stream));
+    // ---- second half on what arrived; the heads of the sorted arrays go round once more (a rank's last scan runs into the next ranks' first tuples)
+    const int capHead = cdm_kpart_cont_cap() + 3;
+    std::vector<uint32_t> head((size_t) capHead + 4, 0);       // [0..1] tuples (64 bit), [2] last target, [3] unused, [4..] the head
+    uint64_t info2[2] = {0, 0};
+    if (int rc = cdm_kpart_sort(ctx, g.p, nRecv ? recv.p : nullptr, nRecv, head.data() + 4, info2)) return rc;
+    recv.free();
+    memcpy(head.data(), &info2[0], 8); head[2] = (uint32_t) info2[1];
+    std::vector<uint32_t> heads((size_t) W * head.size());
+    if (int rc = op.all_gather_host(op.user, head.data(), heads.data(), head.size() * 4)) return rc;
+    std::vector<uint32_t> cont;
+    if (info2[0] != 0) {
+        const uint32_t t = (uint32_t) info2[1];
+        uint32_t thenStale = 1;
+        cont.assign(3, 0);
+        for (int p = R + 1; p < W; p++) {
+            const uint32_t *h = heads.data() + (size_t) p * head.size();
+            uint64_t cnt; memcpy(&cnt, h, 8);
+            if (cnt == 0) continue;
+            const uint32_t *hd = h + 4;                        // hd[0] entries, hd[1] their target id, hd[2] = 1 if the head is the whole array
+            if (hd[1] != t) { thenStale = 0; break; }
+            if (hd[0] > (uint32_t) cdm_kpart_cont_cap()) { cdm_set_error("cdm_kmermatch_dist: the scan of a rank's last target runs over more than %d tuples of the next rank; not reproduced", cdm_kpart_cont_cap()); return CDM_ERR_UNSUPPORTED; }
+            cont.insert(cont.end(), hd + 3, hd + 3 + hd[0]);
+            if (!hd[2]) { thenStale = 0; break; }
+        }
+        cont[0] = (uint32_t) (cont.size() - 3); cont[1] = t; cont[2] = thenStale;
+    }
+    return cdm_kpart_vote(ctx, g.p, cont.empty() ? nullptr : cont.data(), stale, out);
+}
+
+// ------------------------------------------------------------------------------------------------ DBs: the owned ranges, all-gathered
+namespace {
+__global__ void k_row_flags(const uint8_t *__restrict__ hasN, uint64_t lo, uint64_t m, uint8_t *__restrict__ flags) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) flags[i] = (hasN[lo + i] & 2u) ? 1 : 0;
+}
+}  // namespace
+extern "C" int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *local, cdm_seqdb **out) {
+    if (!ctx || !cm || !local || !out) { cdm_set_error("cdm_seqdb_allgather_owned: invalid argument"); return CDM_ERR_INVALID; }
+    const int W = cm->world, R = cm->rank;
+    const cdm_comm_ops &op = cm->ops;
+    CDM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t n = local->n, lo = (uint64_t) R * n / (uint64_t) W, hi = (uint64_t) (R + 1) * n / (uint64_t) W, m = hi - lo;
+    uint32_t wb[2] = {0, 0};
+    if (n) { CDM_HIP(hipMemcpyAsync(&wb[0], local->woff + lo, 4, hipMemcpyDeviceToHost, s)); CDM_HIP(hipMemcpyAsync(&wb[1], local->woff + hi, 4, hipMemcpyDeviceToHost, s)); CDM_HIP(hipStreamSynchronize(s)); }
+    const uint64_t w0 = wb[0], w = wb[1] - wb[0];
+    std::vector<uint64_t> metas(3 * (size_t) W);
+    { const uint64_t mine[3] = {m, w, local->raw ? 1ull : 0ull}; if (int rc = op.all_gather_host(op.user, mine, metas.data(), 24)) return rc; }
+    uint64_t nAll = 0, wAll = 0; bool anyRaw = false;
+    std::vector<uint64_t> seqOff((size_t) W + 1, 0), wordOff((size_t) W + 1, 0);
+    for (int p = 0; p < W; p++) { seqOff[p + 1] = seqOff[p] + metas[3 * p]; wordOff[p + 1] = wordOff[p] + metas[3 * p + 1]; anyRaw |= metas[3 * p + 2] != 0; }
+    nAll = seqOff[W]; wAll = wordOff[W];
+    if (nAll != n) { cdm_set_error("cdm_seqdb_allgather_owned: the ranks' DBs differ in size (%llu sequences here, %llu owned in all)", (unsigned long long) n, (unsigned long long) nAll); return CDM_ERR_INVALID; }
+    DevBuf<uint32_t> codes, lens, keys; DevBuf<uint16_t> mask; DevBuf<uint8_t> ext, raw, flags, myFlags, zeros;
+    if (!codes.alloc(wAll) || !mask.alloc(wAll) || !lens.alloc(nAll) || !keys.alloc(nAll) || !ext.alloc(nAll) || (anyRaw && (!raw.alloc(16 * wAll) || !flags.alloc(nAll) || !myFlags.alloc(m)))) {
+        cdm_set_error("cdm_seqdb_allgather_owned: out of device memory"); return CDM_ERR_HIP;
+    }
+    auto gather = [&](const void *send, uint64_t unit, const std::vector<uint64_t> &offs, uint64_t count, void *recvBuf) -> int {
+        std::vector<uint64_t> ro((size_t) W + 1);
+        for (int p = 0; p <= W; p++) ro[p] = offs[p] * unit;
+        return op.all_gather_dev(op.user, send, count * unit, recvBuf, ro.data(), s);
+    };
+    if (int rc = gather(local->codes + w0, 4, wordOff, w, codes.p)) return rc;
+    if (int rc = gather(reinterpret_cast<const uint16_t *>(local->nmask) + w0, 2, wordOff, w, mask.p)) return rc;
+    if (int rc = gather(local->len + lo, 4, seqOff, m, lens.p)) return rc;
+    if (int rc = gather(local->key + lo, 4, seqOff, m, keys.p)) return rc;
+    if (int rc = gather(local->ext + lo, 1, seqOff, m, ext.p)) return rc;
+    if (anyRaw) {       // letters beyond ACGTN: the original bytes (16 per code word) and which rows count; a rank without such letters sends zeros
+        const uint8_t *rawSend = nullptr;
+        if (local->raw) { rawSend = local->raw + 16 * w0; if (m) hipLaunchKernelGGL(k_row_flags, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, local->hasN, lo, m, myFlags.p); }
+        else {
+            if (!zeros.alloc(16 * w + 16)) { cdm_set_error("cdm_seqdb_allgather_owned: out of device memory"); return CDM_ERR_HIP; }
+            CDM_HIP(hipMemsetAsync(zeros.p, 0, 16 * w + 16, s)); CDM_HIP(hipMemsetAsync(myFlags.p, 0, m + 1, s));
+            rawSend = zeros.p;
+        }
+        if (int rc = gather(rawSend, 16, wordOff, w, raw.p)) return rc;
+        if (int rc = gather(myFlags.p, 1, seqOff, m, flags.p)) return rc;
+    }
+    CDM_HIP(hipStreamSynchronize(s));
+    cdm_seqdb *o = nullptr;
+    if (int rc = cdm_seqdb_from_packed_ext(ctx, codes.p, mask.p, lens.p, keys.p, ext.p, nAll, wAll, &o)) return rc;
+    if (anyRaw && wAll) if (int rc = cdm_seqdb_attach_raw(ctx, o, raw.p, flags.p)) { cdm_seqdb_free(o); return rc; }
+    *out = o;
+    return CDM_OK;
+}
+
+// One iteration of the reads loop over the ranks: the hits of the owned representatives, their alignments, and the two DBs - complete
+// on every rank and identical to the single-device ones.  rpar / apar may be NULL (defaults).  Any of the outputs may be NULL.
+extern "C" int cdm_reads_iteration_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *kpar, const cdm_rescore_params *rpar,
+                                        const cdm_ancient_params *apar, cdm_hits **hitsOut, cdm_alns **alnsOut, cdm_seqdb **corrOut, cdm_seqdb **nextOut) {
+    cdm_hits *hits = nullptr; cdm_alns *alns = nullptr; cdm_seqdb *cLocal = nullptr, *corr = nullptr, *nLocal = nullptr, *next = nullptr;
+    int rc = cdm_kmermatch_dist(ctx, cm, db, kpar, &hits);
+    if (rc == CDM_OK) rc = cdm_rescore(ctx, db, hits, rpar, &alns);
+    if (rc == CDM_OK) rc = cdm_correct(ctx, db, alns, apar, &cLocal);
+    if (rc == CDM_OK) rc = cdm_seqdb_allgather_owned(ctx, cm, cLocal, &corr);
+    if (cLocal) cdm_seqdb_free(cLocal);
+    if (rc == CDM_OK) rc = cdm_extend(ctx, corr, alns, apar, &nLocal, nullptr);
+    if (rc == CDM_OK) rc = cdm_seqdb_allgather_owned(ctx, cm, nLocal, &next);
+    if (nLocal) cdm_seqdb_free(nLocal);
+    if (rc == CDM_OK && hitsOut) { *hitsOut = hits; hits = nullptr; }
+    if (rc == CDM_OK && alnsOut) { *alnsOut = alns; alns = nullptr; }
+    if (rc == CDM_OK && corrOut) { *corrOut = corr; corr = nullptr; }
+    if (rc == CDM_OK && nextOut) { *nextOut = next; next = nullptr; }
+    if (hits) cdm_hits_free(hits);
+    if (alns) cdm_alns_free(alns);
+    if (corr) cdm_seqdb_free(corr);
+    if (next) cdm_seqdb_free(next);
+    return rc;
+}

@@ -308,10 +308,12 @@ __global__ __launch_bounds__(256) void k_gather_ranges(const unsigned long long 
 }
 
 // ---------------------------------------------------------------------------------------------- segments by size class
+constexpr int U_T = 1024;             // slots per unit range of the segmented sort (k_unit_sort below)
 constexpr int SEG_CLASSES = 4;          // 0..2: k_block_sort with 2, 4, 8 waves; 3: longer (rocPRIM)
 struct SegListArgs {
     const uint32_t *recRep; const unsigned long long *dst; uint64_t nRec;
     uint32_t maxWave;                   // segments up to this length are finished by k_bucket_sort
+    const unsigned long long *uEnd; uint64_t units;       // the units' ends (NULL: there are no units): a segment that lies inside its unit is the unit's
     uint32_t cap[SEG_CLASSES - 1];      // capacities of the block classes
     unsigned long long *list[SEG_CLASSES]; unsigned int *cnt;      // cnt[c]
 };
@@ -328,7 +330,10 @@ __global__ __launch_bounds__(1024) void k_seg_list(SegListArgs a) {
             while (hi - lo > 1) { const uint64_t mid = lo + ((hi - lo) >> 1); if (a.recRep[mid] == rep) lo = mid; else hi = mid; }
             s = a.dst[j]; e = a.dst[hi];
             const unsigned long long n = e - s;
-            if (n > a.maxWave) cls = n <= a.cap[0] ? 0 : n <= a.cap[1] ? 1 : n <= a.cap[2] ? 2 : 3;
+            // (with the capacities lowered below a unit's range - tests - a segment beyond maxWave can lie in the middle of a unit: it is
+            // sorted / aggregated with its unit, and listing it as well would hand the fallback two overlapping ranges)
+            const bool inUnit = a.uEnd && s / U_T < a.units && e <= a.uEnd[s / U_T];
+            if (n > a.maxWave && !inUnit) cls = n <= a.cap[0] ? 0 : n <= a.cap[1] ? 1 : n <= a.cap[2] ? 2 : 3;
         }
     }
 #pragma unroll
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(1024) void k_seg_list(SegListArgs a) {
 #define CDM_U_NT0 256
 #define CDM_U_NT1 256
 #endif
-constexpr int U_T = 1024, U_MAXSEG = 2048, U_CAP = U_T + U_MAXSEG, U_NB = 256, U_IDXB = 12, U_ORDB = 11;
+constexpr int U_MAXSEG = 2048, U_CAP = U_T + U_MAXSEG, U_NB = 256, U_IDXB = 12, U_ORDB = 11;
 constexpr int U_CLASSES = 3;
 constexpr int U_CLASS_CAP[U_CLASSES] = {1536, 2048, U_CAP};
 constexpr int U_CLASS_NT[U_CLASSES] = {CDM_U_NT0, CDM_U_NT1, CDM_U_NT};
@@ -568,21 +573,49 @@ __global__ __launch_bounds__(U_NT, CDM_U_MINW) void k_unit_sort(UnitArgs a) {
 // wide (keys without the representative, RunArgs): the units go to unitHook (there is no k_unit_sort for such keys), no block sorter;
 // what is left - long segments, units the hook hands back - is sorted as (key bits [1, shiftHi), range ordinal) pairs in two stable
 // radix sorts, and comes out with the START / DROPPED marks cleared.
-// (a wave per listed range: its keys masked to the member bits, its ordinal next to every key)
-__global__ __launch_bounds__(256) void k_big_ordinals(const unsigned long long *__restrict__ ranges /* start, end, off */, unsigned int cnt, uint64_t keyMask, uint64_t *__restrict__ dense, uint32_t *__restrict__ ord) {
-    const unsigned int lane = threadIdx.x & 63, wavesPerGrid = gridDim.x * 4;
-    for (unsigned int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < cnt; r += wavesPerGrid) {
-        const unsigned long long len = ranges[3 * (size_t) r + 1] - ranges[3 * (size_t) r], o = ranges[3 * (size_t) r + 2];
-        for (unsigned long long i = lane; i < len; i += 64) { dense[o + i] &= keyMask; ord[o + i] = r; }
+// (one block per listed range (start, end, offset in the dense arrays): the range's records expanded straight into the dense arrays -
+// every tuple masked to its member bits, with the ordinal of its SEGMENT (a unit holds several representatives) next to it)
+__global__ __launch_bounds__(256) void k_gather_ranges_dense(const unsigned long long *__restrict__ ranges, unsigned int cnt, const uint64_t *__restrict__ keys,
+                                                             const uint64_t *__restrict__ recVal, const unsigned long long *__restrict__ dst, uint64_t nRec,
+                                                             const uint32_t *__restrict__ segOfRec, uint64_t keyMask, uint64_t *__restrict__ dense, uint32_t *__restrict__ ord) {
+    __shared__ uint32_t sOffAll[4][64];
+    __shared__ uint64_t sStartAll[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *sOff = sOffAll[wave]; uint64_t *sStart = sStartAll[wave];
+    for (unsigned int item = blockIdx.x; item < cnt; item += gridDim.x) {
+        const unsigned long long s = ranges[3 * (size_t) item], e = ranges[3 * (size_t) item + 1], o = ranges[3 * (size_t) item + 2];
+        uint64_t lo = 0, hi = nRec;                              // first record with dst >= s (it starts at s)
+        while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (dst[mid] < s) lo = mid + 1; else hi = mid; }
+        for (uint64_t j0 = lo + 64ull * wave; j0 < nRec; j0 += 256) {
+            const unsigned long long d0 = dst[j0];
+            if (d0 >= e) break;
+            const uint64_t j = j0 + lane;
+            const bool valid = j < nRec && dst[j] < e;
+            const uint64_t rv = valid ? recVal[j] : 0ull;
+            const unsigned int len = (unsigned int) (rv & ((1ull << RUN_CNT_BITS) - 1ull));
+            const unsigned int incl = cdm_wave_incl_sum<unsigned int>(len);
+            sOff[lane] = incl - len; sStart[lane] = rv >> RUN_CNT_BITS;
+            const unsigned int total = (unsigned int) __shfl((int) incl, 63, 64);
+            bucket::waveLdsSync();
+            for (unsigned int x = lane; x < total; x += 64) {
+                int r = 0;
+#pragma unroll
+                for (int st = 32; st > 0; st >>= 1) if (sOff[r + st] <= x) r += st;
+                const unsigned long long at = o + (d0 - s) + x;
+                dense[at] = keys[sStart[r] + (x - sOff[r])] & keyMask;
+                ord[at] = segOfRec[j0 + (uint64_t) r];
+            }
+            bucket::waveLdsSync();
+        }
     }
 }
 typedef void (*UnitHook)(hipStream_t s, unsigned int grid, const unsigned long long *list, const unsigned int *count, bucket::BigList hard, void *user);
 inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t *out, uint64_t n, int shiftHi, int hiShift, int top,
                              const uint32_t *recRep, const unsigned long long *dst, uint64_t nRec, const uint64_t *srcKeys, const uint64_t *recVal,
-                             UnitHook unitHook = nullptr, void *hookUser = nullptr, bool wide = false) {
+                             UnitHook unitHook = nullptr, void *hookUser = nullptr, bool wide = false, const uint32_t *segOfRec = nullptr, int segBits = 0) {
     using namespace bucket;
     if (n == 0) return CDM_OK;
-    if (wide && !unitHook) { cdm_set_error("segmented sort: keys without the representative need the aggregating unit kernel"); return CDM_ERR_UNSUPPORTED; }
+    if (wide && (!unitHook || !segOfRec)) { cdm_set_error("segmented sort: keys without the representative need the aggregating unit kernel and its segment table"); return CDM_ERR_UNSUPPORTED; }
     uint32_t maxSeg = U_MAXSEG, blockCap = wide ? 0 : 4096;
     if (const char *e = cdmGetenv("CDM_UNIT_CAP")) { const long m = atol(e); if (m >= 1 && m <= U_MAXSEG) maxSeg = (uint32_t) m; }
     if (const char *e = cdmGetenv("CDM_BLOCK_CAP")) { const long m = atol(e); if (m >= 0 && m <= 4096) blockCap = (uint32_t) m; }
@@ -619,7 +652,7 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
         }
     }
     // the segments no unit can hold, listed by size class: one block of 8 waves (bitonic network, bucket.h) up to 4096, rocPRIM beyond
-    SegListArgs la; la.recRep = recRep; la.dst = dst; la.nRec = nRec; la.maxWave = maxSeg;
+    SegListArgs la; la.recRep = recRep; la.dst = dst; la.nRec = nRec; la.maxWave = maxSeg; la.uEnd = maxSeg ? uEnd.p : nullptr; la.units = units;
     la.cap[0] = 0; la.cap[1] = 0; la.cap[2] = blockCap;
     for (int c = 0; c < SEG_CLASSES; c++) la.list[c] = lists[c].p;      // (classes 0 and 1 stay empty: their capacities are 0)
     la.cnt = cnt.p;
@@ -638,7 +671,7 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
     // deep pile-ups and hard units: gather, sort on the whole key with rocPRIM (stable), scatter.  (The ranges are disjoint and
     // the array is grouped by representative, so one sort of their concatenation on the whole key sorts each of them.)
     if (hc[SEG_CLASSES]) hipMemcpyAsync(lists[3].p + 2 * (size_t) hc[3], hardList.p, 2 * (size_t) hc[SEG_CLASSES] * 8, hipMemcpyDeviceToDevice, s);
-    {   // their tuples, expanded into `in`
+    if (!wide) {   // their tuples, expanded into `in`
         DevBuf<unsigned int> nb;
         if (!nb.alloc(1)) return CDM_ERR_HIP;
         hipMemcpyAsync(nb.p, &nBig, 4, hipMemcpyHostToDevice, s);
@@ -650,20 +683,20 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
     DevBuf<uint64_t> d0, d1;
     if (!d0.alloc(total) || !d1.alloc(total)) return CDM_ERR_HIP;
     const unsigned int g = bigCopyGrid(nBig);
-    hipLaunchKernelGGL((k_big_copy<uint64_t, true>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(in), d0.p);
     bool inFirst = true;
     if (wide) {
-        // no representative in the keys: (member bits, ordinal of the range) - stable on the member bits, then stable on the ordinal
+        // no representative in the keys: (member bits, segment ordinal) pairs, gathered straight from the records - stable on the
+        // member bits, then stable on the segment
         DevBuf<uint32_t> o0, o1;
         if (!o0.alloc(total) || !o1.alloc(total)) return CDM_ERR_HIP;
-        hipLaunchKernelGGL(k_big_ordinals, dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, (1ull << shiftHi) - 1ull, d0.p, o0.p);
+        hipLaunchKernelGGL(k_gather_ranges_dense, dim3(gatherGrid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, srcKeys, recVal, dst, nRec, segOfRec, (1ull << shiftHi) - 1ull, d0.p, o0.p);
         if (int rc = rx::sortPairs<uint64_t, uint32_t>(s, cuCount, d0.p, d1.p, o0.p, o1.p, total, 1, shiftHi, inFirst)) return rc;
         uint64_t *kA = inFirst ? d0.p : d1.p, *kB = inFirst ? d1.p : d0.p; uint32_t *oA = inFirst ? o0.p : o1.p, *oB = inFirst ? o1.p : o0.p;
-        int ordBits = 1; while ((1ull << ordBits) < (uint64_t) nBig) ordBits++;
         bool second = true;
-        if (int rc = rx::sortPairs<uint32_t, uint64_t>(s, cuCount, oA, oB, kA, kB, total, 0, ordBits, second)) return rc;
+        if (int rc = rx::sortPairs<uint32_t, uint64_t>(s, cuCount, oA, oB, kA, kB, total, 0, std::max(1, segBits), second)) return rc;
         hipLaunchKernelGGL((k_big_copy<uint64_t, false>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, out, second ? kA : kB);
     } else {
+    hipLaunchKernelGGL((k_big_copy<uint64_t, true>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(in), d0.p);
     if (int rc = rx::sortKeys<uint64_t>(s, cuCount, d0.p, d1.p, total, 1, top, inFirst)) return rc;
     hipLaunchKernelGGL((k_big_copy<uint64_t, false>), dim3(g), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, out, inFirst ? d0.p : d1.p);
     }

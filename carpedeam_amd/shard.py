@@ -314,3 +314,83 @@ def exact_iteration(ctx, db, comm, kpar=None, rpar=None, apar=None):
     corr = merge_owned(ctx, ctx.correct(db, alns, apar), comm)
     asm = merge_owned(ctx, ctx.extend(corr, alns, apar), comm)
     return hits, alns, corr, asm
+
+
+# ------------------------------------------------------------------------------------------------ transports for the library's own multi-GPU calls
+# carpedeam_amd.capi.Comm.from_transport binds these to cdm_comm_create_ops (csrc/dist.hip): the C++ calling sequence then runs with
+# several ranks on ONE device, where RCCL - the transport of a deployment, Comm.rccl - wants a device per rank.
+class ThreadTransport:
+    """ranks = threads of one process on one device (ThreadComm.Shared): peers read each other's device memory directly"""
+
+    def __init__(self, shared, rank, ctx):
+        self.sh, self.rank, self.world, self.ctx, self.error = shared, rank, shared.world, ctx, None
+
+    def _gather(self, x):
+        self.sh.slots[self.rank] = x
+        self.sh.barrier.wait()
+        out = list(self.sh.slots)
+        self.sh.barrier.wait()
+        return out
+
+    def all_gather_host(self, b):
+        return self._gather(bytes(b))
+
+    def all_to_all_dev(self, send, soff, recv, roff):
+        parts = self._gather((send, soff))
+        for p, (ptr, off) in enumerate(parts):
+            n = off[self.rank + 1] - off[self.rank]
+            assert n == roff[p + 1] - roff[p]
+            if n:
+                self.ctx.dev_copy(recv + roff[p], ptr + off[self.rank], n)
+        self.sh.barrier.wait()          # nobody frees its send buffer before everybody has copied
+
+    def all_gather_dev(self, send, nbytes, recv, roff):
+        parts = self._gather((send, nbytes))
+        for p, (ptr, n) in enumerate(parts):
+            assert n == roff[p + 1] - roff[p]
+            if n:
+                self.ctx.dev_copy(recv + roff[p], ptr, n)
+        self.sh.barrier.wait()
+
+
+class GlooTransport:
+    """ranks = processes (torch.distributed, gloo), device memory staged through the host with hipMemcpy"""
+
+    def __init__(self, dist, rank, world):
+        import ctypes
+        self.dist, self.rank, self.world, self.error = dist, rank, world, None
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+
+    def _down(self, ptr, n):
+        a = np.empty(max(n, 1), np.uint8)
+        if n:
+            assert self.hip.hipMemcpy(a.ctypes.data, ptr, n, 2) == 0        # hipMemcpyDeviceToHost
+        return a[:n]
+
+    def _up(self, ptr, a):
+        a = np.ascontiguousarray(a, np.uint8)
+        if a.size:
+            assert self.hip.hipMemcpy(ptr, a.ctypes.data, a.size, 1) == 0    # hipMemcpyHostToDevice
+
+    def _gather_objects(self, x):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, x)
+        return out
+
+    def all_gather_host(self, b):
+        return self._gather_objects(bytes(b))
+
+    def all_to_all_dev(self, send, soff, recv, roff):
+        mine = self._down(send, soff[-1])
+        parts = self._gather_objects((mine.tobytes(), soff))
+        for p, (buf, off) in enumerate(parts):
+            piece = np.frombuffer(buf, np.uint8)[off[self.rank]: off[self.rank + 1]]
+            assert piece.size == roff[p + 1] - roff[p]
+            self._up(recv + roff[p], piece)
+
+    def all_gather_dev(self, send, nbytes, recv, roff):
+        parts = self._gather_objects(self._down(send, nbytes).tobytes())
+        for p, buf in enumerate(parts):
+            assert len(buf) == roff[p + 1] - roff[p]
+            self._up(recv + roff[p], np.frombuffer(buf, np.uint8))

@@ -291,6 +291,44 @@ int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
  */
 int cdm_cyclecheck(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t max_seq_len, int chop_cycle, cdm_seqdb **cyclic, cdm_seqdb **rest, uint32_t *split);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Multi-GPU inside the library: one rank per device (one process per GPU, or one host thread per GPU of one process), RCCL over
+ * xGMI called directly (csrc/dist.hip).  The reference shards inside its modules - kmermatcher by k-mer range
+ * (lib/mmseqs/src/linclust/kmermatcher.cpp:634-663, merged :742-784), rescorediagonal by query range
+ * (lib/mmseqs/src/alignment/rescorediagonal.cpp:399-421) - and so do these calls: every rank holds the whole sequence DB, the result is
+ * bit-identical to the single-device calls (the k-mer-range split of cdm_kmermatch_part + ONE all-to-all of the group keys to the owners
+ * of their representatives + the owned ranges of the stages' result DBs all-gathered).
+ *   cdm_comm_unique_id       rank 0: the 128 bytes of ncclGetUniqueId, to be handed to every rank by whatever launched them
+ *   cdm_comm_create_rccl     a rank's communicator (ncclCommInitRank on the context's device; librccl is loaded on first use)
+ *   cdm_comm_create_ops      the same over collectives the caller supplies (tests: W ranks on one device; another collective library)
+ *   cdm_kmermatch_dist       kmermatcher over the ranks: the hits of the representatives this rank owns - sequences
+ *                            [rank n / world, (rank + 1) n / world) -, self hits for all others; the union is cdm_kmermatch's result
+ *   cdm_seqdb_allgather_owned   the owned ranges of the ranks' DBs (same number of sequences on every rank) -> the complete DB
+ *   cdm_reads_iteration_dist    one iteration of the reads loop (data/nuclassemble.sh:100-146) over the ranks; hits / alns hold the
+ *                            owned queries' records, corr / next are complete on every rank and equal the single-device DBs
+ */
+typedef struct cdm_comm cdm_comm;
+typedef struct cdm_comm_ops {
+    void *user;
+    /* host buffers: recv[p * bytes ..] = rank p's send (bytes each) */
+    int (*all_gather_host)(void *user, const void *send, void *recv, uint64_t bytes);
+    /* device buffers, byte offsets [world + 1]: peer p gets send[send_off[p], send_off[p + 1]) and fills recv[recv_off[p], recv_off[p + 1]);
+     * enqueued on `stream` (a hipStream_t) or complete on return */
+    int (*all_to_all_dev)(void *user, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off, void *stream);
+    /* device buffers: recv[recv_off[p], recv_off[p + 1]) = rank p's send (send_bytes of them differ between the ranks) */
+    int (*all_gather_dev)(void *user, const void *send, uint64_t send_bytes, void *recv, const uint64_t *recv_off, void *stream);
+} cdm_comm_ops;
+int cdm_comm_unique_id(void *id128);
+int cdm_comm_create_rccl(cdm_ctx *ctx, int rank, int world, const void *id128, cdm_comm **out);
+int cdm_comm_create_ops(cdm_ctx *ctx, int rank, int world, const cdm_comm_ops *ops, cdm_comm **out);
+void cdm_comm_free(cdm_comm *c);
+int cdm_comm_rank(const cdm_comm *c);
+int cdm_comm_world(const cdm_comm *c);
+int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out);
+int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *local, cdm_seqdb **out);
+int cdm_reads_iteration_dist(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *db, const cdm_kmer_params *kpar, const cdm_rescore_params *rpar,
+                             const cdm_ancient_params *apar, cdm_hits **hits, cdm_alns **alns, cdm_seqdb **corr, cdm_seqdb **next);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,14 @@ assert int(off[hi] - off[lo]) == int(off0[hi] - off0[lo]), "hit count differs on
 assert same(co.download(), c0.download()), "corrected DB differs on rank %d" % rank
 assert same(nx.download(), n0.download()), "next DB differs on rank %d" % rank
 
+# ---- the same through the LIBRARY's own calling sequence (csrc/dist.hip, what a deployment runs over RCCL), here over a gloo transport
+comm = capi.Comm.from_transport(ctx, rank, world, shard.GlooTransport(dist, rank, world))
+h2, a2, co2, nx2 = comm.reads_iteration(db)
+(off2, rec2) = h2.download()
+assert np.array_equal(off2, off) and np.array_equal(rec2, rec), "native hits differ from the Python calling sequence's on rank %d" % rank
+assert same(co2.download(), c0.download()) and same(nx2.download(), n0.download()), "native DBs differ on rank %d" % rank
+del comm, h2, a2, co2, nx2
+
 # ---- reads scheme: each rank its own shard of ONE corpus, then the all-gather of the contigs; every rank must end up holding the
 # contigs of both shards, in shard order
 plan = cd.shard_plan(rank, world, 40_000, 3, "strong")

@@ -214,6 +214,105 @@ def test_exact_kmermatcher_on_small_databases(dhigh_prefix):
             assert np.array_equal(off, want[0]) and np.array_equal(rec, want[1]), (case, world)
 
 
+def run_native_ranks(world, fn):
+    """fn(rank, comm, ctx) on `world` threads, comm = the LIBRARY's communicator (capi.Comm over shard.ThreadTransport): the C++
+    calling sequence of csrc/dist.hip with `world` ranks on the one device"""
+    from carpedeam_amd import shard
+    import threading
+    sh = shard.ThreadComm.Shared(world)
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        tr = None
+        try:
+            c = capi.Ctx(0)
+            tr = shard.ThreadTransport(sh, r, c)
+            out[r] = fn(r, capi.Comm.from_transport(c, r, world, tr), c)
+        except BaseException as e:          # noqa: BLE001
+            err[r] = (tr.error if tr is not None and tr.error is not None else e)
+            sh.barrier.abort()
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    first = [e for e in err if e is not None and not isinstance(e, threading.BrokenBarrierError)] or [e for e in err if e is not None]
+    if first:
+        raise first[0]
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_exact_iteration_equals_single_device(dhigh_prefix, world):
+    """cdm_reads_iteration_dist (csrc/dist.hip: the exact scheme in the library, as a deployment runs it over RCCL) on 200 k mixed-length
+    reads with `world` ranks: hits, corrected DB and next DB equal the single-device calls'."""
+    ref = capi.Ctx(0)
+    ref.damage_load(dhigh_prefix)
+    db = ref.synth(N_READS, 60, 150, 3)
+    hits = ref.kmermatch(db); alns = ref.rescore(db, hits); corr = ref.correct(db, alns); asm = ref.extend(corr, alns)
+    want_hits, want_corr, want_asm = hits.download(), corr.download(), asm.download()
+    del hits, alns, corr, asm
+
+    def rank_fn(rank, comm, c):
+        c.damage_load(dhigh_prefix)
+        h, a, co, nx = comm.reads_iteration(c.synth(N_READS, 60, 150, 3))
+        return h.download(), co.download(), nx.download()
+
+    res = run_native_ranks(world, rank_fn)
+    off, rec = merged_hits([r[0] for r in res], N_READS)
+    assert np.array_equal(off, want_hits[0]) and np.array_equal(rec, want_hits[1])
+    for r in res:
+        for got, want in ((r[1], want_corr), (r[2], want_asm)):
+            assert [bytes(x) for x in got[0]] == [bytes(x) for x in want[0]]
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+
+
+def test_native_kmermatcher_on_small_databases():
+    """cdm_kmermatch_dist on tiny quirk-heavy databases (first-group strand, the run-past-the-end scan across ranks, identical
+    sequences) with 2, 3 and 5 ranks, and on letters beyond ACGTN through cdm_seqdb_allgather_owned."""
+    rng = np.random.default_rng(78)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    ref = capi.Ctx(0)
+    for case in range(16):
+        genome = rng.integers(0, 4, 260)
+        seqs = []
+        for _ in range(int(rng.integers(3, 50))):
+            L = int(rng.integers(18, 110)); st = int(rng.integers(0, 260 - L))
+            c = genome[st:st + L].copy()
+            seqs.append(letters[(3 - c)[::-1] if rng.random() < 0.5 else c].tobytes())
+        seqs += [seqs[0]] * int(rng.integers(0, 3)) + [b"ACG", b""][: int(rng.integers(0, 3))]
+        if case % 4 == 0:
+            seqs[1] = seqs[1][:5].lower() + b"RY" + seqs[1][7:]            # soft-masked / IUPAC letters: the raw plane travels too
+        db = ref.upload_seqs(seqs)
+        want = ref.kmermatch(db).download()
+        want_db = db.download()
+        for world in (2, 3, 5):
+            def rank_fn(rank, comm, c, seqs=seqs):
+                d = c.upload_seqs(seqs)
+                return comm.kmermatch(d).download(), comm.allgather_owned(d).download()
+            res = run_native_ranks(world, rank_fn)
+            off, rec = merged_hits([r[0] for r in res], len(seqs))
+            assert np.array_equal(off, want[0]) and np.array_equal(rec, want[1]), (case, world)
+            for r in res:
+                assert [bytes(x) for x in r[1][0]] == [bytes(x) for x in want_db[0]] and np.array_equal(r[1][1], want_db[1]), (case, world)
+
+
+def test_native_rccl_with_one_rank(dhigh_prefix):
+    """The RCCL transport itself (librccl bound at run time, ncclCommInitRank, grouped send / recv, all-gather) on a one-rank
+    communicator - all this pool's one-GPU boxes allow: every collective of the calling sequence runs, with itself as the only peer."""
+    c = capi.Ctx(0)
+    c.damage_load(dhigh_prefix)
+    comm = capi.Comm.rccl(c, 0, 1, capi.Comm.unique_id())
+    db = c.synth(50_000, 60, 150, 9)
+    h, a, co, nx = comm.reads_iteration(db)
+    h0 = c.kmermatch(db); a0 = c.rescore(db, h0); c0 = c.correct(db, a0); n0 = c.extend(c0, a0)
+    for x, y in ((h.download(), h0.download()), (a.download(), a0.download())):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+    for x, y in ((co.download(), c0.download()), (nx.download(), n0.download())):
+        assert [bytes(s) for s in x[0]] == [bytes(s) for s in y[0]] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
+
+
 def test_exact_scheme_over_rccl_with_one_rank(dhigh_prefix):
     """The torch.distributed flavour of the collectives (TorchComm: all_to_all_single / all_gather over RCCL) on a one-rank group:
     same result as the plain single-device calls."""
