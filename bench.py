@@ -8,9 +8,11 @@ BASELINE.json configs[2]; with N > 1 configs[3]) or of ancient_correction alone 
 synthetic reads that are already resident in HBM (generated on the device before the timed region).
 
 N > 1 (one process per GPU; the driver launches them with torch.distributed.run, `--gpus N` alone spawns them): ONE corpus of R
-reads is split over the ranks (--scaling strong, default: rank r owns reads [r R/N, (r+1) R/N); --scaling weak gives every rank
-its own R-read corpus, seed + rank); every rank runs the stages on its shard with no data-path collective (scheme "reads",
-carpedeam_amd/dist.py) and after the last timed step the per-shard contigs are all-gathered over RCCL in ONE collective.
+reads (--scaling strong, default).  --scheme exact (default): every rank holds the corpus and the LIBRARY splits the work over RCCL
+(csrc/dist.hip: kmermatcher by k-mer range, one all-to-all of the group keys, the other stages on the owned queries, the new DBs
+all-gathered) - the result is the single-device one.  --scheme reads: rank r owns reads [r R/N, (r+1) R/N), runs the stages on them
+alone and the per-shard contigs are all-gathered in ONE collective inside the timed step - the north star's wording, but not the
+single-device result (the JSON line says so).  --scaling weak gives every rank its own R-read corpus, seed + rank.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -208,9 +210,10 @@ def main():
     ap.add_argument("--len", type=int, default=100)
     ap.add_argument("--seed", type=int, default=None, help="generator seed (default: 1, and 2 for --config 5, as SURVEY.md 8(d) specifies the corpora)")
     ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
-    ap.add_argument("--scheme", default="reads", choices=("reads", "exact"),
-                    help="N > 1: reads = every rank runs the stages on its own read shard (north star; not equivalent to the single-device run); "
-                         "exact = k-mer-range split + all-to-all of group keys + query-sharded stages, bit-identical to one device (carpedeam_amd/shard.py)")
+    ap.add_argument("--scheme", default="exact", choices=("exact", "reads"),
+                    help="N > 1: exact (default) = the library's own multi-GPU calls over RCCL (csrc/dist.hip: k-mer-range split + one all-to-all of group keys + "
+                         "query-sharded stages + all-gathers of the new DBs), bit-identical to one device; reads = every rank runs the stages on its own read shard and "
+                         "the contigs are all-gathered (the north star's wording; NOT equivalent to the single-device run: a shard sees 1/N of every pile-up)")
     ap.add_argument("--cpu-reads", type=int, default=10_000_000, help="reads of the sample the reference's modules, the device modules and the fused loop are timed on (same DB files)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -249,10 +252,11 @@ def main():
     from carpedeam_amd import dist as cd
     plan = cd.shard_plan(rank, world, args.reads, args.seed, args.scaling)
     exact = args.scheme == "exact" and dist is not None and args.config == 3
-    if exact:      # every rank holds the whole corpus; the work is split inside the stages
+    if exact:      # every rank holds the whole corpus; the work is split inside the stages, by the library itself over RCCL
         plan = dict(plan, first=0, n=plan["n_total"])
-        from carpedeam_amd import shard
-        comm = shard.TorchComm(dist, rank, world, torch.device("cuda", local_rank))
+        uid = [capi.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)          # (torch.distributed only launches, times and hands the id round: the data path is librccl under libcarpedeam_hip)
+        comm = capi.Comm.rccl(ctx, rank, world, uid[0])
     if args.config == 5:
         return run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch)
     db = ctx.synth(plan["n"], L, L, plan["seed"], n_total=plan["n_total"], first=plan["first"])      # resident in HBM before the timed region
@@ -267,7 +271,7 @@ def main():
 
     def step():
         if exact:
-            hits, alns, corr, asm = shard.exact_iteration(ctx, db, comm)
+            hits, alns, corr, asm = comm.reads_iteration(db)
             return asm, (hits.count, alns.count), [ctx.last_kernel_ms(i) for i in range(16)]
         if args.config == 2:
             corr = ctx.correct(db, pre)
@@ -382,8 +386,9 @@ def main():
             "dtype": "u8 (2-bit packed bases; int32 scores; software x87 f80 likelihood sums)", "data": "synthetic",
             "config": {"workload": workload, "reads_rank0": n, "read_len": L, "seed": args.seed, "prefilter_hits": stats[0], "alignments": stats[1],
                        "multi_gpu_scheme": (None if world == 1 and not exact else
-                                            "exact: k-mer-range kmermatcher + one all-to-all of group keys + query-sharded stages + all-gathers of the new sequences; bit-identical to one device" if exact else
-                                            "reads: every rank runs the stages on its own read shard, no data-path collective, one all-gather of contigs at the end"),
+                                            "exact: the library's own RCCL calls (csrc/dist.hip) - k-mer-range kmermatcher + one all-to-all of group keys + query-sharded stages + all-gathers of the new sequences; bit-identical to one device" if exact else
+                                            "reads: every rank runs the stages on its own read shard, no data-path collective, one all-gather of contigs at the end; NOT equivalent to the single-device run (a shard sees 1/N of every pile-up)"),
+                       "equivalent_to_single_device": bool(world == 1 or exact),
                        "value_is": "kernel-resident: reads already in HBM, no DB files (the module-wall figure is gpu_module_wall)",
                        "stage_kernel_ms": {"kmer_extract": k_ms[3], "kmer_sort1_call": k_ms[5], "kmer_sort1_hash_call": k_ms[7], "kmer_sort2_call": k_ms[6], "rescore": k_ms[1],
                                            "correct": k_ms[0], "extend": k_ms[4]}},

@@ -24,6 +24,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <condition_variable>
+#include <mutex>
 
 #include "carpedeam_hip.h"
 #include "mmdb.h"
@@ -113,11 +115,62 @@ struct Laps {
         fprintf(stderr, "  %-32s %.3f s\n", what, std::chrono::duration<double>(n - t).count()); t = n;
     }
 };
-cdm_ctx *openCtx() {
+cdm_ctx *openCtx(int offset = 0) {
     cdm_ctx *ctx = NULL;
     const char *dev = getenv("CARPEDEAM_DEVICE");
-    check(cdm_ctx_create(dev ? atoi(dev) : 0, &ctx), "Can not initialise the MI355X device");
+    check(cdm_ctx_create((dev ? atoi(dev) : 0) + offset, &ctx), "Can not initialise the MI355X device");
     return ctx;
+}
+// ---- ancient_reads_loop --gpus N: the ranks are host threads of this process, one device each, and the library splits the read
+// iterations over them (cdm_reads_iteration_dist, csrc/dist.hip) - over RCCL.  CDM_LOOP_TRANSPORT=threads (tests on a one-GPU box,
+// where RCCL has no second device to give a rank): all ranks share the first device and the collectives are these few lines - the
+// ranks publish their buffers, meet at a barrier and copy from each other with cdm_dev_copy.
+struct RankBarrier {
+    std::mutex m; std::condition_variable cv; int world = 1, waiting = 0; long generation = 0;
+    void wait() {
+        std::unique_lock<std::mutex> l(m);
+        const long g = generation;
+        if (++waiting == world) { waiting = 0; generation++; cv.notify_all(); }
+        else cv.wait(l, [&] { return generation != g; });
+    }
+};
+struct ThreadTransport {
+    int world = 1; RankBarrier bar;
+    std::vector<const void *> ptr; std::vector<const uint64_t *> off; std::vector<uint64_t> bytes;
+    explicit ThreadTransport(int w) : world(w), ptr(w), off(w), bytes(w) { bar.world = w; }
+};
+struct ThreadRank { ThreadTransport *t; int rank; cdm_ctx *ctx; };
+int ttAllGatherHost(void *user, const void *send, void *recv, uint64_t n) {
+    ThreadRank *r = (ThreadRank *) user; ThreadTransport &t = *r->t;
+    t.ptr[r->rank] = send; t.bar.wait();
+    for (int p = 0; p < t.world; p++) memcpy((char *) recv + (size_t) p * n, t.ptr[p], n);
+    t.bar.wait();
+    return 0;
+}
+int ttAllToAllDev(void *user, const void *send, const uint64_t *soff, void *recv, const uint64_t *roff, void *) {
+    ThreadRank *r = (ThreadRank *) user; ThreadTransport &t = *r->t;
+    if (cdm_ctx_sync(r->ctx)) return -1;                 // what this rank sends is complete
+    t.ptr[r->rank] = send; t.off[r->rank] = soff; t.bar.wait();
+    int rc = 0;
+    for (int p = 0; p < t.world && !rc; p++) {
+        const uint64_t n = t.off[p][r->rank + 1] - t.off[p][r->rank];
+        if (n != roff[p + 1] - roff[p]) rc = -1;
+        else if (n) rc = cdm_dev_copy(r->ctx, (char *) recv + roff[p], (const char *) t.ptr[p] + t.off[p][r->rank], n);
+    }
+    t.bar.wait();                                        // nobody frees its send buffer before everybody has copied
+    return rc;
+}
+int ttAllGatherDev(void *user, const void *send, uint64_t n, void *recv, const uint64_t *roff, void *) {
+    ThreadRank *r = (ThreadRank *) user; ThreadTransport &t = *r->t;
+    if (cdm_ctx_sync(r->ctx)) return -1;
+    t.ptr[r->rank] = send; t.bytes[r->rank] = n; t.bar.wait();
+    int rc = 0;
+    for (int p = 0; p < t.world && !rc; p++) {
+        if (t.bytes[p] != roff[p + 1] - roff[p]) rc = -1;
+        else if (t.bytes[p]) rc = cdm_dev_copy(r->ctx, (char *) recv + roff[p], t.ptr[p], t.bytes[p]);
+    }
+    t.bar.wait();
+    return rc;
 }
 // The device side of a module's start - runtime initialisation and context (0.1-0.2 s), damage tables, sequence upload - in a thread
 // of its own, while the main thread maps and parses the module's text DBs.  Errors are kept and raised by join() on the main thread.
@@ -562,7 +615,7 @@ int readsLoop(Args &a) {
     {   // the workflow's own flags for the reads loop (src/commons/LocalParameters.h:283-318) on top of the stage lists
         static const char *const LOOP_FLAGS[] = {"--k-ancient-reads", "--kmer-per-seq-ancient", "--kmer-per-seq-scale-ancient", "--hash-shift", "--include-only-extendable-ancient-reads",
                                                  "-e", "--num-iter-reads-only", "--shuffle", "--num-iterations", "--k-ancient-contigs", "--include-only-extendable-ancient-contigs",
-                                                 "--cycle-check", "--chop-cycle", NULL};
+                                                 "--cycle-check", "--chop-cycle", "--gpus", NULL};
         checkFlags("ancient_reads_loop", a, ANCIENT_FLAGS, LOOP_FLAGS);
     }
     // input: a sequence DB, or - when there is no <input>.index - FASTA/FASTQ[.gz] reads, parsed and laid out as createdb would
@@ -572,21 +625,25 @@ int readsLoop(Args &a) {
     cdm_ctx *ctx = NULL; cdm_seqdb *db = NULL;
     struct stat st;
     Laps laps;
-    if (stat((a.pos[0] + ".index").c_str(), &st) == 0) {
+    FastxDb fx;
+    const bool fromDb = stat((a.pos[0] + ".index").c_str(), &st) == 0;
+    auto uploadTo = [&](cdm_ctx *c) -> cdm_seqdb * {       // (the same host copy serves every rank of a --gpus N run)
+        if (fromDb) return uploadSeqDb(c, seq);
+        cdm_seqdb *d = NULL;
+        check(cdm_seqdb_upload(c, fx.blob.data(), fx.off.data(), fx.len.data(), fx.key.data(), NULL, fx.key.size(), &d), "Can not load the reads");
+        return d;
+    };
+    if (fromDb) {
         if (!seq.load(a.pos[0], &err)) die(err);
         dbtype = seq.dbtype;
         laps.lap("DB files mapped");
-        ctx = openCtx(); laps.lap("device context");
-        db = uploadSeqDb(ctx, seq); laps.lap("sequences up");
     } else {
-        FastxDb fx;
         if (!readFastxAsDb(std::vector<std::string>(1, a.pos[0]), iflag(a, "--shuffle", 1) != 0, fx, &err)) die(err);
         for (auto &l : fx.len) l -= 2;
         laps.lap("reads file parsed");
-        ctx = openCtx(); laps.lap("device context");
-        check(cdm_seqdb_upload(ctx, fx.blob.data(), fx.off.data(), fx.len.data(), fx.key.data(), NULL, fx.key.size(), &db), "Can not load the reads");
-        laps.lap("sequences up");
     }
+    ctx = openCtx(); laps.lap("device context");
+    db = uploadTo(ctx); laps.lap("sequences up");
     check(cdm_damage_load(ctx, a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"].c_str() : ""), "Profile not 12 fields");
     cdm_kmer_params kp;
     kp.kmer_size = (int) iflag(a, "--k-ancient-reads", 20); kp.kmers_per_seq = (int) iflag(a, "--kmer-per-seq-ancient", 200);
@@ -613,7 +670,50 @@ int readsLoop(Args &a) {
     rc.seq_id_thr = ac.seq_id_thr = fflag(a, "--min-seqid-corr-contigs", 0.9f);
     const bool cycleCheck = iflag(a, "--cycle-check", 1) != 0, chopCycle = iflag(a, "--chop-cycle", 1) != 0;
     OutChunk cyclic;
-    for (long it = 0; it < total && cdm_seqdb_size(db) > 0; it++) {
+    // --gpus N: the read iterations over N ranks = N host threads of this process, a device each; every rank holds the whole DB and
+    // the library splits the work (cdm_reads_iteration_dist: kmermatcher by k-mer range, one all-to-all of group keys, the other stages
+    // on the owned queries, the new DBs all-gathered - the single-device result).  This thread is rank 0 and goes on alone with the
+    // contig iterations (their queue runs on the host).
+    const int gpus = (int) std::max<long>(1, iflag(a, "--gpus", 1));
+    long firstLocal = 0;
+    if (gpus > 1 || getenv("CDM_LOOP_FORCE_COMM")) {
+        const char *tr = getenv("CDM_LOOP_TRANSPORT");
+        const bool threadsTransport = tr && !strcmp(tr, "threads");
+        unsigned char uid[128];
+        if (!threadsTransport) check(cdm_comm_unique_id(uid), "RCCL");
+        ThreadTransport tt(gpus);
+        const std::string damage = a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"] : "";
+        auto rankBody = [&](int r, cdm_ctx *c, cdm_seqdb *&d) {
+            ThreadRank me{&tt, r, c};
+            cdm_comm *cm = NULL;
+            if (threadsTransport) { cdm_comm_ops ops{&me, ttAllGatherHost, ttAllToAllDev, ttAllGatherDev}; check(cdm_comm_create_ops(c, r, gpus, &ops, &cm), "communicator"); }
+            else check(cdm_comm_create_rccl(c, r, gpus, uid, &cm), "RCCL communicator");
+            for (long it = 0; it < iters && cdm_seqdb_size(d) > 0; it++) {
+                cdm_alns *alns = NULL; cdm_seqdb *next = NULL;
+                const auto tIt = std::chrono::steady_clock::now();
+                check(cdm_reads_iteration_dist(c, cm, d, &kp, &rp, &ap, NULL, &alns, NULL, &next), "reads iteration over the ranks");
+                if (r == 0) fprintf(stderr, "STEP: %ld  sequences %llu  residues %llu -> %llu  alignments of rank 0's queries %llu  (%.3f s on %d ranks%s)\n",
+                                    it, (unsigned long long) cdm_seqdb_size(d), (unsigned long long) cdm_seqdb_residues(d), (unsigned long long) cdm_seqdb_residues(next),
+                                    (unsigned long long) cdm_alns_count(alns), std::chrono::duration<double>(std::chrono::steady_clock::now() - tIt).count(), gpus,
+                                    threadsTransport ? ", in-process transport on one device" : ", RCCL");
+                cdm_alns_free(alns); cdm_seqdb_free(d);
+                d = next;
+            }
+            cdm_comm_free(cm);
+        };
+        std::vector<std::thread> helpers;
+        for (int r = 1; r < gpus; r++) helpers.emplace_back([&, r] {
+            cdm_ctx *c = openCtx(threadsTransport ? 0 : r);
+            check(cdm_damage_load(c, damage.c_str()), "Profile not 12 fields");
+            cdm_seqdb *d = uploadTo(c);
+            rankBody(r, c, d);
+            cdm_seqdb_free(d); cdm_ctx_destroy(c);
+        });
+        rankBody(0, ctx, db);
+        for (auto &h : helpers) h.join();
+        firstLocal = iters;
+    }
+    for (long it = firstLocal; it < total && cdm_seqdb_size(db) > 0; it++) {
         cdm_hits *hits = NULL; cdm_alns *alns = NULL; cdm_seqdb *corr = NULL, *next = NULL;
         const bool contigs = it >= iters;
         const auto tIt = std::chrono::steady_clock::now();
