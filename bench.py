@@ -190,8 +190,8 @@ def run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch):
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8 (2-bit packed bases; int32 scores; software x87 f80 likelihood sums)", "data": "synthetic",
             "config": {"workload": "%d synthetic reads of 60-150 bp, dhigh, 12 iterations: 5 x (kmermatcher, rescorediagonal, ancient_correction, ancient_read_assemble) + 7 x "
-                                   "(kmermatcher -k 22, rescorediagonal, ancient_correction, ancient_contig_merge, cyclecheck) (BASELINE.json configs[4] at reduced size: %d reads "
-                                   "per GPU instead of 25 M; the contig phase's host queue grows with the contigs)" % (args.reads, n),
+                                   "(kmermatcher -k 22, rescorediagonal, ancient_correction, ancient_contig_merge, cyclecheck) (BASELINE.json configs[4]%s; the contig phase's host queue "
+                                   "grows with the contigs)" % (args.reads, ": its 25 M reads per GPU" if n >= 25_000_000 else " at reduced size: %d reads per GPU instead of 25 M" % n),
                        "reads_rank0": n, "seed": args.seed, "seconds_per_iteration_rank0": per_it, "final_sequences_rank0": out.n, "final_residues_rank0": out.residues,
                        "circular_contigs_set_aside_rank0": circular, "value_is": "whole job, reads resident in HBM at the start; the contig merge's queue runs on the host"},
             "roofline": {"bound": "hbm", "kernel": "whole chain (no single kernel dominates the 12 iterations; the contig iterations are bound by the host queue)", "achieved": ach,
