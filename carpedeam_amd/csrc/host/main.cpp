@@ -34,6 +34,14 @@
 int createdbModule(const std::vector<std::string> &files, const std::string &outPath, bool shuffle, int dbType, std::string *err);
 int convert2fastaModule(const std::string &dbPath, const std::string &outPath, std::string *err);
 int createhdbModule(const std::string &seqPath, const std::string &cyclePath, const std::string &outPath, std::string *err);
+// host/cluster.cpp: the host-side modules of linclust's tail and the workflow scripts' file modules (status 77: a mode that is not implemented)
+int clustModule(const std::string &seqPath, const std::string &alnPath, const std::string &outPath, int mode, std::string *err);
+int createsubdbModule(const std::string &orderArg, const std::string &inPath, const std::string &outPath, int subDbMode, std::string *err);
+int filterdbModule(const std::string &inPath, const std::string &outPath, const std::string &filterFile, std::string *err);
+int mergeclustersModule(const std::string &seqPath, const std::string &outPath, const std::vector<std::string> &steps, std::string *err);
+int result2repseqModule(const std::string &seqPath, const std::string &cluPath, const std::string &outPath, std::string *err);
+int rmdbModule(const std::string &db);
+int mvdbModule(const std::string &src, const std::string &dst, std::string *err);
 
 namespace {
 std::thread *g_deviceThread = NULL;          // a module's device start-up running beside the main thread (DeviceStart): joined before any exit
@@ -608,6 +616,45 @@ int cyclecheck(Args &a) {
 // - kmermatcher, rescorediagonal, ancient_correction, ancient_read_assemble per iteration - in one process with every
 // intermediate resident in HBM; no prefilter/alignment/correction text DB is written, only the final sequence DB.
 // Not a module of the reference; the per-stage modules above remain the drop-in surface.
+// linclust's host-side tail and the scripts' file modules (host/cluster.cpp); flag lists: Parameters.cpp clust / createsubdb / filterdb /
+// threadsandcompression / onlyverbosity
+int clusterModules(const std::string &cmd, Args &a) {
+    static const FlagSpec CLUST_FLAGS[] = {{"--cluster-mode", 'U', 0, 0}, {"--max-iterations", 'N', 0, "connected-component mode only"}, {"--similarity-type", 'N', 0, "set-cover mode only"},
+                                           {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0}, {"--compressed", 'V', "0", "compressed DBs are not implemented"}, {0, 0, 0, 0}};
+    static const FlagSpec SUBDB_FLAGS[] = {{"--subdb-mode", 'U', 0, 0}, {"-v", 'N', 0, 0}, {"--id-mode", 'V', "0", "look-up mode is not implemented"}, {0, 0, 0, 0}};
+    static const FlagSpec FILTER_FLAGS[] = {{"--filter-file", 'U', 0, 0}, {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0}, {"--compressed", 'V', "0", "compressed DBs are not implemented"},
+                                            {"--filter-column", 'V', "1", "only the first column"}, {"--positive-filter", 'V', "1", "only positive filtering"}, {0, 0, 0, 0}};
+    static const FlagSpec PLAIN_FLAGS[] = {{"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0}, {"--db-load-mode", 'N', 0, 0}, {"--compressed", 'V', "0", "compressed DBs are not implemented"}, {0, 0, 0, 0}};
+    std::string err; int rc = 0;
+    auto need = [&](size_t n, const char *usage) { if (a.pos.size() < n) die(std::string("Usage: carpedeam ") + usage); };
+    if (cmd == "clust") {
+        need(3, "clust <i:sequenceDB> <i:resultDB> <o:clusterDB>"); checkFlags("clust", a, CLUST_FLAGS);
+        rc = clustModule(a.pos[0], a.pos[1], a.pos[2], (int) iflag(a, "--cluster-mode", 0), &err);
+    } else if (cmd == "createsubdb") {
+        need(3, "createsubdb <i:subsetFile|DB> <i:DB> <o:DB>"); checkFlags("createsubdb", a, SUBDB_FLAGS);
+        rc = createsubdbModule(a.pos[0], a.pos[1], a.pos[2], (int) iflag(a, "--subdb-mode", 0), &err);
+    } else if (cmd == "filterdb") {
+        need(2, "filterdb <i:resultDB> <o:resultDB> --filter-file <file>"); checkFlags("filterdb", a, FILTER_FLAGS);
+        if (!a.flag.count("--filter-file")) unsupported("filterdb: only the --filter-file mode is implemented on the MI355X path");
+        rc = filterdbModule(a.pos[0], a.pos[1], a.flag["--filter-file"], &err);
+    } else if (cmd == "mergeclusters") {
+        need(3, "mergeclusters <i:sequenceDB> <o:clusterDB> <i:clusterDB1> ... <i:clusterDBn>"); checkFlags("mergeclusters", a, PLAIN_FLAGS);
+        rc = mergeclustersModule(a.pos[0], a.pos[1], std::vector<std::string>(a.pos.begin() + 2, a.pos.end()), &err);
+    } else if (cmd == "result2repseq") {
+        need(3, "result2repseq <i:sequenceDB> <i:resultDB> <o:sequenceDB>"); checkFlags("result2repseq", a, PLAIN_FLAGS);
+        rc = result2repseqModule(a.pos[0], a.pos[1], a.pos[2], &err);
+    } else if (cmd == "rmdb") {
+        need(1, "rmdb <i:DB>"); checkFlags("rmdb", a, PLAIN_FLAGS);
+        rc = rmdbModule(a.pos[0]);
+    } else {
+        need(2, "mvdb <i:srcDB> <o:dstDB>"); checkFlags("mvdb", a, PLAIN_FLAGS);
+        rc = mvdbModule(a.pos[0], a.pos[1], &err);
+    }
+    if (rc == 77) unsupported(err);
+    if (rc) die(err);
+    return EXIT_SUCCESS;
+}
+
 int readsLoop(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam ancient_reads_loop <i:sequenceDB> <o:sequenceDB> --ancient-damage <prefix> [--num-iter-reads-only N]");
     // the contig iterations' buffers grow ~1.5x per iteration: head room in the device-memory cache lets them fit the previous iteration's blocks
@@ -792,7 +839,7 @@ int createhdb(Args &a) {
 }  // namespace
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: carpedeam <kmermatcher|rescorediagonal|ancient_correction|ancient_read_assemble|ancient_contig_merge|cyclecheck|ancient_reads_loop|createdb|convert2fasta|createhdb> <args>\n"); return EXIT_FAILURE; }
+    if (argc < 2) { fprintf(stderr, "usage: carpedeam <kmermatcher|rescorediagonal|ancient_correction|ancient_read_assemble|ancient_contig_merge|cyclecheck|ancient_reads_loop|createdb|convert2fasta|createhdb|clust|createsubdb|filterdb|mergeclusters|result2repseq|rmdb|mvdb> <args>\n"); return EXIT_FAILURE; }
     const std::string cmd = argv[1];
     Args a = parse(argc - 2, argv + 2);
     {   // --threads / MMSEQS_NUM_THREADS as in Parameters.cpp:2121-2132: the host side (DB parsing, text codecs) uses them
@@ -809,6 +856,7 @@ int main(int argc, char **argv) {
     else if (cmd == "ancient_read_assemble") rc = ancientModule(a, 1);
     else if (cmd == "ancient_contig_merge") rc = ancientModule(a, 2);
     else if (cmd == "ancient_reads_loop") rc = readsLoop(a);
+    else if (cmd == "clust" || cmd == "createsubdb" || cmd == "filterdb" || cmd == "mergeclusters" || cmd == "result2repseq" || cmd == "rmdb" || cmd == "mvdb") rc = clusterModules(cmd, a);
     else if (cmd == "createdb") rc = createdb(a);
     else if (cmd == "convert2fasta") rc = convert2fasta(a);
     else if (cmd == "createhdb") rc = createhdb(a);
