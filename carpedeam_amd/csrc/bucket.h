@@ -20,7 +20,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include <rocprim/rocprim.hpp>
 
 #include "common.h"
 #include "radix.h"
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(256) void k_big_copy(const unsigned long long *__re
 
 inline unsigned int bigCopyGrid(unsigned int cnt) { return std::min<unsigned int>((cnt + 3) / 4, 1u << 16); }
 
-// (start, end) list in append order -> ranges sorted by start with their offsets in a dense array: rocPRIM sort by start, sizes,
+// (start, end) list in append order -> ranges sorted by start with their offsets in a dense array: radix sort (radix.h) by start, sizes,
 // exclusive scan.  Everything stays on the device except the total (and the first start, which the k-mer path wants).
 __global__ void k_big_sizes(const unsigned long long *__restrict__ st, const unsigned long long *__restrict__ en, unsigned int cnt, unsigned long long *__restrict__ sz) {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -413,7 +412,7 @@ inline int loadBigList(hipStream_t s, const unsigned long long *bigList, unsigne
     hipLaunchKernelGGL(k_big_split, dim3(g), dim3(256), 0, s, bigList, cnt, s0.p, e0.p);
     bool inFirst = true;
     if (int rc = rx::sortPairs<unsigned long long, unsigned long long>(s, 256, s0.p, s1.p, e0.p, e1.p, (uint64_t) cnt, 0, 64, inFirst)) return rc;
-    rocprim::double_buffer<unsigned long long> ks(inFirst ? s0.p : s1.p, inFirst ? s1.p : s0.p), vs(inFirst ? e0.p : e1.p, inFirst ? e1.p : e0.p);
+    struct { unsigned long long *c; unsigned long long *current() const { return c; } } ks{inFirst ? s0.p : s1.p}, vs{inFirst ? e0.p : e1.p};
     cdmscan::ScanTemp scanTmp;                                                // alive until the synchronise below
     hipLaunchKernelGGL(k_big_sizes, dim3(g), dim3(256), 0, s, (const unsigned long long *) ks.current(), (const unsigned long long *) vs.current(), cnt, sz.p);
     if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, scanTmp, sz.p, off.p, (size_t) cnt + 1)) return rc;

@@ -19,7 +19,6 @@
 // per-target scan in the writer running on into the next representative's tuples when they have the same target id
 // (:875-887).
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "common.h"
 #include "devutil.h"
@@ -32,6 +31,14 @@
 namespace {
 
 constexpr uint64_t BIT63 = 1ull << 63;
+// the two buffers a sort alternates between: where the data is now, and the other one
+template <typename T> struct DoubleBuf {
+    T *cur = nullptr, *alt = nullptr;
+    DoubleBuf() = default;
+    DoubleBuf(T *c, T *a) : cur(c), alt(a) {}
+    T *current() const { return cur; }
+    T *alternate() const { return alt; }
+};
 
 // xxHash64 of one 8-byte word (lib/mmseqs/lib/xxhash/xxhash.h XXH64, len = 8; kmermatcher.cpp:33-38)
 __host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
@@ -1246,7 +1253,7 @@ struct KmerJob : KmerJobBase {
     DevBuf<uint32_t> listShort, listLong, listSingle, listHuge;
     DevBuf<unsigned long long> slots; DevBuf<uint64_t> slotOff; DevBuf<uint32_t> rankOf;
     uint64_t kmerSlots = 0; unsigned long long nTuples = 0;
-    rocprim::double_buffer<uint64_t> keys; rocprim::double_buffer<V> vals;
+    DoubleBuf<uint64_t> keys; DoubleBuf<V> vals;
     DevBuf<uint64_t> k0, k1; DevBuf<V> v0, v1;
     TupleGeom geom; int lowBits = 0;
     GroupArgs<LY> ga; DevBuf<unsigned long long> statStripes; unsigned long long *startIo = nullptr; DevBuf<uint32_t> staleBuf;
@@ -1294,7 +1301,7 @@ int phaseA() override {
         cdmscan::ScanTemp st;
         bool lenFirst = true;
         if (int rc = rx::sortPairs<uint32_t, uint32_t>(s, ctx->cuCount, lk0.p, lk1.p, lv0.p, lv1.p, (uint64_t) n, 0, (int) lenBits, lenFirst)) return rc;
-        rocprim::double_buffer<uint32_t> lk(lenFirst ? lk0.p : lk1.p, lenFirst ? lk1.p : lk0.p), lv(lenFirst ? lv0.p : lv1.p, lenFirst ? lv1.p : lv0.p);
+        DoubleBuf<uint32_t> lk(lenFirst ? lk0.p : lk1.p, lenFirst ? lk1.p : lk0.p), lv(lenFirst ? lv0.p : lv1.p, lenFirst ? lv1.p : lv0.p);
         hipLaunchKernelGGL(k_slot_counts, dim3((n + 256) / 256), dim3(256), 0, s, db->len, lv.current(), n, k, slots.p);
         if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, st, slots.p, ordOff.p, (size_t) n + 1)) return rc;
         hipLaunchKernelGGL(k_slot_scatter, dim3((n + 256) / 256), dim3(256), 0, s, lv.current(), ordOff.p, n, slotOff.p, rankOf.p);
@@ -1359,28 +1366,16 @@ int phaseA() override {
 
     // ---- sort 1: stable LSD radix sort by k-mer.  Region 1 (k-mer slots) on the 2k key bits, region 2 (whole-sequence hashes)
     // on 63 bits into the same physical buffers; the strand bit 63 rides along outside the sorted bit range.
-    keys = rocprim::double_buffer<uint64_t>(k0.p, k1.p); vals = rocprim::double_buffer<V>(v0.p, v1.p);
+    keys = DoubleBuf<uint64_t>(k0.p, k1.p); vals = DoubleBuf<V>(v0.p, v1.p);
     // Region 1: only the top 27 sort bits go through global passes, the low bits are finished per bucket by k_bucket_groups
     // (bucket.h); CDM_KMER_SORT=lsd sorts all 2k bits globally and keeps the separate scan + k_groups kernels (A/B).
     // With low bits left over the passes cover bits [lowBits, 2k]: bit 2k is set only in unused slots, which end up last.
-    // 27 high bits = 3 onesweep passes of 9 bits (rocPRIM's tuned default is 8 bits per pass; 9 still fits the LDS and three
+    // 27 high bits = 3 onesweep passes of 9 bits (library radix sorts default to 8 bits per pass; 9 still fits the LDS and three
     // 9-bit passes take 29 ms per 2^30 tuples where four 8-bit ones take 35).
-    typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                       rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 16>, rocprim::kernel_config<512, 16>, 9, rocprim::block_radix_rank_algorithm::match>> Sort1Config;
-    const bool fourPasses = sortEnv && !strcmp(sortEnv, "4x8");      // CDM_KMER_SORT=4x8: rocPRIM's default 8-bit passes over 32 bits (A/B)
-    lowBits = lsdOnly ? 0 : std::max(0, 2 * k + 1 - (fourPasses ? 32 : 27));
+    lowBits = lsdOnly ? 0 : std::max(0, 2 * k + 1 - 27);
     const int sortTop = lowBits ? 2 * k + 1 : 2 * k;
-    size_t tmpBytes = 0, tmpBytesH = 0;
-    if (lsdOnly || fourPasses) rocprim::radix_sort_pairs(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s);
-    else rocprim::radix_sort_pairs<Sort1Config>(nullptr, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s);
-    rocprim::radix_sort_pairs(nullptr, tmpBytesH, k0.p + kmerSlots, k1.p + kmerSlots, v0.p + kmerSlots, v1.p + kmerSlots, (size_t) n, 0, 63, s);
-    DevBuf<char> tmp1;
-    if (!tmp1.alloc(std::max(tmpBytes, tmpBytesH) + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
-    // The passes themselves: the hand-written onesweep of radix.h (CDM_KMER_SORT1=rocprim: rocPRIM's, for A/B runs and the tests).
-    const char *sort1Env = cdmGetenv("CDM_KMER_SORT1");
-    const bool ownRadix = !(lsdOnly || fourPasses) && !(sort1Env && !strcmp(sort1Env, "rocprim"));
     hipEventRecord(ctx->ev0, s);
-    if (ownRadix && nparts > 1 && kmerSlots) {
+    if (nparts > 1 && kmerSlots && !lsdOnly) {
         // a k-mer RANGE: most slots are empty.  The real tuples are compacted (stable) into the other buffers first, so that the
         // passes run over this rank's share only; behind them the result holds empty slots again, as if all had been sorted.
         DevBuf<unsigned long long> cnt;
@@ -1394,30 +1389,25 @@ int phaseA() override {
         ctx->lastMs[14] = (float) ((sortTop - lowBits + rx::BITS - 1) / rx::BITS);
         uint64_t *kRes = inFirst ? k1.p : k0.p; V *vRes = inFirst ? v1.p : v0.p;
         hipMemsetAsync(kRes + m, 0xFF, (size_t) (kmerSlots - m) * 8, s);        // (the values of empty slots are never read)
-        keys = rocprim::double_buffer<uint64_t>(kRes, inFirst ? k0.p : k1.p); vals = rocprim::double_buffer<V>(vRes, inFirst ? v0.p : v1.p);
-    } else if (ownRadix) {
+        keys = DoubleBuf<uint64_t>(kRes, inFirst ? k0.p : k1.p); vals = DoubleBuf<V>(vRes, inFirst ? v0.p : v1.p);
+    } else {
         bool inFirst = true;
         if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, k0.p, k1.p, v0.p, v1.p, (uint64_t) kmerSlots, lowBits, sortTop, inFirst, &ctx->lastMs[13])) return rc;
         ctx->lastMs[14] = (float) ((sortTop - lowBits + rx::BITS - 1) / rx::BITS);     // its launches
-        keys = rocprim::double_buffer<uint64_t>(inFirst ? k0.p : k1.p, inFirst ? k1.p : k0.p); vals = rocprim::double_buffer<V>(inFirst ? v0.p : v1.p, inFirst ? v1.p : v0.p);
-    } else if (((lsdOnly || fourPasses) ? rocprim::radix_sort_pairs(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)
-                 : rocprim::radix_sort_pairs<Sort1Config>(tmp1.p, tmpBytes, keys, vals, (size_t) kmerSlots, lowBits, sortTop, s)) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
+        keys = DoubleBuf<uint64_t>(inFirst ? k0.p : k1.p, inFirst ? k1.p : k0.p); vals = DoubleBuf<V>(inFirst ? v0.p : v1.p, inFirst ? v1.p : v0.p);
+    }
     hipEventRecord(ctx->ev1, s);
     hipEventRecord(ctx->ev2, s);
     {
         // region 2 goes to wherever region 1 ended up (the input is always the extraction buffers k0/v0)
         uint64_t *kOut = keys.current() + kmerSlots, *kIn = k0.p + kmerSlots;
         V *vOut = vals.current() + kmerSlots, *vIn = v0.p + kmerSlots;
-        if (ownRadix) {
+        {
             bool inFirst = true;
             if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, kIn, k1.p + kmerSlots, vIn, v1.p + kmerSlots, (uint64_t) n, 0, 63, inFirst)) return rc;
             uint64_t *kRes = inFirst ? kIn : k1.p + kmerSlots; V *vRes = inFirst ? vIn : v1.p + kmerSlots;
             if (kRes != kOut) { hipMemcpyAsync(kOut, kRes, (size_t) n * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(vOut, vRes, (size_t) n * sizeof(V), hipMemcpyDeviceToDevice, s); }
-        } else if (kOut == kIn) {   // region 1 finished in the extraction buffers: sort region 2 via the alternate buffers and copy back
-            if (rocprim::radix_sort_pairs(tmp1.p, tmpBytesH, kIn, k1.p + kmerSlots, vIn, v1.p + kmerSlots, (size_t) n, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
-            hipMemcpyAsync(kOut, k1.p + kmerSlots, (size_t) n * 8, hipMemcpyDeviceToDevice, s);
-            hipMemcpyAsync(vOut, v1.p + kmerSlots, (size_t) n * sizeof(V), hipMemcpyDeviceToDevice, s);
-        } else if (rocprim::radix_sort_pairs(tmp1.p, tmpBytesH, kIn, kOut, vIn, vOut, (size_t) n, 0, 63, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort failed"); return CDM_ERR_HIP; }
+        }
     }
     hipEventRecord(ctx->ev3, s);
     // ---- K3: group keys per slot (fused bucket kernel for region 1, run-start max-scan + k_groups elsewhere), then the
@@ -1484,7 +1474,7 @@ int phaseA() override {
                     hipLaunchKernelGGL((bucket::k_big_copy<V, true>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<V *>(ga.vals), dv0.p);
                     bool bigFirst = true;
                     rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, dk0.p, dk1.p, dv0.p, dv1.p, (uint64_t) total, 0, 2 * k, bigFirst);
-                    rocprim::double_buffer<uint64_t> dk(bigFirst ? dk0.p : dk1.p, bigFirst ? dk1.p : dk0.p); rocprim::double_buffer<V> dv(bigFirst ? dv0.p : dv1.p, bigFirst ? dv1.p : dv0.p);
+                    DoubleBuf<uint64_t> dk(bigFirst ? dk0.p : dk1.p, bigFirst ? dk1.p : dk0.p); DoubleBuf<V> dv(bigFirst ? dv0.p : dv1.p, bigFirst ? dv1.p : dv0.p);
                     if (rc == CDM_OK) {
                         // the sorted tuples go back in place too: k_stale_tail indexes big buckets directly
                         hipLaunchKernelGGL((bucket::k_big_copy<uint64_t, false>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(ga.keys), dk.current());
@@ -1583,7 +1573,7 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
         if (nRec) {
             bool recFirst = true;
             if (int rc = rx::sortPairs<uint32_t, uint64_t>(s, ctx->cuCount, rr0.p, rr1.p, rv0.p, rv1.p, (uint64_t) nRec, 0, (int) idBits, recFirst)) return rc;
-            rocprim::double_buffer<uint32_t> rk(recFirst ? rr0.p : rr1.p, recFirst ? rr1.p : rr0.p); rocprim::double_buffer<uint64_t> rv(recFirst ? rv0.p : rv1.p, recFirst ? rv1.p : rv0.p);
+            DoubleBuf<uint32_t> rk(recFirst ? rr0.p : rr1.p, recFirst ? rr1.p : rr0.p); DoubleBuf<uint64_t> rv(recFirst ? rv0.p : rv1.p, recFirst ? rv1.p : rv0.p);
             // (the scan reads one element past the records: the value buffers have nRec + 1 entries, the last one's length is not used)
             hipMemsetAsync(rv.current() + nRec, 0, 8, s);
             if (int rc = cdmscan::exclusiveScanFn<unsigned long long, RunLen>(s, stB, RunLen{rv.current()}, dst.p, (size_t) nRec + 1)) return rc;
@@ -1619,13 +1609,11 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
         sorted2 = sortedOut;
     }
     if (!sort2Runs || sort2Check) {
-        rocprim::double_buffer<uint64_t> g(const_cast<uint64_t *>(keysIn), bufA);      // (radix variant: keysIn is sorted in place, bufB == keysIn)
+        // (radix variant: the keys are sorted between keysIn and bufA by the passes of radix.h; bufB == keysIn)
         const int shiftHi2 = lsdOnly ? 1 : std::max(1, top2 + 1 - 32);
-        size_t tmpBytes2 = 0;
-        rocprim::radix_sort_keys(nullptr, tmpBytes2, g, (size_t) nIn, shiftHi2, top2 + 1, s);
-        DevBuf<char> tmp3;
-        if (!tmp3.alloc(tmpBytes2 + 256)) { cdm_set_error("cdm_kmermatch: out of device memory (sort temp)"); return CDM_ERR_HIP; }
-        if (rocprim::radix_sort_keys(tmp3.p, tmpBytes2, g, (size_t) nIn, shiftHi2, top2 + 1, s) != hipSuccess) { cdm_set_error("cdm_kmermatch: radix sort 2 failed"); return CDM_ERR_HIP; }
+        bool g2First = true;
+        if (int rc = rx::sortKeys<uint64_t>(s, ctx->cuCount, const_cast<uint64_t *>(keysIn), bufA, (uint64_t) nIn, shiftHi2, top2 + 1, g2First)) return rc;
+        DoubleBuf<uint64_t> g(g2First ? const_cast<uint64_t *>(keysIn) : bufA, g2First ? bufA : const_cast<uint64_t *>(keysIn));
         unsigned long long nGroupR = 0;
         if (nIn) {
             hipLaunchKernelGGL(k_live_count, dim3(1), dim3(1), 0, s, (const uint64_t *) g.current(), (uint64_t) nIn, top2, counters.p + 2);
@@ -1799,7 +1787,7 @@ int gatherByRep() override {
     if (!dst.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
     bool recFirst = true;
     if (int rc = rx::sortPairs<uint32_t, uint64_t>(s, ctx->cuCount, rr0.p, rr1.p, rv0.p, rv1.p, (uint64_t) nRec, 0, (int) idBits, recFirst)) return rc;
-    rocprim::double_buffer<uint32_t> rk(recFirst ? rr0.p : rr1.p, recFirst ? rr1.p : rr0.p); rocprim::double_buffer<uint64_t> rv(recFirst ? rv0.p : rv1.p, recFirst ? rv1.p : rv0.p);
+    DoubleBuf<uint32_t> rk(recFirst ? rr0.p : rr1.p, recFirst ? rr1.p : rr0.p); DoubleBuf<uint64_t> rv(recFirst ? rv0.p : rv1.p, recFirst ? rv1.p : rv0.p);
     hipMemsetAsync(rv.current() + nRec, 0, 8, s);
     if (int rc = cdmscan::exclusiveScanFn<unsigned long long, RunLen>(s, stB, RunLen{rv.current()}, dst.p, (size_t) nRec + 1)) return rc;
     hipMemcpyAsync(&nOut, dst.p + nRec, 8, hipMemcpyDeviceToHost, s);

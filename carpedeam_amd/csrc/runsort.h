@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_gather_ranges(const unsigned long long 
 
 // ---------------------------------------------------------------------------------------------- segments by size class
 constexpr int U_T = 1024;             // slots per unit range of the segmented sort (k_unit_sort below)
-constexpr int SEG_CLASSES = 4;          // 0..2: k_block_sort with 2, 4, 8 waves; 3: longer (rocPRIM)
+constexpr int SEG_CLASSES = 4;          // 0..2: k_block_sort with 2, 4, 8 waves; 3: longer (the global radix sort of radix.h)
 struct SegListArgs {
     const uint32_t *recRep; const unsigned long long *dst; uint64_t nRec;
     uint32_t maxWave;                   // segments up to this length are finished by k_bucket_sort
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(1024) void k_seg_list(SegListArgs a) {
 // every wavefront sorts its 64 sub-buckets (as one group if they hold at most 512 tuples, else in groups of consecutive
 // sub-buckets) with the register network of bucket.h on words (h, diagonal, index in the unit): concatenated, the sorted groups
 // are the sorted unit, ties in input order.  A segment of more than maxSeg = U_CAP - U_T tuples never fits for sure and is left
-// to the caller (k_seg_list lists it); a unit with a sub-bucket beyond 512 tuples goes to the `hard` list (sorted by rocPRIM).
+// to the caller (k_seg_list lists it); a unit with a sub-bucket beyond 512 tuples goes to the `hard` list (sorted by the global radix sort).
 #ifndef CDM_U_NT
 #define CDM_U_NT 512
 #endif
@@ -621,7 +621,7 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
     if (const char *e = cdmGetenv("CDM_BLOCK_CAP")) { const long m = atol(e); if (m >= 0 && m <= 4096) blockCap = (uint32_t) m; }
     uint32_t maxSub = BK_MAXB;
     if (const char *e = cdmGetenv("CDM_UNIT_SUB")) { const long m = atol(e); if (m >= 1 && m <= BK_MAXB) maxSub = (uint32_t) m; }
-    if (shiftHi - 1 + BLK_IDX > 64) blockCap = 0;       // the block sorter's word does not hold such keys: rocPRIM takes them
+    if (shiftHi - 1 + BLK_IDX > 64) blockCap = 0;       // the block sorter's word does not hold such keys: the global radix sort takes them
     if (!unitHook && U_ORDB + shiftHi - 1 + U_IDXB > 64) maxSeg = 0; // nor does the unit sorter's (ordinal, id, diagonal, index): everything goes to the radix sort
     const uint64_t units = (n + U_T - 1) / U_T;
     const size_t listCap = (size_t) (n / ((uint64_t) maxSeg + 1) + 2);
@@ -651,7 +651,7 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
         ua.list = uList[2].p; ua.count = cnt.p + SEG_CLASSES + 3; hipLaunchKernelGGL((k_unit_sort<U_CLASS_CAP[2], U_CLASS_NT[2]>), dim3(grid), dim3(U_CLASS_NT[2]), pad, s, ua);
         }
     }
-    // the segments no unit can hold, listed by size class: one block of 8 waves (bitonic network, bucket.h) up to 4096, rocPRIM beyond
+    // the segments no unit can hold, listed by size class: one block of 8 waves (bitonic network, bucket.h) up to 4096, the global radix sort beyond
     SegListArgs la; la.recRep = recRep; la.dst = dst; la.nRec = nRec; la.maxWave = maxSeg; la.uEnd = maxSeg ? uEnd.p : nullptr; la.units = units;
     la.cap[0] = 0; la.cap[1] = 0; la.cap[2] = blockCap;
     for (int c = 0; c < SEG_CLASSES; c++) la.list[c] = lists[c].p;      // (classes 0 and 1 stay empty: their capacities are 0)
@@ -664,11 +664,11 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
     if (blockCap) hipLaunchKernelGGL(k_block_sort<8>, dim3((unsigned int) std::min<uint64_t>((uint64_t) cuCount * 8, listCap)), dim3(512), 0, s, ba);
     unsigned int hc[NCNT] = {0};
     if (hipMemcpyAsync(hc, cnt.p, NCNT * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return CDM_ERR_HIP;
-    if (cdmGetenv("CDM_BUCKET_STATS")) fprintf(stderr, "segmentedSortKeys%s: n %llu, %llu records, %llu units (%u / %u / %u by size class): segments > %u: %u (<= %u, block sort), %u longer (rocPRIM); %u hard units (rocPRIM)\n",
+    if (cdmGetenv("CDM_BUCKET_STATS")) fprintf(stderr, "segmentedSortKeys%s: n %llu, %llu records, %llu units (%u / %u / %u by size class): segments > %u: %u (<= %u, block sort), %u longer (global radix sort); %u hard units (global radix sort)\n",
                                             unitHook ? " (units aggregated)" : "", (unsigned long long) n, (unsigned long long) nRec, (unsigned long long) units, hc[SEG_CLASSES + 1], hc[SEG_CLASSES + 2], hc[SEG_CLASSES + 3], maxSeg, hc[2], blockCap, hc[3], hc[SEG_CLASSES]);
     const unsigned int nBig = hc[3] + hc[SEG_CLASSES];
     if (nBig == 0) return CDM_OK;
-    // deep pile-ups and hard units: gather, sort on the whole key with rocPRIM (stable), scatter.  (The ranges are disjoint and
+    // deep pile-ups and hard units: gather, sort on the whole key with the radix sort of radix.h (stable), scatter.  (The ranges are disjoint and
     // the array is grouped by representative, so one sort of their concatenation on the whole key sorts each of them.)
     if (hc[SEG_CLASSES]) hipMemcpyAsync(lists[3].p + 2 * (size_t) hc[3], hardList.p, 2 * (size_t) hc[SEG_CLASSES] * 8, hipMemcpyDeviceToDevice, s);
     if (!wide) {   // their tuples, expanded into `in`
