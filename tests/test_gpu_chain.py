@@ -191,19 +191,22 @@ def test_chain_properties_at_scale(ctx, n):
 
 def test_full_size_invariants(ctx, monkeypatch):
     """BASELINE.json configs[2] at full size - 50 M x 100 bp, no oracle there: kmermatcher with its two independent sort-2 pipelines
-    (run records + on-chip sorters vs radix passes + bucket finish) cross-checked on the device over all 4 G tuples, the library's
-    own radix sort against rocPRIM's on the same data (equal hit sets), and the structural invariants that need only counts
+    (run records + on-chip sorters vs radix passes + bucket finish) cross-checked on the device over all 4 G tuples, the wide group key
+    (representative out of the member's key, entries only) against the narrow one on the same data (equal hit arrays, compared on the
+    device's downloads chunk by chunk), and the structural invariants that need only counts
     and per-sequence metadata (no 5 GB downloads into Python objects)."""
     n, L = 50_000_000, 100
     db = ctx.synth(n, L, L, 1)
     monkeypatch.setenv("CDM_KMER_SORT2", "check")            # a mismatch between the two pipelines is an error of the call
     hits = ctx.kmermatch(db)
     monkeypatch.delenv("CDM_KMER_SORT2")
-    monkeypatch.setenv("CDM_KMER_SORT1", "rocprim")
-    hits_lib = ctx.kmermatch(db)
-    monkeypatch.delenv("CDM_KMER_SORT1")
-    assert hits.count == hits_lib.count
-    del hits_lib
+    monkeypatch.setenv("CDM_FORCE_WIDE_KEY", "1")
+    hits_wide = ctx.kmermatch(db)
+    monkeypatch.delenv("CDM_FORCE_WIDE_KEY")
+    assert hits.count == hits_wide.count
+    (off_n, rec_n), (off_w, rec_w) = hits.download(), hits_wide.download()
+    assert np.array_equal(off_n, off_w) and np.array_equal(rec_n, rec_w)
+    del hits_wide, off_n, rec_n, off_w, rec_w
     alns = ctx.rescore(db, hits)
     assert n <= alns.count <= hits.count and hits.count > 3 * n
     del hits

@@ -117,7 +117,7 @@ def test_kmermatch_bucket_sort_paths_agree(ctx, oracle_bin, tmp_path, monkeypatc
                 {"CDM_KMER_SORT2": "radix"}, {"CDM_KMER_SORT2": "check"}, {"CDM_KMER_SORT2": "check", "CDM_UNIT_CAP": "5"},
                 {"CDM_KMER_SORT2": "check", "CDM_UNIT_CAP": "5", "CDM_BLOCK_CAP": "8"}, {"CDM_UNIT_CAP": "1", "CDM_BLOCK_CAP": "0"},
                 {"CDM_KMER_SORT2": "check", "CDM_UNIT_SUB": "3"}, {"CDM_RUN_RECORDS": "twopass"}, {"CDM_KMER_SORT2": "check", "CDM_RUN_CAP": "10"},
-                {"CDM_KMER_SORT1": "rocprim"}, {"CDM_KMER_SORT1": "rocprim", "CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide"},
+                {"CDM_KMER_SORT": "lsd", "CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide"},
                 # the vote: on tuples instead of aggregated entries (aggvote.h); units of more than 3 / 40 distinct triples, segments of
                 # more than 5 / 1 tuples and an entry buffer of 10 entries take the aggregation's other paths (tuple sorters + k_rle_segment,
                 # the fallback to the tuple vote)
@@ -137,7 +137,7 @@ def test_kmermatch_variants_identical_at_scale(ctx, monkeypatch):
     ref = None
     for env in ({}, {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_KMER_SORT": "lsd"}, {"CDM_BUCKET_CAP": "48"},
                 {"CDM_KMER_SORT2": "radix"}, {"CDM_KMER_SORT2": "check"}, {"CDM_KMER_SORT2": "check", "CDM_UNIT_CAP": "700"}, {"CDM_KMER_SORT2": "check", "CDM_UNIT_SUB": "12"},
-                {"CDM_RUN_RECORDS": "twopass"}, {"CDM_RUN_CAP": "1000"}, {"CDM_KMER_SORT1": "rocprim"},
+                {"CDM_RUN_RECORDS": "twopass"}, {"CDM_RUN_CAP": "1000"},
                 {"CDM_KMER_VOTE": "tuples"}, {"CDM_AGG_D": "100"}, {"CDM_UNIT_CAP": "700"}, {"CDM_AGG_CAP": "100000"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
