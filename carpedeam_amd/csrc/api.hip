@@ -112,6 +112,12 @@ extern "C" int cdm_damage_get(cdm_ctx *c, long double *out) {
 }
 extern "C" double cdm_evalue(double raw, double qLen, uint64_t dbRes) { return cdm_evalue_host(raw, qLen, dbRes); }
 extern "C" int cdm_bit_score(double raw) { return cdm_bit_score_host(raw); }
+extern "C" int cdm_gapped_evalue(int gapOpen, int gapExtend, double raw, double qLen, uint64_t dbRes, double *evalue, int *bits) {
+    if (!cdm_gapped_costs_known(gapOpen, gapExtend)) { cdm_set_error("gapped E-values: only nucleotide.out with --gap-open 5 --gap-extend 2 (the costs ancient_assemble passes)"); return CDM_ERR_UNSUPPORTED; }
+    if (evalue) *evalue = cdm_evalue_gapped_host(raw, qLen, dbRes);
+    if (bits) *bits = cdm_bit_score_gapped_host(raw);
+    return CDM_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ sequence DB
 int cdm_seqdb_alloc(cdm_ctx *ctx, uint64_t n, cdm_seqdb **out) {

@@ -200,5 +200,9 @@ int cdm_synth_impl(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, uint64_t n, ui
 // host E-value helpers (host/evalue.cpp)
 double cdm_evalue_host(double rawScore, double qLen, uint64_t dbResidues);
 int cdm_bit_score_host(double rawScore);
+// the same for gapped alignments of nucleotide.out with the gap costs `ancient_assemble` uses (5, 2): host/evalue.cpp
+bool cdm_gapped_costs_known(int gapOpen, int gapExtend);
+double cdm_evalue_gapped_host(double rawScore, double qLen, uint64_t dbResidues);
+int cdm_bit_score_gapped_host(double rawScore);
 // smallest raw score whose E-value is <= thr for a query of that length (monotone in the score); INT_MAX if none up to 2*maxLen
 void cdm_min_score_table(double evalThr, uint64_t dbResidues, uint32_t maxLen, std::vector<int32_t> &table);

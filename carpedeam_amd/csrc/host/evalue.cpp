@@ -70,3 +70,54 @@ void cdm_min_score_table(double evalThr, uint64_t dbResidues, uint32_t maxLen, s
         table[L] = lo;
     }
 }
+
+// ---- gapped alignments (`align`, lib/mmseqs/src/alignment/Alignment.cpp:273: EvalueComputation(dbSize, m, gapOpen, gapExtend)).  For
+// nucleotide.out with --gap-open 5 --gap-extend 2 (what `ancient_assemble` hands its linclust, GuidedNuclassembler.cpp) the reference
+// has no tabulated parameters (EvalueComputation.h:61-82 lists 7 / 1 only) and lets ALP estimate them by its importance-sampling
+// simulation (initGapped, tolerances 0.01 / 0.05, seed 42): the twelve Gumbel parameters and the three thresholds below are that
+// simulation's result, taken hex-exact from the reference's object code (oracle/ref_driver.cpp `probe alp <matrix> 5 2`, fixture
+// tests/golden/functions/alp_gapped_5_2.txt) - the simulation itself is not restated.  area() is ALP's finite-size formula with the
+// intercepts b, beta, tau that vanish in the gapless case (sls_pvalues.cpp:366-541, statement order kept: FMA contraction).
+namespace {
+struct Gumbel { double lambda, K, aI, aJ, alphaI, alphaJ, sigma, bI, bJ, betaI, betaJ, tau, viThr, vjThr, cThr; };
+const Gumbel GAPPED_5_2 = {0x1.3de995e742594p-1, 0x1.6837f664724adp-2, 0x1.7d956af2b60d7p-1, 0x1.7d956af2b60d7p-1, 0x1.037654c94bd2fp+0, 0x1.037654c94bd2fp+0,
+                           0x1.00d16215dfda7p+0, -0x1.6ba8cc62c7c8cp-1, -0x1.6ba8cc62c7c8cp-1, -0x1.42e626a2af9bp+1, -0x1.42e626a2af9bp+1, -0x1.306383babbcf8p+1,
+                           0x1.a1dd95922d781p+1, 0x1.a1dd95922d781p+1, 0x1.9d9b5aeaf525cp+1};
+double areaOf(const Gumbel &g, double y, double m, double n) {
+    const double pi = 3.1415926535897932384626433832795;
+    const double constVal = 1 / sqrt(2.0 * pi);
+    double tmp = g.aI * y + g.bI;
+    double mLi = m - tmp;
+    double viY = std::max(g.viThr, g.alphaI * y + g.betaI);
+    double sVi = sqrt(viY);
+    double mF = (sVi == 0.0) ? 1e100 : mLi / sVi;
+    double PmF = normalProb(mF);
+    double EmF = -constVal * exp(-0.5 * mF * mF);
+    double mLiP = mLi * PmF;
+    double sViE = sVi * EmF;
+    double p1 = mLiP - sViE;
+    tmp = g.aJ * y + g.bJ;
+    double nLj = n - tmp;
+    double vjY = std::max(g.vjThr, g.alphaJ * y + g.betaJ);
+    double sVj = sqrt(vjY);
+    double nF = (sVj == 0.0) ? 1e100 : nLj / sVj;
+    double PnF = normalProb(nF);
+    double EnF = -constVal * exp(-0.5 * nF * nF);
+    double nLjP = nLj * PnF;
+    double sVjE = sVj * EnF;
+    double p2 = nLjP - sVjE;
+    double cY = std::max(g.cThr, g.sigma * y + g.tau);
+    double PP = PmF * PnF;
+    double cPP = cY * PP;
+    double p1p2 = p1 * p2;
+    return p1p2 + cPP;
+}
+const double LOGK_GAPPED_5_2 = log(GAPPED_5_2.K);
+}  // namespace
+bool cdm_gapped_costs_known(int gapOpen, int gapExtend) { return gapOpen == 5 && gapExtend == 2; }
+double cdm_evalue_gapped_host(double rawScore, double qLen, uint64_t dbResidues) {
+    const Gumbel &g = GAPPED_5_2;
+    const double epa = g.K * exp(-g.lambda * rawScore);
+    return epa * areaOf(g, rawScore, (double) dbResidues, qLen);
+}
+int cdm_bit_score_gapped_host(double rawScore) { return static_cast<int>(std::fma(GAPPED_5_2.lambda, rawScore, -LOGK_GAPPED_5_2) / log(2.0) + 0.5); }

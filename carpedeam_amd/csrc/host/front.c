@@ -35,7 +35,7 @@
 static const char *const OWNED[] = {"kmermatcher", "rescorediagonal", "ancient_correction", "ancient_read_assemble", "ancient_contig_merge", "cyclecheck",
                                     "createdb", "createhdb", "convert2fasta", "ancient_reads_loop",
                                     /* the host-side modules of linclust's tail and the scripts' file modules (host/cluster.cpp) */
-                                    "clust", "createsubdb", "filterdb", "mergeclusters", "result2repseq", "rmdb", "mvdb", NULL};
+                                    "clust", "createsubdb", "filterdb", "mergeclusters", "result2repseq", "rmdb", "mvdb", "align", NULL};
 
 static void logLine(const char *where, const char *module) {
     const char *p = getenv("CARPEDEAM_DISPATCH_LOG");

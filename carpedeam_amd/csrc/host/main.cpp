@@ -13,6 +13,7 @@
 // reference ("Debug(Debug::ERROR) << ...; EXIT(EXIT_FAILURE)").
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,12 @@ int filterdbModule(const std::string &inPath, const std::string &outPath, const 
 int mergeclustersModule(const std::string &seqPath, const std::string &outPath, const std::vector<std::string> &steps, std::string *err);
 int result2repseqModule(const std::string &seqPath, const std::string &cluPath, const std::string &outPath, std::string *err);
 int rmdbModule(const std::string &db);
+// host/align.cpp: linclust's gapped alignment step on the assembled contigs
+struct AlignParams {
+    float covThr = 0.f, seqIdThr = 0.f; double evalThr = 0.001; int covMode = 0, seqIdMode = 0, alnLenThr = 0; bool wrapped = false, includeIdentity = false;
+    int gapOpen = 5, gapExtend = 2, zdrop = 40; unsigned maxAccept = INT_MAX, maxReject = INT_MAX; size_t maxSeqLen = 65535;
+};
+int alignModule(const std::string &qPath, const std::string &tPath, const std::string &prefPath, const std::string &outPath, const AlignParams &P, std::string *err);
 int mvdbModule(const std::string &src, const std::string &dst, std::string *err);
 
 namespace {
@@ -625,9 +632,35 @@ int clusterModules(const std::string &cmd, Args &a) {
     static const FlagSpec FILTER_FLAGS[] = {{"--filter-file", 'U', 0, 0}, {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0}, {"--compressed", 'V', "0", "compressed DBs are not implemented"},
                                             {"--filter-column", 'V', "1", "only the first column"}, {"--positive-filter", 'V', "1", "only positive filtering"}, {0, 0, 0, 0}};
     static const FlagSpec PLAIN_FLAGS[] = {{"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0}, {"--db-load-mode", 'N', 0, 0}, {"--compressed", 'V', "0", "compressed DBs are not implemented"}, {0, 0, 0, 0}};
+    // align (Parameters.cpp: par.align): what changes the result of a nucleotide, no-backtrace, no-realign run is read; modes this path
+    // does not have are refused
+    static const FlagSpec ALIGN_FLAGS[] = {
+        {"-e", 'U', 0, 0}, {"--min-seq-id", 'U', 0, 0}, {"--min-aln-len", 'U', 0, 0}, {"--seq-id-mode", 'U', 0, 0}, {"-c", 'U', 0, 0}, {"--cov-mode", 'U', 0, 0}, {"--max-seq-len", 'U', 0, 0},
+        {"--max-rejected", 'U', 0, 0}, {"--max-accept", 'U', 0, 0}, {"--wrapped-scoring", 'U', 0, 0}, {"--gap-open", 'U', 0, 0}, {"--gap-extend", 'U', 0, 0}, {"--zdrop", 'U', 0, 0},
+        {"--alignment-mode", 'N', 0, "nucleotide alignments always compute score, coverage and identity (Matcher.cpp:88)"}, {"--comp-bias-corr", 'N', 0, "amino acids only"},
+        {"--add-self-matches", 'N', 0, "query DB == target DB: the identity hit is kept anyway"}, {"--db-load-mode", 'N', 0, 0}, {"--pca", 'N', 0, "profiles only"}, {"--pcb", 'N', 0, "profiles only"},
+        {"--realign-score-bias", 'N', 0, "no realignment"}, {"--realign-max-seqs", 'N', 0, "no realignment"}, {"--threads", 'N', 0, 0}, {"-v", 'N', 0, 0},
+        {"-a", 'V', "0", "no backtrace output"}, {"--alignment-output-mode", 'V', "0", "only alignment records"}, {"--alt-ali", 'V', "0", "not supported for nucleotides in the reference either"},
+        {"--realign", 'V', "0", "not implemented"}, {"--score-bias", 'V', "0", "not implemented"}, {"--sub-mat", 'V', "*nucleotide.out*", "only the nucleotide matrix"},
+        {"--compressed", 'V', "0", "compressed DBs are not implemented"}, {0, 0, 0, 0}};
     std::string err; int rc = 0;
     auto need = [&](size_t n, const char *usage) { if (a.pos.size() < n) die(std::string("Usage: carpedeam ") + usage); };
-    if (cmd == "clust") {
+    auto nuclValue = [&](const char *flag, long dflt) -> long {      // "5" or "nucl:5,aa:11"
+        if (!a.flag.count(flag)) return dflt;
+        const std::string &v = a.flag[flag];
+        const size_t at = v.find("nucl:");
+        return strtol(v.c_str() + (at == std::string::npos ? 0 : at + 5), NULL, 10);
+    };
+    if (cmd == "align") {
+        need(4, "align <i:queryDB> <i:targetDB> <i:resultDB> <o:alignmentDB>"); checkFlags("align", a, ALIGN_FLAGS);
+        AlignParams P;
+        P.covThr = fflag(a, "-c", 0.0f); P.seqIdThr = fflag(a, "--min-seq-id", 0.0f); P.evalThr = a.flag.count("-e") ? strtod(a.flag["-e"].c_str(), NULL) : 0.001;
+        P.covMode = (int) iflag(a, "--cov-mode", 0); P.seqIdMode = (int) iflag(a, "--seq-id-mode", 0); P.alnLenThr = (int) iflag(a, "--min-aln-len", 0);
+        P.wrapped = iflag(a, "--wrapped-scoring", 0) != 0;
+        P.gapOpen = (int) nuclValue("--gap-open", 5); P.gapExtend = (int) nuclValue("--gap-extend", 2); P.zdrop = (int) iflag(a, "--zdrop", 40);
+        P.maxAccept = (unsigned) iflag(a, "--max-accept", INT_MAX); P.maxReject = (unsigned) iflag(a, "--max-rejected", INT_MAX); P.maxSeqLen = (size_t) iflag(a, "--max-seq-len", 65535);
+        rc = alignModule(a.pos[0], a.pos[1], a.pos[2], a.pos[3], P, &err);
+    } else if (cmd == "clust") {
         need(3, "clust <i:sequenceDB> <i:resultDB> <o:clusterDB>"); checkFlags("clust", a, CLUST_FLAGS);
         rc = clustModule(a.pos[0], a.pos[1], a.pos[2], (int) iflag(a, "--cluster-mode", 0), &err);
     } else if (cmd == "createsubdb") {
@@ -856,7 +889,7 @@ int main(int argc, char **argv) {
     else if (cmd == "ancient_read_assemble") rc = ancientModule(a, 1);
     else if (cmd == "ancient_contig_merge") rc = ancientModule(a, 2);
     else if (cmd == "ancient_reads_loop") rc = readsLoop(a);
-    else if (cmd == "clust" || cmd == "createsubdb" || cmd == "filterdb" || cmd == "mergeclusters" || cmd == "result2repseq" || cmd == "rmdb" || cmd == "mvdb") rc = clusterModules(cmd, a);
+    else if (cmd == "align" || cmd == "clust" || cmd == "createsubdb" || cmd == "filterdb" || cmd == "mergeclusters" || cmd == "result2repseq" || cmd == "rmdb" || cmd == "mvdb") rc = clusterModules(cmd, a);
     else if (cmd == "createdb") rc = createdb(a);
     else if (cmd == "convert2fasta") rc = convert2fasta(a);
     else if (cmd == "createhdb") rc = createhdb(a);

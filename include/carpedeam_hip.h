@@ -241,6 +241,9 @@ int cdm_alns_download(cdm_ctx *ctx, const cdm_alns *a, uint64_t *offsets, cdm_al
 void cdm_alns_free(cdm_alns *a);
 /* host helpers for the text codec of the alignment DB: E-value, bit score (EvalueComputation.h:18-40 over ALP) */
 double cdm_evalue(double raw_score, double query_len, uint64_t db_residues);
+/* E-value and bit score of a GAPPED nucleotide alignment (the `align` step of linclust; Alignment.cpp:273: EvalueComputation with gap
+ * costs): implemented for --gap-open 5 --gap-extend 2, whose Gumbel parameters are ALP's estimate taken from the reference's object code */
+int cdm_gapped_evalue(int gap_open, int gap_extend, double raw_score, double query_len, uint64_t db_residues, double *evalue, int *bit_score);
 int cdm_bit_score(double raw_score);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -203,10 +203,16 @@ static int probeAlp(int argc, const char **argv) {
         for (int j = 0; j < subMat.alphabetSize; j++) tmpMat[i][j] = subMat.subMatrix[i][j];
     }
     Sls::AlignmentEvaluer ev;
+    // probe alp <matrix> <gapOpen> <gapExtend>: the GAPPED parameters, obtained exactly the way EvalueComputation::init does for gap
+    // costs it has no table entry for (M/alignment/EvalueComputation.h:96-110: tolerances 0.01 / 0.05, 60 s, 500 MB, seed 42)
+    if (argc >= 3) ev.initGapped(subMat.alphabetSize - 1, (const long *const *) tmpMat, subMat.pBack, subMat.pBack, atoi(argv[1]), atoi(argv[2]), atoi(argv[1]), atoi(argv[2]),
+                                 false, 0.01, 0.05, 60.0, 500, 42);
+    else
     ev.initGapless(subMat.alphabetSize - 1, (const long *const *) tmpMat, subMat.pBack, subMat.pBack, 60.0);
     const Sls::ALP_set_of_parameters &p = ev.parameters();
     printf("lambda %a\nK %a\na_I %a\na_J %a\nalpha_I %a\nalpha_J %a\nsigma %a\nb_I %a\nb_J %a\nbeta_I %a\nbeta_J %a\ntau %a\n",
            p.lambda, p.K, p.a_I, p.a_J, p.alpha_I, p.alpha_J, p.sigma, p.b_I, p.b_J, p.beta_I, p.beta_J, p.tau);
+    printf("vi_y_thr %a\nvj_y_thr %a\nc_y_thr %a\n", p.vi_y_thr, p.vj_y_thr, p.c_y_thr);
     printf("matrix");
     for (int i = 0; i < subMat.alphabetSize; i++) for (int j = 0; j < subMat.alphabetSize; j++) printf(" %d", (int) subMat.subMatrix[i][j]);
     printf("\npBack");

@@ -20,10 +20,10 @@ REF_MODULES = os.path.join(ROOT, "oracle", "_ref", "carpedeam_ref")
 REF_FULL = os.path.join(ROOT, "oracle", "_ref", "carpedeam_full")
 EXAMPLE = os.path.join(ROOT, "tests", "golden", "example")
 OWNED = ["kmermatcher", "rescorediagonal", "ancient_correction", "ancient_read_assemble", "ancient_contig_merge", "cyclecheck", "createdb", "createhdb",
-         "convert2fasta", "clust", "createsubdb", "filterdb", "mergeclusters", "result2repseq", "rmdb", "mvdb"]
-HOST_ONLY = ["clust", "createsubdb", "filterdb", "mergeclusters", "result2repseq", "rmdb", "mvdb"]      # csrc/host/cluster.cpp: no device needed
-# what is left on the reference binary: its workflow drivers (they write and run the scripts) and linclust's gapped aligner
-ON_REFERENCE = {"ancient_assemble": 1, "nuclassemble": 1, "linclust": 1, "align": 1}
+         "convert2fasta", "clust", "createsubdb", "filterdb", "mergeclusters", "result2repseq", "rmdb", "mvdb", "align"]
+HOST_ONLY = ["clust", "createsubdb", "filterdb", "mergeclusters", "result2repseq", "rmdb", "mvdb", "align"]      # csrc/host/cluster.cpp: no device needed
+# what is left on the reference binary: its three workflow drivers (they parse the workflow's flags, write the shell scripts and run them)
+ON_REFERENCE = {"ancient_assemble": 1, "nuclassemble": 1, "linclust": 1}
 
 
 def fasta_records(path):
@@ -62,7 +62,7 @@ def check_routing(calls, fallbacks):
     assert gpu["kmermatcher"] == 11                            # 10 of the loop + linclust's
     # linclust's tail (linclust.sh:33-87, guidedNuclAssemble.sh:190-195) and the scripts' housekeeping
     assert gpu["clust"] == 2 and gpu["createsubdb"] == 3 and gpu["filterdb"] == 1 and gpu["mergeclusters"] == 1 and gpu["result2repseq"] == 1
-    assert gpu["rmdb"] > 30 and gpu["mvdb"] == 1
+    assert gpu["rmdb"] > 30 and gpu["mvdb"] == 1 and gpu["align"] == 1
     # (a module call the device path refuses - status 77 before any work - is REFUSED by the front end, never handed to the reference,
     # unless CARPEDEAM_ALLOW_REF_FALLBACK=1: none in this workflow - linclust's Hamming-distance pre-clustering pass, linclust.sh:27-31,
     # is a mode of the device module)
