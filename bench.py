@@ -78,7 +78,17 @@ def module_walls(n_reads, L, seed, threads):
             subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
     gpu_bin = os.path.join(ROOT, "carpedeam_amd", "carpedeam_mi355x")
     out = {}
-    with tempfile.TemporaryDirectory() as d:
+    # the DB files of BOTH legs live on the same file system: RAM-backed (/dev/shm) where the box has one with room - the scratch a
+    # deployment gives MMseqs2-style tools -, else the default temporary directory; the JSON line says which
+    scratch = None
+    try:
+        st = os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize > 40 * n_reads * L + (8 << 30) and not os.environ.get("CDM_BENCH_TMPDIR"):
+            scratch = "/dev/shm"
+    except OSError:
+        pass
+    scratch = os.environ.get("CDM_BENCH_TMPDIR", scratch)
+    with tempfile.TemporaryDirectory(dir=scratch) as d:
         p = lambda s: os.path.join(d, s)
         ctx = capi.Ctx(0)
         synth.write_fastq_device(ctx, n_reads, L, p("reads.fq"), seed)
@@ -102,7 +112,8 @@ def module_walls(n_reads, L, seed, threads):
         r = subprocess.run([gpu_bin, "ancient_reads_loop", p("reads"), p("loop_out")] + dmg + ["--num-iter-reads-only", "1"], capture_output=True, text=True)
         loop_s = time.perf_counter() - t0 if r.returncode == 0 else None
     fmt = lambda t: ", ".join("%s %.2f" % kv for kv in t.items())
-    sample = "%d synthetic %d bp dhigh reads (seed %d, 20x coverage), four modules on DB files incl. DB read/parse/write" % (n_reads, L, seed)
+    sample = "%d synthetic %d bp dhigh reads (seed %d, 20x coverage), four modules on DB files (in %s) incl. DB read/parse/write" % (
+        n_reads, L, seed, (scratch + ", RAM-backed") if scratch == "/dev/shm" else (scratch or tempfile.gettempdir()))
     cpu = {"value": n_reads * L / sum(out["cpu"].values()), "unit": "corrected bases/s", "cores": threads, "kind": kind,
            "sample": sample + ", %d threads; stage s: %s" % (threads, fmt(out["cpu"])),
            "ancient_correction_only_value": n_reads * L / out["cpu"]["ancient_correction"]}
@@ -397,6 +408,13 @@ def main():
         if gathered is not None:
             line["config"]["allgather_contigs"] = gathered
         if not args.no_cpu_baseline and world == 1:
+            # the module legs start their own processes on this device: everything this process holds there goes first (sequences,
+            # results, the library's cache of device blocks, torch's), so that they meet the device a deployment's module meets
+            import gc
+            asm = db = pre = None
+            ctx = None
+            gc.collect()
+            torch.cuda.empty_cache()
             try:
                 # the pool gives a one-GPU job 16 host cores; the reference's kmermatcher slows down when oversubscribed
                 cpu, gpu = module_walls(args.cpu_reads, L, args.seed, min(os.cpu_count() or 1, int(os.environ.get("CDM_CPU_THREADS", 16))))
