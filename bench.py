@@ -107,6 +107,8 @@ def module_walls(n_reads, L, seed, threads):
                 if r.returncode != 0:
                     raise RuntimeError("%s module %s failed: %s" % (label, name, r.stderr[-400:]))
                 times[name] = time.perf_counter() - t0
+                if os.environ.get("CDM_TIMING") and label == "gpu":      # where a module's wall time goes (its own laps), on this process's stderr
+                    sys.stderr.write("== %s %.3f s\n%s" % (name, times[name], r.stderr))
             out[label] = times
         t0 = time.perf_counter()
         r = subprocess.run([gpu_bin, "ancient_reads_loop", p("reads"), p("loop_out")] + dmg + ["--num-iter-reads-only", "1"], capture_output=True, text=True)

@@ -152,13 +152,55 @@ extern "C" int cdm_comm_world(const cdm_comm *c) { return c->world; }
 namespace {
 constexpr int STALE_LEN = CDM_STALE_MAX + 5;       // [0] count, [1] sequence id, [2..63] positions, [66] = the scan reached the end of the range
 struct PartGuard { cdm_kpart *p = nullptr; ~PartGuard() { if (p) cdm_kpart_free(p); } };
+// kmermatcher's first half for rank R's k-mer range, the extraction split by reads: every rank extracts its block of the sequences,
+// all-to-alls (keys, values, and the whole-sequence hash tuples to the last rank) carry the tuples to the ranks of their k-mer
+// ranges.  CDM_DIST_EXTRACT=all: every rank extracts every sequence and keeps its range (cdm_kmermatch_part; the A/B and what
+// shard.py does).
+int firstHalf(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_kpart **out) {
+    const int W = cm->world, R = cm->rank;
+    const cdm_comm_ops &op = cm->ops;
+    const char *how = cdmGetenv("CDM_DIST_EXTRACT");
+    if (W == 1 || (how && !strcmp(how, "all"))) return cdm_kmermatch_part(ctx, db, par, R, W, out);
+    if (int rc = cdm_kmermatch_split_begin(ctx, db, par, R, W, out)) return rc;
+    std::vector<uint64_t> off((size_t) W + 1);
+    const void *keys, *vals, *hkeys, *hvals; int vb = 0; uint64_t nHash = 0;
+    if (int rc = cdm_kpart_outgoing(*out, off.data(), &keys, &vals, &vb, &hkeys, &hvals, &nHash)) return rc;
+    const size_t row = (size_t) W + 1;                    // tuples for every rank, then the hash tuples
+    std::vector<uint64_t> counts(row), matrix(row * W);
+    for (int p = 0; p < W; p++) counts[p] = off[p + 1] - off[p];
+    counts[W] = nHash;
+    if (int rc = op.all_gather_host(op.user, counts.data(), matrix.data(), row * 8)) return rc;
+    std::vector<uint64_t> recvCnt((size_t) W + 1, 0), hashCnt((size_t) W + 1, 0);
+    bool below = false;
+    for (int p = 0; p < W; p++) {
+        recvCnt[p + 1] = recvCnt[p] + matrix[p * row + R];
+        hashCnt[p + 1] = hashCnt[p] + (R == W - 1 ? matrix[p * row + W] : 0);
+        for (int q = 0; q < R; q++) below = below || matrix[p * row + q] != 0;
+    }
+    const uint64_t m = recvCnt[W], h = hashCnt[W];
+    DevBuf<uint64_t> rk, rhk; DevBuf<char> rv, rhv;
+    if (!rk.alloc(m) || !rv.alloc(m * vb) || !rhk.alloc(h) || !rhv.alloc(h * vb)) { cdm_set_error("cdm_kmermatch_dist: out of device memory for %llu received k-mer tuples", (unsigned long long) (m + h)); return CDM_ERR_HIP; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    std::vector<uint64_t> so(row), ro(row);
+    auto exchange = [&](const void *send, void *recv, const std::vector<uint64_t> &sOff, const std::vector<uint64_t> &rOff, uint64_t width) -> int {
+        for (int p = 0; p <= W; p++) { so[p] = sOff[p] * width; ro[p] = rOff[p] * width; }
+        return op.all_to_all_dev(op.user, send, so.data(), recv, ro.data(), ctx->stream);
+    };
+    if (int rc = exchange(keys, rk.p, off, recvCnt, 8)) return rc;
+    if (int rc = exchange(vals, rv.p, off, recvCnt, (uint64_t) vb)) return rc;
+    std::vector<uint64_t> hashOff((size_t) W + 1, 0); hashOff[W] = nHash;       // everything to the last rank
+    if (int rc = exchange(hkeys, rhk.p, hashOff, hashCnt, 8)) return rc;
+    if (int rc = exchange(hvals, rhv.p, hashOff, hashCnt, (uint64_t) vb)) return rc;
+    CDM_HIP(hipStreamSynchronize(ctx->stream));
+    return cdm_kmermatch_split_finish(ctx, *out, rk.p, rv.p, m, rhk.p, rhv.p, h, below ? 1 : 0);
+}
 }  // namespace
 extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
     if (!ctx || !cm || !db || !par || !out) { cdm_set_error("cdm_kmermatch_dist: invalid argument"); return CDM_ERR_INVALID; }
     const int W = cm->world, R = cm->rank;
     const cdm_comm_ops &op = cm->ops;
     PartGuard g;
-    if (int rc = cdm_kmermatch_part(ctx, db, par, R, W, &g.p)) return rc;
+    if (int rc = firstHalf(ctx, cm, db, par, &g.p)) return rc;
     uint64_t info[4];
     cdm_kpart_info(g.p, info);
     // ---- the left-over list of the reference's last per-target scan: it starts at k-mer-order index J = number of ALL kept group keys

@@ -158,7 +158,16 @@ template <typename LY> struct ExtractArgs {
     // empty; the whole-sequence hash tuples of region 2 belong to the last range.  belowFlag is set when a real tuple lies
     // below the range (the array's very first run is then not in it).  Single-GPU: kLo = 0, kHi = ~0, lastPart = 1.
     uint64_t kLo, kHi; int lastPart; unsigned int *belowFlag;
+    // The other split of a multi-GPU run (round 4, cdm_kmermatch_split_*): a rank extracts the k-mers of ITS sequences only - the
+    // sequences with order ranks [ordLo, ordHi) in the (length desc, id asc) slot order, all k-mer values - and the tuples then travel
+    // to the owner of their k-mer range.  ordHi = 0: every sequence (one device, and the k-mer-range split above).
+    uint32_t ordLo = 0, ordHi = 0;
 };
+template <typename LY> __device__ __forceinline__ bool ownedSeq(const ExtractArgs<LY> &a, uint32_t seq) {
+    if (a.ordHi == 0) return true;
+    const uint32_t r = a.rankOf[seq];
+    return r >= a.ordLo && r < a.ordHi;
+}
 template <typename LY> __device__ __forceinline__ bool inRange(const ExtractArgs<LY> &a, uint64_t km) { return km >= a.kLo && km < a.kHi; }
 template <typename LY> __device__ __forceinline__ void noteBelow(const ExtractArgs<LY> &a, bool below) {       // whole wave
     if (__ballot(below) != 0ull && (threadIdx.x & 63) == 0 && a.belowFlag[0] == 0u) a.belowFlag[0] = 1u;
@@ -166,7 +175,7 @@ template <typename LY> __device__ __forceinline__ void noteBelow(const ExtractAr
 template <typename LY>
 __device__ __forceinline__ void putSeqHashTuple(const ExtractArgs<LY> &a, uint32_t seq, uint32_t L, uint64_t base, uint64_t h) {
     const uint64_t key = xxh64_u64(h, a.seed);
-    const uint64_t hslot = a.hashBase + a.rankOf[seq];
+    const uint64_t hslot = a.hashBase + (a.rankOf[seq] - a.ordLo);
     const bool small = (key & ~BIT63) < (1ull << (2 * a.k));
     if (small) {
         if (inRange(a, key & ~BIT63)) LY::storeHash(a.keys, a.vals, base, key, seq, L, a.geom); else LY::storeEmpty(a.keys, a.vals, base);
@@ -202,7 +211,7 @@ __device__ __forceinline__ uint64_t groupsReversed(uint64_t x, int k) {
 template <typename LY>
 __global__ __launch_bounds__(256) void k_seq_hash(ExtractArgs<LY> a) {
     const uint32_t seq = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seq >= a.n) return;
+    if (seq >= a.n || !ownedSeq(a, seq)) return;
     const uint32_t L = a.len[seq], w0 = a.woff[seq];
     uint64_t h = 0;
     if (a.hasN[seq]) {
@@ -234,6 +243,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
     const uint32_t nItems = a.listCount ? *a.listCount : a.n;
     for (uint32_t item = blockIdx.x * FAST_WAVES + wave; item < nItems; item += gridDim.x * FAST_WAVES) {
         const uint32_t seq = a.listCount ? a.list[item] : item;
+        if (!a.listCount && !ownedSeq(a, seq)) continue;          // (wave-uniform)
         const uint32_t L = a.len[seq], w0 = a.woff[seq];
         const bool hasN = a.hasN[seq] != 0;
         const uint32_t nPos = (L >= (uint32_t) k) ? (L - k + 1) : 0;
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_pair(ExtractArgs<LY
     const uint32_t nPairs = (a.n + 1) / 2;
     for (uint32_t pr = blockIdx.x * FAST_WAVES + wave; pr < nPairs; pr += gridDim.x * FAST_WAVES) {
         const uint32_t seq = 2 * pr + (uint32_t) half;
-        const bool have = seq < a.n;
+        const bool have = seq < a.n && ownedSeq(a, seq);
         uint32_t L = 0, w0 = 0; bool hasN = false; uint64_t base = 0;
         if (have) { L = a.len[seq]; w0 = a.woff[seq]; hasN = a.hasN[seq] != 0; base = a.slotOff[seq]; }
         const uint32_t nPos = (L >= (uint32_t) k) ? (L - k + 1) : 0;
@@ -1133,6 +1143,37 @@ __global__ void k_slot_scatter(const uint32_t *__restrict__ order, const unsigne
     if (r < n) { slotOff[order[r]] = ordOff[r]; rankOf[order[r]] = r; }
     if (r == n) slotOff[n] = ordOff[n];
 }
+// split by reads: only the sequences with order ranks [lo, hi) get slots
+__global__ void k_slot_mask(unsigned long long *__restrict__ slots, uint32_t n, uint32_t lo, uint32_t hi) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && (r < lo || r >= hi)) slots[r] = 0;
+}
+// k-mer range a tuple belongs to: the largest p with (2^(2k) p) / parts <= k-mer (the ranges of ExtractArgs::kLo / kHi)
+template <typename LY>
+__global__ void k_dest_range(const uint64_t *__restrict__ keys, uint64_t m, TupleGeom geom, int kbits, uint32_t parts, uint32_t *__restrict__ dest, uint32_t *__restrict__ idx) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t km = LY::kmerOf(keys[i], 0, geom);
+    const unsigned __int128 space = (unsigned __int128) 1 << kbits;
+    uint32_t p = (uint32_t) (((unsigned __int128) km * parts) >> kbits);
+    if (p >= parts) p = parts - 1;
+    while (p + 1 < parts && (uint64_t) (space * (p + 1) / parts) <= km) p++;
+    while (p > 0 && (uint64_t) (space * p / parts) > km) p--;
+    dest[i] = p; idx[i] = (uint32_t) i;
+}
+template <typename V>
+__global__ void k_gather_pairs(const uint32_t *__restrict__ idx, uint64_t m, const uint64_t *__restrict__ kin, const V *__restrict__ vin, uint64_t *__restrict__ kout, V *__restrict__ vout) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) { const uint32_t j = idx[i]; kout[i] = kin[j]; vout[i] = vin[j]; }
+}
+// first index of the sorted destinations that is >= p, for p = 0 .. parts
+__global__ void k_dest_bounds(const uint32_t *__restrict__ dest, uint64_t m, uint32_t parts, unsigned long long *__restrict__ out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > parts) return;
+    uint64_t lo = 0, hi = m;
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (dest[mid] < p) lo = mid + 1; else hi = mid; }
+    out[p] = lo;
+}
 __global__ __launch_bounds__(256) void k_reduce_stats(const unsigned long long *__restrict__ stripes, unsigned long long *__restrict__ out) {
     unsigned long long c = 0;
     for (int i = threadIdx.x; i < STAT_STRIPES; i += 256) c += stripes[i];
@@ -1235,6 +1276,13 @@ struct KmerJobBase {
     virtual int gatherByRep() = 0;
     virtual int sortFrom(const uint64_t *devKeys, uint64_t nKeys, uint32_t *head, uint64_t info[2]) = 0;
     virtual int voteWith(const uint32_t *cont, const uint32_t *staleIn, cdm_hits **out) = 0;
+    // the split by reads (cdm_kmermatch_split_*): splitBegin = extraction of the owned sequences + the tuples ordered by destination
+    // range; splitFinish = sort 1 + grouping on what arrived (region 1: m tuples, region 2: h whole-sequence hash tuples)
+    virtual int splitBegin() = 0;
+    virtual int splitFinish(const void *keys, const void *vals, uint64_t m, const void *hkeys, const void *hvals, uint64_t h, bool below) = 0;
+    bool split = false;
+    std::vector<unsigned long long> sendOff;        // [nparts + 1] tuples per destination range, prefix sums
+    const void *sendKeys = nullptr, *sendVals = nullptr, *sendHashKeys = nullptr, *sendHashVals = nullptr; unsigned long long sendHash = 0; int valBytes = 0;
     cdm_ctx *ctx = nullptr; const cdm_seqdb *db = nullptr; cdm_kmer_params parCopy; const cdm_kmer_params *par = nullptr;
     int part = 0, nparts = 1;           // this rank's k-mer range (nparts == 1: everything)
     unsigned long long live = 0, nKept = 0, regionTwo = 0;      // real tuples of region 1 in this range; kept group tuples; real tuples of region 2
@@ -1248,6 +1296,9 @@ struct KmerJob : KmerJobBase {
     hipStream_t s = nullptr; uint32_t n = 0; int k = 0;
     uint32_t idBits = 0, diagBits = 0; int diagBias = 0; const char *sortEnv = nullptr; bool lsdOnly = false;
     bool wide = false;                        // group keys without the representative (runsort.h RunArgs; packGroupKey)
+    uint64_t r2Slots = 0;                     // size of region 2: n (one whole-sequence hash slot per sequence), or what arrived (split by reads)
+    uint32_t ordLo = 0, ordHi = 0;            // split by reads: the order ranks of the sequences this rank extracts
+    DevBuf<uint64_t> splitK; DevBuf<V> splitV; DevBuf<uint32_t> splitD0, splitD1, splitI0, splitI1;
     DevBuf<unsigned long long> counters;      // scratch counters ([2] = number of kept group tuples)
     DevBuf<unsigned int> cls;                 // slow-path list sizes
     DevBuf<uint32_t> listShort, listLong, listSingle, listHuge;
@@ -1303,13 +1354,15 @@ int phaseA() override {
         if (int rc = rx::sortPairs<uint32_t, uint32_t>(s, ctx->cuCount, lk0.p, lk1.p, lv0.p, lv1.p, (uint64_t) n, 0, (int) lenBits, lenFirst)) return rc;
         DoubleBuf<uint32_t> lk(lenFirst ? lk0.p : lk1.p, lenFirst ? lk1.p : lk0.p), lv(lenFirst ? lv0.p : lv1.p, lenFirst ? lv1.p : lv0.p);
         hipLaunchKernelGGL(k_slot_counts, dim3((n + 256) / 256), dim3(256), 0, s, db->len, lv.current(), n, k, slots.p);
+        if (split) hipLaunchKernelGGL(k_slot_mask, dim3((n + 255) / 256), dim3(256), 0, s, slots.p, n, ordLo, ordHi);
         if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, st, slots.p, ordOff.p, (size_t) n + 1)) return rc;
         hipLaunchKernelGGL(k_slot_scatter, dim3((n + 256) / 256), dim3(256), 0, s, lv.current(), ordOff.p, n, slotOff.p, rankOf.p);
         hipMemcpyAsync(&capacity, ordOff.p + n, 8, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: slot layout failed"); return CDM_ERR_HIP; }
     }
     kmerSlots = capacity;                            // region 1: k-mer slots (+ slot 0 per sequence)
-    capacity += n;                                   // region 2: whole-sequence hash tuples
+    r2Slots = split ? (uint64_t) (ordHi - ordLo) : (uint64_t) n;
+    capacity += r2Slots;                             // region 2: whole-sequence hash tuples
     nTuples = capacity;
 
     if (!k0.alloc(capacity) || !k1.alloc(capacity) || !v0.alloc(capacity) || !v1.alloc(capacity)) {
@@ -1327,6 +1380,7 @@ int phaseA() override {
         ea.kLo = (uint64_t) (space * (unsigned) part / (unsigned) nparts);
         ea.kHi = (part == nparts - 1) ? ~0ull : (uint64_t) (space * (unsigned) (part + 1) / (unsigned) nparts);
         ea.lastPart = (part == nparts - 1) ? 1 : 0; ea.belowFlag = cls.p + 5;
+        if (split) { ea.kLo = 0; ea.kHi = ~0ull; ea.lastPart = 1; ea.ordLo = ordLo; ea.ordHi = ordHi; }     // every k-mer of the owned sequences
     }
     hipEventRecord(ctx->ev0, s);
     hipLaunchKernelGGL(k_seq_hash<LY>, dim3((n + 255) / 256), dim3(256), 0, s, ea);
@@ -1363,6 +1417,60 @@ int phaseA() override {
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_kmermatch: extraction (general path) failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     anyBelow = belowHost != 0;
     hipEventElapsedTime(&ctx->lastMs[3], ctx->ev0, ctx->ev1);
+    if (split) return splitPartition();
+    return sortAndGroup();
+}
+// Split by reads, second step: the real tuples of the owned sequences (compacted, still in slot order) ordered by the k-mer range
+// they belong to - a stable one-digit radix sort of (range, index) and a gather -, and the real whole-sequence hash tuples, which all go
+// to the last range.  What a rank receives, concatenated in rank order, is then in the global slot order: ranks own consecutive blocks
+// of that order.
+int splitPartition() {
+    DevBuf<unsigned long long> cnt, bounds;
+    if (!cnt.alloc(2) || !bounds.alloc((size_t) nparts + 2)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    unsigned long long m = 0, h = 0;
+    if (kmerSlots) { if (int rc = rx::compactPairs<uint64_t, V>(s, k0.p, v0.p, (uint64_t) kmerSlots, k1.p, v1.p, cnt.p)) return rc; hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, s); }
+    if (r2Slots) { if (int rc = rx::compactPairs<uint64_t, V>(s, k0.p + kmerSlots, v0.p + kmerSlots, (uint64_t) r2Slots, k1.p + kmerSlots, v1.p + kmerSlots, cnt.p + 1)) return rc; hipMemcpyAsync(&h, cnt.p + 1, 8, hipMemcpyDeviceToHost, s); }
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: compaction failed"); return CDM_ERR_HIP; }
+    if (m >= 0xFFFFFFFFull) { cdm_set_error("cdm_kmermatch: more than 2^32 tuples on one rank of the split by reads"); return CDM_ERR_UNSUPPORTED; }
+    sendOff.assign((size_t) nparts + 1, 0);
+    if (!splitK.alloc(m) || !splitV.alloc(m) || !splitD0.alloc(m) || !splitD1.alloc(m) || !splitI0.alloc(m) || !splitI1.alloc(m)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    if (m) {
+        TupleGeom g1 = geom; g1.kmerSlots = ~0ull;              // (every compacted tuple is a region-1 tuple)
+        hipLaunchKernelGGL(k_dest_range<LY>, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, (const uint64_t *) k1.p, (uint64_t) m, g1, 2 * k, (uint32_t) nparts, splitD0.p, splitI0.p);
+        bool first = true;
+        if (int rc = rx::sortPairs<uint32_t, uint32_t>(s, ctx->cuCount, splitD0.p, splitD1.p, splitI0.p, splitI1.p, (uint64_t) m, 0, (int) bitsFor((uint64_t) nparts), first)) return rc;
+        const uint32_t *dS = first ? splitD0.p : splitD1.p, *iS = first ? splitI0.p : splitI1.p;
+        hipLaunchKernelGGL(k_gather_pairs<V>, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, iS, (uint64_t) m, (const uint64_t *) k1.p, (const V *) v1.p, splitK.p, splitV.p);
+        hipLaunchKernelGGL(k_dest_bounds, dim3(1), dim3(256), 0, s, dS, (uint64_t) m, (uint32_t) nparts, bounds.p);
+        hipMemcpyAsync(sendOff.data(), bounds.p, ((size_t) nparts + 1) * 8, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: ordering the tuples by k-mer range failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    }
+    sendKeys = splitK.p; sendVals = splitV.p; valBytes = (int) sizeof(V);
+    sendHashKeys = k1.p + kmerSlots; sendHashVals = v1.p + kmerSlots; sendHash = h;
+    return CDM_OK;
+}
+int splitBegin() override {
+    split = true;
+    ordLo = (uint32_t) ((uint64_t) db->n * (unsigned) part / (unsigned) nparts); ordHi = (uint32_t) ((uint64_t) db->n * (unsigned) (part + 1) / (unsigned) nparts);
+    if (nparts > 255) { cdm_set_error("cdm_kmermatch: the split by reads takes up to 255 ranks"); return CDM_ERR_UNSUPPORTED; }
+    return phaseA();       // (a rank without sequences of its own - fewer sequences than ranks - goes through with empty buffers)
+}
+int splitFinish(const void *keysIn, const void *valsIn, uint64_t m, const void *hkeys, const void *hvals, uint64_t h, bool below) override {
+    // the extraction's buffers go, the received tuples become the two regions of the tuple array
+    splitD0.free(); splitD1.free(); splitI0.free(); splitI1.free(); slots.free(); slotOff.free(); rankOf.free();
+    listShort.free(); listLong.free(); listSingle.free(); listHuge.free();
+    splitK.free(); splitV.free(); k0.free(); k1.free(); v0.free(); v1.free();        // (sent: the exchange is over)
+    DevBuf<uint64_t> nk0, nk1; DevBuf<V> nv0, nv1;
+    const uint64_t tot = m + h;
+    if (!nk0.alloc(tot) || !nk1.alloc(tot) || !nv0.alloc(tot) || !nv1.alloc(tot)) { cdm_set_error("cdm_kmermatch: out of device memory for %llu received k-mer tuples", (unsigned long long) tot); return CDM_ERR_HIP; }
+    if (m) { hipMemcpyAsync(nk0.p, keysIn, m * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(nv0.p, valsIn, m * sizeof(V), hipMemcpyDeviceToDevice, s); }
+    if (h) { hipMemcpyAsync(nk0.p + m, hkeys, h * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(nv0.p + m, hvals, h * sizeof(V), hipMemcpyDeviceToDevice, s); }
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: taking over the received tuples failed"); return CDM_ERR_HIP; }
+    k0.p = nk0.release(); k1.p = nk1.release(); v0.p = nv0.release(); v1.p = nv1.release();
+    kmerSlots = m; r2Slots = h; nTuples = tot; geom.kmerSlots = m; anyBelow = below;
+    return sortAndGroup();
+}
+int sortAndGroup() {
 
     // ---- sort 1: stable LSD radix sort by k-mer.  Region 1 (k-mer slots) on the 2k key bits, region 2 (whole-sequence hashes)
     // on 63 bits into the same physical buffers; the strand bit 63 rides along outside the sorted bit range.
@@ -1375,7 +1483,7 @@ int phaseA() override {
     lowBits = lsdOnly ? 0 : std::max(0, 2 * k + 1 - 27);
     const int sortTop = lowBits ? 2 * k + 1 : 2 * k;
     hipEventRecord(ctx->ev0, s);
-    if (nparts > 1 && kmerSlots && !lsdOnly) {
+    if (nparts > 1 && kmerSlots && !lsdOnly && !split) {      // (split by reads: what arrived has no empty slots)
         // a k-mer RANGE: most slots are empty.  The real tuples are compacted (stable) into the other buffers first, so that the
         // passes run over this rank's share only; behind them the result holds empty slots again, as if all had been sorted.
         DevBuf<unsigned long long> cnt;
@@ -1404,9 +1512,9 @@ int phaseA() override {
         V *vOut = vals.current() + kmerSlots, *vIn = v0.p + kmerSlots;
         {
             bool inFirst = true;
-            if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, kIn, k1.p + kmerSlots, vIn, v1.p + kmerSlots, (uint64_t) n, 0, 63, inFirst)) return rc;
+            if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, kIn, k1.p + kmerSlots, vIn, v1.p + kmerSlots, (uint64_t) r2Slots, 0, 63, inFirst)) return rc;
             uint64_t *kRes = inFirst ? kIn : k1.p + kmerSlots; V *vRes = inFirst ? vIn : v1.p + kmerSlots;
-            if (kRes != kOut) { hipMemcpyAsync(kOut, kRes, (size_t) n * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(vOut, vRes, (size_t) n * sizeof(V), hipMemcpyDeviceToDevice, s); }
+            if (kRes != kOut && r2Slots) { hipMemcpyAsync(kOut, kRes, (size_t) r2Slots * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(vOut, vRes, (size_t) r2Slots * sizeof(V), hipMemcpyDeviceToDevice, s); }
         }
     }
     hipEventRecord(ctx->ev3, s);
@@ -1415,7 +1523,8 @@ int phaseA() override {
     ga.geom = geom;
     ga.keys = keys.current(); ga.vals = vals.current(); ga.n = nTuples; ga.onlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode;
     ga.covThr = par->cov_thr; ga.idBits = idBits; ga.diagBits = diagBits; ga.diagBias = diagBias; ga.first = 0; ga.wide = wide ? 1 : 0;
-    ga.firstRunIdx = anyBelow ? ~0ull : 0ull;      // the very first run of the (global) array is in the lowest k-mer range that has tuples
+    ga.firstRunIdx = (anyBelow || (split && kmerSlots == 0)) ? ~0ull : 0ull;      // (split with nothing in region 1: index 0 is a hash tuple, which is never the first run)
+    // the very first run of the (global) array is in the lowest k-mer range that has tuples
     if (!statStripes.alloc(STAT_STRIPES)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipMemsetAsync(statStripes.p, 0, STAT_STRIPES * 8, s);
     ga.stat = statStripes.p;
@@ -1498,8 +1607,8 @@ int phaseA() override {
     }
     hipEventElapsedTime(&msSort1, ctx->ev0, ctx->ev1);
     regionTwo = 0;
-    if (nparts > 1 && part == nparts - 1 && n) {        // real whole-sequence hash tuples (they sort in front of the empty slots of region 2)
-        hipLaunchKernelGGL(k_count_hash_tuples, dim3(1), dim3(1), 0, s, (const uint64_t *) ga.keys + kmerSlots, (uint64_t) n, counters.p + 6);
+    if (nparts > 1 && part == nparts - 1 && r2Slots) {        // real whole-sequence hash tuples (they sort in front of the empty slots of region 2)
+        hipLaunchKernelGGL(k_count_hash_tuples, dim3(1), dim3(1), 0, s, (const uint64_t *) ga.keys + kmerSlots, (uint64_t) r2Slots, counters.p + 6);
         hipMemcpyAsync(&regionTwo, counters.p + 6, 8, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed"); return CDM_ERR_HIP; }
     }
@@ -1865,6 +1974,40 @@ extern "C" int cdm_kmermatch_part(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_k
     if (rc != CDM_OK) { cdm_kpart_free(h); return rc; }
     *out = h;
     return CDM_OK;
+}
+// The split by READS of the first half: every rank extracts the k-mers of its own block of sequences (blocks of the (length desc, id asc)
+// slot order, so that the blocks concatenated in rank order are that order), the tuples go to the rank of their k-mer range, and sort 1 +
+// grouping run there on exactly the tuples cdm_kmermatch_part would have extracted for that range - each sequence is read once per job, not
+// once per rank.
+extern "C" int cdm_kmermatch_split_begin(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int rank, int nranks, cdm_kpart **out) {
+    if (!ctx || !db || !par || !out || nranks < 1 || rank < 0 || rank >= nranks) { cdm_set_error("cdm_kmermatch_split_begin: invalid argument"); return CDM_ERR_INVALID; }
+    if (cdmGetenv("CDM_KMER_SORT") || cdmGetenv("CDM_KMER_SORT2")) { cdm_set_error("cdm_kmermatch_split_begin: the A/B switches CDM_KMER_SORT / CDM_KMER_SORT2 apply to the single-device path only"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    cdm_kpart *h = new cdm_kpart();
+    if (packedLayoutFits(db, par->kmer_size)) h->job = new KmerJob<LayoutPacked>(ctx, db, par);
+    else if (db->maxLen < 65535u) h->job = new KmerJob<LayoutWide>(ctx, db, par);
+    else if (db->maxLen < (1u << 20) - 1u && db->n < (1ull << 24)) h->job = new KmerJob<LayoutLong>(ctx, db, par);
+    else if (db->maxLen < MAX_SEQ_LETTERS) h->job = new KmerJob<LayoutHuge>(ctx, db, par);
+    else { delete h; cdm_set_error("cdm_kmermatch_split_begin: sequences of %u letters or more are not implemented", MAX_SEQ_LETTERS); return CDM_ERR_UNSUPPORTED; }
+    h->job->part = rank; h->job->nparts = nranks; h->nSeq = db->n;
+    h->repShift = bitsFor(db->n) + bitsFor(2ull * db->maxLen + 2) + 1;
+    const int rc = h->job->splitBegin();
+    if (rc != CDM_OK) { cdm_kpart_free(h); return rc; }
+    *out = h;
+    return CDM_OK;
+}
+extern "C" int cdm_kpart_outgoing(const cdm_kpart *h, uint64_t *offsets, const void **keys, const void **vals, int *valBytes, const void **hashKeys, const void **hashVals, uint64_t *nHash) {
+    if (!h || !h->job->split || !offsets || !keys || !vals || !valBytes || !hashKeys || !hashVals || !nHash) { cdm_set_error("cdm_kpart_outgoing: invalid argument"); return CDM_ERR_INVALID; }
+    for (int p = 0; p <= h->job->nparts; p++) offsets[p] = h->job->sendOff[p];
+    *keys = h->job->sendKeys; *vals = h->job->sendVals; *valBytes = h->job->valBytes;
+    *hashKeys = h->job->sendHashKeys; *hashVals = h->job->sendHashVals; *nHash = h->job->sendHash;
+    return CDM_OK;
+}
+extern "C" int cdm_kmermatch_split_finish(cdm_ctx *ctx, cdm_kpart *h, const void *keys, const void *vals, uint64_t m, const void *hashKeys, const void *hashVals, uint64_t nHash, int below) {
+    if (!ctx || !h || !h->job->split || (m && (!keys || !vals)) || (nHash && (!hashKeys || !hashVals))) { cdm_set_error("cdm_kmermatch_split_finish: invalid argument"); return CDM_ERR_INVALID; }
+    if (nHash && h->job->part != h->job->nparts - 1) { cdm_set_error("cdm_kmermatch_split_finish: the whole-sequence hash tuples belong to the last rank"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    return h->job->splitFinish(keys, vals, m, hashKeys, hashVals, nHash, below != 0);
 }
 extern "C" void cdm_kpart_free(cdm_kpart *h) { if (!h) return; delete h->job; delete h; }
 extern "C" int cdm_kpart_info(const cdm_kpart *h, uint64_t info[4]) {

@@ -178,6 +178,17 @@ void cdm_hits_free(cdm_hits *h);
  */
 typedef struct cdm_kpart cdm_kpart;
 int cdm_kmermatch_part(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int part, int nparts, cdm_kpart **out);
+/* The same first half with the extraction split by READS (what cdm_kmermatch_dist does): rank r extracts the k-mers of ITS block of the
+ * sequences only - block r of nranks of the (length descending, id ascending) order fillKmerPositionArray's result is sorted into
+ * (kmermatcher.cpp:391-430) - and orders the tuples by the k-mer range they belong to; cdm_kpart_outgoing names the send buffers
+ * (offsets[p]..offsets[p+1] = the tuples for rank p, keys 8 bytes and values *val_bytes each; the whole-sequence hash tuples all go
+ * to the last rank); cdm_kmermatch_split_finish takes what arrived, CONCATENATED IN RANK ORDER (device buffers; `below` = 1 if any
+ * rank sent a tuple to a range in front of this one), and leaves the handle where cdm_kmermatch_part leaves it. */
+int cdm_kmermatch_split_begin(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int rank, int nranks, cdm_kpart **out);
+int cdm_kpart_outgoing(const cdm_kpart *h, uint64_t *offsets, const void **keys, const void **vals, int *val_bytes,
+                       const void **hash_keys, const void **hash_vals, uint64_t *n_hash);
+int cdm_kmermatch_split_finish(cdm_ctx *ctx, cdm_kpart *h, const void *keys, const void *vals, uint64_t m,
+                               const void *hash_keys, const void *hash_vals, uint64_t n_hash, int below);
 int cdm_kpart_info(const cdm_kpart *h, uint64_t info[4]);
 int cdm_kpart_stale(cdm_ctx *ctx, cdm_kpart *h, uint64_t J, uint32_t out[67]);
 int cdm_kpart_gather(cdm_ctx *ctx, cdm_kpart *h, int nranks, uint64_t *offsets, const void **dev_keys);
