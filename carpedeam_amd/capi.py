@@ -139,6 +139,10 @@ def lib():
         l.cdm_correct.argtypes = [vp, vp, vp, C.POINTER(AncientParams), C.POINTER(vp)]
         l.cdm_extend.argtypes = [vp, vp, vp, C.POINTER(AncientParams), C.POINTER(vp), vp]
         l.cdm_kmermatch_part.argtypes = [vp, vp, C.POINTER(KmerParams), C.c_int, C.c_int, C.POINTER(vp)]
+        if hasattr(l, "cdm_kmermatch_split_begin"):
+            l.cdm_kmermatch_split_begin.argtypes = [vp, vp, C.POINTER(KmerParams), C.c_int, C.c_int, C.POINTER(vp)]
+            l.cdm_kpart_outgoing.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]
+            l.cdm_kmermatch_split_finish.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_int]
         l.cdm_kpart_info.argtypes = [vp, vp]
         l.cdm_kpart_stale.argtypes = [vp, vp, C.c_uint64, vp]
         l.cdm_kpart_gather.argtypes = [vp, vp, C.c_int, vp, C.POINTER(vp)]
@@ -307,6 +311,18 @@ class KPart:
         _check(lib().cdm_kpart_info(self.h, _ptr(a)))
         return {"real": int(a[0]), "kept": int(a[1]), "any_below": bool(a[2]), "n": int(a[3])}
 
+    def outgoing(self, nranks):
+        """after Ctx.kmermatch_split_begin -> (offsets[nranks + 1], keys ptr, values ptr, bytes per value, hash keys ptr, hash values ptr,
+        hash tuples): what this rank sends to the ranks of the k-mer ranges"""
+        off = np.zeros(nranks + 1, np.uint64)
+        k, v, hk, hv = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        vb, nh = C.c_int(), C.c_uint64()
+        _check(lib().cdm_kpart_outgoing(self.h, _ptr(off), C.byref(k), C.byref(v), C.byref(vb), C.byref(hk), C.byref(hv), C.byref(nh)))
+        return off, k.value or 0, v.value or 0, vb.value, hk.value or 0, hv.value or 0, nh.value
+
+    def split_finish(self, keys_ptr, vals_ptr, m, hash_keys_ptr, hash_vals_ptr, n_hash, below):
+        _check(lib().cdm_kmermatch_split_finish(self.ctx.h, self.h, keys_ptr, vals_ptr, int(m), hash_keys_ptr, hash_vals_ptr, int(n_hash), int(bool(below))))
+
     def stale(self, j):
         a = np.zeros(67, np.uint32)
         _check(lib().cdm_kpart_stale(self.ctx.h, self.h, int(j), _ptr(a)))
@@ -416,6 +432,14 @@ class Ctx:
         par = par or KmerParams.reads_default()
         h = C.c_void_p()
         _check(lib().cdm_kmermatch_part(self.h, db.h, C.byref(par), part, nparts, C.byref(h)))
+        return KPart(self, h, db)
+
+    def kmermatch_split_begin(self, db, rank, nranks, par=None):
+        """the same first half with the extraction split by reads: this rank's block of the sequences, the tuples ordered by the k-mer
+        range they go to (KPart.outgoing, then KPart.split_finish on what arrived)"""
+        par = par or KmerParams.reads_default()
+        h = C.c_void_p()
+        _check(lib().cdm_kmermatch_split_begin(self.h, db.h, C.byref(par), rank, nranks, C.byref(h)))
         return KPart(self, h, db)
 
     # ---- containers

@@ -243,8 +243,29 @@ def run_native_ranks(world, fn):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_native_exact_iteration_equals_single_device(dhigh_prefix, world):
+def test_split_by_reads_sends_every_tuple_once(ctx):
+    """cdm_kmermatch_split_begin: rank r extracts block r of the sequences only.  What the W ranks send to range p adds up to the real
+    tuples cdm_kmermatch_part extracts for range p (whole-sequence hash tuples: all to the last range, one per sequence that has one),
+    and every rank sends about 1/W of the tuples."""
+    db = ctx.synth(60_000, 60, 150, 3)
+    for world in (2, 3, 5):
+        want = [ctx.kmermatch_part(db, p, world).info()["real"] for p in range(world)]
+        sent = np.zeros((world, world), np.uint64); hashes = 0
+        for r in range(world):
+            part = ctx.kmermatch_split_begin(db, r, world)
+            off, _, _, vb, _, _, nh = part.outgoing(world)
+            assert vb in (4, 8) and off[0] == 0
+            sent[r] = np.diff(off); hashes += nh
+            del part
+        got = sent.sum(axis=0)
+        got[world - 1] += hashes
+        assert got.tolist() == want, (world, sent)
+        assert hashes > 59_000
+        assert sent.sum(axis=1).max() < 1.5 * sent.sum() / world          # (blocks of the length-sorted order: the first block holds the longest reads)
+
+
+@pytest.mark.parametrize("world,extract", [(2, None), (3, None), (2, "all")])
+def test_native_exact_iteration_equals_single_device(dhigh_prefix, world, extract, monkeypatch):
     """cdm_reads_iteration_dist (csrc/dist.hip: the exact scheme in the library, as a deployment runs it over RCCL) on 200 k mixed-length
     reads with `world` ranks: hits, corrected DB and next DB equal the single-device calls'."""
     ref = capi.Ctx(0)
@@ -253,6 +274,9 @@ def test_native_exact_iteration_equals_single_device(dhigh_prefix, world):
     hits = ref.kmermatch(db); alns = ref.rescore(db, hits); corr = ref.correct(db, alns); asm = ref.extend(corr, alns)
     want_hits, want_corr, want_asm = hits.download(), corr.download(), asm.download()
     del hits, alns, corr, asm
+    if extract:                       # every rank extracts every sequence and keeps its k-mer range (the A/B of the split by reads)
+        monkeypatch.setenv("CDM_DIST_EXTRACT", extract)
+        capi.lib().cdm_env_refresh()
 
     def rank_fn(rank, comm, c):
         c.damage_load(dhigh_prefix)
