@@ -62,7 +62,7 @@ EXPORTS = [
     "cdm_evalue", "cdm_bit_score", "cdm_gapped_evalue", "cdm_correct", "cdm_extend",
     "cdm_kmermatch_part", "cdm_kmermatch_split_begin", "cdm_kpart_outgoing", "cdm_kmermatch_split_finish", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_sort", "cdm_kpart_vote", "cdm_kpart_cont_cap", "cdm_kpart_free", "cdm_dev_copy",
     "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
-    "cdm_rescore_hamming", "cdm_pool_headroom", "cdm_env_refresh",
+    "cdm_rescore_hamming", "cdm_pool_headroom", "cdm_pool_stats", "cdm_env_refresh",
     "cdm_comm_unique_id", "cdm_comm_create_rccl", "cdm_comm_create_ops", "cdm_comm_free", "cdm_comm_rank", "cdm_comm_world", "cdm_kmermatch_dist",
     "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist",
 ]

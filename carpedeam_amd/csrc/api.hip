@@ -5,6 +5,7 @@
 #include <cstring>
 #include <vector>
 
+#include <algorithm>
 #include "common.h"
 #include "devutil.h"
 
@@ -19,6 +20,10 @@ extern "C" const char *cdm_last_error(void) { return g_err; }
 #include "pool.h"
 const char *cdmGetenv(const char *name) { return cdmenv::get(name); }
 extern "C" void cdm_env_refresh(void) { (void) cdmenv::refresh(); }
+extern "C" void cdm_pool_stats(uint64_t out[6]) {
+    cdmpool::Stats &st = cdmpool::stats();
+    out[0] = st.requests.load(); out[1] = st.cached.load(); out[2] = st.mallocs.load(); out[3] = st.mallocBytes.load(); out[4] = st.mallocNs.load(); out[5] = st.trims.load();
+}
 extern "C" void cdm_pool_headroom(float factor) { cdmpool::headroom().store(factor > 1.0f ? std::min(factor, 4.0f) : 1.0f, std::memory_order_relaxed); }
 hipError_t cdmMallocRaw(void **p, size_t bytes) { return cdmpool::allocate(p, bytes); }
 void cdmFree(void *p) { cdmpool::release(p); }
@@ -262,7 +267,7 @@ extern "C" int cdm_seqdb_upload(cdm_ctx *ctx, const char *data, const uint64_t *
         residues += lengths[i];
         maxLen = std::max(maxLen, lengths[i]);
         lo = std::min(lo, offsets[i]); hi = std::max(hi, offsets[i] + lengths[i]);
-        if (words >= 0xFFFFFFF0ull) { cdm_set_error("cdm_seqdb_upload: more than 2^32 code words (68 G bases) in one DB"); return CDM_ERR_UNSUPPORTED; }
+        if (words >= 0xFFFFFF00ull) { cdm_set_error("cdm_seqdb_upload: more than 2^32 code words (68 G bases) in one DB"); return CDM_ERR_UNSUPPORTED; }
     }
     woff[n] = (uint32_t) words;
     cdm_seqdb *db = nullptr;
@@ -289,7 +294,7 @@ extern "C" int cdm_seqdb_upload(cdm_ctx *ctx, const char *data, const uint64_t *
         hipMemcpyAsync(db->key, keys, n * 4, hipMemcpyHostToDevice, s);
         if (ext) hipMemcpyAsync(db->ext, ext, n, hipMemcpyHostToDevice, s); else hipMemsetAsync(db->ext, 0, n, s);
         if (words) {
-            hipLaunchKernelGGL(k_pack, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, s, dData, dOff, db->len, db->woff, n, words, db->codes,
+            hipLaunchKernelGGL(k_pack, CDM_GRID((words + 255) / 256, 256), dim3(256), 0, s, dData, dOff, db->len, db->woff, n, words, db->codes,
                                db->nmask, db->hasN, dCnt);
         }
         unsigned long long cnt[2] = {0, 0};
@@ -299,7 +304,7 @@ extern "C" int cdm_seqdb_upload(cdm_ctx *ctx, const char *data, const uint64_t *
         db->nCount = cnt[0];
         if (cnt[1]) {       // lower case / IUPAC codes / other bytes: those sequences keep their original letters beside the mapped codes
             if ((ret = cdm_seqdb_alloc_raw(db)) != CDM_OK) break;
-            hipLaunchKernelGGL(k_pack_raw, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, s, dData, dOff, db->len, db->woff, n, words, db->hasN, db->raw);
+            hipLaunchKernelGGL(k_pack_raw, CDM_GRID((words + 255) / 256, 256), dim3(256), 0, s, dData, dOff, db->len, db->woff, n, words, db->hasN, db->raw);
             e = hipStreamSynchronize(s);
             if (e != hipSuccess) { cdm_set_error("sequence upload/packing failed: %s", hipGetErrorString(e)); ret = CDM_ERR_HIP; break; }
         }
@@ -349,7 +354,7 @@ extern "C" int cdm_seqdb_download(cdm_ctx *ctx, const cdm_seqdb *db, char *out, 
     hipMemsetAsync(dOut, 0, total, ctx->stream);
     hipMemcpyAsync(dOff, outOffsets, db->n * 8, hipMemcpyHostToDevice, ctx->stream);
     // zero-length sequences own no word: their '\n' is written by the host below
-    if (db->words) hipLaunchKernelGGL(k_unpack, dim3((unsigned) ((db->words + 255) / 256)), dim3(256), 0, ctx->stream, db->codes, db->nmask, db->woff, db->len, dOff, db->n, db->words, dOut, db->hasN, db->raw);
+    if (db->words) hipLaunchKernelGGL(k_unpack, CDM_GRID((db->words + 255) / 256, 256), dim3(256), 0, ctx->stream, db->codes, db->nmask, db->woff, db->len, dOff, db->n, db->words, dOut, db->hasN, db->raw);
     hipMemcpyAsync(out, dOut, total, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     cdmFree(dOut); cdmFree(dOff);
@@ -380,9 +385,9 @@ __global__ void k_sel_meta(const cdm_seqdb src, const uint32_t *__restrict__ sel
     const uint32_t r = rank[i];
     dst.len[r] = sel[i]; dst.key[r] = src.key[i]; dst.ext[r] = extValue < 0 ? src.ext[i] : (uint8_t) extValue; dst.hasN[r] = (src.hasN[i] & 2u) ? 3 : 0; dst.woff[r] = wordOff[i];
 }
-__global__ void k_sel_copy(const cdm_seqdb src, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ wordOff, uint32_t n, cdm_seqdb dst) {
-    // one wave per selected sequence; the kept prefix ends inside its last word: the letters behind it are cleared
-    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+__global__ void k_sel_copy(const cdm_seqdb src, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ wordOff, uint32_t n, uint32_t first, cdm_seqdb dst) {
+    // one wave per selected sequence (of this launch's slice, from `first` on); the kept prefix ends inside its last word: the letters behind it are cleared
+    const uint32_t i = first + (uint32_t) (((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (i >= n || sel[i] == 0xFFFFFFFFu) return;
     const uint32_t L = sel[i], w = (L + 15) / 16, s0 = src.woff[i], d0 = wordOff[i], tail = L & 15u;
     for (uint32_t j = lane; j < w; j += 64) {
@@ -430,9 +435,10 @@ int cdm_seqdb_select(cdm_ctx *ctx, const cdm_seqdb *db, const uint32_t *sel, int
     if (rc != CDM_OK) { if (o) cdm_seqdb_free(o); return rc; }
     hipMemsetAsync(o->nmask, 0, (((uint64_t) words * 16 + 31) / 32 + 1) * 4, s);
     if (n) hipLaunchKernelGGL(k_sel_meta, dim3((n + 255) / 256), dim3(256), 0, s, *db, sel, rank.p, wordOff.p, n, extValue, *o);
-    if (n) hipLaunchKernelGGL(k_sel_copy, dim3((unsigned) (((uint64_t) n * 64 + 255) / 256)), dim3(256), 0, s, *db, sel, wordOff.p, n, *o);
+    for (uint64_t first = 0, slice = cdmSliceItems(64); first < n; first += slice)
+        hipLaunchKernelGGL(k_sel_copy, CDM_GRID((std::min<uint64_t>(slice, n - first) * 64 + 255) / 256, 256), dim3(256), 0, s, *db, sel, wordOff.p, n, (uint32_t) first, *o);
     hipMemcpyAsync(o->woff + m, &words, 4, hipMemcpyHostToDevice, s);
-    if (words && m) hipLaunchKernelGGL(k_mark_hasN, dim3((unsigned) (((uint64_t) words + 255) / 256)), dim3(256), 0, s, o->woff, o->nmask, m, (uint64_t) words, o->hasN);
+    if (words && m) hipLaunchKernelGGL(k_mark_hasN, CDM_GRID(((uint64_t) words + 255) / 256, 256), dim3(256), 0, s, o->woff, o->nmask, m, (uint64_t) words, o->hasN);
     // residues / max length on the host (contig lists are small next to the read DB)
     std::vector<uint32_t> l(m);
     hipMemcpyAsync(l.data(), o->len, (size_t) m * 4, hipMemcpyDeviceToHost, s);
@@ -507,7 +513,7 @@ extern "C" int cdm_seqdb_from_packed(cdm_ctx *ctx, const void *codes, const void
     hipMemcpyAsync(o->nmask, nmask16, words * 2, hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(k_words_of, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, s, o->len, (uint32_t) n, w, o->ext, extValue, o->hasN);
     if (cdmscan::exclusiveScan<uint32_t>(s, st, w, o->woff, (size_t) n + 1) != CDM_OK) { cdmFree(w); cdm_seqdb_free(o); return CDM_ERR_HIP; }
-    if (words) hipLaunchKernelGGL(k_mark_hasN, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, s, o->woff, o->nmask, (uint32_t) n, words, o->hasN);
+    if (words) hipLaunchKernelGGL(k_mark_hasN, CDM_GRID(((uint64_t) words + 255) / 256, 256), dim3(256), 0, s, o->woff, o->nmask, (uint32_t) n, words, o->hasN);
     std::vector<uint32_t> l(n);
     hipMemcpyAsync(l.data(), o->len, n * 4, hipMemcpyDeviceToHost, s);
     uint32_t total = 0;

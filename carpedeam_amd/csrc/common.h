@@ -47,6 +47,27 @@ template <typename T> struct DevBuf {
         }                                                                                               \
     } while (0)
 
+// A launch takes FEWER THAN 2^32 THREADS in all.  The runtime accepts more without an error and runs (blocks x threads) mod 2^32 of
+// them (scripts/probes/big_grid.hip: 18.5 M blocks of 256 ran 441 M threads) - which is how k_contig_stats, a wave per alignment
+// record, left 90 % of the statistics of 74 M records unwritten at 25 M reads until round 4.  Kernels that take a wave or a block per
+// item are launched in slices (cdmSliceItems: items per launch; the kernel adds its `first` item); kernels with a thread per item sit
+// behind size checks that keep the item count below 2^32 - CDM_GRID is the assertion that they do.
+constexpr uint64_t CDM_MAX_LAUNCH_THREADS = (1ull << 32) - 1ull;
+const char *cdmGetenv(const char *name);
+inline uint64_t cdmSliceItems(unsigned threadsPerItem) {        // CDM_LAUNCH_SLICE=<items> (tests): small inputs in several launches
+    if (const char *e = cdmGetenv("CDM_LAUNCH_SLICE")) { const long long v = atoll(e); if (v > 0) return (uint64_t) v; }
+    return (1ull << 31) / threadsPerItem;
+}
+inline dim3 cdmGridChecked(uint64_t blocks, unsigned threads, const char *file, int line) {
+    if (blocks * (uint64_t) threads > CDM_MAX_LAUNCH_THREADS || blocks == 0) {
+        if (blocks == 0) return dim3(1);
+        fprintf(stderr, "carpedeam: a launch of %llu blocks x %u threads (%s:%d) is more than the runtime runs (2^32 threads); this is a bug in the size checks in front of it\n", (unsigned long long) blocks, threads, file, line);
+        abort();
+    }
+    return dim3((unsigned) blocks);
+}
+#define CDM_GRID(blocks, threads) cdmGridChecked((uint64_t) (blocks), (threads), __FILE__, __LINE__)
+
 #define CDM_LAUNCH_CHECK()                                                                              \
     do {                                                                                                \
         hipError_t _e = hipGetLastError();                                                              \

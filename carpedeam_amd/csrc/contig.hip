@@ -6,6 +6,7 @@
 // per query: the Beta-posterior comparator (:25-70; lgammaf / logf / exp of the C library decide the order and it is not a
 // strict weak ordering, so the queue is libstdc++'s std::priority_queue with that very comparator), the extension loop and the
 // re-alignment of parked hits - host code of the library (host/contigmerge.cpp), compiled like the reference.
+#include <algorithm>
 #include <chrono>
 #include <memory>
 
@@ -17,6 +18,7 @@ struct StatArgs {
     const SeqMeta *meta; const uint32_t *codes, *nmask; const uint8_t *raw;
     const uint64_t *aoff; const AlnRec *rec; const uint32_t *owner;   // owner[r] = query of record r
     uint64_t nRec;
+    uint64_t first;              // first record of this launch (launches are slices of the records: common.h cdmSliceItems)
     ContigStat *out;
 };
 // hasRaw: the sequence carries letters beyond ACGTN.  Forward, the reference looks at the original byte (letter identity, == 'N',
@@ -35,7 +37,7 @@ __device__ __forceinline__ void letterAt(const StatArgs &a, uint32_t w0, uint32_
 }
 __device__ __forceinline__ uint32_t ryOf(uint32_t code) { return code < 4u ? (code & 1u) : 0u; }
 __global__ __launch_bounds__(256) void k_contig_stats(StatArgs a) {
-    const uint64_t r = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t r = a.first + (((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= a.nRec) return;
     const AlnRec rec = a.rec[r];
@@ -110,7 +112,10 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     if (n) hipLaunchKernelGGL(k_rec_owner, dim3((n + 255) / 256), dim3(256), 0, s, alns->off, n, owner.p);
     StatArgs a; a.meta = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.raw = db->raw; a.aoff = alns->off; a.rec = alns->rec; a.owner = owner.p; a.nRec = nRec; a.out = dStats.p;
     hipEventRecord(ctx->ev0, s);
-    if (nRec) hipLaunchKernelGGL(k_contig_stats, dim3((unsigned) ((nRec * 64 + 255) / 256)), dim3(256), 0, s, a);
+    for (uint64_t first = 0, slice = cdmSliceItems(64); first < nRec; first += slice) {
+        a.first = first;
+        hipLaunchKernelGGL(k_contig_stats, CDM_GRID((std::min(slice, nRec - first) * 64 + 255) / 256, 256), dim3(256), 0, s, a);
+    }
     hipEventRecord(ctx->ev1, s);
     // everything else is per-query bookkeeping on the host: sequences, records and the per-record statistics come down once
     const bool timing = cdmGetenv("CDM_TIMING") != nullptr;

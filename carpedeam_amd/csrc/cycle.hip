@@ -8,7 +8,9 @@
 // the run head (gallop + bisect) is the first front occurrence, a bisect finds the first middle one.  No per-contig sort, no
 // LDS limit on the contig length.  Quirks kept (the oracle lists them): position 0 belongs to no third that matters, N is
 // letter 4 of a base-4 index (collisions included), the band arithmetic runs in the reference's types.
+#include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "common.h"
 #include "devutil.h"
@@ -23,7 +25,9 @@ struct CycArgs {
     const uint32_t *codes, *nmask, *woff, *len; const uint8_t *hasN;
     uint32_t n, maxSeqLen;
     const u64 *koff, *hoff;      // [n+1] first k-mer ordinal / first diagonal counter of each contig
-    u64 totalK, totalH;
+    u64 totalK, totalH;          // k-mer positions / diagonal counters of THIS BATCH of contigs [c0, c0 + nc): ordinals and counters are
+    uint32_t c0, nc;             // local to it (kBase = koff[c0], hBase = hoff[c0]), so that a DB of any size goes through in batches of
+    u64 kBase, hBase;            // fewer than 2^32 positions
     u64 *keys; uint32_t *vals;   // sorted: (k-mer index, ordinal)
     uint32_t *owner;             // contig of every ordinal (the k-mers of different contigs interleave in the sorted array)
     uint32_t *hits, *split;
@@ -44,7 +48,7 @@ __device__ __forceinline__ uint32_t ownerOf(const u64 *__restrict__ off, uint32_
 __global__ __launch_bounds__(256) void k_cyc_kmers(CycArgs a) {
     const u64 g = (u64) blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.totalK) return;
-    const uint32_t i = ownerOf(a.koff, a.n, g), pos = (uint32_t) (g - a.koff[i]);
+    const uint32_t i = a.c0 + ownerOf(a.koff + a.c0, a.nc, a.kBase + g), pos = (uint32_t) (a.kBase + g - a.koff[i]);
     const uint32_t w0 = a.woff[i], last = (a.len[i] + 15) / 16 - 1;
     u64 x = (u64) cdm_window16(a.codes, w0, pos, last) | ((u64) (cdm_window16(a.codes, w0, pos + 16, last) & 0xFFFu) << 32);
     x ^= (x >> 1) & 0x5555555555555555ull;                         // A,C,G,T -> A,C,T,G
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256) void k_cyc_hits(CycArgs a) {
     const u64 key = a.keys[i];
     if (a.keys[i - 1] != key) return;
     const uint32_t g = a.vals[i], c = a.owner[g];
-    const uint32_t base = (uint32_t) a.koff[c], pos = g - base, L = a.len[c], third = L / 3;
+    const uint32_t base = (uint32_t) (a.koff[c] - a.kBase), pos = g - base, L = a.len[c], third = L / 3;
     if (pos < third + 2 || a.vals[i - 1] < base) return;           // a front occurrence (or position 0) matches nothing before it; alone in its run
     // head of the run (same k-mer, same contig): gallop back, then bisect.  in(j) is monotone on [0, i]
     u64 lo = i - 1, step = 1, out = ~0ull;                         // lo: known inside; out: known outside (or -1)
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void k_cyc_hits(CycArgs a) {
     u64 first = lo;
     uint32_t pf = a.vals[first] - base;
     if (pf == 0) { first++; pf = a.vals[first] - base; }            // first <= i
-    uint32_t *hits = a.hits + a.hoff[c];
+    uint32_t *hits = a.hits + (a.hoff[c] - a.hBase);
     if (pf >= 1 && pf <= third + 1 && pos - pf >= third) atomicAdd(&hits[pos - pf - third], 1u);
     if (pos >= 2 * third + 2) {                                      // a back occurrence: also against the first middle one
         u64 l = first, h = i;                                        // first j in [first, i) with position >= third + 2
@@ -93,9 +97,9 @@ __global__ __launch_bounds__(256) void k_cyc_band(CycArgs a) {
     if (x >= a.totalH) return;
     const uint32_t hd = a.hits[x];
     if (hd == 0) return;
-    const uint32_t c = ownerOf(a.hoff, a.n, x), d = (uint32_t) (x - a.hoff[c]), L = a.len[c], third = L / 3;
+    const uint32_t c = a.c0 + ownerOf(a.hoff + a.c0, a.nc, a.hBase + x), d = (uint32_t) (a.hBase + x - a.hoff[c]), L = a.len[c], third = L / 3;
     if (d >= 2 * third) return;
-    const uint32_t *hits = a.hits + a.hoff[c];
+    const uint32_t *hits = a.hits + (a.hoff[c] - a.hBase);
     const uint32_t diag = d + third, diaglen = L - diag;
     const uint32_t gap = (uint32_t) ((double) diaglen * 0.01);
     const uint32_t lower = (uint32_t) max(0, (int) (d - gap)), upper = min(d + gap, 2 * third);
@@ -132,20 +136,44 @@ extern "C" int cdm_cyclecheck(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t maxSeq
     hipMemcpyAsync(&totalK, koff.p + n, 8, hipMemcpyDeviceToHost, s);
     hipMemcpyAsync(&totalH, hoff.p + n, 8, hipMemcpyDeviceToHost, s);
     CDM_HIP(hipStreamSynchronize(s));
-    if (totalK >= 0xFFFFFFFFull) { cdm_set_error("cdm_cyclecheck: more than 2^32-1 k-mer positions (%llu)", totalK); return CDM_ERR_UNSUPPORTED; }
     CDM_HIP(hipMemsetAsync(split.p, 0xFF, (size_t) n * 4 + 4, s));
+    // Batches of contigs with fewer than 2^31 k-mer positions each (CDM_CYC_BATCH=<positions>: tests): the ordinals are 32 bits wide, a
+    // launch takes fewer than 2^32 threads, and the sort buffers stay at 28 bytes x 2^31 whatever the DB's size (a workflow's later
+    // contig iterations hold 6 G letters and more at 25 M reads).
+    u64 batch = 1ull << 31;
+    if (const char *e = cdmGetenv("CDM_CYC_BATCH")) { const long long v = atoll(e); if (v > 0) batch = (u64) v; }
+    std::vector<uint32_t> cuts(1, 0u);
+    if (totalK > batch) {
+        std::vector<u64> hk((size_t) n + 1);
+        CDM_HIP(hipMemcpyAsync(hk.data(), koff.p, ((size_t) n + 1) * 8, hipMemcpyDeviceToHost, s));
+        CDM_HIP(hipStreamSynchronize(s));
+        uint32_t start = 0;
+        for (uint32_t c = 1; c <= n; c++) if (hk[c] - hk[start] > batch && c - 1 > start) { cuts.push_back(c - 1); start = c - 1; }     // (a contig has fewer than 2^31 positions: --max-seq-len, the 2^22-letter bound of the tuple layouts)
+    }
+    cuts.push_back(n);
+    std::vector<u64> hostK(cuts.size()), hostH(cuts.size());
+    for (size_t b = 0; b < cuts.size(); b++) {
+        CDM_HIP(hipMemcpyAsync(&hostK[b], koff.p + cuts[b], 8, hipMemcpyDeviceToHost, s));
+        CDM_HIP(hipMemcpyAsync(&hostH[b], hoff.p + cuts[b], 8, hipMemcpyDeviceToHost, s));
+    }
+    CDM_HIP(hipStreamSynchronize(s));
+    u64 maxK = 0, maxH = 0;
+    for (size_t b = 0; b + 1 < cuts.size(); b++) { maxK = std::max(maxK, hostK[b + 1] - hostK[b]); maxH = std::max(maxH, hostH[b + 1] - hostH[b]); }
+    if (maxK >= 0xFFFFFF00ull || maxH >= 0xFFFFFF00ull) { cdm_set_error("cdm_cyclecheck: a batch of contigs with 2^32 k-mer positions (%llu) or diagonals (%llu)", maxK, maxH); return CDM_ERR_UNSUPPORTED; }
     DevBuf<u64> k0, k1; DevBuf<uint32_t> v0, v1, hits, owner;
-    CycArgs a = {db->codes, db->nmask, db->woff, db->len, db->hasN, n, maxSeqLen, koff.p, hoff.p, totalK, totalH, nullptr, nullptr, nullptr, nullptr, split.p};
-    if (totalK) {
-        if (!k0.alloc(totalK) || !k1.alloc(totalK) || !v0.alloc(totalK) || !v1.alloc(totalK) || !hits.alloc(totalH) || !owner.alloc(totalK)) { cdm_set_error("cdm_cyclecheck: out of device memory"); return CDM_ERR_HIP; }
-        CDM_HIP(hipMemsetAsync(hits.p, 0, (totalH + 1) * 4, s));
+    if (maxK && (!k0.alloc(maxK) || !k1.alloc(maxK) || !v0.alloc(maxK) || !v1.alloc(maxK) || !hits.alloc(maxH) || !owner.alloc(maxK))) { cdm_set_error("cdm_cyclecheck: out of device memory"); return CDM_ERR_HIP; }
+    for (size_t b = 0; b + 1 < cuts.size(); b++) {
+        const u64 bK = hostK[b + 1] - hostK[b], bH = hostH[b + 1] - hostH[b];
+        if (!bK) continue;
+        CycArgs a = {db->codes, db->nmask, db->woff, db->len, db->hasN, n, maxSeqLen, koff.p, hoff.p, bK, bH, cuts[b], cuts[b + 1] - cuts[b], hostK[b], hostH[b], nullptr, nullptr, nullptr, nullptr, split.p};
+        CDM_HIP(hipMemsetAsync(hits.p, 0, (bH + 1) * 4, s));
         a.keys = k0.p; a.vals = v0.p; a.hits = hits.p; a.owner = owner.p;
-        hipLaunchKernelGGL(k_cyc_kmers, dim3((unsigned) ((totalK + 255) / 256)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_cyc_kmers, CDM_GRID((bK + 255) / 256, 256), dim3(256), 0, s, a);
         bool inFirst = true;            // stable radix sort on the 46 index bits (radix.h)
-        if (int rc = rx::sortPairs<uint64_t, uint32_t>(s, ctx->cuCount, reinterpret_cast<uint64_t *>(k0.p), reinterpret_cast<uint64_t *>(k1.p), v0.p, v1.p, (uint64_t) totalK, 0, 2 * CYC_K + 2, inFirst)) return rc;
+        if (int rc = rx::sortPairs<uint64_t, uint32_t>(s, ctx->cuCount, reinterpret_cast<uint64_t *>(k0.p), reinterpret_cast<uint64_t *>(k1.p), v0.p, v1.p, (uint64_t) bK, 0, 2 * CYC_K + 2, inFirst)) return rc;
         a.keys = inFirst ? k0.p : k1.p; a.vals = inFirst ? v0.p : v1.p;
-        hipLaunchKernelGGL(k_cyc_hits, dim3((unsigned) ((totalK + 255) / 256)), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_cyc_band, dim3((unsigned) ((totalH + 255) / 256)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_cyc_hits, CDM_GRID((bK + 255) / 256, 256), dim3(256), 0, s, a);
+        if (bH) hipLaunchKernelGGL(k_cyc_band, CDM_GRID((bH + 255) / 256, 256), dim3(256), 0, s, a);
     }
     if (n) hipLaunchKernelGGL(k_cyc_select, dim3((n + 255) / 256), dim3(256), 0, s, db->len, split.p, n, chopCycle, selCyc.p, selRest.p, splitOut.p);
     if (splitHost && n) CDM_HIP(hipMemcpyAsync(splitHost, splitOut.p, (size_t) n * 4, hipMemcpyDeviceToHost, s));

@@ -314,7 +314,7 @@ extern "C" int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *cm, const cdm_s
     if (int rc = gather(local->ext + lo, 1, seqOff, m, ext.p)) return rc;
     if (anyRaw) {       // letters beyond ACGTN: the original bytes (16 per code word) and which rows count; a rank without such letters sends zeros
         const uint8_t *rawSend = nullptr;
-        if (local->raw) { rawSend = local->raw + 16 * w0; if (m) hipLaunchKernelGGL(k_row_flags, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, local->hasN, lo, m, myFlags.p); }
+        if (local->raw) { rawSend = local->raw + 16 * w0; if (m) hipLaunchKernelGGL(k_row_flags, CDM_GRID((m + 255) / 256, 256), dim3(256), 0, s, local->hasN, lo, m, myFlags.p); }
         else {
             if (!zeros.alloc(16 * w + 16)) { cdm_set_error("cdm_seqdb_allgather_owned: out of device memory"); return CDM_ERR_HIP; }
             CDM_HIP(hipMemsetAsync(zeros.p, 0, 16 * w + 16, s)); CDM_HIP(hipMemsetAsync(myFlags.p, 0, m + 1, s));

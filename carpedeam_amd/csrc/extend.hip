@@ -951,7 +951,7 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
         hipMemsetAsync(pushBits.p, 0, (alns->count / 32 + 2) * 4, s);
         XrArgs X; X.sBound = sBound.p; X.elig = elig.p; X.pushBits = pushBits.p; X.winQ = winQ.p; X.lite = lite.p; X.sLen = sLen.p; X.qMax = qMax.p; X.work = work.p; X.nWork = nActive.p + 1; X.fallback = flags.p + 1;
         hipLaunchKernelGGL(k_xr_windows, dim3(nWin / 256 + 1), dim3(256), 0, s, alns->off, n, nWin, winQ.p);
-        hipLaunchKernelGGL(k_xr_score, dim3(nWin), dim3(XR_NT), 0, s, A, X);
+        hipLaunchKernelGGL(k_xr_score, CDM_GRID(nWin, XR_NT), dim3(XR_NT), 0, s, A, X);
         unsigned int fb = 0;
         hipMemcpyAsync(&fb, flags.p + 1, 4, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_extend: scoring kernel failed"); return CDM_ERR_HIP; }

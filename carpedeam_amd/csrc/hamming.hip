@@ -10,6 +10,7 @@
 // NucleotideMatrix maps each letter to, 'X' for the X class (rescorediagonal.cpp:171-177).
 // Output: prefilter records (target, 100 * seq. id. with the hit's strand as its sign, diagonal) for the hits that pass the
 // coverage / seq. id. / length criteria, and every identity hit; same CSR over the queries as the input.
+#include <algorithm>
 #include "common.h"
 #include "devutil.h"
 #include "scan.h"
@@ -18,7 +19,7 @@ namespace {
 
 struct HamArgs {
     const uint32_t *woff, *len; const uint8_t *hasN; const uint32_t *codes, *nmask; const uint8_t *raw;
-    const uint64_t *hoff; const HitRec *hit; uint32_t n; uint64_t count;
+    const uint64_t *hoff; const HitRec *hit; uint32_t n; uint64_t count, first;       // first: first hit of this launch (slices: common.h cdmSliceItems)
     float seqIdThr, covThr; int covMode, seqIdMode, minAlnLen; int evalOk; int revPref;
     HitRec *tmp; uint32_t *valid;       // [count] record as it would be written, 1 = kept
     unsigned int *flags;                // [0]: an empty target sequence (the reference's probe loop does not end there)
@@ -49,7 +50,7 @@ __device__ __forceinline__ uint32_t hamRevLetter(const HamArgs &a, uint32_t w, u
 }
 
 __global__ __launch_bounds__(256) void k_hamming(HamArgs a) {
-    const uint64_t h = (uint64_t) blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const uint64_t h = a.first + (uint64_t) blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (h >= a.count) return;
     // query of the hit: the last q with hoff[q] <= h
@@ -135,7 +136,10 @@ int cdm_rescore_hamming_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *
     a.seqIdThr = par->seq_id_thr; a.covThr = par->cov_thr; a.covMode = par->cov_mode; a.seqIdMode = par->seq_id_mode; a.minAlnLen = par->min_aln_len;
     a.evalOk = (0.0 <= par->eval_thr) ? 1 : 0; a.revPref = par->reverse_prefilter ? 1 : 0;
     a.tmp = tmp.p; a.valid = valid.p; a.flags = flags.p;
-    if (count) hipLaunchKernelGGL(k_hamming, dim3((unsigned) ((count + 3) / 4)), dim3(256), 0, s, a);
+    for (uint64_t first = 0, slice = cdmSliceItems(64); first < count; first += slice) {
+        a.first = first;
+        hipLaunchKernelGGL(k_hamming, CDM_GRID((std::min(slice, count - first) + 3) / 4, 256), dim3(256), 0, s, a);
+    }
     cdmscan::ScanTemp st;
     if (int rc = cdmscan::exclusiveScan<uint32_t>(s, st, valid.p, pos.p, (size_t) count + 1)) { cdm_hits_free(o); return rc; }
     uint32_t kept = 0; unsigned int hflags = 0;
@@ -145,7 +149,7 @@ int cdm_rescore_hamming_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *
     if (hflags) { cdm_hits_free(o); cdm_set_error("cdm_rescore_hamming: an empty sequence among the hits (the reference's probe loop does not end on one)"); return CDM_ERR_UNSUPPORTED; }
     o->count = kept;
     if (cdmMalloc(&o->rec, ((size_t) kept + 1) * sizeof(HitRec)) != hipSuccess) { cdm_hits_free(o); cdm_set_error("cdm_rescore_hamming: out of device memory"); return CDM_ERR_HIP; }
-    if (count) hipLaunchKernelGGL(k_ham_compact, dim3((unsigned) ((count + 255) / 256)), dim3(256), 0, s, (const uint32_t *) valid.p, (const uint32_t *) pos.p, (const HitRec *) tmp.p, count, o->rec);
+    if (count) hipLaunchKernelGGL(k_ham_compact, CDM_GRID((count + 255) / 256, 256), dim3(256), 0, s, (const uint32_t *) valid.p, (const uint32_t *) pos.p, (const HitRec *) tmp.p, count, o->rec);
     hipLaunchKernelGGL(k_ham_offsets, dim3(n / 256 + 1), dim3(256), 0, s, (const uint64_t *) hits->off, (const uint32_t *) pos.p, n, o->off);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(o); cdm_set_error("cdm_rescore_hamming: compaction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     *out = o;

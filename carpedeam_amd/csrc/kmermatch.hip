@@ -1431,16 +1431,16 @@ int splitPartition() {
     if (kmerSlots) { if (int rc = rx::compactPairs<uint64_t, V>(s, k0.p, v0.p, (uint64_t) kmerSlots, k1.p, v1.p, cnt.p)) return rc; hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, s); }
     if (r2Slots) { if (int rc = rx::compactPairs<uint64_t, V>(s, k0.p + kmerSlots, v0.p + kmerSlots, (uint64_t) r2Slots, k1.p + kmerSlots, v1.p + kmerSlots, cnt.p + 1)) return rc; hipMemcpyAsync(&h, cnt.p + 1, 8, hipMemcpyDeviceToHost, s); }
     if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: compaction failed"); return CDM_ERR_HIP; }
-    if (m >= 0xFFFFFFFFull) { cdm_set_error("cdm_kmermatch: more than 2^32 tuples on one rank of the split by reads"); return CDM_ERR_UNSUPPORTED; }
+    if (m >= 0xFFFFFF00ull) { cdm_set_error("cdm_kmermatch: more than 2^32 tuples on one rank of the split by reads"); return CDM_ERR_UNSUPPORTED; }
     sendOff.assign((size_t) nparts + 1, 0);
     if (!splitK.alloc(m) || !splitV.alloc(m) || !splitD0.alloc(m) || !splitD1.alloc(m) || !splitI0.alloc(m) || !splitI1.alloc(m)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     if (m) {
         TupleGeom g1 = geom; g1.kmerSlots = ~0ull;              // (every compacted tuple is a region-1 tuple)
-        hipLaunchKernelGGL(k_dest_range<LY>, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, (const uint64_t *) k1.p, (uint64_t) m, g1, 2 * k, (uint32_t) nparts, splitD0.p, splitI0.p);
+        hipLaunchKernelGGL(k_dest_range<LY>, CDM_GRID((m + 255) / 256, 256), dim3(256), 0, s, (const uint64_t *) k1.p, (uint64_t) m, g1, 2 * k, (uint32_t) nparts, splitD0.p, splitI0.p);
         bool first = true;
         if (int rc = rx::sortPairs<uint32_t, uint32_t>(s, ctx->cuCount, splitD0.p, splitD1.p, splitI0.p, splitI1.p, (uint64_t) m, 0, (int) bitsFor((uint64_t) nparts), first)) return rc;
         const uint32_t *dS = first ? splitD0.p : splitD1.p, *iS = first ? splitI0.p : splitI1.p;
-        hipLaunchKernelGGL(k_gather_pairs<V>, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, s, iS, (uint64_t) m, (const uint64_t *) k1.p, (const V *) v1.p, splitK.p, splitV.p);
+        hipLaunchKernelGGL(k_gather_pairs<V>, CDM_GRID((m + 255) / 256, 256), dim3(256), 0, s, iS, (uint64_t) m, (const uint64_t *) k1.p, (const V *) v1.p, splitK.p, splitV.p);
         hipLaunchKernelGGL(k_dest_bounds, dim3(1), dim3(256), 0, s, dS, (uint64_t) m, (uint32_t) nparts, bounds.p);
         hipMemcpyAsync(sendOff.data(), bounds.p, ((size_t) nparts + 1) * 8, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: ordering the tuples by k-mer range failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
@@ -1539,7 +1539,8 @@ int sortAndGroup() {
             if (cnt == 0) return CDM_OK;
             cdmscan::ScanTemp t;                                                  // alive until the synchronise below
             if (int rc = cdmscan::inclusiveMaxScanFn(s, t, StartFrom<LY>{StartIndex<LY>{g.keys, g.geom, (unsigned long long) g.first}}, io + g.first, cnt)) return rc;
-            hipLaunchKernelGGL(k_groups<LY>, dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, s, g, io);
+            if (cnt > CDM_MAX_LAUNCH_THREADS - 256) { cdm_set_error("cdm_kmermatch: %zu tuples in one grouping launch (CDM_KMER_SORT=lsd takes fewer than 2^32)", cnt); return CDM_ERR_UNSUPPORTED; }
+            hipLaunchKernelGGL(k_groups<LY>, CDM_GRID((cnt + 255) / 256, 256), dim3(256), 0, s, g, io);
             return hipStreamSynchronize(s) == hipSuccess ? CDM_OK : CDM_ERR_HIP;
         };
         int rc = CDM_OK;
@@ -1802,7 +1803,7 @@ int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *re
     cdmscan::ScanTemp st;
     agEnt.free(); agSegOfRec.free(); agPerRep.free(); agCursor.free(); agFlags.free(); agSegRep.free(); agSegFirstRec.free(); agEntOff.free(); agEntCnt.free(); agPending.free();     // (a second try)
     if (!agSegOfRec.alloc(nRec + 2) || !agPerRep.alloc((size_t) n + 1) || !agCursor.alloc(2) || !agFlags.alloc(4)) { cdm_set_error("cdm_kmermatch: out of device memory (aggregation)"); return CDM_ERR_HIP; }
-    hipLaunchKernelGGL(k_seg_flags, dim3((unsigned) ((nRec + 1024) / 1024)), dim3(1024), 0, s, recRep, (uint64_t) nRec, agSegOfRec.p);
+    hipLaunchKernelGGL(k_seg_flags, CDM_GRID((nRec + 1024) / 1024, 1024), dim3(1024), 0, s, recRep, (uint64_t) nRec, agSegOfRec.p);
     if (int rc = cdmscan::exclusiveScan<uint32_t>(s, st, agSegOfRec.p, agSegOfRec.p, (size_t) nRec + 1)) return rc;
     uint32_t nSeg = 0;
     hipMemcpyAsync(&nSeg, agSegOfRec.p + nRec, 4, hipMemcpyDeviceToHost, s);
@@ -1811,7 +1812,7 @@ int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *re
         !agEnt.alloc(capEnt + 1)) {
         agEnt.free(); cdm_set_error("cdm_kmermatch: out of device memory (aggregation)"); return CDM_ERR_HIP;
     }
-    hipLaunchKernelGGL(k_seg_fill, dim3((unsigned) ((nRec + 1024) / 1024)), dim3(1024), 0, s, recRep, (uint64_t) nRec, agSegOfRec.p, agSegRep.p, agSegFirstRec.p, agEntCnt.p);
+    hipLaunchKernelGGL(k_seg_fill, CDM_GRID((nRec + 1024) / 1024, 1024), dim3(1024), 0, s, recRep, (uint64_t) nRec, agSegOfRec.p, agSegRep.p, agSegFirstRec.p, agEntCnt.p);
     hipMemsetAsync(agPerRep.p, 0, ((size_t) n + 1) * 8, s);
     hipMemsetAsync(agCursor.p, 0, 16, s); hipMemsetAsync(agFlags.p, 0, 16, s);
     AggArgs a;
@@ -1900,7 +1901,7 @@ int gatherByRep() override {
     hipMemsetAsync(rv.current() + nRec, 0, 8, s);
     if (int rc = cdmscan::exclusiveScanFn<unsigned long long, RunLen>(s, stB, RunLen{rv.current()}, dst.p, (size_t) nRec + 1)) return rc;
     hipMemcpyAsync(&nOut, dst.p + nRec, 8, hipMemcpyDeviceToHost, s);
-    hipLaunchKernelGGL(k_run_gather, dim3((unsigned) ((nRec + 255) / 256)), dim3(256), 0, s, (const uint64_t *) startIo, (const uint64_t *) rv.current(), (const unsigned long long *) dst.p, (uint64_t) nRec, gathered);
+    hipLaunchKernelGGL(k_run_gather, CDM_GRID((nRec + 255) / 256, 256), dim3(256), 0, s, (const uint64_t *) startIo, (const uint64_t *) rv.current(), (const unsigned long long *) dst.p, (uint64_t) nRec, gathered);
     if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: gather by representative failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
     if (nOut != nKept) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu gathered", nKept, nOut); return CDM_ERR_HIP; }
     return CDM_OK;

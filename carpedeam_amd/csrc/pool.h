@@ -3,6 +3,7 @@
 // and run it under ThreadSanitizer / AddressSanitizer on a box without a GPU.)
 #pragma once
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -12,6 +13,7 @@
 #include <utility>
 #include <vector>
 #include <sys/syscall.h>
+#include <time.h>
 #include <unistd.h>
 
 extern char **environ;
@@ -49,73 +51,341 @@ inline const char *get(const char *name) {
 }
 }  // namespace cdmenv
 
-// ------------------------------------------------------------------------------------------------ caching allocator
+// ------------------------------------------------------------------------------------------------ device memory
 namespace cdmpool {
-// One cache of free blocks per host thread and device: a context belongs to one host thread, and a block freed by
-// one thread's stream must not be handed to another thread's stream without synchronisation (ranks as threads of one process in
-// the tests).  Which block has which size and whose it is lives in ONE process-wide registry: a block freed by another thread than
-// its allocator's is released and forgotten there, so no cache can meet its address again with a stale size.  The registry also
-// lists the live caches, so that a thread that runs out of device memory can release what the OTHER threads have parked
-// (a cache's own mutex guards its free list for that one cross-thread visitor; uncontended otherwise).
+// Device memory comes out of ARENAS: a range of virtual addresses reserved once (hipMemAddressReserve) whose mapped part grows at its
+// end (hipMemCreate + hipMemMap), cut into blocks that are split on allocation (best fit) and merged with their free neighbours on
+// release.  Why not hipMalloc per buffer with a cache of freed blocks (what this was until round 4; CDM_POOL=blocks still selects
+// it): memory that went back to the driver once costs 33-58 ms per GB to get again on this platform (scripts/probes/vmm_probe.hip:
+// fresh memory maps in 0-9 ms per GB, freed memory is cleared before it is handed out again), and a cache of exact-size blocks keeps
+// every size a growing workload ever asked for - the contig iterations of the workflow loop (buffers 1.02-1.5x larger per iteration)
+// had mapped 390 GB by their last iteration at 25 M reads, ran out of memory, released everything and paid 7 s to map 120 GB again.
+// An arena never gives memory back while its thread lives (out-of-memory in ANOTHER thread's arena excepted: trimAll), and any free
+// range serves any request.
+//
+// One pool (a small-request and a large-request arena) per host thread and device: a context belongs to one host thread
+// (INTEGRATION.md), and a block freed on one thread's stream must not be handed to another thread's stream without synchronisation
+// (ranks as threads of one process in the tests).  A block released by another thread than its owner's goes back to the OWNER's
+// arena, after a device synchronise.  A thread that ends releases what its arenas do not need; blocks of it that are still in use
+// keep their arena alive (an orphan: whoever frees its last block unmaps it).  The registry lists pools and address ranges, so that
+// release() finds the owner of a pointer and a thread that runs out of memory can make the others give back their free chunks.
+#ifndef CDM_POOL_LARGE_CHUNK
+#define CDM_POOL_LARGE_CHUNK ((size_t) 256 << 20)   // the large arena grows in chunks of this size,
+#endif
+#ifndef CDM_POOL_SMALL_CHUNK
+#define CDM_POOL_SMALL_CHUNK ((size_t) 32 << 20)    // the small one in chunks of this
+#endif
+#ifndef CDM_POOL_ROOMY_MIN
+#define CDM_POOL_ROOMY_MIN ((size_t) 64 << 20)      // head room (cdm_pool_headroom) applies to requests of this size and more
+#endif
+constexpr size_t LARGE_CHUNK = CDM_POOL_LARGE_CHUNK, SMALL_CHUNK = CDM_POOL_SMALL_CHUNK, ROOMY_MIN = CDM_POOL_ROOMY_MIN;
+constexpr size_t SMALL_MAX = (size_t) 256 << 10;    // requests below this come from the small arena (long-lived odds and ends do not cut up the large one)
+enum { B_USED = 0, B_FREE = 1, B_HOLE = 2 };        // (a hole: a free range whose chunk was given back - addresses without memory)
+struct Blk { size_t size; int state; };
+struct Chunk { size_t off, size; hipMemGenericAllocationHandle_t h; };
+struct Arena {
+    char *base = nullptr; size_t reserved = 0, end = 0;       // the blocks tile [0, end)
+    std::map<size_t, Blk> blocks;                             // by offset
+    std::multimap<size_t, size_t> freeBySize;                 // size -> offset of the free blocks
+    std::vector<Chunk> chunks;
+    size_t used = 0;                                          // blocks handed out
+    bool small = false;
+};
 struct Pool {
     std::mutex m;
-    std::multimap<size_t, void *> freeBlocks;
+    int device = 0;
+    Arena small, large;
+    bool orphan = false;                                      // its thread ended with blocks still in use
+    std::multimap<size_t, void *> freeBlocks;                 // CDM_POOL=blocks: the cache of exact-size blocks
 };
+struct Range { char *lo, *hi; Pool *pool; Arena *arena; };
 struct Registry {
     std::mutex m;
-    std::unordered_map<void *, std::pair<size_t, Pool *>> blocks;
-    std::vector<Pool *> pools;              // the caches of the threads that are alive
+    std::unordered_map<void *, std::pair<size_t, Pool *>> blocks;      // CDM_POOL=blocks: size and owner of every block
+    std::vector<Pool *> pools;              // the pools of the threads that are alive, and the orphans
+    std::vector<Range> ranges;              // the arenas' address ranges
 };
 inline Registry &registry() { static Registry *r = new Registry(); return *r; }      // (never destroyed: thread_local pools may outlive statics)
-// frees every cached block of `q`.  Lock order: registry, then pool.
+
+// What the allocator cost and saved, process-wide (cdm_pool_stats): requests, requests served without the driver, calls that asked
+// the driver for memory (hipMemCreate / hipMalloc), their bytes and the seconds they took, times free memory was given back after an
+// out-of-memory.
+struct Stats { std::atomic<unsigned long long> requests{0}, cached{0}, mallocs{0}, mallocBytes{0}, mallocNs{0}, trims{0}; };
+inline Stats &stats() { static Stats s; return s; }
+struct DriverTimer {
+    struct timespec t0; size_t bytes;
+    explicit DriverTimer(size_t b) : bytes(b) { clock_gettime(CLOCK_MONOTONIC, &t0); }
+    void done(bool ok) {
+        struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        Stats &st = stats();
+        st.mallocs.fetch_add(1, std::memory_order_relaxed);
+        if (ok) st.mallocBytes.fetch_add(bytes, std::memory_order_relaxed);
+        st.mallocNs.fetch_add((unsigned long long) ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec)), std::memory_order_relaxed);
+    }
+};
+inline hipError_t timedMalloc(void **p, size_t bytes) { DriverTimer t(bytes); const hipError_t e = hipMalloc(p, bytes); t.done(e == hipSuccess); return e; }
+
+// ---- arena bookkeeping (the pool's mutex is held)
+inline void dropFree(Arena &a, size_t off, size_t size) {
+    auto r = a.freeBySize.equal_range(size);
+    for (auto it = r.first; it != r.second; ++it) if (it->second == off) { a.freeBySize.erase(it); return; }
+}
+inline void addFree(Arena &a, size_t off, size_t size) { a.blocks[off] = Blk{size, B_FREE}; a.freeBySize.emplace(size, off); }
+// takes `keep` bytes (at least `bytes`, more where head room is wanted) out of the smallest free block that holds `bytes`
+inline void *takeBlock(Arena &a, size_t bytes, size_t keep) {
+    auto it = a.freeBySize.lower_bound(bytes);
+    if (it == a.freeBySize.end()) return nullptr;
+    const size_t size = it->first, off = it->second;
+    a.freeBySize.erase(it);
+    const size_t mine = size > keep ? keep : size;            // (a block between `bytes` and `keep` is taken whole: that is its head room)
+    a.blocks[off] = Blk{mine, B_USED};
+    if (size > mine) addFree(a, off + mine, size - mine);
+    a.used++;
+    return a.base + off;
+}
+inline void giveBlock(Arena &a, size_t off) {
+    auto it = a.blocks.find(off);
+    size_t at = off, size = it->second.size;
+    auto nx = std::next(it);
+    if (nx != a.blocks.end() && nx->second.state == B_FREE) { dropFree(a, nx->first, nx->second.size); size += nx->second.size; a.blocks.erase(nx); }
+    if (it != a.blocks.begin()) {
+        auto pv = std::prev(it);
+        if (pv->second.state == B_FREE) { dropFree(a, pv->first, pv->second.size); at = pv->first; size += pv->second.size; a.blocks.erase(it); it = pv; }
+    }
+    (void) it;
+    a.blocks[at] = Blk{size, B_FREE};
+    a.freeBySize.emplace(size, at);
+    a.used--;
+}
+// maps more memory at the arena's end until the free block there holds `need` bytes.  Chunks of ONE size per arena: that is what
+// hipMemSetAccess takes on this platform - chunks of mixed sizes in one reservation fail with "invalid argument"
+// (scripts/probes/vmm_sizes.hip, vmm_uniform.hip).  What was mapped before a failure stays (a free block at the end).
+inline hipError_t growArena(Arena &a, int device, size_t need) {
+    const size_t chunk = a.small ? SMALL_CHUNK : LARGE_CHUNK;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+    for (;;) {
+        const bool tail = !a.blocks.empty() && a.blocks.rbegin()->second.state == B_FREE;
+        if (tail && a.blocks.rbegin()->second.size >= need) return hipSuccess;
+        if (a.end + chunk > a.reserved) return hipErrorOutOfMemory;
+        hipMemGenericAllocationHandle_t h;
+        DriverTimer t(chunk);
+        hipError_t e = hipMemCreate(&h, chunk, &prop, 0);
+        if (e == hipSuccess) {
+            e = hipMemMap(a.base + a.end, chunk, 0, h, 0);
+            if (e == hipSuccess) {
+                hipMemAccessDesc d = {}; d.location = prop.location; d.flags = hipMemAccessFlagsProtReadWrite;
+                e = hipMemSetAccess(a.base + a.end, chunk, &d, 1);
+                if (e != hipSuccess) (void) hipMemUnmap(a.base + a.end, chunk);
+            }
+            if (e != hipSuccess) (void) hipMemRelease(h);
+        }
+        t.done(e == hipSuccess);
+        if (e != hipSuccess) {
+            if (cdmenv::get("CDM_POOL_DEBUG")) fprintf(stderr, "carpedeam pool: mapping %zu bytes at offset %zu of the %s arena failed: %s\n", chunk, a.end, a.small ? "small" : "large", hipGetErrorString(e));
+            return e;
+        }
+        a.chunks.push_back(Chunk{a.end, chunk, h});
+        if (tail) {
+            auto last = std::prev(a.blocks.end());
+            dropFree(a, last->first, last->second.size);
+            last->second.size += chunk;
+            a.freeBySize.emplace(last->second.size, last->first);
+        } else addFree(a, a.end, chunk);
+        a.end += chunk;
+    }
+}
+// gives back the chunks that lie in free blocks (their addresses become holes; holes at the end are cut off)
+inline void trimArena(Arena &a) {
+    for (size_t c = 0; c < a.chunks.size();) {
+        const Chunk ch = a.chunks[c];
+        auto it = a.blocks.upper_bound(ch.off);
+        if (it == a.blocks.begin()) { c++; continue; }
+        --it;
+        const size_t bo = it->first, bs = it->second.size;
+        if (it->second.state != B_FREE || bo + bs < ch.off + ch.size) { c++; continue; }
+        (void) hipMemUnmap(a.base + ch.off, ch.size); (void) hipMemRelease(ch.h);
+        dropFree(a, bo, bs);
+        a.blocks.erase(it);
+        if (ch.off > bo) addFree(a, bo, ch.off - bo);
+        a.blocks[ch.off] = Blk{ch.size, B_HOLE};
+        if (bo + bs > ch.off + ch.size) addFree(a, ch.off + ch.size, bo + bs - (ch.off + ch.size));
+        a.chunks[c] = a.chunks.back(); a.chunks.pop_back();
+    }
+    while (!a.blocks.empty() && a.blocks.rbegin()->second.state == B_HOLE) { a.end -= a.blocks.rbegin()->second.size; a.blocks.erase(std::prev(a.blocks.end())); }
+}
+inline void destroyArena(Registry &r, Arena &a) {       // (nothing of it is in use)
+    if (!a.base) return;
+    for (const Chunk &ch : a.chunks) { (void) hipMemUnmap(a.base + ch.off, ch.size); (void) hipMemRelease(ch.h); }
+    (void) hipMemAddressFree(a.base, a.reserved);
+    for (size_t i = 0; i < r.ranges.size(); i++) if (r.ranges[i].arena == &a) { r.ranges[i] = r.ranges.back(); r.ranges.pop_back(); break; }
+    a = Arena();
+}
+// CDM_POOL=blocks, or a platform without the virtual-memory calls (found out at the first reservation): hipMalloc per block
+inline std::atomic<int> &scheme() { static std::atomic<int> s{-1}; return s; }       // 0 blocks, 1 arenas
+inline bool useArenas() {
+    int v = scheme().load(std::memory_order_relaxed);
+    if (v < 0) { const char *e = cdmenv::get("CDM_POOL"); v = (e && !strcmp(e, "blocks")) ? 0 : 1; scheme().store(v, std::memory_order_relaxed); }
+    return v == 1;
+}
+inline bool ensureArena(Pool &pool, Arena &a, bool small) {
+    if (a.base) return true;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) { (void) hipGetLastError(); return false; }
+    const size_t want = small ? 512 * SMALL_CHUNK : (2 * tot + LARGE_CHUNK - 1) / LARGE_CHUNK * LARGE_CHUNK;       // (addresses, not memory)
+    void *base = nullptr;
+    const hipError_t er = hipMemAddressReserve(&base, want, (size_t) 2 << 20, nullptr, 0);
+    if (er != hipSuccess || !base) {
+        if (cdmenv::get("CDM_POOL_DEBUG")) fprintf(stderr, "carpedeam pool: reserving %zu bytes of addresses failed: %s\n", want, hipGetErrorString(er));
+        (void) hipGetLastError(); return false;
+    }
+    a.base = (char *) base; a.reserved = want; a.end = 0; a.small = small;
+    Registry &r = registry();
+    std::lock_guard<std::mutex> g(r.m);
+    r.ranges.push_back(Range{a.base, a.base + want, &pool, &a});
+    return true;
+}
+
+// frees every cached block of `q` (CDM_POOL=blocks) and gives back the free chunks of its arenas.  Lock order: registry, then pool.
 inline void trimLocked(Registry &r, Pool &q) {
     std::lock_guard<std::mutex> g(q.m);
     for (auto &kv : q.freeBlocks) { r.blocks.erase(kv.second); (void) hipFree(kv.second); }
     q.freeBlocks.clear();
+    trimArena(q.small); trimArena(q.large);
 }
 inline void trim(Pool &q) { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); trimLocked(r, q); }
 inline void trimAll() { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); for (Pool *q : r.pools) trimLocked(r, *q); }
+// (registry lock held) an orphan whose last block came back goes
+inline bool retireIfDone(Registry &r, Pool *q) {
+    {
+        std::lock_guard<std::mutex> g(q->m);
+        if (!q->orphan || q->small.used || q->large.used) return false;
+        for (auto &kv : q->freeBlocks) { r.blocks.erase(kv.second); (void) hipFree(kv.second); }
+        q->freeBlocks.clear();
+        destroyArena(r, q->small); destroyArena(r, q->large);
+    }
+    for (size_t i = 0; i < r.pools.size(); i++) if (r.pools[i] == q) { r.pools[i] = r.pools.back(); r.pools.pop_back(); break; }
+    delete q;
+    return true;
+}
 struct Pools {
-    Pool p[64];
-    Pools() { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); for (Pool &q : p) r.pools.push_back(&q); }
-    // a thread that ends gives its cached blocks back and leaves the registry: the blocks it allocated that are still in use stay
-    // registered with no owner (whoever frees them releases them), so that a later thread whose caches happen to get this
-    // address is not taken for their owner.  (The main thread's end is the end of the process: the HIP runtime may be half-way
-    // through its own tear-down by then, so nothing is freed there.)
+    Pool *p[64] = {};
+    // a thread that ends gives back what its pools hold and leaves the registry; blocks of it that are still in use keep their arena
+    // as an orphan (exact-size blocks: they stay registered with no owner, whoever frees them releases them).  (The main thread's end
+    // is the end of the process: the HIP runtime may be half-way through its own tear-down by then, so nothing is freed there.)
     ~Pools() {
         Registry &r = registry();
         std::lock_guard<std::mutex> g(r.m);
         const bool mainThread = getpid() == (pid_t) syscall(SYS_gettid);
-        for (Pool &q : p) {
-            if (!mainThread) trimLocked(r, q);
-            for (size_t i = 0; i < r.pools.size(); i++) if (r.pools[i] == &q) { r.pools[i] = r.pools.back(); r.pools.pop_back(); break; }
+        for (Pool *q : p) {
+            if (!q) continue;
+            if (mainThread) continue;
+            trimLocked(r, *q);
+            for (auto &kv : r.blocks) if (kv.second.second == q) kv.second.second = nullptr;
+            { std::lock_guard<std::mutex> g2(q->m); q->orphan = true; }
+            (void) retireIfDone(r, q);
         }
-        for (auto &kv : r.blocks) if (kv.second.second >= p && kv.second.second < p + 64) kv.second.second = nullptr;
     }
 };
-inline Pool &poolOf(int dev) { static thread_local Pools pools; return pools.p[dev & 63]; }
+inline Pool &poolOf(int dev) {
+    static thread_local Pools pools;
+    Pool *&q = pools.p[dev & 63];
+    if (!q) { q = new Pool(); q->device = dev; Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); r.pools.push_back(q); }
+    return *q;
+}
 
 // Head room for workloads whose buffers GROW from call to call (the contig iterations of the workflow loop: sequences, tuples and
-// records get ~1.5x longer per iteration, so no cached block ever fits the next request and every iteration maps tens of GB anew -
-// which costs ~46 ms per GB on some hosts, 0.1-1.1 s per iteration at 1-2 M reads).  With a factor f > 1 a large block is allocated
-// f times the request - where a cached block of at least half the size shows that the buffer grows - and a cached block up to that
-// much larger than a request is taken: the next iteration's buffers fit the previous iteration's blocks.  Off (1) by default;
-// `ancient_reads_loop` switches it on.  Process-wide, set from any thread.
+// records get 1.02-1.5x longer per iteration).  With a factor f > 1 a large block is handed out f times the request - where a free
+// block of at least half the size shows that the buffer grows - and a free block up to that much larger than a request is taken
+// whole: the next iteration's buffer fits where this one's was, instead of moving to the arena's end every time.  Off (1) by
+// default; `ancient_reads_loop` switches it on.  Process-wide, set from any thread.
 inline std::atomic<float> &headroom() { static std::atomic<float> h{1.0f}; return h; }
 
 inline int poisonByte() {
     // CDM_POOL_POISON=<byte>: every block handed out is filled with that byte first (tests: a kernel that reads what it never wrote
-    // shows itself; fresh device memory is zero, a cached block holds its last owner's data)
+    // shows itself; fresh device memory is zero, a reused range holds its last owner's data)
     static const int poison = cdmenv::get("CDM_POOL_POISON") ? (int) strtol(cdmenv::get("CDM_POOL_POISON"), NULL, 0) & 0xFF : -1;
     return poison;
 }
+inline hipError_t allocateBlocks(Pool &pool, void **p, size_t bytes);
 inline hipError_t allocate(void **p, size_t bytes) {
     int dev = 0; (void) hipGetDevice(&dev);
     Pool &pool = poolOf(dev);
+    stats().requests.fetch_add(1, std::memory_order_relaxed);
+    if (!useArenas()) return allocateBlocks(pool, p, bytes);
+    const bool small = bytes < SMALL_MAX;
+    const size_t align = small ? 256 : (size_t) 4096;
+    bytes = (bytes + align - 1) / align * align;
+    if (bytes == 0) bytes = align;
+    const float hr = headroom().load(std::memory_order_relaxed);
+    const int poison = poisonByte();
+    size_t got = 0;
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        {
+            std::unique_lock<std::mutex> g(pool.m);
+            Arena &a = small ? pool.small : pool.large;
+            if (!a.base) {
+                g.unlock();
+                const bool ok = ensureArena(pool, a, small);
+                if (!ok) {      // no virtual-memory calls here: exact-size blocks from now on (said once)
+                    if (scheme().exchange(0) != 0) fprintf(stderr, "carpedeam: hipMemAddressReserve is not available on this device; device memory comes from hipMalloc per buffer\n");
+                    return allocateBlocks(pool, p, bytes);
+                }
+                g.lock();
+            }
+            bool roomy = hr > 1.0f && bytes >= ROOMY_MIN;
+            if (roomy) {        // head room only where growth shows: a free block that just fails to hold the request
+                auto it = a.freeBySize.lower_bound(bytes);
+                roomy = it != a.freeBySize.begin() && std::prev(it)->first >= bytes / 2;
+                if (!roomy && it != a.freeBySize.end() && it->first <= (size_t) ((double) bytes * hr * 1.125)) roomy = true;     // (a block with head room: kept whole)
+            }
+            const size_t keep = roomy ? ((size_t) ((double) bytes * hr) + align - 1) / align * align : bytes;
+            void *q = takeBlock(a, bytes, keep);
+            if (q) stats().cached.fetch_add(1, std::memory_order_relaxed);
+            else {
+                e = growArena(a, pool.device, keep);
+                if (e != hipSuccess && keep > bytes) e = growArena(a, pool.device, bytes);       // (no room for the head room)
+                if (e == hipSuccess) q = takeBlock(a, bytes, keep);
+            }
+            if (q) { *p = q; got = a.blocks[(size_t) ((char *) q - a.base)].size; break; }
+        }
+        if (attempt == 0) {     // out of memory: every thread's free chunks go back to the driver, then once more
+            (void) hipGetLastError();
+            (void) hipDeviceSynchronize();       // (another thread's free range may still be read by that thread's stream)
+            trimAll();
+            stats().trims.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
+    if (!got) return e == hipSuccess ? hipErrorOutOfMemory : e;
+    if (poison >= 0) { (void) hipDeviceSynchronize(); (void) hipMemset(*p, poison, got); (void) hipDeviceSynchronize(); }
+    return hipSuccess;
+}
+inline void releaseBlocks(Pool &pool, void *p);
+inline void release(void *p) {
+    if (!p) return;
+    int dev = 0; (void) hipGetDevice(&dev);
+    Pool &mine = poolOf(dev);
+    Registry &r = registry();
+    Pool *owner = nullptr; Arena *arena = nullptr;
+    {
+        std::lock_guard<std::mutex> g(r.m);
+        for (const Range &x : r.ranges) if ((char *) p >= x.lo && (char *) p < x.hi) { owner = x.pool; arena = x.arena; break; }
+    }
+    if (!owner) { releaseBlocks(mine, p); return; }
+    if (owner != &mine) (void) hipDeviceSynchronize();          // the owner's stream takes the range next: this thread's work on it must be over
+    std::lock_guard<std::mutex> g(r.m);
+    { std::lock_guard<std::mutex> g2(owner->m); giveBlock(*arena, (size_t) ((char *) p - arena->base)); }
+    if (owner != &mine) (void) retireIfDone(r, owner);
+}
+inline void trimMine() { int dev = 0; (void) hipGetDevice(&dev); trim(poolOf(dev)); }
+
+// ---- CDM_POOL=blocks: one hipMalloc per block, freed blocks cached by exact size per thread (the scheme of rounds 1-3)
+inline hipError_t allocateBlocks(Pool &pool, void **p, size_t bytes) {
     bytes = (bytes + 255) & ~(size_t) 255;
     if (bytes == 0) bytes = 256;
     const float hr = headroom().load(std::memory_order_relaxed);
-    bool roomy = hr > 1.0f && bytes >= ((size_t) 64 << 20);
+    bool roomy = hr > 1.0f && bytes >= ROOMY_MIN;
     const size_t take = roomy ? (size_t) ((double) bytes * hr * 1.125) : bytes + bytes / 8;
     const int poison = poisonByte();
     {
@@ -124,38 +394,35 @@ inline hipError_t allocate(void **p, size_t bytes) {
         if (it != pool.freeBlocks.end() && it->first <= take) {
             *p = it->second; const size_t have = it->first; pool.freeBlocks.erase(it);
             g.unlock();
+            stats().cached.fetch_add(1, std::memory_order_relaxed);
             if (poison >= 0) { (void) hipDeviceSynchronize(); (void) hipMemset(*p, poison, have); (void) hipDeviceSynchronize(); }
             return hipSuccess;
         }
-        // head room only where growth shows: a cached block that just fails to hold the request (at least half its size) is the trace
-        // of the same buffer one call earlier; a first allocation of its kind (the reads, a one-shot module) gets the exact size
         if (roomy) roomy = it != pool.freeBlocks.begin() && std::prev(it)->first >= bytes / 2;
     }
     auto record = [&](size_t size) { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); r.blocks[*p] = {size, &pool}; };
     if (roomy) {
         const size_t want = ((size_t) ((double) bytes * hr) + 255) & ~(size_t) 255;
-        if (hipMalloc(p, want) == hipSuccess) {
+        if (timedMalloc(p, want) == hipSuccess) {
             record(want);
             if (poison >= 0) { (void) hipMemset(*p, poison, want); (void) hipDeviceSynchronize(); }
             return hipSuccess;
         }
         (void) hipGetLastError();       // (no room for the head room: the exact size below)
     }
-    hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = timedMalloc(p, bytes);
     if (e != hipSuccess) {   // out of memory with blocks parked in the caches - this thread's or another's: release them all and retry once
         (void) hipGetLastError();
         (void) hipDeviceSynchronize();       // (another thread's parked block may still be read by that thread's stream)
         trimAll();
-        e = hipMalloc(p, bytes);
+        stats().trims.fetch_add(1, std::memory_order_relaxed);
+        e = timedMalloc(p, bytes);
     }
     if (e == hipSuccess) record(bytes);
     if (e == hipSuccess && poison >= 0) { (void) hipMemset(*p, poison, bytes); (void) hipDeviceSynchronize(); }
     return e;
 }
-inline void release(void *p) {
-    if (!p) return;
-    int dev = 0; (void) hipGetDevice(&dev);
-    Pool &pool = poolOf(dev);
+inline void releaseBlocks(Pool &pool, void *p) {
     size_t bytes = 0;
     {
         Registry &r = registry();
@@ -167,5 +434,4 @@ inline void release(void *p) {
     if (bytes) { std::lock_guard<std::mutex> g(pool.m); pool.freeBlocks.emplace(bytes, p); }
     else (void) hipFree(p);
 }
-inline void trimMine() { int dev = 0; (void) hipGetDevice(&dev); trim(poolOf(dev)); }
 }  // namespace cdmpool

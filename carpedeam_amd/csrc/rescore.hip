@@ -216,6 +216,7 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     const uint32_t n = (uint32_t) db->n;
     const uint64_t nHits = hits->count;
     if (db->maxLen >= (1u << 30)) { cdm_set_error("cdm_rescore: sequence too long"); return CDM_ERR_UNSUPPORTED; }
+    if (nHits >= 0xFFFFFF00ull) { cdm_set_error("cdm_rescore: %llu prefilter hits (a call takes fewer than 2^32)", (unsigned long long) nHits); return CDM_ERR_UNSUPPORTED; }
     DevBuf<unsigned int> undef;
     if (!undef.alloc(2)) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
     CDM_HIP(hipMemsetAsync(undef.p, 0, 8, s));
@@ -246,7 +247,7 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     a.minScore = dMin.p; a.nHits = nHits; a.n = n; a.seqIdThr = par->seq_id_thr; a.covThr = par->cov_thr; a.covMode = par->cov_mode;
     a.minAlnLen = par->min_aln_len; a.tmp = tmp.p; a.tmpRy = tmpRy.p; a.valid = valid.p; a.undef = undef.p;
     hipEventRecord(ctx->ev0, s);
-    if (nHits) hipLaunchKernelGGL(k_rescore, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, s, a, owner.p);
+    if (nHits) hipLaunchKernelGGL(k_rescore, CDM_GRID((nHits + 255) / 256, 256), dim3(256), 0, s, a, owner.p);
     hipEventRecord(ctx->ev1, s);
     hipLaunchKernelGGL(k_count_valid, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid.p, n, cnt.p);
     CDM_LAUNCH_CHECK();
@@ -263,7 +264,7 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     res->count = total; res->undefinedRecords = nUndef;
     if (cdmMalloc(&res->rec, (total + 1) * sizeof(AlnRec)) != hipSuccess || cdmMalloc(&res->ryMism, (total + 1) * sizeof(uint16_t)) != hipSuccess) { cdm_set_error("cdm_rescore: out of device memory"); return CDM_ERR_HIP; }
     res->rySerial = db->serial;
-    if (nHits) hipLaunchKernelGGL(k_scatter, dim3((unsigned) ((nHits + 255) / 256)), dim3(256), 0, s, hits->off, (const uint32_t *) owner.p, valid.p, tmp.p, tmpRy.p, (uint64_t) nHits, res->off, res->rec, res->ryMism);
+    if (nHits) hipLaunchKernelGGL(k_scatter, CDM_GRID((nHits + 255) / 256, 256), dim3(256), 0, s, hits->off, (const uint32_t *) owner.p, valid.p, tmp.p, tmpRy.p, (uint64_t) nHits, res->off, res->rec, res->ryMism);
     hipLaunchKernelGGL(k_scatter_big, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, valid.p, tmp.p, tmpRy.p, n, res->off, res->rec, res->ryMism);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_set_error("cdm_rescore: compaction failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     hipEventElapsedTime(&ctx->lastMs[1], ctx->ev0, ctx->ev1);

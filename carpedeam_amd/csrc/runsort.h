@@ -635,7 +635,7 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
         // a boundary no record reaches (there is none: the records tile [0, n)) would leave its unit empty
         hipMemsetAsync(uStart.p, 0, (units + 2) * 8, s); hipMemsetAsync(uEnd.p, 0, (units + 1) * 8, s); hipMemsetAsync(uRec.p, 0, (units + 2) * 8, s);
         UnitBoundArgs ub; ub.recRep = recRep; ub.dst = dst; ub.nRec = nRec; ub.maxSeg = maxSeg; ub.units = units; ub.uStart = uStart.p; ub.uEnd = uEnd.p; ub.uRec = uRec.p;
-        hipLaunchKernelGGL(k_unit_bounds, dim3((unsigned) ((nRec + 1023) / 1024)), dim3(1024), 0, s, ub);
+        hipLaunchKernelGGL(k_unit_bounds, CDM_GRID((nRec + 1023) / 1024, 1024), dim3(1024), 0, s, ub);
         UnitClassArgs uc; uc.uStart = uStart.p; uc.uEnd = uEnd.p; uc.uRec = uRec.p; uc.units = units; uc.n = n;
         for (int c = 0; c < U_CLASSES; c++) { uc.cap[c] = (uint32_t) U_CLASS_CAP[c]; uc.list[c] = uList[c].p; }
         uc.cnt = cnt.p + SEG_CLASSES + 1;
@@ -656,7 +656,7 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
     la.cap[0] = 0; la.cap[1] = 0; la.cap[2] = blockCap;
     for (int c = 0; c < SEG_CLASSES; c++) la.list[c] = lists[c].p;      // (classes 0 and 1 stay empty: their capacities are 0)
     la.cnt = cnt.p;
-    hipLaunchKernelGGL(k_seg_list, dim3((unsigned) ((nRec + 1023) / 1024)), dim3(1024), 0, s, la);
+    hipLaunchKernelGGL(k_seg_list, CDM_GRID((nRec + 1023) / 1024, 1024), dim3(1024), 0, s, la);
     const unsigned int gatherGrid = (unsigned int) std::min<uint64_t>((uint64_t) cuCount * 8, listCap + units + 1);
     BlockSortArgs ba; ba.in = in; ba.out = out; ba.shiftHi = shiftHi; ba.ign = 1;
     ba.list = lists[2].p; ba.count = cnt.p + 2;

@@ -85,7 +85,7 @@ int cdm_synth_impl(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, uint64_t n, ui
         hipMemsetAsync(db->nmask, 0, maskWords * 4, s);
         hipMemsetAsync(db->ext, 0, n, s);
         hipMemsetAsync(db->hasN, 0, n, s);
-        hipLaunchKernelGGL(k_synth, dim3((unsigned) (((uint64_t) words + 255) / 256)), dim3(256), 0, s, a, db->woff, db->len, (uint64_t) words, db->codes);
+        hipLaunchKernelGGL(k_synth, CDM_GRID(((uint64_t) words + 255) / 256, 256), dim3(256), 0, s, a, db->woff, db->len, (uint64_t) words, db->codes);
         hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess) { cdm_set_error("cdm_seqdb_synth: generator failed: %s", hipGetErrorString(e)); ret = CDM_ERR_HIP; break; }
         db->maxLen = hi; db->nCount = 0;
