@@ -313,8 +313,9 @@ int cdm_cyclecheck(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t max_seq_len, int 
  * xGMI called directly (csrc/dist.hip).  The reference shards inside its modules - kmermatcher by k-mer range
  * (lib/mmseqs/src/linclust/kmermatcher.cpp:634-663, merged :742-784), rescorediagonal by query range
  * (lib/mmseqs/src/alignment/rescorediagonal.cpp:399-421) - and so do these calls: every rank holds the whole sequence DB, the result is
- * bit-identical to the single-device calls (the k-mer-range split of cdm_kmermatch_part + ONE all-to-all of the group keys to the owners
- * of their representatives + the owned ranges of the stages' result DBs all-gathered).
+ * bit-identical to the single-device calls (kmermatcher's first half: every rank extracts its block of the sequences, all-to-alls
+ * carry the k-mer tuples to the rank of their k-mer range - cdm_kmermatch_split_* -; ONE all-to-all of the group keys to the owners of
+ * their representatives; the owned ranges of the stages' result DBs all-gathered).
  *   cdm_comm_unique_id       rank 0: the 128 bytes of ncclGetUniqueId, to be handed to every rank by whatever launched them
  *   cdm_comm_create_rccl     a rank's communicator (ncclCommInitRank on the context's device; librccl is loaded on first use)
  *   cdm_comm_create_ops      the same over collectives the caller supplies (tests: W ranks on one device; another collective library)
