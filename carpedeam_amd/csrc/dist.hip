@@ -65,8 +65,27 @@ struct cdm_comm {
     cdm_ctx *ctx = nullptr; int rank = 0, world = 1;
     cdm_comm_ops ops;                   // the transport (RCCL's functions below, or the caller's)
     void *nccl = nullptr;               // ncclComm_t of the RCCL transport
-    void *stage = nullptr; size_t stageBytes = 0;       // device staging of the host all-gather (RCCL transport)
+    // What RCCL reads and writes are buffers of THIS transport, from hipMalloc: the library's own buffers live in arenas of mapped
+    // memory (csrc/pool.h: hipMemCreate / hipMemMap, access granted to the owning device only), and a peer device or another
+    // process must never be pointed at those - RCCL may hand a user buffer's address to the peer (ranks as threads of one process).
+    // A copy on either side of a transfer costs 2 x bytes / 5 TB/s against bytes / 0.15 TB/s for the link.  CDM_RCCL_DIRECT=1: RCCL
+    // on the caller's buffers (A/B).
+    struct Stage { void *p = nullptr; size_t bytes = 0; } stage, sendStage, recvStage;
 };
+namespace {
+int ensureStage(cdm_comm *c, cdm_comm::Stage &st, size_t need) {
+    if (need <= st.bytes) return CDM_OK;
+    CDM_HIP(hipStreamSynchronize(c->ctx->stream));
+    if (st.p) (void) hipFree(st.p);
+    st.p = nullptr; st.bytes = 0;
+    const size_t want = need + need / 4 + 256;
+    if (hipMalloc(&st.p, want) != hipSuccess && hipMalloc(&st.p, need + 256) != hipSuccess && (cdmPoolTrim(), hipMalloc(&st.p, need + 256)) != hipSuccess) {     // (the arenas give back what is free)
+        (void) hipGetLastError(); st.p = nullptr; cdm_set_error("RCCL transport: out of device memory for %zu bytes of exchange buffer", need); return CDM_ERR_HIP; }
+    st.bytes = need;        // (at least)
+    return CDM_OK;
+}
+bool rcclDirect() { const char *e = cdmGetenv("CDM_RCCL_DIRECT"); return e && *e == '1'; }
+}  // namespace
 #define CDM_NCCL(call, what) do { const int e_ = (call); if (e_ != 0) { cdm_set_error("RCCL %s failed: %s", what, rccl(nullptr)->errorString ? rccl(nullptr)->errorString(e_) : "?"); return CDM_ERR_HIP; } } while (0)
 
 // ---- RCCL transport
@@ -74,8 +93,8 @@ namespace {
 int rcclAllGatherHost(void *user, const void *send, void *recv, uint64_t bytes) {
     cdm_comm *c = (cdm_comm *) user; Rccl *r = rccl(nullptr);
     const size_t need = (size_t) bytes * (size_t) (c->world + 1);
-    if (need > c->stageBytes) { if (c->stage) cdmFree(c->stage); c->stage = nullptr; c->stageBytes = 0; if (cdmMalloc((char **) &c->stage, need + 256) != hipSuccess) { cdm_set_error("all-gather: out of device memory"); return CDM_ERR_HIP; } c->stageBytes = need; }
-    char *dSend = (char *) c->stage, *dRecv = dSend + bytes;
+    if (int rc = ensureStage(c, c->stage, need)) return rc;
+    char *dSend = (char *) c->stage.p, *dRecv = dSend + bytes;
     hipStream_t s = c->ctx->stream;
     CDM_HIP(hipMemcpyAsync(dSend, send, bytes, hipMemcpyHostToDevice, s));
     CDM_NCCL(r->allGather(dSend, dRecv, bytes, NCCL_CHAR, c->nccl, s), "all-gather");
@@ -88,26 +107,46 @@ int rcclAllGatherHost(void *user, const void *send, void *recv, uint64_t bytes) 
 int rcclAllToAllDev(void *user, const void *send, const uint64_t *sendOff, void *recv, const uint64_t *recvOff, void *stream) {
     cdm_comm *c = (cdm_comm *) user; Rccl *r = rccl(nullptr);
     hipStream_t s = (hipStream_t) stream;
+    const int W = c->world;
+    const bool direct = rcclDirect();
+    const char *src = (const char *) send; char *dst = (char *) recv;
+    if (!direct) {
+        if (int rc = ensureStage(c, c->sendStage, sendOff[W] - sendOff[0])) return rc;
+        if (int rc = ensureStage(c, c->recvStage, recvOff[W] - recvOff[0])) return rc;
+        if (sendOff[W] > sendOff[0]) CDM_HIP(hipMemcpyAsync(c->sendStage.p, src + sendOff[0], sendOff[W] - sendOff[0], hipMemcpyDeviceToDevice, s));
+        src = (const char *) c->sendStage.p - sendOff[0]; dst = (char *) c->recvStage.p - recvOff[0];
+    }
     CDM_NCCL(r->groupStart(), "group start");
-    for (int p = 0; p < c->world; p++) {
+    for (int p = 0; p < W; p++) {
         const uint64_t ns = sendOff[p + 1] - sendOff[p], nr = recvOff[p + 1] - recvOff[p];
-        if (ns) CDM_NCCL(r->send((const char *) send + sendOff[p], ns, NCCL_CHAR, p, c->nccl, s), "send");
-        if (nr) CDM_NCCL(r->recv((char *) recv + recvOff[p], nr, NCCL_CHAR, p, c->nccl, s), "recv");
+        if (ns) CDM_NCCL(r->send(src + sendOff[p], ns, NCCL_CHAR, p, c->nccl, s), "send");
+        if (nr) CDM_NCCL(r->recv(dst + recvOff[p], nr, NCCL_CHAR, p, c->nccl, s), "recv");
     }
     CDM_NCCL(r->groupEnd(), "group end");
+    if (!direct && recvOff[W] > recvOff[0]) CDM_HIP(hipMemcpyAsync((char *) recv + recvOff[0], c->recvStage.p, recvOff[W] - recvOff[0], hipMemcpyDeviceToDevice, s));
     return CDM_OK;
 }
 // every rank contributes sendBytes (they differ): recv[recvOff[p], recvOff[p + 1]) = rank p's
 int rcclAllGatherDev(void *user, const void *send, uint64_t sendBytes, void *recv, const uint64_t *recvOff, void *stream) {
     cdm_comm *c = (cdm_comm *) user; Rccl *r = rccl(nullptr);
     hipStream_t s = (hipStream_t) stream;
+    const int W = c->world;
+    const bool direct = rcclDirect();
+    const char *src = (const char *) send; char *dst = (char *) recv;
+    if (!direct) {
+        if (int rc = ensureStage(c, c->sendStage, sendBytes)) return rc;
+        if (int rc = ensureStage(c, c->recvStage, recvOff[W] - recvOff[0])) return rc;
+        if (sendBytes) CDM_HIP(hipMemcpyAsync(c->sendStage.p, send, sendBytes, hipMemcpyDeviceToDevice, s));
+        src = (const char *) c->sendStage.p; dst = (char *) c->recvStage.p - recvOff[0];
+    }
     CDM_NCCL(r->groupStart(), "group start");
-    for (int p = 0; p < c->world; p++) {
+    for (int p = 0; p < W; p++) {
         const uint64_t nr = recvOff[p + 1] - recvOff[p];
-        if (sendBytes) CDM_NCCL(r->send(send, sendBytes, NCCL_CHAR, p, c->nccl, s), "send");
-        if (nr) CDM_NCCL(r->recv((char *) recv + recvOff[p], nr, NCCL_CHAR, p, c->nccl, s), "recv");
+        if (sendBytes) CDM_NCCL(r->send(src, sendBytes, NCCL_CHAR, p, c->nccl, s), "send");
+        if (nr) CDM_NCCL(r->recv(dst + recvOff[p], nr, NCCL_CHAR, p, c->nccl, s), "recv");
     }
     CDM_NCCL(r->groupEnd(), "group end");
+    if (!direct && recvOff[W] > recvOff[0]) CDM_HIP(hipMemcpyAsync((char *) recv + recvOff[0], c->recvStage.p, recvOff[W] - recvOff[0], hipMemcpyDeviceToDevice, s));
     return CDM_OK;
 }
 }  // namespace
@@ -141,7 +180,7 @@ extern "C" int cdm_comm_create_ops(cdm_ctx *ctx, int rank, int world, const cdm_
 }
 extern "C" void cdm_comm_free(cdm_comm *c) {
     if (!c) return;
-    if (c->stage) cdmFree(c->stage);
+    for (cdm_comm::Stage *st : {&c->stage, &c->sendStage, &c->recvStage}) if (st->p) { (void) hipDeviceSynchronize(); (void) hipFree(st->p); st->p = nullptr; }
     if (c->nccl) { Rccl *r = rccl(nullptr); if (r) (void) r->commDestroy(c->nccl); }
     delete c;
 }
