@@ -448,6 +448,77 @@ int cdm_seqdb_select(cdm_ctx *ctx, const cdm_seqdb *db, const uint32_t *sel, int
     *out = o;
     return CDM_OK;
 }
+// ---- overlay: base with some of its sequences replaced (ancient_contig_merge: the grown contigs come up from the host, the others
+// never leave the device).  out[i] = grown[j] where idx[j] == i, else base[i]; keys are base's, ext comes from the caller.
+namespace {
+__global__ void k_ov_source(const uint32_t *__restrict__ idx, uint32_t m, uint32_t *__restrict__ src) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) src[idx[j]] = j;
+}
+__global__ void k_ov_words(const uint32_t *__restrict__ baseLen, const uint32_t *__restrict__ grownLen, const uint32_t *__restrict__ src, uint32_t n, uint32_t *__restrict__ w) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    w[i] = i < n ? ((src[i] == 0xFFFFFFFFu ? baseLen[i] : grownLen[src[i]]) + 15) / 16 : 0;
+}
+__global__ void k_ov_meta(const cdm_seqdb base, const cdm_seqdb grown, const uint32_t *__restrict__ src, const uint32_t *__restrict__ wordOff, const uint8_t *__restrict__ ext, uint32_t n, cdm_seqdb dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = src[i];
+    dst.len[i] = j == 0xFFFFFFFFu ? base.len[i] : grown.len[j];
+    dst.hasN[i] = j == 0xFFFFFFFFu ? base.hasN[i] : grown.hasN[j];
+    dst.key[i] = base.key[i]; dst.ext[i] = ext[i]; dst.woff[i] = wordOff[i];
+}
+__global__ void k_ov_copy(const cdm_seqdb base, const cdm_seqdb grown, const uint32_t *__restrict__ src, const uint32_t *__restrict__ wordOff, uint32_t n, uint32_t first, cdm_seqdb dst) {
+    const uint32_t i = first + (uint32_t) (((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;      // one wave per sequence of this launch's slice
+    if (i >= n) return;
+    const uint32_t j = src[i];
+    const cdm_seqdb &from = j == 0xFFFFFFFFu ? base : grown;
+    const uint32_t k = j == 0xFFFFFFFFu ? i : j;
+    const uint32_t L = from.len[k], w = (L + 15) / 16, s0 = from.woff[k], d0 = wordOff[i];
+    for (uint32_t x = lane; x < w; x += 64) {
+        dst.codes[d0 + x] = from.codes[s0 + x];
+        reinterpret_cast<uint16_t *>(dst.nmask)[d0 + x] = reinterpret_cast<const uint16_t *>(from.nmask)[s0 + x];
+    }
+    if (from.hasN[k] & 2u) for (uint32_t x = lane; x < L; x += 64) dst.raw[(uint64_t) d0 * 16 + x] = from.raw[(uint64_t) s0 * 16 + x];
+}
+}  // namespace
+int cdm_seqdb_overlay(cdm_ctx *ctx, const cdm_seqdb *base, const cdm_seqdb *grown, const uint32_t *idxHost, const uint8_t *extHost, cdm_seqdb **out) {
+    CDM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t) base->n, m = grown ? (uint32_t) grown->n : 0u;
+    DevBuf<uint32_t> src, idx, w, wordOff; DevBuf<uint8_t> ext;
+    if (!src.alloc(n) || !idx.alloc(m) || !w.alloc((size_t) n + 1) || !wordOff.alloc((size_t) n + 1) || !ext.alloc(n)) { cdm_set_error("cdm_seqdb_overlay: out of device memory"); return CDM_ERR_HIP; }
+    CDM_HIP(hipMemsetAsync(src.p, 0xFF, (size_t) n * 4, s));
+    if (m) CDM_HIP(hipMemcpyAsync(idx.p, idxHost, (size_t) m * 4, hipMemcpyHostToDevice, s));
+    CDM_HIP(hipMemcpyAsync(ext.p, extHost, n, hipMemcpyHostToDevice, s));
+    if (m) hipLaunchKernelGGL(k_ov_source, dim3((m + 255) / 256), dim3(256), 0, s, idx.p, m, src.p);
+    const cdm_seqdb &g = grown ? *grown : *base;
+    hipLaunchKernelGGL(k_ov_words, dim3((n + 256) / 256), dim3(256), 0, s, base->len, g.len, src.p, n, w.p);
+    cdmscan::ScanTemp st;
+    if (cdmscan::exclusiveScan<uint32_t>(s, st, w.p, wordOff.p, (size_t) n + 1) != CDM_OK) return CDM_ERR_HIP;
+    if ((uint64_t) base->words + (grown ? grown->words : 0) >= 0xFFFFFF00ull) { cdm_set_error("cdm_seqdb_overlay: more than 2^32 code words (68 G bases) in one DB"); return CDM_ERR_UNSUPPORTED; }
+    uint32_t words = 0;
+    CDM_HIP(hipMemcpyAsync(&words, wordOff.p + n, 4, hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipStreamSynchronize(s));
+    cdm_seqdb *o = nullptr;
+    int rc = cdm_seqdb_alloc(ctx, n, &o);
+    if (rc == CDM_OK) rc = seqdb_alloc_codes(o, words);
+    if (rc == CDM_OK && (base->raw || (grown && grown->raw))) rc = cdm_seqdb_alloc_raw(o);
+    if (rc != CDM_OK) { if (o) cdm_seqdb_free(o); return rc; }
+    hipMemsetAsync(o->nmask, 0, (((uint64_t) words * 16 + 31) / 32 + 1) * 4, s);
+    if (n) hipLaunchKernelGGL(k_ov_meta, dim3((n + 255) / 256), dim3(256), 0, s, *base, g, src.p, wordOff.p, ext.p, n, *o);
+    for (uint64_t first = 0, slice = cdmSliceItems(64); first < n; first += slice)
+        hipLaunchKernelGGL(k_ov_copy, CDM_GRID((std::min<uint64_t>(slice, n - first) * 64 + 255) / 256, 256), dim3(256), 0, s, *base, g, src.p, wordOff.p, n, (uint32_t) first, *o);
+    hipMemcpyAsync(o->woff + n, &words, 4, hipMemcpyHostToDevice, s);
+    std::vector<uint32_t> l(n);
+    hipMemcpyAsync(l.data(), o->len, (size_t) n * 4, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_overlay: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
+    for (uint32_t v : l) { o->residues += v; o->maxLen = std::max(o->maxLen, v); }
+    o->nCount = base->nCount + (grown ? grown->nCount : 0);
+    *out = o;
+    return CDM_OK;
+}
 extern "C" int cdm_seqdb_select_ext(cdm_ctx *ctx, const cdm_seqdb *db, cdm_seqdb **out) {
     CDM_HIP(hipSetDevice(ctx->device));
     const uint32_t n = (uint32_t) db->n;

@@ -139,6 +139,7 @@ struct MetaHasN { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint3
 struct MetaKey { const SeqMeta *m; __host__ __device__ uint32_t operator[](uint32_t i) const { return m[i].key; } };
 struct MetaExt { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) ((m[i].flags >> 1) & 1u); } };
 struct MetaRaw { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) ((m[i].flags >> 2) & 1u); } };
+int cdm_seqdb_overlay(cdm_ctx *ctx, const cdm_seqdb *base, const cdm_seqdb *grown, const uint32_t *idxHost, const uint8_t *extHost, cdm_seqdb **out);      // api.hip
 int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out);      // cdmFree the result
 
 // (the consumers of an alignment set call this first)
@@ -208,6 +209,7 @@ struct ContigStat {            // per alignment record, oriented as :193-214 doe
     int32_t idCnt, idRy;       // identical / same-RY-class letters over [qs, qe] (:217-223; N == N counts)
     int32_t nnTot, nnId, nnRy; // the same over the columns where neither letter is N (what the consensus loops see, safe mode)
     int32_t nCT, nGA;          // query C over target T, query G over target A among those (ancientMatchCount's dimers)
+    uint32_t dbLen, dbKey;     // the target's length and key (the host's candidate gate reads nothing else of the target: no look-up per record there)
 };
 
 // stage implementations (one .hip file each)

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void k_contig_stats(StatArgs a) {
     const uint32_t q = a.owner[r];
     const SeqMeta qm = a.meta[q], tm = a.meta[rec.target];
     ContigStat s;
+    s.dbLen = tm.len; s.dbKey = tm.key;
     s.rev = rec.qStart > rec.qEnd;
     if (s.rev) { s.qs = rec.qEnd; s.qe = rec.qStart; s.ds = (int) tm.len - rec.dbEnd - 1; s.de = (int) tm.len - rec.dbStart - 1; }
     else { s.qs = rec.qStart; s.qe = rec.qEnd; s.ds = rec.dbStart; s.de = rec.dbEnd; }
@@ -89,13 +90,12 @@ __global__ void k_rec_owner(const uint64_t *__restrict__ aoff, uint32_t n, uint3
 }  // namespace
 
 // host/contigmerge.cpp
-// (host/contigmerge.cpp, OpenMP) the DB blob as one string per sequence / the strings as one DB blob "SEQ\n\0..."
+// (host/contigmerge.cpp, OpenMP) the DB blob as one view per sequence
+bool cdm_host_pack(const std::vector<std::string> &seqs, HostBuf<char> &data, std::vector<uint64_t> &off, std::vector<uint32_t> &len);
 void cdm_host_split(const char *blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<SeqView> &seqs);
-bool cdm_host_pack(const std::vector<SeqView> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, HostBuf<char> &data,
-                   std::vector<uint64_t> &off, std::vector<uint32_t> &len);
 int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
                           const cdm_aln *recs, const ContigStat *stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
-                          float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::vector<uint8_t> &changed, std::string *err);
+                          float mergeSeqIdThr, std::vector<uint32_t> &grownIdx, std::vector<std::string> &grownSeqs, std::vector<uint8_t> &outExt, std::string *err);
 
 extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float mergeSeqIdThr, cdm_seqdb **out) {
     if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_contig_merge: NULL argument"); return CDM_ERR_INVALID; }
@@ -138,18 +138,28 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     lap("statistics + records down");
     if (int rc = cdm_seqdb_download(ctx, db, blob.data(), offs.data())) return rc;
     lap("sequences down");
-    std::vector<SeqView> seqs(n); std::vector<std::string> outSeqs; std::vector<uint8_t> outExt, changed;
-    cdm_host_split(blob.data(), offs, lens, seqs);      // views into the blob, which stays until the result is packed
+    std::vector<SeqView> seqs(n); std::vector<uint32_t> grownIdx; std::vector<std::string> grownSeqs; std::vector<uint8_t> outExt;
+    cdm_host_split(blob.data(), offs, lens, seqs);      // views into the blob, which stays until the host part is done
     lap("split");
     std::string err;
-    if (int rc = cdm_contig_merge_host(seqs, keys, ext, aoff, recs.data(), stats.data(), ctx->mats, par, mergeSeqIdThr, outSeqs, outExt, changed, &err)) { cdm_set_error("%s", err.c_str()); return rc; }
+    if (int rc = cdm_contig_merge_host(seqs, keys, ext, aoff, recs.data(), stats.data(), ctx->mats, par, mergeSeqIdThr, grownIdx, grownSeqs, outExt, &err)) { cdm_set_error("%s", err.c_str()); return rc; }
     lap("queues + extension (host)");
-    // the result goes back up as a DB (same keys, new lengths and flags)
-    std::vector<uint64_t> oOff; std::vector<uint32_t> oLen; HostBuf<char> data;
-    if (!cdm_host_pack(seqs, outSeqs, changed, data, oOff, oLen)) { cdm_set_error("cdm_contig_merge: out of host memory"); return CDM_ERR_INVALID; }
-    { std::vector<std::string>().swap(outSeqs); std::vector<SeqView>().swap(seqs); blob.release(); stats.release(); recs.release(); }
-    lap("pack");
-    const int rcUp = cdm_seqdb_upload(ctx, data.data(), oOff.data(), oLen.data(), keys.data(), outExt.data(), n, out);
-    lap("upload");
+    // The result is the input DB with the grown contigs in place of their queries: only those go up (as a small DB of their own),
+    // everything else is copied on the device (cdm_seqdb_overlay).  Same keys, new lengths and flags.
+    { std::vector<SeqView>().swap(seqs); blob.release(); stats.release(); recs.release(); }
+    const size_t m = grownIdx.size();
+    cdm_seqdb *grown = nullptr;
+    if (m) {
+        std::vector<uint64_t> gOff; std::vector<uint32_t> gLen, gKey(m);
+        HostBuf<char> data;
+        if (!cdm_host_pack(grownSeqs, data, gOff, gLen)) { cdm_set_error("cdm_contig_merge: out of host memory"); return CDM_ERR_INVALID; }
+        for (size_t j = 0; j < m; j++) gKey[j] = keys[grownIdx[j]];
+        std::vector<std::string>().swap(grownSeqs);
+        lap("pack");
+        if (int rc = cdm_seqdb_upload(ctx, data.data(), gOff.data(), gLen.data(), gKey.data(), nullptr, m, &grown)) return rc;
+    }
+    const int rcUp = cdm_seqdb_overlay(ctx, db, grown, grownIdx.data(), outExt.data(), out);
+    if (grown) cdm_seqdb_free(grown);
+    lap("upload + overlay");
     return rcUp;
 }

@@ -234,26 +234,24 @@ void cdm_host_split(const char *blob, const std::vector<uint64_t> &offs, const s
 #pragma omp parallel for schedule(dynamic, 512) num_threads(cdm_host_threads())
     for (long i = 0; i < n; i++) { seqs[i].p = blob + offs[i]; seqs[i].n = lens[i]; }
 }
-// changed[i] != 0: sequence i is grown[i], otherwise still seqs[i].  The blob is written by all threads (first touch included).
-bool cdm_host_pack(const std::vector<SeqView> &seqs, const std::vector<std::string> &grown, const std::vector<uint8_t> &changed, HostBuf<char> &data,
-                   std::vector<uint64_t> &off, std::vector<uint32_t> &len) {
-    const long n = (long) seqs.size();
-    off.resize(n); len.resize(n);
+// the strings back to back in one blob (written by all threads, first touch included)
+bool cdm_host_pack(const std::vector<std::string> &seqs, HostBuf<char> &data, std::vector<uint64_t> &off, std::vector<uint32_t> &len) {
+    const long m = (long) seqs.size();
+    off.resize(m); len.resize(m);
     uint64_t total = 0;
-    for (long i = 0; i < n; i++) { const size_t L = changed[i] ? grown[i].size() : seqs[i].size(); off[i] = total; len[i] = (uint32_t) L; total += L + 2; }
+    for (long j = 0; j < m; j++) { off[j] = total; len[j] = (uint32_t) seqs[j].size(); total += seqs[j].size(); }
     if (!data.alloc(total + 1)) return false;
-#pragma omp parallel for schedule(dynamic, 512) num_threads(cdm_host_threads())
-    for (long i = 0; i < n; i++) {
-        const char *x = changed[i] ? grown[i].data() : seqs[i].data(); const size_t L = len[i];
-        char *d = data.data() + off[i]; memcpy(d, x, L); d[L] = '\n'; d[L + 1] = '\0';
-    }
+#pragma omp parallel for schedule(dynamic, 256) num_threads(cdm_host_threads())
+    for (long j = 0; j < m; j++) memcpy(data.data() + off[j], seqs[j].data(), seqs[j].size());
     return true;
 }
+// grownIdx (ascending) / grownSeqs: the queries that were extended and what they became; outExt: the wasExtended flag of every sequence
 int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
                           const cdm_aln *recs, const ContigStat *stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
-                          float mergeSeqIdThr, std::vector<std::string> &outSeqs, std::vector<uint8_t> &outExt, std::vector<uint8_t> &changed, std::string *err) {
+                          float mergeSeqIdThr, std::vector<uint32_t> &grownIdx, std::vector<std::string> &grownSeqs, std::vector<uint8_t> &outExt, std::string *err) {
     const size_t n = seqs.size();
-    outSeqs.assign(n, std::string()); outExt.assign(n, 0); changed.assign(n, 0);
+    grownIdx.clear(); grownSeqs.clear(); outExt.assign(n, 0);
+    std::vector<std::vector<std::pair<uint32_t, std::string>>> perThread((size_t) cdm_host_threads());
     const float ryThr = par->ry_seq_id_thr;
     bool undefinedCase = false;
     const bool timing = cdmGetenv("CDM_TIMING") != nullptr;       // per-thread seconds in: candidate gate, queue pops, string growth, parked hits
@@ -264,10 +262,16 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
         auto lap = [&](int k) { if (timing) { const double n2 = omp_get_wtime(); tl[k] += n2 - tm; tm = n2; } };
         std::vector<Res> contigs, parked;
         std::string revBuf;
-        std::vector<uint8_t> useReverse(n, 0);          // per thread, last writer wins within a query (:136-137,198,212)
+        std::vector<std::pair<uint32_t, std::string>> &mine = perThread[(size_t) omp_get_thread_num()];
 #pragma omp for schedule(dynamic, 100)
         for (size_t id = 0; id < n; id++) {
             const uint32_t queryKey = keys[id];
+            // useReverse[target] of the reference (:136-137,198,212): a per-thread array every record of the query writes, read back
+            // for the targets in the queue - i.e. the orientation of the query's LAST record with that target
+            auto useReverse = [&](uint32_t target) -> bool {
+                for (uint64_t r = aoff[id + 1]; r-- > aoff[id];) if (recs[r].target == target) return stats[r].rev != 0;
+                return false;
+            };
             const SeqView &q0 = seqs[id];
             unsigned qLen = (unsigned) q0.size();
             std::string query;                              // working copy, made once a candidate exists
@@ -280,7 +284,7 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
                 contigs.clear();
                 for (uint64_t r = aoff[id]; r < aoff[id + 1]; r++) {
                     const cdm_aln &a = recs[r]; const ContigStat &st = stats[r];
-                    Res x; x.target = a.target; x.dbKey = keys[a.target]; x.qLen = qLen; x.dbLen = (unsigned) seqs[a.target].size();
+                    Res x; x.target = a.target; x.dbKey = st.dbKey; x.qLen = qLen; x.dbLen = st.dbLen;
                     x.alnLength = (unsigned) std::max(std::abs(a.q_end - a.q_start), std::abs(a.db_end - a.db_start)) + 1u;
                     x.qStartPos = st.qs; x.qEndPos = st.qe; x.dbStartPos = st.ds; x.dbEndPos = st.de; x.isRev = st.rev != 0;
                     x.seqId = static_cast<float>(st.idCnt) / x.alnLength; x.rySeqId = static_cast<float>(st.idRy) / x.alnLength;
@@ -295,11 +299,10 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
             }
             for (uint64_t r = aoff[id]; r < aoff[id + 1]; r++) {
                 const cdm_aln &a = recs[r]; const ContigStat &st = stats[r];
-                Res x; x.target = a.target; x.dbKey = keys[a.target];
-                x.qLen = qLen; x.dbLen = (unsigned) seqs[a.target].size();
+                Res x; x.target = a.target; x.dbKey = st.dbKey;
+                x.qLen = qLen; x.dbLen = st.dbLen;
                 x.alnLength = (unsigned) std::max(std::abs(a.q_end - a.q_start), std::abs(a.db_end - a.db_start)) + 1u;     // Matcher::computeAlnLength
                 x.qStartPos = st.qs; x.qEndPos = st.qe; x.dbStartPos = st.ds; x.dbEndPos = st.de; x.isRev = st.rev != 0;
-                useReverse[a.target] = x.isRev ? 1 : 0;
                 x.seqId = static_cast<float>(st.idCnt) / x.alnLength;
                 x.rySeqId = static_cast<float>(st.idRy) / x.alnLength;
                 if (x.seqId >= mergeSeqIdThr && x.rySeqId >= ryThr && queryKey != x.dbKey) {
@@ -357,13 +360,13 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
                         if (rightOff > 0) { parked.push_back(best); continue; }
                         const unsigned fragLen = tLen - (de + 1);
                         if (query.size() + fragLen >= par->max_seq_len) break;
-                        query += useReverse[best.target] ? revComp(t.data(), fragLen) : t.substr(de + 1, fragLen);
+                        query += useReverse(best.target) ? revComp(t.data(), fragLen) : t.substr(de + 1, fragLen);
                         rightOff += fragLen;
                     } else if (qs == 0 && de == (tLen - 1)) {
                         if (leftOff > 0) { parked.push_back(best); continue; }
                         const unsigned fragLen = ds;
                         if (query.size() + fragLen >= par->max_seq_len) break;
-                        query = (useReverse[best.target] ? revComp(t.data() + (tLen - ds), fragLen) : t.substr(0, fragLen)) + query;
+                        query = (useReverse(best.target) ? revComp(t.data() + (tLen - ds), fragLen) : t.substr(0, fragLen)) + query;
                         leftOff += fragLen;
                     }
                 }
@@ -376,7 +379,7 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
                     // the target as the reference holds it here: its own letters, or getNuclRevFragment's (letter j = complement of letter tLen-1-j)
                     const SeqView &t0 = seqs[a.target];
                     const unsigned tLen = (unsigned) t0.size();
-                    const bool rev = useReverse[a.target] != 0;
+                    const bool rev = useReverse(a.target);
                     const int diag = (a.qStartPos + (int) leftOff) - a.dbStartPos;
                     const unsigned md = (unsigned) std::abs(diag);
                     int startPos = -1, endPos = -1; unsigned diagonalLen = 0;
@@ -409,7 +412,7 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
                 }
                 lap(3);
             }
-            if (couldExtend) { outSeqs[id].swap(query); outExt[id] = 1; changed[id] = 1; }
+            if (couldExtend) { mine.emplace_back((uint32_t) id, std::move(query)); outExt[id] = 1; }
             else outExt[id] = ext[id];
             lap(2);
         }
@@ -422,6 +425,14 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
     if (timing) fprintf(stderr, "  contig merge host threads (sum / max s): gate %.2f / %.2f, queue + growth %.2f / %.2f, parked hits %.2f / %.2f, rest %.2f / %.2f\n",
                         tSum[0], tMax[0], tSum[1], tMax[1], tSum[3], tMax[3], tSum[2], tMax[2]);
     if (timing) fprintf(stderr, "  contig merge comparator: %llu calls, %llu series terms\n", nCmp, nTerms);
+    {   // the grown contigs in the order of their queries
+        size_t m = 0; for (auto &v : perThread) m += v.size();
+        std::vector<std::pair<uint32_t, std::string> *> all; all.reserve(m);
+        for (auto &v : perThread) for (auto &e : v) all.push_back(&e);
+        std::sort(all.begin(), all.end(), [](const std::pair<uint32_t, std::string> *a, const std::pair<uint32_t, std::string> *b) { return a->first < b->first; });
+        grownIdx.resize(m); grownSeqs.resize(m);
+        for (size_t j = 0; j < m; j++) { grownIdx[j] = all[j]->first; grownSeqs[j].swap(all[j]->second); }
+    }
     if (undefinedCase) { *err = "cdm_contig_merge: a target overhangs its query by more than the query's length; the reference pads it with a negative number of letters there (undefined behaviour), not reproduced"; return CDM_ERR_UNSUPPORTED; }
     return CDM_OK;
 }
