@@ -18,6 +18,7 @@
 // after a run unconditionally (:277-350); repIsReverse starting as false for the very first k-mer group (:453-467); the
 // per-target scan in the writer running on into the next representative's tuples when they have the same target id
 // (:875-887).
+#include <cmath>
 #include <cstring>
 
 #include "common.h"
@@ -1296,6 +1297,8 @@ struct KmerJob : KmerJobBase {
     hipStream_t s = nullptr; uint32_t n = 0; int k = 0;
     uint32_t idBits = 0, diagBits = 0; int diagBias = 0; const char *sortEnv = nullptr; bool lsdOnly = false;
     bool wide = false;                        // group keys without the representative (runsort.h RunArgs; packGroupKey)
+    int block = 0, nBlocks = 0;               // splitBegin: block `block` of `nBlocks` of the sequences (0: part of nparts)
+    bool passes = false;                      // a range of the k-mer-range passes on one device (kmermatchPassesT): no exchange of group keys follows
     uint64_t r2Slots = 0;                     // size of region 2: n (one whole-sequence hash slot per sequence), or what arrived (split by reads)
     uint32_t ordLo = 0, ordHi = 0;            // split by reads: the order ranks of the sequences this rank extracts
     DevBuf<uint64_t> splitK; DevBuf<V> splitV; DevBuf<uint32_t> splitD0, splitD1, splitI0, splitI1;
@@ -1316,12 +1319,12 @@ struct KmerJob : KmerJobBase {
     DevBuf<uint32_t> agSegOfRec, agSegRep, agEntCnt, agPending; DevBuf<unsigned long long> agSegFirstRec, agEntOff, agPerRep, agCursor; DevBuf<aggv::Ent> agEnt; DevBuf<unsigned int> agFlags;
     float msSort1 = 0;
     KmerJob(cdm_ctx *c, const cdm_seqdb *d, const cdm_kmer_params *p) { ctx = c; db = d; parCopy = *p; par = &parCopy; }
-int phaseA() override {
+// the members every phase reads: stream, sizes, the form of the group key, the scratch counters
+int init() {
     s = ctx->stream;
     n = (uint32_t) db->n;
     k = par->kmer_size;
     if (k < 4 || k > 31) { cdm_set_error("cdm_kmermatch: k must be in 4..31 (got %d)", k); return CDM_ERR_INVALID; }
-    constexpr uint32_t SHORT_CAP = 256, LONG_CAP = 4096;
     idBits = bitsFor(n); diagBits = bitsFor(2ull * db->maxLen + 2);
     // (rep, id, diagonal, strand) in one word while it fits 63 bits - 2 M sequences with contigs of 500 k letters, 50 M reads of 2 k
     // letters; beyond that (25 M sequences with contigs: BASELINE config 5) the representative leaves the key (the wide form:
@@ -1330,15 +1333,22 @@ int phaseA() override {
     if (wide && (int) (aggv::AG_ORD + idBits + diagBits) > 64) {
         cdm_set_error("cdm_kmermatch: %u sequences x max length %u: ids and diagonals beyond %d bits are not implemented", n, db->maxLen, 64 - aggv::AG_ORD); return CDM_ERR_UNSUPPORTED;
     }
-    if (wide && nparts > 1) { cdm_set_error("cdm_kmermatch_part: %u sequences x max length %u need the wide group key, which the k-mer-range split does not carry yet", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
+    if (wide && nparts > 1 && !passes) { cdm_set_error("cdm_kmermatch_part: %u sequences x max length %u need the wide group key, which the exchange of the k-mer-range split does not carry yet", n, db->maxLen); return CDM_ERR_UNSUPPORTED; }
     diagBias = (int) db->maxLen + 1;
     sortEnv = cdmGetenv("CDM_KMER_SORT");
     lsdOnly = sortEnv && !strcmp(sortEnv, "lsd");
+    if (!counters.alloc(8)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    hipMemsetAsync(counters.p, 0, 8 * 8, s);
+    geom.kbits = 2 * k; geom.lb = (int) bitsFor((uint64_t) db->maxLen + 1); geom.lenArr = db->len;
+    return CDM_OK;
+}
+int phaseA() override {
+    if (int rc = init()) return rc;
+    constexpr uint32_t SHORT_CAP = 256, LONG_CAP = 4096;
 
-    if (!counters.alloc(8) || !cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !listSingle.alloc(n) || !listHuge.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1) || !rankOf.alloc(n)) {
+    if (!cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !listSingle.alloc(n) || !listHuge.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1) || !rankOf.alloc(n)) {
         cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP;
     }
-    hipMemsetAsync(counters.p, 0, 8 * 8, s);
     hipMemsetAsync(cls.p, 0, 8 * 4, s);
     // One slot per k-mer position + one for the whole-sequence tuple, at a fixed offset per sequence (no global counter).
     // Slots are laid out in (sequence length descending, id ascending) order: after the stable k-mer sort the first tuple
@@ -1451,7 +1461,8 @@ int splitPartition() {
 }
 int splitBegin() override {
     split = true;
-    ordLo = (uint32_t) ((uint64_t) db->n * (unsigned) part / (unsigned) nparts); ordHi = (uint32_t) ((uint64_t) db->n * (unsigned) (part + 1) / (unsigned) nparts);
+    const unsigned blk = nBlocks ? (unsigned) block : (unsigned) part, of = nBlocks ? (unsigned) nBlocks : (unsigned) nparts;      // (the passes on one device cut the sequences into more blocks than the k-mers into ranges)
+    ordLo = (uint32_t) ((uint64_t) db->n * blk / of); ordHi = (uint32_t) ((uint64_t) db->n * (blk + 1) / of);
     if (nparts > 255) { cdm_set_error("cdm_kmermatch: the split by reads takes up to 255 ranks"); return CDM_ERR_UNSUPPORTED; }
     return phaseA();       // (a rank without sequences of its own - fewer sequences than ranks - goes through with empty buffers)
 }
@@ -1467,6 +1478,17 @@ int splitFinish(const void *keysIn, const void *valsIn, uint64_t m, const void *
     if (h) { hipMemcpyAsync(nk0.p + m, hkeys, h * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(nv0.p + m, hvals, h * sizeof(V), hipMemcpyDeviceToDevice, s); }
     if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: taking over the received tuples failed"); return CDM_ERR_HIP; }
     k0.p = nk0.release(); k1.p = nk1.release(); v0.p = nv0.release(); v1.p = nv1.release();
+    kmerSlots = m; r2Slots = h; nTuples = tot; geom.kmerSlots = m; anyBelow = below;
+    return sortAndGroup();
+}
+// a range of the passes on one device: its tuples, gathered by the caller (m k-mer tuples, then h whole-sequence hash tuples), are
+// taken over as they are
+int rangeFinishOwned(DevBuf<uint64_t> &keysBuf, DevBuf<V> &valsBuf, uint64_t m, uint64_t h, bool below) {
+    passes = true; split = true;
+    if (int rc = init()) return rc;
+    const uint64_t tot = m + h;
+    if (!k1.alloc(tot) || !v1.alloc(tot)) { cdm_set_error("cdm_kmermatch: out of device memory for a pass over %llu k-mer tuples", (unsigned long long) tot); return CDM_ERR_HIP; }
+    k0.p = keysBuf.release(); v0.p = valsBuf.release();
     kmerSlots = m; r2Slots = h; nTuples = tot; geom.kmerSlots = m; anyBelow = below;
     return sortAndGroup();
 }
@@ -1934,8 +1956,154 @@ int voteWith(const uint32_t *cont, const uint32_t *staleIn, cdm_hits **out) over
 }
 };
 
+// kmermatcher in PASSES over the k-mer space on one device, for inputs whose tuples do not fit it at once (the reference splits the
+// same way when memory is short: kmermatcher.cpp:634-663, merged :742-784).  Pass r takes the tuples whose k-mer lies in range r of P:
+// the sequences are extracted block by block (B blocks of the slot order; every block's tuples ordered by range, the slice of range r
+// appended - the machinery of the multi-GPU split by reads), sorted and grouped as a range of a multi-GPU run is, and the group keys it
+// keeps are appended to ONE array.  The ranges in order ARE the k-mer order, so that array is what a single pass leaves for sort 2,
+// and sort 2 + vote run on it as they are.  What the reference's run-past-the-end scan needs (the tuples behind k-mer-order index J =
+// number of kept keys, known only at the end) comes from running the range that holds J once more.  Cost: P + 2 extractions of the
+// whole DB instead of one.
+template <typename LY>
+int kmermatchPassesT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int P, int B, cdm_hits **out) {
+    typedef typename LY::V V;
+    hipStream_t s = ctx->stream;
+    if (P < 1 || P > 255 || B < 1) { cdm_set_error("cdm_kmermatch: %d passes over %d blocks", P, B); return CDM_ERR_INVALID; }        // (P: at most; fewer where the tuples sit in few slices of the k-mer space)
+    const bool stats = cdmGetenv("CDM_BUCKET_STATS") != nullptr;
+    // ---- how many tuples of every block fall into each of F = 255 fine slices of the k-mer space ([F]: the whole-sequence hash tuples,
+    // which sort behind every k-mer).  The P ranges are runs of fine slices with about the same number of tuples: equal slices of the
+    // k-mer space are anything but equal in tuples (1 M synthetic reads, 3 slices: 55 / 33 / 12 %).
+    constexpr int F = 255;
+    std::vector<std::vector<unsigned long long>> cnt((size_t) B, std::vector<unsigned long long>((size_t) F + 1, 0));
+    auto extractBlock = [&](KmerJob<LY> &ex, int b) -> int { ex.part = 0; ex.nparts = F; ex.block = b; ex.nBlocks = B; ex.passes = true; return ex.splitBegin(); };
+    std::vector<unsigned long long> fine((size_t) F, 0); unsigned long long grand = 0;
+    for (int b = 0; b < B; b++) {
+        KmerJob<LY> ex(ctx, db, par);
+        if (int rc = extractBlock(ex, b)) return rc;
+        for (int f = 0; f < F; f++) { cnt[b][f] = ex.sendOff[f + 1] - ex.sendOff[f]; fine[f] += cnt[b][f]; grand += cnt[b][f]; }
+        cnt[b][F] = ex.sendHash;
+    }
+    std::vector<int> cut(1, 0);          // range r = fine slices [cut[r], cut[r + 1])
+    {
+        const unsigned long long target = (grand + (unsigned) P - 1) / (unsigned) P;
+        unsigned long long acc = 0;
+        for (int f = 0; f < F; f++) { if (acc && acc + fine[f] > target && (int) cut.size() < P) { cut.push_back(f); acc = 0; } acc += fine[f]; }
+        cut.push_back(F);
+    }
+    P = (int) cut.size() - 1;
+    // a range's tuples, gathered from the blocks; then sort 1 + grouping on them
+    auto runRange = [&](int r, KmerJob<LY> &job) -> int {
+        const int f0 = cut[r], f1 = cut[r + 1];
+        unsigned long long m = 0, h = 0; bool below = false;
+        std::vector<unsigned long long> mine((size_t) B, 0);
+        for (int b = 0; b < B; b++) {
+            for (int f = f0; f < f1; f++) mine[b] += cnt[b][f];
+            m += mine[b]; if (r == P - 1) h += cnt[b][F];
+            for (int f = 0; f < f0; f++) below = below || cnt[b][f] != 0;
+        }
+        DevBuf<uint64_t> rk; DevBuf<V> rv;
+        if (!rk.alloc(m + h) || !rv.alloc(m + h)) { cdm_set_error("cdm_kmermatch: out of device memory for a pass over %llu k-mer tuples", m + h); return CDM_ERR_HIP; }
+        unsigned long long at = 0, hat = m;
+        for (int b = 0; b < B; b++) {
+            if (mine[b] == 0 && !(r == P - 1 && cnt[b][F])) continue;
+            KmerJob<LY> ex(ctx, db, par);
+            if (int rc = extractBlock(ex, b)) return rc;
+            if ((unsigned long long) (ex.sendOff[f1] - ex.sendOff[f0]) != mine[b] || ex.sendHash != cnt[b][F]) { cdm_set_error("cdm_kmermatch: internal error: a block's tuple counts changed between two extractions"); return CDM_ERR_HIP; }
+            if (mine[b]) {
+                hipMemcpyAsync(rk.p + at, (const uint64_t *) ex.sendKeys + ex.sendOff[f0], mine[b] * 8, hipMemcpyDeviceToDevice, s);
+                hipMemcpyAsync(rv.p + at, (const V *) ex.sendVals + ex.sendOff[f0], mine[b] * sizeof(V), hipMemcpyDeviceToDevice, s);
+                at += mine[b];
+            }
+            if (r == P - 1 && cnt[b][F]) {
+                hipMemcpyAsync(rk.p + hat, ex.sendHashKeys, cnt[b][F] * 8, hipMemcpyDeviceToDevice, s);
+                hipMemcpyAsync(rv.p + hat, ex.sendHashVals, cnt[b][F] * sizeof(V), hipMemcpyDeviceToDevice, s);
+                hat += cnt[b][F];
+            }
+            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: gathering a pass's tuples failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+        }
+        job.part = r; job.nparts = P;
+        return job.rangeFinishOwned(rk, rv, m, h, below);
+    };
+    // ---- the passes: kept group keys (and, in the wide form, the dropped run starts that name a representative) in k-mer order
+    DevBuf<uint64_t> G; unsigned long long gCap = 0, gCount = 0, J = 0;
+    std::vector<unsigned long long> realOf((size_t) P, 0);
+    DevBuf<unsigned long long> cntDev;
+    if (!cntDev.alloc(1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    for (int r = 0; r < P; r++) {
+        KmerJob<LY> job(ctx, db, par);
+        if (int rc = runRange(r, job)) return rc;
+        realOf[r] = job.live + job.regionTwo; J += job.nKept;
+        const unsigned long long nt = job.nTuples;
+        if (stats) fprintf(stderr, "kmermatch pass %d of %d: %llu tuples, %llu kept\n", r + 1, P, nt, job.nKept);
+        if (nt == 0) continue;
+        if (gCount + nt > gCap) {       // (room for everything this range could keep; grown by doubling)
+            const unsigned long long want = std::max(gCount + nt, gCap * 2);
+            DevBuf<uint64_t> bigger;
+            if (!bigger.alloc(want)) { cdm_set_error("cdm_kmermatch: out of device memory for %llu group keys", want); return CDM_ERR_HIP; }
+            if (gCount) hipMemcpyAsync(bigger.p, G.p, gCount * 8, hipMemcpyDeviceToDevice, s);
+            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: growing the group key array failed"); return CDM_ERR_HIP; }
+            G.free(); G.p = bigger.release(); gCap = want;
+        }
+        DevBuf<uint8_t> d0, d1;         // (the compaction moves pairs: one byte per key stands in for the value)
+        if (!d0.alloc(nt) || !d1.alloc(nt)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+        if (int rc = rx::compactPairs<uint64_t, uint8_t>(s, (const uint64_t *) job.startIo, d0.p, (uint64_t) nt, G.p + gCount, d1.p, cntDev.p)) return rc;
+        unsigned long long got = 0;
+        hipMemcpyAsync(&got, cntDev.p, 8, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: collecting a pass's group keys failed"); return CDM_ERR_HIP; }
+        gCount += got;
+    }
+    // ---- the left-over list of the reference's last per-target scan (:875-887): from k-mer-order index J on, while the tuples belong
+    // to one sequence - the range that holds index J once more, and the ranges behind it while the scan runs on (csrc/dist.hip does
+    // the same across ranks)
+    uint32_t stale[CDM_STALE_MAX + 5]; memset(stale, 0, sizeof(stale));
+    if (J) {
+        int holder = -1; unsigned long long jLocal = 0, base = 0;
+        for (int r = 0; r < P; r++) { if (J < base + realOf[r]) { holder = r; jLocal = J - base; break; } base += realOf[r]; }
+        uint32_t got = 0; bool have = false; uint32_t target = 0;
+        for (int r = holder; holder >= 0 && r < P; r++) {
+            KmerJob<LY> job(ctx, db, par);
+            if (int rc = runRange(r, job)) return rc;
+            if (int rc = job.staleTail(r == holder ? jLocal : 0, false)) return rc;
+            const uint32_t *l = job.staleHost;
+            if (l[0]) {
+                if (!have) { target = l[1]; have = true; } else if (l[1] != target) break;
+                for (uint32_t j = 0; j < l[0] && got < (uint32_t) CDM_STALE_MAX; j++) stale[2 + got++] = l[2 + j];
+            }
+            if (!l[CDM_STALE_MAX + 4]) break;
+        }
+        if (got >= (uint32_t) CDM_STALE_MAX) { cdm_set_error("cdm_kmermatch: the reference's last per-target scan would run over %d or more left-over tuples; not reproduced", CDM_STALE_MAX); return CDM_ERR_UNSUPPORTED; }
+        stale[0] = got; stale[1] = have ? target : 0;
+    }
+    // ---- sort 2 + vote on the collected keys
+    KmerJob<LY> fin(ctx, db, par);
+    fin.passes = true;
+    if (int rc = fin.init()) return rc;
+    if (!fin.staleBuf.alloc(STALE_MAX + 3) || !fin.k0.alloc(gCount)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    if (hipMemcpyAsync(fin.staleBuf.p, stale, (STALE_MAX + 3) * 4, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: stale list upload failed"); return CDM_ERR_HIP; }
+    if (!G.p && !G.alloc(0)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    fin.startIo = (unsigned long long *) G.p; fin.live = gCount; fin.kmerSlots = gCount; fin.nTuples = gCount; fin.nKept = J;
+    fin.keys = DoubleBuf<uint64_t>(fin.k0.p, G.p);
+    if (int rc = fin.sort2(G.p, gCount, gCount, gCount, fin.k0.p, G.p, true)) return rc;
+    return fin.vote(nullptr, true, out);
+}
 template <typename LY>
 int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+    // One pass while the tuples fit the device: 16 bytes of keys + two values per k-mer slot, two buffers of each.  CDM_KMER_PASSES=P[,B]
+    // (tests, A/B): P passes over B blocks for any DB.
+    int P = 1, B = 1;
+    if (const char *e = cdmGetenv("CDM_KMER_PASSES")) { P = atoi(e); const char *c = strchr(e, ','); B = c ? atoi(c + 1) : P; }
+    else {
+        size_t fr = 0, tot = 0;
+        const unsigned long long slots = db->residues + 2 * db->n;          // (an upper bound: a slot per k-mer position and two per sequence)
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) {
+            const double onePass = (double) slots * (16.0 + 2.0 * sizeof(typename LY::V)) * 1.1, budget = 0.80 * (double) tot;
+            if (onePass > budget) {
+                P = (int) std::min(255.0, std::ceil((double) slots * (16.0 + 2.0 * sizeof(typename LY::V) + 8.0) / (0.30 * (double) tot)));
+                B = (int) std::ceil((double) slots * (32.0 + 4.0 * sizeof(typename LY::V) + 16.0) / (0.30 * (double) tot));
+            }
+        } else (void) hipGetLastError();
+    }
+    if (P > 1 || B > 1) return kmermatchPassesT<LY>(ctx, db, par, std::max(P, 1), std::max(B, 1), out);
     KmerJob<LY> job(ctx, db, par);
     if (int rc = job.phaseA()) return rc;
     if (job.nKept) if (int rc = job.staleTail(job.nKept, false)) return rc;
