@@ -20,14 +20,22 @@ extern "C" const char *cdm_last_error(void) { return g_err; }
 #include "pool.h"
 const char *cdmGetenv(const char *name) { return cdmenv::get(name); }
 extern "C" void cdm_env_refresh(void) { (void) cdmenv::refresh(); }
-extern "C" void cdm_pool_stats(uint64_t out[6]) {
+extern "C" void cdm_pool_stats(uint64_t out[8]) {
     cdmpool::Stats &st = cdmpool::stats();
     out[0] = st.requests.load(); out[1] = st.cached.load(); out[2] = st.mallocs.load(); out[3] = st.mallocBytes.load(); out[4] = st.mallocNs.load(); out[5] = st.trims.load();
+    out[6] = out[7] = 0;
+    cdmpool::Registry &r = cdmpool::registry();
+    std::lock_guard<std::mutex> g(r.m);
+    for (cdmpool::Pool *q : r.pools) {
+        std::lock_guard<std::mutex> g2(q->m);
+        for (const cdmpool::Arena *a : {&q->small, &q->large}) for (const auto &kv : a->blocks) { if (kv.second.state != cdmpool::B_HOLE) out[6] += kv.second.size; if (kv.second.state == cdmpool::B_USED) out[7] += kv.second.size; }
+    }
 }
 extern "C" void cdm_pool_headroom(float factor) { cdmpool::headroom().store(factor > 1.0f ? std::min(factor, 4.0f) : 1.0f, std::memory_order_relaxed); }
 hipError_t cdmMallocRaw(void **p, size_t bytes) { return cdmpool::allocate(p, bytes); }
 void cdmFree(void *p) { cdmpool::release(p); }
 void cdmPoolTrim() { cdmpool::trimMine(); }
+float cdmPoolHeadroomSwap(float f) { return cdmpool::headroom().exchange(f, std::memory_order_relaxed); }
 
 // ------------------------------------------------------------------------------------------------ context
 // CDM_SEGV_BACKTRACE=1 (diagnosis, scripts/stress_kpart.py): a SIGSEGV / SIGBUS / SIGABRT of the process prints the faulting thread's

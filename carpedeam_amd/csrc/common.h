@@ -17,6 +17,7 @@ void cdm_set_error(const char *fmt, ...);
 hipError_t cdmMallocRaw(void **p, size_t bytes);
 void cdmFree(void *p);
 void cdmPoolTrim();   // give every cached block back to the driver
+float cdmPoolHeadroomSwap(float f);      // sets the allocator's head room factor (cdm_pool_headroom), returns the previous one
 // value of a CDM_* switch (or OMP_NUM_THREADS) from the library's snapshot of the environment (pool.h: never getenv on a call path)
 const char *cdmGetenv(const char *name);
 template <typename T> inline hipError_t cdmMalloc(T **p, size_t bytes) { return cdmMallocRaw(reinterpret_cast<void **>(p), bytes); }

@@ -19,6 +19,7 @@
 // per-target scan in the writer running on into the next representative's tuples when they have the same target id
 // (:875-887).
 #include <cmath>
+#include <memory>
 #include <cstring>
 
 #include "common.h"
@@ -1149,6 +1150,24 @@ __global__ void k_slot_mask(unsigned long long *__restrict__ slots, uint32_t n, 
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n && (r < lo || r >= hi)) slots[r] = 0;
 }
+// Split by reads: the blocks of the slot order hold about the same number of SLOTS each (not of sequences: the order starts with the
+// longest ones, and in a contig phase a tenth of the sequences holds nine tenths of the letters).  prefix = exclusive sums of the slot
+// counts in that order, prefix[n] = all slots; block `blk` of `of` = the order ranks [out[0], out[1]): first rank whose prefix reaches
+// total * blk / of - the same arithmetic on every rank, so the blocks tile the order.
+__global__ void k_block_cuts(const unsigned long long *__restrict__ prefix, uint32_t n, uint32_t blk, uint32_t of, uint32_t *__restrict__ out) {
+    const unsigned long long total = prefix[n];
+    for (int side = 0; side < 2; side++) {
+        const uint32_t b = blk + (uint32_t) side;
+        uint32_t res = n;
+        if (b < of) {
+            const unsigned long long want = (unsigned long long) (((unsigned __int128) total * b) / of);
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (prefix[mid] < want) lo = mid + 1; else hi = mid; }
+            res = lo;
+        }
+        out[side] = res;
+    }
+}
 // k-mer range a tuple belongs to: the largest p with (2^(2k) p) / parts <= k-mer (the ranges of ExtractArgs::kLo / kHi)
 template <typename LY>
 __global__ void k_dest_range(const uint64_t *__restrict__ keys, uint64_t m, TupleGeom geom, int kbits, uint32_t parts, uint32_t *__restrict__ dest, uint32_t *__restrict__ idx) {
@@ -1364,7 +1383,18 @@ int phaseA() override {
         if (int rc = rx::sortPairs<uint32_t, uint32_t>(s, ctx->cuCount, lk0.p, lk1.p, lv0.p, lv1.p, (uint64_t) n, 0, (int) lenBits, lenFirst)) return rc;
         DoubleBuf<uint32_t> lk(lenFirst ? lk0.p : lk1.p, lenFirst ? lk1.p : lk0.p), lv(lenFirst ? lv0.p : lv1.p, lenFirst ? lv1.p : lv0.p);
         hipLaunchKernelGGL(k_slot_counts, dim3((n + 256) / 256), dim3(256), 0, s, db->len, lv.current(), n, k, slots.p);
-        if (split) hipLaunchKernelGGL(k_slot_mask, dim3((n + 255) / 256), dim3(256), 0, s, slots.p, n, ordLo, ordHi);
+        if (split) {
+            const unsigned blk = nBlocks ? (unsigned) block : (unsigned) part, of = nBlocks ? (unsigned) nBlocks : (unsigned) nparts;      // (the passes on one device cut the sequences into more blocks than the k-mers into ranges)
+            DevBuf<uint32_t> cuts; uint32_t hc[2] = {0, 0};
+            if (!cuts.alloc(2)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+            cdmscan::ScanTemp stCut;
+            if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, stCut, slots.p, ordOff.p, (size_t) n + 1)) return rc;
+            hipLaunchKernelGGL(k_block_cuts, dim3(1), dim3(1), 0, s, (const unsigned long long *) ordOff.p, n, blk, of, cuts.p);
+            hipMemcpyAsync(hc, cuts.p, 8, hipMemcpyDeviceToHost, s);
+            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: slot layout failed"); return CDM_ERR_HIP; }
+            ordLo = hc[0]; ordHi = hc[1];
+            hipLaunchKernelGGL(k_slot_mask, dim3((n + 255) / 256), dim3(256), 0, s, slots.p, n, ordLo, ordHi);
+        }
         if (int rc = cdmscan::exclusiveScan<unsigned long long>(s, st, slots.p, ordOff.p, (size_t) n + 1)) return rc;
         hipLaunchKernelGGL(k_slot_scatter, dim3((n + 256) / 256), dim3(256), 0, s, lv.current(), ordOff.p, n, slotOff.p, rankOf.p);
         hipMemcpyAsync(&capacity, ordOff.p + n, 8, hipMemcpyDeviceToHost, s);
@@ -1461,8 +1491,7 @@ int splitPartition() {
 }
 int splitBegin() override {
     split = true;
-    const unsigned blk = nBlocks ? (unsigned) block : (unsigned) part, of = nBlocks ? (unsigned) nBlocks : (unsigned) nparts;      // (the passes on one device cut the sequences into more blocks than the k-mers into ranges)
-    ordLo = (uint32_t) ((uint64_t) db->n * blk / of); ordHi = (uint32_t) ((uint64_t) db->n * (blk + 1) / of);
+    // (which sequences: phaseA's slot layout, blocks of about equal slot counts)
     if (nparts > 255) { cdm_set_error("cdm_kmermatch: the split by reads takes up to 255 ranks"); return CDM_ERR_UNSUPPORTED; }
     return phaseA();       // (a rank without sequences of its own - fewer sequences than ranks - goes through with empty buffers)
 }
@@ -1481,6 +1510,20 @@ int splitFinish(const void *keysIn, const void *valsIn, uint64_t m, const void *
     kmerSlots = m; r2Slots = h; nTuples = tot; geom.kmerSlots = m; anyBelow = below;
     return sortAndGroup();
 }
+// after splitBegin: everything goes but what would be sent - the tuples ordered by range (splitK / splitV) and the hash tuples, which
+// move out of the extraction buffers into two small ones
+int keepOnlyOutgoing() {
+    DevBuf<uint64_t> hk; DevBuf<V> hv;
+    if (!hk.alloc(sendHash) || !hv.alloc(sendHash)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    if (sendHash) { hipMemcpyAsync(hk.p, sendHashKeys, sendHash * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(hv.p, sendHashVals, sendHash * sizeof(V), hipMemcpyDeviceToDevice, s); }
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: keeping a block's tuples failed"); return CDM_ERR_HIP; }
+    k0.free(); k1.free(); v0.free(); v1.free(); splitD0.free(); splitD1.free(); splitI0.free(); splitI1.free();
+    slots.free(); slotOff.free(); rankOf.free(); listShort.free(); listLong.free(); listSingle.free(); listHuge.free(); cls.free(); counters.free();
+    keptHashK.p = hk.release(); keptHashV.p = hv.release();
+    sendHashKeys = keptHashK.p; sendHashVals = keptHashV.p;
+    return CDM_OK;
+}
+DevBuf<uint64_t> keptHashK; DevBuf<V> keptHashV;
 // a range of the passes on one device: its tuples, gathered by the caller (m k-mer tuples, then h whole-sequence hash tuples), are
 // taken over as they are
 int rangeFinishOwned(DevBuf<uint64_t> &keysBuf, DevBuf<V> &valsBuf, uint64_t m, uint64_t h, bool below) {
@@ -1970,6 +2013,8 @@ int kmermatchPassesT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *p
     hipStream_t s = ctx->stream;
     if (P < 1 || P > 255 || B < 1) { cdm_set_error("cdm_kmermatch: %d passes over %d blocks", P, B); return CDM_ERR_INVALID; }        // (P: at most; fewer where the tuples sit in few slices of the k-mer space)
     const bool stats = cdmGetenv("CDM_BUCKET_STATS") != nullptr;
+    // (this path runs because memory is short: its buffers are planned at their exact sizes, without the allocator's head room)
+    struct NoHeadroom { float was; NoHeadroom() : was(cdmPoolHeadroomSwap(1.0f)) {} ~NoHeadroom() { cdmPoolHeadroomSwap(was); } } noHeadroom;
     // ---- how many tuples of every block fall into each of F = 255 fine slices of the k-mer space ([F]: the whole-sequence hash tuples,
     // which sort behind every k-mer).  The P ranges are runs of fine slices with about the same number of tuples: equal slices of the
     // k-mer space are anything but equal in tuples (1 M synthetic reads, 3 slices: 55 / 33 / 12 %).
@@ -1977,11 +2022,26 @@ int kmermatchPassesT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *p
     std::vector<std::vector<unsigned long long>> cnt((size_t) B, std::vector<unsigned long long>((size_t) F + 1, 0));
     auto extractBlock = [&](KmerJob<LY> &ex, int b) -> int { ex.part = 0; ex.nparts = F; ex.block = b; ex.nBlocks = B; ex.passes = true; return ex.splitBegin(); };
     std::vector<unsigned long long> fine((size_t) F, 0); unsigned long long grand = 0;
+    auto poolLine = [&](const char *what, int i) { if (stats) { uint64_t st[8]; cdm_pool_stats(st); fprintf(stderr, "kmermatch passes (%d x %d): %s %d: %.1f GB mapped, %.1f GB in use\n", P, B, what, i, st[6] / 1e9, st[7] / 1e9); } };
+    poolLine("start", 0);
+    // The same sweep KEEPS every block's ordered tuples while they fit (the real tuples are far fewer than the slots where a per-sequence
+    // budget selects the k-mers: 40 % in a late contig iteration) - then a range is gathered from the kept blocks; where they do not fit,
+    // a range extracts the blocks again.  CDM_KMER_KEEP=<bytes> (tests: 0 = never keep).
+    std::vector<std::unique_ptr<KmerJob<LY>>> kept((size_t) B);
+    bool keepAll = true; unsigned long long keptBytes = 0, keepBudget = 0;
+    { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) keepBudget = (unsigned long long) (0.40 * (double) tot); else (void) hipGetLastError(); }
+    if (const char *e = cdmGetenv("CDM_KMER_KEEP")) keepBudget = strtoull(e, nullptr, 10);
     for (int b = 0; b < B; b++) {
-        KmerJob<LY> ex(ctx, db, par);
-        if (int rc = extractBlock(ex, b)) return rc;
-        for (int f = 0; f < F; f++) { cnt[b][f] = ex.sendOff[f + 1] - ex.sendOff[f]; fine[f] += cnt[b][f]; grand += cnt[b][f]; }
-        cnt[b][F] = ex.sendHash;
+        std::unique_ptr<KmerJob<LY>> ex(new KmerJob<LY>(ctx, db, par));
+        if (int rc = extractBlock(*ex, b)) return rc;
+        for (int f = 0; f < F; f++) { cnt[b][f] = ex->sendOff[f + 1] - ex->sendOff[f]; fine[f] += cnt[b][f]; grand += cnt[b][f]; }
+        cnt[b][F] = ex->sendHash;
+        if (keepAll) {
+            const unsigned long long bytes = (ex->sendOff[F] + ex->sendHash) * (8ull + sizeof(V));
+            if (keptBytes + bytes > keepBudget) { keepAll = false; for (auto &q : kept) q.reset(); }
+            else { if (int rc = ex->keepOnlyOutgoing()) return rc; keptBytes += bytes; kept[b] = std::move(ex); }
+        }
+        poolLine("counted block", b);
     }
     std::vector<int> cut(1, 0);          // range r = fine slices [cut[r], cut[r + 1])
     {
@@ -2006,8 +2066,9 @@ int kmermatchPassesT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *p
         unsigned long long at = 0, hat = m;
         for (int b = 0; b < B; b++) {
             if (mine[b] == 0 && !(r == P - 1 && cnt[b][F])) continue;
-            KmerJob<LY> ex(ctx, db, par);
-            if (int rc = extractBlock(ex, b)) return rc;
+            std::unique_ptr<KmerJob<LY>> again;
+            if (!keepAll) { again.reset(new KmerJob<LY>(ctx, db, par)); if (int rc = extractBlock(*again, b)) return rc; }
+            KmerJob<LY> &ex = keepAll ? *kept[b] : *again;
             if ((unsigned long long) (ex.sendOff[f1] - ex.sendOff[f0]) != mine[b] || ex.sendHash != cnt[b][F]) { cdm_set_error("cdm_kmermatch: internal error: a block's tuple counts changed between two extractions"); return CDM_ERR_HIP; }
             if (mine[b]) {
                 hipMemcpyAsync(rk.p + at, (const uint64_t *) ex.sendKeys + ex.sendOff[f0], mine[b] * 8, hipMemcpyDeviceToDevice, s);
@@ -2075,6 +2136,7 @@ int kmermatchPassesT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *p
         stale[0] = got; stale[1] = have ? target : 0;
     }
     // ---- sort 2 + vote on the collected keys
+    for (auto &q : kept) q.reset();
     KmerJob<LY> fin(ctx, db, par);
     fin.passes = true;
     if (int rc = fin.init()) return rc;

@@ -2,6 +2,7 @@
 // (A header of its own so that tests/cpu/pool_stress.cpp can compile exactly this code against stand-ins for hipMalloc / hipFree
 // and run it under ThreadSanitizer / AddressSanitizer on a box without a GPU.)
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -357,7 +358,20 @@ inline hipError_t allocate(void **p, size_t bytes) {
             stats().trims.fetch_add(1, std::memory_order_relaxed);
         }
     }
-    if (!got) return e == hipSuccess ? hipErrorOutOfMemory : e;
+    if (!got) {
+        if (cdmenv::get("CDM_POOL_DEBUG")) {
+            std::lock_guard<std::mutex> g(pool.m);
+            const Arena &a = small ? pool.small : pool.large;
+            size_t used = 0, fr = 0, hole = 0, largest = 0, nUsed = 0, nFree = 0;
+            for (const auto &kv : a.blocks) {
+                if (kv.second.state == B_USED) { used += kv.second.size; nUsed++; }
+                else if (kv.second.state == B_FREE) { fr += kv.second.size; nFree++; largest = std::max(largest, kv.second.size); }
+                else hole += kv.second.size;
+            }
+            fprintf(stderr, "carpedeam pool: no room for %zu bytes: arena of %zu bytes mapped, %zu in %zu blocks in use, %zu free in %zu blocks (largest %zu), %zu given back\n", bytes, a.end, used, nUsed, fr, nFree, largest, hole);
+        }
+        return e == hipSuccess ? hipErrorOutOfMemory : e;
+    }
     if (poison >= 0) { (void) hipDeviceSynchronize(); (void) hipMemset(*p, poison, got); (void) hipDeviceSynchronize(); }
     return hipSuccess;
 }

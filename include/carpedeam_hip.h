@@ -200,9 +200,10 @@ void cdm_kpart_free(cdm_kpart *h);
  * the workflow loop): large blocks are allocated `factor` times the request, so the next, larger request fits a cached block instead of
  * mapping device memory anew.  1 = off (default); process-wide. */
 void cdm_pool_headroom(float factor);
-/* the cache's counters since the process began: [0] requests, [1] served from a cache, [2] hipMalloc calls, [3] their bytes,
- * [4] the nanoseconds they took, [5] times all parked blocks were released after an out-of-memory */
-void cdm_pool_stats(uint64_t out[6]);
+/* the allocator's counters since the process began: [0] requests, [1] served without the driver, [2] calls that asked the driver for
+ * memory, [3] their bytes, [4] the nanoseconds they took, [5] times free memory was given back after an out-of-memory; and now:
+ * [6] bytes mapped into the arenas of all threads, [7] bytes of them in blocks that are in use (head room included) */
+void cdm_pool_stats(uint64_t out[8]);
 /* The library reads its CDM_* switches (A/B and test aids) from the environment ONCE per process, not with getenv() on
  * its call paths (getenv is not safe beside a setenv elsewhere in the process).  cdm_env_refresh() reads them again - for tests and A/B
  * runs that change a switch inside one process; call it while no other thread is inside the library. */

@@ -30,7 +30,7 @@ def main():
     kc.kmer_size, kc.include_only_extendable = 22, 1
     par = capi.AncientParams.default()
     par.max_seq_len = 200000
-    pool_prev = np.zeros(6, np.uint64)
+    pool_prev = np.zeros(8, np.uint64)
     t_all = time.perf_counter()
     for it in range(12):
         laps = []
@@ -55,11 +55,11 @@ def main():
             laps.append("circular %d" % cyc.n)
             del merged, cyc
         del corr, alns
-        st = np.zeros(6, np.uint64)
+        st = np.zeros(8, np.uint64)
         capi.lib().cdm_pool_stats(st.ctypes.data_as(C.c_void_p))
         d = st - pool_prev
         pool_prev[:] = st
-        laps.append("| pool: %d requests, %d hipMalloc, %.1f GB, %.2f s, %d trims" % (d[0], d[2], d[3] / 1e9, d[4] / 1e9, d[5]))
+        laps.append("| pool: %d requests, %d driver calls, %.1f GB, %.2f s, %d trims; %.1f GB mapped, %.1f GB in use" % (d[0], d[2], d[3] / 1e9, d[4] / 1e9, d[5], st[6] / 1e9, st[7] / 1e9))
         print("it %2d  n %9d  residues %11d  hits %11d  alns %11d  | %s" % (it, db.n, db.residues, nh, na, "  ".join(laps)), flush=True)
         db = nxt
     print("total %.2f s" % (time.perf_counter() - t_all))

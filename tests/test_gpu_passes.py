@@ -29,7 +29,10 @@ def test_passes_equal_one_pass(ctx, monkeypatch, name):
         want = hits_under(ctx, db, par, {}, monkeypatch)
         assert len(want[1]) > len(want[0])
         for passes in PASSES:
-            for extra in ({}, {"CDM_FORCE_WIDE_KEY": "1"}, {"CDM_FORCE_WIDE_KEY": "1", "CDM_UNIT_CAP": "5"}, {"CDM_BUCKET_CAP": "5"}):
+            # (CDM_KMER_KEEP=0: the blocks' tuples are not kept between the passes, every range extracts the blocks again;
+            #  20000 bytes: kept until the budget is passed, then dropped)
+            for extra in ({}, {"CDM_FORCE_WIDE_KEY": "1"}, {"CDM_FORCE_WIDE_KEY": "1", "CDM_UNIT_CAP": "5"}, {"CDM_BUCKET_CAP": "5"}, {"CDM_KMER_KEEP": "0"},
+                          {"CDM_KMER_KEEP": "20000", "CDM_FORCE_WIDE_KEY": "1"}):
                 got = hits_under(ctx, db, par, dict(extra, CDM_KMER_PASSES=passes), monkeypatch)
                 assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (name, par.kmer_size, passes, extra)
 
@@ -66,6 +69,6 @@ def test_passes_at_scale(ctx, monkeypatch):
     db = ctx.synth(1_000_000, 100, 100, 5)
     want = hits_under(ctx, db, READS, {}, monkeypatch)
     assert len(want[1]) > 3_000_000
-    for env in ({"CDM_KMER_PASSES": "3,4"}, {"CDM_KMER_PASSES": "6,2", "CDM_FORCE_WIDE_KEY": "1"}):
+    for env in ({"CDM_KMER_PASSES": "3,4"}, {"CDM_KMER_PASSES": "6,2", "CDM_FORCE_WIDE_KEY": "1"}, {"CDM_KMER_PASSES": "2,3", "CDM_KMER_KEEP": "0"}):
         got = hits_under(ctx, db, READS, env, monkeypatch)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), env
