@@ -183,6 +183,14 @@ def lib():
 _env_seen = None
 
 
+def pool_stats():
+    """the device-memory allocator's counters (cdm_pool_stats)"""
+    a = np.zeros(8, np.uint64)
+    lib().cdm_pool_stats(a.ctypes.data_as(C.c_void_p))
+    return {"requests": int(a[0]), "served_without_driver": int(a[1]), "driver_calls": int(a[2]), "driver_bytes": int(a[3]), "driver_seconds": a[4] / 1e9, "trims": int(a[5]),
+            "mapped_bytes": int(a[6]), "in_use_bytes": int(a[7])}
+
+
 def _check(rc):
     if rc != 0:
         raise CdmError("cdm error %d: %s" % (rc, lib().cdm_last_error().decode()))
