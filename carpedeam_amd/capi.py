@@ -303,6 +303,9 @@ class Alns(_Csr):
     free, count_fn, download_fn, dtype = "cdm_alns_free", "cdm_alns_count", "cdm_alns_download", ALN_DTYPE
 
 
+KPART_SLICES = 256          # CDM_KPART_SLICES
+
+
 class KPart:
     """One k-mer range of a split kmermatcher run (cdm_kpart)."""
 
@@ -319,10 +322,10 @@ class KPart:
         _check(lib().cdm_kpart_info(self.h, _ptr(a)))
         return {"real": int(a[0]), "kept": int(a[1]), "any_below": bool(a[2]), "n": int(a[3])}
 
-    def outgoing(self, nranks):
-        """after Ctx.kmermatch_split_begin -> (offsets[nranks + 1], keys ptr, values ptr, bytes per value, hash keys ptr, hash values ptr,
-        hash tuples): what this rank sends to the ranks of the k-mer ranges"""
-        off = np.zeros(nranks + 1, np.uint64)
+    def outgoing(self):
+        """after Ctx.kmermatch_split_begin -> (offsets[KPART_SLICES + 1], keys ptr, values ptr, bytes per value, hash keys ptr, hash values
+        ptr, hash tuples): this rank's tuples ordered by fine slices of the k-mer space (the ranks' ranges are runs of slices)"""
+        off = np.zeros(KPART_SLICES + 1, np.uint64)
         k, v, hk, hv = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         vb, nh = C.c_int(), C.c_uint64()
         _check(lib().cdm_kpart_outgoing(self.h, _ptr(off), C.byref(k), C.byref(v), C.byref(vb), C.byref(hk), C.byref(hv), C.byref(nh)))

@@ -201,26 +201,41 @@ int firstHalf(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_pa
     const char *how = cdmGetenv("CDM_DIST_EXTRACT");
     if (W == 1 || (how && !strcmp(how, "all"))) return cdm_kmermatch_part(ctx, db, par, R, W, out);
     if (int rc = cdm_kmermatch_split_begin(ctx, db, par, R, W, out)) return rc;
-    std::vector<uint64_t> off((size_t) W + 1);
+    constexpr int F = CDM_KPART_SLICES;
+    std::vector<uint64_t> fineOff((size_t) F + 1);
     const void *keys, *vals, *hkeys, *hvals; int vb = 0; uint64_t nHash = 0;
-    if (int rc = cdm_kpart_outgoing(*out, off.data(), &keys, &vals, &vb, &hkeys, &hvals, &nHash)) return rc;
-    const size_t row = (size_t) W + 1;                    // tuples for every rank, then the hash tuples
+    if (int rc = cdm_kpart_outgoing(*out, fineOff.data(), &keys, &vals, &vb, &hkeys, &hvals, &nHash)) return rc;
+    const size_t row = (size_t) F + 1;                    // tuples per fine slice of the k-mer space, then the hash tuples
     std::vector<uint64_t> counts(row), matrix(row * W);
-    for (int p = 0; p < W; p++) counts[p] = off[p + 1] - off[p];
-    counts[W] = nHash;
+    for (int f = 0; f < F; f++) counts[f] = fineOff[f + 1] - fineOff[f];
+    counts[F] = nHash;
     if (int rc = op.all_gather_host(op.user, counts.data(), matrix.data(), row * 8)) return rc;
-    std::vector<uint64_t> recvCnt((size_t) W + 1, 0), hashCnt((size_t) W + 1, 0);
+    // the ranks' k-mer ranges: runs of fine slices with about the same number of tuples over all ranks (every rank cuts the same way)
+    std::vector<int> cut(1, 0);
+    {
+        std::vector<uint64_t> fine((size_t) F, 0); uint64_t grand = 0;
+        for (int p = 0; p < W; p++) for (int f = 0; f < F; f++) { fine[f] += matrix[p * row + f]; grand += matrix[p * row + f]; }
+        const uint64_t target = (grand + (uint64_t) W - 1) / (uint64_t) W;
+        uint64_t acc = 0;
+        for (int f = 0; f < F; f++) { if (acc && acc + fine[f] > target && (int) cut.size() < W) { cut.push_back(f); acc = 0; } acc += fine[f]; }
+        while ((int) cut.size() < W) cut.push_back(F);      // (fewer occupied slices than ranks: the last ranks get nothing)
+        cut.push_back(F);
+    }
+    std::vector<uint64_t> off((size_t) W + 1), recvCnt((size_t) W + 1, 0), hashCnt((size_t) W + 1, 0);
+    for (int p = 0; p <= W; p++) off[p] = fineOff[cut[p]];
     bool below = false;
     for (int p = 0; p < W; p++) {
-        recvCnt[p + 1] = recvCnt[p] + matrix[p * row + R];
-        hashCnt[p + 1] = hashCnt[p] + (R == W - 1 ? matrix[p * row + W] : 0);
-        for (int q = 0; q < R; q++) below = below || matrix[p * row + q] != 0;
+        uint64_t mine = 0;
+        for (int f = cut[R]; f < cut[R + 1]; f++) mine += matrix[p * row + f];
+        recvCnt[p + 1] = recvCnt[p] + mine;
+        hashCnt[p + 1] = hashCnt[p] + (R == W - 1 ? matrix[p * row + F] : 0);
+        for (int f = 0; f < cut[R]; f++) below = below || matrix[p * row + f] != 0;
     }
     const uint64_t m = recvCnt[W], h = hashCnt[W];
     DevBuf<uint64_t> rk, rhk; DevBuf<char> rv, rhv;
     if (!rk.alloc(m) || !rv.alloc(m * vb) || !rhk.alloc(h) || !rhv.alloc(h * vb)) { cdm_set_error("cdm_kmermatch_dist: out of device memory for %llu received k-mer tuples", (unsigned long long) (m + h)); return CDM_ERR_HIP; }
     CDM_HIP(hipSetDevice(ctx->device));
-    std::vector<uint64_t> so(row), ro(row);
+    std::vector<uint64_t> so((size_t) W + 1), ro((size_t) W + 1);
     auto exchange = [&](const void *send, void *recv, const std::vector<uint64_t> &sOff, const std::vector<uint64_t> &rOff, uint64_t width) -> int {
         for (int p = 0; p <= W; p++) { so[p] = sOff[p] * width; ro[p] = rOff[p] * width; }
         return op.all_to_all_dev(op.user, send, so.data(), recv, ro.data(), ctx->stream);

@@ -1168,30 +1168,13 @@ __global__ void k_block_cuts(const unsigned long long *__restrict__ prefix, uint
         out[side] = res;
     }
 }
-// k-mer range a tuple belongs to: the largest p with (2^(2k) p) / parts <= k-mer (the ranges of ExtractArgs::kLo / kHi)
-template <typename LY>
-__global__ void k_dest_range(const uint64_t *__restrict__ keys, uint64_t m, TupleGeom geom, int kbits, uint32_t parts, uint32_t *__restrict__ dest, uint32_t *__restrict__ idx) {
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const uint64_t km = LY::kmerOf(keys[i], 0, geom);
-    const unsigned __int128 space = (unsigned __int128) 1 << kbits;
-    uint32_t p = (uint32_t) (((unsigned __int128) km * parts) >> kbits);
-    if (p >= parts) p = parts - 1;
-    while (p + 1 < parts && (uint64_t) (space * (p + 1) / parts) <= km) p++;
-    while (p > 0 && (uint64_t) (space * p / parts) > km) p--;
-    dest[i] = p; idx[i] = (uint32_t) i;
-}
-template <typename V>
-__global__ void k_gather_pairs(const uint32_t *__restrict__ idx, uint64_t m, const uint64_t *__restrict__ kin, const V *__restrict__ vin, uint64_t *__restrict__ kout, V *__restrict__ vout) {
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) { const uint32_t j = idx[i]; kout[i] = kin[j]; vout[i] = vin[j]; }
-}
-// first index of the sorted destinations that is >= p, for p = 0 .. parts
-__global__ void k_dest_bounds(const uint32_t *__restrict__ dest, uint64_t m, uint32_t parts, unsigned long long *__restrict__ out) {
+// first index of the keys (ordered by the `slices`-valued field at bit `shift`) whose field is >= p, for p = 0 .. slices
+__global__ void k_slice_bounds(const uint64_t *__restrict__ keys, uint64_t m, int shift, uint32_t slices, unsigned long long *__restrict__ out) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > parts) return;
+    if (p > slices) return;
+    if (p == slices) { out[p] = m; return; }
     uint64_t lo = 0, hi = m;
-    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (dest[mid] < p) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (((keys[mid] >> shift) & (uint64_t) (slices - 1)) < p) lo = mid + 1; else hi = mid; }
     out[p] = lo;
 }
 __global__ __launch_bounds__(256) void k_reduce_stats(const unsigned long long *__restrict__ stripes, unsigned long long *__restrict__ out) {
@@ -1305,6 +1288,7 @@ struct KmerJobBase {
     const void *sendKeys = nullptr, *sendVals = nullptr, *sendHashKeys = nullptr, *sendHashVals = nullptr; unsigned long long sendHash = 0; int valBytes = 0;
     cdm_ctx *ctx = nullptr; const cdm_seqdb *db = nullptr; cdm_kmer_params parCopy; const cdm_kmer_params *par = nullptr;
     int part = 0, nparts = 1;           // this rank's k-mer range (nparts == 1: everything)
+    int block = 0, nBlocks = 0;         // splitBegin: block `block` of `nBlocks` of the sequences (0: block `part` of `nparts`), the tuples ordered by nparts ranges
     unsigned long long live = 0, nKept = 0, regionTwo = 0;      // real tuples of region 1 in this range; kept group tuples; real tuples of region 2
     bool anyBelow = false;              // a real tuple with a k-mer below this range exists (then the array's very first run is not here)
     uint64_t *gathered = nullptr;       // gatherByRep: the kept group keys grouped by representative, k-mer order inside (device)
@@ -1316,11 +1300,10 @@ struct KmerJob : KmerJobBase {
     hipStream_t s = nullptr; uint32_t n = 0; int k = 0;
     uint32_t idBits = 0, diagBits = 0; int diagBias = 0; const char *sortEnv = nullptr; bool lsdOnly = false;
     bool wide = false;                        // group keys without the representative (runsort.h RunArgs; packGroupKey)
-    int block = 0, nBlocks = 0;               // splitBegin: block `block` of `nBlocks` of the sequences (0: part of nparts)
     bool passes = false;                      // a range of the k-mer-range passes on one device (kmermatchPassesT): no exchange of group keys follows
     uint64_t r2Slots = 0;                     // size of region 2: n (one whole-sequence hash slot per sequence), or what arrived (split by reads)
     uint32_t ordLo = 0, ordHi = 0;            // split by reads: the order ranks of the sequences this rank extracts
-    DevBuf<uint64_t> splitK; DevBuf<V> splitV; DevBuf<uint32_t> splitD0, splitD1, splitI0, splitI1;
+    DevBuf<uint64_t> splitK; DevBuf<V> splitV;           // keepOnlyOutgoing: the ordered tuples in buffers of their own size
     DevBuf<unsigned long long> counters;      // scratch counters ([2] = number of kept group tuples)
     DevBuf<unsigned int> cls;                 // slow-path list sizes
     DevBuf<uint32_t> listShort, listLong, listSingle, listHuge;
@@ -1465,39 +1448,45 @@ int phaseA() override {
 // to the last range.  What a rank receives, concatenated in rank order, is then in the global slot order: ranks own consecutive blocks
 // of that order.
 int splitPartition() {
+    // ONE radix pass on the top 8 bits of the k-mer and the bit above it (set in unused slots only, which so end up last): the real tuples
+    // ordered by CDM_KPART_SLICES = 256 slices of the k-mer space, slot order inside a slice
     DevBuf<unsigned long long> cnt, bounds;
-    if (!cnt.alloc(2) || !bounds.alloc((size_t) nparts + 2)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    if (!cnt.alloc(2) || !bounds.alloc((size_t) CDM_KPART_SLICES + 2)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     unsigned long long m = 0, h = 0;
-    if (kmerSlots) { if (int rc = rx::compactPairs<uint64_t, V>(s, k0.p, v0.p, (uint64_t) kmerSlots, k1.p, v1.p, cnt.p)) return rc; hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, s); }
-    if (r2Slots) { if (int rc = rx::compactPairs<uint64_t, V>(s, k0.p + kmerSlots, v0.p + kmerSlots, (uint64_t) r2Slots, k1.p + kmerSlots, v1.p + kmerSlots, cnt.p + 1)) return rc; hipMemcpyAsync(&h, cnt.p + 1, 8, hipMemcpyDeviceToHost, s); }
-    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: compaction failed"); return CDM_ERR_HIP; }
-    if (m >= 0xFFFFFF00ull) { cdm_set_error("cdm_kmermatch: more than 2^32 tuples on one rank of the split by reads"); return CDM_ERR_UNSUPPORTED; }
-    sendOff.assign((size_t) nparts + 1, 0);
-    if (!splitK.alloc(m) || !splitV.alloc(m) || !splitD0.alloc(m) || !splitD1.alloc(m) || !splitI0.alloc(m) || !splitI1.alloc(m)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
-    if (m) {
-        TupleGeom g1 = geom; g1.kmerSlots = ~0ull;              // (every compacted tuple is a region-1 tuple)
-        hipLaunchKernelGGL(k_dest_range<LY>, CDM_GRID((m + 255) / 256, 256), dim3(256), 0, s, (const uint64_t *) k1.p, (uint64_t) m, g1, 2 * k, (uint32_t) nparts, splitD0.p, splitI0.p);
-        bool first = true;
-        if (int rc = rx::sortPairs<uint32_t, uint32_t>(s, ctx->cuCount, splitD0.p, splitD1.p, splitI0.p, splitI1.p, (uint64_t) m, 0, (int) bitsFor((uint64_t) nparts), first)) return rc;
-        const uint32_t *dS = first ? splitD0.p : splitD1.p, *iS = first ? splitI0.p : splitI1.p;
-        hipLaunchKernelGGL(k_gather_pairs<V>, CDM_GRID((m + 255) / 256, 256), dim3(256), 0, s, iS, (uint64_t) m, (const uint64_t *) k1.p, (const V *) v1.p, splitK.p, splitV.p);
-        hipLaunchKernelGGL(k_dest_bounds, dim3(1), dim3(256), 0, s, dS, (uint64_t) m, (uint32_t) nparts, bounds.p);
-        hipMemcpyAsync(sendOff.data(), bounds.p, ((size_t) nparts + 1) * 8, hipMemcpyDeviceToHost, s);
-        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: ordering the tuples by k-mer range failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    bool inFirst = true;
+    const int shift = 2 * k - 8;
+    if (kmerSlots) { if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, k0.p, k1.p, v0.p, v1.p, (uint64_t) kmerSlots, shift, 2 * k + 1, inFirst)) return rc; }
+    uint64_t *rK = inFirst ? k0.p : k1.p, *oK = inFirst ? k1.p : k0.p; V *rV = inFirst ? v0.p : v1.p, *oV = inFirst ? v1.p : v0.p;
+    if (kmerSlots) {
+        hipLaunchKernelGGL(k_live_count, dim3(1), dim3(1), 0, s, (const uint64_t *) rK, (uint64_t) kmerSlots, 2 * k, cnt.p);
+        hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, s);
     }
-    sendKeys = splitK.p; sendVals = splitV.p; valBytes = (int) sizeof(V);
+    // the hash tuples of region 2, compacted (from the extraction buffers into the other pair, behind region 1)
+    if (r2Slots) {
+        if (int rc = rx::compactPairs<uint64_t, V>(s, k0.p + kmerSlots, v0.p + kmerSlots, (uint64_t) r2Slots, k1.p + kmerSlots, v1.p + kmerSlots, cnt.p + 1)) return rc;
+        hipMemcpyAsync(&h, cnt.p + 1, 8, hipMemcpyDeviceToHost, s);
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: ordering the tuples by k-mer slice failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    sendOff.assign((size_t) CDM_KPART_SLICES + 1, 0);
+    if (m) {
+        hipLaunchKernelGGL(k_slice_bounds, dim3(2), dim3(256), 0, s, (const uint64_t *) rK, (uint64_t) m, shift, (uint32_t) CDM_KPART_SLICES, bounds.p);
+        hipMemcpyAsync(sendOff.data(), bounds.p, ((size_t) CDM_KPART_SLICES + 1) * 8, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: ordering the tuples by k-mer slice failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    }
+    (void) oK; (void) oV;
+    sendKeys = rK; sendVals = rV; valBytes = (int) sizeof(V);
     sendHashKeys = k1.p + kmerSlots; sendHashVals = v1.p + kmerSlots; sendHash = h;
     return CDM_OK;
 }
 int splitBegin() override {
     split = true;
     // (which sequences: phaseA's slot layout, blocks of about equal slot counts)
-    if (nparts > 255) { cdm_set_error("cdm_kmermatch: the split by reads takes up to 255 ranks"); return CDM_ERR_UNSUPPORTED; }
+    if (nparts != CDM_KPART_SLICES) { cdm_set_error("cdm_kmermatch: internal error: the split by reads orders its tuples by %d slices", CDM_KPART_SLICES); return CDM_ERR_INVALID; }
     return phaseA();       // (a rank without sequences of its own - fewer sequences than ranks - goes through with empty buffers)
 }
 int splitFinish(const void *keysIn, const void *valsIn, uint64_t m, const void *hkeys, const void *hvals, uint64_t h, bool below) override {
     // the extraction's buffers go, the received tuples become the two regions of the tuple array
-    splitD0.free(); splitD1.free(); splitI0.free(); splitI1.free(); slots.free(); slotOff.free(); rankOf.free();
+    slots.free(); slotOff.free(); rankOf.free();
     listShort.free(); listLong.free(); listSingle.free(); listHuge.free();
     splitK.free(); splitV.free(); k0.free(); k1.free(); v0.free(); v1.free();        // (sent: the exchange is over)
     DevBuf<uint64_t> nk0, nk1; DevBuf<V> nv0, nv1;
@@ -1514,10 +1503,13 @@ int splitFinish(const void *keysIn, const void *valsIn, uint64_t m, const void *
 // move out of the extraction buffers into two small ones
 int keepOnlyOutgoing() {
     DevBuf<uint64_t> hk; DevBuf<V> hv;
-    if (!hk.alloc(sendHash) || !hv.alloc(sendHash)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    const unsigned long long m = sendOff.empty() ? 0 : sendOff.back();
+    if (!hk.alloc(sendHash) || !hv.alloc(sendHash) || !splitK.alloc(m) || !splitV.alloc(m)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    if (m) { hipMemcpyAsync(splitK.p, sendKeys, m * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(splitV.p, sendVals, m * sizeof(V), hipMemcpyDeviceToDevice, s); }
     if (sendHash) { hipMemcpyAsync(hk.p, sendHashKeys, sendHash * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(hv.p, sendHashVals, sendHash * sizeof(V), hipMemcpyDeviceToDevice, s); }
     if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: keeping a block's tuples failed"); return CDM_ERR_HIP; }
-    k0.free(); k1.free(); v0.free(); v1.free(); splitD0.free(); splitD1.free(); splitI0.free(); splitI1.free();
+    k0.free(); k1.free(); v0.free(); v1.free();
+    sendKeys = splitK.p; sendVals = splitV.p;
     slots.free(); slotOff.free(); rankOf.free(); listShort.free(); listLong.free(); listSingle.free(); listHuge.free(); cls.free(); counters.free();
     keptHashK.p = hk.release(); keptHashV.p = hv.release();
     sendHashKeys = keptHashK.p; sendHashVals = keptHashV.p;
@@ -2015,10 +2007,10 @@ int kmermatchPassesT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *p
     const bool stats = cdmGetenv("CDM_BUCKET_STATS") != nullptr;
     // (this path runs because memory is short: its buffers are planned at their exact sizes, without the allocator's head room)
     struct NoHeadroom { float was; NoHeadroom() : was(cdmPoolHeadroomSwap(1.0f)) {} ~NoHeadroom() { cdmPoolHeadroomSwap(was); } } noHeadroom;
-    // ---- how many tuples of every block fall into each of F = 255 fine slices of the k-mer space ([F]: the whole-sequence hash tuples,
+    // ---- how many tuples of every block fall into each of F = 256 fine slices of the k-mer space ([F]: the whole-sequence hash tuples,
     // which sort behind every k-mer).  The P ranges are runs of fine slices with about the same number of tuples: equal slices of the
     // k-mer space are anything but equal in tuples (1 M synthetic reads, 3 slices: 55 / 33 / 12 %).
-    constexpr int F = 255;
+    constexpr int F = CDM_KPART_SLICES;
     std::vector<std::vector<unsigned long long>> cnt((size_t) B, std::vector<unsigned long long>((size_t) F + 1, 0));
     auto extractBlock = [&](KmerJob<LY> &ex, int b) -> int { ex.part = 0; ex.nparts = F; ex.block = b; ex.nBlocks = B; ex.passes = true; return ex.splitBegin(); };
     std::vector<unsigned long long> fine((size_t) F, 0); unsigned long long grand = 0;
@@ -2220,7 +2212,7 @@ extern "C" int cdm_kmermatch_split_begin(cdm_ctx *ctx, const cdm_seqdb *db, cons
     else if (db->maxLen < (1u << 20) - 1u && db->n < (1ull << 24)) h->job = new KmerJob<LayoutLong>(ctx, db, par);
     else if (db->maxLen < MAX_SEQ_LETTERS) h->job = new KmerJob<LayoutHuge>(ctx, db, par);
     else { delete h; cdm_set_error("cdm_kmermatch_split_begin: sequences of %u letters or more are not implemented", MAX_SEQ_LETTERS); return CDM_ERR_UNSUPPORTED; }
-    h->job->part = rank; h->job->nparts = nranks; h->nSeq = db->n;
+    h->job->part = 0; h->job->nparts = CDM_KPART_SLICES; h->job->block = rank; h->job->nBlocks = nranks; h->nSeq = db->n;      // the tuples ordered by FINE slices of the k-mer space: the caller cuts the ranks' ranges from all ranks' counts
     h->repShift = bitsFor(db->n) + bitsFor(2ull * db->maxLen + 2) + 1;
     const int rc = h->job->splitBegin();
     if (rc != CDM_OK) { cdm_kpart_free(h); return rc; }
@@ -2229,13 +2221,14 @@ extern "C" int cdm_kmermatch_split_begin(cdm_ctx *ctx, const cdm_seqdb *db, cons
 }
 extern "C" int cdm_kpart_outgoing(const cdm_kpart *h, uint64_t *offsets, const void **keys, const void **vals, int *valBytes, const void **hashKeys, const void **hashVals, uint64_t *nHash) {
     if (!h || !h->job->split || !offsets || !keys || !vals || !valBytes || !hashKeys || !hashVals || !nHash) { cdm_set_error("cdm_kpart_outgoing: invalid argument"); return CDM_ERR_INVALID; }
-    for (int p = 0; p <= h->job->nparts; p++) offsets[p] = h->job->sendOff[p];
+    for (int p = 0; p <= CDM_KPART_SLICES; p++) offsets[p] = h->job->sendOff[p];
     *keys = h->job->sendKeys; *vals = h->job->sendVals; *valBytes = h->job->valBytes;
     *hashKeys = h->job->sendHashKeys; *hashVals = h->job->sendHashVals; *nHash = h->job->sendHash;
     return CDM_OK;
 }
 extern "C" int cdm_kmermatch_split_finish(cdm_ctx *ctx, cdm_kpart *h, const void *keys, const void *vals, uint64_t m, const void *hashKeys, const void *hashVals, uint64_t nHash, int below) {
     if (!ctx || !h || !h->job->split || (m && (!keys || !vals)) || (nHash && (!hashKeys || !hashVals))) { cdm_set_error("cdm_kmermatch_split_finish: invalid argument"); return CDM_ERR_INVALID; }
+    h->job->part = h->job->block; h->job->nparts = h->job->nBlocks;          // from here on the handle is rank `part` of `nparts` k-mer ranges, as cdm_kmermatch_part leaves it
     if (nHash && h->job->part != h->job->nparts - 1) { cdm_set_error("cdm_kmermatch_split_finish: the whole-sequence hash tuples belong to the last rank"); return CDM_ERR_INVALID; }
     CDM_HIP(hipSetDevice(ctx->device));
     return h->job->splitFinish(keys, vals, m, hashKeys, hashVals, nHash, below != 0);

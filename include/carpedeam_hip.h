@@ -180,10 +180,14 @@ typedef struct cdm_kpart cdm_kpart;
 int cdm_kmermatch_part(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int part, int nparts, cdm_kpart **out);
 /* The same first half with the extraction split by READS (what cdm_kmermatch_dist does): rank r extracts the k-mers of ITS block of the
  * sequences only - block r of nranks of the (length descending, id ascending) order fillKmerPositionArray's result is sorted into
- * (kmermatcher.cpp:391-430) - and orders the tuples by the k-mer range they belong to; cdm_kpart_outgoing names the send buffers
- * (offsets[p]..offsets[p+1] = the tuples for rank p, keys 8 bytes and values *val_bytes each; the whole-sequence hash tuples all go
- * to the last rank); cdm_kmermatch_split_finish takes what arrived, CONCATENATED IN RANK ORDER (device buffers; `below` = 1 if any
- * rank sent a tuple to a range in front of this one), and leaves the handle where cdm_kmermatch_part leaves it. */
+ * (kmermatcher.cpp:391-430), the blocks cut so that they hold about the same number of k-mer slots - and orders its tuples by
+ * CDM_KPART_SLICES equal slices of the k-mer space (its top 8 bits: one radix pass).  cdm_kpart_outgoing names the send buffers (offsets[s]..offsets[s+1] = the tuples of
+ * slice s, keys 8 bytes and values *val_bytes each; the whole-sequence hash tuples sort behind every k-mer).  The CALLER cuts the
+ * ranks' k-mer ranges as runs of slices from all ranks' counts (canonical k-mers crowd the low end of the k-mer space: equal slices
+ * are not equal shares), sends every range to its rank and the hash tuples to the last one; cdm_kmermatch_split_finish takes what
+ * arrived, CONCATENATED IN RANK ORDER (device buffers; `below` = 1 if any rank holds a tuple of a range in front of this one), and
+ * leaves the handle where cdm_kmermatch_part leaves it (rank r of nranks ranges). */
+#define CDM_KPART_SLICES 256
 int cdm_kmermatch_split_begin(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int rank, int nranks, cdm_kpart **out);
 int cdm_kpart_outgoing(const cdm_kpart *h, uint64_t *offsets, const void **keys, const void **vals, int *val_bytes,
                        const void **hash_keys, const void **hash_vals, uint64_t *n_hash);
