@@ -64,7 +64,7 @@ EXPORTS = [
     "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
     "cdm_rescore_hamming", "cdm_pool_headroom", "cdm_pool_stats", "cdm_env_refresh",
     "cdm_comm_unique_id", "cdm_comm_create_rccl", "cdm_comm_create_ops", "cdm_comm_free", "cdm_comm_rank", "cdm_comm_world", "cdm_kmermatch_dist",
-    "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist",
+    "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist", "cdm_comm_owned", "cdm_kpart_gather_at",
 ]
 
 
@@ -163,6 +163,9 @@ def lib():
             l.cdm_comm_free.restype = None
             l.cdm_kmermatch_dist.argtypes = [vp, vp, vp, C.POINTER(KmerParams), C.POINTER(vp)]
             l.cdm_seqdb_allgather_owned.argtypes = [vp, vp, vp, C.POINTER(vp)]
+            if hasattr(l, "cdm_comm_owned"):
+                l.cdm_comm_owned.argtypes = [vp, C.c_uint64, vp]
+                l.cdm_comm_world.argtypes = [vp]
             l.cdm_reads_iteration_dist.argtypes = [vp, vp, vp, C.POINTER(KmerParams), C.POINTER(RescoreParams), C.POINTER(AncientParams), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         try:
             l.cdm_env_refresh.restype = None
@@ -576,6 +579,13 @@ class Comm:
         h = C.c_void_p()
         _check(lib().cdm_seqdb_allgather_owned(self.ctx.h, self.h, db_local.h, C.byref(h)))
         return SeqDb(self.ctx, h)
+
+    def owned(self, n):
+        """bounds[world + 1]: rank r owns the sequences [bounds[r], bounds[r + 1]) of a DB of n sequences (cdm_comm_owned: as this
+        communicator's last kmermatch on such a DB cut them - equal shares of the group keys -, equal id ranges before any)"""
+        b = np.zeros(lib().cdm_comm_world(self.h) + 1, np.uint64)
+        _check(lib().cdm_comm_owned(self.h, int(n), _ptr(b)))
+        return b
 
     def reads_iteration(self, db, kpar=None, rpar=None, apar=None):
         """one iteration of the reads loop over the ranks -> (hits, alns, corrected DB, next DB); the DBs are complete on every rank"""

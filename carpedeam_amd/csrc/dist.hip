@@ -71,6 +71,7 @@ struct cdm_comm {
     // A copy on either side of a transfer costs 2 x bytes / 5 TB/s against bytes / 0.15 TB/s for the link.  CDM_RCCL_DIRECT=1: RCCL
     // on the caller's buffers (A/B).
     struct Stage { void *p = nullptr; size_t bytes = 0; } stage, sendStage, recvStage;
+    std::vector<uint64_t> own; uint64_t ownN = 0;       // the owners' id ranges as the last cdm_kmermatch_dist cut them (for DBs of ownN sequences)
 };
 namespace {
 int ensureStage(cdm_comm *c, cdm_comm::Stage &st, size_t need) {
@@ -184,6 +185,13 @@ extern "C" void cdm_comm_free(cdm_comm *c) {
     if (c->nccl) { Rccl *r = rccl(nullptr); if (r) (void) r->commDestroy(c->nccl); }
     delete c;
 }
+extern "C" int cdm_comm_owned(const cdm_comm *c, uint64_t n, uint64_t *bounds) {
+    if (!c || !bounds) { cdm_set_error("cdm_comm_owned: invalid argument"); return CDM_ERR_INVALID; }
+    const int W = c->world;
+    if (c->ownN == n && (int) c->own.size() == W + 1) { for (int p = 0; p <= W; p++) bounds[p] = c->own[p]; return CDM_OK; }
+    for (int p = 0; p <= W; p++) bounds[p] = (uint64_t) ((unsigned __int128) n * (unsigned) p / (unsigned) W);
+    return CDM_OK;
+}
 extern "C" int cdm_comm_rank(const cdm_comm *c) { return c->rank; }
 extern "C" int cdm_comm_world(const cdm_comm *c) { return c->world; }
 
@@ -284,9 +292,31 @@ extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *d
         stale[0] = cnt; stale[1] = have ? target : 0;
     }
     // ---- the all-to-all of the group keys: slice p of the keys grouped by representative goes to the owner of those representatives
-    std::vector<uint64_t> off((size_t) W + 1);
+    // the owners' id ranges: equal shares of the group keys, cut from all ranks' histograms over 4096 equal id ranges (representatives
+    // are the longest, then lowest ids of their k-mer groups - with equal id ranges the first of 8 ranks owned 88 % of the keys)
     const void *keys = nullptr;
-    if (int rc = cdm_kpart_gather(ctx, g.p, W, off.data(), &keys)) return rc;
+    const uint64_t nSeq = db->n;
+    std::vector<uint64_t> own((size_t) W + 1, 0);
+    {
+        constexpr int S = 4096;
+        std::vector<uint64_t> sb((size_t) S + 1), so((size_t) S + 1), hist((size_t) S), all((size_t) S * W);
+        for (int t = 0; t <= S; t++) sb[t] = (uint64_t) ((unsigned __int128) nSeq * (unsigned) t / (unsigned) S);
+        if (int rc = cdm_kpart_gather_at(ctx, g.p, S + 1, sb.data(), so.data(), &keys)) return rc;
+        so[S] = info[1];
+        for (int t = 0; t < S; t++) hist[t] = so[t + 1] - so[t];
+        if (int rc = op.all_gather_host(op.user, hist.data(), all.data(), (uint64_t) S * 8)) return rc;
+        uint64_t grand = 0;
+        for (int t = 0; t < S; t++) { uint64_t c = 0; for (int p = 0; p < W; p++) c += all[(size_t) p * S + t]; hist[t] = c; grand += c; }
+        const uint64_t target = (grand + (uint64_t) W - 1) / (uint64_t) W;
+        uint64_t acc = 0; int at = 1;
+        for (int t = 0; t < S && at < W; t++) { if (acc && acc + hist[t] > target) { own[at++] = sb[t]; acc = 0; } acc += hist[t]; }
+        while (at < W) own[at++] = nSeq;
+        own[W] = nSeq;
+        cm->own = own; cm->ownN = nSeq;
+    }
+    std::vector<uint64_t> off((size_t) W + 1);
+    if (int rc = cdm_kpart_gather_at(ctx, g.p, W + 1, own.data(), off.data(), &keys)) return rc;
+    off[W] = info[1];
     std::vector<uint64_t> counts((size_t) W), matrix((size_t) W * W);
     for (int p = 0; p < W; p++) counts[p] = off[p + 1] - off[p];
     if (int rc = op.all_gather_host(op.user, counts.data(), matrix.data(), (uint64_t) W * 8)) return rc;
@@ -341,7 +371,9 @@ extern "C" int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *cm, const cdm_s
     const cdm_comm_ops &op = cm->ops;
     CDM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const uint64_t n = local->n, lo = (uint64_t) R * n / (uint64_t) W, hi = (uint64_t) (R + 1) * n / (uint64_t) W, m = hi - lo;
+    std::vector<uint64_t> own((size_t) W + 1);
+    if (int rc = cdm_comm_owned(cm, local->n, own.data())) return rc;
+    const uint64_t n = local->n, lo = own[R], hi = own[R + 1], m = hi - lo;
     uint32_t wb[2] = {0, 0};
     if (n) { CDM_HIP(hipMemcpyAsync(&wb[0], local->woff + lo, 4, hipMemcpyDeviceToHost, s)); CDM_HIP(hipMemcpyAsync(&wb[1], local->woff + hi, 4, hipMemcpyDeviceToHost, s)); CDM_HIP(hipStreamSynchronize(s)); }
     const uint64_t w0 = wb[0], w = wb[1] - wb[0];

@@ -2170,7 +2170,7 @@ constexpr uint32_t MAX_SEQ_LETTERS = 1u << 22;        // (diagonals of 24 bits: 
 static bool packedLayoutFits(const cdm_seqdb *db, int k) { return 2 * k + 1 + 2 * (int) bitsFor((uint64_t) db->maxLen + 1) <= 63; }
 
 // ---- multi-GPU: kmermatcher in two phases with an exchange in between (include/carpedeam_hip.h, carpedeam_amd/shard.py)
-struct cdm_kpart { KmerJobBase *job = nullptr; uint64_t nSeq = 0; uint32_t repShift = 0; };
+struct cdm_kpart { KmerJobBase *job = nullptr; uint64_t nSeq = 0; uint32_t repShift = 0; bool gatheredDone = false; };
 namespace {
 // first index of `keys` (sorted by representative) whose representative is >= bound[t]
 __global__ void k_rep_bounds(const uint64_t *__restrict__ keys, uint64_t n, int repShift, const uint64_t *__restrict__ bound, int nb, unsigned long long *__restrict__ out) {
@@ -2245,23 +2245,29 @@ extern "C" int cdm_kpart_stale(cdm_ctx *ctx, cdm_kpart *h, uint64_t J, uint32_t 
     memcpy(out, h->job->staleHost, 67 * sizeof(uint32_t));
     return CDM_OK;
 }
+// offsets[t] = first gathered group key whose representative is >= bounds[t] (ascending sequence ids; nb of them).  The first call
+// groups the keys by representative (run records, their stable sort, the expanding gather), later calls only look bounds up.
+extern "C" int cdm_kpart_gather_at(cdm_ctx *ctx, cdm_kpart *h, int nb, const uint64_t *bounds, uint64_t *offsets, const void **devKeys) {
+    if (nb < 1 || !bounds || !offsets || !devKeys) { cdm_set_error("cdm_kpart_gather_at: invalid argument"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    if (!h->gatheredDone) { const int rc = h->job->gatherByRep(); if (rc != CDM_OK) return rc; h->gatheredDone = true; }
+    DevBuf<uint64_t> dBound; DevBuf<unsigned long long> dOut;
+    if (!dBound.alloc(nb) || !dOut.alloc(nb)) { cdm_set_error("cdm_kpart_gather_at: out of device memory"); return CDM_ERR_HIP; }
+    CDM_HIP(hipMemcpyAsync(dBound.p, bounds, (size_t) nb * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_rep_bounds, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, (const uint64_t *) h->job->gathered, (uint64_t) h->job->nKept, (int) h->repShift, (const uint64_t *) dBound.p, nb, dOut.p);
+    std::vector<unsigned long long> o((size_t) nb);
+    CDM_HIP(hipMemcpyAsync(o.data(), dOut.p, (size_t) nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CDM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t < nb; t++) offsets[t] = o[t];
+    *devKeys = h->job->gathered;
+    return CDM_OK;
+}
 extern "C" int cdm_kpart_gather(cdm_ctx *ctx, cdm_kpart *h, int nranks, uint64_t *offsets, const void **devKeys) {
     if (nranks < 1 || !offsets || !devKeys) { cdm_set_error("cdm_kpart_gather: invalid argument"); return CDM_ERR_INVALID; }
-    CDM_HIP(hipSetDevice(ctx->device));
-    const int rc = h->job->gatherByRep();
-    if (rc != CDM_OK) return rc;
-    std::vector<uint64_t> bound(nranks + 1);
+    std::vector<uint64_t> bound((size_t) nranks + 1);
     for (int r = 0; r <= nranks; r++) bound[r] = (uint64_t) ((unsigned __int128) h->nSeq * (unsigned) r / (unsigned) nranks);
-    DevBuf<uint64_t> dBound; DevBuf<unsigned long long> dOut;
-    if (!dBound.alloc(nranks + 1) || !dOut.alloc(nranks + 1)) { cdm_set_error("cdm_kpart_gather: out of device memory"); return CDM_ERR_HIP; }
-    CDM_HIP(hipMemcpyAsync(dBound.p, bound.data(), (nranks + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_rep_bounds, dim3((nranks + 64) / 64), dim3(64), 0, ctx->stream, (const uint64_t *) h->job->gathered, (uint64_t) h->job->nKept, (int) h->repShift, (const uint64_t *) dBound.p, nranks + 1, dOut.p);
-    std::vector<unsigned long long> o(nranks + 1);
-    CDM_HIP(hipMemcpyAsync(o.data(), dOut.p, (nranks + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    CDM_HIP(hipStreamSynchronize(ctx->stream));
-    for (int r = 0; r <= nranks; r++) offsets[r] = o[r];
+    if (int rc = cdm_kpart_gather_at(ctx, h, nranks + 1, bound.data(), offsets, devKeys)) return rc;
     offsets[nranks] = h->job->nKept;
-    *devKeys = h->job->gathered;
     return CDM_OK;
 }
 extern "C" int cdm_kpart_sort(cdm_ctx *ctx, cdm_kpart *h, const void *devKeys, uint64_t nKeys, uint32_t *head, uint64_t info[2]) {

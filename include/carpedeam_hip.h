@@ -196,6 +196,10 @@ int cdm_kmermatch_split_finish(cdm_ctx *ctx, cdm_kpart *h, const void *keys, con
 int cdm_kpart_info(const cdm_kpart *h, uint64_t info[4]);
 int cdm_kpart_stale(cdm_ctx *ctx, cdm_kpart *h, uint64_t J, uint32_t out[67]);
 int cdm_kpart_gather(cdm_ctx *ctx, cdm_kpart *h, int nranks, uint64_t *offsets, const void **dev_keys);
+/* the same with the owners' ranges given: offsets[t] = first key whose representative is >= bounds[t] (nb ascending sequence ids; the
+ * keys are grouped by representative on the first call).  cdm_kmermatch_dist calls it twice: with 4097 equal bounds for a histogram of
+ * keys per id range, then with the nranks + 1 bounds it cut from all ranks' histograms. */
+int cdm_kpart_gather_at(cdm_ctx *ctx, cdm_kpart *h, int nb, const uint64_t *bounds, uint64_t *offsets, const void **dev_keys);
 int cdm_kpart_sort(cdm_ctx *ctx, cdm_kpart *h, const void *dev_keys, uint64_t n_keys, uint32_t *head, uint64_t info[2]);
 int cdm_kpart_vote(cdm_ctx *ctx, cdm_kpart *h, const uint32_t *cont, const uint32_t *stale, cdm_hits **out);
 int cdm_kpart_cont_cap(void);
@@ -324,9 +328,13 @@ int cdm_cyclecheck(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t max_seq_len, int 
  *   cdm_comm_unique_id       rank 0: the 128 bytes of ncclGetUniqueId, to be handed to every rank by whatever launched them
  *   cdm_comm_create_rccl     a rank's communicator (ncclCommInitRank on the context's device; librccl is loaded on first use)
  *   cdm_comm_create_ops      the same over collectives the caller supplies (tests: W ranks on one device; another collective library)
- *   cdm_kmermatch_dist       kmermatcher over the ranks: the hits of the representatives this rank owns - sequences
- *                            [rank n / world, (rank + 1) n / world) -, self hits for all others; the union is cdm_kmermatch's result
- *   cdm_seqdb_allgather_owned   the owned ranges of the ranks' DBs (same number of sequences on every rank) -> the complete DB
+ *   cdm_kmermatch_dist       kmermatcher over the ranks: the hits of the representatives this rank OWNS, self hits for all others; the
+ *                            union is cdm_kmermatch's result.  Owned = a range of sequence ids per rank, cut by this call so that every
+ *                            rank owns about the same number of group keys (representatives are the longest, then lowest ids: equal id
+ *                            ranges gave the first of 8 ranks 88 % of them at 50 M reads); cdm_comm_owned reports the ranges
+ *   cdm_comm_owned           bounds[world + 1]: rank r owns the sequences [bounds[r], bounds[r + 1]) of a DB of n sequences - as the
+ *                            communicator's last cdm_kmermatch_dist on such a DB cut them, equal ranges before any
+ *   cdm_seqdb_allgather_owned   the owned ranges (cdm_comm_owned) of the ranks' DBs (same number of sequences on every rank) -> the complete DB
  *   cdm_reads_iteration_dist    one iteration of the reads loop (data/nuclassemble.sh:100-146) over the ranks; hits / alns hold the
  *                            owned queries' records, corr / next are complete on every rank and equal the single-device DBs
  */
@@ -347,6 +355,7 @@ int cdm_comm_create_ops(cdm_ctx *ctx, int rank, int world, const cdm_comm_ops *o
 void cdm_comm_free(cdm_comm *c);
 int cdm_comm_rank(const cdm_comm *c);
 int cdm_comm_world(const cdm_comm *c);
+int cdm_comm_owned(const cdm_comm *c, uint64_t n, uint64_t *bounds);
 int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out);
 int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *local, cdm_seqdb **out);
 int cdm_reads_iteration_dist(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *db, const cdm_kmer_params *kpar, const cdm_rescore_params *rpar,

@@ -63,4 +63,7 @@ for W in (1, 2, 4, 8):
     sync(); t_finish = time.perf_counter() - t0
     print("W %d: every rank extracts all reads: %.1f ms; split by reads: begin %.1f + finish %.1f = %.1f ms (rank 0 receives %d tuples, sends %d)"
           % (W, 1e3 * t_part, 1e3 * t_begin, 1e3 * t_finish, 1e3 * (t_begin + t_finish), m, int(off0[-1])), flush=True)
+    goff, _ = mine.gather(W)
+    share = np.diff(goff).astype(np.float64)
+    print("      group keys of rank 0's range by owner of the representative (equal id ranges): %s %%" % " ".join("%.1f" % (100 * x / max(1.0, share.sum())) for x in share), flush=True)
     del mine, rk, rv

@@ -105,12 +105,13 @@ def run_ranks(world, fn):
     return out
 
 
-def merged_hits(per_rank, n):
-    """rows of the owned representatives from every rank's CSR -> (offsets, records) of the whole prefilter result"""
+def merged_hits(per_rank, n, bounds=None):
+    """rows of the owned representatives from every rank's CSR -> (offsets, records) of the whole prefilter result (bounds: the owners'
+    id ranges as the library's calling sequence cut them, Comm.owned; the Python calling sequence owns equal id ranges)"""
     from carpedeam_amd import shard
     offs, recs = [0], []
     for r, (off, rec) in enumerate(per_rank):
-        lo, hi = shard.owned_range(r, len(per_rank), n)
+        lo, hi = shard.owned_range(r, len(per_rank), n) if bounds is None else (int(bounds[r]), int(bounds[r + 1]))
         for q in range(lo, hi):
             recs.append(rec[int(off[q]):int(off[q + 1])])
             offs.append(offs[-1] + int(off[q + 1] - off[q]))
@@ -282,10 +283,15 @@ def test_native_exact_iteration_equals_single_device(dhigh_prefix, world, extrac
     def rank_fn(rank, comm, c):
         c.damage_load(dhigh_prefix)
         h, a, co, nx = comm.reads_iteration(c.synth(N_READS, 60, 150, 3))
-        return h.download(), co.download(), nx.download()
+        return h.download(), co.download(), nx.download(), comm.owned(N_READS)
 
     res = run_native_ranks(world, rank_fn)
-    off, rec = merged_hits([r[0] for r in res], N_READS)
+    assert all(np.array_equal(r[3], res[0][3]) for r in res)
+    shares = np.diff(res[0][3].astype(np.int64))
+    assert shares.min() > 0 and shares.sum() == N_READS
+    off, rec = merged_hits([r[0] for r in res], N_READS, res[0][3])
+    kept = [int(r[0][0][int(res[0][3][i + 1])] - r[0][0][int(res[0][3][i])]) - int(shares[i]) for i, r in enumerate(res)]       # hits of the owned rows beyond their self hits
+    assert max(kept) < 1.35 * sum(kept) / world, kept
     assert np.array_equal(off, want_hits[0]) and np.array_equal(rec, want_hits[1])
     for r in res:
         for got, want in ((r[1], want_corr), (r[2], want_asm)):
@@ -315,9 +321,9 @@ def test_native_kmermatcher_on_small_databases():
         for world in (2, 3, 5):
             def rank_fn(rank, comm, c, seqs=seqs):
                 d = c.upload_seqs(seqs)
-                return comm.kmermatch(d).download(), comm.allgather_owned(d).download()
+                return comm.kmermatch(d).download(), comm.allgather_owned(d).download(), comm.owned(len(seqs))
             res = run_native_ranks(world, rank_fn)
-            off, rec = merged_hits([r[0] for r in res], len(seqs))
+            off, rec = merged_hits([r[0] for r in res], len(seqs), res[0][2])
             assert np.array_equal(off, want[0]) and np.array_equal(rec, want[1]), (case, world)
             for r in res:
                 assert [bytes(x) for x in r[1][0]] == [bytes(x) for x in want_db[0]] and np.array_equal(r[1][1], want_db[1]), (case, world)
