@@ -292,7 +292,7 @@ extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *d
         stale[0] = cnt; stale[1] = have ? target : 0;
     }
     // ---- the all-to-all of the group keys: slice p of the keys grouped by representative goes to the owner of those representatives
-    // the owners' id ranges: equal shares of the group keys, cut from all ranks' histograms over 4096 equal id ranges (representatives
+    // the owners' id ranges: equal shares of (group keys + sequences), cut from all ranks' histograms over 4096 equal id ranges (representatives
     // are the longest, then lowest ids of their k-mer groups - with equal id ranges the first of 8 ranks owned 88 % of the keys)
     const void *keys = nullptr;
     const uint64_t nSeq = db->n;
@@ -306,7 +306,10 @@ extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *d
         for (int t = 0; t < S; t++) hist[t] = so[t + 1] - so[t];
         if (int rc = op.all_gather_host(op.user, hist.data(), all.data(), (uint64_t) S * 8)) return rc;
         uint64_t grand = 0;
-        for (int t = 0; t < S; t++) { uint64_t c = 0; for (int p = 0; p < W; p++) c += all[(size_t) p * S + t]; hist[t] = c; grand += c; }
+        // (weight of an id range: its group keys - sort 2, vote and the stages behind them work per key - plus its sequences: the owner of
+        //  a range sends those rows of the corrected and of the next DB to every rank, about as many nanoseconds per row over the links
+        //  as a key costs in the kernels)
+        for (int t = 0; t < S; t++) { uint64_t c = sb[t + 1] - sb[t]; for (int p = 0; p < W; p++) c += all[(size_t) p * S + t]; hist[t] = c; grand += c; }
         const uint64_t target = (grand + (uint64_t) W - 1) / (uint64_t) W;
         uint64_t acc = 0; int at = 1;
         for (int t = 0; t < S && at < W; t++) { if (acc && acc + hist[t] > target) { own[at++] = sb[t]; acc = 0; } acc += hist[t]; }

@@ -67,8 +67,8 @@ namespace cdmpool {
 // One pool (a small-request and a large-request arena) per host thread and device: a context belongs to one host thread
 // (INTEGRATION.md), and a block freed on one thread's stream must not be handed to another thread's stream without synchronisation
 // (ranks as threads of one process in the tests).  A block released by another thread than its owner's goes back to the OWNER's
-// arena, after a device synchronise.  A thread that ends releases what its arenas do not need; blocks of it that are still in use
-// keep their arena alive (an orphan: whoever frees its last block unmaps it).  The registry lists pools and address ranges, so that
+// arena, after a device synchronise.  A thread that ends leaves its pool behind as an orphan, which the next thread that needs one for
+// the device adopts (no call into the runtime from a thread's exit: see Pools).  The registry lists pools and address ranges, so that
 // release() finds the owner of a pointer and a thread that runs out of memory can make the others give back their free chunks.
 #ifndef CDM_POOL_LARGE_CHUNK
 #define CDM_POOL_LARGE_CHUNK ((size_t) 256 << 20)   // the large arena grows in chunks of this size,
@@ -124,6 +124,14 @@ struct DriverTimer {
         st.mallocNs.fetch_add((unsigned long long) ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec)), std::memory_order_relaxed);
     }
 };
+// The virtual-memory calls of the driver are made by one thread at a time (ranks as threads of one process each grow an arena of their
+// own; the calls are rare, and nothing says the runtime's bookkeeping of reservations and mappings takes concurrent callers).
+inline std::mutex &driverLockMutex() { static std::mutex *m = new std::mutex(); return *m; }
+struct DriverGuard {        // CDM_POOL_DRIVER_LOCK=0 (A/B, scripts/stress_threads.py): no serialisation
+    bool on;
+    DriverGuard() : on(!(cdmenv::get("CDM_POOL_DRIVER_LOCK") && cdmenv::get("CDM_POOL_DRIVER_LOCK")[0] == '0')) { if (on) driverLockMutex().lock(); }
+    ~DriverGuard() { if (on) driverLockMutex().unlock(); }
+};
 inline hipError_t timedMalloc(void **p, size_t bytes) { DriverTimer t(bytes); const hipError_t e = hipMalloc(p, bytes); t.done(e == hipSuccess); return e; }
 
 // ---- arena bookkeeping (the pool's mutex is held)
@@ -171,7 +179,10 @@ inline hipError_t growArena(Arena &a, int device, size_t need) {
         if (a.end + chunk > a.reserved) return hipErrorOutOfMemory;
         hipMemGenericAllocationHandle_t h;
         DriverTimer t(chunk);
-        hipError_t e = hipMemCreate(&h, chunk, &prop, 0);
+        hipError_t e;
+        {
+        DriverGuard dl;
+        e = hipMemCreate(&h, chunk, &prop, 0);
         if (e == hipSuccess) {
             e = hipMemMap(a.base + a.end, chunk, 0, h, 0);
             if (e == hipSuccess) {
@@ -180,6 +191,7 @@ inline hipError_t growArena(Arena &a, int device, size_t need) {
                 if (e != hipSuccess) (void) hipMemUnmap(a.base + a.end, chunk);
             }
             if (e != hipSuccess) (void) hipMemRelease(h);
+        }
         }
         t.done(e == hipSuccess);
         if (e != hipSuccess) {
@@ -205,7 +217,7 @@ inline void trimArena(Arena &a) {
         --it;
         const size_t bo = it->first, bs = it->second.size;
         if (it->second.state != B_FREE || bo + bs < ch.off + ch.size) { c++; continue; }
-        (void) hipMemUnmap(a.base + ch.off, ch.size); (void) hipMemRelease(ch.h);
+        { DriverGuard dl; (void) hipMemUnmap(a.base + ch.off, ch.size); (void) hipMemRelease(ch.h); }
         dropFree(a, bo, bs);
         a.blocks.erase(it);
         if (ch.off > bo) addFree(a, bo, ch.off - bo);
@@ -217,8 +229,11 @@ inline void trimArena(Arena &a) {
 }
 inline void destroyArena(Registry &r, Arena &a) {       // (nothing of it is in use)
     if (!a.base) return;
-    for (const Chunk &ch : a.chunks) { (void) hipMemUnmap(a.base + ch.off, ch.size); (void) hipMemRelease(ch.h); }
-    (void) hipMemAddressFree(a.base, a.reserved);
+    {
+        DriverGuard dl;
+        for (const Chunk &ch : a.chunks) { (void) hipMemUnmap(a.base + ch.off, ch.size); (void) hipMemRelease(ch.h); }
+        (void) hipMemAddressFree(a.base, a.reserved);
+    }
     for (size_t i = 0; i < r.ranges.size(); i++) if (r.ranges[i].arena == &a) { r.ranges[i] = r.ranges.back(); r.ranges.pop_back(); break; }
     a = Arena();
 }
@@ -235,7 +250,8 @@ inline bool ensureArena(Pool &pool, Arena &a, bool small) {
     if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) { (void) hipGetLastError(); return false; }
     const size_t want = small ? 512 * SMALL_CHUNK : (2 * tot + LARGE_CHUNK - 1) / LARGE_CHUNK * LARGE_CHUNK;       // (addresses, not memory)
     void *base = nullptr;
-    const hipError_t er = hipMemAddressReserve(&base, want, (size_t) 2 << 20, nullptr, 0);
+    hipError_t er;
+    { DriverGuard dl; er = hipMemAddressReserve(&base, want, (size_t) 2 << 20, nullptr, 0); }
     if (er != hipSuccess || !base) {
         if (cdmenv::get("CDM_POOL_DEBUG")) fprintf(stderr, "carpedeam pool: reserving %zu bytes of addresses failed: %s\n", want, hipGetErrorString(er));
         (void) hipGetLastError(); return false;
@@ -256,42 +272,36 @@ inline void trimLocked(Registry &r, Pool &q) {
 }
 inline void trim(Pool &q) { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); trimLocked(r, q); }
 inline void trimAll() { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); for (Pool *q : r.pools) trimLocked(r, *q); }
-// (registry lock held) an orphan whose last block came back goes
-inline bool retireIfDone(Registry &r, Pool *q) {
-    {
-        std::lock_guard<std::mutex> g(q->m);
-        if (!q->orphan || q->small.used || q->large.used) return false;
-        for (auto &kv : q->freeBlocks) { r.blocks.erase(kv.second); (void) hipFree(kv.second); }
-        q->freeBlocks.clear();
-        destroyArena(r, q->small); destroyArena(r, q->large);
-    }
-    for (size_t i = 0; i < r.pools.size(); i++) if (r.pools[i] == q) { r.pools[i] = r.pools.back(); r.pools.pop_back(); break; }
-    delete q;
-    return true;
-}
 struct Pools {
     Pool *p[64] = {};
-    // a thread that ends gives back what its pools hold and leaves the registry; blocks of it that are still in use keep their arena
-    // as an orphan (exact-size blocks: they stay registered with no owner, whoever frees them releases them).  (The main thread's end
-    // is the end of the process: the HIP runtime may be half-way through its own tear-down by then, so nothing is freed there.)
+    // A thread that ends makes NO call into the HIP runtime here: this destructor runs among the thread's other thread-local
+    // destructors, the runtime's own per-thread state may be gone already, and hipMemUnmap / hipFree from here crashed inside
+    // libamdhip64 (scripts/stress_threads.py: short-lived threads, a segmentation fault within seconds; the likely second cause of the
+    // harness crash of round 3, whose block cache called hipFree from this very place).  The thread's pools become ORPHANS - mapped
+    // memory, free lists and all - and the next thread that needs a pool for the device adopts one (poolOf): nothing is unmapped,
+    // nothing is mapped again.  Blocks of the dead thread that others still hold are freed into the pool whoever owns it by then.
     ~Pools() {
         Registry &r = registry();
         std::lock_guard<std::mutex> g(r.m);
-        const bool mainThread = getpid() == (pid_t) syscall(SYS_gettid);
-        for (Pool *q : p) {
-            if (!q) continue;
-            if (mainThread) continue;
-            trimLocked(r, *q);
-            for (auto &kv : r.blocks) if (kv.second.second == q) kv.second.second = nullptr;
-            { std::lock_guard<std::mutex> g2(q->m); q->orphan = true; }
-            (void) retireIfDone(r, q);
-        }
+        for (Pool *q : p) if (q) { std::lock_guard<std::mutex> g2(q->m); q->orphan = true; }
     }
 };
 inline Pool &poolOf(int dev) {
     static thread_local Pools pools;
     Pool *&q = pools.p[dev & 63];
-    if (!q) { q = new Pool(); q->device = dev; Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); r.pools.push_back(q); }
+    if (!q) {
+        bool adopted = false;
+        {
+            Registry &r = registry();
+            std::lock_guard<std::mutex> g(r.m);
+            for (Pool *o : r.pools) {
+                std::lock_guard<std::mutex> g2(o->m);
+                if (o->orphan && o->device == dev) { o->orphan = false; q = o; adopted = true; break; }
+            }
+            if (!q) { q = new Pool(); q->device = dev; r.pools.push_back(q); }
+        }
+        if (adopted) (void) hipDeviceSynchronize();      // (whatever the previous owner's stream still had in flight on its free ranges)
+    }
     return *q;
 }
 
@@ -390,7 +400,6 @@ inline void release(void *p) {
     if (owner != &mine) (void) hipDeviceSynchronize();          // the owner's stream takes the range next: this thread's work on it must be over
     std::lock_guard<std::mutex> g(r.m);
     { std::lock_guard<std::mutex> g2(owner->m); giveBlock(*arena, (size_t) ((char *) p - arena->base)); }
-    if (owner != &mine) (void) retireIfDone(r, owner);
 }
 inline void trimMine() { int dev = 0; (void) hipGetDevice(&dev); trim(poolOf(dev)); }
 

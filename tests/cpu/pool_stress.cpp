@@ -21,7 +21,7 @@ std::mutex m;
 std::set<void *> live;
 std::atomic<size_t> bytes{0}, fails{0}, errors{0};
 std::unordered_map<void *, size_t> *sizes = nullptr;
-size_t budget = (size_t) 512 << 20;
+size_t budget = (size_t) 256 << 20;
 }
 static hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 static hipError_t hipGetLastError() { return hipSuccess; }
@@ -144,6 +144,8 @@ int main(int argc, char **argv) {
     size_t pools, ranges; { std::lock_guard<std::mutex> g(cdmpool::registry().m); pools = cdmpool::registry().pools.size(); ranges = cdmpool::registry().ranges.size(); }
     printf("pool stress: %d threads x %d rounds, %zu allocations, %zu refused for lack of memory (%zu failing driver calls), %zu bytes / %zu blocks left on the device, %zu registered, %zu errors\n",
            threads, rounds, allocs.load(), oom.load(), fake::fails.load(), fake::bytes.load(), fake::live.size() + fake::handles.load(), registered, fake::errors.load());
-    printf("pools left: %zu (the main thread's), address ranges: %zu, reservations: %zu\n", pools, ranges, fake::reservations.load());
-    return (fake::errors || fake::bytes || !fake::live.empty() || fake::handles || registered || pools > 1 || ranges > 2 || fake::reservations > 2) ? 1 : 0;
+    // (pools outlive their threads - a thread's exit makes no driver call - and are adopted by later threads: at most one per thread that
+    //  ever ran at the same time, + the main thread's)
+    printf("pools: %zu (at most %d), address ranges: %zu, reservations: %zu\n", pools, threads + 1, ranges, fake::reservations.load());
+    return (fake::errors || fake::bytes || !fake::live.empty() || fake::handles || registered || pools > (size_t) threads + 1 || ranges > 2 * ((size_t) threads + 1) || fake::reservations != ranges) ? 1 : 0;
 }
