@@ -377,6 +377,30 @@ extern "C" int cdm_seqdb_synth(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, ui
 // ------------------------------------------------------------------------------------------------ multi-GPU hand-off
 #include "scan.h"
 namespace {
+// sum and maximum of the lengths, on the device (the host needs two numbers of a DB it composed, not its 50 M lengths)
+__global__ __launch_bounds__(256) void k_len_stats(const uint32_t *__restrict__ len, uint64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long sum = 0; unsigned int mx = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) { const uint32_t v = len[i]; sum += v; mx = max(mx, v); }
+    sum = cdm_block_sum<unsigned long long>(sum);
+    __shared__ unsigned int sMax;
+    if (threadIdx.x == 0) sMax = 0;
+    __syncthreads();
+    atomicMax(&sMax, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicAdd(&out[0], sum); atomicMax(&out[1], (unsigned long long) sMax); }
+}
+// residues / maxLen of db from its device lengths (enqueued on s; the caller synchronises, then calls the returned setter... kept simple: synchronous)
+int seqdbLenStats(cdm_ctx *ctx, cdm_seqdb *db) {
+    hipStream_t s = ctx->stream;
+    DevBuf<unsigned long long> d; unsigned long long h[2] = {0, 0};
+    if (!d.alloc(2)) { cdm_set_error("out of device memory"); return CDM_ERR_HIP; }
+    CDM_HIP(hipMemsetAsync(d.p, 0, 16, s));
+    if (db->n) hipLaunchKernelGGL(k_len_stats, dim3((unsigned) std::min<uint64_t>((db->n + 255) / 256, 4096)), dim3(256), 0, s, (const uint32_t *) db->len, (uint64_t) db->n, d.p);
+    CDM_HIP(hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipStreamSynchronize(s));
+    db->residues = h[0]; db->maxLen = (uint32_t) h[1];
+    return CDM_OK;
+}
 __global__ void k_sel_from_ext(const uint32_t *__restrict__ len, const uint8_t *__restrict__ ext, uint32_t n, uint32_t *__restrict__ sel) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) sel[i] = ext[i] == 1 ? len[i] : 0xFFFFFFFFu;
@@ -447,12 +471,7 @@ int cdm_seqdb_select(cdm_ctx *ctx, const cdm_seqdb *db, const uint32_t *sel, int
         hipLaunchKernelGGL(k_sel_copy, CDM_GRID((std::min<uint64_t>(slice, n - first) * 64 + 255) / 256, 256), dim3(256), 0, s, *db, sel, wordOff.p, n, (uint32_t) first, *o);
     hipMemcpyAsync(o->woff + m, &words, 4, hipMemcpyHostToDevice, s);
     if (words && m) hipLaunchKernelGGL(k_mark_hasN, CDM_GRID(((uint64_t) words + 255) / 256, 256), dim3(256), 0, s, o->woff, o->nmask, m, (uint64_t) words, o->hasN);
-    // residues / max length on the host (contig lists are small next to the read DB)
-    std::vector<uint32_t> l(m);
-    hipMemcpyAsync(l.data(), o->len, (size_t) m * 4, hipMemcpyDeviceToHost, s);
-    hipError_t e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_select: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
-    for (uint32_t v : l) { o->residues += v; o->maxLen = std::max(o->maxLen, v); }
+    if (int rc2 = seqdbLenStats(ctx, o)) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_select: %s", hipGetErrorString(hipGetLastError())); return rc2; }
     *out = o;
     return CDM_OK;
 }
@@ -518,11 +537,7 @@ int cdm_seqdb_overlay(cdm_ctx *ctx, const cdm_seqdb *base, const cdm_seqdb *grow
     for (uint64_t first = 0, slice = cdmSliceItems(64); first < n; first += slice)
         hipLaunchKernelGGL(k_ov_copy, CDM_GRID((std::min<uint64_t>(slice, n - first) * 64 + 255) / 256, 256), dim3(256), 0, s, *base, g, src.p, wordOff.p, n, (uint32_t) first, *o);
     hipMemcpyAsync(o->woff + n, &words, 4, hipMemcpyHostToDevice, s);
-    std::vector<uint32_t> l(n);
-    hipMemcpyAsync(l.data(), o->len, (size_t) n * 4, hipMemcpyDeviceToHost, s);
-    hipError_t e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_overlay: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
-    for (uint32_t v : l) { o->residues += v; o->maxLen = std::max(o->maxLen, v); }
+    if (int rc2 = seqdbLenStats(ctx, o)) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_overlay: %s", hipGetErrorString(hipGetLastError())); return rc2; }
     o->nCount = base->nCount + (grown ? grown->nCount : 0);
     *out = o;
     return CDM_OK;
@@ -593,15 +608,13 @@ extern "C" int cdm_seqdb_from_packed(cdm_ctx *ctx, const void *codes, const void
     hipLaunchKernelGGL(k_words_of, dim3((unsigned) ((n + 256) / 256)), dim3(256), 0, s, o->len, (uint32_t) n, w, o->ext, extValue, o->hasN);
     if (cdmscan::exclusiveScan<uint32_t>(s, st, w, o->woff, (size_t) n + 1) != CDM_OK) { cdmFree(w); cdm_seqdb_free(o); return CDM_ERR_HIP; }
     if (words) hipLaunchKernelGGL(k_mark_hasN, CDM_GRID(((uint64_t) words + 255) / 256, 256), dim3(256), 0, s, o->woff, o->nmask, (uint32_t) n, words, o->hasN);
-    std::vector<uint32_t> l(n);
-    hipMemcpyAsync(l.data(), o->len, n * 4, hipMemcpyDeviceToHost, s);
     uint32_t total = 0;
     hipMemcpyAsync(&total, o->woff + n, 4, hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
     cdmFree(w); cdmFree(tmp);
     if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_from_packed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; }
     if (total != words) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_from_packed: lengths need %u code words, %llu given", total, (unsigned long long) words); return CDM_ERR_INVALID; }
-    for (uint32_t v : l) { o->residues += v; o->maxLen = std::max(o->maxLen, v); }
+    if (int rc2 = seqdbLenStats(ctx, o)) { cdm_seqdb_free(o); return rc2; }
     *out = o;
     return CDM_OK;
 }

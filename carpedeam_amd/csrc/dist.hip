@@ -41,6 +41,7 @@ struct Rccl {
 };
 struct Id128 { char b[128]; };      // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128), passed by value as the API does
 constexpr int NCCL_CHAR = 0;        // ncclInt8 / ncclChar
+constexpr uint64_t RCCL_PIECE = 256ull << 20;      // one send / recv moves at most this many bytes
 Rccl *rccl(std::string *err) {
     static Rccl *r = nullptr; static std::string why; static std::once_flag once;
     std::call_once(once, [] {
@@ -117,13 +118,23 @@ int rcclAllToAllDev(void *user, const void *send, const uint64_t *sendOff, void 
         if (sendOff[W] > sendOff[0]) CDM_HIP(hipMemcpyAsync(c->sendStage.p, src + sendOff[0], sendOff[W] - sendOff[0], hipMemcpyDeviceToDevice, s));
         src = (const char *) c->sendStage.p - sendOff[0]; dst = (char *) c->recvStage.p - recvOff[0];
     }
-    CDM_NCCL(r->groupStart(), "group start");
-    for (int p = 0; p < W; p++) {
-        const uint64_t ns = sendOff[p + 1] - sendOff[p], nr = recvOff[p + 1] - recvOff[p];
-        if (ns) CDM_NCCL(r->send(src + sendOff[p], ns, NCCL_CHAR, p, c->nccl, s), "send");
-        if (nr) CDM_NCCL(r->recv(dst + recvOff[p], nr, NCCL_CHAR, p, c->nccl, s), "recv");
+    // A rank's own share is a device copy, not a transfer (RCCL's send-to-self of 1.28 GB took 1.2 s and delivered part of it:
+    // scripts/probes/dist1.py at 2 M reads); what goes to a peer goes in pieces of at most RCCL_PIECE bytes, a send / recv pair each.
+    {
+        const uint64_t ns = sendOff[c->rank + 1] - sendOff[c->rank], nr = recvOff[c->rank + 1] - recvOff[c->rank];
+        if (ns != nr) { cdm_set_error("all-to-all: rank %d sends itself %llu bytes and expects %llu", c->rank, (unsigned long long) ns, (unsigned long long) nr); return CDM_ERR_INVALID; }
+        if (ns) CDM_HIP(hipMemcpyAsync(dst + recvOff[c->rank], src + sendOff[c->rank], ns, hipMemcpyDeviceToDevice, s));
     }
-    CDM_NCCL(r->groupEnd(), "group end");
+    if (W > 1) {
+        CDM_NCCL(r->groupStart(), "group start");
+        for (int p = 0; p < W; p++) {
+            if (p == c->rank) continue;
+            const uint64_t ns = sendOff[p + 1] - sendOff[p], nr = recvOff[p + 1] - recvOff[p];
+            for (uint64_t o = 0; o < ns; o += RCCL_PIECE) CDM_NCCL(r->send(src + sendOff[p] + o, std::min(RCCL_PIECE, ns - o), NCCL_CHAR, p, c->nccl, s), "send");
+            for (uint64_t o = 0; o < nr; o += RCCL_PIECE) CDM_NCCL(r->recv(dst + recvOff[p] + o, std::min(RCCL_PIECE, nr - o), NCCL_CHAR, p, c->nccl, s), "recv");
+        }
+        CDM_NCCL(r->groupEnd(), "group end");
+    }
     if (!direct && recvOff[W] > recvOff[0]) CDM_HIP(hipMemcpyAsync((char *) recv + recvOff[0], c->recvStage.p, recvOff[W] - recvOff[0], hipMemcpyDeviceToDevice, s));
     return CDM_OK;
 }
@@ -140,13 +151,21 @@ int rcclAllGatherDev(void *user, const void *send, uint64_t sendBytes, void *rec
         if (sendBytes) CDM_HIP(hipMemcpyAsync(c->sendStage.p, send, sendBytes, hipMemcpyDeviceToDevice, s));
         src = (const char *) c->sendStage.p; dst = (char *) c->recvStage.p - recvOff[0];
     }
-    CDM_NCCL(r->groupStart(), "group start");
-    for (int p = 0; p < W; p++) {
-        const uint64_t nr = recvOff[p + 1] - recvOff[p];
-        if (sendBytes) CDM_NCCL(r->send(src, sendBytes, NCCL_CHAR, p, c->nccl, s), "send");
-        if (nr) CDM_NCCL(r->recv(dst + recvOff[p], nr, NCCL_CHAR, p, c->nccl, s), "recv");
+    {
+        const uint64_t nr = recvOff[c->rank + 1] - recvOff[c->rank];
+        if (nr != sendBytes) { cdm_set_error("all-gather: rank %d contributes %llu bytes and expects %llu of itself", c->rank, (unsigned long long) sendBytes, (unsigned long long) nr); return CDM_ERR_INVALID; }
+        if (nr) CDM_HIP(hipMemcpyAsync(dst + recvOff[c->rank], src, nr, hipMemcpyDeviceToDevice, s));
     }
-    CDM_NCCL(r->groupEnd(), "group end");
+    if (W > 1) {
+        CDM_NCCL(r->groupStart(), "group start");
+        for (int p = 0; p < W; p++) {
+            if (p == c->rank) continue;
+            const uint64_t nr = recvOff[p + 1] - recvOff[p];
+            for (uint64_t o = 0; o < sendBytes; o += RCCL_PIECE) CDM_NCCL(r->send(src + o, std::min(RCCL_PIECE, sendBytes - o), NCCL_CHAR, p, c->nccl, s), "send");
+            for (uint64_t o = 0; o < nr; o += RCCL_PIECE) CDM_NCCL(r->recv(dst + recvOff[p] + o, std::min(RCCL_PIECE, nr - o), NCCL_CHAR, p, c->nccl, s), "recv");
+        }
+        CDM_NCCL(r->groupEnd(), "group end");
+    }
     if (!direct && recvOff[W] > recvOff[0]) CDM_HIP(hipMemcpyAsync((char *) recv + recvOff[0], c->recvStage.p, recvOff[W] - recvOff[0], hipMemcpyDeviceToDevice, s));
     return CDM_OK;
 }

@@ -345,6 +345,22 @@ def test_native_rccl_with_one_rank(dhigh_prefix):
         assert [bytes(s) for s in x[0]] == [bytes(s) for s in y[0]] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
 
 
+def test_native_rccl_moves_more_than_a_gigabyte():
+    """2.5 M reads: the group keys a rank keeps for itself are 1.6 GB.  RCCL's send-to-self of that size took 1.2 s and delivered part of it
+    (4.1 M hits where 7.5 M were due; found when bench.py's one-rank run of the exact scheme took 30 s per step) - a rank's own share is
+    a device copy now, and what goes to a peer goes in pieces of 256 MB."""
+    c = capi.Ctx(0)
+    comm = capi.Comm.rccl(c, 0, 1, capi.Comm.unique_id())
+    db = c.synth(2_500_000, 100, 100, 1)
+    want = c.kmermatch(db).download()
+    got = comm.kmermatch(db).download()
+    assert len(want[1]) > 9_000_000
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    whole = comm.allgather_owned(db).download()
+    mine = db.download()
+    assert [bytes(x) for x in whole[0][::997]] == [bytes(x) for x in mine[0][::997]] and np.array_equal(whole[1], mine[1])
+
+
 def test_exact_scheme_over_rccl_with_one_rank(dhigh_prefix):
     """The torch.distributed flavour of the collectives (TorchComm: all_to_all_single / all_gather over RCCL) on a one-rank group:
     same result as the plain single-device calls."""
