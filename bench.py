@@ -9,7 +9,7 @@ synthetic reads that are already resident in HBM (generated on the device before
 
 N > 1 (one process per GPU; the driver launches them with torch.distributed.run, `--gpus N` alone spawns them): ONE corpus of R
 reads (--scaling strong, default).  --scheme exact (default): every rank holds the corpus and the LIBRARY splits the work over RCCL
-(csrc/dist.hip: kmermatcher by k-mer range, one all-to-all of the group keys, the other stages on the owned queries, the new DBs
+(csrc/dist.hip: kmermatcher's extraction by blocks of the reads, its sorts by k-mer range and by owner of the representative, the other stages on the owned queries, the new DBs
 all-gathered) - the result is the single-device one.  --scheme reads: rank r owns reads [r R/N, (r+1) R/N), runs the stages on them
 alone and the per-shard contigs are all-gathered in ONE collective inside the timed step - the north star's wording, but not the
 single-device result (the JSON line says so).  --scaling weak gives every rank its own R-read corpus, seed + rank.
@@ -332,6 +332,12 @@ def main():
     total_bases = residues * args.steps
     if dist is not None:
         dt = cd.max_over_ranks(dist, dt, device="cuda")
+        if exact:           # a rank's results hold the records of the queries it owns + one self record for every other query:
+            # summed over the ranks (self records of the others taken out) they are the single-device counts - the same two numbers
+            # at every N, which is what "equivalent_to_single_device" claims
+            t2 = torch.tensor([float(stats[0] - n), float(stats[1] - n)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t2)
+            stats = (int(t2[0].item()) + n, int(t2[1].item()) + n)
         if not exact:       # (exact: every rank counted the one shared corpus)
             tb = torch.tensor([float(total_bases)], dtype=torch.float64, device="cuda")
             dist.all_reduce(tb)
@@ -399,7 +405,7 @@ def main():
             "dtype": "u8 (2-bit packed bases; int32 scores; software x87 f80 likelihood sums)", "data": "synthetic",
             "config": {"workload": workload, "reads_rank0": n, "read_len": L, "seed": args.seed, "prefilter_hits": stats[0], "alignments": stats[1],
                        "multi_gpu_scheme": (None if world == 1 and not exact else
-                                            "exact: the library's own RCCL calls (csrc/dist.hip) - k-mer-range kmermatcher + one all-to-all of group keys + query-sharded stages + all-gathers of the new sequences; bit-identical to one device" if exact else
+                                            "exact: the library's own RCCL calls (csrc/dist.hip) - every rank extracts its block of the reads, all-to-alls carry the k-mer tuples to the rank of their k-mer range and the group keys to the owner of their representative (ranges and owners cut per step from all ranks' counts), the other stages run on the owned queries, the new sequences are all-gathered; bit-identical to one device (prefilter_hits / alignments are summed over the ranks: the single-device counts at every N)" if exact else
                                             "reads: every rank runs the stages on its own read shard, no data-path collective, one all-gather of contigs at the end; NOT equivalent to the single-device run (a shard sees 1/N of every pile-up)"),
                        "equivalent_to_single_device": bool(world == 1 or exact),
                        "value_is": "kernel-resident: reads already in HBM, no DB files (the module-wall figure is gpu_module_wall)",
