@@ -72,3 +72,13 @@ def test_passes_at_scale(ctx, monkeypatch):
     for env in ({"CDM_KMER_PASSES": "3,4"}, {"CDM_KMER_PASSES": "6,2", "CDM_FORCE_WIDE_KEY": "1"}, {"CDM_KMER_PASSES": "2,3", "CDM_KMER_KEEP": "0"}):
         got = hits_under(ctx, db, READS, env, monkeypatch)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), env
+
+
+def test_passes_at_the_step_size(ctx, monkeypatch):
+    """The 50 M-read corpus of the headline step (4.1 G k-mer slots): 2 passes over 3 blocks give the single pass's 188 M hits."""
+    db = ctx.synth(50_000_000, 100, 100, 1)
+    want = ctx.kmermatch(db).download()
+    assert len(want[1]) == 188_090_901
+    monkeypatch.setenv("CDM_KMER_PASSES", "2,3")
+    got = ctx.kmermatch(db).download()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
