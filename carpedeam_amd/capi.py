@@ -64,7 +64,7 @@ EXPORTS = [
     "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
     "cdm_rescore_hamming", "cdm_pool_headroom", "cdm_pool_stats", "cdm_env_refresh",
     "cdm_comm_unique_id", "cdm_comm_create_rccl", "cdm_comm_create_ops", "cdm_comm_free", "cdm_comm_rank", "cdm_comm_world", "cdm_kmermatch_dist",
-    "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist", "cdm_comm_owned", "cdm_kpart_gather_at",
+    "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist", "cdm_comm_owned", "cdm_kpart_gather_at", "cdm_comm_standin_group", "cdm_comm_create_standin",
 ]
 
 
@@ -528,6 +528,21 @@ class Comm:
         """RCCL, called by the library itself (one device per rank)"""
         h = C.c_void_p()
         _check(lib().cdm_comm_create_rccl(ctx.h, rank, world, C.create_string_buffer(bytes(unique_id), 128), C.byref(h)))
+        return cls(ctx, h, rank, world)
+
+    @staticmethod
+    def standin_group(world):
+        """shared by the ranks (threads) of one test: the in-process stand-in for RCCL's point-to-point calls"""
+        lib().cdm_comm_standin_group.restype = C.c_void_p
+        lib().cdm_comm_standin_group.argtypes = [C.c_int]
+        return lib().cdm_comm_standin_group(world)
+
+    @classmethod
+    def standin(cls, ctx, group, rank, world):
+        """the RCCL transport's code over the stand-in (several ranks as threads on ONE device)"""
+        lib().cdm_comm_create_standin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        _check(lib().cdm_comm_create_standin(ctx.h, group, rank, C.byref(h)))
         return cls(ctx, h, rank, world)
 
     @classmethod

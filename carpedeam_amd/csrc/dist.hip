@@ -13,6 +13,8 @@
 // of functions the caller supplies (cdm_comm_create_ops: the tests run W ranks on ONE device through it, where RCCL wants a device per
 // rank; another collective library could be bound the same way).  carpedeam_amd/shard.py holds the same calling sequence in Python;
 // it stays as the reference the tests compare this file with.
+#include <chrono>
+#include <condition_variable>
 #include <dlfcn.h>
 #include <mutex>
 #include <algorithm>
@@ -65,7 +67,8 @@ Rccl *rccl(std::string *err) {
 struct cdm_comm {
     cdm_ctx *ctx = nullptr; int rank = 0, world = 1;
     cdm_comm_ops ops;                   // the transport (RCCL's functions below, or the caller's)
-    void *nccl = nullptr;               // ncclComm_t of the RCCL transport
+    void *nccl = nullptr;               // ncclComm_t of the RCCL transport (or a rank of the stand-in below)
+    Rccl *api = nullptr;         // RCCL's entry points - or the in-process stand-in's (tests: the transport's own code with several ranks on ONE device)
     // What RCCL reads and writes are buffers of THIS transport, from hipMalloc: the library's own buffers live in arenas of mapped
     // memory (csrc/pool.h: hipMemCreate / hipMemMap, access granted to the owning device only), and a peer device or another
     // process must never be pointed at those - RCCL may hand a user buffer's address to the peer (ranks as threads of one process).
@@ -88,12 +91,13 @@ int ensureStage(cdm_comm *c, cdm_comm::Stage &st, size_t need) {
 }
 bool rcclDirect() { const char *e = cdmGetenv("CDM_RCCL_DIRECT"); return e && *e == '1'; }
 }  // namespace
-#define CDM_NCCL(call, what) do { const int e_ = (call); if (e_ != 0) { cdm_set_error("RCCL %s failed: %s", what, rccl(nullptr)->errorString ? rccl(nullptr)->errorString(e_) : "?"); return CDM_ERR_HIP; } } while (0)
+#define CDM_NCCL(call, what) do { const int e_ = (call); if (e_ != 0) { cdm_set_error("RCCL %s failed: %s", what, r->errorString ? r->errorString(e_) : "?"); return CDM_ERR_HIP; } } while (0)
 
 // ---- RCCL transport
+void standinEnter(cdm_comm *c);      // (the in-process stand-in's group calls need to know the calling rank: below)
 namespace {
 int rcclAllGatherHost(void *user, const void *send, void *recv, uint64_t bytes) {
-    cdm_comm *c = (cdm_comm *) user; Rccl *r = rccl(nullptr);
+    cdm_comm *c = (cdm_comm *) user; Rccl *r = c->api;
     const size_t need = (size_t) bytes * (size_t) (c->world + 1);
     if (int rc = ensureStage(c, c->stage, need)) return rc;
     char *dSend = (char *) c->stage.p, *dRecv = dSend + bytes;
@@ -107,23 +111,24 @@ int rcclAllGatherHost(void *user, const void *send, void *recv, uint64_t bytes) 
 // peer p gets send[sendOff[p], sendOff[p + 1]) and fills recv[recvOff[p], recvOff[p + 1]): grouped point-to-point transfers - over xGMI
 // every pair of devices has its own link, so the W - 1 transfers of a rank run side by side
 int rcclAllToAllDev(void *user, const void *send, const uint64_t *sendOff, void *recv, const uint64_t *recvOff, void *stream) {
-    cdm_comm *c = (cdm_comm *) user; Rccl *r = rccl(nullptr);
+    cdm_comm *c = (cdm_comm *) user; Rccl *r = c->api;
+    standinEnter(c);
     hipStream_t s = (hipStream_t) stream;
     const int W = c->world;
     const bool direct = rcclDirect();
     const char *src = (const char *) send; char *dst = (char *) recv;
-    if (!direct) {
+    // A rank's own share is a device copy, not a transfer (RCCL's send-to-self of 1.28 GB took 1.2 s and delivered part of it:
+    // scripts/probes/dist1.py at 2 M reads) - straight from the caller's send buffer to its receive buffer; what goes to a peer goes in
+    // pieces of at most RCCL_PIECE bytes, a send / recv pair each, through the transport's own buffers.
+    const uint64_t selfBytes = sendOff[c->rank + 1] - sendOff[c->rank];
+    if (selfBytes != recvOff[c->rank + 1] - recvOff[c->rank]) { cdm_set_error("all-to-all: rank %d sends itself %llu bytes and expects %llu", c->rank, (unsigned long long) selfBytes, (unsigned long long) (recvOff[c->rank + 1] - recvOff[c->rank])); return CDM_ERR_INVALID; }
+    if (selfBytes) CDM_HIP(hipMemcpyAsync((char *) recv + recvOff[c->rank], (const char *) send + sendOff[c->rank], selfBytes, hipMemcpyDeviceToDevice, s));
+    if (W > 1 && !direct) {
         if (int rc = ensureStage(c, c->sendStage, sendOff[W] - sendOff[0])) return rc;
         if (int rc = ensureStage(c, c->recvStage, recvOff[W] - recvOff[0])) return rc;
-        if (sendOff[W] > sendOff[0]) CDM_HIP(hipMemcpyAsync(c->sendStage.p, src + sendOff[0], sendOff[W] - sendOff[0], hipMemcpyDeviceToDevice, s));
+        for (int p = 0; p < W; p++) if (p != c->rank && sendOff[p + 1] > sendOff[p])
+            CDM_HIP(hipMemcpyAsync((char *) c->sendStage.p + (sendOff[p] - sendOff[0]), src + sendOff[p], sendOff[p + 1] - sendOff[p], hipMemcpyDeviceToDevice, s));
         src = (const char *) c->sendStage.p - sendOff[0]; dst = (char *) c->recvStage.p - recvOff[0];
-    }
-    // A rank's own share is a device copy, not a transfer (RCCL's send-to-self of 1.28 GB took 1.2 s and delivered part of it:
-    // scripts/probes/dist1.py at 2 M reads); what goes to a peer goes in pieces of at most RCCL_PIECE bytes, a send / recv pair each.
-    {
-        const uint64_t ns = sendOff[c->rank + 1] - sendOff[c->rank], nr = recvOff[c->rank + 1] - recvOff[c->rank];
-        if (ns != nr) { cdm_set_error("all-to-all: rank %d sends itself %llu bytes and expects %llu", c->rank, (unsigned long long) ns, (unsigned long long) nr); return CDM_ERR_INVALID; }
-        if (ns) CDM_HIP(hipMemcpyAsync(dst + recvOff[c->rank], src + sendOff[c->rank], ns, hipMemcpyDeviceToDevice, s));
     }
     if (W > 1) {
         CDM_NCCL(r->groupStart(), "group start");
@@ -135,26 +140,28 @@ int rcclAllToAllDev(void *user, const void *send, const uint64_t *sendOff, void 
         }
         CDM_NCCL(r->groupEnd(), "group end");
     }
-    if (!direct && recvOff[W] > recvOff[0]) CDM_HIP(hipMemcpyAsync((char *) recv + recvOff[0], c->recvStage.p, recvOff[W] - recvOff[0], hipMemcpyDeviceToDevice, s));
+    if (W > 1 && !direct) for (int p = 0; p < W; p++) if (p != c->rank && recvOff[p + 1] > recvOff[p])
+        CDM_HIP(hipMemcpyAsync((char *) recv + recvOff[p], (const char *) c->recvStage.p + (recvOff[p] - recvOff[0]), recvOff[p + 1] - recvOff[p], hipMemcpyDeviceToDevice, s));
     return CDM_OK;
 }
 // every rank contributes sendBytes (they differ): recv[recvOff[p], recvOff[p + 1]) = rank p's
 int rcclAllGatherDev(void *user, const void *send, uint64_t sendBytes, void *recv, const uint64_t *recvOff, void *stream) {
-    cdm_comm *c = (cdm_comm *) user; Rccl *r = rccl(nullptr);
+    cdm_comm *c = (cdm_comm *) user; Rccl *r = c->api;
+    standinEnter(c);
     hipStream_t s = (hipStream_t) stream;
     const int W = c->world;
     const bool direct = rcclDirect();
     const char *src = (const char *) send; char *dst = (char *) recv;
-    if (!direct) {
+    {
+        const uint64_t nr = recvOff[c->rank + 1] - recvOff[c->rank];
+        if (nr != sendBytes) { cdm_set_error("all-gather: rank %d contributes %llu bytes and expects %llu of itself", c->rank, (unsigned long long) sendBytes, (unsigned long long) nr); return CDM_ERR_INVALID; }
+        if (nr) CDM_HIP(hipMemcpyAsync((char *) recv + recvOff[c->rank], send, nr, hipMemcpyDeviceToDevice, s));
+    }
+    if (W > 1 && !direct) {
         if (int rc = ensureStage(c, c->sendStage, sendBytes)) return rc;
         if (int rc = ensureStage(c, c->recvStage, recvOff[W] - recvOff[0])) return rc;
         if (sendBytes) CDM_HIP(hipMemcpyAsync(c->sendStage.p, send, sendBytes, hipMemcpyDeviceToDevice, s));
         src = (const char *) c->sendStage.p; dst = (char *) c->recvStage.p - recvOff[0];
-    }
-    {
-        const uint64_t nr = recvOff[c->rank + 1] - recvOff[c->rank];
-        if (nr != sendBytes) { cdm_set_error("all-gather: rank %d contributes %llu bytes and expects %llu of itself", c->rank, (unsigned long long) sendBytes, (unsigned long long) nr); return CDM_ERR_INVALID; }
-        if (nr) CDM_HIP(hipMemcpyAsync(dst + recvOff[c->rank], src, nr, hipMemcpyDeviceToDevice, s));
     }
     if (W > 1) {
         CDM_NCCL(r->groupStart(), "group start");
@@ -166,7 +173,8 @@ int rcclAllGatherDev(void *user, const void *send, uint64_t sendBytes, void *rec
         }
         CDM_NCCL(r->groupEnd(), "group end");
     }
-    if (!direct && recvOff[W] > recvOff[0]) CDM_HIP(hipMemcpyAsync((char *) recv + recvOff[0], c->recvStage.p, recvOff[W] - recvOff[0], hipMemcpyDeviceToDevice, s));
+    if (W > 1 && !direct) for (int p = 0; p < W; p++) if (p != c->rank && recvOff[p + 1] > recvOff[p])
+        CDM_HIP(hipMemcpyAsync((char *) recv + recvOff[p], (const char *) c->recvStage.p + (recvOff[p] - recvOff[0]), recvOff[p + 1] - recvOff[p], hipMemcpyDeviceToDevice, s));
     return CDM_OK;
 }
 }  // namespace
@@ -183,10 +191,82 @@ extern "C" int cdm_comm_create_rccl(cdm_ctx *ctx, int rank, int world, const voi
     if (!r) { cdm_set_error("%s", err.c_str()); return CDM_ERR_UNSUPPORTED; }
     CDM_HIP(hipSetDevice(ctx->device));
     cdm_comm *c = new cdm_comm();
-    c->ctx = ctx; c->rank = rank; c->world = world;
+    c->ctx = ctx; c->rank = rank; c->world = world; c->api = r;
     Id128 id; memcpy(id.b, id128, sizeof(id.b));
     const int e = ((int (*)(void **, int, Id128, int)) r->commInitRank)(&c->nccl, world, id, rank);
     if (e != 0) { delete c; cdm_set_error("ncclCommInitRank(rank %d of %d on device %d) failed: %s", rank, world, ctx->device, r->errorString ? r->errorString(e) : "?"); return CDM_ERR_HIP; }
+    c->ops.user = c; c->ops.all_gather_host = rcclAllGatherHost; c->ops.all_to_all_dev = rcclAllToAllDev; c->ops.all_gather_dev = rcclAllGatherDev;
+    *out = c;
+    return CDM_OK;
+}
+// ---- a stand-in for RCCL's calls inside ONE process (tests): the ranks are host threads that share a device.  send / recv are
+// recorded; the group's end waits for all ranks, then every receive copies from the matching send of its peer (the i-th receive from
+// p takes p's i-th send to this rank - RCCL's matching rule), device to device.  What runs on top is the RCCL transport itself - its
+// buffers, its pieces, its offsets - with a peer that is not the rank itself, which one device per box cannot offer RCCL.
+namespace {
+struct FakeOp { const void *buf; size_t n; int peer; };
+struct FakeGroup {
+    int world; std::mutex m; std::condition_variable cv; int waiting = 0; unsigned long long phase = 0; bool failed = false;
+    std::vector<std::vector<FakeOp>> sends, recvs; std::vector<const void *> agSend; std::vector<size_t> agBytes;
+    explicit FakeGroup(int w) : world(w), sends((size_t) w), recvs((size_t) w), agSend((size_t) w), agBytes((size_t) w) {}
+    void barrier() {
+        std::unique_lock<std::mutex> g(m);
+        const unsigned long long ph = phase;
+        if (++waiting == world) { waiting = 0; phase++; cv.notify_all(); }
+        else if (!cv.wait_for(g, std::chrono::seconds(120), [&] { return phase != ph; })) { failed = true; waiting = 0; phase++; cv.notify_all(); }      // (a rank that died must not leave the others waiting for ever)
+    }
+};
+struct FakeRank { FakeGroup *g; int rank; hipStream_t stream; };
+int fakeSend(const void *buf, size_t n, int, int peer, void *comm, hipStream_t) { FakeRank *f = (FakeRank *) comm; f->g->sends[f->rank].push_back(FakeOp{buf, n, peer}); return 0; }
+int fakeRecv(void *buf, size_t n, int, int peer, void *comm, hipStream_t) { FakeRank *f = (FakeRank *) comm; f->g->recvs[f->rank].push_back(FakeOp{buf, n, peer}); return 0; }
+thread_local FakeRank *fakeCurrent = nullptr;       // groupStart / groupEnd carry no communicator: the rank is the calling thread's
+int fakeGroupStart() { return 0; }
+int fakeGroupEnd() {
+    FakeRank *f = fakeCurrent; if (!f) return 1;
+    FakeGroup *g = f->g;
+    if (hipStreamSynchronize(f->stream) != hipSuccess) g->failed = true;       // what the sends read must be there
+    g->barrier();
+    std::vector<size_t> next((size_t) g->world, 0);
+    for (const FakeOp &rv : g->recvs[f->rank]) {
+        const std::vector<FakeOp> &theirs = g->sends[rv.peer];
+        size_t &k = next[rv.peer];
+        while (k < theirs.size() && theirs[k].peer != f->rank) k++;
+        if (k >= theirs.size() || theirs[k].n != rv.n || hipMemcpyAsync(const_cast<void *>(rv.buf), theirs[k].buf, rv.n, hipMemcpyDeviceToDevice, f->stream) != hipSuccess) { g->failed = true; break; }
+        k++;
+    }
+    if (hipStreamSynchronize(f->stream) != hipSuccess) g->failed = true;
+    g->barrier();
+    const bool bad = g->failed;
+    g->sends[f->rank].clear(); g->recvs[f->rank].clear();
+    g->barrier();
+    return bad ? 1 : 0;
+}
+int fakeAllGather(const void *send, void *recv, size_t bytes, int, void *comm, hipStream_t s) {
+    FakeRank *f = (FakeRank *) comm; FakeGroup *g = f->g;
+    if (hipStreamSynchronize(s) != hipSuccess) g->failed = true;
+    g->agSend[f->rank] = send; g->agBytes[f->rank] = bytes;
+    g->barrier();
+    for (int p = 0; p < g->world; p++) if (g->agBytes[p] != bytes || hipMemcpyAsync((char *) recv + (size_t) p * bytes, g->agSend[p], bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) g->failed = true;
+    if (hipStreamSynchronize(s) != hipSuccess) g->failed = true;
+    g->barrier();
+    return g->failed ? 1 : 0;
+}
+int fakeDestroy(void *comm) { delete (FakeRank *) comm; return 0; }
+const char *fakeError(int) { return "the in-process stand-in for RCCL failed (sizes of a send and its receive differ, or a copy failed)"; }
+Rccl *fakeApi() {
+    static Rccl *t = [] { Rccl *a = new Rccl(); a->send = fakeSend; a->recv = fakeRecv; a->groupStart = fakeGroupStart; a->groupEnd = fakeGroupEnd; a->allGather = fakeAllGather; a->commDestroy = fakeDestroy; a->errorString = fakeError; return a; }();
+    return t;
+}
+}  // namespace
+void standinEnter(cdm_comm *c) { fakeCurrent = (c->api == fakeApi()) ? (FakeRank *) c->nccl : nullptr; }
+extern "C" void *cdm_comm_standin_group(int world) { return world > 0 ? new FakeGroup(world) : nullptr; }      // (never freed: a test's handful)
+extern "C" int cdm_comm_create_standin(cdm_ctx *ctx, void *group, int rank, cdm_comm **out) {
+    FakeGroup *g = (FakeGroup *) group;
+    if (!ctx || !g || !out || rank < 0 || rank >= g->world) { cdm_set_error("cdm_comm_create_standin: invalid argument"); return CDM_ERR_INVALID; }
+    cdm_comm *c = new cdm_comm();
+    c->ctx = ctx; c->rank = rank; c->world = g->world; c->api = fakeApi();
+    FakeRank *f = new FakeRank{g, rank, ctx->stream};
+    c->nccl = f;
     c->ops.user = c; c->ops.all_gather_host = rcclAllGatherHost; c->ops.all_to_all_dev = rcclAllToAllDev; c->ops.all_gather_dev = rcclAllGatherDev;
     *out = c;
     return CDM_OK;
@@ -201,7 +281,7 @@ extern "C" int cdm_comm_create_ops(cdm_ctx *ctx, int rank, int world, const cdm_
 extern "C" void cdm_comm_free(cdm_comm *c) {
     if (!c) return;
     for (cdm_comm::Stage *st : {&c->stage, &c->sendStage, &c->recvStage}) if (st->p) { (void) hipDeviceSynchronize(); (void) hipFree(st->p); st->p = nullptr; }
-    if (c->nccl) { Rccl *r = rccl(nullptr); if (r) (void) r->commDestroy(c->nccl); }
+    if (c->nccl && c->api && c->api->commDestroy) (void) c->api->commDestroy(c->nccl);
     delete c;
 }
 extern "C" int cdm_comm_owned(const cdm_comm *c, uint64_t n, uint64_t *bounds) {

@@ -352,6 +352,11 @@ typedef struct cdm_comm_ops {
 int cdm_comm_unique_id(void *id128);
 int cdm_comm_create_rccl(cdm_ctx *ctx, int rank, int world, const void *id128, cdm_comm **out);
 int cdm_comm_create_ops(cdm_ctx *ctx, int rank, int world, const cdm_comm_ops *ops, cdm_comm **out);
+/* tests: the RCCL transport's own code (its buffers, its pieces of 256 MB, its offsets) over a stand-in for RCCL's send / recv /
+ * all-gather inside ONE process - the ranks are host threads that share a device, which RCCL itself refuses.  group: from
+ * cdm_comm_standin_group(world), shared by the world's ranks. */
+void *cdm_comm_standin_group(int world);
+int cdm_comm_create_standin(cdm_ctx *ctx, void *group, int rank, cdm_comm **out);
 void cdm_comm_free(cdm_comm *c);
 int cdm_comm_rank(const cdm_comm *c);
 int cdm_comm_world(const cdm_comm *c);

@@ -244,6 +244,76 @@ def run_native_ranks(world, fn):
     return out
 
 
+def run_standin_ranks(world, fn):
+    """fn(rank, comm, ctx) on `world` threads, comm = the library's RCCL transport over the in-process stand-in for RCCL's calls
+    (capi.Comm.standin): the transport's own buffers, pieces and offsets with peers that are not the rank itself"""
+    import threading
+    group = capi.Comm.standin_group(world)
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            c = capi.Ctx(0)
+            out[r] = fn(r, capi.Comm.standin(c, group, r, world), c)
+        except BaseException as e:          # noqa: BLE001
+            err[r] = e
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    first = [e for e in err if e is not None]
+    if first:
+        raise first[0]
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_rccl_transport_code_with_real_peers(dhigh_prefix, world):
+    """The RCCL transport (csrc/dist.hip rcclAllToAllDev / rcclAllGatherDev / rcclAllGatherHost: a rank's own share copied on the device,
+    the peers' shares through the transport's hipMalloc buffers in pieces) had only ever met itself as a peer - one GPU per box.  Here
+    its code runs over a stand-in for RCCL's send / recv / all-gather inside the process, with 2, 3 and 5 ranks: one iteration of the
+    reads loop on 200 k reads equals the single-device calls."""
+    ref = capi.Ctx(0)
+    ref.damage_load(dhigh_prefix)
+    db = ref.synth(N_READS, 60, 150, 3)
+    hits = ref.kmermatch(db); alns = ref.rescore(db, hits); corr = ref.correct(db, alns); asm = ref.extend(corr, alns)
+    want_hits, want_corr, want_asm = hits.download(), corr.download(), asm.download()
+    del hits, alns, corr, asm
+
+    def rank_fn(rank, comm, c):
+        c.damage_load(dhigh_prefix)
+        h, a, co, nx = comm.reads_iteration(c.synth(N_READS, 60, 150, 3))
+        return h.download(), co.download(), nx.download(), comm.owned(N_READS)
+
+    res = run_standin_ranks(world, rank_fn)
+    off, rec = merged_hits([r[0] for r in res], N_READS, res[0][3])
+    assert np.array_equal(off, want_hits[0]) and np.array_equal(rec, want_hits[1])
+    for r in res:
+        for got, want in ((r[1], want_corr), (r[2], want_asm)):
+            assert [bytes(x) for x in got[0]] == [bytes(x) for x in want[0]]
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+
+
+def test_rccl_transport_pieces(monkeypatch):
+    """2.5 M uniform reads over two ranks of the stand-in: every rank sends the other ~0.8 GB of k-mer tuples and of group keys, i.e.
+    several pieces of 256 MB per transfer."""
+    ref = capi.Ctx(0)
+    n = 2_500_000
+    want = ref.kmermatch(ref.synth(n, 100, 100, 1)).download()
+
+    def rank_fn(rank, comm, c):
+        return comm.kmermatch(c.synth(n, 100, 100, 1)).download(), comm.owned(n)
+
+    res = run_standin_ranks(2, rank_fn)
+    own = res[0][1]
+    for r, ((off, rec), _) in enumerate(res):
+        lo, hi = int(own[r]), int(own[r + 1])
+        assert np.array_equal(off[lo:hi + 1] - off[lo], want[0][lo:hi + 1] - want[0][lo])
+        assert np.array_equal(rec[int(off[lo]):int(off[hi])], want[1][int(want[0][lo]):int(want[0][hi])])
+
+
 def test_split_by_reads_sends_every_tuple_once(ctx):
     """cdm_kmermatch_split_begin: rank r extracts block r of the sequences only, its tuples ordered by fine slices of the k-mer space.
     What the W ranks hold adds up to the real tuples of a whole extraction (whole-sequence hash tuples: one per sequence that has one),
