@@ -191,8 +191,8 @@ def run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch):
     dt = time.perf_counter() - t0
     total = float(bases)
     if dist is not None:
-        dt = cd.max_over_ranks(dist, dt, device="cuda")
-        tb = torch.tensor([total], dtype=torch.float64, device="cuda")
+        dt = cd.max_over_ranks(dist, dt, device=("cpu" if dist.get_backend() == "gloo" else "cuda"))
+        tb = torch.tensor([total], dtype=torch.float64, device=("cpu" if dist.get_backend() == "gloo" else "cuda"))
         dist.all_reduce(tb)
         total = float(tb.item())
     if rank == 0:
@@ -250,8 +250,16 @@ def main():
     dist = None
     if world > 1 or os.environ.get("CDM_FORCE_DIST"):   # CDM_FORCE_DIST: exercise the collective path on one GPU
         import torch.distributed as dist
+        # CDM_BENCH_BACKEND=gloo (tests): the ranks may then share ONE device - RCCL wants a device per rank - and the library's calls go
+        # over a gloo transport (carpedeam_amd/shard.py GlooTransport) instead of librccl; everything else of the run is the same code
+        backend = os.environ.get("CDM_BENCH_BACKEND", "nccl")
+        if backend == "gloo":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     from carpedeam_amd import build, capi, synth
     if rank == 0:
         build.build()
@@ -267,9 +275,13 @@ def main():
     exact = args.scheme == "exact" and dist is not None and args.config == 3
     if exact:      # every rank holds the whole corpus; the work is split inside the stages, by the library itself over RCCL
         plan = dict(plan, first=0, n=plan["n_total"])
-        uid = [capi.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)          # (torch.distributed only launches, times and hands the id round: the data path is librccl under libcarpedeam_hip)
-        comm = capi.Comm.rccl(ctx, rank, world, uid[0])
+        if dist.get_backend() == "gloo":
+            from carpedeam_amd import shard
+            comm = capi.Comm.from_transport(ctx, rank, world, shard.GlooTransport(dist, rank, world))
+        else:
+            uid = [capi.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)          # (torch.distributed only launches, times and hands the id round: the data path is librccl under libcarpedeam_hip)
+            comm = capi.Comm.rccl(ctx, rank, world, uid[0])
     if args.config == 5:
         return run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch)
     db = ctx.synth(plan["n"], L, L, plan["seed"], n_total=plan["n_total"], first=plan["first"])      # resident in HBM before the timed region
@@ -331,15 +343,15 @@ def main():
     gathered = None
     total_bases = residues * args.steps
     if dist is not None:
-        dt = cd.max_over_ranks(dist, dt, device="cuda")
+        dt = cd.max_over_ranks(dist, dt, device=("cpu" if dist.get_backend() == "gloo" else "cuda"))
         if exact:           # a rank's results hold the records of the queries it owns + one self record for every other query:
             # summed over the ranks (self records of the others taken out) they are the single-device counts - the same two numbers
             # at every N, which is what "equivalent_to_single_device" claims
-            t2 = torch.tensor([float(stats[0] - n), float(stats[1] - n)], dtype=torch.float64, device="cuda")
+            t2 = torch.tensor([float(stats[0] - n), float(stats[1] - n)], dtype=torch.float64, device=("cpu" if dist.get_backend() == "gloo" else "cuda"))
             dist.all_reduce(t2)
             stats = (int(t2[0].item()) + n, int(t2[1].item()) + n)
         if not exact:       # (exact: every rank counted the one shared corpus)
-            tb = torch.tensor([float(total_bases)], dtype=torch.float64, device="cuda")
+            tb = torch.tensor([float(total_bases)], dtype=torch.float64, device=("cpu" if dist.get_backend() == "gloo" else "cuda"))
             dist.all_reduce(tb)
             total_bases = float(tb.item())
         if args.config == 3 and not exact and gather_info:

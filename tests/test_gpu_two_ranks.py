@@ -18,3 +18,28 @@ def test_two_processes_share_one_gpu(dhigh_prefix):
                         os.path.join(ROOT, "scripts", "two_rank_check.py"), dhigh_prefix], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     assert "rank 0 of 2 ok" in r.stdout and "rank 1 of 2 ok" in r.stdout
+
+
+def test_bench_line_from_two_ranks():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank, --gpus 2, the exact scheme) - with
+    CDM_BENCH_BACKEND=gloo, so that the two ranks can share this box's one device (RCCL wants a device per rank; the library's calls go
+    over the gloo transport).  The line must say n_gpus 2 and carry the single-device hit and alignment counts."""
+    import json
+    from carpedeam_amd import capi
+    n = 1_500_000
+    ctx = capi.Ctx(0)
+    db = ctx.synth(n, 100, 100, 1)
+    hits = ctx.kmermatch(db)
+    want = (hits.count, ctx.rescore(db, hits).count)
+    del hits, db, ctx
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CDM_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29543",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", str(n), "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["config"]["equivalent_to_single_device"] is True
+    assert (d["config"]["prefilter_hits"], d["config"]["alignments"]) == want, (d["config"], want)
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
