@@ -13,7 +13,8 @@ reads (--scaling strong, default).  --scheme exact (default): every rank holds t
 all-gathered) - the result is the single-device one.  --scheme reads: rank r owns reads [r R/N, (r+1) R/N), runs the stages on them
 alone and the per-shard contigs are all-gathered in ONE collective inside the timed step - the north star's wording, but not the
 single-device result (the JSON line says so).  --scaling weak gives every rank its own R-read corpus, seed + rank.
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  (CDM_BENCH_BACKEND=gloo: the ranks rendezvous over gloo and the library's calls go over a gloo transport
+instead of librccl, so that several ranks can share one device - tests/test_gpu_two_ranks.py; RCCL wants a device per rank.)
 """
 import argparse
 import csv
