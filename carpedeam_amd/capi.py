@@ -64,7 +64,7 @@ EXPORTS = [
     "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
     "cdm_rescore_hamming", "cdm_pool_headroom", "cdm_pool_stats", "cdm_env_refresh",
     "cdm_comm_unique_id", "cdm_comm_create_rccl", "cdm_comm_create_ops", "cdm_comm_free", "cdm_comm_rank", "cdm_comm_world", "cdm_kmermatch_dist",
-    "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist", "cdm_comm_owned", "cdm_kpart_gather_at", "cdm_comm_standin_group", "cdm_comm_create_standin",
+    "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist", "cdm_comm_owned", "cdm_kpart_gather_at", "cdm_comm_standin_group", "cdm_comm_create_standin", "cdm_kpart_set_range",
 ]
 
 

@@ -305,10 +305,37 @@ struct PartGuard { cdm_kpart *p = nullptr; ~PartGuard() { if (p) cdm_kpart_free(
 int firstHalf(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_kpart **out) {
     const int W = cm->world, R = cm->rank;
     const cdm_comm_ops &op = cm->ops;
+    // Three ways to a rank's range of the k-mer space.  "split": every rank extracts its block of the reads and the tuples travel - 49 GB
+    // at 50 M reads, 0.98 s / W^2 over W - 1 links of ~50 GB/s each.  "all": every rank extracts ALL reads, orders them by slice, keeps
+    // its range - 52 ms that do not shrink with W, nothing travels.  The tuples' exchange pays from about 6 ranks on (W = 4: 19 + 61 ms
+    // against 52; W = 8: 13 + 15), so that is the default rule; CDM_DIST_EXTRACT=split|all|part forces one ("part": round 3's
+    // cdm_kmermatch_part, whose ranges are equal slices of the k-mer space by value and far from equal shares).
     const char *how = cdmGetenv("CDM_DIST_EXTRACT");
-    if (W == 1 || (how && !strcmp(how, "all"))) return cdm_kmermatch_part(ctx, db, par, R, W, out);
-    if (int rc = cdm_kmermatch_split_begin(ctx, db, par, R, W, out)) return rc;
+    if (W == 1 || (how && !strcmp(how, "part"))) return cdm_kmermatch_part(ctx, db, par, R, W, out);
+    const bool everything = how ? !strcmp(how, "all") : W < 6;
     constexpr int F = CDM_KPART_SLICES;
+    if (everything) {
+        if (int rc = cdm_kmermatch_split_begin(ctx, db, par, 0, 1, out)) return rc;
+        std::vector<uint64_t> fineOff((size_t) F + 1);
+        const void *keys, *vals, *hkeys, *hvals; int vb = 0; uint64_t nHash = 0;
+        if (int rc = cdm_kpart_outgoing(*out, fineOff.data(), &keys, &vals, &vb, &hkeys, &hvals, &nHash)) return rc;
+        std::vector<int> cut(1, 0);          // (every rank holds the same counts and cuts the same ranges)
+        const uint64_t target = (fineOff[F] + (uint64_t) W - 1) / (uint64_t) W;
+        uint64_t acc = 0;
+        for (int f = 0; f < F; f++) { const uint64_t c = fineOff[f + 1] - fineOff[f]; if (acc && acc + c > target && (int) cut.size() < W) { cut.push_back(f); acc = 0; } acc += c; }
+        while ((int) cut.size() < W) cut.push_back(F);
+        cut.push_back(F);
+        const uint64_t lo = fineOff[cut[R]], m = fineOff[cut[R + 1]] - lo, h = (R == W - 1) ? nHash : 0;
+        DevBuf<uint64_t> rk, rhk; DevBuf<char> rv, rhv;       // (split_finish lets go of the extraction buffers before it takes the tuples over)
+        if (!rk.alloc(m) || !rv.alloc(m * vb) || !rhk.alloc(h) || !rhv.alloc(h * vb)) { cdm_set_error("cdm_kmermatch_dist: out of device memory for %llu k-mer tuples", (unsigned long long) (m + h)); return CDM_ERR_HIP; }
+        CDM_HIP(hipSetDevice(ctx->device));
+        if (m) { CDM_HIP(hipMemcpyAsync(rk.p, (const char *) keys + lo * 8, m * 8, hipMemcpyDeviceToDevice, ctx->stream)); CDM_HIP(hipMemcpyAsync(rv.p, (const char *) vals + lo * vb, m * vb, hipMemcpyDeviceToDevice, ctx->stream)); }
+        if (h) { CDM_HIP(hipMemcpyAsync(rhk.p, hkeys, h * 8, hipMemcpyDeviceToDevice, ctx->stream)); CDM_HIP(hipMemcpyAsync(rhv.p, hvals, h * vb, hipMemcpyDeviceToDevice, ctx->stream)); }
+        CDM_HIP(hipStreamSynchronize(ctx->stream));
+        if (int rc = cdm_kpart_set_range(*out, R, W)) return rc;
+        return cdm_kmermatch_split_finish(ctx, *out, rk.p, rv.p, m, rhk.p, rhv.p, h, lo ? 1 : 0);
+    }
+    if (int rc = cdm_kmermatch_split_begin(ctx, db, par, R, W, out)) return rc;
     std::vector<uint64_t> fineOff((size_t) F + 1);
     const void *keys, *vals, *hkeys, *hvals; int vb = 0; uint64_t nHash = 0;
     if (int rc = cdm_kpart_outgoing(*out, fineOff.data(), &keys, &vals, &vb, &hkeys, &hvals, &nHash)) return rc;

@@ -2226,6 +2226,13 @@ extern "C" int cdm_kpart_outgoing(const cdm_kpart *h, uint64_t *offsets, const v
     *hashKeys = h->job->sendHashKeys; *hashVals = h->job->sendHashVals; *nHash = h->job->sendHash;
     return CDM_OK;
 }
+// the k-mer range the handle is to finish as (cdm_kmermatch_dist, small worlds: every rank extracts ALL sequences - split_begin as
+// block 0 of 1 - and keeps range `rank` of `nranks`, cut from its own counts)
+extern "C" int cdm_kpart_set_range(cdm_kpart *h, int rank, int nranks) {
+    if (!h || !h->job->split || nranks < 1 || rank < 0 || rank >= nranks) { cdm_set_error("cdm_kpart_set_range: invalid argument"); return CDM_ERR_INVALID; }
+    h->job->block = rank; h->job->nBlocks = nranks;
+    return CDM_OK;
+}
 extern "C" int cdm_kmermatch_split_finish(cdm_ctx *ctx, cdm_kpart *h, const void *keys, const void *vals, uint64_t m, const void *hashKeys, const void *hashVals, uint64_t nHash, int below) {
     if (!ctx || !h || !h->job->split || (m && (!keys || !vals)) || (nHash && (!hashKeys || !hashVals))) { cdm_set_error("cdm_kmermatch_split_finish: invalid argument"); return CDM_ERR_INVALID; }
     h->job->part = h->job->block; h->job->nparts = h->job->nBlocks;          // from here on the handle is rank `part` of `nparts` k-mer ranges, as cdm_kmermatch_part leaves it

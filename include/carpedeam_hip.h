@@ -191,6 +191,7 @@ int cdm_kmermatch_part(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
 int cdm_kmermatch_split_begin(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int rank, int nranks, cdm_kpart **out);
 int cdm_kpart_outgoing(const cdm_kpart *h, uint64_t *offsets, const void **keys, const void **vals, int *val_bytes,
                        const void **hash_keys, const void **hash_vals, uint64_t *n_hash);
+int cdm_kpart_set_range(cdm_kpart *h, int rank, int nranks);     /* before split_finish: finish as range `rank` of `nranks` (a handle begun as block 0 of 1: all sequences) */
 int cdm_kmermatch_split_finish(cdm_ctx *ctx, cdm_kpart *h, const void *keys, const void *vals, uint64_t m,
                                const void *hash_keys, const void *hash_vals, uint64_t n_hash, int below);
 int cdm_kpart_info(const cdm_kpart *h, uint64_t info[4]);

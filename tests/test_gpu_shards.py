@@ -269,7 +269,7 @@ def run_standin_ranks(world, fn):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 3, 5])
+@pytest.mark.parametrize("world", [2, 3, 6])
 def test_rccl_transport_code_with_real_peers(dhigh_prefix, world):
     """The RCCL transport (csrc/dist.hip rcclAllToAllDev / rcclAllGatherDev / rcclAllGatherHost: a rank's own share copied on the device,
     the peers' shares through the transport's hipMalloc buffers in pieces) had only ever met itself as a peer - one GPU per box.  Here
@@ -299,6 +299,7 @@ def test_rccl_transport_code_with_real_peers(dhigh_prefix, world):
 def test_rccl_transport_pieces(monkeypatch):
     """2.5 M uniform reads over two ranks of the stand-in: every rank sends the other ~0.8 GB of k-mer tuples and of group keys, i.e.
     several pieces of 256 MB per transfer."""
+    monkeypatch.setenv("CDM_DIST_EXTRACT", "split")       # (two ranks would otherwise each extract everything: no tuples to send)
     ref = capi.Ctx(0)
     n = 2_500_000
     want = ref.kmermatch(ref.synth(n, 100, 100, 1)).download()
@@ -336,7 +337,7 @@ def test_split_by_reads_sends_every_tuple_once(ctx):
         assert per_slice[: capi.KPART_SLICES // 2].sum() > 0.6 * per_slice.sum()
 
 
-@pytest.mark.parametrize("world,extract", [(2, None), (3, None), (2, "all")])
+@pytest.mark.parametrize("world,extract", [(2, None), (3, None), (2, "split"), (3, "split"), (2, "part")])
 def test_native_exact_iteration_equals_single_device(dhigh_prefix, world, extract, monkeypatch):
     """cdm_reads_iteration_dist (csrc/dist.hip: the exact scheme in the library, as a deployment runs it over RCCL) on 200 k mixed-length
     reads with `world` ranks: hits, corrected DB and next DB equal the single-device calls'."""
@@ -346,7 +347,7 @@ def test_native_exact_iteration_equals_single_device(dhigh_prefix, world, extrac
     hits = ref.kmermatch(db); alns = ref.rescore(db, hits); corr = ref.correct(db, alns); asm = ref.extend(corr, alns)
     want_hits, want_corr, want_asm = hits.download(), corr.download(), asm.download()
     del hits, alns, corr, asm
-    if extract:                       # every rank extracts every sequence and keeps its k-mer range (the A/B of the split by reads)
+    if extract:                       # the default for a world below 6 is "all": every rank extracts every read and keeps its range of equal share; "split": by blocks of reads, the tuples travel; "part": round 3's equal slices by value
         monkeypatch.setenv("CDM_DIST_EXTRACT", extract)
         capi.lib().cdm_env_refresh()
 
@@ -389,7 +390,7 @@ def test_native_kmermatcher_on_small_databases():
         db = ref.upload_seqs(seqs)
         want = ref.kmermatch(db).download()
         want_db = db.download()
-        for world in (2, 3, 5):
+        for world in (2, 3, 5, 7):           # (7: the default there is the split by reads; below 6 every rank extracts everything)
             def rank_fn(rank, comm, c, seqs=seqs):
                 d = c.upload_seqs(seqs)
                 return comm.kmermatch(d).download(), comm.allgather_owned(d).download(), comm.owned(len(seqs))
