@@ -383,10 +383,79 @@ int firstHalf(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_pa
     return cdm_kmermatch_split_finish(ctx, *out, rk.p, rv.p, m, rhk.p, rhv.p, h, below ? 1 : 0);
 }
 }  // namespace
+namespace {
+// a rank's view of the whole prefilter result: the rows of the queries [lo, hi) as they are, of every other query its self hit only
+// (the first record of a row: k_offsets / k_self)
+__global__ void k_view_offsets(const uint64_t *__restrict__ off, uint64_t n, uint64_t lo, uint64_t hi, uint64_t *__restrict__ out) {
+    const uint64_t q = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > n) return;
+    const uint64_t owned = off[hi] - off[lo];
+    out[q] = q < lo ? q : q < hi ? lo + (off[q] - off[lo]) : lo + owned + (q - hi);
+}
+__global__ void k_view_selfs(const uint64_t *__restrict__ off, const HitRec *__restrict__ rec, uint64_t n, uint64_t lo, uint64_t hi, const uint64_t *__restrict__ newOff, HitRec *__restrict__ out) {
+    const uint64_t q = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n || (q >= lo && q < hi)) return;
+    out[newOff[q]] = rec[off[q]];
+}
+__global__ void k_pick(const uint64_t *__restrict__ a, const uint64_t *__restrict__ idx, uint32_t m, uint64_t *__restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < m) out[t] = a[idx[t]];
+}
+// Two ranks: kmermatcher WHOLE on every rank, no exchange at all.  The exact scheme moves the group keys - 32 GB per step at 50 M reads,
+// 8 GB per rank over the one link two devices share: more time than the second device saves - so with two ranks
+// only the stages behind kmermatcher are split: every rank computes all hits, cuts the same owners' ranges from the rows' sizes and
+// keeps its view.  CDM_DIST_KMER=replicate|exchange forces either for any world.
+int replicatedKmermatch(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+    const int W = cm->world, R = cm->rank;
+    cdm_hits *full = nullptr;
+    if (int rc = cdm_kmermatch(ctx, db, par, &full)) return rc;
+    struct Guard { cdm_hits *h; ~Guard() { if (h) cdm_hits_free(h); } } guard{full};
+    CDM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t n = db->n;
+    constexpr int S = 4096;
+    std::vector<uint64_t> sb((size_t) S + 1), at((size_t) S + 1), own((size_t) W + 1, 0);
+    for (int t = 0; t <= S; t++) sb[t] = (uint64_t) ((unsigned __int128) n * (unsigned) t / (unsigned) S);
+    {
+        DevBuf<uint64_t> dIdx, dVal;
+        if (!dIdx.alloc(S + 1) || !dVal.alloc(S + 1)) { cdm_set_error("cdm_kmermatch_dist: out of device memory"); return CDM_ERR_HIP; }
+        CDM_HIP(hipMemcpyAsync(dIdx.p, sb.data(), (S + 1) * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pick, dim3((S + 256) / 256), dim3(256), 0, s, (const uint64_t *) full->off, (const uint64_t *) dIdx.p, (uint32_t) (S + 1), dVal.p);
+        CDM_HIP(hipMemcpyAsync(at.data(), dVal.p, (S + 1) * 8, hipMemcpyDeviceToHost, s));
+        CDM_HIP(hipStreamSynchronize(s));
+    }
+    {   // equal shares of the records (a row's records = its group's keys + the self hit: the same weight cdm_kmermatch_dist cuts by)
+        const uint64_t target = (at[S] + (uint64_t) W - 1) / (uint64_t) W;
+        uint64_t acc = 0; int k = 1;
+        for (int t = 0; t < S && k < W; t++) { const uint64_t c = at[t + 1] - at[t]; if (acc && acc + c > target) { own[k++] = sb[t]; acc = 0; } acc += c; }
+        while (k < W) own[k++] = n;
+        own[W] = n;
+        cm->own = own; cm->ownN = n;
+    }
+    const uint64_t lo = own[R], hi = own[R + 1];
+    uint64_t b[2] = {0, 0};
+    CDM_HIP(hipMemcpyAsync(&b[0], full->off + lo, 8, hipMemcpyDeviceToHost, s)); CDM_HIP(hipMemcpyAsync(&b[1], full->off + hi, 8, hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipStreamSynchronize(s));
+    const uint64_t owned = b[1] - b[0], count = owned + (n - (hi - lo));
+    cdm_hits *v = new cdm_hits(); v->n = n; v->count = count;
+    if (cdmMalloc(&v->off, (n + 1) * 8) != hipSuccess || cdmMalloc(&v->rec, (count + 1) * sizeof(HitRec)) != hipSuccess) { cdm_hits_free(v); cdm_set_error("cdm_kmermatch_dist: out of device memory"); return CDM_ERR_HIP; }
+    hipLaunchKernelGGL(k_view_offsets, CDM_GRID((n + 256) / 256, 256), dim3(256), 0, s, (const uint64_t *) full->off, n, lo, hi, v->off);
+    if (n) hipLaunchKernelGGL(k_view_selfs, CDM_GRID((n + 255) / 256, 256), dim3(256), 0, s, (const uint64_t *) full->off, (const HitRec *) full->rec, n, lo, hi, (const uint64_t *) v->off, v->rec);
+    if (owned) CDM_HIP(hipMemcpyAsync(v->rec + lo, full->rec + b[0], owned * sizeof(HitRec), hipMemcpyDeviceToDevice, s));
+    { const hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(v); cdm_set_error("cdm_kmermatch_dist: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
+    *out = v;
+    return CDM_OK;
+}
+}  // namespace
 extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
     if (!ctx || !cm || !db || !par || !out) { cdm_set_error("cdm_kmermatch_dist: invalid argument"); return CDM_ERR_INVALID; }
     const int W = cm->world, R = cm->rank;
     const cdm_comm_ops &op = cm->ops;
+    {
+        const char *km = cdmGetenv("CDM_DIST_KMER");
+        const bool replicate = km ? !strcmp(km, "replicate") : (W == 2 && !cdmGetenv("CDM_DIST_EXTRACT"));
+        if (W > 1 && replicate) return replicatedKmermatch(ctx, cm, db, par, out);
+    }
     PartGuard g;
     if (int rc = firstHalf(ctx, cm, db, par, &g.p)) return rc;
     uint64_t info[4];

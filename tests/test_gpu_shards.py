@@ -337,7 +337,7 @@ def test_split_by_reads_sends_every_tuple_once(ctx):
         assert per_slice[: capi.KPART_SLICES // 2].sum() > 0.6 * per_slice.sum()
 
 
-@pytest.mark.parametrize("world,extract", [(2, None), (3, None), (2, "split"), (3, "split"), (2, "part")])
+@pytest.mark.parametrize("world,extract", [(2, None), (3, None), (2, "split"), (3, "split"), (2, "part"), (2, "all"), (3, "replicate")])
 def test_native_exact_iteration_equals_single_device(dhigh_prefix, world, extract, monkeypatch):
     """cdm_reads_iteration_dist (csrc/dist.hip: the exact scheme in the library, as a deployment runs it over RCCL) on 200 k mixed-length
     reads with `world` ranks: hits, corrected DB and next DB equal the single-device calls'."""
@@ -348,7 +348,7 @@ def test_native_exact_iteration_equals_single_device(dhigh_prefix, world, extrac
     want_hits, want_corr, want_asm = hits.download(), corr.download(), asm.download()
     del hits, alns, corr, asm
     if extract:                       # the default for a world below 6 is "all": every rank extracts every read and keeps its range of equal share; "split": by blocks of reads, the tuples travel; "part": round 3's equal slices by value
-        monkeypatch.setenv("CDM_DIST_EXTRACT", extract)
+        monkeypatch.setenv("CDM_DIST_KMER" if extract == "replicate" else "CDM_DIST_EXTRACT", extract)         # (two ranks replicate kmermatcher by default; naming a first half asks for the exchange)
         capi.lib().cdm_env_refresh()
 
     def rank_fn(rank, comm, c):
