@@ -140,6 +140,7 @@ struct MetaHasN { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint3
 struct MetaKey { const SeqMeta *m; __host__ __device__ uint32_t operator[](uint32_t i) const { return m[i].key; } };
 struct MetaExt { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) ((m[i].flags >> 1) & 1u); } };
 struct MetaRaw { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) ((m[i].flags >> 2) & 1u); } };
+int cdm_kmermatch_needs_wide_key(const cdm_seqdb *db);      // kmermatch.hip
 int cdm_seqdb_overlay(cdm_ctx *ctx, const cdm_seqdb *base, const cdm_seqdb *grown, const uint32_t *idxHost, const uint8_t *extHost, cdm_seqdb **out);      // api.hip
 int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out);      // cdmFree the result
 

@@ -2226,6 +2226,11 @@ extern "C" int cdm_kpart_outgoing(const cdm_kpart *h, uint64_t *offsets, const v
     *hashKeys = h->job->sendHashKeys; *hashVals = h->job->sendHashVals; *nHash = h->job->sendHash;
     return CDM_OK;
 }
+// does this DB take the wide group key (the representative not in the members' keys)?  The exchange of group keys between ranks
+// carries the narrow form only; cdm_kmermatch_dist lets every rank run kmermatcher whole for such a DB.
+int cdm_kmermatch_needs_wide_key(const cdm_seqdb *db) {
+    return (2 * bitsFor(db->n) + bitsFor(2ull * db->maxLen + 2) + 1 > 63 || cdmGetenv("CDM_FORCE_WIDE_KEY") != nullptr) ? 1 : 0;
+}
 // the k-mer range the handle is to finish as (cdm_kmermatch_dist, small worlds: every rank extracts ALL sequences - split_begin as
 // block 0 of 1 - and keeps range `rank` of `nranks`, cut from its own counts)
 extern "C" int cdm_kpart_set_range(cdm_kpart *h, int rank, int nranks) {

@@ -296,6 +296,22 @@ def test_rccl_transport_code_with_real_peers(dhigh_prefix, world):
             assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
 
 
+def test_wide_key_databases_over_several_ranks(monkeypatch):
+    """A DB that takes the wide group key (forced here) goes through cdm_kmermatch_dist with 3 ranks: the exchange carries the narrow
+    form only, so every rank runs kmermatcher whole and keeps its view - the union of the views is the single-device result."""
+    monkeypatch.setenv("CDM_FORCE_WIDE_KEY", "1")
+    ref = capi.Ctx(0)
+    n = 60_000
+    want = ref.kmermatch(ref.synth(n, 60, 150, 5)).download()
+
+    def rank_fn(rank, comm, c):
+        return comm.kmermatch(c.synth(n, 60, 150, 5)).download(), comm.owned(n)
+
+    res = run_standin_ranks(3, rank_fn)
+    off, rec = merged_hits([r[0] for r in res], n, res[0][1])
+    assert np.array_equal(off, want[0]) and np.array_equal(rec, want[1])
+
+
 def test_rccl_transport_pieces(monkeypatch):
     """2.5 M uniform reads over two ranks of the stand-in: every rank sends the other ~0.8 GB of k-mer tuples and of group keys, i.e.
     several pieces of 256 MB per transfer."""
