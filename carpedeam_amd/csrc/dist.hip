@@ -455,7 +455,7 @@ extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *d
         const char *km = cdmGetenv("CDM_DIST_KMER");
         const bool replicate = km ? !strcmp(km, "replicate") : (W == 2 && !cdmGetenv("CDM_DIST_EXTRACT"));
         // (a DB that takes the wide group key - 25 M sequences with contigs - is replicated too: the exchange carries the narrow form only)
-        if (W > 1 && (replicate || cdm_kmermatch_needs_wide_key(db))) return replicatedKmermatch(ctx, cm, db, par, out);
+        if ((W > 1 && replicate) || cdm_kmermatch_needs_wide_key(db)) return replicatedKmermatch(ctx, cm, db, par, out);
     }
     PartGuard g;
     if (int rc = firstHalf(ctx, cm, db, par, &g.p)) return rc;
