@@ -227,16 +227,6 @@ inline void trimArena(Arena &a) {
     }
     while (!a.blocks.empty() && a.blocks.rbegin()->second.state == B_HOLE) { a.end -= a.blocks.rbegin()->second.size; a.blocks.erase(std::prev(a.blocks.end())); }
 }
-inline void destroyArena(Registry &r, Arena &a) {       // (nothing of it is in use)
-    if (!a.base) return;
-    {
-        DriverGuard dl;
-        for (const Chunk &ch : a.chunks) { (void) hipMemUnmap(a.base + ch.off, ch.size); (void) hipMemRelease(ch.h); }
-        (void) hipMemAddressFree(a.base, a.reserved);
-    }
-    for (size_t i = 0; i < r.ranges.size(); i++) if (r.ranges[i].arena == &a) { r.ranges[i] = r.ranges.back(); r.ranges.pop_back(); break; }
-    a = Arena();
-}
 // CDM_POOL=blocks, or a platform without the virtual-memory calls (found out at the first reservation): hipMalloc per block
 inline std::atomic<int> &scheme() { static std::atomic<int> s{-1}; return s; }       // 0 blocks, 1 arenas
 inline bool useArenas() {
