@@ -759,14 +759,19 @@ int readsLoop(Args &a) {
     if (gpus > 1 || getenv("CDM_LOOP_FORCE_COMM")) {
         const char *tr = getenv("CDM_LOOP_TRANSPORT");
         const bool threadsTransport = tr && !strcmp(tr, "threads");
+        // CDM_LOOP_TRANSPORT=standin (tests): the library's RCCL transport over its in-process stand-in for RCCL's calls - the ranks share
+        // device 0, as with "threads", but what runs is the transport a deployment runs
+        void *standin = (tr && !strcmp(tr, "standin")) ? cdm_comm_standin_group(gpus) : NULL;
+        const bool oneDevice = threadsTransport || standin;
         unsigned char uid[128];
-        if (!threadsTransport) check(cdm_comm_unique_id(uid), "RCCL");
+        if (!oneDevice) check(cdm_comm_unique_id(uid), "RCCL");
         ThreadTransport tt(gpus);
         const std::string damage = a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"] : "";
         auto rankBody = [&](int r, cdm_ctx *c, cdm_seqdb *&d) {
             ThreadRank me{&tt, r, c};
             cdm_comm *cm = NULL;
             if (threadsTransport) { cdm_comm_ops ops{&me, ttAllGatherHost, ttAllToAllDev, ttAllGatherDev}; check(cdm_comm_create_ops(c, r, gpus, &ops, &cm), "communicator"); }
+            else if (standin) check(cdm_comm_create_standin(c, standin, r, &cm), "communicator");
             else check(cdm_comm_create_rccl(c, r, gpus, uid, &cm), "RCCL communicator");
             for (long it = 0; it < iters && cdm_seqdb_size(d) > 0; it++) {
                 cdm_alns *alns = NULL; cdm_seqdb *next = NULL;
@@ -775,7 +780,7 @@ int readsLoop(Args &a) {
                 if (r == 0) fprintf(stderr, "STEP: %ld  sequences %llu  residues %llu -> %llu  alignments of rank 0's queries %llu  (%.3f s on %d ranks%s)\n",
                                     it, (unsigned long long) cdm_seqdb_size(d), (unsigned long long) cdm_seqdb_residues(d), (unsigned long long) cdm_seqdb_residues(next),
                                     (unsigned long long) cdm_alns_count(alns), std::chrono::duration<double>(std::chrono::steady_clock::now() - tIt).count(), gpus,
-                                    threadsTransport ? ", in-process transport on one device" : ", RCCL");
+                                    threadsTransport ? ", in-process transport on one device" : standin ? ", the RCCL transport over its in-process stand-in, one device" : ", RCCL");
                 cdm_alns_free(alns); cdm_seqdb_free(d);
                 d = next;
             }
@@ -783,7 +788,7 @@ int readsLoop(Args &a) {
         };
         std::vector<std::thread> helpers;
         for (int r = 1; r < gpus; r++) helpers.emplace_back([&, r] {
-            cdm_ctx *c = openCtx(threadsTransport ? 0 : r);
+            cdm_ctx *c = openCtx(oneDevice ? 0 : r);
             check(cdm_damage_load(c, damage.c_str()), "Profile not 12 fields");
             cdm_seqdb *d = uploadTo(c);
             rankBody(r, c, d);

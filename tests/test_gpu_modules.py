@@ -172,7 +172,8 @@ def test_sequence_db_data_files_end_with_their_nul_on_a_dirty_heap(tmp_path, dhi
 def test_reads_loop_over_several_ranks_equals_one_device(tmp_path, dhigh_prefix):
     """`ancient_reads_loop --gpus N`: the read iterations split over N ranks (host threads of the module, csrc/dist.hip), then the contig
     iterations on rank 0 - the DB of the single-device run, file for file.  On this pool's one-GPU boxes the ranks share the device and
-    the collectives are the module's in-process transport (CDM_LOOP_TRANSPORT=threads); the RCCL transport runs with its one possible
+    the collectives are the module's in-process transport (CDM_LOOP_TRANSPORT=threads) or the library's RCCL transport over its stand-in for
+    RCCL's calls (=standin: 3 ranks exchange group keys, 6 ranks the k-mer tuples as well); RCCL itself runs with its one possible
     rank (CDM_LOOP_FORCE_COMM=1: every collective of the calling sequence, with itself as the only peer)."""
     from carpedeam_amd import build
     build.build()
@@ -181,6 +182,7 @@ def test_reads_loop_over_several_ranks_equals_one_device(tmp_path, dhigh_prefix)
     args = ["--ancient-damage", dhigh_prefix, "--num-iter-reads-only", "3", "--num-iterations", "5"]
     run("ancient_reads_loop", t("in"), t("one"), *args)
     for name, extra, env in (("two", ["--gpus", "2"], {"CDM_LOOP_TRANSPORT": "threads"}), ("three", ["--gpus", "3"], {"CDM_LOOP_TRANSPORT": "threads"}),
+                             ("standin3", ["--gpus", "3"], {"CDM_LOOP_TRANSPORT": "standin"}), ("standin6", ["--gpus", "6"], {"CDM_LOOP_TRANSPORT": "standin"}),
                              ("rccl", [], {"CDM_LOOP_FORCE_COMM": "1"})):
         r = subprocess.run([BIN, "ancient_reads_loop", t("in"), t(name), *args, *extra], capture_output=True, text=True, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
