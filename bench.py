@@ -56,8 +56,7 @@ def host_ram():
 
 
 def stage_cmds(p, exe_threads, dmg):
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from stageflags import A_FLAGS, K_FLAGS, R_FLAGS
+    from carpedeam_amd.stageflags import A_FLAGS, K_FLAGS, R_FLAGS
     th = ["--threads", str(exe_threads)]
     return [("kmermatcher", [p("reads"), p("pref")] + K_FLAGS + th),
             ("rescorediagonal", [p("reads"), p("reads"), p("pref"), p("aln")] + R_FLAGS + th),

@@ -10,16 +10,14 @@
  * ancient_correction / ancient_read_assemble / ancient_contig_merge / cyclecheck / createdb / createhdb / convert2fasta call of
  * those scripts comes back through this program and lands on the MI355X.  A module call whose flags the device path does not
  * implement (carpedeam_mi355x exits with status 77 before doing any work) is REFUSED: this program exits with EXIT_FAILURE and the
- * dispatch log gets a "refused <module>" line.  An owned module is never computed by the reference binary behind the caller's back;
- * only a deployment that sets CARPEDEAM_ALLOW_REF_FALLBACK=1 (an A/B aid, off by default, announced on stderr and logged as
- * "fallback <module>" every time) gets the old hand-over.
+ * dispatch log gets a "refused <module>" line.  An owned module is never computed by the reference binary: this program has no code
+ * path that starts the reference binary with an owned module (the opt-in hand-over of round 4, CARPEDEAM_ALLOW_REF_FALLBACK, is gone).
  *
  * This program never touches the GPU (it is plain C and links nothing of HIP), so it may exec; carpedeam_mi355x never execs.
  *
  *   CARPEDEAM_GPU_BIN        the device module binary   (default: carpedeam_mi355x next to this program)
  *   CARPEDEAM_REF_BIN        the reference binary       (default: none - unknown commands are "Invalid Command")
- *   CARPEDEAM_DISPATCH_LOG   append one line per call: "gpu|ref|refused|fallback <module>"
- *   CARPEDEAM_ALLOW_REF_FALLBACK=1   hand a refused (status 77) owned module to the reference binary (default: the refusal stands)
+ *   CARPEDEAM_DISPATCH_LOG   append one line per call: "gpu|ref|refused <module>"
  */
 #include <errno.h>
 #include <limits.h>
@@ -82,16 +80,12 @@ int main(int argc, char **argv) {
         while (waitpid(pid, &st, 0) < 0) if (errno != EINTR) { perror("carpedeam: waitpid"); return EXIT_FAILURE; }
         if (WIFSIGNALED(st)) { logLine("gpu", argv[1]); return 128 + WTERMSIG(st); }
         if (WEXITSTATUS(st) != CDM_EXIT_UNSUPPORTED) { logLine("gpu", argv[1]); return WEXITSTATUS(st); }
-        const char *allow = getenv("CARPEDEAM_ALLOW_REF_FALLBACK");
-        if (!ref || !allow || strcmp(allow, "1") != 0) {
-            /* the refusal stands: an owned module is not computed by other code than the device path's */
-            fprintf(stderr, "carpedeam: %s refused by the MI355X path (see the message above); not handed to the reference binary\n", argv[1]);
-            logLine("refused", argv[1]);
-            return EXIT_FAILURE;
-        }
-        fprintf(stderr, "carpedeam: CARPEDEAM_ALLOW_REF_FALLBACK=1: %s handed to the REFERENCE binary (see the message above)\n", argv[1]);
-        logLine("fallback", argv[1]);
-    } else {
+        /* the refusal stands: an owned module is not computed by other code than the device path's */
+        fprintf(stderr, "carpedeam: %s refused by the MI355X path (see the message above); not handed to the reference binary\n", argv[1]);
+        logLine("refused", argv[1]);
+        return EXIT_FAILURE;
+    }
+    {
         if (!ref) {
             fprintf(stderr, "Invalid Command: %s\n(the MI355X build implements the modules of the hot path; set CARPEDEAM_REF_BIN to the reference's binary and its workflows - "
                             "ancient_assemble, nuclassemble, linclust, ... - run with those modules on the device)\n", argv[1]);

@@ -51,10 +51,11 @@ int cdm_ctx_sync(cdm_ctx *ctx);
 void *cdm_ctx_stream(cdm_ctx *ctx);
 /* device time in ms of the dominant kernel(s) of the last stage call, measured with HIP events on the context stream;
  * which = 0: ancient_correction pile-up/call kernel, 1: rescore kernel, 2: kmermatcher sorts, 3: kmer extraction,
- * 4: extension kernel, 5: kmermatcher sort 1 on the k-mer slots (rocPRIM radix_sort_pairs call), 6: sort 2 (radix_sort_keys
- * call), 7: sort 1 on the whole-sequence hash tuples (second radix_sort_pairs call); 8..11: the WHOLE stage call (everything
- * it launched, host round trips between kernels included) of kmermatcher, rescorediagonal, ancient_correction,
- * ancient_read_assemble.
+ * 4: extension kernel, 5: kmermatcher sort 1 on the k-mer slots (the library's own onesweep radix passes, csrc/radix.h: histogram +
+ * pass launches), 6: sort 2 (run records, their radix sort, aggregation / unit sorters), 7: sort 1 on the whole-sequence hash tuples;
+ * 8..11: the WHOLE stage call (everything it launched, host round trips between kernels included) of kmermatcher, rescorediagonal,
+ * ancient_correction, ancient_read_assemble; 13: the radix PASS launches of sort 1 on the k-mer slots alone, summed, 14: how many
+ * launches that sum covers (bench.py's roofline figure).
  * Returns a negative value when that stage has not run. */
 float cdm_ctx_last_kernel_ms(cdm_ctx *ctx, int which);
 

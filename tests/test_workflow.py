@@ -64,7 +64,7 @@ def check_routing(calls, fallbacks):
     assert gpu["clust"] == 2 and gpu["createsubdb"] == 3 and gpu["filterdb"] == 1 and gpu["mergeclusters"] == 1 and gpu["result2repseq"] == 1
     assert gpu["rmdb"] > 30 and gpu["mvdb"] == 1 and gpu["align"] == 1
     # (a module call the device path refuses - status 77 before any work - is REFUSED by the front end, never handed to the reference,
-    # unless CARPEDEAM_ALLOW_REF_FALLBACK=1: none in this workflow - linclust's Hamming-distance pre-clustering pass, linclust.sh:27-31,
+    # none in this workflow - linclust's Hamming-distance pre-clustering pass, linclust.sh:27-31,
     # is a mode of the device module)
     assert gpu["rescorediagonal"] == 11
     assert sum(n for (where, _), n in calls.items() if where in ("fallback", "refused")) == fallbacks == 0
@@ -100,11 +100,12 @@ def test_front_end_without_a_reference_binary(tmp_path):
     r = subprocess.run([FRONT, "rescorediagonal", "a", "a", "p", "o", "--rescore-mode", "0"], capture_output=True, text=True, env=env)
     assert r.returncode == 1 and r.stdout == "" and "not handed to the reference binary" in r.stderr
     assert open(log).read().split() == ["refused", "rescorediagonal"]
-    # the hand-over exists only as an explicit opt-in, announced and logged
+    # round 4's opt-in hand-over is gone from the shipped binary: the variable changes nothing
     env["CARPEDEAM_ALLOW_REF_FALLBACK"] = "1"
     r = subprocess.run([FRONT, "rescorediagonal", "a", "a", "p", "o", "--rescore-mode", "0"], capture_output=True, text=True, env=env)
-    assert r.returncode == 0 and r.stdout.strip() == "rescorediagonal a a p o --rescore-mode 0" and "handed to the REFERENCE binary" in r.stderr
-    assert open(log).read().split() == ["refused", "rescorediagonal", "fallback", "rescorediagonal"]
+    assert r.returncode == 1 and r.stdout == "" and "not handed to the reference binary" in r.stderr
+    assert open(log).read().split() == ["refused", "rescorediagonal", "refused", "rescorediagonal"]
+    assert b"ALLOW_REF_FALLBACK" not in open(FRONT, "rb").read()
 
 
 @pytest.mark.gpu
