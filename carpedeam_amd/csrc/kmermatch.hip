@@ -70,13 +70,47 @@ struct TupleGeom {
     int kbits, lb;              // 2k, bits of a length/position field
     uint64_t kmerSlots;         // size of region 1
     const uint32_t *lenArr;     // sequence lengths (region-2 tuples of the packed layout look their length up)
+    // LayoutSlot (every sequence uniL letters): uniS slots per sequence; after sort 1 the region-1 tuples are SLOT TUPLES (radix.h) in
+    // seg[0 .. BINS] segments by head digit (the k-mer bits from headShift on)
+    uint32_t uniS = 0, uniL = 0; int uniK = 0; uint32_t uniMul = 0; int uniSh = 0;       // (uniMul, uniSh: division by uniS, slotSplit)
+    const unsigned long long *seg = nullptr; int headShift = 0;
 };
+// division of a 32-bit number by an invariant d >= 1 (Granlund & Montgomery): q = (t + ((n - t) >> 1)) >> sh with t = mulhi(n, mul)
+inline void divMagic(uint32_t d, uint32_t &mul, int &sh) {
+    int l = 0; while ((1ull << l) < d) l++;
+    mul = (uint32_t) ((((1ull << l) - d) << 32) / d + 1ull); sh = l > 0 ? l - 1 : 0;
+    if (d == 1) { mul = 0; sh = 0; }       // t = 0: q = n >> 1 >> 0 would be wrong - d = 1 is special-cased in slotSplit
+}
+// head digit of the slot tuple at k-mer-order index idx: the last segment that starts at or in front of it
+__device__ __forceinline__ uint32_t headDigit(const TupleGeom &g, uint64_t idx) {
+    uint32_t d = 0;
+#pragma unroll
+    for (uint32_t st = rx::BINS / 2; st > 0; st >>= 1) if (g.seg[d + st] <= idx) d += st;
+    return d;
+}
+// the same for a wave-uniform index: the nine look-ups go through the scalar cache (as vector loads they are nine L2 round trips in a
+// row at the start of every wave of the grouping kernel: 67 instead of 49 ms at 50 M reads)
+__device__ __forceinline__ uint32_t headDigitUniform(const TupleGeom &g, uint64_t idx) {
+    const uint64_t u = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (idx >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) idx);
+    uint32_t d = 0;
+#pragma unroll
+    for (uint32_t st = rx::BINS / 2; st > 0; st >>= 1) { const unsigned long long b = g.seg[d + st]; if (b <= u) d += st; }
+    return (uint32_t) __builtin_amdgcn_readfirstlane((int) d);
+}
+// slot index -> (sequence, slot of the sequence): slots are laid out sequence by sequence, uniS each (0: the whole-sequence hash tuple's
+// slot, 1 + p: k-mer position p).  The quotient by a double product, corrected (exact for any 32-bit slot).
+__device__ __forceinline__ void slotSplit(const TupleGeom &g, uint32_t slot, uint32_t &seq, uint32_t &r) {
+    const uint32_t t = __umulhi(slot, g.uniMul);
+    const uint32_t q = g.uniS == 1u ? slot : (t + ((slot - t) >> 1)) >> g.uniSh;
+    seq = q; r = slot - q * g.uniS;
+}
 // 16 bytes: u64 key = k-mer | strand << 63, u64 value = id << 2 FB | len << FB | pos.  FB = 16: any DB with sequences below
 // 65 536 letters (ids up to 2^32); FB = 20: sequences up to 2^20 letters (the reference's `int` position path,
 // kmermatcher.cpp:803-808: contigs), ids up to 2^24.
 template <int FB>
 struct LayoutWideT {
     typedef uint64_t V;
+    static constexpr bool bySlot = false;
     static constexpr uint64_t FM = (1ull << FB) - 1ull;
     __device__ static void store(uint64_t *keys, V *vals, uint64_t slot, uint64_t kmer63, bool fwd, uint32_t seq, uint32_t L, uint32_t pos, const TupleGeom &) {
         keys[slot] = kmer63 | (fwd ? BIT63 : 0ull); vals[slot] = ((uint64_t) seq << (2 * FB)) | ((uint64_t) L << FB) | pos;
@@ -98,6 +132,7 @@ typedef LayoutWideT<20> LayoutLong;
 // sequences or more with one of them beyond 65 534 letters: the contig iterations of a 25 M-read run, BASELINE config 5)
 struct LayoutHuge {
     typedef uint64_t V;
+    static constexpr bool bySlot = false;
     __device__ static void store(uint64_t *keys, V *vals, uint64_t slot, uint64_t kmer63, bool fwd, uint32_t seq, uint32_t, uint32_t pos, const TupleGeom &) {
         keys[slot] = kmer63 | (fwd ? BIT63 : 0ull); vals[slot] = ((uint64_t) seq << 32) | pos;
     }
@@ -115,6 +150,7 @@ struct LayoutHuge {
 // 2k moves the unused slots behind all real tuples.
 struct LayoutPacked {
     typedef uint32_t V;
+    static constexpr bool bySlot = false;
     __device__ static void store(uint64_t *keys, V *vals, uint64_t slot, uint64_t kmer63, bool fwd, uint32_t seq, uint32_t L, uint32_t pos, const TupleGeom &g) {
         keys[slot] = kmer63 | ((uint64_t) pos << (g.kbits + 1)) | ((uint64_t) L << (g.kbits + 1 + g.lb)) | (fwd ? BIT63 : 0ull); vals[slot] = seq;
     }
@@ -132,6 +168,70 @@ struct LayoutPacked {
         pos = t & m; len = (t >> g.lb) & m;
     }
 };
+// 8 bytes per tuple through all of sort 1, for DBs whose sequences all have ONE length (uniL letters, uniS = uniL - k + 2 slots each,
+// n x uniS < 2^32; k <= 20): the extractor writes only u64 key = k-mer | strand << 63 at the tuple's slot (~0 = empty), and WHICH
+// sequence and position a tuple belongs to is the slot's index - slot = seq x uniS + 1 + position in the forward sequence (slot 0 of a
+// sequence: its whole-sequence hash tuple, if that fits 2k bits).  The head pass of the sort (radix.h sortSlotKeys) drops the empty
+// slots, makes the index explicit and the head digit implicit: the sorted region 1 holds SLOT TUPLES [k-mer bits below headShift | strand
+// | slot index].  Wherever a tuple is looked at - the grouping kernel's window, big buckets, the left-over scan - it is first turned into
+// the (key, id) pair of LayoutPacked (slotTupleToPair), so everything behind sort 1 is that layout's code.  Region 2 (whole-sequence
+// hashes) keeps (key, id) pairs; its values live in an array of their own that `vals` points kmerSlots entries in front of.
+struct LayoutSlot {
+    typedef uint32_t V;
+    static constexpr bool bySlot = true;
+    __device__ static void store(uint64_t *keys, V *, uint64_t slot, uint64_t kmer63, bool fwd, uint32_t, uint32_t, uint32_t, const TupleGeom &) { keys[slot] = kmer63 | (fwd ? BIT63 : 0ull); }
+    __device__ static void storeHash(uint64_t *keys, V *vals, uint64_t slot, uint64_t hash64, uint32_t seq, uint32_t, const TupleGeom &g) { keys[slot] = hash64; if (slot >= g.kmerSlots) vals[slot] = seq; }
+    __device__ static void storeEmpty(uint64_t *keys, V *, uint64_t slot) { keys[slot] = ~0ull; }
+    __device__ static uint64_t kmerOf(uint64_t key, uint64_t slot, const TupleGeom &g) { return LayoutPacked::kmerOf(key, slot, g); }
+    __device__ static uint32_t seqOf(V v) { return v; }
+    __device__ static uint32_t lenOf(uint64_t key, V v, uint64_t slot, const TupleGeom &g) { return LayoutPacked::lenOf(key, v, slot, g); }
+    __device__ static uint32_t posOf(uint64_t key, V v, uint64_t slot, const TupleGeom &g) { return LayoutPacked::posOf(key, v, slot, g); }
+    __device__ static void unpackR1(uint64_t key, V v, const TupleGeom &g, uint32_t &len, uint32_t &pos) { LayoutPacked::unpackR1(key, v, g, len, pos); }
+};
+// sequence, stored position (kmermatcher.cpp:186: counted from the other end on the reverse strand) and strand of a slot tuple
+__device__ __forceinline__ void slotFields(const TupleGeom &g, uint64_t t8, uint32_t &id, uint32_t &pos, bool &fwd) {
+    fwd = ((uint32_t) (t8 >> rx::SLOT_STRAND_SHIFT) & 1u) != 0u;
+    uint32_t r;
+    slotSplit(g, (uint32_t) t8, id, r);
+    pos = r == 0u ? 0u : (fwd ? r - 1u : g.uniL - (r - 1u) - (uint32_t) g.uniK);
+}
+// the slot tuple at k-mer-order index idx (head digit td) as the (key, id) pair LayoutPacked holds
+__device__ __forceinline__ void slotTupleToPair(const TupleGeom &g, uint64_t t8, uint32_t td, uint64_t &key, uint32_t &id) {
+    static_assert(rx::SLOT_STRAND_SHIFT == 32 && rx::SLOT_KEY_SHIFT == 33, "the tuple's high word is k-mer bits << 1 | strand");
+    const uint32_t hiw = (uint32_t) (t8 >> 32);
+    const bool fwd = (hiw & 1u) != 0u;
+    uint32_t r;
+    slotSplit(g, (uint32_t) t8, id, r);
+    const uint32_t pos = r == 0u ? 0u : (fwd ? r - 1u : g.uniL - (r - 1u) - (uint32_t) g.uniK);     // (the reverse strand's position, kmermatcher.cpp:186)
+    if (g.kbits + 1 >= 32) {
+        // the key word by word (64-bit shifts are slow vector instructions, and this runs once per tuple): k-mer = td << headShift | low bits
+        const uint32_t lo = (hiw >> 1) | (td << g.headShift);
+        const uint32_t hi = (g.headShift ? td >> (32 - g.headShift) : 0u) | (pos << (g.kbits + 1 - 32)) | (g.uniL << (g.kbits + 1 + g.lb - 32)) | (fwd ? 0x80000000u : 0u);
+        key = ((uint64_t) hi << 32) | lo;
+    } else {
+        const uint64_t kmer = ((uint64_t) td << g.headShift) | (uint64_t) (hiw >> 1);
+        key = kmer | ((uint64_t) pos << (g.kbits + 1)) | ((uint64_t) g.uniL << (g.kbits + 1 + g.lb)) | (fwd ? BIT63 : 0ull);
+    }
+}
+// ... and back (a tuple that came out of slot 0 - a whole-sequence hash that fits 2k bits, position 0 - gets the slot of position 0 on its
+// strand: the index is only ever read through slotTupleToPair, which gives the same pair again)
+__device__ __forceinline__ uint64_t pairToSlotTuple(const TupleGeom &g, uint64_t key, uint32_t id) {
+    uint32_t len, pos;
+    LayoutPacked::unpackR1(key, id, g, len, pos);
+    const bool fwd = (key & BIT63) != 0ull;
+    const uint32_t slot = id * g.uniS + 1u + (fwd ? pos : g.uniL - pos - (uint32_t) g.uniK);
+    return ((key & ((1ull << g.headShift) - 1ull)) << rx::SLOT_KEY_SHIFT) | ((fwd ? 1ull : 0ull) << rx::SLOT_STRAND_SHIFT) | (uint64_t) slot;
+}
+// what the kernels that look at region 1 IN MEMORY (behind sort 1) go through: the sort bits of the tuple at idx (k-mer + unused-slot bit),
+// and the tuple as a (key, value) pair
+template <typename LY> __device__ __forceinline__ uint64_t memSortBits(const uint64_t *keys, uint64_t idx, const TupleGeom &g) {
+    if constexpr (LY::bySlot) { if (idx < g.kmerSlots) return ((uint64_t) headDigit(g, idx) << g.headShift) | (keys[idx] >> rx::SLOT_KEY_SHIFT); }
+    return keys[idx] & ((2ull << g.kbits) - 1ull);
+}
+template <typename LY> __device__ __forceinline__ void memPair(const uint64_t *keys, const typename LY::V *vals, uint64_t idx, const TupleGeom &g, uint64_t &key, typename LY::V &v) {
+    if constexpr (LY::bySlot) { if (idx < g.kmerSlots) { uint32_t id; slotTupleToPair(g, keys[idx], headDigit(g, idx), key, id); v = id; return; } }
+    key = keys[idx]; v = vals[idx];
+}
 
 struct SeqPos;
 template <typename LY> struct ExtractArgs {
@@ -164,7 +264,20 @@ template <typename LY> struct ExtractArgs {
     // sequences with order ranks [ordLo, ordHi) in the (length desc, id asc) slot order, all k-mer values - and the tuples then travel
     // to the owner of their k-mer range.  ordHi = 0: every sequence (one device, and the k-mer-range split above).
     uint32_t ordLo = 0, ordHi = 0;
+    uint32_t uniS = 0;          // LayoutSlot: every sequence has uniS slots, sequence i the slots from i x uniS on, rank i (slotOff / rankOf are not built)
+    // LayoutSlot: the extraction kernels count the head digits (k-mer bits from headShift on) of the tuples they leave in the slots -
+    // the histogram of sort 1's head pass, which then needs no read of the keys of its own (NULL: not counted)
+    unsigned long long *headHist = nullptr; int headShift = 0;
 };
+constexpr int HEAD_BINS = rx::BINS;
+// a block's head digit counters: cleared at the start of an extraction kernel, added to the global ones at its end
+__device__ __forceinline__ void headHistClear(unsigned int *sHead) { for (int i = threadIdx.x; i < HEAD_BINS; i += blockDim.x) sHead[i] = 0u; __syncthreads(); }
+__device__ __forceinline__ void headHistFlush(const unsigned int *sHead, unsigned long long *hist) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HEAD_BINS; i += blockDim.x) { const unsigned int c = sHead[i]; if (c) atomicAdd(&hist[i], (unsigned long long) c); }
+}
+template <typename LY> __device__ __forceinline__ uint64_t slotBase(const ExtractArgs<LY> &a, uint32_t seq) { if constexpr (LY::bySlot) return (uint64_t) seq * a.uniS; else return a.slotOff[seq]; }
+template <typename LY> __device__ __forceinline__ uint32_t seqRank(const ExtractArgs<LY> &a, uint32_t seq) { if constexpr (LY::bySlot) return seq; else return a.rankOf[seq]; }
 template <typename LY> __device__ __forceinline__ bool ownedSeq(const ExtractArgs<LY> &a, uint32_t seq) {
     if (a.ordHi == 0) return true;
     const uint32_t r = a.rankOf[seq];
@@ -177,10 +290,11 @@ template <typename LY> __device__ __forceinline__ void noteBelow(const ExtractAr
 template <typename LY>
 __device__ __forceinline__ void putSeqHashTuple(const ExtractArgs<LY> &a, uint32_t seq, uint32_t L, uint64_t base, uint64_t h) {
     const uint64_t key = xxh64_u64(h, a.seed);
-    const uint64_t hslot = a.hashBase + (a.rankOf[seq] - a.ordLo);
+    const uint64_t hslot = a.hashBase + (seqRank(a, seq) - a.ordLo);
     const bool small = (key & ~BIT63) < (1ull << (2 * a.k));
     if (small) {
         if (inRange(a, key & ~BIT63)) LY::storeHash(a.keys, a.vals, base, key, seq, L, a.geom); else LY::storeEmpty(a.keys, a.vals, base);
+        if constexpr (LY::bySlot) { if (a.headHist && inRange(a, key & ~BIT63)) atomicAdd(&a.headHist[(key & ~BIT63) >> a.headShift], 1ull); }      // (one sequence in 2^(63 - 2k))
         if ((key & ~BIT63) < a.kLo && a.belowFlag[0] == 0u) a.belowFlag[0] = 1u;
         LY::storeEmpty(a.keys, a.vals, hslot);
     } else {
@@ -229,7 +343,7 @@ __global__ __launch_bounds__(256) void k_seq_hash(ExtractArgs<LY> a) {
             for (uint32_t j = 0; j < nb; j++) { uint32_t c = word & 3u; c ^= c >> 1; h = h * 31 + c; word >>= 2; }
         }
     }
-    putSeqHashTuple(a, seq, L, a.slotOff[seq], h);
+    putSeqHashTuple(a, seq, L, slotBase(a, seq), h);
 }
 
 constexpr int FAST_WAVES = 4, FAST_TABLE = 1024, FAST_CAP = 448;
@@ -239,6 +353,9 @@ constexpr int FAST_WAVES = 4, FAST_TABLE = 1024, FAST_CAP = 448;
 template <typename LY>
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY> a) {
     __shared__ unsigned long long sTable[FAST_WAVES][FAST_TABLE];
+    __shared__ unsigned int sHead[LY::bySlot ? HEAD_BINS : 1];
+    const bool countHead = LY::bySlot && a.headHist != nullptr;
+    if (countHead) headHistClear(sHead);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long *table = sTable[wave];
     const int k = a.k;
@@ -249,7 +366,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
         const uint32_t L = a.len[seq], w0 = a.woff[seq];
         const bool hasN = a.hasN[seq] != 0;
         const uint32_t nPos = (L >= (uint32_t) k) ? (L - k + 1) : 0;
-        const uint64_t base = a.slotOff[seq];
+        const uint64_t base = slotBase(a, seq);
         const size_t cap = (size_t) (float) ((float) (a.kmersPerSeq - 1) + (a.scale * (float) L));
         if (nPos > cap || nPos > FAST_CAP) {   // wave uniform
             if (lane == 0) {
@@ -285,6 +402,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
                 }
                 below |= km < a.kLo;
                 if (inRange(a, km)) LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom); else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
+                if (countHead && !a.ignoreMultiKmer && inRange(a, km)) atomicAdd(&sHead[km >> a.headShift], 1u);      // (no repeated-k-mer rule: what is stored stays)
             } else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
         };
         if (hasN) {
@@ -307,10 +425,18 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_fast(ExtractArgs<LY
                 }
             }
         }
-        if (__ballot(dup) != 0ull && lane == 0) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;   // rewritten by k_extract
+        const bool anyDup = __ballot(dup) != 0ull;
+        if (anyDup && lane == 0) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;   // rewritten by k_extract
+        // head digits: a sequence that stays as written counts the k-mers its hash set holds (every one it stored); one that k_extract
+        // rewrites is counted there
+        if (countHead && a.ignoreMultiKmer && !anyDup) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (uint32_t i = lane; i < tsize; i += 64) { const unsigned long long km = table[i]; if (km != ~0ull && inRange(a, km)) atomicAdd(&sHead[km >> a.headShift], 1u); }
+        }
         noteBelow(a, below);
         __builtin_amdgcn_wave_barrier();
     }
+    if (countHead) headHistFlush(sHead, a.headHist);
 }
 
 
@@ -322,6 +448,9 @@ constexpr int PAIR_POS = 96, PAIR_TABLE = 256;
 template <typename LY>
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_pair(ExtractArgs<LY> a) {
     __shared__ unsigned long long sTable[FAST_WAVES][2 * PAIR_TABLE];
+    __shared__ unsigned int sHead[LY::bySlot ? HEAD_BINS : 1];
+    const bool countHead = LY::bySlot && a.headHist != nullptr;
+    if (countHead) headHistClear(sHead);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
     unsigned long long *table = sTable[wave] + half * PAIR_TABLE;
     const int k = a.k;
@@ -331,7 +460,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_pair(ExtractArgs<LY
         const uint32_t seq = 2 * pr + (uint32_t) half;
         const bool have = seq < a.n && ownedSeq(a, seq);
         uint32_t L = 0, w0 = 0; bool hasN = false; uint64_t base = 0;
-        if (have) { L = a.len[seq]; w0 = a.woff[seq]; hasN = a.hasN[seq] != 0; base = a.slotOff[seq]; }
+        if (have) { L = a.len[seq]; w0 = a.woff[seq]; hasN = a.hasN[seq] != 0; base = slotBase(a, seq); }
         const uint32_t nPos = (L >= (uint32_t) k) ? (L - k + 1) : 0;
         const size_t cap = (size_t) (float) ((float) (a.kmersPerSeq - 1) + (a.scale * (float) L));
         const bool elig = have && nPos <= cap && nPos <= (uint32_t) PAIR_POS && !hasN;
@@ -339,7 +468,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_pair(ExtractArgs<LY
         for (int i = hl; i < PAIR_TABLE; i += 32) table[i] = ~0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
         bool dup = false, below = false;
-        auto emit = [&](uint64_t w, uint64_t idx, uint32_t pos) {
+        constexpr uint32_t NO_DIGIT = 0xFFFFFFFFu;
+        // (returns the head digit of the tuple it stored, NO_DIGIT if the slot stays empty)
+        auto emit = [&](uint64_t w, uint64_t idx, uint32_t pos) -> uint32_t {
             const uint64_t rc = (w ^ 0xAAAAAAAAAAAAAAAAull) & kmask;     // Util::revComplement(idx): window order, complemented
             if (rc != idx) {
                 const bool pickRev = rc < idx;
@@ -355,25 +486,35 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_extract_pair(ExtractArgs<LY
                     }
                 }
                 below |= km < a.kLo;
-                if (inRange(a, km)) LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom); else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
+                if (inRange(a, km)) { LY::store(a.keys, a.vals, base + 1 + pos, km, !pickRev, seq, L, p, a.geom); return (uint32_t) (km >> a.headShift); }
+                LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
             } else LY::storeEmpty(a.keys, a.vals, base + 1 + pos);
+            return NO_DIGIT;
         };
         const uint32_t pos = 3u * (uint32_t) hl;
+        uint32_t dA = NO_DIGIT, dB = NO_DIGIT, dC = NO_DIGIT;
         if (elig && pos < nPos) {
             const uint64_t xr = kmerWindow(a.codes, w0, pos, (L + 15) / 16 - 1, k);     // k + 2 bases
             const uint64_t wA = xr & kmask, idxA = groupsReversed(wA, k);
-            emit(wA, idxA, pos);
+            dA = emit(wA, idxA, pos);
             if (pos + 1 < nPos) {
                 const uint64_t idxB = ((idxA << 2) & kmask) | ((xr >> (2 * k)) & 3ull);
-                emit((xr >> 2) & kmask, idxB, pos + 1);
-                if (pos + 2 < nPos) emit((xr >> 4) & kmask, ((idxB << 2) & kmask) | ((xr >> (2 * k + 2)) & 3ull), pos + 2);
+                dB = emit((xr >> 2) & kmask, idxB, pos + 1);
+                if (pos + 2 < nPos) dC = emit((xr >> 4) & kmask, ((idxB << 2) & kmask) | ((xr >> (2 * k + 2)) & 3ull), pos + 2);
             }
         }
         const unsigned long long dm = __ballot(dup);
-        if ((half ? (dm >> 32) : (dm & 0xFFFFFFFFull)) != 0ull && hl == 0) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;   // rewritten by k_extract
+        const bool halfDup = (half ? (dm >> 32) : (dm & 0xFFFFFFFFull)) != 0ull;
+        if (halfDup && hl == 0) a.slowShort[atomicAdd(&a.slowCnt[0], 1u)] = seq;   // rewritten by k_extract
+        if (countHead && !halfDup) {        // (a sequence k_extract rewrites is counted there)
+            if (dA != NO_DIGIT) atomicAdd(&sHead[dA], 1u);
+            if (dB != NO_DIGIT) atomicAdd(&sHead[dB], 1u);
+            if (dC != NO_DIGIT) atomicAdd(&sHead[dC], 1u);
+        }
         noteBelow(a, below);
         __builtin_amdgcn_wave_barrier();
     }
+    if (countHead) headHistFlush(sHead, a.headHist);
 }
 
 // sort element of the per-sequence ordering compareByScoreReverse (kmermatcher.h:30-46): (score, kmer|bit63, pos)
@@ -504,6 +645,9 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
     // scratch took milliseconds per contig; the walk ends after ~0.2 n + 200 records)
     constexpr uint32_t HEADN = CAP ? 1 : 3072;
     __shared__ SeqPos sHead[HEADN];
+    __shared__ unsigned int sDigits[LY::bySlot ? HEAD_BINS : 1];
+    const bool countHead = LY::bySlot && a.headHist != nullptr;
+    if (countHead) headHistClear(sDigits);
     const int tid = threadIdx.x;
     for (uint32_t item = blockIdx.x; item < a.nList; item += gridDim.x) {
         const uint32_t seq = a.list[item];
@@ -688,8 +832,9 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
         __syncthreads();
         // ---- emit: 1 whole-sequence tuple (:244-267) + the selected k-mers
         {
-            const uint64_t base = a.slotOff[seq];
+            const uint64_t base = slotBase(a, seq);
             if (tid == 0) sCursor = 0;       // (the whole-sequence tuple :244-267 is written by k_seq_hash)
+            if constexpr (LY::bySlot) { for (uint32_t i = tid; i < nPos; i += NT) LY::storeEmpty(a.keys, a.vals, base + 1 + i); }      // (a slot IS a position: every one is written, the selected ones again)
             __syncthreads();
             // selected tuples first (their order within the sequence does not matter: a global sort follows), then sentinels
             for (uint32_t i = tid; i < n; i += NT) {
@@ -698,14 +843,21 @@ __global__ __launch_bounds__(NT) void k_extract(ExtractArgs<LY> a) {
                 const uint64_t km = spKmer63(e);
                 if (km < a.kLo && a.belowFlag[0] == 0u) a.belowFlag[0] = 1u;
                 if (!inRange(a, km)) continue;              // another rank's k-mer range
+                if constexpr (LY::bySlot) {
+                    const bool fwd = (e.b & 1ull) != 0;
+                    LY::store(a.keys, a.vals, base + 1 + (fwd ? spPos(e) : L - spPos(e) - (uint32_t) k), km, fwd, seq, L, spPos(e), a.geom);
+                    if (countHead) atomicAdd(&sDigits[km >> a.headShift], 1u);
+                } else {
                 const uint32_t o = atomicAdd(&sCursor, 1u);
                 LY::store(a.keys, a.vals, base + 1 + o, km, (e.b & 1ull) != 0, seq, L, spPos(e), a.geom);
+                }
             }
             __syncthreads();
-            for (uint32_t i = sCursor + tid; i < nPos; i += NT) LY::storeEmpty(a.keys, a.vals, base + 1 + i);
+            if constexpr (!LY::bySlot) { for (uint32_t i = sCursor + tid; i < nPos; i += NT) LY::storeEmpty(a.keys, a.vals, base + 1 + i); }
         }
         __syncthreads();
     }
+    if (countHead) headHistFlush(sDigits, a.headHist);
 }
 
 // ------------------------------------------------------------------------------------------------ K3: groups
@@ -824,8 +976,100 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs<LY> a, unsigned long l
 // K2b + K3 fused for region 1 when only the top bits of the k-mer went through the global radix passes (bucket.h): a wave
 // sorts a group of buckets on the remaining low bits in registers, finds the k-mer runs in the sorted order and writes the
 // group keys of the members straight to their final slots.  W = word of the network: (bucket ordinal, low bits, position).
+// LayoutSlot: where the slots of a grouping block lie in their head-digit segment - the head digit of the block's first slot and how far
+// the segment reaches to either side of it, in slots relative to that first slot (clipped to 2^30; one 16-byte load per block: looking
+// the digit up in the segment table is nine dependent loads, which every wave of this latency-bound kernel paid at its start)
+struct BlockHead { int32_t lo, hi; uint32_t td, pad; };
+constexpr int REC_CAP = 32;     // staged run records per wave of the grouping kernel (its 128 owned slots: ~8 k-mer runs at 20x coverage)
+__global__ void k_block_heads(TupleGeom geom, uint64_t n, uint64_t perBlock, uint64_t blocks, BlockHead *__restrict__ out) {
+    const uint64_t b = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= blocks) return;
+    const uint64_t base = b * perBlock;
+    const uint32_t td = headDigit(geom, base);
+    const uint64_t since = base - geom.seg[td], until = geom.seg[td + 1] - base;
+    BlockHead h; h.td = td; h.pad = 0; h.lo = -(int32_t) min(since, (uint64_t) 1 << 30); h.hi = (int32_t) min(until, (uint64_t) 1 << 30);
+    out[b] = h;
+}
+// The staged run records of REC_WAVES consecutive waves of the grouping kernel, packed: off = exclusive sums of the waves' counts.
+// The buckets the grouping kernel left to the caller have records of their own (bigVal: sorted by start, nBig of them) - a packed record
+// moves back by the number of those that start in front of it, so that the two lists interleave in k-mer order (k_rec_place_big puts
+// the others in).
+constexpr int REC_WAVES = 256, REC_BIG_LDS = 256;
+struct RecCount { const uint8_t *c; __device__ __forceinline__ unsigned long long operator()(size_t i) const { return c[i]; } };
+__device__ __forceinline__ uint64_t lowerBoundStart(const uint64_t *__restrict__ val, uint64_t n, uint64_t start) {      // first record whose start is >= start
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((val[mid] >> runsort::RUN_CNT_BITS) < start) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_rec_compact(const uint32_t *__restrict__ stRep, const uint64_t *__restrict__ stVal, const unsigned long long *__restrict__ off, uint64_t waves,
+                                                     uint64_t own, const uint64_t *__restrict__ bigVal, uint64_t nBig, uint32_t *__restrict__ recRep, uint64_t *__restrict__ recVal) {
+    __shared__ unsigned long long sOff[REC_WAVES + 1];
+    __shared__ uint64_t sBig[REC_BIG_LDS];
+    __shared__ uint64_t sB[2];
+    const uint64_t w0 = (uint64_t) blockIdx.x * REC_WAVES;
+    const int nw = (int) min((uint64_t) REC_WAVES, waves - w0);
+    for (int i = threadIdx.x; i <= nw; i += 256) sOff[i] = off[w0 + i];
+    if (threadIdx.x < 2) sB[threadIdx.x] = nBig ? lowerBoundStart(bigVal, nBig, (w0 + (threadIdx.x ? (uint64_t) nw : 0ull)) * own) : 0ull;      // the big records inside this block's slots
+    __syncthreads();
+    const uint64_t b0 = sB[0], nb = sB[1] - sB[0];
+    for (uint64_t i = threadIdx.x; i < nb && i < (uint64_t) REC_BIG_LDS; i += 256) sBig[i] = bigVal[b0 + i] >> runsort::RUN_CNT_BITS;
+    __syncthreads();
+    const unsigned long long base = sOff[0], total = sOff[nw] - base;
+    for (unsigned long long i = threadIdx.x; i < total; i += 256) {
+        int w = 0;
+#pragma unroll
+        for (int st = REC_WAVES / 2; st > 0; st >>= 1) if (w + st < nw && sOff[w + st] - base <= i) w += st;
+        const uint64_t src = (w0 + (uint64_t) w) * REC_CAP + (i - (sOff[w] - base));
+        const uint64_t v = stVal[src], start = v >> runsort::RUN_CNT_BITS;
+        uint64_t before = b0;
+        if (nb <= (uint64_t) REC_BIG_LDS) { for (uint64_t q = 0; q < nb; q++) before += sBig[q] < start; }
+        else before = lowerBoundStart(bigVal, nBig, start);
+        recRep[base + i + before] = stRep[src]; recVal[base + i + before] = v;
+    }
+}
+// big record b goes behind the packed records that start in front of it: those of the waves in front of the wave that owns its first
+// slot, and that wave's own ones with a smaller start
+__global__ __launch_bounds__(256) void k_rec_place_big(const uint32_t *__restrict__ bigRep, const uint64_t *__restrict__ bigVal, uint64_t nBig, const uint64_t *__restrict__ stVal,
+                                                       const uint8_t *__restrict__ stCnt, const unsigned long long *__restrict__ off, uint64_t own, uint32_t *__restrict__ recRep, uint64_t *__restrict__ recVal) {
+    const uint64_t b = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nBig) return;
+    const uint64_t v = bigVal[b], start = v >> runsort::RUN_CNT_BITS, w = start / own;
+    uint64_t before = off[w];
+    const int c = stCnt[w];
+    for (int j = 0; j < c; j++) before += (stVal[w * REC_CAP + j] >> runsort::RUN_CNT_BITS) < start;
+    recRep[b + before] = bigRep[b]; recVal[b + before] = v;
+}
+// the group keys of the big buckets (dense staging array, ranges = (start, end, offset)) with one dropped key behind every range: run
+// records made from that array (k_run_records) never span two buckets
+__global__ __launch_bounds__(256) void k_big_gap_copy(const unsigned long long *__restrict__ ranges, unsigned int cnt, const unsigned long long *__restrict__ dense, unsigned long long *__restrict__ gapped) {
+    const unsigned int lane = threadIdx.x & 63, wavesPerGrid = gridDim.x * 4;
+    for (unsigned int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < cnt; r += wavesPerGrid) {
+        const unsigned long long len = ranges[3 * (size_t) r + 1] - ranges[3 * (size_t) r], o = ranges[3 * (size_t) r + 2];
+        for (unsigned long long i = lane; i < len; i += 64) gapped[o + r + i] = dense[o + i];
+        if (lane == 0) gapped[o + r + len] = ~0ull;
+    }
+}
+// their records' starts from the gapped array's coordinates to slots of the key array
+__global__ __launch_bounds__(256) void k_big_rec_starts(const unsigned long long *__restrict__ ranges, unsigned int cnt, uint64_t *__restrict__ recVal, uint64_t nRec) {
+    const uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nRec) return;
+    const uint64_t v = recVal[j], x = v >> runsort::RUN_CNT_BITS;
+    unsigned int lo = 0, hi = cnt;                          // last range r with offset + r <= x
+    while (hi - lo > 1) { const unsigned int mid = lo + ((hi - lo) >> 1); if (ranges[3 * (size_t) mid + 2] + mid <= x) lo = mid; else hi = mid; }
+    const uint64_t slot = ranges[3 * (size_t) lo] + (x - (ranges[3 * (size_t) lo + 2] + lo));
+    recVal[j] = (slot << runsort::RUN_CNT_BITS) | (v & ((1ull << runsort::RUN_CNT_BITS) - 1ull));
+}
 template <typename LY, typename W>
 struct BucketGroupArgs : GroupParams {
+    const BlockHead *blockHead = nullptr;
+    // Run records of sort 2 (runsort.h), emitted while the group keys are written: every wave stages the records of the k-mer runs it
+    // finishes - (representative, first slot << 13 | kept keys) per stretch of kept keys - in its own REC_CAP entries (k_rec_compact packs
+    // them: the waves in order are the k-mer order).  NULL: not staged.
+    uint32_t *recRep = nullptr; uint64_t *recVal = nullptr; uint8_t *recCnt = nullptr;
+    uint32_t recLimit = REC_CAP;        // (CDM_REC_LIMIT lowers it: tests reach the overflow list)
+    // what a wave's stage does not hold goes to a global list (a cursor, ovCap entries; in arrival order - the caller sorts it by start and
+    // merges it like the big buckets' records); only a list that is too small sends the caller back to k_run_records
+    uint32_t *ovRep = nullptr; uint64_t *ovVal = nullptr; unsigned long long *ovCursor = nullptr; unsigned long long ovCap = 0;
     const uint64_t *keys; const typename LY::V *vals; TupleGeom geom;
     unsigned long long *out;        // group key (or ~0) per slot, in k-mer order
     int lowBits;                    // k-mer bits the global passes left unsorted
@@ -842,11 +1086,12 @@ constexpr int GK_OWN = CDM_GK_OWN, GK_WIN = CDM_GK_WIN, GK_FIRST = CDM_GK_FIRST,
 // (the network writes all 64 R slots of ss, R = 1, 2, 4, 8: the largest bucket is one of those sizes)
 static_assert(GK_WIN % 64 == 0 && GK_FIRST % 64 == 0 && GK_FIRST < GK_WIN && GK_OWN <= GK_FIRST && GK_WIN <= (1 << bucket::WV_IDX) &&
               (GK_MAXB == 64 || GK_MAXB == 128 || GK_MAXB == 256 || GK_MAXB == 512), "grouping kernel geometry");
-template <typename LY, typename W>
 #ifndef CDM_GK_MINW
-#define CDM_GK_MINW 1      // waves per SIMD the register allocation of the grouping kernel leaves room for (scripts/build_variant.py sweeps it)
+#define CDM_GK_MINW 0      // waves per SIMD the register allocation of the grouping kernel leaves room for (scripts/build_variant.py sweeps it; 0: as many as its LDS lets run - 6 blocks of 4 waves per CU with (key, value) pairs in the window, 7 with slot tuples)
 #endif
-__global__ __launch_bounds__(bucket::BK_NT, CDM_GK_MINW) void k_bucket_groups(BucketGroupArgs<LY, W> a) {
+template <typename LY> constexpr int gkMinWaves() { return CDM_GK_MINW ? CDM_GK_MINW : (LY::bySlot ? 7 : 1); }
+template <typename LY, typename W>
+__global__ __launch_bounds__(bucket::BK_NT, gkMinWaves<LY>()) void k_bucket_groups(BucketGroupArgs<LY, W> a) {
     using namespace bucket;
     typedef typename LY::V V;
     __shared__ uint64_t sKeyAll[BK_WAVES][GK_WIN];
@@ -863,15 +1108,46 @@ __global__ __launch_bounds__(bucket::BK_NT, CDM_GK_MINW) void k_bucket_groups(Bu
     struct Tup { uint64_t k; V v; };
     constexpr uint32_t IDXM = (1u << WV_IDX) - 1u;
     uint32_t keptCnt = 0;       // wave-uniform
+    uint32_t recCount = 0, prevRowKept = 0;      // (lane 0's copies are complete) run records staged so far; was the last key of the row in front kept
+    // (staged in LDS, written out in one piece at the wave's end)
+    // Only the slot layout's instance stages records: with (key, value) pairs in the window the stage's LDS and registers take the kernel
+    // from six blocks per CU to five (63 instead of 49 ms), more than k_run_records' pass over the keys costs.
+    constexpr bool REC = LY::bySlot;
+    __shared__ uint32_t sRecRep[BK_WAVES][REC ? REC_CAP : 1];
+    __shared__ uint64_t sRecVal[BK_WAVES][REC ? REC_CAP : 1];
+    const uint32_t recLimit = a.recLimit;
+    const uint64_t waveIdx = (uint64_t) blockIdx.x * BK_WAVES + wave;
+    // slot tuples (LayoutSlot): a tuple becomes its (key, id) pair as it is loaded; the head digit is the segment the index lies in -
+    // the wave's own one for nearly every tuple of its window (segments are millions of tuples long)
+    BlockHead bh; bh.lo = 0; bh.hi = 0; bh.td = 0; bh.pad = 0;
+    const uint64_t blockBase = (uint64_t) blockIdx.x * BK_WAVES * (uint64_t) a.own;
+    if constexpr (LY::bySlot) bh = a.blockHead[blockIdx.x];
+    auto digitAt = [&](uint64_t g) -> uint32_t { const long long off = (long long) (g - blockBase); return (off >= (long long) bh.lo && off < (long long) bh.hi) ? bh.td : headDigit(a.geom, g); };
     waveBuckets<Tup, GK_WIN, GK_FIRST>(r0, a.n, a.own, a.maxBucket, hmask & ~lowMask, a.big, w, lane,
-        [&](uint64_t g) { Tup t; t.k = a.keys[g]; t.v = a.vals[g]; return t; },
-        [&](int i, const Tup &t) { sKey[i] = t.k; sVal[i] = t.v; return t.k; },
-        [&](uint64_t g) { return a.keys[g]; },
+        [&](uint64_t g) {
+            Tup t;
+            if constexpr (LY::bySlot) { t.k = a.keys[g]; t.v = digitAt(g); }       // (raw: the window holds far more tuples than the wave owns)
+            else { t.k = a.keys[g]; t.v = a.vals[g]; }
+            return t;
+        },
+        [&](int i, const Tup &t) {
+            sKey[i] = t.k;
+            if constexpr (LY::bySlot) return ((uint64_t) t.v << a.geom.headShift) | (t.k >> rx::SLOT_KEY_SHIFT);       // what buckets are told apart by: the k-mer
+            else { sVal[i] = t.v; return t.k; }
+        },
+        [&](uint64_t g) {
+            if constexpr (LY::bySlot) return ((uint64_t) digitAt(g) << a.geom.headShift) | (a.keys[g] >> rx::SLOT_KEY_SHIFT);
+            else return a.keys[g];
+        },
         [&](int g0, int gm) {
+
             // word of the network: (bucket ordinal within the group, low k-mer bits, position within the group)
             const int idxBits = gm > 256 ? 9 : 8, ord0 = w.ord[g0];
             sortGroup<W>(gm, lane,
-                [&](int i) { return (W) ((((W) (w.ord[g0 + i] - ord0) << lowBits | (W) (sKey[g0 + i] & lowMask)) << idxBits) | (W) i); },
+                [&](int i) {
+                    const uint64_t low = LY::bySlot ? (uint64_t) ((uint32_t) (sKey[g0 + i] >> rx::SLOT_KEY_SHIFT)) & lowMask : sKey[g0 + i] & lowMask;      // (a slot tuple's k-mer bits sit above its index)
+                    return (W) ((((W) (w.ord[g0 + i] - ord0) << lowBits | (W) low) << idxBits) | (W) i);
+                },
                 [&](auto &v) {
                     // per sorted position: window slot of the element, start of its run (= equal bucket and low bits; from an
                     // inclusive max-scan of the start positions over the wave) and whether it starts one
@@ -900,9 +1176,30 @@ __global__ __launch_bounds__(bucket::BK_NT, CDM_GK_MINW) void k_bucket_groups(Bu
 #pragma unroll 1
             for (int p = lane; p < gm; p += 64) {
                 const uint32_t cw = ss[p];
-                const int s0 = (int) ((cw >> WV_IDX) & 1023u), e = (int) (cw & IDXM);
+                const int s0 = (int) ((cw >> WV_IDX) & 1023u), e = (int) (cw & IDXM), p0row = p - lane;
                 unsigned long long gk = ~0ull;
+                uint32_t recRepOfLane = 0;      // the run's representative (kept members only read it)
                 const bool hasNext = (p + 1 < gm) && !(ss[p + 1] >> 31);
+                if constexpr (LY::bySlot) {
+                if (s0 != p || hasNext) {
+                    // slot tuples: sequence, position and strand come straight out of the slot index (the k-mer itself is of no interest
+                    // behind the sort; every sequence has the one length)
+                    const int er = (int) (ss[s0] & IDXM);
+                    uint32_t repId, bestPos, id, tPos; bool repFwd, fwd;
+                    slotFields(a.geom, sKey[er], repId, bestPos, repFwd);
+                    for (int t = s0 + 1; t < gm && !(ss[t] >> 31); t++) {     // same sequence twice in the run (rare)
+                        uint32_t ie, pe; bool fe;
+                        slotFields(a.geom, sKey[(int) (ss[t] & IDXM)], ie, pe, fe);
+                        if (ie != repId) break;
+                        if (pe < bestPos) { bestPos = pe; repFwd = fe; }
+                    }
+                    slotFields(a.geom, sKey[e], id, tPos, fwd);
+                    const bool firstRun = r0 + (uint64_t) (g0 + s0) == a.firstRunIdx;
+                    gk = groupKeyCore(a, repId, (int) a.geom.uniL, (int) bestPos, firstRun ? false : !repFwd, id, (int) a.geom.uniL, (int) tPos, !fwd);
+                    if (a.wide && s0 == p) gk = markRunStart(a, gk, repId);
+                    recRepOfLane = repId;
+                }
+                } else
                 if (s0 != p || hasNext) {       // the staged range holds real tuples only (the unused slots sorted behind it)
                     const int er = (int) (ss[s0] & IDXM);
                     uint64_t bestKey = sKey[er]; const V best = sVal[er];
@@ -922,13 +1219,45 @@ __global__ __launch_bounds__(bucket::BK_NT, CDM_GK_MINW) void k_bucket_groups(Bu
                     const bool firstRun = r0 + (uint64_t) (g0 + s0) == a.firstRunIdx;
                     gk = groupKeyCore(a, repId, (int) repLen, (int) bestPos, firstRun ? false : ((bestKey & BIT63) == 0), LY::seqOf(val), (int) tLen, (int) tPos, (key & BIT63) == 0);
                     if (a.wide && s0 == p) gk = markRunStart(a, gk, repId);
+                    recRepOfLane = repId;
                 }
                 a.out[r0 + (uint64_t) (g0 + p)] = gk;
-                keptCnt += (uint32_t) __popcll(__ballot(runsort::gkKept(gk)));
+                const unsigned long long keptMask = __ballot(runsort::gkKept(gk));
+                keptCnt += (uint32_t) __popcll(keptMask);
+                if constexpr (REC) if (a.recRep) {
+                    // records of this row of 64 sorted positions: a record begins at a kept key that starts a k-mer run or follows a key that
+                    // is not kept, and ends in front of the next run start / not-kept key; a stretch that runs on from the row in front
+                    // (the same k-mer run: rows of one group) lengthens that row's last record instead of beginning one
+                    const uint32_t recBase = (uint32_t) __builtin_amdgcn_readfirstlane((int) recCount);       // (lane 0 runs every row: its values are complete)
+                    const bool lastKept = __builtin_amdgcn_readfirstlane((int) prevRowKept) != 0;
+                    const unsigned long long startMask = __ballot((cw >> 31) != 0u);
+                    const bool runsOn = p0row != 0 && lastKept && (keptMask & 1ull) && !(startMask & 1ull) && recBase - 1u < recLimit;      // (a record on the overflow list is not lengthened: the stretch goes on as a record of its own)
+                    const unsigned long long begins = keptMask & (startMask | ~(keptMask << 1)) & ~(runsOn ? 1ull : 0ull), ends = ~keptMask | startMask;
+                    if (((begins >> lane) & 1ull) || (runsOn && lane == 0)) {
+                        const unsigned long long behind = lane == 63 ? 0ull : ends >> (lane + 1);
+                        const uint32_t len = behind ? (uint32_t) __ffsll(behind) : (uint32_t) (64 - lane);
+                        const uint32_t j = recBase + (uint32_t) __popcll(begins & ((1ull << lane) - 1ull));
+                        // (a wave's LDS operations take effect in program order: the add meets the record an earlier row wrote)
+                        const uint64_t rv = ((r0 + (uint64_t) (g0 + p)) << runsort::RUN_CNT_BITS) | (uint64_t) len;
+                        if (runsOn && lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sRecVal[wave][recBase - 1u]), (unsigned long long) len);
+                        else if (j < recLimit) { sRecRep[wave][j] = recRepOfLane; sRecVal[wave][j] = rv; }
+                        else { const unsigned long long q = atomicAdd(a.ovCursor, 1ull); if (q < a.ovCap) { a.ovRep[q] = recRepOfLane; a.ovVal[q] = rv; } }
+                    }
+                    recCount = recBase + (uint32_t) __popcll(begins);
+                    prevRowKept = (uint32_t) (keptMask >> 63);
+                }
             }
             waveLdsSync();      // ss is reused by the next group
         });
     waveGroupStats(a.stat, keptCnt);
+    recCount = (uint32_t) __builtin_amdgcn_readfirstlane((int) recCount);
+    if constexpr (REC) if (a.recRep && recCount) {
+        // the wave's records go out in one piece
+        const uint32_t m = min(recCount, recLimit);
+        waveLdsSync();
+        if ((uint32_t) lane < m) { const uint64_t slot = waveIdx * (uint64_t) REC_CAP + (uint32_t) lane; a.recRep[slot] = sRecRep[wave][lane]; a.recVal[slot] = sRecVal[wave][lane]; }
+        if (lane == 0) a.recCnt[waveIdx] = (uint8_t) m;
+    }
 }
 
 // tiles of the vote kernels: 4096 keys (256 threads x 16 consecutive items)
@@ -1220,19 +1549,19 @@ __global__ __launch_bounds__(256) void k_stale_tail(StaleArgs<LY> a) {
             idx = j;
             if (!a.sorted) {
                 if (threadIdx.x == 0) {     // bucket of j: equal high bits
-                    const uint64_t h = (a.keys[j] & hmask) >> a.lowBits;
+                    const uint64_t h = (memSortBits<LY>(a.keys, j, a.geom) & hmask) >> a.lowBits;
                     uint64_t lo = 0, hi = j;
-                    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (((a.keys[mid] & hmask) >> a.lowBits) < h) lo = mid + 1; else hi = mid; }
+                    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (((memSortBits<LY>(a.keys, mid, a.geom) & hmask) >> a.lowBits) < h) lo = mid + 1; else hi = mid; }
                     sB[0] = lo;
                     lo = j; hi = a.live;
-                    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (((a.keys[mid] & hmask) >> a.lowBits) == h) lo = mid + 1; else hi = mid; }
+                    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (((memSortBits<LY>(a.keys, mid, a.geom) & hmask) >> a.lowBits) == h) lo = mid + 1; else hi = mid; }
                     sB[1] = lo;
                 }
                 __syncthreads();
                 const uint64_t b0 = sB[0], b1 = sB[1];
                 const int m = (int) min((uint64_t) STALE_BUCKET + 1, b1 - b0);
                 if (m <= STALE_BUCKET) {
-                    for (int i = threadIdx.x; i < m; i += blockDim.x) sC[i] = ((a.keys[b0 + i] & lowMask) << 12) | (uint64_t) i;
+                    for (int i = threadIdx.x; i < m; i += blockDim.x) sC[i] = ((memSortBits<LY>(a.keys, b0 + i, a.geom) & lowMask) << 12) | (uint64_t) i;
                     if (threadIdx.x == 0) sSel = 0;
                     __syncthreads();
                     const int want = (int) (j - b0);
@@ -1250,9 +1579,9 @@ __global__ __launch_bounds__(256) void k_stale_tail(StaleArgs<LY> a) {
             idx = a.kmerSlots + (j - a.live);
             if (idx >= a.nTuples) break;
         }
-        const uint64_t key = a.keys[idx];
-        if (key == ~0ull) break;                                   // end of the real tuples
-        const typename LY::V v = a.vals[idx];
+        if (a.keys[idx] == ~0ull) break;                           // end of the real tuples (the empty slots of region 2; region 1 is read below `live` only)
+        uint64_t key; typename LY::V v;
+        memPair<LY>(a.keys, a.vals, idx, a.geom, key, v);
         if (cnt == 0) target = LY::seqOf(v);                       // the scan can only run on for this sequence id
         else if (LY::seqOf(v) != target) break;
         if (threadIdx.x == 0) a.out[2 + cnt] = LY::posOf(key, v, idx, a.geom);
@@ -1265,12 +1594,35 @@ __global__ void k_first_diff(const uint64_t *__restrict__ a, const uint64_t *__r
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
         if (a[i] != b[i]) { atomicMin(out, (unsigned long long) i); return; }
 }
+// LayoutSlot, buckets the grouping kernel left alone: their slot tuples as (key, id) pairs in the dense staging arrays, and the sorted
+// pairs back as slot tuples (a wave per listed range (start, end, offset), as bucket::k_big_copy)
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_big_slot_pairs(const unsigned long long *__restrict__ ranges, unsigned int cnt, uint64_t *arr, TupleGeom geom, uint64_t *denseK, uint32_t *denseV) {
+    const unsigned int lane = threadIdx.x & 63, wavesPerGrid = gridDim.x * 4;
+    for (unsigned int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < cnt; r += wavesPerGrid) {
+        const unsigned long long s = ranges[3 * (size_t) r], e = ranges[3 * (size_t) r + 1], o = ranges[3 * (size_t) r + 2];
+        const uint32_t td = headDigit(geom, s);         // (a bucket lies inside one segment)
+        for (unsigned long long i = lane; i < e - s; i += 64) {
+            if (GATHER) { uint64_t key; uint32_t id; slotTupleToPair(geom, arr[s + i], td, key, id); denseK[o + i] = key; denseV[o + i] = id; }
+            else arr[s + i] = pairToSlotTuple(geom, denseK[o + i], denseV[o + i]);
+        }
+    }
+}
 inline uint32_t bitsFor(uint64_t v) { uint32_t b = 1; while ((1ull << b) < v) b++; return b; }
 
 // One kmermatcher run, in phases so that a multi-GPU run can exchange between them (shard.py / cdm_kmermatch_part):
 //   phaseA     extraction (of this rank's k-mer range), sort 1, grouping -> group keys in k-mer order (startIo), live, nKept
 //   staleTail  the left-over tuples behind global k-mer-order index J (the reference's run-past-the-end scan)
 //   phaseB     sort 2 + vote -> prefilter hits
+// LayoutSlot serves a DB whose sequences all have one length (Σ lengths = n x longest), of at least k letters, with fewer than 2^32 k-mer
+// slots, a k-mer of 14 .. 20 letters (the tuple keeps 31 k-mer bits behind the 9-bit head digit) and lengths LayoutPacked's key holds
+inline uint32_t slotsPerSeq(uint32_t L, int k) { return L >= (uint32_t) k ? L - (uint32_t) k + 2u : 1u; }
+inline bool slotLayoutFits(const cdm_seqdb *db, int k) {
+    if (db->n == 0 || db->residues != db->n * (uint64_t) db->maxLen || db->maxLen < (uint32_t) k) return false;
+    if (2 * k + 1 <= 27 || 2 * k - rx::BITS > rx::SLOT_REM) return false;       // (k of 14 .. 20 letters: low bits left to the grouping kernel, at most 31 behind the head digit)
+    if (2 * k + 1 + 2 * (int) bitsFor((uint64_t) db->maxLen + 1) > 63) return false;
+    return db->n * (uint64_t) slotsPerSeq(db->maxLen, k) < (1ull << 32);
+}
 struct KmerJobBase {
     virtual ~KmerJobBase() {}
     virtual int phaseA() = 0;
@@ -1311,7 +1663,14 @@ struct KmerJob : KmerJobBase {
     uint64_t kmerSlots = 0; unsigned long long nTuples = 0;
     DoubleBuf<uint64_t> keys; DoubleBuf<V> vals;
     DevBuf<uint64_t> k0, k1; DevBuf<V> v0, v1;
+    V *vA = nullptr, *vB = nullptr;           // v0 / v1 as the kernels index them (LayoutSlot: values exist for region 2 only, the pointers stand kmerSlots entries in front of them)
+    DevBuf<unsigned long long> segBuf;        // LayoutSlot: where every head digit's slot tuples start (rx::sortSlotKeys)
     TupleGeom geom; int lowBits = 0;
+    DevBuf<unsigned long long> headHist; bool headCounted = false;        // LayoutSlot: head digit counts taken by the extraction kernels
+    // run records staged by the grouping kernel (BucketGroupArgs::recRep): valid for region 1 when stagedWaves != 0
+    DevBuf<uint32_t> stRep, ovRep; DevBuf<uint64_t> stVal, ovVal; DevBuf<uint8_t> stCnt; DevBuf<unsigned long long> recFlag; uint64_t stagedWaves = 0, stagedOwn = 0; unsigned long long ovCap = 0, nOvRec = 0;
+    DevBuf<uint32_t> bigRecRep, bigRecRep1; DevBuf<uint64_t> bigRecVal, bigRecVal1; unsigned long long nBigRec = 0;        // ... and the records of the buckets that kernel left to the caller
+    bool ownPipeline = false;                 // sortAndGroup runs for the single-device call that also runs sort 2 on its own buffers (phaseA + phaseB)
     GroupArgs<LY> ga; DevBuf<unsigned long long> statStripes; unsigned long long *startIo = nullptr; DevBuf<uint32_t> staleBuf;
     DevBuf<uint64_t> runsOut, runsTmp;       // sort 2 "check" mode: the run-based result next to the radix one
     DevBuf<uint64_t> recvA, recvB; DevBuf<uint32_t> contBuf;      // multi-GPU second half: received keys / their sorted form, the continuation list
@@ -1342,21 +1701,25 @@ int init() {
     if (!counters.alloc(8)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipMemsetAsync(counters.p, 0, 8 * 8, s);
     geom.kbits = 2 * k; geom.lb = (int) bitsFor((uint64_t) db->maxLen + 1); geom.lenArr = db->len;
+    if constexpr (LY::bySlot) {
+        if (!slotLayoutFits(db, k) || split || nparts != 1 || passes || lsdOnly) { cdm_set_error("cdm_kmermatch: internal error: the slot layout was chosen for a run it does not serve"); return CDM_ERR_INVALID; }
+        geom.uniL = db->maxLen; geom.uniK = k; geom.uniS = slotsPerSeq(db->maxLen, k); divMagic(geom.uniS, geom.uniMul, geom.uniSh); geom.headShift = 2 * k - std::min(rx::BITS, 2 * k);
+    }
     return CDM_OK;
 }
 int phaseA() override {
     if (int rc = init()) return rc;
     constexpr uint32_t SHORT_CAP = 256, LONG_CAP = 4096;
 
-    if (!cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !listSingle.alloc(n) || !listHuge.alloc(n) || !slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1) || !rankOf.alloc(n)) {
-        cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP;
-    }
+    if (!cls.alloc(8) || !listShort.alloc(n) || !listLong.alloc(n) || !listSingle.alloc(n) || !listHuge.alloc(n)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    if (!LY::bySlot && (!slots.alloc((size_t) n + 1) || !slotOff.alloc((size_t) n + 1) || !rankOf.alloc(n))) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipMemsetAsync(cls.p, 0, 8 * 4, s);
     // One slot per k-mer position + one for the whole-sequence tuple, at a fixed offset per sequence (no global counter).
     // Slots are laid out in (sequence length descending, id ascending) order: after the stable k-mer sort the first tuple
     // of every run is then the representative.
     uint64_t capacity = 0;
-    {
+    if constexpr (LY::bySlot) capacity = (uint64_t) n * geom.uniS;       // one length: that order is the id order, sequence i has the slots from i x uniS on
+    else {
         DevBuf<uint32_t> lk0, lk1, lv0, lv1; DevBuf<unsigned long long> ordOff;
         if (!lk0.alloc(n) || !lk1.alloc(n) || !lv0.alloc(n) || !lv1.alloc(n) || !ordOff.alloc((size_t) n + 1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
         hipLaunchKernelGGL(k_len_keys, dim3((n + 255) / 256), dim3(256), 0, s, db->len, n, db->maxLen, lk0.p, lv0.p);
@@ -1388,16 +1751,26 @@ int phaseA() override {
     capacity += r2Slots;                             // region 2: whole-sequence hash tuples
     nTuples = capacity;
 
-    if (!k0.alloc(capacity) || !k1.alloc(capacity) || !v0.alloc(capacity) || !v1.alloc(capacity)) {
-        cdm_set_error("cdm_kmermatch: out of device memory for %llu k-mer tuples (%.1f GB)", (unsigned long long) capacity, capacity * (16.0 + 2 * sizeof(V)) / 1e9); return CDM_ERR_HIP;
+    const uint64_t valSlots = LY::bySlot ? r2Slots : capacity;      // (LayoutSlot: only the whole-sequence hash tuples carry a value)
+    if (!k0.alloc(capacity) || !k1.alloc(capacity) || !v0.alloc(valSlots) || !v1.alloc(valSlots)) {
+        cdm_set_error("cdm_kmermatch: out of device memory for %llu k-mer tuples (%.1f GB)", (unsigned long long) capacity, (capacity * 16.0 + valSlots * 2.0 * sizeof(V)) / 1e9); return CDM_ERR_HIP;
     }
+    vA = LY::bySlot ? v0.p - kmerSlots : v0.p; vB = LY::bySlot ? v1.p - kmerSlots : v1.p;
     geom.kbits = 2 * k; geom.lb = (int) bitsFor((uint64_t) db->maxLen + 1); geom.kmerSlots = kmerSlots; geom.lenArr = db->len;
-    ExtractArgs<LY> ea; ea.geom = geom;
+    ExtractArgs<LY> ea; ea.geom = geom; ea.uniS = geom.uniS;
     ea.woff = db->woff; ea.len = db->len; ea.codes = db->codes; ea.nmask = db->nmask; ea.hasN = db->hasN;
     ea.k = k; ea.kmersPerSeq = par->kmers_per_seq; ea.scale = par->kmers_per_seq_scale; ea.seed = par->hash_shift; ea.ignoreMultiKmer = par->ignore_multi_kmer;
-    ea.keys = k0.p; ea.vals = v0.p; ea.slotOff = slotOff.p; ea.slowShort = listShort.p; ea.slowLong = listLong.p; ea.slowHuge = listHuge.p; ea.slowCnt = cls.p; ea.n = n;
+    ea.keys = k0.p; ea.vals = vA; ea.slotOff = slotOff.p; ea.slowShort = listShort.p; ea.slowLong = listLong.p; ea.slowHuge = listHuge.p; ea.slowCnt = cls.p; ea.n = n;
     ea.hugeSp = nullptr; ea.hugeSel = nullptr; ea.hugeCap = 0;
     ea.list = nullptr; ea.nList = 0; ea.hashBase = kmerSlots; ea.rankOf = rankOf.p;
+    if constexpr (LY::bySlot) {
+        const char *e = cdmGetenv("CDM_SLOT_HIST");        // "kernel": sort 1 counts the head digits itself, with a read of the keys (A/B, tests)
+        if (!(e && !strcmp(e, "kernel"))) {
+            if (!headHist.alloc(HEAD_BINS)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+            hipMemsetAsync(headHist.p, 0, HEAD_BINS * 8, s);
+            ea.headHist = headHist.p; ea.headShift = geom.headShift; headCounted = true;
+        }
+    }
     {   // this rank's k-mer range: equal slices of the 2k-bit k-mer space, in k-mer order
         const unsigned __int128 space = (unsigned __int128) 1 << (2 * k);
         ea.kLo = (uint64_t) (space * (unsigned) part / (unsigned) nparts);
@@ -1495,7 +1868,7 @@ int splitFinish(const void *keysIn, const void *valsIn, uint64_t m, const void *
     if (m) { hipMemcpyAsync(nk0.p, keysIn, m * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(nv0.p, valsIn, m * sizeof(V), hipMemcpyDeviceToDevice, s); }
     if (h) { hipMemcpyAsync(nk0.p + m, hkeys, h * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(nv0.p + m, hvals, h * sizeof(V), hipMemcpyDeviceToDevice, s); }
     if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: taking over the received tuples failed"); return CDM_ERR_HIP; }
-    k0.p = nk0.release(); k1.p = nk1.release(); v0.p = nv0.release(); v1.p = nv1.release();
+    k0.p = nk0.release(); k1.p = nk1.release(); v0.p = nv0.release(); v1.p = nv1.release(); vA = v0.p; vB = v1.p;
     kmerSlots = m; r2Slots = h; nTuples = tot; geom.kmerSlots = m; anyBelow = below;
     return sortAndGroup();
 }
@@ -1523,7 +1896,7 @@ int rangeFinishOwned(DevBuf<uint64_t> &keysBuf, DevBuf<V> &valsBuf, uint64_t m, 
     if (int rc = init()) return rc;
     const uint64_t tot = m + h;
     if (!k1.alloc(tot) || !v1.alloc(tot)) { cdm_set_error("cdm_kmermatch: out of device memory for a pass over %llu k-mer tuples", (unsigned long long) tot); return CDM_ERR_HIP; }
-    k0.p = keysBuf.release(); v0.p = valsBuf.release();
+    k0.p = keysBuf.release(); v0.p = valsBuf.release(); vA = v0.p; vB = v1.p;
     kmerSlots = m; r2Slots = h; nTuples = tot; geom.kmerSlots = m; anyBelow = below;
     return sortAndGroup();
 }
@@ -1531,7 +1904,7 @@ int sortAndGroup() {
 
     // ---- sort 1: stable LSD radix sort by k-mer.  Region 1 (k-mer slots) on the 2k key bits, region 2 (whole-sequence hashes)
     // on 63 bits into the same physical buffers; the strand bit 63 rides along outside the sorted bit range.
-    keys = DoubleBuf<uint64_t>(k0.p, k1.p); vals = DoubleBuf<V>(v0.p, v1.p);
+    keys = DoubleBuf<uint64_t>(k0.p, k1.p); vals = DoubleBuf<V>(vA, vB);
     // Region 1: only the top 27 sort bits go through global passes, the low bits are finished per bucket by k_bucket_groups
     // (bucket.h); CDM_KMER_SORT=lsd sorts all 2k bits globally and keeps the separate scan + k_groups kernels (A/B).
     // With low bits left over the passes cover bits [lowBits, 2k]: bit 2k is set only in unused slots, which end up last.
@@ -1540,37 +1913,47 @@ int sortAndGroup() {
     lowBits = lsdOnly ? 0 : std::max(0, 2 * k + 1 - 27);
     const int sortTop = lowBits ? 2 * k + 1 : 2 * k;
     hipEventRecord(ctx->ev0, s);
+    bool slotSorted = false;
+    if constexpr (LY::bySlot) {
+        // one length, 8-byte tuples: the head pass drops the empty slots and writes slot tuples, the other global passes run inside the
+        // head digit's segments (rx::sortSlotKeys); `live` comes out of the head histogram
+        if (!segBuf.alloc(rx::BINS + 1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+        uint64_t *res = nullptr; unsigned long long liveSlots = 0;
+        if (int rc = rx::sortSlotKeys(s, ctx->cuCount, k0.p, k1.p, (uint64_t) kmerSlots, 2 * k, lowBits, headCounted ? headHist.p : nullptr, segBuf.p, liveSlots, res, &ctx->lastMs[13], &ctx->lastMs[14])) return rc;
+        keys = DoubleBuf<uint64_t>(res, res == k0.p ? k1.p : k0.p); vals = res == k0.p ? DoubleBuf<V>(vA, vB) : DoubleBuf<V>(vB, vA);     // (region 2's values follow its keys' buffer)
+        live = liveSlots; geom.seg = segBuf.p; slotSorted = true;
+    } else
     if (nparts > 1 && kmerSlots && !lsdOnly && !split) {      // (split by reads: what arrived has no empty slots)
         // a k-mer RANGE: most slots are empty.  The real tuples are compacted (stable) into the other buffers first, so that the
         // passes run over this rank's share only; behind them the result holds empty slots again, as if all had been sorted.
         DevBuf<unsigned long long> cnt;
         if (!cnt.alloc(1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
-        if (int rc = rx::compactPairs<uint64_t, V>(s, k0.p, v0.p, (uint64_t) kmerSlots, k1.p, v1.p, cnt.p)) return rc;
+        if (int rc = rx::compactPairs<uint64_t, V>(s, k0.p, vA, (uint64_t) kmerSlots, k1.p, vB, cnt.p)) return rc;
         unsigned long long m = 0;
         hipMemcpyAsync(&m, cnt.p, 8, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: compaction failed"); return CDM_ERR_HIP; }
         bool inFirst = true;        // "first" = (k1, v1) here
-        if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, k1.p, k0.p, v1.p, v0.p, (uint64_t) m, lowBits, sortTop, inFirst, &ctx->lastMs[13])) return rc;
+        if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, k1.p, k0.p, vB, vA, (uint64_t) m, lowBits, sortTop, inFirst, &ctx->lastMs[13])) return rc;
         ctx->lastMs[14] = (float) ((sortTop - lowBits + rx::BITS - 1) / rx::BITS);
-        uint64_t *kRes = inFirst ? k1.p : k0.p; V *vRes = inFirst ? v1.p : v0.p;
+        uint64_t *kRes = inFirst ? k1.p : k0.p; V *vRes = inFirst ? vB : vA;
         hipMemsetAsync(kRes + m, 0xFF, (size_t) (kmerSlots - m) * 8, s);        // (the values of empty slots are never read)
-        keys = DoubleBuf<uint64_t>(kRes, inFirst ? k0.p : k1.p); vals = DoubleBuf<V>(vRes, inFirst ? v0.p : v1.p);
+        keys = DoubleBuf<uint64_t>(kRes, inFirst ? k0.p : k1.p); vals = DoubleBuf<V>(vRes, inFirst ? vA : vB);
     } else {
         bool inFirst = true;
-        if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, k0.p, k1.p, v0.p, v1.p, (uint64_t) kmerSlots, lowBits, sortTop, inFirst, &ctx->lastMs[13])) return rc;
+        if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, k0.p, k1.p, vA, vB, (uint64_t) kmerSlots, lowBits, sortTop, inFirst, &ctx->lastMs[13])) return rc;
         ctx->lastMs[14] = (float) ((sortTop - lowBits + rx::BITS - 1) / rx::BITS);     // its launches
-        keys = DoubleBuf<uint64_t>(inFirst ? k0.p : k1.p, inFirst ? k1.p : k0.p); vals = DoubleBuf<V>(inFirst ? v0.p : v1.p, inFirst ? v1.p : v0.p);
+        keys = DoubleBuf<uint64_t>(inFirst ? k0.p : k1.p, inFirst ? k1.p : k0.p); vals = DoubleBuf<V>(inFirst ? vA : vB, inFirst ? vB : vA);
     }
     hipEventRecord(ctx->ev1, s);
     hipEventRecord(ctx->ev2, s);
     {
         // region 2 goes to wherever region 1 ended up (the input is always the extraction buffers k0/v0)
         uint64_t *kOut = keys.current() + kmerSlots, *kIn = k0.p + kmerSlots;
-        V *vOut = vals.current() + kmerSlots, *vIn = v0.p + kmerSlots;
+        V *vOut = vals.current() + kmerSlots, *vIn = vA + kmerSlots;
         {
             bool inFirst = true;
-            if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, kIn, k1.p + kmerSlots, vIn, v1.p + kmerSlots, (uint64_t) r2Slots, 0, 63, inFirst)) return rc;
-            uint64_t *kRes = inFirst ? kIn : k1.p + kmerSlots; V *vRes = inFirst ? vIn : v1.p + kmerSlots;
+            if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, kIn, k1.p + kmerSlots, vIn, vB + kmerSlots, (uint64_t) r2Slots, 0, 63, inFirst)) return rc;
+            uint64_t *kRes = inFirst ? kIn : k1.p + kmerSlots; V *vRes = inFirst ? vIn : vB + kmerSlots;
             if (kRes != kOut && r2Slots) { hipMemcpyAsync(kOut, kRes, (size_t) r2Slots * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(vOut, vRes, (size_t) r2Slots * sizeof(V), hipMemcpyDeviceToDevice, s); }
         }
     }
@@ -1586,7 +1969,8 @@ int sortAndGroup() {
     hipMemsetAsync(statStripes.p, 0, STAT_STRIPES * 8, s);
     ga.stat = statStripes.p;
     startIo = (unsigned long long *) keys.alternate();   // free after the sort
-    live = 0; nKept = 0;
+    if (!slotSorted) live = 0;
+    nKept = 0;
     if (!staleBuf.alloc(STALE_MAX + 3)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipMemsetAsync(staleBuf.p, 0, (STALE_MAX + 3) * 4, s);
     {
@@ -1601,7 +1985,7 @@ int sortAndGroup() {
             return hipStreamSynchronize(s) == hipSuccess ? CDM_OK : CDM_ERR_HIP;
         };
         int rc = CDM_OK;
-        if (kmerSlots) {        // real tuples of region 1 (the unused slots sort behind them in both variants)
+        if (kmerSlots && !slotSorted) {        // real tuples of region 1 (the unused slots sort behind them in both variants)
             hipLaunchKernelGGL(k_live_count, dim3(1), dim3(1), 0, s, ga.keys, (uint64_t) kmerSlots, 2 * k, counters.p + 3);
             hipMemcpyAsync(&live, counters.p + 3, 8, hipMemcpyDeviceToHost, s);
             if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: grouping failed"); return CDM_ERR_HIP; }
@@ -1614,6 +1998,7 @@ int sortAndGroup() {
             if (!bigList.alloc(bucket::bigListSlots(kmerSlots, maxBucket)) || !bigCnt.alloc(1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
             hipMemsetAsync(bigCnt.p, 0, 4, s);
             if (kmerSlots) hipMemsetAsync(startIo + live, 0xFF, (size_t) (kmerSlots - live) * 8, s);     // unused slots: no group key
+            DevBuf<BlockHead> heads; bool headsFailed = false;        // (freed behind the synchronise below)
             auto launchFused = [&](auto wordTag) {
                 typedef decltype(wordTag) W;
                 BucketGroupArgs<LY, W> ba;
@@ -1621,13 +2006,36 @@ int sortAndGroup() {
                 ba.keys = ga.keys; ba.vals = ga.vals; ba.geom = geom; ba.out = startIo; ba.lowBits = lowBits; ba.own = own; ba.maxBucket = maxBucket;
                 ba.big.list = bigList.p; ba.big.cnt = bigCnt.p;
                 const uint64_t perBlock = (uint64_t) own * bucket::BK_WAVES;
+                // the run records of sort 2 come out of this kernel (on the default single-device pipeline; CDM_RUN_RECORDS=kernel|twopass: from
+                // the key array, as before round 5)
+                stagedWaves = 0;
+                if (LY::bySlot && ownPipeline && live && !cdmGetenv("CDM_RUN_RECORDS") && !cdmGetenv("CDM_RUN_CAP")) {
+                    const uint64_t waves = (live + (uint64_t) own - 1) / (uint64_t) own;
+                    ovCap = live / 256 + 4096;
+                    if (stRep.alloc(waves * REC_CAP) && stVal.alloc(waves * REC_CAP) && stCnt.alloc(waves + 1) && recFlag.alloc(2) && ovRep.alloc(ovCap) && ovVal.alloc(ovCap)) {
+                        hipMemsetAsync(stCnt.p, 0, waves + 1, s); hipMemsetAsync(recFlag.p, 0, 8, s);
+                        ba.recRep = stRep.p; ba.recVal = stVal.p; ba.recCnt = stCnt.p; stagedWaves = waves; stagedOwn = (uint64_t) own; nBigRec = 0;
+                        ba.ovRep = ovRep.p; ba.ovVal = ovVal.p; ba.ovCursor = recFlag.p; ba.ovCap = ovCap;
+                        if (const char *e = cdmGetenv("CDM_REC_LIMIT")) { const long v = atol(e); if (v >= 0 && v <= REC_CAP) ba.recLimit = (uint32_t) v; }
+                    } else { stRep.free(); stVal.free(); stCnt.free(); ovRep.free(); ovVal.free(); (void) hipGetLastError(); }      // (no room: the records come from the key array)
+                }
+                if constexpr (LY::bySlot) {
+                    const uint64_t blocks = (live + perBlock - 1) / perBlock;
+                    if (!heads.alloc(blocks)) { cdm_set_error("cdm_kmermatch: out of device memory"); headsFailed = true; return; }
+                    if (blocks) hipLaunchKernelGGL(k_block_heads, CDM_GRID((blocks + 255) / 256, 256), dim3(256), 0, s, geom, (uint64_t) live, perBlock, blocks, heads.p);
+                    ba.blockHead = heads.p;
+                }
                 if (live) hipLaunchKernelGGL((k_bucket_groups<LY, W>), dim3((unsigned) ((live + perBlock - 1) / perBlock)), dim3(bucket::BK_NT), cdm_lds_pad("CDM_LDS_PAD_GROUPS"), s, ba);
             };
             if (lowBits <= 15) launchFused(uint32_t()); else launchFused(uint64_t());   // 8 bits of bucket ordinal + low bits + 9 of position in one word
-            unsigned int nBig = 0;
+            if (headsFailed) return CDM_ERR_HIP;
+            unsigned int nBig = 0; unsigned long long recOver = 0;
             hipMemcpyAsync(&nBig, bigCnt.p, 4, hipMemcpyDeviceToHost, s);
+            if (stagedWaves) hipMemcpyAsync(&recOver, recFlag.p, 8, hipMemcpyDeviceToHost, s);
             GroupArgs<LY> g2 = ga; g2.first = kmerSlots;                      // region 2 is sorted on all its bits
             rc = scanGroups(g2, startIo);
+            nOvRec = recOver;
+            if (stagedWaves && recOver > ovCap) { stagedWaves = 0; stRep.free(); stVal.free(); stCnt.free(); ovRep.free(); ovVal.free(); }     // (more records beyond the waves' stages than their list holds: from the key array after all)
             if (rc == CDM_OK && nBig) {
                 // buckets the kernel left alone: gather them, sort on the whole k-mer, group, scatter the group keys back
                 DevBuf<unsigned long long> ranges; uint64_t total = 0; unsigned long long firstStart = ~0ull;
@@ -1637,15 +2045,21 @@ int sortAndGroup() {
                 if (rc == CDM_OK && (!dk0.alloc(total) || !dk1.alloc(total) || !dv0.alloc(total) || !dv1.alloc(total) || !ds.alloc(total))) rc = CDM_ERR_HIP;
                 if (rc == CDM_OK) {
                     const unsigned int grid = bucket::bigCopyGrid(nBig);
+                    if constexpr (LY::bySlot) hipLaunchKernelGGL(k_big_slot_pairs<true>, dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(ga.keys), geom, dk0.p, dv0.p);
+                    else {
                     hipLaunchKernelGGL((bucket::k_big_copy<uint64_t, true>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(ga.keys), dk0.p);
                     hipLaunchKernelGGL((bucket::k_big_copy<V, true>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<V *>(ga.vals), dv0.p);
+                    }
                     bool bigFirst = true;
                     rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, dk0.p, dk1.p, dv0.p, dv1.p, (uint64_t) total, 0, 2 * k, bigFirst);
                     DoubleBuf<uint64_t> dk(bigFirst ? dk0.p : dk1.p, bigFirst ? dk1.p : dk0.p); DoubleBuf<V> dv(bigFirst ? dv0.p : dv1.p, bigFirst ? dv1.p : dv0.p);
                     if (rc == CDM_OK) {
                         // the sorted tuples go back in place too: k_stale_tail indexes big buckets directly
+                        if constexpr (LY::bySlot) hipLaunchKernelGGL(k_big_slot_pairs<false>, dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(ga.keys), geom, dk.current(), dv.current());
+                        else {
                         hipLaunchKernelGGL((bucket::k_big_copy<uint64_t, false>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<uint64_t *>(ga.keys), dk.current());
                         hipLaunchKernelGGL((bucket::k_big_copy<V, false>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, const_cast<V *>(ga.vals), dv.current());
+                        }
                         GroupArgs<LY> gd = ga; gd.keys = dk.current(); gd.vals = dv.current(); gd.n = total; gd.first = 0;
                         gd.geom.kmerSlots = ~0ull;                                   // every tuple of the dense view is a region-1 tuple
                         gd.firstRunIdx = (firstStart == 0 && !anyBelow) ? 0ull : ~0ull;           // dense index 0 is the array's first tuple only then
@@ -1654,6 +2068,21 @@ int sortAndGroup() {
                     if (rc == CDM_OK) {
                         hipLaunchKernelGGL((bucket::k_big_copy<unsigned long long, false>), dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, startIo, ds.p);
                         if (hipStreamSynchronize(s) != hipSuccess) rc = CDM_ERR_HIP;
+                    }
+                    if (rc == CDM_OK && stagedWaves) {
+                        // the run records of these buckets (the kernel staged none for them): from their group keys, a dropped key between
+                        // two buckets, the starts put back into the key array's coordinates
+                        DevBuf<unsigned long long> gapped;
+                        if (!gapped.alloc(total + nBig)) rc = CDM_ERR_HIP;
+                        else {
+                            hipLaunchKernelGGL(k_big_gap_copy, dim3(grid), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, (const unsigned long long *) ds.p, gapped.p);
+                            runsort::RunArgs ra; ra.keys = (const uint64_t *) gapped.p; ra.n = total + nBig; ra.skipLo = ra.skipHi = 0; ra.repShift = (int) (idBits + diagBits + 1);
+                            ra.wide = wide ? 1 : 0; ra.idShift = (int) diagBits + 1; ra.idMask = (1ull << idBits) - 1ull;
+                            rc = runsort::makeRunRecords(s, ra, bigRecRep, bigRecRep1, bigRecVal, bigRecVal1, nBigRec);
+                            if (rc == CDM_OK && nBigRec) hipLaunchKernelGGL(k_big_rec_starts, CDM_GRID((nBigRec + 255) / 256, 256), dim3(256), 0, s, (const unsigned long long *) ranges.p, nBig, bigRecVal.p, (uint64_t) nBigRec);
+                            if (rc == CDM_OK && hipStreamSynchronize(s) != hipSuccess) rc = CDM_ERR_HIP;
+                            bigRecRep1.free(); bigRecVal1.free();
+                        }
                     }
                 }
             }
@@ -1735,7 +2164,9 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
         cdmscan::ScanTemp stB;
         unsigned long long nRec = 0;
         DevBuf<uint32_t> rr0, rr1; DevBuf<uint64_t> rv0, rv1; DevBuf<unsigned long long> dst;
-        if (int rc = makeRunRecords(s, ra, rr0, rr1, rv0, rv1, nRec)) return rc;
+        const bool fromStage = stagedWaves && ownBuffers && keysIn == (const uint64_t *) startIo;
+        if (fromStage) { if (int rc = stagedRunRecords(ra, rr0, rr1, rv0, rv1, nRec)) return rc; }
+        else if (int rc = makeRunRecords(s, ra, rr0, rr1, rv0, rv1, nRec)) return rc;
         if (!dst.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
         if (nRec) {
             bool recFirst = true;
@@ -1754,7 +2185,7 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
             const char *voteEnv = cdmGetenv("CDM_KMER_VOTE");
             const bool wordFits = aggv::AG_ORD + idBits + diagBits + aggv::AG_IDX <= 64 && !(wide && cdmGetenv("CDM_FORCE_WIDE_WORD"));    // (tests: the 128-bit entry sort word for any DB)
             bool aggregated = wide || (ownBuffers && !sort2Check && !(voteEnv && !strcmp(voteEnv, "tuples")) && wordFits);
-            if (wide && ownBuffers && nGroup != nKept) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu in the run records", nKept, nGroup); return CDM_ERR_HIP; }
+            if ((wide || fromStage) && ownBuffers && nGroup != nKept) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu in the run records", nKept, nGroup); return CDM_ERR_HIP; }
             if (aggregated) {
                 // (the wide form has no tuple path to fall back to: an entry buffer that proves too small is tried again, larger)
                 unsigned long long capEnt = nGroup / 6 + (4ull << 20);
@@ -1809,6 +2240,45 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
     }
     hipEventRecord(ctx->ev1, s);
     sorted2M = sorted2; nGroupM = nGroup;
+    return CDM_OK;
+}
+// The run records of the whole key array from what the grouping kernel staged for region 1 (k_rec_compact: the waves' records packed,
+// in wave order = k-mer order) + the records of region 2 (the whole-sequence hash tuples' group keys: k_run_records on that part).
+int stagedRunRecords(const runsort::RunArgs &whole, DevBuf<uint32_t> &rr0, DevBuf<uint32_t> &rr1, DevBuf<uint64_t> &rv0, DevBuf<uint64_t> &rv1, unsigned long long &nRec) {
+    DevBuf<unsigned long long> off; cdmscan::ScanTemp st;
+    if (!off.alloc(stagedWaves + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (run records)"); return CDM_ERR_HIP; }
+    if (int rc = cdmscan::exclusiveScanFn<unsigned long long, RecCount>(s, st, RecCount{stCnt.p}, off.p, (size_t) stagedWaves + 1)) return rc;      // (stCnt[stagedWaves] = 0)
+    unsigned long long n1 = 0, n2 = 0;
+    hipMemcpyAsync(&n1, off.p + stagedWaves, 8, hipMemcpyDeviceToHost, s);
+    // region 2
+    DevBuf<uint32_t> q0, q1; DevBuf<uint64_t> w0, w1;
+    runsort::RunArgs r2 = whole; r2.keys = whole.keys + kmerSlots; r2.n = whole.n - kmerSlots; r2.skipLo = r2.skipHi = 0; r2.base = kmerSlots;
+    if (r2.n) { if (int rc = runsort::makeRunRecords(s, r2, q0, q1, w0, w1, n2)) return rc; }
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: run records failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    // the records that are not in the waves' stages - the big buckets' and the stages' overflow - as ONE list sorted by start
+    unsigned long long nb = nBigRec;
+    if (nOvRec) {
+        DevBuf<uint64_t> x0, x1; DevBuf<uint32_t> y0, y1;
+        const unsigned long long tot = nBigRec + nOvRec;
+        if (!x0.alloc(tot) || !x1.alloc(tot) || !y0.alloc(tot) || !y1.alloc(tot)) { cdm_set_error("cdm_kmermatch: out of device memory (run records)"); return CDM_ERR_HIP; }
+        if (nBigRec) { hipMemcpyAsync(x0.p, bigRecVal.p, nBigRec * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(y0.p, bigRecRep.p, nBigRec * 4, hipMemcpyDeviceToDevice, s); }
+        hipMemcpyAsync(x0.p + nBigRec, ovVal.p, nOvRec * 8, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(y0.p + nBigRec, ovRep.p, nOvRec * 4, hipMemcpyDeviceToDevice, s);
+        bool first = true;
+        if (int rc = rx::sortPairs<uint64_t, uint32_t>(s, ctx->cuCount, x0.p, x1.p, y0.p, y1.p, (uint64_t) tot, runsort::RUN_CNT_BITS, 64, first)) return rc;
+        bigRecVal.free(); bigRecRep.free();
+        bigRecVal.p = first ? x0.release() : x1.release(); bigRecRep.p = first ? y0.release() : y1.release();
+        nb = tot;
+    }
+    nRec = n1 + nb + n2;
+    if (!rr0.alloc(nRec) || !rr1.alloc(nRec) || !rv0.alloc(nRec + 1) || !rv1.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
+    if (n1) hipLaunchKernelGGL(k_rec_compact, CDM_GRID((stagedWaves + REC_WAVES - 1) / REC_WAVES, 256), dim3(256), 0, s, (const uint32_t *) stRep.p, (const uint64_t *) stVal.p, (const unsigned long long *) off.p, (uint64_t) stagedWaves,
+                               (uint64_t) stagedOwn, (const uint64_t *) bigRecVal.p, (uint64_t) nb, rr0.p, rv0.p);
+    if (nb) hipLaunchKernelGGL(k_rec_place_big, CDM_GRID((nb + 255) / 256, 256), dim3(256), 0, s, (const uint32_t *) bigRecRep.p, (const uint64_t *) bigRecVal.p, (uint64_t) nb, (const uint64_t *) stVal.p, (const uint8_t *) stCnt.p,
+                               (const unsigned long long *) off.p, (uint64_t) stagedOwn, rr0.p, rv0.p);
+    if (n2) { hipMemcpyAsync(rr0.p + n1 + nb, q0.p, n2 * 4, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(rv0.p + n1 + nb, w0.p, n2 * 8, hipMemcpyDeviceToDevice, s); }
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: run records (packing) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    if (cdmGetenv("CDM_BUCKET_STATS")) fprintf(stderr, "run records: %llu staged by the grouping kernel, %llu beyond its waves' stages, %llu of its big buckets, %llu of the whole-sequence hash region\n", n1, nOvRec, nBigRec, n2);
+    stRep.free(); stVal.free(); stCnt.free(); bigRecRep.free(); bigRecVal.free(); ovRep.free(); ovVal.free(); stagedWaves = 0; nBigRec = 0; nOvRec = 0;
     return CDM_OK;
 }
 // K4 on entries: the per-representative hit counts are known already (aggregate); offsets, self hits, then one thread per segment
@@ -2140,6 +2610,13 @@ int kmermatchPassesT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *p
     if (int rc = fin.sort2(G.p, gCount, gCount, gCount, fin.k0.p, G.p, true)) return rc;
     return fin.vote(nullptr, true, out);
 }
+// do the tuples of one pass (bytesPerSlot for every k-mer slot, both buffers) fit 80 % of the device?
+inline bool onePassFits(const cdm_seqdb *db, double bytesPerSlot) {
+    size_t fr = 0, tot = 0;
+    const unsigned long long slots = db->residues + 2 * db->n;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) { (void) hipGetLastError(); return true; }
+    return (double) slots * bytesPerSlot * 1.1 <= 0.80 * (double) tot;
+}
 template <typename LY>
 int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
     // One pass while the tuples fit the device: 16 bytes of keys + two values per k-mer slot, two buffers of each.  CDM_KMER_PASSES=P[,B]
@@ -2159,6 +2636,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
     }
     if (P > 1 || B > 1) return kmermatchPassesT<LY>(ctx, db, par, std::max(P, 1), std::max(B, 1), out);
     KmerJob<LY> job(ctx, db, par);
+    job.ownPipeline = true;
     if (int rc = job.phaseA()) return rc;
     if (job.nKept) if (int rc = job.staleTail(job.nKept, false)) return rc;
     return job.phaseB(out);
@@ -2307,9 +2785,18 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
     bool packed = fits;
     if (const char *e = cdmGetenv("CDM_KMER_LAYOUT")) {
         if (!strcmp(e, "wide")) packed = false;
+        else if (!strcmp(e, "slot")) {}
         else if (!strcmp(e, "packed")) {
             if (!fits) { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT=packed needs 2k + 1 + 2 x length bits <= 63 (k %d, max length %u)", k, db->maxLen); return CDM_ERR_INVALID; }
-        } else { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT must be wide or packed"); return CDM_ERR_INVALID; }
+        } else { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT must be wide, packed or slot"); return CDM_ERR_INVALID; }
+    }
+    // one length throughout (reads straight from a sequencer, the bench's 50 M x 100 bp): 8-byte tuples through sort 1 (LayoutSlot) - on
+    // the default single-pass pipeline only (no A/B sort variant, one device, tuples that fit the device at once)
+    {
+        const char *e = cdmGetenv("CDM_KMER_LAYOUT");
+        const bool want = !e || !strcmp(e, "slot");
+        if (e && !strcmp(e, "slot") && !slotLayoutFits(db, k)) { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT=slot needs sequences of one length (at least k letters), fewer than 2^32 k-mer slots and 14 <= k <= 20"); return CDM_ERR_INVALID; }
+        if (want && slotLayoutFits(db, k) && !cdmGetenv("CDM_KMER_SORT") && !cdmGetenv("CDM_KMER_PASSES") && onePassFits(db, 16.0 + 8.0)) return kmermatchT<LayoutSlot>(ctx, db, par, out);
     }
     if (packed) return kmermatchT<LayoutPacked>(ctx, db, par, out);
     if (db->maxLen < 65535u && !cdmGetenv("CDM_FORCE_HUGE_LAYOUT")) return kmermatchT<LayoutWide>(ctx, db, par, out);

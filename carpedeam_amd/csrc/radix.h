@@ -15,6 +15,8 @@
 // 9 bits per pass: 512 digits x 8192-pair tiles = 16 pairs per run on average (128 B of keys).  HBM bound by design:
 // 24.6 GB per 2^30 12-byte pairs and pass.
 #pragma once
+#include <cstring>
+#include <algorithm>
 #include "common.h"
 #include "devutil.h"
 
@@ -71,16 +73,31 @@ __global__ __launch_bounds__(BINS) void k_rx_offsets(unsigned long long *hist, i
     }
 }
 
+// Three forms of the pass (MODE):
+//   PASS_PLAIN  the n pairs, stable on the digit
+//   PASS_HEAD   sort 1 of kmermatcher on SLOT KEYS (sortSlotKeys below): kin holds one 64-bit key per k-mer slot, k-mer | strand << 63, ~0 =
+//               empty slot.  The pass is the most significant one: it drops the empty slots, partitions the others by the head digit (the
+//               `bits` key bits from `shift` on) and writes 8-byte SLOT TUPLES [ key bits below shift : 31 | strand : 1 | slot index : 32 ] -
+//               the head digit is implied by where a tuple lands (segment = digit), the slot index says which sequence and position the
+//               k-mer came from (the slots are laid out by sequence: kmermatch.hip).  Keys only.
+//   PASS_SEG    the array is cut into BINS segments (seg[0 .. BINS]: the head pass's digits); every segment is sorted on its own, stable:
+//               tiles do not cross a segment (segTile[d] = first tile of segment d), the chained scan starts afresh at a segment's first
+//               tile, digitBase is [segment][digit]
+enum { PASS_PLAIN = 0, PASS_HEAD = 1, PASS_SEG = 2 };
+constexpr int SLOT_REM = 31, SLOT_IDX_SHIFT = 0, SLOT_STRAND_SHIFT = 32, SLOT_KEY_SHIFT = 33;       // the slot tuple's fields
 template <typename K, typename V>
 struct PassArgs {
     const K *kin; K *kout; const V *vin; V *vout; uint64_t n;
     int shift, bits;
-    const unsigned long long *digitBase;        // [BINS]
+    const unsigned long long *digitBase;        // [BINS] ([BINS][BINS] in PASS_SEG)
     unsigned long long *status;                 // [tiles][BINS], zeroed
     unsigned int *ticket;                       // zeroed
+    const unsigned long long *seg = nullptr; const unsigned int *segTile = nullptr;     // PASS_SEG: [BINS + 1] each
 };
-template <typename K, typename V>
+template <typename K, typename V, int MODE = PASS_PLAIN>
 __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
+    static_assert(MODE == PASS_PLAIN || (sizeof(K) == 8 && !HasValue<V>::value), "the head and segment passes sort 64-bit keys only");
+    static_assert(MODE != PASS_HEAD || TILE <= 8192, "the head pass keeps a key's index in its tile in 13 bits of the exchange word");
     // one 64 KB exchange buffer, used for the keys and then for the values: two blocks per CU
     __shared__ uint64_t sBuf[TILE];
     __shared__ uint16_t sCnt[WAVES][BINS];
@@ -91,8 +108,17 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
     if (tid == 0) sTile = atomicAdd(a.ticket, 1u);
     for (int i = tid; i < WAVES * BINS / 2; i += NT) reinterpret_cast<uint32_t *>(&sCnt[0][0])[i] = 0u;
     __syncthreads();
-    const uint64_t tile = sTile, base = tile * TILE;
-    const int items = (int) min((uint64_t) TILE, a.n - base);
+    const uint64_t tile = sTile;
+    uint64_t base = tile * TILE, chain = tile;          // chain: tiles in front of this one in its chained scan
+    uint64_t segEnd = a.n;
+    const unsigned long long *digitBase = a.digitBase;
+    if constexpr (MODE == PASS_SEG) {
+        const int sg = __syncthreads_count(tid < BINS && (uint64_t) a.segTile[tid < BINS ? tid : 0] <= tile) - 1;      // the last segment whose first tile is not behind this one
+        chain = tile - a.segTile[sg];
+        base = a.seg[sg] + chain * TILE; segEnd = a.seg[sg + 1];
+        digitBase += (size_t) sg * BINS;
+    }
+    const int items = (int) min((uint64_t) TILE, segEnd - base);
     const uint32_t mask = (1u << a.bits) - 1u;
     // ---- load: wave w owns [w * 64 IPT, (w + 1) * 64 IPT), round j its j-th 64 pairs
     K key[IPT]; V val[IPT]; uint16_t pos[IPT];
@@ -100,13 +126,13 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
 #pragma unroll
     for (int j = 0; j < IPT; j++) {
         const int li = w0 + 64 * j;
-        if (li < items) { key[j] = a.kin[base + li]; if constexpr (HasValue<V>::value) val[j] = a.vin[base + li]; } else key[j] = 0;
+        if (li < items) { key[j] = a.kin[base + li]; if constexpr (HasValue<V>::value) val[j] = a.vin[base + li]; } else key[j] = (MODE == PASS_HEAD) ? (K) ~(K) 0 : (K) 0;
     }
     // ---- rank inside the wave's stream, round by round
     uint16_t *cntW = sCnt[wave];
 #pragma unroll
     for (int j = 0; j < IPT; j++) {
-        const bool valid = w0 + 64 * j < items;
+        const bool valid = (MODE == PASS_HEAD) ? key[j] != (K) ~(K) 0 : w0 + 64 * j < items;
         const uint32_t d = digitOf(key[j], a.shift, mask);
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -136,26 +162,30 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
     unsigned long long *st = a.status + tile * BINS + tid;
     if (isDigit) {
         sTileOff[tid] = (uint16_t) ex;
-        __hip_atomic_store(st, (tile == 0 ? ST_PREFIX : ST_AGG) | (unsigned long long) run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(st, (chain == 0 ? ST_PREFIX : ST_AGG) | (unsigned long long) run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     K *sK = reinterpret_cast<K *>(sBuf);
+    const int nOut = (MODE == PASS_HEAD) ? (int) tot : items;       // (the head pass drops the empty slots)
     // ---- the keys into the exchange buffer: slot = digits in front + waves in front + rank (needs nothing of the other tiles)
 #pragma unroll
     for (int j = 0; j < IPT; j++) {
-        if (w0 + 64 * j < items) {
+        const bool valid = (MODE == PASS_HEAD) ? key[j] != (K) ~(K) 0 : w0 + 64 * j < items;
+        if (valid) {
             const uint32_t d = digitOf(key[j], a.shift, mask);
             pos[j] = (uint16_t) ((uint32_t) sTileOff[d] + (uint32_t) sCnt[wave][d] + (uint32_t) pos[j]);
-            sK[pos[j]] = key[j];
+            if constexpr (MODE == PASS_HEAD)     // exchange word: [ key bits below shift | strand | digit : 9 | index in the tile : 13 ]
+                sK[pos[j]] = (K) ((((uint64_t) key[j] & ((1ull << a.shift) - 1ull)) << 23) | (((uint64_t) key[j] >> 63) << 22) | ((uint64_t) d << 13) | (uint64_t) (w0 + 64 * j));
+            else sK[pos[j]] = key[j];
         }
     }
     // ---- the tiles in front: chained scan with decoupled look-back, after the exchange so that the tiles in front had that time to
     // publish their prefix; LB status words are fetched per round trip
     if (isDigit) {
         unsigned long long exclG = 0;
-        if (tile != 0) {
+        if (chain != 0) {
             const unsigned long long *q = st - BINS;
-            uint64_t left = tile;
+            uint64_t left = chain;
             bool done = false;
             while (!done) {
                 unsigned long long v[LB];
@@ -173,17 +203,23 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
             }
             __hip_atomic_store(st, ST_PREFIX | (exclG + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        sGlobal[tid] = a.digitBase[tid] + exclG - ex;       // output position of the pair at exchange slot p with this digit: sGlobal + p
+        sGlobal[tid] = digitBase[tid] + exclG - ex;         // output position of the pair at exchange slot p with this digit: sGlobal + p
     }
     __syncthreads();
     uint16_t dig[IPT];
 #pragma unroll
     for (int r = 0; r < IPT; r++) {
         const int p = tid + NT * r;
-        if (p < items) {
+        if (p < nOut) {
             const K k = sK[p];
-            dig[r] = (uint16_t) digitOf(k, a.shift, mask);
-            a.kout[sGlobal[dig[r]] + (unsigned long long) p] = k;
+            if constexpr (MODE == PASS_HEAD) {
+                const uint64_t w = (uint64_t) k;
+                dig[r] = (uint16_t) ((w >> 13) & (uint64_t) (BINS - 1));
+                a.kout[sGlobal[dig[r]] + (unsigned long long) p] = (K) (((w >> 23) << SLOT_KEY_SHIFT) | (((w >> 22) & 1ull) << SLOT_STRAND_SHIFT) | (uint64_t) (uint32_t) (base + (w & 8191ull)));
+            } else {
+                dig[r] = (uint16_t) digitOf(k, a.shift, mask);
+                a.kout[sGlobal[dig[r]] + (unsigned long long) p] = k;
+            }
         }
     }
     if constexpr (HasValue<V>::value) {
@@ -324,6 +360,177 @@ inline int sortPairs(hipStream_t s, int cuCount, K *k0, K *k1, V *v0, V *v1, uin
 template <typename K>
 inline int sortKeys(hipStream_t s, int cuCount, K *k0, K *k1, uint64_t n, int beginBit, int endBit, bool &inFirst) {
     return sortPairs<K, NoValue>(s, cuCount, k0, k1, (NoValue *) nullptr, (NoValue *) nullptr, n, beginBit, endBit, inFirst);
+}
+
+
+// ---------------------------------------------------------------------------------------------- sort 1 on slot keys
+// kmermatcher's sort 1 (kmermatcher.cpp:412) when every sequence has the same length: the extractor writes ONE 64-bit key per k-mer
+// slot (k-mer | strand << 63, ~0 = empty), and which sequence and position a key belongs to is its slot index - so a tuple is 8 bytes
+// instead of 12, in every pass:
+//   k_rx_hist_head    digit counts of the head pass (skipped when the extractor counted while it wrote: headHist)
+//   k_rx_seg_layout   the segments (= head digits) and their tiles
+//   k_rx_pass<HEAD>   most significant digit first: empty slots dropped, slot tuples out (see PASS_HEAD)
+//   k_rx_hist_seg     digit counts of the remaining global passes per segment (one read of the tuples)
+//   k_rx_pass<SEG>    those passes, least significant digit first, inside every segment
+// The result is ordered on the key bits [lowBits, topBit) - what the plain passes leave - and stable: equal keys stay in slot order.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(NT) void k_rx_hist_head(const uint64_t *__restrict__ keys, uint64_t n, int shift, int bits, unsigned long long *__restrict__ hist) {
+    __shared__ unsigned int sHist[BINS];
+    for (int i = threadIdx.x; i < BINS; i += NT) sHist[i] = 0u;
+    __syncthreads();
+    const uint32_t mask = (1u << bits) - 1u;
+    for (uint64_t t = blockIdx.x; t * TILE < n; t += gridDim.x) {
+        const uint64_t base = t * TILE;
+#pragma unroll 4
+        for (int j = 0; j < IPT; j++) {
+            const uint64_t i = base + (uint64_t) j * NT + threadIdx.x;
+            if (i >= n) break;
+            const uint64_t k = keys[i];
+            if (k != ~0ull) atomicAdd(&sHist[digitOf(k, shift, mask)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BINS; i += NT) { const unsigned int c = sHist[i]; if (c) atomicAdd(&hist[i], (unsigned long long) c); }
+}
+// hist[BINS] -> seg[d] = first tuple of segment d (seg[BINS] = all of them), segTile[d] = its first tile (segTile[BINS] = all tiles)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(BINS) void k_rx_seg_layout(const unsigned long long *__restrict__ hist, unsigned long long *__restrict__ seg, unsigned int *__restrict__ segTile) {
+    const unsigned long long c = hist[threadIdx.x];
+    unsigned long long tot; unsigned int tt;
+    const unsigned long long ex = cdm_block_excl_sum<unsigned long long>(c, tot);
+    const unsigned int tiles = (unsigned int) ((c + TILE - 1) / TILE);
+    const unsigned int et = cdm_block_excl_sum<unsigned int>(tiles, tt);
+    seg[threadIdx.x] = ex; segTile[threadIdx.x] = et;
+    if (threadIdx.x == 0) { seg[BINS] = tot; segTile[BINS] = tt; }
+}
+// digit counts of `passes` passes (bits [beginBit + p BITS, ...) of the tuples, up to endBit) per segment: hist[segment][pass][digit]
+struct SegHistArgs { const uint64_t *keys; const unsigned long long *seg; int beginBit, endBit, passes; unsigned long long *hist; };
+template <int UNUSED = 0>
+__global__ __launch_bounds__(NT) void k_rx_hist_seg(SegHistArgs a) {
+    __shared__ unsigned int sHist[2][BINS];
+    const uint64_t n = a.seg[BINS];
+    // a block takes one contiguous stretch of the tuples and flushes its counters where the stretch crosses into the next segment
+    const uint64_t per = ((n + gridDim.x - 1) / gridDim.x + NT - 1) / NT * NT;
+    const uint64_t e0 = (uint64_t) blockIdx.x * per, e1 = min(n, e0 + per);
+    if (e0 >= e1) return;
+    const int first = __syncthreads_count(threadIdx.x < BINS && a.seg[threadIdx.x < BINS ? threadIdx.x : 0] <= e0) - 1;
+    for (int i = threadIdx.x; i < 2 * BINS; i += NT) (&sHist[0][0])[i] = 0u;
+    __syncthreads();
+    uint64_t e = e0;
+    for (int sg = first; e < e1; sg++) {
+        const uint64_t stop = min(e1, (uint64_t) a.seg[sg + 1]);
+        if (stop <= e) continue;
+        for (uint64_t i = e + threadIdx.x; i < stop; i += NT) {
+            const uint64_t k = a.keys[i];
+            for (int p = 0; p < a.passes; p++) {
+                const int shift = a.beginBit + p * BITS, bits = min(BITS, a.endBit - shift);
+                atomicAdd(&sHist[p][digitOf(k, shift, (1u << bits) - 1u)], 1u);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.passes * BINS; i += NT) {
+            const unsigned int c = (&sHist[0][0])[i];
+            if (c) { atomicAdd(&a.hist[((size_t) sg * a.passes) * BINS + i], (unsigned long long) c); (&sHist[0][0])[i] = 0u; }
+        }
+        __syncthreads();
+        e = stop;
+    }
+}
+// in place: hist[segment][pass][digit] -> first output position of the digit's tuples (block = (segment, pass))
+template <int UNUSED = 0>
+__global__ __launch_bounds__(BINS) void k_rx_offsets_seg(unsigned long long *hist, int passes, const unsigned long long *__restrict__ seg) {
+    unsigned long long *h = hist + (size_t) blockIdx.x * BINS;
+    const unsigned long long c = h[threadIdx.x];
+    unsigned long long tot;
+    const unsigned long long ex = cdm_block_excl_sum<unsigned long long>(c, tot);
+    h[threadIdx.x] = seg[blockIdx.x / passes] + ex;
+}
+// pass-major copy of the per-segment tables: out[pass][segment][digit] (a pass's digitBase is one contiguous [BINS][BINS] table)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(BINS) void k_rx_seg_tables(const unsigned long long *__restrict__ hist, int passes, unsigned long long *__restrict__ out) {
+    const int sg = blockIdx.x / passes, p = blockIdx.x % passes;
+    out[((size_t) p * BINS + sg) * BINS + threadIdx.x] = hist[((size_t) sg * passes + p) * BINS + threadIdx.x];
+}
+// k0: the n slot keys; k1: a second buffer of n keys.  topBit = number of k-mer bits (2k; bit 2k and above are clear in real keys),
+// lowBits = key bits left to the on-chip finish.  Needs HEAD_BITS <= topBit, lowBits <= topBit - HEAD_BITS <= SLOT_REM.
+// headHist: device, [BINS] head digit counts of the real keys if the writer of k0 counted them (else NULL: counted here).
+// Out: segDev (device, [BINS + 1], caller-allocated) = where each head digit's tuples start in the result; live = real tuples;
+// result = the buffer (k0 or k1) that holds the sorted slot tuples.  passMs / launches: HIP-event time of the pass launches, summed.
+inline int sortSlotKeys(hipStream_t s, int cuCount, uint64_t *k0, uint64_t *k1, uint64_t n, int topBit, int lowBits, const unsigned long long *headHist,
+                        unsigned long long *segDev, unsigned long long &live, uint64_t *&result, float *passMs = nullptr, float *launches = nullptr) {
+    live = 0; result = k1;
+    const int headBits = std::min(BITS, topBit), shift = topBit - headBits, rem = shift - lowBits;
+    if (shift > SLOT_REM || rem < 0) { cdm_set_error("slot key sort: %d key bits, %d finished on chip", topBit, lowBits); return CDM_ERR_INVALID; }
+    const int segPasses = (rem + BITS - 1) / BITS;
+    if (segPasses > 2) { cdm_set_error("slot key sort: %d global key bits behind the head digit (two passes take %d)", rem, 2 * BITS); return CDM_ERR_INVALID; }
+    const uint64_t tilesHead = (n + TILE - 1) / TILE;
+    DevBuf<unsigned long long> hist, segHist, segTables, status; DevBuf<unsigned int> ticket, segTile;
+    if (!hist.alloc(BINS) || !ticket.alloc(4) || !segTile.alloc(BINS + 1)) { cdm_set_error("slot key sort: out of device memory"); return CDM_ERR_HIP; }
+    hipMemsetAsync(ticket.p, 0, 16, s);
+    if (headHist) {
+        hipMemcpyAsync(hist.p, headHist, BINS * 8, hipMemcpyDeviceToDevice, s);
+        if (const char *e = cdmGetenv("CDM_SLOT_HIST")) if (!strcmp(e, "check")) {      // tests: the writer's counts against a count of the keys
+            DevBuf<unsigned long long> again; unsigned long long a[BINS], b[BINS];
+            if (!again.alloc(BINS)) { cdm_set_error("slot key sort: out of device memory"); return CDM_ERR_HIP; }
+            hipMemsetAsync(again.p, 0, BINS * 8, s);
+            if (n) hipLaunchKernelGGL(k_rx_hist_head<0>, dim3((unsigned) std::min<uint64_t>(tilesHead, (uint64_t) cuCount * 8)), dim3(NT), 0, s, (const uint64_t *) k0, n, shift, headBits, again.p);
+            hipMemcpyAsync(a, hist.p, BINS * 8, hipMemcpyDeviceToHost, s); hipMemcpyAsync(b, again.p, BINS * 8, hipMemcpyDeviceToHost, s);
+            if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("slot key sort (head histogram check) failed"); return CDM_ERR_HIP; }
+            for (int d = 0; d < BINS; d++) if (a[d] != b[d]) { cdm_set_error("slot key sort: head digit %d: the extraction counted %llu tuples, the slots hold %llu", d, a[d], b[d]); return CDM_ERR_HIP; }
+        }
+    } else {
+        hipMemsetAsync(hist.p, 0, BINS * 8, s);
+        if (n) hipLaunchKernelGGL(k_rx_hist_head<0>, dim3((unsigned) std::min<uint64_t>(tilesHead, (uint64_t) cuCount * 8)), dim3(NT), 0, s, (const uint64_t *) k0, n, shift, headBits, hist.p);
+    }
+    hipLaunchKernelGGL(k_rx_seg_layout<0>, dim3(1), dim3(BINS), 0, s, (const unsigned long long *) hist.p, segDev, segTile.p);
+    unsigned int tilesSeg = 0;
+    hipMemcpyAsync(&live, segDev + BINS, 8, hipMemcpyDeviceToHost, s); hipMemcpyAsync(&tilesSeg, segTile.p + BINS, 4, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("slot key sort (head histogram) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    if (live > n) { cdm_set_error("slot key sort: internal error: %llu keys counted in %llu slots", live, (unsigned long long) n); return CDM_ERR_HIP; }
+    if (live == 0) return CDM_OK;
+    if (!status.alloc(std::max<uint64_t>(tilesHead, tilesSeg) * BINS)) { cdm_set_error("slot key sort: out of device memory"); return CDM_ERR_HIP; }
+    hipEvent_t ev[6];
+    if (passMs) for (int i = 0; i < 2 * (1 + segPasses); i++) hipEventCreate(&ev[i]);
+    // ---- the head pass
+    {
+        hipMemsetAsync(status.p, 0, tilesHead * BINS * 8, s);
+        PassArgs<uint64_t, NoValue> pa;
+        pa.kin = k0; pa.kout = k1; pa.vin = nullptr; pa.vout = nullptr; pa.n = n; pa.shift = shift; pa.bits = headBits; pa.digitBase = segDev; pa.status = status.p; pa.ticket = ticket.p;
+        if (passMs) hipEventRecord(ev[0], s);
+        hipLaunchKernelGGL((k_rx_pass<uint64_t, NoValue, PASS_HEAD>), dim3((unsigned) tilesHead), dim3(NT), 0, s, pa);
+        if (passMs) hipEventRecord(ev[1], s);
+    }
+    // ---- the passes inside the segments
+    if (segPasses) {
+        if (!segHist.alloc((size_t) BINS * segPasses * BINS) || !segTables.alloc((size_t) BINS * segPasses * BINS)) { cdm_set_error("slot key sort: out of device memory"); return CDM_ERR_HIP; }
+        hipMemsetAsync(segHist.p, 0, (size_t) BINS * segPasses * BINS * 8, s);
+        SegHistArgs ha; ha.keys = k1; ha.seg = segDev; ha.beginBit = SLOT_KEY_SHIFT + lowBits; ha.endBit = SLOT_KEY_SHIFT + shift; ha.passes = segPasses; ha.hist = segHist.p;
+        hipLaunchKernelGGL(k_rx_hist_seg<0>, dim3((unsigned) std::min<uint64_t>((live + TILE - 1) / TILE, (uint64_t) cuCount * 8)), dim3(NT), 0, s, ha);
+        hipLaunchKernelGGL(k_rx_offsets_seg<0>, dim3(BINS * segPasses), dim3(BINS), 0, s, segHist.p, segPasses, (const unsigned long long *) segDev);
+        hipLaunchKernelGGL(k_rx_seg_tables<0>, dim3(BINS * segPasses), dim3(BINS), 0, s, (const unsigned long long *) segHist.p, segPasses, segTables.p);
+        uint64_t *in = k1, *out = k0;
+        for (int p = 0; p < segPasses; p++) {
+            hipMemsetAsync(status.p, 0, (size_t) tilesSeg * BINS * 8, s);
+            PassArgs<uint64_t, NoValue> pa;
+            pa.kin = in; pa.kout = out; pa.vin = nullptr; pa.vout = nullptr; pa.n = live;
+            pa.shift = SLOT_KEY_SHIFT + lowBits + p * BITS; pa.bits = std::min(BITS, SLOT_KEY_SHIFT + shift - pa.shift);
+            pa.digitBase = segTables.p + (size_t) p * BINS * BINS; pa.status = status.p; pa.ticket = ticket.p + 1 + p; pa.seg = segDev; pa.segTile = segTile.p;
+            if (passMs) hipEventRecord(ev[2 + 2 * p], s);
+            hipLaunchKernelGGL((k_rx_pass<uint64_t, NoValue, PASS_SEG>), dim3(tilesSeg), dim3(NT), 0, s, pa);
+            if (passMs) hipEventRecord(ev[3 + 2 * p], s);
+            std::swap(in, out);
+        }
+        result = in;
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    if (passMs) {
+        *passMs = 0.f;
+        for (int p = 0; p < 1 + segPasses; p++) { float ms = 0.f; if (e == hipSuccess) hipEventElapsedTime(&ms, ev[2 * p], ev[2 * p + 1]); *passMs += ms; }
+        for (int i = 0; i < 2 * (1 + segPasses); i++) hipEventDestroy(ev[i]);
+        if (launches) *launches = (float) (1 + segPasses);
+    }
+    if (e != hipSuccess) { cdm_set_error("slot key sort failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    return CDM_OK;
 }
 
 }  // namespace rx

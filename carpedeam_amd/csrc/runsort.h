@@ -45,6 +45,8 @@ struct RunArgs {
     const uint64_t *keys;       // group keys in k-mer order, ~0 = dropped / unused slot
     uint64_t n;                 // slots
     uint64_t skipLo, skipHi;    // [skipLo, skipHi) holds only unused slots (the tail of region 1): not read
+    uint64_t base = 0;          // added to a record's start: `keys` is a part of the array the records index (round 5: region 2 alone, behind the
+                                // records the grouping kernel staged for region 1)
     int repShift;               // narrow: rep = key >> repShift
     int wide = 0, idShift = 0; uint64_t idMask = 0;        // wide: id = (key >> idShift) & idMask
 };
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(RUN_NT) void k_run_write(RunArgs a, const unsigned 
             if (m) { e = w * 64 + __ffsll(m) - 1; break; }
         }
         recRep[rank] = sKeys[runPad(li)];
-        recVal[rank] = ((base + (uint64_t) li) << RUN_CNT_BITS) | (uint64_t) (e - li);
+        recVal[rank] = ((a.base + base + (uint64_t) li) << RUN_CNT_BITS) | (uint64_t) (e - li);
         rank++;
     }
 }
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(RUN_NT) void k_run_records(RunArgs a, RunScan sc, u
             if (m) { e = w * 64 + __ffsll(m) - 1; break; }
         }
         recRep[rank] = sKeys[runPad(li)];
-        recVal[rank] = ((base + (uint64_t) li) << RUN_CNT_BITS) | (uint64_t) (e - li);
+        recVal[rank] = ((a.base + base + (uint64_t) li) << RUN_CNT_BITS) | (uint64_t) (e - li);
         rank++;
     }
 }
