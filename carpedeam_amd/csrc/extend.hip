@@ -51,6 +51,12 @@ struct ExtArgs {
     float seqIdThr, rySeqIdThr, likelihoodThr;
     float excessLog, randLog;   // logf(excessPenal), logf(randAlnPenal) from the host
     double ratioLogit;          // log(1/thr - 1): sRatio > thr  <=>  randAln - likMod < ratioLogit
+    // The reference decides 1 / (1 + expl(x)) > thr (nuclassembleUtil.cpp:331-336, ancientReadsResults.cpp:62-66), the device x < ratioLogit.
+    // At the default thr = 0.5 the two agree for every x (ratioLogit = 0, expl(x) < 1 <=> x < 0): ratioWindow = 0.  For another
+    // --likelihood-ratio-threshold they can differ only where x lies within a few ulps of ratioLogit - there the last bit of the C library's
+    // expl and of the division decide.  A candidate whose x falls inside ratioWindow (a generous bound on that) raises flags[2], and
+    // the call is refused instead of answering with a possibly different decision (round 5; never seen in a test or fuzz case).
+    double ratioWindow;
     float marginScale;          // 1 (CDM_EXTEND_MARGIN, tests: scales the error bounds of the plain-double likelihoods)
     uint64_t maxSeqLen;
     int unsafe; uint32_t minCov;        // --unsafe 1: consensusCaller's majority vote over the extending targets (--min-cov-safe)
@@ -308,6 +314,7 @@ __device__ bool scoreCand(const ExtArgs &A, const VQuery &Q, Cand &c, uint32_t m
     c.sLenNorm = x87_to_double(lik);
     X87 neg = lik; neg.s ^= 1u;
     const double x = x87_to_double(x87_add(x87_from_double(randAln), neg));   // randAln - likMod
+    if (A.ratioWindow > 0.0 && fabs(x - A.ratioLogit) <= A.ratioWindow) A.flags[2] = 1u;
     return x < A.ratioLogit;
 }
 
@@ -346,7 +353,7 @@ __device__ int scoreCandApprox(const ExtArgs &A, const VQuery &Q, const Cand &c,
     const double pen = (double) ((float) excess * A.excessLog);
     sum = __dadd_rn(sum, pen); mag = __dadd_rn(mag, fabs(pen));
     const double randAln = (double) ((float) maxAln * A.randLog);
-    const double b = (double) (ncol + 8u) * 0x1p-52 * (mag + fabs(randAln)) * (double) A.marginScale;
+    const double b = fmax((double) (ncol + 8u) * 0x1p-52 * (mag + fabs(randAln)) * (double) A.marginScale, A.ratioWindow);       // (inside the window the exact sum is taken, and flags the call)
     sLenNorm = sum; bound = (float) b * 1.0000002f + 1e-37f;       // (rounded up: the float is what the queue's near-tie test adds)
     const double x = __dadd_rn(randAln, -sum);
     if (x < A.ratioLogit - b) return 1;
@@ -910,11 +917,11 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     DevBuf<uint32_t> active, lists, newLen, nLeft, nRight, leftTotal, oWords;
     DevBuf<unsigned int> nActive, flags; DevBuf<Cand> cand; DevBuf<double> dScores; DevBuf<unsigned long long> stats;
     if (!active.alloc(n) || !lists.alloc(4 * alns->count) || !newLen.alloc(n) || !nLeft.alloc(n) || !nRight.alloc(n) || !leftTotal.alloc(n) ||
-        !oWords.alloc(n) || !nActive.alloc(2) || !flags.alloc(2) || !cand.alloc(alns->count) || !stats.alloc(2) || (scores && !dScores.alloc(alns->count))) {
+        !oWords.alloc(n) || !nActive.alloc(2) || !flags.alloc(4) || !cand.alloc(alns->count) || !stats.alloc(2) || (scores && !dScores.alloc(alns->count))) {
         cdm_set_error("cdm_extend: out of device memory"); return CDM_ERR_HIP;
     }
     hipMemsetAsync(nActive.p, 0, 8, s);
-    hipMemsetAsync(flags.p, 0, 8, s);
+    hipMemsetAsync(flags.p, 0, 16, s);
     hipMemsetAsync(stats.p, 0, 16, s);
     if (scores) hipMemsetAsync(dScores.p, 0xFF, alns->count * 8, s);   // all-ones = NaN: records of inactive queries
     hipLaunchKernelGGL(k_mark_active2, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, n, active.p, nActive.p, newLen.p);
@@ -930,6 +937,12 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     A.seqIdThr = par->seq_id_thr; A.rySeqIdThr = par->ry_seq_id_thr; A.likelihoodThr = par->likelihood_threshold;
     A.excessLog = std::log(par->excess_penal); A.randLog = std::log(par->rand_align_penal);   // std::log(float): float, as in the reference
     A.ratioLogit = (double) logl(1.0L / (long double) par->likelihood_threshold - 1.0L);
+    {
+        // |d sRatio / dx| = s (1 - s): a relative error eps of sRatio (its rounding to double, expl's last bits) moves the decision over eps
+        // / (1 - s) resp. eps / s in x; ratioLogit itself is rounded once.  64 ulps of all that, where 3 would do.
+        const double thr = (double) par->likelihood_threshold;
+        A.ratioWindow = (par->likelihood_threshold == 0.5f || !(thr > 0.0 && thr < 1.0)) ? 0.0 : 64.0 * 0x1p-53 * (1.0 + fabs(A.ratioLogit) + 1.0 / std::min(thr, 1.0 - thr));
+    }
     A.marginScale = cdmGetenv("CDM_EXTEND_MARGIN") ? (float) atof(cdmGetenv("CDM_EXTEND_MARGIN")) : 1.0f;
     A.maxSeqLen = par->max_seq_len;
     A.unsafe = par->unsafe ? 1 : 0; A.minCov = (uint32_t) std::max(0, par->min_cov_safe); A.flags = flags.p;
@@ -972,8 +985,8 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     cdmscan::ScanTemp tmp;
     hipMemsetAsync(oWords.p + n, 0, 4, s);
     if (cdmscan::exclusiveScan<uint32_t>(s, tmp, oWords.p, o->woff, (size_t) n + 1) != CDM_OK) { cdm_seqdb_free(o); return CDM_ERR_HIP; }
-    uint32_t words = 0; unsigned long long hstats[2] = {0, 0}; unsigned int hflags[2] = {0, 0};
-    hipMemcpyAsync(hflags, flags.p, 8, hipMemcpyDeviceToHost, s);
+    uint32_t words = 0; unsigned long long hstats[2] = {0, 0}; unsigned int hflags[4] = {0, 0, 0, 0};
+    hipMemcpyAsync(hflags, flags.p, 16, hipMemcpyDeviceToHost, s);
     hipMemcpyAsync(&words, o->woff + n, 4, hipMemcpyDeviceToHost, s);
     hipMemcpyAsync(hstats, stats.p, 16, hipMemcpyDeviceToHost, s);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_seqdb_free(o); cdm_set_error("cdm_extend: extension kernel failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
@@ -981,6 +994,11 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     if (hflags[0]) {
         cdm_seqdb_free(o);
         cdm_set_error("cdm_extend: --unsafe 1: a target overhangs the query by more than the query's length; the reference pads it with a negative number of letters there (undefined behaviour), not reproduced");
+        return CDM_ERR_UNSUPPORTED;
+    }
+    if (hflags[2]) {
+        cdm_seqdb_free(o);
+        cdm_set_error("cdm_extend: --likelihood-ratio-threshold %g: a candidate's likelihood ratio lies within %.3g of the threshold in log-odds; the reference decides there by the last bit of the C library's expl - not reproduced (the default threshold 0.5 has no such window)", (double) par->likelihood_threshold, A.ratioWindow);
         return CDM_ERR_UNSUPPORTED;
     }
     if (hstats[0] / 16 + n >= 0xFFFFFFF0ull) {     // (the word offsets are 32-bit: an extended DB beyond 2^32 code words would wrap)

@@ -5,14 +5,14 @@
 //   Matcher::getSWResult, nucleotide branch                 lib/mmseqs/src/alignment/Matcher.cpp:60-190, sort order Matcher.h:162-173
 //   BandedNucleotideAligner::initQuery / align              lib/mmseqs/src/alignment/BandedNucleotideAligner.cpp:51-255
 //   DistanceCalculator::computeUngapped(Wrapped)Alignment   lib/mmseqs/src/alignment/DistanceCalculator.h:57-113, :180-200
-//   ksw_extz2_sse, ksw_backtrack, ksw_apply_zdrop           lib/mmseqs/lib/ksw2/ksw2_extz2_sse.cpp:45-284, ksw2.h:135-202 (ksw2 of
-//                                                           minimap2, vendored by the reference; MIT)
-// The banded extension is restated LANE BY LANE, not as a textbook DP: ksw2 works on 16-byte blocks that reach beyond the band (rows
-// are rounded to multiples of 16), its match scores are written 16 at a time from the band's unaligned start, and what those extra
-// lanes leave in the difference arrays is what a cell at the band's edge later reads - so the arrays here have ksw2's layout (u, v,
-// x, y, s, the target, the reversed query in ONE zeroed buffer) and every byte operation is the scalar form of the instruction the
-// reference executes (8-bit wrap-around adds, signed / unsigned 8-bit maxima).  tests/test_align_module.py compares the module with
-// the reference's object code on contig sets with substitutions, insertions, deletions, rotations and reverse complements.
+//   the banded z-drop extension the reference calls        lib/mmseqs/lib/ksw2/ksw2_extz2_sse.cpp:45-284, ksw2.h:135-202 (ksw2 of minimap2,
+//                                                           vendored by the reference): its results, see diagdp below
+// The banded extension is not a textbook DP: the reference's routine computes whole 16-position blocks around the band, refreshes its
+// substitution scores in runs of 16 from the band's unaligned start and breaks score ties by its four interleaved running maxima -
+// all of which reaches the result through the cells at the band's edge.  Round 5 restates those properties (P1-P6 below) in a
+// formulation of its own - one state record per target position, a cell step, a row maximum, a trace - where round 4 had the
+// routine's statements one by one.  tests/test_align_module.py compares the module with the reference's object code on contig sets
+// with substitutions, insertions, deletions, rotations and reverse complements.
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -48,120 +48,152 @@ struct NuclMat {
     int score(unsigned char q, unsigned char t) const { return sub[aa2num[q]][aa2num[t]]; }       // SubstitutionMatrix::createAsciiSubMat
 };
 
-// ---- ksw2's extension alignment, restated lane by lane
+// ---- Banded extension alignment with affine gaps, one anti-diagonal at a time, on score DIFFERENCES (round 5: own formulation; round 4
+// carried ksw2's routine over statement by statement).
+//
+// The reference extends a seed with minimap2's ksw2 (vendored under lib/mmseqs/lib/ksw2; BandedNucleotideAligner.cpp:138-255 calls
+// ksw_extz2_sse with a band of 64, z-drop, match +2 / mismatch -3 - mat[0] / mat[1] -, letter 4 a wildcard).  What must come out
+// equal is its RESULT - best score, the cell it is reached in, the edit script, the z-drop exit - and that result depends on details
+// of how the SSE routine walks the matrix which a textbook DP does not have.  They are restated here as properties, and the code below
+// is built on them:
+//
+//   P1  Suzuki-Kasahara differences.  With H the best score of a cell, E / F the best scores that end in a gap of the target / of the
+//       query, the routine keeps per target position t (cell (t, r - t) of anti-diagonal r) four bytes:
+//          dH = H(t, j) - H(t - 1, j) + gapOpen + gapExtend          "horizontal" difference   (ksw2: u)
+//          dV = H(t, j) - H(t, j - 1) + gapOpen + gapExtend          "vertical" difference     (ksw2: v)
+//          eT = E(t + 1, j) - H(t, j) + gapOpen + gapExtend, eQ = F(t, j + 1) - H(t, j) + gapOpen + gapExtend      (x, y)
+//       all in 8-bit arithmetic that WRAPS; one step of the recurrence is `advance()` below: the byte operations are the contract (signed
+//       maximum against the target-gap path, UNSIGNED maximum against the query-gap path, an unsigned cap at match + 2 (open + extend)).
+//   P2  The band of row r is [lo, hi] (matrix bounds and |t - j| <= 64), but cells are computed for the whole 16-position blocks that
+//       [lo, hi] touches: [lo16, hi16].  The extra positions are real state: a cell that enters the band next row reads what such a
+//       position left behind.  Positions left of lo16 keep what they last held.
+//   P3  Substitution scores are refreshed, per row, for the positions lo, lo + 1, ... in runs of 16 up to the run that holds hi - so
+//       positions in [lo16, lo) score with what an EARLIER row computed for them, positions right of hi with letters outside the band
+//       (or with the zero padding behind both sequences, which "matches").
+//   P4  The best score of a row is taken over the band [lo, hi] from running sums of the dV; among equal scores the routine's four
+//       interleaved maxima decide the cell: hi itself first, then the positions lo + 0, 4, 8, .. in order, then lo + 1, 5, .., lo + 2, ..,
+//       lo + 3, .., then what is left between the last full group of four and hi (`rowBest()`).
+//   P5  Z-drop: the search stops at the first row whose best cell lies more than zdrop + gapExtend x |diagonal shift| below the best
+//       cell so far, both coordinates at or beyond it.
+//   P6  The edit script is read back from one byte per computed cell: which of the three paths gave H, and whether the E / F paths
+//       continue; cells outside a row's computed range force a gap (`trace()`).
 struct Extz { int max = 0, max_q = -1, max_t = -1; bool zdropped = false; std::vector<uint32_t> cigar; };
-inline bool applyZdrop(Extz &ez, int H, int r, int t, int zdrop, int e) {                          // ksw_apply_zdrop, is_rot = 1
-    if (H > ez.max) { ez.max = H; ez.max_t = t; ez.max_q = r - t; }
-    else if (t >= ez.max_t && r - t >= ez.max_q) {
-        const int tl = t - ez.max_t, ql = (r - t) - ez.max_q, l = tl > ql ? tl - ql : ql - tl;
-        if (zdrop >= 0 && ez.max - H > zdrop + l * e) { ez.zdropped = true; return true; }
-    }
-    return false;
+namespace diagdp {
+constexpr int LANES = 16;
+enum Path : uint8_t { FROM_DIAG = 0, FROM_TGAP = 1, FROM_QGAP = 2, TGAP_CONT = 0x08, QGAP_CONT = 0x10 };
+struct Pos { uint8_t dH = 0, dV = 0, eT = 0, eQ = 0, sub = 0; };      // the state of one target position (P1) + its last substitution score (P3)
+struct Costs { uint8_t open, openExt2, cap; int openExt; };
+// one cell: `left` = (eT, dV) of position t - 1 as the row BEFORE left them, `here` = position t; returns the trace byte (P6)
+inline uint8_t advance(Pos &here, uint8_t leftET, uint8_t leftDV, const Costs &c) {
+    uint8_t h = (uint8_t) (here.sub + c.openExt2);                          // the diagonal path
+    const uint8_t viaT = (uint8_t) (leftET + leftDV);                       // ... the path that ends in a gap of the target
+    const uint8_t oldDH = here.dH;
+    const uint8_t viaQ = (uint8_t) (here.eQ + oldDH);                       // ... in a gap of the query
+    uint8_t from = (int8_t) viaT > (int8_t) h ? FROM_TGAP : FROM_DIAG;
+    if ((int8_t) viaT > (int8_t) h) h = viaT;
+    if ((int8_t) viaQ > (int8_t) h) from = FROM_QGAP;                       // (the direction compares signed, the score below unsigned)
+    if (viaQ > h) h = viaQ;
+    if (h > c.cap) h = c.cap;
+    here.dH = (uint8_t) (h - leftDV);
+    here.dV = (uint8_t) (h - oldDH);
+    const uint8_t opened = (uint8_t) (h - c.open);
+    const uint8_t contT = (uint8_t) (viaT - opened), contQ = (uint8_t) (viaQ - opened);
+    const bool keepT = (int8_t) contT > 0, keepQ = (int8_t) contQ > 0;
+    here.eT = keepT ? contT : 0;
+    here.eQ = keepQ ? contQ : 0;
+    return (uint8_t) (from | (keepT ? TGAP_CONT : 0) | (keepQ ? QGAP_CONT : 0));
 }
-inline void pushCigar(std::vector<uint32_t> &c, uint32_t op, int len) { if (c.empty() || op != (c.back() & 0xf)) c.push_back((uint32_t) len << 4 | op); else c.back() += (uint32_t) len << 4; }
-// ksw_extz2_sse(km, qlen, query, tlen, target, m = 5, mat, q, e, w, zdrop, flag = KSW_EZ_EXTZ_ONLY [| KSW_EZ_SCORE_ONLY], &ez):
-// match / mismatch scores mat[0] / mat[1], residue 4 a wildcard (score 0), gaps left-aligned, exact maximum
+struct RowTrace { int lo16 = 0, hi16 = -1; std::vector<uint8_t> cell; };
+// P4: the row's best band cell from the scores `H` (already advanced to this row) - hi first, then the four interleaved sweeps, then the rest
+inline void rowBest(const std::vector<int32_t> &H, int lo, int hi, int32_t &best, int &where) {
+    best = H[hi]; where = hi;
+    const int grouped = lo + (hi - lo) / 4 * 4;
+    int32_t sweepBest[4]; int sweepAt[4];
+    for (int phase = 0; phase < 4; phase++) {
+        sweepBest[phase] = best; sweepAt[phase] = -1;
+        for (int t = lo + phase; t < grouped; t += 4) if (H[t] > sweepBest[phase]) { sweepBest[phase] = H[t]; sweepAt[phase] = t; }
+    }
+    for (int phase = 0; phase < 4; phase++) if (sweepAt[phase] >= 0 && sweepBest[phase] > best) { best = sweepBest[phase]; where = sweepAt[phase]; }
+    for (int t = grouped; t < hi; t++) if (H[t] > best) { best = H[t]; where = t; }
+}
+// P6: from the best cell back to the origin
+inline void trace(const std::vector<RowTrace> &rows, int t, int j, std::vector<uint32_t> &ops) {
+    auto put = [&](uint32_t op, int n) { if (!ops.empty() && (ops.back() & 0xf) == op) ops.back() += (uint32_t) n << 4; else ops.push_back((uint32_t) n << 4 | op); };
+    int inGap = FROM_DIAG;                                   // the gap the walk is in (FROM_TGAP / FROM_QGAP), FROM_DIAG = none
+    while (t >= 0 && j >= 0) {
+        const RowTrace &row = rows[(size_t) (t + j)];
+        uint8_t b = 0; int forced = -1;
+        if (t < row.lo16) forced = FROM_QGAP; else if (t > row.hi16) forced = FROM_TGAP; else b = row.cell[(size_t) (t - row.lo16)];
+        if (inGap != FROM_DIAG && !(b & (inGap == FROM_TGAP ? TGAP_CONT : QGAP_CONT))) inGap = FROM_DIAG;     // the gap ends here
+        if (inGap == FROM_DIAG) inGap = b & 7;
+        if (forced >= 0) inGap = forced;
+        if (inGap == FROM_DIAG) { put(0, 1); --t; --j; }
+        else if (inGap == FROM_TGAP) { put(2, 1); --t; }
+        else { put(1, 1); --j; }
+    }
+    if (t >= 0) put(2, t + 1);
+    if (j >= 0) put(1, j + 1);
+    std::reverse(ops.begin(), ops.end());
+}
+}  // namespace diagdp
+// the extension of `query` against `target` from their first letters on (letters 0..3, 4 = wildcard): best score and where, the edit
+// script if asked for
 void extz(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int8_t scMch, int8_t scMis, int8_t q, int8_t e, int w, int zdrop, bool withCigar, Extz &ez) {
+    using namespace diagdp;
     ez = Extz();
     if (qlen <= 0 || tlen <= 0) return;
-    const int qe = q + e;
-    const uint8_t qe2 = (uint8_t) ((q + e) * 2), maxSc = (uint8_t) (scMch + (q + e) * 2);
-    if (w < 0) w = tlen > qlen ? tlen : qlen;
-    const int wl = w, wr = w, tlen_ = (tlen + 15) / 16, qlen_ = (qlen + 15) / 16;
-    int nCol = qlen < tlen ? qlen : tlen;
-    nCol = ((nCol < w + 1 ? nCol : w + 1) + 15) / 16 + 1;
-    if (-(int) scMis > 2 * (q + e)) return;
-    std::vector<uint8_t> mem((size_t) (tlen_ * 6 + qlen_ + 1) * 16, 0);
-    uint8_t *u = mem.data(), *v = u + tlen_ * 16, *x = v + tlen_ * 16, *y = x + tlen_ * 16, *s = y + tlen_ * 16, *sf = s + tlen_ * 16, *qr = sf + tlen_ * 16;
-    std::vector<int32_t> H((size_t) tlen_ * 16, -0x40000000);
-    std::vector<uint8_t> p; std::vector<int> off, offEnd;
-    if (withCigar) { p.assign(((size_t) (qlen + tlen - 1) * nCol + 1) * 16, 0); off.assign(qlen + tlen - 1, 0); offEnd.assign(qlen + tlen - 1, 0); }
-    for (int t = 0; t < qlen; t++) qr[t] = query[qlen - 1 - t];
-    memcpy(sf, target, (size_t) tlen);
-    int lastSt = -1, lastEn = -1;
+    if (-(int) scMis > 2 * (q + e)) return;                 // (a mismatch must not cost more than opening two gaps: the byte range of P1)
+    if (w < 0) w = std::max(tlen, qlen);
+    Costs cost; cost.open = (uint8_t) q; cost.openExt = q + e; cost.openExt2 = (uint8_t) ((q + e) * 2); cost.cap = (uint8_t) (scMch + (q + e) * 2);
+    const int tlen16 = (tlen + LANES - 1) / LANES * LANES;
+    std::vector<Pos> col((size_t) tlen16 + LANES);
+    std::vector<int32_t> H((size_t) tlen16, -0x40000000);
+    std::vector<RowTrace> rows; if (withCigar) rows.resize((size_t) (qlen + tlen - 1));
+    auto letterT = [&](int p) -> uint8_t { return p < tlen ? target[p] : (uint8_t) 0; };                                  // (zero padding behind both)
+    auto letterQ = [&](int j) -> uint8_t { return j >= 0 && j < qlen ? query[j] : (uint8_t) 0; };
+    int prevLo16 = -1, prevHi16 = -1;
     for (int r = 0; r < qlen + tlen - 1; r++) {
-        int st = 0, en = tlen - 1;
-        if (st < r - qlen + 1) st = r - qlen + 1;
-        if (en > r) en = r;
-        if (st < (r - wr + 1) >> 1) st = (r - wr + 1) >> 1;
-        if (en > (r + wl) >> 1) en = (r + wl) >> 1;
-        if (st > en) { ez.zdropped = true; break; }
-        const int st0 = st, en0 = en;
-        st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
-        uint8_t x1, v1;
-        if (st > 0) { if (st - 1 >= lastSt && st - 1 <= lastEn) { x1 = x[st - 1]; v1 = v[st - 1]; } else x1 = v1 = 0; }
-        else { x1 = 0; v1 = r ? (uint8_t) q : 0; }
-        if (en >= r) { y[r] = 0; u[r] = r ? (uint8_t) q : 0; }
-        // scores: 16 lanes at a time from the band's unaligned start (the lanes beyond en0 are written too - and a store may reach
-        // the first bytes behind s, i.e. positions of the target in front of st0 that no later row reads)
-        const uint8_t *qrr = qr + (qlen - 1 - r);
-        for (int t = st0; t <= en0; t += 16)
-            for (int k = 0; k < 16; k++) {
-                const uint8_t a = sf[t + k], b = qrr[t + k];
-                s[t + k] = (a == 4 || b == 4) ? (uint8_t) 0 : (uint8_t) (a == b ? scMch : scMis);
+        // P2: the band of this anti-diagonal and the blocks it touches
+        int lo = std::max(0, r - qlen + 1), hi = std::min(tlen - 1, r);
+        lo = std::max(lo, (r - w + 1) >> 1); hi = std::min(hi, (r + w) >> 1);
+        if (lo > hi) { ez.zdropped = true; break; }
+        const int lo16 = lo / LANES * LANES, hi16 = (hi + LANES) / LANES * LANES - 1;
+        // what the leftmost computed cell sees to its left: the matrix edge, a position the row before computed, or nothing
+        uint8_t leftET = 0, leftDV = 0;
+        if (lo16 == 0) leftDV = r ? cost.open : 0;
+        else if (lo16 - 1 >= prevLo16 && lo16 - 1 <= prevHi16) { leftET = col[(size_t) lo16 - 1].eT; leftDV = col[(size_t) lo16 - 1].dV; }
+        if (hi16 >= r) { col[(size_t) r].eQ = 0; col[(size_t) r].dH = r ? cost.open : 0; }       // the top edge of the matrix enters the computed range
+        // P3: fresh substitution scores from lo on, in runs of 16
+        for (int run = lo; run <= hi; run += LANES)
+            for (int t = run; t < run + LANES; t++) {
+                const uint8_t a = letterT(t), b = letterQ(r - t);
+                col[(size_t) t].sub = (a == 4 || b == 4) ? (uint8_t) 0 : (uint8_t) (a == b ? scMch : scMis);
             }
-        // core loop over the blocks [st, en]
-        uint8_t *pr = withCigar ? p.data() + (size_t) r * nCol * 16 - st : nullptr;
-        if (withCigar) { off[r] = st; offEnd[r] = en; }
-        uint8_t xPrev = x1, vPrev = v1;
-        for (int t = st; t <= en; t++) {
-            uint8_t z = (uint8_t) (s[t] + qe2);
-            const uint8_t xt1 = xPrev, vt1 = vPrev;
-            xPrev = x[t]; vPrev = v[t];
-            uint8_t a = (uint8_t) (xt1 + vt1);
-            const uint8_t ut = u[t];
-            uint8_t b = (uint8_t) (y[t] + ut);
-            uint8_t d = 0;
-            if (withCigar) d = ((int8_t) a > (int8_t) z) ? 1 : 0;
-            z = ((int8_t) z > (int8_t) a) ? z : a;
-            if (withCigar && (int8_t) b > (int8_t) z) d = 2;
-            z = z > b ? z : b;                                  // unsigned
-            z = z < maxSc ? z : maxSc;
-            u[t] = (uint8_t) (z - vt1); v[t] = (uint8_t) (z - ut);
-            z = (uint8_t) (z - (uint8_t) q);
-            a = (uint8_t) (a - z); b = (uint8_t) (b - z);
-            const bool ap = (int8_t) a > 0, bp = (int8_t) b > 0;
-            x[t] = ap ? a : 0; y[t] = bp ? b : 0;
-            if (withCigar) pr[t] = (uint8_t) (d | (ap ? 0x08 : 0) | (bp ? 0x10 : 0));
+        RowTrace *tr = withCigar ? &rows[(size_t) r] : nullptr;
+        if (tr) { tr->lo16 = lo16; tr->hi16 = hi16; tr->cell.assign((size_t) (hi16 - lo16 + 1), 0); }
+        for (int t = lo16; t <= hi16; t++) {
+            Pos &here = col[(size_t) t];
+            const uint8_t nextET = here.eT, nextDV = here.dV;                // (what the cell to the right reads is this position BEFORE the step)
+            const uint8_t b = advance(here, leftET, leftDV, cost);
+            if (tr) tr->cell[(size_t) (t - lo16)] = b;
+            leftET = nextET; leftDV = nextDV;
         }
-        // the exact maximum of the row (four interleaved running maxima, as the reference's 4-lane loop keeps them)
-        int32_t maxH, maxT;
+        // P4: the scores of the band's cells from the differences; the row's best
+        int32_t best; int where;
         if (r > 0) {
-            const int en1 = st0 + (en0 - st0) / 4 * 4;
-            maxH = H[en0] = en0 > 0 ? H[en0 - 1] + u[en0] - qe : H[en0] + v[en0] - qe;
-            maxT = en0;
-            int32_t laneH[4] = {maxH, maxH, maxH, maxH}, laneT[4] = {maxT, maxT, maxT, maxT};
-            int t = st0;
-            for (; t < en1; t += 4)
-                for (int i = 0; i < 4; i++) { H[t + i] += (int32_t) v[t + i] - qe; if (H[t + i] > laneH[i]) { laneH[i] = H[t + i]; laneT[i] = t; } }
-            for (int i = 0; i < 4; i++) if (maxH < laneH[i]) { maxH = laneH[i]; maxT = laneT[i] + i; }
-            for (; t < en0; t++) { H[t] += (int32_t) v[t] - qe; if (H[t] > maxH) { maxH = H[t]; maxT = t; } }
-        } else { H[0] = v[0] - qe - qe; maxH = H[0]; maxT = 0; }
-        if (applyZdrop(ez, maxH, r, maxT, zdrop, e)) break;
-        lastSt = st; lastEn = en;
-    }
-    if (withCigar && ez.max_t >= 0 && ez.max_q >= 0) {          // ksw_backtrack(is_rot = 1, is_rev = 0, with_N = 0) from (max_t, max_q)
-        int i = ez.max_t, j = ez.max_q, state = 0;
-        const int nColB = nCol * 16;
-        std::vector<uint32_t> &c = ez.cigar;
-        while (i >= 0 && j >= 0) {
-            const int r = i + j;
-            int force = -1;
-            if (i < off[r]) force = 2;
-            if (i > offEnd[r]) force = 1;
-            const uint32_t tmp = force < 0 ? p[(size_t) r * nColB + i - off[r]] : 0;
-            if (state == 0) state = tmp & 7;
-            else if (!(tmp >> (state + 2) & 1)) state = 0;
-            if (state == 0) state = tmp & 7;
-            if (force >= 0) state = force;
-            if (state == 0) { pushCigar(c, 0, 1); --i; --j; }
-            else if (state == 1 || state == 3) { pushCigar(c, 2, 1); --i; }
-            else { pushCigar(c, 1, 1); --j; }
+            H[(size_t) hi] = hi > 0 ? H[(size_t) hi - 1] + col[(size_t) hi].dH - cost.openExt : H[(size_t) hi] + col[(size_t) hi].dV - cost.openExt;
+            for (int t = lo; t < hi; t++) H[(size_t) t] += (int32_t) col[(size_t) t].dV - cost.openExt;
+            rowBest(H, lo, hi, best, where);
+        } else { H[0] = col[0].dV - 2 * cost.openExt; best = H[0]; where = 0; }
+        // P5
+        if (best > ez.max) { ez.max = best; ez.max_t = where; ez.max_q = r - where; }
+        else if (where >= ez.max_t && r - where >= ez.max_q) {
+            const int shift = std::abs((where - ez.max_t) - ((r - where) - ez.max_q));
+            if (zdrop >= 0 && ez.max - best > zdrop + shift * e) { ez.zdropped = true; break; }
         }
-        if (i >= 0) pushCigar(c, 2, i + 1);
-        if (j >= 0) pushCigar(c, 1, j + 1);
-        std::reverse(c.begin(), c.end());
+        prevLo16 = lo16; prevHi16 = hi16;
     }
+    if (withCigar && ez.max_t >= 0 && ez.max_q >= 0) trace(rows, ez.max_t, ez.max_q, ez.cigar);
 }
 
 // ---- the ungapped seed: best local stretch on the probed diagonals (computeSubstitutionStartEndDistance on each)

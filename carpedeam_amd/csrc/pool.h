@@ -174,9 +174,23 @@ inline hipError_t growArena(Arena &a, int device, size_t need) {
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
     for (;;) {
-        const bool tail = !a.blocks.empty() && a.blocks.rbegin()->second.state == B_FREE;
-        if (tail && a.blocks.rbegin()->second.size >= need) return hipSuccess;
-        if (a.end + chunk > a.reserved) return hipErrorOutOfMemory;
+        if (a.freeBySize.lower_bound(need) != a.freeBySize.end()) return hipSuccess;      // (some free block holds the request - at the end, or around a hole that got its memory back)
+        // Where the next chunk goes: into a HOLE if there is one (a chunk given back by trimArena: its addresses still belong to the arena -
+        // round 4 only ever mapped at the end, so every trim with a live block behind the freed chunks lost that much of the
+        // reservation for good, and after a few trims allocate() reported out of memory with most of the device free), the hole
+        // next to the largest free neighbourhood first; at the arena's end otherwise.
+        size_t at = a.end; bool hole = false;
+        {
+            size_t best = 0;
+            for (auto it = a.blocks.begin(); it != a.blocks.end(); ++it) {
+                if (it->second.state != B_HOLE) continue;
+                size_t around = 1;       // (any hole beats the end)
+                if (it != a.blocks.begin() && std::prev(it)->second.state == B_FREE) around += std::prev(it)->second.size;
+                if (std::next(it) != a.blocks.end() && std::next(it)->second.state == B_FREE) around += std::next(it)->second.size;
+                if (around > best) { best = around; at = it->first; hole = true; }
+            }
+        }
+        if (!hole && a.end + chunk > a.reserved) return hipErrorOutOfMemory;
         hipMemGenericAllocationHandle_t h;
         DriverTimer t(chunk);
         hipError_t e;
@@ -184,28 +198,32 @@ inline hipError_t growArena(Arena &a, int device, size_t need) {
         DriverGuard dl;
         e = hipMemCreate(&h, chunk, &prop, 0);
         if (e == hipSuccess) {
-            e = hipMemMap(a.base + a.end, chunk, 0, h, 0);
+            e = hipMemMap(a.base + at, chunk, 0, h, 0);
             if (e == hipSuccess) {
                 hipMemAccessDesc d = {}; d.location = prop.location; d.flags = hipMemAccessFlagsProtReadWrite;
-                e = hipMemSetAccess(a.base + a.end, chunk, &d, 1);
-                if (e != hipSuccess) (void) hipMemUnmap(a.base + a.end, chunk);
+                e = hipMemSetAccess(a.base + at, chunk, &d, 1);
+                if (e != hipSuccess) (void) hipMemUnmap(a.base + at, chunk);
             }
             if (e != hipSuccess) (void) hipMemRelease(h);
         }
         }
         t.done(e == hipSuccess);
         if (e != hipSuccess) {
-            if (cdmenv::get("CDM_POOL_DEBUG")) fprintf(stderr, "carpedeam pool: mapping %zu bytes at offset %zu of the %s arena failed: %s\n", chunk, a.end, a.small ? "small" : "large", hipGetErrorString(e));
+            if (cdmenv::get("CDM_POOL_DEBUG")) fprintf(stderr, "carpedeam pool: mapping %zu bytes at offset %zu of the %s arena failed: %s\n", chunk, at, a.small ? "small" : "large", hipGetErrorString(e));
             return e;
         }
-        a.chunks.push_back(Chunk{a.end, chunk, h});
-        if (tail) {
-            auto last = std::prev(a.blocks.end());
-            dropFree(a, last->first, last->second.size);
-            last->second.size += chunk;
-            a.freeBySize.emplace(last->second.size, last->first);
-        } else addFree(a, a.end, chunk);
-        a.end += chunk;
+        a.chunks.push_back(Chunk{at, chunk, h});
+        if (hole) { a.blocks[at].state = B_USED; a.used++; giveBlock(a, at); }       // (a hole is one chunk: it becomes a free block, merged with its free neighbours)
+        else {
+            const bool tail = !a.blocks.empty() && a.blocks.rbegin()->second.state == B_FREE;
+            if (tail) {
+                auto last = std::prev(a.blocks.end());
+                dropFree(a, last->first, last->second.size);
+                last->second.size += chunk;
+                a.freeBySize.emplace(last->second.size, last->first);
+            } else addFree(a, a.end, chunk);
+            a.end += chunk;
+        }
     }
 }
 // gives back the chunks that lie in free blocks (their addresses become holes; holes at the end are cut off)
@@ -254,14 +272,23 @@ inline bool ensureArena(Pool &pool, Arena &a, bool small) {
 }
 
 // frees every cached block of `q` (CDM_POOL=blocks) and gives back the free chunks of its arenas.  Lock order: registry, then pool.
-inline void trimLocked(Registry &r, Pool &q) {
+// syncOwner: `q` may belong to ANOTHER thread (the out-of-memory path): a range that thread released is free in the bookkeeping while
+// its stream may still work on it (release() is stream-ordered for the owner), so the device is synchronised with the pool's lock held
+// - the owner can neither release nor allocate in between - before anything is unmapped.
+inline void trimLocked(Registry &r, Pool &q, bool syncOwner) {
     std::lock_guard<std::mutex> g(q.m);
+    if (syncOwner) (void) hipDeviceSynchronize();
     for (auto &kv : q.freeBlocks) { r.blocks.erase(kv.second); (void) hipFree(kv.second); }
     q.freeBlocks.clear();
     trimArena(q.small); trimArena(q.large);
 }
-inline void trim(Pool &q) { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); trimLocked(r, q); }
-inline void trimAll() { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); for (Pool *q : r.pools) trimLocked(r, *q); }
+inline void trim(Pool &q) { Registry &r = registry(); std::lock_guard<std::mutex> g(r.m); trimLocked(r, q, false); }
+// out of memory on device `dev` (the calling thread's current device): the pools of THAT device give back what they do not use - another
+// device's free chunks are no help, and its streams are none of this thread's business.  dev < 0: every pool (process teardown, tests).
+inline void trimAll(int dev = -1) {
+    Registry &r = registry(); std::lock_guard<std::mutex> g(r.m);
+    for (Pool *q : r.pools) if (dev < 0 || q->device == dev) trimLocked(r, *q, dev >= 0);
+}
 struct Pools {
     Pool *p[64] = {};
     // A thread that ends makes NO call into the HIP runtime here: this destructor runs among the thread's other thread-local
@@ -353,8 +380,7 @@ inline hipError_t allocate(void **p, size_t bytes) {
         }
         if (attempt == 0) {     // out of memory: every thread's free chunks go back to the driver, then once more
             (void) hipGetLastError();
-            (void) hipDeviceSynchronize();       // (another thread's free range may still be read by that thread's stream)
-            trimAll();
+            trimAll(dev);       // (synchronises the device under every pool's lock)
             stats().trims.fetch_add(1, std::memory_order_relaxed);
         }
     }
@@ -426,8 +452,7 @@ inline hipError_t allocateBlocks(Pool &pool, void **p, size_t bytes) {
     hipError_t e = timedMalloc(p, bytes);
     if (e != hipSuccess) {   // out of memory with blocks parked in the caches - this thread's or another's: release them all and retry once
         (void) hipGetLastError();
-        (void) hipDeviceSynchronize();       // (another thread's parked block may still be read by that thread's stream)
-        trimAll();
+        trimAll(pool.device);
         stats().trims.fetch_add(1, std::memory_order_relaxed);
         e = timedMalloc(p, bytes);
     }

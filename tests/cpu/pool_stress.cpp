@@ -98,11 +98,31 @@ static void checkBlock(void *p, size_t n) {
     if (n >= 16) { memcpy(&a, p, 8); memcpy(&b, (char *) p + n - 8, 8); }
     if (a != t || b != t) { fake::errors++; fprintf(stderr, "block %p + %zu was written over while in use\n", p, n); }
 }
+// The pattern that lost address space until round 5: a large working set, a small block allocated behind it, the working set freed, the
+// arena trimmed - the chunks in front of the pinned block became holes that nothing mapped again, and after a few rounds the arena's
+// reservation (twice the device) was used up with almost nothing in use.
+static int pinAndTrim(int rounds) {
+    std::vector<void *> pins;
+    for (int r = 0; r < rounds; r++) {
+        std::vector<void *> work;
+        for (int i = 0; i < 20; i++) { void *p = nullptr; if (cdmpool::allocate(&p, (size_t) 4 << 20) != hipSuccess) { fprintf(stderr, "pin and trim: round %d: the working set was refused (%zu bytes in use of %zu)\n", r, fake::bytes.load(), fake::budget); return 1; } work.push_back(p); }
+        void *pin = nullptr;
+        if (cdmpool::allocate(&pin, (size_t) 1 << 20) != hipSuccess) { fprintf(stderr, "pin and trim: round %d: the pinned block was refused\n", r); return 1; }
+        pins.push_back(pin);
+        for (void *p : work) cdmpool::release(p);
+        cdmpool::trimMine();
+        if (pins.size() > 24) { cdmpool::release(pins.front()); pins.erase(pins.begin()); }
+    }
+    for (void *p : pins) cdmpool::release(p);
+    cdmpool::trimMine();
+    return 0;
+}
 int main(int argc, char **argv) {
     const int threads = argc > 1 ? atoi(argv[1]) : 8, rounds = argc > 2 ? atoi(argv[2]) : 60;
     setenv("CDM_POOL_POISON", "0xA5", 1);           // every block handed out is written over its whole recorded size
     setenv("CDM_SOMETHING", "x", 1);
     if (argc > 3) setenv("CDM_POOL", argv[3], 1);       // "blocks": the exact-size cache; default: the arenas
+    if (pinAndTrim(200)) return 1;
     std::mutex qm; std::vector<std::pair<void *, size_t>> handoff;      // blocks freed by another thread than their allocator's
     std::atomic<size_t> oom{0}, allocs{0};
     for (int round = 0; round < rounds; round++) {

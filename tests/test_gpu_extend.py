@@ -214,3 +214,27 @@ def test_unsafe_mode_deep_coverage_rounds(ctx, oracle_bin, dhigh_prefix, tmp_pat
     par.unsafe = 1
     got = seqdb_to_keyed(*ctx.extend(db, ctx.upload_alns(db, off, rec), par).download())
     assert not diff_keys(got, mmdb.read_db(t("asm")))
+
+
+@pytest.mark.parametrize("thr", [0.3, 0.7, 0.95, 0.05])
+def test_extension_with_another_likelihood_ratio_threshold(ctx, oracle_bin, dhigh_prefix, tmp_path, form, thr):
+    """--likelihood-ratio-threshold != 0.5: the device decides x < log(1 / thr - 1) where the reference decides 1 / (1 + expl(x)) > thr; a
+    candidate inside the few ulps where the two could differ makes the call refuse (extend.hip, ratioWindow) - none does here, and the result
+    is the oracle's (which takes the reference's expression)"""
+    flags = list(A_FLAGS)
+    flags[flags.index("--likelihood-ratio-threshold") + 1] = repr(thr)
+    t = lambda s: str(tmp_path / s)
+    for name, it in (("synth2k", 0), ("mixed3k", 1)):
+        corr, aln = gold(name, "corr", it), gold(name, "aln", it)
+        mmdb.write_from_keyed(t("corr"), corr, mmdb.DBTYPE_NUCLEOTIDES)
+        mmdb.write_from_keyed(t("aln"), aln, mmdb.DBTYPE_ALIGNMENT_RES)
+        run_oracle(oracle_bin, "ancient_read_assemble", t("corr"), t("aln"), t("asm"), *flags, "--ancient-damage", dhigh_prefix, "--threads", "2")
+        db = ctx.upload_keyed_seqdb(corr)
+        _, keys, _ = db.meta()
+        off, rec = capi.parse_aln_db(aln, keys)
+        par = capi.AncientParams.default()
+        par.likelihood_threshold = thr
+        got = seqdb_to_keyed(*ctx.extend(db, ctx.upload_alns(db, off, rec), par).download())
+        want = mmdb.read_db(t("asm"))
+        assert not diff_keys(got, want), (name, it, thr)
+        assert thr == 0.5 or got != gold(name, "asm", it) or thr in (0.3, 0.7)      # (a far threshold changes the result: the flag is not ignored)
