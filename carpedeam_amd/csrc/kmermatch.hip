@@ -980,7 +980,11 @@ __global__ __launch_bounds__(256) void k_groups(GroupArgs<LY> a, unsigned long l
 // the segment reaches to either side of it, in slots relative to that first slot (clipped to 2^30; one 16-byte load per block: looking
 // the digit up in the segment table is nine dependent loads, which every wave of this latency-bound kernel paid at its start)
 struct BlockHead { int32_t lo, hi; uint32_t td, pad; };
-constexpr int REC_CAP = 32;     // staged run records per wave of the grouping kernel (its 128 owned slots: ~8 k-mer runs at 20x coverage)
+#ifndef CDM_REC_CAP
+#define CDM_REC_CAP 32
+#endif
+constexpr int REC_CAP = CDM_REC_CAP;     // staged run records per wave of the grouping kernel (its owned slots hold ~8 k-mer runs per 128 at 20x coverage)
+static_assert(REC_CAP <= 64, "a wave writes its stage out with one lane per record");
 __global__ void k_block_heads(TupleGeom geom, uint64_t n, uint64_t perBlock, uint64_t blocks, BlockHead *__restrict__ out) {
     const uint64_t b = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= blocks) return;
@@ -1082,10 +1086,19 @@ struct BucketGroupArgs : GroupParams {
 #define CDM_GK_WIN 384
 #define CDM_GK_FIRST 256
 #endif
-constexpr int GK_OWN = CDM_GK_OWN, GK_WIN = CDM_GK_WIN, GK_FIRST = CDM_GK_FIRST, GK_MAXB = GK_WIN - GK_OWN;
-// (the network writes all 64 R slots of ss, R = 1, 2, 4, 8: the largest bucket is one of those sizes)
-static_assert(GK_WIN % 64 == 0 && GK_FIRST % 64 == 0 && GK_FIRST < GK_WIN && GK_OWN <= GK_FIRST && GK_WIN <= (1 << bucket::WV_IDX) &&
-              (GK_MAXB == 64 || GK_MAXB == 128 || GK_MAXB == 256 || GK_MAXB == 512), "grouping kernel geometry");
+// With slot tuples (8 bytes per window slot, no value array) twice the owned range costs the LDS the (key, value) window did: 256 owned
+// slots in a window of 512 take the kernel from 59 to 53 ms at 50 M reads (384 / 640, 512 / 768 and a 768-slot window for buckets of
+// up to 512 all lose: 64-66 ms; profiles/r05_probe_grouping_geometry.txt).
+#ifndef CDM_GKS_OWN
+#define CDM_GKS_OWN 256
+#define CDM_GKS_WIN 512
+#define CDM_GKS_FIRST 384
+#endif
+template <typename LY> struct GkGeom {
+    static constexpr int OWN = LY::bySlot ? CDM_GKS_OWN : CDM_GK_OWN, WIN = LY::bySlot ? CDM_GKS_WIN : CDM_GK_WIN, FIRST = LY::bySlot ? CDM_GKS_FIRST : CDM_GK_FIRST, MAXB = WIN - OWN;
+    // (the network writes all 64 R slots of ss, R = 1, 2, 4, 8: the largest bucket is one of those sizes)
+    static_assert(WIN % 64 == 0 && FIRST % 64 == 0 && FIRST < WIN && OWN <= FIRST && WIN <= (1 << bucket::WV_IDX) && (MAXB == 64 || MAXB == 128 || MAXB == 256 || MAXB == 512), "grouping kernel geometry");
+};
 #ifndef CDM_GK_MINW
 #define CDM_GK_MINW 0      // waves per SIMD the register allocation of the grouping kernel leaves room for (scripts/build_variant.py sweeps it; 0: as many as its LDS lets run - 6 blocks of 4 waves per CU with (key, value) pairs in the window, 7 with slot tuples)
 #endif
@@ -1094,6 +1107,7 @@ template <typename LY, typename W>
 __global__ __launch_bounds__(bucket::BK_NT, gkMinWaves<LY>()) void k_bucket_groups(BucketGroupArgs<LY, W> a) {
     using namespace bucket;
     typedef typename LY::V V;
+    constexpr int GK_WIN = GkGeom<LY>::WIN, GK_FIRST = GkGeom<LY>::FIRST, GK_MAXB = GkGeom<LY>::MAXB;
     __shared__ uint64_t sKeyAll[BK_WAVES][GK_WIN];
     __shared__ V sValAll[BK_WAVES][GK_WIN];
     __shared__ uint32_t sSAll[BK_WAVES][GK_MAXB];
@@ -1993,7 +2007,7 @@ int sortAndGroup() {
         if (lowBits == 0) rc = scanGroups(ga, startIo);
         else {
             int own; uint32_t maxBucket; bucket::capacities(own, maxBucket);
-            own = std::min(own, GK_OWN); maxBucket = std::min<uint32_t>(maxBucket, GK_MAXB);
+            own = std::min(own, GkGeom<LY>::OWN); maxBucket = std::min<uint32_t>(maxBucket, (uint32_t) GkGeom<LY>::MAXB);
             DevBuf<unsigned long long> bigList; DevBuf<unsigned int> bigCnt;
             if (!bigList.alloc(bucket::bigListSlots(kmerSlots, maxBucket)) || !bigCnt.alloc(1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
             hipMemsetAsync(bigCnt.p, 0, 4, s);
