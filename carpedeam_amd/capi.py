@@ -61,7 +61,7 @@ EXPORTS = [
     "cdm_hits_download", "cdm_hits_free", "cdm_rescore", "cdm_alns_upload", "cdm_alns_count", "cdm_alns_download", "cdm_alns_free",
     "cdm_evalue", "cdm_bit_score", "cdm_gapped_evalue", "cdm_correct", "cdm_extend",
     "cdm_kmermatch_part", "cdm_kmermatch_split_begin", "cdm_kpart_outgoing", "cdm_kmermatch_split_finish", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_sort", "cdm_kpart_vote", "cdm_kpart_cont_cap", "cdm_kpart_free", "cdm_dev_copy",
-    "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
+    "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_seqdb_export_packed", "cdm_seqdb_import_packed", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
     "cdm_rescore_hamming", "cdm_pool_headroom", "cdm_pool_stats", "cdm_env_refresh",
     "cdm_comm_unique_id", "cdm_comm_create_rccl", "cdm_comm_create_ops", "cdm_comm_free", "cdm_comm_rank", "cdm_comm_world", "cdm_kmermatch_dist",
     "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist", "cdm_comm_owned", "cdm_kpart_gather_at", "cdm_comm_standin_group", "cdm_comm_create_standin", "cdm_kpart_set_range",

@@ -639,6 +639,50 @@ extern "C" int cdm_seqdb_from_packed_ext(cdm_ctx *ctx, const void *codes, const 
     return CDM_OK;
 }
 
+// The packed form to and from HOST memory (round 5: the binary side-cars a module process leaves next to the DB it wrote, host/sidecar.cpp -
+// the next module of the workflow takes the sequences from there instead of parsing and packing the text again).  nmask16 / raw /
+// rawFlags may be NULL on both sides (export: not wanted; import: the DB has no letter beyond ACGT / no raw plane).
+extern "C" int cdm_seqdb_export_packed(cdm_ctx *ctx, const cdm_seqdb *db, void *codes, void *nmask16, void *lengths, void *keys, void *ext, void *raw, void *rawFlags) {
+    if (!ctx || !db) { cdm_set_error("cdm_seqdb_export_packed: invalid argument"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (codes && db->words) CDM_HIP(hipMemcpyAsync(codes, db->codes, db->words * 4, hipMemcpyDeviceToHost, s));
+    if (nmask16 && db->words) CDM_HIP(hipMemcpyAsync(nmask16, db->nmask, db->words * 2, hipMemcpyDeviceToHost, s));
+    if (lengths && db->n) CDM_HIP(hipMemcpyAsync(lengths, db->len, db->n * 4, hipMemcpyDeviceToHost, s));
+    if (keys && db->n) CDM_HIP(hipMemcpyAsync(keys, db->key, db->n * 4, hipMemcpyDeviceToHost, s));
+    if (ext && db->n) CDM_HIP(hipMemcpyAsync(ext, db->ext, db->n, hipMemcpyDeviceToHost, s));
+    if (raw && db->raw && db->words) CDM_HIP(hipMemcpyAsync(raw, db->raw, db->words * 16, hipMemcpyDeviceToHost, s));
+    if (rawFlags && db->n) CDM_HIP(hipMemcpyAsync(rawFlags, db->hasN, db->n, hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipStreamSynchronize(s));
+    return CDM_OK;
+}
+extern "C" int cdm_seqdb_import_packed(cdm_ctx *ctx, const void *codes, const void *nmask16, const void *lengths, const void *keys, const void *ext, const void *raw,
+                                       const void *rawFlags, uint64_t n, uint64_t words, cdm_seqdb **out) {
+    if (!ctx || !out || (n && (!lengths || !keys)) || (words && !codes)) { cdm_set_error("cdm_seqdb_import_packed: invalid argument"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DevBuf<uint32_t> dCodes, dLen, dKey; DevBuf<uint16_t> dMask; DevBuf<uint8_t> dExt, dRaw, dFlags;
+    if (!dCodes.alloc(words) || !dLen.alloc(n) || !dKey.alloc(n) || !dMask.alloc(words) || !dExt.alloc(n) || (raw && (!dRaw.alloc(words * 16) || !dFlags.alloc(n)))) {
+        cdm_set_error("cdm_seqdb_import_packed: out of device memory"); return CDM_ERR_HIP;
+    }
+    if (words) CDM_HIP(hipMemcpyAsync(dCodes.p, codes, words * 4, hipMemcpyHostToDevice, s));
+    if (n) { CDM_HIP(hipMemcpyAsync(dLen.p, lengths, n * 4, hipMemcpyHostToDevice, s)); CDM_HIP(hipMemcpyAsync(dKey.p, keys, n * 4, hipMemcpyHostToDevice, s)); }
+    if (words) { if (nmask16) CDM_HIP(hipMemcpyAsync(dMask.p, nmask16, words * 2, hipMemcpyHostToDevice, s)); else CDM_HIP(hipMemsetAsync(dMask.p, 0, words * 2, s)); }
+    if (n) { if (ext) CDM_HIP(hipMemcpyAsync(dExt.p, ext, n, hipMemcpyHostToDevice, s)); else CDM_HIP(hipMemsetAsync(dExt.p, 0, n, s)); }
+    if (raw) { if (words) CDM_HIP(hipMemcpyAsync(dRaw.p, raw, words * 16, hipMemcpyHostToDevice, s)); if (n) CDM_HIP(hipMemcpyAsync(dFlags.p, rawFlags, n, hipMemcpyHostToDevice, s)); }
+    CDM_HIP(hipStreamSynchronize(s));
+    cdm_seqdb *o = nullptr;
+    if (int rc = cdm_seqdb_from_packed_ext(ctx, dCodes.p, dMask.p, dLen.p, dKey.p, dExt.p, n, words, &o)) return rc;
+    if (raw) {      // (the export's flags are the DB's own letter flags: bit 1 = the row of the raw plane counts - what attach wants to know)
+        DevBuf<uint8_t> rowCounts;
+        if (!rowCounts.alloc(n)) { cdm_seqdb_free(o); cdm_set_error("cdm_seqdb_import_packed: out of device memory"); return CDM_ERR_HIP; }
+        if (n) hipLaunchKernelGGL(k_raw_flags, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *) dFlags.p, n, rowCounts.p);
+        if (int rc = cdm_seqdb_attach_raw(ctx, o, dRaw.p, rowCounts.p)) { cdm_seqdb_free(o); return rc; }
+    }
+    *out = o;
+    return CDM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ hits / alignments
 // fn(lo, hi) over [0, n) on a few host threads; with `weight` (n + 1 prefix sums) the ranges carry about the same weight each
 #include <thread>

@@ -253,7 +253,7 @@ int result2repseqModule(const std::string &seqPath, const std::string &cluPath, 
 // ---- rmdb / mvdb: DBReader::removeDb / moveDb
 int rmdbModule(const std::string &db) {
     for (const std::string &f : dataFiles(db)) unlink(f.c_str());
-    for (const char *s : {".index", ".dbtype", ".source", ".lookup"}) if (exists(db + s)) unlink((db + s).c_str());
+    for (const char *s : {".index", ".dbtype", ".source", ".lookup", ".cdmbin"}) if (exists(db + s)) unlink((db + s).c_str());      // (.cdmbin: the binary side-car, host/sidecar.h)
     return 0;
 }
 int mvdbModule(const std::string &src, const std::string &dst, std::string *err) {
@@ -261,6 +261,6 @@ int mvdbModule(const std::string &src, const std::string &dst, std::string *err)
     auto mv = [&](const std::string &a, const std::string &b) { if (rename(a.c_str(), b.c_str()) != 0) { *err = "Could not move " + a + " to " + b; return false; } return true; };
     if (files.size() == 1) { if (!mv(files[0], dst)) return 1; }
     else for (const std::string &f : files) if (!mv(f, dst + f.substr(f.rfind('.')))) return 1;
-    for (const char *s : {".index", ".dbtype", ".lookup"}) if (exists(src + s) && !mv(src + s, dst + s)) return 1;
+    for (const char *s : {".index", ".dbtype", ".lookup", ".cdmbin"}) if (exists(src + s) && !mv(src + s, dst + s)) return 1;      // (a rename keeps sizes and times: the side-car's stamp still fits)
     return 0;
 }

@@ -30,6 +30,7 @@
 
 #include "carpedeam_hip.h"
 #include "mmdb.h"
+#include "sidecar.h"
 
 // host/ingest.cpp
 int createdbModule(const std::vector<std::string> &files, const std::string &outPath, bool shuffle, int dbType, std::string *err);
@@ -130,6 +131,18 @@ struct Laps {
         fprintf(stderr, "  %-32s %.3f s\n", what, std::chrono::duration<double>(n - t).count()); t = n;
     }
 };
+// The end of a module whose outputs are written and closed: the process leaves HERE - no release of device buffers (giving tens of GB
+// back to the driver costs seconds, profiles/r05_time_modules_50M_*), no unmapping of the input files, no destructors of the
+// multi-GB host buffers; the operating system and the driver take everything back at once.  (Not under a profiler or sanitizer that
+// writes its results from an exit handler - ROCP_TOOL_LIBRARIES / LD_PRELOAD / CDM_NORMAL_EXIT: then the caller releases and returns.)
+std::chrono::steady_clock::time_point g_t0;
+bool leaveAtOnce() { return !(getenv("ROCP_TOOL_LIBRARIES") || getenv("LD_PRELOAD") || getenv("CDM_NORMAL_EXIT")); }
+void finishModule(int rc) {
+    if (!leaveAtOnce()) return;
+    fprintf(stderr, "Time for processing: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_t0).count());
+    fflush(stdout); fflush(stderr);
+    _exit(rc);
+}
 cdm_ctx *openCtx(int offset = 0) {
     cdm_ctx *ctx = NULL;
     const char *dev = getenv("CARPEDEAM_DEVICE");
@@ -189,17 +202,58 @@ int ttAllGatherDev(void *user, const void *send, uint64_t n, void *recv, const u
 }
 // The device side of a module's start - runtime initialisation and context (0.1-0.2 s), damage tables, sequence upload - in a thread
 // of its own, while the main thread maps and parses the module's text DBs.  Errors are kept and raised by join() on the main thread.
+// ---- binary side-cars (host/sidecar.h)
+// sections of a sequence side-car: keys, lengths, wasExtended flags, letter flags (hasN), code words, [N masks], [raw plane]
+bool importSeqSide(cdm_ctx *ctx, const SideFile &f, cdm_seqdb **out) {
+    const SideHeader &h = *f.h;
+    const bool hasMask = (h.flags & SIDE_F_HAS_NMASK) != 0, hasRaw = (h.flags & SIDE_F_HAS_RAW) != 0;
+    return cdm_seqdb_import_packed(ctx, f.section(4), hasMask ? f.section(5) : NULL, f.section(1), f.section(0), f.section(2), hasRaw ? f.section(6) : NULL,
+                                   hasRaw ? f.section(3) : NULL, h.n, h.count, out) == CDM_OK;
+}
+// the device DB `h` as the side-car of the text DB at `path` (whose files are complete); a failure leaves the text DB on its own
+void exportSeqSide(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) {
+    if (!sideEnabled()) return;
+    const uint64_t n = cdm_seqdb_size(h), words = cdm_seqdb_words(h);
+    if (n == 0) return;
+    HVec<uint32_t> keys(n), lens(n), codes(words + 1); HVec<uint8_t> ext(n), flags(n); HVec<uint16_t> mask(words + 1); HVec<uint8_t> raw;
+    const bool hasRaw = cdm_seqdb_has_raw(h) != 0;
+    if (hasRaw) raw.resize(words * 16 + 1);
+    if (cdm_seqdb_export_packed(ctx, h, codes.data(), mask.data(), lens.data(), keys.data(), ext.data(), hasRaw ? raw.data() : NULL, flags.data()) != CDM_OK) return;
+    bool anyN = false;
+#pragma omp parallel for reduction(|| : anyN) schedule(static)
+    for (size_t i = 0; i < n; i++) anyN = anyN || flags[i] != 0;
+    const SidePiece pc[7] = {{keys.data(), n * 4}, {lens.data(), n * 4}, {ext.data(), n}, {flags.data(), n}, {codes.data(), words * 4}, {mask.data(), anyN ? words * 2 : 0}, {raw.data(), hasRaw ? words * 16 : 0}};
+    sideWrite(path, SIDE_SEQ, (anyN ? SIDE_F_HAS_NMASK : 0) | (hasRaw ? SIDE_F_HAS_RAW : 0), n, words, 0, 0, dbtype, pc, 7);
+}
+// A sequence DB as a module takes it: from its side-car when that matches the files - index columns from the side-car's arrays, no text
+// mapped - else from the text (MmDb::load).
+struct SeqInput {
+    MmDb db; SideFile side; bool fromSide = false;
+    void load(const std::string &path) {
+        if (sideOpen(path, SIDE_SEQ, side)) {
+            const SideHeader &h = *side.h;
+            db.adoptIndex((const uint32_t *) side.section(0), (const uint32_t *) side.section(1), (const uint8_t *) side.section(2), h.n, h.dbtype);
+            fromSide = true;
+            if (getenv("CDM_TIMING")) fprintf(stderr, "  sequence DB %s: from its side-car\n", path.c_str());
+            return;
+        }
+        std::string err; if (!db.load(path, &err)) die(err);
+        if (getenv("CDM_TIMING")) fprintf(stderr, "  sequence DB %s: from the text\n", path.c_str());
+    }
+};
 struct DeviceStart {
     std::thread th; cdm_ctx *ctx = NULL; cdm_seqdb *db = NULL;
     std::string err; int code = 0;
     void fail(int c, const std::string &m) { code = c; err = m; }
-    void begin(const MmDb *seq, const std::string *damagePrefix) {
-        th = std::thread([this, seq, damagePrefix] {
+    void begin(const SeqInput *in, const std::string *damagePrefix) { begin(in ? &in->db : NULL, damagePrefix, in && in->fromSide ? &in->side : NULL); }
+    void begin(const MmDb *seq, const std::string *damagePrefix, const SideFile *side = NULL) {
+        th = std::thread([this, seq, damagePrefix, side] {
             const char *dev = getenv("CARPEDEAM_DEVICE");
             if (cdm_ctx_create(dev ? atoi(dev) : 0, &ctx) != CDM_OK) return fail(EXIT_FAILURE, std::string("Can not initialise the MI355X device: ") + cdm_last_error());
             if (damagePrefix && cdm_damage_load(ctx, damagePrefix->c_str()) != CDM_OK) return fail(EXIT_FAILURE, std::string("Profile not 12 fields: ") + cdm_last_error());
             if (!seq) return;
             if ((seq->dbtype & 0x7FFFFFFF) != 1) return fail(77, "The MI355X path works on nucleotide sequence DBs only (dbtype " + std::to_string(seq->dbtype & 0x7FFFFFFF) + " given)");
+            if (side) { if (!importSeqSide(ctx, *side, &db)) fail(EXIT_FAILURE, std::string("Can not load the sequence DB: ") + cdm_last_error()); return; }
             std::vector<uint32_t> lens(seq->size());
             for (size_t i = 0; i < seq->size(); i++) lens[i] = seq->len[i] >= 2 ? (uint32_t) (seq->len[i] - 2) : 0;   // DBReader::getSeqLen
             if (cdm_seqdb_upload(ctx, seq->data(), seq->off.data(), lens.data(), seq->key.data(), seq->ext.data(), seq->size(), &db) != CDM_OK)
@@ -250,6 +304,8 @@ void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype)
     laps.lap("    (letters unpacked and down)");
     std::string err; if (!mmdbWriteBlob(path, dbtype, buf.data(), buf.size(), keys.data(), offs.data(), elen.data(), ext.data(), n, &err)) die(err);
     laps.lap("    (data + index files written)");
+    exportSeqSide(ctx, h, path, dbtype);
+    laps.lap("    (side-car written)");
 }
 // ---- text codecs
 // decimal text, two digits per division
@@ -435,7 +491,11 @@ void parsePrefDb(const MmDb &pref, const MmDb &seq, HVec<uint64_t> &off, HVec<cd
     if (badEntry >= 0) die("Invalid database read: the entry of key " + std::to_string(badEntry) + " does not end where its index length says");
 }
 // Matcher::resultToBuffer per record, one DB entry per query that has a prefilter entry (rescorediagonal.cpp:145-356)
-void formatAlnDb(const MmDb &seq, const MmDb &pref, const uint64_t *aoff, const cdm_aln *arec, uint64_t dbRes, std::vector<OutChunk> &chunks) {
+// (asParsed, if given: every record as parseAlnDb would read it back from the text written here - raw score recomputed from the bit
+// score, the coordinates, and in `ident` the identity in thousandths as the text truncates it: what writeAlnsSide takes.
+// pref == NULL: every query has a prefilter entry - the hits came from kmermatcher's own side-car.)
+void formatAlnDb(const MmDb &seq, const MmDb *pref, const uint64_t *aoff, const cdm_aln *arec, uint64_t dbRes, std::vector<OutChunk> &chunks, cdm_aln *asParsed = NULL) {
+    const double lam = 0x1.4478764a1b24ap-1, logk = log(0x1.a1c1e68ea2ab1p-2), LN2 = std::log(2.0);
     const int T = std::max(1, omp_get_max_threads());
     chunks.clear(); chunks.resize(T);
     const size_t MAXREC = 10 + 11 + 5 + 14 + 6 * 11 + 10;      // key, bits, seq.id., E-value, six coordinates, separators
@@ -449,7 +509,7 @@ void formatAlnDb(const MmDb &seq, const MmDb &pref, const uint64_t *aoff, const 
         struct EvalText { int qLen = -1, score = -1, bits = 0; unsigned char n = 0; char txt[15]; };
         std::vector<EvalText> cache(1u << 14);
         for (size_t i = lo; i < hi; i++) {
-            if (pref.idOf(seq.key[i]) < 0) continue;
+            if (pref && pref->idOf(seq.key[i]) < 0) continue;
             const int qLen = (int) (seq.len[i] - 2);
             char *const w0 = c.open((aoff[i + 1] - aoff[i]) * MAXREC), *w = w0;
             for (uint64_t r = aoff[i]; r < aoff[i + 1]; r++) {   // Matcher::resultToBuffer (Matcher.cpp:356-404)
@@ -468,6 +528,11 @@ void formatAlnDb(const MmDb &seq, const MmDb &pref, const uint64_t *aoff, const 
                 memcpy(w, ev.txt, ev.n); w += ev.n; *w++ = '\t';
                 w = itoa(x.q_start, w); *w++ = '\t'; w = itoa(x.q_end, w); *w++ = '\t'; w = itoa(qLen, w); *w++ = '\t';
                 w = itoa(x.db_start, w); *w++ = '\t'; w = itoa(x.db_end, w); *w++ = '\t'; w = itoa((int) (seq.len[x.target] - 2), w); *w++ = '\n';
+                if (asParsed) {
+                    cdm_aln p = x;
+                    p.raw_score = static_cast<int>((logk + ev.bits * LN2) / lam + 0.5); p.ident = (int) seqIdTo1000(sid); p.seq_id = seqIdFrom1000((uint32_t) p.ident);
+                    asParsed[r] = p;
+                }
             }
             c.close(seq.key[i], w0, w, 0);
         }
@@ -496,15 +561,108 @@ void formatRescoredPrefDb(const MmDb &seq, const MmDb &pref, const uint64_t *off
     }
 }
 
+// ---- record side-cars: the CSR a consumer's parser would produce from the text, as cdm_hits_upload / cdm_alns_upload take it
+void writeHitsSide(const std::string &path, const MmDb &seq, const uint64_t *off, const cdm_hit *rec, int dbtype) {
+    if (!sideEnabled()) return;
+    const uint64_t n = seq.size(), count = off[n];
+    bool fits = true;
+#pragma omp parallel for reduction(&& : fits) schedule(static)
+    for (uint64_t i = 0; i < count; i++) { cdm_hit h = rec[i]; h.diagonal = (short) h.diagonal; fits = fits && fitsHit8(h); }
+    const uint64_t hash = sideKeyHash(seq.key.data(), n);
+    if (fits) {
+        HVec<SideHit8> c(count);
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < count; i++) { c[i].target = rec[i].target; c[i].score = (int16_t) rec[i].score; c[i].diagonal = (int16_t) (short) rec[i].diagonal; }
+        const SidePiece pc[2] = {{off, (n + 1) * 8}, {c.data(), count * sizeof(SideHit8)}};
+        sideWrite(path, SIDE_HITS, SIDE_F_COMPACT, n, count, n, hash, dbtype, pc, 2);
+    } else {
+        HVec<cdm_hit> c(count);
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < count; i++) { c[i] = rec[i]; c[i].diagonal = (short) rec[i].diagonal; }       // (the text holds the diagonal as a short: QueryMatcher.h:114-126)
+        const SidePiece pc[2] = {{off, (n + 1) * 8}, {c.data(), count * sizeof(cdm_hit)}};
+        sideWrite(path, SIDE_HITS, 0, n, count, n, hash, dbtype, pc, 2);
+    }
+}
+// hits / alignments of the DB at `path` from its side-car if that belongs to these files and to this sequence DB
+bool readHitsSide(const std::string &path, const MmDb &seq, HVec<uint64_t> &off, HVec<cdm_hit> &rec, int *dbtype) {
+    SideFile f;
+    if (!sideOpen(path, SIDE_HITS, f)) return false;
+    const SideHeader &h = *f.h;
+    if (h.n != seq.size() || h.seqN != seq.size() || h.seqKeyHash != sideKeyHash(seq.key.data(), seq.size())) return false;
+    off.resize(h.n + 1); rec.resize(h.count);
+    memcpy(off.data(), f.section(0), (h.n + 1) * 8);
+    if (off[h.n] != h.count) return false;
+    if (h.flags & SIDE_F_COMPACT) {
+        const SideHit8 *c = (const SideHit8 *) f.section(1);
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < h.count; i++) { rec[i].target = c[i].target; rec[i].score = c[i].score; rec[i].diagonal = c[i].diagonal; }
+    } else memcpy(rec.data(), f.section(1), h.count * sizeof(cdm_hit));
+    *dbtype = h.dbtype;
+    return true;
+}
+void writeAlnsSide(const std::string &path, const MmDb &seq, const uint64_t *off, const cdm_aln *asParsed) {
+    if (!sideEnabled()) return;
+    const uint64_t n = seq.size(), count = off[n];
+    bool fits = true;
+#pragma omp parallel for reduction(&& : fits) schedule(static)
+    for (uint64_t i = 0; i < count; i++) {
+        const cdm_aln &r = asParsed[i];
+        auto s16 = [](int v) { return v >= -32768 && v <= 32767; };
+        fits = fits && r.raw_score >= 0 && r.raw_score <= 65535 && s16(r.q_start) && s16(r.q_end) && s16(r.db_start) && s16(r.db_end);
+    }
+    const uint64_t hash = sideKeyHash(seq.key.data(), n);
+    if (fits) {
+        HVec<SideAln16> c(count);
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < count; i++) {
+            const cdm_aln &r = asParsed[i];
+            c[i].target = r.target; c[i].rawScore = (uint16_t) r.raw_score; c[i].seqId1000 = (uint16_t) r.ident;       // (ident carries the identity in thousandths here, see formatAlnDb)
+            c[i].qStart = (int16_t) r.q_start; c[i].qEnd = (int16_t) r.q_end; c[i].dbStart = (int16_t) r.db_start; c[i].dbEnd = (int16_t) r.db_end;
+        }
+        const SidePiece pc[2] = {{off, (n + 1) * 8}, {c.data(), count * sizeof(SideAln16)}};
+        sideWrite(path, SIDE_ALNS, SIDE_F_COMPACT, n, count, n, hash, 5, pc, 2);
+    } else {
+        const SidePiece pc[2] = {{off, (n + 1) * 8}, {asParsed, count * sizeof(cdm_aln)}};
+        sideWrite(path, SIDE_ALNS, 0, n, count, n, hash, 5, pc, 2);
+    }
+}
+bool readAlnsSide(const std::string &path, const MmDb &seq, HVec<uint64_t> &off, HVec<cdm_aln> &rec) {
+    SideFile f;
+    if (!sideOpen(path, SIDE_ALNS, f)) return false;
+    const SideHeader &h = *f.h;
+    if (h.n != seq.size() || h.seqN != seq.size() || h.seqKeyHash != sideKeyHash(seq.key.data(), seq.size())) return false;
+    off.resize(h.n + 1); rec.resize(h.count);
+    memcpy(off.data(), f.section(0), (h.n + 1) * 8);
+    if (off[h.n] != h.count) return false;
+    if (h.flags & SIDE_F_COMPACT) {
+        const SideAln16 *c = (const SideAln16 *) f.section(1);
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < h.count; i++) {
+            cdm_aln r;
+            r.target = c[i].target; r.raw_score = c[i].rawScore; r.ident = -1; r.q_start = c[i].qStart; r.q_end = c[i].qEnd; r.db_start = c[i].dbStart; r.db_end = c[i].dbEnd;
+            r.seq_id = seqIdFrom1000(c[i].seqId1000);
+            rec[i] = r;
+        }
+    } else {
+        const cdm_aln *c = (const cdm_aln *) f.section(1);
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < h.count; i++) { cdm_aln r = c[i]; r.seq_id = seqIdFrom1000((uint32_t) r.ident); r.ident = -1; rec[i] = r; }
+    }
+    return true;
+}
+
 int kmermatcher(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam kmermatcher <i:sequenceDB> <o:prefilterDB>");
     checkFlags("kmermatcher", a, KMERMATCHER_FLAGS);
     Laps laps;
-    DeviceStart dev; dev.begin(NULL, NULL);                 // (the context comes up while the DB is mapped and its index parsed)
-    MmDb seq; std::string err; if (!seq.load(a.pos[0], &err)) die(err);
-    laps.lap("DB files mapped");
+    DeviceStart dev; dev.begin((const MmDb *) NULL, NULL);                 // (the context comes up while the DB is mapped and its index parsed)
+    SeqInput in; in.load(a.pos[0]); MmDb &seq = in.db; std::string err;
+    laps.lap(in.fromSide ? "sequence side-car mapped" : "DB files mapped");
     dev.join(); cdm_ctx *ctx = dev.ctx; laps.lap("device context");
-    cdm_seqdb *db = uploadSeqDb(ctx, seq); laps.lap("sequences up");
+    cdm_seqdb *db = NULL;
+    if (in.fromSide) { if ((seq.dbtype & 0x7FFFFFFF) != 1) unsupported("The MI355X path works on nucleotide sequence DBs only"); if (!importSeqSide(ctx, in.side, &db)) die(std::string("Can not load the sequence DB: ") + cdm_last_error()); }
+    else db = uploadSeqDb(ctx, seq);
+    laps.lap("sequences up");
     cdm_kmer_params p;
     p.kmer_size = (int) iflag(a, "-k", 15); p.kmers_per_seq = (int) iflag(a, "--kmer-per-seq", 21); p.kmers_per_seq_scale = fflag(a, "--kmer-per-seq-scale", 0.2f);
     p.hash_shift = (uint64_t) iflag(a, "--hash-shift", 67); p.ignore_multi_kmer = (int) iflag(a, "--ignore-multi-kmer", 0);
@@ -519,6 +677,10 @@ int kmermatcher(Args &a) {
     laps.lap("prefilter text formatted");
     if (!mmdbWriteChunks(a.pos[1], 14, chunks, &err, true)) die(err);   // DBTYPE_PREFILTER_REV_RES (kmermatcher.cpp:682)
     laps.lap("result DB written");
+    writeHitsSide(a.pos[1], seq, off.data(), rec.data(), 14);
+    if (!in.fromSide) exportSeqSide(ctx, db, a.pos[0], seq.dbtype);       // (the next modules of the workflow read this DB again)
+    laps.lap("side-cars written");
+    finishModule(EXIT_SUCCESS);
     cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
@@ -552,13 +714,18 @@ int rescorediagonal(Args &a) {
     }
     if (!a.flag.count("--rescore-mode")) unsupported("rescorediagonal: --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is implemented with --wrapped-scoring 1 only on the MI355X path)");
     Laps laps;
-    MmDb seq, pref; std::string err; if (!seq.load(a.pos[1], &err)) die(err);
-    DeviceStart dev; dev.begin(&seq, NULL);                 // context + sequence upload while the prefilter text is mapped and parsed
-    if (!pref.load(a.pos[2], &err)) die(err);
-    laps.lap("DB files mapped");
+    SeqInput in; in.load(a.pos[1]); MmDb &seq = in.db; MmDb pref; std::string err;
+    DeviceStart dev; dev.begin(&in, NULL);                  // context + sequence upload while the prefilter records are read
     HVec<uint64_t> off; HVec<cdm_hit> rec;
-    parsePrefDb(pref, seq, off, rec);
-    laps.lap("prefilter text parsed");
+    int prefType = 0;
+    const bool hitsFromSide = readHitsSide(a.pos[2], seq, off, rec, &prefType);
+    if (hitsFromSide) laps.lap("side-cars mapped, prefilter records read");
+    else {
+        if (!pref.load(a.pos[2], &err)) die(err);
+        laps.lap("DB files mapped");
+        parsePrefDb(pref, seq, off, rec);
+        laps.lap("prefilter text parsed");
+    }
     dev.join(); cdm_ctx *ctx = dev.ctx; cdm_seqdb *db = dev.db; laps.lap("(device context, sequences up: waited)");
     cdm_hits *hits = NULL; cdm_alns *alns = NULL;
     check(cdm_hits_upload(ctx, db, off.data(), rec.data(), &hits), "upload");
@@ -570,10 +737,18 @@ int rescorediagonal(Args &a) {
     check(cdm_alns_download(ctx, alns, aoff.data(), arec.data()), "download");
     laps.lap("hits up, kernels, records down");
     std::vector<OutChunk> chunks;
-    formatAlnDb(seq, pref, aoff.data(), arec.data(), cdm_seqdb_residues(db), chunks);
+    HVec<cdm_aln> asParsed; if (sideEnabled()) asParsed.resize(arec.size());
+    formatAlnDb(seq, hitsFromSide ? NULL : &pref, aoff.data(), arec.data(), cdm_seqdb_residues(db), chunks, sideEnabled() ? asParsed.data() : NULL);
     laps.lap("alignment text formatted");
     if (!mmdbWriteChunks(a.pos[3], 5, chunks, &err, true)) die(err);
     laps.lap("result DB written");
+    // (an alignment side-car holds every query: only when every query has a prefilter entry - kmermatcher's output - does the text too)
+    bool allPresent = hitsFromSide;
+    if (!allPresent) { allPresent = true; for (size_t i = 0; i < seq.size() && allPresent; i++) allPresent = pref.idOf(seq.key[i]) >= 0; }
+    if (allPresent) writeAlnsSide(a.pos[3], seq, aoff.data(), asParsed.data());
+    if (!in.fromSide) exportSeqSide(ctx, db, a.pos[1], seq.dbtype);
+    laps.lap("side-cars written");
+    finishModule(EXIT_SUCCESS);
     cdm_alns_free(alns); cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
@@ -585,13 +760,16 @@ int ancientModule(Args &a, int mode) {      // 0 ancient_correction, 1 ancient_r
     checkFlags(name, a, ANCIENT_FLAGS);
     if (mode >= 1 && !a.flag.count("--rescore-mode")) unsupported(std::string(name) + ": --rescore-mode 3 has to be given (the module's default, 0 = Hamming distance, is not implemented on the MI355X path)");
     Laps laps;
-    MmDb seq, aln; std::string err; if (!seq.load(a.pos[0], &err)) die(err);
+    SeqInput in; in.load(a.pos[0]); MmDb &seq = in.db; MmDb aln; std::string err;
     const std::string damage = a.flag.count("--ancient-damage") ? a.flag["--ancient-damage"] : "";
-    DeviceStart dev; dev.begin(&seq, &damage);              // context, damage tables, sequence upload while the alignment text is parsed
-    if (!aln.load(a.pos[1], &err)) die(err);
-    laps.lap("DB files mapped");
+    DeviceStart dev; dev.begin(&in, &damage);               // context, damage tables, sequence upload while the alignment records are read
     HVec<uint64_t> off; HVec<cdm_aln> rec;
-    parseAlnDb(aln, seq, off, rec); laps.lap("alignment text parsed");
+    if (readAlnsSide(a.pos[1], seq, off, rec)) laps.lap("side-cars mapped, alignment records read");
+    else {
+        if (!aln.load(a.pos[1], &err)) die(err);
+        laps.lap("DB files mapped");
+        parseAlnDb(aln, seq, off, rec); laps.lap("alignment text parsed");
+    }
     dev.join(); cdm_ctx *ctx = dev.ctx; cdm_seqdb *db = dev.db; laps.lap("(device context, damage tables, sequences up: waited)");
     cdm_alns *alns = NULL; cdm_seqdb *out = NULL;
     check(cdm_alns_upload(ctx, db, off.data(), rec.data(), &alns), "upload");
@@ -601,6 +779,8 @@ int ancientModule(Args &a, int mode) {      // 0 ancient_correction, 1 ancient_r
     else check(cdm_correct(ctx, db, alns, &p, &out), "ancient_correction");
     laps.lap("records up, kernels");
     writeSeqDb(ctx, out, a.pos[2], seq.dbtype); laps.lap("sequences down, DB written");
+    if (!in.fromSide) { exportSeqSide(ctx, db, a.pos[0], seq.dbtype); laps.lap("input side-car written"); }
+    finishModule(EXIT_SUCCESS);
     cdm_seqdb_free(out); cdm_alns_free(alns); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
@@ -886,7 +1066,7 @@ int main(int argc, char **argv) {
         omp_set_dynamic(0);      // every slice of the per-thread loops below has its thread
         if (th > 0) { omp_set_num_threads((int) th); setenv("OMP_NUM_THREADS", std::to_string(th).c_str(), 1); }      // (the library's own loops read it)
     }
-    auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now(); g_t0 = t0;
     int rc;
     if (cmd == "kmermatcher") rc = kmermatcher(a);
     else if (cmd == "rescorediagonal") rc = rescorediagonal(a);

@@ -43,6 +43,9 @@ struct MmDb {
     MmDb &operator=(const MmDb &) = delete;
     ~MmDb();
     bool load(const std::string &path, std::string *err, bool indexOnly = false);   // indexOnly: DBReader's USE_INDEX - no data file is opened (createhdb.cpp:21-31)
+    // the index columns from arrays (a binary side-car, host/sidecar.h): entries in key order, payLen = payload letters (the text DB's
+    // length column is payLen + 2); no data is mapped - data() / entry() are not to be called
+    void adoptIndex(const uint32_t *keys, const uint32_t *payLen, const uint8_t *extFlags, size_t n, int type);
     size_t size() const { return key.size(); }
     const char *data() const { return base; }
     size_t dataSize() const { return bytes; }

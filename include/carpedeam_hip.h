@@ -111,6 +111,14 @@ int cdm_seqdb_attach_raw(cdm_ctx *ctx, cdm_seqdb *db, const void *dev_raw, const
 int cdm_seqdb_from_packed_ext(cdm_ctx *ctx, const void *dev_codes, const void *dev_nmask16, const void *dev_lengths, const void *dev_keys,
                               const void *dev_ext, uint64_t n, uint64_t words, cdm_seqdb **out);
 int cdm_seqdb_copy_ext(cdm_ctx *ctx, const cdm_seqdb *db, void *dev_ext);
+/* The same packed form to and from HOST buffers: what a module process leaves in a binary side-car next to the sequence DB it read or wrote
+ * (csrc/host/sidecar.cpp), so that the next module of data/nuclassemble.sh:100-146 uploads 2 bits per base instead of parsing and packing
+ * the text DB again (lib/mmseqs/src/commons/DBReader.cpp:108-133, DBWriter.cpp:322-427 stay the format every reference module reads).
+ * nmask16 / raw / raw_flags may be NULL: export - not wanted; import - no letter beyond ACGT / no raw plane.  raw_flags of an export:
+ * one byte per sequence, bit 0 = the sequence has a letter beyond ACGT, bit 1 = its row of the raw plane counts. */
+int cdm_seqdb_export_packed(cdm_ctx *ctx, const cdm_seqdb *db, void *codes, void *nmask16, void *lengths, void *keys, void *ext, void *raw, void *raw_flags);
+int cdm_seqdb_import_packed(cdm_ctx *ctx, const void *codes, const void *nmask16, const void *lengths, const void *keys, const void *ext, const void *raw,
+                            const void *raw_flags, uint64_t n, uint64_t words, cdm_seqdb **out);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Damage model.  Replaces the per-thread initDeamProbabilities + getSeqErrorProf calls
