@@ -122,24 +122,33 @@ float fflag(Args &a, const char *n, float d) { return a.flag.count(n) ? strtof(a
 long iflag(Args &a, const char *n, long d) { return a.flag.count(n) ? strtol(a.flag[n].c_str(), NULL, 10) : d; }
 
 // CDM_TIMING=1: where a module's wall time goes (stderr)
+std::chrono::steady_clock::time_point g_t0, g_lastLap;
 struct Laps {
     bool on; std::chrono::steady_clock::time_point t;
-    Laps() : on(getenv("CDM_TIMING") != NULL), t(std::chrono::steady_clock::now()) {}
+    Laps() : on(getenv("CDM_TIMING") != NULL), t(std::chrono::steady_clock::now()) {
+        if (on && g_t0.time_since_epoch().count()) fprintf(stderr, "  %-32s %.3f s\n", "(arguments, flags)", std::chrono::duration<double>(t - g_t0).count());
+        g_lastLap = t;
+    }
     void lap(const char *what) {
         if (!on) return;
         const auto n = std::chrono::steady_clock::now();
-        fprintf(stderr, "  %-32s %.3f s\n", what, std::chrono::duration<double>(n - t).count()); t = n;
+        fprintf(stderr, "  %-32s %.3f s\n", what, std::chrono::duration<double>(n - t).count()); t = n; g_lastLap = n;
     }
 };
 // The end of a module whose outputs are written and closed: the process leaves HERE - no release of device buffers (giving tens of GB
 // back to the driver costs seconds, profiles/r05_time_modules_50M_*), no unmapping of the input files, no destructors of the
 // multi-GB host buffers; the operating system and the driver take everything back at once.  (Not under a profiler or sanitizer that
 // writes its results from an exit handler - ROCP_TOOL_LIBRARIES / LD_PRELOAD / CDM_NORMAL_EXIT: then the caller releases and returns.)
-std::chrono::steady_clock::time_point g_t0;
-bool leaveAtOnce() { return !(getenv("ROCP_TOOL_LIBRARIES") || getenv("LD_PRELOAD") || getenv("CDM_NORMAL_EXIT")); }
+bool leaveAtOnce() {
+    if (getenv("ROCP_TOOL_LIBRARIES") || getenv("CDM_NORMAL_EXIT")) return false;
+    const char *pre = getenv("LD_PRELOAD");         // (a profiler's preload counts, any other preloaded library - a deployment's exec guard, an allocator - does not)
+    return !(pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "rocprofiler")));
+}
 void finishModule(int rc) {
     if (!leaveAtOnce()) return;
-    fprintf(stderr, "Time for processing: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_t0).count());
+    const auto n = std::chrono::steady_clock::now();
+    if (getenv("CDM_TIMING")) fprintf(stderr, "  %-32s %.3f s\n", "(since the last lap)", std::chrono::duration<double>(n - g_lastLap).count());
+    fprintf(stderr, "Time for processing: %.3fs\n", std::chrono::duration<double>(n - g_t0).count());
     fflush(stdout); fflush(stderr);
     _exit(rc);
 }
@@ -210,21 +219,45 @@ bool importSeqSide(cdm_ctx *ctx, const SideFile &f, cdm_seqdb **out) {
     return cdm_seqdb_import_packed(ctx, f.section(4), hasMask ? f.section(5) : NULL, f.section(1), f.section(0), f.section(2), hasRaw ? f.section(6) : NULL,
                                    hasRaw ? f.section(3) : NULL, h.n, h.count, out) == CDM_OK;
 }
-// the device DB `h` as the side-car of the text DB at `path` (whose files are complete); a failure leaves the text DB on its own
-void exportSeqSide(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) {
-    if (!sideEnabled()) return;
-    const uint64_t n = cdm_seqdb_size(h), words = cdm_seqdb_words(h);
-    if (n == 0) return;
-    HVec<uint32_t> keys(n), lens(n), codes(words + 1); HVec<uint8_t> ext(n), flags(n); HVec<uint16_t> mask(words + 1); HVec<uint8_t> raw;
-    const bool hasRaw = cdm_seqdb_has_raw(h) != 0;
-    if (hasRaw) raw.resize(words * 16 + 1);
-    if (cdm_seqdb_export_packed(ctx, h, codes.data(), mask.data(), lens.data(), keys.data(), ext.data(), hasRaw ? raw.data() : NULL, flags.data()) != CDM_OK) return;
-    bool anyN = false;
+// the device DB `h` as a side-car, in two steps: take() brings the packed form to the host while the device still holds it, write() puts
+// it next to the text DB at `path` once that DB's files are complete; a failure of either leaves the text DB on its own
+struct SeqSideHost {
+    HVec<uint32_t> keys, lens, codes; HVec<uint8_t> ext, flags, raw; HVec<uint16_t> mask;
+    uint64_t n = 0, words = 0; bool have = false, hasRaw = false;
+    void take(cdm_ctx *ctx, cdm_seqdb *h) {
+        have = false;
+        if (!sideEnabled()) return;
+        n = cdm_seqdb_size(h); words = cdm_seqdb_words(h);
+        if (n == 0) return;
+        keys.resize(n); lens.resize(n); codes.resize(words + 1); ext.resize(n); flags.resize(n); mask.resize(words + 1);
+        hasRaw = cdm_seqdb_has_raw(h) != 0;
+        if (hasRaw) raw.resize(words * 16 + 1);
+        have = cdm_seqdb_export_packed(ctx, h, codes.data(), mask.data(), lens.data(), keys.data(), ext.data(), hasRaw ? raw.data() : NULL, flags.data()) == CDM_OK;
+    }
+    void write(const std::string &path, int dbtype) {
+        if (!have) return;
+        bool anyN = false;
 #pragma omp parallel for reduction(|| : anyN) schedule(static)
-    for (size_t i = 0; i < n; i++) anyN = anyN || flags[i] != 0;
-    const SidePiece pc[7] = {{keys.data(), n * 4}, {lens.data(), n * 4}, {ext.data(), n}, {flags.data(), n}, {codes.data(), words * 4}, {mask.data(), anyN ? words * 2 : 0}, {raw.data(), hasRaw ? words * 16 : 0}};
-    sideWrite(path, SIDE_SEQ, (anyN ? SIDE_F_HAS_NMASK : 0) | (hasRaw ? SIDE_F_HAS_RAW : 0), n, words, 0, 0, dbtype, pc, 7);
-}
+        for (size_t i = 0; i < n; i++) anyN = anyN || flags[i] != 0;
+        const SidePiece pc[7] = {{keys.data(), n * 4}, {lens.data(), n * 4}, {ext.data(), n}, {flags.data(), n}, {codes.data(), words * 4}, {mask.data(), anyN ? words * 2 : 0}, {raw.data(), hasRaw ? words * 16 : 0}};
+        sideWrite(path, SIDE_SEQ, (anyN ? SIDE_F_HAS_NMASK : 0) | (hasRaw ? SIDE_F_HAS_RAW : 0), n, words, 0, 0, dbtype, pc, 7);
+    }
+};
+// What a module still holds on the device goes back to the driver as soon as its last result is on the host, BEFORE the text is formatted
+// and written: memory a process gives back is cleared by the driver before another process gets it (~30 ms per GB, in the background:
+// profiles/r05_probe_exit.txt), and the next module of the workflow starts milliseconds after this one ends - it found that clearing in
+// its way (0.35 -> 2.5 s for rescorediagonal's kernels behind kmermatcher).  Giving back is quick (10 ms for 140 GB); it is this thread's
+// arenas that hold the memory (the kernels ran here), so this thread does it.
+struct DeviceEnd {
+    void begin(cdm_ctx *ctx, cdm_hits *hits, cdm_alns *alns, cdm_seqdb *a, cdm_seqdb *b) {
+        if (hits) cdm_hits_free(hits);
+        if (alns) cdm_alns_free(alns);
+        if (a) cdm_seqdb_free(a);
+        if (b) cdm_seqdb_free(b);
+        cdm_ctx_destroy(ctx);
+    }
+    void join() {}
+};
 // A sequence DB as a module takes it: from its side-car when that matches the files - index columns from the side-car's arrays, no text
 // mapped - else from the text (MmDb::load).
 struct SeqInput {
@@ -288,25 +321,31 @@ void appendEntries(cdm_ctx *ctx, cdm_seqdb *h, OutChunk &c) {
     c.reserve(c.key.size() + n, c.data.size() + tot);
     for (uint64_t i = 0; i < n; i++) c.add(keys[i], buf.data() + offs[i], lens[i] + 1, ext[i]);
 }
-void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) {
-    const uint64_t n = cdm_seqdb_size(h);
-    if (n == 0) { std::string err; if (!mmdbWriteChunks(path, dbtype, std::vector<OutChunk>(1), &err)) die(err); return; }
-    std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
-    check(cdm_seqdb_meta(ctx, h, lens.data(), keys.data(), ext.data()), "meta");
-    // the download buffer has the data file's layout already: "SEQ\n\0" per entry (the NULs are the buffer's zero fill)
-    Laps laps;
-    HVec<uint64_t> offs(n); HVec<uint32_t> elen(n); uint64_t tot = 0;
-    for (uint64_t i = 0; i < n; i++) { offs[i] = tot; elen[i] = lens[i] + 2; tot += lens[i] + 2; }
-    HVec<char> buf(tot);
-    buf[tot - 1] = '\0';           // the download writes [0, tot - 1): "SEQ\n" per entry and the NULs between them; the last entry's NUL is ours
-    laps.lap("    (lengths down, offsets)");
-    check(cdm_seqdb_download(ctx, h, buf.data(), offs.data()), "download");
-    laps.lap("    (letters unpacked and down)");
-    std::string err; if (!mmdbWriteBlob(path, dbtype, buf.data(), buf.size(), keys.data(), offs.data(), elen.data(), ext.data(), n, &err)) die(err);
-    laps.lap("    (data + index files written)");
-    exportSeqSide(ctx, h, path, dbtype);
-    laps.lap("    (side-car written)");
-}
+// a device DB as a text DB (+ its side-car): down() takes everything off the device, write() needs the device no more
+struct SeqDbOut {
+    uint64_t n = 0; HVec<uint32_t> keys, elen; HVec<uint8_t> ext; HVec<uint64_t> offs; HVec<char> buf; SeqSideHost side;
+    void down(cdm_ctx *ctx, cdm_seqdb *h) {
+        n = cdm_seqdb_size(h);
+        if (n == 0) return;
+        std::vector<uint32_t> lens(n);
+        keys.resize(n); ext.resize(n);
+        check(cdm_seqdb_meta(ctx, h, lens.data(), keys.data(), ext.data()), "meta");
+        // the download buffer has the data file's layout already: "SEQ\n\0" per entry (the NULs are the buffer's zero fill)
+        offs.resize(n); elen.resize(n); uint64_t tot = 0;
+        for (uint64_t i = 0; i < n; i++) { offs[i] = tot; elen[i] = lens[i] + 2; tot += lens[i] + 2; }
+        buf.resize(tot);
+        buf[tot - 1] = '\0';           // the download writes [0, tot - 1): "SEQ\n" per entry and the NULs between them; the last entry's NUL is ours
+        check(cdm_seqdb_download(ctx, h, buf.data(), offs.data()), "download");
+        side.take(ctx, h);
+    }
+    void write(const std::string &path, int dbtype) {
+        std::string err;
+        if (n == 0) { if (!mmdbWriteChunks(path, dbtype, std::vector<OutChunk>(1), &err)) die(err); return; }
+        if (!mmdbWriteBlob(path, dbtype, buf.data(), buf.size(), keys.data(), offs.data(), elen.data(), ext.data(), n, &err)) die(err);
+        side.write(path, dbtype);
+    }
+};
+void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) { SeqDbOut o; o.down(ctx, h); o.write(path, dbtype); }
 // ---- text codecs
 // decimal text, two digits per division
 char *utoa(unsigned long long v, char *p) {
@@ -671,17 +710,18 @@ int kmermatcher(Args &a) {
     check(cdm_kmermatch(ctx, db, &p, &hits), "kmermatcher");
     HVec<uint64_t> off(seq.size() + 1); HVec<cdm_hit> rec(cdm_hits_count(hits));
     check(cdm_hits_download(ctx, hits, off.data(), rec.data()), "download");
+    SeqSideHost inSide; if (!in.fromSide) inSide.take(ctx, db);       // (the next modules of the workflow read this DB again)
     laps.lap("kernels, hits down");
+    DeviceEnd end; end.begin(ctx, hits, NULL, db, NULL); laps.lap("device memory back to the driver");
     std::vector<OutChunk> chunks;
     formatPrefDb(seq, off.data(), rec.data(), chunks);
     laps.lap("prefilter text formatted");
     if (!mmdbWriteChunks(a.pos[1], 14, chunks, &err, true)) die(err);   // DBTYPE_PREFILTER_REV_RES (kmermatcher.cpp:682)
     laps.lap("result DB written");
     writeHitsSide(a.pos[1], seq, off.data(), rec.data(), 14);
-    if (!in.fromSide) exportSeqSide(ctx, db, a.pos[0], seq.dbtype);       // (the next modules of the workflow read this DB again)
+    inSide.write(a.pos[0], seq.dbtype);
     laps.lap("side-cars written");
     finishModule(EXIT_SUCCESS);
-    cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
 
@@ -735,10 +775,13 @@ int rescorediagonal(Args &a) {
     check(cdm_rescore(ctx, db, hits, &p, &alns), "rescorediagonal");
     HVec<uint64_t> aoff(seq.size() + 1); HVec<cdm_aln> arec(cdm_alns_count(alns));
     check(cdm_alns_download(ctx, alns, aoff.data(), arec.data()), "download");
+    const uint64_t dbResidues = cdm_seqdb_residues(db);
+    SeqSideHost inSide; if (!in.fromSide) inSide.take(ctx, db);
     laps.lap("hits up, kernels, records down");
+    DeviceEnd end; end.begin(ctx, hits, alns, db, NULL); laps.lap("device memory back to the driver");
     std::vector<OutChunk> chunks;
     HVec<cdm_aln> asParsed; if (sideEnabled()) asParsed.resize(arec.size());
-    formatAlnDb(seq, hitsFromSide ? NULL : &pref, aoff.data(), arec.data(), cdm_seqdb_residues(db), chunks, sideEnabled() ? asParsed.data() : NULL);
+    formatAlnDb(seq, hitsFromSide ? NULL : &pref, aoff.data(), arec.data(), dbResidues, chunks, sideEnabled() ? asParsed.data() : NULL);
     laps.lap("alignment text formatted");
     if (!mmdbWriteChunks(a.pos[3], 5, chunks, &err, true)) die(err);
     laps.lap("result DB written");
@@ -746,10 +789,9 @@ int rescorediagonal(Args &a) {
     bool allPresent = hitsFromSide;
     if (!allPresent) { allPresent = true; for (size_t i = 0; i < seq.size() && allPresent; i++) allPresent = pref.idOf(seq.key[i]) >= 0; }
     if (allPresent) writeAlnsSide(a.pos[3], seq, aoff.data(), asParsed.data());
-    if (!in.fromSide) exportSeqSide(ctx, db, a.pos[1], seq.dbtype);
+    inSide.write(a.pos[1], seq.dbtype);
     laps.lap("side-cars written");
     finishModule(EXIT_SUCCESS);
-    cdm_alns_free(alns); cdm_hits_free(hits); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
 
@@ -778,10 +820,13 @@ int ancientModule(Args &a, int mode) {      // 0 ancient_correction, 1 ancient_r
     else if (mode == 2) check(cdm_contig_merge(ctx, db, alns, &p, fflag(a, "--min-merge-seq-id", 0.99f), &out), "ancient_contig_merge");
     else check(cdm_correct(ctx, db, alns, &p, &out), "ancient_correction");
     laps.lap("records up, kernels");
-    writeSeqDb(ctx, out, a.pos[2], seq.dbtype); laps.lap("sequences down, DB written");
-    if (!in.fromSide) { exportSeqSide(ctx, db, a.pos[0], seq.dbtype); laps.lap("input side-car written"); }
+    SeqDbOut o; o.down(ctx, out);
+    SeqSideHost inSide; if (!in.fromSide) inSide.take(ctx, db);
+    laps.lap("sequences down");
+    DeviceEnd end; end.begin(ctx, NULL, alns, db, out); laps.lap("device memory back to the driver");
+    o.write(a.pos[2], seq.dbtype); laps.lap("DB + side-car written");
+    inSide.write(a.pos[0], seq.dbtype);
     finishModule(EXIT_SUCCESS);
-    cdm_seqdb_free(out); cdm_alns_free(alns); cdm_seqdb_free(db); cdm_ctx_destroy(ctx);
     return EXIT_SUCCESS;
 }
 // cyclecheck <i:sequenceDB> <o:sequenceDBcycle> (src/assembler/cyclecheck.cpp:30-269; flags: LocalParameters.h:183-187)
@@ -1083,8 +1128,8 @@ int main(int argc, char **argv) {
     fprintf(stderr, "Time for processing: %.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     // Every output file is written and closed, every handle and the context released: leave without the static destructors (the
     // HIP runtime's own tear-down is where one module run in ~1 500 of the fuzz campaigns ended with a signal after its work was done)
-    // (not under a profiler or sanitizer that writes its results from an exit handler: ROCP_TOOL_LIBRARIES / LD_PRELOAD / CDM_NORMAL_EXIT)
-    if (getenv("ROCP_TOOL_LIBRARIES") || getenv("LD_PRELOAD") || getenv("CDM_NORMAL_EXIT")) return rc;
+    // (not under a profiler that writes its results from an exit handler: ROCP_TOOL_LIBRARIES / a profiler's LD_PRELOAD / CDM_NORMAL_EXIT)
+    if (!leaveAtOnce()) return rc;
     fflush(stdout); fflush(stderr);
     _exit(rc);
 }
