@@ -29,6 +29,10 @@
 #include <mutex>
 
 #include "carpedeam_hip.h"
+#include <sys/prctl.h>
+#include <sys/wait.h>
+#include <signal.h>
+#include <cerrno>
 #include "mmdb.h"
 #include "sidecar.h"
 
@@ -144,12 +148,28 @@ bool leaveAtOnce() {
     const char *pre = getenv("LD_PRELOAD");         // (a profiler's preload counts, any other preloaded library - a deployment's exec guard, an allocator - does not)
     return !(pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "rocprofiler")));
 }
+// The caller gets its answer before this process is torn down: the work runs in a CHILD of the process the caller started (forked first
+// thing in main, before anything touches the device), the parent waits for one byte - the exit status, sent when every output file is
+// written and closed - and leaves with it at once.  Tearing down a module's address space (tens of GB of host buffers and mapped DB
+// files at 50 M reads: 0.4-1.3 s, profiles/r05_probe_module_gap.txt) then happens beside the next module of the workflow instead of
+// in front of it.  A child that ends without the byte (a crash, an error exit) is waited for and its status handed on.
+// Not under a profiler (leaveAtOnce()) and not with CDM_NO_FORK=1.
+int g_doneFd = -1;
+void reportDone(int rc) {
+    if (g_doneFd < 0) return;
+    prctl(PR_SET_PDEATHSIG, 0);         // (from here on the parent's leaving is the plan, not an accident)
+    const unsigned char b = (unsigned char) rc;
+    if (write(g_doneFd, &b, 1) != 1) {}
+    close(g_doneFd); g_doneFd = -1;
+    close(0); close(1); close(2);       // (a caller that reads this process's output through pipes waits for their last writer)
+}
 void finishModule(int rc) {
     if (!leaveAtOnce()) return;
     const auto n = std::chrono::steady_clock::now();
     if (getenv("CDM_TIMING")) fprintf(stderr, "  %-32s %.3f s\n", "(since the last lap)", std::chrono::duration<double>(n - g_lastLap).count());
     fprintf(stderr, "Time for processing: %.3fs\n", std::chrono::duration<double>(n - g_t0).count());
     fflush(stdout); fflush(stderr);
+    reportDone(rc);
     _exit(rc);
 }
 cdm_ctx *openCtx(int offset = 0) {
@@ -234,14 +254,20 @@ struct SeqSideHost {
         if (hasRaw) raw.resize(words * 16 + 1);
         have = cdm_seqdb_export_packed(ctx, h, codes.data(), mask.data(), lens.data(), keys.data(), ext.data(), hasRaw ? raw.data() : NULL, flags.data()) == CDM_OK;
     }
-    void write(const std::string &path, int dbtype) {
+    // begin(): the sections go out in a thread of their own (the caller writes the text DB meanwhile); commit(): the text DB is complete
+    std::thread th; SideHeader hdr; bool bodyOk = false; std::string path;
+    void begin(const std::string &p, int dbtype) {
         if (!have) return;
-        bool anyN = false;
-#pragma omp parallel for reduction(|| : anyN) schedule(static)
-        for (size_t i = 0; i < n; i++) anyN = anyN || flags[i] != 0;
-        const SidePiece pc[7] = {{keys.data(), n * 4}, {lens.data(), n * 4}, {ext.data(), n}, {flags.data(), n}, {codes.data(), words * 4}, {mask.data(), anyN ? words * 2 : 0}, {raw.data(), hasRaw ? words * 16 : 0}};
-        sideWrite(path, SIDE_SEQ, (anyN ? SIDE_F_HAS_NMASK : 0) | (hasRaw ? SIDE_F_HAS_RAW : 0), n, words, 0, 0, dbtype, pc, 7);
+        path = p;
+        th = std::thread([this, dbtype] {
+            bool anyN = false;
+            for (size_t i = 0; i < n && !anyN; i++) anyN = flags[i] != 0;
+            const SidePiece pc[7] = {{keys.data(), n * 4}, {lens.data(), n * 4}, {ext.data(), n}, {flags.data(), n}, {codes.data(), words * 4}, {mask.data(), anyN ? words * 2 : 0}, {raw.data(), hasRaw ? words * 16 : 0}};
+            bodyOk = sideWriteBody(path, SIDE_SEQ, (anyN ? SIDE_F_HAS_NMASK : 0) | (hasRaw ? SIDE_F_HAS_RAW : 0), n, words, 0, 0, dbtype, pc, 7, &hdr);
+        });
     }
+    void commit() { if (th.joinable()) { th.join(); if (bodyOk) sideCommit(path, &hdr); } }
+    void write(const std::string &p, int dbtype) { begin(p, dbtype); commit(); }
 };
 // What a module still holds on the device goes back to the driver as soon as its last result is on the host, BEFORE the text is formatted
 // and written: memory a process gives back is cleared by the driver before another process gets it (~30 ms per GB, in the background:
@@ -341,8 +367,9 @@ struct SeqDbOut {
     void write(const std::string &path, int dbtype) {
         std::string err;
         if (n == 0) { if (!mmdbWriteChunks(path, dbtype, std::vector<OutChunk>(1), &err)) die(err); return; }
+        side.begin(path, dbtype);       // (beside the text: other files)
         if (!mmdbWriteBlob(path, dbtype, buf.data(), buf.size(), keys.data(), offs.data(), elen.data(), ext.data(), n, &err)) die(err);
-        side.write(path, dbtype);
+        side.commit();
     }
 };
 void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) { SeqDbOut o; o.down(ctx, h); o.write(path, dbtype); }
@@ -601,8 +628,8 @@ void formatRescoredPrefDb(const MmDb &seq, const MmDb &pref, const uint64_t *off
 }
 
 // ---- record side-cars: the CSR a consumer's parser would produce from the text, as cdm_hits_upload / cdm_alns_upload take it
-void writeHitsSide(const std::string &path, const MmDb &seq, const uint64_t *off, const cdm_hit *rec, int dbtype) {
-    if (!sideEnabled()) return;
+bool writeHitsSide(const std::string &path, const MmDb &seq, const uint64_t *off, const cdm_hit *rec, int dbtype, SideHeader *hdr) {
+    if (!sideEnabled()) return false;
     const uint64_t n = seq.size(), count = off[n];
     bool fits = true;
 #pragma omp parallel for reduction(&& : fits) schedule(static)
@@ -613,13 +640,13 @@ void writeHitsSide(const std::string &path, const MmDb &seq, const uint64_t *off
 #pragma omp parallel for schedule(static)
         for (uint64_t i = 0; i < count; i++) { c[i].target = rec[i].target; c[i].score = (int16_t) rec[i].score; c[i].diagonal = (int16_t) (short) rec[i].diagonal; }
         const SidePiece pc[2] = {{off, (n + 1) * 8}, {c.data(), count * sizeof(SideHit8)}};
-        sideWrite(path, SIDE_HITS, SIDE_F_COMPACT, n, count, n, hash, dbtype, pc, 2);
+        return sideWriteBody(path, SIDE_HITS, SIDE_F_COMPACT, n, count, n, hash, dbtype, pc, 2, hdr);
     } else {
         HVec<cdm_hit> c(count);
 #pragma omp parallel for schedule(static)
         for (uint64_t i = 0; i < count; i++) { c[i] = rec[i]; c[i].diagonal = (short) rec[i].diagonal; }       // (the text holds the diagonal as a short: QueryMatcher.h:114-126)
         const SidePiece pc[2] = {{off, (n + 1) * 8}, {c.data(), count * sizeof(cdm_hit)}};
-        sideWrite(path, SIDE_HITS, 0, n, count, n, hash, dbtype, pc, 2);
+        return sideWriteBody(path, SIDE_HITS, 0, n, count, n, hash, dbtype, pc, 2, hdr);
     }
 }
 // hits / alignments of the DB at `path` from its side-car if that belongs to these files and to this sequence DB
@@ -639,8 +666,8 @@ bool readHitsSide(const std::string &path, const MmDb &seq, HVec<uint64_t> &off,
     *dbtype = h.dbtype;
     return true;
 }
-void writeAlnsSide(const std::string &path, const MmDb &seq, const uint64_t *off, const cdm_aln *asParsed) {
-    if (!sideEnabled()) return;
+bool writeAlnsSide(const std::string &path, const MmDb &seq, const uint64_t *off, const cdm_aln *asParsed, SideHeader *hdr) {
+    if (!sideEnabled()) return false;
     const uint64_t n = seq.size(), count = off[n];
     bool fits = true;
 #pragma omp parallel for reduction(&& : fits) schedule(static)
@@ -659,10 +686,10 @@ void writeAlnsSide(const std::string &path, const MmDb &seq, const uint64_t *off
             c[i].qStart = (int16_t) r.q_start; c[i].qEnd = (int16_t) r.q_end; c[i].dbStart = (int16_t) r.db_start; c[i].dbEnd = (int16_t) r.db_end;
         }
         const SidePiece pc[2] = {{off, (n + 1) * 8}, {c.data(), count * sizeof(SideAln16)}};
-        sideWrite(path, SIDE_ALNS, SIDE_F_COMPACT, n, count, n, hash, 5, pc, 2);
+        return sideWriteBody(path, SIDE_ALNS, SIDE_F_COMPACT, n, count, n, hash, 5, pc, 2, hdr);
     } else {
         const SidePiece pc[2] = {{off, (n + 1) * 8}, {asParsed, count * sizeof(cdm_aln)}};
-        sideWrite(path, SIDE_ALNS, 0, n, count, n, hash, 5, pc, 2);
+        return sideWriteBody(path, SIDE_ALNS, 0, n, count, n, hash, 5, pc, 2, hdr);
     }
 }
 bool readAlnsSide(const std::string &path, const MmDb &seq, HVec<uint64_t> &off, HVec<cdm_aln> &rec) {
@@ -690,6 +717,13 @@ bool readAlnsSide(const std::string &path, const MmDb &seq, HVec<uint64_t> &off,
     return true;
 }
 
+// the record side-cars beside the text: their sections are built and written in a thread while the caller formats and writes the text DB
+struct SideThread {
+    std::thread th; SideHeader hdr; bool ok = false; std::string path;
+    template <typename F> void begin(const std::string &p, F body) { if (!sideEnabled()) return; path = p; th = std::thread([this, body] { ok = body(&hdr); }); }
+    void commit() { if (th.joinable()) { th.join(); if (ok) sideCommit(path, &hdr); } }
+};
+
 int kmermatcher(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam kmermatcher <i:sequenceDB> <o:prefilterDB>");
     checkFlags("kmermatcher", a, KMERMATCHER_FLAGS);
@@ -713,14 +747,15 @@ int kmermatcher(Args &a) {
     SeqSideHost inSide; if (!in.fromSide) inSide.take(ctx, db);       // (the next modules of the workflow read this DB again)
     laps.lap("kernels, hits down");
     DeviceEnd end; end.begin(ctx, hits, NULL, db, NULL); laps.lap("device memory back to the driver");
+    SideThread hitsSide; hitsSide.begin(a.pos[1], [&](SideHeader *h) { return writeHitsSide(a.pos[1], seq, off.data(), rec.data(), 14, h); });
+    inSide.begin(a.pos[0], seq.dbtype);
     std::vector<OutChunk> chunks;
     formatPrefDb(seq, off.data(), rec.data(), chunks);
     laps.lap("prefilter text formatted");
     if (!mmdbWriteChunks(a.pos[1], 14, chunks, &err, true)) die(err);   // DBTYPE_PREFILTER_REV_RES (kmermatcher.cpp:682)
     laps.lap("result DB written");
-    writeHitsSide(a.pos[1], seq, off.data(), rec.data(), 14);
-    inSide.write(a.pos[0], seq.dbtype);
-    laps.lap("side-cars written");
+    hitsSide.commit(); inSide.commit();
+    laps.lap("(side-cars, written beside: waited)");
     finishModule(EXIT_SUCCESS);
     return EXIT_SUCCESS;
 }
@@ -768,11 +803,11 @@ int rescorediagonal(Args &a) {
     }
     dev.join(); cdm_ctx *ctx = dev.ctx; cdm_seqdb *db = dev.db; laps.lap("(device context, sequences up: waited)");
     cdm_hits *hits = NULL; cdm_alns *alns = NULL;
-    check(cdm_hits_upload(ctx, db, off.data(), rec.data(), &hits), "upload");
+    check(cdm_hits_upload(ctx, db, off.data(), rec.data(), &hits), "upload"); laps.lap("  (hits up)");
     cdm_rescore_params p;
     p.seq_id_thr = fflag(a, "--min-seq-id", 0.0f); p.eval_thr = a.flag.count("-e") ? strtod(a.flag["-e"].c_str(), NULL) : 0.001;
     p.cov_mode = (int) iflag(a, "--cov-mode", 0); p.cov_thr = fflag(a, "-c", 0.0f); p.seq_id_mode = (int) iflag(a, "--seq-id-mode", 0); p.min_aln_len = (int) iflag(a, "--min-aln-len", 0);
-    check(cdm_rescore(ctx, db, hits, &p, &alns), "rescorediagonal");
+    check(cdm_rescore(ctx, db, hits, &p, &alns), "rescorediagonal"); laps.lap("  (kernels)");
     HVec<uint64_t> aoff(seq.size() + 1); HVec<cdm_aln> arec(cdm_alns_count(alns));
     check(cdm_alns_download(ctx, alns, aoff.data(), arec.data()), "download");
     const uint64_t dbResidues = cdm_seqdb_residues(db);
@@ -783,14 +818,15 @@ int rescorediagonal(Args &a) {
     HVec<cdm_aln> asParsed; if (sideEnabled()) asParsed.resize(arec.size());
     formatAlnDb(seq, hitsFromSide ? NULL : &pref, aoff.data(), arec.data(), dbResidues, chunks, sideEnabled() ? asParsed.data() : NULL);
     laps.lap("alignment text formatted");
-    if (!mmdbWriteChunks(a.pos[3], 5, chunks, &err, true)) die(err);
-    laps.lap("result DB written");
     // (an alignment side-car holds every query: only when every query has a prefilter entry - kmermatcher's output - does the text too)
     bool allPresent = hitsFromSide;
     if (!allPresent) { allPresent = true; for (size_t i = 0; i < seq.size() && allPresent; i++) allPresent = pref.idOf(seq.key[i]) >= 0; }
-    if (allPresent) writeAlnsSide(a.pos[3], seq, aoff.data(), asParsed.data());
-    inSide.write(a.pos[1], seq.dbtype);
-    laps.lap("side-cars written");
+    SideThread alnSide; if (allPresent) alnSide.begin(a.pos[3], [&](SideHeader *h) { return writeAlnsSide(a.pos[3], seq, aoff.data(), asParsed.data(), h); });
+    inSide.begin(a.pos[1], seq.dbtype);
+    if (!mmdbWriteChunks(a.pos[3], 5, chunks, &err, true)) die(err);
+    laps.lap("result DB written");
+    alnSide.commit(); inSide.commit();
+    laps.lap("(side-cars, written beside: waited)");
     finishModule(EXIT_SUCCESS);
     return EXIT_SUCCESS;
 }
@@ -824,8 +860,9 @@ int ancientModule(Args &a, int mode) {      // 0 ancient_correction, 1 ancient_r
     SeqSideHost inSide; if (!in.fromSide) inSide.take(ctx, db);
     laps.lap("sequences down");
     DeviceEnd end; end.begin(ctx, NULL, alns, db, out); laps.lap("device memory back to the driver");
-    o.write(a.pos[2], seq.dbtype); laps.lap("DB + side-car written");
-    inSide.write(a.pos[0], seq.dbtype);
+    inSide.begin(a.pos[0], seq.dbtype);
+    o.write(a.pos[2], seq.dbtype); laps.lap("DB written, its side-car beside it");
+    inSide.commit();
     finishModule(EXIT_SUCCESS);
     return EXIT_SUCCESS;
 }
@@ -1101,7 +1138,26 @@ int createhdb(Args &a) {
 }
 }  // namespace
 
+// see reportDone(): true in the process that goes on with the work
+static bool workInChild() {
+    if (!leaveAtOnce() || getenv("CDM_NO_FORK")) return true;
+    int fds[2];
+    if (pipe(fds) != 0) return true;
+    fflush(stdout); fflush(stderr);
+    const pid_t pid = fork();
+    if (pid < 0) { close(fds[0]); close(fds[1]); return true; }
+    if (pid == 0) { close(fds[0]); g_doneFd = fds[1]; prctl(PR_SET_PDEATHSIG, SIGKILL); if (getppid() == 1) _exit(EXIT_FAILURE); return true; }
+    close(fds[1]);
+    unsigned char b = 0; ssize_t r;
+    while ((r = read(fds[0], &b, 1)) < 0 && errno == EINTR) {}
+    if (r == 1) _exit((int) b);
+    int st = 0;
+    while (waitpid(pid, &st, 0) < 0) if (errno != EINTR) _exit(EXIT_FAILURE);
+    if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); _exit(128 + WTERMSIG(st)); }
+    _exit(WEXITSTATUS(st));
+}
 int main(int argc, char **argv) {
+    workInChild();
     if (argc < 2) { fprintf(stderr, "usage: carpedeam <kmermatcher|rescorediagonal|ancient_correction|ancient_read_assemble|ancient_contig_merge|cyclecheck|ancient_reads_loop|createdb|convert2fasta|createhdb|clust|createsubdb|filterdb|mergeclusters|result2repseq|rmdb|mvdb> <args>\n"); return EXIT_FAILURE; }
     const std::string cmd = argv[1];
     Args a = parse(argc - 2, argv + 2);
@@ -1131,5 +1187,6 @@ int main(int argc, char **argv) {
     // (not under a profiler that writes its results from an exit handler: ROCP_TOOL_LIBRARIES / a profiler's LD_PRELOAD / CDM_NORMAL_EXIT)
     if (!leaveAtOnce()) return rc;
     fflush(stdout); fflush(stderr);
+    reportDone(rc);
     _exit(rc);
 }

@@ -36,28 +36,40 @@ uint64_t sideKeyHash(const uint32_t *keys, size_t n) {
     return h ^ (uint64_t) n;
 }
 static uint64_t pad64(uint64_t b) { return (b + 63) & ~63ull; }
-bool sideWrite(const std::string &db, uint32_t kind, uint32_t flags, uint64_t n, uint64_t count, uint64_t seqN, uint64_t seqKeyHash, int dbtype, const SidePiece *pieces, int nPieces) {
+// In two steps, so that the sections can be written WHILE the text DB they belong to is still being formatted and written (other
+// files: other inode locks): sideWriteBody puts the sections into X.cdmbin.tmp, sideCommit - once X's files are complete - stamps the
+// header with their sizes and times, writes it and renames the file into place (complete or absent: a reader never sees half a side-car).
+bool sideWriteBody(const std::string &db, uint32_t kind, uint32_t flags, uint64_t n, uint64_t count, uint64_t seqN, uint64_t seqKeyHash, int dbtype, const SidePiece *pieces, int nPieces, SideHeader *h) {
     if (!sideEnabled() || nPieces > SIDE_SECTIONS) return false;
-    SideHeader h;
-    memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "CDMSIDE1", 8);
-    h.kind = kind; h.flags = flags; h.n = n; h.count = count; h.seqN = seqN; h.seqKeyHash = seqKeyHash; h.dbtype = dbtype;
-    if (!sideStampOf(db, &h.stamp)) return false;
-    for (int i = 0; i < nPieces; i++) h.section[i] = pieces[i].bytes;
+    memset(h, 0, sizeof(*h));
+    memcpy(h->magic, "CDMSIDE1", 8);
+    h->kind = kind; h->flags = flags; h->n = n; h->count = count; h->seqN = seqN; h->seqKeyHash = seqKeyHash; h->dbtype = dbtype;
+    for (int i = 0; i < nPieces; i++) h->section[i] = pieces[i].bytes;
     const std::string tmp = sidePath(db) + ".tmp";
     const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) return false;
     bool ok = true;
     auto put = [&](const void *p, uint64_t bytes, uint64_t at) { const char *c = (const char *) p; while (bytes && ok) { const ssize_t w = pwrite(fd, c, bytes, (off_t) at); if (w <= 0) { ok = false; break; } c += w; bytes -= (uint64_t) w; at += (uint64_t) w; } };
     uint64_t at = pad64(sizeof(SideHeader));
-    put(&h, sizeof(h), 0);
     for (int i = 0; i < nPieces && ok; i++) { put(pieces[i].p, pieces[i].bytes, at); at += pad64(pieces[i].bytes); }
     if (ok && ftruncate(fd, (off_t) at) != 0) ok = false;
     ok = (close(fd) == 0) && ok;
-    // (complete or absent: a reader never sees half a side-car)
+    if (!ok) unlink(tmp.c_str());
+    return ok;
+}
+bool sideCommit(const std::string &db, SideHeader *h) {
+    const std::string tmp = sidePath(db) + ".tmp";
+    bool ok = sideStampOf(db, &h->stamp);
+    const int fd = ok ? open(tmp.c_str(), O_WRONLY) : -1;
+    ok = ok && fd >= 0 && pwrite(fd, h, sizeof(*h), 0) == (ssize_t) sizeof(*h);
+    if (fd >= 0) ok = (close(fd) == 0) && ok;
     if (ok) ok = rename(tmp.c_str(), sidePath(db).c_str()) == 0;
     if (!ok) unlink(tmp.c_str());
     return ok;
+}
+bool sideWrite(const std::string &db, uint32_t kind, uint32_t flags, uint64_t n, uint64_t count, uint64_t seqN, uint64_t seqKeyHash, int dbtype, const SidePiece *pieces, int nPieces) {
+    SideHeader h;
+    return sideWriteBody(db, kind, flags, n, count, seqN, seqKeyHash, dbtype, pieces, nPieces, &h) && sideCommit(db, &h);
 }
 SideFile::~SideFile() { if (base) munmap((void *) base, bytes); }
 const void *SideFile::section(int i) const {

@@ -37,6 +37,9 @@ bool sideStampOf(const std::string &db, SideStamp *st);
 uint64_t sideKeyHash(const uint32_t *keys, size_t n);
 // writes X.cdmbin for the DB X whose text files are complete (their stamp is taken here); false: could not (the text DB stands on its own)
 bool sideWrite(const std::string &db, uint32_t kind, uint32_t flags, uint64_t n, uint64_t count, uint64_t seqN, uint64_t seqKeyHash, int dbtype, const SidePiece *pieces, int nPieces);
+// the same in two steps (the sections while X is still being written, the stamped header and the rename once X is complete)
+bool sideWriteBody(const std::string &db, uint32_t kind, uint32_t flags, uint64_t n, uint64_t count, uint64_t seqN, uint64_t seqKeyHash, int dbtype, const SidePiece *pieces, int nPieces, SideHeader *h);
+bool sideCommit(const std::string &db, SideHeader *h);
 // a mapped side-car whose stamp matches X's files
 struct SideFile {
     const SideHeader *h = nullptr; const char *base = nullptr; size_t bytes = 0;

@@ -1,6 +1,6 @@
 // What does a process that holds ~140 GB of device memory cost when it ends - released chunk by chunk, or just left to the driver - and
 // what does the NEXT process pay for getting the same memory right afterwards?  (round 5: the module processes of a workflow follow each
-// other within milliseconds.)   exit_probe.bin <GB> <chunk MB> <release|leave> [vmm|malloc]
+// other within milliseconds.)   exit_probe.bin <GB> <chunk MB> <release|leave> [vmm|malloc] [seconds to stay alive behind the release]
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -38,6 +38,7 @@ int main(int argc, char **argv) {
         else for (void *p : ptrs) hipFree(p);
         t3 = now();
     }
+    if (argc > 5) { usleep((useconds_t) (atof(argv[5]) * 1e6)); }      // stay alive for a while behind the release
     printf("%zu GB in %zu chunks of %zu MB (%s): runtime up %.3f s, mapped %.3f s, touched %.3f s, %s %.3f s\n", gb, n, chunk >> 20, vmm ? "vmm" : "hipMalloc", t0 - t00, t1 - t0, t2 - t1, release ? "released" : "left to the driver", t3 - t2);
     fflush(stdout);
     _exit(0);
