@@ -1112,6 +1112,43 @@ const FlagSpec CREATEDB_FLAGS[] = {   // Parameters.cpp:733-737 createdb
     {"--write-lookup", 'V', "1", "the .lookup file is always written"}, {"--id-offset", 'V', "0", "not implemented"}, {"--compressed", 'V', "0", "compressed DBs are not implemented"},
     {"-v", 'N', 0, 0}, {"--threads", 'N', 0, 0}, {0, 0, 0, 0}};
 const FlagSpec PLAIN_FLAGS[] = {{"-v", 'N', 0, 0}, {"--threads", 'N', 0, 0}, {"--compressed", 'V', "0", "compressed DBs are not implemented"}, {"--use-fasta-header", 'V', "0", "not implemented"}, {0, 0, 0, 0}};
+// The side-car of a sequence DB straight from its text, on the host (createdb has no device): the letters packed as cdm_seqdb_upload
+// packs them (api.hip k_pack: A, C, G, T = 0..3, 16 per word, every sequence on a word boundary; 'N' = code 0 + a bit of the N mask).
+// Only for DBs of upper-case ACGTN - any other letter takes the device's mapping and its raw plane (the first module that uploads the
+// DB then writes the side-car).
+void seqSideFromText(const std::string &path) {
+    if (!sideEnabled()) return;
+    MmDb db; std::string err;
+    if (!db.load(path, &err) || (db.dbtype & 0x7FFFFFFF) != 1 || db.size() == 0) return;
+    const size_t n = db.size();
+    HVec<uint32_t> lens(n), woff(n + 1); HVec<uint8_t> ext(n), flags(n);
+    woff[0] = 0;
+    for (size_t i = 0; i < n; i++) { lens[i] = db.len[i] >= 2 ? (uint32_t) (db.len[i] - 2) : 0; ext[i] = db.ext[i]; const uint64_t w = (uint64_t) woff[i] + (lens[i] + 15) / 16; if (w > 0xFFFFFFFFull) return; woff[i + 1] = (uint32_t) w; }
+    const uint64_t words = woff[n];
+    HVec<uint32_t> codes(words + 1); HVec<uint16_t> mask(words + 1);
+    bool other = false, anyN = false;
+#pragma omp parallel for reduction(|| : other, anyN) schedule(dynamic, 4096)
+    for (size_t i = 0; i < n; i++) {
+        const char *sq = db.entry(i);
+        const uint32_t L = lens[i];
+        uint8_t fl = 0;
+        for (uint32_t w = 0; w * 16 < L; w++) {
+            uint32_t code = 0, nb = 0;
+            const uint32_t cnt = std::min(16u, L - w * 16);
+            for (uint32_t j = 0; j < cnt; j++) {
+                uint32_t v = 0;
+                switch (sq[w * 16 + j]) { case 'A': v = 0; break; case 'C': v = 1; break; case 'G': v = 2; break; case 'T': v = 3; break; case 'N': nb |= 1u << j; break; default: other = true; }
+                code |= v << (2 * j);
+            }
+            codes[woff[i] + w] = code; mask[woff[i] + w] = (uint16_t) nb;
+            if (nb) fl = 1;
+        }
+        flags[i] = fl; anyN = anyN || fl;
+    }
+    if (other) return;
+    const SidePiece pc[7] = {{db.key.data(), n * 4}, {lens.data(), n * 4}, {ext.data(), n}, {flags.data(), n}, {codes.data(), words * 4}, {mask.data(), anyN ? words * 2 : 0}, {NULL, 0}};
+    sideWrite(path, SIDE_SEQ, anyN ? SIDE_F_HAS_NMASK : 0, n, words, 0, 0, db.dbtype, pc, 7);
+}
 int createdb(Args &a) {
     if (a.pos.size() < 2) die("Usage: carpedeam createdb <i:fastaFile1[.gz]> ... <i:fastaFileN[.gz]> <o:sequenceDB>");
     checkFlags("createdb", a, CREATEDB_FLAGS);
@@ -1120,6 +1157,7 @@ int createdb(Args &a) {
     const long dbType = iflag(a, "--dbtype", 0);        // 0 = guess from the first entries, as createdb does (createdb.cpp:40-45)
     if (dbType != 0 && dbType != 2) unsupported("createdb: --dbtype " + std::to_string(dbType) + " is not supported by the MI355X path (nucleotide sequences only; accepted: 0, 2)");
     if (createdbModule(files, a.pos.back(), iflag(a, "--shuffle", 1) != 0, (int) dbType, &err)) die(err);
+    seqSideFromText(a.pos.back());
     return EXIT_SUCCESS;
 }
 int convert2fasta(Args &a) {

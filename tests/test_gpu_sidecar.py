@@ -112,3 +112,31 @@ def test_rmdb_and_mvdb_take_the_side_car_along(tmp_path, dhigh_prefix):
     assert "prefilter records read" in log              # (a rename keeps sizes and times)
     run("rmdb", t("moved"))
     assert not [f for f in os.listdir(str(tmp_path)) if f.startswith("moved")]
+
+
+def test_createdb_leaves_the_sequence_side_car(tmp_path):
+    """createdb packs upper-case ACGTN reads on the host exactly as the device's upload does (kmermatcher on the side-car = kmermatcher on the
+    text); a read set with any other letter gets its side-car from the first module that uploads it"""
+    import numpy as np
+    from carpedeam_amd import build, synth
+    build.build()
+    t = lambda s: str(tmp_path / s)
+    rng = np.random.default_rng(7)
+    reads = synth.generate_strings(3000, seed=21, mixed=(30, 150))
+    reads = ["".join("N" if rng.random() < 0.01 else c for c in s) for s in reads]
+    open(t("r.fa"), "w").write("".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(reads)))
+    run("createdb", t("r.fa"), t("db"), "--shuffle", "0")
+    assert os.path.exists(t("db.cdmbin"))
+    log = run("kmermatcher", t("db"), t("pref"), *K_FLAGS, "--threads", "4")
+    assert "db: from its side-car" in log
+    run("kmermatcher", t("db"), t("pref_text"), *K_FLAGS, "--threads", "4", env={"CDM_SIDECAR": "0"})
+    assert db_files(t("pref")) == db_files(t("pref_text"))
+    log = run("rescorediagonal", t("db"), t("db"), t("pref"), t("aln"), *R_FLAGS, "--threads", "4")
+    run("rescorediagonal", t("db"), t("db"), t("pref_text"), t("aln_text"), *R_FLAGS, "--threads", "4", env={"CDM_SIDECAR": "0"})
+    assert db_files(t("aln")) == db_files(t("aln_text"))
+    # lower-case letters: the device's letter mapping and raw plane are not restated on the host
+    open(t("l.fa"), "w").write("".join(">r%d\n%s\n" % (i, s if i % 7 else s.lower()) for i, s in enumerate(reads[:500])))
+    run("createdb", t("l.fa"), t("ldb"), "--shuffle", "0")
+    assert not os.path.exists(t("ldb.cdmbin"))
+    log = run("kmermatcher", t("ldb"), t("lpref"), *K_FLAGS, "--threads", "4")
+    assert "ldb: from the text" in log and os.path.exists(t("ldb.cdmbin"))
