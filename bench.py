@@ -372,29 +372,33 @@ def main():
                     "stage_level": {"ancient_correction": {"ms": k_ms[10], "achieved": gbs(ALG_B_PER_BASE["ancient_correction"], k_ms[10]), "unit": "GB/s"}}}
             workload = "%d synthetic %d bp reads, dhigh, ancient_correction only on the alignments of one kmermatcher + rescorediagonal pass (BASELINE.json configs[1])" % (n, L)
         else:
-            # Dominant kernel by rocprofv3 --stats (profiles/): rx::k_rx_pass<u64 key, u32 value> (carpedeam_amd/csrc/radix.h), the
-            # hand-written onesweep pass of kmermatcher's sort 1: 3 launches per step (27 high k-mer bits, 9 per pass), each reads
-            # and writes every 12-byte tuple of the k-mer slots once - that is a launch's algorithmic traffic.  Its launch time is
-            # measured live: HIP events on the library's stream around each pass launch, summed by the library
-            # (cdm_ctx_last_kernel_ms(13); (14) = number of launches).
-            tuples_per_read = L - 20 + 2
-            n1 = tuples_per_read * n
+            # Dominant kernel by rocprofv3 --stats (profiles/): rx::k_rx_pass (carpedeam_amd/csrc/radix.h), the hand-written onesweep pass of
+            # kmermatcher's sort 1: 3 launches per step over the k-mer slots.  Reads of one length (this workload) go through them as
+            # 8-byte slot keys / slot tuples (round 5: a head pass that drops the empty slots + two passes inside the head digit's
+            # segments); other DBs as 12-byte (u64 key, u32 value) pairs.  A launch's algorithmic traffic = everything it sorts read once and
+            # written once; the library sums it (cdm_ctx_last_kernel_ms(15), GB) next to the launches' time, measured live with HIP
+            # events on its stream around each pass launch ((13) = ms, (14) = launches).
             launches = max(1, int(round(k_ms[14]))) if k_ms[14] > 0 else 3
             iter_ms = k_ms[13] / launches if k_ms[13] > 0 else 0.0
-            sort_bytes = 2.0 * 12.0 * n1
+            sort_bytes = (k_ms[15] * 1e9 / launches) if k_ms[15] > 0 else 2.0 * 12.0 * (L - 20 + 2) * n
             achieved = sort_bytes / (iter_ms * 1e-3) / 1e9 if iter_ms > 0 else 0.0
+            slot_layout = k_ms[15] > 0 and k_ms[15] * 1e9 / launches < 2.0 * 10.0 * (L - 20 + 2) * n
             traffic, traffic_total, traffic_from = None, None, None
             pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_50M*.json")))
             if n == 50_000_000 and L == 100 and world == 1 and pmcs:
                 try:
                     pj = json.load(open(pmcs[-1]))
-                    traffic = pj["kernels"]["rx::k_rx_pass<unsigned long, unsigned int>"]["hbm_bytes_per_launch"]
+                    names = [k for k in pj["kernels"] if k.startswith("rx::k_rx_pass<unsigned long, " + ("rx::NoValue" if slot_layout else "unsigned int")) and "small launches" not in k]
+                    by = sum(pj["kernels"][k]["hbm_bytes_per_launch"] * pj["kernels"][k]["launches"] for k in names)
+                    ln = sum(pj["kernels"][k]["launches"] for k in names)
+                    traffic = by / ln if ln else None
                     traffic_total = {"file": os.path.basename(pmcs[-1]), "hbm_bytes_per_step": pj.get("stages")}
                     traffic_from = "profiles/" + os.path.basename(pmcs[-1]) + " (rocprofv3 --pmc passes of this workload, committed; not collected in this run)"
                 except Exception:
                     traffic = None
             stages = {"kmermatcher": k_ms[8], "rescorediagonal": k_ms[9], "ancient_correction": k_ms[10], "ancient_read_assemble": k_ms[11]}
-            roof = {"bound": "hbm", "kernel": "rx::k_rx_pass<u64 key, u32 value> (hand-written onesweep radix pass, 9 bits; kmermatcher sort 1: 3 passes over the k-mer slots)",
+            roof = {"bound": "hbm", "kernel": ("rx::k_rx_pass<u64 slot keys / slot tuples> (hand-written onesweep radix passes of kmermatcher's sort 1 on 8-byte tuples: head pass + 2 passes inside its segments; average over the 3 launches)"
+                                               if slot_layout else "rx::k_rx_pass<u64 key, u32 value> (hand-written onesweep radix pass, 9 bits; kmermatcher sort 1: 3 passes over the k-mer slots)"),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
                     # frac is the dominant kernel's per-launch figure; frac_8d prices the whole step on SURVEY.md 8(d)'s bytes (32.2 B/base:
                     # every radix pass beyond one write + one read of the tuples is overhead there) - the smaller, stricter number

@@ -1935,6 +1935,9 @@ int sortAndGroup() {
         uint64_t *res = nullptr; unsigned long long liveSlots = 0;
         if (int rc = rx::sortSlotKeys(s, ctx->cuCount, k0.p, k1.p, (uint64_t) kmerSlots, 2 * k, lowBits, headCounted ? headHist.p : nullptr, segBuf.p, liveSlots, res, &ctx->lastMs[13], &ctx->lastMs[14])) return rc;
         keys = DoubleBuf<uint64_t>(res, res == k0.p ? k1.p : k0.p); vals = res == k0.p ? DoubleBuf<V>(vA, vB) : DoubleBuf<V>(vB, vA);     // (region 2's values follow its keys' buffer)
+        // what those launches move at the least, in GB: the head pass reads every slot's key and writes the real ones' tuples, the passes
+        // inside the segments read and write every tuple (bench.py's roofline figure)
+        ctx->lastMs[15] = (float) (((double) kmerSlots * 8.0 + (double) liveSlots * 8.0 + (double) (ctx->lastMs[14] - 1.f) * (double) liveSlots * 16.0) / 1e9);
         live = liveSlots; geom.seg = segBuf.p; slotSorted = true;
     } else
     if (nparts > 1 && kmerSlots && !lsdOnly && !split) {      // (split by reads: what arrived has no empty slots)
@@ -1949,6 +1952,7 @@ int sortAndGroup() {
         bool inFirst = true;        // "first" = (k1, v1) here
         if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, k1.p, k0.p, vB, vA, (uint64_t) m, lowBits, sortTop, inFirst, &ctx->lastMs[13])) return rc;
         ctx->lastMs[14] = (float) ((sortTop - lowBits + rx::BITS - 1) / rx::BITS);
+        ctx->lastMs[15] = (float) ((double) ctx->lastMs[14] * (double) m * 2.0 * (8.0 + sizeof(V)) / 1e9);
         uint64_t *kRes = inFirst ? k1.p : k0.p; V *vRes = inFirst ? vB : vA;
         hipMemsetAsync(kRes + m, 0xFF, (size_t) (kmerSlots - m) * 8, s);        // (the values of empty slots are never read)
         keys = DoubleBuf<uint64_t>(kRes, inFirst ? k0.p : k1.p); vals = DoubleBuf<V>(vRes, inFirst ? vA : vB);
@@ -1956,6 +1960,7 @@ int sortAndGroup() {
         bool inFirst = true;
         if (int rc = rx::sortPairs<uint64_t, V>(s, ctx->cuCount, k0.p, k1.p, vA, vB, (uint64_t) kmerSlots, lowBits, sortTop, inFirst, &ctx->lastMs[13])) return rc;
         ctx->lastMs[14] = (float) ((sortTop - lowBits + rx::BITS - 1) / rx::BITS);     // its launches
+        ctx->lastMs[15] = (float) ((double) ctx->lastMs[14] * (double) kmerSlots * 2.0 * (8.0 + sizeof(V)) / 1e9);
         keys = DoubleBuf<uint64_t>(inFirst ? k0.p : k1.p, inFirst ? k1.p : k0.p); vals = DoubleBuf<V>(inFirst ? vA : vB, inFirst ? vB : vA);
     }
     hipEventRecord(ctx->ev1, s);

@@ -55,7 +55,8 @@ void *cdm_ctx_stream(cdm_ctx *ctx);
  * pass launches), 6: sort 2 (run records, their radix sort, aggregation / unit sorters), 7: sort 1 on the whole-sequence hash tuples;
  * 8..11: the WHOLE stage call (everything it launched, host round trips between kernels included) of kmermatcher, rescorediagonal,
  * ancient_correction, ancient_read_assemble; 13: the radix PASS launches of sort 1 on the k-mer slots alone, summed, 14: how many
- * launches that sum covers (bench.py's roofline figure).
+ * launches that sum covers, 15: the bytes those launches move at the least, in GB - every pair or tuple they sort read once and
+ * written once per launch (bench.py's roofline figure).
  * Returns a negative value when that stage has not run. */
 float cdm_ctx_last_kernel_ms(cdm_ctx *ctx, int which);
 

@@ -2,8 +2,17 @@
 
     python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<command>"
 
-Counter values are KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM section), so it is
-doubled.  Kernels are grouped by a short name; `hbm_bytes_per_launch` = (2 * fetch + write) / launches.
+Counter values are KiB.  What FETCH_SIZE means on this machine was calibrated in round 5 (scripts/probes/pmc_calib.hip,
+profiles/r05_pmc_calibration.json): the counter is 64 bytes per request of the L2 to the fabric WHATEVER the request's size -
+  * a streaming read (4, 8 or 16 bytes per lane, consecutive lanes) goes out as 128-byte requests: the counter shows HALF the bytes
+    (factor 2.000 on all three widths, and on aligned 128-byte segments gathered at random);
+  * a random segment of 32 or 64 bytes is one 64-byte request: the counter shows 64 bytes per segment (1.0 x a 64-byte segment, 2 x
+    the useful bytes of a 32-byte one; a random 4-byte word: 64 bytes);
+  * WRITE_SIZE is exact for streaming stores and for scattered runs of 64 bytes and more.
+So the correction is per kernel CLASS, not global (round 4 doubled every kernel): streaming kernels x 2; gather kernels (a thread or a
+few lanes per randomly placed record / target / segment: k_rescore, k_correct*, k_xr_*, k_extend, the record and entry walkers) x 1 -
+their requests are single 64-byte lines for the most part; where a gather covers both halves of a 128-byte line the true figure lies
+between x 1 and x 2 (`fetch_bytes_upper`).  `hbm_bytes_per_launch` = (factor * fetch + write) / launches.
 """
 import collections
 import csv
@@ -60,27 +69,40 @@ def load(path, counter):
     return tot, {k: len(v) for k, v in launches.items()}
 
 
+# kernels whose reads are gathers of records / targets / segments at random places (one 64-byte request each for the most part)
+GATHER = ("k_rescore", "k_correct", "k_xr_score", "k_xr_extend", "k_extend", "k_hamming", "k_contig_stats", "aggv::k_unit_agg", "aggv::k_vote_entries", "aggv::k_rle_segment",
+          "runsort::k_unit_bounds", "runsort::k_seg_list", "runsort::k_unit_sort", "runsort::k_gather_ranges", "runsort::k_run_gather", "k_seg_place", "k_write", "k_cyc_hits",
+          "k_rec_place_big", "k_big_", "bucket::k_big_copy", "k_stale_tail", "k_out_meta", "k_mark_active")
+
+
+def fetch_factor(kernel):
+    return 1.0 if any(kernel.startswith(g) or ("::" not in g and kernel.split("<")[0] == g) for g in GATHER) else 2.0
+
+
 def main():
     fetch, nl = load(sys.argv[1], "FETCH_SIZE")
     write, _ = load(sys.argv[2], "WRITE_SIZE")
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), " + sys.argv[4],
-           "units": "bytes; FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section)",
+           "units": "bytes; FETCH_SIZE = 64 B per request whatever its size (profiles/r05_pmc_calibration.json): x 2 for streaming kernels (128-byte requests), "
+                    "x 1 for gather kernels (single 64-byte lines; fetch_bytes_upper = x 2 bounds them from above)",
            "kernels": {}}
-    for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
-        f, w, n = 2 * fetch[k], write.get(k, 0.0), max(1, nl.get(k, 1))
+    corrected = {k: fetch_factor(k) * fetch[k] for k in fetch}
+    for k in sorted(fetch, key=lambda k: -(corrected[k] + write.get(k, 0))):
+        f, w, n = corrected[k], write.get(k, 0.0), max(1, nl.get(k, 1))
         if f + w < 1e8:
             continue
-        out["kernels"][k] = {"launches": n, "fetch_bytes": f, "write_bytes": w, "hbm_bytes_per_launch": (f + w) / n}
+        out["kernels"][k] = {"launches": n, "class": "gather" if fetch_factor(k) == 1.0 else "stream", "fetch_counter_bytes": fetch[k], "fetch_bytes": f, "fetch_bytes_upper": 2 * fetch[k],
+                             "write_bytes": w, "hbm_bytes_per_launch": (f + w) / n}
     # per-stage totals of the chain (one step: the PMC passes run `bench.py --steps 1 --warmup 0`)
     stage_of = (("kmermatcher", ("k_seq_hash", "k_extract", "rocprim", "rx::", "k_bucket_groups", "k_groups", "runsort::", "k_unit_sort", "k_block_sort", "k_bucket_sort", "k_seg_",
-                                 "aggv::", "k_self", "k_offsets", "k_len_keys", "k_slot_", "k_live_count", "k_stale_tail", "k_reduce_stats", "k_big_", "k_head_segment", "k_count_hash", "cdmscan")),
+                                 "aggv::", "k_self", "k_offsets", "k_len_keys", "k_slot_", "k_live_count", "k_stale_tail", "k_reduce_stats", "k_big_", "k_head_segment", "k_count_hash", "cdmscan", "k_block_heads", "k_rec_")),
                 ("rescorediagonal", ("k_rescore", "k_expand", "k_count_valid", "k_scatter", "k_min_score")),
                 ("ancient_correction", ("k_correct", "k_mark_active<", "k_mark_active(")),
                 ("ancient_read_assemble", ("k_extend", "k_xr_", "k_write", "k_out_meta", "k_mark_active2")))
     stages = {name: 0.0 for name, _ in stage_of}
     stages["other (synthetic reads, metadata, copies)"] = 0.0
     for k in fetch:
-        b = 2 * fetch[k] + write.get(k, 0.0)
+        b = corrected[k] + write.get(k, 0.0)
         for name, pats in stage_of:
             if any(p in k for p in pats) and not (name == "ancient_correction" and "k_mark_active2" in k):
                 stages[name] += b
