@@ -8,10 +8,14 @@
 // re-alignment of parked hits - host code of the library (host/contigmerge.cpp), compiled like the reference.
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <memory>
+#include <string>
+#include <vector>
 
 #include "common.h"
 #include "devutil.h"
+#include "contigqueue.h"
 
 namespace {
 struct StatArgs {
@@ -95,8 +99,60 @@ bool cdm_host_pack(const std::vector<std::string> &seqs, HostBuf<char> &data, st
 void cdm_host_split(const char *blob, const std::vector<uint64_t> &offs, const std::vector<uint32_t> &lens, std::vector<SeqView> &seqs);
 int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
                           const cdm_aln *recs, const ContigStat *stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
-                          float mergeSeqIdThr, std::vector<uint32_t> &grownIdx, std::vector<std::string> &grownSeqs, std::vector<uint8_t> &outExt, std::string *err);
+                          float mergeSeqIdThr, std::vector<uint32_t> &grownIdx, std::vector<std::string> &grownSeqs, std::vector<uint8_t> &outExt, std::string *err,
+                          const uint8_t *only);
 
+namespace {
+// The queue on the host (all queries, or those `only` marks): statistics, records and the DB come down, host/contigmerge.cpp runs, the
+// grown contigs go up as a DB of their own.  grown may come back NULL (nothing grew).
+int hostQueue(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float mergeSeqIdThr, const ContigStat *dStats, const uint8_t *only,
+              std::vector<uint32_t> &grownIdx, cdm_seqdb **grown, std::vector<uint8_t> &outExt) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n = (uint32_t) db->n;
+    const uint64_t nRec = alns->count;
+    const bool timing = cdmGetenv("CDM_TIMING") != nullptr;
+    auto tNow = [] { return std::chrono::steady_clock::now(); };
+    auto tPrev = tNow();
+    auto lap = [&](const char *what) { if (timing) { const auto t = tNow(); fprintf(stderr, "  contig merge: %-28s %.3f s\n", what, std::chrono::duration<double>(t - tPrev).count()); tPrev = t; } };
+    HostBuf<ContigStat> stats; HostBuf<cdm_aln> recs; std::vector<uint64_t> aoff(n + 1);
+    if (!stats.alloc(nRec) || !recs.alloc(nRec)) { cdm_set_error("cdm_contig_merge: out of host memory"); return CDM_ERR_INVALID; }
+    std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
+    CDM_HIP(hipMemcpyAsync(stats.data(), dStats, nRec * sizeof(ContigStat), hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipMemcpyAsync(aoff.data(), alns->off, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (nRec) CDM_HIP(hipMemcpyAsync(recs.data(), alns->rec, nRec * sizeof(cdm_aln), hipMemcpyDeviceToHost, s));
+    CDM_HIP(hipStreamSynchronize(s));
+    if (int rc = cdm_seqdb_meta(ctx, db, lens.data(), keys.data(), ext.data())) return rc;
+    std::vector<uint64_t> offs(n); uint64_t tot = 0;
+    for (uint32_t i = 0; i < n; i++) { offs[i] = tot; tot += lens[i] + 1; }
+    HostBuf<char> blob;
+    if (!blob.alloc(tot)) { cdm_set_error("cdm_contig_merge: out of host memory"); return CDM_ERR_INVALID; }
+    lap("statistics + records down");
+    if (int rc = cdm_seqdb_download(ctx, db, blob.data(), offs.data())) return rc;
+    lap("sequences down");
+    std::vector<SeqView> seqs(n); std::vector<std::string> grownSeqs;
+    cdm_host_split(blob.data(), offs, lens, seqs);      // views into the blob, which stays until the host part is done
+    lap("split");
+    std::string err;
+    if (int rc = cdm_contig_merge_host(seqs, keys, ext, aoff, recs.data(), stats.data(), ctx->mats, par, mergeSeqIdThr, grownIdx, grownSeqs, outExt, &err, only)) { cdm_set_error("%s", err.c_str()); return rc; }
+    lap("queues + extension (host)");
+    { std::vector<SeqView>().swap(seqs); blob.release(); stats.release(); recs.release(); }
+    const size_t m = grownIdx.size();
+    *grown = nullptr;
+    if (m) {
+        std::vector<uint64_t> gOff; std::vector<uint32_t> gLen, gKey(m);
+        HostBuf<char> data;
+        if (!cdm_host_pack(grownSeqs, data, gOff, gLen)) { cdm_set_error("cdm_contig_merge: out of host memory"); return CDM_ERR_INVALID; }
+        for (size_t j = 0; j < m; j++) gKey[j] = keys[grownIdx[j]];
+        std::vector<std::string>().swap(grownSeqs);
+        lap("pack");
+        if (int rc = cdm_seqdb_upload(ctx, data.data(), gOff.data(), gLen.data(), gKey.data(), nullptr, m, grown)) return rc;
+        lap("upload");
+    }
+    return CDM_OK;
+}
+}  // namespace
+
+// CDM_CONTIG_QUEUE=host: the round-4 path for every query (what --unsafe 1 takes in any case: its consensus works on the host's strings)
 extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float mergeSeqIdThr, cdm_seqdb **out) {
     if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_contig_merge: NULL argument"); return CDM_ERR_INVALID; }
     CDM_REFUSE_UNDEFINED_ALNS(alns, "cdm_contig_merge");
@@ -117,49 +173,45 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
         hipLaunchKernelGGL(k_contig_stats, CDM_GRID((std::min(slice, nRec - first) * 64 + 255) / 256, 256), dim3(256), 0, s, a);
     }
     hipEventRecord(ctx->ev1, s);
-    // everything else is per-query bookkeeping on the host: sequences, records and the per-record statistics come down once
     const bool timing = cdmGetenv("CDM_TIMING") != nullptr;
-    auto tNow = [] { return std::chrono::steady_clock::now(); };
-    auto tPrev = tNow();
-    auto lap = [&](const char *what) { if (timing) { const auto t = tNow(); fprintf(stderr, "  contig merge: %-28s %.3f s\n", what, std::chrono::duration<double>(t - tPrev).count()); tPrev = t; } };
-    HostBuf<ContigStat> stats; HostBuf<cdm_aln> recs; std::vector<uint64_t> aoff(n + 1);
-    if (!stats.alloc(nRec) || !recs.alloc(nRec)) { cdm_set_error("cdm_contig_merge: out of host memory"); return CDM_ERR_INVALID; }
-    std::vector<uint32_t> lens(n), keys(n); std::vector<uint8_t> ext(n);
-    CDM_HIP(hipMemcpyAsync(stats.data(), dStats.p, nRec * sizeof(ContigStat), hipMemcpyDeviceToHost, s));
-    CDM_HIP(hipMemcpyAsync(aoff.data(), alns->off, (n + 1) * 8, hipMemcpyDeviceToHost, s));
-    if (nRec) CDM_HIP(hipMemcpyAsync(recs.data(), alns->rec, nRec * sizeof(cdm_aln), hipMemcpyDeviceToHost, s));
-    CDM_HIP(hipStreamSynchronize(s));
-    hipEventElapsedTime(&ctx->lastMs[12], ctx->ev0, ctx->ev1);
-    if (int rc = cdm_seqdb_meta(ctx, db, lens.data(), keys.data(), ext.data())) return rc;
-    std::vector<uint64_t> offs(n); uint64_t tot = 0;
-    for (uint32_t i = 0; i < n; i++) { offs[i] = tot; tot += lens[i] + 1; }
-    HostBuf<char> blob;
-    if (!blob.alloc(tot)) { cdm_set_error("cdm_contig_merge: out of host memory"); return CDM_ERR_INVALID; }
-    lap("statistics + records down");
-    if (int rc = cdm_seqdb_download(ctx, db, blob.data(), offs.data())) return rc;
-    lap("sequences down");
-    std::vector<SeqView> seqs(n); std::vector<uint32_t> grownIdx; std::vector<std::string> grownSeqs; std::vector<uint8_t> outExt;
-    cdm_host_split(blob.data(), offs, lens, seqs);      // views into the blob, which stays until the host part is done
-    lap("split");
-    std::string err;
-    if (int rc = cdm_contig_merge_host(seqs, keys, ext, aoff, recs.data(), stats.data(), ctx->mats, par, mergeSeqIdThr, grownIdx, grownSeqs, outExt, &err)) { cdm_set_error("%s", err.c_str()); return rc; }
-    lap("queues + extension (host)");
-    // The result is the input DB with the grown contigs in place of their queries: only those go up (as a small DB of their own),
-    // everything else is copied on the device (cdm_seqdb_overlay).  Same keys, new lengths and flags.
-    { std::vector<SeqView>().swap(seqs); blob.release(); stats.release(); recs.release(); }
-    const size_t m = grownIdx.size();
-    cdm_seqdb *grown = nullptr;
-    if (m) {
-        std::vector<uint64_t> gOff; std::vector<uint32_t> gLen, gKey(m);
-        HostBuf<char> data;
-        if (!cdm_host_pack(grownSeqs, data, gOff, gLen)) { cdm_set_error("cdm_contig_merge: out of host memory"); return CDM_ERR_INVALID; }
-        for (size_t j = 0; j < m; j++) gKey[j] = keys[grownIdx[j]];
-        std::vector<std::string>().swap(grownSeqs);
-        lap("pack");
-        if (int rc = cdm_seqdb_upload(ctx, data.data(), gOff.data(), gLen.data(), gKey.data(), nullptr, m, &grown)) return rc;
+    auto tPrev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (timing) { const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  contig merge: %-28s %.3f s\n", what, std::chrono::duration<double>(t - tPrev).count()); tPrev = t; } };
+    const char *where = cdmGetenv("CDM_CONTIG_QUEUE");
+    const bool onHost = par->unsafe != 0 || (where && !strcmp(where, "host"));
+    std::vector<uint32_t> grownIdx; std::vector<uint8_t> outExt; cdm_seqdb *grown = nullptr;
+    if (onHost) {
+        if (int rc = hostQueue(ctx, db, alns, par, mergeSeqIdThr, dStats.p, nullptr, grownIdx, &grown, outExt)) return rc;
+        hipEventElapsedTime(&ctx->lastMs[12], ctx->ev0, ctx->ev1);
+        tPrev = std::chrono::steady_clock::now();
+        const int rcUp = cdm_seqdb_overlay(ctx, db, grown, grownIdx.data(), outExt.data(), out);
+        if (grown) cdm_seqdb_free(grown);
+        lap("overlay");
+        return rcUp;
     }
-    const int rcUp = cdm_seqdb_overlay(ctx, db, grown, grownIdx.data(), outExt.data(), out);
+    CqResult res;
+    if (int rc = cdm_contig_queue_device(ctx, db, alns, par, mergeSeqIdThr, meta.p, owner.p, dStats.p, &res)) { if (res.grown) cdm_seqdb_free(res.grown); return rc; }
+    hipEventElapsedTime(&ctx->lastMs[12], ctx->ev0, ctx->ev1);
+    tPrev = std::chrono::steady_clock::now();
+    if (!res.nHandedBack) {
+        const int rcUp = cdm_seqdb_overlay(ctx, db, res.grown, res.grownIdx.data(), res.outExt.data(), out);
+        if (res.grown) cdm_seqdb_free(res.grown);
+        lap("overlay");
+        return rcUp;
+    }
+    // the few queries the device handed back: the host code on those alone, its contigs overlaid on the device's
+    cdm_seqdb *mid = nullptr;
+    int rc = cdm_seqdb_overlay(ctx, db, res.grown, res.grownIdx.data(), res.outExt.data(), &mid);
+    if (res.grown) cdm_seqdb_free(res.grown);
+    if (rc != CDM_OK) return rc;
+    lap("overlay");
+    std::vector<uint8_t> hostExt;
+    rc = hostQueue(ctx, db, alns, par, mergeSeqIdThr, dStats.p, res.handedBack.data(), grownIdx, &grown, hostExt);
+    if (rc != CDM_OK) { cdm_seqdb_free(mid); return rc; }
+    for (uint32_t i = 0; i < n; i++) if (res.handedBack[i]) res.outExt[i] = hostExt[i];
+    tPrev = std::chrono::steady_clock::now();
+    rc = cdm_seqdb_overlay(ctx, mid, grown, grownIdx.data(), res.outExt.data(), out);
     if (grown) cdm_seqdb_free(grown);
-    lap("upload + overlay");
-    return rcUp;
+    cdm_seqdb_free(mid);
+    lap("overlay of the handed-back queries");
+    return rc;
 }

@@ -138,19 +138,26 @@ void overlapCounts(const char *qa, const char *fwd, const char *back, size_t fro
 // is damage rather than a true mismatch.  The prior for "the two sequences match here" mixes the overlap's own match rate with a
 // length prior that falls off as 1.4e-9 / length^3 between 10 and 1e5 letters (in logs); the likelihood of the observed letter
 // under damage comes from the damage matrix.  Float literals and double variables alternate exactly as in the reference.
-double deamMatches(unsigned overlap, unsigned score, double damageLik) {
+// In two parts since round 5: the length prior is the only place a logarithm enters - the C library's, whose last bits the device
+// cannot restate, so the device queue (contigqueue.hip) reads it from a table this very function fills (cdm_contig_host_tables) - and
+// the rest is IEEE arithmetic the device repeats operation by operation.  The one contraction g++ makes at this file's flags that is
+// not exact either way (1 + ratio * odds, a fused multiply-add) is spelled out, so that both sides say the same thing.
+inline double lengthPriorOf(unsigned overlap) {
     const double logConst = std::log(1.4e-9);
     const unsigned longest = 1e5;
     auto logPrior = [logConst](unsigned len) { return logConst - 3.0 * std::log(len); };
     const double atShortest = logPrior(10), atLongest = logPrior(longest), here = logPrior(std::min(overlap, longest));
     const double shareOfRange = (static_cast<double>(std::abs(here) - std::abs(atLongest))) / static_cast<double>((std::abs(atShortest) - std::abs(atLongest)));
-    const double lengthPrior = 1 - shareOfRange;
+    return 1 - shareOfRange;
+}
+inline double deamFromPrior(unsigned overlap, unsigned score, double damageLik, double lengthPrior) {
     const double pMatch = 0.5f * ((((static_cast<double>(score) + 3.0f * overlap) / 5.0f) + 0.9f) / (overlap + 1)) + 0.5f * lengthPrior;
     const double pMismatch = 1 - pMatch;
     const double likelihoodRatio = pMismatch / damageLik;
     const double priorOdds = (1 - pMatch) / pMatch;
-    return 1 / (1 + likelihoodRatio * priorOdds);
+    return 1 / std::fma(likelihoodRatio, priorOdds, 1.0);
 }
+double deamMatches(unsigned overlap, unsigned score, double damageLik) { return deamFromPrior(overlap, score, damageLik, lengthPriorOf(overlap)); }
 // selectNuclFragmentToExtendContigs (:73-91)
 bool selectFragment(Queue &q, uint32_t queryKey, Res &out) {
     while (!q.empty()) {
@@ -245,10 +252,31 @@ bool cdm_host_pack(const std::vector<std::string> &seqs, HostBuf<char> &data, st
     for (long j = 0; j < m; j++) memcpy(data.data() + off[j], seqs[j].data(), seqs[j].size());
     return true;
 }
-// grownIdx (ascending) / grownSeqs: the queries that were extended and what they became; outExt: the wasExtended flag of every sequence
+// The C library's functions the comparator's last bits hang on, as tables for the device queue (contigqueue.hip): lgammaf over every
+// float in [1, 2^lgTop), logf over every float in [1, 2^lfTop) (entry i: the float whose bits are those of 1.0f plus i), the double
+// log of the integers below nInt, the length prior of deamMatches for overlaps 0 .. 100 000.  A table IS the function: exact by
+// construction, whatever the library's version.  About a second on 16 threads for 19 + 20 binades.
+void cdm_contig_host_tables(float *lgam, int lgTop, float *lf, int lfTop, double *logInt, size_t nInt, double *lenPrior) {
+    const long nLg = (long) lgTop << 23, nLf = (long) lfTop << 23;
+#pragma omp parallel num_threads(cdm_host_threads())
+    {
+#pragma omp for schedule(static) nowait
+        for (long i = 0; i < nLg; i++) { const uint32_t u = 0x3F800000u + (uint32_t) i; float x; memcpy(&x, &u, 4); lgam[i] = lgammaQuiet(x); }
+#pragma omp for schedule(static) nowait
+        for (long i = 0; i < nLf; i++) { const uint32_t u = 0x3F800000u + (uint32_t) i; float x; memcpy(&x, &u, 4); lf[i] = std::log(x); }
+#pragma omp for schedule(static) nowait
+        for (long i = 0; i < (long) nInt; i++) logInt[i] = std::log((size_t) i);
+#pragma omp for schedule(static)
+        for (long i = 0; i <= 100000; i++) lenPrior[i] = lengthPriorOf((unsigned) i);
+    }
+}
+// grownIdx (ascending) / grownSeqs: the queries that were extended and what they became; outExt: the wasExtended flag of every sequence.
+// only: NULL, or a byte per query - the queries with a zero are left alone (no entry in grownIdx, outExt = 0): the few queries the
+// device queue hands back (contigqueue.hip)
 int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<uint32_t> &keys, const std::vector<uint8_t> &ext, const std::vector<uint64_t> &aoff,
                           const cdm_aln *recs, const ContigStat *stats, const long double mats[2][11][4][4], const cdm_ancient_params *par,
-                          float mergeSeqIdThr, std::vector<uint32_t> &grownIdx, std::vector<std::string> &grownSeqs, std::vector<uint8_t> &outExt, std::string *err) {
+                          float mergeSeqIdThr, std::vector<uint32_t> &grownIdx, std::vector<std::string> &grownSeqs, std::vector<uint8_t> &outExt, std::string *err,
+                          const uint8_t *only) {
     const size_t n = seqs.size();
     grownIdx.clear(); grownSeqs.clear(); outExt.assign(n, 0);
     std::vector<std::vector<std::pair<uint32_t, std::string>>> perThread((size_t) cdm_host_threads());
@@ -265,6 +293,7 @@ int cdm_contig_merge_host(const std::vector<SeqView> &seqs, const std::vector<ui
         std::vector<std::pair<uint32_t, std::string>> &mine = perThread[(size_t) omp_get_thread_num()];
 #pragma omp for schedule(dynamic, 100)
         for (size_t id = 0; id < n; id++) {
+            if (only && !only[id]) continue;
             const uint32_t queryKey = keys[id];
             // useReverse[target] of the reference (:136-137,198,212): a per-thread array every record of the query writes, read back
             // for the targets in the queue - i.e. the orientation of the query's LAST record with that target

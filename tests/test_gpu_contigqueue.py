@@ -1,0 +1,115 @@
+"""ancient_contig_merge's queue and extension loop on the device (csrc/contigqueue.hip; ancientContigsResults.cpp:25-70, 276-470)
+against the same loop on the host (csrc/host/contigmerge.cpp, CDM_CONTIG_QUEUE=host) and the reference's goldens: the comparator from
+the tables of the C library's own lgammaf / logf, libstdc++'s heap step for step, the rounds of the extension, the queries handed back
+to the host and overlaid."""
+import os
+
+import numpy as np
+import pytest
+
+from carpedeam_amd import capi, synth
+from gpuutil import diff_keys, seqdb_to_keyed
+from test_contig_phase import CASES, cgold, contig_input
+
+pytestmark = pytest.mark.gpu
+
+
+def ctx_with_damage(dhigh_prefix):
+    ctx = capi.Ctx(0)
+    ctx.damage_load(dhigh_prefix)
+    return ctx
+
+
+@pytest.mark.parametrize("name,last_it,step", CASES)
+def test_device_queue_equals_host_queue_on_the_goldens(dhigh_prefix, monkeypatch, name, last_it, step):
+    ctx = ctx_with_damage(dhigh_prefix)
+    corr = ctx.upload_keyed_seqdb(cgold(name, "ccorr", step))
+    _, keys, _ = corr.meta()
+    aoff, arec = capi.parse_aln_db(cgold(name, "caln", step), keys)
+    want = cgold(name, "cmerge", step)
+    for where in ("device", "host"):
+        monkeypatch.setenv("CDM_CONTIG_QUEUE", where)
+        merged = ctx.contig_merge(corr, ctx.upload_alns(corr, aoff, arec))
+        assert not diff_keys(seqdb_to_keyed(*merged.download()), want), where
+        ext = merged.meta()[2]
+        if where == "device":
+            ext_dev = ext.copy()
+        else:
+            assert np.array_equal(ext, ext_dev)
+
+
+@pytest.mark.parametrize("every", [1, 3])
+def test_queries_handed_back_to_the_host_are_overlaid(dhigh_prefix, monkeypatch, every):
+    """CDM_CONTIG_HAND_BACK_EVERY=k: every k-th query takes the way of a comparison too close to call - the host code on those queries alone,
+    its contigs over the device's"""
+    ctx = ctx_with_damage(dhigh_prefix)
+    name, step = "mixed3k", 1
+    corr = ctx.upload_keyed_seqdb(cgold(name, "ccorr", step))
+    _, keys, _ = corr.meta()
+    aoff, arec = capi.parse_aln_db(cgold(name, "caln", step), keys)
+    monkeypatch.setenv("CDM_CONTIG_HAND_BACK_EVERY", str(every))
+    merged = ctx.contig_merge(corr, ctx.upload_alns(corr, aoff, arec))
+    assert not diff_keys(seqdb_to_keyed(*merged.download()), cgold(name, "cmerge", step))
+
+
+def loop(ctx, n, seed, iters_reads, iters_contigs, monkeypatch, where):
+    """the workflow loop through the C ABI (as bench.py --config 5 runs it); -> the DB after every contig iteration"""
+    monkeypatch.setenv("CDM_CONTIG_QUEUE", where)
+    db = ctx.synth(n, 60, 150, seed)
+    kp = capi.KmerParams.reads_default()
+    kc = capi.KmerParams.reads_default()
+    kc.kmer_size, kc.include_only_extendable = 22, 1
+    par = capi.AncientParams.default()
+    par.max_seq_len = 200000
+    out = []
+    for it in range(iters_reads + iters_contigs):
+        alns = ctx.rescore(db, ctx.kmermatch(db, kp if it < iters_reads else kc))
+        corr = ctx.correct(db, alns, par)
+        if it < iters_reads:
+            db = ctx.extend(corr, alns, par)
+        else:
+            db = ctx.contig_merge(corr, alns, par)
+            lens, keys, ext = db.meta()
+            out.append((db.download()[0], lens.copy(), ext.copy()))
+    return out
+
+
+def test_seven_contig_iterations_device_against_host(dhigh_prefix, monkeypatch):
+    """200 000 mixed-length reads, 5 read + 7 contig iterations: the DB after every contig iteration, queue on the device against queue on
+    the host - letters, lengths, wasExtended flags; contigs grow over many rounds (parked hits re-aligned and pushed again)"""
+    ctx = ctx_with_damage(dhigh_prefix)
+    dev = loop(ctx, 200_000, 2, 5, 7, monkeypatch, "device")
+    host = loop(ctx, 200_000, 2, 5, 7, monkeypatch, "host")
+    grew = 0
+    for it, ((d, dl, de), (h, hl, he)) in enumerate(zip(dev, host)):
+        assert np.array_equal(dl, hl), it
+        assert np.array_equal(de, he), it
+        assert d == h, it
+        grew += int(de.sum())
+    assert grew > 10_000 and int(dev[-1][1].max()) > 1000
+
+
+def test_max_seq_len_stops_the_growth(dhigh_prefix, monkeypatch):
+    """--max-seq-len small enough to bite: the loop leaves its queue non-empty (:362, :403) - same contigs either way"""
+    ctx = ctx_with_damage(dhigh_prefix)
+    res = {}
+    for where in ("device", "host"):
+        monkeypatch.setenv("CDM_CONTIG_QUEUE", where)
+        db = ctx.synth(60_000, 60, 150, 5)
+        kp = capi.KmerParams.reads_default()
+        kc = capi.KmerParams.reads_default()
+        kc.kmer_size, kc.include_only_extendable = 22, 1
+        par = capi.AncientParams.default()
+        par.max_seq_len = 200000
+        for it in range(6):
+            if it == 3:
+                par.max_seq_len = 260
+                longest_read = int(db.meta()[0].max())
+            alns = ctx.rescore(db, ctx.kmermatch(db, kp if it < 3 else kc))
+            corr = ctx.correct(db, alns, par)
+            db = ctx.extend(corr, alns, par) if it < 3 else ctx.contig_merge(corr, alns, par)
+        res[where] = (db.download()[0], db.meta())
+    assert res["device"][0] == res["host"][0]
+    assert np.array_equal(res["device"][1][2], res["host"][1][2])
+    assert int(res["device"][1][0].max()) <= max(longest_read, 259)          # nothing reaches 260 letters by growing
+    assert int((res["device"][1][0] > 200).sum()) > 100
