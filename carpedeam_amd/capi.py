@@ -64,7 +64,7 @@ EXPORTS = [
     "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_seqdb_export_packed", "cdm_seqdb_import_packed", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
     "cdm_rescore_hamming", "cdm_pool_headroom", "cdm_pool_stats", "cdm_env_refresh",
     "cdm_comm_unique_id", "cdm_comm_create_rccl", "cdm_comm_create_ops", "cdm_comm_free", "cdm_comm_rank", "cdm_comm_world", "cdm_kmermatch_dist",
-    "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist", "cdm_comm_owned", "cdm_kpart_gather_at", "cdm_comm_standin_group", "cdm_comm_create_standin", "cdm_kpart_set_range",
+    "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist", "cdm_contig_iteration_dist", "cdm_comm_owned", "cdm_kpart_gather_at", "cdm_comm_standin_group", "cdm_comm_create_standin", "cdm_kpart_set_range",
 ]
 
 
@@ -167,6 +167,7 @@ def lib():
                 l.cdm_comm_owned.argtypes = [vp, C.c_uint64, vp]
                 l.cdm_comm_world.argtypes = [vp]
             l.cdm_reads_iteration_dist.argtypes = [vp, vp, vp, C.POINTER(KmerParams), C.POINTER(RescoreParams), C.POINTER(AncientParams), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+            l.cdm_contig_iteration_dist.argtypes = [vp, vp, vp, C.POINTER(KmerParams), C.POINTER(RescoreParams), C.POINTER(AncientParams), C.c_float, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         try:
             l.cdm_env_refresh.restype = None
         except AttributeError:          # (CDM_LIB names an older build of the library - bisecting: it reads its switches with getenv)
@@ -608,6 +609,13 @@ class Comm:
         hh, ah, ch, nh = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         _check(lib().cdm_reads_iteration_dist(self.ctx.h, self.h, db.h, C.byref(kpar), C.byref(rpar), C.byref(apar), C.byref(hh), C.byref(ah), C.byref(ch), C.byref(nh)))
         return Hits(self.ctx, hh, db.n), Alns(self.ctx, ah, db.n), SeqDb(self.ctx, ch), SeqDb(self.ctx, nh)
+
+    def contig_iteration(self, db, kpar, rpar=None, apar=None, merge_seq_id=0.99):
+        """one iteration of the contig loop over the ranks, up to ancient_contig_merge -> (alns, corrected DB, merged DB); the DBs are complete on every rank"""
+        rpar, apar = rpar or RescoreParams.default(), apar or AncientParams.default()
+        ah, ch, nh = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().cdm_contig_iteration_dist(self.ctx.h, self.h, db.h, C.byref(kpar), C.byref(rpar), C.byref(apar), merge_seq_id, C.byref(ah), C.byref(ch), C.byref(nh)))
+        return Alns(self.ctx, ah, db.n), SeqDb(self.ctx, ch), SeqDb(self.ctx, nh)
 
 
 # ------------------------------------------------------------------------------------------------ text codecs (tests)

@@ -639,3 +639,29 @@ extern "C" int cdm_reads_iteration_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_se
     if (next) cdm_seqdb_free(next);
     return rc;
 }
+
+// One iteration of the CONTIG loop (data/nuclassemble.sh:148-196) over the ranks: kmermatcher with the contig parameters over the ranks,
+// rescorediagonal / ancient_correction / ancient_contig_merge on the owned queries - the reference's `omp for` over independent queries
+// (ancientContigsResults.cpp:94-509; shared state: the wasExtended bytes, :271-467, which travel with the owned rows) -, the corrected and
+// the merged DB all-gathered.  The script's cyclecheck step is the caller's (cdm_cyclecheck on the complete DB: every rank, same result).
+extern "C" int cdm_contig_iteration_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *kpar, const cdm_rescore_params *rpar,
+                                         const cdm_ancient_params *apar, float mergeSeqIdThr, cdm_alns **alnsOut, cdm_seqdb **corrOut, cdm_seqdb **nextOut) {
+    if (!ctx || !cm || !db || !kpar || !apar) { cdm_set_error("cdm_contig_iteration_dist: invalid argument"); return CDM_ERR_INVALID; }
+    cdm_hits *hits = nullptr; cdm_alns *alns = nullptr; cdm_seqdb *cLocal = nullptr, *corr = nullptr, *nLocal = nullptr, *next = nullptr;
+    int rc = cdm_kmermatch_dist(ctx, cm, db, kpar, &hits);
+    if (rc == CDM_OK) rc = cdm_rescore(ctx, db, hits, rpar, &alns);
+    if (hits) cdm_hits_free(hits);
+    if (rc == CDM_OK) rc = cdm_correct(ctx, db, alns, apar, &cLocal);
+    if (rc == CDM_OK) rc = cdm_seqdb_allgather_owned(ctx, cm, cLocal, &corr);
+    if (cLocal) cdm_seqdb_free(cLocal);
+    if (rc == CDM_OK) rc = cdm_contig_merge(ctx, corr, alns, apar, mergeSeqIdThr, &nLocal);
+    if (rc == CDM_OK) rc = cdm_seqdb_allgather_owned(ctx, cm, nLocal, &next);
+    if (nLocal) cdm_seqdb_free(nLocal);
+    if (rc == CDM_OK && alnsOut) { *alnsOut = alns; alns = nullptr; }
+    if (rc == CDM_OK && corrOut) { *corrOut = corr; corr = nullptr; }
+    if (rc == CDM_OK && nextOut) { *nextOut = next; next = nullptr; }
+    if (alns) cdm_alns_free(alns);
+    if (corr) cdm_seqdb_free(corr);
+    if (next) cdm_seqdb_free(next);
+    return rc;
+}

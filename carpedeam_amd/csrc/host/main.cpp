@@ -1014,8 +1014,9 @@ int readsLoop(Args &a) {
     OutChunk cyclic;
     // --gpus N: the read iterations over N ranks = N host threads of this process, a device each; every rank holds the whole DB and
     // the library splits the work (cdm_reads_iteration_dist: kmermatcher by k-mer range, one all-to-all of group keys, the other stages
-    // on the owned queries, the new DBs all-gathered - the single-device result).  This thread is rank 0 and goes on alone with the
-    // contig iterations (their queue runs on the host).
+    // on the owned queries, the new DBs all-gathered - the single-device result), the contig iterations likewise since round 5
+    // (cdm_contig_iteration_dist: ancient_contig_merge's queue runs on the device, on the owned queries), the script's cyclecheck step on
+    // every rank.  This thread is rank 0.
     const int gpus = (int) std::max<long>(1, iflag(a, "--gpus", 1));
     long firstLocal = 0;
     if (gpus > 1 || getenv("CDM_LOOP_FORCE_COMM")) {
@@ -1035,16 +1036,28 @@ int readsLoop(Args &a) {
             if (threadsTransport) { cdm_comm_ops ops{&me, ttAllGatherHost, ttAllToAllDev, ttAllGatherDev}; check(cdm_comm_create_ops(c, r, gpus, &ops, &cm), "communicator"); }
             else if (standin) check(cdm_comm_create_standin(c, standin, r, &cm), "communicator");
             else check(cdm_comm_create_rccl(c, r, gpus, uid, &cm), "RCCL communicator");
-            for (long it = 0; it < iters && cdm_seqdb_size(d) > 0; it++) {
+            for (long it = 0; it < total && cdm_seqdb_size(d) > 0; it++) {
                 cdm_alns *alns = NULL; cdm_seqdb *next = NULL;
+                const bool contigs = it >= iters;
                 const auto tIt = std::chrono::steady_clock::now();
-                check(cdm_reads_iteration_dist(c, cm, d, &kp, &rp, &ap, NULL, &alns, NULL, &next), "reads iteration over the ranks");
+                if (contigs) check(cdm_contig_iteration_dist(c, cm, d, &kc, &rc, &ac, mergeThr, &alns, NULL, &next), "contig iteration over the ranks");
+                else check(cdm_reads_iteration_dist(c, cm, d, &kp, &rp, &ap, NULL, &alns, NULL, &next), "reads iteration over the ranks");
                 if (r == 0) fprintf(stderr, "STEP: %ld  sequences %llu  residues %llu -> %llu  alignments of rank 0's queries %llu  (%.3f s on %d ranks%s)\n",
                                     it, (unsigned long long) cdm_seqdb_size(d), (unsigned long long) cdm_seqdb_residues(d), (unsigned long long) cdm_seqdb_residues(next),
                                     (unsigned long long) cdm_alns_count(alns), std::chrono::duration<double>(std::chrono::steady_clock::now() - tIt).count(), gpus,
                                     threadsTransport ? ", in-process transport on one device" : standin ? ", the RCCL transport over its in-process stand-in, one device" : ", RCCL");
                 cdm_alns_free(alns); cdm_seqdb_free(d);
                 d = next;
+                if (contigs && cycleCheck) {        // every rank holds the whole merged DB: the same check, the same rest on all of them; rank 0 keeps the circular contigs
+                    cdm_seqdb *cyc = NULL, *rest = NULL;
+                    check(cdm_cyclecheck(c, d, (uint32_t) std::min<uint64_t>(ap.max_seq_len, 0xFFFFFFFFull), chopCycle, &cyc, &rest, NULL), "cyclecheck");
+                    if (r == 0) {
+                        if (cdm_seqdb_size(cyc)) fprintf(stderr, "         %llu circular contigs set aside\n", (unsigned long long) cdm_seqdb_size(cyc));
+                        appendEntries(c, cyc, cyclic);
+                    }
+                    cdm_seqdb_free(cyc); cdm_seqdb_free(d);
+                    d = rest;
+                }
             }
             cdm_comm_free(cm);
         };
@@ -1058,7 +1071,7 @@ int readsLoop(Args &a) {
         });
         rankBody(0, ctx, db);
         for (auto &h : helpers) h.join();
-        firstLocal = iters;
+        firstLocal = total;
     }
     for (long it = firstLocal; it < total && cdm_seqdb_size(db) > 0; it++) {
         cdm_hits *hits = NULL; cdm_alns *alns = NULL; cdm_seqdb *corr = NULL, *next = NULL;

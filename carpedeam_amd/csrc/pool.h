@@ -210,6 +210,10 @@ inline hipError_t growArena(Arena &a, int device, size_t need) {
         t.done(e == hipSuccess);
         if (e != hipSuccess) {
             if (cdmenv::get("CDM_POOL_DEBUG")) fprintf(stderr, "carpedeam pool: mapping %zu bytes at offset %zu of the %s arena failed: %s\n", chunk, at, a.small ? "small" : "large", hipGetErrorString(e));
+            // the caller gets the code; the runtime's per-thread "last error" must not keep it - the request may yet be served (without its
+            // head room, or after a trim), and the next CDM_LAUNCH_CHECK of this thread would report "kernel launch failed: out of
+            // memory" for a launch that went fine (the 25 M-read workflow's ninth iteration, round 5)
+            (void) hipGetLastError();
             return e;
         }
         a.chunks.push_back(Chunk{at, chunk, h});

@@ -348,6 +348,9 @@ int cdm_cyclecheck(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t max_seq_len, int 
  *   cdm_seqdb_allgather_owned   the owned ranges (cdm_comm_owned) of the ranks' DBs (same number of sequences on every rank) -> the complete DB
  *   cdm_reads_iteration_dist    one iteration of the reads loop (data/nuclassemble.sh:100-146) over the ranks; hits / alns hold the
  *                            owned queries' records, corr / next are complete on every rank and equal the single-device DBs
+ *   cdm_contig_iteration_dist   one iteration of the contig loop (data/nuclassemble.sh:148-196) over the ranks, up to ancient_contig_merge:
+ *                            the reference's loop over independent queries (ancientContigsResults.cpp:94-509) sharded by owned queries like
+ *                            the other stages; corr / next complete on every rank; the script's cyclecheck step is the caller's
  */
 typedef struct cdm_comm cdm_comm;
 typedef struct cdm_comm_ops {
@@ -376,6 +379,8 @@ int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *db, const 
 int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *local, cdm_seqdb **out);
 int cdm_reads_iteration_dist(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *db, const cdm_kmer_params *kpar, const cdm_rescore_params *rpar,
                              const cdm_ancient_params *apar, cdm_hits **hits, cdm_alns **alns, cdm_seqdb **corr, cdm_seqdb **next);
+int cdm_contig_iteration_dist(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *db, const cdm_kmer_params *kpar, const cdm_rescore_params *rpar,
+                              const cdm_ancient_params *apar, float merge_seq_id_thr, cdm_alns **alns, cdm_seqdb **corr, cdm_seqdb **next);
 
 #ifdef __cplusplus
 }

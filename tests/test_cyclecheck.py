@@ -139,6 +139,13 @@ def test_fused_loop_sets_circular_contigs_aside(dhigh_prefix, tmp_path):
     got, want = mmdb.read_db(t("out")), g("circ", "final")
     bad = diff_keys(got, want)
     assert not bad, (len(bad), bad[:5])
+    # the same over three ranks (the library's RCCL transport over its stand-in, one device): every rank runs the cycle check on the whole
+    # merged DB, rank 0 keeps the circular contigs
+    r = subprocess.run([exe, "ancient_reads_loop", t("in"), t("out3"), "--ancient-damage", dhigh_prefix, "--num-iter-reads-only", "3", "--num-iterations", "7", "--gpus", "3"],
+                       capture_output=True, text=True, env=dict(os.environ, CDM_LOOP_TRANSPORT="standin"))
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert "circular contigs set aside" in r.stderr and "on 3 ranks" in r.stderr
+    assert not diff_keys(mmdb.read_db(t("out3")), want)
     r = subprocess.run([exe, "ancient_reads_loop", t("in"), t("out0"), "--ancient-damage", dhigh_prefix, "--num-iter-reads-only", "3", "--num-iterations", "7", "--cycle-check", "0"],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "set aside" not in r.stderr

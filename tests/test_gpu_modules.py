@@ -170,8 +170,8 @@ def test_sequence_db_data_files_end_with_their_nul_on_a_dirty_heap(tmp_path, dhi
 
 
 def test_reads_loop_over_several_ranks_equals_one_device(tmp_path, dhigh_prefix):
-    """`ancient_reads_loop --gpus N`: the read iterations split over N ranks (host threads of the module, csrc/dist.hip), then the contig
-    iterations on rank 0 - the DB of the single-device run, file for file.  On this pool's one-GPU boxes the ranks share the device and
+    """`ancient_reads_loop --gpus N`: the read iterations AND the contig iterations split over N ranks (host threads of the module,
+    csrc/dist.hip cdm_reads_iteration_dist / cdm_contig_iteration_dist) - the DB of the single-device run, file for file.  On this pool's one-GPU boxes the ranks share the device and
     the collectives are the module's in-process transport (CDM_LOOP_TRANSPORT=threads) or the library's RCCL transport over its stand-in for
     RCCL's calls (=standin: 3 ranks exchange group keys, 6 ranks the k-mer tuples as well); RCCL itself runs with its one possible
     rank (CDM_LOOP_FORCE_COMM=1: every collective of the calling sequence, with itself as the only peer)."""

@@ -387,6 +387,55 @@ def test_native_exact_iteration_equals_single_device(dhigh_prefix, world, extrac
             assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
 
 
+@pytest.mark.parametrize("world,transport,wide", [(2, "threads", False), (3, "standin", False), (6, "standin", False), (3, "threads", True)])
+def test_native_contig_iteration_equals_single_device(dhigh_prefix, world, transport, wide, monkeypatch):
+    """cdm_contig_iteration_dist: contigs grown by three read iterations go through two contig iterations (kmermatcher -k 22 over the ranks,
+    rescorediagonal, ancient_correction, ancient_contig_merge with its queue on the device - each on the owned queries -, the DBs
+    all-gathered) with `world` ranks: corrected DB, merged DB and wasExtended flags equal the single-device calls'; `wide`: with the wide
+    group key forced, as a DB of the 25 M-read workflow's size takes it (kmermatcher is then run whole on every rank)"""
+    if wide:
+        monkeypatch.setenv("CDM_FORCE_WIDE_KEY", "1")
+        capi.lib().cdm_env_refresh()
+    n = 60_000
+    kc = capi.KmerParams.reads_default()
+    kc.kmer_size, kc.include_only_extendable = 22, 1
+
+    def start(c):
+        db = c.synth(n, 60, 150, 3)
+        for _ in range(3):
+            alns = c.rescore(db, c.kmermatch(db))
+            db = c.extend(c.correct(db, alns), alns)
+        return db
+
+    ref = capi.Ctx(0)
+    ref.damage_load(dhigh_prefix)
+    db = start(ref)
+    want = []
+    for _ in range(2):
+        alns = ref.rescore(db, ref.kmermatch(db, kc))
+        corr = ref.correct(db, alns)
+        db = ref.contig_merge(corr, alns)
+        want.append((corr.download(), db.download()))
+    assert int(want[1][1][2].sum()) > 1000           # contigs were merged
+    del db, corr, alns
+
+    def rank_fn(rank, comm, c):
+        c.damage_load(dhigh_prefix)
+        d = start(c)
+        got = []
+        for _ in range(2):
+            _, corr, d = comm.contig_iteration(d, kc)
+            got.append((corr.download(), d.download()))
+        return got
+
+    res = (run_native_ranks if transport == "threads" else run_standin_ranks)(world, rank_fn)
+    for r in res:
+        for it in range(2):
+            for got, exp in zip(r[it], want[it]):
+                assert [bytes(x) for x in got[0]] == [bytes(x) for x in exp[0]]
+                assert np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2])
+
+
 def test_native_kmermatcher_on_small_databases():
     """cdm_kmermatch_dist on tiny quirk-heavy databases (first-group strand, the run-past-the-end scan across ranks, identical
     sequences) with 2, 3 and 5 ranks, and on letters beyond ACGTN through cdm_seqdb_allgather_owned."""
