@@ -134,11 +134,13 @@ def spawn_ranks(n):
     sys.exit(subprocess.run(cmd).returncode)
 
 
-def run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch):
+def run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch, comm=None):
     """--config 5 (BASELINE.json configs[4], at a reduced size by default): the workflow loop of data/nuclassemble.sh:96-199 on
     mixed-length reads - 5 read iterations (kmermatcher, rescorediagonal, ancient_correction, ancient_read_assemble) and 7 contig
     iterations (kmermatcher -k 22 --include-only-extendable 1, rescorediagonal, ancient_correction, ancient_contig_merge,
-    cyclecheck) - through the C ABI with every intermediate resident in HBM; a rank works on its shard of the reads.
+    cyclecheck) - through the C ABI with every intermediate resident in HBM.  comm (N > 1, --scheme exact): every rank holds the corpus and
+    the library splits every iteration over the ranks (cdm_reads_iteration_dist / cdm_contig_iteration_dist: the single-device result);
+    without it (--scheme reads) a rank works on its own shard of the reads.
     value = bases fed to ancient_correction over all iterations / wall time of the whole job."""
     capi.lib().cdm_pool_headroom(1.6)      # the contig iterations' buffers grow ~1.5x per iteration (the loop binary does the same)
     n = plan["n"]
@@ -153,10 +155,23 @@ def run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch):
         db, bases, per_it, circular = db0, 0, [], 0
         for it in range(12):
             t0 = time.perf_counter()
+            bases += db.residues
+            if comm is not None:
+                if it < 5:
+                    _, _, _, nxt = comm.reads_iteration(db, kp, None, par)
+                else:
+                    _, _, merged = comm.contig_iteration(db, kc, None, par)
+                    cyc, nxt, _ = ctx.cyclecheck(merged, 200000, True)
+                    circular += cyc.n
+                    del merged, cyc
+                db = nxt
+                per_it.append(round(time.perf_counter() - t0, 3))
+                if db.n == 0:
+                    break
+                continue
             hits = ctx.kmermatch(db, kp if it < 5 else kc)
             alns = ctx.rescore(db, hits)
             del hits
-            bases += db.residues
             corr = ctx.correct(db, alns, par)
             if it < 5:
                 nxt = ctx.extend(corr, alns, par)
@@ -192,9 +207,10 @@ def run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch):
     total = float(bases)
     if dist is not None:
         dt = cd.max_over_ranks(dist, dt, device=("cpu" if dist.get_backend() == "gloo" else "cuda"))
-        tb = torch.tensor([total], dtype=torch.float64, device=("cpu" if dist.get_backend() == "gloo" else "cuda"))
-        dist.all_reduce(tb)
-        total = float(tb.item())
+        if comm is None:        # (exact: every rank counted the one shared corpus)
+            tb = torch.tensor([total], dtype=torch.float64, device=("cpu" if dist.get_backend() == "gloo" else "cuda"))
+            dist.all_reduce(tb)
+            total = float(tb.item())
     if rank == 0:
         chain_b = sum(ALG_B_PER_BASE.values())
         ach = chain_b * total / dt / 1e9
@@ -203,11 +219,12 @@ def run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch):
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8 (2-bit packed bases; int32 scores; software x87 f80 likelihood sums)", "data": "synthetic",
             "config": {"workload": "%d synthetic reads of 60-150 bp, dhigh, 12 iterations: 5 x (kmermatcher, rescorediagonal, ancient_correction, ancient_read_assemble) + 7 x "
-                                   "(kmermatcher -k 22, rescorediagonal, ancient_correction, ancient_contig_merge, cyclecheck) (BASELINE.json configs[4]%s; the contig phase's host queue "
-                                   "grows with the contigs)" % (args.reads, ": its 25 M reads per GPU" if n >= 25_000_000 else " at reduced size: %d reads per GPU instead of 25 M" % n),
-                       "reads_rank0": n, "seed": args.seed, "seconds_per_iteration_rank0": per_it, "final_sequences_rank0": out.n, "final_residues_rank0": out.residues,
-                       "circular_contigs_set_aside_rank0": circular, "value_is": "whole job, reads resident in HBM at the start; the contig merge's queue runs on the host"},
-            "roofline": {"bound": "hbm", "kernel": "whole chain (no single kernel dominates the 12 iterations; the contig iterations are bound by the host queue)", "achieved": ach,
+                                   "(kmermatcher -k 22, rescorediagonal, ancient_correction, ancient_contig_merge, cyclecheck) (BASELINE.json configs[4]%s; ancient_contig_merge's queue and extension loop run on the "
+                                   "device)" % (args.reads, ": its 25 M reads per GPU" if n >= 25_000_000 else " at reduced size: %d reads per GPU instead of 25 M" % n),
+                       "reads_rank0": n, "seed": args.seed, "multi_gpu_scheme": (None if world == 1 else "exact: every iteration split over the ranks by the library (csrc/dist.hip cdm_reads_iteration_dist / cdm_contig_iteration_dist), the single-device result" if comm is not None else "reads: every rank runs the loop on its own shard of the reads (not the single-device result)"),
+                       "equivalent_to_single_device": bool(world == 1 or comm is not None), "seconds_per_iteration_rank0": per_it, "final_sequences_rank0": out.n, "final_residues_rank0": out.residues,
+                       "circular_contigs_set_aside_rank0": circular, "value_is": "whole job, reads resident in HBM at the start"},
+            "roofline": {"bound": "hbm", "kernel": "whole chain (no single kernel dominates the 12 iterations: kmermatcher's passes over the grown contigs, the cycle check, the merge)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}}))
     if dist is not None:
         dist.destroy_process_group()
@@ -272,7 +289,7 @@ def main():
     L = args.len
     from carpedeam_amd import dist as cd
     plan = cd.shard_plan(rank, world, args.reads, args.seed, args.scaling)
-    exact = args.scheme == "exact" and dist is not None and args.config == 3
+    exact = args.scheme == "exact" and dist is not None and args.config in (3, 5)
     if exact:      # every rank holds the whole corpus; the work is split inside the stages, by the library itself over RCCL
         plan = dict(plan, first=0, n=plan["n_total"])
         if dist.get_backend() == "gloo":
@@ -283,7 +300,7 @@ def main():
             dist.broadcast_object_list(uid, src=0)          # (torch.distributed only launches, times and hands the id round: the data path is librccl under libcarpedeam_hip)
             comm = capi.Comm.rccl(ctx, rank, world, uid[0])
     if args.config == 5:
-        return run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch)
+        return run_loop_config(args, ctx, capi, cd, dist, rank, world, plan, torch, comm if exact else None)
     db = ctx.synth(plan["n"], L, L, plan["seed"], n_total=plan["n_total"], first=plan["first"])      # resident in HBM before the timed region
     n = plan["n"]
     residues = db.residues

@@ -113,3 +113,50 @@ def test_max_seq_len_stops_the_growth(dhigh_prefix, monkeypatch):
     assert np.array_equal(res["device"][1][2], res["host"][1][2])
     assert int(res["device"][1][0].max()) <= max(longest_read, 259)          # nothing reaches 260 letters by growing
     assert int((res["device"][1][0] > 200).sum()) > 100
+
+
+def _csum(a):
+    """scripts/probes/stage_sums.py csum"""
+    a = np.ascontiguousarray(a).view(np.uint8)
+    pad = (-a.size) % 8
+    if pad:
+        a = np.concatenate([a, np.zeros(pad, np.uint8)])
+    w = a.view(np.uint64)
+    return "%016x" % (int(w.sum(dtype=np.uint64)) ^ (int((w * np.arange(1, w.size + 1, dtype=np.uint64)).sum(dtype=np.uint64)) << 1) & 0xFFFFFFFFFFFFFFFF)
+
+
+def test_config5_workflow_at_10M_reads_ends_in_the_recorded_db(dhigh_prefix):
+    """BASELINE.json configs[4] (the 12-iteration loop on mixed-length reads) at 10 M reads - 25 M, its own size, wants 260 GB of the device
+    and a minute, which a suite that shares a process's device memory with 200 other tests does not have; profiles/ holds that run: the
+    final DB's sizes, flags and letters as recorded (tests/golden/config5/checksums.json; the same sums came out with the queue on the host
+    and on the device)"""
+    import json
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5", "checksums.json")))["10000000"]
+    ctx = ctx_with_damage(dhigh_prefix)
+    capi.lib().cdm_pool_headroom(1.6)
+    try:
+        db = ctx.synth(10_000_000, 60, 150, 2)
+        kp = capi.KmerParams.reads_default()
+        kc = capi.KmerParams.reads_default()
+        kc.kmer_size, kc.include_only_extendable = 22, 1
+        par = capi.AncientParams.default()
+        par.max_seq_len = 200000
+        circular = 0
+        for it in range(12):
+            alns = ctx.rescore(db, ctx.kmermatch(db, kp if it < 5 else kc))
+            corr = ctx.correct(db, alns, par)
+            if it < 5:
+                db = ctx.extend(corr, alns, par)
+            else:
+                cyc, db, _ = ctx.cyclecheck(ctx.contig_merge(corr, alns, par), 200000, True)
+                circular += cyc.n
+            del corr, alns
+        lens, _, ext = db.meta()
+        assert db.n == want["final_sequences"] and db.residues == want["final_residues"] and circular == want["circular"]
+        offs = np.zeros(db.n, np.uint64)
+        offs[1:] = np.cumsum(lens[:-1].astype(np.uint64) + 1)
+        buf = np.zeros(int(lens.astype(np.uint64).sum() + db.n), np.uint8)
+        db.download_into(buf, offs)
+        assert _csum(buf) + "/" + _csum(lens) + "/" + _csum(ext) == want["next"]
+    finally:
+        capi.lib().cdm_pool_headroom(1.0)          # (the context's end gives the cached device memory back: cdm_ctx_destroy)

@@ -43,3 +43,21 @@ def test_bench_line_from_two_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["config"]["equivalent_to_single_device"] is True
     assert (d["config"]["prefilter_hits"], d["config"]["alignments"]) == want, (d["config"], want)
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+
+
+def test_config5_line_from_two_ranks_equals_one_rank():
+    """`bench.py --config 5 --gpus 2` (the 12-iteration loop, every iteration split over the ranks by the library - read iterations and
+    contig iterations alike) ends in the DB of the single-process run: same final sequences and letters"""
+    import json
+    n = 150_000
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CDM_BENCH_BACKEND="gloo")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--reads", str(n), "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert one.returncode == 0, (one.stdout[-1500:], one.stderr[-2500:])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29545",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "5", "--reads", str(n), "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, (two.stdout[-1500:], two.stderr[-2500:])
+    a, b = (json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][0]) for r in (one, two))
+    assert b["n_gpus"] == 2 and b["config"]["equivalent_to_single_device"] is True and "cdm_contig_iteration_dist" in b["config"]["multi_gpu_scheme"]
+    for k in ("final_sequences_rank0", "final_residues_rank0", "circular_contigs_set_aside_rank0"):
+        assert a["config"][k] == b["config"][k], k
+    assert a["config"]["final_residues_rank0"] > n * 110          # the contigs grew (the reads hold 105 letters on average)
