@@ -184,16 +184,31 @@ extern "C" void cdm_seqdb_free(cdm_seqdb *db) {
     delete db;
 }
 __global__ void k_build_meta(const uint32_t *__restrict__ woff, const uint32_t *__restrict__ len, const uint8_t *__restrict__ hasN, const uint8_t *__restrict__ ext,
-                             const uint32_t *__restrict__ key, uint32_t n, SeqMeta *__restrict__ out) {
+                             const uint32_t *__restrict__ key, uint32_t n, SeqMeta *__restrict__ out, uint32_t uniLen, uint32_t uniWords, unsigned int *__restrict__ notUniform) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     SeqMeta m; m.woff = woff[i]; m.len = len[i]; m.flags = (hasN[i] ? 1u : 0u) | (ext[i] ? 2u : 0u) | ((hasN[i] & 2u) ? 4u : 0u); m.key = key[i];
     out[i] = m;
+    if (notUniform && (m.len != uniLen || m.woff != i * uniWords || m.flags != 0u)) atomicOr(notUniform, 1u);
 }
-int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out) {
+// CDM_META_UNIFORM=0: the records for every DB (A/B)
+int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out, MetaUniform *uniform) {
     SeqMeta *m = nullptr;
     if (cdmMalloc(&m, (db->n + 1) * sizeof(SeqMeta)) != hipSuccess) { cdm_set_error("out of device memory (sequence metadata)"); return CDM_ERR_HIP; }
-    if (db->n) hipLaunchKernelGGL(k_build_meta, dim3((unsigned) ((db->n + 255) / 256)), dim3(256), 0, ctx->stream, db->woff, db->len, db->hasN, db->ext, db->key, (uint32_t) db->n, m);
+    // a candidate for the plain uniform form: the lengths sum to n x the longest, no N counted, no row of original letters
+    const char *sw = cdmGetenv("CDM_META_UNIFORM");
+    const bool candidate = uniform && db->n && db->maxLen && db->residues == db->n * (uint64_t) db->maxLen && db->nCount == 0 && !db->raw && !(sw && !strcmp(sw, "0")) &&
+                           db->n * (uint64_t) ((db->maxLen + 15) / 16) < (1ull << 32);
+    DevBuf<unsigned int> bad;
+    if (candidate) { if (!bad.alloc(1)) { cdmFree(m); cdm_set_error("out of device memory (sequence metadata)"); return CDM_ERR_HIP; } hipMemsetAsync(bad.p, 0, 4, ctx->stream); }
+    if (db->n) hipLaunchKernelGGL(k_build_meta, dim3((unsigned) ((db->n + 255) / 256)), dim3(256), 0, ctx->stream, db->woff, db->len, db->hasN, db->ext, db->key, (uint32_t) db->n, m,
+                                  db->maxLen, (db->maxLen + 15) / 16, candidate ? bad.p : nullptr);
+    if (uniform) { uniform->words = 0; uniform->len = 0; }
+    if (candidate) {
+        unsigned int h = 1;
+        if (hipMemcpyAsync(&h, bad.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { cdmFree(m); cdm_set_error("sequence metadata: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+        if (!h) { uniform->words = (db->maxLen + 15) / 16; uniform->len = db->maxLen; }
+    }
     *out = m;
     return CDM_OK;
 }

@@ -134,15 +134,26 @@ struct cdm_seqdb {
 // (a random target then costs one cache line, not four).  Built per call from the cdm_seqdb arrays (cdm_build_meta, api.hip);
 // the proxies keep the kernels' `a.len[t]` spelling.
 struct SeqMeta { uint32_t woff, len, flags, key; };      // flags: 1 = has N (not plain ACGT), 2 = wasExtended, 4 = has a raw row
-struct MetaWoff { const SeqMeta *m; __host__ __device__ uint32_t operator[](uint32_t i) const { return m[i].woff; } };
-struct MetaLen { const SeqMeta *m; __host__ __device__ uint32_t operator[](uint32_t i) const { return m[i].len; } };
-struct MetaHasN { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) (m[i].flags & 1u); } };
+// A PLAIN UNIFORM DB - every sequence of the same length, stored back to back, no flag set on any (no N, no other letter, never
+// extended): fresh reads of one sequencing run, the metric's 50 M x 100 bp corpus - needs no record at all: word offset and length
+// follow from the index, the flags are zero.  The three stages that gather their targets at random (rescore, correction, extension)
+// then fetch ONE line per target, its letters, instead of two (round 5: the metadata line was 64 of the ~130 bytes a target cost,
+// profiles/r05_pmc_calibration.json).  uw / ul: words and letters per sequence, 0 = look the record up (cdm_build_meta finds out).
+struct MetaUniform { uint32_t words = 0, len = 0; };
+struct MetaWoff { const SeqMeta *m; uint32_t uw = 0; __host__ __device__ uint32_t operator[](uint32_t i) const { return uw ? i * uw : m[i].woff; } };
+struct MetaLen { const SeqMeta *m; uint32_t ul = 0; __host__ __device__ uint32_t operator[](uint32_t i) const { return ul ? ul : m[i].len; } };
+struct MetaHasN { const SeqMeta *m; uint32_t plain = 0; __host__ __device__ uint8_t operator[](uint32_t i) const { return plain ? (uint8_t) 0 : (uint8_t) (m[i].flags & 1u); } };
 struct MetaKey { const SeqMeta *m; __host__ __device__ uint32_t operator[](uint32_t i) const { return m[i].key; } };
-struct MetaExt { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) ((m[i].flags >> 1) & 1u); } };
-struct MetaRaw { const SeqMeta *m; __host__ __device__ uint8_t operator[](uint32_t i) const { return (uint8_t) ((m[i].flags >> 2) & 1u); } };
+struct MetaExt { const SeqMeta *m; uint32_t plain = 0; __host__ __device__ uint8_t operator[](uint32_t i) const { return plain ? (uint8_t) 0 : (uint8_t) ((m[i].flags >> 1) & 1u); } };
+struct MetaRaw { const SeqMeta *m; uint32_t plain = 0; __host__ __device__ uint8_t operator[](uint32_t i) const { return plain ? (uint8_t) 0 : (uint8_t) ((m[i].flags >> 2) & 1u); } };
+// all proxies of a stage's argument block from one table
+template <typename A> inline void cdmSetMeta(A &a, const SeqMeta *m, const MetaUniform &u) {
+    a.woff.m = a.len.m = a.hasN.m = a.hasRaw.m = m;
+    a.woff.uw = u.words; a.len.ul = u.len; a.hasN.plain = a.hasRaw.plain = u.words;
+}
 int cdm_kmermatch_needs_wide_key(const cdm_seqdb *db);      // kmermatch.hip
 int cdm_seqdb_overlay(cdm_ctx *ctx, const cdm_seqdb *base, const cdm_seqdb *grown, const uint32_t *idxHost, const uint8_t *extHost, cdm_seqdb **out);      // api.hip
-int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out);      // cdmFree the result
+int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out, MetaUniform *uniform = nullptr);      // cdmFree the result; uniform: filled (and the stream synchronised) if asked for
 
 // (the consumers of an alignment set call this first)
 #define CDM_REFUSE_UNDEFINED_ALNS(alns, who) do { if ((alns)->undefinedRecords) { cdm_set_error("%s: %llu identity record(s) carry the coordinates -1 (a sequence that scores 0 against itself: more than 40 %% N); the reference indexes the sequence with them here - undefined, not reproduced", who, (unsigned long long) (alns)->undefinedRecords); return CDM_ERR_UNSUPPORTED; } } while (0)

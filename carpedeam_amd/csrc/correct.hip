@@ -526,9 +526,10 @@ int cdm_correct_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, co
     } else
     hipLaunchKernelGGL(k_mark_active, dim3((n + 1023) / 1024), dim3(1024), 0, s, alns->off, n, smallW ? 15u : 0u, active.p, activeFast.p, activeSmall.p, counters.p);
     DevBuf<SeqMeta> meta;
-    if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
+    MetaUniform uni;
+    if (int rc = cdm_build_meta(ctx, db, &meta.p, &uni)) return rc;
     CorrectArgs a;
-    a.woff.m = a.len.m = a.hasN.m = a.ext.m = a.hasRaw.m = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.raw = db->raw; a.outRaw = out->raw;
+    cdmSetMeta(a, meta.p, uni); a.ext.m = meta.p; a.ext.plain = uni.words; a.codes = db->codes; a.nmask = db->nmask; a.raw = db->raw; a.outRaw = out->raw;
     a.aoff = alns->off; a.rec = alns->rec; a.ry = (alns->ryMism && alns->rySerial == db->serial) ? alns->ryMism : nullptr; a.active = active.p; a.nActive = counters.p; a.accept = accept.p; a.errFlag = counters.p + 1;
     a.outCodes = out->codes; a.outNmask = out->nmask; a.lut = ctx->lutDev; a.seqIdThr = par->seq_id_thr; a.corrRy = par->corr_reads_ry_seq_id;
     const int blocks = ctx->cuCount * 8;

@@ -929,9 +929,10 @@ int cdm_extend_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, con
     hipMemcpyAsync(&hAct, nActive.p, 4, hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_extend: setup failed"); return CDM_ERR_HIP; }
     DevBuf<SeqMeta> meta;
-    if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
+    MetaUniform uni;
+    if (int rc = cdm_build_meta(ctx, db, &meta.p, &uni)) return rc;
     ExtArgs A;
-    A.woff.m = A.len.m = A.hasN.m = A.ext.m = A.key.m = A.hasRaw.m = meta.p; A.codes = db->codes; A.nmask = db->nmask; A.raw = db->raw;
+    cdmSetMeta(A, meta.p, uni); A.ext.m = A.key.m = meta.p; A.ext.plain = uni.words; A.codes = db->codes; A.nmask = db->nmask; A.raw = db->raw;
     A.aoff = alns->off; A.rec = alns->rec; A.active = active.p; A.nActive = nActive.p; A.lut = ctx->lutDev; A.cand = cand.p; A.lists = lists.p;
     A.newLen = newLen.p; A.nLeft = nLeft.p; A.nRight = nRight.p; A.leftTotal = leftTotal.p; A.scores = scores ? dScores.p : nullptr;
     A.seqIdThr = par->seq_id_thr; A.rySeqIdThr = par->ry_seq_id_thr; A.likelihoodThr = par->likelihood_threshold;

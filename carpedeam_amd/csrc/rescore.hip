@@ -241,9 +241,10 @@ int cdm_rescore_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_hits *hits, co
     CDM_HIP(hipMemcpyAsync(dMin.p, minScore.data(), (size_t) (db->maxLen + 1) * 4, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_expand, dim3((n + 255) / 256), dim3(256), 0, s, hits->off, n, owner.p);
     DevBuf<SeqMeta> meta;
-    if (int rc = cdm_build_meta(ctx, db, &meta.p)) return rc;
+    MetaUniform uni;
+    if (int rc = cdm_build_meta(ctx, db, &meta.p, &uni)) return rc;
     RescoreArgs a;
-    a.woff.m = a.len.m = a.hasN.m = a.hasRaw.m = meta.p; a.codes = db->codes; a.nmask = db->nmask; a.raw = db->raw; a.hoff = hits->off; a.hit = hits->rec;
+    cdmSetMeta(a, meta.p, uni); a.codes = db->codes; a.nmask = db->nmask; a.raw = db->raw; a.hoff = hits->off; a.hit = hits->rec;
     a.minScore = dMin.p; a.nHits = nHits; a.n = n; a.seqIdThr = par->seq_id_thr; a.covThr = par->cov_thr; a.covMode = par->cov_mode;
     a.minAlnLen = par->min_aln_len; a.tmp = tmp.p; a.tmpRy = tmpRy.p; a.valid = valid.p; a.undef = undef.p;
     hipEventRecord(ctx->ev0, s);
