@@ -54,6 +54,16 @@ struct AggArgs {
     int wideWord = 0;               // (host side: the entry sort needs the 128-bit word)
 };
 constexpr int AG_H = 1024, AG_D = 512, AG_IDX = 9, AG_ORD = 11;
+// Room in the entry array is taken from the one global cursor in CHUNKS of this many entries, a block (k_unit_agg) or a wave
+// (k_rle_segment) handing them out to its units from there: one atomic per unit on a single word - 1.9 M units and 0.5 M segments in the
+// 50 M-read step - ran at the ~88 atomics per microsecond such a word takes, and that WAS the two kernels' time (round 5: k_rle_segment
+// 6.3 ms for 0.52 M segments of 34 tuples on average, whether a block or a wave took a segment).  What a chunk's end leaves unused
+// stays unused: the caller's capacity holds a chunk per block / wave on top (aggChunkSlack).
+constexpr unsigned long long AG_CHUNK = 2048;
+inline unsigned long long aggChunkSlack(unsigned long long units, unsigned long long segments, int cuCount) {
+    const unsigned long long g = (unsigned long long) cuCount * 64;
+    return (3 * std::min(units + 1, g) + std::min(segments + 1, g)) * AG_CHUNK;
+}
 static_assert((1 << AG_IDX) >= AG_D && (1 << AG_ORD) > runsort::U_T, "aggregation geometry");
 __device__ __forceinline__ uint32_t aggHash(uint64_t k) { return (uint32_t) ((k * 0x9E3779B97F4A7C15ull) >> 40); }
 
@@ -80,9 +90,10 @@ __global__ __launch_bounds__(NT, CDM_AGG_MINW) void k_unit_agg(AggArgs a) {
     __shared__ uint64_t sGStart[NT];
     __shared__ uint32_t sGOff[NT], sGSeg[NT];
     __shared__ unsigned int sDistinct, sOver, sMaxOrd;
-    __shared__ unsigned long long sBase;
+    __shared__ unsigned long long sBase, sChunkAt, sChunkEnd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned int nUnits = *a.count;
+    if (tid == 0) { sChunkAt = 0; sChunkEnd = 0; }             // (the loop's first barrier publishes them)
     const int lowBits = a.repShift - 1;                         // id and diagonal
     const uint64_t lowMask = (1ull << lowBits) - 1ull;
     for (unsigned int item = blockIdx.x; item < nUnits; item += gridDim.x) {
@@ -166,7 +177,9 @@ __global__ __launch_bounds__(NT, CDM_AGG_MINW) void k_unit_agg(AggArgs a) {
         const unsigned int nOrd = sMaxOrd + 1u;
         for (unsigned int o = tid; o < nOrd; o += NT) { oFirst[o] = 0xFFFFFFFFu; oEnt[o] = 0u; oHit[o] = 0u; }      // (the table's memory: its entries are in d* now)
         if (tid == 0) {
-            const unsigned long long b = atomicAdd(a.cursor, (unsigned long long) D);
+            if (sChunkAt + D > sChunkEnd) { const unsigned long long want = max(AG_CHUNK, (unsigned long long) D); sChunkAt = atomicAdd(a.cursor, want); sChunkEnd = sChunkAt + want; }
+            const unsigned long long b = sChunkAt;
+            sChunkAt += D;
             if (b + D > a.cap) { atomicExch(a.overflow, 1u); sBase = ~0ull; } else sBase = b;
         }
         __syncthreads();
@@ -206,50 +219,56 @@ __global__ __launch_bounds__(1024) void k_pending_list(const uint32_t *__restric
     const uint32_t q = cdm_block_append(cnt, p);
     if (p) list[q] = (uint32_t) g;
 }
-// one block per listed segment: its tuples stand sorted in a.sorted[dst[first record] .. dst[first record of the next segment]) -> entries
+// one WAVE per listed segment: its tuples stand sorted in a.sorted[dst[first record] .. dst[first record of the next segment]) -> entries.
+// (A block per segment until round 5: the segments of the units that overflow the aggregation table are many and short - a few dozen
+// tuples -, and 256 threads with two block-wide scans per 256 tuples spent 6.4 ms of the 50 M-read step on them.)
 __global__ __launch_bounds__(256) void k_rle_segment(AggArgs a, const uint32_t *__restrict__ list, const unsigned int *__restrict__ nList) {
-    __shared__ unsigned long long sBase, sRun;
     const unsigned int n = *nList;
+    const int lane = threadIdx.x & 63;
     const uint64_t idMask = (1ull << a.idBits) - 1ull, diagMask = (1ull << a.diagBits) - 1ull;
-    for (unsigned int it = blockIdx.x; it < n; it += gridDim.x) {
+    const uint64_t below = (1ull << lane) - 1ull;
+    unsigned long long chunkAt = 0, chunkEnd = 0;               // (lane 0's)
+    for (unsigned int it = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); it < n; it += gridDim.x * (blockDim.x >> 6)) {
         const uint32_t g = list[it];
         const uint64_t s = a.dst[a.segFirstRec[g]], e = a.dst[a.segFirstRec[g + 1]];
         const uint32_t rep = a.segRep[g];
         unsigned int runs = 0, hits = 0;
-        for (uint64_t i = s + threadIdx.x; i < e; i += 256) {
+        for (uint64_t i = s + lane; i < e; i += 64) {
             const uint64_t k = a.sorted[i], p = i > s ? a.sorted[i - 1] : ~0ull;
             if (i == s || (k >> 1) != (p >> 1)) runs++;
             if (i == s || (k >> (a.diagBits + 1)) != (p >> (a.diagBits + 1))) hits += ((uint32_t) ((k >> (a.diagBits + 1)) & idMask) != rep);
         }
-        const unsigned int D = cdm_block_sum<unsigned int>(runs), H = cdm_block_sum<unsigned int>(hits);
-        if (threadIdx.x == 0) {
-            const unsigned long long b = atomicAdd(a.cursor, (unsigned long long) D);
-            if (b + D > a.cap) { atomicExch(a.overflow, 1u); sBase = ~0ull; }
-            else { sBase = b; a.entOff[g] = b; a.entCnt[g] = D; a.perRep[rep] = H; }
-            sRun = 0;
+        const unsigned int D = (unsigned int) cdm_wave_sum((int) runs), H = (unsigned int) cdm_wave_sum((int) hits);
+        unsigned long long b = 0;
+        if (lane == 0) {
+            if (chunkAt + D > chunkEnd) { const unsigned long long want = max(AG_CHUNK, (unsigned long long) D); chunkAt = atomicAdd(a.cursor, want); chunkEnd = chunkAt + want; }
+            b = chunkAt; chunkAt += D;
+            if (b + D > a.cap) { atomicExch(a.overflow, 1u); b = ~0ull; }
+            else { a.entOff[g] = b; a.entCnt[g] = D; a.perRep[rep] = H; }
         }
-        __syncthreads();
-        const unsigned long long b = sBase;
-        if (b != ~0ull) {
-            for (uint64_t t0 = s; t0 < e; t0 += 256) {
-                const uint64_t i = t0 + threadIdx.x;
-                bool start = false; uint64_t k = 0;
-                if (i < e) { k = a.sorted[i]; start = i == s || (k >> 1) != (a.sorted[i - 1] >> 1); }
-                unsigned int tot;
-                const unsigned int ex = cdm_block_excl_sum<unsigned int>(start ? 1u : 0u, tot);
-                if (start) {
-                    uint64_t lo = i, hi = e;                     // end of the run: first index behind i whose triple differs
+        b = (unsigned long long) __shfl((long long) b, 0, 64);
+        if (b == ~0ull) continue;
+        unsigned long long run = 0;                              // entries written so far
+        for (uint64_t t0 = s; t0 < e; t0 += 64) {
+            const uint64_t i = t0 + lane;
+            bool start = false; uint64_t k = 0;
+            if (i < e) { k = a.sorted[i]; start = i == s || (k >> 1) != (a.sorted[i - 1] >> 1); }
+            const uint64_t m = __ballot(start);
+            if (start) {
+                // end of the run: the next start in this stretch of 64, or - behind it - the first index whose triple differs
+                const uint64_t later = lane < 63 ? (m >> (lane + 1)) : 0ull;
+                uint64_t hi;
+                if (later) hi = i + (uint64_t) __ffsll((unsigned long long) later);
+                else {
+                    uint64_t lo = min(t0 + 63, e - 1); hi = e;          // (the stretch's last tuple belongs to this run)
                     while (hi - lo > 1) { const uint64_t mid = lo + ((hi - lo) >> 1); if ((a.sorted[mid] >> 1) == (k >> 1)) lo = mid; else hi = mid; }
-                    Ent en; en.id = (uint32_t) ((k >> (a.diagBits + 1)) & idMask); en.diag = (uint32_t) ((k >> 1) & diagMask);
-                    en.cs = ((uint32_t) (hi - i) << 1) | (uint32_t) (a.sorted[hi - 1] & 1ull);
-                    a.ent[b + sRun + ex] = en;
                 }
-                __syncthreads();
-                if (threadIdx.x == 0) sRun += tot;
-                __syncthreads();
+                Ent en; en.id = (uint32_t) ((k >> (a.diagBits + 1)) & idMask); en.diag = (uint32_t) ((k >> 1) & diagMask);
+                en.cs = ((uint32_t) (hi - i) << 1) | (uint32_t) (a.sorted[hi - 1] & 1ull);
+                a.ent[b + run + (unsigned long long) __popcll(m & below)] = en;
             }
+            run += (unsigned long long) __popcll(m);
         }
-        __syncthreads();
     }
 }
 

@@ -403,6 +403,7 @@ __global__ __launch_bounds__(256) void k_cq_grow_sizes(CqArgs a, const uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------ the parked hits on the grown query (:404-455), a wave each
+// (nWork: the end of this launch's slice - the launch is rounded up to whole blocks, and an item done twice would be re-aligned from its own result)
 __global__ __launch_bounds__(256) void k_cq_parked(CqArgs a, const uint64_t *__restrict__ work, uint32_t nWork, uint32_t first) {
     const uint32_t wi = first + ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
@@ -551,13 +552,13 @@ int cdm_contig_queue_device(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *a
             hipMemcpyAsync(bufs.p + round, &b, sizeof(CqBuf), hipMemcpyHostToDevice, s);
             hipStreamSynchronize(s);        // (b is a local)
             for (uint64_t first = 0, slice = cdmSliceItems(64); first < nGrown; first += slice)
-                hipLaunchKernelGGL(k_cq_grow, CDM_GRID((std::min<uint64_t>(slice, nGrown - first) * 64 + 255) / 256, 256), dim3(256), 0, s, a, grown.p, ops.p, gWoff.p, nGrown, (uint32_t) first, round,
+                hipLaunchKernelGGL(k_cq_grow, CDM_GRID((std::min<uint64_t>(slice, nGrown - first) * 64 + 255) / 256, 256), dim3(256), 0, s, a, grown.p, ops.p, gWoff.p, (uint32_t) std::min<uint64_t>(nGrown, first + slice), (uint32_t) first, round,
                                    prevRound.p, prevWoff.p, prevLen.p);
             grownTotal += nGrown;
         }
         if (nPark) {
             for (uint64_t first = 0, slice = cdmSliceItems(64); first < nPark; first += slice)
-                hipLaunchKernelGGL(k_cq_parked, CDM_GRID((std::min<uint64_t>(slice, nPark - first) * 64 + 255) / 256, 256), dim3(256), 0, s, a, parkWork.p, nPark, (uint32_t) first);
+                hipLaunchKernelGGL(k_cq_parked, CDM_GRID((std::min<uint64_t>(slice, nPark - first) * 64 + 255) / 256, 256), dim3(256), 0, s, a, parkWork.p, (uint32_t) std::min<uint64_t>(nPark, first + slice), (uint32_t) first);
             parkedTotal += nPark;
         }
         std::swap(act, nxt);

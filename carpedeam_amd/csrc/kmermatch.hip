@@ -2207,11 +2207,12 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
             if ((wide || fromStage) && ownBuffers && nGroup != nKept) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu in the run records", nKept, nGroup); return CDM_ERR_HIP; }
             if (aggregated) {
                 // (the wide form has no tuple path to fall back to: an entry buffer that proves too small is tried again, larger)
-                unsigned long long capEnt = nGroup / 6 + (4ull << 20);
+                const unsigned long long slack = aggv::aggChunkSlack(nGroup / runsort::U_T, nRec, ctx->cuCount);     // (the units' and segments' chunks of the entry array: aggvote.h AG_CHUNK)
+                unsigned long long capEnt = nGroup / 6 + (4ull << 20) + slack;
                 if (const char *e = cdmGetenv("CDM_AGG_CAP")) capEnt = strtoull(e, nullptr, 10);      // tests: force the overflow fallback
                 int rc = aggregate(sortedOut, nGroup, rk.current(), (const uint64_t *) rv.current(), dst.p, nRec, gk, top2, capEnt, !wordFits);
-                while (rc == CDM_ERR_UNSUPPORTED && wide && capEnt < nGroup + 1) {
-                    capEnt = std::min<unsigned long long>(nGroup + 1, std::max<unsigned long long>(capEnt * 3, 1024));
+                while (rc == CDM_ERR_UNSUPPORTED && wide && capEnt < nGroup + 1 + slack) {
+                    capEnt = std::min<unsigned long long>(nGroup + 1 + slack, std::max<unsigned long long>(capEnt * 3, 1024));
                     rc = aggregate(sortedOut, nGroup, rk.current(), (const uint64_t *) rv.current(), dst.p, nRec, gk, top2, capEnt, !wordFits);
                 }
                 if (rc == CDM_ERR_UNSUPPORTED && !wide) aggregated = false;      // (entry buffer too small for this input: the tuple path)
@@ -2376,8 +2377,16 @@ int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *re
     unsigned int fl[4] = {0, 0, 0, 0};
     hipMemcpyAsync(fl, agFlags.p, 16, hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: aggregation failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+    if (fl[1] && cdmGetenv("CDM_RLE_STATS")) {      // diagnosis: how many segments the tuple sorters finished, and how long they are
+        std::vector<uint32_t> pl(fl[1]); std::vector<unsigned long long> fr((size_t) nSeg + 1), dd((size_t) nRec + 1);
+        hipMemcpy(pl.data(), agPending.p, (size_t) fl[1] * 4, hipMemcpyDeviceToHost); hipMemcpy(fr.data(), agSegFirstRec.p, ((size_t) nSeg + 1) * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(dd.data(), dst, ((size_t) nRec + 1) * 8, hipMemcpyDeviceToHost);
+        unsigned long long tot = 0, mx = 0, over4k = 0, over64k = 0, inBig = 0;
+        for (uint32_t g : pl) { const unsigned long long m = dd[fr[g + 1]] - dd[fr[g]]; tot += m; mx = std::max(mx, m); if (m > 4096) { over4k++; inBig += m; } if (m > 65536) over64k++; }
+        fprintf(stderr, "rle segments: %u of %llu, %llu tuples (longest %llu; %llu beyond 4096 tuples holding %llu, %llu beyond 65536)\n", fl[1], (unsigned long long) nSeg, tot, mx, over4k, inBig, over64k);
+    }
     if (fl[1] && !fl[0]) {
-        hipLaunchKernelGGL(k_rle_segment, dim3(std::min<unsigned int>(fl[1], (unsigned int) ctx->cuCount * 16)), dim3(256), 0, s, a, (const uint32_t *) agPending.p, (const unsigned int *) (agFlags.p + 1));
+        hipLaunchKernelGGL(k_rle_segment, dim3(std::min<unsigned int>((fl[1] + 3) / 4, (unsigned int) ctx->cuCount * 16)), dim3(256), 0, s, a, (const uint32_t *) agPending.p, (const unsigned int *) (agFlags.p + 1));
         hipMemcpyAsync(fl, agFlags.p, 16, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: aggregation (segments of the tuple sorters) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
     }
