@@ -235,11 +235,8 @@ __device__ __forceinline__ bool useReverse(const CqArgs &a, uint64_t r0, uint64_
     for (uint64_t r = r1; r-- > r0;) if (a.rec[r].target == target) return a.st[r].rev != 0;
     return false;
 }
-__global__ __launch_bounds__(64) void k_cq_round(CqArgs a, const uint32_t *__restrict__ active, uint32_t nActive, uint32_t round, uint32_t *__restrict__ next, uint32_t *__restrict__ grown,
-                                                 CqOp *__restrict__ ops, uint64_t *__restrict__ parkWork) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nActive) return;
-    const uint32_t q = active[slot];
+// -> the round's fragments (op), the number of parked hits (the query goes on if there are any), whether it grew, whether the host takes it
+__device__ __forceinline__ void cqRound(const CqArgs &a, uint32_t q, uint32_t round, CqOp &op, uint32_t &parked, bool &grew, bool &back) {
     const uint64_t r0 = a.aoff[q], r1 = a.aoff[q + 1];
     uint32_t *h = a.heap + r0, *pk = a.park + r0;
     const CqKey *key = a.key + r0;
@@ -265,7 +262,7 @@ __global__ __launch_bounds__(64) void k_cq_round(CqArgs a, const uint32_t *__res
     }
     uint32_t np = 0, leftOff = 0, rightOff = 0;
     const unsigned qLen = a.curLen[q];
-    CqOp op; op.lR = op.lL = 0; op.tR = op.tL = op.oR = op.oL = op.revR = op.revL = 0;
+    op.lR = op.lL = 0; op.tR = op.tL = op.oR = op.oL = op.revR = op.revL = 0;
     if (!giveUp && !cmp.handBack && hn > 0) {
         while (true) {
             // selectNuclFragmentToExtendContigs (:73-91)
@@ -304,26 +301,39 @@ __global__ __launch_bounds__(64) void k_cq_round(CqArgs a, const uint32_t *__res
             }
         }
     }
-    if (giveUp || cmp.handBack) {
-        a.qflags[q] = flags | QF_FALLBACK; a.heapN[q] = 0; a.parkN[q] = 0;
-        atomicAdd(&a.counters[1], 1u);
-        return;
-    }
-    if (leftOff > 0 || rightOff > 0) {
-        flags |= QF_EXTENDED;
-        const uint32_t g = atomicAdd(&a.counters[2], 1u);
-        grown[g] = q; ops[g] = op;
-        a.curLen[q] = qLen + leftOff + rightOff;
-    }
+    if (giveUp || cmp.handBack) { a.qflags[q] = flags | QF_FALLBACK; a.heapN[q] = 0; a.parkN[q] = 0; back = true; return; }
+    if (leftOff > 0 || rightOff > 0) { flags |= QF_EXTENDED; grew = true; a.curLen[q] = qLen + leftOff + rightOff; }
     a.leftOff[q] = leftOff;
     a.qflags[q] = flags;
-    if (hn != 0) { a.heapN[q] = 0; a.parkN[q] = 0; return; }          // :403 the loop ends on a queue that is not empty (--max-seq-len)
-    a.heapN[q] = 0; a.parkN[q] = np;
-    if (np) {
-        const uint32_t w = atomicAdd(&a.counters[3], np);
-        for (uint32_t j = 0; j < np; j++) parkWork[w + j] = ((uint64_t) q << 32) | j;
-        next[atomicAdd(&a.counters[4], 1u)] = q;
-    }
+    a.heapN[q] = 0;
+    if (hn != 0) { a.parkN[q] = 0; return; }          // :403 the loop ends on a queue that is not empty (--max-seq-len)
+    a.parkN[q] = np;
+    parked = np;
+}
+// a wave of queries; what they append to the round's lists goes out with one atomic per wave and list (a single word takes ~88 atomics
+// per microsecond: 25 M queries' worth of them was most of a round)
+__global__ __launch_bounds__(64) void k_cq_round(CqArgs a, const uint32_t *__restrict__ active, uint32_t nActive, uint32_t round, uint32_t *__restrict__ next, uint32_t *__restrict__ grown,
+                                                 CqOp *__restrict__ ops, uint64_t *__restrict__ parkWork) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t q = 0, parked = 0; bool grew = false, back = false;
+    CqOp op; op.lR = op.lL = 0; op.tR = op.tL = op.oR = op.oL = op.revR = op.revL = 0;
+    if (slot < nActive) { q = active[slot]; cqRound(a, q, round, op, parked, grew, back); }
+    const uint64_t mb = __ballot(back);
+    if (mb && lane == __ffsll((unsigned long long) mb) - 1) atomicAdd(&a.counters[1], (unsigned int) __popcll(mb));
+    const uint32_t g = cdm_wave_append(a.counters + 2, grew);
+    if (grew) { grown[g] = q; ops[g] = op; }
+    uint32_t incl = parked;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t) __shfl_up((int) incl, o, 64); if (lane >= o) incl += t; }
+    const uint32_t total = (uint32_t) __shfl((int) incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(&a.counters[3], total);
+    base = (uint32_t) __shfl((int) base, 63, 64);
+    const uint32_t w = base + incl - parked;
+    for (uint32_t j = 0; j < parked; j++) parkWork[w + j] = ((uint64_t) q << 32) | j;
+    const uint32_t nx = cdm_wave_append(a.counters + 4, parked > 0);
+    if (parked) next[nx] = q;
 }
 
 // ------------------------------------------------------------------------------------------------ letters
@@ -567,6 +577,10 @@ int cdm_contig_queue_device(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *a
     }
     if (timing) fprintf(stderr, "  contig merge: %u rounds, %llu growths, %llu parked hits re-aligned, %u queries handed back to the host\n", round, (unsigned long long) grownTotal, (unsigned long long) parkedTotal, hc[1]);
     lap("queues + extension (device)");
+    // (what the rounds worked on goes back before the results are allocated: a result placed behind these blocks would sit in the middle
+    // of the arena's free space once they are released, and the next kmermatcher's 30 GB buffers would have to be mapped anew)
+    key.free(); co.free(); gate.free(); heap.free(); park.free(); parkWork.free(); ops.free(); listA.free(); listB.free(); grown.free(); gWords.free(); gWoff.free();
+    prevRound.free(); prevWoff.free(); prevLen.free(); heapN.free(); parkN.free(); leftOff.free();
     // ---- the grown contigs as a DB of their own, in the order of their queries
     DevBuf<uint32_t> words, wpos;
     if (!words.alloc((size_t) n + 1) || !wpos.alloc((size_t) n + 1)) { freeRounds(); cdm_set_error("cdm_contig_merge: out of device memory"); return CDM_ERR_HIP; }

@@ -79,6 +79,7 @@ namespace cdmpool {
 #ifndef CDM_POOL_ROOMY_MIN
 #define CDM_POOL_ROOMY_MIN ((size_t) 64 << 20)      // head room (cdm_pool_headroom) applies to requests of this size and more
 #endif
+constexpr size_t RUNTIME_RESERVE = (size_t) 1 << 30;      // device memory the pool leaves alone (growArena)
 constexpr size_t LARGE_CHUNK = CDM_POOL_LARGE_CHUNK, SMALL_CHUNK = CDM_POOL_SMALL_CHUNK, ROOMY_MIN = CDM_POOL_ROOMY_MIN;
 constexpr size_t SMALL_MAX = (size_t) 256 << 10;    // requests below this come from the small arena (long-lived odds and ends do not cut up the large one)
 enum { B_USED = 0, B_FREE = 1, B_HOLE = 2 };        // (a hole: a free range whose chunk was given back - addresses without memory)
@@ -191,6 +192,18 @@ inline hipError_t growArena(Arena &a, int device, size_t need) {
             }
         }
         if (!hole && a.end + chunk > a.reserved) return hipErrorOutOfMemory;
+        // The driver hands out MORE than the device holds - hipMemCreate kept succeeding at 307 GB mapped on a 288 GB MI355X (the 25 M-read
+        // workflow's ninth iteration, round 5), 3.3 s in the calls, and kmermatcher then ran three times slower on whatever backed the
+        // excess.  So the pool asks first: below a chunk plus what the runtime needs for its own launches, this is out of memory - the
+        // caller trims the arenas' free chunks and tries again.
+        {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) (void) hipGetLastError();
+            else if (fr < chunk + RUNTIME_RESERVE) {
+                if (cdmenv::get("CDM_POOL_DEBUG")) fprintf(stderr, "carpedeam pool: %zu bytes free on the device, a chunk of %zu is not mapped\n", fr, chunk);
+                return hipErrorOutOfMemory;
+            }
+        }
         hipMemGenericAllocationHandle_t h;
         DriverTimer t(chunk);
         hipError_t e;
