@@ -438,7 +438,9 @@ def main():
             "dtype": "u8 (2-bit packed bases; int32 scores; software x87 f80 likelihood sums)", "data": "synthetic",
             "config": {"workload": workload, "reads_rank0": n, "read_len": L, "seed": args.seed, "prefilter_hits": stats[0], "alignments": stats[1],
                        "multi_gpu_scheme": (None if world == 1 and not exact else
-                                            "exact: the library's own RCCL calls (csrc/dist.hip) - every rank extracts its block of the reads, all-to-alls carry the k-mer tuples to the rank of their k-mer range and the group keys to the owner of their representative (ranges and owners cut per step from all ranks' counts), the other stages run on the owned queries, the new sequences are all-gathered; bit-identical to one device (prefilter_hits / alignments are summed over the ranks: the single-device counts at every N)" if exact else
+                                            ("exact: the library's own RCCL calls (csrc/dist.hip), bit-identical to one device (prefilter_hits / alignments are summed over the ranks: the single-device counts at every N); kmermatcher this run: " +
+                                             {"replicate": "every rank ran it whole (two ranks, or a DB that takes the wide group key) and kept its owned representatives' hits - no exchange", "all": "every rank extracted all reads, kept its range of the k-mer space, one all-to-all of group keys to the owners of their representatives", "split": "every rank extracted its block of the reads, all-to-alls carried the k-mer tuples to the rank of their k-mer range and the group keys to the owners of their representatives", "part": "equal slices of the k-mer space by value, one all-to-all of group keys", None: "(not run)"}[comm.last_path()] +
+                                             "; rescorediagonal / ancient_correction / ancient_read_assemble on the owned queries, the new sequences all-gathered") if exact else
                                             "reads: every rank runs the stages on its own read shard, no data-path collective, one all-gather of contigs at the end; NOT equivalent to the single-device run (a shard sees 1/N of every pile-up)"),
                        "equivalent_to_single_device": bool(world == 1 or exact),
                        "value_is": "kernel-resident: reads already in HBM, no DB files (the module-wall figure is gpu_module_wall)",
@@ -472,7 +474,9 @@ def main():
                 if cpu.get("value"):
                     line["vs_cpu_baseline"] = {"device_modules_on_db_files": gpu["value"] / cpu["value"],
                                                "fused_reads_loop_on_db_files": (gpu["fused_reads_loop_value"] / cpu["value"]) if gpu.get("fused_reads_loop_value") else None,
-                                               "kernel_resident_value": line["value"] / cpu["value"], "sample_reads": args.cpu_reads}
+                                               "sample_reads": args.cpu_reads}
+                    # (no ratio of `value` to this baseline: value is kernel-resident on the whole corpus, the baseline a run on DB files of
+                    #  the sample - the two legs above are the like-for-like ones)
             except Exception as e:   # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "corrected bases/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": str(e)[:300]}
         print(json.dumps(line))

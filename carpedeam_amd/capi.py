@@ -64,7 +64,7 @@ EXPORTS = [
     "cdm_seqdb_from_packed_ext", "cdm_seqdb_copy_ext", "cdm_seqdb_export_packed", "cdm_seqdb_import_packed", "cdm_contig_merge", "cdm_cyclecheck", "cdm_seqdb_has_raw", "cdm_seqdb_copy_raw", "cdm_seqdb_attach_raw",
     "cdm_rescore_hamming", "cdm_pool_headroom", "cdm_pool_stats", "cdm_env_refresh",
     "cdm_comm_unique_id", "cdm_comm_create_rccl", "cdm_comm_create_ops", "cdm_comm_free", "cdm_comm_rank", "cdm_comm_world", "cdm_kmermatch_dist",
-    "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist", "cdm_contig_iteration_dist", "cdm_comm_owned", "cdm_kpart_gather_at", "cdm_comm_standin_group", "cdm_comm_create_standin", "cdm_kpart_set_range",
+    "cdm_seqdb_allgather_owned", "cdm_reads_iteration_dist", "cdm_contig_iteration_dist", "cdm_comm_owned", "cdm_comm_last_path", "cdm_kpart_gather_at", "cdm_comm_standin_group", "cdm_comm_create_standin", "cdm_kpart_set_range",
 ]
 
 
@@ -602,6 +602,11 @@ class Comm:
         b = np.zeros(lib().cdm_comm_world(self.h) + 1, np.uint64)
         _check(lib().cdm_comm_owned(self.h, int(n), _ptr(b)))
         return b
+
+    def last_path(self):
+        """what the last kmermatch over the ranks did (cdm_comm_last_path)"""
+        lib().cdm_comm_last_path.argtypes = [C.c_void_p]
+        return {0: None, 1: "replicate", 2: "all", 3: "split", 4: "part"}[int(lib().cdm_comm_last_path(self.h))]
 
     def reads_iteration(self, db, kpar=None, rpar=None, apar=None):
         """one iteration of the reads loop over the ranks -> (hits, alns, corrected DB, next DB); the DBs are complete on every rank"""

@@ -76,6 +76,8 @@ struct cdm_comm {
     // on the caller's buffers (A/B).
     struct Stage { void *p = nullptr; size_t bytes = 0; } stage, sendStage, recvStage;
     std::vector<uint64_t> own; uint64_t ownN = 0;       // the owners' id ranges as the last cdm_kmermatch_dist cut them (for DBs of ownN sequences)
+    bool knowsFailure = false;          // this call: a rank's failure has been agreed on (or announced by this rank) - no further collective is entered
+    int lastPath = 0;                   // what the last cdm_kmermatch_dist did: 1 every rank ran kmermatcher whole, 2 every rank extracted all reads and kept its k-mer range, 3 the reads were split and the tuples travelled, 4 equal k-mer slices by value (cdm_kmermatch_part)
 };
 namespace {
 int ensureStage(cdm_comm *c, cdm_comm::Stage &st, size_t need) {
@@ -92,6 +94,42 @@ int ensureStage(cdm_comm *c, cdm_comm::Stage &st, size_t need) {
 bool rcclDirect() { const char *e = cdmGetenv("CDM_RCCL_DIRECT"); return e && *e == '1'; }
 }  // namespace
 #define CDM_NCCL(call, what) do { const int e_ = (call); if (e_ != 0) { cdm_set_error("RCCL %s failed: %s", what, r->errorString ? r->errorString(e_) : "?"); return CDM_ERR_HIP; } } while (0)
+
+// ---- a failure on ONE rank must not leave the others inside a collective (out of memory for an exchange buffer, a refusal that depends
+// on a rank's data): every collective of the calling sequences below is entered through co*(), which first all-gathers a status word;
+// a rank that failed announces its code once (Sequence's end) - its peers meet that in their next co*() or at their own end - and
+// every rank returns an error from the same call.
+namespace {
+int agree(cdm_comm *cm, int mine, const char *where) {
+    if (cm->world == 1) return mine;
+    std::vector<int32_t> all((size_t) cm->world, 0);
+    const int32_t m = mine;
+    if (int rc = cm->ops.all_gather_host(cm->ops.user, &m, all.data(), 4)) { cm->knowsFailure = true; return rc; }
+    for (int p = 0; p < cm->world; p++) if (all[p] != 0) {
+        cm->knowsFailure = true;
+        if (mine == CDM_OK) cdm_set_error("%s: rank %d failed with error %d (its message is that rank's cdm_last_error)", where, p, (int) all[p]);
+        return mine != CDM_OK ? mine : (int) all[p];
+    }
+    return CDM_OK;
+}
+int coAllGatherHost(cdm_comm *cm, const void *send, void *recv, uint64_t bytes) {
+    if (int rc = agree(cm, CDM_OK, "a collective of the multi-GPU calls")) return rc;
+    return cm->ops.all_gather_host(cm->ops.user, send, recv, bytes);
+}
+int coAllToAllDev(cdm_comm *cm, const void *send, const uint64_t *so, void *recv, const uint64_t *ro, void *stream) {
+    if (int rc = agree(cm, CDM_OK, "a collective of the multi-GPU calls")) return rc;
+    return cm->ops.all_to_all_dev(cm->ops.user, send, so, recv, ro, stream);
+}
+int coAllGatherDev(cdm_comm *cm, const void *send, uint64_t bytes, void *recv, const uint64_t *ro, void *stream) {
+    if (int rc = agree(cm, CDM_OK, "a collective of the multi-GPU calls")) return rc;
+    return cm->ops.all_gather_dev(cm->ops.user, send, bytes, recv, ro, stream);
+}
+// the end of a calling sequence: a rank that failed on its own tells the others; the others learn it here at the latest
+int finish(cdm_comm *cm, int rc, const char *where) {
+    if (cm->world == 1 || cm->knowsFailure) return rc;
+    return agree(cm, rc, where);
+}
+}  // namespace
 
 // ---- RCCL transport
 void standinEnter(cdm_comm *c);      // (the in-process stand-in's group calls need to know the calling rank: below)
@@ -288,6 +326,9 @@ extern "C" int cdm_comm_owned(const cdm_comm *c, uint64_t n, uint64_t *bounds) {
     if (!c || !bounds) { cdm_set_error("cdm_comm_owned: invalid argument"); return CDM_ERR_INVALID; }
     const int W = c->world;
     if (c->ownN == n && (int) c->own.size() == W + 1) { for (int p = 0; p <= W; p++) bounds[p] = c->own[p]; return CDM_OK; }
+    // equal id ranges only while nothing has been cut: a DB of another size than the one the last cdm_kmermatch_dist cut the owners for
+    // would be gathered by a partition its hits and alignments were not computed for
+    if (!c->own.empty()) { cdm_set_error("cdm_comm_owned: the owners' ranges were cut for a DB of %llu sequences (the last cdm_kmermatch_dist), not %llu", (unsigned long long) c->ownN, (unsigned long long) n); return CDM_ERR_INVALID; }
     for (int p = 0; p <= W; p++) bounds[p] = (uint64_t) ((unsigned __int128) n * (unsigned) p / (unsigned) W);
     return CDM_OK;
 }
@@ -311,8 +352,9 @@ int firstHalf(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_pa
     // against 52; W = 8: 13 + 15), so that is the default rule; CDM_DIST_EXTRACT=split|all|part forces one ("part": round 3's
     // cdm_kmermatch_part, whose ranges are equal slices of the k-mer space by value and far from equal shares).
     const char *how = cdmGetenv("CDM_DIST_EXTRACT");
-    if (W == 1 || (how && !strcmp(how, "part"))) return cdm_kmermatch_part(ctx, db, par, R, W, out);
+    if (W == 1 || (how && !strcmp(how, "part"))) { cm->lastPath = 4; return cdm_kmermatch_part(ctx, db, par, R, W, out); }
     const bool everything = how ? !strcmp(how, "all") : W < 6;
+    cm->lastPath = everything ? 2 : 3;
     constexpr int F = CDM_KPART_SLICES;
     if (everything) {
         if (int rc = cdm_kmermatch_split_begin(ctx, db, par, 0, 1, out)) return rc;
@@ -343,7 +385,7 @@ int firstHalf(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_pa
     std::vector<uint64_t> counts(row), matrix(row * W);
     for (int f = 0; f < F; f++) counts[f] = fineOff[f + 1] - fineOff[f];
     counts[F] = nHash;
-    if (int rc = op.all_gather_host(op.user, counts.data(), matrix.data(), row * 8)) return rc;
+    if (int rc = coAllGatherHost(cm, counts.data(), matrix.data(), row * 8)) return rc;
     // the ranks' k-mer ranges: runs of fine slices with about the same number of tuples over all ranks (every rank cuts the same way)
     std::vector<int> cut(1, 0);
     {
@@ -372,7 +414,7 @@ int firstHalf(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_pa
     std::vector<uint64_t> so((size_t) W + 1), ro((size_t) W + 1);
     auto exchange = [&](const void *send, void *recv, const std::vector<uint64_t> &sOff, const std::vector<uint64_t> &rOff, uint64_t width) -> int {
         for (int p = 0; p <= W; p++) { so[p] = sOff[p] * width; ro[p] = rOff[p] * width; }
-        return op.all_to_all_dev(op.user, send, so.data(), recv, ro.data(), ctx->stream);
+        return coAllToAllDev(cm, send, so.data(), recv, ro.data(), ctx->stream);
     };
     if (int rc = exchange(keys, rk.p, off, recvCnt, 8)) return rc;
     if (int rc = exchange(vals, rv.p, off, recvCnt, (uint64_t) vb)) return rc;
@@ -447,15 +489,14 @@ int replicatedKmermatch(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const c
     return CDM_OK;
 }
 }  // namespace
-extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
-    if (!ctx || !cm || !db || !par || !out) { cdm_set_error("cdm_kmermatch_dist: invalid argument"); return CDM_ERR_INVALID; }
+static int kmermatchDistBody(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
     const int W = cm->world, R = cm->rank;
     const cdm_comm_ops &op = cm->ops;
     {
         const char *km = cdmGetenv("CDM_DIST_KMER");
         const bool replicate = km ? !strcmp(km, "replicate") : (W == 2 && !cdmGetenv("CDM_DIST_EXTRACT"));
         // (a DB that takes the wide group key - 25 M sequences with contigs - is replicated too: the exchange carries the narrow form only)
-        if ((W > 1 && replicate) || cdm_kmermatch_needs_wide_key(db)) return replicatedKmermatch(ctx, cm, db, par, out);
+        if ((W > 1 && replicate) || cdm_kmermatch_needs_wide_key(db)) { cm->lastPath = 1; return replicatedKmermatch(ctx, cm, db, par, out); }
     }
     PartGuard g;
     if (int rc = firstHalf(ctx, cm, db, par, &g.p)) return rc;
@@ -464,14 +505,14 @@ extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *d
     // ---- the left-over list of the reference's last per-target scan: it starts at k-mer-order index J = number of ALL kept group keys
     // (assignGroup's compaction, :875-887) - which range holds that index, and what the ranges behind it begin with
     std::vector<uint64_t> infos(2 * (size_t) W);
-    { const uint64_t mine[2] = {info[0], info[1]}; if (int rc = op.all_gather_host(op.user, mine, infos.data(), 16)) return rc; }
+    { const uint64_t mine[2] = {info[0], info[1]}; if (int rc = coAllGatherHost(cm, mine, infos.data(), 16)) return rc; }
     uint64_t J = 0; for (int p = 0; p < W; p++) J += infos[2 * p + 1];
     int holder = -1; uint64_t jLocal = 0;
     { uint64_t base = 0; for (int p = 0; p < W; p++) { if (J < base + infos[2 * p]) { holder = p; jLocal = J - base; break; } base += infos[2 * p]; } }
     uint32_t mineStale[STALE_LEN]; memset(mineStale, 0, sizeof(mineStale));
     if (holder >= 0 && R >= holder) if (int rc = cdm_kpart_stale(ctx, g.p, R == holder ? jLocal : 0, mineStale)) return rc;
     std::vector<uint32_t> lists((size_t) W * STALE_LEN);
-    if (int rc = op.all_gather_host(op.user, mineStale, lists.data(), sizeof(mineStale))) return rc;
+    if (int rc = coAllGatherHost(cm, mineStale, lists.data(), sizeof(mineStale))) return rc;
     uint32_t stale[STALE_LEN]; memset(stale, 0, sizeof(stale));
     if (holder >= 0) {      // the scan collects tuples while they belong to one sequence; it goes on into the next range when it consumed the current one
         uint32_t cnt = 0; bool have = false; uint32_t target = 0;
@@ -500,7 +541,7 @@ extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *d
         if (int rc = cdm_kpart_gather_at(ctx, g.p, S + 1, sb.data(), so.data(), &keys)) return rc;
         so[S] = info[1];
         for (int t = 0; t < S; t++) hist[t] = so[t + 1] - so[t];
-        if (int rc = op.all_gather_host(op.user, hist.data(), all.data(), (uint64_t) S * 8)) return rc;
+        if (int rc = coAllGatherHost(cm, hist.data(), all.data(), (uint64_t) S * 8)) return rc;
         uint64_t grand = 0;
         // (weight of an id range: its group keys - sort 2, vote and the stages behind them work per key - plus its sequences: the owner of
         //  a range sends those rows of the corrected and of the next DB to every rank, about as many nanoseconds per row over the links
@@ -518,7 +559,7 @@ extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *d
     off[W] = info[1];
     std::vector<uint64_t> counts((size_t) W), matrix((size_t) W * W);
     for (int p = 0; p < W; p++) counts[p] = off[p + 1] - off[p];
-    if (int rc = op.all_gather_host(op.user, counts.data(), matrix.data(), (uint64_t) W * 8)) return rc;
+    if (int rc = coAllGatherHost(cm, counts.data(), matrix.data(), (uint64_t) W * 8)) return rc;
     std::vector<uint64_t> sendOff((size_t) W + 1), recvOff((size_t) W + 1, 0);
     for (int p = 0; p <= W; p++) sendOff[p] = off[p] * 8;
     for (int p = 0; p < W; p++) recvOff[p + 1] = recvOff[p] + matrix[(size_t) p * W + R] * 8;      // rank p's slice for me, in rank = k-mer order
@@ -526,7 +567,7 @@ extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *d
     DevBuf<uint64_t> recv;
     if (!recv.alloc(nRecv)) { cdm_set_error("cdm_kmermatch_dist: out of device memory for %llu received group keys", (unsigned long long) nRecv); return CDM_ERR_HIP; }
     CDM_HIP(hipSetDevice(ctx->device));
-    if (int rc = op.all_to_all_dev(op.user, keys, sendOff.data(), recv.p, recvOff.data(), ctx->stream)) return rc;
+    if (int rc = coAllToAllDev(cm, keys, sendOff.data(), recv.p, recvOff.data(), ctx->stream)) return rc;
     CDM_HIP(hipStreamSynchronize(ctx->stream));
     // ---- second half on what arrived; the heads of the sorted arrays go round once more (a rank's last scan runs into the next ranks' first tuples)
     const int capHead = cdm_kpart_cont_cap() + 3;
@@ -536,7 +577,7 @@ extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *d
     recv.free();
     memcpy(head.data(), &info2[0], 8); head[2] = (uint32_t) info2[1];
     std::vector<uint32_t> heads((size_t) W * head.size());
-    if (int rc = op.all_gather_host(op.user, head.data(), heads.data(), head.size() * 4)) return rc;
+    if (int rc = coAllGatherHost(cm, head.data(), heads.data(), head.size() * 4)) return rc;
     std::vector<uint32_t> cont;
     if (info2[0] != 0) {
         const uint32_t t = (uint32_t) info2[1];
@@ -564,8 +605,7 @@ __global__ void k_row_flags(const uint8_t *__restrict__ hasN, uint64_t lo, uint6
     if (i < m) flags[i] = (hasN[lo + i] & 2u) ? 1 : 0;
 }
 }  // namespace
-extern "C" int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *local, cdm_seqdb **out) {
-    if (!ctx || !cm || !local || !out) { cdm_set_error("cdm_seqdb_allgather_owned: invalid argument"); return CDM_ERR_INVALID; }
+static int allgatherOwnedBody(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *local, cdm_seqdb **out) {
     const int W = cm->world, R = cm->rank;
     const cdm_comm_ops &op = cm->ops;
     CDM_HIP(hipSetDevice(ctx->device));
@@ -577,7 +617,7 @@ extern "C" int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *cm, const cdm_s
     if (n) { CDM_HIP(hipMemcpyAsync(&wb[0], local->woff + lo, 4, hipMemcpyDeviceToHost, s)); CDM_HIP(hipMemcpyAsync(&wb[1], local->woff + hi, 4, hipMemcpyDeviceToHost, s)); CDM_HIP(hipStreamSynchronize(s)); }
     const uint64_t w0 = wb[0], w = wb[1] - wb[0];
     std::vector<uint64_t> metas(3 * (size_t) W);
-    { const uint64_t mine[3] = {m, w, local->raw ? 1ull : 0ull}; if (int rc = op.all_gather_host(op.user, mine, metas.data(), 24)) return rc; }
+    { const uint64_t mine[3] = {m, w, local->raw ? 1ull : 0ull}; if (int rc = coAllGatherHost(cm, mine, metas.data(), 24)) return rc; }
     uint64_t nAll = 0, wAll = 0; bool anyRaw = false;
     std::vector<uint64_t> seqOff((size_t) W + 1, 0), wordOff((size_t) W + 1, 0);
     for (int p = 0; p < W; p++) { seqOff[p + 1] = seqOff[p] + metas[3 * p]; wordOff[p + 1] = wordOff[p] + metas[3 * p + 1]; anyRaw |= metas[3 * p + 2] != 0; }
@@ -590,7 +630,7 @@ extern "C" int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *cm, const cdm_s
     auto gather = [&](const void *send, uint64_t unit, const std::vector<uint64_t> &offs, uint64_t count, void *recvBuf) -> int {
         std::vector<uint64_t> ro((size_t) W + 1);
         for (int p = 0; p <= W; p++) ro[p] = offs[p] * unit;
-        return op.all_gather_dev(op.user, send, count * unit, recvBuf, ro.data(), s);
+        return coAllGatherDev(cm, send, count * unit, recvBuf, ro.data(), s);
     };
     if (int rc = gather(local->codes + w0, 4, wordOff, w, codes.p)) return rc;
     if (int rc = gather(reinterpret_cast<const uint16_t *>(local->nmask) + w0, 2, wordOff, w, mask.p)) return rc;
@@ -616,6 +656,24 @@ extern "C" int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *cm, const cdm_s
     return CDM_OK;
 }
 
+extern "C" int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+    if (!ctx || !cm || !db || !par || !out) { cdm_set_error("cdm_kmermatch_dist: invalid argument"); return CDM_ERR_INVALID; }
+    cm->knowsFailure = false; *out = nullptr;
+    const int rc = kmermatchDistBody(ctx, cm, db, par, out);
+    const int all = finish(cm, rc, "cdm_kmermatch_dist");
+    if (all != CDM_OK && *out) { cdm_hits_free(*out); *out = nullptr; }
+    return all;
+}
+extern "C" int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *local, cdm_seqdb **out) {
+    if (!ctx || !cm || !local || !out) { cdm_set_error("cdm_seqdb_allgather_owned: invalid argument"); return CDM_ERR_INVALID; }
+    cm->knowsFailure = false; *out = nullptr;
+    const int rc = allgatherOwnedBody(ctx, cm, local, out);
+    const int all = finish(cm, rc, "cdm_seqdb_allgather_owned");
+    if (all != CDM_OK && *out) { cdm_seqdb_free(*out); *out = nullptr; }
+    return all;
+}
+extern "C" int cdm_comm_last_path(const cdm_comm *c) { return c ? c->lastPath : 0; }
+
 // One iteration of the reads loop over the ranks: the hits of the owned representatives, their alignments, and the two DBs - complete
 // on every rank and identical to the single-device ones.  rpar / apar may be NULL (defaults).  Any of the outputs may be NULL.
 extern "C" int cdm_reads_iteration_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *kpar, const cdm_rescore_params *rpar,
@@ -629,6 +687,7 @@ extern "C" int cdm_reads_iteration_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_se
     if (rc == CDM_OK) rc = cdm_extend(ctx, corr, alns, apar, &nLocal, nullptr);
     if (rc == CDM_OK) rc = cdm_seqdb_allgather_owned(ctx, cm, nLocal, &next);
     if (nLocal) cdm_seqdb_free(nLocal);
+    if (rc != CDM_OK) rc = finish(cm, rc, "cdm_reads_iteration_dist");       // (a stage that failed on this rank alone: the peers wait in the next collective)
     if (rc == CDM_OK && hitsOut) { *hitsOut = hits; hits = nullptr; }
     if (rc == CDM_OK && alnsOut) { *alnsOut = alns; alns = nullptr; }
     if (rc == CDM_OK && corrOut) { *corrOut = corr; corr = nullptr; }
@@ -657,6 +716,7 @@ extern "C" int cdm_contig_iteration_dist(cdm_ctx *ctx, cdm_comm *cm, const cdm_s
     if (rc == CDM_OK) rc = cdm_contig_merge(ctx, corr, alns, apar, mergeSeqIdThr, &nLocal);
     if (rc == CDM_OK) rc = cdm_seqdb_allgather_owned(ctx, cm, nLocal, &next);
     if (nLocal) cdm_seqdb_free(nLocal);
+    if (rc != CDM_OK) rc = finish(cm, rc, "cdm_contig_iteration_dist");
     if (rc == CDM_OK && alnsOut) { *alnsOut = alns; alns = nullptr; }
     if (rc == CDM_OK && corrOut) { *corrOut = corr; corr = nullptr; }
     if (rc == CDM_OK && nextOut) { *nextOut = next; next = nullptr; }

@@ -344,7 +344,10 @@ int cdm_cyclecheck(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t max_seq_len, int 
  *                            rank owns about the same number of group keys (representatives are the longest, then lowest ids: equal id
  *                            ranges gave the first of 8 ranks 88 % of them at 50 M reads); cdm_comm_owned reports the ranges
  *   cdm_comm_owned           bounds[world + 1]: rank r owns the sequences [bounds[r], bounds[r + 1]) of a DB of n sequences - as the
- *                            communicator's last cdm_kmermatch_dist on such a DB cut them, equal ranges before any
+ *                            communicator's last cdm_kmermatch_dist on such a DB cut them, equal ranges before any; CDM_ERR_INVALID for a
+ *                            DB of another size than the one the ranges were cut for
+ * A failure on one rank (out of memory for an exchange buffer, a refusal that depends on the rank's data) is agreed on before the next
+ * collective is entered: every rank returns an error from the same call, none is left waiting in RCCL.
  *   cdm_seqdb_allgather_owned   the owned ranges (cdm_comm_owned) of the ranks' DBs (same number of sequences on every rank) -> the complete DB
  *   cdm_reads_iteration_dist    one iteration of the reads loop (data/nuclassemble.sh:100-146) over the ranks; hits / alns hold the
  *                            owned queries' records, corr / next are complete on every rank and equal the single-device DBs
@@ -375,6 +378,10 @@ void cdm_comm_free(cdm_comm *c);
 int cdm_comm_rank(const cdm_comm *c);
 int cdm_comm_world(const cdm_comm *c);
 int cdm_comm_owned(const cdm_comm *c, uint64_t n, uint64_t *bounds);
+/* what the communicator's last cdm_kmermatch_dist did: 0 nothing yet, 1 every rank ran kmermatcher whole (two ranks; a DB that takes the wide
+ * group key), 2 every rank extracted all reads and kept its range of the k-mer space, 3 the reads were split and the k-mer tuples travelled,
+ * 4 equal slices of the k-mer space by value (cdm_kmermatch_part) */
+int cdm_comm_last_path(const cdm_comm *c);
 int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out);
 int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *local, cdm_seqdb **out);
 int cdm_reads_iteration_dist(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *db, const cdm_kmer_params *kpar, const cdm_rescore_params *rpar,

@@ -269,11 +269,12 @@ def run_standin_ranks(world, fn):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 3, 6])
+@pytest.mark.parametrize("world", [2, 3, 6, 8])
 def test_rccl_transport_code_with_real_peers(dhigh_prefix, world):
     """The RCCL transport (csrc/dist.hip rcclAllToAllDev / rcclAllGatherDev / rcclAllGatherHost: a rank's own share copied on the device,
     the peers' shares through the transport's hipMalloc buffers in pieces) had only ever met itself as a peer - one GPU per box.  Here
-    its code runs over a stand-in for RCCL's send / recv / all-gather inside the process, with 2, 3 and 5 ranks: one iteration of the
+    its code runs over a stand-in for RCCL's send / recv / all-gather inside the process, with 2, 3, 6 and 8 ranks (threads of this one
+    process: the box's limit of six PROCESSES on the card does not apply): one iteration of the
     reads loop on 200 k reads equals the single-device calls."""
     ref = capi.Ctx(0)
     ref.damage_load(dhigh_prefix)
@@ -353,7 +354,7 @@ def test_split_by_reads_sends_every_tuple_once(ctx):
         assert per_slice[: capi.KPART_SLICES // 2].sum() > 0.6 * per_slice.sum()
 
 
-@pytest.mark.parametrize("world,extract", [(2, None), (3, None), (2, "split"), (3, "split"), (2, "part"), (2, "all"), (3, "replicate")])
+@pytest.mark.parametrize("world,extract", [(2, None), (3, None), (8, None), (2, "split"), (3, "split"), (2, "part"), (2, "all"), (3, "replicate")])
 def test_native_exact_iteration_equals_single_device(dhigh_prefix, world, extract, monkeypatch):
     """cdm_reads_iteration_dist (csrc/dist.hip: the exact scheme in the library, as a deployment runs it over RCCL) on 200 k mixed-length
     reads with `world` ranks: hits, corrected DB and next DB equal the single-device calls'."""
@@ -434,6 +435,32 @@ def test_native_contig_iteration_equals_single_device(dhigh_prefix, world, trans
             for got, exp in zip(r[it], want[it]):
                 assert [bytes(x) for x in got[0]] == [bytes(x) for x in exp[0]]
                 assert np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2])
+
+
+def test_a_failure_on_one_rank_ends_the_call_on_all(dhigh_prefix, monkeypatch):
+    """A failure local to one rank - here: rank 1's DB differs in size, which its all-gather of the owned rows refuses - is agreed on before
+    the next collective (csrc/dist.hip agree / finish): every rank's call returns an error, none waits in the transport for a peer that
+    left; and cdm_comm_owned refuses a DB of another size than the one the owners' ranges were cut for."""
+    world = 3
+
+    def rank_fn(rank, comm, c):
+        c.damage_load(dhigh_prefix)
+        db = c.synth(20_000, 60, 150, 3)
+        h = comm.kmermatch(db)                     # cuts the owners' ranges for 20 000 sequences
+        other = c.synth(20_000 if rank != 1 else 19_000, 60, 150, 3)
+        try:
+            comm.allgather_owned(other)
+            return "ok"
+        except capi.CdmError as e:
+            msg = str(e)
+        with pytest.raises(capi.CdmError):
+            comm.owned(19_000)
+        return msg
+
+    res = run_native_ranks(world, rank_fn)
+    assert all(r != "ok" for r in res), res
+    assert "19000" in res[1] or "were cut for" in res[1]
+    assert all("rank 1 failed" in res[r] for r in (0, 2)), res
 
 
 def test_native_kmermatcher_on_small_databases():
