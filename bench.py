@@ -439,7 +439,7 @@ def main():
             "config": {"workload": workload, "reads_rank0": n, "read_len": L, "seed": args.seed, "prefilter_hits": stats[0], "alignments": stats[1],
                        "multi_gpu_scheme": (None if world == 1 and not exact else
                                             ("exact: the library's own RCCL calls (csrc/dist.hip), bit-identical to one device (prefilter_hits / alignments are summed over the ranks: the single-device counts at every N); kmermatcher this run: " +
-                                             {"replicate": "every rank ran it whole (two ranks, or a DB that takes the wide group key) and kept its owned representatives' hits - no exchange", "all": "every rank extracted all reads, kept its range of the k-mer space, one all-to-all of group keys to the owners of their representatives", "split": "every rank extracted its block of the reads, all-to-alls carried the k-mer tuples to the rank of their k-mer range and the group keys to the owners of their representatives", "part": "equal slices of the k-mer space by value, one all-to-all of group keys", None: "(not run)"}[comm.last_path()] +
+                                             {"replicate": "every rank ran it whole (two ranks, or a DB that takes the wide group key) and kept its owned representatives' hits - no exchange", "all": "every rank extracted all reads, kept its range of the k-mer space, one all-to-all of group keys to the owners of their representatives", "split": "every rank extracted its block of the reads, all-to-alls carried the k-mer tuples to the rank of their k-mer range and the group keys to the owners of their representatives", "part": "equal slices of the k-mer space by value, one all-to-all of group keys", "ranges": "extraction and sort 1 / grouping by ranges of the k-mer space, the kept group keys all-gathered, sort 2 and the vote on every rank", None: "(not run)"}[comm.last_path()] +
                                              "; rescorediagonal / ancient_correction / ancient_read_assemble on the owned queries, the new sequences all-gathered") if exact else
                                             "reads: every rank runs the stages on its own read shard, no data-path collective, one all-gather of contigs at the end; NOT equivalent to the single-device run (a shard sees 1/N of every pile-up)"),
                        "equivalent_to_single_device": bool(world == 1 or exact),

@@ -606,7 +606,7 @@ class Comm:
     def last_path(self):
         """what the last kmermatch over the ranks did (cdm_comm_last_path)"""
         lib().cdm_comm_last_path.argtypes = [C.c_void_p]
-        return {0: None, 1: "replicate", 2: "all", 3: "split", 4: "part"}[int(lib().cdm_comm_last_path(self.h))]
+        return {0: None, 1: "replicate", 2: "all", 3: "split", 4: "part", 5: "ranges"}[int(lib().cdm_comm_last_path(self.h))]
 
     def reads_iteration(self, db, kpar=None, rpar=None, apar=None):
         """one iteration of the reads loop over the ranks -> (hits, alns, corrected DB, next DB); the DBs are complete on every rank"""

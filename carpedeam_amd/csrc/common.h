@@ -152,6 +152,14 @@ template <typename A> inline void cdmSetMeta(A &a, const SeqMeta *m, const MetaU
     a.woff.uw = u.words; a.len.ul = u.len; a.hasN.plain = a.hasRaw.plain = u.words;
 }
 int cdm_kmermatch_needs_wide_key(const cdm_seqdb *db);      // kmermatch.hip
+// kmermatcher's first half over ranks by ranges of the k-mer space (kmermatch.hip kmermatchPassesT; csrc/dist.hip fills the hooks from its
+// communicator): the whole hit set on every rank
+struct KmerRanks {
+    int rank, world; void *user;
+    int (*gatherHost)(void *user, const void *send, void *recv, uint64_t bytes);                                            // recv[p * bytes ..] = rank p's send
+    int (*gatherDev)(void *user, const void *send, uint64_t sendBytes, void *recv, const uint64_t *recvOff, void *stream);  // device buffers, byte offsets [world + 1]
+};
+int cdm_kmermatch_ranks_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, const KmerRanks *ranks, cdm_hits **out);
 int cdm_seqdb_overlay(cdm_ctx *ctx, const cdm_seqdb *base, const cdm_seqdb *grown, const uint32_t *idxHost, const uint8_t *extHost, cdm_seqdb **out);      // api.hip
 int cdm_build_meta(cdm_ctx *ctx, const cdm_seqdb *db, SeqMeta **out, MetaUniform *uniform = nullptr);      // cdmFree the result; uniform: filled (and the stream synchronised) if asked for
 

@@ -77,7 +77,7 @@ struct cdm_comm {
     struct Stage { void *p = nullptr; size_t bytes = 0; } stage, sendStage, recvStage;
     std::vector<uint64_t> own; uint64_t ownN = 0;       // the owners' id ranges as the last cdm_kmermatch_dist cut them (for DBs of ownN sequences)
     bool knowsFailure = false;          // this call: a rank's failure has been agreed on (or announced by this rank) - no further collective is entered
-    int lastPath = 0;                   // what the last cdm_kmermatch_dist did: 1 every rank ran kmermatcher whole, 2 every rank extracted all reads and kept its k-mer range, 3 the reads were split and the tuples travelled, 4 equal k-mer slices by value (cdm_kmermatch_part)
+    int lastPath = 0;                   // what the last cdm_kmermatch_dist did: 1 every rank ran kmermatcher whole, 2 every rank extracted all reads and kept its k-mer range, 3 the reads were split and the tuples travelled, 4 equal k-mer slices by value (cdm_kmermatch_part), 5 the first half by ranges of the k-mer space, the kept group keys all-gathered, the second half on every rank
 };
 namespace {
 int ensureStage(cdm_comm *c, cdm_comm::Stage &st, size_t need) {
@@ -447,10 +447,20 @@ __global__ void k_pick(const uint64_t *__restrict__ a, const uint64_t *__restric
 // 8 GB per rank over the one link two devices share: more time than the second device saves - so with two ranks
 // only the stages behind kmermatcher are split: every rank computes all hits, cuts the same owners' ranges from the rows' sizes and
 // keeps its view.  CDM_DIST_KMER=replicate|exchange forces either for any world.
-int replicatedKmermatch(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+// ... or, `ranges`: kmermatcher's first half split over the ranks by ranges of the k-mer space (kmermatch.hip kmermatchPassesT with its
+// rank hooks: each range's sort 1 and grouping on one rank, the kept group keys - the wide form included - all-gathered), sort 2 and the
+// vote on every rank.  What a DB with the wide group key takes since round 5 (until then: every rank ran kmermatcher whole), and
+// CDM_DIST_KMER=ranges for any DB.
+int ranksGatherHost(void *user, const void *send, void *recv, uint64_t bytes) { return coAllGatherHost((cdm_comm *) user, send, recv, bytes); }
+int ranksGatherDev(void *user, const void *send, uint64_t bytes, void *recv, const uint64_t *ro, void *stream) { return coAllGatherDev((cdm_comm *) user, send, bytes, recv, ro, stream); }
+int replicatedKmermatch(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out, bool ranges = false) {
     const int W = cm->world, R = cm->rank;
     cdm_hits *full = nullptr;
-    if (int rc = cdm_kmermatch(ctx, db, par, &full)) return rc;
+    if (ranges && W > 1) {
+        KmerRanks kr; kr.rank = R; kr.world = W; kr.user = cm; kr.gatherHost = ranksGatherHost; kr.gatherDev = ranksGatherDev;
+        if (cdmGetenv("CDM_KMER_SORT") || cdmGetenv("CDM_KMER_SORT2")) { cdm_set_error("cdm_kmermatch_dist: the A/B switches CDM_KMER_SORT / CDM_KMER_SORT2 apply to the single-device path only"); return CDM_ERR_INVALID; }
+        if (int rc = cdm_kmermatch_ranks_impl(ctx, db, par, &kr, &full)) return rc;
+    } else if (int rc = cdm_kmermatch(ctx, db, par, &full)) return rc;
     struct Guard { cdm_hits *h; ~Guard() { if (h) cdm_hits_free(h); } } guard{full};
     CDM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -495,7 +505,10 @@ static int kmermatchDistBody(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, co
     {
         const char *km = cdmGetenv("CDM_DIST_KMER");
         const bool replicate = km ? !strcmp(km, "replicate") : (W == 2 && !cdmGetenv("CDM_DIST_EXTRACT"));
-        // (a DB that takes the wide group key - 25 M sequences with contigs - is replicated too: the exchange carries the narrow form only)
+        // a DB that takes the wide group key - 25 M sequences with contigs: the exchange of group keys by owner carries the narrow form only;
+        // its first half goes over the ranks by k-mer ranges, the kept keys are all-gathered
+        const bool ranges = W > 1 && ((km && !strcmp(km, "ranges")) || (cdm_kmermatch_needs_wide_key(db) && !(km && !strcmp(km, "replicate"))));
+        if (ranges) { cm->lastPath = 5; return replicatedKmermatch(ctx, cm, db, par, out, true); }
         if ((W > 1 && replicate) || cdm_kmermatch_needs_wide_key(db)) { cm->lastPath = 1; return replicatedKmermatch(ctx, cm, db, par, out); }
     }
     PartGuard g;

@@ -2497,10 +2497,17 @@ int voteWith(const uint32_t *cont, const uint32_t *staleIn, cdm_hits **out) over
 // and sort 2 + vote run on it as they are.  What the reference's run-past-the-end scan needs (the tuples behind k-mer-order index J =
 // number of kept keys, known only at the end) comes from running the range that holds J once more.  Cost: P + 2 extractions of the
 // whole DB instead of one.
+// OVER RANKS (ranks != NULL; csrc/dist.hip for DBs that take the wide group key): the same passes, each range run by ONE rank - every rank
+// sweeps the blocks (the counts, hence the cuts, are the same everywhere), runs the ranges it owns (range r belongs to rank r W / P:
+// consecutive ranges, in rank order), and the kept group keys - run starts included in the wide form, so the array describes itself -
+// are all-gathered: every rank then holds the array a single device would have built and runs sort 2 + vote on it whole.  What is
+// split is the first half (extraction aside), 70 % of kmermatcher; what travels is 8 bytes per kept key to every rank.
 template <typename LY>
-int kmermatchPassesT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int P, int B, cdm_hits **out) {
+int kmermatchPassesT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int P, int B, cdm_hits **out, const KmerRanks *ranks = nullptr) {
     typedef typename LY::V V;
     hipStream_t s = ctx->stream;
+    const int W = ranks ? ranks->world : 1, R = ranks ? ranks->rank : 0;
+    if (W > 1) P = std::min(255, (std::max(P, 1) + W - 1) / W * W);
     if (P < 1 || P > 255 || B < 1) { cdm_set_error("cdm_kmermatch: %d passes over %d blocks", P, B); return CDM_ERR_INVALID; }        // (P: at most; fewer where the tuples sit in few slices of the k-mer space)
     const bool stats = cdmGetenv("CDM_BUCKET_STATS") != nullptr;
     // (this path runs because memory is short: its buffers are planned at their exact sizes, without the allocator's head room)
@@ -2580,10 +2587,13 @@ int kmermatchPassesT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *p
     std::vector<unsigned long long> realOf((size_t) P, 0);
     DevBuf<unsigned long long> cntDev;
     if (!cntDev.alloc(1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+    auto ownerOf = [&](int r) { return (int) ((long long) r * W / P); };
+    std::vector<unsigned long long> keptOf((size_t) P, 0);
     for (int r = 0; r < P; r++) {
+        if (ownerOf(r) != R) continue;
         KmerJob<LY> job(ctx, db, par);
         if (int rc = runRange(r, job)) return rc;
-        realOf[r] = job.live + job.regionTwo; J += job.nKept;
+        realOf[r] = job.live + job.regionTwo; J += job.nKept; keptOf[r] = job.nKept;
         const unsigned long long nt = job.nTuples;
         if (stats) fprintf(stderr, "kmermatch pass %d of %d: %llu tuples, %llu kept\n", r + 1, P, nt, job.nKept);
         if (nt == 0) continue;
@@ -2603,9 +2613,30 @@ int kmermatchPassesT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *p
         if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: collecting a pass's group keys failed"); return CDM_ERR_HIP; }
         gCount += got;
     }
+    if (W > 1) {
+        // every range's counts from its owner, then the kept keys of all ranks in rank (= range = k-mer) order
+        std::vector<unsigned long long> mine(2 * (size_t) P + 1), all((2 * (size_t) P + 1) * W);
+        for (int r = 0; r < P; r++) { mine[2 * r] = realOf[r]; mine[2 * r + 1] = keptOf[r]; }
+        mine[2 * (size_t) P] = gCount;
+        if (int rc = ranks->gatherHost(ranks->user, mine.data(), all.data(), mine.size() * 8)) return rc;
+        J = 0;
+        std::vector<uint64_t> recvOff((size_t) W + 1, 0);
+        for (int p = 0; p < W; p++) {
+            const unsigned long long *a = all.data() + (size_t) p * mine.size();
+            for (int r = 0; r < P; r++) if (ownerOf(r) == p) { realOf[r] = a[2 * r]; J += a[2 * r + 1]; }
+            recvOff[p + 1] = recvOff[p] + a[2 * (size_t) P] * 8;
+        }
+        const unsigned long long total = recvOff[W] / 8;
+        DevBuf<uint64_t> whole;
+        if (!whole.alloc(total)) { cdm_set_error("cdm_kmermatch: out of device memory for %llu group keys of all ranks", total); return CDM_ERR_HIP; }
+        if (!G.p && !G.alloc(0)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
+        if (int rc = ranks->gatherDev(ranks->user, G.p, gCount * 8, whole.p, recvOff.data(), s)) return rc;
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: gathering the ranks' group keys failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+        G.free(); G.p = whole.release(); gCount = total; gCap = total;
+    }
     // ---- the left-over list of the reference's last per-target scan (:875-887): from k-mer-order index J on, while the tuples belong
     // to one sequence - the range that holds index J once more, and the ranges behind it while the scan runs on (csrc/dist.hip does
-    // the same across ranks)
+    // the same across ranks; over ranks here, every rank runs that range itself: no exchange, one range's work)
     uint32_t stale[CDM_STALE_MAX + 5]; memset(stale, 0, sizeof(stale));
     if (J) {
         int holder = -1; unsigned long long jLocal = 0, base = 0;
@@ -2646,7 +2677,7 @@ inline bool onePassFits(const cdm_seqdb *db, double bytesPerSlot) {
     return (double) slots * bytesPerSlot * 1.1 <= 0.80 * (double) tot;
 }
 template <typename LY>
-int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out, const KmerRanks *ranks = nullptr) {
     // One pass while the tuples fit the device: 16 bytes of keys + two values per k-mer slot, two buffers of each.  CDM_KMER_PASSES=P[,B]
     // (tests, A/B): P passes over B blocks for any DB.
     int P = 1, B = 1;
@@ -2662,6 +2693,7 @@ int kmermatchT(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cd
             }
         } else (void) hipGetLastError();
     }
+    if (ranks && ranks->world > 1) return kmermatchPassesT<LY>(ctx, db, par, std::max(P, ranks->world), std::max(B, 1), out, ranks);
     if (P > 1 || B > 1) return kmermatchPassesT<LY>(ctx, db, par, std::max(P, 1), std::max(B, 1), out);
     KmerJob<LY> job(ctx, db, par);
     job.ownPipeline = true;
@@ -2806,7 +2838,10 @@ extern "C" int cdm_dev_copy(cdm_ctx *ctx, void *dst, const void *src, uint64_t b
     return CDM_OK;
 }
 
-int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
+int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) { return cdm_kmermatch_ranks_impl(ctx, db, par, nullptr, out); }
+// ranks != NULL: kmermatcher's first half split over the ranks by ranges of the k-mer space, the whole hit set on every rank (the passes
+// path above; csrc/dist.hip cuts the owned view out of it)
+int cdm_kmermatch_ranks_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, const KmerRanks *ranks, cdm_hits **out) {
     // packed 12-byte tuples when k-mer, position and length share 63 key bits; CDM_KMER_LAYOUT=wide|packed pins one (tests)
     const int k = par->kmer_size;
     const bool fits = 2 * k + 1 + 2 * (int) bitsFor((uint64_t) db->maxLen + 1) <= 63;
@@ -2824,12 +2859,12 @@ int cdm_kmermatch_impl(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params 
         const char *e = cdmGetenv("CDM_KMER_LAYOUT");
         const bool want = !e || !strcmp(e, "slot");
         if (e && !strcmp(e, "slot") && !slotLayoutFits(db, k)) { cdm_set_error("cdm_kmermatch: CDM_KMER_LAYOUT=slot needs sequences of one length (at least k letters), fewer than 2^32 k-mer slots and 14 <= k <= 20"); return CDM_ERR_INVALID; }
-        if (want && slotLayoutFits(db, k) && !cdmGetenv("CDM_KMER_SORT") && !cdmGetenv("CDM_KMER_PASSES") && onePassFits(db, 16.0 + 8.0)) return kmermatchT<LayoutSlot>(ctx, db, par, out);
+        if (want && !ranks && slotLayoutFits(db, k) && !cdmGetenv("CDM_KMER_SORT") && !cdmGetenv("CDM_KMER_PASSES") && onePassFits(db, 16.0 + 8.0)) return kmermatchT<LayoutSlot>(ctx, db, par, out);
     }
-    if (packed) return kmermatchT<LayoutPacked>(ctx, db, par, out);
-    if (db->maxLen < 65535u && !cdmGetenv("CDM_FORCE_HUGE_LAYOUT")) return kmermatchT<LayoutWide>(ctx, db, par, out);
-    if (db->maxLen < (1u << 20) - 1u && db->n < (1ull << 24) && !cdmGetenv("CDM_FORCE_HUGE_LAYOUT")) return kmermatchT<LayoutLong>(ctx, db, par, out);
-    if (db->maxLen < MAX_SEQ_LETTERS) return kmermatchT<LayoutHuge>(ctx, db, par, out);       // (CDM_FORCE_HUGE_LAYOUT=1 with CDM_KMER_LAYOUT=wide: this layout for any DB, tests)
+    if (packed) return kmermatchT<LayoutPacked>(ctx, db, par, out, ranks);
+    if (db->maxLen < 65535u && !cdmGetenv("CDM_FORCE_HUGE_LAYOUT")) return kmermatchT<LayoutWide>(ctx, db, par, out, ranks);
+    if (db->maxLen < (1u << 20) - 1u && db->n < (1ull << 24) && !cdmGetenv("CDM_FORCE_HUGE_LAYOUT")) return kmermatchT<LayoutLong>(ctx, db, par, out, ranks);
+    if (db->maxLen < MAX_SEQ_LETTERS) return kmermatchT<LayoutHuge>(ctx, db, par, out, ranks);       // (CDM_FORCE_HUGE_LAYOUT=1 with CDM_KMER_LAYOUT=wide: this layout for any DB, tests)
     cdm_set_error("cdm_kmermatch: sequences of %u letters or more are not implemented", MAX_SEQ_LETTERS);
     return CDM_ERR_UNSUPPORTED;
 }

@@ -380,7 +380,8 @@ int cdm_comm_world(const cdm_comm *c);
 int cdm_comm_owned(const cdm_comm *c, uint64_t n, uint64_t *bounds);
 /* what the communicator's last cdm_kmermatch_dist did: 0 nothing yet, 1 every rank ran kmermatcher whole (two ranks; a DB that takes the wide
  * group key), 2 every rank extracted all reads and kept its range of the k-mer space, 3 the reads were split and the k-mer tuples travelled,
- * 4 equal slices of the k-mer space by value (cdm_kmermatch_part) */
+ * 4 equal slices of the k-mer space by value (cdm_kmermatch_part), 5 the first half by ranges of the k-mer space, the kept group keys (wide form
+ * included) all-gathered, sort 2 and the vote on every rank (DBs that take the wide group key) */
 int cdm_comm_last_path(const cdm_comm *c);
 int cdm_kmermatch_dist(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out);
 int cdm_seqdb_allgather_owned(cdm_ctx *ctx, cdm_comm *comm, const cdm_seqdb *local, cdm_seqdb **out);

@@ -297,18 +297,27 @@ def test_rccl_transport_code_with_real_peers(dhigh_prefix, world):
             assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
 
 
-def test_wide_key_databases_over_several_ranks(monkeypatch):
-    """A DB that takes the wide group key (forced here) goes through cdm_kmermatch_dist with 3 ranks: the exchange carries the narrow
-    form only, so every rank runs kmermatcher whole and keeps its view - the union of the views is the single-device result."""
+@pytest.mark.parametrize("world,passes", [(3, None), (8, None), (3, "7,2"), (5, "3,3")])
+def test_wide_key_databases_over_several_ranks(monkeypatch, world, passes):
+    """A DB that takes the wide group key (forced here) goes through cdm_kmermatch_dist with 3, 5 and 8 ranks: the exchange of group keys by
+    owner carries the narrow form only, so such a DB's first half is split by RANGES of the k-mer space - each range sorted and grouped on
+    one rank, the kept group keys (with the run starts that name the representatives) all-gathered, sort 2 and the vote on every rank; the
+    union of the ranks' views is the single-device result.  passes: more ranges than ranks, over several blocks of the sequences
+    (CDM_KMER_PASSES: what a DB that does not fit a device at once takes)."""
     monkeypatch.setenv("CDM_FORCE_WIDE_KEY", "1")
     ref = capi.Ctx(0)
     n = 60_000
     want = ref.kmermatch(ref.synth(n, 60, 150, 5)).download()
+    if passes:
+        monkeypatch.setenv("CDM_KMER_PASSES", passes)
+        capi.lib().cdm_env_refresh()
 
     def rank_fn(rank, comm, c):
-        return comm.kmermatch(c.synth(n, 60, 150, 5)).download(), comm.owned(n)
+        h = comm.kmermatch(c.synth(n, 60, 150, 5))
+        return h.download(), comm.owned(n), comm.last_path()
 
-    res = run_standin_ranks(3, rank_fn)
+    res = run_standin_ranks(world, rank_fn)
+    assert all(r[2] == "ranges" for r in res)
     off, rec = merged_hits([r[0] for r in res], n, res[0][1])
     assert np.array_equal(off, want[0]) and np.array_equal(rec, want[1])
 
@@ -354,7 +363,7 @@ def test_split_by_reads_sends_every_tuple_once(ctx):
         assert per_slice[: capi.KPART_SLICES // 2].sum() > 0.6 * per_slice.sum()
 
 
-@pytest.mark.parametrize("world,extract", [(2, None), (3, None), (8, None), (2, "split"), (3, "split"), (2, "part"), (2, "all"), (3, "replicate")])
+@pytest.mark.parametrize("world,extract", [(2, None), (3, None), (8, None), (2, "split"), (3, "split"), (2, "part"), (2, "all"), (3, "replicate"), (3, "ranges"), (6, "ranges")])
 def test_native_exact_iteration_equals_single_device(dhigh_prefix, world, extract, monkeypatch):
     """cdm_reads_iteration_dist (csrc/dist.hip: the exact scheme in the library, as a deployment runs it over RCCL) on 200 k mixed-length
     reads with `world` ranks: hits, corrected DB and next DB equal the single-device calls'."""
@@ -365,7 +374,7 @@ def test_native_exact_iteration_equals_single_device(dhigh_prefix, world, extrac
     want_hits, want_corr, want_asm = hits.download(), corr.download(), asm.download()
     del hits, alns, corr, asm
     if extract:                       # the default for a world below 6 is "all": every rank extracts every read and keeps its range of equal share; "split": by blocks of reads, the tuples travel; "part": round 3's equal slices by value
-        monkeypatch.setenv("CDM_DIST_KMER" if extract == "replicate" else "CDM_DIST_EXTRACT", extract)         # (two ranks replicate kmermatcher by default; naming a first half asks for the exchange)
+        monkeypatch.setenv("CDM_DIST_KMER" if extract in ("replicate", "ranges") else "CDM_DIST_EXTRACT", extract)         # (two ranks replicate kmermatcher by default; naming a first half asks for the exchange)
         capi.lib().cdm_env_refresh()
 
     def rank_fn(rank, comm, c):
@@ -393,7 +402,8 @@ def test_native_contig_iteration_equals_single_device(dhigh_prefix, world, trans
     """cdm_contig_iteration_dist: contigs grown by three read iterations go through two contig iterations (kmermatcher -k 22 over the ranks,
     rescorediagonal, ancient_correction, ancient_contig_merge with its queue on the device - each on the owned queries -, the DBs
     all-gathered) with `world` ranks: corrected DB, merged DB and wasExtended flags equal the single-device calls'; `wide`: with the wide
-    group key forced, as a DB of the 25 M-read workflow's size takes it (kmermatcher is then run whole on every rank)"""
+    group key forced, as a DB of the 25 M-read workflow's size takes it (kmermatcher's first half then goes over the ranks by ranges of the k-mer
+    space, the kept group keys are all-gathered)"""
     if wide:
         monkeypatch.setenv("CDM_FORCE_WIDE_KEY", "1")
         capi.lib().cdm_env_refresh()
