@@ -199,7 +199,7 @@ inline hipError_t growArena(Arena &a, int device, size_t need) {
         {
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess) (void) hipGetLastError();
-            else if (fr < chunk + RUNTIME_RESERVE) {
+            else if (fr < chunk + std::min(RUNTIME_RESERVE, tot / 64)) {
                 if (cdmenv::get("CDM_POOL_DEBUG")) fprintf(stderr, "carpedeam pool: %zu bytes free on the device, a chunk of %zu is not mapped\n", fr, chunk);
                 return hipErrorOutOfMemory;
             }
