@@ -278,7 +278,32 @@ struct VoteEntArgs {
     const uint64_t *hitOff;     // per sequence: its self hit, then its hits
     const uint32_t *stale;      // k_stale_tail's list
     int diagBias;
+    // Multi-GPU runs (a rank votes on the representatives it owns): what the scan of this rank's LAST target runs into is the head of the
+    // next ranks' entries (k_head_entries) - cont[0] WORDS, two per entry (biased diagonal | "reverse" << 31, tuples), that apply if
+    // the target is cont[1]; only if cont[2] is set does the scan go on into the left-over tuples after them.  NULL on one device.
+    const uint32_t *cont = nullptr;
 };
+constexpr int HEAD_WORDS = 2048;        // = kmermatch.hip CONT_CAP: the words of a head the ranks exchange
+// The head of a rank's entries: from its first entry on while the member id stays the same, whatever the representative (what a scan
+// coming in from the rank in front runs through, kmermatcher.cpp:875-887).  out[0] = words (2 per entry; HEAD_WORDS + 1: longer than
+// the list), out[1] = that id, out[2] = 1 if the head is everything this rank holds, out[3..] the entries, out[HEAD_WORDS + 3] = the
+// member id of the rank's LAST entry.
+__global__ void k_head_entries(const Ent *__restrict__ ent, const unsigned long long *__restrict__ entOff, const uint32_t *__restrict__ entCnt, uint64_t nSeg, uint32_t *__restrict__ out) {
+    if (nSeg == 0) { out[0] = 0; out[1] = 0; out[2] = 1; out[HEAD_WORDS + 3] = 0; return; }
+    const uint32_t id = ent[entOff[0]].id;
+    uint32_t words = 0; bool whole = true;
+    for (uint64_t g = 0; g < nSeg && whole && words <= (uint32_t) HEAD_WORDS; g++) {
+        const Ent *e = ent + entOff[g]; const uint32_t c = entCnt[g];
+        for (uint32_t j = 0; j < c; j++) {
+            if (e[j].id != id) { whole = false; break; }
+            if (words + 2 <= (uint32_t) HEAD_WORDS) { out[3 + words] = e[j].diag | ((e[j].cs & 1u) ? 0u : 1u << 31); out[4 + words] = e[j].cs >> 1; words += 2; }
+            else { words = (uint32_t) HEAD_WORDS + 1; whole = false; break; }
+        }
+    }
+    out[0] = words; out[1] = id; out[2] = whole ? 1u : 0u;
+    const uint64_t gl = nSeg - 1;
+    out[HEAD_WORDS + 3] = ent[entOff[gl] + entCnt[gl] - 1].id;
+}
 struct Walk {
     uint32_t prevDiag = 0, diagCnt = 0, maxDiag = 0, diagonal = 0, top = 0; int bestRev = 0; bool any = false;
     __device__ __forceinline__ void add(uint32_t d, uint32_t c, int rev) {        // c tuples of diagonal d, the last of them on strand `rev`
@@ -311,7 +336,12 @@ __global__ __launch_bounds__(256) void k_vote_entries(VoteEntArgs a, HitT *__res
                 for (; j < c2 && f[j].id == id; j++) w.add(f[j].diag, f[j].cs >> 1, (f[j].cs & 1u) ? 0 : 1);
                 done = j < c2;
             }
-            if (!done && id == a.stale[1]) {
+            bool intoStale = !done;
+            if (!done && a.cont) {                      // the end of this rank's entries: on into the next ranks' heads
+                if (id == a.cont[1]) for (uint32_t j = 0; j + 1 < a.cont[0]; j += 2) w.add(a.cont[3 + j] & 0x7FFFFFFFu, a.cont[4 + j], (int) (a.cont[3 + j] >> 31));
+                intoStale = a.cont[2] != 0u;
+            }
+            if (intoStale && id == a.stale[1]) {
                 const uint32_t m = a.stale[0];
                 for (uint32_t j = 0; j < m; j++) w.add(a.stale[2 + j] + (uint32_t) a.diagBias, 1u, 0);
             }

@@ -2203,7 +2203,10 @@ int sort2(const uint64_t *keysIn, unsigned long long nIn, unsigned long long ski
             // under CDM_KMER_VOTE=tuples, and as the fallback when the entry buffer overflows.
             const char *voteEnv = cdmGetenv("CDM_KMER_VOTE");
             const bool wordFits = aggv::AG_ORD + idBits + diagBits + aggv::AG_IDX <= 64 && !(wide && cdmGetenv("CDM_FORCE_WIDE_WORD"));    // (tests: the 128-bit entry sort word for any DB)
-            bool aggregated = wide || (ownBuffers && !sort2Check && !(voteEnv && !strcmp(voteEnv, "tuples")) && wordFits);
+            // (a rank's second half - sortFrom, !ownBuffers - aggregates as well since round 5: the heads the ranks exchange and the continuation
+            //  of a rank's last scan are expressed on entries, aggvote.h k_head_entries / VoteEntArgs::cont; CDM_DIST_VOTE=tuples keeps the tuple path)
+            const char *distVote = cdmGetenv("CDM_DIST_VOTE");
+            bool aggregated = wide || ((ownBuffers || !(distVote && !strcmp(distVote, "tuples"))) && !sort2Check && !(voteEnv && !strcmp(voteEnv, "tuples")) && wordFits);
             if ((wide || fromStage) && ownBuffers && nGroup != nKept) { cdm_set_error("cdm_kmermatch: internal error: %llu group tuples counted, %llu in the run records", nKept, nGroup); return CDM_ERR_HIP; }
             if (aggregated) {
                 // (the wide form has no tuple path to fall back to: an entry buffer that proves too small is tried again, larger)
@@ -2302,7 +2305,7 @@ int stagedRunRecords(const runsort::RunArgs &whole, DevBuf<uint32_t> &rr0, DevBu
     return CDM_OK;
 }
 // K4 on entries: the per-representative hit counts are known already (aggregate); offsets, self hits, then one thread per segment
-int voteEntries(cdm_hits **out) {
+int voteEntries(cdm_hits **out, const uint32_t *contDev = nullptr) {
     DevBuf<unsigned long long> perRepScan;
     if (!perRepScan.alloc((size_t) n + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (vote)"); return CDM_ERR_HIP; }
     cdmscan::ScanTemp st4a;
@@ -2316,7 +2319,7 @@ int voteEntries(cdm_hits **out) {
     res->count = total;
     if (cdmMalloc(&res->rec, (total + 1) * sizeof(HitRec)) != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
     hipLaunchKernelGGL(k_self, dim3((n + 255) / 256), dim3(256), 0, s, res->off, n, res->rec);
-    aggv::VoteEntArgs va; va.ent = agEnt.p; va.entOff = agEntOff.p; va.entCnt = agEntCnt.p; va.segRep = agSegRep.p; va.nSeg = nSegM; va.hitOff = res->off; va.stale = staleBuf.p; va.diagBias = diagBias;
+    aggv::VoteEntArgs va; va.ent = agEnt.p; va.entOff = agEntOff.p; va.entCnt = agEntCnt.p; va.segRep = agSegRep.p; va.nSeg = nSegM; va.hitOff = res->off; va.stale = staleBuf.p; va.diagBias = diagBias; va.cont = contDev;
     if (nSegM) hipLaunchKernelGGL(aggv::k_vote_entries<HitRec>, dim3((unsigned) ((nSegM + 255) / 256)), dim3(256), 0, s, va, res->rec);
     { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { cdm_hits_free(res); cdm_set_error("cdm_kmermatch: placing hits failed: %s", hipGetErrorString(e)); return CDM_ERR_HIP; } }
     float msSort2 = 0; hipEventElapsedTime(&msSort2, ctx->ev0, ctx->ev1);
@@ -2400,7 +2403,7 @@ int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *re
 }
 // ---- K4: count hit-producing segments (per tile and per representative), scan, vote + place.  contDev: VoteArgs::cont
 int vote(const uint32_t *contDev, bool ownBuffers, cdm_hits **out) {
-    if (haveEntries) return voteEntries(out);
+    if (haveEntries) return voteEntries(out, contDev);
     const uint64_t *sorted2 = sorted2M; const unsigned long long nGroup = nGroupM;
     DevBuf<unsigned long long> perRep, perRepScan, vTileCnt, vTileOff;
     const uint64_t vTiles = (nGroup + CP_TILE - 1) / CP_TILE;
@@ -2469,6 +2472,16 @@ int sortFrom(const uint64_t *devKeys, uint64_t nKeys, uint32_t *head, uint64_t i
     if (!recvA.alloc(nKeys) || !recvB.alloc(nKeys) || !contBuf.alloc(CONT_CAP + 4)) { cdm_set_error("cdm_kmermatch: out of device memory for %llu received group tuples", (unsigned long long) nKeys); return CDM_ERR_HIP; }
     if (nKeys) hipMemcpyAsync(recvB.p, devKeys, nKeys * 8, hipMemcpyDeviceToDevice, s);
     if (int rc = sort2(recvB.p, nKeys, 0, 0, recvA.p, recvB.p, false)) return rc;
+    if (haveEntries) {      // the head and the last target from the aggregated entries (two words per entry)
+        static_assert(aggv::HEAD_WORDS == CONT_CAP, "the words of a head");
+        uint32_t lastId = 0;
+        hipLaunchKernelGGL(aggv::k_head_entries, dim3(1), dim3(1), 0, s, (const aggv::Ent *) agEnt.p, (const unsigned long long *) agEntOff.p, (const uint32_t *) agEntCnt.p, (uint64_t) nSegM, contBuf.p);
+        hipMemcpyAsync(head, contBuf.p, (CONT_CAP + 3) * 4, hipMemcpyDeviceToHost, s);
+        hipMemcpyAsync(&lastId, contBuf.p + CONT_CAP + 3, 4, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { cdm_set_error("cdm_kmermatch: second half (aggregation) failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP; }
+        info[0] = nGroupM; info[1] = lastId;
+        return CDM_OK;
+    }
     hipLaunchKernelGGL(k_head_segment, dim3(1), dim3(1), 0, s, sorted2M, (uint64_t) nGroupM, idBits, diagBits, contBuf.p);
     uint64_t last = 0;
     hipMemcpyAsync(head, contBuf.p, (CONT_CAP + 3) * 4, hipMemcpyDeviceToHost, s);
