@@ -2372,7 +2372,7 @@ int aggregate(uint64_t *sortedOut, unsigned long long nGroup, const uint32_t *re
     if (const char *e = cdmGetenv("CDM_AGG_D")) { const long v = atol(e); if (v >= 1 && v <= AG_D) a.maxD = (uint32_t) v; }
     a.repShift = (int) (idBits + diagBits + 1); a.diagBits = (int) diagBits; a.idBits = idBits; a.sorted = sortedOut; a.list = nullptr; a.count = nullptr; a.hard.list = nullptr; a.hard.cnt = nullptr;
     a.wideWord = wideWord ? 1 : 0;
-    if (runsort::segmentedSortKeys(s, ctx->cuCount, sortedOut, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, recRep, dst, nRec, gk, recVal, aggUnitHook, &a, wide, agSegOfRec.p, (int) bitsFor((uint64_t) nSeg + 1)) != CDM_OK) {
+    if (runsort::segmentedSortKeys(s, ctx->cuCount, sortedOut, sortedOut, nGroup, (int) (idBits + diagBits + 1), (int) (diagBits + 1), top2, recRep, dst, nRec, gk, recVal, aggUnitHook, &a, wide, agSegOfRec.p, (int) bitsFor((uint64_t) nSeg + 1), agSegFirstRec.p, (uint64_t) nSeg) != CDM_OK) {
         cdm_set_error("cdm_kmermatch: segmented sort 2 failed: %s", hipGetErrorString(hipGetLastError())); return CDM_ERR_HIP;
     }
     // the segments the tuple sorters finished (deep pile-ups, units with too many distinct triples)

@@ -318,6 +318,7 @@ struct SegListArgs {
     const unsigned long long *uEnd; uint64_t units;       // the units' ends (NULL: there are no units): a segment that lies inside its unit is the unit's
     uint32_t cap[SEG_CLASSES - 1];      // capacities of the block classes
     unsigned long long *list[SEG_CLASSES]; unsigned int *cnt;      // cnt[c]
+    const unsigned long long *segFirstRec = nullptr; uint64_t nSeg = 0;      // (k_seg_list_segments) first record of every segment, [nSeg] = nRec
 };
 // one thread per record; the first record of a representative measures its segment and lists it if a wave cannot sort it
 __global__ __launch_bounds__(1024) void k_seg_list(SegListArgs a) {
@@ -338,6 +339,28 @@ __global__ __launch_bounds__(1024) void k_seg_list(SegListArgs a) {
             if (n > a.maxWave && !inUnit) cls = n <= a.cap[0] ? 0 : n <= a.cap[1] ? 1 : n <= a.cap[2] ? 2 : 3;
         }
     }
+    // (a segment that no unit holds is rare - 49 of 3.9 M at 50 M reads: most blocks have nothing to list, and the four block-wide
+    // appends below are twelve barriers)
+    if (!__syncthreads_or(cls >= 0)) return;
+#pragma unroll
+    for (int c = 0; c < SEG_CLASSES; c++) {
+        const uint32_t q = cdm_block_append(a.cnt + c, cls == c);
+        if (cls == c) { a.list[c][2 * (size_t) q] = s; a.list[c][2 * (size_t) q + 1] = e; }
+    }
+}
+
+// the same with the segment table at hand (aggvote.h builds one: the aggregated sort 2): a thread per SEGMENT, no search - 8.4 M threads
+// with two look-ups each where k_seg_list runs 530 M threads, 8.4 M of which gallop and bisect over the records (3.6 ms at 50 M reads)
+__global__ __launch_bounds__(1024) void k_seg_list_segments(SegListArgs a) {
+    const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1; unsigned long long s = 0, e = 0;
+    if (g < a.nSeg) {
+        s = a.dst[a.segFirstRec[g]]; e = a.dst[a.segFirstRec[g + 1]];
+        const unsigned long long n = e - s;
+        const bool inUnit = a.uEnd && s / U_T < a.units && e <= a.uEnd[s / U_T];
+        if (n > a.maxWave && !inUnit) cls = n <= a.cap[0] ? 0 : n <= a.cap[1] ? 1 : n <= a.cap[2] ? 2 : 3;
+    }
+    if (!__syncthreads_or(cls >= 0)) return;
 #pragma unroll
     for (int c = 0; c < SEG_CLASSES; c++) {
         const uint32_t q = cdm_block_append(a.cnt + c, cls == c);
@@ -377,6 +400,7 @@ struct UnitBoundArgs {
     const uint32_t *recRep; const unsigned long long *dst; uint64_t nRec;
     uint32_t maxSeg; uint64_t units;
     unsigned long long *uStart, *uEnd, *uRec;       // [units + 1], [units], [units + 1]: first tuple / end / first record of a unit
+    const uint32_t *segOfRec = nullptr; const unsigned long long *segFirstRec = nullptr;     // the segment table, if there is one: no search for a segment's ends
 };
 // one thread per record; a record with a unit boundary B in (dst[r], dst[r + 1]] finds the end (and, if need be, the start) of its
 // segment: the unit that begins at B starts where the segment ends
@@ -387,15 +411,19 @@ __global__ __launch_bounds__(1024) void k_unit_bounds(UnitBoundArgs a) {
     const uint64_t uLo = d0 / U_T + 1, uHi = (r == a.nRec - 1) ? a.units : d1 / U_T;       // (the end of the array closes the last unit)
     if (r == 0) { a.uStart[0] = 0; a.uRec[0] = 0; }
     if (uLo > uHi) return;
-    const uint32_t rep = a.recRep[r];
-    uint64_t lo = r, step = 1;                              // last record of the segment: gallop, then bisect
-    while (lo + step < a.nRec && a.recRep[lo + step] == rep) { lo += step; step <<= 1; }
-    uint64_t hi = min(lo + step, a.nRec);
-    while (hi - lo > 1) { const uint64_t mid = lo + ((hi - lo) >> 1); if (a.recRep[mid] == rep) lo = mid; else hi = mid; }
+    uint64_t hi, first;
+    if (a.segFirstRec) { const uint32_t g = a.segOfRec[r]; first = a.segFirstRec[g]; hi = a.segFirstRec[g + 1]; }
+    else {
+        const uint32_t rep = a.recRep[r];
+        uint64_t lo = r, step = 1;                              // last record of the segment: gallop, then bisect
+        while (lo + step < a.nRec && a.recRep[lo + step] == rep) { lo += step; step <<= 1; }
+        hi = min(lo + step, a.nRec);
+        while (hi - lo > 1) { const uint64_t mid = lo + ((hi - lo) >> 1); if (a.recRep[mid] == rep) lo = mid; else hi = mid; }
+        first = r; uint64_t out = ~0ull, st = 1;                // first record of the segment: `first` is inside, `out` outside (or -1)
+        while (first >= st) { if (a.recRep[first - st] == rep) { first -= st; st <<= 1; } else { out = first - st; break; } }
+        while (first - out > 1) { const uint64_t mid = out + ((first - out) >> 1); if (a.recRep[mid] == rep) first = mid; else out = mid; }
+    }
     const unsigned long long e = a.dst[hi];
-    uint64_t first = r, out = ~0ull, st = 1;                // first record of the segment: `first` is inside, `out` outside (or -1)
-    while (first >= st) { if (a.recRep[first - st] == rep) { first -= st; st <<= 1; } else { out = first - st; break; } }
-    while (first - out > 1) { const uint64_t mid = out + ((first - out) >> 1); if (a.recRep[mid] == rep) first = mid; else out = mid; }
     const unsigned long long sSeg = a.dst[first];
     for (uint64_t u = uLo; u <= uHi; u++) {
         if (u <= a.units) { a.uStart[u] = e; a.uRec[u] = hi; }
@@ -614,7 +642,8 @@ __global__ __launch_bounds__(256) void k_gather_ranges_dense(const unsigned long
 typedef void (*UnitHook)(hipStream_t s, unsigned int grid, const unsigned long long *list, const unsigned int *count, bucket::BigList hard, void *user);
 inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t *out, uint64_t n, int shiftHi, int hiShift, int top,
                              const uint32_t *recRep, const unsigned long long *dst, uint64_t nRec, const uint64_t *srcKeys, const uint64_t *recVal,
-                             UnitHook unitHook = nullptr, void *hookUser = nullptr, bool wide = false, const uint32_t *segOfRec = nullptr, int segBits = 0) {
+                             UnitHook unitHook = nullptr, void *hookUser = nullptr, bool wide = false, const uint32_t *segOfRec = nullptr, int segBits = 0,
+                             const unsigned long long *segFirstRec = nullptr, uint64_t nSeg = 0) {
     using namespace bucket;
     if (n == 0) return CDM_OK;
     if (wide && (!unitHook || !segOfRec)) { cdm_set_error("segmented sort: keys without the representative need the aggregating unit kernel and its segment table"); return CDM_ERR_UNSUPPORTED; }
@@ -637,6 +666,7 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
         // a boundary no record reaches (there is none: the records tile [0, n)) would leave its unit empty
         hipMemsetAsync(uStart.p, 0, (units + 2) * 8, s); hipMemsetAsync(uEnd.p, 0, (units + 1) * 8, s); hipMemsetAsync(uRec.p, 0, (units + 2) * 8, s);
         UnitBoundArgs ub; ub.recRep = recRep; ub.dst = dst; ub.nRec = nRec; ub.maxSeg = maxSeg; ub.units = units; ub.uStart = uStart.p; ub.uEnd = uEnd.p; ub.uRec = uRec.p;
+        if (segOfRec && segFirstRec) { ub.segOfRec = segOfRec; ub.segFirstRec = segFirstRec; }
         hipLaunchKernelGGL(k_unit_bounds, CDM_GRID((nRec + 1023) / 1024, 1024), dim3(1024), 0, s, ub);
         UnitClassArgs uc; uc.uStart = uStart.p; uc.uEnd = uEnd.p; uc.uRec = uRec.p; uc.units = units; uc.n = n;
         for (int c = 0; c < U_CLASSES; c++) { uc.cap[c] = (uint32_t) U_CLASS_CAP[c]; uc.list[c] = uList[c].p; }
@@ -658,7 +688,8 @@ inline int segmentedSortKeys(hipStream_t s, int cuCount, uint64_t *in, uint64_t 
     la.cap[0] = 0; la.cap[1] = 0; la.cap[2] = blockCap;
     for (int c = 0; c < SEG_CLASSES; c++) la.list[c] = lists[c].p;      // (classes 0 and 1 stay empty: their capacities are 0)
     la.cnt = cnt.p;
-    hipLaunchKernelGGL(k_seg_list, CDM_GRID((nRec + 1023) / 1024, 1024), dim3(1024), 0, s, la);
+    if (segFirstRec && nSeg) { la.segFirstRec = segFirstRec; la.nSeg = nSeg; hipLaunchKernelGGL(k_seg_list_segments, CDM_GRID((nSeg + 1023) / 1024, 1024), dim3(1024), 0, s, la); }
+    else hipLaunchKernelGGL(k_seg_list, CDM_GRID((nRec + 1023) / 1024, 1024), dim3(1024), 0, s, la);
     const unsigned int gatherGrid = (unsigned int) std::min<uint64_t>((uint64_t) cuCount * 8, listCap + units + 1);
     BlockSortArgs ba; ba.in = in; ba.out = out; ba.shiftHi = shiftHi; ba.ign = 1;
     ba.list = lists[2].p; ba.count = cnt.p + 2;
