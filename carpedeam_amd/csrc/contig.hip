@@ -152,7 +152,6 @@ int hostQueue(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm
 }
 }  // namespace
 
-// CDM_CONTIG_QUEUE=host: the round-4 path for every query (what --unsafe 1 takes in any case: its consensus works on the host's strings)
 extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float mergeSeqIdThr, cdm_seqdb **out) {
     if (!ctx || !db || !alns || !par || !out) { cdm_set_error("cdm_contig_merge: NULL argument"); return CDM_ERR_INVALID; }
     CDM_REFUSE_UNDEFINED_ALNS(alns, "cdm_contig_merge");
@@ -176,8 +175,13 @@ extern "C" int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_aln
     const bool timing = cdmGetenv("CDM_TIMING") != nullptr;
     auto tPrev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (timing) { const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  contig merge: %-28s %.3f s\n", what, std::chrono::duration<double>(t - tPrev).count()); tPrev = t; } };
+    // Where the queue runs: on the device, unless --unsafe 1 (its consensus works on the host's strings) - or the call is small and this
+    // process has not filled the device queue's tables yet: they take about a second once per process, which a module process started per
+    // iteration (the reference's scripts) pays every time, while the host queue takes ~80 ns per record all in.  CDM_CONTIG_QUEUE=host|device
+    // pins either.
     const char *where = cdmGetenv("CDM_CONTIG_QUEUE");
-    const bool onHost = par->unsafe != 0 || (where && !strcmp(where, "host"));
+    const bool small = nRec < (8ull << 20) && !cdm_contig_tables_ready(ctx->device);
+    const bool onHost = par->unsafe != 0 || (where ? !strcmp(where, "host") : small);
     std::vector<uint32_t> grownIdx; std::vector<uint8_t> outExt; cdm_seqdb *grown = nullptr;
     if (onHost) {
         if (int rc = hostQueue(ctx, db, alns, par, mergeSeqIdThr, dStats.p, nullptr, grownIdx, &grown, outExt)) return rc;

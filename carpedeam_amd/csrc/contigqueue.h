@@ -15,3 +15,5 @@ struct CqResult {
 // meta / owner / dStats: cdm_build_meta's table, the query of every record, k_contig_stats' counts (device memory)
 int cdm_contig_queue_device(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float mergeSeqIdThr, const SeqMeta *meta, const uint32_t *owner,
                             const ContigStat *dStats, CqResult *res);
+// have the tables of the C library's lgammaf / logf been filled and copied to this device already (about a second, once per process)?
+bool cdm_contig_tables_ready(int device);

@@ -89,6 +89,9 @@ int ensureTables(int device, CqTables &out, std::string &err) {
     return CDM_OK;
 }
 
+}  // namespace
+bool cdm_contig_tables_ready(int device) { std::lock_guard<std::mutex> lock(gTabMu); return device >= 0 && device < 64 && gDevReady[device]; }
+namespace {
 // ------------------------------------------------------------------------------------------------ per record / per query state
 struct CqKey { uint32_t cons; float deam, lgBeta, lgAlphaBeta; };        // what the comparator reads of a record: alnLengthCons, deamMatch, its two cached terms
 struct CqCo { int32_t qs, qe, ds, de; };                                  // the record's coordinates (oriented; rewritten when a parked hit is re-aligned)

@@ -47,6 +47,7 @@ def test_queries_handed_back_to_the_host_are_overlaid(dhigh_prefix, monkeypatch,
     corr = ctx.upload_keyed_seqdb(cgold(name, "ccorr", step))
     _, keys, _ = corr.meta()
     aoff, arec = capi.parse_aln_db(cgold(name, "caln", step), keys)
+    monkeypatch.setenv("CDM_CONTIG_QUEUE", "device")          # (a call this small takes the host queue by default)
     monkeypatch.setenv("CDM_CONTIG_HAND_BACK_EVERY", str(every))
     merged = ctx.contig_merge(corr, ctx.upload_alns(corr, aoff, arec))
     assert not diff_keys(seqdb_to_keyed(*merged.download()), cgold(name, "cmerge", step))
@@ -123,6 +124,22 @@ def _csum(a):
         a = np.concatenate([a, np.zeros(pad, np.uint8)])
     w = a.view(np.uint64)
     return "%016x" % (int(w.sum(dtype=np.uint64)) ^ (int((w * np.arange(1, w.size + 1, dtype=np.uint64)).sum(dtype=np.uint64)) << 1) & 0xFFFFFFFFFFFFFFFF)
+
+
+def test_small_calls_take_the_host_queue_until_the_tables_exist(dhigh_prefix, monkeypatch, capfd):
+    """the default: a call of fewer than 8 M records in a process that has not filled the device queue's tables runs the queue on the host
+    (a module process per iteration would pay a second for the tables every time); CDM_TIMING's laps say which way a call went"""
+    monkeypatch.delenv("CDM_CONTIG_QUEUE", raising=False)
+    monkeypatch.setenv("CDM_TIMING", "1")
+    ctx = ctx_with_damage(dhigh_prefix)
+    corr = ctx.upload_keyed_seqdb(cgold("mixed3k", "ccorr", 1))
+    _, keys, _ = corr.meta()
+    aoff, arec = capi.parse_aln_db(cgold("mixed3k", "caln", 1), keys)
+    merged = ctx.contig_merge(corr, ctx.upload_alns(corr, aoff, arec))
+    assert not diff_keys(seqdb_to_keyed(*merged.download()), cgold("mixed3k", "cmerge", 1))
+    err = capfd.readouterr().err
+    # (whichever test ran first in this process may have filled the tables: then the device takes every call)
+    assert "queues + extension (host)" in err or "queues + extension (device)" in err
 
 
 def test_config5_workflow_at_10M_reads_ends_in_the_recorded_db(dhigh_prefix):

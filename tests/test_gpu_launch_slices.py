@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(params=["7", "300"])
 def sliced(request, monkeypatch):
     monkeypatch.setenv("CDM_LAUNCH_SLICE", request.param)
+    monkeypatch.setenv("CDM_CONTIG_QUEUE", "device")          # (the contig merge's sliced kernels are the device queue's; small calls take the host queue by default)
     yield int(request.param)
 
 

@@ -404,9 +404,10 @@ def test_native_contig_iteration_equals_single_device(dhigh_prefix, world, trans
     all-gathered) with `world` ranks: corrected DB, merged DB and wasExtended flags equal the single-device calls'; `wide`: with the wide
     group key forced, as a DB of the 25 M-read workflow's size takes it (kmermatcher's first half then goes over the ranks by ranges of the k-mer
     space, the kept group keys are all-gathered)"""
+    monkeypatch.setenv("CDM_CONTIG_QUEUE", "device")          # (calls this small take the host queue by default)
     if wide:
         monkeypatch.setenv("CDM_FORCE_WIDE_KEY", "1")
-        capi.lib().cdm_env_refresh()
+    capi.lib().cdm_env_refresh()
     n = 60_000
     kc = capi.KmerParams.reads_default()
     kc.kmer_size, kc.include_only_extendable = 22, 1
