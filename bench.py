@@ -405,7 +405,8 @@ def main():
             if n == 50_000_000 and L == 100 and world == 1 and pmcs:
                 try:
                     pj = json.load(open(pmcs[-1]))
-                    names = [k for k in pj["kernels"] if k.startswith("rx::k_rx_pass<unsigned long, " + ("rx::NoValue" if slot_layout else "unsigned int")) and "small launches" not in k]
+                    names = [k for k in pj["kernels"] if k.startswith("rx::k_rx_pass<unsigned long, " + ("rx::NoValue" if slot_layout else "unsigned int")) and "small launches" not in k
+                             and (not slot_layout or k.rstrip().endswith((", 1>", ", 2>")))]          # (slot layout: the head pass and the passes inside its segments, not the plain key-only passes of other sorts)
                     by = sum(pj["kernels"][k]["hbm_bytes_per_launch"] * pj["kernels"][k]["launches"] for k in names)
                     ln = sum(pj["kernels"][k]["launches"] for k in names)
                     traffic = by / ln if ln else None

@@ -152,6 +152,7 @@ template <typename A> inline void cdmSetMeta(A &a, const SeqMeta *m, const MetaU
     a.woff.uw = u.words; a.len.ul = u.len; a.hasN.plain = a.hasRaw.plain = u.words;
 }
 int cdm_kmermatch_needs_wide_key(const cdm_seqdb *db);      // kmermatch.hip
+int cdm_kmermatch_part_takes_slots(const cdm_seqdb *db, const cdm_kmer_params *par);      // kmermatch.hip
 // kmermatcher's first half over ranks by ranges of the k-mer space (kmermatch.hip kmermatchPassesT; csrc/dist.hip fills the hooks from its
 // communicator): the whole hit set on every rank
 struct KmerRanks {

@@ -1,11 +1,13 @@
 // ancient_contig_merge (src/assembler/ancientContigsResults.cpp:94-509), SURVEY.md 8(f) rank 1.
 //
 // Split: the per-alignment work that touches every aligned column - orientation, identities against the query, the counts
-// updateSeqIdConsensus and ancientMatchCount take over the consensus (nuclassembleUtil.cpp:705-790, 1047-1181) - runs on the
-// device, a wavefront per alignment record on 2-bit words.  What follows is order-dependent arithmetic on a handful of numbers
-// per query: the Beta-posterior comparator (:25-70; lgammaf / logf / exp of the C library decide the order and it is not a
-// strict weak ordering, so the queue is libstdc++'s std::priority_queue with that very comparator), the extension loop and the
-// re-alignment of parked hits - host code of the library (host/contigmerge.cpp), compiled like the reference.
+// updateSeqIdConsensus and ancientMatchCount take over the consensus (nuclassembleUtil.cpp:705-790, 1047-1181) - is k_contig_stats below,
+// a wavefront per alignment record on 2-bit words.  What follows - the contig filter, the priority queue with its Beta-posterior
+// comparator (:25-70: lgammaf / logf / exp of the C library decide the order, and it is no strict weak ordering), the extension loop
+// and the re-alignment of parked hits - runs on the device as well since round 5 (contigqueue.hip: the comparator from tables of the
+// C library's own values, libstdc++'s heap step for step).  The host code of rounds 2-4 (host/contigmerge.cpp, compiled like the
+// reference) stays for --unsafe 1, for small calls in a process that has not filled those tables, for the queries the device hands
+// back, and as what the tests compare the device queue with (hostQueue below).
 #include <algorithm>
 #include <chrono>
 #include <cstring>

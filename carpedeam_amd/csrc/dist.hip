@@ -355,6 +355,9 @@ int firstHalf(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_pa
     if (W == 1 || (how && !strcmp(how, "part"))) { cm->lastPath = 4; return cdm_kmermatch_part(ctx, db, par, R, W, out); }
     const bool everything = how ? !strcmp(how, "all") : W < 6;
     cm->lastPath = everything ? 2 : 3;
+    // a DB of one read length: every rank extracts all reads on the 8-byte slot layout and its head pass keeps the rank's range of head
+    // digits, cut from the head histogram into equal shares (kmermatch.hip KmerJob::headRange) - same ranges on every rank, nothing travels
+    if (everything && cdm_kmermatch_part_takes_slots(db, par)) return cdm_kmermatch_part(ctx, db, par, R, W, out);
     constexpr int F = CDM_KPART_SLICES;
     if (everything) {
         if (int rc = cdm_kmermatch_split_begin(ctx, db, par, 0, 1, out)) return rc;

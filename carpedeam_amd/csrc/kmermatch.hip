@@ -1685,6 +1685,10 @@ struct KmerJob : KmerJobBase {
     DevBuf<uint32_t> stRep, ovRep; DevBuf<uint64_t> stVal, ovVal; DevBuf<uint8_t> stCnt; DevBuf<unsigned long long> recFlag; uint64_t stagedWaves = 0, stagedOwn = 0; unsigned long long ovCap = 0, nOvRec = 0;
     DevBuf<uint32_t> bigRecRep, bigRecRep1; DevBuf<uint64_t> bigRecVal, bigRecVal1; unsigned long long nBigRec = 0;        // ... and the records of the buckets that kernel left to the caller
     bool ownPipeline = false;                 // sortAndGroup runs for the single-device call that also runs sort 2 on its own buffers (phaseA + phaseB)
+    // slot layout on a rank (cdm_kmermatch_part for a DB of one read length): the rank extracts every read, the head histogram the
+    // extraction counts cuts the 512 head digits into nparts ranges of equal tuple counts (the same cuts on every rank), and the head
+    // pass keeps this rank's digits only - what it drops costs a read, not a write
+    bool headRange = false; uint32_t headLo = 0, headHi = 0xFFFFFFFFu;
     GroupArgs<LY> ga; DevBuf<unsigned long long> statStripes; unsigned long long *startIo = nullptr; DevBuf<uint32_t> staleBuf;
     DevBuf<uint64_t> runsOut, runsTmp;       // sort 2 "check" mode: the run-based result next to the radix one
     DevBuf<uint64_t> recvA, recvB; DevBuf<uint32_t> contBuf;      // multi-GPU second half: received keys / their sorted form, the continuation list
@@ -1716,7 +1720,7 @@ int init() {
     hipMemsetAsync(counters.p, 0, 8 * 8, s);
     geom.kbits = 2 * k; geom.lb = (int) bitsFor((uint64_t) db->maxLen + 1); geom.lenArr = db->len;
     if constexpr (LY::bySlot) {
-        if (!slotLayoutFits(db, k) || split || nparts != 1 || passes || lsdOnly) { cdm_set_error("cdm_kmermatch: internal error: the slot layout was chosen for a run it does not serve"); return CDM_ERR_INVALID; }
+        if (!slotLayoutFits(db, k) || split || (nparts != 1 && !headRange) || passes || lsdOnly) { cdm_set_error("cdm_kmermatch: internal error: the slot layout was chosen for a run it does not serve"); return CDM_ERR_INVALID; }
         geom.uniL = db->maxLen; geom.uniK = k; geom.uniS = slotsPerSeq(db->maxLen, k); divMagic(geom.uniS, geom.uniMul, geom.uniSh); geom.headShift = 2 * k - std::min(rx::BITS, 2 * k);
     }
     return CDM_OK;
@@ -1779,7 +1783,7 @@ int phaseA() override {
     ea.list = nullptr; ea.nList = 0; ea.hashBase = kmerSlots; ea.rankOf = rankOf.p;
     if constexpr (LY::bySlot) {
         const char *e = cdmGetenv("CDM_SLOT_HIST");        // "kernel": sort 1 counts the head digits itself, with a read of the keys (A/B, tests)
-        if (!(e && !strcmp(e, "kernel"))) {
+        if (headRange || !(e && !strcmp(e, "kernel"))) {
             if (!headHist.alloc(HEAD_BINS)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
             hipMemsetAsync(headHist.p, 0, HEAD_BINS * 8, s);
             ea.headHist = headHist.p; ea.headShift = geom.headShift; headCounted = true;
@@ -1791,6 +1795,7 @@ int phaseA() override {
         ea.kHi = (part == nparts - 1) ? ~0ull : (uint64_t) (space * (unsigned) (part + 1) / (unsigned) nparts);
         ea.lastPart = (part == nparts - 1) ? 1 : 0; ea.belowFlag = cls.p + 5;
         if (split) { ea.kLo = 0; ea.kHi = ~0ull; ea.lastPart = 1; ea.ordLo = ordLo; ea.ordHi = ordHi; }     // every k-mer of the owned sequences
+        if (headRange) { ea.kLo = 0; ea.kHi = ~0ull; }      // (every k-mer: the head pass keeps the rank's range; the whole-sequence hash tuples stay the last rank's)
     }
     hipEventRecord(ctx->ev0, s);
     hipLaunchKernelGGL(k_seq_hash<LY>, dim3((n + 255) / 256), dim3(256), 0, s, ea);
@@ -1828,6 +1833,19 @@ int phaseA() override {
     anyBelow = belowHost != 0;
     hipEventElapsedTime(&ctx->lastMs[3], ctx->ev0, ctx->ev1);
     if (split) return splitPartition();
+    if constexpr (LY::bySlot) if (headRange) {
+        unsigned long long hh[HEAD_BINS];
+        if (hipMemcpy(hh, headHist.p, sizeof(hh), hipMemcpyDeviceToHost) != hipSuccess) { cdm_set_error("cdm_kmermatch: reading the head histogram failed"); return CDM_ERR_HIP; }
+        unsigned long long grand = 0; for (int d = 0; d < HEAD_BINS; d++) grand += hh[d];
+        std::vector<uint32_t> cut(1, 0u);
+        const unsigned long long target = (grand + (unsigned) nparts - 1) / (unsigned) nparts;
+        unsigned long long acc = 0;
+        for (int d = 0; d < HEAD_BINS; d++) { if (acc && acc + hh[d] > target && (int) cut.size() < nparts) { cut.push_back((uint32_t) d); acc = 0; } acc += hh[d]; }
+        while ((int) cut.size() < nparts) cut.push_back((uint32_t) HEAD_BINS);
+        cut.push_back((uint32_t) HEAD_BINS);
+        headLo = cut[part]; headHi = cut[part + 1];
+        anyBelow = false; for (uint32_t d = 0; d < headLo; d++) anyBelow = anyBelow || hh[d] != 0;
+    }
     return sortAndGroup();
 }
 // Split by reads, second step: the real tuples of the owned sequences (compacted, still in slot order) ordered by the k-mer range
@@ -1933,7 +1951,8 @@ int sortAndGroup() {
         // head digit's segments (rx::sortSlotKeys); `live` comes out of the head histogram
         if (!segBuf.alloc(rx::BINS + 1)) { cdm_set_error("cdm_kmermatch: out of device memory"); return CDM_ERR_HIP; }
         uint64_t *res = nullptr; unsigned long long liveSlots = 0;
-        if (int rc = rx::sortSlotKeys(s, ctx->cuCount, k0.p, k1.p, (uint64_t) kmerSlots, 2 * k, lowBits, headCounted ? headHist.p : nullptr, segBuf.p, liveSlots, res, &ctx->lastMs[13], &ctx->lastMs[14])) return rc;
+        if (int rc = rx::sortSlotKeys(s, ctx->cuCount, k0.p, k1.p, (uint64_t) kmerSlots, 2 * k, lowBits, headCounted ? headHist.p : nullptr, segBuf.p, liveSlots, res, &ctx->lastMs[13], &ctx->lastMs[14],
+                                      headRange ? headLo : 0u, headRange ? std::min<uint32_t>(headHi, (uint32_t) rx::BINS) : (uint32_t) rx::BINS)) return rc;
         keys = DoubleBuf<uint64_t>(res, res == k0.p ? k1.p : k0.p); vals = res == k0.p ? DoubleBuf<V>(vA, vB) : DoubleBuf<V>(vB, vA);     // (region 2's values follow its keys' buffer)
         // what those launches move at the least, in GB: the head pass reads every slot's key and writes the real ones' tuples, the passes
         // inside the segments read and write every tuple (bench.py's roofline figure)
@@ -2028,7 +2047,7 @@ int sortAndGroup() {
                 // the run records of sort 2 come out of this kernel (on the default single-device pipeline; CDM_RUN_RECORDS=kernel|twopass: from
                 // the key array, as before round 5)
                 stagedWaves = 0;
-                if (LY::bySlot && ownPipeline && live && !cdmGetenv("CDM_RUN_RECORDS") && !cdmGetenv("CDM_RUN_CAP")) {
+                if (LY::bySlot && (ownPipeline || headRange) && live && !cdmGetenv("CDM_RUN_RECORDS") && !cdmGetenv("CDM_RUN_CAP")) {
                     const uint64_t waves = (live + (uint64_t) own - 1) / (uint64_t) own;
                     ovCap = live / 256 + 4096;
                     if (stRep.alloc(waves * REC_CAP) && stVal.alloc(waves * REC_CAP) && stCnt.alloc(waves + 1) && recFlag.alloc(2) && ovRep.alloc(ovCap) && ovVal.alloc(ovCap)) {
@@ -2449,7 +2468,8 @@ int gatherByRep() override {
     RunArgs ra; ra.keys = (const uint64_t *) startIo; ra.n = nTuples; ra.skipLo = live; ra.skipHi = kmerSlots; ra.repShift = (int) (idBits + diagBits + 1);
     unsigned long long nRec = 0, nOut = 0;
     DevBuf<uint32_t> rr0, rr1; DevBuf<uint64_t> rv0, rv1; DevBuf<unsigned long long> dst;
-    if (int rc = makeRunRecords(s, ra, rr0, rr1, rv0, rv1, nRec)) return rc;
+    if (stagedWaves) { if (int rc = stagedRunRecords(ra, rr0, rr1, rv0, rv1, nRec)) return rc; }       // (the slot layout's grouping kernel wrote them already)
+    else if (int rc = makeRunRecords(s, ra, rr0, rr1, rv0, rv1, nRec)) return rc;
     gathered = keys.current();
     if (nRec == 0) return CDM_OK;
     if (!dst.alloc(nRec + 1)) { cdm_set_error("cdm_kmermatch: out of device memory (%llu run records)", nRec); return CDM_ERR_HIP; }
@@ -2732,12 +2752,21 @@ __global__ void k_rep_bounds(const uint64_t *__restrict__ keys, uint64_t n, int 
     out[t] = lo;
 }
 }  // namespace
+// does cdm_kmermatch_part run this DB on the slot layout with balanced head-digit ranges? (csrc/dist.hip then takes it in place of the
+// extract-everything-and-order-by-slice first half)
+int cdm_kmermatch_part_takes_slots(const cdm_seqdb *db, const cdm_kmer_params *par) {
+    const char *lay = cdmGetenv("CDM_KMER_LAYOUT");
+    return ((!lay || !strcmp(lay, "slot")) && slotLayoutFits(db, par->kmer_size) && onePassFits(db, 16.0 + 8.0) && !cdm_kmermatch_needs_wide_key(db)) ? 1 : 0;
+}
 extern "C" int cdm_kmermatch_part(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_kmer_params *par, int part, int nparts, cdm_kpart **out) {
     if (!ctx || !db || !par || !out || nparts < 1 || part < 0 || part >= nparts) { cdm_set_error("cdm_kmermatch_part: invalid argument"); return CDM_ERR_INVALID; }
     if (cdmGetenv("CDM_KMER_SORT") || cdmGetenv("CDM_KMER_SORT2")) { cdm_set_error("cdm_kmermatch_part: the A/B switches CDM_KMER_SORT / CDM_KMER_SORT2 apply to the single-device path only"); return CDM_ERR_INVALID; }
     CDM_HIP(hipSetDevice(ctx->device));
     cdm_kpart *h = new cdm_kpart();
-    if (packedLayoutFits(db, par->kmer_size)) h->job = new KmerJob<LayoutPacked>(ctx, db, par);
+    // a DB of one read length takes the 8-byte slot layout here as on one device (round 5), the rank's range a run of head digits with
+    // its share of the tuples (CDM_KMER_LAYOUT=packed|wide: the 12-byte layouts and equal slices of the k-mer space by value, as before)
+    if (cdm_kmermatch_part_takes_slots(db, par)) { KmerJob<LayoutSlot> *j = new KmerJob<LayoutSlot>(ctx, db, par); j->headRange = true; h->job = j; }
+    else if (packedLayoutFits(db, par->kmer_size)) h->job = new KmerJob<LayoutPacked>(ctx, db, par);
     else if (db->maxLen < 65535u) h->job = new KmerJob<LayoutWide>(ctx, db, par);
     else if (db->maxLen < (1u << 20) - 1u && db->n < (1ull << 24)) h->job = new KmerJob<LayoutLong>(ctx, db, par);
     else if (db->maxLen < MAX_SEQ_LETTERS) h->job = new KmerJob<LayoutHuge>(ctx, db, par);

@@ -93,6 +93,7 @@ struct PassArgs {
     unsigned long long *status;                 // [tiles][BINS], zeroed
     unsigned int *ticket;                       // zeroed
     const unsigned long long *seg = nullptr; const unsigned int *segTile = nullptr;     // PASS_SEG: [BINS + 1] each
+    uint32_t keepLo = 0, keepHi = 0xFFFFFFFFu;  // PASS_HEAD: keys whose digit lies outside [keepLo, keepHi) are dropped like empty slots (a rank's range of the k-mer space)
 };
 template <typename K, typename V, int MODE = PASS_PLAIN>
 __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(NT) void k_rx_pass(PassArgs<K, V> a) {
     for (int j = 0; j < IPT; j++) {
         const int li = w0 + 64 * j;
         if (li < items) { key[j] = a.kin[base + li]; if constexpr (HasValue<V>::value) val[j] = a.vin[base + li]; } else key[j] = (MODE == PASS_HEAD) ? (K) ~(K) 0 : (K) 0;
+        if constexpr (MODE == PASS_HEAD) { const uint32_t d = digitOf(key[j], a.shift, mask); if (d < a.keepLo || d >= a.keepHi) key[j] = (K) ~(K) 0; }
     }
     // ---- rank inside the wave's stream, round by round
     uint16_t *cntW = sCnt[wave];
@@ -457,7 +459,8 @@ __global__ __launch_bounds__(BINS) void k_rx_seg_tables(const unsigned long long
 // Out: segDev (device, [BINS + 1], caller-allocated) = where each head digit's tuples start in the result; live = real tuples;
 // result = the buffer (k0 or k1) that holds the sorted slot tuples.  passMs / launches: HIP-event time of the pass launches, summed.
 inline int sortSlotKeys(hipStream_t s, int cuCount, uint64_t *k0, uint64_t *k1, uint64_t n, int topBit, int lowBits, const unsigned long long *headHist,
-                        unsigned long long *segDev, unsigned long long &live, uint64_t *&result, float *passMs = nullptr, float *launches = nullptr) {
+                        unsigned long long *segDev, unsigned long long &live, uint64_t *&result, float *passMs = nullptr, float *launches = nullptr,
+                        uint32_t keepLo = 0, uint32_t keepHi = BINS) {
     live = 0; result = k1;
     const int headBits = std::min(BITS, topBit), shift = topBit - headBits, rem = shift - lowBits;
     if (shift > SLOT_REM || rem < 0) { cdm_set_error("slot key sort: %d key bits, %d finished on chip", topBit, lowBits); return CDM_ERR_INVALID; }
@@ -482,6 +485,9 @@ inline int sortSlotKeys(hipStream_t s, int cuCount, uint64_t *k0, uint64_t *k1, 
         hipMemsetAsync(hist.p, 0, BINS * 8, s);
         if (n) hipLaunchKernelGGL(k_rx_hist_head<0>, dim3((unsigned) std::min<uint64_t>(tilesHead, (uint64_t) cuCount * 8)), dim3(NT), 0, s, (const uint64_t *) k0, n, shift, headBits, hist.p);
     }
+    // (a rank's range of head digits: the others' counts are not this call's)
+    if (keepLo > 0) hipMemsetAsync(hist.p, 0, (size_t) std::min<uint32_t>(keepLo, BINS) * 8, s);
+    if (keepHi < (uint32_t) BINS) hipMemsetAsync(hist.p + keepHi, 0, (size_t) (BINS - keepHi) * 8, s);
     hipLaunchKernelGGL(k_rx_seg_layout<0>, dim3(1), dim3(BINS), 0, s, (const unsigned long long *) hist.p, segDev, segTile.p);
     unsigned int tilesSeg = 0;
     hipMemcpyAsync(&live, segDev + BINS, 8, hipMemcpyDeviceToHost, s); hipMemcpyAsync(&tilesSeg, segTile.p + BINS, 4, hipMemcpyDeviceToHost, s);
@@ -496,6 +502,7 @@ inline int sortSlotKeys(hipStream_t s, int cuCount, uint64_t *k0, uint64_t *k1, 
         hipMemsetAsync(status.p, 0, tilesHead * BINS * 8, s);
         PassArgs<uint64_t, NoValue> pa;
         pa.kin = k0; pa.kout = k1; pa.vin = nullptr; pa.vout = nullptr; pa.n = n; pa.shift = shift; pa.bits = headBits; pa.digitBase = segDev; pa.status = status.p; pa.ticket = ticket.p;
+        pa.keepLo = keepLo; pa.keepHi = keepHi;
         if (passMs) hipEventRecord(ev[0], s);
         hipLaunchKernelGGL((k_rx_pass<uint64_t, NoValue, PASS_HEAD>), dim3((unsigned) tilesHead), dim3(NT), 0, s, pa);
         if (passMs) hipEventRecord(ev[1], s);

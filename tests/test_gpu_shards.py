@@ -448,6 +448,37 @@ def test_native_contig_iteration_equals_single_device(dhigh_prefix, world, trans
                 assert np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2])
 
 
+@pytest.mark.parametrize("world,extract", [(1, None), (3, None), (5, None), (2, "part"), (4, "part"), (7, None)])
+def test_reads_of_one_length_over_ranks_take_the_slot_layout(dhigh_prefix, world, extract, monkeypatch):
+    """A DB of one read length - the metric's corpus - runs a rank's first half on the 8-byte slot layout as a single device does: every
+    rank extracts all reads, the head histogram cuts the 512 head digits into ranges of equal tuple counts (the same on every rank) and
+    the head pass keeps the rank's range (worlds below six, and cdm_kmermatch_part in any world; seven ranks split the reads and take the
+    12-byte layout as before).  300 k reads of 100 letters: hits, corrected DB and next DB equal the single-device calls'."""
+    n = 300_000
+    ref = capi.Ctx(0)
+    ref.damage_load(dhigh_prefix)
+    db = ref.synth(n, 100, 100, 7)
+    hits = ref.kmermatch(db); alns = ref.rescore(db, hits); corr = ref.correct(db, alns); asm = ref.extend(corr, alns)
+    want_hits, want_corr, want_asm = hits.download(), corr.download(), asm.download()
+    del hits, alns, corr, asm
+    if extract:
+        monkeypatch.setenv("CDM_DIST_EXTRACT", extract)
+        capi.lib().cdm_env_refresh()
+
+    def rank_fn(rank, comm, c):
+        c.damage_load(dhigh_prefix)
+        h, a, co, nx = comm.reads_iteration(c.synth(n, 100, 100, 7))
+        return h.download(), co.download(), nx.download(), comm.owned(n), comm.last_path()
+
+    res = run_native_ranks(world, rank_fn) if world > 1 else [rank_fn(0, capi.Comm.rccl(ref, 0, 1, capi.Comm.unique_id()), ref)]
+    off, rec = merged_hits([r[0] for r in res], n, res[0][3])
+    assert np.array_equal(off, want_hits[0]) and np.array_equal(rec, want_hits[1])
+    for r in res:
+        for got, want in ((r[1], want_corr), (r[2], want_asm)):
+            assert [bytes(x) for x in got[0]] == [bytes(x) for x in want[0]]
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+
+
 def test_a_failure_on_one_rank_ends_the_call_on_all(dhigh_prefix, monkeypatch):
     """A failure local to one rank - here: rank 1's DB differs in size, which its all-gather of the owned rows refuses - is agreed on before
     the next collective (csrc/dist.hip agree / finish): every rank's call returns an error, none waits in the transport for a peer that
