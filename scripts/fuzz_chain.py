@@ -3,7 +3,7 @@
 modes: small, deep (100x+ pile-ups, > 64 records per query), repeats (low-complexity / tandem repeats), contigparams (k = 22,
 include-only-extendable), longreads (up to 600 bp: general extraction kernel), nrich (N letters), verylong (wide tuple layout), tiling (chains of
 extensions), tiny (reads around and below k), palrepeats (tandem repeats of reverse-palindromic
-units: comparator ties in the per-sequence k-mer sort), letters (lower-case stretches, IUPAC codes, bytes that are no letters;
+units: comparator ties in the per-sequence k-mer sort), uniform (one read length per case: the slot layout of sort 1), letters (lower-case stretches, IUPAC codes, bytes that are no letters;
 FUZZ_LETTERS=1 in the environment puts them on top of any other mode)."""
 import os
 import subprocess
@@ -38,9 +38,9 @@ ties = 0
 unsupported = 0
 undefined = 0
 for case in range(cases):
-    G = {"small": 300, "deep": 150, "repeats": 200, "contigparams": 400, "longreads": 1500, "palrepeats": 700, "nrich": 300, "verylong": 6000, "tiling": 600, "tiny": 60, "letters": 300}[mode]
+    G = {"small": 300, "deep": 150, "repeats": 200, "contigparams": 400, "longreads": 1500, "palrepeats": 700, "nrich": 300, "verylong": 6000, "tiling": 600, "tiny": 60, "letters": 300, "uniform": 300}[mode]
     genome = rng.integers(0, 4, G)
-    if mode == "repeats":
+    if mode == "repeats" or (mode == "uniform" and case % 3 == 0):
         unit = rng.integers(0, 4, int(rng.integers(1, 9)))
         a = int(rng.integers(0, G - 80)); genome[a:a + 80] = np.resize(unit, 80)
     if mode == "palrepeats":
@@ -48,11 +48,12 @@ for case in range(cases):
         for _ in range(2):
             u = np.array(["ACGT".index(ch) for ch in units[int(rng.integers(0, len(units)))]])
             ln = int(rng.integers(60, 300)); a = int(rng.integers(0, G - ln)); genome[a:a + ln] = np.resize(u, ln)
-    nreads = {"small": (6, 61), "deep": (150, 400), "repeats": (10, 80), "contigparams": (10, 80), "longreads": (10, 60), "palrepeats": (8, 50), "nrich": (10, 80), "verylong": (6, 30), "tiling": (30, 120), "tiny": (2, 40), "letters": (8, 70)}[mode]
-    lr = {"small": (30, 121), "deep": (40, 101), "repeats": (30, 121), "contigparams": (40, 200), "longreads": (100, 600), "palrepeats": (30, 320), "nrich": (30, 150), "verylong": (600, 3000), "tiling": (40, 90), "tiny": (5, 45), "letters": (30, 140)}[mode]
+    nreads = {"small": (6, 61), "uniform": (6, 90), "deep": (150, 400), "repeats": (10, 80), "contigparams": (10, 80), "longreads": (10, 60), "palrepeats": (8, 50), "nrich": (10, 80), "verylong": (6, 30), "tiling": (30, 120), "tiny": (2, 40), "letters": (8, 70)}[mode]
+    lr = {"small": (30, 121), "uniform": (22, 121), "deep": (40, 101), "repeats": (30, 121), "contigparams": (40, 200), "longreads": (100, 600), "palrepeats": (30, 320), "nrich": (30, 150), "verylong": (600, 3000), "tiling": (40, 90), "tiny": (5, 45), "letters": (30, 140)}[mode]
     seqs = []
+    fixedL = int(rng.integers(*lr)) if mode == "uniform" else 0        # uniform: one read length per case (the 8-byte slot layout of sort 1)
     for _ in range(int(rng.integers(*nreads))):
-        L = int(rng.integers(*lr)); L = min(L, G - 1); st = int(rng.integers(0, G - L))
+        L = fixedL or int(rng.integers(*lr)); L = min(L, G - 1); st = int(rng.integers(0, G - L))
         c = genome[st:st + L].copy()
         if rng.random() < 0.5:
             c = (3 - c)[::-1]
