@@ -112,16 +112,24 @@ int agree(cdm_comm *cm, int mine, const char *where) {
     }
     return CDM_OK;
 }
+// (the RCCL transport's own exchange buffers are taken BEFORE the status goes round: an allocation that fails inside the transport, behind
+// the agreement, would strand the peers in ncclGroupEnd all the same)
+int prepareStages(cdm_comm *cm, uint64_t sendBytes, uint64_t recvBytes) {
+    if (!cm->nccl || cm->world == 1 || rcclDirect()) return CDM_OK;
+    if (int rc = ensureStage(cm, cm->sendStage, sendBytes)) return rc;
+    return ensureStage(cm, cm->recvStage, recvBytes);
+}
 int coAllGatherHost(cdm_comm *cm, const void *send, void *recv, uint64_t bytes) {
-    if (int rc = agree(cm, CDM_OK, "a collective of the multi-GPU calls")) return rc;
+    const int mine = (cm->nccl && cm->world > 1) ? ensureStage(cm, cm->stage, (size_t) bytes * (size_t) (cm->world + 1)) : CDM_OK;
+    if (int rc = agree(cm, mine, "a collective of the multi-GPU calls")) return rc;
     return cm->ops.all_gather_host(cm->ops.user, send, recv, bytes);
 }
 int coAllToAllDev(cdm_comm *cm, const void *send, const uint64_t *so, void *recv, const uint64_t *ro, void *stream) {
-    if (int rc = agree(cm, CDM_OK, "a collective of the multi-GPU calls")) return rc;
+    if (int rc = agree(cm, prepareStages(cm, so[cm->world] - so[0], ro[cm->world] - ro[0]), "a collective of the multi-GPU calls")) return rc;
     return cm->ops.all_to_all_dev(cm->ops.user, send, so, recv, ro, stream);
 }
 int coAllGatherDev(cdm_comm *cm, const void *send, uint64_t bytes, void *recv, const uint64_t *ro, void *stream) {
-    if (int rc = agree(cm, CDM_OK, "a collective of the multi-GPU calls")) return rc;
+    if (int rc = agree(cm, prepareStages(cm, bytes, ro[cm->world] - ro[0]), "a collective of the multi-GPU calls")) return rc;
     return cm->ops.all_gather_dev(cm->ops.user, send, bytes, recv, ro, stream);
 }
 // the end of a calling sequence: a rank that failed on its own tells the others; the others learn it here at the latest
