@@ -311,10 +311,13 @@ int cdm_extend(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cd
 /* ---------------------------------------------------------------------------------------------------------
  * ancient_contig_merge (contig phase of the workflow, data/nuclassemble.sh:148-196).  Replaces the loop at
  * src/assembler/ancientContigsResults.cpp:94-509.  db must be the corrected contig DB.  The per-alignment column work
- * (orientation, identities, the counts of updateSeqIdConsensus / ancientMatchCount) runs on the device; the queue order - a
- * Beta-posterior comparator built on the C library's lgammaf / logf (:25-70), not a strict weak ordering - and the extension
- * loop run in the library's host code, which uses the same libstdc++ priority queue as the reference.
- * merge_seq_id_thr is --min-merge-seq-id; par->ry_seq_id_thr, max_seq_len, unsafe (0 only) are used from par.
+ * (orientation, identities, the counts of updateSeqIdConsensus / ancientMatchCount) runs on the device, and since round 5 so do the
+ * queue - a Beta-posterior comparator built on the C library's lgammaf / logf (:25-70), not a strict weak ordering: the device reads
+ * those two functions from tables of the library's own values and replays libstdc++'s heap step for step (csrc/contigqueue.hip) -
+ * and the extension loop (:276-470).  The library's host code (the same libstdc++ priority queue as the reference) runs for
+ * par->unsafe = 1, for small calls in a process that has not filled the tables yet, and for the rare query the device hands back
+ * (CDM_CONTIG_QUEUE=host|device pins either).  Same result either way.
+ * merge_seq_id_thr is --min-merge-seq-id; par->ry_seq_id_thr, max_seq_len, unsafe, min_cov_safe are used from par.
  */
 int cdm_contig_merge(cdm_ctx *ctx, const cdm_seqdb *db, const cdm_alns *alns, const cdm_ancient_params *par, float merge_seq_id_thr,
                      cdm_seqdb **out);
