@@ -57,7 +57,7 @@ class AncientParams(C.Structure):
 EXPORTS = [
     "cdm_last_error", "cdm_ctx_create", "cdm_ctx_destroy", "cdm_ctx_sync", "cdm_ctx_stream", "cdm_ctx_last_kernel_ms",
     "cdm_seqdb_upload", "cdm_seqdb_synth", "cdm_seqdb_size", "cdm_seqdb_residues", "cdm_seqdb_max_len", "cdm_seqdb_meta",
-    "cdm_seqdb_download", "cdm_seqdb_free", "cdm_seqdb_select_ext", "cdm_seqdb_words", "cdm_seqdb_copy_packed", "cdm_seqdb_from_packed", "cdm_damage_load", "cdm_damage_get", "cdm_kmermatch", "cdm_hits_upload", "cdm_hits_count",
+    "cdm_seqdb_download", "cdm_seqdb_download_stream", "cdm_seqdb_free", "cdm_seqdb_select_ext", "cdm_seqdb_words", "cdm_seqdb_copy_packed", "cdm_seqdb_from_packed", "cdm_damage_load", "cdm_damage_get", "cdm_kmermatch", "cdm_hits_upload", "cdm_hits_count",
     "cdm_hits_download", "cdm_hits_free", "cdm_rescore", "cdm_alns_upload", "cdm_alns_count", "cdm_alns_download", "cdm_alns_free",
     "cdm_evalue", "cdm_bit_score", "cdm_gapped_evalue", "cdm_correct", "cdm_extend",
     "cdm_kmermatch_part", "cdm_kmermatch_split_begin", "cdm_kpart_outgoing", "cdm_kmermatch_split_finish", "cdm_kpart_info", "cdm_kpart_stale", "cdm_kpart_gather", "cdm_kpart_sort", "cdm_kpart_vote", "cdm_kpart_cont_cap", "cdm_kpart_free", "cdm_dev_copy",

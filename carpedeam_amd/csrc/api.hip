@@ -385,6 +385,51 @@ extern "C" int cdm_seqdb_download(cdm_ctx *ctx, const cdm_seqdb *db, char *out, 
     for (uint64_t i = 0; i < db->n; i++) if (len[i] == 0) out[outOffsets[i]] = '\n';
     return CDM_OK;
 }
+// The same blob in PIECES, for a caller that writes it out as it comes (round 5: a module process's sequence DB - the copy from the
+// device lands in pinned staging buffers of the library at the link's speed, and the caller's sink - a pwrite into the DB's data file -
+// runs on piece i while piece i + 1 is on its way; before, the whole text came down into pageable memory at 8 GB/s and was then written
+// out at the file system's 4 GB/s, one after the other).  sink(user, data, offset, bytes): consecutive pieces, data valid during the
+// call; a non-zero return ends the download with CDM_ERR_INVALID.
+extern "C" int cdm_seqdb_download_stream(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *outOffsets, uint64_t pieceBytes,
+                                         int (*sink)(void *user, const char *data, uint64_t offset, uint64_t bytes), void *user) {
+    if (!ctx || !db || !sink || (db->n && !outOffsets)) { cdm_set_error("cdm_seqdb_download_stream: invalid argument"); return CDM_ERR_INVALID; }
+    CDM_HIP(hipSetDevice(ctx->device));
+    if (db->n == 0) return CDM_OK;
+    if (pieceBytes < (1u << 20)) pieceBytes = 64u << 20;
+    std::vector<uint32_t> len(db->n);
+    CDM_HIP(hipMemcpy(len.data(), db->len, db->n * 4, hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < db->n; i++) total = std::max(total, outOffsets[i] + len[i] + 1);
+    // (the entries must ascend for the zero-length fix-up below to find them piece by piece; every caller's do)
+    for (uint64_t i = 1; i < db->n; i++) if (outOffsets[i] < outOffsets[i - 1]) { cdm_set_error("cdm_seqdb_download_stream: the offsets must ascend"); return CDM_ERR_INVALID; }
+    DevBuf<char> dOut; DevBuf<uint64_t> dOff;
+    if (!dOut.alloc(total + 16) || !dOff.alloc(db->n)) { cdm_set_error("out of device memory in cdm_seqdb_download_stream"); return CDM_ERR_HIP; }
+    hipStream_t s = ctx->stream;
+    hipMemsetAsync(dOut.p, 0, total, s);
+    hipMemcpyAsync(dOff.p, outOffsets, db->n * 8, hipMemcpyHostToDevice, s);
+    if (db->words) hipLaunchKernelGGL(k_unpack, CDM_GRID((db->words + 255) / 256, 256), dim3(256), 0, s, db->codes, db->nmask, db->woff, db->len, dOff.p, db->n, db->words, dOut.p, db->hasN, db->raw);
+    char *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr};
+    auto cleanup = [&] { for (int b = 0; b < 2; b++) { if (pin[b]) (void) hipHostFree(pin[b]); if (ev[b]) (void) hipEventDestroy(ev[b]); } };
+    pieceBytes = std::min(pieceBytes, total);
+    for (int b = 0; b < 2; b++) if (hipHostMalloc((void **) &pin[b], pieceBytes, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) != hipSuccess) {
+        (void) hipGetLastError(); cleanup(); cdm_set_error("cdm_seqdb_download_stream: no pinned staging buffer of %llu bytes", (unsigned long long) pieceBytes); return CDM_ERR_HIP;
+    }
+    const uint64_t pieces = (total + pieceBytes - 1) / pieceBytes;
+    auto issue = [&](uint64_t i) { const uint64_t at = i * pieceBytes, nb = std::min(pieceBytes, total - at); hipMemcpyAsync(pin[i & 1], dOut.p + at, nb, hipMemcpyDeviceToHost, s); hipEventRecord(ev[i & 1], s); };
+    issue(0);
+    uint64_t z = 0;             // next sequence to look at for the zero-length fix-up ('\n' of an empty sequence: it owns no code word)
+    int rc = CDM_OK;
+    for (uint64_t i = 0; i < pieces && rc == CDM_OK; i++) {
+        if (i + 1 < pieces) issue(i + 1);
+        if (hipEventSynchronize(ev[i & 1]) != hipSuccess) { cdm_set_error("cdm_seqdb_download_stream failed: %s", hipGetErrorString(hipGetLastError())); rc = CDM_ERR_HIP; break; }
+        const uint64_t at = i * pieceBytes, nb = std::min(pieceBytes, total - at);
+        while (z < db->n && outOffsets[z] < at + nb) { if (len[z] == 0 && outOffsets[z] >= at) pin[i & 1][outOffsets[z] - at] = '\n'; z++; }
+        if (sink(user, pin[i & 1], at, nb) != 0) { cdm_set_error("cdm_seqdb_download_stream: the sink refused a piece at offset %llu", (unsigned long long) at); rc = CDM_ERR_INVALID; }
+    }
+    (void) hipStreamSynchronize(s);
+    cleanup();
+    return rc;
+}
 extern "C" int cdm_seqdb_synth(cdm_ctx *ctx, uint64_t nTotal, uint64_t first, uint64_t n, uint32_t lo, uint32_t hi, uint64_t seed, cdm_seqdb **out) {
     return cdm_synth_impl(ctx, nTotal, first, n, lo, hi, seed, out);
 }

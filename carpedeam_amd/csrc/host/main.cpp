@@ -372,7 +372,33 @@ struct SeqDbOut {
         side.commit();
     }
 };
-void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) { SeqDbOut o; o.down(ctx, h); o.write(path, dbtype); }
+// The same in one go where the DB's data file takes its pieces straight off the device (a RAM-backed file system, where one writer per
+// file is the fast way): the text streams through the library's pinned staging buffers into the file (cdm_seqdb_download_stream) while the
+// index and the side-car go out in threads of their own - the text never stands in pageable memory.  false: not here (nothing was
+// written; down() + write() as before).  The device DB is still needed until this returns.
+static int seqDbPieceSink(void *user, const char *data, uint64_t offset, uint64_t bytes) { return mmdbWritePiece(*(int *) user, data, offset, bytes) ? 0 : 1; }
+bool streamSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) {
+    const uint64_t n = cdm_seqdb_size(h);
+    if (n == 0) return false;
+    HVec<uint32_t> keys(n), elen(n); HVec<uint8_t> ext(n); HVec<uint64_t> offs(n); std::vector<uint32_t> lens(n);
+    check(cdm_seqdb_meta(ctx, h, lens.data(), keys.data(), ext.data()), "meta");
+    uint64_t tot = 0;
+    for (uint64_t i = 0; i < n; i++) { offs[i] = tot; elen[i] = lens[i] + 2; tot += lens[i] + 2; }
+    int fd = mmdbOpenStreamedData(path, tot);
+    if (fd < 0) return false;
+    SeqSideHost side; side.take(ctx, h); side.begin(path, dbtype);
+    bool okIx = true; std::string errIx;
+    std::thread ix([&] { okIx = mmdbWriteBlob(path, dbtype, nullptr, 0, keys.data(), offs.data(), elen.data(), ext.data(), n, &errIx, MMDB_DATA_ELSEWHERE); });
+    const int rc = cdm_seqdb_download_stream(ctx, h, offs.data(), 64u << 20, seqDbPieceSink, &fd);
+    const bool okClose = close(fd) == 0;
+    ix.join();
+    if (rc != CDM_OK) die(std::string("download: ") + cdm_last_error());
+    if (!okClose) die("Could not write " + path);
+    if (!okIx) die(errIx);
+    side.commit();
+    return true;
+}
+void writeSeqDb(cdm_ctx *ctx, cdm_seqdb *h, const std::string &path, int dbtype) { if (streamSeqDb(ctx, h, path, dbtype)) return; SeqDbOut o; o.down(ctx, h); o.write(path, dbtype); }
 // ---- text codecs
 // decimal text, two digits per division
 char *utoa(unsigned long long v, char *p) {
@@ -856,12 +882,17 @@ int ancientModule(Args &a, int mode) {      // 0 ancient_correction, 1 ancient_r
     else if (mode == 2) check(cdm_contig_merge(ctx, db, alns, &p, fflag(a, "--min-merge-seq-id", 0.99f), &out), "ancient_contig_merge");
     else check(cdm_correct(ctx, db, alns, &p, &out), "ancient_correction");
     laps.lap("records up, kernels");
-    SeqDbOut o; o.down(ctx, out);
     SeqSideHost inSide; if (!in.fromSide) inSide.take(ctx, db);
-    laps.lap("sequences down");
-    DeviceEnd end; end.begin(ctx, NULL, alns, db, out); laps.lap("device memory back to the driver");
     inSide.begin(a.pos[0], seq.dbtype);
-    o.write(a.pos[2], seq.dbtype); laps.lap("DB written, its side-car beside it");
+    if (streamSeqDb(ctx, out, a.pos[2], seq.dbtype)) {      // (tmpfs: the text goes from the device into the data file piece by piece)
+        laps.lap("sequences down into the DB's data file, index and side-car beside it");
+        DeviceEnd end; end.begin(ctx, NULL, alns, db, out); laps.lap("device memory back to the driver");
+    } else {
+        SeqDbOut o; o.down(ctx, out);
+        laps.lap("sequences down");
+        DeviceEnd end; end.begin(ctx, NULL, alns, db, out); laps.lap("device memory back to the driver");
+        o.write(a.pos[2], seq.dbtype); laps.lap("DB written, its side-car beside it");
+    }
     inSide.commit();
     finishModule(EXIT_SUCCESS);
     return EXIT_SUCCESS;

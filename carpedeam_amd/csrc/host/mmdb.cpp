@@ -273,10 +273,25 @@ bool mmdbWriteChunks(const std::string &path, int dbtype, const std::vector<OutC
     if (!ok) *err = "Could not write " + path;
     return ok;
 }
+// The data file of a DB that the caller fills piece by piece as the pieces come off the device (cdm_seqdb_download_stream): opened and
+// sized here (the tail the pieces do not cover - the last entry's NUL - is the file's zero fill), -1 where that does not pay: the
+// pieces are written by ONE thread, which is the fast way on tmpfs and the slow one elsewhere (CDM_STREAM_DB=0|1 pins either).
+int mmdbOpenStreamedData(const std::string &path, size_t bytes) {
+    static const char *sw = getenv("CDM_STREAM_DB");
+    if ((sw && !strcmp(sw, "0")) || bytes == 0) return -1;
+    const int d = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (d < 0) return -1;
+    if ((!oneWriterIsFaster(d) && !(sw && !strcmp(sw, "1"))) || ftruncate(d, (off_t) bytes) != 0) { close(d); return -1; }
+    for (int i = 0; i < 4096; i++) { const std::string part = path + "." + std::to_string(i); if (unlink(part.c_str()) != 0) break; }
+    return d;
+}
+bool mmdbWritePiece(int fd, const char *data, uint64_t offset, uint64_t bytes) { return pwriteAll(fd, data, bytes, offset); }
+// blob == NULL: the data file is in place already (dataFd: mmdbOpenStreamedData's, closed here) - index and dbtype only
 bool mmdbWriteBlob(const std::string &path, int dbtype, const char *blob, size_t blobBytes, const uint32_t *key, const uint64_t *off,
-                   const uint32_t *len, const uint8_t *ext, size_t n, std::string *err) {
-    const int d = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644), ix = open((path + ".index").c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
-    if (d < 0 || ix < 0) { if (d >= 0) close(d); if (ix >= 0) close(ix); *err = "Could not open " + path + " for writing"; return false; }
+                   const uint32_t *len, const uint8_t *ext, size_t n, std::string *err, int dataFd) {
+    const bool dataElsewhere = !blob && dataFd == MMDB_DATA_ELSEWHERE;      // (the caller writes and closes the data file itself, meanwhile)
+    const int d = blob ? open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644) : dataFd, ix = open((path + ".index").c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if ((d < 0 && !dataElsewhere) || ix < 0) { if (d >= 0) close(d); if (ix >= 0) close(ix); *err = "Could not open " + path + " for writing"; return false; }
     const int T = std::max(1, omp_get_max_threads());
     std::vector<std::string> ixText(T);
     std::vector<uint64_t> ixBase(T + 1, 0);
@@ -290,10 +305,10 @@ bool mmdbWriteBlob(const std::string &path, int dbtype, const char *blob, size_t
     // (two files, two inode locks: the index goes out beside the data)
     bool okIx = true;
     std::thread ixWriter([&] { okIx = writePieces(ix, ixBase[T], ixPieces); });
-    bool ok = writePieces(d, blobBytes, std::vector<Piece>(1, Piece{blob, blobBytes, 0}));
+    bool ok = blob ? writePieces(d, blobBytes, std::vector<Piece>(1, Piece{blob, blobBytes, 0})) : true;
     ixWriter.join();
     ok = ok && okIx;
-    ok = (close(d) == 0) & (close(ix) == 0) & ok;
+    ok = (dataElsewhere || close(d) == 0) & (close(ix) == 0) & ok;
     ok = ok && writeDbtype(path, dbtype);
     if (!ok) *err = "Could not write " + path;
     return ok;

@@ -80,7 +80,11 @@ struct alignas(128) OutChunk {     // (a cache line of its own: the threads upda
 bool mmdbWriteChunks(const std::string &path, int dbtype, const std::vector<OutChunk> &chunks, std::string *err, bool splitData = false);
 // one blob that already has the data file's layout: entry i at off[i], len[i] bytes incl. the NUL
 bool mmdbWriteBlob(const std::string &path, int dbtype, const char *blob, size_t blobBytes, const uint32_t *key, const uint64_t *off,
-                   const uint32_t *len, const uint8_t *ext, size_t n, std::string *err);
+                   const uint32_t *len, const uint8_t *ext, size_t n, std::string *err, int dataFd = -1);
+constexpr int MMDB_DATA_ELSEWHERE = -2;      // mmdbWriteBlob(blob = NULL, dataFd = this): index and dbtype only, the caller writes and closes the data file itself
+// a DB's data file filled piece by piece as the pieces come off the device (-1: write it the usual way); mmdbWriteBlob(blob = NULL, dataFd) finishes it
+int mmdbOpenStreamedData(const std::string &path, size_t bytes);
+bool mmdbWritePiece(int fd, const char *data, uint64_t offset, uint64_t bytes);
 
 // host/ingest.cpp: FASTA/FASTQ[.gz] reads as an in-memory sequence DB (what createdb would write, without the files)
 struct FastxDb { HVec<char> blob; HVec<uint32_t> key, len; HVec<uint64_t> off; };     // entry j: blob[off[j] .. off[j] + len[j]) = "SEQ\n\0"

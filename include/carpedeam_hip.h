@@ -89,6 +89,11 @@ uint32_t cdm_seqdb_max_len(const cdm_seqdb *db);
 int cdm_seqdb_meta(cdm_ctx *ctx, const cdm_seqdb *db, uint32_t *lengths, uint32_t *keys, uint8_t *ext);
 /* ASCII download: out must hold sum(len[i] + 1) bytes; entry i is written at out_offsets[i] followed by '\n' */
 int cdm_seqdb_download(cdm_ctx *ctx, const cdm_seqdb *db, char *out, const uint64_t *out_offsets);
+/* the same blob in consecutive pieces of (about) piece_bytes through pinned staging buffers of the library: sink(user, data, offset,
+ * bytes) gets piece i while piece i + 1 is on its way (data is valid during the call; non-zero return: the download ends with an error).
+ * out_offsets must ascend.  What a module process writes its sequence DB with (csrc/host/main.cpp). */
+int cdm_seqdb_download_stream(cdm_ctx *ctx, const cdm_seqdb *db, const uint64_t *out_offsets, uint64_t piece_bytes,
+                              int (*sink)(void *user, const char *data, uint64_t offset, uint64_t bytes), void *user);
 void cdm_seqdb_free(cdm_seqdb *db);
 /* Multi-GPU hand-off (one process per GPU, RCCL all-gather of per-shard contigs): the sequences with wasExtended == 1
  * (the contigs an ancient_read_assemble pass produced) as a new DB; its packed form copied into caller-provided DEVICE
