@@ -140,3 +140,52 @@ def test_createdb_leaves_the_sequence_side_car(tmp_path):
     assert not os.path.exists(t("ldb.cdmbin"))
     log = run("kmermatcher", t("ldb"), t("lpref"), *K_FLAGS, "--threads", "4")
     assert "ldb: from the text" in log and os.path.exists(t("ldb.cdmbin"))
+
+
+@pytest.mark.parametrize("name", ["mixed3k", "letters"])
+def test_streamed_sequence_dbs_are_the_same_files(tmp_path, dhigh_prefix, name):
+    """A sequence DB's text goes from the device into its data file piece by piece where that pays (tmpfs; CDM_STREAM_DB=1 forces it anywhere,
+    =0 never: csrc/host/main.cpp streamSeqDb, cdm_seqdb_download_stream) - the same files, byte for byte, as the whole text downloaded and
+    then written, side-cars included in what the next module reads"""
+    from carpedeam_amd import build
+    build.build()
+    on, logs_on = chain(str(tmp_path), "stream", dhigh_prefix, {"CDM_STREAM_DB": "1"}, name)
+    off, logs_off = chain(str(tmp_path), "whole", dhigh_prefix, {"CDM_STREAM_DB": "0"}, name)
+    for db in ("corr", "asm"):
+        a, b = db_files(on(db)), db_files(off(db))
+        assert a.keys() == b.keys() and all(a[k] == b[k] for k in a), db
+        assert os.path.exists(on(db) + ".cdmbin")
+    assert "sequences down into the DB's data file" in logs_on[2] and "sequences down into the DB's data file" in logs_on[3]
+    assert "sequences down into the DB's data file" not in logs_off[2]
+    assert "_corr: from its side-car" in logs_on[3]
+
+
+def test_download_stream_pieces_equal_the_whole_download():
+    """cdm_seqdb_download_stream through the C ABI: pieces of 1 MB of a DB with empty sequences in it, against cdm_seqdb_download"""
+    import ctypes as C
+    import numpy as np
+    from carpedeam_amd import capi
+    ctx = capi.Ctx(0)
+    rng = np.random.default_rng(3)
+    seqs = [b"" if i % 97 == 0 else bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), int(rng.integers(1, 400)), p=[.24, .24, .24, .24, .04])) for i in range(20000)]
+    db = ctx.upload_seqs(seqs)
+    lens, _, _ = db.meta()
+    offs = np.zeros(db.n, np.uint64)
+    offs[1:] = np.cumsum(lens[:-1].astype(np.uint64) + 2)
+    total = int(offs[-1]) + int(lens[-1]) + 1
+    whole = np.zeros(total + 1, np.uint8)
+    db.download_into(whole, offs)
+    got = np.zeros(total + 1, np.uint8)
+    pieces = []
+    SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64)
+
+    def sink(user, data, offset, nbytes):
+        got[offset:offset + nbytes] = np.frombuffer(C.string_at(data, nbytes), np.uint8)
+        pieces.append((int(offset), int(nbytes)))
+        return 0
+
+    fn = capi.lib().cdm_seqdb_download_stream
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, SINK, C.c_void_p]
+    assert fn(ctx.h, db.h, offs.ctypes.data, 1 << 20, SINK(sink), None) == 0
+    assert len(pieces) > 3 and pieces[0][0] == 0 and all(pieces[i][0] + pieces[i][1] == pieces[i + 1][0] for i in range(len(pieces) - 1))
+    assert np.array_equal(got[:total], whole[:total])
