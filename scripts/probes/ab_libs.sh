@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds on the GPU box:  scripts/ab_libs.sh <tag> <variant> [<variant> ...]   ("default" = the regular build)
+# A/B of library builds on the GPU box:  scripts/probes/ab_libs.sh <tag> <variant> [<variant> ...]   ("default" = the regular build)
 # For every build: bench.py --steps 2 --warmup 1 --no-cpu-baseline (config 3) -> ms per step, the radix pass's average launch, the stage times.
 tag=$1; shift
 O=gpurun_out; mkdir -p $O

@@ -1,9 +1,9 @@
-"""Correction kernel time on a synthetic read set, under the environment's CDM_CORRECT_* switches: scripts/correct_probe.py [reads] [lo hi]"""
+"""Correction kernel time on a synthetic read set, under the environment's CDM_CORRECT_* switches: scripts/probes/correct_probe.py [reads] [lo hi]"""
 import os
 import sys
 import tempfile
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from carpedeam_amd import capi, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000

@@ -1,7 +1,7 @@
 """debug: slot layout against packed on a uniform DB; prints the first differing records"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from carpedeam_amd import capi
 from test_gpu_slotlayout import uniform_reads, text
 ctx = capi.Ctx(0)

@@ -1,9 +1,9 @@
-"""Extension kernel time on a synthetic read set, under the environment's CDM_EXTEND / CDM_XR_* switches: scripts/extend_probe.py [reads]"""
+"""Extension kernel time on a synthetic read set, under the environment's CDM_EXTEND / CDM_XR_* switches: scripts/probes/extend_probe.py [reads]"""
 import os
 import sys
 import tempfile
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 from carpedeam_amd import capi, synth
 

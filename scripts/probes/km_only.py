@@ -1,9 +1,9 @@
-"""kmermatcher alone on synthetic reads (profiling helper): python scripts/km_only.py <reads> [repeats]"""
+"""kmermatcher alone on synthetic reads (profiling helper): python scripts/probes/km_only.py <reads> [repeats]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from carpedeam_amd import capi
 
 n = int(sys.argv[1])

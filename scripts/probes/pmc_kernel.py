@@ -1,4 +1,4 @@
-"""Sum of the named PMC counters per kernel: scripts/pmc_kernel.py <counter_collection.csv> <name-substring> [...]"""
+"""Sum of the named PMC counters per kernel: scripts/probes/pmc_kernel.py <counter_collection.csv> <name-substring> [...]"""
 import collections
 import csv
 import sys

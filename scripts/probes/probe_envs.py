@@ -1,11 +1,11 @@
 """Debug helper: kmermatcher on the bucket-path test database under each environment variant, one subprocess per variant,
-so that a crash names its variant.  python scripts/probe_envs.py [child <json env>]"""
+so that a crash names its variant.  python scripts/probes/probe_envs.py [child <json env>]"""
 import json
 import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 ENVS = [{}, {"CDM_BUCKET_CAP": "64"}, {"CDM_BUCKET_CAP": "5"}, {"CDM_BUCKET_CAP": "3,17"}, {"CDM_BUCKET_CAP": "1"}, {"CDM_BUCKET_CAP": "512,40"},
         {"CDM_KMER_SORT": "lsd"}, {"CDM_KMER_LAYOUT": "wide"}, {"CDM_KMER_LAYOUT": "wide", "CDM_BUCKET_CAP": "6,100"},

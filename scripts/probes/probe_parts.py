@@ -1,10 +1,10 @@
 """First half of the exact multi-GPU kmermatcher (extraction of a k-mer range, sort 1, grouping) for one of W ranges:
-python scripts/probe_parts.py <reads> <W> ...   - wall time of cdm_kmermatch_part(part 0 of W) on one device"""
+python scripts/probes/probe_parts.py <reads> <W> ...   - wall time of cdm_kmermatch_part(part 0 of W) on one device"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from carpedeam_amd import capi  # noqa: E402
 
 n = int(sys.argv[1])

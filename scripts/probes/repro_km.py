@@ -1,11 +1,11 @@
 """Reproduce a kmermatcher difference on a list of reads (one per line): device vs oracle, prints differing records.
-    python scripts/repro_km.py <reads.txt> [ENV=VALUE ...]"""
+    python scripts/probes/repro_km.py <reads.txt> [ENV=VALUE ...]"""
 import os
 import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 for kv in sys.argv[2:]:
     k, v = kv.split("=", 1); os.environ[k] = v

@@ -1,4 +1,4 @@
-"""Idle time between consecutive kernels of a rocprofv3 kernel trace: python scripts/trace_gaps.py <kernel_trace.csv> [min_gap_us [first kernel]]"""
+"""Idle time between consecutive kernels of a rocprofv3 kernel trace: python scripts/probes/trace_gaps.py <kernel_trace.csv> [min_gap_us [first kernel]]"""
 import csv
 import sys
 
