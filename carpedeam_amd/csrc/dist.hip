@@ -353,7 +353,6 @@ struct PartGuard { cdm_kpart *p = nullptr; ~PartGuard() { if (p) cdm_kpart_free(
 // shard.py does).
 int firstHalf(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_kpart **out) {
     const int W = cm->world, R = cm->rank;
-    const cdm_comm_ops &op = cm->ops;
     // Three ways to a rank's range of the k-mer space.  "split": every rank extracts its block of the reads and the tuples travel - 49 GB
     // at 50 M reads, 0.98 s / W^2 over W - 1 links of ~50 GB/s each.  "all": every rank extracts ALL reads, orders them by slice, keeps
     // its range - 52 ms that do not shrink with W, nothing travels.  The tuples' exchange pays from about 6 ranks on (W = 4: 19 + 61 ms
@@ -512,7 +511,6 @@ int replicatedKmermatch(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const c
 }  // namespace
 static int kmermatchDistBody(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *db, const cdm_kmer_params *par, cdm_hits **out) {
     const int W = cm->world, R = cm->rank;
-    const cdm_comm_ops &op = cm->ops;
     {
         const char *km = cdmGetenv("CDM_DIST_KMER");
         const bool replicate = km ? !strcmp(km, "replicate") : (W == 2 && !cdmGetenv("CDM_DIST_EXTRACT"));
@@ -631,7 +629,6 @@ __global__ void k_row_flags(const uint8_t *__restrict__ hasN, uint64_t lo, uint6
 }  // namespace
 static int allgatherOwnedBody(cdm_ctx *ctx, cdm_comm *cm, const cdm_seqdb *local, cdm_seqdb **out) {
     const int W = cm->world, R = cm->rank;
-    const cdm_comm_ops &op = cm->ops;
     CDM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     std::vector<uint64_t> own((size_t) W + 1);
